@@ -1,0 +1,336 @@
+#!/usr/bin/env python
+"""Generate the committed fixtures under tests/golden/ by EXECUTING the
+reference (read in place from /root/reference via oracle/ref_shim.py).
+
+Run in the build container only (the reference does not travel):
+
+    python oracle/gen_golden.py
+
+Outputs (all numpy .npz, inputs + expected outputs only -- no reference text):
+  prob3_ref_goldens.npz   the reference's own golden pickles for the 13 named
+                          cases x 10 host functions (f8), re-encoded
+                          (pisa_examples/resources/osc/numba_osc_tests_data)
+  prob3_grid_prem12.npz   reference osc_probs_layers_kernel on a coarse (E,cz)
+                          PREM-12 grid, nu/nubar x {NO, IO, std-NSI, decay}
+  layers_ref.npz          reference Layers.calcLayers for PREM-4/12/59
+  params_ref.npz          OscParams / NSI / decay / LRI matrices
+  lookup_ref.npz          reference lookup_regular_* outputs
+  stats_ref.npz           reference stats.llh/poisson_llh/chi2/mod_chi2
+  barr_ref.npz            reference barr_simple.apply_sys_kernel
+  hist_ref.npz            np.histogramdd recipe of translation.test_histogram
+"""
+import glob
+import os
+import pickle
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_shim  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+warnings.filterwarnings("ignore")
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrays)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+def gen_ref_pickles():
+    d = os.path.join(ref_shim.REF_RESOURCES, "osc", "numba_osc_tests_data")
+    out = {}
+    for f in sorted(glob.glob(os.path.join(d, "*__f8.pkl"))):
+        base = os.path.basename(f)[: -len("__f8.pkl")]
+        with open(f, "rb") as fh:
+            t = pickle.load(fh)
+        for k, v in t.items():
+            out["%s::%s" % (base, k)] = np.asarray(v)
+    save("prob3_ref_goldens.npz", **out)
+
+
+OSC_SCENARIOS = {
+    # osc_example.cfg nominal (nufit v2.0 NH)
+    "no": dict(theta12=33.48, theta13=8.5, theta23=42.0, deltacp=0.0, dm21=7.5e-5, dm31=2.457e-3),
+    "io": dict(theta12=33.48, theta13=8.51, theta23=49.5, deltacp=254.0, dm21=7.5e-5, dm31=-2.374e-3),
+    "nsi": dict(theta12=33.48, theta13=8.5, theta23=42.3, deltacp=306.0, dm21=7.5e-5, dm31=2.457e-3),
+    "decay": dict(theta12=33.48, theta13=8.5, theta23=42.0, deltacp=90.0, dm21=7.5e-5, dm31=2.457e-3),
+}
+
+
+def scenario_matrices(name):
+    op = ref_shim.ref_module("pisa.stages.osc.osc_params")
+    nsi = ref_shim.ref_module("pisa.stages.osc.nsi_params")
+    dec = ref_shim.ref_module("pisa.stages.osc.decay_params")
+    s = OSC_SCENARIOS[name]
+    o = op.OscParams()
+    o.theta12 = np.deg2rad(s["theta12"])
+    o.theta13 = np.deg2rad(s["theta13"])
+    o.theta23 = np.deg2rad(s["theta23"])
+    o.deltacp = np.deg2rad(s["deltacp"])
+    o.dm21 = s["dm21"]
+    o.dm31 = s["dm31"]
+    mat_pot = np.diag([1.0, 0, 0]).astype(np.complex128)
+    decay_flag = -1
+    mat_decay = np.zeros((3, 3), np.complex128)
+    if name == "nsi":
+        n = nsi.StdNSIParams()
+        n.eps_emu = (0.07, np.deg2rad(340))
+        n.eps_etau = (0.06, np.deg2rad(35))
+        n.eps_mutau = (0.003, np.deg2rad(175))
+        n.eps_ee = 0.1
+        n.eps_tautau = -0.05
+        mat_pot = mat_pot + n.eps_matrix
+    if name == "decay":
+        dp = dec.DecayParams()
+        dp.decay_alpha3 = 1.0e-4
+        mat_decay = dp.decay_matrix
+        decay_flag = 1
+    return dict(
+        dm=o.dm_matrix, mix=o.mix_matrix_complex, mat_pot=mat_pot, decay_flag=decay_flag,
+        mat_decay=mat_decay, lri_pot=np.zeros((3, 3)),
+    )
+
+
+def gen_grid():
+    k = ref_shim.kernels()
+    L = ref_shim.layers_mod()
+    lay = L.Layers("osc/PREM_12layer.dat", 2.0, 20.0)
+    lay.setElecFrac(0.4656, 0.4656, 0.4957)
+    n_e, n_cz = 20, 24
+    e_edges = np.logspace(0, 3, n_e + 1)
+    energy = np.sqrt(e_edges[:-1] * e_edges[1:])
+    cz_edges = np.linspace(-1, 1, n_cz + 1)
+    cz = 0.5 * (cz_edges[:-1] + cz_edges[1:])
+    lay.calcLayers(cz)
+    dens = lay.density.reshape(n_cz, lay.max_layers)
+    dist = lay.distance.reshape(n_cz, lay.max_layers)
+    out = dict(energy=energy, coszen=cz, densities=dens, distances=dist)
+    for name in OSC_SCENARIOS:
+        m = scenario_matrices(name)
+        for key, val in m.items():
+            out["%s::%s" % (name, key)] = np.asarray(val)
+        for nubar in (1, -1):
+            P = np.zeros((n_e, n_cz, 3, 3))
+            for i in range(n_e):
+                for j in range(n_cz):
+                    k.osc_probs_layers_kernel(
+                        m["dm"], m["mix"], m["mat_pot"], m["decay_flag"], m["mat_decay"],
+                        m["lri_pot"], nubar, float(energy[i]), dens[j], dist[j], P[i, j],
+                    )
+            out["%s::prob_%s" % (name, "nu" if nubar > 0 else "nubar")] = P
+        print("grid scenario", name, "done")
+    save("prob3_grid_prem12.npz", **out)
+
+
+def gen_layers():
+    L = ref_shim.layers_mod()
+    rs = np.random.RandomState(42)
+    out = {}
+    for tag, fn, depth, height, ye in [
+        ("prem4", "osc/PREM_4layer.dat", 1.0, 20.0, (0.5, 0.5, 0.5)),
+        ("prem4b", "osc/PREM_4layer.dat", 10.0, 18.0, (0.5, 0.5, 0.5)),
+        ("prem12", "osc/PREM_12layer.dat", 2.0, 20.0, (0.4656, 0.4656, 0.4957)),
+        ("prem59", "osc/PREM_59layer.dat", 2.0, 20.0, (0.4656, 0.4656, 0.4957)),
+        ("prem10", "osc/PREM_10layer.dat", 2.0, 20.0, (0.466, 0.467, 0.494)),
+    ]:
+        lay = L.Layers(fn, depth, height)
+        lay.setElecFrac(*ye)
+        cz = np.concatenate(
+            [
+                np.array([1.0, 0.0, -0.4461133826191877, -1.0, 0.5, -0.2, -0.9, 1e-9, -1e-9]),
+                # just either side of every tangency (the reference itself raises a shape
+                # error AT an exact tangency value for some shells, layers.py:158)
+                lay.coszen_limit[lay.coszen_limit < 1.0] + 1e-9,
+                lay.coszen_limit[lay.coszen_limit < 1.0][:-1] - 1e-9,
+                rs.rand(64) * 2 - 1,
+                0.5 * (np.linspace(-1, 1, 201)[:-1] + np.linspace(-1, 1, 201)[1:]),
+            ]
+        )
+        lay.calcLayers(cz)
+        out[tag + "::prem"] = np.loadtxt(os.path.join(ref_shim.REF_RESOURCES, fn))
+        out[tag + "::args"] = np.array([depth, height, *ye])
+        out[tag + "::cz"] = cz
+        out[tag + "::radii"] = lay.radii
+        out[tag + "::rhos"] = lay.rhos
+        out[tag + "::coszen_limit"] = lay.coszen_limit
+        out[tag + "::n_layers"] = lay.n_layers
+        out[tag + "::density"] = lay.density.reshape(len(cz), lay.max_layers)
+        out[tag + "::distance"] = lay.distance.reshape(len(cz), lay.max_layers)
+    save("layers_ref.npz", **out)
+
+
+def gen_params():
+    op = ref_shim.ref_module("pisa.stages.osc.osc_params")
+    nsi = ref_shim.ref_module("pisa.stages.osc.nsi_params")
+    dec = ref_shim.ref_module("pisa.stages.osc.decay_params")
+    lri = ref_shim.ref_module("pisa.stages.osc.lri_params")
+    rs = np.random.RandomState(7)
+    out = {}
+    angles = []
+    for i in range(8):
+        a = dict(
+            theta12=rs.rand() * np.pi / 2, theta13=rs.rand() * np.pi / 2,
+            theta23=rs.rand() * np.pi / 2, deltacp=rs.rand() * 2 * np.pi,
+            dm21=rs.rand() * 1e-4, dm31=(rs.rand() - 0.5) * 1e-2,
+        )
+        if i == 0:
+            a.update(dm21=0.0, dm31=0.0, deltacp=0.0)
+        o = op.OscParams()
+        for kk, vv in a.items():
+            setattr(o, kk, vv)
+        angles.append([a[k] for k in ("theta12", "theta13", "theta23", "deltacp", "dm21", "dm31")])
+        out["osc%d::mix" % i] = o.mix_matrix_complex
+        out["osc%d::mix_reparam" % i] = o.mix_matrix_reparam_complex
+        out["osc%d::dm" % i] = o.dm_matrix
+    out["osc::inputs"] = np.array(angles)
+    # standard NSI
+    vals = []
+    for i in range(4):
+        v = rs.rand(9)
+        n = nsi.StdNSIParams()
+        n.eps_ee = v[0] - 0.5
+        n.eps_emu = (v[1], v[2] * 2 * np.pi)
+        n.eps_etau = (v[3], v[4] * 2 * np.pi)
+        n.eps_mumu = v[5] - 0.5
+        n.eps_mutau = (v[6], v[7] * 2 * np.pi)
+        n.eps_tautau = v[8] - 0.5
+        vals.append([v[0] - 0.5, v[1], v[2] * 2 * np.pi, v[3], v[4] * 2 * np.pi, v[5] - 0.5, v[6],
+                     v[7] * 2 * np.pi, v[8] - 0.5])
+        out["stdnsi%d::eps" % i] = n.eps_matrix
+    out["stdnsi::inputs"] = np.array(vals)
+    vals = []
+    for i in range(4):
+        v = rs.rand(8)
+        n = nsi.VacuumLikeNSIParams()
+        n.eps_scale = v[0] * 2
+        n.eps_prime = v[1] - 0.5
+        n.phi12 = (v[2] - 0.5) * np.pi
+        n.phi13 = (v[3] - 0.5) * np.pi
+        n.phi23 = (v[4] - 0.5) * np.pi
+        n.alpha1 = v[5] * 2 * np.pi
+        n.alpha2 = v[6] * 2 * np.pi
+        n.deltansi = v[7] * 2 * np.pi
+        vals.append([n.eps_scale, n.eps_prime, n.phi12, n.phi13, n.phi23, n.alpha1, n.alpha2, n.deltansi])
+        out["vacnsi%d::eps" % i] = n.eps_matrix
+    out["vacnsi::inputs"] = np.array(vals)
+    d = dec.DecayParams()
+    d.decay_alpha3 = 3.3e-4
+    out["decay::matrix"] = d.decay_matrix
+    out["decay::alpha3"] = np.array(3.3e-4)
+    l = lri.LRIParams()
+    l.v_lri = 2.5e-14
+    out["lri::v"] = np.array(2.5e-14)
+    out["lri::emu"] = l.potential_matrix_emu
+    out["lri::etau"] = l.potential_matrix_etau
+    out["lri::mutau"] = l.potential_matrix_mutau
+    save("params_ref.npz", **out)
+
+
+def gen_lookup():
+    tr = ref_shim.ref_module("pisa.core.translation")
+    rs = np.random.RandomState(3)
+    n = 2000
+    out = {}
+    x = rs.rand(n) * 1.4 - 0.2
+    y = rs.rand(n) * 2.6 - 1.3
+    z = rs.rand(n) * 3 - 0.5
+    # exact edge values / NaN / inf
+    x[:6] = [0.0, 1.0, np.nextafter(1.0, 0), np.nan, np.inf, -np.inf]
+    y[6:10] = [-1.0, 1.0, np.nextafter(1.0, 0), np.nextafter(-1.0, -2)]
+    out["x"], out["y"], out["z"] = x, y, z
+    h1 = rs.rand(7)
+    o = np.zeros(n)
+    tr.lookup_regular_1d(x, h1, 0.0, 1.0, 7, o)
+    out["h1"], out["o1"] = h1, o.copy()
+    h2 = rs.rand(7 * 5)
+    o = np.zeros(n)
+    tr.lookup_regular_2d(x, y, h2, 0.0, 1.0, 7, -1.0, 1.0, 5, o)
+    out["h2"], out["o2"] = h2, o.copy()
+    h3 = rs.rand(7 * 5 * 3)
+    o = np.zeros(n)
+    tr.lookup_regular_3d(x, y, z, h3, 0.0, 1.0, 7, -1.0, 1.0, 5, 0.0, 2.0, 3, o)
+    out["h3"], out["o3"] = h3, o.copy()
+    h2a = rs.rand(7 * 5, 2)
+    o = np.zeros((n, 2))
+    tr.lookup_regular_2d_array(x, y, h2a, 0.0, 1.0, 7, -1.0, 1.0, 5, o)
+    out["h2a"], out["o2a"] = h2a, o.copy()
+    save("lookup_ref.npz", **out)
+
+
+def gen_stats():
+    st = ref_shim.ref_module("pisa.utils.stats")
+    rs = np.random.RandomState(5)
+    expected = rs.rand(128) * 50
+    expected[:4] = [0.0, 1e-12, 1e-10, 5.0]
+    actual = rs.poisson(np.maximum(expected, 0.5)).astype(np.float64)
+    actual[4:8] = 0.0
+    out = dict(actual=actual, expected=expected)
+    for name in ("llh", "poisson_llh", "chi2", "mod_chi2"):
+        v = getattr(st, name)(actual.copy(), expected.copy())
+        v = np.ma.filled(np.ma.masked_invalid(np.ma.asarray(v, dtype=float)), np.nan)
+        out[name] = np.asarray(v, dtype=np.float64)
+        out[name + "_total"] = np.array(np.nansum(out[name]))
+    save("stats_ref.npz", **out)
+
+
+def gen_barr():
+    bs = ref_shim.ref_module("pisa.stages.flux.barr_simple")
+    rs = np.random.RandomState(11)
+    n = 300
+    e = 10 ** (rs.rand(n) * 3)
+    cz = rs.rand(n) * 2 - 1
+    nu = rs.rand(n, 2) * 10
+    nub = rs.rand(n, 2) * 10
+    nu[:3] = 0.0
+    nub[:3] = 0.0
+    nu[3] = [0.0, 1.0]
+    nub[3] = [0.0, 1.0]
+    out = dict(true_energy=e, true_coszen=cz, nu_flux_nominal=nu, nubar_flux_nominal=nub)
+    psets = [
+        (1.0, 1.0, 0.0, 0.0, 0.0),
+        (1.03, 0.9, 0.05, 0.7, -0.4),
+        (0.8, 1.2, -0.1, -1.5, 2.0),
+    ]
+    out["params"] = np.array(psets)
+    for ip, ps in enumerate(psets):
+        for nubar in (1, -1):
+            o = np.zeros((n, 2))
+            for i in range(n):
+                bs.apply_sys_kernel(e[i], cz[i], nu[i], nub[i], nubar, *ps, o[i])
+            out["out%d_%s" % (ip, "nu" if nubar > 0 else "nubar")] = o
+    save("barr_ref.npz", **out)
+
+
+def gen_hist():
+    """translation.test_histogram recipe (translation.py:779-818): the
+    reference pins fast_histogram against np.histogramdd on these samples."""
+    all_num_bins = [2, 3, 4]
+    n_evts = 10000
+    rand = np.random.RandomState(seed=0)
+    weights = rand.rand(n_evts)
+    out = dict(weights=weights)
+    sample = []
+    for nd, nb in enumerate(all_num_bins, start=1):
+        s = rand.rand(n_evts) * nb
+        sample.append(s)
+        out["s%d" % (nd - 1)] = s
+        edges = [np.linspace(0, b, b + 1) for b in all_num_bins[:nd]]
+        ref, _ = np.histogramdd(sample=sample, bins=edges, weights=weights)
+        cnt, _ = np.histogramdd(sample=sample, bins=edges, weights=None)
+        out["ref%dd" % nd] = ref.ravel()
+        out["cnt%dd" % nd] = cnt.ravel()
+    save("hist_ref.npz", **out)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ["pickles", "layers", "params", "lookup", "stats", "barr", "hist", "grid"]
+    fns = dict(pickles=gen_ref_pickles, layers=gen_layers, params=gen_params, lookup=gen_lookup,
+               stats=gen_stats, barr=gen_barr, hist=gen_hist, grid=gen_grid)
+    for w in which:
+        fns[w]()

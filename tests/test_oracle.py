@@ -1,0 +1,260 @@
+"""Pins the CPU oracle (oracle/pisa_oracle.c) to the reference:
+
+* the reference's OWN golden pickles for prob3 (13 named cases x 10 host
+  functions, pisa_examples/resources/osc/numba_osc_tests_data, re-encoded in
+  tests/golden/prob3_ref_goldens.npz) with the reference's own tolerance
+  (numba_osc_tests.py:82  AC_KW: rtol 1e-10, atol 1e-14);
+* vectors produced by executing the reference's Python in the build
+  container (oracle/gen_golden.py): PREM-12 coarse grid, Layers, lookup,
+  stats, Barr flux, parameter matrices;
+* the reference's known-answer constants for Layers (layers.py:552, 640-662);
+* translation.test_histogram's equivalence with np.histogramdd.
+"""
+import numpy as np
+import pytest
+
+from tests.conftest import PROB3_ATOL, PROB3_RTOL, load_golden
+
+AC = dict(rtol=PROB3_RTOL, atol=PROB3_ATOL)
+
+
+def _cases(g, func):
+    names = sorted({k.split("::")[0] for k in g.files if k.startswith(func + "__")})
+    return names
+
+
+def _args(g, case):
+    return {k.split("::")[1]: g[k] for k in g.files if k.startswith(case + "::")}
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return load_golden("prob3_ref_goldens.npz")
+
+
+def test_pins_propagate_scalar(oracle, ref):
+    cases = _cases(ref, "propagate_scalar")
+    assert len(cases) == 13
+    for c in cases:
+        a = _args(ref, c)
+        out = oracle.propagate_array(
+            a["dm"], a["mix"], a["mat_pot"], int(a["decay_flag"]), a["mat_decay"], a["lri_pot"],
+            int(a["nubar"]), [float(a["energy"])], a["densities"], a["distances"],
+        )[0]
+        np.testing.assert_allclose(out, a["probability"], err_msg=c, **AC)
+        # unitarity unless decay is on (numba_osc_tests.py:457-470)
+        if int(a["decay_flag"]) != 1:
+            np.testing.assert_allclose(out.sum(axis=0), 1.0, rtol=1e-9)
+            np.testing.assert_allclose(out.sum(axis=1), 1.0, rtol=1e-9)
+
+
+def test_pins_subfunctions(oracle, ref):
+    n = 0
+    for c in _cases(ref, "get_H_vac_hostfunc"):
+        a = _args(ref, c)
+        np.testing.assert_allclose(
+            oracle.get_H_vac(a["mix_nubar"], a["mix_nubar_conj_transp"], a["dm_vac_vac"]),
+            a["H_vac"], err_msg=c, **AC)
+        n += 1
+    for c in _cases(ref, "get_H_decay_hostfunc"):
+        a = _args(ref, c)
+        np.testing.assert_allclose(
+            oracle.get_H_decay(a["mix_nubar"], a["mix_nubar_conj_transp"], a["mat_decay"]),
+            a["H_decay"], err_msg=c, **AC)
+        n += 1
+    for c in _cases(ref, "get_H_mat_hostfunc"):
+        a = _args(ref, c)
+        np.testing.assert_allclose(
+            oracle.get_H_mat(float(a["rho"]), a["mat_pot"], int(a["nubar"])), a["H_mat"],
+            err_msg=c, **AC)
+        n += 1
+    for c in _cases(ref, "get_dms_hostfunc"):
+        a = _args(ref, c)
+        dmm, dmat = oracle.get_dms(float(a["energy"]), a["H_full"], a["dm_vac_vac"])
+        np.testing.assert_allclose(dmm, a["dm_mat_mat"], err_msg=c, **AC)
+        np.testing.assert_allclose(dmat, a["dm_mat"], err_msg=c, **AC)
+        n += 1
+    for c in _cases(ref, "product_hostfunc"):
+        a = _args(ref, c)
+        np.testing.assert_allclose(
+            oracle.get_product(float(a["energy"]), a["dm_mat"], a["dm_mat_mat"],
+                               a["H_full_mass_eigenstate_basis"]),
+            a["product"], err_msg=c, **AC)
+        n += 1
+    for c in _cases(ref, "get_transition_matrix_massbasis_hostfunc"):
+        a = _args(ref, c)
+        np.testing.assert_allclose(
+            oracle.get_transition_matrix_massbasis(
+                float(a["baseline"]), float(a["energy"]), a["dm_mat"], a["dm_mat_mat"],
+                a["H_full_mass_eigenstate_basis"]),
+            a["transition_matrix"], err_msg=c, **AC)
+        n += 1
+    for c in _cases(ref, "get_transition_matrix_hostfunc"):
+        a = _args(ref, c)
+        np.testing.assert_allclose(
+            oracle.get_transition_matrix(
+                int(a["nubar"]), float(a["energy"]), float(a["rho"]), float(a["baseline"]),
+                a["mix_nubar"], a["mix_nubar_conj_transp"], a["mat_pot"], a["H_vac"],
+                int(a["decay_flag"]), a["H_decay"], a["lri_pot"], a["dm"]),
+            a["transition_matrix"], err_msg=c, **AC)
+        n += 1
+    assert n == 13 * 7
+
+
+def test_pins_dms_numerical(oracle, ref):
+    """Decay branch: LAPACK eigenvalue ORDER is not part of the contract
+    (get_product / massbasis are symmetric in k), so compare as sets."""
+    cases = _cases(ref, "get_dms_numerical_hostfunc")
+    assert len(cases) == 1
+    a = _args(ref, cases[0])
+    dmm, dmat = oracle.get_dms_numerical(float(a["energy"]), a["H_full"])
+    got = np.sort_complex(dmat[:, 0])
+    want = np.sort_complex(a["dm_mat"][:, 0])
+    np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-14)
+
+
+def test_grid_prem12_vs_reference(oracle):
+    g = load_golden("prob3_grid_prem12.npz")
+    e, dens, dist = g["energy"], g["densities"], g["distances"]
+    n_e, n_cz = len(e), dens.shape[0]
+    for name in ("no", "io", "nsi", "decay"):
+        for nubar, tag in ((1, "nu"), (-1, "nubar")):
+            ee = np.repeat(e, n_cz)
+            rho = np.tile(dens, (n_e, 1))
+            dd = np.tile(dist, (n_e, 1))
+            P = oracle.propagate_array(
+                g[name + "::dm"], g[name + "::mix"], g[name + "::mat_pot"],
+                int(g[name + "::decay_flag"]), g[name + "::mat_decay"], g[name + "::lri_pot"],
+                nubar, ee, rho, dd).reshape(n_e, n_cz, 3, 3)
+            np.testing.assert_allclose(P, g["%s::prob_%s" % (name, tag)],
+                                       err_msg="%s %s" % (name, tag), **AC)
+
+
+def test_propagate_broadcast(oracle, ref):
+    """numba_osc_tests.py:266-312: broadcasting energies gives identical rows."""
+    a = _args(ref, "propagate_scalar__nufit32_no")
+    P = oracle.propagate_array(
+        a["dm"], a["mix"], a["mat_pot"], -1, a["mat_decay"], a["lri_pot"], 1,
+        np.full(20, float(a["energy"])), a["densities"], a["distances"])
+    assert np.all(np.isfinite(P))
+    assert np.all(P == P[0])
+
+
+def test_layers_vs_reference(oracle):
+    g = load_golden("layers_ref.npz")
+    for tag in ("prem4", "prem4b", "prem12", "prem59", "prem10"):
+        depth, height, yi, yo, ym = g[tag + "::args"]
+        lay = oracle.Layers(g[tag + "::prem"], depth, height)
+        lay.setElecFrac(yi, yo, ym)
+        np.testing.assert_array_equal(lay.radii, g[tag + "::radii"])
+        np.testing.assert_allclose(lay.rhos, g[tag + "::rhos"], rtol=1e-15)
+        np.testing.assert_allclose(lay.coszen_limit, g[tag + "::coszen_limit"], rtol=1e-15)
+        lay.calcLayers(g[tag + "::cz"])
+        np.testing.assert_array_equal(lay.n_layers, g[tag + "::n_layers"])
+        np.testing.assert_allclose(lay.density, g[tag + "::density"], rtol=1e-15, atol=0)
+        np.testing.assert_allclose(lay.distance, g[tag + "::distance"], rtol=1e-13, atol=1e-12)
+
+
+def test_layers_known_answers(oracle):
+    """Constants hard-coded in the reference's own tests (layers.py:552, 640-662)."""
+    g = load_golden("layers_ref.npz")
+    lay = oracle.Layers(g["prem4::prem"], detector_depth=1.0, prop_height=20.0)
+    ref_cz_crit = np.array([1.0, 1.0, -0.4461133826191877, -0.8375825182106081,
+                            -0.9814881717430358, -1.0])
+    np.testing.assert_allclose(lay.coszen_limit, ref_cz_crit, rtol=1e-12)
+    lay.setElecFrac(0.5, 0.5, 0.5)
+    lay.calcLayers(np.array([1.0, 0.0, -0.4461133826191877, -1.0]))
+    d = lay.distance
+    np.testing.assert_allclose(d[0], [20.0, 1.0] + [0] * 10, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(
+        d[1], [404.79277484435556, 112.87603820120549] + [0] * 10, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(
+        d[2], [44.525143211129944, 5685.725369597015] + [0] * 10, rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(
+        d[3], [20.0, 670.0, 2221.0, 2260.0, 2440.0, 2260.0, 2221.0, 669.0, 0, 0, 0, 0],
+        rtol=1e-12, atol=1e-9)
+    # sum of segments == vacuum path length (layers.py:664)
+    r_prop = lay.r_detector + lay.detector_depth + lay.prop_height
+    cz = np.array([1.0, 0.0, -0.4461133826191877, -1.0])
+    vac = -lay.r_detector * cz + np.sqrt(lay.r_detector ** 2 * cz ** 2 - (lay.r_detector ** 2 - r_prop ** 2))
+    np.testing.assert_allclose(d.sum(axis=1), vac, rtol=1e-12)
+
+
+def test_param_matrices_vs_reference(oracle):
+    g = load_golden("params_ref.npz")
+    inp = g["osc::inputs"]
+    for i in range(len(inp)):
+        t12, t13, t23, dcp, dm21, dm31 = inp[i]
+        np.testing.assert_allclose(oracle.mix_matrix(t12, t13, t23, dcp), g["osc%d::mix" % i],
+                                   rtol=1e-14, atol=1e-16)
+        np.testing.assert_allclose(oracle.mix_matrix(t12, t13, t23, dcp, reparam=True),
+                                   g["osc%d::mix_reparam" % i], rtol=1e-14, atol=1e-16)
+        np.testing.assert_array_equal(oracle.dm_matrix(dm21, dm31), g["osc%d::dm" % i])
+
+
+def test_lookup_vs_reference(oracle):
+    g = load_golden("lookup_ref.npz")
+    x, y, z = g["x"], g["y"], g["z"]
+    np.testing.assert_array_equal(oracle.lookup_regular([x], g["h1"], [0.0], [1.0], [7]), g["o1"])
+    np.testing.assert_array_equal(
+        oracle.lookup_regular([x, y], g["h2"], [0.0, -1.0], [1.0, 1.0], [7, 5]), g["o2"])
+    np.testing.assert_array_equal(
+        oracle.lookup_regular([x, y, z], g["h3"], [0.0, -1.0, 0.0], [1.0, 1.0, 2.0], [7, 5, 3]),
+        g["o3"])
+    np.testing.assert_array_equal(
+        oracle.lookup_regular([x, y], g["h2a"], [0.0, -1.0], [1.0, 1.0], [7, 5]), g["o2a"])
+
+
+def test_histogram_matches_histogramdd(oracle):
+    """translation.py:779-818 recipe: fast_histogram rule == np.histogramdd on
+    these samples (summed and averaged)."""
+    g = load_golden("hist_ref.npz")
+    nbs = [2, 3, 4]
+    sample = []
+    for nd in (1, 2, 3):
+        sample.append(g["s%d" % (nd - 1)])
+        mins = [0.0] * nd
+        maxs = [float(b) for b in nbs[:nd]]
+        h = oracle.histogram_regular(sample, g["weights"], mins, maxs, nbs[:nd])
+        np.testing.assert_allclose(h, g["ref%dd" % nd], rtol=1e-12)
+        c = oracle.histogram_regular(sample, None, mins, maxs, nbs[:nd])
+        np.testing.assert_array_equal(c, g["cnt%dd" % nd])
+
+
+def test_histogram_edges(oracle):
+    """[min, max) per dimension; upper edge and NaN excluded, lower included."""
+    x = np.array([0.0, 1.0, np.nextafter(1.0, 0), -1e-300, np.nan, 0.5, np.inf])
+    h = oracle.histogram_regular([x], None, [0.0], [1.0], [4])
+    np.testing.assert_array_equal(h, [1, 0, 1, 1])
+    h = oracle.histogram_regular([np.array([])], np.array([]), [0.0], [1.0], [4])
+    np.testing.assert_array_equal(h, [0, 0, 0, 0])
+
+
+def test_stats_vs_reference(oracle):
+    g = load_golden("stats_ref.npz")
+    for name in ("llh", "poisson_llh", "chi2", "mod_chi2"):
+        per_bin, total = oracle.metric(name, g["actual"], g["expected"])
+        np.testing.assert_allclose(per_bin, g[name], rtol=1e-13, atol=0, equal_nan=True)
+        np.testing.assert_allclose(total, float(g[name + "_total"]), rtol=1e-13)
+    with pytest.raises(ValueError):
+        oracle.metric("llh", np.array([-1.0]), np.array([1.0]))
+
+
+def test_barr_vs_reference(oracle):
+    g = load_golden("barr_ref.npz")
+    for ip, ps in enumerate(g["params"]):
+        for nubar, tag in ((1, "nu"), (-1, "nubar")):
+            out = oracle.barr_simple(g["true_energy"], g["true_coszen"], g["nu_flux_nominal"],
+                                     g["nubar_flux_nominal"], nubar, *ps)
+            np.testing.assert_allclose(out, g["out%d_%s" % (ip, tag)], rtol=1e-13, atol=1e-300)
+
+
+def test_reweight_order_of_operations(oracle):
+    rs = np.random.RandomState(0)
+    n = 1000
+    w0, flux = rs.rand(n), rs.rand(n, 2)
+    pe, pmu, aeff = rs.rand(n), rs.rand(n), rs.rand(n)
+    w = w0.copy()
+    w *= (flux[:, 0] * pe) + (flux[:, 1] * pmu)  # prob3.py:622
+    w *= aeff * 3.7  # aeff.py:87
+    np.testing.assert_array_equal(oracle.reweight(w0, flux, pe, pmu, aeff, 3.7), w)
