@@ -1,0 +1,244 @@
+#!/usr/bin/env python
+"""Headline benchmark: pipeline evals/sec (osc + reweight + hist + LLH) on 1e7
+synthetic MC events (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one template evaluation with fresh oscillation parameters (every
+stage recomputes, no memo hit; protocol of
+pisa/scripts/benchmark_pipeline_performance.py:196-223):
+    prob3 on the 200x100 (E, coszen) calc grid for nu and nubar
+    fused grid->event lookup + flux*osc*aeff reweight + 8x8x2 histogram (+sumw2)
+      over all 12 containers
+    [integer all-reduce of the histogram limbs if N > 1]
+    fixed point -> fp64 maps, Poisson LLH against pseudo-data
+and the host reads the LLH back (a fit loop needs it to choose the next point).
+N > 1 shards the 1e7 events across ranks (strong scaling of a fixed sample).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--events", type=float, default=1e7)
+    ap.add_argument("--grid", default="200x100", help="calc grid n_E x n_coszen")
+    ap.add_argument("--binning", default="dragon", choices=["dragon", "example2d"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-events", type=float, default=2.4e6)
+    return ap.parse_args()
+
+
+def param_list(wl, n):
+    """fixed seeded scan of (theta23, dm31) over the ranges of SURVEY 8d (C4)"""
+    import numpy as np
+
+    rs = np.random.RandomState(2024)
+    out = []
+    for _ in range(n):
+        out.append(wl.osc_params(theta23_deg=31.0 + 28.0 * rs.rand(), dm31=1e-3 + 6e-3 * rs.rand()))
+    return out
+
+
+def cpu_baseline(wl, sample_events):
+    """The oracle (C restatement of the reference algorithms) timed on this
+    box's host cores on a bounded sample: the full calc grid + a subsample of
+    the events, scaled to the full event count."""
+    import numpy as np
+
+    from oracle import oracle as orc
+    from oracle.pipeline_oracle import oracle_eval
+
+    orc.build()
+    cores = os.cpu_count() or 1
+    orc.set_num_threads(cores)
+    n_per = max(1, int(sample_events) // len(wl.events))
+    sub = []
+    for ev in wl.events:
+        d = dict(ev)
+        for k in ("true_energy", "true_coszen", "nu_flux", "weighted_aeff", "initial_weights"):
+            d[k] = ev[k][:n_per]
+        d["sample"] = [s[:n_per] for s in ev["sample"]]
+        sub.append(d)
+    wl.osc_params()
+    oracle_eval(wl, containers=[])  # warm-up (loads the library, touches the grid)
+    t0 = time.perf_counter()
+    ref = oracle_eval(wl, containers=sub)
+    t_all = time.perf_counter() - t0
+    # split: grid part is independent of the number of events
+    t0 = time.perf_counter()
+    oracle_eval(wl, containers=[])
+    t_grid = time.perf_counter() - t0
+    t_events = max(t_all - t_grid, 1e-9)
+    n_sub = n_per * len(sub)
+    t_full = t_grid + t_events * (wl.n_events / n_sub)
+    orc.metric("llh", ref["hist"].sum(axis=0) + 1, ref["hist"].sum(axis=0) + 1)
+    return {
+        "value": 1.0 / t_full,
+        "unit": "evals/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "full %dx%dx2-node prob3 grid (%.3f s) + %d of %d events through "
+                  "lookup/reweight/hist (%.3f s), event part scaled to all events; "
+                  "OpenMP over %d threads (histogram loop sequential)"
+                  % (wl.grid.n_e, wl.grid.n_cz, t_grid, n_sub, wl.n_events, t_events, cores),
+    }
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from pisa_amd import _lib, synthetic
+
+    n_e, n_cz = (int(v) for v in args.grid.split("x"))
+    wl = synthetic.Workload(n_events=int(args.events), grid=(n_e, n_cz), out_binning=args.binning,
+                            seed=0)
+    st = synthetic.DeviceState(wl, rank=rank, world_size=world)
+    nominal = wl.osc_params()
+    st.make_pseudo_data(nominal, seed=0)
+    plist = param_list(wl, args.warmup + args.steps)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    llh = 0.0
+    for p in plist[: args.warmup]:
+        llh = st.eval(p, "llh").item()
+    st.check_status()
+
+    # ---- timed region: exactly K evaluations, LLH read back every time
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    fused_ms = []
+    barrier()
+    t0 = time.perf_counter()
+    for p in plist[args.warmup:]:
+        llh = st.eval(p, "llh").item()
+    barrier()
+    dt = time.perf_counter() - t0
+    st.check_status()
+
+    # ---- dominant kernel, measured live with HIP events on the launch stream
+    lib = _lib.lib()
+    k_meas = max(10, min(args.steps, 50))
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+             for _ in range(k_meas)]
+    torch.cuda.synchronize()
+    for (a, b), p in zip(pairs, plist[args.warmup:] + plist):
+        a.record(); b.record()  # materialise the hipEvent handles
+        lib.pisa_hip_profile_events(a.cuda_event, b.cuda_event)
+        st.eval(p, "llh")
+    lib.pisa_hip_profile_events(None, None)
+    torch.cuda.synchronize()
+    fused_ms = [a.elapsed_time(b) for a, b in pairs]
+    fused_avg_s = float(np.mean(fused_ms)) * 1e-3
+    d_out = len(wl.ob["nbins"])
+    bytes_per_event = 8 * (2 + 2 + 1 + 1 + d_out)  # 72 B (D=3), 64 B (D=2)
+    achieved = bytes_per_event * st.n_local / fused_avg_s / 1e9
+
+    # per-phase device times (extra information, not part of the contract)
+    def time_phase(fn, n=10):
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(n):
+            fn()
+        ev1.record()
+        torch.cuda.synchronize()
+        return ev0.elapsed_time(ev1) / n
+
+    t_prob3 = time_phase(lambda: st.compute_probs(nominal))
+    t_tail = time_phase(lambda: (st.finalize(), st.metric("llh")))
+
+    # max over ranks
+    if world > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        evals_per_s = args.steps / dt
+        out = {
+            "metric": "pipeline evals/sec (osc+reweight+hist+LLH) on 1e7 MC events",
+            "value": evals_per_s,
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic (toy_event_generator-style E/coszen, builder-defined reco/flux/aeff; see pisa_amd/synthetic.py)",
+            "config": {
+                "workload": "%d events in 12 containers, prob3 on %dx%d (E,coszen) PREM-12 calc grid "
+                            "(nu+nubar), fused lookup+reweight+%s hist with sumw2, Poisson LLH; "
+                            "theta23/dm31 changed every eval, LLH read back every eval"
+                            % (wl.n_events, n_e, n_cz, "x".join(str(b) for b in wl.ob["nbins"])),
+                "events": wl.n_events,
+                "calc_grid": [n_e, n_cz],
+                "out_bins": wl.ob["nbins"],
+                "parallelism": "events sharded over %d GPU(s), int64 limb all-reduce" % world,
+            },
+            "event_evals_per_s": evals_per_s * wl.n_events,
+            "last_llh": llh,
+            "phase_ms": {"prob3_grid": t_prob3, "fused_reweight_hist": 1e3 * fused_avg_s,
+                         "finalize_metric": t_tail},
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "hist_accumulate_kernel<FUSED=true, LDS_ACC=true>",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "bytes_per_event": bytes_per_event,
+                "events_per_launch": st.n_local,
+                "avg_launch_ms": 1e3 * fused_avg_s,
+                "traffic": None,
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_sample_events)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,248 @@
+/*
+ * pisa_hip.h -- C ABI of libpisa_hip.so, the MI355X (gfx950) implementation of
+ * PISA's per-event hot path:  prob3 oscillation -> flux x osc x aeff reweight
+ * -> weighted N-D histogram -> LLH / chi2.
+ *
+ * Conventions
+ *   - every entry point returns an int status: 0 = OK, negative = error
+ *     (pisa_hip_strerror() gives the text).  No exceptions cross the ABI.
+ *   - `d_` pointers are DEVICE pointers (hipMalloc'ed or torch-allocated
+ *     tensor.data_ptr()); `h_` pointers are host pointers.  Small parameter
+ *     blocks are passed by host pointer and travel in the kernel-argument
+ *     segment.
+ *   - `stream` is a hipStream_t cast to void* (NULL = default stream).  All
+ *     calls are asynchronous w.r.t. the host unless the name ends in _host.
+ *   - fp64 throughout (PISA FTYPE=float64); complex numbers are interleaved
+ *     (re, im) doubles, matrices are row-major 3x3 -- i.e. exactly the memory
+ *     layout of the numpy arrays the reference passes to its numba kernels.
+ *   - the library is stateless apart from an optional scratch context.
+ *
+ * Each declaration names the reference interface it replaces (file:line
+ * relative to the icecube/pisa tree).
+ */
+#ifndef PISA_HIP_H
+#define PISA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PISA_HIP_OK 0
+#define PISA_HIP_ERR_INVALID -1     /* bad argument (shape, NULL, range)            */
+#define PISA_HIP_ERR_LAYERS -2      /* >120 layers (numba_osc_kernels.py:227)       */
+#define PISA_HIP_ERR_HIP -3         /* HIP runtime error (see pisa_hip_last_hip_error) */
+#define PISA_HIP_ERR_GEOMETRY -4    /* Earth model/detector geometry unsupported    */
+#define PISA_HIP_ERR_NEGATIVE -5    /* negative counts passed to a metric (stats.py:231-240) */
+#define PISA_HIP_ERR_OVERFLOW -6    /* weight outside the fixed-point accumulator range */
+#define PISA_HIP_ERR_NOMEM -7
+
+#define PISA_HIP_MAX_LAYERS 120     /* numba_osc_kernels.py:227 */
+#define PISA_HIP_MAX_SHELLS 64      /* PREM-59 + atmosphere = 61 */
+#define PISA_HIP_MAX_DIMS 3         /* translation.py:252 "can only do up to 3D" */
+#define PISA_HIP_ACC_LIMBS 6        /* 6 x 32-bit payload limbs, see DESIGN.md */
+
+const char *pisa_hip_strerror(int status);
+const char *pisa_hip_last_hip_error(void);
+int pisa_hip_version(void);
+/* number of visible GPUs (<=0: none). Does not initialise a device context. */
+int pisa_hip_device_count(void);
+
+/* ------------------------------------------------------------------ prob3 */
+
+/* The scalar arguments of `propagate_array`
+ * (pisa/stages/osc/prob3numba/numba_osc_hostfuncs.py:56-70), as prepared by
+ * prob3.compute_function / calc_probs (pisa/stages/osc/prob3.py:429-450, 539-578). */
+typedef struct {
+    double dm[9];         /* dm_matrix  f8[3,3]   (osc_params.py:265-292)        */
+    double mix[18];       /* PMNS       c16[3,3]  (osc_params.py:174-211)        */
+    double mat_pot[18];   /* generalised matter potential c16[3,3] (prob3.py:539-557) */
+    double mat_decay[18]; /* decay matrix c16[3,3] (prob3.py:559-563)            */
+    double lri_pot[9];    /* LRI potential f8[3,3] (prob3.py:565-578)            */
+    int64_t decay_flag;   /* +1 decay on, -1 off  (prob3.py:226-229)             */
+} pisa_hip_prob3_params;
+
+/* Replaces the gufunc `propagate_array` for one container
+ * (numba_osc_hostfuncs.py:56-70 -> osc_probs_layers_kernel,
+ * numba_osc_kernels.py:121-345).
+ *   d_energy[n]; d_densities / d_distances: [n][n_layers] if
+ *   layers_per_element != 0, else one shared row [n_layers];
+ *   d_probability[n][3][3] (P[init][final]).
+ * nubar = +1 / -1 (container aux datum). */
+int pisa_hip_propagate_array(const pisa_hip_prob3_params *h_params, int64_t nubar,
+                             const double *d_energy, const double *d_densities,
+                             const double *d_distances, int64_t n, int32_t n_layers,
+                             int32_t layers_per_element, double *d_probability, void *stream);
+
+/* Same contract with HOST buffers (numpy arrays): allocates, copies, runs,
+ * copies back, synchronises.  This is the call a reference-side binding would
+ * use in place of the numba gufunc. */
+int pisa_hip_propagate_array_host(const pisa_hip_prob3_params *h_params, int64_t nubar,
+                                  const double *h_energy, const double *h_densities,
+                                  const double *h_distances, int64_t n, int32_t n_layers,
+                                  int32_t layers_per_element, double *h_probability);
+
+/* Grid fast path used when calc_mode is a 2-D (true_energy x true_coszen)
+ * binning (prob3.py:452-459 links the 12 containers into 'nu' and 'nubar'):
+ * one launch evaluates nu AND nubar on every node.
+ *   d_energy[n_e]       node energies along the energy axis
+ *   d_densities/d_distances[n_cz][n_layers]   one row per coszen node
+ *   node index = e_major ? iE*n_cz + jcz : jcz*n_e + iE   (container.py:769-773)
+ *   d_prob_nu / d_prob_nubar [n_e*n_cz][3][3]  (either may be NULL) */
+int pisa_hip_prob3_grid(const pisa_hip_prob3_params *h_params, const double *d_energy,
+                        int32_t n_e, const double *d_densities, const double *d_distances,
+                        int32_t n_cz, int32_t n_layers, int32_t e_major, double *d_prob_nu,
+                        double *d_prob_nubar, void *stream);
+
+/* Earth model as held by `Layers` (pisa/stages/osc/layers.py:216-335, 411-439):
+ * shells ordered from the production sphere inwards. */
+typedef struct {
+    int32_t n_shell;
+    double r_detector;
+    double radii[PISA_HIP_MAX_SHELLS];
+    double rhos[PISA_HIP_MAX_SHELLS];         /* electron-fraction weighted */
+    double coszen_limit[PISA_HIP_MAX_SHELLS]; /* layers.py:308-335 */
+} pisa_hip_earth;
+
+/* Replaces `extCalcLayers` (layers.py:38-169).  Outputs [n][max_layers],
+ * zero padded; max_layers >= 2*n_shell (layers.py:244).  d_n_layers may be
+ * NULL.  d_status (int32, may be NULL) is set non-zero if any coszen hit the
+ * geometry the reference cannot handle (it raises a broadcast error there). */
+int pisa_hip_calc_layers(const pisa_hip_earth *h_earth, const double *d_coszen, int64_t n,
+                         int32_t max_layers, double *d_n_layers, double *d_densities,
+                         double *d_distances, int32_t *d_status, void *stream);
+
+/* Event-by-event prob3 (calc_mode = "events", prob3.py:406-409 + 581-588)
+ * WITHOUT materialising densities/distances[n][L]: the layer path of every
+ * event is rebuilt in-kernel from its coszen with the shell table in LDS. */
+int pisa_hip_prob3_events(const pisa_hip_prob3_params *h_params, const pisa_hip_earth *h_earth,
+                          int64_t nubar, const double *d_energy, const double *d_coszen,
+                          int64_t n, double *d_probability, int32_t *d_status, void *stream);
+
+/* `fill_probs` (numba_osc_hostfuncs.py:206-221): out[i] = P[i][init_flav][flav]. */
+int pisa_hip_fill_probs(const double *d_probability, int64_t init_flav, int64_t flav, int64_t n,
+                        double *d_out, void *stream);
+
+/* ------------------------------------------------------------ translation */
+
+typedef struct {
+    int32_t ndim;                         /* 1..3 */
+    int64_t nbins[PISA_HIP_MAX_DIMS];
+    double mins[PISA_HIP_MAX_DIMS];       /* regularised (linear) domain:      */
+    double maxs[PISA_HIP_MAX_DIMS];       /* ln(lo), ln(hi) for log dimensions */
+} pisa_hip_binning;
+
+/* `lookup_regular_{1,2,3}d` and `_array` variants
+ * (pisa/core/translation.py:417-501): nearest-bin gather, 0 outside
+ * [min,max).  d_flat_hist[n_bins][width], d_out[n][width]. */
+int pisa_hip_lookup_regular(const pisa_hip_binning *h_binning, const double *const *h_d_sample,
+                            int64_t n, const double *d_flat_hist, int32_t width, double *d_out,
+                            void *stream);
+
+/* `histogram(sample, weights, binning, averaged)` for regular linear
+ * binnings (translation.py:90-129, 171-205 -> fast_histogram.histogramdd).
+ * d_weights may be NULL (counts).  Sums are accumulated in 192-bit fixed
+ * point (order independent, bit-reproducible) and rounded once to fp64.
+ * averaged != 0 divides by the per-bin count with NaN->0 (translation.py:118-127). */
+int pisa_hip_histogram_regular(const pisa_hip_binning *h_binning,
+                               const double *const *h_d_sample, int64_t n,
+                               const double *d_weights, int32_t averaged, double *d_hist,
+                               void *stream);
+
+/* ------------------------------------- fused reweight + histogram (hot loop) */
+
+/* One PISA container (pisa/core/container.py:451) as seen by the fused
+ * kernel: device columns + the aux scalars the stages read. */
+typedef struct {
+    int64_t n_events;
+    const double *d_grid_x;          /* lookup coordinate on calc-grid dim 0 (ln E if log) */
+    const double *d_grid_y;          /* lookup coordinate on calc-grid dim 1               */
+    const double *d_nu_flux;         /* [n][2]  (nue, numu) flux  (barr_simple.py:100)     */
+    const double *d_weighted_aeff;   /* [n]                                              */
+    const double *d_initial_weights; /* [n]   (toy_event_generator.py:101-104)           */
+    const double *d_sample[PISA_HIP_MAX_DIMS]; /* output-binning coordinates, regularised */
+    int32_t flav;                    /* 0 e, 1 mu, 2 tau  (aux 'flav')                     */
+    int32_t nubar;                   /* +1 / -1           (aux 'nubar')                    */
+    double scale;                    /* aeff_scale*livetime_s*norms (aeff.py:78-86)        */
+} pisa_hip_container;
+
+/* Workspace sizes (bytes) for n_containers x n_bins histograms. */
+int64_t pisa_hip_hist_workspace_bytes(int32_t n_containers, int64_t n_bins);
+
+/* Fused  prob3.apply (prob3.py:621-622, with the grid->event lookup of
+ * container.py:981-1012 / translation.py:427-438)  +  aeff.apply
+ * (aeff.py:78-88)  +  hist.apply with error_method='sumw2'
+ * (utils/hist.py:163-218)  over all containers in ONE pass over the events:
+ *     w  = w0 * (f_e*P[e->flav] + f_mu*P[mu->flav]) * (aeff*scale)
+ *     hist[c][bin] += w ;  sumw2[c][bin] += w*w
+ * Result: d_limbs[n_containers][n_bins][2][PISA_HIP_ACC_LIMBS] int64 -- exact
+ * partial sums in normalised fixed point, safe to SUM-all-reduce across ranks
+ * (integer addition is associative => bit-reproducible for any GPU count).
+ * d_workspace: pisa_hip_hist_workspace_bytes() bytes of scratch.
+ * d_status: int32 flag, set non-zero on accumulator overflow. */
+int pisa_hip_reweight_hist(const pisa_hip_container *h_containers, int32_t n_containers,
+                           const pisa_hip_binning *h_calc_grid, const double *d_prob_nu,
+                           const double *d_prob_nubar, const pisa_hip_binning *h_out_binning,
+                           int64_t *d_limbs, void *d_workspace, int32_t *d_status, void *stream);
+
+/* Measurement hook: hipEvent_t handles (cast to void*, NULL to disable) that the
+ * next pisa_hip_reweight_hist / pisa_hip_histogram_regular calls of this host
+ * thread record immediately before and after the accumulate kernel on `stream`. */
+int pisa_hip_profile_events(void *start_event, void *stop_event);
+
+/* Unfused stage-by-stage variants (same arithmetic, one stage each) so that a
+ * pipeline with other services interleaved still runs on the device. */
+int pisa_hip_apply_osc_weights(const double *d_nu_flux, const double *d_prob_e,
+                               const double *d_prob_mu, int64_t n, double *d_weights,
+                               void *stream); /* prob3.py:621-622 */
+int pisa_hip_apply_aeff(const double *d_weighted_aeff, double scale, int64_t n,
+                        double *d_weights, void *stream); /* aeff.py:87 */
+
+/* Converts all-reduced limbs to fp64 maps: d_hist / d_sumw2 [n_containers][n_bins]
+ * (either may be NULL). `errors` = sqrt(sumw2) is left to the caller (hist.py:215). */
+int pisa_hip_hist_finalize(const int64_t *d_limbs, int32_t n_containers, int64_t n_bins,
+                           double *d_hist, double *d_sumw2, void *stream);
+
+/* ------------------------------------------------------------------ metric */
+
+#define PISA_HIP_METRIC_LLH 0          /* stats.py:169-253 */
+#define PISA_HIP_METRIC_POISSON_LLH 1  /* stats.py:255-326 */
+#define PISA_HIP_METRIC_CHI2 2         /* stats.py:98-167  */
+#define PISA_HIP_METRIC_MOD_CHI2 3     /* stats.py:651-695 */
+
+/* Map.metric / metric_total (pisa/core/map.py:1572-1604): per-bin metric of
+ * (actual, expected[, sigma2]) and its nansum.  If n_maps > 1 the expectation
+ * and variance are first summed over maps in index order
+ * (distribution_maker.py:274-281; map.py:1811-1838 adds variances):
+ *     d_expected[n_maps][n_bins], d_sigma2[n_maps][n_bins] (may be NULL).
+ * d_per_bin[n_bins] may be NULL.  d_total[1] receives the sum; d_status[1]
+ * (int32) is set to PISA_HIP_ERR_NEGATIVE for negative inputs. */
+int pisa_hip_metric(int32_t kind, const double *d_actual, const double *d_expected,
+                    const double *d_sigma2, int32_t n_maps, int64_t n_bins, double *d_per_bin,
+                    double *d_total, int32_t *d_status, void *stream);
+
+/* -------------------------------------------------------------------- flux */
+
+/* `apply_sys_vectorized` (pisa/stages/flux/barr_simple.py:147-233). Flux arrays [n][2]. */
+int pisa_hip_barr_simple(const double *d_true_energy, const double *d_true_coszen,
+                         const double *d_nu_flux_nominal, const double *d_nubar_flux_nominal,
+                         int64_t nubar, double nue_numu_ratio, double nu_nubar_ratio,
+                         double delta_index, double Barr_uphor_ratio, double Barr_nu_nubar_ratio,
+                         int64_t n, double *d_out, void *stream);
+
+/* ------------------------------------------------------- raw device memory */
+/* Thin wrappers so hosts without torch (a cgo/ctypes binding of the
+ * reference) can own device buffers. */
+int pisa_hip_malloc(void **d_ptr, int64_t bytes);
+int pisa_hip_free(void *d_ptr);
+int pisa_hip_memcpy_h2d(void *d_dst, const void *h_src, int64_t bytes, void *stream);
+int pisa_hip_memcpy_d2h(void *h_dst, const void *d_src, int64_t bytes, void *stream);
+int pisa_hip_memset(void *d_dst, int value, int64_t bytes, void *stream);
+int pisa_hip_stream_synchronize(void *stream);
+int pisa_hip_set_device(int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PISA_HIP_H */

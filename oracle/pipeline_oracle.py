@@ -1,0 +1,50 @@
+"""CPU oracle for one whole template evaluation (TEST INFRASTRUCTURE ONLY).
+
+Chains the restated reference functions in the order the reference pipeline
+runs them (pisa/core/pipeline.py:537-558):
+  prob3.compute_function (prob3.py:581-608)  -> propagate_array + fill_probs
+  prob3.apply_function  (prob3.py:621-622)   with grid->event lookup
+                        (container.py:981-1012 -> translation.py:427-438)
+  aeff.apply_function   (aeff.py:78-88)
+  hist.apply_function   (hist.py:163-218)    hist, sumw2 per container
+Inputs are the same `pisa_amd.synthetic.Workload` the device path is fed with.
+"""
+import numpy as np
+
+from . import oracle as orc
+
+
+def oracle_eval(wl, matrices=None, containers=None):
+    m = matrices or wl.last_matrices
+    g = wl.grid
+    lay = orc.Layers(wl.layers.prem, wl.layers.detector_depth, wl.layers.prop_height)
+    lay.rhos = np.array(wl.layers.rhos)  # identical shell table (host numpy, bit equal)
+    lay.calcLayers(g.coszen)
+    # node order: iE*n_cz + jcz  (container.py:769-773 for order (energy, coszen))
+    ee = np.repeat(g.energy, g.n_cz)
+    rho = np.tile(lay.density, (g.n_e, 1))
+    dist = np.tile(lay.distance, (g.n_e, 1))
+    probs = {}
+    for nubar in (1, -1):
+        probs[nubar] = orc.propagate_array(m["dm"], m["mix"], m["mat_pot"], m["decay_flag"],
+                                           m["mat_decay"], m["lri_pot"], nubar, ee, rho, dist)
+    mins = [g.binning.mins[0], g.binning.mins[1]]
+    maxs = [g.binning.maxs[0], g.binning.maxs[1]]
+    nb = [g.binning.nbins[0], g.binning.nbins[1]]
+    ob = wl.ob
+    hists, sumw2s, weights = [], [], []
+    for ev in (wl.events if containers is None else containers):
+        P = probs[ev["nubar"]]
+        pe_grid = orc.fill_probs(P, 0, ev["flav"])
+        pmu_grid = orc.fill_probs(P, 1, ev["flav"])
+        sample = [np.log(ev["true_energy"]), ev["true_coszen"]]
+        pe = orc.lookup_regular(sample, pe_grid, mins, maxs, nb)
+        pmu = orc.lookup_regular(sample, pmu_grid, mins, maxs, nb)
+        w = orc.reweight(ev["initial_weights"], ev["nu_flux"], pe, pmu, ev["weighted_aeff"],
+                         ev["scale"])
+        hists.append(orc.histogram_regular(ev["sample"], w, ob["mins"], ob["maxs"], ob["nbins"]))
+        sumw2s.append(orc.histogram_regular(ev["sample"], np.square(w), ob["mins"], ob["maxs"],
+                                            ob["nbins"]))
+        weights.append(w)
+    return dict(prob_nu=probs[1], prob_nubar=probs[-1], hist=np.array(hists),
+                sumw2=np.array(sumw2s), weights=weights)

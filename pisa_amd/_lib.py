@@ -1,0 +1,180 @@
+"""ctypes binding of ``libpisa_hip.so`` (C ABI: ``include/pisa_hip.h``).
+
+The shared library is the product; this module only marshals arguments.
+There is NO CPU fallback: if the library is missing, fails to load, or a call
+returns a non-zero status, an exception is raised.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpisa_hip.so")
+
+MAX_SHELLS = 64
+MAX_DIMS = 3
+ACC_LIMBS = 6
+MAX_LAYERS = 120
+
+ERR_NEGATIVE = -5
+ERR_OVERFLOW = -6
+
+
+class PisaHipError(RuntimeError):
+    def __init__(self, status, text):
+        super().__init__("libpisa_hip: %s (status %d)" % (text, status))
+        self.status = status
+
+
+class Prob3Params(C.Structure):
+    _fields_ = [
+        ("dm", C.c_double * 9),
+        ("mix", C.c_double * 18),
+        ("mat_pot", C.c_double * 18),
+        ("mat_decay", C.c_double * 18),
+        ("lri_pot", C.c_double * 9),
+        ("decay_flag", C.c_int64),
+    ]
+
+
+class Earth(C.Structure):
+    _fields_ = [
+        ("n_shell", C.c_int32),
+        ("r_detector", C.c_double),
+        ("radii", C.c_double * MAX_SHELLS),
+        ("rhos", C.c_double * MAX_SHELLS),
+        ("coszen_limit", C.c_double * MAX_SHELLS),
+    ]
+
+
+class Binning(C.Structure):
+    _fields_ = [
+        ("ndim", C.c_int32),
+        ("nbins", C.c_int64 * MAX_DIMS),
+        ("mins", C.c_double * MAX_DIMS),
+        ("maxs", C.c_double * MAX_DIMS),
+    ]
+
+
+class Container(C.Structure):
+    _fields_ = [
+        ("n_events", C.c_int64),
+        ("d_grid_x", C.c_void_p),
+        ("d_grid_y", C.c_void_p),
+        ("d_nu_flux", C.c_void_p),
+        ("d_weighted_aeff", C.c_void_p),
+        ("d_initial_weights", C.c_void_p),
+        ("d_sample", C.c_void_p * MAX_DIMS),
+        ("flav", C.c_int32),
+        ("nubar", C.c_int32),
+        ("scale", C.c_double),
+    ]
+
+
+_SIGS = {
+    "pisa_hip_strerror": (C.c_char_p, [C.c_int]),
+    "pisa_hip_last_hip_error": (C.c_char_p, []),
+    "pisa_hip_version": (C.c_int, []),
+    "pisa_hip_device_count": (C.c_int, []),
+    "pisa_hip_propagate_array": (C.c_int, [C.POINTER(Prob3Params), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "pisa_hip_propagate_array_host": (C.c_int, [C.POINTER(Prob3Params), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "pisa_hip_prob3_grid": (C.c_int, [C.POINTER(Prob3Params), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pisa_hip_calc_layers": (C.c_int, [C.POINTER(Earth), C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pisa_hip_prob3_events": (C.c_int, [C.POINTER(Prob3Params), C.POINTER(Earth), C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pisa_hip_fill_probs": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "pisa_hip_lookup_regular": (C.c_int, [C.POINTER(Binning), C.POINTER(C.c_void_p), C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "pisa_hip_histogram_regular": (C.c_int, [C.POINTER(Binning), C.POINTER(C.c_void_p), C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "pisa_hip_hist_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int64]),
+    "pisa_hip_reweight_hist": (C.c_int, [C.POINTER(Container), C.c_int32, C.POINTER(Binning), C.c_void_p, C.c_void_p, C.POINTER(Binning), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pisa_hip_profile_events": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pisa_hip_apply_osc_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "pisa_hip_apply_aeff": (C.c_int, [C.c_void_p, C.c_double, C.c_int64, C.c_void_p, C.c_void_p]),
+    "pisa_hip_hist_finalize": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pisa_hip_metric": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pisa_hip_barr_simple": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_void_p, C.c_void_p]),
+    "pisa_hip_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_int64]),
+    "pisa_hip_free": (C.c_int, [C.c_void_p]),
+    "pisa_hip_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "pisa_hip_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "pisa_hip_memset": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
+    "pisa_hip_stream_synchronize": (C.c_int, [C.c_void_p]),
+    "pisa_hip_set_device": (C.c_int, [C.c_int]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+_lib = None
+
+
+def lib():
+    """Load libpisa_hip.so (after torch, so both share one HIP runtime)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C pisa_amd/csrc`.  There is no CPU fallback." % LIB_PATH
+        )
+    try:
+        import torch  # noqa: F401  (loads libamdhip64.so first -> single runtime instance)
+    except Exception:  # pragma: no cover - torch is optional for the C ABI itself
+        pass
+    handle = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(handle, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = handle
+    return _lib
+
+
+def check(status):
+    if status != 0:
+        l = lib()
+        text = l.pisa_hip_strerror(int(status)).decode()
+        if status == -3:
+            text += " -- " + l.pisa_hip_last_hip_error().decode()
+        if status == ERR_NEGATIVE:
+            raise ValueError(text)  # stats.py:231-240 raises ValueError
+        if status == ERR_OVERFLOW:
+            raise OverflowError(text)
+        raise PisaHipError(status, text)
+
+
+def make_prob3_params(dm, mix, mat_pot, decay_flag, mat_decay, lri_pot):
+    p = Prob3Params()
+    p.dm[:] = np.ascontiguousarray(dm, np.float64).ravel()
+    p.mix[:] = np.ascontiguousarray(mix, np.complex128).ravel().view(np.float64)
+    p.mat_pot[:] = np.ascontiguousarray(mat_pot, np.complex128).ravel().view(np.float64)
+    p.mat_decay[:] = np.ascontiguousarray(mat_decay, np.complex128).ravel().view(np.float64)
+    p.lri_pot[:] = np.ascontiguousarray(lri_pot, np.float64).ravel()
+    p.decay_flag = int(decay_flag)
+    return p
+
+
+def make_earth(radii, rhos, coszen_limit, r_detector):
+    n = len(radii)
+    if n > MAX_SHELLS:
+        raise ValueError("Earth model has %d shells; at most %d supported" % (n, MAX_SHELLS))
+    e = Earth()
+    e.n_shell = n
+    e.r_detector = float(r_detector)
+    for k in range(n):
+        e.radii[k] = float(radii[k])
+        e.rhos[k] = float(rhos[k])
+        e.coszen_limit[k] = float(coszen_limit[k])
+    return e
+
+
+def make_binning(mins, maxs, nbins):
+    b = Binning()
+    b.ndim = len(nbins)
+    if not 1 <= b.ndim <= MAX_DIMS:
+        raise ValueError("can only do up to 3D at the moment")  # translation.py:252
+    for k in range(b.ndim):
+        b.nbins[k] = int(nbins[k])
+        b.mins[k] = float(mins[k])
+        b.maxs[k] = float(maxs[k])
+    return b

@@ -1,0 +1,66 @@
+// common.hpp -- shared host-side helpers of libpisa_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pisa_hip.h"
+
+#define PISA_API extern "C" __attribute__((visibility("default")))
+
+namespace pisa {
+
+void set_last_hip_error(hipError_t e, const char *what);
+
+inline int check_hip(hipError_t e, const char *what) {
+    if (e != hipSuccess) {
+        set_last_hip_error(e, what);
+        return PISA_HIP_ERR_HIP;
+    }
+    return PISA_HIP_OK;
+}
+
+#define PISA_TRY_HIP(expr)                                       \
+    do {                                                         \
+        int _rc = ::pisa::check_hip((expr), #expr);              \
+        if (_rc != PISA_HIP_OK) return _rc;                      \
+    } while (0)
+
+#define PISA_CHECK_LAUNCH(name)                                  \
+    do {                                                         \
+        int _rc = ::pisa::check_hip(hipGetLastError(), name);    \
+        if (_rc != PISA_HIP_OK) return _rc;                      \
+    } while (0)
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Regular (linear, equal-width) binning as the kernels see it
+// (fast_histogram rule / translation.py:417-456): bin = (int)((x - min) * norm)
+struct DevBinning {
+    int32_t ndim;
+    int32_t nb[3];
+    double mins[3];
+    double maxs[3];
+    double norm[3];
+};
+
+inline int make_dev_binning(const pisa_hip_binning *b, DevBinning &d, int64_t &total) {
+    if (!b || b->ndim < 1 || b->ndim > PISA_HIP_MAX_DIMS) return PISA_HIP_ERR_INVALID;
+    d.ndim = b->ndim;
+    total = 1;
+    for (int k = 0; k < 3; k++) {
+        d.nb[k] = 1; d.mins[k] = 0; d.maxs[k] = 1; d.norm[k] = 1;
+    }
+    for (int k = 0; k < b->ndim; k++) {
+        if (b->nbins[k] < 1 || b->nbins[k] > (1 << 24) || !(b->maxs[k] > b->mins[k]))
+            return PISA_HIP_ERR_INVALID;
+        d.nb[k] = (int32_t)b->nbins[k];
+        d.mins[k] = b->mins[k];
+        d.maxs[k] = b->maxs[k];
+        // normx = nx / (xmax - xmin)   (translation.py:419; fast_histogram)
+        d.norm[k] = (double)b->nbins[k] / (b->maxs[k] - b->mins[k]);
+        total *= b->nbins[k];
+    }
+    return PISA_HIP_OK;
+}
+
+}  // namespace pisa

@@ -1,0 +1,212 @@
+// metric_flux.hip -- bin-sized metric reduction and the Barr flux systematics.
+//
+//   metric_kernel       Map.metric + np.nansum (map.py:1572-1604) for
+//                       llh / poisson_llh / chi2 / mod_chi2 (stats.py); a single
+//                       workgroup with a fixed reduction tree => deterministic
+//   barr_simple_kernel  apply_sys_vectorized (flux/barr_simple.py:147-233)
+#include "common.hpp"
+
+namespace pisa {
+
+constexpr double SMALL_POS = 1e-10;  // stats.py:40
+constexpr double FTYPE_PREC = 2.220446049250313e-16;
+
+__device__ __forceinline__ double metric_bin(int kind, double k, double lam, double s2) {
+    // expected clipped to >= SMALL_POS (stats.py:154-155, 246-247, 319-320, 686-687)
+    if (lam < SMALL_POS) lam = SMALL_POS;
+    double v;
+    switch (kind) {
+    case PISA_HIP_METRIC_LLH:
+        v = k * log(lam) - lam;
+        v -= k * log(k) - k;  // k == 0 -> NaN, dropped by nansum
+        break;
+    case PISA_HIP_METRIC_POISSON_LLH:
+        v = k * log(lam) - lam;
+        v -= lgamma(k + 1);
+        break;
+    case PISA_HIP_METRIC_CHI2: {
+        double d = k - lam;
+        v = (d * d) / lam;
+        break;
+    }
+    default: {
+        double d = k - lam;
+        v = (d * d) / (s2 + lam);
+    }
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+metric_kernel(int kind, const double *__restrict__ actual, const double *__restrict__ expected,
+              const double *__restrict__ sigma2, int n_maps, int64_t n_bins,
+              double *__restrict__ per_bin, double *__restrict__ total,
+              int32_t *__restrict__ status) {
+    __shared__ double s_sum[256];
+    __shared__ int s_flag[2];  // [0] negative input, [1] some |delta| >= 5 eps (chi2)
+    if (threadIdx.x < 2) s_flag[threadIdx.x] = 0;
+    __syncthreads();
+    double acc = 0.0;
+    for (int64_t b = threadIdx.x; b < n_bins; b += blockDim.x) {
+        double k = actual[b];
+        // sum of the maps in index order (distribution_maker.py:274-281)
+        double lam = 0.0, s2 = 0.0;
+        for (int m = 0; m < n_maps; m++) {
+            lam = (m == 0) ? expected[b] : lam + expected[(int64_t)m * n_bins + b];
+            if (sigma2) s2 = (m == 0) ? sigma2[b] : s2 + sigma2[(int64_t)m * n_bins + b];
+        }
+        double v;
+        bool finite = (k == k) && (lam == lam) && !isinf(k) && !isinf(lam);
+        if (!finite) {
+            v = __longlong_as_double(0x7ff8000000000000LL);
+        } else {
+            if (k < 0.0 || lam < 0.0) atomicOr(&s_flag[0], 1);
+            if (kind == PISA_HIP_METRIC_CHI2) {
+                double lc = lam < SMALL_POS ? SMALL_POS : lam;
+                if (!(fabs(k - lc) < 5 * FTYPE_PREC)) atomicOr(&s_flag[1], 1);
+            }
+            v = metric_bin(kind, k, lam, s2);
+        }
+        if (per_bin) per_bin[b] = v;
+        if (v == v) acc += v;  // np.nansum
+    }
+    s_sum[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) s_sum[threadIdx.x] += s_sum[threadIdx.x + off];
+        __syncthreads();
+    }
+    bool chi2_zero = (kind == PISA_HIP_METRIC_CHI2) && s_flag[1] == 0;  // stats.py:160-161
+    if (chi2_zero && per_bin) {
+        for (int64_t b = threadIdx.x; b < n_bins; b += blockDim.x) per_bin[b] = 0.0;
+    }
+    if (threadIdx.x == 0) {
+        total[0] = chi2_zero ? 0.0 : s_sum[0];
+        if (status && s_flag[0]) status[0] = PISA_HIP_ERR_NEGATIVE;
+    }
+}
+
+// ------------------------------------------------------- Barr flux systematics
+// pisa/utils/barr_parameterization.py:17-113
+__device__ __forceinline__ double sign_(double v) {
+    if (v == 0) return 0.0;
+    return v >= 0 ? 1.0 : -1.0;
+}
+__device__ __forceinline__ double LogLogParam(double true_energy, double y1, double y2, double x1,
+                                              double x2, bool use_cutoff, double cutoff_value) {
+    double nu_nubar = sign_(y2);
+    y1 = sign_(y1) * log10(fabs(y1) + 0.0001);
+    y2 = log10(fabs(y2 + 0.0001));
+    double modification =
+        nu_nubar * pow(10., (((y2 - y1) / (x2 - x1)) * (log10(true_energy) - x1) + y1 - 2.));
+    if (use_cutoff) modification *= exp(-1. * true_energy / cutoff_value);
+    return modification;
+}
+__device__ __forceinline__ double norm_fcn(double x, double A, double sigma) {
+    const double pi = 3.14159265358979323846;
+    return A / sqrt(2 * pi * (sigma * sigma)) * exp(-(x * x) / (2 * (sigma * sigma)));
+}
+__device__ __forceinline__ double ModFlux(int flav, double e, double cz) {
+    // all eight e*/z* scale arguments are 1 at the only call site (modRatioNuBar)
+    const double e1max_mu = 3., e2max_mu = 43, e1max_e = 2.5, e2max_e = 10;
+    const double x1e = 0.5, x2e = 3.;
+    const double z1max_mu = 0.6, z2max_mu = 5., z1max_e = 0.3, z2max_e = 5.;
+    const double nue_cutoff = 650., numu_cutoff = 1000.;
+    const double x1z = 0.5, x2z = 2.;
+    if (flav == 1) {
+        double A_ave = LogLogParam(e, e1max_mu * 1., e2max_mu * 1., x1e, x2e, false, 0);
+        double A_shape = 2.5 * LogLogParam(e, z1max_mu * 1., z2max_mu * 1., x1z, x2z, true, numu_cutoff);
+        return A_ave - (norm_fcn(cz, A_shape, 0.36) - 0.6 * A_shape);
+    }
+    double A_ave = LogLogParam(e, e1max_mu * 1. + e1max_e * 1., e2max_mu * 1. + e2max_e * 1., x1e, x2e, false, 0);
+    double A_shape = 1. * LogLogParam(e, z1max_mu * 1. + z1max_e * 1., z2max_mu * 1. + z2max_e * 1., x1z, x2z, true, nue_cutoff);
+    return A_ave - (1.5 * norm_fcn(cz, A_shape, 0.36) - 0.7 * A_shape);
+}
+__device__ __forceinline__ double modRatioUpHor(int flav, double e, double cz, double uphor) {
+    const double z1max_mu = 0.6, z2max_mu = 5., z1max_e = 0.3, z2max_e = 5.;
+    const double nue_cutoff = 650.;
+    const double x1z = 0.5, x2z = 2.;
+    if (flav == 0) {
+        double A_shape = 1. * fabs(uphor) *
+                         LogLogParam(e, (z1max_e + z1max_mu), (z2max_e + z2max_mu), x1z, x2z, true, nue_cutoff);
+        return 1 - 0.3 * sign_(uphor) * norm_fcn(cz, A_shape, 0.35);
+    }
+    return 1.;
+}
+__device__ __forceinline__ double modRatioNuBar(int nubar, int flav, double e, double cz,
+                                                double nubar_sys) {
+    double modfactor = nubar_sys * ModFlux(flav, e, cz);
+    if (nubar < 0) return fmax(0., 1. / (1 + 0.5 * modfactor));
+    return fmax(0., 1. + 0.5 * modfactor);
+}
+// barr_simple.py:107-138
+__device__ __forceinline__ void apply_ratio_scale(double ratio_scale, double in1, double in2,
+                                                  double &o0, double &o1) {
+    if (in1 == 0. && in2 == 0.) { o0 = 0.; o1 = 0.; return; }
+    double orig_ratio = in1 / in2;
+    double orig_sum = in1 + in2;
+    double nw = orig_sum / (1. + ratio_scale * orig_ratio);
+    o0 = ratio_scale * orig_ratio * nw;
+    o1 = nw;
+}
+
+__global__ void __launch_bounds__(256)
+barr_simple_kernel(const double *__restrict__ true_energy, const double *__restrict__ true_coszen,
+                   const double *__restrict__ nu_nom, const double *__restrict__ nubar_nom,
+                   int nubar, double nue_numu_ratio, double nu_nubar_ratio, double delta_index,
+                   double uphor, double barr_nu_nubar, int64_t n, double *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double e = true_energy[i], cz = true_coszen[i];
+    double2 fn = reinterpret_cast<const double2 *>(nu_nom)[i];
+    double2 fb = reinterpret_cast<const double2 *>(nubar_nom)[i];
+    double nu0, nu1, nb0, nb1;
+    apply_ratio_scale(nue_numu_ratio, fn.x, fn.y, nu0, nu1);
+    apply_ratio_scale(nue_numu_ratio, fb.x, fb.y, nb0, nb1);
+    double idx_scale = pow(e / 24.0900951261, delta_index);
+    nu0 *= idx_scale; nu1 *= idx_scale; nb0 *= idx_scale; nb1 *= idx_scale;
+    double e0, e1, m0, m1;
+    apply_ratio_scale(nu_nubar_ratio, nu0, nb0, e0, e1);  // nue: (nu, nubar)
+    apply_ratio_scale(nu_nubar_ratio, nu1, nb1, m0, m1);  // numu
+    double o0 = nubar < 0 ? e1 : e0;
+    double o1 = nubar < 0 ? m1 : m0;
+    o0 *= modRatioNuBar(nubar, 0, e, cz, barr_nu_nubar);
+    o1 *= modRatioNuBar(nubar, 1, e, cz, barr_nu_nubar);
+    o0 *= modRatioUpHor(0, e, cz, uphor);
+    o1 *= modRatioUpHor(1, e, cz, uphor);
+    reinterpret_cast<double2 *>(out)[i] = make_double2(o0, o1);
+}
+
+}  // namespace pisa
+
+using namespace pisa;
+
+PISA_API int pisa_hip_metric(int32_t kind, const double *d_actual, const double *d_expected,
+                             const double *d_sigma2, int32_t n_maps, int64_t n_bins,
+                             double *d_per_bin, double *d_total, int32_t *d_status, void *stream) {
+    if (kind < 0 || kind > 3 || n_maps < 1 || n_bins < 0 || !d_total) return PISA_HIP_ERR_INVALID;
+    if (n_bins > 0 && (!d_actual || !d_expected)) return PISA_HIP_ERR_INVALID;
+    hipLaunchKernelGGL(metric_kernel, dim3(1), dim3(256), 0, as_stream(stream), (int)kind, d_actual,
+                       d_expected, d_sigma2, (int)n_maps, n_bins, d_per_bin, d_total, d_status);
+    PISA_CHECK_LAUNCH("metric_kernel");
+    return PISA_HIP_OK;
+}
+
+PISA_API int pisa_hip_barr_simple(const double *d_true_energy, const double *d_true_coszen,
+                                  const double *d_nu_flux_nominal,
+                                  const double *d_nubar_flux_nominal, int64_t nubar,
+                                  double nue_numu_ratio, double nu_nubar_ratio, double delta_index,
+                                  double Barr_uphor_ratio, double Barr_nu_nubar_ratio, int64_t n,
+                                  double *d_out, void *stream) {
+    if (n < 0 || (nubar != 1 && nubar != -1)) return PISA_HIP_ERR_INVALID;
+    if (n == 0) return PISA_HIP_OK;
+    if (!d_true_energy || !d_true_coszen || !d_nu_flux_nominal || !d_nubar_flux_nominal || !d_out)
+        return PISA_HIP_ERR_INVALID;
+    dim3 block(256), grid((unsigned)((n + 255) / 256));
+    hipLaunchKernelGGL(barr_simple_kernel, grid, block, 0, as_stream(stream), d_true_energy,
+                       d_true_coszen, d_nu_flux_nominal, d_nubar_flux_nominal, (int)nubar,
+                       nue_numu_ratio, nu_nubar_ratio, delta_index, Barr_uphor_ratio,
+                       Barr_nu_nubar_ratio, n, d_out);
+    PISA_CHECK_LAUNCH("barr_simple_kernel");
+    return PISA_HIP_OK;
+}

@@ -1,0 +1,473 @@
+// prob3_device.hpp -- three-flavour matter oscillation core for gfx950.
+//
+// Device-side implementation of the per-element work of PISA's prob3
+// (pisa/stages/osc/prob3numba/numba_osc_kernels.py:121-872).  One thread owns
+// one (energy, path) element and keeps its 3x3 complex state in VGPRs; every
+// element-invariant quantity (PMNS, H_vac, H_decay, matter potential, mass
+// splittings) is prepared once on the host per nu / nubar sign
+// (prob3_make_consts) and arrives through the kernel-argument segment, so it is
+// read with scalar loads and lives in SGPRs.
+//
+// The arithmetic keeps the reference's operation order (the library is built
+// with -ffp-contract=off) so that results track the reference to a few ulp;
+// the algebraic reformulations are confined to (a) hoisting the invariant
+// prologue, (b) never materialising product[3][3][3] / H_minus_M[3][3][3]
+// (each (i,j) term is formed and consumed in registers), (c) resolving the
+// layer-matrix cache by index instead of storing 120 matrices per thread.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pisa {
+
+struct cplx {
+    double re, im;
+};
+
+#define PISA_HD __host__ __device__ __forceinline__
+
+PISA_HD cplx cmake(double re, double im) { return cplx{re, im}; }
+PISA_HD cplx cadd(cplx a, cplx b) { return cplx{a.re + b.re, a.im + b.im}; }
+PISA_HD cplx csub(cplx a, cplx b) { return cplx{a.re - b.re, a.im - b.im}; }
+PISA_HD cplx cconj(cplx a) { return cplx{a.re, -a.im}; }
+PISA_HD cplx cmul(cplx a, cplx b) {
+    return cplx{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+}
+PISA_HD cplx cscale(double x, cplx a) { return cplx{x * a.re, x * a.im}; }
+PISA_HD double cabs2(cplx a) { return a.re * a.re + a.im * a.im; }
+// Smith division (what numba / CPython use for complex / complex)
+PISA_HD cplx cdiv(cplx a, cplx b) {
+    cplx r;
+    if (fabs(b.re) >= fabs(b.im)) {
+        double ratio = b.im / b.re;
+        double denom = b.re + b.im * ratio;
+        r.re = (a.re + a.im * ratio) / denom;
+        r.im = (a.im - a.re * ratio) / denom;
+    } else {
+        double ratio = b.re / b.im;
+        double denom = b.re * ratio + b.im;
+        r.re = (a.re * ratio + a.im) / denom;
+        r.im = (a.im * ratio - a.re) / denom;
+    }
+    return r;
+}
+
+struct mat3 {
+    cplx m[3][3];
+};
+
+// C = A.B with the reference's accumulation order (numba_tools.py:278-289)
+PISA_HD void mat_mul(const mat3 &A, const mat3 &B, mat3 &C) {
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            cplx acc = cmul(A.m[i][0], B.m[0][j]);
+            acc = cadd(acc, cmul(A.m[i][1], B.m[1][j]));
+            acc = cadd(acc, cmul(A.m[i][2], B.m[2][j]));
+            C.m[i][j] = acc;
+        }
+}
+
+// Element-invariant quantities for ONE nu/nubar sign
+// (numba_osc_kernels.py:208-221 and the sign handling of :435-440, :647-653).
+struct Prob3Side {
+    mat3 U;        // mix_nubar
+    mat3 Ud;       // conjugate transpose
+    mat3 Hvd;      // H_vac (+ H_decay if decay_flag == 1), without 1/2E
+    mat3 V;        // mat_pot (nu) or conj(mat_pot) (nubar)
+    double lri[3][3];  // +-lri_pot*1e9 added to Re(H_mat)
+    double a_sign;     // +1 (nu) / -1 (nubar): H_mat = a_sign*a*V
+};
+
+struct Prob3Consts {
+    Prob3Side side[2];  // [0] nu, [1] nubar
+    double dm[3][3];
+    int32_t decay;      // 1: decay branch (complex eigenvalues)
+    int32_t pad;
+};
+
+// Host-side prologue: get_H_vac (:534-569), get_H_decay (:571-603) and the
+// nubar conjugations (:208-217), evaluated once per call instead of per element.
+inline void prob3_make_consts(const double *dm, const double *mix, const double *mat_pot,
+                              const double *mat_decay, const double *lri_pot, int64_t decay_flag,
+                              Prob3Consts &c) {
+    const cplx *mixc = reinterpret_cast<const cplx *>(mix);
+    const cplx *potc = reinterpret_cast<const cplx *>(mat_pot);
+    const cplx *decc = reinterpret_cast<const cplx *>(mat_decay);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) c.dm[i][j] = dm[3 * i + j];
+    c.decay = (decay_flag == 1) ? 1 : 0;
+    c.pad = 0;
+    for (int s = 0; s < 2; s++) {
+        Prob3Side &S = c.side[s];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                cplx u = mixc[3 * i + j];
+                S.U.m[i][j] = (s == 0) ? u : cconj(u);
+            }
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) S.Ud.m[j][i] = cconj(S.U.m[i][j]);
+        // H_vac = U . diag(0, dm21, dm31) . U^dagger
+        mat3 diag, tmp, Hvac, Hdec, D;
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) diag.m[i][j] = cmake(0.0, 0.0);
+        diag.m[1][1] = cmake(c.dm[1][0] + 0.0, 0.0);
+        diag.m[2][2] = cmake(c.dm[2][0] + 0.0, 0.0);
+        // the reference accumulates from an explicit 0.0: 0 + x == x
+        mat_mul(diag, S.Ud, tmp);
+        mat_mul(S.U, tmp, Hvac);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) D.m[i][j] = decc[3 * i + j];
+        mat_mul(D, S.Ud, tmp);
+        mat_mul(S.U, tmp, Hdec);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                S.Hvd.m[i][j] = c.decay ? cadd(Hvac.m[i][j], Hdec.m[i][j]) : Hvac.m[i][j];
+                cplx v = potc[3 * i + j];
+                S.V.m[i][j] = (s == 0) ? v : cconj(v);
+                double l = lri_pot[3 * i + j] * 1e9;
+                S.lri[i][j] = (s == 0) ? l : -l;
+            }
+        S.a_sign = (s == 0) ? 1.0 : -1.0;
+    }
+}
+
+// ---------------------------------------------------------------- eigenvalues
+
+// get_dms (numba_osc_kernels.py:687-831): real eigenvalues of the Hermitian
+// H_full via the trigonometric cubic solution, re-ordered to follow the vacuum
+// ordering.  M[k] = 2E * lambda_k.
+__device__ __forceinline__ void get_dms(double energy, const mat3 &H, const double (&dm)[3][3],
+                                        double (&M)[3]) {
+    const cplx h01 = H.m[0][1], h12 = H.m[1][2], h20 = H.m[2][0];
+    const cplx h00 = H.m[0][0], h11 = H.m[1][1], h22 = H.m[2][2], h02 = H.m[0][2];
+    double real_product_a = cmul(cmul(h01, h12), h20).re;
+    double real_product_b = cmul(cmul(h00, h11), h22).re;
+    double n_emu = h01.re * h01.re + h01.im * h01.im;
+    double n_etau = h02.re * h02.re + h02.im * h02.im;
+    double n_mutau = h12.re * h12.re + h12.im * h12.im;
+    cplx s12 = cadd(h11, h22);
+    double c1 = (h00.re * s12.re) - (h00.im * s12.im) + (h11.re * h22.re) - (h11.im * h22.im) -
+                n_emu - n_mutau - n_etau;
+    double c0 = h00.re * n_mutau + h11.re * n_etau + h22.re * n_emu - 2.0 * real_product_a -
+                real_product_b;
+    double c2 = -h00.re - h11.re - h22.re;
+
+    double one_over_two_e = 0.5 / energy;
+    const double one_third = 1.0 / 3.0;
+    const double two_third = 2.0 / 3.0;
+    double x = dm[1][0];
+    double y = dm[2][0];
+    double c2_v = -one_over_two_e * (x + y);
+    double p = c2 * c2 - 3.0 * c1;
+    double p_v = (one_over_two_e * one_over_two_e) * (x * x + y * y - x * y);
+    p = fmax(0.0, p);
+    double q = -13.5 * c0 - c2 * (c2 * c2) + 4.5 * c1 * c2;
+    double q_v = (one_over_two_e * (one_over_two_e * one_over_two_e)) * (x + y) *
+                 ((x + y) * (x + y) - 4.5 * x * y);
+    double tmp = 27 * (0.25 * (c1 * c1) * (p - c1) + c0 * (q + 6.75 * c0));
+    double tmp_v = p_v * (p_v * p_v) - q_v * q_v;
+    tmp = fmax(0.0, tmp);
+
+    const double a = two_third * 3.14159265358979323846;
+    double res = atan2(sqrt(tmp), q) * one_third;
+    double res_v = atan2(sqrt(tmp_v), q_v) * one_third;
+    double b = two_third * sqrt(p);
+    double b_v = two_third * sqrt(p_v);
+    double th[3] = {res + a, res - a, res};
+    double thv[3] = {res_v + a, res_v - a, res_v};
+    double mu[3], mv[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        mu[i] = 2.0 * energy * (b * cos(th[i]) - c2 * one_third + dm[0][0]);
+        mv[i] = 2.0 * energy * (b_v * cos(thv[i]) - c2_v * one_third + dm[0][0]);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        double best = fabs(dm[i][0] - mv[0]);
+        double sel = mu[0];
+#pragma unroll
+        for (int j = 1; j < 3; j++) {
+            double t = fabs(dm[i][0] - mv[j]);
+            bool lt = t < best;
+            sel = lt ? mu[j] : sel;
+            best = lt ? t : best;
+        }
+        M[i] = sel;
+    }
+}
+
+// Complex helpers for the decay branch (general complex 3x3 eigenvalues;
+// the reference calls LAPACK zgeev through np.linalg.eigvals,
+// numba_osc_kernels.py:655-685).  Closed-form cubic + Newton polishing; the
+// order of the eigenvalues is irrelevant to everything downstream.
+__device__ __forceinline__ cplx csqrt_d(cplx z) {
+    double r = hypot(z.re, z.im);
+    if (r == 0.0) return cmake(0.0, 0.0);
+    double t = sqrt(0.5 * (r + fabs(z.re)));
+    if (z.re >= 0.0) return cmake(t, z.im / (2.0 * t));
+    return cmake(fabs(z.im) / (2.0 * t), z.im >= 0.0 ? t : -t);
+}
+__device__ __forceinline__ cplx ccbrt_d(cplx z) {
+    double r = hypot(z.re, z.im);
+    if (r == 0.0) return cmake(0.0, 0.0);
+    double ang = atan2(z.im, z.re) / 3.0;
+    double m = cbrt(r);
+    double s, c;
+    sincos(ang, &s, &c);
+    return cmake(m * c, m * s);
+}
+__device__ inline void eigvals3_general(const mat3 &H, cplx (&lam)[3]) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) s = fmax(s, fmax(fabs(H.m[i][j].re), fabs(H.m[i][j].im)));
+    if (s == 0.0) {
+        lam[0] = lam[1] = lam[2] = cmake(0.0, 0.0);
+        return;
+    }
+    double inv = 1.0 / s;
+    mat3 A;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) A.m[i][j] = cscale(inv, H.m[i][j]);
+    cplx tr = cadd(cadd(A.m[0][0], A.m[1][1]), A.m[2][2]);
+    cplx c2 = cscale(-1.0, tr);
+    cplx m00 = csub(cmul(A.m[1][1], A.m[2][2]), cmul(A.m[1][2], A.m[2][1]));
+    cplx m11 = csub(cmul(A.m[0][0], A.m[2][2]), cmul(A.m[0][2], A.m[2][0]));
+    cplx m22 = csub(cmul(A.m[0][0], A.m[1][1]), cmul(A.m[0][1], A.m[1][0]));
+    cplx c1 = cadd(cadd(m00, m11), m22);
+    cplx det = cadd(
+        csub(cmul(A.m[0][0], m00),
+             cmul(A.m[0][1], csub(cmul(A.m[1][0], A.m[2][2]), cmul(A.m[1][2], A.m[2][0])))),
+        cmul(A.m[0][2], csub(cmul(A.m[1][0], A.m[2][1]), cmul(A.m[1][1], A.m[2][0]))));
+    cplx c0 = cscale(-1.0, det);
+    cplx c2sq = cmul(c2, c2);
+    cplx p = csub(c1, cscale(1.0 / 3.0, c2sq));
+    cplx q = cadd(csub(cscale(2.0 / 27.0, cmul(c2sq, c2)), cscale(1.0 / 3.0, cmul(c2, c1))), c0);
+    cplx halfq = cscale(0.5, q);
+    cplx disc = cadd(cmul(halfq, halfq), cscale(1.0 / 27.0, cmul(cmul(p, p), p)));
+    cplx sd = csqrt_d(disc);
+    cplx u1 = csub(sd, halfq), u2 = csub(cscale(-1.0, sd), halfq);
+    cplx u3 = (cabs2(u1) >= cabs2(u2)) ? u1 : u2;
+    cplx u = ccbrt_d(u3);
+    const cplx w1 = {-0.5, 0.86602540378443864676}, w2 = {-0.5, -0.86602540378443864676};
+    cplx us[3] = {u, cmul(u, w1), cmul(u, w2)};
+    cplx shift = cscale(1.0 / 3.0, c2);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        cplx t = (cabs2(us[k]) == 0.0) ? cmake(0.0, 0.0) : csub(us[k], cdiv(p, cscale(3.0, us[k])));
+        lam[k] = csub(t, shift);
+    }
+    for (int it = 0; it < 4; it++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            cplx xk = lam[k];
+            cplx f = cadd(cmul(cadd(cmul(cadd(xk, c2), xk), c1), xk), c0);
+            cplx df = cadd(cmul(cadd(cscale(3.0, xk), cscale(2.0, c2)), xk), c1);
+            if (cabs2(df) > 0.0) lam[k] = csub(xk, cdiv(f, df));
+        }
+#pragma unroll
+    for (int k = 0; k < 3; k++) lam[k] = cscale(s, lam[k]);
+}
+
+// ------------------------------------------------------ one layer's amplitude
+
+// get_transition_matrix (numba_osc_kernels.py:348-478) with
+// get_transition_matrix_massbasis (:481-531) and get_product (:834-872) fused:
+// returns A (mass basis) for a layer of electron density rho and length
+// baseline.  DECAY selects the complex-eigenvalue branch at compile time.
+template <bool DECAY>
+__device__ __forceinline__ void layer_amplitude(const Prob3Side &S, const double (&dm)[3][3],
+                                                double energy, double rho, double baseline,
+                                                mat3 &A) {
+    // get_H_mat (:605-653) + LRI (:435-440)
+    const double tworttwoGf = 1.52588e-4;
+    double a = 0.5 * rho * tworttwoGf;
+    double sa = S.a_sign * a;  // exact sign flip
+    double one_over_two_e = 0.5 / energy;
+    mat3 Hf;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            cplx hm = cscale(sa, S.V.m[i][j]);
+            hm.re = hm.re + S.lri[i][j];
+            Hf.m[i][j] = cadd(cscale(one_over_two_e, S.Hvd.m[i][j]), hm);
+        }
+
+    // H in the mass basis, times 2E  (:466-467, :857)
+    mat3 tmp, X;
+    mat_mul(Hf, S.U, tmp);
+    mat_mul(S.Ud, tmp, X);
+    double two_e = 2.0 * energy;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) X.m[i][j] = cscale(two_e, X.m[i][j]);
+
+    double L_over_E = baseline / energy;
+    const double hbar_c_factor = 2.534;
+
+    if (!DECAY) {
+        double M[3];
+        get_dms(energy, Hf, dm, M);
+        // phases exp(-i M_k L/E 2.534)
+        cplx ph[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            double arg = (-M[k]) * L_over_E * hbar_c_factor;
+            double s, c;
+            sincos(arg, &s, &c);
+            ph[k] = cmake(c, s);
+        }
+        // real denominators (M_k - M_j)(M_k - M_l)  (:870-872)
+        double den0 = (M[0] - M[1]) * (M[0] - M[2]);
+        double den1 = (M[1] - M[2]) * (M[1] - M[0]);
+        double den2 = (M[2] - M[0]) * (M[2] - M[1]);
+        // diagonal entries of (2E H - M_k): Xd[k][i]
+        cplx Xd[3][3];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int i = 0; i < 3; i++) Xd[k][i] = cmake(X.m[i][i].re - M[k], X.m[i][i].im);
+#define HMM(i_, j_, k_) (((i_) == (j_)) ? Xd[k_][i_] : X.m[i_][j_])
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                cplx p0 = cmul(HMM(i, 0, 1), HMM(0, j, 2));
+                p0 = cadd(p0, cmul(HMM(i, 1, 1), HMM(1, j, 2)));
+                p0 = cadd(p0, cmul(HMM(i, 2, 1), HMM(2, j, 2)));
+                cplx p1 = cmul(HMM(i, 0, 2), HMM(0, j, 0));
+                p1 = cadd(p1, cmul(HMM(i, 1, 2), HMM(1, j, 0)));
+                p1 = cadd(p1, cmul(HMM(i, 2, 2), HMM(2, j, 0)));
+                cplx p2 = cmul(HMM(i, 0, 0), HMM(0, j, 1));
+                p2 = cadd(p2, cmul(HMM(i, 1, 0), HMM(1, j, 1)));
+                p2 = cadd(p2, cmul(HMM(i, 2, 0), HMM(2, j, 1)));
+                p0 = cmake(p0.re / den0, p0.im / den0);
+                p1 = cmake(p1.re / den1, p1.im / den1);
+                p2 = cmake(p2.re / den2, p2.im / den2);
+                cplx acc = cmul(ph[0], p0);
+                acc = cadd(acc, cmul(ph[1], p1));
+                acc = cadd(acc, cmul(ph[2], p2));
+                A.m[i][j] = acc;
+            }
+#undef HMM
+    } else {
+        cplx lam[3], M[3];
+        eigvals3_general(Hf, lam);
+#pragma unroll
+        for (int k = 0; k < 3; k++) M[k] = cscale(two_e, lam[k]);
+        cplx ph[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            cplx arg = cscale(hbar_c_factor, cscale(L_over_E, cscale(-1.0, M[k])));
+            // arg * 1j = (-arg.im, arg.re); exp
+            double l = exp(-arg.im);
+            double s, c;
+            sincos(arg.re, &s, &c);
+            ph[k] = cmake(l * c, l * s);
+        }
+        cplx den0 = cmul(csub(M[0], M[1]), csub(M[0], M[2]));
+        cplx den1 = cmul(csub(M[1], M[2]), csub(M[1], M[0]));
+        cplx den2 = cmul(csub(M[2], M[0]), csub(M[2], M[1]));
+        cplx Xd[3][3];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int i = 0; i < 3; i++) Xd[k][i] = csub(X.m[i][i], M[k]);
+#define HMM(i_, j_, k_) (((i_) == (j_)) ? Xd[k_][i_] : X.m[i_][j_])
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                cplx p0 = cmul(HMM(i, 0, 1), HMM(0, j, 2));
+                p0 = cadd(p0, cmul(HMM(i, 1, 1), HMM(1, j, 2)));
+                p0 = cadd(p0, cmul(HMM(i, 2, 1), HMM(2, j, 2)));
+                cplx p1 = cmul(HMM(i, 0, 2), HMM(0, j, 0));
+                p1 = cadd(p1, cmul(HMM(i, 1, 2), HMM(1, j, 0)));
+                p1 = cadd(p1, cmul(HMM(i, 2, 2), HMM(2, j, 0)));
+                cplx p2 = cmul(HMM(i, 0, 0), HMM(0, j, 1));
+                p2 = cadd(p2, cmul(HMM(i, 1, 0), HMM(1, j, 1)));
+                p2 = cadd(p2, cmul(HMM(i, 2, 0), HMM(2, j, 1)));
+                p0 = cdiv(p0, den0);
+                p1 = cdiv(p1, den1);
+                p2 = cdiv(p2, den2);
+                cplx acc = cmul(ph[0], p0);
+                acc = cadd(acc, cmul(ph[1], p1));
+                acc = cadd(acc, cmul(ph[2], p2));
+                A.m[i][j] = acc;
+            }
+#undef HMM
+    }
+}
+
+// Layer-matrix cache of the reference (numba_osc_kernels.py:230-249): layer i
+// re-uses the matrix of the LAST earlier layer j with |drho|<1e-5 and
+// |ddist|<1e-5.  Instead of storing up to 120 matrices per thread, the chain of
+// matches is followed to the layer whose matrix was actually computed and that
+// layer's (rho, dist) are returned: A(i) == A(src(i)) bit for bit.
+template <class LayerFn>
+__device__ __forceinline__ void resolve_layer(const LayerFn &layer, int i, double &rho,
+                                              double &dist) {
+    int cur = i;
+    layer(cur, rho, dist);
+    while (true) {
+        int found = -1;
+        for (int j = 0; j < cur; j++) {
+            double rj, dj;
+            layer(j, rj, dj);
+            if (dj > 0.0 && fabs(rj - rho) < 1e-5 && fabs(dj - dist) < 1e-5) found = j;
+        }
+        if (found < 0) break;
+        cur = found;
+        layer(cur, rho, dist);
+    }
+}
+
+// osc_probs_layers_kernel (numba_osc_kernels.py:121-345) for one element.
+// `layer(i, rho, dist)` yields the i-th layer of this element's path.
+// P receives P[init][final] (9 doubles).
+template <bool DECAY, class LayerFn>
+__device__ __forceinline__ void propagate_element(const Prob3Side &S, const double (&dm)[3][3],
+                                                  double energy, int n_layers,
+                                                  const LayerFn &layer, double (&P)[9]) {
+    mat3 T;
+    bool first = true;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) T.m[i][j] = cmake(0.0, 0.0);
+    for (int l = 0; l < n_layers; l++) {
+        double rho, dist;
+        layer(l, rho, dist);
+        if (dist > 0.0) {
+            resolve_layer(layer, l, rho, dist);
+            mat3 A;
+            layer_amplitude<DECAY>(S, dm, energy, rho, dist, A);
+            if (first) {
+                T = A;
+                first = false;
+            } else {
+                mat3 t2;
+                mat_mul(A, T, t2);
+                T = t2;
+            }
+        }
+    }
+    // flavour basis (:326-328) and probabilities (:331-345)
+    mat3 t2, Tf;
+    mat_mul(T, S.Ud, t2);
+    mat_mul(S.U, t2, Tf);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            P[3 * i + j] = Tf.m[j][i].re * Tf.m[j][i].re + Tf.m[j][i].im * Tf.m[j][i].im;
+}
+
+}  // namespace pisa

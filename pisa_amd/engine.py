@@ -1,0 +1,159 @@
+"""Device-resident evaluation engine of the hot path.
+
+One `HotPathEngine` per process / GPU owns the event columns of all containers
+in HBM (uploaded once) and evaluates, per parameter point,
+
+    prob3 on the calc grid (nu + nubar)                 1 launch
+    fused lookup + reweight + histogram(+sumw2)         1 launch (+1 slab reduce)
+    [all-reduce of the integer histogram limbs]         RCCL, only if world_size > 1
+    fixed point -> fp64 maps, LLH / chi2 reduction      2 launches
+
+Per-eval host->device traffic is the kernel-argument blocks only; device->host
+is the 8-byte metric (or the maps on `get_outputs`).
+
+This is what the Stage classes in ``pisa_amd.stages`` drive when a pipeline has
+the shape  loader -> [flux] -> osc.prob3 -> aeff.aeff -> utils.hist
+(pisa/core/pipeline.py:537-558 runs those stages one after another on host
+numpy arrays; here the three apply_functions are one pass over HBM).
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from . import kernels as K
+
+
+class GridSpec:
+    """2-D (true_energy x true_coszen) calc grid.
+
+    Node coordinates are the reference's `weighted_centers`
+    (pisa/core/binning.py:901-911): geometric mean of log-spaced edges
+    (`np.logspace`, binning.py:416-421), midpoints of linear ones; a binned
+    container flattens `meshgrid(indexing='ij')` (container.py:769-773), so the
+    node index is iE*n_cz + jcz when the binning order is (energy, coszen).
+    Lookups use the regularised binning: ln(E) for the log dimension
+    (container.py:992-1005)."""
+
+    def __init__(self, e_range=(1.0, 1000.0), n_e=200, cz_range=(-1.0, 1.0), n_cz=200,
+                 energy_first=True):
+        self.n_e, self.n_cz, self.energy_first = int(n_e), int(n_cz), bool(energy_first)
+        self.e_edges = np.logspace(np.log10(e_range[0]), np.log10(e_range[1]), self.n_e + 1)
+        self.cz_edges = np.linspace(cz_range[0], cz_range[1], self.n_cz + 1)
+        self.energy = np.sqrt(self.e_edges[:-1] * self.e_edges[1:])
+        self.coszen = 0.5 * (self.cz_edges[:-1] + self.cz_edges[1:])
+        ln_dom = np.log(np.array([e_range[0], e_range[1]], dtype=np.float64))
+        if self.energy_first:
+            mins, maxs, nb = [ln_dom[0], cz_range[0]], [ln_dom[1], cz_range[1]], [self.n_e, self.n_cz]
+        else:
+            mins, maxs, nb = [cz_range[0], ln_dom[0]], [cz_range[1], ln_dom[1]], [self.n_cz, self.n_e]
+        self.binning = _lib.make_binning(mins, maxs, nb)
+
+    @property
+    def size(self):
+        return self.n_e * self.n_cz
+
+
+class HotPathEngine:
+    """See module docstring.  `containers` is a list of dicts with keys
+    name, flav, nubar, true_energy, true_coszen, nu_flux[n,2], weighted_aeff,
+    initial_weights, sample (list of D host columns, already regularised),
+    scale."""
+
+    def __init__(self, containers, grid, out_binning, earth, max_layers, rank=0, world_size=1,
+                 group=None):
+        self.dev = K.device()
+        self.grid = grid
+        self.out_binning = out_binning
+        self.n_bins = int(np.prod([out_binning.nbins[k] for k in range(out_binning.ndim)]))
+        self.rank, self.world_size, self.group = rank, world_size, group
+        self.names = [c["name"] for c in containers]
+        self._keep = []  # device tensors referenced by raw pointer
+        self.cont = []
+        self.n_local = 0
+        for c in containers:
+            n = len(c["true_energy"])
+            lo, hi = (rank * n) // world_size, ((rank + 1) * n) // world_size
+            sl = slice(lo, hi)
+            d = _lib.Container()
+            d.n_events = hi - lo
+            self.n_local += hi - lo
+            lnE = self._up(np.log(np.asarray(c["true_energy"], dtype=np.float64)[sl]))
+            cz = self._up(np.asarray(c["true_coszen"], dtype=np.float64)[sl])
+            gx, gy = (lnE, cz) if grid.energy_first else (cz, lnE)
+            d.d_grid_x, d.d_grid_y = gx.data_ptr(), gy.data_ptr()
+            d.d_nu_flux = self._up(np.asarray(c["nu_flux"], dtype=np.float64)[sl]).data_ptr()
+            d.d_weighted_aeff = self._up(np.asarray(c["weighted_aeff"])[sl]).data_ptr()
+            d.d_initial_weights = self._up(np.asarray(c["initial_weights"])[sl]).data_ptr()
+            for k, col in enumerate(c["sample"]):
+                d.d_sample[k] = self._up(np.asarray(col)[sl]).data_ptr()
+            d.flav, d.nubar, d.scale = int(c["flav"]), int(c["nubar"]), float(c["scale"])
+            self.cont.append(d)
+        # Earth layers for the coszen nodes (prob3.setup_function, prob3.py:398-409)
+        self.earth = earth
+        self.energy_d = K.to_device(grid.energy)
+        _, self.dens_d, self.dist_d = K.calc_layers(earth, K.to_device(grid.coszen), max_layers)
+        self.prob_nu = torch.empty((grid.size, 3, 3), dtype=torch.float64, device=self.dev)
+        self.prob_nubar = torch.empty((grid.size, 3, 3), dtype=torch.float64, device=self.dev)
+        self.ws = K.HistWorkspace(len(self.cont), self.n_bins, self.dev)
+        self.metric_out = torch.zeros(1, dtype=torch.float64, device=self.dev)
+        self.metric_status = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.data = None
+
+    def _up(self, a):
+        t = K.to_device(a)
+        self._keep.append(t)
+        return t
+
+    def set_scale(self, name, scale):
+        self.cont[self.names.index(name)].scale = float(scale)
+
+    # -- per-eval steps ----------------------------------------------------
+    def compute_probs(self, params):
+        K.prob3_grid(params, self.energy_d, self.dens_d, self.dist_d, e_major=self.grid.energy_first,
+                     out_nu=self.prob_nu, out_nubar=self.prob_nubar)
+
+    def accumulate(self, params=None):
+        if params is not None:
+            self.compute_probs(params)
+        K.reweight_hist(self.cont, self.grid.binning, self.prob_nu, self.prob_nubar,
+                        self.out_binning, self.ws)
+
+    def allreduce(self):
+        """Integer SUM all-reduce of the histogram limbs over RCCL/xGMI (or gloo in
+        CPU tests): exact, hence independent of ring order and rank count."""
+        if self.world_size > 1:
+            import torch.distributed as dist
+
+            dist.all_reduce(self.ws.limbs, op=dist.ReduceOp.SUM, group=self.group)
+
+    def finalize(self):
+        return K.hist_finalize(self.ws)
+
+    def set_data(self, data_hist):
+        self.data = K.to_device(np.asarray(data_hist, dtype=np.float64).ravel())
+
+    def metric(self, kind="llh"):
+        return K.metric(kind, self.data, self.ws.hist, self.ws.sumw2, total_out=self.metric_out,
+                        status=self.metric_status)
+
+    def eval(self, params, kind="llh"):
+        """One template evaluation + metric; returns a 1-element device tensor."""
+        self.accumulate(params)
+        self.allreduce()
+        self.finalize()
+        if self.data is not None:
+            return self.metric(kind)
+        return None
+
+    def check_status(self):
+        if int(self.ws.status.item()) != 0:
+            self.ws.status.zero_()
+            raise OverflowError("event weight not finite or outside the accumulator range")
+        st = int(self.metric_status.item())
+        if st != 0:
+            self.metric_status.zero_()
+            _lib.check(st)
+
+    def maps(self):
+        """host copies: (hist[n_cont, n_bins], sumw2[...])"""
+        return self.ws.hist.cpu().numpy(), self.ws.sumw2.cpu().numpy()

@@ -1,0 +1,245 @@
+"""Device-tensor front-end of the C ABI.
+
+Arguments are ``torch`` CUDA(=HIP) tensors used purely as device buffers
+(``data_ptr()`` + current stream are handed to ``libpisa_hip.so``); every
+function launches hand-written gfx950 kernels and returns device tensors.
+Function names follow the reference functions they replace.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+F8 = torch.float64
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device tensors must be contiguous CUDA tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def device(index=None):
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "pisa_amd needs a HIP device (MI355X); none is visible and there is no CPU fallback"
+        )
+    return torch.device("cuda", torch.cuda.current_device() if index is None else index)
+
+
+def to_device(a, dtype=np.float64):
+    """Host numpy array -> contiguous device tensor."""
+    arr = np.ascontiguousarray(a, dtype=dtype)
+    return torch.from_numpy(arr).to(device(), non_blocking=False)
+
+
+def _status_buffer():
+    return torch.zeros(1, dtype=torch.int32, device=device())
+
+
+# ---------------------------------------------------------------- prob3
+def propagate_array(params, nubar, energy, densities, distances, out=None):
+    """`propagate_array` gufunc (numba_osc_hostfuncs.py:56-70)."""
+    lib = _lib.lib()
+    n = energy.numel()
+    per_elem = 1 if densities.dim() == 2 else 0
+    n_layers = densities.shape[-1]
+    if out is None:
+        out = torch.empty((n, 3, 3), dtype=F8, device=energy.device)
+    _lib.check(lib.pisa_hip_propagate_array(
+        C.byref(params), int(nubar), _ptr(energy), _ptr(densities), _ptr(distances), n,
+        n_layers, per_elem, _ptr(out), _stream()))
+    return out
+
+
+def prob3_grid(params, energy, densities, distances, e_major=True, out_nu=None, out_nubar=None):
+    """Both 'nu' and 'nubar' linked containers of a 2-D calc grid in one launch
+    (prob3.py:452-459, 581-588)."""
+    lib = _lib.lib()
+    n_e, n_cz, n_layers = energy.numel(), densities.shape[0], densities.shape[1]
+    if out_nu is None:
+        out_nu = torch.empty((n_e * n_cz, 3, 3), dtype=F8, device=energy.device)
+    if out_nubar is None:
+        out_nubar = torch.empty((n_e * n_cz, 3, 3), dtype=F8, device=energy.device)
+    _lib.check(lib.pisa_hip_prob3_grid(
+        C.byref(params), _ptr(energy), n_e, _ptr(densities), _ptr(distances), n_cz, n_layers,
+        1 if e_major else 0, _ptr(out_nu), _ptr(out_nubar), _stream()))
+    return out_nu, out_nubar
+
+
+def calc_layers(earth, coszen, max_layers):
+    """`extCalcLayers` (layers.py:38-169) -> (n_layers, densities, distances)."""
+    lib = _lib.lib()
+    n = coszen.numel()
+    dev = coszen.device
+    n_layers = torch.empty(n, dtype=F8, device=dev)
+    dens = torch.empty((n, max_layers), dtype=F8, device=dev)
+    dist = torch.empty((n, max_layers), dtype=F8, device=dev)
+    st = _status_buffer()
+    _lib.check(lib.pisa_hip_calc_layers(
+        C.byref(earth), _ptr(coszen), n, max_layers, _ptr(n_layers), _ptr(dens), _ptr(dist),
+        _ptr(st), _stream()))
+    if int(st.item()) != 0:
+        # the reference raises a broadcast ValueError here (layers.py:158)
+        raise ValueError("path geometry not representable (detector below the first Earth "
+                         "shell boundary, or coszen exactly tangent to a shell)")
+    return n_layers, dens, dist
+
+
+def prob3_events(params, earth, nubar, energy, coszen, out=None):
+    """Event-by-event prob3 with in-kernel layer reconstruction."""
+    lib = _lib.lib()
+    n = energy.numel()
+    if out is None:
+        out = torch.empty((n, 3, 3), dtype=F8, device=energy.device)
+    st = _status_buffer()
+    _lib.check(lib.pisa_hip_prob3_events(
+        C.byref(params), C.byref(earth), int(nubar), _ptr(energy), _ptr(coszen), n, _ptr(out),
+        _ptr(st), _stream()))
+    if int(st.item()) != 0:
+        raise ValueError("path geometry not representable (see calc_layers)")
+    return out
+
+
+def fill_probs(probability, init_flav, flav, out=None):
+    """`fill_probs` (numba_osc_hostfuncs.py:206-221)."""
+    lib = _lib.lib()
+    n = probability.shape[0]
+    if out is None:
+        out = torch.empty(n, dtype=F8, device=probability.device)
+    _lib.check(lib.pisa_hip_fill_probs(_ptr(probability), int(init_flav), int(flav), n, _ptr(out),
+                                       _stream()))
+    return out
+
+
+# ---------------------------------------------------------- translation
+def _sample_array(sample):
+    arr = (C.c_void_p * len(sample))(*[s.data_ptr() for s in sample])
+    for s in sample:
+        assert s.is_cuda and s.is_contiguous()
+    return arr
+
+
+def lookup_regular(sample, flat_hist, binning):
+    """`lookup` on regular binnings (translation.py:417-501)."""
+    lib = _lib.lib()
+    n = sample[0].numel()
+    width = 1 if flat_hist.dim() == 1 else flat_hist.shape[1]
+    out = torch.empty((n,) if flat_hist.dim() == 1 else (n, width), dtype=F8,
+                      device=flat_hist.device)
+    _lib.check(lib.pisa_hip_lookup_regular(
+        C.byref(binning), _sample_array(sample), n, _ptr(flat_hist), width, _ptr(out), _stream()))
+    return out
+
+
+def histogram_regular(sample, weights, binning, averaged=False):
+    """`histogram` on regular binnings (translation.py:90-129)."""
+    lib = _lib.lib()
+    n = sample[0].numel()
+    n_bins = int(np.prod([binning.nbins[k] for k in range(binning.ndim)]))
+    out = torch.empty(n_bins, dtype=F8, device=sample[0].device)
+    _lib.check(lib.pisa_hip_histogram_regular(
+        C.byref(binning), _sample_array(sample), n, _ptr(weights), 1 if averaged else 0,
+        _ptr(out), _stream()))
+    return out
+
+
+class HistWorkspace:
+    """Scratch + limb buffers for `reweight_hist` (allocated once, reused)."""
+
+    def __init__(self, n_containers, n_bins, dev=None):
+        lib = _lib.lib()
+        dev = dev or device()
+        nbytes = lib.pisa_hip_hist_workspace_bytes(n_containers, n_bins)
+        if nbytes < 0:
+            _lib.check(int(nbytes))
+        self.n_containers, self.n_bins = n_containers, n_bins
+        self.scratch = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
+        self.limbs = torch.zeros((n_containers, n_bins, 2, _lib.ACC_LIMBS), dtype=torch.int64,
+                                 device=dev)
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.hist = torch.empty((n_containers, n_bins), dtype=F8, device=dev)
+        self.sumw2 = torch.empty((n_containers, n_bins), dtype=F8, device=dev)
+
+
+def reweight_hist(containers, calc_grid, prob_nu, prob_nubar, out_binning, ws):
+    """Fused prob3.apply + aeff.apply + hist.apply(sumw2); fills ws.limbs."""
+    lib = _lib.lib()
+    arr = (_lib.Container * len(containers))(*containers)
+    _lib.check(lib.pisa_hip_reweight_hist(
+        arr, len(containers), C.byref(calc_grid), _ptr(prob_nu), _ptr(prob_nubar),
+        C.byref(out_binning), _ptr(ws.limbs), _ptr(ws.scratch), _ptr(ws.status), _stream()))
+    return ws.limbs
+
+
+def hist_finalize(ws):
+    lib = _lib.lib()
+    _lib.check(lib.pisa_hip_hist_finalize(_ptr(ws.limbs), ws.n_containers, ws.n_bins,
+                                          _ptr(ws.hist), _ptr(ws.sumw2), _stream()))
+    return ws.hist, ws.sumw2
+
+
+def apply_osc_weights(nu_flux, prob_e, prob_mu, weights):
+    """prob3.apply_function (prob3.py:621-622), in place on `weights`."""
+    lib = _lib.lib()
+    _lib.check(lib.pisa_hip_apply_osc_weights(_ptr(nu_flux), _ptr(prob_e), _ptr(prob_mu),
+                                              weights.numel(), _ptr(weights), _stream()))
+    return weights
+
+
+def apply_aeff(weighted_aeff, scale, weights):
+    """aeff.apply_function (aeff.py:87), in place on `weights`."""
+    lib = _lib.lib()
+    _lib.check(lib.pisa_hip_apply_aeff(_ptr(weighted_aeff), float(scale), weights.numel(),
+                                       _ptr(weights), _stream()))
+    return weights
+
+
+# --------------------------------------------------------------- metric
+METRIC_KIND = {"llh": 0, "poisson_llh": 1, "chi2": 2, "mod_chi2": 3}
+
+
+def metric(kind, actual, expected, sigma2=None, per_bin=False, total_out=None, status=None):
+    """Map.metric + nansum (map.py:1572-1604) on device.  `expected` (and
+    `sigma2`) may be [n_maps, n_bins]; maps are summed in index order first.
+    Returns a 1-element device tensor (and per-bin values if requested)."""
+    lib = _lib.lib()
+    n_bins = actual.numel()
+    n_maps = 1 if expected.dim() == 1 else expected.shape[0]
+    dev = actual.device
+    if total_out is None:
+        total_out = torch.empty(1, dtype=F8, device=dev)
+    pb = torch.empty(n_bins, dtype=F8, device=dev) if per_bin else None
+    own_status = status is None
+    if own_status:
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(lib.pisa_hip_metric(
+        METRIC_KIND[kind], _ptr(actual), _ptr(expected), _ptr(sigma2), n_maps, n_bins, _ptr(pb),
+        _ptr(total_out), _ptr(status), _stream()))
+    if own_status:
+        st = int(status.item())
+        if st != 0:
+            _lib.check(st)
+    return (total_out, pb) if per_bin else total_out
+
+
+def barr_simple(true_energy, true_coszen, nu_flux_nominal, nubar_flux_nominal, nubar,
+                nue_numu_ratio, nu_nubar_ratio, delta_index, Barr_uphor_ratio,
+                Barr_nu_nubar_ratio, out=None):
+    """`apply_sys_vectorized` (flux/barr_simple.py:207-233)."""
+    lib = _lib.lib()
+    n = true_energy.numel()
+    if out is None:
+        out = torch.empty((n, 2), dtype=F8, device=true_energy.device)
+    _lib.check(lib.pisa_hip_barr_simple(
+        _ptr(true_energy), _ptr(true_coszen), _ptr(nu_flux_nominal), _ptr(nubar_flux_nominal),
+        int(nubar), float(nue_numu_ratio), float(nu_nubar_ratio), float(delta_index),
+        float(Barr_uphor_ratio), float(Barr_nu_nubar_ratio), n, _ptr(out), _stream()))
+    return out

@@ -1,0 +1,114 @@
+"""Vacuum oscillation parameters -> PMNS and mass-splitting matrices.
+
+Host-side counterpart of pisa/stages/osc/osc_params.py (OscParams): same
+attribute names and conventions (angles are stored as sin(theta), cos comes
+from sqrt(1 - s^2), osc_params.py:178-184), so results are bit identical; the
+matrices are 72+144 bytes and are rebuilt per parameter point on the host,
+then travel in the kernel-argument block of the prob3 kernels.
+"""
+import numpy as np
+
+from pisa_amd import CTYPE, FTYPE
+
+__all__ = ["OscParams"]
+
+
+class OscParams:
+    def __init__(self):
+        self._s = {"12": 0.0, "13": 0.0, "23": 0.0, "14": 0.0}
+        self._deltacp = 0.0
+        self.dm21 = 0.0
+        self.dm31 = 0.0
+        self.dm41 = 0.0
+
+    # sinXY / thetaXY pairs (osc_params.py:86-152)
+    def _get_sin(self, ij):
+        return self._s[ij]
+
+    def _set_sin(self, ij, value):
+        assert abs(value) <= 1
+        self._s[ij] = value
+
+    sin12 = property(lambda self: self._get_sin("12"), lambda self, v: self._set_sin("12", v))
+    sin13 = property(lambda self: self._get_sin("13"), lambda self, v: self._set_sin("13", v))
+    sin23 = property(lambda self: self._get_sin("23"), lambda self, v: self._set_sin("23", v))
+    sin14 = property(lambda self: self._get_sin("14"), lambda self, v: self._set_sin("14", v))
+    theta12 = property(lambda self: np.arcsin(self.sin12),
+                       lambda self, v: self._set_sin("12", np.sin(v)))
+    theta13 = property(lambda self: np.arcsin(self.sin13),
+                       lambda self, v: self._set_sin("13", np.sin(v)))
+    theta23 = property(lambda self: np.arcsin(self.sin23),
+                       lambda self, v: self._set_sin("23", np.sin(v)))
+    theta14 = property(lambda self: np.arcsin(self.sin14),
+                       lambda self, v: self._set_sin("14", np.sin(v)))
+
+    @property
+    def deltacp(self):
+        return self._deltacp
+
+    @deltacp.setter
+    def deltacp(self, value):
+        assert 0.0 <= value <= 2 * np.pi  # osc_params.py:167
+        self._deltacp = value
+
+    def _trig(self):
+        s12, s13, s23 = self.sin12, self.sin13, self.sin23
+        return (s12, s13, s23, np.sqrt(1.0 - s12 ** 2), np.sqrt(1.0 - s13 ** 2),
+                np.sqrt(1.0 - s23 ** 2), np.sin(self.deltacp), np.cos(self.deltacp))
+
+    @property
+    def mix_matrix_complex(self):
+        """PDG parameterisation (osc_params.py:174-211)."""
+        s12, s13, s23, c12, c13, c23, sd, cd = self._trig()
+        re = np.array([
+            [c12 * c13, s12 * c13, s13 * cd],
+            [-s12 * c23 - c12 * s23 * s13 * cd, c12 * c23 - s12 * s23 * s13 * cd, s23 * c13],
+            [s12 * s23 - c12 * c23 * s13 * cd, -c12 * s23 - s12 * c23 * s13 * cd, c23 * c13],
+        ], dtype=FTYPE)
+        im = np.array([
+            [0.0, 0.0, -s13 * sd],
+            [-c12 * s23 * s13 * sd, -s12 * s23 * s13 * sd, 0.0],
+            [-c12 * c23 * s13 * sd, -s12 * c23 * s13 * sd, 0.0],
+        ], dtype=FTYPE)
+        return re + im * 1.0j
+
+    @property
+    def mix_matrix(self):
+        m = self.mix_matrix_complex
+        return np.stack([m.real, m.imag], axis=2)
+
+    @property
+    def mix_matrix_reparam_complex(self):
+        """diag(e^{i delta},1,1) U diag(e^{-i delta},1,1) (osc_params.py:213-258)."""
+        s12, s13, s23, c12, c13, c23, sd, cd = self._trig()
+        re = np.array([
+            [c12 * c13, s12 * c13 * cd, s13],
+            [-s12 * c23 * cd - c12 * s23 * s13, c12 * c23 - s12 * s23 * s13 * cd, s23 * c13],
+            [s12 * s23 * cd - c12 * c23 * s13, -c12 * s23 - s12 * c23 * s13 * cd, c23 * c13],
+        ], dtype=FTYPE)
+        im = np.array([
+            [0.0, s12 * c13 * sd, 0.0],
+            [s12 * c23 * sd, -s12 * s23 * s13 * sd, 0.0],
+            [-s12 * s23 * sd, -s12 * c23 * s13 * sd, 0.0],
+        ], dtype=FTYPE)
+        return re + im * 1.0j
+
+    @property
+    def mix_matrix_reparam(self):
+        m = self.mix_matrix_reparam_complex
+        return np.stack([m.real, m.imag], axis=2)
+
+    @property
+    def dm_matrix(self):
+        """dm[i, j] = m_i - m_j with the degeneracy nudges of osc_params.py:265-292."""
+        m = np.array([0.0, self.dm21, self.dm31], dtype=FTYPE)
+        delta = 5.0e-9
+        if m[1] == 0.0:
+            m[0] -= delta
+        if m[2] == 0.0:
+            m[2] += delta
+        dm = np.zeros((3, 3), dtype=FTYPE)
+        for i, j in ((0, 1), (0, 2), (1, 2)):
+            dm[i, j] = m[i] - m[j]
+            dm[j, i] = -dm[i, j]
+        return dm

@@ -1,0 +1,337 @@
+"""Parity tests proper: every HIP kernel, called through the C ABI
+(pisa_amd._lib / pisa_amd.kernels), against the CPU oracle and the committed
+golden fixtures.  Needs a real MI355X:  pytest -m gpu.
+
+Tolerances
+  prob3 probabilities : rtol 1e-10, atol 1e-14  (the reference's own AC_KW,
+                        numba_osc_tests.py:82; device sincos/atan2 differ from
+                        glibc by <= 2 ulp so bit equality is not attainable)
+  layers, lookups, bin indices, histogram limbs: bit exact
+  histogram sums / maps: rtol 1e-12 (oracle sums sequentially in fp64, the
+                        device sums exactly and rounds once)
+  LLH / chi2 totals   : rtol 1e-10 (north star)
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.conftest import PROB3_ATOL, PROB3_RTOL, load_golden
+
+pytestmark = pytest.mark.gpu
+AC = dict(rtol=PROB3_RTOL, atol=PROB3_ATOL)
+
+
+@pytest.fixture(scope="module")
+def K():
+    import torch
+
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    from pisa_amd import kernels
+
+    return kernels
+
+
+@pytest.fixture(scope="module")
+def L():
+    from pisa_amd import _lib
+
+    return _lib
+
+
+def _args(g, case):
+    return {k.split("::")[1]: g[k] for k in g.files if k.startswith(case + "::")}
+
+
+def _cases(g, func):
+    return sorted({k.split("::")[0] for k in g.files if k.startswith(func + "__")})
+
+
+# ------------------------------------------------------------------ prob3
+def test_propagate_array_reference_goldens(K, L):
+    g = load_golden("prob3_ref_goldens.npz")
+    cases = _cases(g, "propagate_scalar")
+    assert len(cases) == 13
+    for c in cases:
+        a = _args(g, c)
+        p = L.make_prob3_params(a["dm"], a["mix"], a["mat_pot"], int(a["decay_flag"]),
+                                a["mat_decay"], a["lri_pot"])
+        out = K.propagate_array(
+            p, int(a["nubar"]), K.to_device([float(a["energy"])]), K.to_device(a["densities"]),
+            K.to_device(a["distances"])).cpu().numpy()[0]
+        np.testing.assert_allclose(out, a["probability"], err_msg=c, **AC)
+
+
+def test_propagate_array_host_entry_point(L):
+    """the numpy-in/numpy-out call a reference-side binding would use"""
+    g = load_golden("prob3_ref_goldens.npz")
+    a = _args(g, "propagate_scalar__nufit32_no")
+    p = L.make_prob3_params(a["dm"], a["mix"], a["mat_pot"], -1, a["mat_decay"], a["lri_pot"])
+    n = 37
+    e = np.full(n, float(a["energy"]))
+    out = np.full((n, 3, 3), np.nan)
+    rho, dist = np.ascontiguousarray(a["densities"]), np.ascontiguousarray(a["distances"])
+    L.check(L.lib().pisa_hip_propagate_array_host(
+        C.byref(p), 1, e.ctypes.data, rho.ctypes.data, dist.ctypes.data, n, len(rho), 0,
+        out.ctypes.data))
+    assert np.all(out == out[0])  # broadcast test of numba_osc_tests.py:266-312
+    np.testing.assert_allclose(out[0], a["probability"], **AC)
+    # too many layers -> error status, as the hard 120 cap of the reference
+    with pytest.raises(L.PisaHipError):
+        L.check(L.lib().pisa_hip_propagate_array_host(
+            C.byref(p), 1, e.ctypes.data, rho.ctypes.data, dist.ctypes.data, n, 121, 0,
+            out.ctypes.data))
+
+
+def test_prob3_grid_golden_and_oracle(K, L, oracle):
+    g = load_golden("prob3_grid_prem12.npz")
+    e, dens, dist = g["energy"], g["densities"], g["distances"]
+    n_e, n_cz = len(e), dens.shape[0]
+    for name in ("no", "io", "nsi", "decay"):
+        p = L.make_prob3_params(g[name + "::dm"], g[name + "::mix"], g[name + "::mat_pot"],
+                                int(g[name + "::decay_flag"]), g[name + "::mat_decay"],
+                                g[name + "::lri_pot"])
+        for e_major in (True, False):
+            nu, nubar = K.prob3_grid(p, K.to_device(e), K.to_device(dens), K.to_device(dist),
+                                     e_major=e_major)
+            nu, nubar = nu.cpu().numpy(), nubar.cpu().numpy()
+            if e_major:
+                nu, nubar = nu.reshape(n_e, n_cz, 3, 3), nubar.reshape(n_e, n_cz, 3, 3)
+            else:
+                nu = nu.reshape(n_cz, n_e, 3, 3).transpose(1, 0, 2, 3)
+                nubar = nubar.reshape(n_cz, n_e, 3, 3).transpose(1, 0, 2, 3)
+            np.testing.assert_allclose(nu, g[name + "::prob_nu"], err_msg=name, **AC)
+            np.testing.assert_allclose(nubar, g[name + "::prob_nubar"], err_msg=name, **AC)
+
+
+def test_prob3_random_vs_oracle(K, L, oracle):
+    """seeded random parameters / paths incl. zero-length layers and cache hits"""
+    rs = np.random.RandomState(123)
+    g = load_golden("prob3_grid_prem12.npz")
+    n, nl = 2000, 12
+    e = 10 ** (rs.rand(n) * 4 - 1)
+    rho = rs.rand(n, nl) * 6
+    dist = rs.rand(n, nl) * 800
+    dist[rs.rand(n, nl) < 0.2] = 0.0
+    rho[:, 7] = rho[:, 2]; dist[:, 7] = dist[:, 2] + 1e-9  # cache hit (numba_osc_kernels.py:236-241)
+    rho[:, 9] = rho[:, 7]; dist[:, 9] = dist[:, 7]          # chained cache hit
+    for name in ("io", "nsi", "decay"):
+        pa = [g[name + "::dm"], g[name + "::mix"], g[name + "::mat_pot"],
+              int(g[name + "::decay_flag"]), g[name + "::mat_decay"], g[name + "::lri_pot"]]
+        p = L.make_prob3_params(*pa)
+        for nubar in (1, -1):
+            ref = oracle.propagate_array(*pa, nubar, e, rho, dist)
+            out = K.propagate_array(p, nubar, K.to_device(e), K.to_device(rho),
+                                    K.to_device(dist)).cpu().numpy()
+            np.testing.assert_allclose(out, ref, err_msg="%s %d" % (name, nubar), **AC)
+
+
+def test_prob3_empty_and_ragged(K, L):
+    g = load_golden("prob3_grid_prem12.npz")
+    p = L.make_prob3_params(g["no::dm"], g["no::mix"], g["no::mat_pot"], -1, g["no::mat_decay"],
+                            g["no::lri_pot"])
+    import torch
+
+    empty = torch.empty(0, dtype=torch.float64, device="cuda")
+    out = K.propagate_array(p, 1, empty, K.to_device(np.zeros((0, 4))), K.to_device(np.zeros((0, 4))))
+    assert out.shape == (0, 3, 3)
+    # n not a multiple of the workgroup size
+    e = np.linspace(1, 50, 257)
+    out = K.propagate_array(p, 1, K.to_device(e), K.to_device(g["densities"][3]),
+                            K.to_device(g["distances"][3])).cpu().numpy()
+    assert out.shape == (257, 3, 3) and np.all(np.isfinite(out))
+    np.testing.assert_allclose(out.sum(axis=2), 1.0, rtol=1e-9)
+
+
+# ----------------------------------------------------------------- layers
+@pytest.mark.parametrize("tag", ["prem4", "prem4b", "prem12", "prem59", "prem10"])
+def test_calc_layers_bit_exact(K, L, oracle, tag):
+    g = load_golden("layers_ref.npz")
+    earth = L.make_earth(g[tag + "::radii"], g[tag + "::rhos"], g[tag + "::coszen_limit"],
+                         g[tag + "::prem"][-1, 0] - g[tag + "::args"][0])
+    max_layers = 2 * len(g[tag + "::radii"])
+    nl, dens, dist = K.calc_layers(earth, K.to_device(g[tag + "::cz"]), max_layers)
+    np.testing.assert_array_equal(nl.cpu().numpy(), g[tag + "::n_layers"])
+    np.testing.assert_array_equal(dens.cpu().numpy(), g[tag + "::density"])
+    np.testing.assert_array_equal(dist.cpu().numpy(), g[tag + "::distance"])
+
+
+def test_prob3_events_vs_oracle(K, L, oracle):
+    """event mode: in-kernel layers == oracle layers + oracle propagate"""
+    gl = load_golden("layers_ref.npz")
+    gg = load_golden("prob3_grid_prem12.npz")
+    rs = np.random.RandomState(5)
+    n = 3000
+    e = 10 ** (rs.rand(n) * 3)
+    cz = rs.rand(n) * 2 - 1
+    for tag in ("prem12", "prem4"):
+        depth, height, yi, yo, ym = gl[tag + "::args"]
+        lay = oracle.Layers(gl[tag + "::prem"], depth, height)
+        lay.setElecFrac(yi, yo, ym)
+        lay.calcLayers(cz)
+        earth = L.make_earth(lay.radii, lay.rhos, lay.coszen_limit, lay.r_detector)
+        for name in ("no", "nsi"):
+            pa = [gg[name + "::dm"], gg[name + "::mix"], gg[name + "::mat_pot"],
+                  int(gg[name + "::decay_flag"]), gg[name + "::mat_decay"], gg[name + "::lri_pot"]]
+            p = L.make_prob3_params(*pa)
+            for nubar in (1, -1):
+                ref = oracle.propagate_array(*pa, nubar, e, lay.density, lay.distance)
+                out = K.prob3_events(p, earth, nubar, K.to_device(e), K.to_device(cz)).cpu().numpy()
+                np.testing.assert_allclose(out, ref, err_msg="%s %s %d" % (tag, name, nubar), **AC)
+
+
+# ------------------------------------------------------------ translation
+def test_lookup_golden(K, L):
+    g = load_golden("lookup_ref.npz")
+    x, y, z = (K.to_device(g[k]) for k in "xyz")
+    out = K.lookup_regular([x], K.to_device(g["h1"]), L.make_binning([0.0], [1.0], [7]))
+    np.testing.assert_array_equal(out.cpu().numpy(), g["o1"])
+    b2 = L.make_binning([0.0, -1.0], [1.0, 1.0], [7, 5])
+    out = K.lookup_regular([x, y], K.to_device(g["h2"]), b2)
+    np.testing.assert_array_equal(out.cpu().numpy(), g["o2"])
+    out = K.lookup_regular([x, y, z], K.to_device(g["h3"]),
+                           L.make_binning([0.0, -1.0, 0.0], [1.0, 1.0, 2.0], [7, 5, 3]))
+    np.testing.assert_array_equal(out.cpu().numpy(), g["o3"])
+    out = K.lookup_regular([x, y], K.to_device(g["h2a"]), b2)
+    np.testing.assert_array_equal(out.cpu().numpy(), g["o2a"])
+
+
+def test_histogram_golden_recipe(K, L):
+    """translation.py:779-818: == np.histogramdd, summed and averaged"""
+    g = load_golden("hist_ref.npz")
+    nbs = [2, 3, 4]
+    sample = []
+    w = K.to_device(g["weights"])
+    for nd in (1, 2, 3):
+        sample.append(K.to_device(g["s%d" % (nd - 1)]))
+        b = L.make_binning([0.0] * nd, [float(v) for v in nbs[:nd]], nbs[:nd])
+        h = K.histogram_regular(sample, w, b).cpu().numpy()
+        np.testing.assert_allclose(h, g["ref%dd" % nd], rtol=1e-13)
+        c = K.histogram_regular(sample, None, b).cpu().numpy()
+        np.testing.assert_array_equal(c, g["cnt%dd" % nd])
+        avg = K.histogram_regular(sample, w, b, averaged=True).cpu().numpy()
+        np.testing.assert_allclose(avg, g["ref%dd" % nd] / g["cnt%dd" % nd], rtol=1e-13)
+
+
+def test_histogram_edges_empty_negative_and_large(K, L, oracle):
+    x = np.array([0.0, 1.0, np.nextafter(1.0, 0), -1e-300, np.nan, 0.5, np.inf])
+    b = L.make_binning([0.0], [1.0], [4])
+    np.testing.assert_array_equal(K.histogram_regular([K.to_device(x)], None, b).cpu().numpy(),
+                                  [1, 0, 1, 1])
+    import torch
+
+    e = torch.empty(0, dtype=torch.float64, device="cuda")
+    np.testing.assert_array_equal(K.histogram_regular([e], e, b).cpu().numpy(), [0, 0, 0, 0])
+    # empty bins average to 0 (NaN -> 0, translation.py:125-127)
+    avg = K.histogram_regular([K.to_device([0.1])], K.to_device([2.0]), b, averaged=True)
+    np.testing.assert_array_equal(avg.cpu().numpy(), [2.0, 0, 0, 0])
+    # signed weights spanning 40 orders of magnitude: exact accumulation
+    rs = np.random.RandomState(9)
+    n = 200000
+    xs = rs.rand(n)
+    w = rs.randn(n) * 10 ** (rs.rand(n) * 40 - 30)
+    h = K.histogram_regular([K.to_device(xs)], K.to_device(w), b).cpu().numpy()
+    import math
+
+    idx = np.minimum((xs * 4).astype(int), 3)
+    exact = np.array([math.fsum(w[idx == k]) for k in range(4)])
+    np.testing.assert_allclose(h, exact, rtol=1e-15, atol=1e-34)
+    # many bins -> global-accumulator path (no LDS privatisation)
+    nb = [200, 200]
+    b2 = L.make_binning([0.0, 0.0], [1.0, 1.0], nb)
+    ys = rs.rand(n)
+    ww = rs.rand(n)
+    h2 = K.histogram_regular([K.to_device(xs), K.to_device(ys)], K.to_device(ww), b2).cpu().numpy()
+    ref = oracle.histogram_regular([xs, ys], ww, [0.0, 0.0], [1.0, 1.0], nb)
+    np.testing.assert_allclose(h2, ref, rtol=1e-13)
+    # non-finite weight is an error, not a silent NaN bin
+    with pytest.raises(OverflowError):
+        K.histogram_regular([K.to_device([0.1])], K.to_device([np.inf]), b)
+
+
+# ------------------------------------------- fused reweight + hist + metric
+def test_fused_reweight_hist_vs_oracle(K, L, oracle):
+    from pisa_amd import synthetic
+
+    wl = synthetic.Workload(n_events=120000, grid=(40, 20), out_binning="dragon", seed=3)
+    st = synthetic.DeviceState(wl)
+    st.eval(wl.osc_params(theta23_deg=44.0, dm31=2.5e-3))
+    hist = st.ws.hist.cpu().numpy()
+    sumw2 = st.ws.sumw2.cpu().numpy()
+    from oracle.pipeline_oracle import oracle_eval
+
+    ref = oracle_eval(wl)
+    np.testing.assert_allclose(hist, ref["hist"], rtol=1e-12, atol=1e-300)
+    np.testing.assert_allclose(sumw2, ref["sumw2"], rtol=1e-12, atol=1e-300)
+    # probability tables feeding the fused kernel
+    np.testing.assert_allclose(st.prob_nu.cpu().numpy(), ref["prob_nu"], **AC)
+    np.testing.assert_allclose(st.prob_nubar.cpu().numpy(), ref["prob_nubar"], **AC)
+    # LLH / mod_chi2 against pseudo-data
+    data = np.random.RandomState(0).poisson(ref["hist"].sum(axis=0)).astype(float)
+    for kind in ("llh", "mod_chi2", "poisson_llh", "chi2"):
+        got = float(K.metric(kind, K.to_device(data), st.ws.hist, st.ws.sumw2).item())
+        _, want = oracle.metric(kind, data, ref["hist"].sum(axis=0), ref["sumw2"].sum(axis=0))
+        np.testing.assert_allclose(got, want, rtol=1e-10, err_msg=kind)
+
+
+def test_fused_bit_reproducible_and_shardable(K, L):
+    """run-to-run identical; event shards summed as integers == unsharded
+    (this is what makes the LLH independent of the GPU count)"""
+    from pisa_amd import synthetic
+
+    wl = synthetic.Workload(n_events=60000, grid=(20, 10), out_binning="dragon", seed=1)
+    p = wl.osc_params()
+    full = synthetic.DeviceState(wl)
+    full.make_pseudo_data(p)
+    full.eval(p)
+    l1 = full.ws.limbs.clone()
+    h1 = full.ws.hist.clone()
+    full.eval(p)
+    assert bool((full.ws.limbs == l1).all())
+    total = None
+    for rank in range(3):
+        sh = synthetic.DeviceState(wl, rank=rank, world_size=3)
+        sh.accumulate(p)
+        total = sh.ws.limbs.clone() if total is None else total + sh.ws.limbs
+    sh.ws.limbs.copy_(total)
+    K.hist_finalize(sh.ws)
+    assert bool((sh.ws.hist == h1).all())  # bit identical maps
+    llh_a = K.metric("llh", full.data, full.ws.hist, full.ws.sumw2)
+    llh_b = K.metric("llh", full.data, sh.ws.hist, sh.ws.sumw2)
+    assert float(llh_a.item()) == float(llh_b.item())
+
+
+def test_unfused_stage_kernels(K, oracle):
+    rs = np.random.RandomState(2)
+    n = 10001
+    w0, flux, pe, pmu, aeff = rs.rand(n), rs.rand(n, 2), rs.rand(n), rs.rand(n), rs.rand(n)
+    w = K.to_device(w0)
+    K.apply_osc_weights(K.to_device(flux), K.to_device(pe), K.to_device(pmu), w)
+    K.apply_aeff(K.to_device(aeff), 3.25, w)
+    np.testing.assert_array_equal(w.cpu().numpy(), oracle.reweight(w0, flux, pe, pmu, aeff, 3.25))
+    P = rs.rand(n, 3, 3)
+    np.testing.assert_array_equal(K.fill_probs(K.to_device(P), 1, 2).cpu().numpy(), P[:, 1, 2])
+
+
+def test_metric_golden_and_errors(K):
+    g = load_golden("stats_ref.npz")
+    a, e = K.to_device(g["actual"]), K.to_device(g["expected"])
+    for name in ("llh", "poisson_llh", "chi2", "mod_chi2"):
+        total, pb = K.metric(name, a, e, per_bin=True)
+        np.testing.assert_allclose(pb.cpu().numpy(), g[name], rtol=1e-12, equal_nan=True)
+        np.testing.assert_allclose(float(total.item()), float(g[name + "_total"]), rtol=1e-12)
+    with pytest.raises(ValueError):
+        K.metric("llh", K.to_device([-1.0, 2.0]), K.to_device([1.0, 2.0]))
+    # chi2 returns exactly 0 when all |delta| < 5 eps (stats.py:160-161)
+    t = K.metric("chi2", K.to_device([1.0, 2.0]), K.to_device([1.0, 2.0]))
+    assert float(t.item()) == 0.0
+
+
+def test_barr_flux_golden(K):
+    g = load_golden("barr_ref.npz")
+    args = [K.to_device(g[k]) for k in ("true_energy", "true_coszen", "nu_flux_nominal",
+                                        "nubar_flux_nominal")]
+    for ip, ps in enumerate(g["params"]):
+        for nubar, tag in ((1, "nu"), (-1, "nubar")):
+            out = K.barr_simple(*args, nubar, *ps).cpu().numpy()
+            np.testing.assert_allclose(out, g["out%d_%s" % (ip, tag)], rtol=1e-12, atol=1e-300)
