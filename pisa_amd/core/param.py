@@ -1,0 +1,445 @@
+"""Parameters: `Prior`, `Param`, `ParamSet`, `ParamSelector`.
+
+Host-side counterparts of pisa/core/param.py and pisa/core/prior.py with the
+semantics the evaluation loop relies on:
+
+* `ParamSet.values_hash` drives the per-stage compute memo (stage.py:536-557).
+  The reference md5-hashes 12-significant-figure-normalised pint quantities
+  (param.py:1560-1565, ~ms per stage); here it is a tuple of the current
+  magnitudes in the parameter's own units rounded the same way -- cheap and
+  with the same equality classes.
+* `_rescaled_value` maps values to [0,1] over `range` for minimisers
+  (param.py:358-400); `randomize_free` draws uniform [0,1] per free param
+  (param.py:1433-1449).
+* `priors_penalty(metric)` = sum of prior llh (or chi2 = -2 llh) values
+  (param.py:1372-1396, prior.py:204-253).
+"""
+from collections import OrderedDict
+from collections.abc import Iterable, Mapping, Sequence
+
+import numpy as np
+
+from pisa_amd.core.units import Quantity, ureg
+
+__all__ = ["Prior", "Param", "ParamSet", "ParamSelector"]
+
+HASH_SIGFIGS = 12  # pisa/__init__.py:277
+FTYPE_PREC = np.finfo(np.float64).eps
+
+LLH_METRICS = ("llh", "poisson_llh", "conv_llh", "barlow_llh", "mcllh_mean", "mcllh_eff",
+               "generalized_poisson_llh")
+CHI2_METRICS = ("chi2", "mod_chi2", "correct_chi2", "weighted_chi2", "signed_sqrt_mod_chi2")
+
+
+def _as_quantity(v):
+    if isinstance(v, Quantity) or v is None or isinstance(v, (bool, str)):
+        return v
+    return Quantity(v)
+
+
+class Prior:
+    """uniform / gaussian / jeffreys priors (prior.py:189-262). `llh(x)` returns the
+    log-prior (up to a constant); chi2 = -2 llh (prior.py:395-400)."""
+
+    def __init__(self, kind, **kwargs):
+        self.kind = None if kind is None else str(kind).lower()
+        if self.kind in (None, "none", "uniform"):
+            self.kind = "uniform"
+            self.llh_offset = kwargs.get("llh_offset", 0.0)
+            self.units = None
+        elif self.kind == "gaussian":
+            self.mean = _as_quantity(kwargs["mean"])
+            self.stddev = _as_quantity(kwargs["stddev"]).to(self.mean.units)
+            self.units = self.mean.units
+        elif self.kind == "jeffreys":
+            self.A = _as_quantity(kwargs["A"])
+            self.B = _as_quantity(kwargs["B"]).to(self.A.units)
+            self.units = self.A.units
+        else:
+            raise ValueError("prior kind '%s' not supported by this build (uniform, gaussian, "
+                             "jeffreys)" % kind)
+
+    def _strip(self, x):
+        x = _as_quantity(x)
+        return x.m_as(self.units) if self.units is not None else x.magnitude
+
+    def llh(self, x):
+        if self.kind == "uniform":
+            return 0.0 * _as_quantity(x).magnitude + self.llh_offset
+        v = self._strip(x)
+        if self.kind == "gaussian":
+            m, s = self.mean.magnitude, self.stddev.magnitude
+            return -(v - m) ** 2 / (2 * s ** 2)
+        a, b = self.A.magnitude, self.B.magnitude
+        return -np.log(v) + np.log(np.log(b) - np.log(a))
+
+    def chi2(self, x):
+        return -2 * self.llh(x)
+
+    def __repr__(self):
+        if self.kind == "gaussian":
+            return "Prior(gaussian, mean=%s, stddev=%s)" % (self.mean, self.stddev)
+        return "Prior(%s)" % self.kind
+
+
+class Param:
+    """One named quantity with prior, range and fixed flag (param.py:60-330)."""
+
+    def __init__(self, name, value, prior=None, range=None, is_fixed=True, unique_id=None,
+                 is_discrete=False, nominal_value=None, tex=None, help="", scales_as_log=False):
+        self.name = name
+        self.unique_id = unique_id if unique_id is not None else name
+        self._tex = tex
+        self.help = help
+        self.is_fixed = bool(is_fixed)
+        self.is_discrete = bool(is_discrete)
+        self.scales_as_log = bool(scales_as_log)
+        self._value = _as_quantity(value)
+        self._units = self._value.units if isinstance(self._value, Quantity) else None
+        self.prior = prior if (prior is None or isinstance(prior, Prior)) else Prior(**prior)
+        self._range = None
+        self.range = range
+        self._nominal_value = self._value if nominal_value is None else _as_quantity(nominal_value)
+
+    # -- value -----------------------------------------------------------
+    @property
+    def value(self):
+        return self._value
+
+    @value.setter
+    def value(self, val):
+        val = _as_quantity(val)
+        if isinstance(self._value, Quantity):
+            if not isinstance(val, Quantity):
+                raise TypeError("value must be a quantity")
+            if val.units.dims != self._units.dims:
+                raise ValueError('Value "%s" units incompatible with units "%s".' % (val, self._units))
+            val = val.to(self._units)
+        self.validate_value(val)
+        self._value = val
+
+    def validate_value(self, val):
+        if self._range is not None and isinstance(val, Quantity):
+            lo, hi = self._range[0].m_as(self._units), self._range[1].m_as(self._units)
+            v = val.m_as(self._units)
+            if v < min(lo, hi) or v > max(lo, hi):
+                raise ValueError("Param %s has a value %s which is not in the range of %s"
+                                 % (self.name, val, self._range))
+
+    m = property(lambda self: self._value.magnitude)
+    magnitude = m
+    units = property(lambda self: self._units)
+    u = units
+    dimensionality = property(lambda self: self._value.dimensionality)
+
+    def m_as(self, u):
+        return self._value.m_as(u)
+
+    @property
+    def range(self):
+        return self._range
+
+    @range.setter
+    def range(self, rng):
+        if rng is None:
+            self._range = None
+            return
+        if isinstance(rng, Quantity):
+            rng = [rng[0], rng[1]]
+        rng = [_as_quantity(v) for v in rng]
+        assert len(rng) == 2
+        self._range = [v.to(self._units) if isinstance(self._value, Quantity) else v for v in rng]
+
+    @property
+    def nominal_value(self):
+        return self._nominal_value
+
+    @nominal_value.setter
+    def nominal_value(self, v):
+        self._nominal_value = _as_quantity(v)
+
+    @property
+    def tex(self):
+        return r"{\rm %s}" % self.name.replace("_", r"\;") if self._tex is None else self._tex
+
+    def reset(self):
+        self._value = self._nominal_value
+
+    def set_nominal_to_current_value(self):
+        self._nominal_value = self._value
+
+    def randomize(self, random_state=None):
+        rs = random_state if isinstance(random_state, np.random.RandomState) \
+            else np.random.RandomState(random_state)
+        self._rescaled_value = rs.rand()
+
+    # -- [0,1] rescaling for minimisers (param.py:358-400) -----------------
+    @property
+    def _rescaled_value(self):
+        if self.is_discrete:
+            return self.value
+        if self._range is None:
+            raise ValueError("Cannot rescale without a range specified for parameter %s" % self.name)
+        r0, r1 = self._range[0].m_as(self._units), self._range[1].m_as(self._units)
+        v = self._value.m_as(self._units)
+        if self.scales_as_log:
+            if r0 < 0:
+                r0, r1, v = -r0, -r1, -v
+            return (np.log(v) - np.log(r0)) / (np.log(r1) - np.log(r0))
+        return (v - r0) / (r1 - r0)
+
+    @_rescaled_value.setter
+    def _rescaled_value(self, rval):
+        if self._range is None:
+            raise ValueError("Cannot rescale without a range specified for parameter %s" % self.name)
+        if rval < 0 or rval > 1 + FTYPE_PREC:
+            raise ValueError("%s: `rval`=%.15e, but cannot be outside [0, 1]" % (self.name, rval))
+        rval = np.min([1.0, rval])
+        r0, r1 = self._range[0].m_as(self._units), self._range[1].m_as(self._units)
+        if self.scales_as_log:
+            v = np.exp(rval * (np.log(np.abs(r1)) - np.log(np.abs(r0)))) * r0
+        else:
+            v = r0 + (r1 - r0) * rval
+        v = min(max(v, min(r0, r1)), max(r0, r1))
+        self._value = Quantity(v, self._units)
+
+    def prior_penalty(self, metric):
+        metric = metric.strip().lower()
+        if self.prior is None:
+            return 0
+        if metric in LLH_METRICS:
+            return self.prior.llh(self._value)
+        if metric in CHI2_METRICS:
+            return self.prior.chi2(self._value)
+        raise ValueError('Metric "%s" is invalid' % metric)
+
+    def _hashable(self):
+        v = self._value
+        if isinstance(v, Quantity):
+            m = v.magnitude
+            if np.isscalar(m) and isinstance(m, (float, np.floating)) and m != 0 and np.isfinite(m):
+                # normQuant: round to HASH_SIGFIGS significant figures (utils/comparisons.py)
+                m = float("%.*e" % (HASH_SIGFIGS - 1, m))
+            elif not np.isscalar(m):
+                m = tuple(np.ravel(m).tolist())
+            return (m, v.units.scale, v.units.dims)
+        return v
+
+    def __repr__(self):
+        return "Param(%s=%s, fixed=%s, range=%s, prior=%s)" % (self.name, self._value,
+                                                               self.is_fixed, self._range, self.prior)
+
+
+class ParamSet(Sequence):
+    """Ordered set of `Param`s with name access (param.py:776-1600)."""
+
+    def __init__(self, *args):
+        params = []
+        for a in args:
+            if a is None:
+                continue
+            if isinstance(a, Param):
+                params.append(a)
+            elif isinstance(a, (ParamSet, Sequence, Iterable)) and not isinstance(a, Mapping):
+                params.extend(list(a))
+            elif isinstance(a, Mapping):
+                params.append(Param(**a))
+        names = [p.name for p in params]
+        if len(set(names)) != len(names):
+            raise ValueError("duplicate parameter names: %s" % sorted(n for n in names if names.count(n) > 1))
+        object.__setattr__(self, "_params", params)
+        object.__setattr__(self, "normalize_values", True)
+
+    # sequence protocol
+    def __len__(self):
+        return len(self._params)
+
+    def __iter__(self):
+        return iter(self._params)
+
+    def __getitem__(self, i):
+        if isinstance(i, str):
+            return self._params[self.index(i)]
+        return self._params[i]
+
+    def __contains__(self, item):
+        name = item.name if isinstance(item, Param) else item
+        return name in self.names
+
+    def __getattr__(self, attr):
+        if attr.startswith("_"):
+            raise AttributeError(attr)
+        try:
+            return self._params[self.names.index(attr)]
+        except ValueError:
+            raise AttributeError("no parameter named '%s'" % attr)
+
+    def __setattr__(self, attr, val):
+        if attr in self.__dict__ or attr in type(self).__dict__:
+            object.__setattr__(self, attr, val)
+            return
+        try:
+            self._params[self.names.index(attr)].value = val
+        except ValueError:
+            object.__setattr__(self, attr, val)
+
+    names = property(lambda self: tuple(p.name for p in self._params))
+    values = property(lambda self: tuple(p.value for p in self._params))
+    nominal_values = property(lambda self: tuple(p.nominal_value for p in self._params))
+    free = property(lambda self: ParamSet([p for p in self._params if not p.is_fixed]))
+    fixed = property(lambda self: ParamSet([p for p in self._params if p.is_fixed]))
+    are_fixed = property(lambda self: tuple(p.is_fixed for p in self._params))
+    has_derived = False
+
+    def index(self, name):
+        if isinstance(name, Param):
+            name = name.name
+        if isinstance(name, (int, np.integer)):
+            return int(name)
+        try:
+            return self.names.index(name)
+        except ValueError:
+            raise ValueError("'%s' is not a parameter of this set" % name)
+
+    def fix(self, x):
+        for n in ([x] if isinstance(x, (str, Param)) else x):
+            self[self.index(n)].is_fixed = True
+
+    def unfix(self, x):
+        for n in ([x] if isinstance(x, (str, Param)) else x):
+            self[self.index(n)].is_fixed = False
+
+    def extend(self, obj):
+        new = [obj] if isinstance(obj, Param) else list(obj)
+        for p in new:
+            if p.name in self.names:
+                raise ValueError("parameter '%s' already present" % p.name)
+        self._params.extend(new)
+
+    def replace(self, new):
+        self._params[self.index(new.name)] = new
+
+    def update(self, obj, existing_must_match=False, extend=True):
+        """param.py:1221-1260"""
+        new = [obj] if isinstance(obj, Param) else list(obj)
+        for p in new:
+            if p.name in self.names:
+                if existing_must_match and p._hashable() != self[p.name]._hashable():
+                    raise ValueError("Param '%s' specified in multiple stages with different values"
+                                     % p.name)
+                self._params[self.index(p.name)] = p
+            elif extend:
+                self._params.append(p)
+
+    def reset_all(self):
+        for p in self._params:
+            p.reset()
+
+    def reset_free(self):
+        for p in self.free:
+            p.reset()
+
+    def set_nominal_by_current_values(self):
+        for p in self._params:
+            p.set_nominal_to_current_value()
+
+    def randomize_free(self, random_state=None):
+        rs = random_state if isinstance(random_state, np.random.RandomState) \
+            else np.random.RandomState(random_state)
+        free = self.free
+        free._rescaled_values = rs.rand(len(free))
+
+    @property
+    def _rescaled_values(self):
+        return tuple(p._rescaled_value for p in self._params)
+
+    @_rescaled_values.setter
+    def _rescaled_values(self, vals):
+        assert len(vals) == len(self)
+        for p, v in zip(self._params, vals):
+            p._rescaled_value = v
+
+    def priors_penalty(self, metric):
+        return np.sum([p.prior_penalty(metric=metric) for p in self._params])
+
+    @property
+    def values_hash(self):
+        return hash(tuple(p._hashable() for p in self._params))
+
+    @property
+    def hash(self):
+        return hash(tuple((p.name, p._hashable(), p.is_fixed) for p in self._params))
+
+    def __repr__(self):
+        return "ParamSet(\n  %s\n)" % "\n  ".join(repr(p) for p in self._params)
+
+
+class ParamSelector:
+    """Regular params + alternative param sets keyed by selector
+    (param.py:1604-1900): `param.nh.theta23` / `param.ih.theta23`."""
+
+    def __init__(self, regular_params=None, selector_param_sets=None, selections=None):
+        self._regular = ParamSet(regular_params) if regular_params is not None else ParamSet()
+        self._selector_sets = OrderedDict()
+        if selector_param_sets:
+            for sel, ps in selector_param_sets.items():
+                self._selector_sets[sel.strip().lower()] = ParamSet(ps)
+        self._selections = []
+        self._current = ParamSet(list(self._regular))
+        self.select_params(selections, error_on_missing=False)
+
+    @property
+    def params(self):
+        return self._current
+
+    @property
+    def param_selections(self):
+        return list(self._selections)
+
+    def select_params(self, selections=None, error_on_missing=False):
+        if selections is None:
+            return self._current
+        if isinstance(selections, str):
+            selections = [s.strip() for s in selections.split(",")]
+        found = False
+        for sel in selections:
+            if sel is None:
+                continue
+            key = sel.strip().lower()
+            if key not in self._selector_sets:
+                continue
+            found = True
+            # one selection per "dimension": drop selections sharing param names
+            new_names = set(self._selector_sets[key].names)
+            self._selections = [s for s in self._selections
+                                if not (set(self._selector_sets[s].names) & new_names)]
+            self._selections.append(key)
+            self._current.update(self._selector_sets[key], extend=True)
+        if error_on_missing and not found and len(self._selector_sets) > 0:
+            raise KeyError("none of the selections %s present" % (selections,))
+        return self._current
+
+    def update(self, p, selector=None, existing_must_match=False, extend=False):
+        """Update params; params shared by name across stages become one object
+        (pipeline.py:342-346)."""
+        new = [p] if isinstance(p, Param) else list(p)
+        if selector is not None:
+            self._selector_sets.setdefault(selector.strip().lower(), ParamSet()).update(
+                new, existing_must_match=existing_must_match, extend=True)
+            return
+        for q in new:
+            if q.name in self._regular.names:
+                self._regular.update(q, existing_must_match=existing_must_match)
+            for sel, ps in self._selector_sets.items():
+                if q.name in ps.names and sel in self._selections:
+                    ps.update(q)
+            if q.name in self._current.names:
+                self._current.update(q, existing_must_match=False)
+            elif extend:
+                self._regular.extend(q)
+                self._current.extend(q)
+
+    def get(self, name, selector=None):
+        if selector is None:
+            return self._regular[name]
+        return self._selector_sets[selector.strip().lower()][name]
