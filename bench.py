@@ -40,6 +40,11 @@ def parse():
     ap.add_argument("--grid", default="200x100", help="calc grid n_E x n_coszen")
     ap.add_argument("--binning", default="dragon", choices=["dragon", "example2d"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="skip the HIP-event measurement of the dominant kernel (use under rocprofv3 --pmc)")
+    ap.add_argument("--coordinate-form", action="store_true",
+                    help="bin event coordinates on the fly (72 B/event) instead of the pre-digitised "
+                         "index columns (40 B/event)")
     ap.add_argument("--cpu-sample-events", type=float, default=2.4e6)
     return ap.parse_args()
 
@@ -65,7 +70,10 @@ def cpu_baseline(wl, sample_events):
     from oracle.pipeline_oracle import oracle_eval
 
     orc.build()
-    cores = os.cpu_count() or 1
+    # one thread per physical core of one socket at most: the event loops are
+    # memory bound and the histogram loop is sequential, more threads only add
+    # OpenMP overhead (measured: 256 SMT threads ran 10x slower than 8)
+    cores = min(len(os.sched_getaffinity(0)), 64)
     orc.set_num_threads(cores)
     n_per = max(1, int(sample_events) // len(wl.events))
     sub = []
@@ -121,7 +129,7 @@ def main():
     n_e, n_cz = (int(v) for v in args.grid.split("x"))
     wl = synthetic.Workload(n_events=int(args.events), grid=(n_e, n_cz), out_binning=args.binning,
                             seed=0)
-    st = synthetic.DeviceState(wl, rank=rank, world_size=world)
+    st = synthetic.DeviceState(wl, rank=rank, world_size=world, indexed=not args.coordinate_form)
     nominal = wl.osc_params()
     st.make_pseudo_data(nominal, seed=0)
     plist = param_list(wl, args.warmup + args.steps)
@@ -156,16 +164,22 @@ def main():
     pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
              for _ in range(k_meas)]
     torch.cuda.synchronize()
-    for (a, b), p in zip(pairs, plist[args.warmup:] + plist):
-        a.record(); b.record()  # materialise the hipEvent handles
-        lib.pisa_hip_profile_events(a.cuda_event, b.cuda_event)
-        st.eval(p, "llh")
-    lib.pisa_hip_profile_events(None, None)
-    torch.cuda.synchronize()
-    fused_ms = [a.elapsed_time(b) for a, b in pairs]
-    fused_avg_s = float(np.mean(fused_ms)) * 1e-3
     d_out = len(wl.ob["nbins"])
-    bytes_per_event = 8 * (2 + 2 + 1 + 1 + d_out)  # 72 B (D=3), 64 B (D=2)
+    if args.coordinate_form:
+        bytes_per_event = 8 * (2 + 2 + 1 + 1 + d_out)  # 72 B (D=3), 64 B (D=2)
+    else:
+        bytes_per_event = 4 + 4 + 16 + 8 + 8  # node, bin (int32) + flux(2) + aeff + w0 = 40 B
+    if args.no_kernel_timing:
+        fused_avg_s = float("nan")
+    else:
+        for (a, b), p in zip(pairs, plist[args.warmup:] + plist):
+            a.record(); b.record()  # materialise the hipEvent handles
+            lib.pisa_hip_profile_events(a.cuda_event, b.cuda_event)
+            st.eval(p, "llh")
+        lib.pisa_hip_profile_events(None, None)
+        torch.cuda.synchronize()
+        fused_ms = [a.elapsed_time(b) for a, b in pairs]
+        fused_avg_s = float(np.mean(fused_ms)) * 1e-3
     achieved = bytes_per_event * st.n_local / fused_avg_s / 1e9
 
     # per-phase device times (extra information, not part of the contract)
@@ -220,7 +234,7 @@ def main():
                          "finalize_metric": t_tail},
             "roofline": {
                 "bound": "hbm",
-                "kernel": "hist_accumulate_kernel<FUSED=true, LDS_ACC=true>",
+                "kernel": "hist_accumulate_kernel<MODE=%d, LDS_ACC=true>" % (1 if args.coordinate_form else 2),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

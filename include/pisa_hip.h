@@ -89,11 +89,32 @@ int pisa_hip_propagate_array_host(const pisa_hip_prob3_params *h_params, int64_t
  *   d_energy[n_e]       node energies along the energy axis
  *   d_densities/d_distances[n_cz][n_layers]   one row per coszen node
  *   node index = e_major ? iE*n_cz + jcz : jcz*n_e + iE   (container.py:769-773)
- *   d_prob_nu / d_prob_nubar [n_e*n_cz][3][3]  (either may be NULL) */
+ *   d_prob_nu / d_prob_nubar [n_e*n_cz][3][3]  (either may be NULL)
+ *   d_pepmu [2][3][n_e*n_cz][2] (may be NULL): compact gather tables
+ *       pepmu[side][flav][node] = (P[e->flav], P[mu->flav]), side 0 nu / 1 nubar,
+ *       i.e. prob_e / prob_mu of `fill_probs` (prob3.py:593-608) for every
+ *       container class, laid out for one 16-byte gather per event. */
 int pisa_hip_prob3_grid(const pisa_hip_prob3_params *h_params, const double *d_energy,
                         int32_t n_e, const double *d_densities, const double *d_distances,
                         int32_t n_cz, int32_t n_layers, int32_t e_major, double *d_prob_nu,
-                        double *d_prob_nubar, void *stream);
+                        double *d_prob_nubar, double *d_pepmu, void *stream);
+
+/* Two-stage form of the same computation.  A plan is built once per set of
+ * layer rows (i.e. at setup, and again only when Ye / tomography parameters
+ * change, prob3.py:461-475): it resolves the reference's layer-matrix cache
+ * (numba_osc_kernels.py:230-249) per coszen row and lists the distinct shell
+ * densities.  Per evaluation, stage A then diagonalises H(E, rho) once per
+ * (energy, distinct density) instead of once per node and layer, stage B chains
+ * the per-layer amplitudes.  Results are bit identical to pisa_hip_prob3_grid.
+ * plan_create synchronises (it reads the rows back); the planned call is async. */
+typedef struct pisa_hip_grid_plan pisa_hip_grid_plan;
+int pisa_hip_grid_plan_create(const double *d_densities, const double *d_distances, int32_t n_cz,
+                              int32_t n_layers, pisa_hip_grid_plan **out);
+int pisa_hip_grid_plan_destroy(pisa_hip_grid_plan *plan);
+int pisa_hip_prob3_grid_planned(const pisa_hip_prob3_params *h_params, pisa_hip_grid_plan *plan,
+                                const double *d_energy, int32_t n_e, int32_t e_major,
+                                double *d_prob_nu, double *d_prob_nubar, double *d_pepmu,
+                                void *stream);
 
 /* Earth model as held by `Layers` (pisa/stages/osc/layers.py:216-335, 411-439):
  * shells ordered from the production sphere inwards. */
@@ -152,8 +173,20 @@ int pisa_hip_histogram_regular(const pisa_hip_binning *h_binning,
 
 /* ------------------------------------- fused reweight + histogram (hot loop) */
 
+/* Digitise event coordinates once: d_index[i] = flat C-order bin of the regular
+ * binning, or -1 outside [min,max) / NaN (same rule as the lookups and
+ * histograms above).  Event coordinates do not change between evaluations, so
+ * the engine stores the calc-grid node and the output bin of every event as
+ * int32 columns (the reference pre-digitises irregular dimensions the same way,
+ * utils/hist.py:100-113). */
+int pisa_hip_event_indices(const pisa_hip_binning *h_binning, const double *const *h_d_sample,
+                           int64_t n, int32_t *d_index, void *stream);
+
 /* One PISA container (pisa/core/container.py:451) as seen by the fused
- * kernel: device columns + the aux scalars the stages read. */
+ * kernel: device columns + the aux scalars the stages read.  Either the
+ * coordinate columns (d_grid_*, d_sample) or the pre-digitised index columns
+ * (d_node, d_bin) must be given; the indexed form moves 40 B/event, the
+ * coordinate form 48 + 8*D B/event. */
 typedef struct {
     int64_t n_events;
     const double *d_grid_x;          /* lookup coordinate on calc-grid dim 0 (ln E if log) */
@@ -162,13 +195,12 @@ typedef struct {
     const double *d_weighted_aeff;   /* [n]                                              */
     const double *d_initial_weights; /* [n]   (toy_event_generator.py:101-104)           */
     const double *d_sample[PISA_HIP_MAX_DIMS]; /* output-binning coordinates, regularised */
+    const int32_t *d_node;           /* [n] calc-grid node of each event, -1 outside (optional) */
+    const int32_t *d_bin;            /* [n] output bin of each event, -1 outside (optional)     */
     int32_t flav;                    /* 0 e, 1 mu, 2 tau  (aux 'flav')                     */
     int32_t nubar;                   /* +1 / -1           (aux 'nubar')                    */
     double scale;                    /* aeff_scale*livetime_s*norms (aeff.py:78-86)        */
 } pisa_hip_container;
-
-/* Workspace sizes (bytes) for n_containers x n_bins histograms. */
-int64_t pisa_hip_hist_workspace_bytes(int32_t n_containers, int64_t n_bins);
 
 /* Fused  prob3.apply (prob3.py:621-622, with the grid->event lookup of
  * container.py:981-1012 / translation.py:427-438)  +  aeff.apply
@@ -176,15 +208,18 @@ int64_t pisa_hip_hist_workspace_bytes(int32_t n_containers, int64_t n_bins);
  * (utils/hist.py:163-218)  over all containers in ONE pass over the events:
  *     w  = w0 * (f_e*P[e->flav] + f_mu*P[mu->flav]) * (aeff*scale)
  *     hist[c][bin] += w ;  sumw2[c][bin] += w*w
- * Result: d_limbs[n_containers][n_bins][2][PISA_HIP_ACC_LIMBS] int64 -- exact
- * partial sums in normalised fixed point, safe to SUM-all-reduce across ranks
- * (integer addition is associative => bit-reproducible for any GPU count).
- * d_workspace: pisa_hip_hist_workspace_bytes() bytes of scratch.
- * d_status: int32 flag, set non-zero on accumulator overflow. */
+ * Result: d_limbs[n_containers][n_bins][2][PISA_HIP_ACC_LIMBS] int64 (zeroed by
+ * the call) -- exact sums in 192-bit fixed point spread over six 32-bit-spaced
+ * limbs, safe to SUM-all-reduce across ranks (integer addition is associative
+ * => bit-reproducible for any workgroup schedule and any GPU count).
+ * d_pepmu: gather tables of pisa_hip_prob3_grid (required for the indexed form,
+ * else d_prob_nu / d_prob_nubar are read).
+ * d_status: int32 flag, set non-zero if a weight is not finite or >= 2^76. */
 int pisa_hip_reweight_hist(const pisa_hip_container *h_containers, int32_t n_containers,
                            const pisa_hip_binning *h_calc_grid, const double *d_prob_nu,
-                           const double *d_prob_nubar, const pisa_hip_binning *h_out_binning,
-                           int64_t *d_limbs, void *d_workspace, int32_t *d_status, void *stream);
+                           const double *d_prob_nubar, const double *d_pepmu,
+                           const pisa_hip_binning *h_out_binning, int64_t *d_limbs,
+                           int32_t *d_status, void *stream);
 
 /* Measurement hook: hipEvent_t handles (cast to void*, NULL to disable) that the
  * next pisa_hip_reweight_hist / pisa_hip_histogram_regular calls of this host
@@ -202,7 +237,7 @@ int pisa_hip_apply_aeff(const double *d_weighted_aeff, double scale, int64_t n,
 /* Converts all-reduced limbs to fp64 maps: d_hist / d_sumw2 [n_containers][n_bins]
  * (either may be NULL). `errors` = sqrt(sumw2) is left to the caller (hist.py:215). */
 int pisa_hip_hist_finalize(const int64_t *d_limbs, int32_t n_containers, int64_t n_bins,
-                           double *d_hist, double *d_sumw2, void *stream);
+                           double *d_hist, double *d_sumw2, int32_t *d_status, void *stream);
 
 /* ------------------------------------------------------------------ metric */
 

@@ -66,6 +66,8 @@ class Container(C.Structure):
         ("d_weighted_aeff", C.c_void_p),
         ("d_initial_weights", C.c_void_p),
         ("d_sample", C.c_void_p * MAX_DIMS),
+        ("d_node", C.c_void_p),
+        ("d_bin", C.c_void_p),
         ("flav", C.c_int32),
         ("nubar", C.c_int32),
         ("scale", C.c_double),
@@ -79,18 +81,21 @@ _SIGS = {
     "pisa_hip_device_count": (C.c_int, []),
     "pisa_hip_propagate_array": (C.c_int, [C.POINTER(Prob3Params), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "pisa_hip_propagate_array_host": (C.c_int, [C.POINTER(Prob3Params), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
-    "pisa_hip_prob3_grid": (C.c_int, [C.POINTER(Prob3Params), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pisa_hip_prob3_grid": (C.c_int, [C.POINTER(Prob3Params), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pisa_hip_grid_plan_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "pisa_hip_grid_plan_destroy": (C.c_int, [C.c_void_p]),
+    "pisa_hip_prob3_grid_planned": (C.c_int, [C.POINTER(Prob3Params), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pisa_hip_calc_layers": (C.c_int, [C.POINTER(Earth), C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pisa_hip_prob3_events": (C.c_int, [C.POINTER(Prob3Params), C.POINTER(Earth), C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pisa_hip_fill_probs": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "pisa_hip_lookup_regular": (C.c_int, [C.POINTER(Binning), C.POINTER(C.c_void_p), C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "pisa_hip_histogram_regular": (C.c_int, [C.POINTER(Binning), C.POINTER(C.c_void_p), C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
-    "pisa_hip_hist_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int64]),
-    "pisa_hip_reweight_hist": (C.c_int, [C.POINTER(Container), C.c_int32, C.POINTER(Binning), C.c_void_p, C.c_void_p, C.POINTER(Binning), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pisa_hip_event_indices": (C.c_int, [C.POINTER(Binning), C.POINTER(C.c_void_p), C.c_int64, C.c_void_p, C.c_void_p]),
+    "pisa_hip_reweight_hist": (C.c_int, [C.POINTER(Container), C.c_int32, C.POINTER(Binning), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Binning), C.c_void_p, C.c_void_p, C.c_void_p]),
     "pisa_hip_profile_events": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pisa_hip_apply_osc_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "pisa_hip_apply_aeff": (C.c_int, [C.c_void_p, C.c_double, C.c_int64, C.c_void_p, C.c_void_p]),
-    "pisa_hip_hist_finalize": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pisa_hip_hist_finalize": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pisa_hip_metric": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pisa_hip_barr_simple": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_void_p, C.c_void_p]),
     "pisa_hip_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_int64]),

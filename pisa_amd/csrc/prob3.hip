@@ -17,6 +17,22 @@
 
 namespace pisa {
 
+// P[init][final] of one node -> full matrix and/or the compact gather tables
+// pepmu[side][flav][node] = (P[e->flav], P[mu->flav]) read by the fused kernel
+__device__ __forceinline__ void store_node(const double (&P)[9], int64_t node, int64_t n_nodes,
+                                           int side, double *__restrict__ out,
+                                           double2 *__restrict__ pepmu) {
+    if (out) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) out[9 * node + k] = P[k];
+    }
+    if (pepmu) {
+#pragma unroll
+        for (int f = 0; f < 3; f++)
+            pepmu[((int64_t)side * 3 + f) * n_nodes + node] = make_double2(P[f], P[3 + f]);
+    }
+}
+
 // ----------------------------------------------------------------- array form
 template <bool DECAY>
 __global__ void __launch_bounds__(256)
@@ -44,11 +60,11 @@ __global__ void __launch_bounds__(256)
 prob3_grid_kernel(const Prob3Consts c, const double *__restrict__ energy, int n_e,
                   const double *__restrict__ densities, const double *__restrict__ distances,
                   int n_cz, int n_layers, int e_major, double *__restrict__ prob_nu,
-                  double *__restrict__ prob_nubar) {
+                  double *__restrict__ prob_nubar, double2 *__restrict__ pepmu) {
     const int jcz = blockIdx.x;
     const int side = blockIdx.y;
     double *out = side == 0 ? prob_nu : prob_nubar;
-    if (out == nullptr) return;
+    if (out == nullptr && pepmu == nullptr) return;
     // workgroup-uniform row pointers -> scalar loads
     const double *rho_row = densities + (int64_t)jcz * n_layers;
     const double *dist_row = distances + (int64_t)jcz * n_layers;
@@ -60,8 +76,70 @@ prob3_grid_kernel(const Prob3Consts c, const double *__restrict__ energy, int n_
         double P[9];
         propagate_element<DECAY>(c.side[side], c.dm, energy[ie], n_layers, layer, P);
         int64_t node = e_major ? (int64_t)ie * n_cz + jcz : (int64_t)jcz * n_e + ie;
+        store_node(P, node, (int64_t)n_e * n_cz, side, out, pepmu);
+    }
+}
+
+// ------------------------------------------------- planned (two-stage) grid
+// Stage A: one thread per (side, unique shell density, energy).
+template <bool DECAY>
+__global__ void __launch_bounds__(64)
+prob3_terms_kernel(const Prob3Consts c, const double *__restrict__ energy, int n_e,
+                   const double *__restrict__ rho_unique, int n_unique,
+                   double *__restrict__ rec) {
+    const int ie = blockIdx.x * blockDim.x + threadIdx.x;
+    const int u = blockIdx.y;
+    const int side = blockIdx.z;
+    if (ie >= n_e) return;
+    double *r = rec + ((int64_t)(side * n_unique + u) * PROB3_NF) * n_e + ie;
+    auto store = [&](int f, double v) { r[(int64_t)f * n_e] = v; };
+    eigen_terms<DECAY>(c.side[side], c.dm, energy[ie], rho_unique[u], store);
+}
+
+// Stage B: workgroup = one coszen row of one sign, lanes along energy.
+template <bool DECAY>
+__global__ void __launch_bounds__(256)
+prob3_chain_kernel(const Prob3Consts c, const double *__restrict__ energy, int n_e,
+                   const int32_t *__restrict__ rho_idx, const double *__restrict__ dist,
+                   const int32_t *__restrict__ n_used, int n_cz, int n_layers, int n_unique,
+                   const double *__restrict__ rec, int e_major, double *__restrict__ prob_nu,
+                   double *__restrict__ prob_nubar, double2 *__restrict__ pepmu) {
+    const int jcz = blockIdx.x;
+    const int side = blockIdx.y;
+    double *out = side == 0 ? prob_nu : prob_nubar;
+    const Prob3Side &S = c.side[side];
+    const int32_t *idx_row = rho_idx + (int64_t)jcz * n_layers;
+    const double *dist_row = dist + (int64_t)jcz * n_layers;
+    const int nl = n_used[jcz];
+    for (int ie = threadIdx.x; ie < n_e; ie += blockDim.x) {
+        const double e = energy[ie];
+        mat3 T;
+        bool first = true;
 #pragma unroll
-        for (int k = 0; k < 9; k++) out[9 * node + k] = P[k];
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) T.m[i][j] = cmake(0.0, 0.0);
+        for (int l = 0; l < nl; l++) {
+            const int u = idx_row[l];  // workgroup-uniform
+            if (u < 0) continue;
+            const double *r = rec + ((int64_t)(side * n_unique + u) * PROB3_NF) * n_e + ie;
+            auto load = [&](int f) { return r[(int64_t)f * n_e]; };
+            mat3 A;
+            amplitude_from_terms<DECAY>(load, dist_row[l] / e, A);
+            if (first) { T = A; first = false; }
+            else { mat3 t2; mat_mul(A, T, t2); T = t2; }
+        }
+        mat3 t2, Tf;
+        mat_mul(T, S.Ud, t2);
+        mat_mul(S.U, t2, Tf);
+        double P[9];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                P[3 * i + j] = Tf.m[j][i].re * Tf.m[j][i].re + Tf.m[j][i].im * Tf.m[j][i].im;
+        int64_t node = e_major ? (int64_t)ie * n_cz + jcz : (int64_t)jcz * n_e + ie;
+        store_node(P, node, (int64_t)n_e * n_cz, side, out, pepmu);
     }
 }
 
@@ -320,7 +398,7 @@ PISA_API int pisa_hip_prob3_grid(const pisa_hip_prob3_params *h_params, const do
                                  int32_t n_e, const double *d_densities,
                                  const double *d_distances, int32_t n_cz, int32_t n_layers,
                                  int32_t e_major, double *d_prob_nu, double *d_prob_nubar,
-                                 void *stream) {
+                                 double *d_pepmu, void *stream) {
     if (n_e < 0 || n_cz < 0 || n_layers < 0) return PISA_HIP_ERR_INVALID;
     if (n_layers > PISA_HIP_MAX_LAYERS) return PISA_HIP_ERR_LAYERS;
     if (n_e == 0 || n_cz == 0) return PISA_HIP_OK;
@@ -334,11 +412,11 @@ PISA_API int pisa_hip_prob3_grid(const pisa_hip_prob3_params *h_params, const do
     if (c.decay)
         hipLaunchKernelGGL(prob3_grid_kernel<true>, grid, block, 0, as_stream(stream), c, d_energy,
                            (int)n_e, d_densities, d_distances, (int)n_cz, (int)n_layers,
-                           (int)e_major, d_prob_nu, d_prob_nubar);
+                           (int)e_major, d_prob_nu, d_prob_nubar, (double2 *)d_pepmu);
     else
         hipLaunchKernelGGL(prob3_grid_kernel<false>, grid, block, 0, as_stream(stream), c, d_energy,
                            (int)n_e, d_densities, d_distances, (int)n_cz, (int)n_layers,
-                           (int)e_major, d_prob_nu, d_prob_nubar);
+                           (int)e_major, d_prob_nu, d_prob_nubar, (double2 *)d_pepmu);
     PISA_CHECK_LAUNCH("prob3_grid_kernel");
     return PISA_HIP_OK;
 }
@@ -395,5 +473,130 @@ PISA_API int pisa_hip_fill_probs(const double *d_probability, int64_t init_flav,
     hipLaunchKernelGGL(fill_probs_kernel, grid, block, 0, as_stream(stream), d_probability,
                        (int)init_flav, (int)flav, n, d_out);
     PISA_CHECK_LAUNCH("fill_probs_kernel");
+    return PISA_HIP_OK;
+}
+
+// ------------------------------------------------------------ grid plan (host)
+struct pisa_hip_grid_plan {
+    int n_cz, n_layers, n_unique;
+    int32_t *d_rho_idx;
+    double *d_dist;
+    double *d_rho;
+    int32_t *d_n_used;
+    double *d_rec;
+    int n_e_alloc;
+};
+
+PISA_API int pisa_hip_grid_plan_create(const double *d_densities, const double *d_distances,
+                                       int32_t n_cz, int32_t n_layers,
+                                       pisa_hip_grid_plan **out) {
+    if (!out || n_cz < 1 || n_layers < 1 || !d_densities || !d_distances) return PISA_HIP_ERR_INVALID;
+    if (n_layers > PISA_HIP_MAX_LAYERS) return PISA_HIP_ERR_LAYERS;
+    size_t n = (size_t)n_cz * n_layers;
+    double *rho = new double[n], *dist = new double[n], *dres = new double[n];
+    int32_t *idx = new int32_t[n], *used = new int32_t[n_cz];
+    double *uniq = new double[n];
+    int nu = 0;
+    int rc = check_hip(hipMemcpy(rho, d_densities, n * 8, hipMemcpyDeviceToHost), "d2h");
+    if (!rc) rc = check_hip(hipMemcpy(dist, d_distances, n * 8, hipMemcpyDeviceToHost), "d2h");
+    if (!rc) {
+        for (int r = 0; r < n_cz; r++) {
+            const double *rr = rho + (size_t)r * n_layers, *dd = dist + (size_t)r * n_layers;
+            int last = 0;
+            for (int i = 0; i < n_layers; i++) {
+                size_t o = (size_t)r * n_layers + i;
+                idx[o] = -1;
+                dres[o] = 0.0;
+                if (!(dd[i] > 0.0)) continue;
+                last = i + 1;
+                // follow the reference's cache matches (numba_osc_kernels.py:236-249)
+                int cur = i;
+                double cr = rr[i], cd = dd[i];
+                while (true) {
+                    int found = -1;
+                    for (int j = 0; j < cur; j++)
+                        if (dd[j] > 0.0 && fabs(rr[j] - cr) < 1e-5 && fabs(dd[j] - cd) < 1e-5) found = j;
+                    if (found < 0) break;
+                    cur = found; cr = rr[cur]; cd = dd[cur];
+                }
+                int u = -1;
+                for (int k = 0; k < nu; k++)
+                    if (uniq[k] == cr) { u = k; break; }
+                if (u < 0) { u = nu; uniq[nu++] = cr; }
+                idx[o] = u;
+                dres[o] = cd;
+            }
+            used[r] = last;
+        }
+    }
+    pisa_hip_grid_plan *p = nullptr;
+    if (!rc) {
+        p = new pisa_hip_grid_plan();
+        p->n_cz = n_cz; p->n_layers = n_layers; p->n_unique = nu > 0 ? nu : 1;
+        p->d_rho_idx = nullptr; p->d_dist = nullptr; p->d_rho = nullptr; p->d_n_used = nullptr;
+        p->d_rec = nullptr; p->n_e_alloc = 0;
+        if (nu == 0) uniq[0] = 0.0;
+        rc = check_hip(hipMalloc(&p->d_rho_idx, n * 4), "hipMalloc");
+        if (!rc) rc = check_hip(hipMalloc(&p->d_dist, n * 8), "hipMalloc");
+        if (!rc) rc = check_hip(hipMalloc(&p->d_rho, (size_t)p->n_unique * 8), "hipMalloc");
+        if (!rc) rc = check_hip(hipMalloc(&p->d_n_used, (size_t)n_cz * 4), "hipMalloc");
+        if (!rc) rc = check_hip(hipMemcpy(p->d_rho_idx, idx, n * 4, hipMemcpyHostToDevice), "h2d");
+        if (!rc) rc = check_hip(hipMemcpy(p->d_dist, dres, n * 8, hipMemcpyHostToDevice), "h2d");
+        if (!rc) rc = check_hip(hipMemcpy(p->d_rho, uniq, (size_t)p->n_unique * 8, hipMemcpyHostToDevice), "h2d");
+        if (!rc) rc = check_hip(hipMemcpy(p->d_n_used, used, (size_t)n_cz * 4, hipMemcpyHostToDevice), "h2d");
+    }
+    delete[] rho; delete[] dist; delete[] dres; delete[] idx; delete[] used; delete[] uniq;
+    if (rc && p) { pisa_hip_grid_plan_destroy(p); p = nullptr; }
+    *out = p;
+    return rc;
+}
+
+PISA_API int pisa_hip_grid_plan_destroy(pisa_hip_grid_plan *p) {
+    if (!p) return PISA_HIP_OK;
+    if (p->d_rho_idx) (void)hipFree(p->d_rho_idx);
+    if (p->d_dist) (void)hipFree(p->d_dist);
+    if (p->d_rho) (void)hipFree(p->d_rho);
+    if (p->d_n_used) (void)hipFree(p->d_n_used);
+    if (p->d_rec) (void)hipFree(p->d_rec);
+    delete p;
+    return PISA_HIP_OK;
+}
+
+PISA_API int pisa_hip_prob3_grid_planned(const pisa_hip_prob3_params *h_params,
+                                         pisa_hip_grid_plan *plan, const double *d_energy,
+                                         int32_t n_e, int32_t e_major, double *d_prob_nu,
+                                         double *d_prob_nubar, double *d_pepmu, void *stream) {
+    if (!plan || n_e < 1 || !d_energy) return PISA_HIP_ERR_INVALID;
+    Prob3Consts c;
+    int rc = make_consts(h_params, c);
+    if (rc) return rc;
+    if (plan->n_e_alloc < n_e) {
+        if (plan->d_rec) (void)hipFree(plan->d_rec);
+        plan->d_rec = nullptr;
+        size_t bytes = (size_t)2 * plan->n_unique * PROB3_NF * n_e * sizeof(double);
+        PISA_TRY_HIP(hipMalloc(&plan->d_rec, bytes));
+        plan->n_e_alloc = n_e;
+    }
+    hipStream_t s = as_stream(stream);
+    dim3 ablock(64), agrid((unsigned)((n_e + 63) / 64), (unsigned)plan->n_unique, 2);
+    int threads = ((n_e + 63) / 64) * 64;
+    if (threads > 256) threads = 256;
+    dim3 bblock(threads), bgrid((unsigned)plan->n_cz, 2);
+    if (c.decay) {
+        hipLaunchKernelGGL(prob3_terms_kernel<true>, agrid, ablock, 0, s, c, d_energy, (int)n_e,
+                           plan->d_rho, plan->n_unique, plan->d_rec);
+        hipLaunchKernelGGL(prob3_chain_kernel<true>, bgrid, bblock, 0, s, c, d_energy, (int)n_e,
+                           plan->d_rho_idx, plan->d_dist, plan->d_n_used, plan->n_cz,
+                           plan->n_layers, plan->n_unique, plan->d_rec, (int)e_major, d_prob_nu,
+                           d_prob_nubar, (double2 *)d_pepmu);
+    } else {
+        hipLaunchKernelGGL(prob3_terms_kernel<false>, agrid, ablock, 0, s, c, d_energy, (int)n_e,
+                           plan->d_rho, plan->n_unique, plan->d_rec);
+        hipLaunchKernelGGL(prob3_chain_kernel<false>, bgrid, bblock, 0, s, c, d_energy, (int)n_e,
+                           plan->d_rho_idx, plan->d_dist, plan->d_n_used, plan->n_cz,
+                           plan->n_layers, plan->n_unique, plan->d_rec, (int)e_major, d_prob_nu,
+                           d_prob_nubar, (double2 *)d_pepmu);
+    }
+    PISA_CHECK_LAUNCH("prob3_chain_kernel");
     return PISA_HIP_OK;
 }

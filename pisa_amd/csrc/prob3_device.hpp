@@ -406,6 +406,136 @@ __device__ __forceinline__ void layer_amplitude(const Prob3Side &S, const double
     }
 }
 
+// ---------------------------------------------------------------------------
+// Two-stage form used on (E x coszen) grids.  Everything in
+// get_transition_matrix except the three phases exp(-i M_k L/E 2.534) depends
+// only on (energy, density): the eigenvalues M_k and the 27 quotients
+// product[i][j][k] / ((M_k-M_j)(M_k-M_l)) (numba_osc_kernels.py:432-467,
+// 834-872).  Stage A evaluates them once per (E, shell density) -- a few
+// thousand times per evaluation instead of once per node and crossed layer --
+// and stage B assembles A = sum_k phase_k * Q_k per layer.  Same operations on
+// the same operands as layer_amplitude(), so the result is bit identical.
+constexpr int PROB3_NF = 60;  // fields per record: M[3] (re,im) + Q[3][3][3] (re,im)
+
+// field(f) = value callback; f in [0, PROB3_NF)
+template <bool DECAY, class StoreFn>
+__device__ __forceinline__ void eigen_terms(const Prob3Side &S, const double (&dm)[3][3],
+                                            double energy, double rho, const StoreFn &store) {
+    const double tworttwoGf = 1.52588e-4;
+    double a = 0.5 * rho * tworttwoGf;
+    double sa = S.a_sign * a;
+    double one_over_two_e = 0.5 / energy;
+    mat3 Hf;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            cplx hm = cscale(sa, S.V.m[i][j]);
+            hm.re = hm.re + S.lri[i][j];
+            Hf.m[i][j] = cadd(cscale(one_over_two_e, S.Hvd.m[i][j]), hm);
+        }
+    mat3 tmp, X;
+    mat_mul(Hf, S.U, tmp);
+    mat_mul(S.Ud, tmp, X);
+    double two_e = 2.0 * energy;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) X.m[i][j] = cscale(two_e, X.m[i][j]);
+
+    cplx M[3], den[3];
+    if (!DECAY) {
+        double Mr[3];
+        get_dms(energy, Hf, dm, Mr);
+#pragma unroll
+        for (int k = 0; k < 3; k++) M[k] = cmake(Mr[k], 0.0);
+        den[0] = cmake((Mr[0] - Mr[1]) * (Mr[0] - Mr[2]), 0.0);
+        den[1] = cmake((Mr[1] - Mr[2]) * (Mr[1] - Mr[0]), 0.0);
+        den[2] = cmake((Mr[2] - Mr[0]) * (Mr[2] - Mr[1]), 0.0);
+    } else {
+        cplx lam[3];
+        eigvals3_general(Hf, lam);
+#pragma unroll
+        for (int k = 0; k < 3; k++) M[k] = cscale(two_e, lam[k]);
+        den[0] = cmul(csub(M[0], M[1]), csub(M[0], M[2]));
+        den[1] = cmul(csub(M[1], M[2]), csub(M[1], M[0]));
+        den[2] = cmul(csub(M[2], M[0]), csub(M[2], M[1]));
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        store(2 * k, M[k].re);
+        store(2 * k + 1, M[k].im);
+    }
+    cplx Xd[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            Xd[k][i] = DECAY ? csub(X.m[i][i], M[k]) : cmake(X.m[i][i].re - M[k].re, X.m[i][i].im);
+#define HMM(i_, j_, k_) (((i_) == (j_)) ? Xd[k_][i_] : X.m[i_][j_])
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            cplx p0 = cmul(HMM(i, 0, 1), HMM(0, j, 2));
+            p0 = cadd(p0, cmul(HMM(i, 1, 1), HMM(1, j, 2)));
+            p0 = cadd(p0, cmul(HMM(i, 2, 1), HMM(2, j, 2)));
+            cplx p1 = cmul(HMM(i, 0, 2), HMM(0, j, 0));
+            p1 = cadd(p1, cmul(HMM(i, 1, 2), HMM(1, j, 0)));
+            p1 = cadd(p1, cmul(HMM(i, 2, 2), HMM(2, j, 0)));
+            cplx p2 = cmul(HMM(i, 0, 0), HMM(0, j, 1));
+            p2 = cadd(p2, cmul(HMM(i, 1, 0), HMM(1, j, 1)));
+            p2 = cadd(p2, cmul(HMM(i, 2, 0), HMM(2, j, 1)));
+            if (!DECAY) {
+                p0 = cmake(p0.re / den[0].re, p0.im / den[0].re);
+                p1 = cmake(p1.re / den[1].re, p1.im / den[1].re);
+                p2 = cmake(p2.re / den[2].re, p2.im / den[2].re);
+            } else {
+                p0 = cdiv(p0, den[0]);
+                p1 = cdiv(p1, den[1]);
+                p2 = cdiv(p2, den[2]);
+            }
+            const int base = 6 + 6 * (3 * i + j);
+            store(base + 0, p0.re); store(base + 1, p0.im);
+            store(base + 2, p1.re); store(base + 3, p1.im);
+            store(base + 4, p2.re); store(base + 5, p2.im);
+        }
+#undef HMM
+}
+
+// A = sum_k exp(-i M_k L/E 2.534) Q_k from a stage-A record (load(f) reads field f)
+template <bool DECAY, class LoadFn>
+__device__ __forceinline__ void amplitude_from_terms(const LoadFn &load, double L_over_E, mat3 &A) {
+    const double hbar_c_factor = 2.534;
+    cplx ph[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (!DECAY) {
+            double arg = (-load(2 * k)) * L_over_E * hbar_c_factor;
+            double s, c;
+            sincos(arg, &s, &c);
+            ph[k] = cmake(c, s);
+        } else {
+            cplx Mk = cmake(load(2 * k), load(2 * k + 1));
+            cplx arg = cscale(hbar_c_factor, cscale(L_over_E, cscale(-1.0, Mk)));
+            double l = exp(-arg.im);
+            double s, c;
+            sincos(arg.re, &s, &c);
+            ph[k] = cmake(l * c, l * s);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int base = 6 + 6 * (3 * i + j);
+            cplx acc = cmul(ph[0], cmake(load(base + 0), load(base + 1)));
+            acc = cadd(acc, cmul(ph[1], cmake(load(base + 2), load(base + 3))));
+            acc = cadd(acc, cmul(ph[2], cmake(load(base + 4), load(base + 5))));
+            A.m[i][j] = acc;
+        }
+}
+
 // Layer-matrix cache of the reference (numba_osc_kernels.py:230-249): layer i
 // re-uses the matrix of the LAST earlier layer j with |drho|<1e-5 and
 // |ddist|<1e-5.  Instead of storing up to 120 matrices per thread, the chain of

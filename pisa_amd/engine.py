@@ -60,7 +60,7 @@ class HotPathEngine:
     scale."""
 
     def __init__(self, containers, grid, out_binning, earth, max_layers, rank=0, world_size=1,
-                 group=None):
+                 group=None, indexed=True, planned=True):
         self.dev = K.device()
         self.grid = grid
         self.out_binning = out_binning
@@ -68,6 +68,7 @@ class HotPathEngine:
         self.rank, self.world_size, self.group = rank, world_size, group
         self.names = [c["name"] for c in containers]
         self._keep = []  # device tensors referenced by raw pointer
+        self.indexed, self.planned = indexed, planned
         self.cont = []
         self.n_local = 0
         for c in containers:
@@ -84,16 +85,26 @@ class HotPathEngine:
             d.d_nu_flux = self._up(np.asarray(c["nu_flux"], dtype=np.float64)[sl]).data_ptr()
             d.d_weighted_aeff = self._up(np.asarray(c["weighted_aeff"])[sl]).data_ptr()
             d.d_initial_weights = self._up(np.asarray(c["initial_weights"])[sl]).data_ptr()
-            for k, col in enumerate(c["sample"]):
-                d.d_sample[k] = self._up(np.asarray(col)[sl]).data_ptr()
+            cols = [self._up(np.asarray(col)[sl]) for col in c["sample"]]
+            for k, col in enumerate(cols):
+                d.d_sample[k] = col.data_ptr()
+            if indexed:
+                # coordinates never change between evaluations: digitise once
+                node = K.event_indices([gx, gy], grid.binning)
+                obin = K.event_indices(cols, out_binning)
+                self._keep += [node, obin]
+                d.d_node, d.d_bin = node.data_ptr(), obin.data_ptr()
             d.flav, d.nubar, d.scale = int(c["flav"]), int(c["nubar"]), float(c["scale"])
             self.cont.append(d)
+        self._cont_arr = (_lib.Container * len(self.cont))(*self.cont)
         # Earth layers for the coszen nodes (prob3.setup_function, prob3.py:398-409)
         self.earth = earth
         self.energy_d = K.to_device(grid.energy)
         _, self.dens_d, self.dist_d = K.calc_layers(earth, K.to_device(grid.coszen), max_layers)
         self.prob_nu = torch.empty((grid.size, 3, 3), dtype=torch.float64, device=self.dev)
         self.prob_nubar = torch.empty((grid.size, 3, 3), dtype=torch.float64, device=self.dev)
+        self.pepmu = torch.empty((2, 3, grid.size, 2), dtype=torch.float64, device=self.dev)
+        self.plan = K.GridPlan(self.dens_d, self.dist_d) if planned else None
         self.ws = K.HistWorkspace(len(self.cont), self.n_bins, self.dev)
         self.metric_out = torch.zeros(1, dtype=torch.float64, device=self.dev)
         self.metric_status = torch.zeros(1, dtype=torch.int32, device=self.dev)
@@ -105,18 +116,26 @@ class HotPathEngine:
         return t
 
     def set_scale(self, name, scale):
-        self.cont[self.names.index(name)].scale = float(scale)
+        i = self.names.index(name)
+        self.cont[i].scale = float(scale)
+        self._cont_arr[i].scale = float(scale)
 
     # -- per-eval steps ----------------------------------------------------
     def compute_probs(self, params):
-        K.prob3_grid(params, self.energy_d, self.dens_d, self.dist_d, e_major=self.grid.energy_first,
-                     out_nu=self.prob_nu, out_nubar=self.prob_nubar)
+        if self.plan is not None:
+            K.prob3_grid_planned(params, self.plan, self.energy_d, e_major=self.grid.energy_first,
+                                 out_nu=self.prob_nu, out_nubar=self.prob_nubar,
+                                 out_pepmu=self.pepmu)
+        else:
+            K.prob3_grid(params, self.energy_d, self.dens_d, self.dist_d,
+                         e_major=self.grid.energy_first, out_nu=self.prob_nu,
+                         out_nubar=self.prob_nubar, out_pepmu=self.pepmu)
 
     def accumulate(self, params=None):
         if params is not None:
             self.compute_probs(params)
-        K.reweight_hist(self.cont, self.grid.binning, self.prob_nu, self.prob_nubar,
-                        self.out_binning, self.ws)
+        K.reweight_hist(self._cont_arr, self.grid.binning, self.prob_nu, self.prob_nubar,
+                        self.pepmu if self.indexed else None, self.out_binning, self.ws)
 
     def allreduce(self):
         """Integer SUM all-reduce of the histogram limbs over RCCL/xGMI (or gloo in

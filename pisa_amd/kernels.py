@@ -59,19 +59,64 @@ def propagate_array(params, nubar, energy, densities, distances, out=None):
     return out
 
 
-def prob3_grid(params, energy, densities, distances, e_major=True, out_nu=None, out_nubar=None):
+def prob3_grid(params, energy, densities, distances, e_major=True, out_nu=None, out_nubar=None,
+               out_pepmu=None, want_pepmu=False):
     """Both 'nu' and 'nubar' linked containers of a 2-D calc grid in one launch
-    (prob3.py:452-459, 581-588)."""
+    (prob3.py:452-459, 581-588).  Returns (P_nu, P_nubar[, pepmu])."""
     lib = _lib.lib()
     n_e, n_cz, n_layers = energy.numel(), densities.shape[0], densities.shape[1]
     if out_nu is None:
         out_nu = torch.empty((n_e * n_cz, 3, 3), dtype=F8, device=energy.device)
     if out_nubar is None:
         out_nubar = torch.empty((n_e * n_cz, 3, 3), dtype=F8, device=energy.device)
+    if out_pepmu is None and want_pepmu:
+        out_pepmu = torch.empty((2, 3, n_e * n_cz, 2), dtype=F8, device=energy.device)
     _lib.check(lib.pisa_hip_prob3_grid(
         C.byref(params), _ptr(energy), n_e, _ptr(densities), _ptr(distances), n_cz, n_layers,
-        1 if e_major else 0, _ptr(out_nu), _ptr(out_nubar), _stream()))
+        1 if e_major else 0, _ptr(out_nu), _ptr(out_nubar), _ptr(out_pepmu), _stream()))
+    if out_pepmu is not None:
+        return out_nu, out_nubar, out_pepmu
     return out_nu, out_nubar
+
+
+class GridPlan:
+    """Per-layer-table plan of the two-stage grid kernels (`pisa_hip_grid_plan`):
+    cache matches resolved per coszen row + list of distinct shell densities."""
+
+    def __init__(self, densities, distances):
+        lib = _lib.lib()
+        self.n_cz, self.n_layers = densities.shape
+        h = C.c_void_p()
+        torch.cuda.synchronize()
+        _lib.check(lib.pisa_hip_grid_plan_create(_ptr(densities), _ptr(distances), self.n_cz,
+                                                 self.n_layers, C.byref(h)))
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.lib().pisa_hip_grid_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def prob3_grid_planned(params, plan, energy, e_major=True, out_nu=None, out_nubar=None,
+                       out_pepmu=None):
+    """Two-stage grid evaluation (bit identical to `prob3_grid`)."""
+    lib = _lib.lib()
+    n_e = energy.numel()
+    n = n_e * plan.n_cz
+    if out_nu is None:
+        out_nu = torch.empty((n, 3, 3), dtype=F8, device=energy.device)
+    if out_nubar is None:
+        out_nubar = torch.empty((n, 3, 3), dtype=F8, device=energy.device)
+    if out_pepmu is None:
+        out_pepmu = torch.empty((2, 3, n, 2), dtype=F8, device=energy.device)
+    _lib.check(lib.pisa_hip_prob3_grid_planned(
+        C.byref(params), plan.handle, _ptr(energy), n_e, 1 if e_major else 0, _ptr(out_nu),
+        _ptr(out_nubar), _ptr(out_pepmu), _stream()))
+    return out_nu, out_nubar, out_pepmu
 
 
 def calc_layers(earth, coszen, max_layers):
@@ -151,17 +196,22 @@ def histogram_regular(sample, weights, binning, averaged=False):
     return out
 
 
+def event_indices(sample, binning):
+    """flat bin index (int32, -1 outside) of every event in a regular binning"""
+    lib = _lib.lib()
+    n = sample[0].numel()
+    out = torch.empty(n, dtype=torch.int32, device=sample[0].device)
+    _lib.check(lib.pisa_hip_event_indices(C.byref(binning), _sample_array(sample), n, _ptr(out),
+                                          _stream()))
+    return out
+
+
 class HistWorkspace:
-    """Scratch + limb buffers for `reweight_hist` (allocated once, reused)."""
+    """Limb / map buffers for `reweight_hist` (allocated once, reused)."""
 
     def __init__(self, n_containers, n_bins, dev=None):
-        lib = _lib.lib()
         dev = dev or device()
-        nbytes = lib.pisa_hip_hist_workspace_bytes(n_containers, n_bins)
-        if nbytes < 0:
-            _lib.check(int(nbytes))
         self.n_containers, self.n_bins = n_containers, n_bins
-        self.scratch = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
         self.limbs = torch.zeros((n_containers, n_bins, 2, _lib.ACC_LIMBS), dtype=torch.int64,
                                  device=dev)
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -169,20 +219,21 @@ class HistWorkspace:
         self.sumw2 = torch.empty((n_containers, n_bins), dtype=F8, device=dev)
 
 
-def reweight_hist(containers, calc_grid, prob_nu, prob_nubar, out_binning, ws):
+def reweight_hist(containers, calc_grid, prob_nu, prob_nubar, pepmu, out_binning, ws):
     """Fused prob3.apply + aeff.apply + hist.apply(sumw2); fills ws.limbs."""
     lib = _lib.lib()
-    arr = (_lib.Container * len(containers))(*containers)
+    arr = containers if isinstance(containers, C.Array) else (_lib.Container * len(containers))(*containers)
     _lib.check(lib.pisa_hip_reweight_hist(
-        arr, len(containers), C.byref(calc_grid), _ptr(prob_nu), _ptr(prob_nubar),
-        C.byref(out_binning), _ptr(ws.limbs), _ptr(ws.scratch), _ptr(ws.status), _stream()))
+        arr, len(arr), C.byref(calc_grid), _ptr(prob_nu), _ptr(prob_nubar), _ptr(pepmu),
+        C.byref(out_binning), _ptr(ws.limbs), _ptr(ws.status), _stream()))
     return ws.limbs
 
 
 def hist_finalize(ws):
     lib = _lib.lib()
     _lib.check(lib.pisa_hip_hist_finalize(_ptr(ws.limbs), ws.n_containers, ws.n_bins,
-                                          _ptr(ws.hist), _ptr(ws.sumw2), _stream()))
+                                          _ptr(ws.hist), _ptr(ws.sumw2), _ptr(ws.status),
+                                          _stream()))
     return ws.hist, ws.sumw2
 
 

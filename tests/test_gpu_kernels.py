@@ -104,6 +104,28 @@ def test_prob3_grid_golden_and_oracle(K, L, oracle):
             np.testing.assert_allclose(nubar, g[name + "::prob_nubar"], err_msg=name, **AC)
 
 
+def test_prob3_grid_planned_bit_identical(K, L):
+    """two-stage (hoisted eigen-decomposition) grid == direct grid, bit for bit,
+    incl. the compact (P_e, P_mu) gather tables"""
+    g = load_golden("prob3_grid_prem12.npz")
+    e, dens, dist = K.to_device(g["energy"]), K.to_device(g["densities"]), K.to_device(g["distances"])
+    plan = K.GridPlan(dens, dist)
+    for name in ("no", "nsi", "decay"):
+        p = L.make_prob3_params(g[name + "::dm"], g[name + "::mix"], g[name + "::mat_pot"],
+                                int(g[name + "::decay_flag"]), g[name + "::mat_decay"],
+                                g[name + "::lri_pot"])
+        for e_major in (True, False):
+            nu, nubar, pepmu = K.prob3_grid(p, e, dens, dist, e_major=e_major, want_pepmu=True)
+            nu2, nubar2, pepmu2 = K.prob3_grid_planned(p, plan, e, e_major=e_major)
+            assert bool((nu == nu2).all()) and bool((nubar == nubar2).all())
+            assert bool((pepmu == pepmu2).all())
+            pm = pepmu.cpu().numpy()
+            for side, P in ((0, nu.cpu().numpy()), (1, nubar.cpu().numpy())):
+                for f in range(3):
+                    np.testing.assert_array_equal(pm[side, f, :, 0], P[:, 0, f])  # fill_probs(P, 0, flav)
+                    np.testing.assert_array_equal(pm[side, f, :, 1], P[:, 1, f])  # fill_probs(P, 1, flav)
+
+
 def test_prob3_random_vs_oracle(K, L, oracle):
     """seeded random parameters / paths incl. zero-length layers and cache hits"""
     rs = np.random.RandomState(123)
@@ -299,6 +321,27 @@ def test_fused_bit_reproducible_and_shardable(K, L):
     llh_a = K.metric("llh", full.data, full.ws.hist, full.ws.sumw2)
     llh_b = K.metric("llh", full.data, sh.ws.hist, sh.ws.sumw2)
     assert float(llh_a.item()) == float(llh_b.item())
+
+
+def test_indexed_equals_coordinate_form(K, L, oracle):
+    """pre-digitised (node, bin) columns + gather tables give the same exact
+    limbs as binning the coordinates on the fly; indices match the oracle rule"""
+    from pisa_amd import synthetic
+
+    wl = synthetic.Workload(n_events=50001 * 12, grid=(30, 20), out_binning="dragon", seed=5)
+    p = wl.osc_params(theta23_deg=47.0)
+    a = synthetic.DeviceState(wl, indexed=True, planned=True)
+    b = synthetic.DeviceState(wl, indexed=False, planned=False)
+    a.accumulate(p)
+    b.accumulate(p)
+    assert bool((a.ws.limbs == b.ws.limbs).all())
+    ev = wl.events[4]
+    idx = K.event_indices([K.to_device(s) for s in ev["sample"]], wl.out_binning).cpu().numpy()
+    ob = wl.ob
+    ones = np.ones(len(idx))
+    ref = oracle.histogram_regular(ev["sample"], ones, ob["mins"], ob["maxs"], ob["nbins"])
+    np.testing.assert_array_equal(np.bincount(idx[idx >= 0], minlength=wl.n_bins), ref)
+    assert (idx < 0).sum() == len(idx) - int(ref.sum())
 
 
 def test_unfused_stage_kernels(K, oracle):
