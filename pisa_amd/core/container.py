@@ -1,0 +1,526 @@
+"""`Container`, `ContainerSet`, `VirtualContainer`: the data contract between
+stages (counterpart of pisa/core/container.py:199-1012).
+
+Same public behaviour as the reference -- variables stored per representation
+("events", "log_events", or a `MultiDimBinning`), validity bits, automatic
+translation between representations on access, `mark_changed`, aux data,
+linking -- but every array is a `DualArray` that can live in host memory, in
+HBM, or both:
+
+    container[key]            -> numpy array (copied back from HBM if the device
+                                 copy is newer): what third-party services see
+    container.device(key)     -> torch device tensor (uploaded if the host copy
+                                 is newer): what the HIP stages use
+    container[key] = array    -> accepts numpy arrays or device tensors
+    container.mark_changed(k) -> host copy is authoritative again
+
+The translations themselves run on the GPU:
+    binned -> events   `pisa_hip_lookup_regular`     (container.py:981-1012)
+    events -> binned   `pisa_hip_histogram_regular`  (container.py:933-979)
+Log dimensions are looked up / histogrammed in ln-space exactly as the
+reference regularises them (container.py:950-958, 992-1005); irregular
+dimensions are digitised on the host once (np.searchsorted) and binned in index
+space.
+"""
+import re
+from collections import defaultdict
+from collections.abc import Sequence
+
+import numpy as np
+
+from pisa_amd import FTYPE, _lib
+from pisa_amd.core.binning import MultiDimBinning, OneDimBinning
+from pisa_amd.core.map import Map, MapSet
+
+__all__ = ["Container", "ContainerSet", "VirtualContainer", "DualArray"]
+
+
+def _is_tensor(x):
+    return hasattr(x, "is_cuda") and hasattr(x, "data_ptr")
+
+
+class DualArray:
+    """A variable's storage: host numpy and/or device tensor with validity."""
+
+    __slots__ = ("host", "dev", "host_valid", "dev_valid")
+
+    def __init__(self, data):
+        if _is_tensor(data):
+            self.host, self.dev = None, data.contiguous()
+            self.host_valid, self.dev_valid = False, True
+        else:
+            self.host, self.dev = np.asarray(data), None
+            self.host_valid, self.dev_valid = True, False
+
+    @property
+    def shape(self):
+        return tuple(self.dev.shape) if (self.dev_valid and not self.host_valid) else self.host.shape
+
+    def get_host(self):
+        if not self.host_valid:
+            self.host = self.dev.cpu().numpy()
+            self.host_valid = True
+        return self.host
+
+    def get_dev(self):
+        if not self.dev_valid:
+            from pisa_amd import kernels as K
+
+            h = self.host
+            self.dev = K.to_device(h, dtype=h.dtype if h.dtype in (np.int32, np.int64) else np.float64)
+            self.dev_valid = True
+        return self.dev
+
+    def host_changed(self):
+        self.dev_valid = False
+
+
+def regularized(binning, get_column):
+    """Linear, regular stand-in for `binning` plus matching sample columns.
+
+    get_column(name, log) must return the (host) event column `name`, or its
+    natural logarithm if `log`.  Log-uniform dimensions become linear in ln(x)
+    (container.py:950-958); irregular ones are digitised to a bin index
+    (utils/hist.py:100-113 does the same for the hist stage)."""
+    mins, maxs, nbins, cols = [], [], [], []
+    for d in binning:
+        if d.is_irregular:
+            edges = d.edge_magnitudes
+            x = np.asarray(get_column(d.name, False), dtype=FTYPE)
+            idx = (np.searchsorted(edges, x, side="right") - 1).astype(FTYPE)
+            idx[x == edges[-1]] -= 1  # numpy's closed last bin
+            idx[np.isnan(x)] = -1.0
+            cols.append(idx)
+            mins.append(0.0); maxs.append(float(d.num_bins)); nbins.append(d.num_bins)
+        elif d.is_log:
+            dom = np.log(d.domain.magnitude)
+            cols.append(get_column(d.name, True))
+            mins.append(dom[0]); maxs.append(dom[1]); nbins.append(d.num_bins)
+        else:
+            dom = d.domain.magnitude
+            cols.append(get_column(d.name, False))
+            mins.append(dom[0]); maxs.append(dom[1]); nbins.append(d.num_bins)
+    return _lib.make_binning(mins, maxs, nbins), cols
+
+
+class Container:
+    valid_translation_modes = ("average", "sum")
+    sum_mode_keys = ()
+    array_representations = ("events", "log_events")
+
+    def __init__(self, name, representation="events"):
+        self.name = name
+        self._representation = None
+        self.linked = False
+        self._aux_data = {}
+        self.validity = defaultdict(dict)
+        self.translation_modes = {}
+        self.data = defaultdict(dict)
+        self._representations = {}
+        self.precedence = defaultdict(int)
+        self.representation = representation
+
+    def __repr__(self):
+        return "Container containing keys %s" % self.all_keys
+
+    # -- representation ------------------------------------------------------
+    @property
+    def representation(self):
+        return self._representation
+
+    @representation.setter
+    def representation(self, representation):
+        key = hash(representation)
+        if key not in self._representations:
+            self._representations[key] = representation
+            if isinstance(representation, MultiDimBinning):
+                for name in representation.names:
+                    self.validity[name][key] = True
+            elif isinstance(representation, str):
+                if representation not in self.array_representations:
+                    raise ValueError("Unknown representation '%s'" % representation)
+        self._representation = representation
+        self.current_data = self.data[key]
+
+    representations = property(lambda self: tuple(self._representations.values()))
+    representation_keys = property(lambda self: tuple(self._representations.keys()))
+
+    @property
+    def is_map(self):
+        return isinstance(self._representation, MultiDimBinning)
+
+    @property
+    def shape(self):
+        if self.is_map:
+            return self._representation.shape
+        if len(self.keys) == 0:
+            return None
+        return self.current_data[self.keys[0]].shape[0:1]
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape))
+
+    @property
+    def num_dims(self):
+        return self._representation.num_dims if self.is_map else 1
+
+    @property
+    def keys(self):
+        keys = tuple(self.current_data.keys())
+        if self.is_map:
+            keys += tuple(self._representation.names)
+        return keys
+
+    keys_incl_aux_data = property(lambda self: list(self.keys) + list(self._aux_data.keys()))
+    all_keys = property(lambda self: list(self.validity.keys()))
+    all_keys_incl_aux_data = property(lambda self: self.all_keys + list(self._aux_data.keys()))
+
+    def set_aux_data(self, key, val):
+        if key in self.all_keys:
+            raise KeyError("Key %s already exsits" % key)
+        self._aux_data[key] = val
+
+    # -- validity --------------------------------------------------------------
+    def mark_changed(self, key):
+        for rep in self.validity[key]:
+            self.validity[key][rep] = False
+        if key in self.current_data:
+            self.mark_valid(key)
+            self.current_data[key].host_changed()
+
+    def mark_valid(self, key):
+        self.validity[key][hash(self._representation)] = True
+
+    def _invalidate_others(self, key):
+        for rep in self.validity[key]:
+            self.validity[key][rep] = False
+        self.mark_valid(key)
+
+    # -- access ------------------------------------------------------------------
+    def __getitem__(self, key):
+        arr = self._get(key)
+        return arr.get_host() if isinstance(arr, DualArray) else arr
+
+    def device(self, key):
+        """current-representation data as a device tensor"""
+        arr = self._get(key)
+        if isinstance(arr, DualArray):
+            return arr.get_dev()
+        from pisa_amd import kernels as K
+
+        return K.to_device(np.asarray(arr, dtype=FTYPE))
+
+    def _get(self, key):
+        if self.is_map and key in self._representation.names:
+            return DualArray(self.unroll_binning(key, self._representation))
+        if key not in self.current_data:
+            if key in self.validity:
+                self.auto_translate(key)
+            elif key in self._aux_data:
+                return self._aux_data[key]
+            else:
+                raise KeyError('Key "%s" not present in Container "%s"' % (key, self.name))
+        if not self.validity[key].get(hash(self._representation), False):
+            self.auto_translate(key)
+        return self.current_data[key]
+
+    def __setitem__(self, key, data):
+        if self.is_map and key in self._representation.names:
+            raise Exception("Cannot add variable %s, as it is a binning dimension" % key)
+        self._add_data(key, data)
+        if key not in self.translation_modes:
+            self.translation_modes[key] = "sum" if key in self.sum_mode_keys else "average"
+        self._invalidate_others(key)
+
+    def _add_data(self, key, data):
+        if isinstance(data, Map):
+            assert hash(self._representation) == hash(data.binning)
+            self.current_data[key] = DualArray(data.hist.ravel())
+            return
+        if isinstance(data, Sequence) and not isinstance(data, np.ndarray) and len(data) == 2 \
+                and isinstance(data[0], MultiDimBinning):
+            binning, data = data
+            assert hash(self._representation) == hash(binning)
+        if not (isinstance(data, np.ndarray) or _is_tensor(data)):
+            raise TypeError("unknown dataformat")
+        if self.is_map:
+            b = self._representation
+            shape = tuple(data.shape)
+            if shape[0] != b.size:
+                assert shape[: b.num_dims] == b.shape, "Incompatible dimensions"
+                tail = shape[b.num_dims:]
+                data = data.reshape((b.size,) + tuple(tail))
+        else:
+            cur = self.shape
+            if cur is not None:
+                assert tuple(data.shape[:1]) == tuple(cur), "Incompatible dimensions"
+        self.current_data[key] = DualArray(data)
+
+    @staticmethod
+    def unroll_binning(key, binning):
+        grid = binning.meshgrid(entity="weighted_centers", attach_units=False)
+        return grid[binning.index(key)].ravel()
+
+    def get_hist(self, key):
+        assert self.is_map, "Cannot retrieve hists from non-map data"
+        data = self[key]
+        binning = self._representation
+        full = list(binning.shape) + ([-1] if data.ndim > 1 else [])
+        return data.reshape(full), binning
+
+    def get_map(self, key, error=None):
+        hist, binning = self.get_hist(key)
+        error_hist = np.abs(self.get_hist(error)[0]) if error is not None else None
+        assert hist.ndim == binning.num_dims
+        return Map(name=self.name, hist=hist, error_hist=error_hist, binning=binning)
+
+    # -- translation ------------------------------------------------------------
+    def find_valid_representation(self, key):
+        best, prec = None, np.inf
+        for h, ok in self.validity[key].items():
+            if ok and self.precedence[h] < prec:
+                prec, best = self.precedence[h], self._representations[h]
+        return best
+
+    def auto_translate(self, key):
+        src = self.find_valid_representation(key)
+        if src is None:
+            raise Exception("No valid representation for %s in container" % key)
+        self.translate(key, src)
+
+    def _column(self, name, log):
+        """event column (or its log) as a DEVICE tensor; logs are taken on the host
+        with numpy like the reference's cached 'log_events' representation"""
+        keep = self._representation
+        try:
+            self.representation = "log_events" if log else "events"
+            return self.device(name)
+        finally:
+            self.representation = keep
+
+    def _host_column(self, name, log):
+        keep = self._representation
+        try:
+            self.representation = "log_events" if log else "events"
+            return self[name]
+        finally:
+            self.representation = keep
+
+    def translate(self, key, src_representation):
+        assert hash(src_representation) in self._representations
+        dest = self._representation
+        if hash(src_representation) == hash(dest):
+            return
+        from_map = isinstance(src_representation, MultiDimBinning)
+        to_map = isinstance(dest, MultiDimBinning)
+        mode = self.translation_modes[key]
+        if mode not in self.valid_translation_modes:
+            raise ValueError("Unknown translation mode for variable '%s': '%s'!" % (key, mode))
+        if from_map and to_map:
+            raise NotImplementedError("map -> map resampling is not part of this build")
+        if to_map:
+            out = self.array_to_binned(key, src_representation, dest, averaged=(mode == "average"))
+        elif mode == "sum":
+            raise NotImplementedError("Translating %s to %s in 'sum' mode!" % (src_representation, dest))
+        elif from_map:
+            out = self.binned_to_array(key, src_representation, dest)
+        elif src_representation == "events" and dest == "log_events":
+            self.representation = "events"
+            out = np.log(self[key])
+        elif src_representation == "log_events" and dest == "events":
+            self.representation = "log_events"
+            out = np.exp(self[key])
+        else:
+            raise NotImplementedError("Translating %s to %s" % (src_representation, dest))
+        self.representation = dest
+        self._add_data(key, out)
+        self.validity[key][hash(dest)] = True
+        self.validity[key][hash(src_representation)] = True
+
+    def array_to_binned(self, key, src_representation, dest_representation, averaged=True):
+        """events -> map (container.py:933-979) on the GPU"""
+        from pisa_amd import kernels as K
+
+        assert src_representation in self.array_representations
+        self.representation = src_representation
+        weights = self.device(key)
+        needs_host = any(d.is_irregular for d in dest_representation)
+        if needs_host:
+            b, cols = regularized(dest_representation, self._host_column)
+            cols = [K.to_device(c) for c in cols]
+        else:
+            b, cols = regularized(dest_representation, self._column)
+        if weights.dim() == 2:
+            import torch
+
+            outs = [K.histogram_regular(cols, weights[:, i].contiguous(), b, averaged=averaged)
+                    for i in range(weights.shape[1])]
+            return torch.stack(outs, dim=1)
+        return K.histogram_regular(cols, weights, b, averaged=averaged)
+
+    def binned_to_array(self, key, src_representation, dest_representation):
+        """map -> events nearest-bin lookup (container.py:981-1012) on the GPU"""
+        from pisa_amd import kernels as K
+
+        self.representation = src_representation
+        flat = self.device(key)
+        self.representation = dest_representation
+        needs_host = any(d.is_irregular for d in src_representation)
+        if needs_host:
+            b, cols = regularized(src_representation, self._host_column)
+            cols = [K.to_device(c) for c in cols]
+        else:
+            b, cols = regularized(src_representation, self._column)
+        return K.lookup_regular(cols, flat, b)
+
+    def get_keep_mask(self, keep_criteria):
+        assert isinstance(keep_criteria, str)
+        for var in self.keys:
+            keep_criteria = re.sub(r"\b%s\b" % var, 'self["%s"]' % var, keep_criteria)
+        return eval(keep_criteria)  # pylint: disable=eval-used
+
+
+class VirtualContainer:
+    """Linked containers behave as one for binned data (container.py:363-448)."""
+
+    def __init__(self, name, containers):
+        self.name = name
+        for c in containers:
+            if c.linked:
+                raise ValueError("Cannot link container %s since it is already linked" % c.name)
+            c.linked = True
+        self.containers = containers
+
+    def __repr__(self):
+        return "VirtualContainer containing %s" % [c.name for c in self]
+
+    def unlink(self):
+        for c in self:
+            c.linked = False
+
+    def __iter__(self):
+        return iter(self.containers)
+
+    def __getitem__(self, key):
+        return self.containers[0][key]
+
+    def device(self, key):
+        return self.containers[0].device(key)
+
+    def __setitem__(self, key, value):
+        for c in self:
+            c[key] = value
+
+    def set_aux_data(self, key, val):
+        for c in self:
+            c.set_aux_data(key, val)
+
+    def mark_changed(self, key):
+        # one array is shared by all linked containers (the reference copies it
+        # 5 times, container.py:415-423; sharing is equivalent for readers)
+        src = self.containers[0]
+        arr = src.current_data.get(key)
+        for c in self.containers[1:]:
+            if arr is not None:
+                c.current_data[key] = arr
+                if key not in c.translation_modes:
+                    c.translation_modes[key] = src.translation_modes.get(key, "average")
+        for c in self:
+            c.mark_changed(key)
+
+    def mark_valid(self, key):
+        for c in self:
+            c.mark_valid(key)
+
+    @property
+    def representation(self):
+        return self.containers[0].representation
+
+    @representation.setter
+    def representation(self, representation):
+        for c in self:
+            c.representation = representation
+
+    shape = property(lambda self: self.containers[0].shape)
+    size = property(lambda self: int(np.prod(self.shape)))
+
+
+class ContainerSet:
+    def __init__(self, name, containers=None, representation=None):
+        self.name = name
+        self.linked_containers = []
+        self.containers = []
+        for c in containers or []:
+            self.add_container(c)
+        self._glob_aux_data = {}
+        self.representation = representation
+
+    def __repr__(self):
+        return "ContainerSet containing %s" % [c.name for c in self]
+
+    @property
+    def is_map(self):
+        if len(self.containers):
+            return self.containers[0].is_map
+        return None
+
+    def add_container(self, container):
+        if container.name in self.names:
+            raise ValueError("container with name %s already exists" % container.name)
+        self.containers.append(container)
+
+    @property
+    def representation(self):
+        return self._representation
+
+    @representation.setter
+    def representation(self, representation):
+        self._representation = representation
+        for c in self:
+            c.representation = representation
+
+    names = property(lambda self: [c.name for c in self.containers])
+
+    def get_shared_keys(self, rep_indep=True):
+        if len(self.containers) == 0:
+            return ()
+        return tuple(set.intersection(*[
+            set(c.all_keys_incl_aux_data if rep_indep else c.keys_incl_aux_data)
+            for c in self.containers]))
+
+    def link_containers(self, key, names):
+        link_names = [n for n in names if n in self.names]
+        containers = [self[n] for n in link_names]
+        if containers:
+            self.linked_containers.append(VirtualContainer(key, containers))
+
+    def unlink_containers(self):
+        for c in self.linked_containers:
+            c.unlink()
+        self.linked_containers = []
+
+    def __getitem__(self, key):
+        if key in self.names:
+            return self.containers[self.names.index(key)]
+        for c in self.linked_containers:
+            if c.name == key:
+                return c
+        if key in self._glob_aux_data:
+            return self._glob_aux_data[key]
+        raise KeyError("No name `%s` in container" % key)
+
+    def __setitem__(self, key, data):
+        if key in self.names:
+            raise KeyError("`%s` is a container name." % key)
+        if key in [c.name for c in self.linked_containers]:
+            raise KeyError("`%s` is a linked container name and can't be overwritten." % key)
+        self._glob_aux_data[key] = data
+
+    def __iter__(self):
+        return iter([c for c in self.containers if not c.linked] + self.linked_containers)
+
+    def get_mapset(self, key, error=None):
+        return MapSet(name=self.name, maps=[c.get_map(key, error=error) for c in self])
+
+    glob_aux_data_keys = property(lambda self: self._glob_aux_data.keys())

@@ -25,6 +25,8 @@
 //                pre-digitised irregular dimensions, utils/hist.py:100-113)
 // and the coordinate form reads 8 B x (2 lookup coords + D sample coords) more
 // = 72 B (D=3).  The (P_e, P_mu) gather tables (<= 3.8 MB) stay in L2.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace pisa {
@@ -124,6 +126,7 @@ struct HistArgs {
     const double2 *pepmu;    // optional compact tables [side][flav][node] = (P_e->f, P_mu->f)
     ContDev cont[MAX_CONT];
     int32_t blk_start[MAX_CONT + 1];
+    int32_t dbg;          // development probe (PISA_HIP_HIST_DBG): 1 skip sumw2, 2 skip all deposits
 };
 
 // MODE 0: generic histogram (weights or counts; quantities (w, 1))
@@ -161,8 +164,12 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
             if (LDS_ACC) atomicAdd(&s_acc[(j * 2 + 1) * n_bins + bin], q);
             else atomicAdd(&g_out[((int64_t)bin * 2 + 1) * NL + j], (unsigned long long)slab_to_units(q, j));
         };
+        if (a.dbg & 2) {  // probe: keep the loads and the weight chain alive, no atomics
+            if (w == 1.2345e-300 || w2 == 1.2345e-300) bad = true;
+            return;
+        }
         bool ok = deposit(w, add0);
-        ok = deposit(w2, add1) && ok;
+        if (!(a.dbg & 1)) ok = deposit(w2, add1) && ok;
         if (!ok) bad = true;
     };
 
@@ -397,6 +404,10 @@ static int run_hist(const ContDev *conts, int n_cont, int mode, const DevBinning
         a.prob[0] = prob_nu;
         a.prob[1] = prob_nubar;
         a.pepmu = reinterpret_cast<const double2 *>(pepmu);
+        {
+            const char *dbg = getenv("PISA_HIP_HIST_DBG");
+            a.dbg = dbg ? atoi(dbg) : 0;
+        }
         int64_t nev[MAX_CONT];
         for (int c = 0; c < nc; c++) { a.cont[c] = conts[base + c]; nev[c] = conts[base + c].n; }
         int nblocks = plan_blocks(nev, nc, a.chunk, a.blk_start);
