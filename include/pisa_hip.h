@@ -197,6 +197,8 @@ typedef struct {
     const double *d_sample[PISA_HIP_MAX_DIMS]; /* output-binning coordinates, regularised */
     const int32_t *d_node;           /* [n] calc-grid node of each event, -1 outside (optional) */
     const int32_t *d_bin;            /* [n] output bin of each event, -1 outside (optional)     */
+    const int32_t *d_node_bin;       /* [n][2] the two above interleaved (optional, fastest)    */
+    const double *d_aeff_w0;         /* [n][2] (weighted_aeff, initial_weights) interleaved (opt.) */
     int32_t flav;                    /* 0 e, 1 mu, 2 tau  (aux 'flav')                     */
     int32_t nubar;                   /* +1 / -1           (aux 'nubar')                    */
     double scale;                    /* aeff_scale*livetime_s*norms (aeff.py:78-86)        */

@@ -68,6 +68,8 @@ class Container(C.Structure):
         ("d_sample", C.c_void_p * MAX_DIMS),
         ("d_node", C.c_void_p),
         ("d_bin", C.c_void_p),
+        ("d_node_bin", C.c_void_p),
+        ("d_aeff_w0", C.c_void_p),
         ("flav", C.c_int32),
         ("nubar", C.c_int32),
         ("scale", C.c_double),

@@ -110,6 +110,8 @@ struct ContDev {
     const double *gx, *gy, *flux, *aeff, *w0;
     const double *s[3];
     const int32_t *node, *bin;  // optional pre-digitised indices
+    const int2 *node_bin;       // optional packed (node, bin) per event
+    const double2 *aeff_w0;     // optional packed (weighted_aeff, initial_weights) per event
     double scale;
     int32_t flav, side;
 };
@@ -133,10 +135,11 @@ struct HistArgs {
 // MODE 1: fused reweight chain from coordinates (quantities (w, w^2))
 // MODE 2: fused reweight chain from pre-digitised indices, 2 events / thread / sweep
 template <int MODE, bool LDS_ACC>
-__global__ void __launch_bounds__(HIST_THREADS)
+__global__ void __launch_bounds__(1024)
 hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limbs,
                        int32_t *__restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double s_acc[];  // [slab][quantity][bin]
+    const int nthreads = blockDim.x;
     int c = 0;
     const int bid = blockIdx.x;
     while (c + 1 < a.n_cont && bid >= a.blk_start[c + 1]) c++;  // workgroup-uniform
@@ -150,7 +153,7 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
     unsigned long long *g_out = g_limbs + (int64_t)(a.cont_base + c) * a.n_bins * 2 * NL;
 
     if (LDS_ACC) {
-        for (int k = threadIdx.x; k < n_acc; k += HIST_THREADS) s_acc[k] = 0.0;
+        for (int k = threadIdx.x; k < n_acc; k += nthreads) s_acc[k] = 0.0;
         __syncthreads();
     }
     bool bad = false;
@@ -173,7 +176,45 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
         if (!ok) bad = true;
     };
 
-    if (MODE == 2) {
+    if (MODE == 3) {
+        // packed columns: (node, bin) int2 and (aeff, w0) double2 per event; every load is 16 B
+        const double2 *tab = a.pepmu + ((int64_t)C.side * 3 + C.flav) * a.n_nodes;
+        const double scale = C.scale;
+        const int64_t p0 = start >> 1, p1 = end >> 1;
+        const int4 *idx4 = reinterpret_cast<const int4 *>(C.node_bin);
+        const double2 *aw = C.aeff_w0;
+        const double2 *flux2 = reinterpret_cast<const double2 *>(C.flux);
+        for (int64_t p = p0 + threadIdx.x; p < p1; p += nthreads) {
+            const int4 ix = idx4[p];  // node0, bin0, node1, bin1
+            const double2 awa = aw[2 * p], awb = aw[2 * p + 1];
+            const double2 fa = flux2[2 * p], fb = flux2[2 * p + 1];
+            double2 pa = make_double2(0.0, 0.0), pb = make_double2(0.0, 0.0);
+            if (ix.x >= 0) pa = tab[ix.x];
+            if (ix.z >= 0) pb = tab[ix.z];
+            if (ix.y >= 0) {
+                double w = awa.y * ((fa.x * pa.x) + (fa.y * pa.y));  // prob3.py:622
+                w = w * (awa.x * scale);                             // aeff.py:87
+                accumulate(ix.y, w, w * w);
+            }
+            if (ix.w >= 0) {
+                double w = awb.y * ((fb.x * pb.x) + (fb.y * pb.y));
+                w = w * (awb.x * scale);
+                accumulate(ix.w, w, w * w);
+            }
+        }
+        if ((end & 1) && threadIdx.x == 0 && end > start) {  // odd tail of the container
+            const int64_t i = end - 1;
+            const int2 ix = C.node_bin[i];
+            if (ix.y >= 0) {
+                double2 pp = ix.x >= 0 ? tab[ix.x] : make_double2(0.0, 0.0);
+                double2 f = flux2[i];
+                double2 x = aw[i];
+                double w = x.y * ((f.x * pp.x) + (f.y * pp.y));
+                w = w * (x.x * scale);
+                accumulate(ix.y, w, w * w);
+            }
+        }
+    } else if (MODE == 2) {
         // (P_e, P_mu) of this container's class, one 16-B gather per event
         const double2 *tab = a.pepmu + ((int64_t)C.side * 3 + C.flav) * a.n_nodes;
         const double scale = C.scale;
@@ -183,7 +224,7 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
         const double2 *aeff2 = reinterpret_cast<const double2 *>(C.aeff);
         const double2 *w02 = reinterpret_cast<const double2 *>(C.w0);
         const double2 *flux2 = reinterpret_cast<const double2 *>(C.flux);
-        for (int64_t p = p0 + threadIdx.x; p < p1; p += HIST_THREADS) {
+        for (int64_t p = p0 + threadIdx.x; p < p1; p += nthreads) {
             const int2 nd = node2[p];
             const int2 bn = bin2[p];
             const double2 ae = aeff2[p];
@@ -218,7 +259,7 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
         const double *prob = MODE == 1 ? a.prob[C.side] : nullptr;
         const int po_e = 0 * 3 + C.flav;   // P[e  -> flav]
         const int po_mu = 1 * 3 + C.flav;  // P[mu -> flav]
-        for (int64_t i = start + threadIdx.x; i < end; i += HIST_THREADS) {
+        for (int64_t i = start + threadIdx.x; i < end; i += nthreads) {
             double w;
             if (MODE == 1) {
                 // grid -> event lookup of prob_e, prob_mu (container.py:981-1012,
@@ -246,10 +287,10 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
     }
     if (bad && status) atomicOr(status, 1);
 
-    if (LDS_ACC) {
+    if (LDS_ACC && !(a.dbg & 4)) {
         __syncthreads();
         // slab accumulators -> integer units, added to the global limbs
-        for (int k = threadIdx.x; k < n_acc; k += HIST_THREADS) {
+        for (int k = threadIdx.x; k < n_acc; k += nthreads) {
             const double v = s_acc[k];
             if (v != 0.0) {
                 const int j = k / (2 * n_bins);
@@ -362,15 +403,21 @@ apply_aeff_kernel(const double *__restrict__ aeff, double scale, int64_t n,
 // ---------------------------------------------------------------- host side
 static int64_t lds_acc_bytes(int64_t n_bins) { return n_bins * 2 * NL * 8; }
 
-static int plan_blocks(const int64_t *n_events, int n_cont, int64_t &chunk, int32_t *blk_start) {
+static int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+static int plan_blocks(const int64_t *n_events, int n_cont, int threads, int64_t &chunk,
+                       int32_t *blk_start) {
     int64_t total = 0;
     for (int c = 0; c < n_cont; c++) total += n_events[c];
-    // ~4 workgroups per CU; a chunk is a whole number of 512-event sweeps
-    const int64_t target_blocks = 1024;
+    // a few workgroups per CU; a chunk is a whole number of two-event sweeps
+    const int64_t target_blocks = env_int("PISA_HIP_HIST_BLOCKS", 1024);
     chunk = (total + target_blocks - 1) / target_blocks;
     if (chunk < 4096) chunk = 4096;
     if (chunk > (1 << 18)) chunk = 1 << 18;  // keeps every slab accumulator exact (< 2^53 units)
-    const int64_t q = 2 * HIST_THREADS;
+    const int64_t q = 2 * threads;
     chunk = ((chunk + q - 1) / q) * q;
     blk_start[0] = 0;
     for (int c = 0; c < n_cont; c++) {
@@ -410,14 +457,17 @@ static int run_hist(const ContDev *conts, int n_cont, int mode, const DevBinning
         }
         int64_t nev[MAX_CONT];
         for (int c = 0; c < nc; c++) { a.cont[c] = conts[base + c]; nev[c] = conts[base + c].n; }
-        int nblocks = plan_blocks(nev, nc, a.chunk, a.blk_start);
+        int threads = env_int("PISA_HIP_HIST_THREADS", HIST_THREADS);
+        if (threads < 64 || threads > 1024 || (threads & 63)) threads = HIST_THREADS;
+        int nblocks = plan_blocks(nev, nc, threads, a.chunk, a.blk_start);
         if (nblocks <= 0) continue;
-        dim3 grid_dim((unsigned)nblocks), block(HIST_THREADS);
+        dim3 grid_dim((unsigned)nblocks), block(threads);
         size_t shmem = lds ? (size_t)lds_bytes : 0;
         unsigned long long *out = reinterpret_cast<unsigned long long *>(d_limbs);
         if (g_prof_start) PISA_TRY_HIP(hipEventRecord(g_prof_start, s));
 #define LAUNCH(M, L) hipLaunchKernelGGL((hist_accumulate_kernel<M, L>), grid_dim, block, shmem, s, a, out, d_status)
-        if (mode == 2) { if (lds) LAUNCH(2, true); else LAUNCH(2, false); }
+        if (mode == 3) { if (lds) LAUNCH(3, true); else LAUNCH(3, false); }
+        else if (mode == 2) { if (lds) LAUNCH(2, true); else LAUNCH(2, false); }
         else if (mode == 1) { if (lds) LAUNCH(1, true); else LAUNCH(1, false); }
         else { if (lds) LAUNCH(0, true); else LAUNCH(0, false); }
 #undef LAUNCH
@@ -472,19 +522,23 @@ PISA_API int pisa_hip_reweight_hist(const pisa_hip_container *h_containers, int3
     if ((rc = make_dev_binning(h_out_binning, outb, n_bins))) return rc;
     ContDev *conts = new ContDev[n_containers];
     bool all_indexed = d_pepmu != nullptr;
+    bool all_packed = d_pepmu != nullptr;
     for (int c = 0; c < n_containers; c++) {
         const pisa_hip_container &h = h_containers[c];
         ContDev &d = conts[c];
-        bool indexed = h.d_node && h.d_bin;
+        bool packed = h.d_node_bin && h.d_aeff_w0;
+        bool indexed = packed || (h.d_node && h.d_bin);
         bool bad = h.n_events < 0 || h.flav < 0 || h.flav > 2 || (h.nubar != 1 && h.nubar != -1);
         if (h.n_events > 0) {
-            bad = bad || !h.d_nu_flux || !h.d_weighted_aeff || !h.d_initial_weights;
+            bad = bad || !h.d_nu_flux;
+            if (!(packed && d_pepmu)) bad = bad || !h.d_weighted_aeff || !h.d_initial_weights;
             if (!(indexed && d_pepmu)) {
                 bad = bad || !h.d_grid_x || (grid.ndim > 1 && !h.d_grid_y);
                 for (int k = 0; k < outb.ndim; k++) bad = bad || !h.d_sample[k];
                 bad = bad || (h.nubar > 0 ? !d_prob_nu : !d_prob_nubar);
             }
-            all_indexed = all_indexed && indexed;
+            all_indexed = all_indexed && indexed && (h.d_node && h.d_bin);
+            all_packed = all_packed && packed;
         }
         if (bad) { delete[] conts; return PISA_HIP_ERR_INVALID; }
         d.n = h.n_events;
@@ -492,11 +546,13 @@ PISA_API int pisa_hip_reweight_hist(const pisa_hip_container *h_containers, int3
         d.w0 = h.d_initial_weights;
         for (int k = 0; k < 3; k++) d.s[k] = h.d_sample[k];
         d.node = h.d_node; d.bin = h.d_bin;
+        d.node_bin = reinterpret_cast<const int2 *>(h.d_node_bin);
+        d.aeff_w0 = reinterpret_cast<const double2 *>(h.d_aeff_w0);
         d.scale = h.scale;
         d.flav = h.flav;
         d.side = h.nubar > 0 ? 0 : 1;
     }
-    rc = run_hist(conts, n_containers, all_indexed ? 2 : 1, &grid, n_nodes, d_prob_nu, d_prob_nubar,
+    rc = run_hist(conts, n_containers, all_packed ? 3 : (all_indexed ? 2 : 1), &grid, n_nodes, d_prob_nu, d_prob_nubar,
                   d_pepmu, outb, n_bins, (long long *)d_limbs, d_status, as_stream(stream));
     delete[] conts;
     return rc;
@@ -541,6 +597,7 @@ PISA_API int pisa_hip_histogram_regular(const pisa_hip_binning *h_binning,
         c.n = n; c.gx = c.gy = c.flux = c.aeff = nullptr; c.w0 = d_weights;
         for (int k = 0; k < 3; k++) c.s[k] = k < outb.ndim ? h_d_sample[k] : nullptr;
         c.node = c.bin = nullptr;
+        c.node_bin = nullptr; c.aeff_w0 = nullptr;
         c.scale = 1.0; c.flav = 0; c.side = 0;
         rc = run_hist(&c, 1, 0, nullptr, 0, nullptr, nullptr, nullptr, outb, n_bins, limbs, st, s);
     }

@@ -60,7 +60,7 @@ class HotPathEngine:
     scale."""
 
     def __init__(self, containers, grid, out_binning, earth, max_layers, rank=0, world_size=1,
-                 group=None, indexed=True, planned=True):
+                 group=None, indexed=True, planned=True, packed=True):
         self.dev = K.device()
         self.grid = grid
         self.out_binning = out_binning
@@ -83,8 +83,9 @@ class HotPathEngine:
             gx, gy = (lnE, cz) if grid.energy_first else (cz, lnE)
             d.d_grid_x, d.d_grid_y = gx.data_ptr(), gy.data_ptr()
             d.d_nu_flux = self._up(np.asarray(c["nu_flux"], dtype=np.float64)[sl]).data_ptr()
-            d.d_weighted_aeff = self._up(np.asarray(c["weighted_aeff"])[sl]).data_ptr()
-            d.d_initial_weights = self._up(np.asarray(c["initial_weights"])[sl]).data_ptr()
+            aeff_d = self._up(np.asarray(c["weighted_aeff"])[sl])
+            w0_d = self._up(np.asarray(c["initial_weights"])[sl])
+            d.d_weighted_aeff, d.d_initial_weights = aeff_d.data_ptr(), w0_d.data_ptr()
             cols = [self._up(np.asarray(col)[sl]) for col in c["sample"]]
             for k, col in enumerate(cols):
                 d.d_sample[k] = col.data_ptr()
@@ -94,6 +95,12 @@ class HotPathEngine:
                 obin = K.event_indices(cols, out_binning)
                 self._keep += [node, obin]
                 d.d_node, d.d_bin = node.data_ptr(), obin.data_ptr()
+                if packed:
+                    # interleaved columns: every load of the fused kernel is 16 bytes
+                    nb = torch.stack([node, obin], dim=1).contiguous()
+                    aw = torch.stack([aeff_d, w0_d], dim=1).contiguous()
+                    self._keep += [nb, aw]
+                    d.d_node_bin, d.d_aeff_w0 = nb.data_ptr(), aw.data_ptr()
             d.flav, d.nubar, d.scale = int(c["flav"]), int(c["nubar"]), float(c["scale"])
             self.cont.append(d)
         self._cont_arr = (_lib.Container * len(self.cont))(*self.cont)
