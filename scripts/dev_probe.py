@@ -26,16 +26,16 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for packed in (False, True):
-    st = synthetic.DeviceState(wl, packed=packed)
+for packed, srt in ((True, False), (True, True), (False, True)):
+    st = synthetic.DeviceState(wl, packed=packed, sort_events=srt)
     st.eval(p)
-    for blocks, threads in ((1024, 256), (2048, 256), (512, 512), (1024, 512), (256, 1024), (512, 1024)):
+    for blocks, threads in ((1024, 256), (512, 512), (256, 1024), (512, 1024), (768, 1024)):
         os.environ["PISA_HIP_HIST_BLOCKS"] = str(blocks)
         os.environ["PISA_HIP_HIST_THREADS"] = str(threads)
         res = []
         for dbg in ("0", "4", "2"):
             os.environ["PISA_HIP_HIST_DBG"] = dbg
             res.append(timeit(lambda: st.accumulate()))
-        print("packed=%d blocks=%4d threads=%4d : full %.1f us | no-flush %.1f | no-atomics %.1f"
-              % (packed, blocks, threads, *res))
+        print("sorted=%d packed=%d blocks=%4d threads=%4d : full %.1f us | no-flush %.1f | no-atomics %.1f"
+              % (srt, packed, blocks, threads, *res))
     del st
