@@ -128,6 +128,7 @@ struct HistArgs {
     const double2 *pepmu;    // optional compact tables [side][flav][node] = (P_e->f, P_mu->f)
     ContDev cont[MAX_CONT];
     int32_t blk_start[MAX_CONT + 1];
+    int32_t copies;       // LDS replicas of the accumulators (power of two), lane-interleaved
     int32_t dbg;          // development probe (PISA_HIP_HIST_DBG): 1 skip sumw2, 2 skip all deposits
 };
 
@@ -150,21 +151,24 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
     if (end > C.n) end = C.n;
     const int n_bins = (int)a.n_bins;
     const int n_acc = NL * 2 * n_bins;
+    // replica used by this lane: neighbouring lanes (neighbouring, i.e. correlated,
+    // events) add into different copies, which cuts same-address serialisation
+    double *my_acc = s_acc + (LDS_ACC ? (int)(threadIdx.x & (a.copies - 1)) * n_acc : 0);
     unsigned long long *g_out = g_limbs + (int64_t)(a.cont_base + c) * a.n_bins * 2 * NL;
 
     if (LDS_ACC) {
-        for (int k = threadIdx.x; k < n_acc; k += nthreads) s_acc[k] = 0.0;
+        for (int k = threadIdx.x; k < n_acc * a.copies; k += nthreads) s_acc[k] = 0.0;
         __syncthreads();
     }
     bool bad = false;
 
     auto accumulate = [&](int bin, double w, double w2) {
         auto add0 = [&](int j, double q) {
-            if (LDS_ACC) atomicAdd(&s_acc[(j * 2 + 0) * n_bins + bin], q);
+            if (LDS_ACC) atomicAdd(&my_acc[(j * 2 + 0) * n_bins + bin], q);
             else atomicAdd(&g_out[((int64_t)bin * 2 + 0) * NL + j], (unsigned long long)slab_to_units(q, j));
         };
         auto add1 = [&](int j, double q) {
-            if (LDS_ACC) atomicAdd(&s_acc[(j * 2 + 1) * n_bins + bin], q);
+            if (LDS_ACC) atomicAdd(&my_acc[(j * 2 + 1) * n_bins + bin], q);
             else atomicAdd(&g_out[((int64_t)bin * 2 + 1) * NL + j], (unsigned long long)slab_to_units(q, j));
         };
         if (a.dbg & 2) {  // probe: keep the loads and the weight chain alive, no atomics
@@ -291,7 +295,8 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
         __syncthreads();
         // slab accumulators -> integer units, added to the global limbs
         for (int k = threadIdx.x; k < n_acc; k += nthreads) {
-            const double v = s_acc[k];
+            double v = s_acc[k];
+            for (int r = 1; r < a.copies; r++) v += s_acc[r * n_acc + k];  // exact
             if (v != 0.0) {
                 const int j = k / (2 * n_bins);
                 const int rem = k - j * 2 * n_bins;
@@ -438,6 +443,10 @@ static int run_hist(const ContDev *conts, int n_cont, int mode, const DevBinning
     if (n_bins > (1 << 28)) return PISA_HIP_ERR_INVALID;
     const int64_t lds_bytes = lds_acc_bytes(n_bins);
     const bool lds = lds_bytes <= LDS_ACC_BYTES_MAX;
+    int copies = env_int("PISA_HIP_HIST_COPIES", 4);
+    while (copies > 1 && (copies & (copies - 1))) copies--;
+    while (copies > 1 && lds_bytes * copies > LDS_ACC_BYTES_MAX) copies >>= 1;
+    if (copies < 1) copies = 1;
     PISA_TRY_HIP(hipMemsetAsync(d_limbs, 0, (size_t)n_cont * n_bins * 2 * NL * 8, s));
     for (int base = 0; base < n_cont; base += MAX_CONT) {
         int nc = n_cont - base < MAX_CONT ? n_cont - base : MAX_CONT;
@@ -462,7 +471,8 @@ static int run_hist(const ContDev *conts, int n_cont, int mode, const DevBinning
         int nblocks = plan_blocks(nev, nc, threads, a.chunk, a.blk_start);
         if (nblocks <= 0) continue;
         dim3 grid_dim((unsigned)nblocks), block(threads);
-        size_t shmem = lds ? (size_t)lds_bytes : 0;
+        size_t shmem = lds ? (size_t)lds_bytes * copies : 0;
+        a.copies = lds ? copies : 1;
         unsigned long long *out = reinterpret_cast<unsigned long long *>(d_limbs);
         if (g_prof_start) PISA_TRY_HIP(hipEventRecord(g_prof_start, s));
 #define LAUNCH(M, L) hipLaunchKernelGGL((hist_accumulate_kernel<M, L>), grid_dim, block, shmem, s, a, out, d_status)

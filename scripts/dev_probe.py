@@ -26,16 +26,18 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for packed, srt in ((True, False), (True, True), (False, True)):
+for packed, srt in ((True, True),):
     st = synthetic.DeviceState(wl, packed=packed, sort_events=srt)
     st.eval(p)
-    for blocks, threads in ((1024, 256), (512, 512), (256, 1024), (512, 1024), (768, 1024)):
+    for blocks, threads, copies in ((1024, 256, 1), (1024, 256, 2), (1024, 256, 4), (768, 512, 4), (512, 1024, 4),
+                                    (768, 1024, 4), (768, 1024, 2), (1536, 256, 4), (2048, 256, 4)):
         os.environ["PISA_HIP_HIST_BLOCKS"] = str(blocks)
         os.environ["PISA_HIP_HIST_THREADS"] = str(threads)
+        os.environ["PISA_HIP_HIST_COPIES"] = str(copies)
         res = []
         for dbg in ("0", "4", "2"):
             os.environ["PISA_HIP_HIST_DBG"] = dbg
             res.append(timeit(lambda: st.accumulate()))
-        print("sorted=%d packed=%d blocks=%4d threads=%4d : full %.1f us | no-flush %.1f | no-atomics %.1f"
-              % (srt, packed, blocks, threads, *res))
+        print("sorted=%d packed=%d copies=%d blocks=%4d threads=%4d : full %.1f us | no-flush %.1f | no-atomics %.1f"
+              % (srt, packed, copies, blocks, threads, *res))
     del st
