@@ -34,7 +34,7 @@ namespace pisa {
 constexpr int NL = PISA_HIP_ACC_LIMBS;  // slabs ("limbs") per accumulator
 constexpr int FX_LSB = 116;             // value = sum limb_j * 2^(32j - 116)
 constexpr int MAX_CONT = 16;            // containers per launch (kernarg budget)
-constexpr int HIST_THREADS = 256;
+constexpr int HIST_THREADS = 1024;
 constexpr int64_t LDS_ACC_BYTES_MAX = 64 * 1024;
 
 // ---------------------------------------------------------------------------
@@ -418,7 +418,7 @@ static int plan_blocks(const int64_t *n_events, int n_cont, int threads, int64_t
     int64_t total = 0;
     for (int c = 0; c < n_cont; c++) total += n_events[c];
     // a few workgroups per CU; a chunk is a whole number of two-event sweeps
-    const int64_t target_blocks = env_int("PISA_HIP_HIST_BLOCKS", 1024);
+    const int64_t target_blocks = env_int("PISA_HIP_HIST_BLOCKS", 768);
     chunk = (total + target_blocks - 1) / target_blocks;
     if (chunk < 4096) chunk = 4096;
     if (chunk > (1 << 18)) chunk = 1 << 18;  // keeps every slab accumulator exact (< 2^53 units)
@@ -466,7 +466,7 @@ static int run_hist(const ContDev *conts, int n_cont, int mode, const DevBinning
         }
         int64_t nev[MAX_CONT];
         for (int c = 0; c < nc; c++) { a.cont[c] = conts[base + c]; nev[c] = conts[base + c].n; }
-        int threads = env_int("PISA_HIP_HIST_THREADS", HIST_THREADS);
+        int threads = env_int("PISA_HIP_HIST_THREADS", 1024);
         if (threads < 64 || threads > 1024 || (threads & 63)) threads = HIST_THREADS;
         int nblocks = plan_blocks(nev, nc, threads, a.chunk, a.blk_start);
         if (nblocks <= 0) continue;

@@ -12,6 +12,8 @@
 //
 // Roofline: all of these are FP64-VALU / transcendental bound (~16 kflop per
 // element against <= 88 B of traffic); there is no dense contraction, so no MFMA.
+#include <string.h>
+
 #include "common.hpp"
 #include "prob3_device.hpp"
 
@@ -96,38 +98,75 @@ prob3_terms_kernel(const Prob3Consts c, const double *__restrict__ energy, int n
     eigen_terms<DECAY>(c.side[side], c.dm, energy[ie], rho_unique[u], store);
 }
 
-// Stage B: workgroup = one coszen row of one sign, lanes along energy.
+// Stage B: one workgroup per (crossed layer of a coszen row, sign), lanes along
+// energy: amplitude matrix A of that layer -> scratch [side][pair][18][n_e].
+// All layers of all rows run in parallel (the per-row chains are short but the
+// longest row has 24 layers: doing the transcendental work inside the chain
+// made the whole launch wait for that row).
 template <bool DECAY>
 __global__ void __launch_bounds__(256)
-prob3_chain_kernel(const Prob3Consts c, const double *__restrict__ energy, int n_e,
-                   const int32_t *__restrict__ rho_idx, const double *__restrict__ dist,
-                   const int32_t *__restrict__ n_used, int n_cz, int n_layers, int n_unique,
-                   const double *__restrict__ rec, int e_major, double *__restrict__ prob_nu,
+prob3_amp_kernel(const double *__restrict__ energy, int n_e, const int32_t *__restrict__ pair_u,
+                 const double *__restrict__ pair_dist, int n_pairs, int n_unique,
+                 const double *__restrict__ rec, double *__restrict__ amp) {
+    const int k = blockIdx.x;
+    const int side = blockIdx.y;
+    const int u = pair_u[k];
+    const double d = pair_dist[k];
+    for (int ie = threadIdx.x; ie < n_e; ie += blockDim.x) {
+        const double *r = rec + ((int64_t)(side * n_unique + u) * PROB3_NF) * n_e + ie;
+        auto load = [&](int f) { return r[(int64_t)f * n_e]; };
+        mat3 A;
+        amplitude_from_terms<DECAY>(load, d / energy[ie], A);
+        double *o = amp + ((int64_t)(side * n_pairs + k) * 18) * n_e + ie;
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                o[(int64_t)(6 * i + 2 * j) * n_e] = A.m[i][j].re;
+                o[(int64_t)(6 * i + 2 * j + 1) * n_e] = A.m[i][j].im;
+            }
+    }
+}
+
+// Stage C: ordered product of a row's layer matrices (numba_osc_kernels.py:281-294),
+// flavour basis and probabilities (:326-345).  Workgroup = (coszen row, sign).
+__global__ void __launch_bounds__(256)
+prob3_chain_kernel(const Prob3Consts c, int n_e, const int32_t *__restrict__ row_start,
+                   const int32_t *__restrict__ row_cnt, int n_cz, int n_pairs,
+                   const double *__restrict__ amp, int e_major, double *__restrict__ prob_nu,
                    double *__restrict__ prob_nubar, double2 *__restrict__ pepmu) {
     const int jcz = blockIdx.x;
     const int side = blockIdx.y;
     double *out = side == 0 ? prob_nu : prob_nubar;
     const Prob3Side &S = c.side[side];
-    const int32_t *idx_row = rho_idx + (int64_t)jcz * n_layers;
-    const double *dist_row = dist + (int64_t)jcz * n_layers;
-    const int nl = n_used[jcz];
+    const int k0 = row_start[jcz];
+    const int cnt = row_cnt[jcz];
     for (int ie = threadIdx.x; ie < n_e; ie += blockDim.x) {
-        const double e = energy[ie];
+        auto load_A = [&](int k, mat3 &A) {
+            const double *a = amp + ((int64_t)(side * n_pairs + k) * 18) * n_e + ie;
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+                    A.m[i][j] = cmake(a[(int64_t)(6 * i + 2 * j) * n_e], a[(int64_t)(6 * i + 2 * j + 1) * n_e]);
+        };
         mat3 T;
-        bool first = true;
 #pragma unroll
         for (int i = 0; i < 3; i++)
 #pragma unroll
             for (int j = 0; j < 3; j++) T.m[i][j] = cmake(0.0, 0.0);
-        for (int l = 0; l < nl; l++) {
-            const int u = idx_row[l];  // workgroup-uniform
-            if (u < 0) continue;
-            const double *r = rec + ((int64_t)(side * n_unique + u) * PROB3_NF) * n_e + ie;
-            auto load = [&](int f) { return r[(int64_t)f * n_e]; };
+        if (cnt > 0) {
+            load_A(k0, T);
             mat3 A;
-            amplitude_from_terms<DECAY>(load, dist_row[l] / e, A);
-            if (first) { T = A; first = false; }
-            else { mat3 t2; mat_mul(A, T, t2); T = t2; }
+            if (cnt > 1) load_A(k0 + 1, A);
+            for (int t = 1; t < cnt; t++) {
+                mat3 An;
+                if (t + 1 < cnt) load_A(k0 + t + 1, An);  // prefetch the next layer
+                mat3 t2;
+                mat_mul(A, T, t2);
+                T = t2;
+                A = An;
+            }
         }
         mat3 t2, Tf;
         mat_mul(T, S.Ud, t2);
@@ -478,14 +517,25 @@ PISA_API int pisa_hip_fill_probs(const double *d_probability, int64_t init_flav,
 
 // ------------------------------------------------------------ grid plan (host)
 struct pisa_hip_grid_plan {
-    int n_cz, n_layers, n_unique;
-    int32_t *d_rho_idx;
-    double *d_dist;
-    double *d_rho;
-    int32_t *d_n_used;
-    double *d_rec;
+    int n_cz, n_layers, n_unique, n_pairs;
+    int32_t *d_pair_u;     // [n_pairs] distinct-density index of each crossed layer
+    double *d_pair_dist;   // [n_pairs] its (cache-resolved) length
+    int32_t *d_row_start;  // [n_cz] first pair of the row
+    int32_t *d_row_cnt;    // [n_cz] crossed layers of the row, in path order
+    double *d_rho;         // [n_unique]
+    double *d_rec;         // stage-A records [2][n_unique][NF][n_e]
+    double *d_amp;         // stage-B amplitudes [2][n_pairs][18][n_e]
     int n_e_alloc;
 };
+
+PISA_API int pisa_hip_grid_plan_destroy(pisa_hip_grid_plan *p) {
+    if (!p) return PISA_HIP_OK;
+    void *ptrs[] = {p->d_pair_u, p->d_pair_dist, p->d_row_start, p->d_row_cnt, p->d_rho, p->d_rec, p->d_amp};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    delete p;
+    return PISA_HIP_OK;
+}
 
 PISA_API int pisa_hip_grid_plan_create(const double *d_densities, const double *d_distances,
                                        int32_t n_cz, int32_t n_layers,
@@ -493,22 +543,18 @@ PISA_API int pisa_hip_grid_plan_create(const double *d_densities, const double *
     if (!out || n_cz < 1 || n_layers < 1 || !d_densities || !d_distances) return PISA_HIP_ERR_INVALID;
     if (n_layers > PISA_HIP_MAX_LAYERS) return PISA_HIP_ERR_LAYERS;
     size_t n = (size_t)n_cz * n_layers;
-    double *rho = new double[n], *dist = new double[n], *dres = new double[n];
-    int32_t *idx = new int32_t[n], *used = new int32_t[n_cz];
-    double *uniq = new double[n];
-    int nu = 0;
+    double *rho = new double[n], *dist = new double[n], *pdist = new double[n + 1];
+    int32_t *pu = new int32_t[n + 1], *rstart = new int32_t[n_cz], *rcnt = new int32_t[n_cz];
+    double *uniq = new double[n + 1];
+    int nu = 0, np = 0;
     int rc = check_hip(hipMemcpy(rho, d_densities, n * 8, hipMemcpyDeviceToHost), "d2h");
     if (!rc) rc = check_hip(hipMemcpy(dist, d_distances, n * 8, hipMemcpyDeviceToHost), "d2h");
     if (!rc) {
         for (int r = 0; r < n_cz; r++) {
             const double *rr = rho + (size_t)r * n_layers, *dd = dist + (size_t)r * n_layers;
-            int last = 0;
+            rstart[r] = np;
             for (int i = 0; i < n_layers; i++) {
-                size_t o = (size_t)r * n_layers + i;
-                idx[o] = -1;
-                dres[o] = 0.0;
                 if (!(dd[i] > 0.0)) continue;
-                last = i + 1;
                 // follow the reference's cache matches (numba_osc_kernels.py:236-249)
                 int cur = i;
                 double cr = rr[i], cd = dd[i];
@@ -523,43 +569,37 @@ PISA_API int pisa_hip_grid_plan_create(const double *d_densities, const double *
                 for (int k = 0; k < nu; k++)
                     if (uniq[k] == cr) { u = k; break; }
                 if (u < 0) { u = nu; uniq[nu++] = cr; }
-                idx[o] = u;
-                dres[o] = cd;
+                pu[np] = u;
+                pdist[np] = cd;
+                np++;
             }
-            used[r] = last;
+            rcnt[r] = np - rstart[r];
         }
     }
     pisa_hip_grid_plan *p = nullptr;
     if (!rc) {
         p = new pisa_hip_grid_plan();
-        p->n_cz = n_cz; p->n_layers = n_layers; p->n_unique = nu > 0 ? nu : 1;
-        p->d_rho_idx = nullptr; p->d_dist = nullptr; p->d_rho = nullptr; p->d_n_used = nullptr;
-        p->d_rec = nullptr; p->n_e_alloc = 0;
+        memset(p, 0, sizeof(*p));
+        p->n_cz = n_cz; p->n_layers = n_layers;
+        p->n_unique = nu > 0 ? nu : 1;
+        p->n_pairs = np;
         if (nu == 0) uniq[0] = 0.0;
-        rc = check_hip(hipMalloc(&p->d_rho_idx, n * 4), "hipMalloc");
-        if (!rc) rc = check_hip(hipMalloc(&p->d_dist, n * 8), "hipMalloc");
+        size_t npa = np > 0 ? np : 1;
+        rc = check_hip(hipMalloc(&p->d_pair_u, npa * 4), "hipMalloc");
+        if (!rc) rc = check_hip(hipMalloc(&p->d_pair_dist, npa * 8), "hipMalloc");
+        if (!rc) rc = check_hip(hipMalloc(&p->d_row_start, (size_t)n_cz * 4), "hipMalloc");
+        if (!rc) rc = check_hip(hipMalloc(&p->d_row_cnt, (size_t)n_cz * 4), "hipMalloc");
         if (!rc) rc = check_hip(hipMalloc(&p->d_rho, (size_t)p->n_unique * 8), "hipMalloc");
-        if (!rc) rc = check_hip(hipMalloc(&p->d_n_used, (size_t)n_cz * 4), "hipMalloc");
-        if (!rc) rc = check_hip(hipMemcpy(p->d_rho_idx, idx, n * 4, hipMemcpyHostToDevice), "h2d");
-        if (!rc) rc = check_hip(hipMemcpy(p->d_dist, dres, n * 8, hipMemcpyHostToDevice), "h2d");
+        if (!rc && np > 0) rc = check_hip(hipMemcpy(p->d_pair_u, pu, (size_t)np * 4, hipMemcpyHostToDevice), "h2d");
+        if (!rc && np > 0) rc = check_hip(hipMemcpy(p->d_pair_dist, pdist, (size_t)np * 8, hipMemcpyHostToDevice), "h2d");
+        if (!rc) rc = check_hip(hipMemcpy(p->d_row_start, rstart, (size_t)n_cz * 4, hipMemcpyHostToDevice), "h2d");
+        if (!rc) rc = check_hip(hipMemcpy(p->d_row_cnt, rcnt, (size_t)n_cz * 4, hipMemcpyHostToDevice), "h2d");
         if (!rc) rc = check_hip(hipMemcpy(p->d_rho, uniq, (size_t)p->n_unique * 8, hipMemcpyHostToDevice), "h2d");
-        if (!rc) rc = check_hip(hipMemcpy(p->d_n_used, used, (size_t)n_cz * 4, hipMemcpyHostToDevice), "h2d");
     }
-    delete[] rho; delete[] dist; delete[] dres; delete[] idx; delete[] used; delete[] uniq;
+    delete[] rho; delete[] dist; delete[] pdist; delete[] pu; delete[] rstart; delete[] rcnt; delete[] uniq;
     if (rc && p) { pisa_hip_grid_plan_destroy(p); p = nullptr; }
     *out = p;
     return rc;
-}
-
-PISA_API int pisa_hip_grid_plan_destroy(pisa_hip_grid_plan *p) {
-    if (!p) return PISA_HIP_OK;
-    if (p->d_rho_idx) (void)hipFree(p->d_rho_idx);
-    if (p->d_dist) (void)hipFree(p->d_dist);
-    if (p->d_rho) (void)hipFree(p->d_rho);
-    if (p->d_n_used) (void)hipFree(p->d_n_used);
-    if (p->d_rec) (void)hipFree(p->d_rec);
-    delete p;
-    return PISA_HIP_OK;
 }
 
 PISA_API int pisa_hip_prob3_grid_planned(const pisa_hip_prob3_params *h_params,
@@ -572,31 +612,39 @@ PISA_API int pisa_hip_prob3_grid_planned(const pisa_hip_prob3_params *h_params,
     if (rc) return rc;
     if (plan->n_e_alloc < n_e) {
         if (plan->d_rec) (void)hipFree(plan->d_rec);
-        plan->d_rec = nullptr;
-        size_t bytes = (size_t)2 * plan->n_unique * PROB3_NF * n_e * sizeof(double);
-        PISA_TRY_HIP(hipMalloc(&plan->d_rec, bytes));
+        if (plan->d_amp) (void)hipFree(plan->d_amp);
+        plan->d_rec = plan->d_amp = nullptr;
+        plan->n_e_alloc = 0;
+        size_t rec_bytes = (size_t)2 * plan->n_unique * PROB3_NF * n_e * sizeof(double);
+        size_t amp_bytes = (size_t)2 * (plan->n_pairs > 0 ? plan->n_pairs : 1) * 18 * n_e * sizeof(double);
+        PISA_TRY_HIP(hipMalloc(&plan->d_rec, rec_bytes));
+        PISA_TRY_HIP(hipMalloc(&plan->d_amp, amp_bytes));
         plan->n_e_alloc = n_e;
     }
     hipStream_t s = as_stream(stream);
     dim3 ablock(64), agrid((unsigned)((n_e + 63) / 64), (unsigned)plan->n_unique, 2);
     int threads = ((n_e + 63) / 64) * 64;
     if (threads > 256) threads = 256;
-    dim3 bblock(threads), bgrid((unsigned)plan->n_cz, 2);
+    dim3 bblock(threads), bgrid((unsigned)(plan->n_pairs > 0 ? plan->n_pairs : 1), 2);
+    dim3 cgrid((unsigned)plan->n_cz, 2);
     if (c.decay) {
         hipLaunchKernelGGL(prob3_terms_kernel<true>, agrid, ablock, 0, s, c, d_energy, (int)n_e,
                            plan->d_rho, plan->n_unique, plan->d_rec);
-        hipLaunchKernelGGL(prob3_chain_kernel<true>, bgrid, bblock, 0, s, c, d_energy, (int)n_e,
-                           plan->d_rho_idx, plan->d_dist, plan->d_n_used, plan->n_cz,
-                           plan->n_layers, plan->n_unique, plan->d_rec, (int)e_major, d_prob_nu,
-                           d_prob_nubar, (double2 *)d_pepmu);
+        if (plan->n_pairs > 0)
+            hipLaunchKernelGGL(prob3_amp_kernel<true>, bgrid, bblock, 0, s, d_energy, (int)n_e,
+                               plan->d_pair_u, plan->d_pair_dist, plan->n_pairs, plan->n_unique,
+                               plan->d_rec, plan->d_amp);
     } else {
         hipLaunchKernelGGL(prob3_terms_kernel<false>, agrid, ablock, 0, s, c, d_energy, (int)n_e,
                            plan->d_rho, plan->n_unique, plan->d_rec);
-        hipLaunchKernelGGL(prob3_chain_kernel<false>, bgrid, bblock, 0, s, c, d_energy, (int)n_e,
-                           plan->d_rho_idx, plan->d_dist, plan->d_n_used, plan->n_cz,
-                           plan->n_layers, plan->n_unique, plan->d_rec, (int)e_major, d_prob_nu,
-                           d_prob_nubar, (double2 *)d_pepmu);
+        if (plan->n_pairs > 0)
+            hipLaunchKernelGGL(prob3_amp_kernel<false>, bgrid, bblock, 0, s, d_energy, (int)n_e,
+                               plan->d_pair_u, plan->d_pair_dist, plan->n_pairs, plan->n_unique,
+                               plan->d_rec, plan->d_amp);
     }
+    hipLaunchKernelGGL(prob3_chain_kernel, cgrid, bblock, 0, s, c, (int)n_e, plan->d_row_start,
+                       plan->d_row_cnt, plan->n_cz, plan->n_pairs, plan->d_amp, (int)e_major,
+                       d_prob_nu, d_prob_nubar, (double2 *)d_pepmu);
     PISA_CHECK_LAUNCH("prob3_chain_kernel");
     return PISA_HIP_OK;
 }
