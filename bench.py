@@ -108,6 +108,22 @@ def cpu_baseline(wl, sample_events):
     }
 
 
+def pmc_traffic(args):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3
+    PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; collected by
+    separate `rocprofv3 --pmc` runs of this same command, see profiles/*/traffic.json).
+    Only valid for the default workload."""
+    if args.coordinate_form or int(args.events) != 10000000 or args.binning != "dragon":
+        return None
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))
+    if not files:
+        return None
+    with open(files[-1]) as fh:
+        return json.load(fh).get("hbm_bytes")
+
+
 def main():
     args = parse()
     import numpy as np
@@ -234,7 +250,7 @@ def main():
                          "finalize_metric": t_tail},
             "roofline": {
                 "bound": "hbm",
-                "kernel": "hist_accumulate_kernel<MODE=%d, LDS_ACC=true>" % (1 if args.coordinate_form else 2),
+                "kernel": "hist_accumulate_kernel<%d, true>" % (1 if args.coordinate_form else 3),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -242,7 +258,7 @@ def main():
                 "bytes_per_event": bytes_per_event,
                 "events_per_launch": st.n_local,
                 "avg_launch_ms": 1e3 * fused_avg_s,
-                "traffic": None,
+                "traffic": pmc_traffic(args),
             },
         }
         if not args.no_cpu_baseline and world == 1:
