@@ -118,10 +118,42 @@ class Container:
         self.data = defaultdict(dict)
         self._representations = {}
         self.precedence = defaultdict(int)
+        # deferred operations per key (see pisa_amd/stages/deferred.py)
+        self.pending = {}
+        self._pending_rep = {}
         self.representation = representation
 
     def __repr__(self):
         return "Container containing keys %s" % self.all_keys
+
+    # -- deferred operations ------------------------------------------------
+    def touch_pending(self, key):
+        """`key` now has pending operations defined in the current representation"""
+        self._pending_rep[key] = self._representation
+        if key not in self.current_data:
+            self.current_data[key] = DualArray(np.empty(0, dtype=FTYPE))
+        if key not in self.translation_modes:
+            self.translation_modes[key] = "average"
+        self._invalidate_others(key)
+
+    def _store(self, key, data):
+        """(re)place the array of `key` in the current representation, keep pending ops"""
+        self.current_data[key] = DualArray(data)
+        self._invalidate_others(key)
+
+    def device_raw(self, key):
+        return self.current_data[key].get_dev()
+
+    def _flush_pending(self, key):
+        if self.pending.get(key):
+            from pisa_amd.stages import deferred
+
+            keep = self._representation
+            try:
+                self.representation = self._pending_rep.get(key, keep)
+                deferred.materialize(self, key)
+            finally:
+                self.representation = keep
 
     # -- representation ------------------------------------------------------
     @property
@@ -212,6 +244,8 @@ class Container:
         return K.to_device(np.asarray(arr, dtype=FTYPE))
 
     def _get(self, key):
+        if key in self.pending:
+            self._flush_pending(key)
         if self.is_map and key in self._representation.names:
             return DualArray(self.unroll_binning(key, self._representation))
         if key not in self.current_data:
@@ -228,6 +262,7 @@ class Container:
     def __setitem__(self, key, data):
         if self.is_map and key in self._representation.names:
             raise Exception("Cannot add variable %s, as it is a binning dimension" % key)
+        self.pending.pop(key, None)  # overwritten
         self._add_data(key, data)
         if key not in self.translation_modes:
             self.translation_modes[key] = "sum" if key in self.sum_mode_keys else "average"

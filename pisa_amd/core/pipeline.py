@@ -1,0 +1,175 @@
+"""`Pipeline`: ordered list of services sharing one `ContainerSet`
+(counterpart of pisa/core/pipeline.py:73-785).
+
+`Pipeline(cfg)` parses the reference's cfg grammar, instantiates
+`pisa_amd.stages.<stage>.<service>` (falling back to `<stage>.<service>` on
+`sys.path`, like pipeline.py:282-296), shares same-named params between stages
+(:342-346), applies `param_selections`, runs `setup()`; `get_outputs()` runs
+every stage (`run` = `compute` + `apply`) and returns the output `MapSet`.
+"""
+from collections import OrderedDict
+from importlib import import_module
+from time import time
+
+import numpy as np
+
+from pisa_amd.core.binning import MultiDimBinning
+from pisa_amd.core.config_parser import PISAConfigParser, parse_pipeline_config
+from pisa_amd.core.container import ContainerSet
+from pisa_amd.core.param import ParamSet
+from pisa_amd.core.stage import Stage
+
+__all__ = ["Pipeline"]
+
+
+class Pipeline:
+    def __init__(self, config, profile=False):
+        if isinstance(config, (str, PISAConfigParser)):
+            config = parse_pipeline_config(config=config)
+        elif not isinstance(config, OrderedDict):
+            raise TypeError("`config` passed is of type %s but must be string, PISAConfigParser, "
+                            "or OrderedDict" % type(config).__name__)
+        self.name = config["pipeline"]["name"]
+        self.detector_name = config["pipeline"].get("detector_name")
+        self.data = ContainerSet(self.name)
+        self.data["output_binning"] = config["pipeline"]["output_binning"]
+        self.output_key = config["pipeline"]["output_key"]
+        self._profile = profile
+        self._setup_times, self._run_times, self._get_outputs_times = [], [], []
+        self._stages = []
+        self._config = config
+        self._init_stages()
+
+    # -- construction ---------------------------------------------------------------
+    def _init_stages(self):
+        stages = []
+        for name, settings in self._config.items():
+            if name == "pipeline":
+                continue
+            stage_name, service_name = name
+            service_name = service_name.replace("pi_", "")
+            try:
+                module = import_module("pisa_amd.stages.%s.%s" % (stage_name, service_name))
+            except ImportError:
+                module = import_module("%s.%s" % (stage_name, service_name))
+            service_cls = getattr(module, service_name)
+            service = service_cls(**settings, profile=self._profile)
+            if not isinstance(service, Stage):
+                raise TypeError('Trying to create service "%s" for stage "%s", but the class is not '
+                                "a Stage" % (service_name, stage_name))
+            stages.append(service)
+        self._stages = stages
+        # identical names -> identical Param objects (pipeline.py:342-346)
+        self.update_params(self.params, existing_must_match=True, extend=False)
+        selections = set()
+        for s in stages:
+            selections.update(s.param_selections)
+        for s in stages:
+            s.select_params(sorted(selections), error_on_missing=False)
+        self.setup()
+
+    # -- container protocol -----------------------------------------------------------
+    def __len__(self):
+        return len(self._stages)
+
+    def __iter__(self):
+        return iter(self._stages)
+
+    def __getitem__(self, idx):
+        if isinstance(idx, str):
+            for s in self._stages:
+                if idx in (s.service_name, s.stage_name, "%s.%s" % (s.stage_name, s.service_name)):
+                    return s
+            raise KeyError(idx)
+        return self._stages[idx]
+
+    stages = property(lambda self: list(self._stages))
+    stage_names = property(lambda self: [s.stage_name for s in self._stages])
+    service_names = property(lambda self: [s.service_name for s in self._stages])
+    config = property(lambda self: self._config)
+    profile = property(lambda self: self._profile)
+
+    @property
+    def output_binning(self):
+        return self.data["output_binning"]
+
+    @output_binning.setter
+    def output_binning(self, binning):
+        self.data["output_binning"] = binning
+        self.setup()
+
+    # -- params ----------------------------------------------------------------------
+    @property
+    def params(self):
+        params = ParamSet()
+        for s in self._stages:
+            params.update(s.params, existing_must_match=False, extend=True)
+        return params
+
+    @property
+    def param_selections(self):
+        sel = set()
+        for s in self._stages:
+            sel.update(s.param_selections)
+        return sorted(sel)
+
+    def update_params(self, params, existing_must_match=False, extend=False):
+        for s in self._stages:
+            s._param_selector.update(params, existing_must_match=existing_must_match, extend=extend)
+
+    def select_params(self, selections, error_on_missing=False):
+        found = False
+        for s in self._stages:
+            try:
+                s.select_params(selections, error_on_missing=True)
+                found = True
+            except KeyError:
+                pass
+        if not found and error_on_missing:
+            raise KeyError("None of the stages has all selections %s" % (selections,))
+
+    # -- execution --------------------------------------------------------------------
+    def setup(self):
+        t0 = time()
+        output_binning = self.data["output_binning"]
+        self.data = ContainerSet(self.name)
+        self.data["output_binning"] = output_binning
+        for s in self._stages:
+            s.data = self.data
+            s.setup()
+        if self._profile:
+            self._setup_times.append(time() - t0)
+
+    def run(self):
+        t0 = time()
+        for s in self._stages:
+            s.run()
+        if self._profile:
+            self._run_times.append(time() - t0)
+
+    def get_outputs(self, output_binning=None, output_key=None):
+        t0 = time()
+        self.run()
+        if output_binning is None:
+            output_binning = self.output_binning
+        if output_key is None:
+            output_key = self.output_key
+        assert isinstance(output_binning, MultiDimBinning)
+        self.data.representation = output_binning
+        if isinstance(output_key, tuple):
+            assert len(output_key) == 2
+            outputs = self.data.get_mapset(output_key[0], error=output_key[1])
+        else:
+            outputs = self.data.get_mapset(output_key)
+        if self._profile:
+            self._get_outputs_times.append(time() - t0)
+        return outputs
+
+    def report_profile(self, detailed=False):
+        for label, times in (("setup", self._setup_times), ("run", self._run_times),
+                             ("get_outputs", self._get_outputs_times)):
+            if times:
+                print("%-12s total %.5f s, n=%d, mean %.5f s" % (label, np.sum(times), len(times),
+                                                               np.mean(times)))
+        for s in self._stages:
+            s.report_profile(detailed=detailed)

@@ -60,7 +60,8 @@ class HotPathEngine:
     scale."""
 
     def __init__(self, containers, grid, out_binning, earth, max_layers, rank=0, world_size=1,
-                 group=None, indexed=True, planned=True, packed=True, sort_events=True):
+                 group=None, indexed=True, planned=True, packed=True, sort_events=True,
+                 external_tables=False):
         self.dev = K.device()
         self.grid = grid
         self.out_binning = out_binning
@@ -70,11 +71,13 @@ class HotPathEngine:
         self._keep = []  # device tensors referenced by raw pointer
         self.indexed, self.planned = indexed, planned
         self.cont = []
+        self._perm, self._flux, self._slices = [], [], []
         self.n_local = 0
         for c in containers:
             n = len(c["true_energy"])
             lo, hi = (rank * n) // world_size, ((rank + 1) * n) // world_size
             sl = slice(lo, hi)
+            self._slices.append((lo, hi))
             d = _lib.Container()
             d.n_events = hi - lo
             self.n_local += hi - lo
@@ -85,7 +88,7 @@ class HotPathEngine:
             aeff_d = K.to_device(np.asarray(c["weighted_aeff"])[sl])
             w0_d = K.to_device(np.asarray(c["initial_weights"])[sl])
             cols = [K.to_device(np.asarray(col)[sl]) for col in c["sample"]]
-            node = obin = None
+            node = obin = perm = None
             if indexed:
                 # coordinates never change between evaluations: digitise once
                 node = K.event_indices([gx, gy], grid.binning)
@@ -102,6 +105,8 @@ class HotPathEngine:
                     cols = [t[perm].contiguous() for t in cols]
                     node, obin = node[perm].contiguous(), obin[perm].contiguous()
             self._keep += [gx, gy, flux_d, aeff_d, w0_d] + cols
+            self._perm.append(perm)
+            self._flux.append(flux_d)
             d.d_grid_x, d.d_grid_y = gx.data_ptr(), gy.data_ptr()
             d.d_nu_flux = flux_d.data_ptr()
             d.d_weighted_aeff, d.d_initial_weights = aeff_d.data_ptr(), w0_d.data_ptr()
@@ -121,12 +126,14 @@ class HotPathEngine:
         self._cont_arr = (_lib.Container * len(self.cont))(*self.cont)
         # Earth layers for the coszen nodes (prob3.setup_function, prob3.py:398-409)
         self.earth = earth
-        self.energy_d = K.to_device(grid.energy)
-        _, self.dens_d, self.dist_d = K.calc_layers(earth, K.to_device(grid.coszen), max_layers)
-        self.prob_nu = torch.empty((grid.size, 3, 3), dtype=torch.float64, device=self.dev)
-        self.prob_nubar = torch.empty((grid.size, 3, 3), dtype=torch.float64, device=self.dev)
-        self.pepmu = torch.empty((2, 3, grid.size, 2), dtype=torch.float64, device=self.dev)
-        self.plan = K.GridPlan(self.dens_d, self.dist_d) if planned else None
+        self.prob_nu = self.prob_nubar = self.pepmu = self.plan = None
+        if not external_tables:
+            self.energy_d = K.to_device(grid.energy)
+            _, self.dens_d, self.dist_d = K.calc_layers(earth, K.to_device(grid.coszen), max_layers)
+            self.prob_nu = torch.empty((grid.size, 3, 3), dtype=torch.float64, device=self.dev)
+            self.prob_nubar = torch.empty((grid.size, 3, 3), dtype=torch.float64, device=self.dev)
+            self.pepmu = torch.empty((2, 3, grid.size, 2), dtype=torch.float64, device=self.dev)
+            self.plan = K.GridPlan(self.dens_d, self.dist_d) if planned else None
         self.ws = K.HistWorkspace(len(self.cont), self.n_bins, self.dev)
         self.metric_out = torch.zeros(1, dtype=torch.float64, device=self.dev)
         self.metric_status = torch.zeros(1, dtype=torch.int32, device=self.dev)
@@ -136,6 +143,15 @@ class HotPathEngine:
         t = K.to_device(a)
         self._keep.append(t)
         return t
+
+    def update_flux(self, i, flux):
+        """new nu_flux column for container i (flux systematics changed): written in
+        place, in this engine's event order"""
+        lo, hi = self._slices[i]
+        f = flux[lo:hi]
+        if self._perm[i] is not None:
+            f = f[self._perm[i]]
+        self._flux[i].copy_(f)
 
     def set_scale(self, name, scale):
         i = self.names.index(name)

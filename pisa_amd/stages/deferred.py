@@ -1,0 +1,67 @@
+"""Deferred operations on a container's `weights`.
+
+The reference applies every stage's `apply_function` immediately on host numpy
+arrays: `weights = copy(initial_weights)` (loader), `weights *= flux.prob`
+(prob3.py:621-622), `weights *= weighted_aeff*scale` (aeff.py:87), then three
+histogram passes (hist.py:198-209).  Here the stages RECORD these operations on
+the container; `utils.hist` recognises the chain [reset, osc, aeff] and runs it
+as ONE pass over HBM (`pisa_hip_reweight_hist`).  Any other access to
+`container['weights']` first materialises the pending chain with the unfused
+kernels (`pisa_hip_apply_osc_weights`, `pisa_hip_apply_aeff`), so third-party
+stages always observe the values the reference would have produced.
+"""
+from pisa_amd import kernels as K
+
+KEY = "weights"
+
+
+def _ops(container):
+    return container.pending.setdefault(KEY, [])
+
+
+def reset_weights(container):
+    """weights = copy(initial_weights)  (toy_event_generator.py:101-104)"""
+    if container.is_map:
+        container[KEY] = container.device("initial_weights").clone()
+        return
+    container.pending[KEY] = [("reset",)]
+    container.touch_pending(KEY)
+
+
+def osc(container, flux_key="nu_flux"):
+    """weights *= flux[:,0]*prob_e + flux[:,1]*prob_mu  (prob3.py:621-622)"""
+    _ops(container).append(("osc", flux_key))
+    container.touch_pending(KEY)
+
+
+def aeff(container, scale):
+    """weights *= weighted_aeff * scale  (aeff.py:87)"""
+    _ops(container).append(("aeff", float(scale)))
+    container.touch_pending(KEY)
+
+
+def materialize(container, key=KEY):
+    """Apply the pending chain with the one-stage-at-a-time kernels."""
+    ops = container.pending.pop(key, [])
+    if not ops:
+        return
+    for op in ops:
+        if op[0] == "reset":
+            container._store(key, container.device("initial_weights").clone())
+        elif op[0] == "osc":
+            w = container.device_raw(key)
+            K.apply_osc_weights(container.device(op[1]), container.device("prob_e"),
+                                container.device("prob_mu"), w)
+            container._store(key, w)
+        elif op[0] == "aeff":
+            w = container.device_raw(key)
+            K.apply_aeff(container.device("weighted_aeff"), op[1], w)
+            container._store(key, w)
+
+
+def fusable_chain(container):
+    """(flux_key, scale) if the pending chain is exactly reset -> osc -> aeff."""
+    ops = container.pending.get(KEY, [])
+    if len(ops) == 3 and ops[0][0] == "reset" and ops[1][0] == "osc" and ops[2][0] == "aeff":
+        return ops[1][1], ops[2][1]
+    return None

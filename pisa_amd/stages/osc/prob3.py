@@ -1,0 +1,219 @@
+"""Three-flavour oscillation probabilities in layered-Earth matter, with NSI,
+decay, LRI and NLO options (counterpart of pisa/stages/osc/prob3.py:37-641:
+same constructor kwargs, params, container keys and results).
+
+Host side per evaluation: parameter values -> PMNS / dm / generalised matter
+potential / decay / LRI matrices (prob3.py:476-578).  Device side:
+
+* calc_mode = 2-D (true_energy x true_coszen) binning: the planned two-stage
+  grid kernels evaluate nu and nubar on every node at once
+  (`pisa_hip_prob3_grid_planned`); layers are computed for the coszen nodes only;
+* calc_mode = "events": `pisa_hip_prob3_events` rebuilds each event's path from
+  its coszen (no densities/distances[N, L] arrays);
+* any other binned calc_mode: generic `pisa_hip_propagate_array` with per-node
+  layer rows.
+
+`apply_function` (prob3.py:611-622) multiplies the weights by
+flux_e*prob_e + flux_mu*prob_mu; in an event representation this is recorded
+as a deferred operation and fused with aeff + hist by `utils.hist`.
+"""
+import numpy as np
+
+from pisa_amd import CTYPE, FTYPE, _lib
+from pisa_amd import kernels as K
+from pisa_amd.core.binning import MultiDimBinning
+from pisa_amd.core.stage import Stage
+from pisa_amd.core.units import ureg
+from pisa_amd.stages import deferred
+from pisa_amd.stages.osc.decay_params import DecayParams
+from pisa_amd.stages.osc.layers import Layers
+from pisa_amd.stages.osc.lri_params import LRIParams
+from pisa_amd.stages.osc.nsi_params import StdNSIParams, VacuumLikeNSIParams
+from pisa_amd.stages.osc.osc_params import OscParams
+
+__all__ = ["prob3", "LRI_TYPES", "NSI_TYPES"]
+
+LRI_TYPES = ["emu-symmetry", "etau-symmetry", "mutau-symmetry"]
+NSI_TYPES = ["standard", "vacuum-like"]
+
+NU = ["nue_cc", "numu_cc", "nutau_cc", "nue_nc", "numu_nc", "nutau_nc"]
+NUBAR = ["nuebar_cc", "numubar_cc", "nutaubar_cc", "nuebar_nc", "numubar_nc", "nutaubar_nc"]
+
+
+class prob3(Stage):  # pylint: disable=invalid-name
+    def __init__(self, include_nlo=False, nsi_type=None, reparam_mix_matrix=False,
+                 neutrino_decay=False, tomography_type=None, lri_type=None, **std_kwargs):
+        expected_params = ("detector_depth", "earth_model", "prop_height", "YeI", "YeO", "YeM",
+                           "theta12", "theta13", "theta23", "deltam21", "deltam31", "deltacp")
+        expected_container_keys = ("true_energy", "true_coszen", "nubar", "flav", "nu_flux", "weights")
+        self.include_nlo = include_nlo
+        if nsi_type is not None:
+            nsi_type = nsi_type.strip().lower()
+            if nsi_type not in NSI_TYPES:
+                raise ValueError('Chosen NSI type "%s" not available! Choose one of %s.' % (nsi_type, NSI_TYPES))
+        self.nsi_type = nsi_type
+        self.reparam_mix_matrix = reparam_mix_matrix
+        self.neutrino_decay = neutrino_decay
+        self.decay_flag = 1 if neutrino_decay else -1
+        if nsi_type == "vacuum-like":
+            expected_params += ("eps_scale", "eps_prime", "phi12", "phi13", "phi23", "alpha1",
+                                "alpha2", "deltansi")
+        elif nsi_type == "standard":
+            expected_params += ("eps_ee", "eps_emu_magn", "eps_emu_phase", "eps_etau_magn",
+                                "eps_etau_phase", "eps_mumu", "eps_mutau_magn", "eps_mutau_phase",
+                                "eps_tautau")
+        if neutrino_decay:
+            expected_params += ("decay_alpha3",)
+        if lri_type is not None:
+            lri_type = lri_type.strip().lower()
+            if lri_type not in LRI_TYPES:
+                raise ValueError('Chosen LRI symmetry type "%s" not available! Choose one of %s.'
+                                 % (lri_type, LRI_TYPES))
+            expected_params += ("v_lri",)
+        self.lri_type = lri_type
+        if tomography_type is not None:
+            raise NotImplementedError("Earth tomography scalings are not part of this build")
+        self.tomography_type = None
+        super().__init__(expected_params=expected_params,
+                         expected_container_keys=expected_container_keys, **std_kwargs)
+        self.layers = self.osc_params = self.nsi_params = self.decay_params = self.lri_params = None
+        self.gen_mat_pot_matrix_complex = self.decay_matrix = self.lri_pot = None
+        self.YeI = self.YeO = self.YeM = None
+        self.grid = None          # dict describing the 2-D calc grid, if any
+        self.pepmu = None         # [2][3][node][2] gather tables of the last compute
+        self.prob_tables = None   # (P_nu, P_nubar)
+
+    # ---------------------------------------------------------------- setup
+    def setup_function(self):
+        self.osc_params = OscParams()
+        if self.nsi_type == "vacuum-like":
+            self.nsi_params = VacuumLikeNSIParams()
+        elif self.nsi_type == "standard":
+            self.nsi_params = StdNSIParams()
+        if self.neutrino_decay:
+            self.decay_params = DecayParams()
+        if self.lri_type is not None:
+            self.lri_params = LRIParams()
+        p = self.params
+        self.YeI = p.YeI.value.m_as("dimensionless")
+        self.YeO = p.YeO.value.m_as("dimensionless")
+        self.YeM = p.YeM.value.m_as("dimensionless")
+        self.layers = Layers(p.earth_model.value, p.detector_depth.value.m_as("km"),
+                             p.prop_height.value.m_as("km"))
+        self.layers.setElecFrac(self.YeI, self.YeO, self.YeM)
+        cm = self.calc_mode
+        if isinstance(cm, MultiDimBinning) and sorted(cm.names) == ["true_coszen", "true_energy"]:
+            e_dim, cz_dim = cm["true_energy"], cm["true_coszen"]
+            self.grid = dict(
+                e_major=(cm.names[0] == "true_energy"),
+                energy=K.to_device(e_dim.weighted_centers.m_as("GeV")),
+                coszen=K.to_device(cz_dim.weighted_centers.magnitude),
+                n_e=e_dim.num_bins, n_cz=cz_dim.num_bins)
+        self._calc_layers()
+        self.data["_prob3_stage"] = self  # lets utils.hist find the gather tables
+
+    def _calc_layers(self):
+        if self.grid is not None:
+            self.layers.calcLayers(self.grid["coszen"])
+            _, dens, dist = self.layers.device_arrays
+            self.grid["plan"] = K.GridPlan(dens, dist)
+            self.grid["rows"] = (dens, dist)
+        elif self.calc_mode != "events":
+            for container in self.data:
+                self.layers.calcLayers(container.device("true_coszen"))
+                _, dens, dist = self.layers.device_arrays
+                container["densities"] = dens
+                container["distances"] = dist
+
+    # ---------------------------------------------------------------- compute
+    def _matrices(self):
+        p = self.params
+        for name in ("theta12", "theta13", "theta23", "deltacp"):
+            if p[name].value.units == ureg.dimensionless:
+                raise ValueError("%s is dimensionless, but needs units rad or deg!" % name)
+        o = self.osc_params
+        o.theta12 = p.theta12.value.m_as("rad")
+        o.theta13 = p.theta13.value.m_as("rad")
+        o.theta23 = p.theta23.value.m_as("rad")
+        o.dm21 = p.deltam21.value.m_as("eV**2")
+        o.dm31 = p.deltam31.value.m_as("eV**2")
+        o.deltacp = p.deltacp.value.m_as("rad")
+        if self.nsi_type == "vacuum-like":
+            n = self.nsi_params
+            n.eps_scale = p.eps_scale.value.m_as("dimensionless")
+            n.eps_prime = p.eps_prime.value.m_as("dimensionless")
+            for a in ("phi12", "phi13", "phi23", "alpha1", "alpha2", "deltansi"):
+                setattr(n, a, p[a].value.m_as("rad"))
+        elif self.nsi_type == "standard":
+            n = self.nsi_params
+            n.eps_ee = p.eps_ee.value.m_as("dimensionless")
+            n.eps_emu = (p.eps_emu_magn.value.m_as("dimensionless"), p.eps_emu_phase.value.m_as("rad"))
+            n.eps_etau = (p.eps_etau_magn.value.m_as("dimensionless"), p.eps_etau_phase.value.m_as("rad"))
+            n.eps_mumu = p.eps_mumu.value.m_as("dimensionless")
+            n.eps_mutau = (p.eps_mutau_magn.value.m_as("dimensionless"), p.eps_mutau_phase.value.m_as("rad"))
+            n.eps_tautau = p.eps_tautau.value.m_as("dimensionless")
+        # generalised matter potential (prob3.py:539-557)
+        std = np.zeros((3, 3), dtype=FTYPE) + 1.0j * np.zeros((3, 3), dtype=FTYPE)
+        std[0, 0] += 1.020 if self.include_nlo else 1.0
+        self.gen_mat_pot_matrix_complex = std + self.nsi_params.eps_matrix if self.nsi_type else std
+        if self.neutrino_decay:
+            self.decay_params.decay_alpha3 = p.decay_alpha3.value.m_as("eV**2")
+            self.decay_matrix = self.decay_params.decay_matrix
+        else:
+            self.decay_matrix = np.zeros((3, 3), dtype=CTYPE)
+        self.lri_pot = np.zeros((3, 3), dtype=FTYPE)
+        if self.lri_type is not None:
+            self.lri_params.v_lri = p.v_lri.value.m_as("eV")
+            self.lri_pot = getattr(self.lri_params, "potential_matrix_" + self.lri_type.split("-")[0])
+        mix = o.mix_matrix_reparam_complex if self.reparam_mix_matrix else o.mix_matrix_complex
+        return _lib.make_prob3_params(o.dm_matrix, mix, self.gen_mat_pot_matrix_complex,
+                                      self.decay_flag, self.decay_matrix, self.lri_pot)
+
+    def compute_function(self):
+        p = self.params
+        ye = (p.YeI.value.m_as("dimensionless"), p.YeO.value.m_as("dimensionless"),
+              p.YeM.value.m_as("dimensionless"))
+        if ye != (self.YeI, self.YeO, self.YeM):
+            self.YeI, self.YeO, self.YeM = ye
+            self.layers.setElecFrac(*ye)
+            self._calc_layers()
+        params = self._matrices()
+        if self.grid is not None:
+            g = self.grid
+            P_nu, P_nubar, pepmu = K.prob3_grid_planned(
+                params, g["plan"], g["energy"], e_major=g["e_major"],
+                out_nu=None if self.prob_tables is None else self.prob_tables[0],
+                out_nubar=None if self.prob_tables is None else self.prob_tables[1],
+                out_pepmu=self.pepmu)
+            self.prob_tables, self.pepmu = (P_nu, P_nubar), pepmu
+            for container in self.data.containers:
+                side = 0 if container["nubar"] > 0 else 1
+                flav = int(container["flav"])
+                container["probability"] = self.prob_tables[side]
+                container["prob_e"] = pepmu[side, flav, :, 0].contiguous()
+                container["prob_mu"] = pepmu[side, flav, :, 1].contiguous()
+        else:
+            events = self.calc_mode == "events"
+            earth = self.layers.earth_struct() if events else None
+            for container in self.data.containers:
+                if events:
+                    P = K.prob3_events(params, earth, container["nubar"],
+                                       container.device("true_energy"),
+                                       container.device("true_coszen"))
+                else:
+                    P = K.propagate_array(params, container["nubar"], container.device("true_energy"),
+                                          container.device("densities"), container.device("distances"))
+                container["probability"] = P
+                container["prob_e"] = K.fill_probs(P, 0, container["flav"])   # prob3.py:593-608
+                container["prob_mu"] = K.fill_probs(P, 1, container["flav"])
+
+    # ---------------------------------------------------------------- apply
+    def apply_function(self):
+        for container in self.data:
+            if not container.is_map:
+                deferred.osc(container, "nu_flux")
+            else:
+                w = container.device("weights")
+                K.apply_osc_weights(container.device("nu_flux"), container.device("prob_e"),
+                                    container.device("prob_mu"), w)
+                container["weights"] = w

@@ -1,0 +1,146 @@
+"""Weighted histogramming of events into the output binning (counterpart of
+pisa/stages/utils/hist.py:19-223; events calc_mode).
+
+hist = sum(w), errors = sqrt(sum(w^2)), bin_unc2 = sum(unc^2 * w) on the
+regularised (all-linear) binning: log dimensions are binned in ln(x), irregular
+ones are pre-digitised at setup (hist.py:86-127).
+
+Fast path: if every container's `weights` carry the deferred chain
+[reset, osc, aeff] (loader -> osc.prob3 on a 2-D calc grid -> aeff.aeff), the
+three apply_functions and the three histogram passes of the reference
+(hist.py:198-209) run as ONE pass over HBM through `HotPathEngine`
+(`pisa_hip_reweight_hist`), with exact, order-independent accumulation.
+Otherwise the weights are materialised and histogrammed by
+`pisa_hip_histogram_regular` -- same results, more passes.
+"""
+import numpy as np
+import torch
+
+from pisa_amd import FTYPE
+from pisa_amd import kernels as K
+from pisa_amd.core.binning import MultiDimBinning
+from pisa_amd.core.container import regularized
+from pisa_amd.core.stage import Stage
+from pisa_amd.stages import deferred
+
+__all__ = ["hist"]
+
+
+class hist(Stage):  # pylint: disable=invalid-name
+    def __init__(self, apply_unc_weights=False, unweighted=False, **std_kwargs):
+        keys = ["weights"] + (["unc_weights"] if apply_unc_weights else [])
+        supported_reps = {"calc_mode": [MultiDimBinning, "events"],
+                          "apply_mode": [None, MultiDimBinning]}
+        super().__init__(expected_params=(), expected_container_keys=keys,
+                         supported_reps=supported_reps, **std_kwargs)
+        self.apply_unc_weights = apply_unc_weights
+        self.unweighted = unweighted
+        self._engine = None
+        self._engine_flux_ids = None
+        self.fused_last_eval = False
+
+    def setup_function(self):
+        if self.apply_mode is None:
+            self.apply_mode = self.data["output_binning"]
+        else:
+            assert self.apply_mode == self.data["output_binning"]
+        if isinstance(self.calc_mode, MultiDimBinning):
+            raise NotImplementedError("binned calc_mode (hist_transform) is not part of this build; "
+                                      "use calc_mode = events")
+        # regularised binning + per-container sample columns (device), once
+        self._samples = {}
+        for container in self.data.containers:
+            container.representation = "events"
+            binning, cols = regularized(self.apply_mode, lambda n, log, c=container: (
+                np.log(c[n]) if log else c[n]))
+            self._samples[container.name] = [K.to_device(np.asarray(col, dtype=FTYPE)) for col in cols]
+        self._reg_binning = binning
+        self.data["regularized_output_binning"] = binning
+        self._engine = None
+
+    # ------------------------------------------------------------------ fused
+    def _find_prob3(self):
+        stage = self.data._glob_aux_data.get("_prob3_stage")
+        return stage if (stage is not None and stage.grid is not None and stage.pepmu is not None) else None
+
+    def _fused(self):
+        if self.unweighted or self.apply_unc_weights:
+            return False
+        conts = self.data.containers
+        chains = [deferred.fusable_chain(c) for c in conts]
+        if any(ch is None for ch in chains) or any("astro_weights" in c.all_keys for c in conts):
+            return False
+        osc = self._find_prob3()
+        if osc is None:
+            return False
+        from pisa_amd.engine import GridSpec, HotPathEngine
+
+        flux_key = chains[0][0]
+        if self._engine is None:
+            g = osc.grid
+            cm = osc.calc_mode
+            e_dim, cz_dim = cm["true_energy"], cm["true_coszen"]
+            grid = GridSpec(tuple(e_dim.domain.m_as("GeV")), e_dim.num_bins,
+                            tuple(cz_dim.domain.magnitude), cz_dim.num_bins, energy_first=g["e_major"])
+            import torch.distributed as dist
+
+            world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+            rank = dist.get_rank() if world > 1 else 0
+            evs = []
+            for c in conts:
+                c.representation = "events"
+                evs.append(dict(name=c.name, flav=int(c["flav"]), nubar=int(c["nubar"]),
+                                true_energy=c["true_energy"], true_coszen=c["true_coszen"],
+                                nu_flux=c[flux_key], weighted_aeff=c["weighted_aeff"],
+                                initial_weights=c["initial_weights"],
+                                sample=[s.cpu().numpy() for s in self._samples[c.name]], scale=1.0))
+            self._engine = HotPathEngine(evs, grid, self._reg_binning, None, 0, rank=rank,
+                                         world_size=world, external_tables=True)
+            self._engine_flux_ids = [id(c.current_data[flux_key]) for c in conts]
+        eng = self._engine
+        for i, (c, ch) in enumerate(zip(conts, chains)):
+            c.representation = "events"
+            eng.set_scale(c.name, ch[1])
+            if id(c.current_data[flux_key]) != self._engine_flux_ids[i]:
+                eng.update_flux(i, c.device(flux_key))   # flux systematics changed
+                self._engine_flux_ids[i] = id(c.current_data[flux_key])
+        eng.pepmu = osc.pepmu
+        eng.accumulate()
+        eng.allreduce()
+        hist_d, sumw2_d = eng.finalize()
+        for i, c in enumerate(conts):
+            c.pending.pop(deferred.KEY, None)  # consumed by the fused kernel
+            c.representation = self.apply_mode
+            c["weights"] = hist_d[i]
+            if self.error_method == "sumw2":
+                c["errors"] = torch.sqrt(sumw2_d[i])
+                c["bin_unc2"] = hist_d[i]  # sum(1^2 * w), hist.py:207-209
+        return True
+
+    # ------------------------------------------------------------------ apply
+    def apply_function(self):
+        self.fused_last_eval = self._fused()
+        if self.fused_last_eval:
+            return
+        for container in self.data:
+            container.representation = "events"
+            sample = self._samples[container.name]
+            weights = container.device("weights")  # materialises any deferred chain
+            if "astro_weights" in container.keys:
+                weights = weights + container.device("astro_weights")
+            if self.unweighted:
+                weights = torch.ones_like(weights)
+            unc = container.device("unc_weights") if self.apply_unc_weights else None
+            w = weights if unc is None else unc * weights
+            h = K.histogram_regular(sample, w, self._reg_binning)
+            if self.error_method == "sumw2":
+                sumw2 = K.histogram_regular(sample, w * w, self._reg_binning)
+                bin_unc2 = h if unc is None else K.histogram_regular(sample, unc * unc * weights,
+                                                                    self._reg_binning)
+            container.representation = self.apply_mode
+            container["weights"] = h
+            # histogramming does not invalidate the event-wise weights (hist.py:213)
+            container.validity["weights"][hash("events")] = True
+            if self.error_method == "sumw2":
+                container["errors"] = torch.sqrt(sumw2)
+                container["bin_unc2"] = bin_unc2

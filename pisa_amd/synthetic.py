@@ -56,11 +56,11 @@ def aeff_scale_for(name, aeff_scale=1.0, livetime_s=LIVETIME_S, nutau_cc_norm=1.
     return scale
 
 
-def make_events(n_per, seed=0):
+def make_events(n_per, seed=0, names=NAMES):
     rs = np.random.RandomState(seed)
     rr = np.random.RandomState(seed + 1)
     out = []
-    for name in NAMES:
+    for name in names:
         flav, nubar = flav_nubar(name)
         e = np.power(10, rs.rand(n_per) * 3)
         cz = rs.rand(n_per) * 2 - 1

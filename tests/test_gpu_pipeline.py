@@ -1,0 +1,153 @@
+"""Drop-in boundary tests on the GPU: the reference's `Pipeline(cfg)` /
+`Stage` / `Container` protocol driving the HIP kernels, checked against the CPU
+oracle.  `settings/pipeline/osc_example.cfg` is the reference's file, unmodified."""
+import numpy as np
+import pytest
+
+from tests.conftest import PROB3_ATOL, PROB3_RTOL
+
+pytestmark = pytest.mark.gpu
+AC = dict(rtol=PROB3_RTOL, atol=PROB3_ATOL)
+
+NAMES = ["nue_cc", "numu_cc", "nutau_cc", "nue_nc", "numu_nc", "nutau_nc",
+         "nuebar_cc", "numubar_cc", "nutaubar_cc", "nuebar_nc", "numubar_nc", "nutaubar_nc"]
+
+
+def _oracle_grid(oracle, binning, theta23_deg=42.0, dm31=2.457e-3):
+    """P[nubar][iE, jcz, 3, 3] on the calc grid with osc_example.cfg's nominal parameters"""
+    e = binning["true_energy"].weighted_centers.m_as("GeV")
+    cz = binning["true_coszen"].weighted_centers.magnitude
+    prem = np.loadtxt(__import__("pisa_amd.utils.resources", fromlist=["x"]).find_resource("osc/PREM_12layer.dat"))
+    lay = oracle.Layers(prem, 2.0, 20.0)
+    lay.setElecFrac(0.4656, 0.4656, 0.4957)
+    lay.calcLayers(cz)
+    mix = oracle.mix_matrix(np.deg2rad(33.48), np.deg2rad(8.5), np.deg2rad(theta23_deg), 0.0)
+    dm = oracle.dm_matrix(7.5e-5, dm31)
+    mat_pot = np.diag([1.0, 0, 0]).astype(complex)
+    zero = np.zeros((3, 3))
+    out = {}
+    for nubar in (1, -1):
+        P = oracle.propagate_array(dm, mix, mat_pot, -1, zero.astype(complex), zero, nubar,
+                                   np.repeat(e, len(cz)), np.tile(lay.density, (len(e), 1)),
+                                   np.tile(lay.distance, (len(e), 1)))
+        out[nubar] = P.reshape(len(e), len(cz), 3, 3)
+    return out
+
+
+def test_osc_example_cfg_unmodified(oracle):
+    from pisa_amd.core.pipeline import Pipeline
+
+    pipe = Pipeline("settings/pipeline/osc_example.cfg", profile=True)
+    assert pipe.service_names == ["toy_event_generator", "barr_simple", "prob3"]
+    maps = pipe.get_outputs()
+    assert maps.names == NAMES
+    binning = pipe.output_binning
+    assert binning.shape == (200, 200)
+    ref = _oracle_grid(oracle, binning)
+    for m in maps:
+        nubar = -1 if "bar" in m.name else 1
+        flav = 0 if "nue" in m.name else (1 if "numu" in m.name else 2)
+        # nominal toy flux is (0, 1): the map is the P(numu -> nu_flav) oscillogram
+        np.testing.assert_allclose(m.hist, ref[nubar][:, :, 1, flav], err_msg=m.name, **AC)
+    # SURVEY Appendix A known answers (oracle executed on the reference itself)
+    mu = maps["numu_cc"].hist
+    np.testing.assert_allclose(mu[0, 0], 0.615974149730982, rtol=1e-10)
+    np.testing.assert_allclose(mu[60, 10], 0.22092348875739223, rtol=1e-10)
+    np.testing.assert_allclose(maps["nutaubar_cc"].hist[100, 0], 0.8420728703910567, rtol=1e-10)
+    # compute memo: unchanged params -> prob3.compute_function is not re-run (stage.py:536-557)
+    osc = pipe["prob3"]
+    n = len(osc.calc_times)
+    pipe.get_outputs()
+    assert len(osc.calc_times) == n
+    # change a free parameter -> recomputed, new oscillogram
+    from pisa_amd.core.units import ureg
+
+    pipe.params.theta23.value = 49.0 * ureg.degree
+    maps2 = pipe.get_outputs()
+    assert len(osc.calc_times) == n + 1
+    ref2 = _oracle_grid(oracle, binning, theta23_deg=49.0)
+    np.testing.assert_allclose(maps2["numu_cc"].hist, ref2[1][:, :, 1, 1], **AC)
+    assert np.abs(maps2["numu_cc"].hist - mu).max() > 1e-3
+
+
+def _oracle_event_pipeline(oracle, pipe, flux_params=(1.0, 1.0, 0.0, 0.0, 0.0), theta23_deg=42.3,
+                           aeff_scale=1.0):
+    """reference chain on the pipeline's own input columns"""
+    grid = _oracle_grid(oracle, pipe["prob3"].calc_mode, theta23_deg=theta23_deg)
+    cm = pipe["prob3"].calc_mode
+    lo, hi = cm["true_energy"].domain.m_as("GeV")
+    mins, maxs, nb = [np.log(lo), -1.0], [np.log(hi), 1.0], [cm["true_energy"].num_bins, cm["true_coszen"].num_bins]
+    ob = pipe.output_binning
+    omin = [np.log(5.0), -1.0, -1000.0]
+    omax = [np.log(100.0), 1.0, 1000.0]
+    onb = list(ob.shape)
+    livetime = 2.5 * 365 * 86400.0
+    hists, errs = {}, {}
+    for c in pipe.data.containers:
+        c.representation = "events"
+        e, cz = c["true_energy"], c["true_coszen"]
+        nubar, flav = c["nubar"], c["flav"]
+        flux = oracle.barr_simple(e, cz, c["nu_flux_nominal"], c["nubar_flux_nominal"], nubar, *flux_params)
+        P = grid[nubar].reshape(-1, 3, 3)
+        pe = oracle.lookup_regular([np.log(e), cz], np.ascontiguousarray(P[:, 0, flav]), mins, maxs, nb)
+        pmu = oracle.lookup_regular([np.log(e), cz], np.ascontiguousarray(P[:, 1, flav]), mins, maxs, nb)
+        w = oracle.reweight(c["initial_weights"], flux, pe, pmu, c["weighted_aeff"], aeff_scale * livetime)
+        sample = [np.log(c["reco_energy"]), c["reco_coszen"], c["pid"]]
+        hists[c.name] = oracle.histogram_regular(sample, w, omin, omax, onb).reshape(ob.shape)
+        errs[c.name] = np.sqrt(oracle.histogram_regular(sample, w * w, omin, omax, onb)).reshape(ob.shape)
+    return hists, errs
+
+
+def test_event_pipeline_fused_and_unfused(oracle):
+    from pisa_amd.core.pipeline import Pipeline
+    from pisa_amd.core.units import ureg
+
+    pipe = Pipeline("settings/pipeline/example_hip.cfg")
+    hist_stage = pipe["hist"]
+    maps = pipe.get_outputs()
+    assert hist_stage.fused_last_eval, "the deferred chain reset->osc->aeff must take the fused kernel"
+    ref_h, ref_e = _oracle_event_pipeline(oracle, pipe)
+    for m in maps:
+        np.testing.assert_allclose(m.hist, ref_h[m.name], rtol=1e-11, atol=1e-300, err_msg=m.name)
+        np.testing.assert_allclose(m.std_devs, ref_e[m.name], rtol=1e-11, atol=1e-300, err_msg=m.name)
+    assert sum(m.hist.sum() for m in maps) > 0
+
+    # free parameters of three different stages change: flux (engine.update_flux),
+    # osc (new gather tables), aeff (scale)
+    pipe.params.delta_index.value = 0.05 * ureg.dimensionless
+    pipe.params.theta23.value = 47.0 * ureg.degree
+    pipe.params.aeff_scale.value = 1.3 * ureg.dimensionless
+    maps2 = pipe.get_outputs()
+    assert hist_stage.fused_last_eval
+    ref_h2, ref_e2 = _oracle_event_pipeline(oracle, pipe, flux_params=(1.0, 1.0, 0.05, 0.0, 0.0),
+                                            theta23_deg=47.0, aeff_scale=1.3)
+    for m in maps2:
+        np.testing.assert_allclose(m.hist, ref_h2[m.name], rtol=1e-11, atol=1e-300, err_msg=m.name)
+        np.testing.assert_allclose(m.std_devs, ref_e2[m.name], rtol=1e-11, atol=1e-300)
+
+    # stage-by-stage (unfused) execution gives the same maps: touching the
+    # weights materialises the deferred chain with the one-stage kernels
+    pipe2 = Pipeline("settings/pipeline/example_hip.cfg")
+    pipe2.params.delta_index.value = 0.05 * ureg.dimensionless
+    pipe2.params.theta23.value = 47.0 * ureg.degree
+    pipe2.params.aeff_scale.value = 1.3 * ureg.dimensionless
+    pipe2["hist"]._fused = lambda: False
+    maps3 = pipe2.get_outputs()
+    assert not pipe2["hist"].fused_last_eval
+    for a, b in zip(maps2, maps3):
+        np.testing.assert_allclose(a.hist, b.hist, rtol=1e-13, atol=1e-300)
+        np.testing.assert_allclose(a.std_devs, b.std_devs, rtol=1e-13, atol=1e-300)
+    # event-wise weights are visible to host code exactly as the reference leaves them
+    c = pipe2.data["numu_cc"]
+    c.representation = "events"
+    assert c["weights"].shape == c["true_energy"].shape and np.all(np.isfinite(c["weights"]))
+
+    # metric through the Map API (GPU kernel) against the oracle
+    total = sum(maps2)
+    data = total.fluctuate("poisson", random_state=0)
+    got = data.llh(total)
+    _, want = oracle.metric("llh", data.hist, total.hist)
+    np.testing.assert_allclose(got, want, rtol=1e-10)
+    got = data.mod_chi2(total)
+    _, want = oracle.metric("mod_chi2", data.hist, total.hist, total.variances)
+    np.testing.assert_allclose(got, want, rtol=1e-10)
