@@ -53,6 +53,51 @@ class GridSpec:
         return self.n_e * self.n_cz
 
 
+def shard_bounds(n, rank, world_size):
+    """contiguous equal slices of a container's events over the ranks"""
+    return (rank * n) // world_size, ((rank + 1) * n) // world_size
+
+
+def allreduce_limbs(limbs, world_size, group=None):
+    """Integer SUM all-reduce of the histogram limbs over RCCL/xGMI (gloo in the
+    CPU tests).  The limbs are exact fixed-point partial sums, so the reduced
+    value -- and every map / LLH derived from it -- does not depend on the ring
+    order or on the number of ranks."""
+    if world_size > 1:
+        import torch.distributed as dist
+
+        dist.all_reduce(limbs, op=dist.ReduceOp.SUM, group=group)
+    return limbs
+
+
+LIMB_BITS, LIMB_LSB, N_LIMBS = 32, 116, 6
+
+
+def limbs_to_float(limbs):
+    """Host-side decoder of one accumulator (6 int64 limbs, possibly
+    un-normalised sums over workgroups / ranks): value = sum limb_j*2^(32j-116),
+    rounded once to fp64.  Python integers are exact; used by tests and tools --
+    the product path converts on the device (`hist_finalize_kernel`)."""
+    from fractions import Fraction
+
+    total = sum(int(v) << (LIMB_BITS * j) for j, v in enumerate(limbs))
+    return float(Fraction(total, 1 << LIMB_LSB))
+
+
+def float_to_limbs(x):
+    """exact canonical limbs of a double (|x| < 2^76, resolution 2^-116)"""
+    from fractions import Fraction
+
+    f = Fraction(float(x)) * (1 << LIMB_LSB)
+    total = int(f) if f >= 0 else -int(-f)  # truncate towards zero below 2^-116
+    out = []
+    for _ in range(N_LIMBS - 1):
+        out.append(total & 0xFFFFFFFF)
+        total >>= LIMB_BITS
+    out.append(total)
+    return out
+
+
 class HotPathEngine:
     """See module docstring.  `containers` is a list of dicts with keys
     name, flav, nubar, true_energy, true_coszen, nu_flux[n,2], weighted_aeff,
@@ -75,7 +120,7 @@ class HotPathEngine:
         self.n_local = 0
         for c in containers:
             n = len(c["true_energy"])
-            lo, hi = (rank * n) // world_size, ((rank + 1) * n) // world_size
+            lo, hi = shard_bounds(n, rank, world_size)
             sl = slice(lo, hi)
             self._slices.append((lo, hi))
             d = _lib.Container()
@@ -176,12 +221,7 @@ class HotPathEngine:
                         self.pepmu if self.indexed else None, self.out_binning, self.ws)
 
     def allreduce(self):
-        """Integer SUM all-reduce of the histogram limbs over RCCL/xGMI (or gloo in
-        CPU tests): exact, hence independent of ring order and rank count."""
-        if self.world_size > 1:
-            import torch.distributed as dist
-
-            dist.all_reduce(self.ws.limbs, op=dist.ReduceOp.SUM, group=self.group)
+        allreduce_limbs(self.ws.limbs, self.world_size, self.group)
 
     def finalize(self):
         return K.hist_finalize(self.ws)

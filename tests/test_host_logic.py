@@ -1,0 +1,148 @@
+"""CPU tests of the host-side mirror of the reference interface (no GPU):
+units, binning numerics, cfg grammar, params / priors / hashing."""
+import numpy as np
+import pytest
+
+from pisa_amd.core.binning import MultiDimBinning, OneDimBinning
+from pisa_amd.core.config_parser import parse_pipeline_config, parse_quantity
+from pisa_amd.core.param import Param, ParamSelector, ParamSet, Prior
+from pisa_amd.core.units import DimensionalityError, Quantity, ureg
+
+
+def test_units_match_pint_conventions():
+    q = 42.0 * ureg.degree
+    assert q.m_as("rad") == np.deg2rad(42.0)
+    assert (2.5 * ureg.common_year).m_as("sec") == 2.5 * 365 * 86400
+    assert (7.5e-5 * ureg.eV ** 2).m_as("eV**2") == 7.5e-5
+    r = [0.001, 0.007] * ureg.eV ** 2
+    np.testing.assert_array_equal(r.magnitude, [0.001, 0.007])
+    assert (np.array([1.0, 80.0]) * ureg.GeV).m_as("GeV")[1] == 80.0
+    assert Quantity(0.3).units == ureg.dimensionless
+    assert not (q.units == ureg.dimensionless)
+    with pytest.raises(DimensionalityError):
+        q.m_as("km")
+    assert ureg.parse_expression("33.48 deg").m_as("deg") == 33.48
+    assert (1 * ureg.GeV).m_as("eV") == 1e9
+
+
+def test_binning_numerics_follow_reference():
+    # edges: np.logspace / np.linspace (binning.py:416-428); centres: geometric mean (:901-911)
+    e = OneDimBinning("true_energy", num_bins=200, is_log=True, domain=[1.0, 1000] * ureg.GeV)
+    edges = np.logspace(0, 3, 201)
+    np.testing.assert_array_equal(e.edge_magnitudes, edges)
+    np.testing.assert_array_equal(e.weighted_centers.m, np.sqrt(edges[:-1] * edges[1:]))
+    assert e.weighted_centers.m[0] == 1.017419366180605
+    cz = OneDimBinning("true_coszen", num_bins=200, is_lin=True, domain=[-1, 1])
+    assert cz.weighted_centers.m[0] == -0.995 and not cz.is_irregular and not e.is_irregular
+    b = MultiDimBinning([e, cz])
+    assert b.shape == (200, 200) and b.size == 40000 and b.names == ["true_energy", "true_coszen"]
+    grid = b.meshgrid("weighted_centers")
+    assert grid[0].ravel()[201] == e.weighted_centers.m[1]  # flat = iE*n_cz + jcz
+    assert hash(b) == hash(MultiDimBinning([e, cz])) and b == MultiDimBinning([e, cz])
+    assert hash(b) != hash(MultiDimBinning([cz, e]))
+    # dragon's 8-digit log edges are NOT log-uniform at rtol 1e-12 -> irregular
+    dragon = OneDimBinning("reco_energy", is_log=True, bin_edges=[5.62341325, 7.49894209, 10.0,
+                           13.33521432, 17.7827941, 23.71373706, 31.6227766, 42.16965034, 56.23413252])
+    assert dragon.is_irregular
+    pid = OneDimBinning("pid", bin_edges=[-1000.0, 0.0, 1000.0])
+    assert not pid.is_irregular and pid.is_lin
+    inf_pid = OneDimBinning("pid", bin_edges=[-np.inf, 0.55, np.inf])
+    assert inf_pid.is_irregular
+    over = cz.oversample(10)
+    assert over.num_bins == 2000 and over.edge_magnitudes[10] == cz.edge_magnitudes[1]
+    vol = MultiDimBinning([cz, pid]).bin_volumes()
+    assert vol.shape == (200, 2) and np.isclose(vol[0, 0], 0.01 * 1000)
+
+
+def test_cfg_grammar_osc_example():
+    cfg = parse_pipeline_config("settings/pipeline/osc_example.cfg")
+    assert list(cfg)[1:] == [("data", "toy_event_generator"), ("flux", "barr_simple"), ("osc", "prob3")]
+    pl = cfg["pipeline"]
+    assert pl["name"] == "neutrinos" and pl["output_key"] == "weights"
+    assert pl["output_binning"].shape == (200, 200)
+    osc = cfg[("osc", "prob3")]
+    assert osc["calc_mode"] == pl["output_binning"]
+    p = osc["params"].params
+    # param_selections = nh picks the nh variants; ${osc:...} interpolation + 'units.' parsing
+    assert p.theta23.value.m_as("deg") == 42.0 and not p.theta23.is_fixed
+    assert p.theta23.range[1].m_as("deg") == 90.0 and p.theta23.prior.kind == "uniform"
+    assert p.deltam31.value.m_as("eV**2") == 2.457e-3
+    assert p.theta13.value.m_as("deg") == 8.5 and p.theta13.prior.kind == "gaussian"
+    assert p.theta13.prior.stddev.m_as("deg") == 0.205
+    assert p.theta12.value.m_as("deg") == 33.48 and p.YeM.value.m == 0.4957
+    assert p.detector_depth.value.m_as("km") == 2.0 and p.earth_model.value == "osc/PREM_12layer.dat"
+    osc["params"].select_params(["ih"])
+    assert osc["params"].params.deltam31.value.m_as("eV**2") == -2.374e-3
+    flux = cfg[("flux", "barr_simple")]["params"].params
+    # 'nominal + [-5, +5] * sigma'
+    np.testing.assert_allclose([r.m for r in flux.delta_index.range], [-0.5, 0.5])
+    assert flux.delta_index.prior.kind == "gaussian" and not flux.delta_index.is_fixed
+    toy = cfg[("data", "toy_event_generator")]
+    assert toy["output_names"][0] == "nue_cc" and len(toy["output_names"]) == 12
+    assert toy["params"].params.random.value is False
+    q = parse_quantity("1.2 +/- 0.7 * units.meter")
+    assert (q.nominal_value, q.std_dev) == (1.2, 0.7) and q.units == ureg.m
+
+
+def test_param_rescaling_hash_and_priors():
+    p = Param("theta23", 42.0 * ureg.deg, prior=Prior("uniform"), range=[0.0, 90.0] * ureg.deg,
+              is_fixed=False)
+    assert np.isclose(p._rescaled_value, 42.0 / 90.0)
+    p._rescaled_value = 0.5
+    assert p.value.m_as("deg") == 45.0
+    with pytest.raises(ValueError):
+        p._rescaled_value = 1.5
+    with pytest.raises(ValueError):
+        p.value = 100.0 * ureg.deg
+    g = Param("x", 1.0, prior=Prior("gaussian", mean=Quantity(1.0), stddev=Quantity(0.5)),
+              range=[0.0, 2.0], is_fixed=False)
+    ps = ParamSet([p, g, Param("fixed", 3.0)])
+    h0 = ps.values_hash
+    g.value = Quantity(1.5)
+    assert ps.values_hash != h0
+    assert np.isclose(ps.priors_penalty("llh"), -0.5)       # -(x-m)^2/(2 s^2), prior.py:249-253
+    assert np.isclose(ps.priors_penalty("mod_chi2"), 1.0)   # chi2 = -2 llh
+    g.value = Quantity(1.0 + 1e-14)  # below 12 significant figures: same hash as 1.0
+    g2 = Quantity(1.0)
+    hh = ps.values_hash
+    g.value = g2
+    assert ps.values_hash == hh
+    assert ps.free.names == ("theta23", "x")
+    ps.randomize_free(random_state=0)
+    rs = np.random.RandomState(0).rand(2)
+    assert np.isclose(p.value.m_as("deg"), 90 * rs[0]) and np.isclose(g.value.m, 2 * rs[1])
+    ps.reset_free()
+    assert p.value.m_as("deg") == 42.0
+    sel = ParamSelector(regular_params=[Param("a", 1.0)],
+                        selector_param_sets={"nh": [Param("dm", 2.0)], "ih": [Param("dm", -2.0)]},
+                        selections=["nh"])
+    assert sel.params.dm.value.m == 2.0
+    sel.select_params(["ih"])
+    assert sel.params.dm.value.m == -2.0 and sel.params.a.value.m == 1.0
+
+
+def test_stage_param_checks_and_memo():
+    from pisa_amd.core.stage import Stage
+
+    class demo(Stage):  # pylint: disable=invalid-name
+        def __init__(self, **kw):
+            super().__init__(expected_params=("a",), expected_container_keys=(), **kw)
+            self.n = 0
+
+        def compute_function(self):
+            self.n += 1
+
+    with pytest.raises(ValueError):
+        demo(params=ParamSet([Param("b", 1.0)]))
+    from pisa_amd.core.container import ContainerSet
+
+    s = demo(params=ParamSet([Param("a", 1.0, is_fixed=False, range=[0, 2])]), calc_mode="events")
+    s.data = ContainerSet("x")
+    s.setup()
+    s.compute(); s.compute()
+    assert s.n == 1
+    s.params.a.value = Quantity(1.5)
+    s.compute()
+    assert s.n == 2
+    with pytest.raises(ValueError):
+        demo(params=ParamSet([Param("a", 1.0)]), calc_mode="nonsense")
