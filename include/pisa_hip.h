@@ -141,6 +141,23 @@ int pisa_hip_prob3_events(const pisa_hip_prob3_params *h_params, const pisa_hip_
                           int64_t nubar, const double *d_energy, const double *d_coszen,
                           int64_t n, double *d_probability, int32_t *d_status, void *stream);
 
+/* The same for several containers in ONE launch (prob3.py:581-588 loops over the
+ * 12 containers), optionally writing only the two probabilities the container
+ * needs: d_pepmu[n][2] = (P[e->flav], P[mu->flav]) = (prob_e, prob_mu) of
+ * `fill_probs` (prob3.py:593-608). */
+typedef struct {
+    int64_t n_events;
+    const double *d_energy;
+    const double *d_coszen;
+    double *d_probability;   /* [n][3][3] or NULL */
+    double *d_pepmu;         /* [n][2] or NULL    */
+    int32_t nubar;           /* +1 / -1 */
+    int32_t flav;            /* 0, 1, 2 */
+} pisa_hip_event_set;
+int pisa_hip_prob3_events_multi(const pisa_hip_prob3_params *h_params,
+                                const pisa_hip_earth *h_earth, const pisa_hip_event_set *h_sets,
+                                int32_t n_sets, int32_t *d_status, void *stream);
+
 /* `fill_probs` (numba_osc_hostfuncs.py:206-221): out[i] = P[i][init_flav][flav]. */
 int pisa_hip_fill_probs(const double *d_probability, int64_t init_flav, int64_t flav, int64_t n,
                         double *d_out, void *stream);
@@ -199,6 +216,8 @@ typedef struct {
     const int32_t *d_bin;            /* [n] output bin of each event, -1 outside (optional)     */
     const int32_t *d_node_bin;       /* [n][2] the two above interleaved (optional, fastest)    */
     const double *d_aeff_w0;         /* [n][2] (weighted_aeff, initial_weights) interleaved (opt.) */
+    const double *d_pepmu;           /* [n_nodes][2] this container's own (P_e, P_mu) table,
+                                        overrides the grid tables (event-mode prob3: node = event) */
     int32_t flav;                    /* 0 e, 1 mu, 2 tau  (aux 'flav')                     */
     int32_t nubar;                   /* +1 / -1           (aux 'nubar')                    */
     double scale;                    /* aeff_scale*livetime_s*norms (aeff.py:78-86)        */

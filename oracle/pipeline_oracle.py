@@ -14,6 +14,28 @@ import numpy as np
 from . import oracle as orc
 
 
+def oracle_eval_events(wl, matrices=None, containers=None):
+    """Event-by-event oscillation (calc_mode = events, prob3.py:406-409, 581-608):
+    layers per event, propagate_array per container, no grid lookup."""
+    m = matrices or wl.last_matrices
+    lay = orc.Layers(wl.layers.prem, wl.layers.detector_depth, wl.layers.prop_height)
+    lay.rhos = np.array(wl.layers.rhos)
+    ob = wl.ob
+    hists, sumw2s = [], []
+    for ev in (wl.events if containers is None else containers):
+        lay.calcLayers(ev["true_coszen"])
+        P = orc.propagate_array(m["dm"], m["mix"], m["mat_pot"], m["decay_flag"], m["mat_decay"],
+                                m["lri_pot"], ev["nubar"], ev["true_energy"], lay.density,
+                                lay.distance)
+        pe, pmu = orc.fill_probs(P, 0, ev["flav"]), orc.fill_probs(P, 1, ev["flav"])
+        w = orc.reweight(ev["initial_weights"], ev["nu_flux"], pe, pmu, ev["weighted_aeff"],
+                         ev["scale"])
+        hists.append(orc.histogram_regular(ev["sample"], w, ob["mins"], ob["maxs"], ob["nbins"]))
+        sumw2s.append(orc.histogram_regular(ev["sample"], np.square(w), ob["mins"], ob["maxs"],
+                                            ob["nbins"]))
+    return dict(hist=np.array(hists), sumw2=np.array(sumw2s))
+
+
 def oracle_eval(wl, matrices=None, containers=None):
     m = matrices or wl.last_matrices
     g = wl.grid

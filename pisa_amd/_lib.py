@@ -57,6 +57,18 @@ class Binning(C.Structure):
     ]
 
 
+class EventSet(C.Structure):
+    _fields_ = [
+        ("n_events", C.c_int64),
+        ("d_energy", C.c_void_p),
+        ("d_coszen", C.c_void_p),
+        ("d_probability", C.c_void_p),
+        ("d_pepmu", C.c_void_p),
+        ("nubar", C.c_int32),
+        ("flav", C.c_int32),
+    ]
+
+
 class Container(C.Structure):
     _fields_ = [
         ("n_events", C.c_int64),
@@ -70,6 +82,7 @@ class Container(C.Structure):
         ("d_bin", C.c_void_p),
         ("d_node_bin", C.c_void_p),
         ("d_aeff_w0", C.c_void_p),
+        ("d_pepmu", C.c_void_p),
         ("flav", C.c_int32),
         ("nubar", C.c_int32),
         ("scale", C.c_double),
@@ -89,6 +102,7 @@ _SIGS = {
     "pisa_hip_prob3_grid_planned": (C.c_int, [C.POINTER(Prob3Params), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pisa_hip_calc_layers": (C.c_int, [C.POINTER(Earth), C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pisa_hip_prob3_events": (C.c_int, [C.POINTER(Prob3Params), C.POINTER(Earth), C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pisa_hip_prob3_events_multi": (C.c_int, [C.POINTER(Prob3Params), C.POINTER(Earth), C.POINTER(EventSet), C.c_int32, C.c_void_p, C.c_void_p]),
     "pisa_hip_fill_probs": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "pisa_hip_lookup_regular": (C.c_int, [C.POINTER(Binning), C.POINTER(C.c_void_p), C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "pisa_hip_histogram_regular": (C.c_int, [C.POINTER(Binning), C.POINTER(C.c_void_p), C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),

@@ -112,6 +112,7 @@ struct ContDev {
     const int32_t *node, *bin;  // optional pre-digitised indices
     const int2 *node_bin;       // optional packed (node, bin) per event
     const double2 *aeff_w0;     // optional packed (weighted_aeff, initial_weights) per event
+    const double2 *pepmu_own;   // optional per-container (P_e, P_mu) table (event-mode prob3)
     double scale;
     int32_t flav, side;
 };
@@ -182,7 +183,8 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
 
     if (MODE == 3) {
         // packed columns: (node, bin) int2 and (aeff, w0) double2 per event; every load is 16 B
-        const double2 *tab = a.pepmu + ((int64_t)C.side * 3 + C.flav) * a.n_nodes;
+        const double2 *tab = C.pepmu_own ? C.pepmu_own
+                                         : a.pepmu + ((int64_t)C.side * 3 + C.flav) * a.n_nodes;
         const double scale = C.scale;
         const int64_t p0 = start >> 1, p1 = end >> 1;
         const int4 *idx4 = reinterpret_cast<const int4 *>(C.node_bin);
@@ -531,8 +533,10 @@ PISA_API int pisa_hip_reweight_hist(const pisa_hip_container *h_containers, int3
     if (grid.ndim > 2) return PISA_HIP_ERR_INVALID;
     if ((rc = make_dev_binning(h_out_binning, outb, n_bins))) return rc;
     ContDev *conts = new ContDev[n_containers];
+    bool any_table = d_pepmu != nullptr;
+    for (int c = 0; c < n_containers; c++) any_table = any_table || h_containers[c].d_pepmu;
     bool all_indexed = d_pepmu != nullptr;
-    bool all_packed = d_pepmu != nullptr;
+    bool all_packed = any_table;
     for (int c = 0; c < n_containers; c++) {
         const pisa_hip_container &h = h_containers[c];
         ContDev &d = conts[c];
@@ -541,14 +545,15 @@ PISA_API int pisa_hip_reweight_hist(const pisa_hip_container *h_containers, int3
         bool bad = h.n_events < 0 || h.flav < 0 || h.flav > 2 || (h.nubar != 1 && h.nubar != -1);
         if (h.n_events > 0) {
             bad = bad || !h.d_nu_flux;
-            if (!(packed && d_pepmu)) bad = bad || !h.d_weighted_aeff || !h.d_initial_weights;
-            if (!(indexed && d_pepmu)) {
+            const bool has_tab = d_pepmu || h.d_pepmu;
+            if (!(packed && has_tab)) bad = bad || !h.d_weighted_aeff || !h.d_initial_weights;
+            if (!(indexed && has_tab)) {
                 bad = bad || !h.d_grid_x || (grid.ndim > 1 && !h.d_grid_y);
                 for (int k = 0; k < outb.ndim; k++) bad = bad || !h.d_sample[k];
                 bad = bad || (h.nubar > 0 ? !d_prob_nu : !d_prob_nubar);
             }
             all_indexed = all_indexed && indexed && (h.d_node && h.d_bin);
-            all_packed = all_packed && packed;
+            all_packed = all_packed && packed && has_tab;
         }
         if (bad) { delete[] conts; return PISA_HIP_ERR_INVALID; }
         d.n = h.n_events;
@@ -558,6 +563,7 @@ PISA_API int pisa_hip_reweight_hist(const pisa_hip_container *h_containers, int3
         d.node = h.d_node; d.bin = h.d_bin;
         d.node_bin = reinterpret_cast<const int2 *>(h.d_node_bin);
         d.aeff_w0 = reinterpret_cast<const double2 *>(h.d_aeff_w0);
+        d.pepmu_own = reinterpret_cast<const double2 *>(h.d_pepmu);
         d.scale = h.scale;
         d.flav = h.flav;
         d.side = h.nubar > 0 ? 0 : 1;
@@ -607,7 +613,7 @@ PISA_API int pisa_hip_histogram_regular(const pisa_hip_binning *h_binning,
         c.n = n; c.gx = c.gy = c.flux = c.aeff = nullptr; c.w0 = d_weights;
         for (int k = 0; k < 3; k++) c.s[k] = k < outb.ndim ? h_d_sample[k] : nullptr;
         c.node = c.bin = nullptr;
-        c.node_bin = nullptr; c.aeff_w0 = nullptr;
+        c.node_bin = nullptr; c.aeff_w0 = nullptr; c.pepmu_own = nullptr;
         c.scale = 1.0; c.flav = 0; c.side = 0;
         rc = run_hist(&c, 1, 0, nullptr, 0, nullptr, nullptr, nullptr, outb, n_bins, limbs, st, s);
     }

@@ -288,12 +288,32 @@ calc_layers_kernel(const EarthDev e, const double *__restrict__ cz, int64_t n, i
 // ---------------------------------------------------------------- event mode
 // Per-thread path staged in LDS as [layer][lane] (conflict free): length (f64)
 // and shell index (u8).  Dynamic LDS = blockDim.x * max_seg * 9 bytes + table.
+constexpr int EV_MAX_CONT = 16;
+struct EvCont {
+    int64_t n;
+    const double *energy, *coszen;
+    double *prob;      // [n][3][3] or NULL
+    double2 *pepmu;    // [n] (P[e->flav], P[mu->flav]) or NULL
+    int32_t side, flav;
+};
+struct EvArgs {
+    int32_t n_cont;
+    int32_t blk_start[EV_MAX_CONT + 1];
+    EvCont cont[EV_MAX_CONT];
+};
+
 template <bool DECAY>
 __global__ void __launch_bounds__(128)
-prob3_events_kernel(const Prob3Consts c, int side, const EarthDev earth,
-                    const double *__restrict__ energy, const double *__restrict__ coszen,
-                    int64_t n, int max_seg, double *__restrict__ prob,
+prob3_events_kernel(const Prob3Consts c, const EarthDev earth, const EvArgs ev, int max_seg,
                     int32_t *__restrict__ status) {
+    int ci = 0;
+    while (ci + 1 < ev.n_cont && (int)blockIdx.x >= ev.blk_start[ci + 1]) ci++;  // workgroup-uniform
+    const EvCont &C = ev.cont[ci];
+    const int side = C.side;
+    const double *__restrict__ energy = C.energy;
+    const double *__restrict__ coszen = C.coszen;
+    const int64_t n = C.n;
+    double *__restrict__ prob = C.prob;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // shell table in LDS (radii, rhos, coszen_limit)
     double *s_radii = reinterpret_cast<double *>(smem);
@@ -313,7 +333,7 @@ prob3_events_kernel(const Prob3Consts c, int side, const EarthDev earth,
         const double *radii, *rhos, *coszen_limit;
     } e{earth.n_shell, earth.idx, earth.r_detector, s_radii, s_rhos, s_lim};
 
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t i = (int64_t)(blockIdx.x - ev.blk_start[ci]) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int lane = threadIdx.x;
     const int bd = blockDim.x;
@@ -335,8 +355,11 @@ prob3_events_kernel(const Prob3Consts c, int side, const EarthDev earth,
     };
     double P[9];
     propagate_element<DECAY>(c.side[side], c.dm, energy[i], nseg, layer, P);
+    if (prob) {
 #pragma unroll
-    for (int k = 0; k < 9; k++) prob[9 * i + k] = P[k];
+        for (int k = 0; k < 9; k++) prob[9 * i + k] = P[k];
+    }
+    if (C.pepmu) C.pepmu[i] = make_double2(P[C.flav], P[3 + C.flav]);
 }
 
 __global__ void fill_probs_kernel(const double *__restrict__ prob, int init_flav, int flav,
@@ -476,6 +499,32 @@ PISA_API int pisa_hip_calc_layers(const pisa_hip_earth *h_earth, const double *d
     return PISA_HIP_OK;
 }
 
+static int launch_events(const Prob3Consts &c, const EarthDev &e, const EvCont *conts, int n_cont,
+                         int32_t *d_status, hipStream_t s) {
+    int max_seg = 2 * e.n_shell;
+    if (max_seg > PISA_HIP_MAX_LAYERS + 8) return PISA_HIP_ERR_LAYERS;
+    const int threads = 64;
+    size_t lds = 3 * PISA_HIP_MAX_SHELLS * sizeof(double) + (size_t)max_seg * threads * 9 + 16;
+    for (int base = 0; base < n_cont; base += EV_MAX_CONT) {
+        int nc = n_cont - base < EV_MAX_CONT ? n_cont - base : EV_MAX_CONT;
+        EvArgs a;
+        a.n_cont = nc;
+        a.blk_start[0] = 0;
+        for (int k = 0; k < nc; k++) {
+            a.cont[k] = conts[base + k];
+            a.blk_start[k + 1] = a.blk_start[k] + (int)((conts[base + k].n + threads - 1) / threads);
+        }
+        if (a.blk_start[nc] == 0) continue;
+        dim3 block(threads), grid((unsigned)a.blk_start[nc]);
+        if (c.decay)
+            hipLaunchKernelGGL(prob3_events_kernel<true>, grid, block, lds, s, c, e, a, max_seg, d_status);
+        else
+            hipLaunchKernelGGL(prob3_events_kernel<false>, grid, block, lds, s, c, e, a, max_seg, d_status);
+        PISA_CHECK_LAUNCH("prob3_events_kernel");
+    }
+    return PISA_HIP_OK;
+}
+
 PISA_API int pisa_hip_prob3_events(const pisa_hip_prob3_params *h_params,
                                    const pisa_hip_earth *h_earth, int64_t nubar,
                                    const double *d_energy, const double *d_coszen, int64_t n,
@@ -486,22 +535,37 @@ PISA_API int pisa_hip_prob3_events(const pisa_hip_prob3_params *h_params,
     if (rc) return rc;
     Prob3Consts c;
     if ((rc = make_consts(h_params, c))) return rc;
-    int max_seg = 2 * e.n_shell;
-    if (max_seg > PISA_HIP_MAX_LAYERS + 8) return PISA_HIP_ERR_LAYERS;
     if (n == 0) return PISA_HIP_OK;
     if (!d_energy || !d_coszen || !d_probability) return PISA_HIP_ERR_INVALID;
-    int side = nubar > 0 ? 0 : 1;
-    const int threads = 64;
-    size_t lds = 3 * PISA_HIP_MAX_SHELLS * sizeof(double) + (size_t)max_seg * threads * 9 + 16;
-    dim3 block(threads), grid((unsigned)((n + threads - 1) / threads));
-    if (c.decay)
-        hipLaunchKernelGGL(prob3_events_kernel<true>, grid, block, lds, as_stream(stream), c, side,
-                           e, d_energy, d_coszen, n, max_seg, d_probability, d_status);
-    else
-        hipLaunchKernelGGL(prob3_events_kernel<false>, grid, block, lds, as_stream(stream), c, side,
-                           e, d_energy, d_coszen, n, max_seg, d_probability, d_status);
-    PISA_CHECK_LAUNCH("prob3_events_kernel");
-    return PISA_HIP_OK;
+    EvCont ec;
+    ec.n = n; ec.energy = d_energy; ec.coszen = d_coszen; ec.prob = d_probability;
+    ec.pepmu = nullptr; ec.side = nubar > 0 ? 0 : 1; ec.flav = 0;
+    return launch_events(c, e, &ec, 1, d_status, as_stream(stream));
+}
+
+PISA_API int pisa_hip_prob3_events_multi(const pisa_hip_prob3_params *h_params,
+                                         const pisa_hip_earth *h_earth,
+                                         const pisa_hip_event_set *h_sets, int32_t n_sets,
+                                         int32_t *d_status, void *stream) {
+    if (!h_sets || n_sets < 1 || n_sets > 1024) return PISA_HIP_ERR_INVALID;
+    EarthDev e;
+    int rc = make_earth_dev(h_earth, e);
+    if (rc) return rc;
+    Prob3Consts c;
+    if ((rc = make_consts(h_params, c))) return rc;
+    EvCont *ec = new EvCont[n_sets];
+    for (int k = 0; k < n_sets; k++) {
+        const pisa_hip_event_set &h = h_sets[k];
+        bool bad = h.n_events < 0 || (h.nubar != 1 && h.nubar != -1) || h.flav < 0 || h.flav > 2 ||
+                   (h.n_events > 0 && (!h.d_energy || !h.d_coszen || (!h.d_probability && !h.d_pepmu)));
+        if (bad) { delete[] ec; return PISA_HIP_ERR_INVALID; }
+        ec[k].n = h.n_events; ec[k].energy = h.d_energy; ec[k].coszen = h.d_coszen;
+        ec[k].prob = h.d_probability; ec[k].pepmu = reinterpret_cast<double2 *>(h.d_pepmu);
+        ec[k].side = h.nubar > 0 ? 0 : 1; ec[k].flav = h.flav;
+    }
+    rc = launch_events(c, e, ec, n_sets, d_status, as_stream(stream));
+    delete[] ec;
+    return rc;
 }
 
 PISA_API int pisa_hip_fill_probs(const double *d_probability, int64_t init_flav, int64_t flav,

@@ -153,6 +153,15 @@ def prob3_events(params, earth, nubar, energy, coszen, out=None):
     return out
 
 
+def prob3_events_multi(params, earth, event_sets, status):
+    """Event-by-event prob3 for several containers in one launch; each set
+    receives its (prob_e, prob_mu) pairs and/or full matrices."""
+    lib = _lib.lib()
+    arr = event_sets if isinstance(event_sets, C.Array) else (_lib.EventSet * len(event_sets))(*event_sets)
+    _lib.check(lib.pisa_hip_prob3_events_multi(C.byref(params), C.byref(earth), arr, len(arr),
+                                               _ptr(status), _stream()))
+
+
 def fill_probs(probability, init_flav, flav, out=None):
     """`fill_probs` (numba_osc_hostfuncs.py:206-221)."""
     lib = _lib.lib()
