@@ -1,0 +1,108 @@
+"""Fit-loop driver: the reference's minimiser callable around this build's
+template evaluation (counterpart of `Analysis._minimizer_callable`,
+pisa/analysis/analysis.py:2493-2670, and the scipy strategy `_fit_scipy`,
+:1561-1780; minimizer settings as in `settings/minimizer/*.json`).
+
+    metric_val = data.metric_total(hypo.get_outputs(return_sum=True), metric)
+                 + hypo.params.priors_penalty(metric)
+    return sign * metric_val          (sign = -1 for llh-type metrics)
+
+Free parameters are exposed to scipy rescaled to [0, 1] (param.py:358-400).
+The metric itself is evaluated on the GPU (`pisa_hip_metric`).
+"""
+from collections import OrderedDict
+
+import numpy as np
+
+from pisa_amd.core.param import CHI2_METRICS, LLH_METRICS
+
+__all__ = ["Analysis", "Counter", "HypoFitResult"]
+
+
+class Counter:
+    def __init__(self, i=0):
+        self.count = i
+
+    def __iadd__(self, inc):
+        self.count += inc
+        return self
+
+
+class HypoFitResult:
+    def __init__(self, metric, metric_val, params, hypo_asimov_dist, fit_history, minimizer_result,
+                 num_distributions_generated):
+        self.metric, self.metric_val = metric, metric_val
+        self.params = params
+        self.hypo_asimov_dist = hypo_asimov_dist
+        self.fit_history = fit_history
+        self.minimizer_metadata = minimizer_result
+        self.num_distributions_generated = num_distributions_generated
+
+    def __repr__(self):
+        vals = ", ".join("%s=%s" % (p.name, p.value) for p in self.params.free)
+        return "HypoFitResult(%s=%.8g; %s)" % (self.metric, self.metric_val, vals)
+
+
+class Analysis:
+    def __init__(self):
+        self._nit = 0
+        self.pprint = False
+        self.blindness = False
+
+    @staticmethod
+    def _sign(metric):
+        if metric in LLH_METRICS:
+            return -1
+        if metric in CHI2_METRICS:
+            return +1
+        raise ValueError("Defined metrics are not compatible")
+
+    def _minimizer_callable(self, scaled_param_vals, hypo_maker, data_dist, metric, counter,
+                            fit_history, flip_x0=None, external_priors_penalty=None):
+        sign = self._sign(metric)
+        x = np.asarray(scaled_param_vals, dtype=np.float64)
+        if flip_x0 is not None:
+            x = np.where(flip_x0, 1 - x, x)
+        hypo_maker._set_rescaled_free_params(np.clip(x, 0.0, 1.0))  # pylint: disable=protected-access
+        hypo = hypo_maker.get_outputs(return_sum=True)
+        metric_val = (data_dist.metric_total(expected_values=hypo, metric=metric)
+                      + hypo_maker.params.priors_penalty(metric=metric))
+        counter += 1
+        if fit_history is not None:
+            fit_history.append([metric_val] + [p.value.m for p in hypo_maker.params.free])
+        if external_priors_penalty is not None:
+            metric_val += external_priors_penalty(hypo_maker=hypo_maker, metric=metric)
+        if self.pprint:
+            print("%6d %12.5e | %s" % (counter.count, metric_val,
+                                       " ".join("%12.5e" % p.value.m for p in hypo_maker.params.free)))
+        return sign * metric_val
+
+    def fit_hypo(self, data_dist, hypo_maker, metric, minimizer_settings=None, reset_free=True):
+        """scipy.optimize.minimize over the free params (L-BFGS-B by default, as
+        settings/minimizer/l-bfgs-b_ftol2e-5_gtol1e-5_eps1e-4_maxiter200.json)."""
+        from scipy import optimize
+
+        if reset_free:
+            hypo_maker.reset_free()
+        ms = dict(method="L-BFGS-B", options=dict(ftol=2e-5, gtol=1e-5, eps=1e-4, maxiter=200))
+        if minimizer_settings:
+            ms.update(minimizer_settings)
+        free = hypo_maker.params.free
+        if len(free) == 0:
+            hypo = hypo_maker.get_outputs(return_sum=True)
+            val = (data_dist.metric_total(expected_values=hypo, metric=metric)
+                   + hypo_maker.params.priors_penalty(metric=metric))
+            return HypoFitResult(metric, val, hypo_maker.params, hypo, [], None, 1)
+        x0 = np.array(free._rescaled_values, dtype=np.float64)
+        bounds = [(0.0, 1.0)] * len(x0)
+        counter, history = Counter(), []
+        res = optimize.minimize(
+            fun=self._minimizer_callable, x0=x0, args=(hypo_maker, data_dist, metric, counter, history),
+            bounds=bounds if ms["method"].lower() in ("l-bfgs-b", "slsqp", "tnc", "trust-constr") else None,
+            method=ms["method"], options=ms.get("options", {}))
+        hypo_maker._set_rescaled_free_params(np.clip(res.x, 0.0, 1.0))  # pylint: disable=protected-access
+        hypo = hypo_maker.get_outputs(return_sum=True)
+        val = self._sign(metric) * res.fun
+        meta = OrderedDict(success=bool(res.success), nit=int(getattr(res, "nit", -1)),
+                           nfev=int(res.nfev), message=str(res.message))
+        return HypoFitResult(metric, val, hypo_maker.params, hypo, history, meta, counter.count)
