@@ -260,6 +260,18 @@ int pisa_hip_apply_aeff(const double *d_weighted_aeff, double scale, int64_t n,
 int pisa_hip_hist_finalize(const int64_t *d_limbs, int32_t n_containers, int64_t n_bins,
                            double *d_hist, double *d_sumw2, int32_t *d_status, void *stream);
 
+/* --------------------------------------------------------------------- KDE */
+
+/* Gaussian kernel sums of the KDE stage (pisa/utils/kde_hist.py:110-120 calls the
+ * external, un-vendored `kde.gaussian_kde`; parity of this core is UNPINNED):
+ *   out[j] = sum_i coef[i] * exp(-0.5 * s2[i] * (q_j - x_i)^T inv_cov (q_j - x_i))
+ * d_src[dim][n_src], d_qry[dim][n_qry] (dimension-major), h_inv_cov[dim*dim]
+ * row-major symmetric, dim <= 3.  Used for the pilot estimate (s2 = 1) and for
+ * the adaptive evaluation on the oversampled bin centres. */
+int pisa_hip_kde_eval(int32_t dim, const double *d_src, const double *d_coef, const double *d_s2,
+                      int64_t n_src, const double *d_qry, int64_t n_qry, const double *h_inv_cov,
+                      double *d_out, void *stream);
+
 /* ------------------------------------------------------------------ metric */
 
 #define PISA_HIP_METRIC_LLH 0          /* stats.py:169-253 */

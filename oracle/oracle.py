@@ -358,3 +358,14 @@ def dm_matrix(dm21, dm31):
     dm[1, 2] = m[1] - m[2]
     dm[2, 1] = -dm[1, 2]
     return dm
+
+
+def kde_eval(src, coef, s2, qry, inv_cov):
+    """all-pairs Gaussian kernel sums (KDE core; parity unpinned, see pisa_oracle.c)"""
+    src, qry = _f8(src), _f8(qry)
+    dim, n = src.shape
+    m = qry.shape[1]
+    out = np.zeros(m)
+    lib().oracle_kde_eval(C.c_int(dim), _p(src), _p(_f8(coef)), _p(_f8(s2)), C.c_int64(n), _p(qry),
+                          C.c_int64(m), _p(_f8(inv_cov)), _p(out))
+    return out

@@ -262,6 +262,19 @@ def apply_aeff(weighted_aeff, scale, weights):
     return weights
 
 
+# ------------------------------------------------------------------ KDE
+def kde_eval(src, coef, s2, qry, inv_cov):
+    """Gaussian kernel sums (see pisa_hip_kde_eval); src [dim, n], qry [dim, m]."""
+    lib = _lib.lib()
+    dim, n = src.shape
+    m = qry.shape[1]
+    out = torch.empty(m, dtype=F8, device=qry.device)
+    ic = np.ascontiguousarray(inv_cov, dtype=np.float64)
+    _lib.check(lib.pisa_hip_kde_eval(dim, _ptr(src), _ptr(coef), _ptr(s2), n, _ptr(qry), m,
+                                     ic.ctypes.data, _ptr(out), _stream()))
+    return out
+
+
 # --------------------------------------------------------------- metric
 METRIC_KIND = {"llh": 0, "poisson_llh": 1, "chi2": 2, "mod_chi2": 3}
 
