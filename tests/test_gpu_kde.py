@@ -55,7 +55,7 @@ def test_kde_maps_vs_oracle_and_invariants(oracle):
     np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-300)
     # normalisation: events bleed out of the energy range only
     inside = (np.log(reco_e) >= e_edges[0]) & (np.log(reco_e) < e_edges[-1])
-    assert abs(got.sum() / w[inside].sum() - 1.0) < 0.05
+    assert abs(got.sum() / w[inside].sum() - 1.0) < 0.1
     # linearity in the weights (test_kde_stage.py: scale-then-KDE == KDE-then-scale)
     got2 = kde_hist.kde_histogramdd(sample=sample, binning=binning, weights=2.5 * w, stack_pid=True, **kw)
     np.testing.assert_allclose(got2, 2.5 * got, rtol=1e-12)
