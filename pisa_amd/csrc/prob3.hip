@@ -156,16 +156,22 @@ prob3_chain_kernel(const Prob3Consts c, int n_e, const int32_t *__restrict__ row
 #pragma unroll
             for (int j = 0; j < 3; j++) T.m[i][j] = cmake(0.0, 0.0);
         if (cnt > 0) {
+            // the product itself is ~200 flops per layer; what costs is the latency of
+            // fetching the next matrix, so keep three layers in flight
             load_A(k0, T);
-            mat3 A;
-            if (cnt > 1) load_A(k0 + 1, A);
+            mat3 A0, A1, A2;
+            if (cnt > 1) load_A(k0 + 1, A0);
+            if (cnt > 2) load_A(k0 + 2, A1);
+            if (cnt > 3) load_A(k0 + 3, A2);
             for (int t = 1; t < cnt; t++) {
                 mat3 An;
-                if (t + 1 < cnt) load_A(k0 + t + 1, An);  // prefetch the next layer
+                if (t + 3 < cnt) load_A(k0 + t + 3, An);  // prefetch three layers ahead
                 mat3 t2;
-                mat_mul(A, T, t2);
+                mat_mul(A0, T, t2);
                 T = t2;
-                A = An;
+                A0 = A1;
+                A1 = A2;
+                A2 = An;
             }
         }
         mat3 t2, Tf;
