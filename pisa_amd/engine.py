@@ -275,6 +275,44 @@ class HotPathEngine:
             return self.metric(kind)
         return None
 
+    def eval_batch(self, params_list, kind="llh"):
+        """Several INDEPENDENT parameter points (e.g. the 2n+1 points of a
+        finite-difference gradient): the oscillation kernels of point k+1 run on
+        a second HIP stream while the fused reweight+histogram kernel of point k
+        streams the events, with double-buffered probability tables.  Results
+        are identical to calling `eval` point by point; one host sync at the
+        end.  Returns a device tensor with one metric value per point."""
+        assert not self.osc_events and self.plan is not None and self.data is not None
+        n = len(params_list)
+        out = torch.empty(n, dtype=torch.float64, device=self.dev)
+        if not hasattr(self, "_osc_stream"):
+            self._osc_stream = torch.cuda.Stream(device=self.dev)
+            self._tables = [(self.prob_nu, self.prob_nubar, self.pepmu),
+                            tuple(torch.empty_like(t) for t in (self.prob_nu, self.prob_nubar, self.pepmu))]
+        main = torch.cuda.current_stream()
+        osc_done = [torch.cuda.Event() for _ in range(n)]
+        used = [None, None]  # event after which a table set may be overwritten
+        self._osc_stream.wait_stream(main)
+        for k, p in enumerate(params_list):
+            tab = self._tables[k % 2]
+            with torch.cuda.stream(self._osc_stream):
+                if used[k % 2] is not None:
+                    self._osc_stream.wait_event(used[k % 2])
+                K.prob3_grid_planned(p, self.plan, self.energy_d, e_major=self.grid.energy_first,
+                                     out_nu=tab[0], out_nubar=tab[1], out_pepmu=tab[2])
+                osc_done[k].record(self._osc_stream)
+            main.wait_event(osc_done[k])
+            K.reweight_hist(self._cont_arr, self.grid.binning, tab[0], tab[1], tab[2],
+                            self.out_binning, self.ws)
+            used[k % 2] = torch.cuda.Event()
+            used[k % 2].record(main)
+            self.allreduce()
+            self.finalize()
+            K.metric(kind, self.data, self.ws.hist, self.ws.sumw2, total_out=out[k:k + 1],
+                     status=self.metric_status)
+        self.prob_nu, self.prob_nubar, self.pepmu = self._tables[(n - 1) % 2] if n else self._tables[0]
+        return out
+
     def check_status(self):
         if int(self.ws.status.item()) != 0:
             self.ws.status.zero_()
