@@ -286,7 +286,9 @@ class HotPathEngine:
         n = len(params_list)
         out = torch.empty(n, dtype=torch.float64, device=self.dev)
         if not hasattr(self, "_osc_stream"):
-            self._osc_stream = torch.cuda.Stream(device=self.dev)
+            # high priority: the small oscillation kernels must not queue behind the
+            # chip-filling fused kernel of the previous point
+            self._osc_stream = torch.cuda.Stream(device=self.dev, priority=-1)
             self._tables = [(self.prob_nu, self.prob_nubar, self.pepmu),
                             tuple(torch.empty_like(t) for t in (self.prob_nu, self.prob_nubar, self.pepmu))]
         main = torch.cuda.current_stream()
