@@ -1,0 +1,90 @@
+"""Edge cases the reference tests or implies, on the GPU path: container
+round trips (pisa/core/container.py:1043-1189), empty / ragged containers,
+NaN and out-of-range coordinates, weights of extreme magnitude."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_container_round_trip_events_binned_events():
+    """container.py:1043-1189: events -> binned (average) -> events lookup"""
+    from pisa_amd.core.binning import MultiDimBinning, OneDimBinning
+    from pisa_amd.core.container import Container
+
+    rs = np.random.RandomState(0)
+    n = 20000
+    c = Container("test", representation="events")
+    c["true_energy"] = 10 ** (rs.rand(n) * 2)
+    c["true_coszen"] = rs.rand(n) * 2 - 1
+    binning = MultiDimBinning([
+        OneDimBinning("true_energy", num_bins=10, is_log=True, domain=[1.0, 100.0]),
+        OneDimBinning("true_coszen", num_bins=8, is_lin=True, domain=[-1, 1])])
+    # a variable that is constant inside every bin survives the round trip exactly
+    ie = np.minimum((np.log(c["true_energy"]) / np.log(100.0) * 10).astype(int), 9)
+    icz = np.minimum(((c["true_coszen"] + 1) / 2 * 8).astype(int), 7)
+    c["x"] = (ie * 8 + icz).astype(float)
+    c.representation = binning
+    binned = c["x"]                       # auto-translation: averaged histogram on the GPU
+    assert binned.shape == (80,)
+    np.testing.assert_allclose(binned, np.arange(80.0), rtol=1e-13)
+    c.mark_changed("x")                   # binned copy is now the authoritative one
+    c.representation = "events"
+    back = c["x"]                         # auto-translation: lookup on the GPU
+    np.testing.assert_allclose(back, ie * 8 + icz, rtol=1e-13)
+    # the binning dimensions themselves unroll to the weighted centres (container.py:769-773)
+    c.representation = binning
+    np.testing.assert_array_equal(c["true_coszen"][:8], binning["true_coszen"].weighted_centers.m)
+    # device access returns tensors, host access numpy, both views stay consistent
+    t = c.device("x")
+    assert t.is_cuda and t.shape == (80,)
+    c["y"] = t * 2
+    np.testing.assert_allclose(c["y"], 2 * np.arange(80.0))
+    with pytest.raises(KeyError):
+        c["nope"]
+
+
+def test_fused_kernel_empty_ragged_nan_out_of_range(oracle):
+    from oracle.pipeline_oracle import oracle_eval
+    from pisa_amd import synthetic
+
+    wl = synthetic.Workload(n_events=12 * 1001, grid=(16, 12), out_binning="dragon", seed=9)
+    ev = wl.events
+    # container 0: empty; container 1: a single event; container 2: odd count
+    for k in ("true_energy", "true_coszen", "nu_flux", "weighted_aeff", "initial_weights"):
+        ev[0][k] = ev[0][k][:0]
+        ev[1][k] = ev[1][k][:1]
+    ev[0]["sample"] = [s[:0] for s in ev[0]["sample"]]
+    ev[1]["sample"] = [s[:1] for s in ev[1]["sample"]]
+    # NaN / inf / out-of-range coordinates: dropped from lookup (prob 0) or from the histogram
+    e3 = ev[3]
+    e3["true_coszen"][:5] = [np.nan, 1.0, -1.0, 2.0, -3.0]       # cz == 1.0 is outside [min,max)
+    e3["true_energy"][5:8] = [0.5, 1000.0, 1e5]                   # below / at / above the grid
+    e3["sample"][0][8:11] = [np.nan, np.inf, -np.inf]
+    e3["sample"][1][11] = 1.0
+    # extreme but finite weights
+    ev[4]["initial_weights"][:3] = [1e-30, 1e20, 0.0]
+    for rank_world in ((0, 1), (1, 2)):
+        st = synthetic.DeviceState(wl, rank=rank_world[0], world_size=rank_world[1])
+        st.accumulate(wl.osc_params())
+        st.finalize()
+        st.check_status()
+    st = synthetic.DeviceState(wl)
+    st.accumulate(wl.osc_params())
+    st.finalize()
+    hist, sumw2 = st.maps()
+    ref = oracle_eval(wl)
+    assert np.all(hist[0] == 0)
+    np.testing.assert_allclose(hist, ref["hist"], rtol=1e-11, atol=1e-300)
+    np.testing.assert_allclose(sumw2, ref["sumw2"], rtol=1e-11, atol=1e-300)
+    # coordinate form agrees bit for bit on the same awkward inputs
+    st2 = synthetic.DeviceState(wl, indexed=False, planned=False)
+    st2.accumulate(wl.osc_params())
+    assert bool((st.ws.limbs == st2.ws.limbs).all())
+    # a non-finite weight is an error, not a silent NaN map
+    ev[5]["initial_weights"][0] = np.inf
+    st3 = synthetic.DeviceState(wl)
+    st3.accumulate(wl.osc_params())
+    st3.finalize()
+    with pytest.raises(OverflowError):
+        st3.check_status()
