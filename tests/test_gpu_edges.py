@@ -82,7 +82,7 @@ def test_fused_kernel_empty_ragged_nan_out_of_range(oracle):
     st2.accumulate(wl.osc_params())
     assert bool((st.ws.limbs == st2.ws.limbs).all())
     # a non-finite weight is an error, not a silent NaN map
-    ev[5]["initial_weights"][0] = np.inf
+    ev[5]["initial_weights"][:200] = np.inf  # (some of these events are inside the binning)
     st3 = synthetic.DeviceState(wl)
     st3.accumulate(wl.osc_params())
     st3.finalize()
