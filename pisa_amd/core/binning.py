@@ -227,14 +227,16 @@ class MultiDimBinning:
         self.name = name
         self.mask = mask
         self._hash = None
+        self._shape = tuple(d.num_bins for d in dims)
+        self._size = int(np.prod(self._shape)) if dims else 1
 
     dimensions = property(lambda self: self._dimensions)
     dims = dimensions
     names = property(lambda self: [d.name for d in self._dimensions])
     num_dims = property(lambda self: len(self._dimensions))
-    shape = property(lambda self: tuple(d.num_bins for d in self._dimensions))
+    shape = property(lambda self: self._shape)
     num_bins = shape
-    size = property(lambda self: int(np.prod(self.shape)))
+    size = property(lambda self: self._size)
     tot_num_bins = size
     bin_edges = property(lambda self: [d.bin_edges for d in self._dimensions])
     domains = property(lambda self: [d.domain for d in self._dimensions])

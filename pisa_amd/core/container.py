@@ -44,10 +44,15 @@ class DualArray:
 
     __slots__ = ("host", "dev", "host_valid", "dev_valid")
 
-    def __init__(self, data):
+    def __init__(self, data, host=None):
+        """`data`: numpy array or device tensor.  A strided device view is kept
+        as is and only compacted when somebody asks for it (`get_dev`), so
+        stages can publish views of one shared table at no cost.  `host`:
+        optional host mirror of a device tensor that is already up to date
+        (saves a D2H per variable when a stage copied a whole block back)."""
         if _is_tensor(data):
-            self.host, self.dev = None, data.contiguous()
-            self.host_valid, self.dev_valid = False, True
+            self.host, self.dev = host, data
+            self.host_valid, self.dev_valid = host is not None, True
         else:
             self.host, self.dev = np.asarray(data), None
             self.host_valid, self.dev_valid = True, False
@@ -69,6 +74,8 @@ class DualArray:
             h = self.host
             self.dev = K.to_device(h, dtype=h.dtype if h.dtype in (np.int32, np.int64) else np.float64)
             self.dev_valid = True
+        elif not self.dev.is_contiguous():
+            self.dev = self.dev.contiguous()
         return self.dev
 
     def host_changed(self):
@@ -267,6 +274,13 @@ class Container:
         if key not in self.translation_modes:
             self.translation_modes[key] = "sum" if key in self.sum_mode_keys else "average"
         self._invalidate_others(key)
+
+    def set_mirrored(self, key, dev, host):
+        """`container[key] = dev` where `host` already holds the same values
+        (a stage copied a whole block back in one transfer)."""
+        self[key] = dev
+        arr = self.current_data[key]
+        arr.host, arr.host_valid = np.asarray(host).reshape(tuple(arr.dev.shape)), True
 
     def _add_data(self, key, data):
         if isinstance(data, Map):

@@ -190,8 +190,8 @@ class prob3(Stage):  # pylint: disable=invalid-name
                 side = 0 if container["nubar"] > 0 else 1
                 flav = int(container["flav"])
                 container["probability"] = self.prob_tables[side]
-                container["prob_e"] = pepmu[side, flav, :, 0].contiguous()
-                container["prob_mu"] = pepmu[side, flav, :, 1].contiguous()
+                container["prob_e"] = pepmu[side, flav, :, 0]    # strided views: compacted on access only
+                container["prob_mu"] = pepmu[side, flav, :, 1]
         else:
             events = self.calc_mode == "events"
             earth = self.layers.earth_struct() if events else None

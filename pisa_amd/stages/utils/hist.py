@@ -108,13 +108,18 @@ class hist(Stage):  # pylint: disable=invalid-name
         eng.accumulate()
         eng.allreduce()
         hist_d, sumw2_d = eng.finalize()
+        # one D2H for all containers' maps and errors (the caller reads them as
+        # Maps right away); the device rows stay available for later stages
+        sumw2 = self.error_method == "sumw2"
+        both = torch.stack((hist_d, torch.sqrt(sumw2_d), hist_d)) if sumw2 else hist_d[None]
+        both_h = both.cpu().numpy()
         for i, c in enumerate(conts):
             c.pending.pop(deferred.KEY, None)  # consumed by the fused kernel
             c.representation = self.apply_mode
-            c["weights"] = hist_d[i]
-            if self.error_method == "sumw2":
-                c["errors"] = torch.sqrt(sumw2_d[i])
-                c["bin_unc2"] = hist_d[i]  # sum(1^2 * w), hist.py:207-209
+            c.set_mirrored("weights", both[0, i], both_h[0, i])
+            if sumw2:
+                c.set_mirrored("errors", both[1, i], both_h[1, i])
+                c.set_mirrored("bin_unc2", both[2, i], both_h[2, i])  # sum(1^2 * w), hist.py:207-209
         return True
 
     # ------------------------------------------------------------------ apply
