@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--events", type=float, default=1e7)
     ap.add_argument("--grid", default="200x100", help="calc grid n_E x n_coszen")
-    ap.add_argument("--binning", default="dragon", choices=["dragon", "example2d"])
+    ap.add_argument("--binning", default="dragon", choices=["dragon", "example2d", "fine3d"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="skip the HIP-event measurement of the dominant kernel (use under rocprofv3 --pmc)")
@@ -46,6 +46,8 @@ def parse():
                     help="bin event coordinates on the fly (72 B/event) instead of the pre-digitised "
                          "index columns (40 B/event)")
     ap.add_argument("--cpu-sample-events", type=float, default=2.4e6)
+    ap.add_argument("--event-order", default="auto", choices=["auto", "node", "bin"],
+                    help="resident event order: sorted by calc-grid node, or by (output bin, node)")
     return ap.parse_args()
 
 
@@ -145,7 +147,8 @@ def main():
     n_e, n_cz = (int(v) for v in args.grid.split("x"))
     wl = synthetic.Workload(n_events=int(args.events), grid=(n_e, n_cz), out_binning=args.binning,
                             seed=0)
-    st = synthetic.DeviceState(wl, rank=rank, world_size=world, indexed=not args.coordinate_form)
+    st = synthetic.DeviceState(wl, rank=rank, world_size=world, indexed=not args.coordinate_form,
+                               sort_events=True if args.event_order == "auto" else args.event_order)
     nominal = wl.osc_params()
     st.make_pseudo_data(nominal, seed=0)
     plist = param_list(wl, args.warmup + args.steps)

@@ -131,6 +131,7 @@ struct HistArgs {
     int32_t blk_start[MAX_CONT + 1];
     int32_t copies;       // LDS replicas of the accumulators (power of two), lane-interleaved
     int32_t dbg;          // development probe (PISA_HIP_HIST_DBG): 1 skip sumw2, 2 skip all deposits
+    int32_t window;       // > 0: LDS holds this many bins starting at the chunk's lowest bin
 };
 
 // MODE 0: generic histogram (weights or counts; quantities (w, 1))
@@ -150,26 +151,53 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
     const int64_t start = lb * a.chunk;
     int64_t end = start + a.chunk;
     if (end > C.n) end = C.n;
-    const int n_bins = (int)a.n_bins;
+    // bins held in LDS: all of them, or (a.window > 0, MODE 3 only) the window
+    // [bin_lo, bin_lo + window) that starts at the smallest bin of this workgroup's
+    // chunk -- a binning too large for LDS still gets LDS accumulation when the
+    // events are stored in an order that keeps a chunk inside a few hundred
+    // neighbouring bins; deposits outside the window go to the global limbs directly
+    const int n_bins = a.window > 0 ? a.window : (int)a.n_bins;
     const int n_acc = NL * 2 * n_bins;
     // replica used by this lane: neighbouring lanes (neighbouring, i.e. correlated,
     // events) add into different copies, which cuts same-address serialisation
     double *my_acc = s_acc + (LDS_ACC ? (int)(threadIdx.x & (a.copies - 1)) * n_acc : 0);
     unsigned long long *g_out = g_limbs + (int64_t)(a.cont_base + c) * a.n_bins * 2 * NL;
+    int bin_lo = 0;
 
     if (LDS_ACC) {
         for (int k = threadIdx.x; k < n_acc * a.copies; k += nthreads) s_acc[k] = 0.0;
+        if (MODE == 3 && a.window > 0) {
+            __shared__ int s_lo;
+            if (threadIdx.x == 0) s_lo = 0x7fffffff;
+            __syncthreads();
+            int m = 0x7fffffff;
+            const int4 *idx4 = reinterpret_cast<const int4 *>(C.node_bin);
+            for (int64_t p = (start >> 1) + threadIdx.x; p < (end >> 1); p += nthreads) {
+                const int4 ix = idx4[p];
+                if (ix.y >= 0 && ix.y < m) m = ix.y;
+                if (ix.w >= 0 && ix.w < m) m = ix.w;
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                const int other = __shfl_xor(m, o);
+                m = other < m ? other : m;
+            }
+            if ((threadIdx.x & 63) == 0 && m != 0x7fffffff) atomicMin(&s_lo, m);
+            __syncthreads();
+            bin_lo = s_lo == 0x7fffffff ? 0 : s_lo;
+        }
         __syncthreads();
     }
     bool bad = false;
 
     auto accumulate = [&](int bin, double w, double w2) {
+        const int rel = bin - bin_lo;
+        const bool in_lds = LDS_ACC && (unsigned)rel < (unsigned)n_bins;
         auto add0 = [&](int j, double q) {
-            if (LDS_ACC) atomicAdd(&my_acc[(j * 2 + 0) * n_bins + bin], q);
+            if (in_lds) atomicAdd(&my_acc[(j * 2 + 0) * n_bins + rel], q);
             else atomicAdd(&g_out[((int64_t)bin * 2 + 0) * NL + j], (unsigned long long)slab_to_units(q, j));
         };
         auto add1 = [&](int j, double q) {
-            if (LDS_ACC) atomicAdd(&my_acc[(j * 2 + 1) * n_bins + bin], q);
+            if (in_lds) atomicAdd(&my_acc[(j * 2 + 1) * n_bins + rel], q);
             else atomicAdd(&g_out[((int64_t)bin * 2 + 1) * NL + j], (unsigned long long)slab_to_units(q, j));
         };
         if (a.dbg & 2) {  // probe: keep the loads and the weight chain alive, no atomics
@@ -190,34 +218,59 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
         const int4 *idx4 = reinterpret_cast<const int4 *>(C.node_bin);
         const double2 *aw = C.aeff_w0;
         const double2 *flux2 = reinterpret_cast<const double2 *>(C.flux);
-        for (int64_t p = p0 + threadIdx.x; p < p1; p += nthreads) {
-            const int4 ix = idx4[p];  // node0, bin0, node1, bin1
-            const double2 awa = aw[2 * p], awb = aw[2 * p + 1];
-            const double2 fa = flux2[2 * p], fb = flux2[2 * p + 1];
-            double2 pa = make_double2(0.0, 0.0), pb = make_double2(0.0, 0.0);
-            if (ix.x >= 0) pa = tab[ix.x];
-            if (ix.z >= 0) pb = tab[ix.z];
-            if (ix.y >= 0) {
-                double w = awa.y * ((fa.x * pa.x) + (fa.y * pa.y));  // prob3.py:622
-                w = w * (awa.x * scale);                             // aeff.py:87
-                accumulate(ix.y, w, w * w);
-            }
-            if (ix.w >= 0) {
-                double w = awb.y * ((fb.x * pb.x) + (fb.y * pb.y));
-                w = w * (awb.x * scale);
-                accumulate(ix.w, w, w * w);
-            }
+        // Software-pipelined: the five streaming loads of the NEXT pair of events are
+        // issued before the current pair is consumed, and the two dependent table
+        // gathers of the current pair before them, so a wave always has a full
+        // iteration of HBM requests in flight (a thread only runs ~6-10 iterations;
+        // without this the idx -> gather -> use chain is exposed every time).
+        int64_t p = p0 + threadIdx.x;
+        bool have = p < p1;
+        int4 ix = make_int4(-1, -1, -1, -1);  // node0, bin0, node1, bin1
+        double2 awa = make_double2(0.0, 0.0), awb = awa, fa = awa, fb = awa;
+        if (have) {
+            ix = idx4[p];
+            awa = aw[2 * p]; awb = aw[2 * p + 1];
+            fa = flux2[2 * p]; fb = flux2[2 * p + 1];
+        }
+        while (have) {
+            // node < 0 (outside the calc grid): read entry 0, then force P = 0
+            double2 pa = tab[ix.x < 0 ? 0 : ix.x];
+            double2 pb = tab[ix.z < 0 ? 0 : ix.z];
+            const int64_t pn = p + nthreads;
+            const bool have_n = pn < p1;
+            // unconditional (the last sweep re-reads its own pair, never used): a
+            // branch here would make the compiler wait for these loads as well
+            const int64_t pl = have_n ? pn : p;
+            const int4 ixn = idx4[pl];
+            const double2 awan = aw[2 * pl], awbn = aw[2 * pl + 1];
+            const double2 fan = flux2[2 * pl], fbn = flux2[2 * pl + 1];
+            if (ix.x < 0) pa = make_double2(0.0, 0.0);
+            if (ix.z < 0) pb = make_double2(0.0, 0.0);
+            // branch-free on purpose (an event outside the binning deposits w = 0,
+            // i.e. nothing): a conditional here lets the compiler sink the gathers
+            // below the prefetch and wait for all of it
+            double wa = awa.y * ((fa.x * pa.x) + (fa.y * pa.y));  // prob3.py:622
+            wa = wa * (awa.x * scale);                            // aeff.py:87
+            double wb = awb.y * ((fb.x * pb.x) + (fb.y * pb.y));
+            wb = wb * (awb.x * scale);
+            if (ix.y < 0) wa = 0.0;
+            if (ix.w < 0) wb = 0.0;
+            accumulate(ix.y < 0 ? bin_lo : ix.y, wa, wa * wa);
+            accumulate(ix.w < 0 ? bin_lo : ix.w, wb, wb * wb);
+            ix = ixn; awa = awan; awb = awbn; fa = fan; fb = fbn;
+            p = pn;
+            have = have_n;
         }
         if ((end & 1) && threadIdx.x == 0 && end > start) {  // odd tail of the container
             const int64_t i = end - 1;
-            const int2 ix = C.node_bin[i];
-            if (ix.y >= 0) {
-                double2 pp = ix.x >= 0 ? tab[ix.x] : make_double2(0.0, 0.0);
+            const int2 ix1 = C.node_bin[i];
+            if (ix1.y >= 0) {
+                double2 pp = ix1.x >= 0 ? tab[ix1.x] : make_double2(0.0, 0.0);
                 double2 f = flux2[i];
                 double2 x = aw[i];
                 double w = x.y * ((f.x * pp.x) + (f.y * pp.y));
                 w = w * (x.x * scale);
-                accumulate(ix.y, w, w * w);
+                accumulate(ix1.y, w, w * w);
             }
         }
     } else if (MODE == 2) {
@@ -303,7 +356,7 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
                 const int j = k / (2 * n_bins);
                 const int rem = k - j * 2 * n_bins;
                 const int q = rem / n_bins;
-                const int bin = rem - q * n_bins;
+                const int bin = bin_lo + rem - q * n_bins;  // < a.n_bins: only real bins are non-zero
                 atomicAdd(&g_out[((int64_t)bin * 2 + q) * NL + j],
                           (unsigned long long)slab_to_units(v, j));
             }
@@ -443,9 +496,16 @@ static int run_hist(const ContDev *conts, int n_cont, int mode, const DevBinning
                     const double *pepmu, const DevBinning &outb, int64_t n_bins,
                     long long *d_limbs, int32_t *d_status, hipStream_t s) {
     if (n_bins > (1 << 28)) return PISA_HIP_ERR_INVALID;
-    const int64_t lds_bytes = lds_acc_bytes(n_bins);
-    const bool lds = lds_bytes <= LDS_ACC_BYTES_MAX;
-    int copies = env_int("PISA_HIP_HIST_COPIES", 4);
+    int64_t lds_bytes = lds_acc_bytes(n_bins);
+    bool lds = lds_bytes <= LDS_ACC_BYTES_MAX;
+    int window = 0;
+    if (!lds && mode == 3 && !env_int("PISA_HIP_HIST_NO_WINDOW", 0)) {
+        // binning too large for LDS: accumulate a window of it (see the kernel)
+        window = (int)(LDS_ACC_BYTES_MAX / lds_acc_bytes(1));
+        lds_bytes = lds_acc_bytes(window);
+        lds = true;
+    }
+    int copies = window ? 1 : env_int("PISA_HIP_HIST_COPIES", 4);
     while (copies > 1 && (copies & (copies - 1))) copies--;
     while (copies > 1 && lds_bytes * copies > LDS_ACC_BYTES_MAX) copies >>= 1;
     if (copies < 1) copies = 1;
@@ -475,6 +535,7 @@ static int run_hist(const ContDev *conts, int n_cont, int mode, const DevBinning
         dim3 grid_dim((unsigned)nblocks), block(threads);
         size_t shmem = lds ? (size_t)lds_bytes * copies : 0;
         a.copies = lds ? copies : 1;
+        a.window = window;
         unsigned long long *out = reinterpret_cast<unsigned long long *>(d_limbs);
         if (g_prof_start) PISA_TRY_HIP(hipEventRecord(g_prof_start, s));
 #define LAUNCH(M, L) hipLaunchKernelGGL((hist_accumulate_kernel<M, L>), grid_dim, block, shmem, s, a, out, d_status)

@@ -70,6 +70,35 @@ def allreduce_limbs(limbs, world_size, group=None):
     return limbs
 
 
+def bin_window_order(obin, n_bins, lds_window=682):
+    """Event order for binnings too large for LDS accumulators (> 682 bins).
+
+    The fused kernel then keeps only a WINDOW of the binning in LDS: the
+    `lds_window` bins that start at the lowest bin of a workgroup's chunk
+    (hist.hip); deposits outside it fall back to global atomics.  So events are
+    sorted by output bin -- a chunk of ~10^4 consecutive events spans few bins --
+    and, inside segments of S consecutive events, dealt round-robin over the
+    segment's bins, so that the 64 lanes of a wavefront add into different bins
+    instead of queueing on one LDS address.  S is chosen so that a segment holds
+    ~192 bins (> 128 lanes' worth, and chunk + 2 segments stay inside the window).
+    Returns the permutation (device int64)."""
+    n = obin.numel()
+    perm1 = torch.argsort(obin, stable=True)
+    if n < 2:
+        return perm1
+    b = obin[perm1].long()
+    per_bin = max(1.0, n / max(1, n_bins))
+    seg_len = int(min(max(1024, 192 * per_bin), max(1024, 0.3 * lds_window * per_bin)))
+    idx = torch.arange(n, device=obin.device)
+    is_start = torch.ones(n, dtype=torch.bool, device=obin.device)
+    is_start[1:] = b[1:] != b[:-1]
+    run_start = torch.cummax(torch.where(is_start, idx, torch.zeros_like(idx)), 0).values
+    seg = idx // seg_len
+    rank_in_run = idx - torch.maximum(run_start, seg * seg_len)
+    key = (seg * (seg_len + 1) + rank_in_run) * (n_bins + 2) + (b + 1)
+    return perm1[torch.argsort(key, stable=True)]
+
+
 LIMB_BITS, LIMB_LSB, N_LIMBS = 32, 116, 6
 
 
@@ -117,6 +146,10 @@ class HotPathEngine:
         self.grid = grid
         self.out_binning = out_binning
         self.n_bins = int(np.prod([out_binning.nbins[k] for k in range(out_binning.ndim)]))
+        if sort_events is True:
+            # LDS accumulators (96 B per bin, <= 64 KiB) take events in any order, so
+            # order them for the table gathers; larger binnings need runs of equal bin
+            sort_events = "node" if self.n_bins * 96 <= 65536 else "bin"
         self.rank, self.world_size, self.group = rank, world_size, group
         self.names = [c["name"] for c in containers]
         self._keep = []  # device tensors referenced by raw pointer
@@ -172,7 +205,10 @@ class HotPathEngine:
                     # shard is stored sorted by calc-grid node: the (P_e, P_mu)
                     # gathers of a wavefront then hit a handful of cache lines
                     # instead of 64 different ones.
-                    perm = torch.argsort(node, stable=True)
+                    if sort_events == "bin":
+                        perm = bin_window_order(obin, self.n_bins)
+                    else:
+                        perm = torch.argsort(node, stable=True)
                     gx, gy, flux_d, aeff_d, w0_d = (t[perm].contiguous() for t in
                                                    (gx, gy, flux_d, aeff_d, w0_d))
                     cols = [t[perm].contiguous() for t in cols]

@@ -28,6 +28,10 @@ DRAGON = dict(mins=[np.log(5.62341325), -1.0, -0.5], maxs=[np.log(56.23413252), 
 # reco_energy x reco_coszen 10x10 (settings/binning/example.cfg:56-59 without pid)
 EXAMPLE2D = dict(mins=[np.log(5.0), -1.0], maxs=[np.log(100.0), 1.0], nbins=[10, 10],
                  log=[True, False])
+# a fine analysis binning (40 x 40 x 3 = 4800 bins): too large for LDS accumulators
+FINE3D = dict(mins=[np.log(5.0), -1.0, -0.5], maxs=[np.log(100.0), 1.0, 2.5], nbins=[40, 40, 3],
+              log=[True, False, False])
+BINNINGS = dict(dragon=DRAGON, example2d=EXAMPLE2D, fine3d=FINE3D)
 
 LIVETIME_S = 2.5 * 365 * 86400.0  # 2.5 common_year (example.cfg aeff.livetime)
 
@@ -86,7 +90,7 @@ class Workload:
         self.n_per = int(n_events) // len(NAMES)
         self.n_events = self.n_per * len(NAMES)
         self.grid = GridSpec((1.0, 1000.0), grid[0], (-1.0, 1.0), grid[1], energy_first=True)
-        self.ob = DRAGON if out_binning == "dragon" else EXAMPLE2D
+        self.ob = BINNINGS[out_binning]
         self.out_binning = _lib.make_binning(self.ob["mins"], self.ob["maxs"], self.ob["nbins"])
         self.n_bins = int(np.prod(self.ob["nbins"]))
         self.layers = Layers(earth_model, detector_depth, prop_height)
