@@ -260,6 +260,35 @@ int pisa_hip_apply_aeff(const double *d_weighted_aeff, double scale, int64_t n,
 int pisa_hip_hist_finalize(const int64_t *d_limbs, int32_t n_containers, int64_t n_bins,
                            double *d_hist, double *d_sumw2, int32_t *d_status, void *stream);
 
+/* pisa_hip_reweight_hist without the initial clear of d_limbs: ADDS this call's
+ * events to whatever the limbs hold (e.g. the zeros left behind by
+ * pisa_hip_finalize_metric(clear_limbs=1), or the sums of another batch). */
+int pisa_hip_reweight_hist_acc(const pisa_hip_container *h_containers, int32_t n_containers,
+                               const pisa_hip_binning *h_calc_grid, const double *d_prob_nu,
+                               const double *d_prob_nubar, const double *d_pepmu,
+                               const pisa_hip_binning *h_out_binning, int64_t *d_limbs,
+                               int32_t *d_status, void *stream);
+
+/* Largest n_containers*n_bins pisa_hip_finalize_metric accepts (one workgroup). */
+#define PISA_HIP_FINALIZE_METRIC_MAX 4096
+
+/* pisa_hip_hist_finalize + pisa_hip_metric(kind, d_actual, d_hist, d_sumw2,
+ * n_maps = n_containers) in ONE launch, for the tail of a template evaluation
+ * (hist.py:215 -> distribution_maker.py:274-281 -> map.py:1572-1604): same
+ * arithmetic in the same order as the two separate calls, bit for bit.
+ * d_hist / d_sumw2 [n_containers][n_bins] are written (required).
+ * total[1] may be device memory or device-mapped pinned host memory (the host
+ * then only waits for the stream; no copy kernel).
+ * clear_limbs != 0: d_limbs is zero again when the kernel ends, ready for
+ * pisa_hip_reweight_hist_acc.
+ * d_status: overflow flag of the limbs (as pisa_hip_hist_finalize);
+ * d_metric_status: PISA_HIP_ERR_NEGATIVE for negative inputs (as pisa_hip_metric).
+ * PISA_HIP_ERR_INVALID if n_containers*n_bins > PISA_HIP_FINALIZE_METRIC_MAX. */
+int pisa_hip_finalize_metric(int64_t *d_limbs, int32_t n_containers, int64_t n_bins,
+                             double *d_hist, double *d_sumw2, int32_t kind,
+                             const double *d_actual, double *total, int32_t *d_status,
+                             int32_t *d_metric_status, int32_t clear_limbs, void *stream);
+
 /* --------------------------------------------------------------------- KDE */
 
 /* Gaussian kernel sums of the KDE stage (pisa/utils/kde_hist.py:110-120 calls the

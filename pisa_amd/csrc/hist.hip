@@ -28,6 +28,7 @@
 #include <stdlib.h>
 
 #include "common.hpp"
+#include "metric_device.hpp"
 
 namespace pisa {
 
@@ -422,6 +423,73 @@ hist_finalize_kernel(const long long *__restrict__ limbs, int64_t n_total_bins,
     if (ovf && status) atomicOr(status, 1);
 }
 
+// hist_finalize_kernel + metric_kernel (metric_flux.hip) in one workgroup: the
+// tail of a template evaluation is launch-bound, not work-bound.  The metric part
+// repeats metric_kernel's loop and reduction tree exactly (first 256 threads).
+__global__ void __launch_bounds__(1024)
+finalize_metric_kernel(long long *__restrict__ limbs, int n_cont, int n_bins,
+                       double *__restrict__ hist, double *__restrict__ q1, int kind,
+                       const double *__restrict__ actual, double *__restrict__ total,
+                       int32_t *__restrict__ status, int32_t *__restrict__ mstatus, int clear) {
+    extern __shared__ __attribute__((aligned(16))) double s_map[];  // [2][n_cont][n_bins]
+    __shared__ double s_sum[256];
+    __shared__ int s_flag[2];
+    const int n_tot = n_cont * n_bins;
+    if (threadIdx.x < 2) s_flag[threadIdx.x] = 0;
+    bool ovf = false;
+    for (int i = threadIdx.x; i < n_tot; i += blockDim.x) {
+        long long *L = limbs + (int64_t)i * 2 * NL;
+        const double h = limbs_to_double(L, ovf);
+        const double s = limbs_to_double(L + NL, ovf);
+        hist[i] = h;
+        q1[i] = s;
+        s_map[i] = h;
+        s_map[n_tot + i] = s;
+        if (clear) {
+#pragma unroll
+            for (int k = 0; k < 2 * NL; k++) L[k] = 0;
+        }
+    }
+    if (ovf && status) atomicOr(status, 1);
+    __syncthreads();
+    const double *expected = s_map, *sigma2 = s_map + n_tot;
+    double acc = 0.0;
+    if (threadIdx.x < 256) {
+        for (int b = threadIdx.x; b < n_bins; b += 256) {
+            const double k = actual[b];
+            double lam = 0.0, s2 = 0.0;
+            for (int m = 0; m < n_cont; m++) {
+                lam = (m == 0) ? expected[b] : lam + expected[m * n_bins + b];
+                s2 = (m == 0) ? sigma2[b] : s2 + sigma2[m * n_bins + b];
+            }
+            double v;
+            const bool finite = (k == k) && (lam == lam) && !isinf(k) && !isinf(lam);
+            if (!finite) {
+                v = __longlong_as_double(0x7ff8000000000000LL);
+            } else {
+                if (k < 0.0 || lam < 0.0) atomicOr(&s_flag[0], 1);
+                if (kind == PISA_HIP_METRIC_CHI2) {
+                    const double lc = lam < SMALL_POS ? SMALL_POS : lam;
+                    if (!(fabs(k - lc) < 5 * FTYPE_PREC)) atomicOr(&s_flag[1], 1);
+                }
+                v = metric_bin(kind, k, lam, s2);
+            }
+            if (v == v) acc += v;  // np.nansum
+        }
+        s_sum[threadIdx.x] = acc;
+    }
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) s_sum[threadIdx.x] += s_sum[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const bool chi2_zero = (kind == PISA_HIP_METRIC_CHI2) && s_flag[1] == 0;  // stats.py:160-161
+        total[0] = chi2_zero ? 0.0 : s_sum[0];
+        if (mstatus && s_flag[0]) mstatus[0] = PISA_HIP_ERR_NEGATIVE;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 hist_average_kernel(int64_t n_bins, double *__restrict__ hist, const double *__restrict__ cnt) {
     int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -494,7 +562,7 @@ static thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
 static int run_hist(const ContDev *conts, int n_cont, int mode, const DevBinning *grid,
                     int64_t n_nodes, const double *prob_nu, const double *prob_nubar,
                     const double *pepmu, const DevBinning &outb, int64_t n_bins,
-                    long long *d_limbs, int32_t *d_status, hipStream_t s) {
+                    long long *d_limbs, int32_t *d_status, hipStream_t s, bool clear_first = true) {
     if (n_bins > (1 << 28)) return PISA_HIP_ERR_INVALID;
     int64_t lds_bytes = lds_acc_bytes(n_bins);
     bool lds = lds_bytes <= LDS_ACC_BYTES_MAX;
@@ -509,7 +577,8 @@ static int run_hist(const ContDev *conts, int n_cont, int mode, const DevBinning
     while (copies > 1 && (copies & (copies - 1))) copies--;
     while (copies > 1 && lds_bytes * copies > LDS_ACC_BYTES_MAX) copies >>= 1;
     if (copies < 1) copies = 1;
-    PISA_TRY_HIP(hipMemsetAsync(d_limbs, 0, (size_t)n_cont * n_bins * 2 * NL * 8, s));
+    if (clear_first)
+        PISA_TRY_HIP(hipMemsetAsync(d_limbs, 0, (size_t)n_cont * n_bins * 2 * NL * 8, s));
     for (int base = 0; base < n_cont; base += MAX_CONT) {
         int nc = n_cont - base < MAX_CONT ? n_cont - base : MAX_CONT;
         HistArgs a;
@@ -580,11 +649,11 @@ PISA_API int pisa_hip_event_indices(const pisa_hip_binning *h_binning,
     return PISA_HIP_OK;
 }
 
-PISA_API int pisa_hip_reweight_hist(const pisa_hip_container *h_containers, int32_t n_containers,
-                                    const pisa_hip_binning *h_calc_grid, const double *d_prob_nu,
-                                    const double *d_prob_nubar, const double *d_pepmu,
-                                    const pisa_hip_binning *h_out_binning, int64_t *d_limbs,
-                                    int32_t *d_status, void *stream) {
+static int reweight_hist_impl(const pisa_hip_container *h_containers, int32_t n_containers,
+                              const pisa_hip_binning *h_calc_grid, const double *d_prob_nu,
+                              const double *d_prob_nubar, const double *d_pepmu,
+                              const pisa_hip_binning *h_out_binning, int64_t *d_limbs,
+                              int32_t *d_status, void *stream, bool clear_first) {
     if (!h_containers || n_containers < 1 || n_containers > 1024 || !d_limbs)
         return PISA_HIP_ERR_INVALID;
     DevBinning grid, outb;
@@ -630,9 +699,49 @@ PISA_API int pisa_hip_reweight_hist(const pisa_hip_container *h_containers, int3
         d.side = h.nubar > 0 ? 0 : 1;
     }
     rc = run_hist(conts, n_containers, all_packed ? 3 : (all_indexed ? 2 : 1), &grid, n_nodes, d_prob_nu, d_prob_nubar,
-                  d_pepmu, outb, n_bins, (long long *)d_limbs, d_status, as_stream(stream));
+                  d_pepmu, outb, n_bins, (long long *)d_limbs, d_status, as_stream(stream), clear_first);
     delete[] conts;
     return rc;
+}
+
+PISA_API int pisa_hip_reweight_hist(const pisa_hip_container *h_containers, int32_t n_containers,
+                                    const pisa_hip_binning *h_calc_grid, const double *d_prob_nu,
+                                    const double *d_prob_nubar, const double *d_pepmu,
+                                    const pisa_hip_binning *h_out_binning, int64_t *d_limbs,
+                                    int32_t *d_status, void *stream) {
+    return reweight_hist_impl(h_containers, n_containers, h_calc_grid, d_prob_nu, d_prob_nubar,
+                              d_pepmu, h_out_binning, d_limbs, d_status, stream, true);
+}
+
+PISA_API int pisa_hip_reweight_hist_acc(const pisa_hip_container *h_containers,
+                                        int32_t n_containers, const pisa_hip_binning *h_calc_grid,
+                                        const double *d_prob_nu, const double *d_prob_nubar,
+                                        const double *d_pepmu,
+                                        const pisa_hip_binning *h_out_binning, int64_t *d_limbs,
+                                        int32_t *d_status, void *stream) {
+    return reweight_hist_impl(h_containers, n_containers, h_calc_grid, d_prob_nu, d_prob_nubar,
+                              d_pepmu, h_out_binning, d_limbs, d_status, stream, false);
+}
+
+PISA_API int pisa_hip_finalize_metric(int64_t *d_limbs, int32_t n_containers, int64_t n_bins,
+                                      double *d_hist, double *d_sumw2, int32_t kind,
+                                      const double *d_actual, double *total, int32_t *d_status,
+                                      int32_t *d_metric_status, int32_t clear_limbs,
+                                      void *stream) {
+    if (!d_limbs || !d_hist || !d_sumw2 || !d_actual || !total || n_containers < 1 || n_bins < 1)
+        return PISA_HIP_ERR_INVALID;
+    if (kind < PISA_HIP_METRIC_LLH || kind > PISA_HIP_METRIC_MOD_CHI2) return PISA_HIP_ERR_INVALID;
+    if ((int64_t)n_containers * n_bins > PISA_HIP_FINALIZE_METRIC_MAX) return PISA_HIP_ERR_INVALID;
+    const int n_tot = (int)(n_containers * n_bins);
+    int threads = ((n_tot + 63) / 64) * 64;
+    if (threads < 256) threads = 256;  // the metric reduction tree is 256 wide
+    if (threads > 1024) threads = 1024;
+    hipLaunchKernelGGL(finalize_metric_kernel, dim3(1), dim3(threads), (size_t)n_tot * 16,
+                       as_stream(stream), (long long *)d_limbs, (int)n_containers, (int)n_bins,
+                       d_hist, d_sumw2, (int)kind, d_actual, total, d_status, d_metric_status,
+                       (int)clear_limbs);
+    PISA_CHECK_LAUNCH("finalize_metric_kernel");
+    return PISA_HIP_OK;
 }
 
 PISA_API int pisa_hip_hist_finalize(const int64_t *d_limbs, int32_t n_containers, int64_t n_bins,

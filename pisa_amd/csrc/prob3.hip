@@ -82,42 +82,47 @@ prob3_grid_kernel(const Prob3Consts c, const double *__restrict__ energy, int n_
     }
 }
 
-// ------------------------------------------------- planned (two-stage) grid
-// Stage A: one thread per (side, unique shell density, energy).
+// ------------------------------------------------------- planned grid form
+// The work of a grid evaluation is tiny (~0.1 GFLOP); what costs is latency: the
+// eigenvalue/projector terms of one (E, density) are a ~8 us dependent chain and a
+// row's ordered matrix product is up to 24 dependent 3x3 complex products.  The
+// plan (host, once per Earth model / coszen grid) therefore
+//   * resolves the reference's layer-matrix cache (numba_osc_kernels.py:236-249)
+//     and gives mirrored layers of a row ONE matrix ("pair" = (density, length)),
+//   * cuts the pairs of each distinct density into work items of a few pairs,
+//   * lists every row's chain as pair indices in path order,
+// and an evaluation is two launches:
+//   stage AB  wave = (item, sign, 64 energies): terms of (E, rho) in registers, then
+//             A = sum_k phase_k Q_k for the item's pairs -> amp[side][pair][18][n_e]
+//   stage C   workgroup = (row, sign, 64 energies) x G waves: wave g multiplies its
+//             g-th part of the chain, wave 0 joins the G partial products (LDS),
+//             rotates to the flavour basis and stores P and the gather tables.
+// Stage C associates the product differently from the sequential reference
+// (parts first), so its results agree with prob3_grid_kernel to rounding
+// (~1e-15), not bit for bit.
+constexpr int CHAIN_GROUPS = 4;
+
 template <bool DECAY>
 __global__ void __launch_bounds__(64)
-prob3_terms_kernel(const Prob3Consts c, const double *__restrict__ energy, int n_e,
-                   const double *__restrict__ rho_unique, int n_unique,
-                   double *__restrict__ rec) {
-    const int ie = blockIdx.x * blockDim.x + threadIdx.x;
-    const int u = blockIdx.y;
-    const int side = blockIdx.z;
-    if (ie >= n_e) return;
-    double *r = rec + ((int64_t)(side * n_unique + u) * PROB3_NF) * n_e + ie;
-    auto store = [&](int f, double v) { r[(int64_t)f * n_e] = v; };
-    eigen_terms<DECAY>(c.side[side], c.dm, energy[ie], rho_unique[u], store);
-}
-
-// Stage B: one workgroup per (crossed layer of a coszen row, sign), lanes along
-// energy: amplitude matrix A of that layer -> scratch [side][pair][18][n_e].
-// All layers of all rows run in parallel (the per-row chains are short but the
-// longest row has 24 layers: doing the transcendental work inside the chain
-// made the whole launch wait for that row).
-template <bool DECAY>
-__global__ void __launch_bounds__(256)
-prob3_amp_kernel(const double *__restrict__ energy, int n_e, const int32_t *__restrict__ pair_u,
-                 const double *__restrict__ pair_dist, int n_pairs, int n_unique,
-                 const double *__restrict__ rec, double *__restrict__ amp) {
-    const int k = blockIdx.x;
+prob3_terms_amp_kernel(const Prob3Consts c, const double *__restrict__ energy, int n_e,
+                       const double *__restrict__ rho_unique, const int32_t *__restrict__ item_u,
+                       const int32_t *__restrict__ item_p0, const int32_t *__restrict__ item_cnt,
+                       const double *__restrict__ pair_dist, int n_pairs,
+                       double *__restrict__ amp) {
+    const int item = blockIdx.x;
     const int side = blockIdx.y;
-    const int u = pair_u[k];
-    const double d = pair_dist[k];
-    for (int ie = threadIdx.x; ie < n_e; ie += blockDim.x) {
-        const double *r = rec + ((int64_t)(side * n_unique + u) * PROB3_NF) * n_e + ie;
-        auto load = [&](int f) { return r[(int64_t)f * n_e]; };
+    const int ie = blockIdx.z * 64 + threadIdx.x;
+    if (ie >= n_e) return;
+    const double e = energy[ie];
+    double rec[PROB3_NF];
+    auto store = [&](int f, double v) { rec[f] = v; };
+    eigen_terms<DECAY>(c.side[side], c.dm, e, rho_unique[item_u[item]], store);
+    auto load = [&](int f) { return rec[f]; };
+    const int p0 = item_p0[item], cnt = item_cnt[item];
+    for (int q = 0; q < cnt; q++) {
         mat3 A;
-        amplitude_from_terms<DECAY>(load, d / energy[ie], A);
-        double *o = amp + ((int64_t)(side * n_pairs + k) * 18) * n_e + ie;
+        amplitude_from_terms<DECAY>(load, pair_dist[p0 + q] / e, A);
+        double *o = amp + ((int64_t)(side * n_pairs + p0 + q) * 18) * n_e + ie;
 #pragma unroll
         for (int i = 0; i < 3; i++)
 #pragma unroll
@@ -128,64 +133,98 @@ prob3_amp_kernel(const double *__restrict__ energy, int n_e, const int32_t *__re
     }
 }
 
-// Stage C: ordered product of a row's layer matrices (numba_osc_kernels.py:281-294),
-// flavour basis and probabilities (:326-345).  Workgroup = (coszen row, sign).
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * CHAIN_GROUPS)
 prob3_chain_kernel(const Prob3Consts c, int n_e, const int32_t *__restrict__ row_start,
-                   const int32_t *__restrict__ row_cnt, int n_cz, int n_pairs,
-                   const double *__restrict__ amp, int e_major, double *__restrict__ prob_nu,
-                   double *__restrict__ prob_nubar, double2 *__restrict__ pepmu) {
+                   const int32_t *__restrict__ row_cnt, const int32_t *__restrict__ row_pairs,
+                   int n_cz, int n_pairs, const double *__restrict__ amp, int e_major,
+                   double *__restrict__ prob_nu, double *__restrict__ prob_nubar,
+                   double2 *__restrict__ pepmu) {
+    __shared__ double s_part[(CHAIN_GROUPS - 1) * 18 * 64];  // [group-1][18][lane]
     const int jcz = blockIdx.x;
     const int side = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int g = threadIdx.x >> 6;
+    const int ie = blockIdx.z * 64 + lane;
+    const bool live = ie < n_e;
     double *out = side == 0 ? prob_nu : prob_nubar;
     const Prob3Side &S = c.side[side];
     const int k0 = row_start[jcz];
     const int cnt = row_cnt[jcz];
-    for (int ie = threadIdx.x; ie < n_e; ie += blockDim.x) {
-        auto load_A = [&](int k, mat3 &A) {
-            const double *a = amp + ((int64_t)(side * n_pairs + k) * 18) * n_e + ie;
-#pragma unroll
-            for (int i = 0; i < 3; i++)
-#pragma unroll
-                for (int j = 0; j < 3; j++)
-                    A.m[i][j] = cmake(a[(int64_t)(6 * i + 2 * j) * n_e], a[(int64_t)(6 * i + 2 * j + 1) * n_e]);
-        };
-        mat3 T;
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-            for (int j = 0; j < 3; j++) T.m[i][j] = cmake(0.0, 0.0);
-        if (cnt > 0) {
-            // the product itself is ~200 flops per layer; what costs is the latency of
-            // fetching the next matrix, so keep three layers in flight
-            load_A(k0, T);
-            mat3 A0, A1, A2;
-            if (cnt > 1) load_A(k0 + 1, A0);
-            if (cnt > 2) load_A(k0 + 2, A1);
-            if (cnt > 3) load_A(k0 + 3, A2);
-            for (int t = 1; t < cnt; t++) {
-                mat3 An;
-                if (t + 3 < cnt) load_A(k0 + t + 3, An);  // prefetch three layers ahead
-                mat3 t2;
-                mat_mul(A0, T, t2);
-                T = t2;
-                A0 = A1;
-                A1 = A2;
-                A2 = An;
-            }
-        }
-        mat3 t2, Tf;
-        mat_mul(T, S.Ud, t2);
-        mat_mul(S.U, t2, Tf);
-        double P[9];
+    // this wave's part of the chain: layers [t0, t1) in path order
+    const int t0 = (int)(((int64_t)cnt * g) / CHAIN_GROUPS);
+    const int t1 = (int)(((int64_t)cnt * (g + 1)) / CHAIN_GROUPS);
+    auto load_A = [&](int t, mat3 &A) {
+        const int k = row_pairs[k0 + t];
+        const double *a = amp + ((int64_t)(side * n_pairs + k) * 18) * n_e + ie;
 #pragma unroll
         for (int i = 0; i < 3; i++)
 #pragma unroll
             for (int j = 0; j < 3; j++)
-                P[3 * i + j] = Tf.m[j][i].re * Tf.m[j][i].re + Tf.m[j][i].im * Tf.m[j][i].im;
-        int64_t node = e_major ? (int64_t)ie * n_cz + jcz : (int64_t)jcz * n_e + ie;
-        store_node(P, node, (int64_t)n_e * n_cz, side, out, pepmu);
+                A.m[i][j] = cmake(a[(int64_t)(6 * i + 2 * j) * n_e], a[(int64_t)(6 * i + 2 * j + 1) * n_e]);
+    };
+    mat3 T;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) T.m[i][j] = cmake(0.0, 0.0);
+    if (live && t1 > t0) {
+        load_A(t0, T);
+        mat3 A0, A1;
+        if (t0 + 1 < t1) load_A(t0 + 1, A0);
+        if (t0 + 2 < t1) load_A(t0 + 2, A1);
+        for (int t = t0 + 1; t < t1; t++) {
+            mat3 An;
+            if (t + 2 < t1) load_A(t + 2, An);  // two layers ahead
+            mat3 t2;
+            mat_mul(A0, T, t2);  // later layer on the left (numba_osc_kernels.py:281-294)
+            T = t2;
+            A0 = A1;
+            A1 = An;
+        }
     }
+    if (g > 0 && live && t1 > t0) {
+        double *o = s_part + (g - 1) * 18 * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                o[(6 * i + 2 * j) * 64] = T.m[i][j].re;
+                o[(6 * i + 2 * j + 1) * 64] = T.m[i][j].im;
+            }
+    }
+    __syncthreads();
+    if (g != 0 || !live) return;
+    bool have = t1 > t0;
+    for (int h = 1; h < CHAIN_GROUPS; h++) {
+        const int h0 = (int)(((int64_t)cnt * h) / CHAIN_GROUPS);
+        const int h1 = (int)(((int64_t)cnt * (h + 1)) / CHAIN_GROUPS);
+        if (h1 <= h0) continue;  // workgroup-uniform
+        mat3 Ph;
+        const double *o = s_part + (h - 1) * 18 * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) Ph.m[i][j] = cmake(o[(6 * i + 2 * j) * 64], o[(6 * i + 2 * j + 1) * 64]);
+        if (have) {
+            mat3 t2;
+            mat_mul(Ph, T, t2);
+            T = t2;
+        } else {
+            T = Ph;
+            have = true;
+        }
+    }
+    mat3 t2, Tf;
+    mat_mul(T, S.Ud, t2);
+    mat_mul(S.U, t2, Tf);
+    double P[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            P[3 * i + j] = Tf.m[j][i].re * Tf.m[j][i].re + Tf.m[j][i].im * Tf.m[j][i].im;
+    int64_t node = e_major ? (int64_t)ie * n_cz + jcz : (int64_t)jcz * n_e + ie;
+    store_node(P, node, (int64_t)n_e * n_cz, side, out, pepmu);
 }
 
 // ------------------------------------------------------------------- layers
@@ -587,24 +626,65 @@ PISA_API int pisa_hip_fill_probs(const double *d_probability, int64_t init_flav,
 
 // ------------------------------------------------------------ grid plan (host)
 struct pisa_hip_grid_plan {
-    int n_cz, n_layers, n_unique, n_pairs;
-    int32_t *d_pair_u;     // [n_pairs] distinct-density index of each crossed layer
-    double *d_pair_dist;   // [n_pairs] its (cache-resolved) length
-    int32_t *d_row_start;  // [n_cz] first pair of the row
-    int32_t *d_row_cnt;    // [n_cz] crossed layers of the row, in path order
+    int n_cz, n_layers, n_unique, n_pairs, n_items, n_chain;
+    int32_t *d_item_u;     // [n_items] distinct-density index of the item
+    int32_t *d_item_p0;    // [n_items] first pair of the item
+    int32_t *d_item_cnt;   // [n_items] pairs of the item (consecutive, same density)
+    double *d_pair_dist;   // [n_pairs] (cache-resolved) layer length of each pair
+    int32_t *d_row_start;  // [n_cz] first chain entry of the row
+    int32_t *d_row_cnt;    // [n_cz] crossed layers of the row
+    int32_t *d_row_pairs;  // [n_chain] pair index per crossed layer, in path order
     double *d_rho;         // [n_unique]
-    double *d_rec;         // stage-A records [2][n_unique][NF][n_e]
-    double *d_amp;         // stage-B amplitudes [2][n_pairs][18][n_e]
+    double *d_amp;         // stage-AB amplitudes [2][n_pairs][18][n_e]
     int n_e_alloc;
+    // host copies for re-cutting the items when n_e changes
+    int32_t *h_pair_u;
+    int items_for_n_e;
 };
 
 PISA_API int pisa_hip_grid_plan_destroy(pisa_hip_grid_plan *p) {
     if (!p) return PISA_HIP_OK;
-    void *ptrs[] = {p->d_pair_u, p->d_pair_dist, p->d_row_start, p->d_row_cnt, p->d_rho, p->d_rec, p->d_amp};
+    void *ptrs[] = {p->d_item_u, p->d_item_p0, p->d_item_cnt, p->d_pair_dist, p->d_row_start,
+                    p->d_row_cnt, p->d_row_pairs, p->d_rho, p->d_amp};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
+    delete[] p->h_pair_u;
     delete p;
     return PISA_HIP_OK;
+}
+
+// Cut the (density-sorted) pairs into items of <= ch consecutive pairs of one density.
+// ch is chosen so that stage AB has about 2000 waves: enough to occupy the chip
+// with the ~8 us terms chain running once per wave.
+static int cut_items(pisa_hip_grid_plan *p, int n_e) {
+    const int tiles = (n_e + 63) / 64;
+    int ch = (int)(((int64_t)p->n_pairs * 2 * tiles + 2047) / 2048);
+    if (ch < 1) ch = 1;
+    const int np = p->n_pairs;
+    int32_t *iu = new int32_t[np + 1], *ip0 = new int32_t[np + 1], *icnt = new int32_t[np + 1];
+    int ni = 0;
+    for (int k = 0; k < np;) {
+        int e = k;
+        while (e < np && e - k < ch && p->h_pair_u[e] == p->h_pair_u[k]) e++;
+        iu[ni] = p->h_pair_u[k]; ip0[ni] = k; icnt[ni] = e - k;
+        ni++;
+        k = e;
+    }
+    int rc = 0;
+    for (void *q : {(void *)p->d_item_u, (void *)p->d_item_p0, (void *)p->d_item_cnt})
+        if (q) (void)hipFree(q);
+    p->d_item_u = p->d_item_p0 = p->d_item_cnt = nullptr;
+    size_t bytes = (size_t)(ni > 0 ? ni : 1) * 4;
+    rc = check_hip(hipMalloc(&p->d_item_u, bytes), "hipMalloc");
+    if (!rc) rc = check_hip(hipMalloc(&p->d_item_p0, bytes), "hipMalloc");
+    if (!rc) rc = check_hip(hipMalloc(&p->d_item_cnt, bytes), "hipMalloc");
+    if (!rc && ni > 0) rc = check_hip(hipMemcpy(p->d_item_u, iu, (size_t)ni * 4, hipMemcpyHostToDevice), "h2d");
+    if (!rc && ni > 0) rc = check_hip(hipMemcpy(p->d_item_p0, ip0, (size_t)ni * 4, hipMemcpyHostToDevice), "h2d");
+    if (!rc && ni > 0) rc = check_hip(hipMemcpy(p->d_item_cnt, icnt, (size_t)ni * 4, hipMemcpyHostToDevice), "h2d");
+    delete[] iu; delete[] ip0; delete[] icnt;
+    p->n_items = ni;
+    p->items_for_n_e = n_e;
+    return rc;
 }
 
 PISA_API int pisa_hip_grid_plan_create(const double *d_densities, const double *d_distances,
@@ -615,17 +695,20 @@ PISA_API int pisa_hip_grid_plan_create(const double *d_densities, const double *
     size_t n = (size_t)n_cz * n_layers;
     double *rho = new double[n], *dist = new double[n], *pdist = new double[n + 1];
     int32_t *pu = new int32_t[n + 1], *rstart = new int32_t[n_cz], *rcnt = new int32_t[n_cz];
+    int32_t *chain = new int32_t[n + 1], *layer_pair = new int32_t[n_layers];
     double *uniq = new double[n + 1];
-    int nu = 0, np = 0;
+    int nu = 0, np = 0, nc = 0;
     int rc = check_hip(hipMemcpy(rho, d_densities, n * 8, hipMemcpyDeviceToHost), "d2h");
     if (!rc) rc = check_hip(hipMemcpy(dist, d_distances, n * 8, hipMemcpyDeviceToHost), "d2h");
     if (!rc) {
         for (int r = 0; r < n_cz; r++) {
             const double *rr = rho + (size_t)r * n_layers, *dd = dist + (size_t)r * n_layers;
-            rstart[r] = np;
+            rstart[r] = nc;
             for (int i = 0; i < n_layers; i++) {
+                layer_pair[i] = -1;
                 if (!(dd[i] > 0.0)) continue;
                 // follow the reference's cache matches (numba_osc_kernels.py:236-249)
+                // to the layer whose matrix is actually computed
                 int cur = i;
                 double cr = rr[i], cd = dd[i];
                 while (true) {
@@ -635,16 +718,33 @@ PISA_API int pisa_hip_grid_plan_create(const double *d_densities, const double *
                     if (found < 0) break;
                     cur = found; cr = rr[cur]; cd = dd[cur];
                 }
-                int u = -1;
-                for (int k = 0; k < nu; k++)
-                    if (uniq[k] == cr) { u = k; break; }
-                if (u < 0) { u = nu; uniq[nu++] = cr; }
-                pu[np] = u;
-                pdist[np] = cd;
-                np++;
+                if (cur != i) {
+                    layer_pair[i] = layer_pair[cur];  // the same matrix, stored once
+                } else {
+                    int u = -1;
+                    for (int k = 0; k < nu; k++)
+                        if (uniq[k] == cr) { u = k; break; }
+                    if (u < 0) { u = nu; uniq[nu++] = cr; }
+                    pu[np] = u;
+                    pdist[np] = cd;
+                    layer_pair[i] = np++;
+                }
+                chain[nc++] = layer_pair[i];
             }
-            rcnt[r] = np - rstart[r];
+            rcnt[r] = nc - rstart[r];
         }
+    }
+    // renumber the pairs sorted by density so that an item is a run of consecutive pairs
+    int32_t *order = new int32_t[np + 1], *newid = new int32_t[np + 1];
+    double *sdist = new double[np + 1];
+    int32_t *su = new int32_t[np + 1];
+    {
+        int w = 0;
+        for (int u = 0; u < nu; u++)
+            for (int k = 0; k < np; k++)
+                if (pu[k] == u) order[w++] = k;
+        for (int k = 0; k < np; k++) { newid[order[k]] = k; sdist[k] = pdist[order[k]]; su[k] = pu[order[k]]; }
+        for (int k = 0; k < nc; k++) chain[k] = newid[chain[k]];
     }
     pisa_hip_grid_plan *p = nullptr;
     if (!rc) {
@@ -653,20 +753,24 @@ PISA_API int pisa_hip_grid_plan_create(const double *d_densities, const double *
         p->n_cz = n_cz; p->n_layers = n_layers;
         p->n_unique = nu > 0 ? nu : 1;
         p->n_pairs = np;
+        p->n_chain = nc;
+        p->h_pair_u = su;
+        su = nullptr;
         if (nu == 0) uniq[0] = 0.0;
-        size_t npa = np > 0 ? np : 1;
-        rc = check_hip(hipMalloc(&p->d_pair_u, npa * 4), "hipMalloc");
-        if (!rc) rc = check_hip(hipMalloc(&p->d_pair_dist, npa * 8), "hipMalloc");
+        size_t npa = np > 0 ? np : 1, nca = nc > 0 ? nc : 1;
+        rc = check_hip(hipMalloc(&p->d_pair_dist, npa * 8), "hipMalloc");
         if (!rc) rc = check_hip(hipMalloc(&p->d_row_start, (size_t)n_cz * 4), "hipMalloc");
         if (!rc) rc = check_hip(hipMalloc(&p->d_row_cnt, (size_t)n_cz * 4), "hipMalloc");
+        if (!rc) rc = check_hip(hipMalloc(&p->d_row_pairs, nca * 4), "hipMalloc");
         if (!rc) rc = check_hip(hipMalloc(&p->d_rho, (size_t)p->n_unique * 8), "hipMalloc");
-        if (!rc && np > 0) rc = check_hip(hipMemcpy(p->d_pair_u, pu, (size_t)np * 4, hipMemcpyHostToDevice), "h2d");
-        if (!rc && np > 0) rc = check_hip(hipMemcpy(p->d_pair_dist, pdist, (size_t)np * 8, hipMemcpyHostToDevice), "h2d");
+        if (!rc && np > 0) rc = check_hip(hipMemcpy(p->d_pair_dist, sdist, (size_t)np * 8, hipMemcpyHostToDevice), "h2d");
         if (!rc) rc = check_hip(hipMemcpy(p->d_row_start, rstart, (size_t)n_cz * 4, hipMemcpyHostToDevice), "h2d");
         if (!rc) rc = check_hip(hipMemcpy(p->d_row_cnt, rcnt, (size_t)n_cz * 4, hipMemcpyHostToDevice), "h2d");
+        if (!rc && nc > 0) rc = check_hip(hipMemcpy(p->d_row_pairs, chain, (size_t)nc * 4, hipMemcpyHostToDevice), "h2d");
         if (!rc) rc = check_hip(hipMemcpy(p->d_rho, uniq, (size_t)p->n_unique * 8, hipMemcpyHostToDevice), "h2d");
     }
     delete[] rho; delete[] dist; delete[] pdist; delete[] pu; delete[] rstart; delete[] rcnt; delete[] uniq;
+    delete[] chain; delete[] layer_pair; delete[] order; delete[] newid; delete[] sdist; delete[] su;
     if (rc && p) { pisa_hip_grid_plan_destroy(p); p = nullptr; }
     *out = p;
     return rc;
@@ -681,40 +785,31 @@ PISA_API int pisa_hip_prob3_grid_planned(const pisa_hip_prob3_params *h_params,
     int rc = make_consts(h_params, c);
     if (rc) return rc;
     if (plan->n_e_alloc < n_e) {
-        if (plan->d_rec) (void)hipFree(plan->d_rec);
         if (plan->d_amp) (void)hipFree(plan->d_amp);
-        plan->d_rec = plan->d_amp = nullptr;
+        plan->d_amp = nullptr;
         plan->n_e_alloc = 0;
-        size_t rec_bytes = (size_t)2 * plan->n_unique * PROB3_NF * n_e * sizeof(double);
         size_t amp_bytes = (size_t)2 * (plan->n_pairs > 0 ? plan->n_pairs : 1) * 18 * n_e * sizeof(double);
-        PISA_TRY_HIP(hipMalloc(&plan->d_rec, rec_bytes));
         PISA_TRY_HIP(hipMalloc(&plan->d_amp, amp_bytes));
         plan->n_e_alloc = n_e;
     }
+    if (plan->items_for_n_e != n_e && (rc = cut_items(plan, n_e))) return rc;
     hipStream_t s = as_stream(stream);
-    dim3 ablock(64), agrid((unsigned)((n_e + 63) / 64), (unsigned)plan->n_unique, 2);
-    int threads = ((n_e + 63) / 64) * 64;
-    if (threads > 256) threads = 256;
-    dim3 bblock(threads), bgrid((unsigned)(plan->n_pairs > 0 ? plan->n_pairs : 1), 2);
-    dim3 cgrid((unsigned)plan->n_cz, 2);
-    if (c.decay) {
-        hipLaunchKernelGGL(prob3_terms_kernel<true>, agrid, ablock, 0, s, c, d_energy, (int)n_e,
-                           plan->d_rho, plan->n_unique, plan->d_rec);
-        if (plan->n_pairs > 0)
-            hipLaunchKernelGGL(prob3_amp_kernel<true>, bgrid, bblock, 0, s, d_energy, (int)n_e,
-                               plan->d_pair_u, plan->d_pair_dist, plan->n_pairs, plan->n_unique,
-                               plan->d_rec, plan->d_amp);
-    } else {
-        hipLaunchKernelGGL(prob3_terms_kernel<false>, agrid, ablock, 0, s, c, d_energy, (int)n_e,
-                           plan->d_rho, plan->n_unique, plan->d_rec);
-        if (plan->n_pairs > 0)
-            hipLaunchKernelGGL(prob3_amp_kernel<false>, bgrid, bblock, 0, s, d_energy, (int)n_e,
-                               plan->d_pair_u, plan->d_pair_dist, plan->n_pairs, plan->n_unique,
-                               plan->d_rec, plan->d_amp);
+    const unsigned tiles = (unsigned)((n_e + 63) / 64);
+    dim3 ablock(64), agrid((unsigned)(plan->n_items > 0 ? plan->n_items : 1), 2, tiles);
+    dim3 cblock(64 * CHAIN_GROUPS), cgrid((unsigned)plan->n_cz, 2, tiles);
+    if (plan->n_items > 0) {
+        if (c.decay)
+            hipLaunchKernelGGL(prob3_terms_amp_kernel<true>, agrid, ablock, 0, s, c, d_energy, (int)n_e,
+                               plan->d_rho, plan->d_item_u, plan->d_item_p0, plan->d_item_cnt,
+                               plan->d_pair_dist, plan->n_pairs, plan->d_amp);
+        else
+            hipLaunchKernelGGL(prob3_terms_amp_kernel<false>, agrid, ablock, 0, s, c, d_energy, (int)n_e,
+                               plan->d_rho, plan->d_item_u, plan->d_item_p0, plan->d_item_cnt,
+                               plan->d_pair_dist, plan->n_pairs, plan->d_amp);
     }
-    hipLaunchKernelGGL(prob3_chain_kernel, cgrid, bblock, 0, s, c, (int)n_e, plan->d_row_start,
-                       plan->d_row_cnt, plan->n_cz, plan->n_pairs, plan->d_amp, (int)e_major,
-                       d_prob_nu, d_prob_nubar, (double2 *)d_pepmu);
+    hipLaunchKernelGGL(prob3_chain_kernel, cgrid, cblock, 0, s, c, (int)n_e, plan->d_row_start,
+                       plan->d_row_cnt, plan->d_row_pairs, plan->n_cz, plan->n_pairs, plan->d_amp,
+                       (int)e_major, d_prob_nu, d_prob_nubar, (double2 *)d_pepmu);
     PISA_CHECK_LAUNCH("prob3_chain_kernel");
     return PISA_HIP_OK;
 }

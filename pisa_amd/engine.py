@@ -248,6 +248,9 @@ class HotPathEngine:
         self.ws = K.HistWorkspace(len(self.cont), self.n_bins, self.dev)
         self.metric_out = torch.zeros(1, dtype=torch.float64, device=self.dev)
         self.metric_status = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.metric_host = torch.zeros(1, dtype=torch.float64).pin_memory()
+        self.fused_tail = True
+        self._limbs_zero = self._maps_valid = False
         self.data = None
 
     def _up(self, a):
@@ -287,13 +290,18 @@ class HotPathEngine:
             self.compute_probs(params)
         K.reweight_hist(self._cont_arr, self.grid.binning, self.prob_nu, self.prob_nubar,
                         self.pepmu if (self.indexed and not self.osc_events) else None,
-                        self.out_binning, self.ws)
+                        self.out_binning, self.ws, clear=not self._limbs_zero)
+        self._limbs_zero = self._maps_valid = False
 
     def allreduce(self):
         allreduce_limbs(self.ws.limbs, self.world_size, self.group)
 
     def finalize(self):
-        return K.hist_finalize(self.ws)
+        """limbs -> fp64 maps (no-op if the fused tail of `eval` already wrote them)"""
+        if not self._maps_valid:
+            K.hist_finalize(self.ws)
+            self._maps_valid = True
+        return self.ws.hist, self.ws.sumw2
 
     def set_data(self, data_hist):
         self.data = K.to_device(np.asarray(data_hist, dtype=np.float64).ravel())
@@ -302,14 +310,39 @@ class HotPathEngine:
         return K.metric(kind, self.data, self.ws.hist, self.ws.sumw2, total_out=self.metric_out,
                         status=self.metric_status)
 
+    def _tail(self, kind, out):
+        """maps + metric of the accumulated (and all-reduced) limbs into `out`.
+        One launch (`pisa_hip_finalize_metric`, which also leaves the limbs zeroed
+        for the next accumulate) when a single workgroup can hold the maps; the
+        separate finalize and metric kernels otherwise.  Same bits either way."""
+        if (self.fused_tail and not self._maps_valid
+                and len(self.cont) * self.n_bins <= K.FINALIZE_METRIC_MAX):
+            K.finalize_metric(self.ws, kind, self.data, out, self.metric_status, clear_limbs=True)
+            self._limbs_zero = self._maps_valid = True
+        else:
+            self.finalize()
+            K.metric(kind, self.data, self.ws.hist, self.ws.sumw2, total_out=out,
+                     status=self.metric_status)
+        return out
+
     def eval(self, params, kind="llh"):
         """One template evaluation + metric; returns a 1-element device tensor."""
         self.accumulate(params)
         self.allreduce()
-        self.finalize()
-        if self.data is not None:
-            return self.metric(kind)
-        return None
+        if self.data is None:
+            self.finalize()
+            return None
+        return self._tail(kind, self.metric_out)
+
+    def eval_host(self, params, kind="llh"):
+        """`eval` for a fit loop that needs the number on the host: the tail kernel
+        writes the metric into pinned, device-mapped host memory, so the host only
+        waits for the stream (no device->host copy operation).  Returns a float."""
+        self.accumulate(params)
+        self.allreduce()
+        self._tail(kind, self.metric_host)
+        torch.cuda.current_stream().synchronize()
+        return float(self.metric_host[0])
 
     def eval_batch(self, params_list, kind="llh"):
         """Several INDEPENDENT parameter points (e.g. the 2n+1 points of a
@@ -341,13 +374,12 @@ class HotPathEngine:
                 osc_done[k].record(self._osc_stream)
             main.wait_event(osc_done[k])
             K.reweight_hist(self._cont_arr, self.grid.binning, tab[0], tab[1], tab[2],
-                            self.out_binning, self.ws)
+                            self.out_binning, self.ws, clear=not self._limbs_zero)
             used[k % 2] = torch.cuda.Event()
             used[k % 2].record(main)
+            self._limbs_zero = self._maps_valid = False
             self.allreduce()
-            self.finalize()
-            K.metric(kind, self.data, self.ws.hist, self.ws.sumw2, total_out=out[k:k + 1],
-                     status=self.metric_status)
+            self._tail(kind, out[k:k + 1])
         self.prob_nu, self.prob_nubar, self.pepmu = self._tables[(n - 1) % 2] if n else self._tables[0]
         return out
 

@@ -15,7 +15,15 @@ from . import _lib
 F8 = torch.float64
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """torch's current HIP stream of the current device as a raw handle.  The raw
+    accessor costs ~0.3 us; `torch.cuda.current_stream()` builds a Python Stream
+    object (~7 us), which matters in front of the first launch of an evaluation."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -228,11 +236,14 @@ class HistWorkspace:
         self.sumw2 = torch.empty((n_containers, n_bins), dtype=F8, device=dev)
 
 
-def reweight_hist(containers, calc_grid, prob_nu, prob_nubar, pepmu, out_binning, ws):
-    """Fused prob3.apply + aeff.apply + hist.apply(sumw2); fills ws.limbs."""
+def reweight_hist(containers, calc_grid, prob_nu, prob_nubar, pepmu, out_binning, ws,
+                  clear=True):
+    """Fused prob3.apply + aeff.apply + hist.apply(sumw2); fills ws.limbs
+    (`clear=False`: adds to them, e.g. after `finalize_metric(..., clear_limbs=True)`)."""
     lib = _lib.lib()
     arr = containers if isinstance(containers, C.Array) else (_lib.Container * len(containers))(*containers)
-    _lib.check(lib.pisa_hip_reweight_hist(
+    fn = lib.pisa_hip_reweight_hist if clear else lib.pisa_hip_reweight_hist_acc
+    _lib.check(fn(
         arr, len(arr), C.byref(calc_grid), _ptr(prob_nu), _ptr(prob_nubar), _ptr(pepmu),
         C.byref(out_binning), _ptr(ws.limbs), _ptr(ws.status), _stream()))
     return ws.limbs
@@ -244,6 +255,21 @@ def hist_finalize(ws):
                                           _ptr(ws.hist), _ptr(ws.sumw2), _ptr(ws.status),
                                           _stream()))
     return ws.hist, ws.sumw2
+
+
+FINALIZE_METRIC_MAX = 4096
+
+
+def finalize_metric(ws, kind, actual, total_out, metric_status, clear_limbs=True):
+    """`hist_finalize` + `metric` (maps summed over containers) in one launch;
+    `total_out` may be a device tensor or a pinned host tensor.  Same bits as the
+    two separate calls."""
+    lib = _lib.lib()
+    _lib.check(lib.pisa_hip_finalize_metric(
+        _ptr(ws.limbs), ws.n_containers, ws.n_bins, _ptr(ws.hist), _ptr(ws.sumw2),
+        METRIC_KIND[kind], _ptr(actual), total_out.data_ptr(), _ptr(ws.status),
+        _ptr(metric_status), 1 if clear_limbs else 0, _stream()))
+    return total_out
 
 
 def apply_osc_weights(nu_flux, prob_e, prob_mu, weights):

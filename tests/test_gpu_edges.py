@@ -78,7 +78,7 @@ def test_fused_kernel_empty_ragged_nan_out_of_range(oracle):
     np.testing.assert_allclose(hist, ref["hist"], rtol=1e-11, atol=1e-300)
     np.testing.assert_allclose(sumw2, ref["sumw2"], rtol=1e-11, atol=1e-300)
     # coordinate form agrees bit for bit on the same awkward inputs
-    st2 = synthetic.DeviceState(wl, indexed=False, planned=False)
+    st2 = synthetic.DeviceState(wl, indexed=False)
     st2.accumulate(wl.osc_params())
     assert bool((st.ws.limbs == st2.ws.limbs).all())
     # a non-finite weight is an error, not a silent NaN map
