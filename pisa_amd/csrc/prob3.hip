@@ -100,7 +100,7 @@ prob3_grid_kernel(const Prob3Consts c, const double *__restrict__ energy, int n_
 // Stage C associates the product differently from the sequential reference
 // (parts first), so its results agree with prob3_grid_kernel to rounding
 // (~1e-15), not bit for bit.
-constexpr int CHAIN_GROUPS = 4;
+constexpr int CHAIN_GROUPS_DEFAULT = 4;
 
 template <bool DECAY>
 __global__ void __launch_bounds__(64)
@@ -133,13 +133,14 @@ prob3_terms_amp_kernel(const Prob3Consts c, const double *__restrict__ energy, i
     }
 }
 
-__global__ void __launch_bounds__(64 * CHAIN_GROUPS)
+template <int CHAIN_GROUPS>
+__global__ void __launch_bounds__(64 * CHAIN_GROUPS) __attribute__((amdgpu_waves_per_eu(4, 8)))
 prob3_chain_kernel(const Prob3Consts c, int n_e, const int32_t *__restrict__ row_start,
                    const int32_t *__restrict__ row_cnt, const int32_t *__restrict__ row_pairs,
                    int n_cz, int n_pairs, const double *__restrict__ amp, int e_major,
                    double *__restrict__ prob_nu, double *__restrict__ prob_nubar,
                    double2 *__restrict__ pepmu) {
-    __shared__ double s_part[(CHAIN_GROUPS - 1) * 18 * 64];  // [group-1][18][lane]
+    __shared__ double s_part[(CHAIN_GROUPS > 1 ? CHAIN_GROUPS - 1 : 1) * 18 * 64];  // [group-1][18][lane]
     const int jcz = blockIdx.x;
     const int side = blockIdx.y;
     const int lane = threadIdx.x & 63;
@@ -169,17 +170,15 @@ prob3_chain_kernel(const Prob3Consts c, int n_e, const int32_t *__restrict__ row
         for (int j = 0; j < 3; j++) T.m[i][j] = cmake(0.0, 0.0);
     if (live && t1 > t0) {
         load_A(t0, T);
-        mat3 A0, A1;
+        mat3 A0;
         if (t0 + 1 < t1) load_A(t0 + 1, A0);
-        if (t0 + 2 < t1) load_A(t0 + 2, A1);
         for (int t = t0 + 1; t < t1; t++) {
             mat3 An;
-            if (t + 2 < t1) load_A(t + 2, An);  // two layers ahead
+            if (t + 1 < t1) load_A(t + 1, An);  // next layer in flight during the product
             mat3 t2;
             mat_mul(A0, T, t2);  // later layer on the left (numba_osc_kernels.py:281-294)
             T = t2;
-            A0 = A1;
-            A1 = An;
+            A0 = An;
         }
     }
     if (g > 0 && live && t1 > t0) {
@@ -660,6 +659,7 @@ static int cut_items(pisa_hip_grid_plan *p, int n_e) {
     const int tiles = (n_e + 63) / 64;
     int ch = (int)(((int64_t)p->n_pairs * 2 * tiles + 2047) / 2048);
     if (ch < 1) ch = 1;
+    if (const char *v = getenv("PISA_HIP_PROB3_CH")) ch = atoi(v) > 0 ? atoi(v) : ch;  // development probe
     const int np = p->n_pairs;
     int32_t *iu = new int32_t[np + 1], *ip0 = new int32_t[np + 1], *icnt = new int32_t[np + 1];
     int ni = 0;
@@ -796,7 +796,12 @@ PISA_API int pisa_hip_prob3_grid_planned(const pisa_hip_prob3_params *h_params,
     hipStream_t s = as_stream(stream);
     const unsigned tiles = (unsigned)((n_e + 63) / 64);
     dim3 ablock(64), agrid((unsigned)(plan->n_items > 0 ? plan->n_items : 1), 2, tiles);
-    dim3 cblock(64 * CHAIN_GROUPS), cgrid((unsigned)plan->n_cz, 2, tiles);
+    static const int groups = []() {
+        const char *v = getenv("PISA_HIP_CHAIN_GROUPS");
+        int g = v ? atoi(v) : CHAIN_GROUPS_DEFAULT;
+        return (g == 1 || g == 2 || g == 4 || g == 8) ? g : CHAIN_GROUPS_DEFAULT;
+    }();
+    dim3 cblock(64 * groups), cgrid((unsigned)plan->n_cz, 2, tiles);
     if (plan->n_items > 0) {
         if (c.decay)
             hipLaunchKernelGGL(prob3_terms_amp_kernel<true>, agrid, ablock, 0, s, c, d_energy, (int)n_e,
@@ -807,9 +812,11 @@ PISA_API int pisa_hip_prob3_grid_planned(const pisa_hip_prob3_params *h_params,
                                plan->d_rho, plan->d_item_u, plan->d_item_p0, plan->d_item_cnt,
                                plan->d_pair_dist, plan->n_pairs, plan->d_amp);
     }
-    hipLaunchKernelGGL(prob3_chain_kernel, cgrid, cblock, 0, s, c, (int)n_e, plan->d_row_start,
-                       plan->d_row_cnt, plan->d_row_pairs, plan->n_cz, plan->n_pairs, plan->d_amp,
-                       (int)e_major, d_prob_nu, d_prob_nubar, (double2 *)d_pepmu);
+#define CHAIN(G) hipLaunchKernelGGL(prob3_chain_kernel<G>, cgrid, cblock, 0, s, c, (int)n_e, plan->d_row_start, \
+                       plan->d_row_cnt, plan->d_row_pairs, plan->n_cz, plan->n_pairs, plan->d_amp,          \
+                       (int)e_major, d_prob_nu, d_prob_nubar, (double2 *)d_pepmu)
+    if (groups == 1) CHAIN(1); else if (groups == 2) CHAIN(2); else if (groups == 8) CHAIN(8); else CHAIN(4);
+#undef CHAIN
     PISA_CHECK_LAUNCH("prob3_chain_kernel");
     return PISA_HIP_OK;
 }

@@ -1,0 +1,11 @@
+"""Target for PMC passes: a few launches of the fused kernel on the default workload."""
+import torch
+
+from pisa_amd import synthetic
+
+wl = synthetic.Workload(n_events=10_000_000, grid=(200, 100), out_binning="dragon", seed=0)
+st = synthetic.DeviceState(wl)
+st.compute_probs(wl.osc_params())
+for _ in range(4):
+    st.accumulate()
+torch.cuda.synchronize()

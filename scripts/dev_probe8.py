@@ -1,0 +1,21 @@
+"""Development probe: device time of one planned prob3 grid evaluation (200x100, PREM-12)."""
+import sys
+
+import torch
+
+from pisa_amd import synthetic
+
+wl = synthetic.Workload(n_events=12000, grid=(200, 100), out_binning="dragon", seed=0)
+st = synthetic.DeviceState(wl)
+p = wl.osc_params()
+for _ in range(5):
+    st.compute_probs(p)
+torch.cuda.synchronize()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+n = 100
+a.record()
+for _ in range(n):
+    st.compute_probs(p)
+b.record()
+torch.cuda.synchronize()
+print("prob3 planned grid: %.1f us per evaluation" % (a.elapsed_time(b) / n * 1e3))

@@ -358,7 +358,10 @@ def test_indexed_equals_coordinate_form(K, L, oracle):
     b = synthetic.DeviceState(wl, indexed=False, planned=True)
     a.accumulate(p)
     b.accumulate(p)
-    assert bool((a.ws.limbs == b.ws.limbs).all())
+    # same exact sums (the un-normalised limb words may differ between kernels)
+    ha, sa = (t.clone() for t in a.finalize())
+    hb, sb = b.finalize()
+    assert bool((ha == hb).all()) and bool((sa == sb).all())
     ev = wl.events[4]
     idx = K.event_indices([K.to_device(s) for s in ev["sample"]], wl.out_binning).cpu().numpy()
     ob = wl.ob
