@@ -122,13 +122,14 @@ prob3_terms_amp_kernel(const Prob3Consts c, const double *__restrict__ energy, i
     for (int q = 0; q < cnt; q++) {
         mat3 A;
         amplitude_from_terms<DECAY>(load, pair_dist[p0 + q] / e, A);
-        double *o = amp + ((int64_t)(side * n_pairs + p0 + q) * 18) * n_e + ie;
+        const int64_t ns = (int64_t)gridDim.z * 64;  // energy stride: whole tiles, cache-line aligned
+        double *o = amp + ((int64_t)(side * n_pairs + p0 + q) * 18) * ns + ie;
 #pragma unroll
         for (int i = 0; i < 3; i++)
 #pragma unroll
             for (int j = 0; j < 3; j++) {
-                o[(int64_t)(6 * i + 2 * j) * n_e] = A.m[i][j].re;
-                o[(int64_t)(6 * i + 2 * j + 1) * n_e] = A.m[i][j].im;
+                o[(int64_t)(6 * i + 2 * j) * ns] = A.m[i][j].re;
+                o[(int64_t)(6 * i + 2 * j + 1) * ns] = A.m[i][j].im;
             }
     }
 }
@@ -156,12 +157,13 @@ prob3_chain_kernel(const Prob3Consts c, int n_e, const int32_t *__restrict__ row
     const int t1 = (int)(((int64_t)cnt * (g + 1)) / CHAIN_GROUPS);
     auto load_A = [&](int t, mat3 &A) {
         const int k = row_pairs[k0 + t];
-        const double *a = amp + ((int64_t)(side * n_pairs + k) * 18) * n_e + ie;
+        const int64_t ns = (int64_t)gridDim.z * 64;
+        const double *a = amp + ((int64_t)(side * n_pairs + k) * 18) * ns + ie;
 #pragma unroll
         for (int i = 0; i < 3; i++)
 #pragma unroll
             for (int j = 0; j < 3; j++)
-                A.m[i][j] = cmake(a[(int64_t)(6 * i + 2 * j) * n_e], a[(int64_t)(6 * i + 2 * j + 1) * n_e]);
+                A.m[i][j] = cmake(a[(int64_t)(6 * i + 2 * j) * ns], a[(int64_t)(6 * i + 2 * j + 1) * ns]);
     };
     mat3 T;
 #pragma unroll
@@ -788,7 +790,7 @@ PISA_API int pisa_hip_prob3_grid_planned(const pisa_hip_prob3_params *h_params,
         if (plan->d_amp) (void)hipFree(plan->d_amp);
         plan->d_amp = nullptr;
         plan->n_e_alloc = 0;
-        size_t amp_bytes = (size_t)2 * (plan->n_pairs > 0 ? plan->n_pairs : 1) * 18 * n_e * sizeof(double);
+        size_t amp_bytes = (size_t)2 * (plan->n_pairs > 0 ? plan->n_pairs : 1) * 18 * (((size_t)n_e + 63) / 64 * 64) * sizeof(double);
         PISA_TRY_HIP(hipMalloc(&plan->d_amp, amp_bytes));
         plan->n_e_alloc = n_e;
     }

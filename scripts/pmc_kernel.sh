@@ -1,0 +1,22 @@
+# usage: pmc_kernel.sh <target.py> <kernel-substring> <tag>   (run on the GPU box)
+cd /tmp && export TMPDIR=/tmp
+export PYTHONPATH=$GRAFT_REPO_ROOT
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$3; rm -rf $OUT; mkdir -p $OUT
+i=0
+for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_BUSY_CU_CYCLES" \
+           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+           "SQ_INST_LEVEL_VMEM SQ_WAVES SQ_LEVEL_WAVES SQ_IFETCH TCP_PENDING_STALL_CYCLES_sum"; do
+  i=$((i+1))
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/p$i -o p -- python3 $GRAFT_REPO_ROOT/$1 > /dev/null 2> $OUT/p$i.log
+done
+python3 - <<PY
+import csv, glob, collections
+for f in sorted(glob.glob("$OUT/p*/p_counter_collection.csv")):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if "$2" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        print(k, "per launch %.4g" % (sum(v) / len(v)), "launches", len(v))
+PY
