@@ -99,13 +99,14 @@ int pisa_hip_prob3_grid(const pisa_hip_prob3_params *h_params, const double *d_e
                         int32_t n_cz, int32_t n_layers, int32_t e_major, double *d_prob_nu,
                         double *d_prob_nubar, double *d_pepmu, void *stream);
 
-/* Two-stage form of the same computation.  A plan is built once per set of
+/* Planned form of the same computation.  A plan is built once per set of
  * layer rows (i.e. at setup, and again only when Ye / tomography parameters
  * change, prob3.py:461-475): it resolves the reference's layer-matrix cache
- * (numba_osc_kernels.py:230-249) per coszen row and lists the distinct shell
- * densities.  Per evaluation, stage A then diagonalises H(E, rho) once per
- * (energy, distinct density) instead of once per node and layer, stage B chains
- * the per-layer amplitudes.  Results are bit identical to pisa_hip_prob3_grid.
+ * (numba_osc_kernels.py:230-249) per coszen row, gives mirrored layers of a row one
+ * matrix and lists the distinct shell densities.  Per evaluation H(E, rho) is then
+ * diagonalised per (energy, distinct density) instead of per node and layer, and
+ * each row's chain is multiplied in parts.  Results equal pisa_hip_prob3_grid to
+ * rounding (<= 1e-13 absolute on the probabilities), not bit for bit.
  * plan_create synchronises (it reads the rows back); the planned call is async. */
 typedef struct pisa_hip_grid_plan pisa_hip_grid_plan;
 int pisa_hip_grid_plan_create(const double *d_densities, const double *d_distances, int32_t n_cz,
@@ -319,7 +320,49 @@ int pisa_hip_metric(int32_t kind, const double *d_actual, const double *d_expect
                     const double *d_sigma2, int32_t n_maps, int64_t n_bins, double *d_per_bin,
                     double *d_total, int32_t *d_status, void *stream);
 
+/* ----------------------------------------------- binned post-histogram stages */
+
+/* d_out[i] = d_x[i] * d_scale[i] * scalar  (d_scale may be NULL = 1), then, if
+ * has_floor, v < floor ? floor : v  (NaN stays NaN, as np.clip / the reference's
+ * apply_floor_gufunc).  d_out may alias d_x.  Used by
+ *   discr_sys.hypersurfaces  weights = clip(weights*hs_scales, 0, inf), errors *= hs_scales
+ *                            (pisa/stages/discr_sys/hypersurfaces.py:236-257)
+ *   utils.set_variance       manual_variance = weights*scale [floored]
+ *                            (pisa/stages/utils/set_variance.py:88-104)
+ *   data.csv_icc_hist        weights = count*atm_muon_scale (pisa/stages/data/csv_icc_hist.py:79-84) */
+int pisa_hip_bin_scale(const double *d_x, const double *d_scale, double scalar, int32_t has_floor,
+                       double floor_value, int64_t n, double *d_out, void *stream);
+/* d_out[i] = sqrt(d_x[i])  (set_variance.py:84-86: errors = sqrt(manual_variance)) */
+int pisa_hip_bin_sqrt(const double *d_x, int64_t n, double *d_out, void *stream);
+
 /* -------------------------------------------------------------------- flux */
+
+/* 2-D (azimuth-averaged) Honda flux table prepared for `pisa_hip_flux_2d`
+ * (host side: scipy splrep exactly as pisa/utils/flux_weights.py:50-131 builds the
+ * integral-preserving band splines).  All pointers are device memory. */
+typedef struct pisa_hip_flux_table {
+    int32_t n_bands;          /* coszen bands of the table (20)                               */
+    int32_t n_knots_e;        /* knots of a band spline in log10(E) (106)                     */
+    const double *d_knots_e;  /* [n_knots_e]                                                  */
+    const double *d_coef_e;   /* [4][n_bands][n_knots_e-4] cubic B-spline coefficients of the
+                                 running integrals; primaries (nue, numu, nuebar, numubar),
+                                 bands in ascending coszen                                   */
+    int32_t n_knots_cz;       /* knots of the coszen spline = n_bands + 1 + 4                 */
+    int32_t enpow;            /* flux_weights.py `enpow` (1)                                  */
+    const double *d_knots_cz; /* [n_knots_cz]                                                 */
+    const double *d_cardinal; /* [n_knots_cz-4][n_bands+1]: coefficients of the interpolating
+                                 cubic splines through the unit vectors at the coszen knots   */
+    double cz_step;           /* 0.1 (flux_weights.py:343)                                    */
+} pisa_hip_flux_table;
+
+/* `calculate_2d_flux_weights` (pisa/utils/flux_weights.py:267-349) for all four
+ * primaries at once, as flux.honda_ip uses it (pisa/stages/flux/honda_ip.py:86-104):
+ * d_nu_flux[n][2] = (nue, numu), d_nubar_flux[n][2] = (nuebar, numubar).
+ * d_status (int32, may be NULL) is set non-zero if a coszen is outside [-1, 1]
+ * (the reference raises ValueError, :318-319). */
+int pisa_hip_flux_2d(const pisa_hip_flux_table *h_table, const double *d_true_energy,
+                     const double *d_true_coszen, int64_t n, double *d_nu_flux,
+                     double *d_nubar_flux, int32_t *d_status, void *stream);
 
 /* `apply_sys_vectorized` (pisa/stages/flux/barr_simple.py:147-233). Flux arrays [n][2]. */
 int pisa_hip_barr_simple(const double *d_true_energy, const double *d_true_coszen,

@@ -327,10 +327,29 @@ def gen_hist():
     save("hist_ref.npz", **out)
 
 
+def gen_flux():
+    """Honda 2-D (azimuth-averaged) table -> nominal fluxes at sample points, by the
+    reference's own integral-preserving spline code (pisa/utils/flux_weights.py:50-131,
+    267-349), incl. points outside the table's energy range and at cz = +-1."""
+    fw = ref_shim.ref_module("pisa.utils.flux_weights")
+    table = "flux/honda-2015-spl-solmin-aa.d"
+    splines = fw.load_2d_table(table)
+    rs = np.random.RandomState(21)
+    n = 400
+    e = 10 ** (rs.rand(n) * 5 - 1)          # 0.1 GeV .. 10 TeV
+    cz = rs.rand(n) * 2 - 1
+    e[:6] = [0.05, 0.09, 0.1, 1.0e4, 1.2e4, 3.0e4]   # below / at / above the table range
+    cz[6:12] = [-1.0, 1.0, -0.95, 0.95, 0.0, -0.9]
+    out = dict(table=np.array(table), true_energy=e, true_coszen=cz)
+    for prim in ("nue", "numu", "nuebar", "numubar"):
+        out[prim] = fw.calculate_2d_flux_weights(e, cz, splines[prim])
+    save("flux_ref.npz", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["pickles", "layers", "params", "lookup", "stats", "barr", "hist", "grid"]
+    which = sys.argv[1:] or ["pickles", "layers", "params", "lookup", "stats", "barr", "hist", "grid", "flux"]
     fns = dict(pickles=gen_ref_pickles, layers=gen_layers, params=gen_params, lookup=gen_lookup,
-               stats=gen_stats, barr=gen_barr, hist=gen_hist, grid=gen_grid)
+               stats=gen_stats, barr=gen_barr, hist=gen_hist, grid=gen_grid, flux=gen_flux)
     for w in which:
         fns[w]()

@@ -12,7 +12,8 @@ What becomes importable:
   pisa.utils.numba_tools, pisa.stages.osc.prob3numba.numba_osc_kernels,
   pisa.stages.osc.layers, osc_params, nsi_params, decay_params, lri_params,
   pisa.stages.flux.barr_simple (+ utils.barr_parameterization),
-  pisa.core.translation (lookup_* / find_index bodies), pisa.utils.stats.
+  pisa.core.translation (lookup_* / find_index bodies), pisa.utils.stats,
+  pisa.utils.flux_weights (scipy/FITPACK splines; load_2d_table, calculate_2d_flux_weights).
 """
 import importlib
 import logging as _logging
@@ -146,6 +147,14 @@ def install():
         return np.loadtxt(path)
 
     _mod("pisa.utils.fileio", from_file=from_file)
+
+    def find_resource(fname, fail=True):
+        return fname if os.path.isabs(fname) else os.path.join(REF_RESOURCES, fname)
+
+    def open_resource(fname, mode="r"):
+        return open(find_resource(fname), mode)
+
+    _mod("pisa.utils.resources", find_resource=find_resource, open_resource=open_resource)
     _mod("pisa.utils.profiler", profile=lambda f: f, line_profile=lambda f: f)
     _mod("pisa.utils.likelihood_functions")
 

@@ -89,6 +89,20 @@ class Container(C.Structure):
     ]
 
 
+class FluxTable(C.Structure):
+    _fields_ = [
+        ("n_bands", C.c_int32),
+        ("n_knots_e", C.c_int32),
+        ("d_knots_e", C.c_void_p),
+        ("d_coef_e", C.c_void_p),
+        ("n_knots_cz", C.c_int32),
+        ("enpow", C.c_int32),
+        ("d_knots_cz", C.c_void_p),
+        ("d_cardinal", C.c_void_p),
+        ("cz_step", C.c_double),
+    ]
+
+
 _SIGS = {
     "pisa_hip_strerror": (C.c_char_p, [C.c_int]),
     "pisa_hip_last_hip_error": (C.c_char_p, []),
@@ -116,6 +130,9 @@ _SIGS = {
     "pisa_hip_hist_finalize": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pisa_hip_kde_eval": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pisa_hip_metric": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pisa_hip_bin_scale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_int32, C.c_double, C.c_int64, C.c_void_p, C.c_void_p]),
+    "pisa_hip_bin_sqrt": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "pisa_hip_flux_2d": (C.c_int, [C.POINTER(FluxTable), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pisa_hip_barr_simple": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_void_p, C.c_void_p]),
     "pisa_hip_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_int64]),
     "pisa_hip_free": (C.c_int, [C.c_void_p]),

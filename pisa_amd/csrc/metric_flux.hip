@@ -58,6 +58,28 @@ metric_kernel(int kind, const double *__restrict__ actual, const double *__restr
     }
 }
 
+// ------------------------------------------------ binned post-histogram stages
+// out = x * scale[i] * scalar, optionally floored (`v < floor ? floor : v`, so NaN
+// stays NaN like np.clip / apply_floor_gufunc): hypersurfaces.py:243-257,
+// set_variance.py:88-104, csv_icc_hist.py:83
+__global__ void __launch_bounds__(256)
+bin_scale_kernel(const double *__restrict__ x, const double *__restrict__ scale, double scalar,
+                 int has_floor, double floor_, int64_t n, double *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double v = x[i];
+    if (scale) v = v * scale[i];
+    v = v * scalar;
+    if (has_floor) v = v < floor_ ? floor_ : v;
+    out[i] = v;
+}
+
+__global__ void __launch_bounds__(256)
+bin_sqrt_kernel(const double *__restrict__ x, int64_t n, double *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = sqrt(x[i]);  // set_variance.py:84-86
+}
+
 // ------------------------------------------------------- Barr flux systematics
 // pisa/utils/barr_parameterization.py:17-113
 __device__ __forceinline__ double sign_(double v) {
@@ -180,5 +202,28 @@ PISA_API int pisa_hip_barr_simple(const double *d_true_energy, const double *d_t
                        nue_numu_ratio, nu_nubar_ratio, delta_index, Barr_uphor_ratio,
                        Barr_nu_nubar_ratio, n, d_out);
     PISA_CHECK_LAUNCH("barr_simple_kernel");
+    return PISA_HIP_OK;
+}
+
+PISA_API int pisa_hip_bin_scale(const double *d_x, const double *d_scale, double scalar,
+                                int32_t has_floor, double floor_value, int64_t n, double *d_out,
+                                void *stream) {
+    if (n < 0) return PISA_HIP_ERR_INVALID;
+    if (n == 0) return PISA_HIP_OK;
+    if (!d_x || !d_out) return PISA_HIP_ERR_INVALID;
+    dim3 block(256), grid((unsigned)((n + 255) / 256));
+    hipLaunchKernelGGL(bin_scale_kernel, grid, block, 0, as_stream(stream), d_x, d_scale, scalar,
+                       (int)has_floor, floor_value, n, d_out);
+    PISA_CHECK_LAUNCH("bin_scale_kernel");
+    return PISA_HIP_OK;
+}
+
+PISA_API int pisa_hip_bin_sqrt(const double *d_x, int64_t n, double *d_out, void *stream) {
+    if (n < 0) return PISA_HIP_ERR_INVALID;
+    if (n == 0) return PISA_HIP_OK;
+    if (!d_x || !d_out) return PISA_HIP_ERR_INVALID;
+    dim3 block(256), grid((unsigned)((n + 255) / 256));
+    hipLaunchKernelGGL(bin_sqrt_kernel, grid, block, 0, as_stream(stream), d_x, n, d_out);
+    PISA_CHECK_LAUNCH("bin_sqrt_kernel");
     return PISA_HIP_OK;
 }

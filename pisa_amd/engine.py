@@ -251,6 +251,7 @@ class HotPathEngine:
         self.metric_host = torch.zeros(1, dtype=torch.float64).pin_memory()
         self.fused_tail = True
         self._limbs_zero = self._maps_valid = False
+        self._lean = None
         self.data = None
 
     def _up(self, a):
@@ -337,12 +338,59 @@ class HotPathEngine:
     def eval_host(self, params, kind="llh"):
         """`eval` for a fit loop that needs the number on the host: the tail kernel
         writes the metric into pinned, device-mapped host memory, so the host only
-        waits for the stream (no device->host copy operation).  Returns a float."""
-        self.accumulate(params)
-        self.allreduce()
-        self._tail(kind, self.metric_host)
+        waits for the stream (no device->host copy operation).  Returns a float.
+
+        For the standard shape (planned grid, packed columns, fused tail) the four
+        launches go through `_lean_eval`: the same C-ABI calls as the generic
+        methods, minus their per-call Python (tensor -> pointer conversions,
+        contiguity asserts, keyword handling) -- this sits between the LLH
+        read-back and the first kernel of the next point."""
+        if (self.plan is not None and self.indexed and not self.osc_events and self.fused_tail
+                and self.data is not None
+                and len(self.cont) * self.n_bins <= K.FINALIZE_METRIC_MAX):
+            self._lean_eval(params, kind)
+        else:
+            self.accumulate(params)
+            self.allreduce()
+            self._tail(kind, self.metric_host)
         torch.cuda.current_stream().synchronize()
         return float(self.metric_host[0])
+
+    def _lean_eval(self, params, kind):
+        import ctypes as C
+
+        a = self._lean
+        tabs = (self.prob_nu, self.prob_nubar, self.pepmu)
+        if a is None or a["tabs"] is not tabs[2]:
+            lib = _lib.lib()
+            a = self._lean = dict(
+                tabs=self.pepmu, lib=lib, cont=self._cont_arr, n_cont=len(self._cont_arr),
+                plan=self.plan.handle, energy=C.c_void_p(self.energy_d.data_ptr()),
+                n_e=self.energy_d.numel(), e_major=1 if self.grid.energy_first else 0,
+                nu=C.c_void_p(self.prob_nu.data_ptr()), nubar=C.c_void_p(self.prob_nubar.data_ptr()),
+                pepmu=C.c_void_p(self.pepmu.data_ptr()), grid=C.byref(self.grid.binning),
+                outb=C.byref(self.out_binning), limbs=C.c_void_p(self.ws.limbs.data_ptr()),
+                status=C.c_void_p(self.ws.status.data_ptr()), hist=C.c_void_p(self.ws.hist.data_ptr()),
+                sumw2=C.c_void_p(self.ws.sumw2.data_ptr()), data=C.c_void_p(self.data.data_ptr()),
+                data_t=self.data, out=C.c_void_p(self.metric_host.data_ptr()),
+                mstatus=C.c_void_p(self.metric_status.data_ptr()))
+        if a["data_t"] is not self.data:  # new pseudo-data
+            a["data"], a["data_t"] = C.c_void_p(self.data.data_ptr()), self.data
+        lib, s = a["lib"], K._stream()
+        rc = lib.pisa_hip_prob3_grid_planned(C.byref(params), a["plan"], a["energy"], a["n_e"],
+                                             a["e_major"], a["nu"], a["nubar"], a["pepmu"], s)
+        if rc == 0:
+            fn = lib.pisa_hip_reweight_hist_acc if self._limbs_zero else lib.pisa_hip_reweight_hist
+            rc = fn(a["cont"], a["n_cont"], a["grid"], a["nu"], a["nubar"], a["pepmu"], a["outb"],
+                    a["limbs"], a["status"], s)
+        self._limbs_zero = self._maps_valid = False
+        if rc == 0:
+            self.allreduce()
+            rc = lib.pisa_hip_finalize_metric(a["limbs"], a["n_cont"], self.n_bins, a["hist"],
+                                              a["sumw2"], K.METRIC_KIND[kind], a["data"], a["out"],
+                                              a["status"], a["mstatus"], 1, s)
+            self._limbs_zero = self._maps_valid = rc == 0
+        _lib.check(rc)
 
     def eval_batch(self, params_list, kind="llh"):
         """Several INDEPENDENT parameter points (e.g. the 2n+1 points of a

@@ -111,7 +111,7 @@ class GridPlan:
 
 def prob3_grid_planned(params, plan, energy, e_major=True, out_nu=None, out_nubar=None,
                        out_pepmu=None):
-    """Two-stage grid evaluation (bit identical to `prob3_grid`)."""
+    """Planned grid evaluation (equal to `prob3_grid` to rounding, see csrc/prob3.hip)."""
     lib = _lib.lib()
     n_e = energy.numel()
     n = n_e * plan.n_cz
@@ -327,6 +327,43 @@ def metric(kind, actual, expected, sigma2=None, per_bin=False, total_out=None, s
         if st != 0:
             _lib.check(st)
     return (total_out, pb) if per_bin else total_out
+
+
+def bin_scale(x, scale=None, scalar=1.0, floor=None, out=None):
+    """out = x * scale * scalar [floored]; see `pisa_hip_bin_scale`."""
+    lib = _lib.lib()
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(lib.pisa_hip_bin_scale(_ptr(x), _ptr(scale), float(scalar), 0 if floor is None else 1,
+                                      0.0 if floor is None else float(floor), x.numel(), _ptr(out),
+                                      _stream()))
+    return out
+
+
+def bin_sqrt(x, out=None):
+    lib = _lib.lib()
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(lib.pisa_hip_bin_sqrt(_ptr(x), x.numel(), _ptr(out), _stream()))
+    return out
+
+
+def flux_2d(table, true_energy, true_coszen, out_nu=None, out_nubar=None):
+    """`calculate_2d_flux_weights` (flux_weights.py:267-349) for (nue, numu) and
+    (nuebar, numubar) at once; `table` is a `pisa_amd.utils.flux_weights.FluxTable2D`."""
+    lib = _lib.lib()
+    n = true_energy.numel()
+    dev = true_energy.device
+    if out_nu is None:
+        out_nu = torch.empty((n, 2), dtype=F8, device=dev)
+    if out_nubar is None:
+        out_nubar = torch.empty((n, 2), dtype=F8, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(lib.pisa_hip_flux_2d(C.byref(table.struct), _ptr(true_energy), _ptr(true_coszen), n,
+                                    _ptr(out_nu), _ptr(out_nubar), _ptr(status), _stream()))
+    if int(status.item()) != 0:
+        raise ValueError("Not all coszens found between -1 and 1")  # flux_weights.py:318-319
+    return out_nu, out_nubar
 
 
 def barr_simple(true_energy, true_coszen, nu_flux_nominal, nubar_flux_nominal, nubar,

@@ -1,0 +1,26 @@
+"""Freeze the errors at the values of the last recompute (counterpart of
+pisa/stages/utils/fix_error.py:13-55)."""
+import numpy as np
+
+from pisa_amd import FTYPE
+from pisa_amd.core.stage import Stage
+
+__all__ = ["fix_error"]
+
+
+class fix_error(Stage):  # pylint: disable=invalid-name
+    def __init__(self, **std_kwargs):
+        super().__init__(expected_params=(), expected_container_keys=("errors",), **std_kwargs)
+
+    def setup_function(self):
+        for container in self.data:
+            container["frozen_errors"] = np.empty(container.size, dtype=FTYPE)
+
+    def compute_function(self):
+        for container in self.data:
+            container["frozen_errors"] = container.device("errors").clone()
+            container.mark_valid("frozen_errors")
+
+    def apply_function(self):
+        for container in self.data:
+            container["errors"] = container.device("frozen_errors").clone()

@@ -258,3 +258,22 @@ def test_reweight_order_of_operations(oracle):
     w *= (flux[:, 0] * pe) + (flux[:, 1] * pmu)  # prob3.py:622
     w *= aeff * 3.7  # aeff.py:87
     np.testing.assert_array_equal(oracle.reweight(w0, flux, pe, pmu, aeff, 3.7), w)
+
+
+def test_flux_oracle_reproduces_reference_honda_fluxes():
+    """oracle/flux_oracle.py vs values computed by the reference's own
+    pisa/utils/flux_weights.py (oracle/gen_golden.py:gen_flux), bit for bit"""
+    from oracle import flux_oracle
+    from pisa_amd.utils.resources import find_resource
+
+    g = load_golden("flux_ref.npz")
+    splines = flux_oracle.load_2d_honda_table(find_resource(str(g["table"])))
+    for prim in ("nue", "numu", "nuebar", "numubar"):
+        got = flux_oracle.calculate_2d_flux_weights(g["true_energy"], g["true_coszen"], splines[prim])
+        np.testing.assert_array_equal(got, g[prim])
+    # grid form == per-point form
+    e, cz = g["true_energy"][20:24], np.sort(g["true_coszen"][30:40])
+    grid = flux_oracle.grid_flux(e, cz, splines["numu"])
+    for i in range(len(e)):
+        np.testing.assert_array_equal(
+            grid[i], flux_oracle.calculate_2d_flux_weights(np.full(len(cz), e[i]), cz, splines["numu"]))
