@@ -127,3 +127,32 @@ def test_neutrino_cfg_unmodified_vs_oracle(oracle, tmp_path, monkeypatch):
         np.testing.assert_allclose(m.hist.ravel(), want_w, rtol=1e-10, atol=1e-300, err_msg=m.name)
         np.testing.assert_allclose(m.std_devs.ravel(), want_e, rtol=1e-10, atol=1e-300, err_msg=m.name)
     assert sum(m.hist.sum() for m in maps) > 0
+
+
+def test_published_analysis_template_and_metrics(oracle, tmp_path, monkeypatch):
+    """neutrinos + muons DistributionMaker against the released data histogram
+    (the published 3-year analysis setup): total template = sum of the 13 maps with
+    variances added (distribution_maker.py:274-281, map.py:1811-1838), mod_chi2 / llh
+    against the data == oracle metrics of the same arrays"""
+    from pisa_amd.core.distribution_maker import DistributionMaker
+    from pisa_amd.core.pipeline import Pipeline
+
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "make_synthetic_3y_mc.py"),
+                           str(tmp_path), "24000", "7"])
+    monkeypatch.setenv("PISA_RESOURCES", str(tmp_path))
+    template = DistributionMaker(["settings/pipeline/IceCube_3y_neutrinos.cfg",
+                                  "settings/pipeline/IceCube_3y_muons.cfg"])
+    parts = template.get_outputs()
+    assert [len(ms) for ms in parts] == [12, 1]
+    total = template.get_outputs(return_sum=True)[0]
+    want = sum(m.hist for ms in parts for m in ms)
+    want_var = sum(m.std_devs ** 2 for ms in parts for m in ms)
+    np.testing.assert_allclose(total.hist, want, rtol=1e-13)
+    np.testing.assert_allclose(total.std_devs ** 2, want_var, rtol=1e-12)
+    # scale the synthetic MC to the size of the data so that the metrics are meaningful
+    data = Pipeline("settings/pipeline/IceCube_3y_data.cfg").get_outputs()[0]
+    assert data.hist.sum() > 1e4
+    for kind in ("mod_chi2", "llh", "chi2"):
+        got = data.metric_total(expected_values=total, metric=kind)
+        _, ref = oracle.metric(kind, data.hist.ravel(), total.hist.ravel(), (total.std_devs ** 2).ravel())
+        np.testing.assert_allclose(got, ref, rtol=1e-10, err_msg=kind)
