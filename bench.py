@@ -46,6 +46,11 @@ def parse():
                     help="bin event coordinates on the fly (72 B/event) instead of the pre-digitised "
                          "index columns (40 B/event)")
     ap.add_argument("--cpu-sample-events", type=float, default=2.4e6)
+    ap.add_argument("--weak-scaling", action="store_true",
+                    help="N > 1: every rank holds --events events of its own (seed = rank) instead of a "
+                         "1/N shard of one sample; `value` then counts evaluations of --events-sized units "
+                         "(N per step).  Default is strong scaling of ONE fixed sample, as BASELINE.json's "
+                         "metric is worded.")
     ap.add_argument("--event-order", default="auto", choices=["auto", "node", "bin"],
                     help="resident event order: sorted by calc-grid node, or by (output bin, node)")
     return ap.parse_args()
@@ -145,10 +150,14 @@ def main():
     from pisa_amd import _lib, synthetic
 
     n_e, n_cz = (int(v) for v in args.grid.split("x"))
+    weak = args.weak_scaling and world > 1
     wl = synthetic.Workload(n_events=int(args.events), grid=(n_e, n_cz), out_binning=args.binning,
-                            seed=0)
-    st = synthetic.DeviceState(wl, rank=rank, world_size=world, indexed=not args.coordinate_form,
+                            seed=rank if weak else 0)
+    st = synthetic.DeviceState(wl, rank=0 if weak else rank, world_size=1 if weak else world,
+                               indexed=not args.coordinate_form,
                                sort_events=True if args.event_order == "auto" else args.event_order)
+    if weak:
+        st.world_size = world  # whole local sample per rank; the limb all-reduce still spans all ranks
     nominal = wl.osc_params()
     st.make_pseudo_data(nominal, seed=0)
     plist = param_list(wl, args.warmup + args.steps)
@@ -242,16 +251,17 @@ def main():
 
     if rank == 0:
         evals_per_s = args.steps / dt
+        units = world if weak else 1  # weak scaling: one step evaluates `world` samples of --events events
         out = {
             "metric": "pipeline evals/sec (osc+reweight+hist+LLH) on 1e7 MC events",
-            "value": evals_per_s,
+            "value": evals_per_s * units,
             "unit": "evals/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "weak" if weak else "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic (toy_event_generator-style E/coszen, builder-defined reco/flux/aeff; see pisa_amd/synthetic.py)",
@@ -263,9 +273,10 @@ def main():
                 "events": wl.n_events,
                 "calc_grid": [n_e, n_cz],
                 "out_bins": wl.ob["nbins"],
-                "parallelism": "events sharded over %d GPU(s), int64 limb all-reduce" % world,
+                "parallelism": ("%d GPU(s) x %d events each, int64 limb all-reduce" % (world, wl.n_events)) if weak
+                               else "events sharded over %d GPU(s), int64 limb all-reduce" % world,
             },
-            "event_evals_per_s": evals_per_s * wl.n_events,
+            "event_evals_per_s": evals_per_s * wl.n_events * units,
             "last_llh": llh,
             "pipelined_evals_per_s": pipelined,
             "phase_ms": {"prob3_grid": t_prob3, "fused_reweight_hist": 1e3 * fused_avg_s,
@@ -280,7 +291,7 @@ def main():
                 "bytes_per_event": bytes_per_event,
                 "events_per_launch": st.n_local,
                 "avg_launch_ms": 1e3 * fused_avg_s,
-                "traffic": pmc_traffic(args),
+                "traffic": pmc_traffic(args) if world == 1 else None,
             },
         }
         if not args.no_cpu_baseline and world == 1:
