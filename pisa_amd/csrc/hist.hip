@@ -165,6 +165,27 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
     unsigned long long *g_out = g_limbs + (int64_t)(a.cont_base + c) * a.n_bins * 2 * NL;
     int bin_lo = 0;
 
+    // MODE 3 sweep order: the workgroups of a container advance through its columns
+    // TOGETHER (workgroup j takes pairs j*T + t, stepping by n_wg*T), so that at any
+    // moment the chip reads a few contiguous windows of HBM; the LDS window of a large
+    // binning needs bin-contiguous chunks and keeps them.  The loads of the first sweep
+    // are issued here, before the LDS accumulators are cleared, so that the clearing
+    // overlaps the first HBM round trip.
+    const bool together = a.window == 0;
+    const int64_t n_wg = a.blk_start[c + 1] - a.blk_start[c];
+    const int64_t step = together ? n_wg * nthreads : nthreads;
+    const int64_t p_end = together ? (C.n >> 1) : (end >> 1);
+    int64_t p = (together ? lb * nthreads : (start >> 1)) + threadIdx.x;
+    bool have = p < p_end;
+    int4 ix = make_int4(-1, -1, -1, -1);  // node0, bin0, node1, bin1
+    double2 awa = make_double2(0.0, 0.0), awb = awa, fa = awa, fb = awa;
+    if (MODE == 3 && have) {
+        ix = reinterpret_cast<const int4 *>(C.node_bin)[p];
+        awa = C.aeff_w0[2 * p]; awb = C.aeff_w0[2 * p + 1];
+        fa = reinterpret_cast<const double2 *>(C.flux)[2 * p];
+        fb = reinterpret_cast<const double2 *>(C.flux)[2 * p + 1];
+    }
+
     if (LDS_ACC) {
         for (int k = threadIdx.x; k < n_acc * a.copies; k += nthreads) s_acc[k] = 0.0;
         if (MODE == 3 && a.window > 0) {
@@ -215,7 +236,6 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
         const double2 *tab = C.pepmu_own ? C.pepmu_own
                                          : a.pepmu + ((int64_t)C.side * 3 + C.flav) * a.n_nodes;
         const double scale = C.scale;
-        const int64_t p0 = start >> 1, p1 = end >> 1;
         const int4 *idx4 = reinterpret_cast<const int4 *>(C.node_bin);
         const double2 *aw = C.aeff_w0;
         const double2 *flux2 = reinterpret_cast<const double2 *>(C.flux);
@@ -224,21 +244,13 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
         // gathers of the current pair before them, so a wave always has a full
         // iteration of HBM requests in flight (a thread only runs ~6-10 iterations;
         // without this the idx -> gather -> use chain is exposed every time).
-        int64_t p = p0 + threadIdx.x;
-        bool have = p < p1;
-        int4 ix = make_int4(-1, -1, -1, -1);  // node0, bin0, node1, bin1
-        double2 awa = make_double2(0.0, 0.0), awb = awa, fa = awa, fb = awa;
-        if (have) {
-            ix = idx4[p];
-            awa = aw[2 * p]; awb = aw[2 * p + 1];
-            fa = flux2[2 * p]; fb = flux2[2 * p + 1];
-        }
         while (have) {
             // node < 0 (outside the calc grid): read entry 0, then force P = 0
-            double2 pa = tab[ix.x < 0 ? 0 : ix.x];
-            double2 pb = tab[ix.z < 0 ? 0 : ix.z];
-            const int64_t pn = p + nthreads;
-            const bool have_n = pn < p1;
+            const int gmask = (a.dbg & 8) ? 0 : -1;  // probe: all gathers hit entry 0
+            double2 pa = tab[(ix.x < 0 ? 0 : ix.x) & gmask];
+            double2 pb = tab[(ix.z < 0 ? 0 : ix.z) & gmask];
+            const int64_t pn = p + step;
+            const bool have_n = pn < p_end;
             // unconditional (the last sweep re-reads its own pair, never used): a
             // branch here would make the compiler wait for these loads as well
             const int64_t pl = have_n ? pn : p;
@@ -541,7 +553,7 @@ static int plan_blocks(const int64_t *n_events, int n_cont, int threads, int64_t
     int64_t total = 0;
     for (int c = 0; c < n_cont; c++) total += n_events[c];
     // a few workgroups per CU; a chunk is a whole number of two-event sweeps
-    const int64_t target_blocks = env_int("PISA_HIP_HIST_BLOCKS", 768);
+    const int64_t target_blocks = env_int("PISA_HIP_HIST_BLOCKS", 512);
     chunk = (total + target_blocks - 1) / target_blocks;
     if (chunk < 4096) chunk = 4096;
     if (chunk > (1 << 18)) chunk = 1 << 18;  // keeps every slab accumulator exact (< 2^53 units)

@@ -16,7 +16,7 @@ plist = [wl.osc_params(theta23_deg=40 + 10 * rs.rand()) for _ in range(30)]
 for order in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("node", "bin")):
     st = synthetic.DeviceState(wl, sort_events=order)
     st.make_pseudo_data(wl.osc_params(), seed=0)
-    for dbg in ("0", "2"):
+    for dbg in (sys.argv[3].split(",") if len(sys.argv) > 3 else ("0", "2")):
         os.environ["PISA_HIP_HIST_DBG"] = dbg
         for p in plist[:5]:
             st.eval(p, "llh")
