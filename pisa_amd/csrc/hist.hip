@@ -64,6 +64,22 @@ __device__ __forceinline__ bool deposit(double x, F &&add) {
     return true;
 }
 
+// 16-byte streaming loads, optionally with the non-temporal hint (PISA_HIP_HIST_DBG=16).
+// Measured A/B in one session: nt makes this kernel 5 us SLOWER (92.3 vs 87.4 us) and leaves
+// the whole evaluation unchanged, so plain loads are the default.
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double2 ld_stream(const double2 *p, bool nt) {
+    if (!nt) return *p;
+    const v2d_t v = __builtin_nontemporal_load(reinterpret_cast<const v2d_t *>(p));
+    return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ int4 ld_stream(const int4 *p, bool nt) {
+    if (!nt) return *p;
+    const v4i_t v = __builtin_nontemporal_load(reinterpret_cast<const v4i_t *>(p));
+    return make_int4(v.x, v.y, v.z, v.w);
+}
+
 // slab accumulator (multiple of 2^(32j-116), |v| < 2^53 units) -> int64 units
 __device__ __forceinline__ long long slab_to_units(double v, int j) {
     const int e = -(32 * j - FX_LSB) + 1023;  // 2^-(32j-116)
@@ -180,10 +196,11 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
     int4 ix = make_int4(-1, -1, -1, -1);  // node0, bin0, node1, bin1
     double2 awa = make_double2(0.0, 0.0), awb = awa, fa = awa, fb = awa;
     if (MODE == 3 && have) {
-        ix = reinterpret_cast<const int4 *>(C.node_bin)[p];
-        awa = C.aeff_w0[2 * p]; awb = C.aeff_w0[2 * p + 1];
-        fa = reinterpret_cast<const double2 *>(C.flux)[2 * p];
-        fb = reinterpret_cast<const double2 *>(C.flux)[2 * p + 1];
+        const bool nt0 = (a.dbg & 16) != 0;
+        ix = ld_stream(reinterpret_cast<const int4 *>(C.node_bin) + p, nt0);
+        awa = ld_stream(C.aeff_w0 + 2 * p, nt0); awb = ld_stream(C.aeff_w0 + 2 * p + 1, nt0);
+        fa = ld_stream(reinterpret_cast<const double2 *>(C.flux) + 2 * p, nt0);
+        fb = ld_stream(reinterpret_cast<const double2 *>(C.flux) + 2 * p + 1, nt0);
     }
 
     if (LDS_ACC) {
@@ -254,9 +271,10 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
             // unconditional (the last sweep re-reads its own pair, never used): a
             // branch here would make the compiler wait for these loads as well
             const int64_t pl = have_n ? pn : p;
-            const int4 ixn = idx4[pl];
-            const double2 awan = aw[2 * pl], awbn = aw[2 * pl + 1];
-            const double2 fan = flux2[2 * pl], fbn = flux2[2 * pl + 1];
+            const bool nt = (a.dbg & 16) != 0;  // probe: non-temporal loads
+            const int4 ixn = ld_stream(idx4 + pl, nt);
+            const double2 awan = ld_stream(aw + 2 * pl, nt), awbn = ld_stream(aw + 2 * pl + 1, nt);
+            const double2 fan = ld_stream(flux2 + 2 * pl, nt), fbn = ld_stream(flux2 + 2 * pl + 1, nt);
             if (ix.x < 0) pa = make_double2(0.0, 0.0);
             if (ix.z < 0) pb = make_double2(0.0, 0.0);
             // branch-free on purpose (an event outside the binning deposits w = 0,
