@@ -400,7 +400,9 @@ prob3_events_kernel(const Prob3Consts c, const EarthDev earth, const EvArgs ev, 
         rho = s_rhos[s_shell[(size_t)l * bd + lane]] * (dist > 0. ? 1.0 : 0.0);
     };
     double P[9];
-    propagate_element<DECAY>(c.side[side], c.dm, energy[i], nseg, layer, P);
+    // through-going paths: in 0..m-2, innermost m-1, out m..2m-3 (path_segment)
+    propagate_path_nested<DECAY>(c.side[side], c.dm, energy[i], nseg,
+                                 (ok && !g.tangent_free) ? g.m - 1 : -1, layer, P);
     if (prob) {
 #pragma unroll
         for (int k = 0; k < 9; k++) prob[9 * i + k] = P[k];

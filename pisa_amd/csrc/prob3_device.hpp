@@ -138,8 +138,34 @@ inline void prob3_make_consts(const double *dm, const double *mix, const double 
 // get_dms (numba_osc_kernels.py:687-831): real eigenvalues of the Hermitian
 // H_full via the trigonometric cubic solution, re-ordered to follow the vacuum
 // ordering.  M[k] = 2E * lambda_k.
-__device__ __forceinline__ void get_dms(double energy, const mat3 &H, const double (&dm)[3][3],
-                                        double (&M)[3]) {
+// vacuum half of get_dms: eigenvalues of the vacuum Hamiltonian, used only to ORDER the
+// matter eigenvalues (:816-825).  Depends on the energy alone, so a kernel that walks many
+// layers at one energy (event mode) evaluates it once.
+__device__ __forceinline__ void get_dms_vacuum(double energy, const double (&dm)[3][3],
+                                               double (&mv)[3]) {
+    double one_over_two_e = 0.5 / energy;
+    const double one_third = 1.0 / 3.0;
+    const double two_third = 2.0 / 3.0;
+    double x = dm[1][0];
+    double y = dm[2][0];
+    double c2_v = -one_over_two_e * (x + y);
+    double p_v = (one_over_two_e * one_over_two_e) * (x * x + y * y - x * y);
+    double q_v = (one_over_two_e * (one_over_two_e * one_over_two_e)) * (x + y) *
+                 ((x + y) * (x + y) - 4.5 * x * y);
+    double tmp_v = p_v * (p_v * p_v) - q_v * q_v;
+    const double a = two_third * 3.14159265358979323846;
+    double res_v = atan2(sqrt(tmp_v), q_v) * one_third;
+    double b_v = two_third * sqrt(p_v);
+    double thv[3] = {res_v + a, res_v - a, res_v};
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+        mv[i] = 2.0 * energy * (b_v * cos(thv[i]) - c2_v * one_third + dm[0][0]);
+}
+
+// matter half of get_dms, given the vacuum eigenvalues
+__device__ __forceinline__ void get_dms_matter(double energy, const mat3 &H,
+                                               const double (&dm)[3][3], const double (&mv)[3],
+                                               double (&M)[3]) {
     const cplx h01 = H.m[0][1], h12 = H.m[1][2], h20 = H.m[2][0];
     const cplx h00 = H.m[0][0], h11 = H.m[1][1], h22 = H.m[2][2], h02 = H.m[0][2];
     double real_product_a = cmul(cmul(h01, h12), h20).re;
@@ -154,35 +180,21 @@ __device__ __forceinline__ void get_dms(double energy, const mat3 &H, const doub
                 real_product_b;
     double c2 = -h00.re - h11.re - h22.re;
 
-    double one_over_two_e = 0.5 / energy;
     const double one_third = 1.0 / 3.0;
     const double two_third = 2.0 / 3.0;
-    double x = dm[1][0];
-    double y = dm[2][0];
-    double c2_v = -one_over_two_e * (x + y);
     double p = c2 * c2 - 3.0 * c1;
-    double p_v = (one_over_two_e * one_over_two_e) * (x * x + y * y - x * y);
     p = fmax(0.0, p);
     double q = -13.5 * c0 - c2 * (c2 * c2) + 4.5 * c1 * c2;
-    double q_v = (one_over_two_e * (one_over_two_e * one_over_two_e)) * (x + y) *
-                 ((x + y) * (x + y) - 4.5 * x * y);
     double tmp = 27 * (0.25 * (c1 * c1) * (p - c1) + c0 * (q + 6.75 * c0));
-    double tmp_v = p_v * (p_v * p_v) - q_v * q_v;
     tmp = fmax(0.0, tmp);
 
     const double a = two_third * 3.14159265358979323846;
     double res = atan2(sqrt(tmp), q) * one_third;
-    double res_v = atan2(sqrt(tmp_v), q_v) * one_third;
     double b = two_third * sqrt(p);
-    double b_v = two_third * sqrt(p_v);
     double th[3] = {res + a, res - a, res};
-    double thv[3] = {res_v + a, res_v - a, res_v};
-    double mu[3], mv[3];
+    double mu[3];
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
-        mu[i] = 2.0 * energy * (b * cos(th[i]) - c2 * one_third + dm[0][0]);
-        mv[i] = 2.0 * energy * (b_v * cos(thv[i]) - c2_v * one_third + dm[0][0]);
-    }
+    for (int i = 0; i < 3; i++) mu[i] = 2.0 * energy * (b * cos(th[i]) - c2 * one_third + dm[0][0]);
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         double best = fabs(dm[i][0] - mv[0]);
@@ -196,6 +208,13 @@ __device__ __forceinline__ void get_dms(double energy, const mat3 &H, const doub
         }
         M[i] = sel;
     }
+}
+
+__device__ __forceinline__ void get_dms(double energy, const mat3 &H, const double (&dm)[3][3],
+                                        double (&M)[3]) {
+    double mv[3];
+    get_dms_vacuum(energy, dm, mv);
+    get_dms_matter(energy, H, dm, mv, M);
 }
 
 // Complex helpers for the decay branch (general complex 3x3 eigenvalues;
@@ -280,10 +299,15 @@ __device__ inline void eigvals3_general(const mat3 &H, cplx (&lam)[3]) {
 // get_transition_matrix_massbasis (:481-531) and get_product (:834-872) fused:
 // returns A (mass basis) for a layer of electron density rho and length
 // baseline.  DECAY selects the complex-eigenvalue branch at compile time.
-template <bool DECAY>
+//
+// FAST (event-mode kernel): the caller passes the vacuum eigenvalues it computed once
+// for this energy (`get_dms_vacuum`; identical values, just not recomputed per layer) and
+// the 54 divisions by the three real denominators become multiplications by their
+// reciprocals (<= 1 ulp per quotient).
+template <bool DECAY, bool FAST = false>
 __device__ __forceinline__ void layer_amplitude(const Prob3Side &S, const double (&dm)[3][3],
                                                 double energy, double rho, double baseline,
-                                                mat3 &A) {
+                                                mat3 &A, const double *vacuum_dms = nullptr) {
     // get_H_mat (:605-653) + LRI (:435-440)
     const double tworttwoGf = 1.52588e-4;
     double a = 0.5 * rho * tworttwoGf;
@@ -314,7 +338,12 @@ __device__ __forceinline__ void layer_amplitude(const Prob3Side &S, const double
 
     if (!DECAY) {
         double M[3];
-        get_dms(energy, Hf, dm, M);
+        if (FAST) {
+            const double mv[3] = {vacuum_dms[0], vacuum_dms[1], vacuum_dms[2]};
+            get_dms_matter(energy, Hf, dm, mv, M);
+        } else {
+            get_dms(energy, Hf, dm, M);
+        }
         // phases exp(-i M_k L/E 2.534)
         cplx ph[3];
 #pragma unroll
@@ -328,6 +357,8 @@ __device__ __forceinline__ void layer_amplitude(const Prob3Side &S, const double
         double den0 = (M[0] - M[1]) * (M[0] - M[2]);
         double den1 = (M[1] - M[2]) * (M[1] - M[0]);
         double den2 = (M[2] - M[0]) * (M[2] - M[1]);
+        const double inv0 = FAST ? 1.0 / den0 : 0.0, inv1 = FAST ? 1.0 / den1 : 0.0,
+                     inv2 = FAST ? 1.0 / den2 : 0.0;
         // diagonal entries of (2E H - M_k): Xd[k][i]
         cplx Xd[3][3];
 #pragma unroll
@@ -348,9 +379,15 @@ __device__ __forceinline__ void layer_amplitude(const Prob3Side &S, const double
                 cplx p2 = cmul(HMM(i, 0, 0), HMM(0, j, 1));
                 p2 = cadd(p2, cmul(HMM(i, 1, 0), HMM(1, j, 1)));
                 p2 = cadd(p2, cmul(HMM(i, 2, 0), HMM(2, j, 1)));
-                p0 = cmake(p0.re / den0, p0.im / den0);
-                p1 = cmake(p1.re / den1, p1.im / den1);
-                p2 = cmake(p2.re / den2, p2.im / den2);
+                if (FAST) {
+                    p0 = cmake(p0.re * inv0, p0.im * inv0);
+                    p1 = cmake(p1.re * inv1, p1.im * inv1);
+                    p2 = cmake(p2.re * inv2, p2.im * inv2);
+                } else {
+                    p0 = cmake(p0.re / den0, p0.im / den0);
+                    p1 = cmake(p1.re / den1, p1.im / den1);
+                    p2 = cmake(p2.re / den2, p2.im / den2);
+                }
                 cplx acc = cmul(ph[0], p0);
                 acc = cadd(acc, cmul(ph[1], p1));
                 acc = cadd(acc, cmul(ph[2], p2));
@@ -598,6 +635,101 @@ __device__ __forceinline__ void propagate_element(const Prob3Side &S, const doub
         }
     }
     // flavour basis (:326-328) and probabilities (:331-345)
+    mat3 t2, Tf;
+    mat_mul(T, S.Ud, t2);
+    mat_mul(S.U, t2, Tf);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            P[3 * i + j] = Tf.m[j][i].re * Tf.m[j][i].re + Tf.m[j][i].im * Tf.m[j][i].im;
+}
+
+// Index form of resolve_layer: the layer whose matrix the reference's cache would hand out
+// for layer i (i itself if there is no earlier match).
+template <class LayerFn>
+__device__ __forceinline__ int resolve_layer_index(const LayerFn &layer, int i) {
+    int cur = i;
+    double rho, dist;
+    layer(cur, rho, dist);
+    while (true) {
+        int found = -1;
+        for (int j = 0; j < cur; j++) {
+            double rj, dj;
+            layer(j, rj, dj);
+            if (dj > 0.0 && fabs(rj - rho) < 1e-5 && fabs(dj - dist) < 1e-5) found = j;
+        }
+        if (found < 0) break;
+        cur = found;
+        layer(cur, rho, dist);
+    }
+    return cur;
+}
+
+// Event-mode form of propagate_element for a path through the Earth that goes IN through
+// layers 0..mid-1, crosses the innermost layer `mid` and comes OUT through mid+1..n-1, the
+// out-going layer mid+s being the mirror of the in-going layer mid-s (layers.py:118-158).
+// The product is built from the middle outwards,  T <- A_out(s) . T . A_in(s),  so that a
+// mirrored pair needs ONE amplitude evaluation whenever the reference's cache would hand
+// the in-going layer's matrix to the out-going one (`resolve_layer_index`); otherwise the
+// out-going matrix is computed from its own resolved (rho, length), as propagate_element
+// does.  Same matrices as the sequential form, associated differently: equal to rounding.
+// mid < 0: no mirror structure (down-going paths), plain sequential product.
+template <bool DECAY, class LayerFn>
+__device__ __forceinline__ void propagate_path_nested(const Prob3Side &S, const double (&dm)[3][3],
+                                                      double energy, int n_layers, int mid,
+                                                      const LayerFn &layer, double (&P)[9]) {
+    double mv[3] = {0.0, 0.0, 0.0};
+    if (!DECAY) get_dms_vacuum(energy, dm, mv);
+    mat3 T;
+    bool have = false;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) T.m[i][j] = cmake(0.0, 0.0);
+    auto amplitude = [&](int l, mat3 &A) {  // matrix the reference uses for layer l
+        double rho, dist;
+        resolve_layer(layer, l, rho, dist);
+        layer_amplitude<DECAY, true>(S, dm, energy, rho, dist, A, mv);
+    };
+    auto left = [&](const mat3 &A) {   // T <- A . T  (A later on the path)
+        if (have) { mat3 t2; mat_mul(A, T, t2); T = t2; } else { T = A; have = true; }
+    };
+    auto right = [&](const mat3 &A) {  // T <- T . A  (A earlier on the path)
+        if (have) { mat3 t2; mat_mul(T, A, t2); T = t2; } else { T = A; have = true; }
+    };
+    if (mid < 0) {
+        for (int l = 0; l < n_layers; l++) {
+            double rho, dist;
+            layer(l, rho, dist);
+            if (dist > 0.0) { mat3 A; amplitude(l, A); left(A); }
+        }
+    } else {
+        {
+            double rho, dist;
+            layer(mid, rho, dist);
+            if (dist > 0.0) { mat3 A; amplitude(mid, A); left(A); }
+        }
+        for (int s = 1; mid - s >= 0 || mid + s < n_layers; s++) {
+            const int li = mid - s, lo = mid + s;
+            double rho_i = 0.0, d_i = 0.0, rho_o = 0.0, d_o = 0.0;
+            if (li >= 0) layer(li, rho_i, d_i);
+            if (lo < n_layers) layer(lo, rho_o, d_o);
+            mat3 A;
+            const bool in_ok = li >= 0 && d_i > 0.0, out_ok = lo < n_layers && d_o > 0.0;
+            if (in_ok) {
+                amplitude(li, A);
+                right(A);
+            }
+            if (out_ok) {
+                // the reference re-uses the in-going layer's matrix iff the cache chain of
+                // the out-going layer ends where the in-going layer's does
+                const bool same = in_ok && resolve_layer_index(layer, lo) == resolve_layer_index(layer, li);
+                if (!same) amplitude(lo, A);
+                left(A);
+            }
+        }
+    }
     mat3 t2, Tf;
     mat_mul(T, S.Ud, t2);
     mat_mul(S.U, t2, Tf);
