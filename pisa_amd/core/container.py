@@ -570,6 +570,31 @@ class ContainerSet:
         return iter([c for c in self.containers if not c.linked] + self.linked_containers)
 
     def get_mapset(self, key, error=None):
+        self._prefetch_to_host([k for k in (key, error) if k is not None])
         return MapSet(name=self.name, maps=[c.get_map(key, error=error) for c in self])
+
+    def _prefetch_to_host(self, keys):
+        """One device->host transfer for all containers' arrays of `keys` that only live in
+        HBM (instead of one synchronising copy per container and key)."""
+        todo = []
+        for c in self.containers:
+            for k in keys:
+                try:
+                    arr = c._get(k)
+                except Exception:  # missing key: let get_map raise the proper error
+                    return
+                if isinstance(arr, DualArray) and not arr.host_valid and arr.dev_valid:
+                    todo.append(arr)
+        if len(todo) < 2:
+            return
+        import torch
+
+        flat = torch.cat([a.get_dev().reshape(-1) for a in todo]).cpu().numpy()
+        off = 0
+        for a in todo:
+            n = int(np.prod(a.dev.shape))
+            a.host = flat[off:off + n].reshape(tuple(a.dev.shape))
+            a.host_valid = True
+            off += n
 
     glob_aux_data_keys = property(lambda self: self._glob_aux_data.keys())

@@ -66,11 +66,23 @@ class hypersurfaces(Stage):  # pylint: disable=invalid-name
         self.data.unlink_containers()
 
     def apply_function(self):
-        for container in self.data:
-            scales = container.device("hs_scales")
-            if self.error_method == "sumw2":
-                if self.data.representation != "events":
-                    container["errors"] = K.bin_scale(container.device("errors"), scales)
-                if "bin_unc2" in container.keys:
-                    container["bin_unc2"] = K.bin_scale(container.device("bin_unc2"), scales, floor=0.0)
-            container["weights"] = K.bin_scale(container.device("weights"), scales, floor=0.0)
+        # all containers at once: the maps are a few hundred bins each, so the cost is the
+        # number of launches and copies, not the arithmetic
+        import torch
+
+        conts = list(self.data)
+        scales = torch.stack([c.device("hs_scales") for c in conts])
+
+        def scaled(key, floor):
+            x = torch.stack([c.device(key) for c in conts])
+            out = K.bin_scale(x.reshape(-1), scales.reshape(-1), floor=floor).reshape(x.shape)
+            host = out.cpu().numpy()  # the maps are read on the host right after (get_outputs)
+            for i, c in enumerate(conts):
+                c.set_mirrored(key, out[i], host[i])
+
+        if self.error_method == "sumw2":
+            if self.data.representation != "events":
+                scaled("errors", None)                     # errors *= hs_scales (:251)
+            if all("bin_unc2" in c.keys for c in conts):
+                scaled("bin_unc2", 0.0)                    # clip(bin_unc2 * hs_scales, 0, inf) (:254-256)
+        scaled("weights", 0.0)                             # clip(weights * hs_scales, 0, inf) (:259)
