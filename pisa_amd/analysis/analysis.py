@@ -43,6 +43,25 @@ class HypoFitResult:
         return "HypoFitResult(%s=%.8g; %s)" % (self.metric, self.metric_val, vals)
 
 
+def load_minimizer_settings(settings):
+    """`settings`: a dict {method, options}, or the reference's minimizer-settings format
+    (`settings/minimizer/*.json`: {"method": {"value": ..., "desc": ...}, "options": {"value":
+    {...}, "desc": {...}}}, analysis.py:2560-2575), or the resource path of such a file."""
+    if isinstance(settings, str):
+        import json
+
+        from pisa_amd.utils.resources import find_resource
+
+        with open(find_resource(settings)) as fh:
+            settings = json.load(fh)
+    out = {}
+    for key in ("method", "options"):
+        if key in settings:
+            val = settings[key]
+            out[key] = val["value"] if isinstance(val, dict) and "value" in val else val
+    return out
+
+
 class Analysis:
     def __init__(self):
         self._nit = 0
@@ -86,7 +105,7 @@ class Analysis:
             hypo_maker.reset_free()
         ms = dict(method="L-BFGS-B", options=dict(ftol=2e-5, gtol=1e-5, eps=1e-4, maxiter=200))
         if minimizer_settings:
-            ms.update(minimizer_settings)
+            ms.update(load_minimizer_settings(minimizer_settings))
         free = hypo_maker.params.free
         if len(free) == 0:
             hypo = hypo_maker.get_outputs(return_sum=True)

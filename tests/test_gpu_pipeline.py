@@ -178,3 +178,25 @@ def test_fit_loop_recovers_injected_parameters():
     np.testing.assert_allclose(res.params.deltam31.value.m_as("eV**2"), 2.6e-3, rtol=5e-3)
     assert res.num_distributions_generated >= 10 and len(res.fit_history) == res.num_distributions_generated
     assert dm.pipelines[0]["hist"].fused_last_eval
+
+
+def test_fit_with_reference_minimizer_settings_file():
+    """the reference's own minimiser settings file (settings/minimizer/slsqp_*.json, nested
+    {"value", "desc"} format) drives the same fit"""
+    from pisa_amd.analysis.analysis import Analysis, load_minimizer_settings
+    from pisa_amd.core.distribution_maker import DistributionMaker
+    from pisa_amd.core.units import ureg
+
+    ms = load_minimizer_settings("settings/minimizer/slsqp_ftol1e-6_eps1e-4_maxiter1000.json")
+    assert ms == {"method": "SLSQP", "options": {"ftol": 1.0e-6, "eps": 1.0e-4, "maxiter": 1000}}
+    dm = DistributionMaker("settings/pipeline/example_hip.cfg")
+    for name in dm.params.free.names:
+        if name != "theta23":
+            dm.params.fix(name)
+    dm.params.theta23.value = 45.2 * ureg.degree
+    data = dm.get_outputs(return_sum=True)
+    dm.params.reset_free()
+    res = Analysis().fit_hypo(data, dm, "chi2",
+                              minimizer_settings="settings/minimizer/slsqp_ftol1e-6_eps1e-4_maxiter1000.json")
+    assert res.minimizer_metadata["success"], res.minimizer_metadata
+    np.testing.assert_allclose(res.params.theta23.value.m_as("deg"), 45.2, atol=0.2)

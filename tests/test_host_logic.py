@@ -201,3 +201,13 @@ def test_data_release_hyperplanes_and_csv_loader_host_side(tmp_path, monkeypatch
     assert c["nubar"] == -1 and c["flav"] == 1
     np.testing.assert_array_equal(c["weighted_aeff"], mc["weight"].values[sel])
     np.testing.assert_array_equal(c["initial_weights"], np.ones(sel.sum()))
+
+
+def test_minimizer_settings_formats():
+    from pisa_amd.analysis.analysis import load_minimizer_settings
+
+    ref = load_minimizer_settings("settings/minimizer/l-bfgs-b_ftol2e-5_gtol1e-5_eps1e-4_maxiter200.json")
+    assert ref["method"] == "L-BFGS-B" and ref["options"]["maxiter"] == 200 and ref["options"]["eps"] == 1e-4
+    assert load_minimizer_settings({"method": "SLSQP"}) == {"method": "SLSQP"}
+    nested = {"method": {"value": "TNC", "desc": "x"}, "options": {"value": {"maxiter": 3}, "desc": {}}}
+    assert load_minimizer_settings(nested) == {"method": "TNC", "options": {"maxiter": 3}}
