@@ -9,6 +9,9 @@
 // estimate) and coef[i] = w_i * s_i^d / norm.  One thread owns one query point
 // and keeps its partial sum in a register; sources are streamed through LDS in
 // tiles (every lane reads the same source -> LDS broadcast, no bank conflicts).
+// With few query points (the evaluation grid of a map is ~10^4 points, 40 workgroups) the
+// sources are additionally split over blockIdx.y so that the launch fills the chip; the
+// per-split partial sums are added in split order by a second kernel.
 // Summation order per query point is fixed => bit-reproducible.
 // Roofline: FP64 VALU + one exp per pair (compute bound; N*M pairs, 40 B/source).
 #include "common.hpp"
@@ -23,7 +26,7 @@ __global__ void __launch_bounds__(KDE_THREADS)
 kde_eval_kernel(const double *__restrict__ src, const double *__restrict__ coef,
                 const double *__restrict__ s2, int64_t n_src, const double *__restrict__ qry,
                 int64_t n_qry, double ic00, double ic01, double ic02, double ic11, double ic12,
-                double ic22, double *__restrict__ out) {
+                double ic22, int64_t src_chunk, double *__restrict__ out) {
     __shared__ double t_x[D][KDE_TILE];
     __shared__ double t_c[KDE_TILE];
     __shared__ double t_s[KDE_TILE];
@@ -32,8 +35,12 @@ kde_eval_kernel(const double *__restrict__ src, const double *__restrict__ coef,
 #pragma unroll
     for (int d = 0; d < D; d++) q[d] = j < n_qry ? qry[(int64_t)d * n_qry + j] : 0.0;
     double acc = 0.0;
-    for (int64_t base = 0; base < n_src; base += KDE_TILE) {
-        const int cnt = (int)((n_src - base) < KDE_TILE ? (n_src - base) : KDE_TILE);
+    // this workgroup's share of the sources; its sums go to row blockIdx.y of `out`
+    const int64_t src_lo = (int64_t)blockIdx.y * src_chunk;
+    const int64_t src_hi = src_lo + src_chunk < n_src ? src_lo + src_chunk : n_src;
+    out += (int64_t)blockIdx.y * n_qry;
+    for (int64_t base = src_lo; base < src_hi; base += KDE_TILE) {
+        const int cnt = (int)((src_hi - base) < KDE_TILE ? (src_hi - base) : KDE_TILE);
         __syncthreads();
         for (int k = threadIdx.x; k < cnt; k += KDE_THREADS) {
 #pragma unroll
@@ -59,6 +66,22 @@ kde_eval_kernel(const double *__restrict__ src, const double *__restrict__ coef,
     if (j < n_qry) out[j] = acc;
 }
 
+// out[j] = partial[0][j] + partial[1][j] + ... in split order
+__global__ void __launch_bounds__(256)
+kde_reduce_kernel(const double *__restrict__ partial, int n_split, int64_t n_qry,
+                  double *__restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_qry) return;
+    double acc = partial[j];
+    for (int s = 1; s < n_split; s++) acc += partial[(int64_t)s * n_qry + j];
+    out[j] = acc;
+}
+
+// scratch for the per-split partial sums (grown on demand; one per process, like the rest
+// of the library not meant for concurrent calls from several host threads)
+static double *g_kde_scratch = nullptr;
+static size_t g_kde_scratch_bytes = 0;
+
 }  // namespace pisa
 
 using namespace pisa;
@@ -74,13 +97,43 @@ PISA_API int pisa_hip_kde_eval(int32_t dim, const double *d_src, const double *d
     double c00 = ic[0], c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
     if (dim >= 2) { c01 = ic[1]; c11 = ic[dim + 1]; }
     if (dim == 3) { c02 = ic[2]; c12 = ic[dim + 2]; c22 = ic[2 * dim + 2]; }
-    dim3 block(KDE_THREADS), grid((unsigned)((n_qry + KDE_THREADS - 1) / KDE_THREADS));
+    const unsigned qblocks = (unsigned)((n_qry + KDE_THREADS - 1) / KDE_THREADS);
+    // enough workgroups for 256 CUs x 4: split the sources when there are few query points
+    int n_split = 1;
+    if (qblocks < 1024 && n_src > 4 * KDE_TILE) {
+        n_split = (int)((1024 + qblocks - 1) / qblocks);
+        const int64_t max_split = n_src / (2 * KDE_TILE);
+        if (n_split > max_split) n_split = (int)max_split;
+        if (n_split > 64) n_split = 64;
+        if (n_split < 1) n_split = 1;
+    }
+    int64_t src_chunk = n_src;
+    double *dst = d_out;
     hipStream_t s = as_stream(stream);
-#define KDE_LAUNCH(DD) hipLaunchKernelGGL(kde_eval_kernel<DD>, grid, block, 0, s, d_src, d_coef, d_s2, n_src, d_qry, n_qry, c00, c01, c02, c11, c12, c22, d_out)
+    if (n_split > 1) {
+        src_chunk = ((n_src + n_split - 1) / n_split + KDE_TILE - 1) / KDE_TILE * KDE_TILE;
+        n_split = (int)((n_src + src_chunk - 1) / src_chunk);
+        const size_t need = (size_t)n_split * n_qry * sizeof(double);
+        if (need > g_kde_scratch_bytes) {
+            PISA_TRY_HIP(hipStreamSynchronize(s));
+            if (g_kde_scratch) (void)hipFree(g_kde_scratch);
+            g_kde_scratch = nullptr;
+            g_kde_scratch_bytes = 0;
+            PISA_TRY_HIP(hipMalloc(&g_kde_scratch, need));
+            g_kde_scratch_bytes = need;
+        }
+        dst = g_kde_scratch;
+    }
+    dim3 block(KDE_THREADS), grid(qblocks, (unsigned)n_split);
+#define KDE_LAUNCH(DD) hipLaunchKernelGGL(kde_eval_kernel<DD>, grid, block, 0, s, d_src, d_coef, d_s2, n_src, d_qry, n_qry, c00, c01, c02, c11, c12, c22, src_chunk, dst)
     if (dim == 1) KDE_LAUNCH(1);
     else if (dim == 2) KDE_LAUNCH(2);
     else KDE_LAUNCH(3);
 #undef KDE_LAUNCH
     PISA_CHECK_LAUNCH("kde_eval_kernel");
+    if (n_split > 1) {
+        hipLaunchKernelGGL(kde_reduce_kernel, dim3(qblocks), dim3(256), 0, s, dst, n_split, n_qry, d_out);
+        PISA_CHECK_LAUNCH("kde_reduce_kernel");
+    }
     return PISA_HIP_OK;
 }
