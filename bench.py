@@ -46,6 +46,8 @@ def parse():
                     help="bin event coordinates on the fly (72 B/event) instead of the pre-digitised "
                          "index columns (40 B/event)")
     ap.add_argument("--cpu-sample-events", type=float, default=2.4e6)
+    ap.add_argument("--no-drop-probe", action="store_true",
+                    help="skip the informational second engine without the events outside the binning")
     ap.add_argument("--weak-scaling", action="store_true",
                     help="N > 1: every rank holds --events events of its own (seed = rank) instead of a "
                          "1/N shard of one sample; `value` then counts evaluations of --events-sized units "
@@ -241,6 +243,24 @@ def main():
     dtb = time.perf_counter() - t0b
     pipelined = nb / dtb if nb else None
 
+    # for information: the same evaluations with the events that can never land in a bin
+    # (static reco coordinates outside the output binning) not kept resident
+    dropped = None
+    if world == 1 and not args.coordinate_form and not args.no_drop_probe:
+        st2 = synthetic.DeviceState(wl, sort_events=True if args.event_order == "auto" else args.event_order,
+                                    drop_unbinned=True)
+        st2.set_data(st.data.cpu().numpy())
+        for p in plist[: args.warmup]:
+            st2.eval_host(p, "llh")
+        torch.cuda.synchronize()
+        t0d = time.perf_counter()
+        for p in plist[args.warmup:]:
+            llh2 = st2.eval_host(p, "llh")
+        dtd = time.perf_counter() - t0d
+        dropped = {"evals_per_s": args.steps / dtd, "events_resident": st2.n_local,
+                   "same_llh": bool(llh2 == llh)}
+        del st2
+
     # max over ranks
     if world > 1:
         import torch.distributed as dist
@@ -279,6 +299,7 @@ def main():
             "event_evals_per_s": evals_per_s * wl.n_events * units,
             "last_llh": llh,
             "pipelined_evals_per_s": pipelined,
+            "unbinned_events_dropped": dropped,
             "phase_ms": {"prob3_grid": t_prob3, "fused_reweight_hist": 1e3 * fused_avg_s,
                          "finalize_metric": t_tail},
             "roofline": {

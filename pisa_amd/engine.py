@@ -135,7 +135,7 @@ class HotPathEngine:
 
     def __init__(self, containers, grid, out_binning, earth, max_layers, rank=0, world_size=1,
                  group=None, indexed=True, planned=True, packed=True, sort_events=True,
-                 external_tables=False, osc_mode="grid"):
+                 external_tables=False, osc_mode="grid", drop_unbinned=False):
         self.dev = K.device()
         assert osc_mode in ("grid", "events")
         self.osc_events = osc_mode == "events"
@@ -209,10 +209,19 @@ class HotPathEngine:
                         perm = bin_window_order(obin, self.n_bins)
                     else:
                         perm = torch.argsort(node, stable=True)
+                if drop_unbinned:
+                    # an event outside the output binning (or outside the calc grid: P = 0)
+                    # adds nothing to any map, whatever the parameters: the coordinates are
+                    # static, so such events need not be resident at all
+                    keep = (obin >= 0) & (node >= 0)
+                    perm = torch.nonzero(keep).reshape(-1) if perm is None else perm[keep[perm]]
+                if perm is not None:
                     gx, gy, flux_d, aeff_d, w0_d = (t[perm].contiguous() for t in
                                                    (gx, gy, flux_d, aeff_d, w0_d))
                     cols = [t[perm].contiguous() for t in cols]
                     node, obin = node[perm].contiguous(), obin[perm].contiguous()
+                    self.n_local += int(perm.numel()) - d.n_events
+                    d.n_events = int(perm.numel())
             self._keep += [gx, gy, flux_d, aeff_d, w0_d] + cols
             self._perm.append(perm)
             self._flux.append(flux_d)
