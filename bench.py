@@ -46,6 +46,10 @@ def parse():
                     help="bin event coordinates on the fly (72 B/event) instead of the pre-digitised "
                          "index columns (40 B/event)")
     ap.add_argument("--cpu-sample-events", type=float, default=2.4e6)
+    ap.add_argument("--exact-association", action="store_true",
+                    help="stream the 40 B/event columns (initial_weights, weighted_aeff, nu_flux kept separate, "
+                         "the reference's operation order) instead of the 24 B/event compact form in which the "
+                         "static per-event factors are folded into the flux pair once")
     ap.add_argument("--no-drop-probe", action="store_true",
                     help="skip the informational second engine without the events outside the binning")
     ap.add_argument("--weak-scaling", action="store_true",
@@ -122,7 +126,7 @@ def pmc_traffic(args):
     PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; collected by
     separate `rocprofv3 --pmc` runs of this same command, see profiles/*/traffic.json).
     Only valid for the default workload."""
-    if args.coordinate_form or int(args.events) != 10000000 or args.binning != "dragon":
+    if args.coordinate_form or args.exact_association or int(args.events) != 10000000 or args.binning != "dragon":
         return None
     import glob
 
@@ -153,11 +157,13 @@ def main():
 
     n_e, n_cz = (int(v) for v in args.grid.split("x"))
     weak = args.weak_scaling and world > 1
+    compact = not (args.exact_association or args.coordinate_form)
     wl = synthetic.Workload(n_events=int(args.events), grid=(n_e, n_cz), out_binning=args.binning,
                             seed=rank if weak else 0)
     st = synthetic.DeviceState(wl, rank=0 if weak else rank, world_size=1 if weak else world,
                                indexed=not args.coordinate_form,
-                               sort_events=True if args.event_order == "auto" else args.event_order)
+                               sort_events=True if args.event_order == "auto" else args.event_order,
+                               compact=compact)
     if weak:
         st.world_size = world  # whole local sample per rank; the limb all-reduce still spans all ranks
     nominal = wl.osc_params()
@@ -199,6 +205,8 @@ def main():
         bytes_per_event = 8 * (2 + 2 + 1 + 1 + d_out)  # 72 B (D=3), 64 B (D=2)
     else:
         bytes_per_event = 4 + 4 + 16 + 8 + 8  # node, bin (int32) + flux(2) + aeff + w0 = 40 B
+        if compact:
+            bytes_per_event = 4 + 4 + 16  # node, bin + (w0*aeff*f_e, w0*aeff*f_mu) = 24 B
     if args.no_kernel_timing:
         fused_avg_s = float("nan")
     else:
@@ -248,7 +256,7 @@ def main():
     dropped = None
     if world == 1 and not args.coordinate_form and not args.no_drop_probe:
         st2 = synthetic.DeviceState(wl, sort_events=True if args.event_order == "auto" else args.event_order,
-                                    drop_unbinned=True)
+                                    drop_unbinned=True, compact=compact)
         st2.set_data(st.data.cpu().numpy())
         for p in plist[: args.warmup]:
             st2.eval_host(p, "llh")
@@ -288,8 +296,12 @@ def main():
             "config": {
                 "workload": "%d events in 12 containers, prob3 on %dx%d (E,coszen) PREM-12 calc grid "
                             "(nu+nubar), fused lookup+reweight+%s hist with sumw2, Poisson LLH; "
-                            "theta23/dm31 changed every eval, LLH read back every eval"
-                            % (wl.n_events, n_e, n_cz, "x".join(str(b) for b in wl.ob["nbins"])),
+                            "theta23/dm31 changed every eval, LLH read back every eval; %s"
+                            % (wl.n_events, n_e, n_cz, "x".join(str(b) for b in wl.ob["nbins"]),
+                               "event columns %d B/event (%s)" % (
+                                   bytes_per_event,
+                                   "static factors initial_weights*weighted_aeff folded into the flux pair"
+                                   if compact else "reference operation order")),
                 "events": wl.n_events,
                 "calc_grid": [n_e, n_cz],
                 "out_bins": wl.ob["nbins"],
@@ -304,7 +316,7 @@ def main():
                          "finalize_metric": t_tail},
             "roofline": {
                 "bound": "hbm",
-                "kernel": "hist_accumulate_kernel<%d, true>" % (1 if args.coordinate_form else 3),
+                "kernel": "hist_accumulate_kernel<%d, true>" % (1 if args.coordinate_form else (5 if compact else 3)),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

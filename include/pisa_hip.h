@@ -222,6 +222,14 @@ typedef struct {
     int32_t flav;                    /* 0 e, 1 mu, 2 tau  (aux 'flav')                     */
     int32_t nubar;                   /* +1 / -1           (aux 'nubar')                    */
     double scale;                    /* aeff_scale*livetime_s*norms (aeff.py:78-86)        */
+    const double *d_weighted_flux;   /* [n][2] optional COMPACT form, used together with d_node_bin:
+                                        initial_weights*weighted_aeff*(nu_flux_e, nu_flux_mu), i.e. the
+                                        factors of the weight that do not depend on the oscillation
+                                        parameters multiplied once (24 B per event instead of 40).
+                                        w = ((g_e*P_e) + (g_mu*P_mu)) * scale: the reference's product
+                                        with the static factors associated first (differs from the
+                                        40-B form by rounding, <= 3 ulp per weight).  The caller
+                                        refreshes it when nu_flux changes (flux systematics). */
 } pisa_hip_container;
 
 /* Fused  prob3.apply (prob3.py:621-622, with the grid->event lookup of

@@ -86,6 +86,7 @@ class Container(C.Structure):
         ("flav", C.c_int32),
         ("nubar", C.c_int32),
         ("scale", C.c_double),
+        ("d_weighted_flux", C.c_void_p),
     ]
 
 

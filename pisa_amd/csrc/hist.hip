@@ -130,6 +130,7 @@ struct ContDev {
     const int2 *node_bin;       // optional packed (node, bin) per event
     const double2 *aeff_w0;     // optional packed (weighted_aeff, initial_weights) per event
     const double2 *pepmu_own;   // optional per-container (P_e, P_mu) table (event-mode prob3)
+    const double2 *wflux;       // optional static-weighted flux (w0*aeff*f_e, w0*aeff*f_mu) per event
     double scale;
     int32_t flav, side;
 };
@@ -154,6 +155,11 @@ struct HistArgs {
 // MODE 0: generic histogram (weights or counts; quantities (w, 1))
 // MODE 1: fused reweight chain from coordinates (quantities (w, w^2))
 // MODE 2: fused reweight chain from pre-digitised indices, 2 events / thread / sweep
+// MODE 3: same from the packed 16-byte columns (node,bin) / (aeff,w0) / flux: 40 B per event
+// MODE 5: compact form, (node,bin) + the flux pair pre-multiplied by the static per-event
+//         factor initial_weights*weighted_aeff: 24 B per event, two loads fewer per pair.
+//         w = ((g_e*P_e) + (g_mu*P_mu)) * scale  -- the reference's product with the static
+//         factors associated first; differs from MODE 3 by rounding only (<= 3 ulp per weight)
 template <int MODE, bool LDS_ACC>
 __global__ void __launch_bounds__(1024)
 hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limbs,
@@ -195,17 +201,22 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
     bool have = p < p_end;
     int4 ix = make_int4(-1, -1, -1, -1);  // node0, bin0, node1, bin1
     double2 awa = make_double2(0.0, 0.0), awb = awa, fa = awa, fb = awa;
-    if (MODE == 3 && have) {
+    constexpr bool PACKED = MODE == 3 || MODE == 5;
+    constexpr bool COMPACT = MODE == 5;
+    if (PACKED && have) {
         const bool nt0 = (a.dbg & 16) != 0;
+        const double2 *col = COMPACT ? C.wflux : C.aeff_w0;
         ix = ld_stream(reinterpret_cast<const int4 *>(C.node_bin) + p, nt0);
-        awa = ld_stream(C.aeff_w0 + 2 * p, nt0); awb = ld_stream(C.aeff_w0 + 2 * p + 1, nt0);
-        fa = ld_stream(reinterpret_cast<const double2 *>(C.flux) + 2 * p, nt0);
-        fb = ld_stream(reinterpret_cast<const double2 *>(C.flux) + 2 * p + 1, nt0);
+        awa = ld_stream(col + 2 * p, nt0); awb = ld_stream(col + 2 * p + 1, nt0);
+        if (!COMPACT) {
+            fa = ld_stream(reinterpret_cast<const double2 *>(C.flux) + 2 * p, nt0);
+            fb = ld_stream(reinterpret_cast<const double2 *>(C.flux) + 2 * p + 1, nt0);
+        }
     }
 
     if (LDS_ACC) {
         for (int k = threadIdx.x; k < n_acc * a.copies; k += nthreads) s_acc[k] = 0.0;
-        if (MODE == 3 && a.window > 0) {
+        if (PACKED && a.window > 0) {
             __shared__ int s_lo;
             if (threadIdx.x == 0) s_lo = 0x7fffffff;
             __syncthreads();
@@ -248,13 +259,13 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
         if (!ok) bad = true;
     };
 
-    if (MODE == 3) {
+    if (PACKED) {
         // packed columns: (node, bin) int2 and (aeff, w0) double2 per event; every load is 16 B
         const double2 *tab = C.pepmu_own ? C.pepmu_own
                                          : a.pepmu + ((int64_t)C.side * 3 + C.flav) * a.n_nodes;
         const double scale = C.scale;
         const int4 *idx4 = reinterpret_cast<const int4 *>(C.node_bin);
-        const double2 *aw = C.aeff_w0;
+        const double2 *aw = COMPACT ? C.wflux : C.aeff_w0;
         const double2 *flux2 = reinterpret_cast<const double2 *>(C.flux);
         // Software-pipelined: the five streaming loads of the NEXT pair of events are
         // issued before the current pair is consumed, and the two dependent table
@@ -274,16 +285,26 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
             const bool nt = (a.dbg & 16) != 0;  // probe: non-temporal loads
             const int4 ixn = ld_stream(idx4 + pl, nt);
             const double2 awan = ld_stream(aw + 2 * pl, nt), awbn = ld_stream(aw + 2 * pl + 1, nt);
-            const double2 fan = ld_stream(flux2 + 2 * pl, nt), fbn = ld_stream(flux2 + 2 * pl + 1, nt);
+            double2 fan = make_double2(0.0, 0.0), fbn = fan;
+            if (!COMPACT) {
+                fan = ld_stream(flux2 + 2 * pl, nt);
+                fbn = ld_stream(flux2 + 2 * pl + 1, nt);
+            }
             if (ix.x < 0) pa = make_double2(0.0, 0.0);
             if (ix.z < 0) pb = make_double2(0.0, 0.0);
             // branch-free on purpose (an event outside the binning deposits w = 0,
             // i.e. nothing): a conditional here lets the compiler sink the gathers
             // below the prefetch and wait for all of it
-            double wa = awa.y * ((fa.x * pa.x) + (fa.y * pa.y));  // prob3.py:622
-            wa = wa * (awa.x * scale);                            // aeff.py:87
-            double wb = awb.y * ((fb.x * pb.x) + (fb.y * pb.y));
-            wb = wb * (awb.x * scale);
+            double wa, wb;
+            if (COMPACT) {
+                wa = ((awa.x * pa.x) + (awa.y * pa.y)) * scale;
+                wb = ((awb.x * pb.x) + (awb.y * pb.y)) * scale;
+            } else {
+                wa = awa.y * ((fa.x * pa.x) + (fa.y * pa.y));  // prob3.py:622
+                wa = wa * (awa.x * scale);                     // aeff.py:87
+                wb = awb.y * ((fb.x * pb.x) + (fb.y * pb.y));
+                wb = wb * (awb.x * scale);
+            }
             if (ix.y < 0) wa = 0.0;
             if (ix.w < 0) wb = 0.0;
             accumulate(ix.y < 0 ? bin_lo : ix.y, wa, wa * wa);
@@ -297,10 +318,15 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
             const int2 ix1 = C.node_bin[i];
             if (ix1.y >= 0) {
                 double2 pp = ix1.x >= 0 ? tab[ix1.x] : make_double2(0.0, 0.0);
-                double2 f = flux2[i];
                 double2 x = aw[i];
-                double w = x.y * ((f.x * pp.x) + (f.y * pp.y));
-                w = w * (x.x * scale);
+                double w;
+                if (COMPACT) {
+                    w = ((x.x * pp.x) + (x.y * pp.y)) * scale;
+                } else {
+                    double2 f = flux2[i];
+                    w = x.y * ((f.x * pp.x) + (f.y * pp.y));
+                    w = w * (x.x * scale);
+                }
                 accumulate(ix1.y, w, w * w);
             }
         }
@@ -597,7 +623,7 @@ static int run_hist(const ContDev *conts, int n_cont, int mode, const DevBinning
     int64_t lds_bytes = lds_acc_bytes(n_bins);
     bool lds = lds_bytes <= LDS_ACC_BYTES_MAX;
     int window = 0;
-    if (!lds && mode == 3 && !env_int("PISA_HIP_HIST_NO_WINDOW", 0)) {
+    if (!lds && (mode == 3 || mode == 5) && !env_int("PISA_HIP_HIST_NO_WINDOW", 0)) {
         // binning too large for LDS: accumulate a window of it (see the kernel)
         window = (int)(LDS_ACC_BYTES_MAX / lds_acc_bytes(1));
         lds_bytes = lds_acc_bytes(window);
@@ -638,7 +664,8 @@ static int run_hist(const ContDev *conts, int n_cont, int mode, const DevBinning
         unsigned long long *out = reinterpret_cast<unsigned long long *>(d_limbs);
         if (g_prof_start) PISA_TRY_HIP(hipEventRecord(g_prof_start, s));
 #define LAUNCH(M, L) hipLaunchKernelGGL((hist_accumulate_kernel<M, L>), grid_dim, block, shmem, s, a, out, d_status)
-        if (mode == 3) { if (lds) LAUNCH(3, true); else LAUNCH(3, false); }
+        if (mode == 5) { if (lds) LAUNCH(5, true); else LAUNCH(5, false); }
+        else if (mode == 3) { if (lds) LAUNCH(3, true); else LAUNCH(3, false); }
         else if (mode == 2) { if (lds) LAUNCH(2, true); else LAUNCH(2, false); }
         else if (mode == 1) { if (lds) LAUNCH(1, true); else LAUNCH(1, false); }
         else { if (lds) LAUNCH(0, true); else LAUNCH(0, false); }
@@ -697,15 +724,17 @@ static int reweight_hist_impl(const pisa_hip_container *h_containers, int32_t n_
     for (int c = 0; c < n_containers; c++) any_table = any_table || h_containers[c].d_pepmu;
     bool all_indexed = d_pepmu != nullptr;
     bool all_packed = any_table;
+    bool all_compact = any_table;
     for (int c = 0; c < n_containers; c++) {
         const pisa_hip_container &h = h_containers[c];
         ContDev &d = conts[c];
-        bool packed = h.d_node_bin && h.d_aeff_w0;
+        const bool compact = h.d_node_bin && h.d_weighted_flux;
+        bool packed = h.d_node_bin && (h.d_aeff_w0 || h.d_weighted_flux);
         bool indexed = packed || (h.d_node && h.d_bin);
         bool bad = h.n_events < 0 || h.flav < 0 || h.flav > 2 || (h.nubar != 1 && h.nubar != -1);
         if (h.n_events > 0) {
-            bad = bad || !h.d_nu_flux;
             const bool has_tab = d_pepmu || h.d_pepmu;
+            bad = bad || (!h.d_nu_flux && !(compact && has_tab));
             if (!(packed && has_tab)) bad = bad || !h.d_weighted_aeff || !h.d_initial_weights;
             if (!(indexed && has_tab)) {
                 bad = bad || !h.d_grid_x || (grid.ndim > 1 && !h.d_grid_y);
@@ -713,7 +742,8 @@ static int reweight_hist_impl(const pisa_hip_container *h_containers, int32_t n_
                 bad = bad || (h.nubar > 0 ? !d_prob_nu : !d_prob_nubar);
             }
             all_indexed = all_indexed && indexed && (h.d_node && h.d_bin);
-            all_packed = all_packed && packed && has_tab;
+            all_packed = all_packed && packed && has_tab && h.d_aeff_w0 && h.d_nu_flux;
+            all_compact = all_compact && compact && has_tab;
         }
         if (bad) { delete[] conts; return PISA_HIP_ERR_INVALID; }
         d.n = h.n_events;
@@ -724,11 +754,12 @@ static int reweight_hist_impl(const pisa_hip_container *h_containers, int32_t n_
         d.node_bin = reinterpret_cast<const int2 *>(h.d_node_bin);
         d.aeff_w0 = reinterpret_cast<const double2 *>(h.d_aeff_w0);
         d.pepmu_own = reinterpret_cast<const double2 *>(h.d_pepmu);
+        d.wflux = reinterpret_cast<const double2 *>(h.d_weighted_flux);
         d.scale = h.scale;
         d.flav = h.flav;
         d.side = h.nubar > 0 ? 0 : 1;
     }
-    rc = run_hist(conts, n_containers, all_packed ? 3 : (all_indexed ? 2 : 1), &grid, n_nodes, d_prob_nu, d_prob_nubar,
+    rc = run_hist(conts, n_containers, all_compact ? 5 : (all_packed ? 3 : (all_indexed ? 2 : 1)), &grid, n_nodes, d_prob_nu, d_prob_nubar,
                   d_pepmu, outb, n_bins, (long long *)d_limbs, d_status, as_stream(stream), clear_first);
     delete[] conts;
     return rc;
@@ -813,7 +844,7 @@ PISA_API int pisa_hip_histogram_regular(const pisa_hip_binning *h_binning,
         c.n = n; c.gx = c.gy = c.flux = c.aeff = nullptr; c.w0 = d_weights;
         for (int k = 0; k < 3; k++) c.s[k] = k < outb.ndim ? h_d_sample[k] : nullptr;
         c.node = c.bin = nullptr;
-        c.node_bin = nullptr; c.aeff_w0 = nullptr; c.pepmu_own = nullptr;
+        c.node_bin = nullptr; c.aeff_w0 = nullptr; c.pepmu_own = nullptr; c.wflux = nullptr;
         c.scale = 1.0; c.flav = 0; c.side = 0;
         rc = run_hist(&c, 1, 0, nullptr, 0, nullptr, nullptr, nullptr, outb, n_bins, limbs, st, s);
     }

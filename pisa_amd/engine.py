@@ -135,7 +135,7 @@ class HotPathEngine:
 
     def __init__(self, containers, grid, out_binning, earth, max_layers, rank=0, world_size=1,
                  group=None, indexed=True, planned=True, packed=True, sort_events=True,
-                 external_tables=False, osc_mode="grid", drop_unbinned=False):
+                 external_tables=False, osc_mode="grid", drop_unbinned=False, compact=False):
         self.dev = K.device()
         assert osc_mode in ("grid", "events")
         self.osc_events = osc_mode == "events"
@@ -156,6 +156,8 @@ class HotPathEngine:
         self.indexed, self.planned = indexed, planned
         self.cont = []
         self._perm, self._flux, self._slices = [], [], []
+        self._static_w, self._wflux = [], []
+        self.compact = bool(compact)
         self.n_local = 0
         for c in containers:
             n = len(c["true_energy"])
@@ -173,6 +175,7 @@ class HotPathEngine:
             w0_d = K.to_device(np.asarray(c["initial_weights"])[sl])
             cols = [K.to_device(np.asarray(col)[sl]) for col in c["sample"]]
             node = obin = perm = None
+            static_w = wflux = None
             if self.osc_events:
                 # event-by-event oscillation: every event is its own "node"; the shard
                 # is stored sorted by coszen so that the lanes of a wavefront cross the
@@ -239,7 +242,17 @@ class HotPathEngine:
                     aw = torch.stack([aeff_d, w0_d], dim=1).contiguous()
                     self._keep += [nb, aw]
                     d.d_node_bin, d.d_aeff_w0 = nb.data_ptr(), aw.data_ptr()
+                    if compact:
+                        # the factors of the weight that no oscillation parameter touches,
+                        # multiplied once: (w0*aeff) * (f_e, f_mu), 24 B/event with node_bin
+                        cst = (w0_d * aeff_d).contiguous()
+                        wf = (cst[:, None] * flux_d).contiguous()
+                        self._keep += [cst, wf]
+                        d.d_weighted_flux = wf.data_ptr()
+                        static_w, wflux = cst, wf
             d.flav, d.nubar, d.scale = int(c["flav"]), int(c["nubar"]), float(c["scale"])
+            self._static_w.append(static_w)
+            self._wflux.append(wflux)
             self.cont.append(d)
         self._cont_arr = (_lib.Container * len(self.cont))(*self.cont)
         # Earth layers for the coszen nodes (prob3.setup_function, prob3.py:398-409)
@@ -276,6 +289,8 @@ class HotPathEngine:
         if self._perm[i] is not None:
             f = f[self._perm[i]]
         self._flux[i].copy_(f)
+        if self._wflux[i] is not None:
+            torch.mul(self._static_w[i][:, None], self._flux[i], out=self._wflux[i])
 
     def set_scale(self, name, scale):
         i = self.names.index(name)

@@ -95,3 +95,45 @@ def test_dropping_unbinned_events_changes_nothing():
     assert bool((full.ws.hist == lean.ws.hist).all()) and bool((full.ws.sumw2 == lean.ws.sumw2).all())
     full.check_status()
     lean.check_status()
+
+
+def test_compact_layout_matches_exact_association(oracle):
+    """24 B/event form: initial_weights*weighted_aeff folded into the flux pair once.
+    Same product with the static factors associated first: equal to the 40 B form to a few ulp
+    per weight, to the oracle within the parity bar; flux updates refresh the folded column."""
+    from oracle import pipeline_oracle
+    from pisa_amd import kernels as K
+    from pisa_amd import synthetic
+
+    wl = synthetic.Workload(n_events=240000, grid=(60, 40), out_binning="dragon", seed=9)
+    p = wl.osc_params(theta23_deg=48.0)
+    mats = dict(wl.last_matrices)
+    exact = synthetic.DeviceState(wl)
+    comp = synthetic.DeviceState(wl, compact=True)
+    for st in (exact, comp):
+        st.make_pseudo_data(wl.osc_params(), seed=0)
+    np.testing.assert_array_equal(exact.data.cpu().numpy(), comp.data.cpu().numpy())
+    a, b = exact.eval_host(p), comp.eval_host(p)
+    np.testing.assert_allclose(b, a, rtol=1e-12)
+    he, se = exact.maps()
+    hc, sc = comp.maps()
+    np.testing.assert_allclose(hc, he, rtol=1e-14, atol=0)
+    np.testing.assert_allclose(sc, se, rtol=1e-14, atol=0)
+    ref = pipeline_oracle.oracle_eval(wl, mats)
+    np.testing.assert_allclose(hc, np.asarray(ref["hist"]).reshape(hc.shape), rtol=1e-10, atol=1e-300)
+    np.testing.assert_allclose(sc, np.asarray(ref["sumw2"]).reshape(sc.shape), rtol=1e-10, atol=1e-300)
+    # run-to-run and order independence hold for the compact form as well
+    comp2 = synthetic.DeviceState(wl, compact=True, sort_events=False)
+    comp2.set_data(comp.data.cpu().numpy())
+    assert comp2.eval_host(p) == b
+    # a flux systematic changes nu_flux of one container: both engines follow
+    i = 1
+    new_flux = K.to_device(wl.events[i]["nu_flux"] * np.array([1.07, 0.96]))
+    for st in (exact, comp):
+        st.update_flux(i, new_flux)
+    a2, b2 = exact.eval_host(p), comp.eval_host(p)
+    assert a2 != a
+    np.testing.assert_allclose(b2, a2, rtol=1e-12)
+    np.testing.assert_allclose(comp.maps()[0], exact.maps()[0], rtol=1e-14, atol=0)
+    exact.check_status()
+    comp.check_status()
