@@ -64,21 +64,8 @@ __device__ __forceinline__ bool deposit(double x, F &&add) {
     return true;
 }
 
-// 16-byte streaming loads, optionally with the non-temporal hint (PISA_HIP_HIST_DBG=16).
-// Measured A/B in one session: nt makes this kernel 5 us SLOWER (92.3 vs 87.4 us) and leaves
-// the whole evaluation unchanged, so plain loads are the default.
-typedef double v2d_t __attribute__((ext_vector_type(2)));
-typedef int v4i_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ double2 ld_stream(const double2 *p, bool nt) {
-    if (!nt) return *p;
-    const v2d_t v = __builtin_nontemporal_load(reinterpret_cast<const v2d_t *>(p));
-    return make_double2(v.x, v.y);
-}
-__device__ __forceinline__ int4 ld_stream(const int4 *p, bool nt) {
-    if (!nt) return *p;
-    const v4i_t v = __builtin_nontemporal_load(reinterpret_cast<const v4i_t *>(p));
-    return make_int4(v.x, v.y, v.z, v.w);
-}
+// (Non-temporal streaming loads were measured A/B in one session: this kernel got 5 us SLOWER,
+// 92.3 vs 87.4 us, and the whole evaluation did not change; plain loads are used.)
 
 // slab accumulator (multiple of 2^(32j-116), |v| < 2^53 units) -> int64 units
 __device__ __forceinline__ long long slab_to_units(double v, int j) {
@@ -204,13 +191,12 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
     constexpr bool PACKED = MODE == 3 || MODE == 5;
     constexpr bool COMPACT = MODE == 5;
     if (PACKED && have) {
-        const bool nt0 = (a.dbg & 16) != 0;
         const double2 *col = COMPACT ? C.wflux : C.aeff_w0;
-        ix = ld_stream(reinterpret_cast<const int4 *>(C.node_bin) + p, nt0);
-        awa = ld_stream(col + 2 * p, nt0); awb = ld_stream(col + 2 * p + 1, nt0);
+        ix = reinterpret_cast<const int4 *>(C.node_bin)[p];
+        awa = col[2 * p]; awb = col[2 * p + 1];
         if (!COMPACT) {
-            fa = ld_stream(reinterpret_cast<const double2 *>(C.flux) + 2 * p, nt0);
-            fb = ld_stream(reinterpret_cast<const double2 *>(C.flux) + 2 * p + 1, nt0);
+            fa = reinterpret_cast<const double2 *>(C.flux)[2 * p];
+            fb = reinterpret_cast<const double2 *>(C.flux)[2 * p + 1];
         }
     }
 
@@ -274,21 +260,19 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
         // without this the idx -> gather -> use chain is exposed every time).
         while (have) {
             // node < 0 (outside the calc grid): read entry 0, then force P = 0
-            const int gmask = (a.dbg & 8) ? 0 : -1;  // probe: all gathers hit entry 0
-            double2 pa = tab[(ix.x < 0 ? 0 : ix.x) & gmask];
-            double2 pb = tab[(ix.z < 0 ? 0 : ix.z) & gmask];
+            double2 pa = tab[ix.x < 0 ? 0 : ix.x];
+            double2 pb = tab[ix.z < 0 ? 0 : ix.z];
             const int64_t pn = p + step;
             const bool have_n = pn < p_end;
             // unconditional (the last sweep re-reads its own pair, never used): a
             // branch here would make the compiler wait for these loads as well
             const int64_t pl = have_n ? pn : p;
-            const bool nt = (a.dbg & 16) != 0;  // probe: non-temporal loads
-            const int4 ixn = ld_stream(idx4 + pl, nt);
-            const double2 awan = ld_stream(aw + 2 * pl, nt), awbn = ld_stream(aw + 2 * pl + 1, nt);
+            const int4 ixn = idx4[pl];
+            const double2 awan = aw[2 * pl], awbn = aw[2 * pl + 1];
             double2 fan = make_double2(0.0, 0.0), fbn = fan;
             if (!COMPACT) {
-                fan = ld_stream(flux2 + 2 * pl, nt);
-                fbn = ld_stream(flux2 + 2 * pl + 1, nt);
+                fan = flux2[2 * pl];
+                fbn = flux2[2 * pl + 1];
             }
             if (ix.x < 0) pa = make_double2(0.0, 0.0);
             if (ix.z < 0) pb = make_double2(0.0, 0.0);
