@@ -10,10 +10,10 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; rm -rf $OUT; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.stderr
 tail -c 600 $OUT/bench.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --no-cpu-baseline --no-drop-probe > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
 cp $OUT/stats/bench_kernel_stats.csv $OUT/kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing > /dev/null 2> $OUT/pmc_$c.log
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-drop-probe > /dev/null 2> $OUT/pmc_$c.log
   cp $OUT/pmc_$c/p_counter_collection.csv $OUT/pmc_$c.csv
 done
 python3 - <<PY
@@ -24,13 +24,13 @@ def per_launch(path, name):
     return sum(v) / len(v), len(v)
 f, nf = per_launch("$OUT/pmc_FETCH_SIZE.csv", "FETCH_SIZE")
 w, nw = per_launch("$OUT/pmc_WRITE_SIZE.csv", "WRITE_SIZE")
-d = {"kernel": "hist_accumulate_kernel<3,true>", "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "launches": [nf, nw],
+d = {"kernel": "hist_accumulate_kernel<5,true> (compact 24 B/event layout)", "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "launches": [nf, nw],
      "fetch_bytes_corrected": f * 1024 * 2, "write_bytes": w * 1024,
      "hbm_bytes": f * 1024 * 2 + w * 1024,
      "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (bench.py --steps 3 --no-kernel-timing); "
                "FETCH_SIZE is in KiB and on gfx950 reports half of the bytes of 16-B/lane coalesced streams "
                "(MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE exact",
-     "algorithmic_bytes": 399999840}
+     "algorithmic_bytes": 239999904}
 json.dump(d, open("$OUT/traffic.json", "w"), indent=1)
 print(d["hbm_bytes"], d["launches"])
 for r in list(csv.reader(open("$OUT/kernel_stats.csv")))[:8]:
