@@ -271,6 +271,8 @@ class HotPathEngine:
         self.metric_out = torch.zeros(1, dtype=torch.float64, device=self.dev)
         self.metric_status = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.metric_host = torch.zeros(1, dtype=torch.float64).pin_memory()
+        self._metric_host_np = self.metric_host.numpy()
+        self.spin_wait = 50000  # polls of the pinned result (~7 ms) before falling back to a stream sync
         self.fused_tail = True
         self._limbs_zero = self._maps_valid = False
         self._lean = None
@@ -372,7 +374,19 @@ class HotPathEngine:
         if (self.plan is not None and self.indexed and not self.osc_events and self.fused_tail
                 and self.data is not None
                 and len(self.cont) * self.n_bins <= K.FINALIZE_METRIC_MAX):
-            self._lean_eval(params, kind)
+            if self.spin_wait:
+                # The tail kernel's store into pinned host memory is visible a few us before the
+                # stream-completion signal has travelled through the runtime: poll it.  NaN is
+                # the "not yet" marker (a genuine NaN result falls through to the stream sync).
+                h = self._metric_host_np
+                h[0] = np.nan
+                self._lean_eval(params, kind)
+                for _ in range(self.spin_wait):
+                    v = h[0]
+                    if v == v:
+                        return float(v)
+            else:
+                self._lean_eval(params, kind)
         else:
             self.accumulate(params)
             self.allreduce()

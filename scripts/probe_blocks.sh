@@ -1,4 +1,2 @@
-export PYTHONPATH=.
-for t in 1024 512; do for b in 512 768 1024 1536 2048; do
-echo "threads=$t blocks=$b"; PISA_HIP_HIST_THREADS=$t PISA_HIP_HIST_BLOCKS=$b python scripts/dev_probe5.py 1e7 node 2>&1 | grep order
-done; done
+p() { python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.0f evals/s, pipelined %.0f, fused %.1f us' % (d['value'], d['pipelined_evals_per_s'], 1e3*d['phase_ms']['fused_reweight_hist']))"; }
+for b in 512 384 256 192 128; do echo -n "blocks=$b: "; PISA_HIP_HIST_BLOCKS=$b python bench.py --no-cpu-baseline --no-drop-probe 2>&1 | tail -1 | p; done
