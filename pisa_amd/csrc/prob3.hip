@@ -84,7 +84,7 @@ prob3_grid_kernel(const Prob3Consts c, const double *__restrict__ energy, int n_
 
 // ------------------------------------------------------- planned grid form
 // The work of a grid evaluation is tiny (~0.1 GFLOP); what costs is latency: the
-// eigenvalue/projector terms of one (E, density) are a ~8 us dependent chain and a
+// eigenvalue/projector terms of one (E, density) are a ~15 us dependent chain and a
 // row's ordered matrix product is up to 24 dependent 3x3 complex products.  The
 // plan (host, once per Earth model / coszen grid) therefore
 //   * resolves the reference's layer-matrix cache (numba_osc_kernels.py:236-249)
@@ -94,13 +94,14 @@ prob3_grid_kernel(const Prob3Consts c, const double *__restrict__ energy, int n_
 // and an evaluation is two launches:
 //   stage AB  wave = (item, sign, 64 energies): terms of (E, rho) in registers, then
 //             A = sum_k phase_k Q_k for the item's pairs -> amp[side][pair][18][n_e]
-//   stage C   workgroup = (row, sign, 64 energies) x G waves: wave g multiplies its
-//             g-th part of the chain, wave 0 joins the G partial products (LDS),
-//             rotates to the flavour basis and stores P and the gather tables.
-// Stage C associates the product differently from the sequential reference
-// (parts first), so its results agree with prob3_grid_kernel to rounding
-// (~1e-15), not bit for bit.
-constexpr int CHAIN_GROUPS_DEFAULT = 4;
+//   stage C   workgroup = (row, sign, 64 energies) x G waves: the chain is multiplied from
+//             its middle outwards on both sides at once (see prob3_chain_kernel), wave 0
+//             joins the waves' partial products (LDS), rotates to the flavour basis and
+//             stores P and the gather tables.
+// Stage C associates the product differently from the sequential reference and uses
+// fused multiply-adds, so its results agree with prob3_grid_kernel to rounding
+// (<= 1e-13 absolute on the probabilities), not bit for bit.
+constexpr int CHAIN_GROUPS_DEFAULT = 2;
 
 template <bool DECAY>
 __global__ void __launch_bounds__(64)
@@ -134,14 +135,48 @@ prob3_terms_amp_kernel(const Prob3Consts c, const double *__restrict__ energy, i
     }
 }
 
-template <int CHAIN_GROUPS>
-__global__ void __launch_bounds__(64 * CHAIN_GROUPS) __attribute__((amdgpu_waves_per_eu(4, 8)))
+// C = A.B with fused multiply-adds (4 per complex multiply-accumulate instead of 4 mul + 4
+// add).  Stage C is a short dependent sequence of 3x3 complex products per wave: instruction
+// count is latency.  Only used where the product is already associated differently from the
+// sequential reference order (equal to it to rounding either way).
+__device__ __forceinline__ void mat_mul_fma(const mat3 &A, const mat3 &B, mat3 &C) {
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            double re = A.m[i][0].re * B.m[0][j].re;
+            double im = A.m[i][0].re * B.m[0][j].im;
+            re = __builtin_fma(-A.m[i][0].im, B.m[0][j].im, re);
+            im = __builtin_fma(A.m[i][0].im, B.m[0][j].re, im);
+#pragma unroll
+            for (int k = 1; k < 3; k++) {
+                re = __builtin_fma(A.m[i][k].re, B.m[k][j].re, re);
+                im = __builtin_fma(A.m[i][k].re, B.m[k][j].im, im);
+                re = __builtin_fma(-A.m[i][k].im, B.m[k][j].im, re);
+                im = __builtin_fma(A.m[i][k].im, B.m[k][j].re, im);
+            }
+            C.m[i][j] = cmake(re, im);
+        }
+}
+
+// Two-sided form of stage C.  A row's chain, in path order a_0 .. a_{n-1}, is split at its
+// middle element m = n/2:   T = (a_{n-1} .. a_{m+1}) . a_m . (a_{m-1} .. a_0).
+// Step s pairs the out-going layer a_{m+s} with the in-going layer a_{m-s}; for the mirror
+// symmetric paths through the Earth these are the SAME matrix (plan: one pair per distinct
+// matrix of a row), so one load feeds two products,  L <- A . L  and  R <- R . A,  which are
+// independent of each other (instruction-level parallelism where the one-sided form has a
+// single dependent chain).  Wave g of the workgroup takes the g-th part of the steps; wave 0
+// joins  L_{G-1} .. L_0 . a_m . R_0 .. R_{G-1}.  Valid for any sequence (non-mirrored steps just
+// load two matrices); same matrices as the other forms, associated differently.
+template <int G>
+__global__ void __launch_bounds__(64 * G)
 prob3_chain_kernel(const Prob3Consts c, int n_e, const int32_t *__restrict__ row_start,
-                   const int32_t *__restrict__ row_cnt, const int32_t *__restrict__ row_pairs,
-                   int n_cz, int n_pairs, const double *__restrict__ amp, int e_major,
-                   double *__restrict__ prob_nu, double *__restrict__ prob_nubar,
-                   double2 *__restrict__ pepmu) {
-    __shared__ double s_part[(CHAIN_GROUPS > 1 ? CHAIN_GROUPS - 1 : 1) * 18 * 64];  // [group-1][18][lane]
+                    const int32_t *__restrict__ row_cnt, const int32_t *__restrict__ row_pairs,
+                    int n_cz, int n_pairs, const double *__restrict__ amp, int e_major,
+                    double *__restrict__ prob_nu, double *__restrict__ prob_nubar,
+                    double2 *__restrict__ pepmu) {
+    auto MM = [](const mat3 &A_, const mat3 &B_, mat3 &C_) { mat_mul_fma(A_, B_, C_); };
+    __shared__ double s_part[(G > 1 ? G - 1 : 1) * 2 * 18 * 64];  // [group-1][L|R][18][lane]
     const int jcz = blockIdx.x;
     const int side = blockIdx.y;
     const int lane = threadIdx.x & 63;
@@ -152,12 +187,12 @@ prob3_chain_kernel(const Prob3Consts c, int n_e, const int32_t *__restrict__ row
     const Prob3Side &S = c.side[side];
     const int k0 = row_start[jcz];
     const int cnt = row_cnt[jcz];
-    // this wave's part of the chain: layers [t0, t1) in path order
-    const int t0 = (int)(((int64_t)cnt * g) / CHAIN_GROUPS);
-    const int t1 = (int)(((int64_t)cnt * (g + 1)) / CHAIN_GROUPS);
-    auto load_A = [&](int t, mat3 &A) {
-        const int k = row_pairs[k0 + t];
-        const int64_t ns = (int64_t)gridDim.z * 64;
+    const int mid = cnt >> 1;
+    const int n_steps = mid;  // steps s = 1..mid (out-going side may be one shorter)
+    const int s0 = 1 + (int)(((int64_t)n_steps * g) / G);
+    const int s1 = 1 + (int)(((int64_t)n_steps * (g + 1)) / G);
+    const int64_t ns = (int64_t)gridDim.z * 64;
+    auto load_pair = [&](int k, mat3 &A) {
         const double *a = amp + ((int64_t)(side * n_pairs + k) * 18) * ns + ie;
 #pragma unroll
         for (int i = 0; i < 3; i++)
@@ -165,59 +200,85 @@ prob3_chain_kernel(const Prob3Consts c, int n_e, const int32_t *__restrict__ row
             for (int j = 0; j < 3; j++)
                 A.m[i][j] = cmake(a[(int64_t)(6 * i + 2 * j) * ns], a[(int64_t)(6 * i + 2 * j + 1) * ns]);
     };
-    mat3 T;
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) T.m[i][j] = cmake(0.0, 0.0);
-    if (live && t1 > t0) {
-        load_A(t0, T);
-        mat3 A0;
-        if (t0 + 1 < t1) load_A(t0 + 1, A0);
-        for (int t = t0 + 1; t < t1; t++) {
-            mat3 An;
-            if (t + 1 < t1) load_A(t + 1, An);  // next layer in flight during the product
-            mat3 t2;
-            mat_mul(A0, T, t2);  // later layer on the left (numba_osc_kernels.py:281-294)
-            T = t2;
-            A0 = An;
+    mat3 L, R;
+    bool have_l = false, have_r = false;
+    if (live && cnt > 0 && s1 > s0) {
+        mat3 A, An;
+        load_pair(row_pairs[k0 + mid - s0], A);
+        for (int s = s0; s < s1; s++) {
+            const int k_in = row_pairs[k0 + mid - s];
+            const int k_out = mid + s < cnt ? row_pairs[k0 + mid + s] : -1;
+            if (s + 1 < s1) load_pair(row_pairs[k0 + mid - (s + 1)], An);  // next in flight
+            if (have_r) { mat3 t; MM(R, A, t); R = t; } else { R = A; have_r = true; }
+            if (k_out >= 0) {
+                if (k_out != k_in) load_pair(k_out, A);  // not a mirrored pair (workgroup-uniform)
+                if (have_l) { mat3 t; MM(A, L, t); L = t; } else { L = A; have_l = true; }
+            }
+            A = An;
         }
     }
-    if (g > 0 && live && t1 > t0) {
-        double *o = s_part + (g - 1) * 18 * 64 + lane;
+    if (g > 0 && live) {
+        double *o = s_part + (size_t)(g - 1) * 2 * 18 * 64 + lane;
+        if (have_l) {
 #pragma unroll
-        for (int i = 0; i < 3; i++)
+            for (int i = 0; i < 3; i++)
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
-                o[(6 * i + 2 * j) * 64] = T.m[i][j].re;
-                o[(6 * i + 2 * j + 1) * 64] = T.m[i][j].im;
-            }
+                for (int j = 0; j < 3; j++) {
+                    o[(6 * i + 2 * j) * 64] = L.m[i][j].re;
+                    o[(6 * i + 2 * j + 1) * 64] = L.m[i][j].im;
+                }
+        }
+        if (have_r) {
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    o[(18 + 6 * i + 2 * j) * 64] = R.m[i][j].re;
+                    o[(18 + 6 * i + 2 * j + 1) * 64] = R.m[i][j].im;
+                }
+        }
     }
     __syncthreads();
     if (g != 0 || !live) return;
-    bool have = t1 > t0;
-    for (int h = 1; h < CHAIN_GROUPS; h++) {
-        const int h0 = (int)(((int64_t)cnt * h) / CHAIN_GROUPS);
-        const int h1 = (int)(((int64_t)cnt * (h + 1)) / CHAIN_GROUPS);
-        if (h1 <= h0) continue;  // workgroup-uniform
+    // wave 0: T_right = R_0 . R_1 .. (later groups further right), T_left = .. L_1 . L_0
+    for (int h = 1; h < G; h++) {
+        const int h0 = 1 + (int)(((int64_t)n_steps * h) / G);
+        const int h1 = 1 + (int)(((int64_t)n_steps * (h + 1)) / G);
+        if (h1 <= h0 || cnt == 0) continue;  // workgroup-uniform: group h had no steps
+        const double *o = s_part + (size_t)(h - 1) * 2 * 18 * 64 + lane;
         mat3 Ph;
-        const double *o = s_part + (h - 1) * 18 * 64 + lane;
+        // right part of group h always exists when it had steps
 #pragma unroll
         for (int i = 0; i < 3; i++)
 #pragma unroll
-            for (int j = 0; j < 3; j++) Ph.m[i][j] = cmake(o[(6 * i + 2 * j) * 64], o[(6 * i + 2 * j + 1) * 64]);
-        if (have) {
-            mat3 t2;
-            mat_mul(Ph, T, t2);
-            T = t2;
-        } else {
-            T = Ph;
-            have = true;
+            for (int j = 0; j < 3; j++)
+                Ph.m[i][j] = cmake(o[(18 + 6 * i + 2 * j) * 64], o[(18 + 6 * i + 2 * j + 1) * 64]);
+        if (have_r) { mat3 t; MM(R, Ph, t); R = t; } else { R = Ph; have_r = true; }
+        // its left part exists unless its only step was the unpaired last one
+        const bool h_has_l = mid + h0 < cnt;
+        if (h_has_l) {
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+                    Ph.m[i][j] = cmake(o[(6 * i + 2 * j) * 64], o[(6 * i + 2 * j + 1) * 64]);
+            if (have_l) { mat3 t; MM(Ph, L, t); L = t; } else { L = Ph; have_l = true; }
         }
     }
+    mat3 T;
+    if (cnt > 0) {
+        load_pair(row_pairs[k0 + mid], T);
+        if (have_r) { mat3 t; MM(T, R, t); T = t; }
+        if (have_l) { mat3 t; MM(L, T, t); T = t; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) T.m[i][j] = cmake(0.0, 0.0);
+    }
     mat3 t2, Tf;
-    mat_mul(T, S.Ud, t2);
-    mat_mul(S.U, t2, Tf);
+    MM(T, S.Ud, t2);
+    MM(S.U, t2, Tf);
     double P[9];
 #pragma unroll
     for (int i = 0; i < 3; i++)
@@ -803,7 +864,7 @@ PISA_API int pisa_hip_prob3_grid_planned(const pisa_hip_prob3_params *h_params,
     static const int groups = []() {
         const char *v = getenv("PISA_HIP_CHAIN_GROUPS");
         int g = v ? atoi(v) : CHAIN_GROUPS_DEFAULT;
-        return (g == 1 || g == 2 || g == 4 || g == 8) ? g : CHAIN_GROUPS_DEFAULT;
+        return (g == 1 || g == 2 || g == 4) ? g : CHAIN_GROUPS_DEFAULT;
     }();
     dim3 cblock(64 * groups), cgrid((unsigned)plan->n_cz, 2, tiles);
     if (plan->n_items > 0) {
@@ -819,7 +880,7 @@ PISA_API int pisa_hip_prob3_grid_planned(const pisa_hip_prob3_params *h_params,
 #define CHAIN(G) hipLaunchKernelGGL(prob3_chain_kernel<G>, cgrid, cblock, 0, s, c, (int)n_e, plan->d_row_start, \
                        plan->d_row_cnt, plan->d_row_pairs, plan->n_cz, plan->n_pairs, plan->d_amp,          \
                        (int)e_major, d_prob_nu, d_prob_nubar, (double2 *)d_pepmu)
-    if (groups == 1) CHAIN(1); else if (groups == 2) CHAIN(2); else if (groups == 8) CHAIN(8); else CHAIN(4);
+    if (groups == 1) CHAIN(1); else if (groups == 4) CHAIN(4); else CHAIN(2);
 #undef CHAIN
     PISA_CHECK_LAUNCH("prob3_chain_kernel");
     return PISA_HIP_OK;
