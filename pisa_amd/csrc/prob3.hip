@@ -19,22 +19,6 @@
 
 namespace pisa {
 
-// P[init][final] of one node -> full matrix and/or the compact gather tables
-// pepmu[side][flav][node] = (P[e->flav], P[mu->flav]) read by the fused kernel
-__device__ __forceinline__ void store_node(const double (&P)[9], int64_t node, int64_t n_nodes,
-                                           int side, double *__restrict__ out,
-                                           double2 *__restrict__ pepmu) {
-    if (out) {
-#pragma unroll
-        for (int k = 0; k < 9; k++) out[9 * node + k] = P[k];
-    }
-    if (pepmu) {
-#pragma unroll
-        for (int f = 0; f < 3; f++)
-            pepmu[((int64_t)side * 3 + f) * n_nodes + node] = make_double2(P[f], P[3 + f]);
-    }
-}
-
 // ----------------------------------------------------------------- array form
 template <bool DECAY>
 __global__ void __launch_bounds__(256)
@@ -80,213 +64,6 @@ prob3_grid_kernel(const Prob3Consts c, const double *__restrict__ energy, int n_
         int64_t node = e_major ? (int64_t)ie * n_cz + jcz : (int64_t)jcz * n_e + ie;
         store_node(P, node, (int64_t)n_e * n_cz, side, out, pepmu);
     }
-}
-
-// ------------------------------------------------------- planned grid form
-// The work of a grid evaluation is tiny (~0.1 GFLOP); what costs is latency: the
-// eigenvalue/projector terms of one (E, density) are a ~15 us dependent chain and a
-// row's ordered matrix product is up to 24 dependent 3x3 complex products.  The
-// plan (host, once per Earth model / coszen grid) therefore
-//   * resolves the reference's layer-matrix cache (numba_osc_kernels.py:236-249)
-//     and gives mirrored layers of a row ONE matrix ("pair" = (density, length)),
-//   * cuts the pairs of each distinct density into work items of a few pairs,
-//   * lists every row's chain as pair indices in path order,
-// and an evaluation is two launches:
-//   stage AB  wave = (item, sign, 64 energies): terms of (E, rho) in registers, then
-//             A = sum_k phase_k Q_k for the item's pairs -> amp[side][pair][18][n_e]
-//   stage C   workgroup = (row, sign, 64 energies) x G waves: the chain is multiplied from
-//             its middle outwards on both sides at once (see prob3_chain_kernel), wave 0
-//             joins the waves' partial products (LDS), rotates to the flavour basis and
-//             stores P and the gather tables.
-// Stage C associates the product differently from the sequential reference and uses
-// fused multiply-adds, so its results agree with prob3_grid_kernel to rounding
-// (<= 1e-13 absolute on the probabilities), not bit for bit.
-constexpr int CHAIN_GROUPS_DEFAULT = 2;
-
-template <bool DECAY>
-__global__ void __launch_bounds__(64)
-prob3_terms_amp_kernel(const Prob3Consts c, const double *__restrict__ energy, int n_e,
-                       const double *__restrict__ rho_unique, const int32_t *__restrict__ item_u,
-                       const int32_t *__restrict__ item_p0, const int32_t *__restrict__ item_cnt,
-                       const double *__restrict__ pair_dist, int n_pairs,
-                       double *__restrict__ amp) {
-    const int item = blockIdx.x;
-    const int side = blockIdx.y;
-    const int ie = blockIdx.z * 64 + threadIdx.x;
-    if (ie >= n_e) return;
-    const double e = energy[ie];
-    double rec[PROB3_NF];
-    auto store = [&](int f, double v) { rec[f] = v; };
-    eigen_terms<DECAY>(c.side[side], c.dm, e, rho_unique[item_u[item]], store);
-    auto load = [&](int f) { return rec[f]; };
-    const int p0 = item_p0[item], cnt = item_cnt[item];
-    for (int q = 0; q < cnt; q++) {
-        mat3 A;
-        amplitude_from_terms<DECAY>(load, pair_dist[p0 + q] / e, A);
-        const int64_t ns = (int64_t)gridDim.z * 64;  // energy stride: whole tiles, cache-line aligned
-        double *o = amp + ((int64_t)(side * n_pairs + p0 + q) * 18) * ns + ie;
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                o[(int64_t)(6 * i + 2 * j) * ns] = A.m[i][j].re;
-                o[(int64_t)(6 * i + 2 * j + 1) * ns] = A.m[i][j].im;
-            }
-    }
-}
-
-// C = A.B with fused multiply-adds (4 per complex multiply-accumulate instead of 4 mul + 4
-// add).  Stage C is a short dependent sequence of 3x3 complex products per wave: instruction
-// count is latency.  Only used where the product is already associated differently from the
-// sequential reference order (equal to it to rounding either way).
-__device__ __forceinline__ void mat_mul_fma(const mat3 &A, const mat3 &B, mat3 &C) {
-#pragma unroll
-    for (int j = 0; j < 3; j++)
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-            double re = A.m[i][0].re * B.m[0][j].re;
-            double im = A.m[i][0].re * B.m[0][j].im;
-            re = __builtin_fma(-A.m[i][0].im, B.m[0][j].im, re);
-            im = __builtin_fma(A.m[i][0].im, B.m[0][j].re, im);
-#pragma unroll
-            for (int k = 1; k < 3; k++) {
-                re = __builtin_fma(A.m[i][k].re, B.m[k][j].re, re);
-                im = __builtin_fma(A.m[i][k].re, B.m[k][j].im, im);
-                re = __builtin_fma(-A.m[i][k].im, B.m[k][j].im, re);
-                im = __builtin_fma(A.m[i][k].im, B.m[k][j].re, im);
-            }
-            C.m[i][j] = cmake(re, im);
-        }
-}
-
-// Two-sided form of stage C.  A row's chain, in path order a_0 .. a_{n-1}, is split at its
-// middle element m = n/2:   T = (a_{n-1} .. a_{m+1}) . a_m . (a_{m-1} .. a_0).
-// Step s pairs the out-going layer a_{m+s} with the in-going layer a_{m-s}; for the mirror
-// symmetric paths through the Earth these are the SAME matrix (plan: one pair per distinct
-// matrix of a row), so one load feeds two products,  L <- A . L  and  R <- R . A,  which are
-// independent of each other (instruction-level parallelism where the one-sided form has a
-// single dependent chain).  Wave g of the workgroup takes the g-th part of the steps; wave 0
-// joins  L_{G-1} .. L_0 . a_m . R_0 .. R_{G-1}.  Valid for any sequence (non-mirrored steps just
-// load two matrices); same matrices as the other forms, associated differently.
-template <int G>
-__global__ void __launch_bounds__(64 * G)
-prob3_chain_kernel(const Prob3Consts c, int n_e, const int32_t *__restrict__ row_start,
-                    const int32_t *__restrict__ row_cnt, const int32_t *__restrict__ row_pairs,
-                    int n_cz, int n_pairs, const double *__restrict__ amp, int e_major,
-                    double *__restrict__ prob_nu, double *__restrict__ prob_nubar,
-                    double2 *__restrict__ pepmu) {
-    auto MM = [](const mat3 &A_, const mat3 &B_, mat3 &C_) { mat_mul_fma(A_, B_, C_); };
-    __shared__ double s_part[(G > 1 ? G - 1 : 1) * 2 * 18 * 64];  // [group-1][L|R][18][lane]
-    const int jcz = blockIdx.x;
-    const int side = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int g = threadIdx.x >> 6;
-    const int ie = blockIdx.z * 64 + lane;
-    const bool live = ie < n_e;
-    double *out = side == 0 ? prob_nu : prob_nubar;
-    const Prob3Side &S = c.side[side];
-    const int k0 = row_start[jcz];
-    const int cnt = row_cnt[jcz];
-    const int mid = cnt >> 1;
-    const int n_steps = mid;  // steps s = 1..mid (out-going side may be one shorter)
-    const int s0 = 1 + (int)(((int64_t)n_steps * g) / G);
-    const int s1 = 1 + (int)(((int64_t)n_steps * (g + 1)) / G);
-    const int64_t ns = (int64_t)gridDim.z * 64;
-    auto load_pair = [&](int k, mat3 &A) {
-        const double *a = amp + ((int64_t)(side * n_pairs + k) * 18) * ns + ie;
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-            for (int j = 0; j < 3; j++)
-                A.m[i][j] = cmake(a[(int64_t)(6 * i + 2 * j) * ns], a[(int64_t)(6 * i + 2 * j + 1) * ns]);
-    };
-    mat3 L, R;
-    bool have_l = false, have_r = false;
-    if (live && cnt > 0 && s1 > s0) {
-        mat3 A, An;
-        load_pair(row_pairs[k0 + mid - s0], A);
-        for (int s = s0; s < s1; s++) {
-            const int k_in = row_pairs[k0 + mid - s];
-            const int k_out = mid + s < cnt ? row_pairs[k0 + mid + s] : -1;
-            if (s + 1 < s1) load_pair(row_pairs[k0 + mid - (s + 1)], An);  // next in flight
-            if (have_r) { mat3 t; MM(R, A, t); R = t; } else { R = A; have_r = true; }
-            if (k_out >= 0) {
-                if (k_out != k_in) load_pair(k_out, A);  // not a mirrored pair (workgroup-uniform)
-                if (have_l) { mat3 t; MM(A, L, t); L = t; } else { L = A; have_l = true; }
-            }
-            A = An;
-        }
-    }
-    if (g > 0 && live) {
-        double *o = s_part + (size_t)(g - 1) * 2 * 18 * 64 + lane;
-        if (have_l) {
-#pragma unroll
-            for (int i = 0; i < 3; i++)
-#pragma unroll
-                for (int j = 0; j < 3; j++) {
-                    o[(6 * i + 2 * j) * 64] = L.m[i][j].re;
-                    o[(6 * i + 2 * j + 1) * 64] = L.m[i][j].im;
-                }
-        }
-        if (have_r) {
-#pragma unroll
-            for (int i = 0; i < 3; i++)
-#pragma unroll
-                for (int j = 0; j < 3; j++) {
-                    o[(18 + 6 * i + 2 * j) * 64] = R.m[i][j].re;
-                    o[(18 + 6 * i + 2 * j + 1) * 64] = R.m[i][j].im;
-                }
-        }
-    }
-    __syncthreads();
-    if (g != 0 || !live) return;
-    // wave 0: T_right = R_0 . R_1 .. (later groups further right), T_left = .. L_1 . L_0
-    for (int h = 1; h < G; h++) {
-        const int h0 = 1 + (int)(((int64_t)n_steps * h) / G);
-        const int h1 = 1 + (int)(((int64_t)n_steps * (h + 1)) / G);
-        if (h1 <= h0 || cnt == 0) continue;  // workgroup-uniform: group h had no steps
-        const double *o = s_part + (size_t)(h - 1) * 2 * 18 * 64 + lane;
-        mat3 Ph;
-        // right part of group h always exists when it had steps
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-            for (int j = 0; j < 3; j++)
-                Ph.m[i][j] = cmake(o[(18 + 6 * i + 2 * j) * 64], o[(18 + 6 * i + 2 * j + 1) * 64]);
-        if (have_r) { mat3 t; MM(R, Ph, t); R = t; } else { R = Ph; have_r = true; }
-        // its left part exists unless its only step was the unpaired last one
-        const bool h_has_l = mid + h0 < cnt;
-        if (h_has_l) {
-#pragma unroll
-            for (int i = 0; i < 3; i++)
-#pragma unroll
-                for (int j = 0; j < 3; j++)
-                    Ph.m[i][j] = cmake(o[(6 * i + 2 * j) * 64], o[(6 * i + 2 * j + 1) * 64]);
-            if (have_l) { mat3 t; MM(Ph, L, t); L = t; } else { L = Ph; have_l = true; }
-        }
-    }
-    mat3 T;
-    if (cnt > 0) {
-        load_pair(row_pairs[k0 + mid], T);
-        if (have_r) { mat3 t; MM(T, R, t); T = t; }
-        if (have_l) { mat3 t; MM(L, T, t); T = t; }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-            for (int j = 0; j < 3; j++) T.m[i][j] = cmake(0.0, 0.0);
-    }
-    mat3 t2, Tf;
-    MM(T, S.Ud, t2);
-    MM(S.U, t2, Tf);
-    double P[9];
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++)
-            P[3 * i + j] = Tf.m[j][i].re * Tf.m[j][i].re + Tf.m[j][i].im * Tf.m[j][i].im;
-    int64_t node = e_major ? (int64_t)ie * n_cz + jcz : (int64_t)jcz * n_e + ie;
-    store_node(P, node, (int64_t)n_e * n_cz, side, out, pepmu);
 }
 
 // ------------------------------------------------------------------- layers
@@ -688,200 +465,3 @@ PISA_API int pisa_hip_fill_probs(const double *d_probability, int64_t init_flav,
     return PISA_HIP_OK;
 }
 
-// ------------------------------------------------------------ grid plan (host)
-struct pisa_hip_grid_plan {
-    int n_cz, n_layers, n_unique, n_pairs, n_items, n_chain;
-    int32_t *d_item_u;     // [n_items] distinct-density index of the item
-    int32_t *d_item_p0;    // [n_items] first pair of the item
-    int32_t *d_item_cnt;   // [n_items] pairs of the item (consecutive, same density)
-    double *d_pair_dist;   // [n_pairs] (cache-resolved) layer length of each pair
-    int32_t *d_row_start;  // [n_cz] first chain entry of the row
-    int32_t *d_row_cnt;    // [n_cz] crossed layers of the row
-    int32_t *d_row_pairs;  // [n_chain] pair index per crossed layer, in path order
-    double *d_rho;         // [n_unique]
-    double *d_amp;         // stage-AB amplitudes [2][n_pairs][18][n_e]
-    int n_e_alloc;
-    // host copies for re-cutting the items when n_e changes
-    int32_t *h_pair_u;
-    int items_for_n_e;
-};
-
-PISA_API int pisa_hip_grid_plan_destroy(pisa_hip_grid_plan *p) {
-    if (!p) return PISA_HIP_OK;
-    void *ptrs[] = {p->d_item_u, p->d_item_p0, p->d_item_cnt, p->d_pair_dist, p->d_row_start,
-                    p->d_row_cnt, p->d_row_pairs, p->d_rho, p->d_amp};
-    for (void *q : ptrs)
-        if (q) (void)hipFree(q);
-    delete[] p->h_pair_u;
-    delete p;
-    return PISA_HIP_OK;
-}
-
-// Cut the (density-sorted) pairs into items of <= ch consecutive pairs of one density.
-// ch is chosen so that stage AB has about 2000 waves: enough to occupy the chip
-// with the ~8 us terms chain running once per wave.
-static int cut_items(pisa_hip_grid_plan *p, int n_e) {
-    const int tiles = (n_e + 63) / 64;
-    int ch = (int)(((int64_t)p->n_pairs * 2 * tiles + 2047) / 2048);
-    if (ch < 1) ch = 1;
-    if (const char *v = getenv("PISA_HIP_PROB3_CH")) ch = atoi(v) > 0 ? atoi(v) : ch;  // development probe
-    const int np = p->n_pairs;
-    int32_t *iu = new int32_t[np + 1], *ip0 = new int32_t[np + 1], *icnt = new int32_t[np + 1];
-    int ni = 0;
-    for (int k = 0; k < np;) {
-        int e = k;
-        while (e < np && e - k < ch && p->h_pair_u[e] == p->h_pair_u[k]) e++;
-        iu[ni] = p->h_pair_u[k]; ip0[ni] = k; icnt[ni] = e - k;
-        ni++;
-        k = e;
-    }
-    int rc = 0;
-    for (void *q : {(void *)p->d_item_u, (void *)p->d_item_p0, (void *)p->d_item_cnt})
-        if (q) (void)hipFree(q);
-    p->d_item_u = p->d_item_p0 = p->d_item_cnt = nullptr;
-    size_t bytes = (size_t)(ni > 0 ? ni : 1) * 4;
-    rc = check_hip(hipMalloc(&p->d_item_u, bytes), "hipMalloc");
-    if (!rc) rc = check_hip(hipMalloc(&p->d_item_p0, bytes), "hipMalloc");
-    if (!rc) rc = check_hip(hipMalloc(&p->d_item_cnt, bytes), "hipMalloc");
-    if (!rc && ni > 0) rc = check_hip(hipMemcpy(p->d_item_u, iu, (size_t)ni * 4, hipMemcpyHostToDevice), "h2d");
-    if (!rc && ni > 0) rc = check_hip(hipMemcpy(p->d_item_p0, ip0, (size_t)ni * 4, hipMemcpyHostToDevice), "h2d");
-    if (!rc && ni > 0) rc = check_hip(hipMemcpy(p->d_item_cnt, icnt, (size_t)ni * 4, hipMemcpyHostToDevice), "h2d");
-    delete[] iu; delete[] ip0; delete[] icnt;
-    p->n_items = ni;
-    p->items_for_n_e = n_e;
-    return rc;
-}
-
-PISA_API int pisa_hip_grid_plan_create(const double *d_densities, const double *d_distances,
-                                       int32_t n_cz, int32_t n_layers,
-                                       pisa_hip_grid_plan **out) {
-    if (!out || n_cz < 1 || n_layers < 1 || !d_densities || !d_distances) return PISA_HIP_ERR_INVALID;
-    if (n_layers > PISA_HIP_MAX_LAYERS) return PISA_HIP_ERR_LAYERS;
-    size_t n = (size_t)n_cz * n_layers;
-    double *rho = new double[n], *dist = new double[n], *pdist = new double[n + 1];
-    int32_t *pu = new int32_t[n + 1], *rstart = new int32_t[n_cz], *rcnt = new int32_t[n_cz];
-    int32_t *chain = new int32_t[n + 1], *layer_pair = new int32_t[n_layers];
-    double *uniq = new double[n + 1];
-    int nu = 0, np = 0, nc = 0;
-    int rc = check_hip(hipMemcpy(rho, d_densities, n * 8, hipMemcpyDeviceToHost), "d2h");
-    if (!rc) rc = check_hip(hipMemcpy(dist, d_distances, n * 8, hipMemcpyDeviceToHost), "d2h");
-    if (!rc) {
-        for (int r = 0; r < n_cz; r++) {
-            const double *rr = rho + (size_t)r * n_layers, *dd = dist + (size_t)r * n_layers;
-            rstart[r] = nc;
-            for (int i = 0; i < n_layers; i++) {
-                layer_pair[i] = -1;
-                if (!(dd[i] > 0.0)) continue;
-                // follow the reference's cache matches (numba_osc_kernels.py:236-249)
-                // to the layer whose matrix is actually computed
-                int cur = i;
-                double cr = rr[i], cd = dd[i];
-                while (true) {
-                    int found = -1;
-                    for (int j = 0; j < cur; j++)
-                        if (dd[j] > 0.0 && fabs(rr[j] - cr) < 1e-5 && fabs(dd[j] - cd) < 1e-5) found = j;
-                    if (found < 0) break;
-                    cur = found; cr = rr[cur]; cd = dd[cur];
-                }
-                if (cur != i) {
-                    layer_pair[i] = layer_pair[cur];  // the same matrix, stored once
-                } else {
-                    int u = -1;
-                    for (int k = 0; k < nu; k++)
-                        if (uniq[k] == cr) { u = k; break; }
-                    if (u < 0) { u = nu; uniq[nu++] = cr; }
-                    pu[np] = u;
-                    pdist[np] = cd;
-                    layer_pair[i] = np++;
-                }
-                chain[nc++] = layer_pair[i];
-            }
-            rcnt[r] = nc - rstart[r];
-        }
-    }
-    // renumber the pairs sorted by density so that an item is a run of consecutive pairs
-    int32_t *order = new int32_t[np + 1], *newid = new int32_t[np + 1];
-    double *sdist = new double[np + 1];
-    int32_t *su = new int32_t[np + 1];
-    {
-        int w = 0;
-        for (int u = 0; u < nu; u++)
-            for (int k = 0; k < np; k++)
-                if (pu[k] == u) order[w++] = k;
-        for (int k = 0; k < np; k++) { newid[order[k]] = k; sdist[k] = pdist[order[k]]; su[k] = pu[order[k]]; }
-        for (int k = 0; k < nc; k++) chain[k] = newid[chain[k]];
-    }
-    pisa_hip_grid_plan *p = nullptr;
-    if (!rc) {
-        p = new pisa_hip_grid_plan();
-        memset(p, 0, sizeof(*p));
-        p->n_cz = n_cz; p->n_layers = n_layers;
-        p->n_unique = nu > 0 ? nu : 1;
-        p->n_pairs = np;
-        p->n_chain = nc;
-        p->h_pair_u = su;
-        su = nullptr;
-        if (nu == 0) uniq[0] = 0.0;
-        size_t npa = np > 0 ? np : 1, nca = nc > 0 ? nc : 1;
-        rc = check_hip(hipMalloc(&p->d_pair_dist, npa * 8), "hipMalloc");
-        if (!rc) rc = check_hip(hipMalloc(&p->d_row_start, (size_t)n_cz * 4), "hipMalloc");
-        if (!rc) rc = check_hip(hipMalloc(&p->d_row_cnt, (size_t)n_cz * 4), "hipMalloc");
-        if (!rc) rc = check_hip(hipMalloc(&p->d_row_pairs, nca * 4), "hipMalloc");
-        if (!rc) rc = check_hip(hipMalloc(&p->d_rho, (size_t)p->n_unique * 8), "hipMalloc");
-        if (!rc && np > 0) rc = check_hip(hipMemcpy(p->d_pair_dist, sdist, (size_t)np * 8, hipMemcpyHostToDevice), "h2d");
-        if (!rc) rc = check_hip(hipMemcpy(p->d_row_start, rstart, (size_t)n_cz * 4, hipMemcpyHostToDevice), "h2d");
-        if (!rc) rc = check_hip(hipMemcpy(p->d_row_cnt, rcnt, (size_t)n_cz * 4, hipMemcpyHostToDevice), "h2d");
-        if (!rc && nc > 0) rc = check_hip(hipMemcpy(p->d_row_pairs, chain, (size_t)nc * 4, hipMemcpyHostToDevice), "h2d");
-        if (!rc) rc = check_hip(hipMemcpy(p->d_rho, uniq, (size_t)p->n_unique * 8, hipMemcpyHostToDevice), "h2d");
-    }
-    delete[] rho; delete[] dist; delete[] pdist; delete[] pu; delete[] rstart; delete[] rcnt; delete[] uniq;
-    delete[] chain; delete[] layer_pair; delete[] order; delete[] newid; delete[] sdist; delete[] su;
-    if (rc && p) { pisa_hip_grid_plan_destroy(p); p = nullptr; }
-    *out = p;
-    return rc;
-}
-
-PISA_API int pisa_hip_prob3_grid_planned(const pisa_hip_prob3_params *h_params,
-                                         pisa_hip_grid_plan *plan, const double *d_energy,
-                                         int32_t n_e, int32_t e_major, double *d_prob_nu,
-                                         double *d_prob_nubar, double *d_pepmu, void *stream) {
-    if (!plan || n_e < 1 || !d_energy) return PISA_HIP_ERR_INVALID;
-    Prob3Consts c;
-    int rc = make_consts(h_params, c);
-    if (rc) return rc;
-    if (plan->n_e_alloc < n_e) {
-        if (plan->d_amp) (void)hipFree(plan->d_amp);
-        plan->d_amp = nullptr;
-        plan->n_e_alloc = 0;
-        size_t amp_bytes = (size_t)2 * (plan->n_pairs > 0 ? plan->n_pairs : 1) * 18 * (((size_t)n_e + 63) / 64 * 64) * sizeof(double);
-        PISA_TRY_HIP(hipMalloc(&plan->d_amp, amp_bytes));
-        plan->n_e_alloc = n_e;
-    }
-    if (plan->items_for_n_e != n_e && (rc = cut_items(plan, n_e))) return rc;
-    hipStream_t s = as_stream(stream);
-    const unsigned tiles = (unsigned)((n_e + 63) / 64);
-    dim3 ablock(64), agrid((unsigned)(plan->n_items > 0 ? plan->n_items : 1), 2, tiles);
-    static const int groups = []() {
-        const char *v = getenv("PISA_HIP_CHAIN_GROUPS");
-        int g = v ? atoi(v) : CHAIN_GROUPS_DEFAULT;
-        return (g == 1 || g == 2 || g == 4) ? g : CHAIN_GROUPS_DEFAULT;
-    }();
-    dim3 cblock(64 * groups), cgrid((unsigned)plan->n_cz, 2, tiles);
-    if (plan->n_items > 0) {
-        if (c.decay)
-            hipLaunchKernelGGL(prob3_terms_amp_kernel<true>, agrid, ablock, 0, s, c, d_energy, (int)n_e,
-                               plan->d_rho, plan->d_item_u, plan->d_item_p0, plan->d_item_cnt,
-                               plan->d_pair_dist, plan->n_pairs, plan->d_amp);
-        else
-            hipLaunchKernelGGL(prob3_terms_amp_kernel<false>, agrid, ablock, 0, s, c, d_energy, (int)n_e,
-                               plan->d_rho, plan->d_item_u, plan->d_item_p0, plan->d_item_cnt,
-                               plan->d_pair_dist, plan->n_pairs, plan->d_amp);
-    }
-#define CHAIN(G) hipLaunchKernelGGL(prob3_chain_kernel<G>, cgrid, cblock, 0, s, c, (int)n_e, plan->d_row_start, \
-                       plan->d_row_cnt, plan->d_row_pairs, plan->n_cz, plan->n_pairs, plan->d_amp,          \
-                       (int)e_major, d_prob_nu, d_prob_nubar, (double2 *)d_pepmu)
-    if (groups == 1) CHAIN(1); else if (groups == 4) CHAIN(4); else CHAIN(2);
-#undef CHAIN
-    PISA_CHECK_LAUNCH("prob3_chain_kernel");
-    return PISA_HIP_OK;
-}

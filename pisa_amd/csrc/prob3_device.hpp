@@ -740,4 +740,21 @@ __device__ __forceinline__ void propagate_path_nested(const Prob3Side &S, const 
             P[3 * i + j] = Tf.m[j][i].re * Tf.m[j][i].re + Tf.m[j][i].im * Tf.m[j][i].im;
 }
 
+// P[init][final] of one node -> full matrix and/or the compact gather tables
+// pepmu[side][flav][node] = (P[e->flav], P[mu->flav]) read by the fused kernel
+__device__ __forceinline__ void store_node(const double (&P)[9], int64_t node, int64_t n_nodes,
+                                           int side, double *__restrict__ out,
+                                           double2 *__restrict__ pepmu) {
+    if (out) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) out[9 * node + k] = P[k];
+    }
+    if (pepmu) {
+#pragma unroll
+        for (int f = 0; f < 3; f++)
+            pepmu[((int64_t)side * 3 + f) * n_nodes + node] = make_double2(P[f], P[3 + f]);
+    }
+}
+
+
 }  // namespace pisa
