@@ -1,3 +1,10 @@
 export PYTHONPATH=.
-for f in 0 1; do for g in 1 2 4; do echo -n "two-sided G=$g fma=$f: "; PISA_HIP_CHAIN_FMA=$f PISA_HIP_CHAIN_TWO_SIDED=1 PISA_HIP_CHAIN_GROUPS=$g python scripts/dev_probe8.py; done; done
-PISA_HIP_CHAIN_FMA=1 PISA_HIP_CHAIN_TWO_SIDED=1 PISA_HIP_CHAIN_GROUPS=2 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_pipeline.py -x -q 2>&1 | tail -3
+for ch in 1 2 3 4 8; do echo -n "ch=$ch: "; PISA_HIP_PROB3_CH=$ch python scripts/dev_probe8.py; done
+cd /tmp && export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_prob3; rm -rf $OUT; mkdir -p $OUT; cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o p -- python3 scripts/dev_probe8.py > /dev/null 2> $OUT/stderr.log
+python3 - <<PY
+import csv
+for r in list(csv.reader(open("$OUT/p_kernel_stats.csv")))[:4]:
+    print(r[0][:60].ljust(60), r[1:5])
+PY
