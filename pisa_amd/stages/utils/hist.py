@@ -94,8 +94,10 @@ class hist(Stage):  # pylint: disable=invalid-name
                                 nu_flux=c[flux_key], weighted_aeff=c["weighted_aeff"],
                                 initial_weights=c["initial_weights"],
                                 sample=[s.cpu().numpy() for s in self._samples[c.name]], scale=1.0))
+            # compact columns: initial_weights*weighted_aeff folded into the flux pair once
+            # (refreshed by update_flux below whenever a flux systematic moved)
             self._engine = HotPathEngine(evs, grid, self._reg_binning, None, 0, rank=rank,
-                                         world_size=world, external_tables=True)
+                                         world_size=world, external_tables=True, compact=True)
             self._engine_flux_ids = [id(c.current_data[flux_key]) for c in conts]
         eng = self._engine
         for i, (c, ch) in enumerate(zip(conts, chains)):
