@@ -294,7 +294,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True,
-            "scaling": "weak" if weak else "strong",
+            "scaling": "strong" if args.strong_scaling else "weak",  # identical workloads at N = 1
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic (toy_event_generator-style E/coszen, builder-defined reco/flux/aeff; see pisa_amd/synthetic.py)",
