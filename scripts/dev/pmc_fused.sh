@@ -9,7 +9,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_I
            "SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_LDS" \
            "SQ_INST_LEVEL_VMEM TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum SQ_WAVES"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/p$i -o p -- python3 $GRAFT_REPO_ROOT/scripts/dev_pmc_target.py > /dev/null 2> $OUT/p$i.log
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/p$i -o p -- python3 $GRAFT_REPO_ROOT/scripts/dev/dev_pmc_target.py > /dev/null 2> $OUT/p$i.log
 done
 python3 - <<PY
 import csv, glob, collections
