@@ -99,6 +99,47 @@ def bin_window_order(obin, n_bins, lds_window=682):
     return perm1[torch.argsort(key, stable=True)]
 
 
+def lds_bank_order(obin, window=4096, banks=32):
+    """Second-level event order (applied on top of the node sort) that takes the LDS bank
+    conflicts out of the deposits.
+
+    An fp64 LDS accumulator occupies one of `banks` = 32 bank pairs, selected by the output
+    bin modulo 32 (all other terms of the accumulator address are multiples of 32 elements).
+    The 32 lanes of a half-wavefront deposit the k-th event of their pair in one `ds_add_f64`;
+    if those 32 events have 32 different bins modulo 32 the instruction is conflict free.
+    Inside windows of `window` events (so the node locality of the table gathers survives)
+    the events are therefore dealt round-robin over the 32 residues, and the emitted sequence
+    is laid out so that 32 consecutive emissions land in the same slot (first or second event)
+    of 32 consecutive pairs.  The accumulation is exact, so this is free to choose.
+    Returns a permutation (device int64) of arange(n)."""
+    n = obin.numel()
+    dev = obin.device
+    idx = torch.arange(n, device=dev)
+    n_full = (n // window) * window
+    if n_full == 0:
+        return idx
+    b = obin[:n_full].long()
+    # events outside the binning deposit nothing: spread them evenly over the residues
+    res = torch.where(b >= 0, b % banks, idx[:n_full] % banks)
+    win = idx[:n_full] // window
+    key1 = win * banks + res
+    order1 = torch.argsort(key1, stable=True)
+    k1 = key1[order1]
+    start = torch.ones(n_full, dtype=torch.bool, device=dev)
+    start[1:] = k1[1:] != k1[:-1]
+    pos = torch.arange(n_full, device=dev)
+    group_start = torch.cummax(torch.where(start, pos, torch.zeros_like(pos)), 0).values
+    rank = pos - group_start                       # k-th event of its (window, residue) queue
+    key2 = (win[order1] * (window + 1) + rank) * banks + res[order1]
+    seq = order1[torch.argsort(key2, stable=True)]  # emission order: one event per residue in turn
+    s = pos % window
+    blk, t = s // 64, s % 64
+    slot = (pos // window) * window + 2 * (blk * 32 + (t % 32)) + (t // 32)
+    perm = idx.clone()
+    perm[slot] = seq
+    return perm
+
+
 LIMB_BITS, LIMB_LSB, N_LIMBS = 32, 116, 6
 
 
@@ -135,7 +176,8 @@ class HotPathEngine:
 
     def __init__(self, containers, grid, out_binning, earth, max_layers, rank=0, world_size=1,
                  group=None, indexed=True, planned=True, packed=True, sort_events=True,
-                 external_tables=False, osc_mode="grid", drop_unbinned=False, compact=False):
+                 external_tables=False, osc_mode="grid", drop_unbinned=False, compact=False,
+                 lds_order=True):
         self.dev = K.device()
         assert osc_mode in ("grid", "events")
         self.osc_events = osc_mode == "events"
@@ -212,6 +254,8 @@ class HotPathEngine:
                         perm = bin_window_order(obin, self.n_bins)
                     else:
                         perm = torch.argsort(node, stable=True)
+                if lds_order and perm is not None and sort_events != "bin" and self.n_bins * 96 <= 65536:
+                    perm = perm[lds_bank_order(obin[perm])]
                 if drop_unbinned:
                     # an event outside the output binning (or outside the calc grid: P = 0)
                     # adds nothing to any map, whatever the parameters: the coordinates are

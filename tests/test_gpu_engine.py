@@ -37,8 +37,8 @@ def test_bin_run_order_is_bit_identical(n_events):
     wl = synthetic.Workload(n_events=n_events, grid=(60, 40), out_binning="dragon", seed=5)
     p = wl.osc_params(theta23_deg=47.0)
     maps = []
-    for order in ("node", "bin", False):
-        st = synthetic.DeviceState(wl, sort_events=order)
+    for order, lds in (("node", False), ("node", True), ("bin", False), (False, False)):
+        st = synthetic.DeviceState(wl, sort_events=order, lds_order=lds)
         st.make_pseudo_data(wl.osc_params(), seed=0)
         llh = float(st.eval(p, "llh").item())
         st.check_status()
