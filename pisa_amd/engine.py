@@ -255,7 +255,9 @@ class HotPathEngine:
                     else:
                         perm = torch.argsort(node, stable=True)
                 if lds_order and perm is not None and sort_events != "bin" and self.n_bins * 96 <= 65536:
-                    perm = perm[lds_bank_order(obin[perm])]
+                    import os  # development overrides (scripts/dev)
+                    perm = perm[lds_bank_order(obin[perm], window=int(os.environ.get("PISA_LDS_WINDOW", 4096)),
+                                               banks=int(os.environ.get("PISA_LDS_BANKS", 32)))]
                 if drop_unbinned:
                     # an event outside the output binning (or outside the calc grid: P = 0)
                     # adds nothing to any map, whatever the parameters: the coordinates are
