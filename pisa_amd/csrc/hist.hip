@@ -525,14 +525,20 @@ finalize_metric_kernel(long long *__restrict__ limbs, int n_cont, int n_bins,
         s_sum[threadIdx.x] = acc;
     }
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) s_sum[threadIdx.x] += s_sum[threadIdx.x + off];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const bool chi2_zero = (kind == PISA_HIP_METRIC_CHI2) && s_flag[1] == 0;  // stats.py:160-161
-        total[0] = chi2_zero ? 0.0 : s_sum[0];
-        if (mstatus && s_flag[0]) mstatus[0] = PISA_HIP_ERR_NEGATIVE;
+    // metric_kernel's reduction tree (s_sum[t] += s_sum[t + off], off = 128 .. 1): the same
+    // additions in the same pairing, the last six levels inside wave 0 with lane shuffles
+    // instead of LDS round trips and workgroup barriers
+    if (threadIdx.x < 128) s_sum[threadIdx.x] += s_sum[threadIdx.x + 128];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        double v = s_sum[threadIdx.x] + s_sum[threadIdx.x + 64];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (threadIdx.x == 0) {
+            const bool chi2_zero = (kind == PISA_HIP_METRIC_CHI2) && s_flag[1] == 0;  // stats.py:160-161
+            total[0] = chi2_zero ? 0.0 : v;
+            if (mstatus && s_flag[0]) mstatus[0] = PISA_HIP_ERR_NEGATIVE;
+        }
     }
 }
 
