@@ -1,0 +1,114 @@
+"""BASELINE.json's full-size workload (1e7 events, 200x100 calc grid, 8x8x2 binning) checked
+through size-independent properties: the oracle would need minutes here, the properties do not."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def workload():
+    from pisa_amd import synthetic
+
+    return synthetic.Workload(n_events=10_000_000, grid=(200, 100), out_binning="dragon", seed=0)
+
+
+def _maps(st):
+    h, s = st.finalize()
+    return h.clone(), s.clone()
+
+
+def test_full_size_properties(workload):
+    from pisa_amd import kernels as K
+    from pisa_amd import synthetic
+
+    wl = workload
+    p = wl.osc_params(theta23_deg=47.5, dm31=2.6e-3)
+    st = synthetic.DeviceState(wl, compact=True)
+    st.accumulate(p)
+    st.check_status()
+    limbs = st.ws.limbs.clone()
+    h, s2 = _maps(st)
+    assert float(h.sum()) > 0
+
+    # (1) reproducible: a second launch leaves the same limbs
+    st.accumulate()
+    assert bool((st.ws.limbs == limbs).all())
+
+    # (2) event order / kernel variant independent: unsorted events, reference-order columns of the
+    #     same order give their own exact sums; compact vs reference-order agree to a few ulp
+    plain = synthetic.DeviceState(wl, compact=True, sort_events=False, lds_order=False)
+    plain.accumulate(p)
+    hp, sp = _maps(plain)
+    assert bool((hp == h).all()) and bool((sp == s2).all())
+    exact = synthetic.DeviceState(wl, compact=False)
+    exact.accumulate(p)
+    he, se = _maps(exact)
+    assert float(((he - h).abs() / he.abs().clamp_min(1e-300)).max()) < 1e-14
+    assert float(((se - s2).abs() / se.abs().clamp_min(1e-300)).max()) < 1e-14
+    del plain
+
+    # (3) linear in the per-container scale: a factor 2 is exact in binary floating point
+    exact.set_scale(wl.events[3]["name"], 2.0 * wl.events[3]["scale"])
+    exact.accumulate()
+    h2, s22 = _maps(exact)
+    assert bool((h2[3] == 2.0 * he[3]).all()) and bool((s22[3] == 4.0 * se[3]).all())
+    assert bool((h2[0] == he[0]).all())
+    del exact
+
+    # (4) shards add as integers: the sum of the limbs of 3 event shards is the unsharded array
+    #     (what makes the result independent of the GPU count)
+    total = None
+    for rank in range(3):
+        sh = synthetic.DeviceState(wl, rank=rank, world_size=3, compact=True)
+        sh.accumulate(p)
+        total = sh.ws.limbs.clone() if total is None else total + sh.ws.limbs
+        last = sh
+    last.ws.limbs.copy_(total)
+    K.hist_finalize(last.ws)
+    assert bool((last.ws.hist == h).all()) and bool((last.ws.sumw2 == s2).all())
+    del last, sh
+
+    # (5) conservation: the maps of a container sum to the sum of its in-binning event weights,
+    #     computed independently (table lookup with torch, one stage at a time, fp64)
+    c = 4
+    ev = wl.events[c]
+    node = K.event_indices([K.to_device(np.log(ev["true_energy"])), K.to_device(ev["true_coszen"])],
+                           wl.grid.binning).long()
+    obin = K.event_indices([K.to_device(x) for x in ev["sample"]], wl.out_binning)
+    tab = st.pepmu[0 if ev["nubar"] > 0 else 1, ev["flav"]]  # [node][2]
+    pe_pmu = tab[node.clamp_min(0)] * (node >= 0)[:, None]
+    flux = K.to_device(ev["nu_flux"])
+    w = K.to_device(ev["initial_weights"]) * (flux[:, 0] * pe_pmu[:, 0] + flux[:, 1] * pe_pmu[:, 1])
+    w = w * (K.to_device(ev["weighted_aeff"]) * ev["scale"])
+    inside = obin >= 0
+    want = float(w[inside].sum())
+    want2 = float((w[inside] ** 2).sum())
+    np.testing.assert_allclose(float(h[c].sum()), want, rtol=1e-11)
+    np.testing.assert_allclose(float(s2[c].sum()), want2, rtol=1e-11)
+    # per bin as well (torch's own histogram of the same weights)
+    ref = torch.zeros(wl.n_bins, dtype=torch.float64, device=w.device)
+    ref.index_add_(0, obin[inside].long(), w[inside])
+    np.testing.assert_allclose(h[c].cpu().numpy(), ref.cpu().numpy(), rtol=1e-11)
+
+
+def test_full_grid_probabilities_are_unitary(workload):
+    """200x100 PREM-12 grid, nu and nubar, planned path: without decay every row and every
+    column of P sums to one; the (P_e, P_mu) gather tables are exact copies of P; nu != nubar
+    in matter"""
+    from pisa_amd import synthetic
+
+    wl = workload
+    st = synthetic.DeviceState(synthetic.Workload(n_events=1200, grid=(200, 100), out_binning="dragon", seed=1))
+    for params in (wl.osc_params(), wl.osc_params(theta23_deg=51.0, dm31=-2.4e-3, deltacp_deg=230.0)):
+        st.compute_probs(params)
+        for P in (st.prob_nu, st.prob_nubar):
+            assert float((P.sum(dim=2) - 1.0).abs().max()) < 5e-13
+            assert float((P.sum(dim=1) - 1.0).abs().max()) < 5e-13
+            assert float(P.min()) > -1e-15 and float(P.max()) < 1.0 + 1e-12
+        for side, P in ((0, st.prob_nu), (1, st.prob_nubar)):
+            for f in range(3):
+                assert bool((st.pepmu[side, f, :, 0] == P[:, 0, f]).all())
+                assert bool((st.pepmu[side, f, :, 1] == P[:, 1, f]).all())
+        assert float((st.prob_nu - st.prob_nubar).abs().max()) > 1e-3
