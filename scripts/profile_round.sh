@@ -10,10 +10,10 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; rm -rf $OUT; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.stderr
 tail -c 600 $OUT/bench.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --no-cpu-baseline --no-drop-probe > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --no-cpu-baseline --no-drop-probe --no-batch-probe > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
 cp $OUT/stats/bench_kernel_stats.csv $OUT/kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-drop-probe > /dev/null 2> $OUT/pmc_$c.log
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-drop-probe --no-batch-probe > /dev/null 2> $OUT/pmc_$c.log
   cp $OUT/pmc_$c/p_counter_collection.csv $OUT/pmc_$c.csv
 done
 python3 - <<PY
