@@ -78,6 +78,11 @@ struct Prob3Side {
     mat3 V;        // mat_pot (nu) or conj(mat_pot) (nubar)
     double lri[3][3];  // +-lri_pot*1e9 added to Re(H_mat)
     double a_sign;     // +1 (nu) / -1 (nubar): H_mat = a_sign*a*V
+    // mass-basis images used by the planned grid form only (eigen_terms):
+    // 2E.U^dagger.H.U = X0 + (2E.a_sign.a).XV + 2E.XL
+    mat3 X0;       // U^dagger . Hvd . U
+    mat3 XV;       // U^dagger . V . U
+    mat3 XL;       // U^dagger . lri . U
 };
 
 struct Prob3Consts {
@@ -130,6 +135,12 @@ inline void prob3_make_consts(const double *dm, const double *mix, const double 
                 S.lri[i][j] = (s == 0) ? l : -l;
             }
         S.a_sign = (s == 0) ? 1.0 : -1.0;
+        mat3 Lc;
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) Lc.m[i][j] = cmake(S.lri[i][j], 0.0);
+        mat_mul(S.Hvd, S.U, tmp); mat_mul(S.Ud, tmp, S.X0);
+        mat_mul(S.V, S.U, tmp);   mat_mul(S.Ud, tmp, S.XV);
+        mat_mul(Lc, S.U, tmp);    mat_mul(S.Ud, tmp, S.XL);
     }
 }
 
@@ -472,14 +483,17 @@ __device__ __forceinline__ void eigen_terms(const Prob3Side &S, const double (&d
             hm.re = hm.re + S.lri[i][j];
             Hf.m[i][j] = cadd(cscale(one_over_two_e, S.Hvd.m[i][j]), hm);
         }
-    mat3 tmp, X;
-    mat_mul(Hf, S.U, tmp);
-    mat_mul(S.Ud, tmp, X);
+    // 2E.U^dagger.Hf.U is linear in the layer's potential a: it is assembled from three
+    // matrices prepared once on the host instead of two 3x3 complex products per (E, rho)
+    // (planned form only; same matrix to rounding)
+    mat3 X;
     double two_e = 2.0 * energy;
+    const double ka = two_e * sa;
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
-        for (int j = 0; j < 3; j++) X.m[i][j] = cscale(two_e, X.m[i][j]);
+        for (int j = 0; j < 3; j++)
+            X.m[i][j] = cadd(S.X0.m[i][j], cadd(cscale(ka, S.XV.m[i][j]), cscale(two_e, S.XL.m[i][j])));
 
     cplx M[3], den[3];
     if (!DECAY) {

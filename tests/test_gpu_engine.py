@@ -160,3 +160,42 @@ def test_large_binning_compact_and_dropped():
         else:
             assert np.array_equal(h, h0) and np.array_equal(s, s0)
     assert h0.sum() > 0
+
+
+def test_rccl_limb_allreduce_single_rank(tmp_path):
+    """The N > 1 code path on the one GPU a test box has: a 1-rank RCCL group, the engine told
+    it is one of two ranks so that every evaluation goes through the int64 limb all-reduce on
+    the device (identity on a 1-rank group).  Checks that RCCL accepts the int64 SUM, that the
+    collective is ordered between the raw-stream launches of the fused kernel and of the tail,
+    and that the polled host result is the one of the plain path, bit for bit."""
+    import time
+
+    import torch
+    import torch.distributed as dist
+
+    from pisa_amd import synthetic
+
+    wl = synthetic.Workload(n_events=240000, grid=(60, 30))
+    st = synthetic.DeviceState(wl, compact=True)
+    st.make_pseudo_data(wl.osc_params(), seed=0)
+    points = [wl.osc_params(theta23_deg=t) for t in (38.0, 45.0, 51.0)]
+    ref = [st.eval_host(p, "llh") for p in points]
+    dist.init_process_group("nccl", init_method="file://%s" % (tmp_path / "store"), rank=0,
+                            world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        st.world_size = 2
+        got = [st.eval_host(p, "llh") for p in points]
+        assert got == ref
+        t0 = time.perf_counter()
+        for _ in range(50):
+            st.eval_host(points[0], "llh")
+        dt = (time.perf_counter() - t0) / 50
+        st.world_size = 1
+        t0 = time.perf_counter()
+        for _ in range(50):
+            st.eval_host(points[0], "llh")
+        dt1 = (time.perf_counter() - t0) / 50
+        print("eval with 1-rank RCCL all-reduce %.1f us, without %.1f us" % (dt * 1e6, dt1 * 1e6))
+        st.check_status()
+    finally:
+        dist.destroy_process_group()
