@@ -50,8 +50,11 @@ def parse():
     ap.add_argument("--cpu-sample-events", type=float, default=2.4e6)
     ap.add_argument("--exact-association", action="store_true",
                     help="stream the 40 B/event columns (initial_weights, weighted_aeff, nu_flux kept separate, "
-                         "the reference's operation order) instead of the 24 B/event compact form in which the "
+                         "the reference's operation order) instead of the compact form in which the "
                          "static per-event factors are folded into the flux pair once")
+    ap.add_argument("--wide-index", action="store_true",
+                    help="compact form with 32-bit node and bin indices (24 B/event) instead of the "
+                         "16-bit ones (20 B/event; same weights, same arithmetic, identical results)")
     ap.add_argument("--no-batch-probe", action="store_true",
                     help="skip the informational stream-overlapped batch evaluation (keeps a rocprofv3 "
                          "kernel average free of launches that share the chip with another stream)")
@@ -134,11 +137,14 @@ def pmc_traffic(args):
     PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; collected by
     separate `rocprofv3 --pmc` runs of this same command, see profiles/*/traffic.json).
     Only valid for the default workload."""
-    if args.coordinate_form or args.exact_association or int(args.events) != 10000000 or args.binning != "dragon":
+    if args.coordinate_form or args.exact_association or args.wide_index or int(args.events) != 10000000 or args.binning != "dragon":
         return None
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))
+    import re
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")),
+                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(os.path.dirname(f)))])
     if not files:
         return None
     with open(files[-1]) as fh:
@@ -166,12 +172,13 @@ def main():
     n_e, n_cz = (int(v) for v in args.grid.split("x"))
     weak = world > 1 and not args.strong_scaling
     compact = not (args.exact_association or args.coordinate_form)
+    index16 = compact and not args.wide_index
     wl = synthetic.Workload(n_events=int(args.events), grid=(n_e, n_cz), out_binning=args.binning,
                             seed=rank if weak else 0)
     st = synthetic.DeviceState(wl, rank=0 if weak else rank, world_size=1 if weak else world,
                                indexed=not args.coordinate_form,
                                sort_events=True if args.event_order == "auto" else args.event_order,
-                               compact=compact)
+                               compact=compact, index16=index16)
     if weak:
         st.world_size = world  # whole local sample per rank; the limb all-reduce still spans all ranks
     nominal = wl.osc_params()
@@ -215,6 +222,8 @@ def main():
         bytes_per_event = 4 + 4 + 16 + 8 + 8  # node, bin (int32) + flux(2) + aeff + w0 = 40 B
         if compact:
             bytes_per_event = 4 + 4 + 16  # node, bin + (w0*aeff*f_e, w0*aeff*f_mu) = 24 B
+            if st.index16:
+                bytes_per_event = 2 + 2 + 16  # both indices in 16 bits = 20 B
     if args.no_kernel_timing:
         fused_avg_s = float("nan")
     else:
@@ -266,7 +275,7 @@ def main():
     dropped = None
     if world == 1 and not args.coordinate_form and not args.no_drop_probe:
         st2 = synthetic.DeviceState(wl, sort_events=True if args.event_order == "auto" else args.event_order,
-                                    drop_unbinned=True, compact=compact)
+                                    drop_unbinned=True, compact=compact, index16=index16)
         st2.set_data(st.data.cpu().numpy())
         for p in plist[: args.warmup]:
             st2.eval_host(p, "llh")
@@ -310,7 +319,8 @@ def main():
                             % (wl.n_events, n_e, n_cz, "x".join(str(b) for b in wl.ob["nbins"]),
                                "event columns %d B/event (%s)" % (
                                    bytes_per_event,
-                                   "static factors initial_weights*weighted_aeff folded into the flux pair"
+                                   ("static factors initial_weights*weighted_aeff folded into the flux pair"
+                                    + (", 16-bit node and bin indices" if st.index16 else ""))
                                    if compact else "reference operation order")),
                 "events": wl.n_events,
                 "calc_grid": [n_e, n_cz],
@@ -326,7 +336,8 @@ def main():
                          "finalize_metric": t_tail},
             "roofline": {
                 "bound": "hbm",
-                "kernel": "hist_accumulate_kernel<%d, true>" % (1 if args.coordinate_form else (5 if compact else 3)),
+                "kernel": "hist_accumulate_kernel<%d, true>" % (1 if args.coordinate_form else
+                                                               ((7 if st.index16 else 5) if compact else 3)),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

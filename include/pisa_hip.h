@@ -230,6 +230,18 @@ typedef struct {
                                         with the static factors associated first (differs from the
                                         40-B form by rounding, <= 3 ulp per weight).  The caller
                                         refreshes it when nu_flux changes (flux systematics). */
+    /* 16-BIT INDEX form of the compact columns (20 B per event), for calc grids below 65535
+     * nodes and output binnings below 65535 bins whose accumulators fit the LDS (<= 682 bins).
+     * Given for every container it is the form used; it stands alone (d_node_bin and
+     * d_weighted_flux may be NULL).  For a grid / binning it does not apply to these two
+     * columns are ignored: the call uses the other forms if they are given as well and is
+     * PISA_HIP_ERR_INVALID if not.  Both arrays are padded to a multiple of 256 events with events
+     * outside the binning (index word 0xffffffff, flux pair 0). */
+    const uint32_t *d_node_bin16;    /* [n_pad] node | bin << 16, 0xffff in a half = outside */
+    const double *d_weighted_flux_q; /* [n_pad / 256][4][64][2]: d_weighted_flux with the pairs of a
+                                        quad of consecutive events e = 4q + k stored at
+                                        [q / 64][k][q % 64], so that the 64 lanes of a wavefront
+                                        (one quad each) read 16 contiguous bytes per lane */
 } pisa_hip_container;
 
 /* Fused  prob3.apply (prob3.py:621-622, with the grid->event lookup of

@@ -87,6 +87,8 @@ class Container(C.Structure):
         ("nubar", C.c_int32),
         ("scale", C.c_double),
         ("d_weighted_flux", C.c_void_p),
+        ("d_node_bin16", C.c_void_p),
+        ("d_weighted_flux_q", C.c_void_p),
     ]
 
 

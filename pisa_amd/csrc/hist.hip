@@ -118,6 +118,8 @@ struct ContDev {
     const double2 *aeff_w0;     // optional packed (weighted_aeff, initial_weights) per event
     const double2 *pepmu_own;   // optional per-container (P_e, P_mu) table (event-mode prob3)
     const double2 *wflux;       // optional static-weighted flux (w0*aeff*f_e, w0*aeff*f_mu) per event
+    const uint32_t *idx16;      // optional 16-bit packed (node | bin << 16) per event, 0xffff = outside
+    const double2 *wflux_q;     // wflux in quad-blocked order [q / 64][4][q % 64], padded to 256 events
     double scale;
     int32_t flav, side;
 };
@@ -147,8 +149,10 @@ struct HistArgs {
 //         factor initial_weights*weighted_aeff: 24 B per event, two loads fewer per pair.
 //         w = ((g_e*P_e) + (g_mu*P_mu)) * scale  -- the reference's product with the static
 //         factors associated first; differs from MODE 3 by rounding only (<= 3 ulp per weight)
+// MODE 7: MODE 5 with the two indices in 16 bits each (grids and binnings below 65535 entries):
+//         20 B per event, four events per thread and sweep so that every load stays 16 bytes
 template <int MODE, bool LDS_ACC>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
 hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limbs,
                        int32_t *__restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double s_acc[];  // [slab][quantity][bin]
@@ -185,11 +189,23 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
     const int64_t step = together ? n_wg * nthreads : nthreads;
     const int64_t p_end = together ? (C.n >> 1) : (end >> 1);
     int64_t p = (together ? lb * nthreads : (start >> 1)) + threadIdx.x;
-    bool have = p < p_end;
+    constexpr bool QUAD = MODE == 7;
+    bool have = !QUAD && p < p_end;
     int4 ix = make_int4(-1, -1, -1, -1);  // node0, bin0, node1, bin1
     double2 awa = make_double2(0.0, 0.0), awb = awa, fa = awa, fb = awa;
     constexpr bool PACKED = MODE == 3 || MODE == 5;
     constexpr bool COMPACT = MODE == 5;
+    // MODE 7: quads of events, always swept together
+    const int64_t q_end = (C.n + 3) >> 2;  // columns padded to whole blocks of 64 quads
+    int64_t q = lb * nthreads + threadIdx.x;
+    bool qhave = QUAD && q < q_end;
+    uint4 qx = make_uint4(~0u, ~0u, ~0u, ~0u);
+    double2 g0 = awa, g1 = awa;
+    if (QUAD && qhave) {
+        qx = reinterpret_cast<const uint4 *>(C.idx16)[q];
+        const double2 *gq = C.wflux_q + ((q >> 6) * 256 + (q & 63));
+        g0 = gq[0]; g1 = gq[64];
+    }
     if (PACKED && have) {
         const double2 *col = COMPACT ? C.wflux : C.aeff_w0;
         ix = reinterpret_cast<const int4 *>(C.node_bin)[p];
@@ -245,7 +261,58 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
         if (!ok) bad = true;
     };
 
-    if (PACKED) {
+    if (QUAD) {
+        const double2 *tab = C.pepmu_own ? C.pepmu_own
+                                         : a.pepmu + ((int64_t)C.side * 3 + C.flav) * a.n_nodes;
+        const double scale = C.scale;
+        const uint4 *idxq = reinterpret_cast<const uint4 *>(C.idx16);
+        const double2 *aw = C.wflux_q;
+        const int64_t qstep = n_wg * nthreads;
+        const double2 zero2 = make_double2(0.0, 0.0);
+        // The pair loop's software pipeline (see below), two half-sweeps per quad: while
+        // events 0,1 of the quad are consumed the flux of events 2,3 is in flight, while 2,3
+        // are consumed the next quad's indices and the flux of its events 0,1.
+        while (qhave) {
+            const double2 *gq = aw + ((q >> 6) * 256 + (q & 63));  // lane-contiguous 16-B loads
+            {
+                const unsigned n0 = qx.x & 0xffffu, n1 = qx.y & 0xffffu;
+                const unsigned b0 = qx.x >> 16, b1 = qx.y >> 16;
+                double2 p0 = tab[n0 == 0xffffu ? 0 : n0];
+                double2 p1 = tab[n1 == 0xffffu ? 0 : n1];
+                const double2 g2 = gq[128], g3 = gq[192];
+                if (n0 == 0xffffu) p0 = zero2;
+                if (n1 == 0xffffu) p1 = zero2;
+                double w0 = ((g0.x * p0.x) + (g0.y * p0.y)) * scale;
+                double w1 = ((g1.x * p1.x) + (g1.y * p1.y)) * scale;
+                if (b0 == 0xffffu) w0 = 0.0;
+                if (b1 == 0xffffu) w1 = 0.0;
+                accumulate(b0 == 0xffffu ? 0 : (int)b0, w0, w0 * w0);
+                accumulate(b1 == 0xffffu ? 0 : (int)b1, w1, w1 * w1);
+                g0 = g2; g1 = g3;
+            }
+            const unsigned n2 = qx.z & 0xffffu, n3 = qx.w & 0xffffu;
+            const unsigned b2 = qx.z >> 16, b3 = qx.w >> 16;
+            double2 p2 = tab[n2 == 0xffffu ? 0 : n2];
+            double2 p3 = tab[n3 == 0xffffu ? 0 : n3];
+            const int64_t qn = q + qstep;
+            const bool have_n = qn < q_end;
+            const int64_t ql = have_n ? qn : q;  // unconditional loads (the last sweep re-reads its own quad)
+            const uint4 qxn = idxq[ql];
+            const double2 *gn = aw + ((ql >> 6) * 256 + (ql & 63));
+            const double2 g0n = gn[0], g1n = gn[64];
+            if (n2 == 0xffffu) p2 = zero2;
+            if (n3 == 0xffffu) p3 = zero2;
+            double w2 = ((g0.x * p2.x) + (g0.y * p2.y)) * scale;
+            double w3 = ((g1.x * p3.x) + (g1.y * p3.y)) * scale;
+            if (b2 == 0xffffu) w2 = 0.0;
+            if (b3 == 0xffffu) w3 = 0.0;
+            accumulate(b2 == 0xffffu ? 0 : (int)b2, w2, w2 * w2);
+            accumulate(b3 == 0xffffu ? 0 : (int)b3, w3, w3 * w3);
+            qx = qxn; g0 = g0n; g1 = g1n;
+            q = qn;
+            qhave = have_n;
+        }
+    } else if (PACKED) {
         // packed columns: (node, bin) int2 and (aeff, w0) double2 per event; every load is 16 B
         const double2 *tab = C.pepmu_own ? C.pepmu_own
                                          : a.pepmu + ((int64_t)C.side * 3 + C.flav) * a.n_nodes;
@@ -472,28 +539,56 @@ hist_finalize_kernel(const long long *__restrict__ limbs, int64_t n_total_bins,
 // hist_finalize_kernel + metric_kernel (metric_flux.hip) in one workgroup: the
 // tail of a template evaluation is launch-bound, not work-bound.  The metric part
 // repeats metric_kernel's loop and reduction tree exactly (first 256 threads).
+// One instantiation per metric: with a run-time `kind` the lgamma of poisson_llh sets the
+// register need of every variant and the 128-VGPR budget of a 1024-thread workgroup spills.
+template <int KIND>
 __global__ void __launch_bounds__(1024)
 finalize_metric_kernel(long long *__restrict__ limbs, int n_cont, int n_bins,
-                       double *__restrict__ hist, double *__restrict__ q1, int kind,
+                       double *__restrict__ hist, double *__restrict__ q1,
                        const double *__restrict__ actual, double *__restrict__ total,
                        int32_t *__restrict__ status, int32_t *__restrict__ mstatus, int clear) {
     extern __shared__ __attribute__((aligned(16))) double s_map[];  // [2][n_cont][n_bins]
     __shared__ double s_sum[256];
     __shared__ int s_flag[2];
+    constexpr int kind = KIND;
     const int n_tot = n_cont * n_bins;
     if (threadIdx.x < 2) s_flag[threadIdx.x] = 0;
+    // first bin's observed count: requested before anything else, used after the barrier
+    double k_first = 0.0;
+    if (threadIdx.x < 256 && (int)threadIdx.x < n_bins) k_first = actual[threadIdx.x];
     bool ovf = false;
-    for (int i = threadIdx.x; i < n_tot; i += blockDim.x) {
-        long long *L = limbs + (int64_t)i * 2 * NL;
-        const double h = limbs_to_double(L, ovf);
-        const double s = limbs_to_double(L + NL, ovf);
-        hist[i] = h;
-        q1[i] = s;
-        s_map[i] = h;
-        s_map[n_tot + i] = s;
-        if (clear) {
+    // One item = the NL limbs of one (bin, quantity) sum; item `it` sits at limbs + it*NL, so
+    // a wave reads one contiguous run.  The limbs were produced by device-scope atomics and
+    // come from beyond the L2: every load of (up to) four items per thread is issued before
+    // the first conversion, so the kernel pays that latency once.
+    const int n_items = 2 * n_tot;
+    constexpr int UNR = 4;
+    for (int base = 0; base < n_items; base += UNR * (int)blockDim.x) {
+        long long w[UNR][NL];
 #pragma unroll
-            for (int k = 0; k < 2 * NL; k++) L[k] = 0;
+        for (int u = 0; u < UNR; u++) {
+            const int it = base + u * (int)blockDim.x + (int)threadIdx.x;
+            const long long *L = limbs + (int64_t)(it < n_items ? it : 0) * NL;
+#pragma unroll
+            for (int k = 0; k < NL; k++) w[u][k] = L[k];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            const int it = base + u * (int)blockDim.x + (int)threadIdx.x;
+            if (it < n_items) {
+                if (clear) {
+                    long long *L = limbs + (int64_t)it * NL;
+#pragma unroll
+                    for (int k = 0; k < NL; k++) L[k] = 0;
+                }
+                const int i = it >> 1, q = it & 1;
+                const double d = limbs_to_double(w[u], ovf);
+                (q ? q1 : hist)[i] = d;
+                s_map[q * n_tot + i] = d;
+            }
+            // conversions one after the other: interleaved they exceed the 128-VGPR budget
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     if (ovf && status) atomicOr(status, 1);
@@ -502,7 +597,7 @@ finalize_metric_kernel(long long *__restrict__ limbs, int n_cont, int n_bins,
     double acc = 0.0;
     if (threadIdx.x < 256) {
         for (int b = threadIdx.x; b < n_bins; b += 256) {
-            const double k = actual[b];
+            const double k = (b == (int)threadIdx.x) ? k_first : actual[b];
             double lam = 0.0, s2 = 0.0;
             for (int m = 0; m < n_cont; m++) {
                 lam = (m == 0) ? expected[b] : lam + expected[m * n_bins + b];
@@ -660,7 +755,8 @@ static int run_hist(const ContDev *conts, int n_cont, int mode, const DevBinning
         unsigned long long *out = reinterpret_cast<unsigned long long *>(d_limbs);
         if (g_prof_start) PISA_TRY_HIP(hipEventRecord(g_prof_start, s));
 #define LAUNCH(M, L) hipLaunchKernelGGL((hist_accumulate_kernel<M, L>), grid_dim, block, shmem, s, a, out, d_status)
-        if (mode == 5) { if (lds) LAUNCH(5, true); else LAUNCH(5, false); }
+        if (mode == 7) LAUNCH(7, true);
+        else if (mode == 5) { if (lds) LAUNCH(5, true); else LAUNCH(5, false); }
         else if (mode == 3) { if (lds) LAUNCH(3, true); else LAUNCH(3, false); }
         else if (mode == 2) { if (lds) LAUNCH(2, true); else LAUNCH(2, false); }
         else if (mode == 1) { if (lds) LAUNCH(1, true); else LAUNCH(1, false); }
@@ -721,18 +817,23 @@ static int reweight_hist_impl(const pisa_hip_container *h_containers, int32_t n_
     bool all_indexed = d_pepmu != nullptr;
     bool all_packed = any_table;
     bool all_compact = any_table;
+    // the 16-bit index form needs whole-binning LDS accumulators and 16-bit node / bin numbers;
+    // where it does not apply its columns are ignored (the other forms, if given, are used)
+    const bool ok16 = lds_acc_bytes(n_bins) <= LDS_ACC_BYTES_MAX && n_nodes < 0xffff && n_bins < 0xffff;
+    bool all_idx16 = any_table && ok16;
     for (int c = 0; c < n_containers; c++) {
         const pisa_hip_container &h = h_containers[c];
         ContDev &d = conts[c];
         const bool compact = h.d_node_bin && h.d_weighted_flux;
+        const bool c16 = ok16 && h.d_node_bin16 && h.d_weighted_flux_q;  // stands alone
         bool packed = h.d_node_bin && (h.d_aeff_w0 || h.d_weighted_flux);
         bool indexed = packed || (h.d_node && h.d_bin);
         bool bad = h.n_events < 0 || h.flav < 0 || h.flav > 2 || (h.nubar != 1 && h.nubar != -1);
         if (h.n_events > 0) {
             const bool has_tab = d_pepmu || h.d_pepmu;
-            bad = bad || (!h.d_nu_flux && !(compact && has_tab));
-            if (!(packed && has_tab)) bad = bad || !h.d_weighted_aeff || !h.d_initial_weights;
-            if (!(indexed && has_tab)) {
+            bad = bad || (!h.d_nu_flux && !((compact || c16) && has_tab));
+            if (!((packed || c16) && has_tab)) bad = bad || !h.d_weighted_aeff || !h.d_initial_weights;
+            if (!((indexed || c16) && has_tab)) {
                 bad = bad || !h.d_grid_x || (grid.ndim > 1 && !h.d_grid_y);
                 for (int k = 0; k < outb.ndim; k++) bad = bad || !h.d_sample[k];
                 bad = bad || (h.nubar > 0 ? !d_prob_nu : !d_prob_nubar);
@@ -740,6 +841,7 @@ static int reweight_hist_impl(const pisa_hip_container *h_containers, int32_t n_
             all_indexed = all_indexed && indexed && (h.d_node && h.d_bin);
             all_packed = all_packed && packed && has_tab && h.d_aeff_w0 && h.d_nu_flux;
             all_compact = all_compact && compact && has_tab;
+            all_idx16 = all_idx16 && c16 && has_tab;
         }
         if (bad) { delete[] conts; return PISA_HIP_ERR_INVALID; }
         d.n = h.n_events;
@@ -751,11 +853,13 @@ static int reweight_hist_impl(const pisa_hip_container *h_containers, int32_t n_
         d.aeff_w0 = reinterpret_cast<const double2 *>(h.d_aeff_w0);
         d.pepmu_own = reinterpret_cast<const double2 *>(h.d_pepmu);
         d.wflux = reinterpret_cast<const double2 *>(h.d_weighted_flux);
+        d.idx16 = h.d_node_bin16;
+        d.wflux_q = reinterpret_cast<const double2 *>(h.d_weighted_flux_q);
         d.scale = h.scale;
         d.flav = h.flav;
         d.side = h.nubar > 0 ? 0 : 1;
     }
-    rc = run_hist(conts, n_containers, all_compact ? 5 : (all_packed ? 3 : (all_indexed ? 2 : 1)), &grid, n_nodes, d_prob_nu, d_prob_nubar,
+    rc = run_hist(conts, n_containers, all_idx16 ? 7 : all_compact ? 5 : (all_packed ? 3 : (all_indexed ? 2 : 1)), &grid, n_nodes, d_prob_nu, d_prob_nubar,
                   d_pepmu, outb, n_bins, (long long *)d_limbs, d_status, as_stream(stream), clear_first);
     delete[] conts;
     return rc;
@@ -793,10 +897,17 @@ PISA_API int pisa_hip_finalize_metric(int64_t *d_limbs, int32_t n_containers, in
     int threads = ((n_tot + 63) / 64) * 64;
     if (threads < 256) threads = 256;  // the metric reduction tree is 256 wide
     if (threads > 1024) threads = 1024;
-    hipLaunchKernelGGL(finalize_metric_kernel, dim3(1), dim3(threads), (size_t)n_tot * 16,
-                       as_stream(stream), (long long *)d_limbs, (int)n_containers, (int)n_bins,
-                       d_hist, d_sumw2, (int)kind, d_actual, total, d_status, d_metric_status,
-                       (int)clear_limbs);
+    auto launch = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(1), dim3(threads), (size_t)n_tot * 16, as_stream(stream),
+                           (long long *)d_limbs, (int)n_containers, (int)n_bins, d_hist, d_sumw2,
+                           d_actual, total, d_status, d_metric_status, (int)clear_limbs);
+    };
+    switch (kind) {
+    case PISA_HIP_METRIC_LLH: launch(finalize_metric_kernel<PISA_HIP_METRIC_LLH>); break;
+    case PISA_HIP_METRIC_POISSON_LLH: launch(finalize_metric_kernel<PISA_HIP_METRIC_POISSON_LLH>); break;
+    case PISA_HIP_METRIC_CHI2: launch(finalize_metric_kernel<PISA_HIP_METRIC_CHI2>); break;
+    default: launch(finalize_metric_kernel<PISA_HIP_METRIC_MOD_CHI2>);
+    }
     PISA_CHECK_LAUNCH("finalize_metric_kernel");
     return PISA_HIP_OK;
 }

@@ -99,7 +99,7 @@ def bin_window_order(obin, n_bins, lds_window=682):
     return perm1[torch.argsort(key, stable=True)]
 
 
-def lds_bank_order(obin, window=4096, banks=32):
+def lds_bank_order(obin, window=4096, banks=32, per=2):
     """Second-level event order (applied on top of the node sort) that takes the LDS bank
     conflicts out of the deposits.
 
@@ -110,7 +110,8 @@ def lds_bank_order(obin, window=4096, banks=32):
     Inside windows of `window` events (so the node locality of the table gathers survives)
     the events are therefore dealt round-robin over the 32 residues, and the emitted sequence
     is laid out so that 32 consecutive emissions land in the same slot (first or second event)
-    of 32 consecutive pairs.  The accumulation is exact, so this is free to choose.
+    of 32 consecutive pairs (`per` = 2 events per thread and sweep; 4 for the 16-bit index
+    form, whose threads take quads).  The accumulation is exact, so this is free to choose.
     Returns a permutation (device int64) of arange(n)."""
     n = obin.numel()
     dev = obin.device
@@ -133,8 +134,8 @@ def lds_bank_order(obin, window=4096, banks=32):
     key2 = (win[order1] * (window + 1) + rank) * banks + res[order1]
     seq = order1[torch.argsort(key2, stable=True)]  # emission order: one event per residue in turn
     s = pos % window
-    blk, t = s // 64, s % 64
-    slot = (pos // window) * window + 2 * (blk * 32 + (t % 32)) + (t // 32)
+    blk, t = s // (32 * per), s % (32 * per)
+    slot = (pos // window) * window + per * (blk * 32 + (t % 32)) + (t // 32)
     perm = idx.clone()
     perm[slot] = seq
     return perm
@@ -176,7 +177,7 @@ class HotPathEngine:
 
     def __init__(self, containers, grid, out_binning, earth, max_layers, rank=0, world_size=1,
                  group=None, indexed=True, planned=True, packed=True, sort_events=True,
-                 external_tables=False, osc_mode="grid", drop_unbinned=False, compact=False,
+                 external_tables=False, osc_mode="grid", drop_unbinned=False, compact=False, index16=True,
                  lds_order=True):
         self.dev = K.device()
         assert osc_mode in ("grid", "events")
@@ -200,6 +201,13 @@ class HotPathEngine:
         self._perm, self._flux, self._slices = [], [], []
         self._static_w, self._wflux = [], []
         self.compact = bool(compact)
+        import os
+        # 16-bit index form of the compact columns (20 B/event) where it applies: grid mode, calc
+        # grid below 65535 nodes, output binning whose accumulators fit the LDS
+        index16 = (bool(index16) and bool(int(os.environ.get("PISA_IDX16", "1"))) and self.compact
+                   and packed and indexed and not self.osc_events and grid.size < 0xFFFF
+                   and self.n_bins * 96 <= 65536)
+        self.index16 = index16
         self.n_local = 0
         for c in containers:
             n = len(c["true_energy"])
@@ -257,7 +265,8 @@ class HotPathEngine:
                 if lds_order and perm is not None and sort_events != "bin" and self.n_bins * 96 <= 65536:
                     import os  # development overrides (scripts/dev)
                     perm = perm[lds_bank_order(obin[perm], window=int(os.environ.get("PISA_LDS_WINDOW", 4096)),
-                                               banks=int(os.environ.get("PISA_LDS_BANKS", 32)))]
+                                               banks=int(os.environ.get("PISA_LDS_BANKS", 32)),
+                                               per=4 if index16 else 2)]
                 if drop_unbinned:
                     # an event outside the output binning (or outside the calc grid: P = 0)
                     # adds nothing to any map, whatever the parameters: the coordinates are
@@ -290,12 +299,32 @@ class HotPathEngine:
                     d.d_node_bin, d.d_aeff_w0 = nb.data_ptr(), aw.data_ptr()
                     if compact:
                         # the factors of the weight that no oscillation parameter touches,
-                        # multiplied once: (w0*aeff) * (f_e, f_mu), 24 B/event with node_bin
+                        # multiplied once: (w0*aeff) * (f_e, f_mu)
                         cst = (w0_d * aeff_d).contiguous()
-                        wf = (cst[:, None] * flux_d).contiguous()
-                        self._keep += [cst, wf]
-                        d.d_weighted_flux = wf.data_ptr()
-                        static_w, wflux = cst, wf
+                        self._keep.append(cst)
+                        static_w = cst
+                        if index16:
+                            # 20 B/event: both indices in 16 bits, and the flux pairs of a quad of
+                            # events stored lane-contiguously ([quad / 64][4][quad % 64]) so that
+                            # every load of the kernel is 16 contiguous bytes per lane; columns
+                            # padded to whole blocks of 64 quads with events outside the binning
+                            n_ev = int(node.numel())
+                            n_pad = -(-n_ev // 256) * 256
+                            v = torch.full((n_pad,), 0xFFFFFFFF, dtype=torch.int64, device=self.dev)
+                            v[:n_ev] = (torch.where(node < 0, 0xFFFF, node.long())
+                                        | (torch.where(obin < 0, 0xFFFF, obin.long()) << 16))
+                            nb16 = torch.where(v >= 2 ** 31, v - 2 ** 32, v).to(torch.int32).contiguous()
+                            wq = torch.zeros((n_pad // 256, 4, 64, 2), dtype=torch.float64, device=self.dev)
+                            self._keep += [nb16, wq]
+                            d.d_node_bin16, d.d_weighted_flux_q = nb16.data_ptr(), wq.data_ptr()
+                            wflux = wq
+                            self._fill_wflux(wq, cst, flux_d)
+                        else:
+                            # 24 B/event with node_bin
+                            wf = (cst[:, None] * flux_d).contiguous()
+                            self._keep.append(wf)
+                            d.d_weighted_flux = wf.data_ptr()
+                            wflux = wf
             d.flav, d.nubar, d.scale = int(c["flav"]), int(c["nubar"]), float(c["scale"])
             self._static_w.append(static_w)
             self._wflux.append(wflux)
@@ -338,7 +367,18 @@ class HotPathEngine:
             f = f[self._perm[i]]
         self._flux[i].copy_(f)
         if self._wflux[i] is not None:
-            torch.mul(self._static_w[i][:, None], self._flux[i], out=self._wflux[i])
+            self._fill_wflux(self._wflux[i], self._static_w[i], self._flux[i])
+
+    @staticmethod
+    def _fill_wflux(out, static_w, flux):
+        """static_w * (f_e, f_mu) into the plain [n][2] column or the quad-blocked one"""
+        if out.dim() == 2:
+            torch.mul(static_w[:, None], flux, out=out)
+        else:
+            n = flux.shape[0]
+            tmp = torch.zeros((out.shape[0] * 256, 2), dtype=torch.float64, device=out.device)
+            torch.mul(static_w[:, None], flux, out=tmp[:n])
+            out.permute(0, 2, 1, 3).copy_(tmp.view(out.shape[0], 64, 4, 2))
 
     def set_scale(self, name, scale):
         i = self.names.index(name)

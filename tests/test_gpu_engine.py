@@ -139,6 +139,94 @@ def test_compact_layout_matches_exact_association(oracle):
     comp.check_status()
 
 
+@pytest.mark.parametrize("n_events", [240000, 12 * 1001, 12 * 3])
+def test_index16_form_is_bit_identical_to_compact(n_events):
+    """20 B/event form (both indices in 16 bits, quad-blocked flux pairs, padded columns): the
+    same weights in the same arithmetic as the 24 B compact form, so maps and LLH are identical
+    bit for bit -- for event counts that are not multiples of the 256-event blocks, with events
+    outside the binning, after a flux update, without the events that never land in a bin, and
+    through the plain (non-lean) entry points."""
+    from pisa_amd import kernels as K
+    from pisa_amd import synthetic
+
+    wl = synthetic.Workload(n_events=n_events, grid=(60, 40), out_binning="dragon", seed=21)
+    p = wl.osc_params(theta23_deg=44.0)
+    wide = synthetic.DeviceState(wl, compact=True, index16=False)
+    narrow = synthetic.DeviceState(wl, compact=True)
+    assert narrow.index16 and not wide.index16
+    assert narrow.cont[0].d_weighted_flux_q and not narrow.cont[0].d_weighted_flux
+    wide.make_pseudo_data(wl.osc_params(), seed=0)
+    narrow.set_data(wide.data.cpu().numpy())
+    assert narrow.eval_host(p) == wide.eval_host(p)
+    for a, b in zip(narrow.maps(), wide.maps()):
+        assert np.array_equal(a, b)
+    assert wide.maps()[0].sum() > 0
+    i = 4
+    new_flux = K.to_device(wl.events[i]["nu_flux"] * np.array([0.9, 1.2]))
+    before = wide.eval_host(p)
+    for st in (wide, narrow):
+        st.update_flux(i, new_flux)
+    assert narrow.eval_host(p) == wide.eval_host(p) != before
+    # generic entry points (accumulate / finalize) and the event set without unbinned events
+    dropped = synthetic.DeviceState(wl, compact=True, drop_unbinned=True)
+    assert dropped.index16
+    dropped.update_flux(i, new_flux)
+    dropped.accumulate(p)
+    wide.accumulate(p)
+    for a, b in zip(dropped.finalize(), wide.finalize()):
+        assert torch_equal(a, b)
+    narrow.check_status()
+    dropped.check_status()
+
+
+def torch_equal(a, b):
+    import torch
+
+    return torch.equal(a, b)
+
+
+def test_index16_form_needs_a_fallback_where_it_does_not_apply():
+    """ABI: for a binning whose accumulators do not fit the LDS the 16-bit columns are ignored:
+    the call falls back to the other forms of the container, and is refused when the 16-bit
+    form is all a container offers."""
+    import ctypes
+
+    import torch
+
+    from pisa_amd import _lib, synthetic
+    from pisa_amd import kernels as K
+
+    wl = synthetic.Workload(n_events=12 * 500, grid=(20, 10), out_binning="fine3d", seed=3)
+    small = _lib.make_binning(synthetic.DRAGON["mins"], synthetic.DRAGON["maxs"], synthetic.DRAGON["nbins"])
+    # engine on the small binning (16-bit form built), then asked for the 4800-bin one: the bin
+    # numbers of its index columns belong to the small binning, so only the status matters here
+    wl_small = synthetic.Workload(n_events=12 * 500, grid=(20, 10), out_binning="dragon", seed=3)
+    st = synthetic.DeviceState(wl_small, compact=True)
+    assert st.index16
+    st.compute_probs(wl_small.osc_params())
+    ws = K.HistWorkspace(len(st.cont), wl.n_bins, st.dev)
+    K.reweight_hist(st._cont_arr, st.grid.binning, st.prob_nu, st.prob_nubar, st.pepmu,
+                    wl.out_binning, ws)  # falls back to the packed 40 B columns
+    only16 = []
+    for c in st.cont:
+        d = _lib.Container()
+        ctypes.memmove(ctypes.byref(d), ctypes.byref(c), ctypes.sizeof(d))
+        d.d_node = d.d_bin = d.d_node_bin = d.d_aeff_w0 = None
+        d.d_grid_x = d.d_grid_y = d.d_nu_flux = d.d_weighted_aeff = d.d_initial_weights = None
+        for k in range(3):
+            d.d_sample[k] = None
+        only16.append(d)
+    ws_small = K.HistWorkspace(len(st.cont), wl_small.n_bins, st.dev)
+    K.reweight_hist(only16, st.grid.binning, st.prob_nu, st.prob_nubar, st.pepmu, small, ws_small)
+    st.accumulate(wl_small.osc_params())
+    K.hist_finalize(ws_small)
+    assert torch.equal(ws_small.hist, st.finalize()[0])  # the 16-bit form stands alone
+    with pytest.raises(_lib.PisaHipError):
+        K.reweight_hist(only16, st.grid.binning, st.prob_nu, st.prob_nubar, st.pepmu,
+                        wl.out_binning, ws)
+    torch.cuda.synchronize()
+
+
 def test_large_binning_compact_and_dropped():
     """the LDS-window path (4800 bins) with the compact columns and without the events that
     can never land in a bin: same maps as the reference-order columns to a few ulp"""
