@@ -90,6 +90,12 @@ struct Prob3Consts {
     double dm[3][3];
     int32_t decay;      // 1: decay branch (complex eigenvalues)
     int32_t pad;
+    // planned grid form only: which cubic root follows which vacuum mass state.  get_dms orders
+    // the matter eigenvalues by the vacuum ones (:816-825), M_i = mu[argmin_j |dm[i][0] - mv_j|];
+    // the vacuum eigenvalues mv_j = 2E.eig(H_vac/2E) do not depend on the energy (only their
+    // rounding does), so the assignment is found once per evaluation on the host.
+    int32_t vac_order[3];
+    int32_t pad2;
 };
 
 // Host-side prologue: get_H_vac (:534-569), get_H_decay (:571-603) and the
@@ -103,7 +109,31 @@ inline void prob3_make_consts(const double *dm, const double *mix, const double 
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) c.dm[i][j] = dm[3 * i + j];
     c.decay = (decay_flag == 1) ? 1 : 0;
-    c.pad = 0;
+    c.pad = c.pad2 = 0;
+    {
+        // vacuum half of get_dms (:754-789) at E = 1 and its ordering rule (:816-825)
+        const double x = c.dm[1][0], y = c.dm[2][0];
+        const double h = 0.5, one_third = 1.0 / 3.0, two_third = 2.0 / 3.0;
+        const double c2_v = -h * (x + y);
+        const double p_v = (h * h) * (x * x + y * y - x * y);
+        const double q_v = (h * (h * h)) * (x + y) * ((x + y) * (x + y) - 4.5 * x * y);
+        const double tmp_v = p_v * (p_v * p_v) - q_v * q_v;
+        const double a = two_third * 3.14159265358979323846;
+        const double res_v = ::atan2(::sqrt(tmp_v), q_v) * one_third;
+        const double b_v = two_third * ::sqrt(p_v);
+        const double thv[3] = {res_v + a, res_v - a, res_v};
+        double mv[3];
+        for (int i = 0; i < 3; i++) mv[i] = 2.0 * (b_v * ::cos(thv[i]) - c2_v * one_third + c.dm[0][0]);
+        for (int i = 0; i < 3; i++) {
+            double best = ::fabs(c.dm[i][0] - mv[0]);
+            int sel = 0;
+            for (int j = 1; j < 3; j++) {
+                const double t = ::fabs(c.dm[i][0] - mv[j]);
+                if (t < best) { best = t; sel = j; }
+            }
+            c.vac_order[i] = sel;
+        }
+    }
     for (int s = 0; s < 2; s++) {
         Prob3Side &S = c.side[s];
         for (int i = 0; i < 3; i++)
@@ -173,10 +203,10 @@ __device__ __forceinline__ void get_dms_vacuum(double energy, const double (&dm)
         mv[i] = 2.0 * energy * (b_v * cos(thv[i]) - c2_v * one_third + dm[0][0]);
 }
 
-// matter half of get_dms, given the vacuum eigenvalues
-__device__ __forceinline__ void get_dms_matter(double energy, const mat3 &H,
-                                               const double (&dm)[3][3], const double (&mv)[3],
-                                               double (&M)[3]) {
+// matter half of get_dms: the three roots 2E.lambda of the characteristic cubic of H, in the
+// order of the trigonometric solution (before the vacuum ordering)
+__device__ __forceinline__ void get_dms_matter_roots(double energy, const mat3 &H,
+                                                     const double (&dm)[3][3], double (&mu)[3]) {
     const cplx h01 = H.m[0][1], h12 = H.m[1][2], h20 = H.m[2][0];
     const cplx h00 = H.m[0][0], h11 = H.m[1][1], h22 = H.m[2][2], h02 = H.m[0][2];
     double real_product_a = cmul(cmul(h01, h12), h20).re;
@@ -203,9 +233,16 @@ __device__ __forceinline__ void get_dms_matter(double energy, const mat3 &H,
     double res = atan2(sqrt(tmp), q) * one_third;
     double b = two_third * sqrt(p);
     double th[3] = {res + a, res - a, res};
-    double mu[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) mu[i] = 2.0 * energy * (b * cos(th[i]) - c2 * one_third + dm[0][0]);
+}
+
+// matter half of get_dms, given the vacuum eigenvalues
+__device__ __forceinline__ void get_dms_matter(double energy, const mat3 &H,
+                                               const double (&dm)[3][3], const double (&mv)[3],
+                                               double (&M)[3]) {
+    double mu[3];
+    get_dms_matter_roots(energy, H, dm, mu);
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         double best = fabs(dm[i][0] - mv[0]);
@@ -469,7 +506,8 @@ constexpr int PROB3_NF = 60;  // fields per record: M[3] (re,im) + Q[3][3][3] (r
 // field(f) = value callback; f in [0, PROB3_NF)
 template <bool DECAY, class StoreFn>
 __device__ __forceinline__ void eigen_terms(const Prob3Side &S, const double (&dm)[3][3],
-                                            double energy, double rho, const StoreFn &store) {
+                                            const int32_t (&vac_order)[3], double energy, double rho,
+                                            const StoreFn &store) {
     const double tworttwoGf = 1.52588e-4;
     double a = 0.5 * rho * tworttwoGf;
     double sa = S.a_sign * a;
@@ -497,8 +535,11 @@ __device__ __forceinline__ void eigen_terms(const Prob3Side &S, const double (&d
 
     cplx M[3], den[3];
     if (!DECAY) {
-        double Mr[3];
-        get_dms(energy, Hf, dm, Mr);
+        double mu[3], Mr[3];
+        get_dms_matter_roots(energy, Hf, dm, mu);
+#pragma unroll
+        for (int k = 0; k < 3; k++)  // vacuum ordering, resolved on the host (Prob3Consts::vac_order)
+            Mr[k] = vac_order[k] == 0 ? mu[0] : (vac_order[k] == 1 ? mu[1] : mu[2]);
 #pragma unroll
         for (int k = 0; k < 3; k++) M[k] = cmake(Mr[k], 0.0);
         den[0] = cmake((Mr[0] - Mr[1]) * (Mr[0] - Mr[2]), 0.0);

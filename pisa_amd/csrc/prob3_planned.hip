@@ -51,7 +51,7 @@ prob3_terms_amp_kernel(const Prob3Consts c, const double *__restrict__ energy, i
     const double e = energy[ie];
     double rec[PROB3_NF];
     auto store = [&](int f, double v) { rec[f] = v; };
-    eigen_terms<DECAY>(c.side[side], c.dm, e, rho_unique[item_u[item]], store);
+    eigen_terms<DECAY>(c.side[side], c.dm, c.vac_order, e, rho_unique[item_u[item]], store);
     auto load = [&](int f) { return rec[f]; };
     const int p0 = item_p0[item], cnt = item_cnt[item];
     for (int q = 0; q < cnt; q++) {
