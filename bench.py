@@ -238,14 +238,19 @@ def main():
     achieved = bytes_per_event * st.n_local / fused_avg_s / 1e9
 
     # per-phase device times (extra information, not part of the contract)
-    def time_phase(fn, n=10):
-        torch.cuda.synchronize()
-        ev0.record()
-        for _ in range(n):
+    def time_phase(fn, n=30):
+        # median of individually timed calls: a single slow call (the chip dropping its clocks
+        # after the host-side pause between phases) does not distort it
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for _ in range(3):
             fn()
-        ev1.record()
         torch.cuda.synchronize()
-        return ev0.elapsed_time(ev1) / n
+        for a, b in evs:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        return float(np.median([a.elapsed_time(b) for a, b in evs]))
 
     t_prob3 = time_phase(lambda: st.compute_probs(nominal))
     def tail():
