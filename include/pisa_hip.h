@@ -106,7 +106,7 @@ int pisa_hip_prob3_grid(const pisa_hip_prob3_params *h_params, const double *d_e
  * matrix and lists the distinct shell densities.  Per evaluation H(E, rho) is then
  * diagonalised per (energy, distinct density) instead of per node and layer, and
  * each row's chain is multiplied in parts.  Results equal pisa_hip_prob3_grid to
- * rounding (<= 1e-13 absolute on the probabilities), not bit for bit.
+ * rounding (<= 3e-13 absolute on the probabilities), not bit for bit.
  * plan_create synchronises (it reads the rows back); the planned call is async. */
 typedef struct pisa_hip_grid_plan pisa_hip_grid_plan;
 int pisa_hip_grid_plan_create(const double *d_densities, const double *d_distances, int32_t n_cz,

@@ -501,7 +501,7 @@ __device__ __forceinline__ void layer_amplitude(const Prob3Side &S, const double
 // and stage B assembles A = sum_k phase_k * Q_k per layer.  Same operations on
 // the same operands as layer_amplitude() except that the quotients are formed with
 // one reciprocal per eigenvalue: equal to rounding (~1e-16), not bit for bit.
-constexpr int PROB3_NF = 60;  // fields per record: M[3] (re,im) + Q[3][3][3] (re,im)
+constexpr int PROB3_NF = 60;  // fields per record, decay form: M[3] (re,im) + Q[3][3][3] (re,im)
 
 // field(f) = value callback; f in [0, PROB3_NF)
 template <bool DECAY, class StoreFn>
@@ -554,15 +554,29 @@ __device__ __forceinline__ void eigen_terms(const Prob3Side &S, const double (&d
         den[1] = cmul(csub(M[1], M[2]), csub(M[1], M[0]));
         den[2] = cmul(csub(M[2], M[0]), csub(M[2], M[1]));
     }
+    // Record layout.  DECAY: M[3] (re, im) then Q_k[i][j] (re, im), k fastest: 60 fields.
+    // Otherwise the REDUCED form.  A unit phase common to a layer's amplitude drops out of every
+    // probability (the chain product only collects a global phase), so the layer matrix may be
+    // taken as  A' = exp(+i Mbar t) A = exp(-i (H - tr H / 3) t),  Mbar = (M_0+M_1+M_2)/3, which
+    // is in SU(3): its third row is the conjugate cross product of the first two and is neither
+    // computed nor stored.  With the projectors summing to the identity (sum_k Q_k = 1),
+    //     A' = e_0 + (e_1 - e_0) Q_1 + (e_2 - e_0) Q_2,  e_k = exp(-i G_k t),  e_0 = conj(e_1 e_2),
+    // G_k = M_k - Mbar: fields G_1, G_2, then rows 0 and 1 of Q_1, Q_2 ([i][j] (re, im)): 26 fields.
+    if (DECAY) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        store(2 * k, M[k].re);
-        store(2 * k + 1, M[k].im);
+        for (int k = 0; k < 3; k++) {
+            store(2 * k, M[k].re);
+            store(2 * k + 1, M[k].im);
+        }
+    } else {
+        const double d1 = M[1].re - M[0].re, d2 = M[2].re - M[0].re;
+        store(0, (2.0 * d1 - d2) * (1.0 / 3.0));
+        store(1, (2.0 * d2 - d1) * (1.0 / 3.0));
     }
     double inv_den[3] = {1.0, 1.0, 1.0};
     if (!DECAY) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) inv_den[k] = 1.0 / den[k].re;
+        for (int k = 1; k < 3; k++) inv_den[k] = 1.0 / den[k].re;
     }
     cplx Xd[3][3];
 #pragma unroll
@@ -572,12 +586,9 @@ __device__ __forceinline__ void eigen_terms(const Prob3Side &S, const double (&d
             Xd[k][i] = DECAY ? csub(X.m[i][i], M[k]) : cmake(X.m[i][i].re - M[k].re, X.m[i][i].im);
 #define HMM(i_, j_, k_) (((i_) == (j_)) ? Xd[k_][i_] : X.m[i_][j_])
 #pragma unroll
-    for (int i = 0; i < 3; i++)
+    for (int i = 0; i < (DECAY ? 3 : 2); i++)
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-            cplx p0 = cmul(HMM(i, 0, 1), HMM(0, j, 2));
-            p0 = cadd(p0, cmul(HMM(i, 1, 1), HMM(1, j, 2)));
-            p0 = cadd(p0, cmul(HMM(i, 2, 1), HMM(2, j, 2)));
             cplx p1 = cmul(HMM(i, 0, 2), HMM(0, j, 0));
             p1 = cadd(p1, cmul(HMM(i, 1, 2), HMM(1, j, 0)));
             p1 = cadd(p1, cmul(HMM(i, 2, 2), HMM(2, j, 0)));
@@ -585,44 +596,68 @@ __device__ __forceinline__ void eigen_terms(const Prob3Side &S, const double (&d
             p2 = cadd(p2, cmul(HMM(i, 1, 0), HMM(1, j, 1)));
             p2 = cadd(p2, cmul(HMM(i, 2, 0), HMM(2, j, 1)));
             if (!DECAY) {
-                // one reciprocal per eigenvalue instead of 54 fp64 divisions (~1/6 of
-                // this function's instructions); differs from p/den by <= 1 ulp
-                p0 = cmake(p0.re * inv_den[0], p0.im * inv_den[0]);
+                // one reciprocal per eigenvalue instead of 36 fp64 divisions; differs from
+                // p/den by <= 1 ulp
                 p1 = cmake(p1.re * inv_den[1], p1.im * inv_den[1]);
                 p2 = cmake(p2.re * inv_den[2], p2.im * inv_den[2]);
+                const int base = 2 + 4 * (3 * i + j);
+                store(base + 0, p1.re); store(base + 1, p1.im);
+                store(base + 2, p2.re); store(base + 3, p2.im);
             } else {
+                cplx p0 = cmul(HMM(i, 0, 1), HMM(0, j, 2));
+                p0 = cadd(p0, cmul(HMM(i, 1, 1), HMM(1, j, 2)));
+                p0 = cadd(p0, cmul(HMM(i, 2, 1), HMM(2, j, 2)));
                 p0 = cdiv(p0, den[0]);
                 p1 = cdiv(p1, den[1]);
                 p2 = cdiv(p2, den[2]);
+                const int base = 6 + 6 * (3 * i + j);
+                store(base + 0, p0.re); store(base + 1, p0.im);
+                store(base + 2, p1.re); store(base + 3, p1.im);
+                store(base + 4, p2.re); store(base + 5, p2.im);
             }
-            const int base = 6 + 6 * (3 * i + j);
-            store(base + 0, p0.re); store(base + 1, p0.im);
-            store(base + 2, p1.re); store(base + 3, p1.im);
-            store(base + 4, p2.re); store(base + 5, p2.im);
         }
 #undef HMM
 }
 
-// A = sum_k exp(-i M_k L/E 2.534) Q_k from a stage-A record (load(f) reads field f)
+// A = sum_k exp(-i M_k L/E 2.534) Q_k from a stage-A record (load(f) reads field f); in the
+// reduced (no-decay) form rows 0 and 1 of the SU(3) matrix A' (see eigen_terms), row 2 of A
+// is left untouched
 template <bool DECAY, class LoadFn>
 __device__ __forceinline__ void amplitude_from_terms(const LoadFn &load, double L_over_E, mat3 &A) {
     const double hbar_c_factor = 2.534;
+    if (!DECAY) {
+        cplx e[3];
+#pragma unroll
+        for (int k = 1; k < 3; k++) {
+            double arg = (-load(k - 1)) * L_over_E * hbar_c_factor;
+            double sn, cs;
+            sincos(arg, &sn, &cs);
+            e[k] = cmake(cs, sn);
+        }
+        e[0] = cmul(e[1], e[2]);
+        e[0].im = -e[0].im;
+        const cplx f1 = csub(e[1], e[0]), f2 = csub(e[2], e[0]);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const int base = 2 + 4 * (3 * i + j);
+                cplx acc = cmul(f1, cmake(load(base + 0), load(base + 1)));
+                acc = cadd(acc, cmul(f2, cmake(load(base + 2), load(base + 3))));
+                if (i == j) acc = cadd(acc, e[0]);
+                A.m[i][j] = acc;
+            }
+        return;
+    }
     cplx ph[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        if (!DECAY) {
-            double arg = (-load(2 * k)) * L_over_E * hbar_c_factor;
-            double s, c;
-            sincos(arg, &s, &c);
-            ph[k] = cmake(c, s);
-        } else {
-            cplx Mk = cmake(load(2 * k), load(2 * k + 1));
-            cplx arg = cscale(hbar_c_factor, cscale(L_over_E, cscale(-1.0, Mk)));
-            double l = exp(-arg.im);
-            double s, c;
-            sincos(arg.re, &s, &c);
-            ph[k] = cmake(l * c, l * s);
-        }
+        cplx Mk = cmake(load(2 * k), load(2 * k + 1));
+        cplx arg = cscale(hbar_c_factor, cscale(L_over_E, cscale(-1.0, Mk)));
+        double l = exp(-arg.im);
+        double s, c;
+        sincos(arg.re, &s, &c);
+        ph[k] = cmake(l * c, l * s);
     }
 #pragma unroll
     for (int i = 0; i < 3; i++)
@@ -634,6 +669,16 @@ __device__ __forceinline__ void amplitude_from_terms(const LoadFn &load, double 
             acc = cadd(acc, cmul(ph[2], cmake(load(base + 4), load(base + 5))));
             A.m[i][j] = acc;
         }
+}
+
+// third row of an SU(3) matrix from its first two: conj(row0 x row1)
+__device__ __forceinline__ void su3_complete(mat3 &A) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int k = (j + 1) % 3, l = (j + 2) % 3;
+        cplx c = csub(cmul(A.m[0][k], A.m[1][l]), cmul(A.m[0][l], A.m[1][k]));
+        A.m[2][j] = cmake(c.re, -c.im);
+    }
 }
 
 // Layer-matrix cache of the reference (numba_osc_kernels.py:230-249): layer i

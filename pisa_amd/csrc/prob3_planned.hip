@@ -28,13 +28,14 @@ namespace pisa {
 // and an evaluation is two launches:
 //   stage AB  wave = (item, sign, 64 energies): terms of (E, rho) in registers, then
 //             A = sum_k phase_k Q_k for the item's pairs -> amp[side][pair][18][n_e]
+//             (without decay: the SU(3) form of A, two rows stored; see eigen_terms)
 //   stage C   workgroup = (row, sign, 64 energies) x G waves: the chain is multiplied from
 //             its middle outwards on both sides at once (see prob3_chain_kernel), wave 0
 //             joins the waves' partial products (LDS), rotates to the flavour basis and
 //             stores P and the gather tables.
 // Stage C associates the product differently from the sequential reference and uses
 // fused multiply-adds, so its results agree with prob3_grid_kernel to rounding
-// (<= 1e-13 absolute on the probabilities), not bit for bit.
+// (<= 3e-13 absolute on the probabilities), not bit for bit.
 constexpr int CHAIN_GROUPS_DEFAULT = 2;
 
 template <bool DECAY>
@@ -59,8 +60,10 @@ prob3_terms_amp_kernel(const Prob3Consts c, const double *__restrict__ energy, i
         amplitude_from_terms<DECAY>(load, pair_dist[p0 + q] / e, A);
         const int64_t ns = (int64_t)gridDim.z * 64;  // energy stride: whole tiles, cache-line aligned
         double *o = amp + ((int64_t)(side * n_pairs + p0 + q) * 18) * ns + ie;
+        // no decay: rows 0 and 1 of the SU(3) form only (12 of the 18 slots of a pair); the
+        // chain kernel completes the third row.  This kernel is bound by these stores.
 #pragma unroll
-        for (int i = 0; i < 3; i++)
+        for (int i = 0; i < (DECAY ? 3 : 2); i++)
 #pragma unroll
             for (int j = 0; j < 3; j++) {
                 o[(int64_t)(6 * i + 2 * j) * ns] = A.m[i][j].re;
@@ -115,6 +118,7 @@ prob3_chain_kernel(const Prob3Consts c, int n_e, const int32_t *__restrict__ row
     const int side = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int g = threadIdx.x >> 6;
+    const bool decay = c.decay != 0;  // uniform: full 3x3 matrices were stored
     const int ie = blockIdx.z * 64 + lane;
     const bool live = ie < n_e;
     double *out = side == 0 ? prob_nu : prob_nubar;
@@ -129,10 +133,11 @@ prob3_chain_kernel(const Prob3Consts c, int n_e, const int32_t *__restrict__ row
     auto load_pair = [&](int k, mat3 &A) {
         const double *a = amp + ((int64_t)(side * n_pairs + k) * 18) * ns + ie;
 #pragma unroll
-        for (int i = 0; i < 3; i++)
+        for (int i = 0; i < (decay ? 3 : 2); i++)
 #pragma unroll
             for (int j = 0; j < 3; j++)
                 A.m[i][j] = cmake(a[(int64_t)(6 * i + 2 * j) * ns], a[(int64_t)(6 * i + 2 * j + 1) * ns]);
+        if (!decay) su3_complete(A);
     };
     mat3 L, R;
     bool have_l = false, have_r = false;

@@ -122,7 +122,7 @@ def test_prob3_grid_planned(K, L):
             nu, nubar, pepmu = K.prob3_grid(p, e, dens, dist, e_major=e_major, want_pepmu=True)
             nu2, nubar2, pepmu2 = K.prob3_grid_planned(p, plan, e, e_major=e_major)
             for a, b in ((nu, nu2), (nubar, nubar2), (pepmu, pepmu2)):
-                assert float((a - b).abs().max()) < 1e-13
+                assert float((a - b).abs().max()) < 3e-13
             pm = pepmu2.cpu().numpy()
             for side, P in ((0, nu2.cpu().numpy()), (1, nubar2.cpu().numpy())):
                 for f in range(3):
