@@ -26,13 +26,19 @@ namespace pisa {
 //   * cuts the pairs of each distinct density into work items of a few pairs,
 //   * lists every row's chain as pair indices in path order,
 // and an evaluation is two launches:
-//   stage AB  wave = (item, sign, 64 energies): terms of (E, rho) in registers, then
-//             A = sum_k phase_k Q_k for the item's pairs -> amp[side][pair][18][n_e]
-//             (without decay: the SU(3) form of A, two rows stored; see eigen_terms)
-//   stage C   workgroup = (row, sign, 64 energies) x G waves: the chain is multiplied from
-//             its middle outwards on both sides at once (see prob3_chain_kernel), wave 0
-//             joins the waves' partial products (LDS), rotates to the flavour basis and
-//             stores P and the gather tables.
+//   stage A   wave = (distinct density, sign, 64 energies): the terms of (E, rho)
+//             -> records terms[sign][density][field][n_e]  (1-3 MB, L2 resident)
+//   stage C   workgroup = (row, sign, 64 energies) x G waves: forms each layer matrix
+//             A = sum_k phase_k Q_k from the record of the layer's density where it multiplies
+//             it (a pair belongs to one row: nothing is computed twice) -- the chain is
+//             multiplied from its middle outwards on both sides at once (see
+//             prob3_chain_kernel), wave 0 joins the waves' partial products (LDS), rotates to
+//             the flavour basis and stores P and the gather tables.
+// The earlier split is kept as an option (PISA_HIP_PROB3_FUSED_AMP=0 at plan creation):
+//   stage AB  wave = (item of a few pairs of one density, sign, 64 energies): terms in registers,
+//             then the item's layer matrices -> amp[sign][pair][18][n_e]; stage C reads them.
+//             Stage AB is bound by those stores (20-29 MB per evaluation through HBM).
+// Without decay the layer matrices are taken in their SU(3) form (see eigen_terms).
 // Stage C associates the product differently from the sequential reference and uses
 // fused multiply-adds, so its results agree with prob3_grid_kernel to rounding
 // (<= 3e-13 absolute on the probabilities), not bit for bit.
@@ -72,6 +78,24 @@ prob3_terms_amp_kernel(const Prob3Consts c, const double *__restrict__ energy, i
     }
 }
 
+// Stage A alone: the terms of every (distinct density, sign, energy), field-major so that the
+// lanes of a wave (64 energies) read and write contiguously.  Used with the chain kernel's
+// AMP mode, which forms each layer matrix from these records where it multiplies it.
+template <bool DECAY>
+__global__ void __launch_bounds__(64)
+prob3_terms_kernel(const Prob3Consts c, const double *__restrict__ energy, int n_e,
+                   const double *__restrict__ rho_unique, int n_unique,
+                   double *__restrict__ terms) {
+    const int u = blockIdx.x;
+    const int side = blockIdx.y;
+    const int ie = blockIdx.z * 64 + threadIdx.x;
+    if (ie >= n_e) return;
+    const int64_t ns = (int64_t)gridDim.z * 64;
+    double *o = terms + ((int64_t)(side * n_unique + u) * PROB3_NF) * ns + ie;
+    auto store = [&](int f, double v) { o[(int64_t)f * ns] = v; };
+    eigen_terms<DECAY>(c.side[side], c.dm, c.vac_order, energy[ie], rho_unique[u], store);
+}
+
 // C = A.B with fused multiply-adds (4 per complex multiply-accumulate instead of 4 mul + 4
 // add).  Stage C is a short dependent sequence of 3x3 complex products per wave: instruction
 // count is latency.  Only used where the product is already associated differently from the
@@ -105,20 +129,26 @@ __device__ __forceinline__ void mat_mul_fma(const mat3 &A, const mat3 &B, mat3 &
 // single dependent chain).  Wave g of the workgroup takes the g-th part of the steps; wave 0
 // joins  L_{G-1} .. L_0 . a_m . R_0 .. R_{G-1}.  Valid for any sequence (non-mirrored steps just
 // load two matrices); same matrices as the other forms, associated differently.
-template <int G>
+// AMP = 0: layer matrices read from stage AB's `amp`.  AMP = 1 (no decay) / 2 (decay): formed here
+// from the stage-A records `terms` of the layer's density (a pair belongs to one row, so nothing
+// is computed twice, and the records -- 2 x n_unique x 26 x n_e doubles -- stay in the L2 where
+// the amplitudes, 12-18 doubles per pair and energy, had to travel through HBM).
+template <int G, int AMP>
 __global__ void __launch_bounds__(64 * G)
 prob3_chain_kernel(const Prob3Consts c, int n_e, const int32_t *__restrict__ row_start,
                     const int32_t *__restrict__ row_cnt, const int32_t *__restrict__ row_pairs,
                     int n_cz, int n_pairs, const double *__restrict__ amp, int e_major,
                     double *__restrict__ prob_nu, double *__restrict__ prob_nubar,
-                    double2 *__restrict__ pepmu) {
+                    double2 *__restrict__ pepmu, const double *__restrict__ energy,
+                    const int32_t *__restrict__ pair_u, const double *__restrict__ pair_dist,
+                    int n_unique) {
     auto MM = [](const mat3 &A_, const mat3 &B_, mat3 &C_) { mat_mul_fma(A_, B_, C_); };
     __shared__ double s_part[(G > 1 ? G - 1 : 1) * 2 * 18 * 64];  // [group-1][L|R][18][lane]
     const int jcz = blockIdx.x;
     const int side = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int g = threadIdx.x >> 6;
-    const bool decay = c.decay != 0;  // uniform: full 3x3 matrices were stored
+    const bool decay = AMP == 0 ? c.decay != 0 : AMP == 2;  // full 3x3 matrices stored / formed
     const int ie = blockIdx.z * 64 + lane;
     const bool live = ie < n_e;
     double *out = side == 0 ? prob_nu : prob_nubar;
@@ -130,7 +160,16 @@ prob3_chain_kernel(const Prob3Consts c, int n_e, const int32_t *__restrict__ row
     const int s0 = 1 + (int)(((int64_t)n_steps * g) / G);
     const int s1 = 1 + (int)(((int64_t)n_steps * (g + 1)) / G);
     const int64_t ns = (int64_t)gridDim.z * 64;
+    const double e_lane = (AMP != 0 && live) ? energy[ie] : 1.0;
     auto load_pair = [&](int k, mat3 &A) {
+        if (AMP != 0) {
+            // `amp` holds the stage-A records here
+            const double *r = amp + ((int64_t)(side * n_unique + pair_u[k]) * PROB3_NF) * ns + ie;
+            auto load = [&](int f) { return r[(int64_t)f * ns]; };
+            amplitude_from_terms<AMP == 2>(load, pair_dist[k] / e_lane, A);
+            if (AMP == 1) su3_complete(A);
+            return;
+        }
         const double *a = amp + ((int64_t)(side * n_pairs + k) * 18) * ns + ie;
 #pragma unroll
         for (int i = 0; i < (decay ? 3 : 2); i++)
@@ -251,6 +290,12 @@ struct pisa_hip_grid_plan {
     double *d_rho;         // [n_unique]
     double *d_amp;         // stage-AB amplitudes [2][n_pairs][18][n_e]
     int n_e_alloc;
+    int32_t *d_pair_u;     // [n_pairs] distinct-density index of each pair
+    double *d_terms;       // stage-A records [2][n_unique][PROB3_NF][n_e] (AMP mode)
+    int n_e_terms;
+    int fused_amp;         // 1 (default): stage A + chain kernel forming the layer matrices itself;
+                           // 0 (PISA_HIP_PROB3_FUSED_AMP=0 when the plan is created): stage AB
+                           // stores the layer matrices, the chain kernel reads them
     // host copies for re-cutting the items when n_e changes
     int32_t *h_pair_u;
     int items_for_n_e;
@@ -259,7 +304,7 @@ struct pisa_hip_grid_plan {
 PISA_API int pisa_hip_grid_plan_destroy(pisa_hip_grid_plan *p) {
     if (!p) return PISA_HIP_OK;
     void *ptrs[] = {p->d_item_u, p->d_item_p0, p->d_item_cnt, p->d_pair_dist, p->d_row_start,
-                    p->d_row_cnt, p->d_row_pairs, p->d_rho, p->d_amp};
+                    p->d_row_cnt, p->d_row_pairs, p->d_rho, p->d_amp, p->d_pair_u, p->d_terms};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete[] p->h_pair_u;
@@ -371,6 +416,10 @@ PISA_API int pisa_hip_grid_plan_create(const double *d_densities, const double *
         p->n_chain = nc;
         p->h_pair_u = su;
         su = nullptr;
+        {
+            const char *v = getenv("PISA_HIP_PROB3_FUSED_AMP");
+            p->fused_amp = v ? (atoi(v) != 0) : 1;
+        }
         if (nu == 0) uniq[0] = 0.0;
         size_t npa = np > 0 ? np : 1, nca = nc > 0 ? nc : 1;
         rc = check_hip(hipMalloc(&p->d_pair_dist, npa * 8), "hipMalloc");
@@ -378,6 +427,8 @@ PISA_API int pisa_hip_grid_plan_create(const double *d_densities, const double *
         if (!rc) rc = check_hip(hipMalloc(&p->d_row_cnt, (size_t)n_cz * 4), "hipMalloc");
         if (!rc) rc = check_hip(hipMalloc(&p->d_row_pairs, nca * 4), "hipMalloc");
         if (!rc) rc = check_hip(hipMalloc(&p->d_rho, (size_t)p->n_unique * 8), "hipMalloc");
+        if (!rc) rc = check_hip(hipMalloc(&p->d_pair_u, npa * 4), "hipMalloc");
+        if (!rc && np > 0) rc = check_hip(hipMemcpy(p->d_pair_u, p->h_pair_u, (size_t)np * 4, hipMemcpyHostToDevice), "h2d");
         if (!rc && np > 0) rc = check_hip(hipMemcpy(p->d_pair_dist, sdist, (size_t)np * 8, hipMemcpyHostToDevice), "h2d");
         if (!rc) rc = check_hip(hipMemcpy(p->d_row_start, rstart, (size_t)n_cz * 4, hipMemcpyHostToDevice), "h2d");
         if (!rc) rc = check_hip(hipMemcpy(p->d_row_cnt, rcnt, (size_t)n_cz * 4, hipMemcpyHostToDevice), "h2d");
@@ -399,6 +450,42 @@ PISA_API int pisa_hip_prob3_grid_planned(const pisa_hip_prob3_params *h_params,
     Prob3Consts c;
     int rc = make_consts(h_params, c);
     if (rc) return rc;
+    hipStream_t s = as_stream(stream);
+    const unsigned tiles = (unsigned)((n_e + 63) / 64);
+    static const int groups = []() {
+        const char *v = getenv("PISA_HIP_CHAIN_GROUPS");
+        int g = v ? atoi(v) : CHAIN_GROUPS_DEFAULT;
+        return (g == 1 || g == 2 || g == 4) ? g : CHAIN_GROUPS_DEFAULT;
+    }();
+    const int fused_amp = plan->fused_amp;
+    dim3 cblock(64 * groups), cgrid((unsigned)plan->n_cz, 2, tiles);
+    if (fused_amp) {
+        if (plan->n_e_terms < n_e) {
+            if (plan->d_terms) (void)hipFree(plan->d_terms);
+            plan->d_terms = nullptr;
+            plan->n_e_terms = 0;
+            size_t bytes = (size_t)2 * plan->n_unique * PROB3_NF * ((size_t)tiles * 64) * sizeof(double);
+            PISA_TRY_HIP(hipMalloc(&plan->d_terms, bytes));
+            plan->n_e_terms = n_e;
+        }
+        dim3 tblock(64), tgrid((unsigned)plan->n_unique, 2, tiles);
+        if (c.decay)
+            hipLaunchKernelGGL(prob3_terms_kernel<true>, tgrid, tblock, 0, s, c, d_energy, (int)n_e,
+                               plan->d_rho, plan->n_unique, plan->d_terms);
+        else
+            hipLaunchKernelGGL(prob3_terms_kernel<false>, tgrid, tblock, 0, s, c, d_energy, (int)n_e,
+                               plan->d_rho, plan->n_unique, plan->d_terms);
+        PISA_CHECK_LAUNCH("prob3_terms_kernel");
+#define CHAIN(G, A) hipLaunchKernelGGL((prob3_chain_kernel<G, A>), cgrid, cblock, 0, s, c, (int)n_e, plan->d_row_start, \
+                       plan->d_row_cnt, plan->d_row_pairs, plan->n_cz, plan->n_pairs, plan->d_terms,              \
+                       (int)e_major, d_prob_nu, d_prob_nubar, (double2 *)d_pepmu, d_energy, plan->d_pair_u,       \
+                       plan->d_pair_dist, plan->n_unique)
+        if (c.decay) { if (groups == 1) CHAIN(1, 2); else if (groups == 4) CHAIN(4, 2); else CHAIN(2, 2); }
+        else { if (groups == 1) CHAIN(1, 1); else if (groups == 4) CHAIN(4, 1); else CHAIN(2, 1); }
+#undef CHAIN
+        PISA_CHECK_LAUNCH("prob3_chain_kernel");
+        return PISA_HIP_OK;
+    }
     if (plan->n_e_alloc < n_e) {
         if (plan->d_amp) (void)hipFree(plan->d_amp);
         plan->d_amp = nullptr;
@@ -408,15 +495,7 @@ PISA_API int pisa_hip_prob3_grid_planned(const pisa_hip_prob3_params *h_params,
         plan->n_e_alloc = n_e;
     }
     if (plan->items_for_n_e != n_e && (rc = cut_items(plan, n_e))) return rc;
-    hipStream_t s = as_stream(stream);
-    const unsigned tiles = (unsigned)((n_e + 63) / 64);
     dim3 ablock(64), agrid((unsigned)(plan->n_items > 0 ? plan->n_items : 1), 2, tiles);
-    static const int groups = []() {
-        const char *v = getenv("PISA_HIP_CHAIN_GROUPS");
-        int g = v ? atoi(v) : CHAIN_GROUPS_DEFAULT;
-        return (g == 1 || g == 2 || g == 4) ? g : CHAIN_GROUPS_DEFAULT;
-    }();
-    dim3 cblock(64 * groups), cgrid((unsigned)plan->n_cz, 2, tiles);
     if (plan->n_items > 0) {
         if (c.decay)
             hipLaunchKernelGGL(prob3_terms_amp_kernel<true>, agrid, ablock, 0, s, c, d_energy, (int)n_e,
@@ -427,9 +506,10 @@ PISA_API int pisa_hip_prob3_grid_planned(const pisa_hip_prob3_params *h_params,
                                plan->d_rho, plan->d_item_u, plan->d_item_p0, plan->d_item_cnt,
                                plan->d_pair_dist, plan->n_pairs, plan->d_amp);
     }
-#define CHAIN(G) hipLaunchKernelGGL(prob3_chain_kernel<G>, cgrid, cblock, 0, s, c, (int)n_e, plan->d_row_start, \
+#define CHAIN(G) hipLaunchKernelGGL((prob3_chain_kernel<G, 0>), cgrid, cblock, 0, s, c, (int)n_e, plan->d_row_start, \
                        plan->d_row_cnt, plan->d_row_pairs, plan->n_cz, plan->n_pairs, plan->d_amp,          \
-                       (int)e_major, d_prob_nu, d_prob_nubar, (double2 *)d_pepmu)
+                       (int)e_major, d_prob_nu, d_prob_nubar, (double2 *)d_pepmu, d_energy, plan->d_pair_u,  \
+                       plan->d_pair_dist, plan->n_unique)
     if (groups == 1) CHAIN(1); else if (groups == 4) CHAIN(4); else CHAIN(2);
 #undef CHAIN
     PISA_CHECK_LAUNCH("prob3_chain_kernel");

@@ -104,14 +104,18 @@ def test_prob3_grid_golden_and_oracle(K, L, oracle):
             np.testing.assert_allclose(nubar, g[name + "::prob_nubar"], err_msg=name, **AC)
 
 
-def test_prob3_grid_planned(K, L):
-    """planned grid form (terms hoisted per (E, density), mirrored layers share one
+@pytest.mark.parametrize("fused_amp", ["1", "0"])
+def test_prob3_grid_planned(K, L, fused_amp, monkeypatch):
+    """both variants of the planned form (layer matrices formed inside the chain kernel from the
+    per-density records / stored by stage AB and read back);
+    planned grid form (terms hoisted per (E, density), mirrored layers share one
     matrix, chain multiplied in parts) == direct grid kernel to rounding (the
     product is associated differently), == reference goldens within the prob3
     tolerance; the compact (P_e, P_mu) gather tables are exact copies of P"""
     g = load_golden("prob3_grid_prem12.npz")
     e, dens, dist = K.to_device(g["energy"]), K.to_device(g["densities"]), K.to_device(g["distances"])
     n_e, n_cz = len(g["energy"]), g["densities"].shape[0]
+    monkeypatch.setenv("PISA_HIP_PROB3_FUSED_AMP", fused_amp)  # read when the plan is created
     plan = K.GridPlan(dens, dist)
     # "io": the vacuum ordering of the eigenvalues (resolved on the host in this form) differs
     for name in ("no", "io", "nsi", "decay"):
