@@ -359,6 +359,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
+        st.close()
         dist.destroy_process_group()
 
 

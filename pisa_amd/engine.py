@@ -194,6 +194,7 @@ class HotPathEngine:
             # order them for the table gathers; larger binnings need runs of equal bin
             sort_events = "node" if self.n_bins * 96 <= 65536 else "bin"
         self.rank, self.world_size, self.group = rank, world_size, group
+        self._rccl = None  # direct RCCL limb all-reduce, created at the first use
         self.names = [c["name"] for c in containers]
         self._keep = []  # device tensors referenced by raw pointer
         self.indexed, self.planned = indexed, planned
@@ -407,7 +408,29 @@ class HotPathEngine:
         self._limbs_zero = self._maps_valid = False
 
     def allreduce(self):
-        allreduce_limbs(self.ws.limbs, self.world_size, self.group)
+        """int64 SUM of the limbs over the ranks: RCCL called directly on the launch stream where
+        the group runs on RCCL (`pisa_amd/rccl.py`; all ranks agree on it at the first call),
+        `torch.distributed` otherwise (gloo in the CPU tests, or PISA_HIP_DIRECT_RCCL=0)."""
+        if self.world_size <= 1:
+            return
+        if self._rccl is None:
+            import os
+
+            from . import rccl
+
+            self._rccl = False
+            if int(os.environ.get("PISA_HIP_DIRECT_RCCL", "1")):
+                self._rccl = rccl.LimbAllReduce.create(self.dev, self.group) or False
+        if self._rccl:
+            self._rccl.all_reduce_(self.ws.limbs, K._stream())
+        else:
+            allreduce_limbs(self.ws.limbs, self.world_size, self.group)
+
+    def close(self):
+        """release the direct RCCL communicator (before the process group is destroyed)"""
+        if self._rccl:
+            self._rccl.destroy()
+        self._rccl = None
 
     def finalize(self):
         """limbs -> fp64 maps (no-op if the fused tail of `eval` already wrote them)"""

@@ -250,7 +250,7 @@ def test_large_binning_compact_and_dropped():
     assert h0.sum() > 0
 
 
-def test_rccl_limb_allreduce_single_rank(tmp_path):
+def test_rccl_limb_allreduce_single_rank(tmp_path, monkeypatch):
     """The N > 1 code path on the one GPU a test box has: a 1-rank RCCL group, the engine told
     it is one of two ranks so that every evaluation goes through the int64 limb all-reduce on
     the device (identity on a 1-rank group).  Checks that RCCL accepts the int64 SUM, that the
@@ -271,19 +271,27 @@ def test_rccl_limb_allreduce_single_rank(tmp_path):
     dist.init_process_group("nccl", init_method="file://%s" % (tmp_path / "store"), rank=0,
                             world_size=1, device_id=torch.device("cuda", 0))
     try:
+        def timed():
+            t0 = time.perf_counter()
+            for _ in range(50):
+                st.eval_host(points[0], "llh")
+            return (time.perf_counter() - t0) / 50 * 1e6
+
+        t_plain = timed()
         st.world_size = 2
         got = [st.eval_host(p, "llh") for p in points]
         assert got == ref
-        t0 = time.perf_counter()
-        for _ in range(50):
-            st.eval_host(points[0], "llh")
-        dt = (time.perf_counter() - t0) / 50
-        st.world_size = 1
-        t0 = time.perf_counter()
-        for _ in range(50):
-            st.eval_host(points[0], "llh")
-        dt1 = (time.perf_counter() - t0) / 50
-        print("eval with 1-rank RCCL all-reduce %.1f us, without %.1f us" % (dt * 1e6, dt1 * 1e6))
+        assert st._rccl, "direct RCCL communicator not created"
+        t_direct = timed()
+        # the same through torch.distributed (the fall-back path)
+        st.close()
+        monkeypatch.setenv("PISA_HIP_DIRECT_RCCL", "0")
+        got = [st.eval_host(p, "llh") for p in points]
+        assert got == ref
+        assert st._rccl is False
+        t_torch = timed()
+        print("eval: plain %.1f us, 1-rank RCCL direct %.1f us, through torch.distributed %.1f us"
+              % (t_plain, t_direct, t_torch))
         st.check_status()
     finally:
         dist.destroy_process_group()
