@@ -186,14 +186,20 @@ struct EvArgs {
     EvCont cont[EV_MAX_CONT];
 };
 
-template <bool DECAY>
-__global__ void __launch_bounds__(128)
+// SIDE (0 nu / 1 nubar) is a template parameter: indexing the by-value constants with a run-time
+// side made the compiler copy them to scratch (2.3 KB per lane) and read them back into VGPRs
+template <bool DECAY, int SIDE>
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
 prob3_events_kernel(const Prob3Consts c, const EarthDev earth, const EvArgs ev, int max_seg,
                     int32_t *__restrict__ status) {
-    int ci = 0;
-    while (ci + 1 < ev.n_cont && (int)blockIdx.x >= ev.blk_start[ci + 1]) ci++;  // workgroup-uniform
+    // Workgroups are dealt to the containers round-robin (workgroup b = chunk b / n_cont of
+    // container b % n_cont).  Every container's events are sorted by coszen, longest paths
+    // first, so the long paths of ALL containers run first and the short ones fill the tail
+    // (container-major order left each later container's long paths for the end).
+    const int ci = (int)(blockIdx.x % (unsigned)ev.n_cont);  // workgroup-uniform
+    const int chunk = (int)(blockIdx.x / (unsigned)ev.n_cont);
     const EvCont &C = ev.cont[ci];
-    const int side = C.side;
+    constexpr int side = SIDE;
     const double *__restrict__ energy = C.energy;
     const double *__restrict__ coszen = C.coszen;
     const int64_t n = C.n;
@@ -205,6 +211,7 @@ prob3_events_kernel(const Prob3Consts c, const EarthDev earth, const EvArgs ev, 
     double *s_lim = s_rhos + PISA_HIP_MAX_SHELLS;
     double *s_len = s_lim + PISA_HIP_MAX_SHELLS;                       // [max_seg][blockDim]
     unsigned char *s_shell = reinterpret_cast<unsigned char *>(s_len + (size_t)max_seg * blockDim.x);
+    unsigned char *s_src = s_shell + (size_t)max_seg * blockDim.x;
     for (int k = threadIdx.x; k < earth.n_shell; k += blockDim.x) {
         s_radii[k] = earth.radii[k];
         s_rhos[k] = earth.rhos[k];
@@ -217,7 +224,7 @@ prob3_events_kernel(const Prob3Consts c, const EarthDev earth, const EvArgs ev, 
         const double *radii, *rhos, *coszen_limit;
     } e{earth.n_shell, earth.idx, earth.r_detector, s_radii, s_rhos, s_lim};
 
-    int64_t i = (int64_t)(blockIdx.x - ev.blk_start[ci]) * blockDim.x + threadIdx.x;
+    int64_t i = (int64_t)chunk * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int lane = threadIdx.x;
     const int bd = blockDim.x;
@@ -237,10 +244,30 @@ prob3_events_kernel(const Prob3Consts c, const EarthDev earth, const EvArgs ev, 
         dist = s_len[(size_t)l * bd + lane];
         rho = s_rhos[s_shell[(size_t)l * bd + lane]] * (dist > 0. ? 1.0 : 0.0);
     };
+    // the reference's layer-matrix cache, resolved once per path: src[l] = the layer whose
+    // matrix layer l uses (numba_osc_kernels.py:236-249: the LAST earlier layer within 1e-5 in
+    // density and length, followed through its own matches)
+    for (int l = 0; l < nseg; l++) {
+        double rho_l, d_l;
+        layer(l, rho_l, d_l);
+        int sl = l;
+        if (d_l > 0.0) {
+            int found = -1;
+            for (int j = 0; j < l; j++) {
+                double rj, dj;
+                layer(j, rj, dj);
+                if (dj > 0.0 && fabs(rj - rho_l) < 1e-5 && fabs(dj - d_l) < 1e-5) found = j;
+            }
+            if (found >= 0) sl = s_src[(size_t)found * bd + lane];
+        }
+        s_src[(size_t)l * bd + lane] = (unsigned char)sl;
+    }
+    auto src = [&](int l) { return (int)s_src[(size_t)l * bd + lane]; };
     double P[9];
     // through-going paths: in 0..m-2, innermost m-1, out m..2m-3 (path_segment)
-    propagate_path_nested<DECAY>(c.side[side], c.dm, energy[i], nseg,
-                                 (ok && !g.tangent_free) ? g.m - 1 : -1, layer, P);
+    const int32_t vac_order[3] = {c.vac_order[0], c.vac_order[1], c.vac_order[2]};
+    propagate_path_nested<DECAY>(c.side[side], c.dm, vac_order, energy[i], nseg,
+                                 (ok && !g.tangent_free) ? g.m - 1 : -1, layer, src, P);
     if (prob) {
 #pragma unroll
         for (int k = 0; k < 9; k++) prob[9 * i + k] = P[k];
@@ -390,23 +417,40 @@ static int launch_events(const Prob3Consts &c, const EarthDev &e, const EvCont *
     int max_seg = 2 * e.n_shell;
     if (max_seg > PISA_HIP_MAX_LAYERS + 8) return PISA_HIP_ERR_LAYERS;
     const int threads = 64;
-    size_t lds = 3 * PISA_HIP_MAX_SHELLS * sizeof(double) + (size_t)max_seg * threads * 9 + 16;
-    for (int base = 0; base < n_cont; base += EV_MAX_CONT) {
-        int nc = n_cont - base < EV_MAX_CONT ? n_cont - base : EV_MAX_CONT;
+    size_t lds = 3 * PISA_HIP_MAX_SHELLS * sizeof(double) + (size_t)max_seg * threads * 10 + 16;
+    // one launch per sign (see the kernel) and per EV_MAX_CONT containers
+    for (int side = 0; side < 2; side++) {
         EvArgs a;
-        a.n_cont = nc;
+        a.n_cont = 0;
         a.blk_start[0] = 0;
-        for (int k = 0; k < nc; k++) {
-            a.cont[k] = conts[base + k];
-            a.blk_start[k + 1] = a.blk_start[k] + (int)((conts[base + k].n + threads - 1) / threads);
+        auto flush = [&]() -> int {
+            if (a.n_cont == 0 || a.blk_start[a.n_cont] == 0) { a.n_cont = 0; return PISA_HIP_OK; }
+            int max_blocks = 0;
+            for (int k = 0; k < a.n_cont; k++) {
+                const int nb = a.blk_start[k + 1] - a.blk_start[k];
+                max_blocks = nb > max_blocks ? nb : max_blocks;
+            }
+            dim3 block(threads), grid((unsigned)max_blocks * (unsigned)a.n_cont);
+#define LAUNCH_EV(D, S_) hipLaunchKernelGGL((prob3_events_kernel<D, S_>), grid, block, lds, s, c, e, a, max_seg, d_status)
+            if (c.decay) { if (side == 0) LAUNCH_EV(true, 0); else LAUNCH_EV(true, 1); }
+            else { if (side == 0) LAUNCH_EV(false, 0); else LAUNCH_EV(false, 1); }
+#undef LAUNCH_EV
+            PISA_CHECK_LAUNCH("prob3_events_kernel");
+            a.n_cont = 0;
+            return PISA_HIP_OK;
+        };
+        for (int k = 0; k < n_cont; k++) {
+            if (conts[k].side != side) continue;
+            a.cont[a.n_cont] = conts[k];
+            a.blk_start[a.n_cont + 1] = a.blk_start[a.n_cont] + (int)((conts[k].n + threads - 1) / threads);
+            a.n_cont++;
+            if (a.n_cont == EV_MAX_CONT) {
+                int rc = flush();
+                if (rc) return rc;
+            }
         }
-        if (a.blk_start[nc] == 0) continue;
-        dim3 block(threads), grid((unsigned)a.blk_start[nc]);
-        if (c.decay)
-            hipLaunchKernelGGL(prob3_events_kernel<true>, grid, block, lds, s, c, e, a, max_seg, d_status);
-        else
-            hipLaunchKernelGGL(prob3_events_kernel<false>, grid, block, lds, s, c, e, a, max_seg, d_status);
-        PISA_CHECK_LAUNCH("prob3_events_kernel");
+        int rc = flush();
+        if (rc) return rc;
     }
     return PISA_HIP_OK;
 }

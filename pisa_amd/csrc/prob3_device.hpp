@@ -775,12 +775,22 @@ __device__ __forceinline__ int resolve_layer_index(const LayerFn &layer, int i) 
 // out-going matrix is computed from its own resolved (rho, length), as propagate_element
 // does.  Same matrices as the sequential form, associated differently: equal to rounding.
 // mid < 0: no mirror structure (down-going paths), plain sequential product.
-template <bool DECAY, class LayerFn>
+// Without decay the layer matrices are formed in the reduced SU(3) form of the planned grid
+// path (eigen_terms / amplitude_from_terms: host-prepared mass-basis matrices and vacuum
+// ordering, two projectors, two sincos, third row completed) -- about half the instructions
+// of layer_amplitude; a layer matrix then differs from the reference's by a unit phase, which
+// no probability sees.
+// `src(l)` = resolve_layer_index(layer, l), tabulated by the caller once per path (each
+// resolution is a scan over the earlier layers; three per step added up to a third of the
+// event kernel).
+template <bool DECAY, class LayerFn, class SrcFn>
 __device__ __forceinline__ void propagate_path_nested(const Prob3Side &S, const double (&dm)[3][3],
+                                                      const int32_t (&vac_order)[3],
                                                       double energy, int n_layers, int mid,
-                                                      const LayerFn &layer, double (&P)[9]) {
+                                                      const LayerFn &layer, const SrcFn &src,
+                                                      double (&P)[9]) {
     double mv[3] = {0.0, 0.0, 0.0};
-    if (!DECAY) get_dms_vacuum(energy, dm, mv);
+    if (DECAY) get_dms_vacuum(energy, dm, mv);  // unused by the decay branch, kept for the signature
     mat3 T;
     bool have = false;
 #pragma unroll
@@ -789,8 +799,17 @@ __device__ __forceinline__ void propagate_path_nested(const Prob3Side &S, const 
         for (int j = 0; j < 3; j++) T.m[i][j] = cmake(0.0, 0.0);
     auto amplitude = [&](int l, mat3 &A) {  // matrix the reference uses for layer l
         double rho, dist;
-        resolve_layer(layer, l, rho, dist);
-        layer_amplitude<DECAY, true>(S, dm, energy, rho, dist, A, mv);
+        layer(src(l), rho, dist);
+        if (DECAY) {
+            layer_amplitude<DECAY, true>(S, dm, energy, rho, dist, A, mv);
+        } else {
+            double rec[26];
+            auto store = [&](int f, double v) { rec[f] = v; };
+            eigen_terms<false>(S, dm, vac_order, energy, rho, store);
+            auto load = [&](int f) { return rec[f]; };
+            amplitude_from_terms<false>(load, dist / energy, A);
+            su3_complete(A);
+        }
     };
     auto left = [&](const mat3 &A) {   // T <- A . T  (A later on the path)
         if (have) { mat3 t2; mat_mul(A, T, t2); T = t2; } else { T = A; have = true; }
@@ -824,7 +843,7 @@ __device__ __forceinline__ void propagate_path_nested(const Prob3Side &S, const 
             if (out_ok) {
                 // the reference re-uses the in-going layer's matrix iff the cache chain of
                 // the out-going layer ends where the in-going layer's does
-                const bool same = in_ok && resolve_layer_index(layer, lo) == resolve_layer_index(layer, li);
+                const bool same = in_ok && src(lo) == src(li);
                 if (!same) amplitude(lo, A);
                 left(A);
             }
