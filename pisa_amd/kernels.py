@@ -308,7 +308,8 @@ METRIC_KIND = {"llh": 0, "poisson_llh": 1, "chi2": 2, "mod_chi2": 3}
 def metric(kind, actual, expected, sigma2=None, per_bin=False, total_out=None, status=None):
     """Map.metric + nansum (map.py:1572-1604) on device.  `expected` (and
     `sigma2`) may be [n_maps, n_bins]; maps are summed in index order first.
-    Returns a 1-element device tensor (and per-bin values if requested)."""
+    Returns a 1-element device tensor (and per-bin values if requested);
+    `total_out` may also be a pinned (device-mapped) host tensor."""
     lib = _lib.lib()
     n_bins = actual.numel()
     n_maps = 1 if expected.dim() == 1 else expected.shape[0]
@@ -321,7 +322,8 @@ def metric(kind, actual, expected, sigma2=None, per_bin=False, total_out=None, s
         status = torch.zeros(1, dtype=torch.int32, device=dev)
     _lib.check(lib.pisa_hip_metric(
         METRIC_KIND[kind], _ptr(actual), _ptr(expected), _ptr(sigma2), n_maps, n_bins, _ptr(pb),
-        _ptr(total_out), _ptr(status), _stream()))
+        total_out.data_ptr() if not total_out.is_cuda and total_out.is_pinned() else _ptr(total_out),
+        _ptr(status), _stream()))
     if own_status:
         st = int(status.item())
         if st != 0:

@@ -39,7 +39,7 @@ for r in list(csv.reader(open("$OUT/kernel_stats.csv")))[:8]:
 # 20 warm-up evaluations), from the kernel trace of the same rocprofv3 run
 rows = sorted(csv.DictReader(open("$OUT/stats/bench_kernel_trace.csv")), key=lambda r: int(r["Start_Timestamp"]))
 phase = {}
-for key in ("hist_accumulate_kernel", "prob3_terms_amp_kernel", "prob3_chain_kernel", "finalize_metric_kernel"):
+for key in ("hist_accumulate_kernel", "prob3_terms_kernel", "prob3_chain_kernel", "finalize_metric_kernel"):
     d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if key in r["Kernel_Name"]]
     loop = d[21:521]
     phase[key] = {"timed_loop_mean_us": sum(loop) / len(loop) / 1e3, "all_launches_mean_us": sum(d) / len(d) / 1e3,

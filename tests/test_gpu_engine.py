@@ -248,6 +248,10 @@ def test_large_binning_compact_and_dropped():
         else:
             assert np.array_equal(h, h0) and np.array_equal(s, s0)
     assert h0.sum() > 0
+    # the host-polled evaluation works for binnings beyond the one-launch tail as well
+    # (separate finalize and metric kernels, metric written to pinned host memory)
+    ref.make_pseudo_data(wl.osc_params(), seed=0)
+    assert ref.eval_host(p, "llh") == float(ref.eval(p, "llh").item())
 
 
 def test_rccl_limb_allreduce_single_rank(tmp_path, monkeypatch):
