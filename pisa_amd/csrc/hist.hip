@@ -22,7 +22,9 @@
 // Roofline: HBM.  Per event the indexed fused kernel reads
 //   node i32 + bin i32 + nu_flux 2xf64 + weighted_aeff f64 + initial_weights f64
 //   = 40 B      (coordinates digitised once at setup, like the reference's own
-//                pre-digitised irregular dimensions, utils/hist.py:100-113)
+//                pre-digitised irregular dimensions, utils/hist.py:100-113),
+//   24 B in the compact form (static factors folded into the flux pair once),
+//   20 B with the two indices in 16 bits each (MODE 7, the default where it applies),
 // and the coordinate form reads 8 B x (2 lookup coords + D sample coords) more
 // = 72 B (D=3).  The (P_e, P_mu) gather tables (<= 3.8 MB) stay in L2.
 #include <stdlib.h>
