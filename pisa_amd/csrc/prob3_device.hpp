@@ -789,8 +789,7 @@ __device__ __forceinline__ void propagate_path_nested(const Prob3Side &S, const 
                                                       double energy, int n_layers, int mid,
                                                       const LayerFn &layer, const SrcFn &src,
                                                       double (&P)[9]) {
-    double mv[3] = {0.0, 0.0, 0.0};
-    if (DECAY) get_dms_vacuum(energy, dm, mv);  // unused by the decay branch, kept for the signature
+    const double mv[3] = {0.0, 0.0, 0.0};  // vacuum eigenvalues: not needed by either branch here
     mat3 T;
     bool have = false;
 #pragma unroll
