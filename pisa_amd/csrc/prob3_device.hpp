@@ -619,6 +619,54 @@ __device__ __forceinline__ void eigen_terms(const Prob3Side &S, const double (&d
 #undef HMM
 }
 
+// sin and cos of a phase of moderate size.  The phases of the reduced form are
+// (M_k - Mbar) L/E 2.534, a few hundred radians at most; the library sincos carries the machinery
+// for arguments up to 1e308 and is a fifth of the chain kernel.  Three-term Cody-Waite reduction
+// with fused multiply-adds (exact products) and the fdlibm kernel polynomials: < 0.8 ulp for
+// |x| <= 1e9 (checked against long double over 4e7 random arguments between 1e-6 and 1e9);
+// the quadrant is taken from a 64-bit integer, so the reduction keeps working beyond (absolute
+// error <= 1e-16 up to 1e12, 1e-14 up to 1e15 -- smaller than the rounding of such a phase
+// itself); NaN and infinities give NaN.
+__device__ __forceinline__ void sincos_phase(double x, double *s, double *c) {
+    const double two_over_pi = 6.36619772367581382433e-01;
+    const double p1 = 1.57079632679489655800e+00;  // pi/2 rounded to 53 bits
+    const double p2 = 6.12323399573676603587e-17;  // next 53 bits
+    const double p3 = -1.49738490485916983e-33;    // remainder
+    const double k = rint(x * two_over_pi);
+    const double r0 = __builtin_fma(-k, p1, x);
+    const double r = __builtin_fma(-k, p2, r0);
+    double rl = __builtin_fma(-k, p2, r0 - r);     // what the second step rounded away
+    rl = __builtin_fma(-k, p3, rl);
+    const double z = r * r;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double v = z * r;
+    double ps = __builtin_fma(z, S6, S5);
+    ps = __builtin_fma(z, ps, S4);
+    ps = __builtin_fma(z, ps, S3);
+    ps = __builtin_fma(z, ps, S2);
+    const double sn = r - ((z * (0.5 * rl - v * ps) - rl) - v * S1);
+    double pc = __builtin_fma(z, C6, C5);
+    pc = __builtin_fma(z, pc, C4);
+    pc = __builtin_fma(z, pc, C3);
+    pc = __builtin_fma(z, pc, C2);
+    pc = __builtin_fma(z, pc, C1);
+    pc = z * pc;
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    const double cs = w + (((1.0 - w) - hz) + (z * pc - r * rl));
+    const int q = (int)((long long)k & 3);
+    double ss = (q & 1) ? cs : sn, cc = (q & 1) ? sn : cs;
+    if (q == 1 || q == 2) cc = -cc;
+    if (q >= 2) ss = -ss;
+    *s = ss;
+    *c = cc;
+}
+
 // A = sum_k exp(-i M_k L/E 2.534) Q_k from a stage-A record (load(f) reads field f); in the
 // reduced (no-decay) form rows 0 and 1 of the SU(3) matrix A' (see eigen_terms), row 2 of A
 // is left untouched
@@ -631,7 +679,7 @@ __device__ __forceinline__ void amplitude_from_terms(const LoadFn &load, double 
         for (int k = 1; k < 3; k++) {
             double arg = (-load(k - 1)) * L_over_E * hbar_c_factor;
             double sn, cs;
-            sincos(arg, &sn, &cs);
+            sincos_phase(arg, &sn, &cs);
             e[k] = cmake(cs, sn);
         }
         e[0] = cmul(e[1], e[2]);
