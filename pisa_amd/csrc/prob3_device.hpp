@@ -203,8 +203,59 @@ __device__ __forceinline__ void get_dms_vacuum(double energy, const double (&dm)
         mv[i] = 2.0 * energy * (b_v * cos(thv[i]) - c2_v * one_third + dm[0][0]);
 }
 
+// sin and cos of a phase of moderate size.  The phases of the reduced form are
+// (M_k - Mbar) L/E 2.534, a few hundred radians at most; the library sincos carries the machinery
+// for arguments up to 1e308 and is a fifth of the chain kernel.  Three-term Cody-Waite reduction
+// with fused multiply-adds (exact products) and the fdlibm kernel polynomials: < 0.8 ulp for
+// |x| <= 1e9 (checked against long double over 4e7 random arguments between 1e-6 and 1e9);
+// the quadrant is taken from a 64-bit integer, so the reduction keeps working beyond (absolute
+// error <= 1e-16 up to 1e12, 1e-14 up to 1e15 -- smaller than the rounding of such a phase
+// itself); NaN and infinities give NaN.
+__device__ __forceinline__ void sincos_phase(double x, double *s, double *c) {
+    const double two_over_pi = 6.36619772367581382433e-01;
+    const double p1 = 1.57079632679489655800e+00;  // pi/2 rounded to 53 bits
+    const double p2 = 6.12323399573676603587e-17;  // next 53 bits
+    const double p3 = -1.49738490485916983e-33;    // remainder
+    const double k = rint(x * two_over_pi);
+    const double r0 = __builtin_fma(-k, p1, x);
+    const double r = __builtin_fma(-k, p2, r0);
+    double rl = __builtin_fma(-k, p2, r0 - r);     // what the second step rounded away
+    rl = __builtin_fma(-k, p3, rl);
+    const double z = r * r;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double v = z * r;
+    double ps = __builtin_fma(z, S6, S5);
+    ps = __builtin_fma(z, ps, S4);
+    ps = __builtin_fma(z, ps, S3);
+    ps = __builtin_fma(z, ps, S2);
+    const double sn = r - ((z * (0.5 * rl - v * ps) - rl) - v * S1);
+    double pc = __builtin_fma(z, C6, C5);
+    pc = __builtin_fma(z, pc, C4);
+    pc = __builtin_fma(z, pc, C3);
+    pc = __builtin_fma(z, pc, C2);
+    pc = __builtin_fma(z, pc, C1);
+    pc = z * pc;
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    const double cs = w + (((1.0 - w) - hz) + (z * pc - r * rl));
+    const int q = (int)((long long)k & 3);
+    double ss = (q & 1) ? cs : sn, cc = (q & 1) ? sn : cs;
+    if (q == 1 || q == 2) cc = -cc;
+    if (q >= 2) ss = -ss;
+    *s = ss;
+    *c = cc;
+}
+
 // matter half of get_dms: the three roots 2E.lambda of the characteristic cubic of H, in the
 // order of the trigonometric solution (before the vacuum ordering)
+// FAST (reduced form only): the three cosines cos(res), cos(res +- 2pi/3) from ONE sincos and
+// the addition theorem instead of three library calls (differs by rounding).
+template <bool FAST = false>
 __device__ __forceinline__ void get_dms_matter_roots(double energy, const mat3 &H,
                                                      const double (&dm)[3][3], double (&mu)[3]) {
     const cplx h01 = H.m[0][1], h12 = H.m[1][2], h20 = H.m[2][0];
@@ -232,6 +283,15 @@ __device__ __forceinline__ void get_dms_matter_roots(double energy, const mat3 &
     const double a = two_third * 3.14159265358979323846;
     double res = atan2(sqrt(tmp), q) * one_third;
     double b = two_third * sqrt(p);
+    if (FAST) {
+        double sn, cs;
+        sincos_phase(res, &sn, &cs);
+        const double ca = -0.5, sa = 0.86602540378443864676;  // cos, sin of 2pi/3
+        const double cth[3] = {cs * ca - sn * sa, cs * ca + sn * sa, cs};
+#pragma unroll
+        for (int i = 0; i < 3; i++) mu[i] = 2.0 * energy * (b * cth[i] - c2 * one_third + dm[0][0]);
+        return;
+    }
     double th[3] = {res + a, res - a, res};
 #pragma unroll
     for (int i = 0; i < 3; i++) mu[i] = 2.0 * energy * (b * cos(th[i]) - c2 * one_third + dm[0][0]);
@@ -536,7 +596,7 @@ __device__ __forceinline__ void eigen_terms(const Prob3Side &S, const double (&d
     cplx M[3], den[3];
     if (!DECAY) {
         double mu[3], Mr[3];
-        get_dms_matter_roots(energy, Hf, dm, mu);
+        get_dms_matter_roots<true>(energy, Hf, dm, mu);
 #pragma unroll
         for (int k = 0; k < 3; k++)  // vacuum ordering, resolved on the host (Prob3Consts::vac_order)
             Mr[k] = vac_order[k] == 0 ? mu[0] : (vac_order[k] == 1 ? mu[1] : mu[2]);
@@ -617,54 +677,6 @@ __device__ __forceinline__ void eigen_terms(const Prob3Side &S, const double (&d
             }
         }
 #undef HMM
-}
-
-// sin and cos of a phase of moderate size.  The phases of the reduced form are
-// (M_k - Mbar) L/E 2.534, a few hundred radians at most; the library sincos carries the machinery
-// for arguments up to 1e308 and is a fifth of the chain kernel.  Three-term Cody-Waite reduction
-// with fused multiply-adds (exact products) and the fdlibm kernel polynomials: < 0.8 ulp for
-// |x| <= 1e9 (checked against long double over 4e7 random arguments between 1e-6 and 1e9);
-// the quadrant is taken from a 64-bit integer, so the reduction keeps working beyond (absolute
-// error <= 1e-16 up to 1e12, 1e-14 up to 1e15 -- smaller than the rounding of such a phase
-// itself); NaN and infinities give NaN.
-__device__ __forceinline__ void sincos_phase(double x, double *s, double *c) {
-    const double two_over_pi = 6.36619772367581382433e-01;
-    const double p1 = 1.57079632679489655800e+00;  // pi/2 rounded to 53 bits
-    const double p2 = 6.12323399573676603587e-17;  // next 53 bits
-    const double p3 = -1.49738490485916983e-33;    // remainder
-    const double k = rint(x * two_over_pi);
-    const double r0 = __builtin_fma(-k, p1, x);
-    const double r = __builtin_fma(-k, p2, r0);
-    double rl = __builtin_fma(-k, p2, r0 - r);     // what the second step rounded away
-    rl = __builtin_fma(-k, p3, rl);
-    const double z = r * r;
-    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
-                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
-                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
-                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
-                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    const double v = z * r;
-    double ps = __builtin_fma(z, S6, S5);
-    ps = __builtin_fma(z, ps, S4);
-    ps = __builtin_fma(z, ps, S3);
-    ps = __builtin_fma(z, ps, S2);
-    const double sn = r - ((z * (0.5 * rl - v * ps) - rl) - v * S1);
-    double pc = __builtin_fma(z, C6, C5);
-    pc = __builtin_fma(z, pc, C4);
-    pc = __builtin_fma(z, pc, C3);
-    pc = __builtin_fma(z, pc, C2);
-    pc = __builtin_fma(z, pc, C1);
-    pc = z * pc;
-    const double hz = 0.5 * z;
-    const double w = 1.0 - hz;
-    const double cs = w + (((1.0 - w) - hz) + (z * pc - r * rl));
-    const int q = (int)((long long)k & 3);
-    double ss = (q & 1) ? cs : sn, cc = (q & 1) ? sn : cs;
-    if (q == 1 || q == 2) cc = -cc;
-    if (q >= 2) ss = -ss;
-    *s = ss;
-    *c = cc;
 }
 
 // A = sum_k exp(-i M_k L/E 2.534) Q_k from a stage-A record (load(f) reads field f); in the
