@@ -160,16 +160,21 @@ prob3_chain_kernel(const Prob3Consts c, int n_e, const int32_t *__restrict__ row
     const int s0 = 1 + (int)(((int64_t)n_steps * g) / G);
     const int s1 = 1 + (int)(((int64_t)n_steps * (g + 1)) / G);
     const int64_t ns = (int64_t)gridDim.z * 64;
-    const double e_lane = (AMP != 0 && live) ? energy[ie] : 1.0;
-    auto load_pair = [&](int k, mat3 &A) {
+    // 1/E once per lane: L/E as a product (one rounding more than the quotient, 1e-16 on a phase)
+    const double inv_e = (AMP != 0 && live) ? 1.0 / energy[ie] : 1.0;
+    // `pos` = position in the row-pairs list.  In the AMP modes the density index and the length of
+    // the layer are read from lists indexed by that position (chain_u / chain_dist) rather than
+    // through the pair number: one dependent scalar load less in front of every layer matrix.
+    auto load_pair = [&](int pos, mat3 &A) {
         if (AMP != 0) {
             // `amp` holds the stage-A records here
-            const double *r = amp + ((int64_t)(side * n_unique + pair_u[k]) * PROB3_NF) * ns + ie;
+            const double *r = amp + ((int64_t)(side * n_unique + pair_u[pos]) * PROB3_NF) * ns + ie;
             auto load = [&](int f) { return r[(int64_t)f * ns]; };
-            amplitude_from_terms<AMP == 2>(load, pair_dist[k] / e_lane, A);
+            amplitude_from_terms<AMP == 2>(load, pair_dist[pos] * inv_e, A);
             if (AMP == 1) su3_complete(A);
             return;
         }
+        const int k = row_pairs[pos];
         const double *a = amp + ((int64_t)(side * n_pairs + k) * 18) * ns + ie;
 #pragma unroll
         for (int i = 0; i < (decay ? 3 : 2); i++)
@@ -182,14 +187,14 @@ prob3_chain_kernel(const Prob3Consts c, int n_e, const int32_t *__restrict__ row
     bool have_l = false, have_r = false;
     if (live && cnt > 0 && s1 > s0) {
         mat3 A, An;
-        load_pair(row_pairs[k0 + mid - s0], A);
+        load_pair(k0 + mid - s0, A);
         for (int s = s0; s < s1; s++) {
             const int k_in = row_pairs[k0 + mid - s];
             const int k_out = mid + s < cnt ? row_pairs[k0 + mid + s] : -1;
-            if (s + 1 < s1) load_pair(row_pairs[k0 + mid - (s + 1)], An);  // next in flight
+            if (s + 1 < s1) load_pair(k0 + mid - (s + 1), An);  // next in flight
             if (have_r) { mat3 t; MM(R, A, t); R = t; } else { R = A; have_r = true; }
             if (k_out >= 0) {
-                if (k_out != k_in) load_pair(k_out, A);  // not a mirrored pair (workgroup-uniform)
+                if (k_out != k_in) load_pair(k0 + mid + s, A);  // not a mirrored pair (workgroup-uniform)
                 if (have_l) { mat3 t; MM(A, L, t); L = t; } else { L = A; have_l = true; }
             }
             A = An;
@@ -245,7 +250,7 @@ prob3_chain_kernel(const Prob3Consts c, int n_e, const int32_t *__restrict__ row
     }
     mat3 T;
     if (cnt > 0) {
-        load_pair(row_pairs[k0 + mid], T);
+        load_pair(k0 + mid, T);
         if (have_r) { mat3 t; MM(T, R, t); T = t; }
         if (have_l) { mat3 t; MM(L, T, t); T = t; }
     } else {
@@ -291,6 +296,8 @@ struct pisa_hip_grid_plan {
     double *d_amp;         // stage-AB amplitudes [2][n_pairs][18][n_e]
     int n_e_alloc;
     int32_t *d_pair_u;     // [n_pairs] distinct-density index of each pair
+    int32_t *d_chain_u;    // [n_chain] the same per chain entry (position in d_row_pairs)
+    double *d_chain_dist;  // [n_chain] layer length per chain entry
     double *d_terms;       // stage-A records [2][n_unique][PROB3_NF][n_e] (AMP mode)
     int n_e_terms;
     int fused_amp;         // 1 (default): stage A + chain kernel forming the layer matrices itself;
@@ -304,7 +311,8 @@ struct pisa_hip_grid_plan {
 PISA_API int pisa_hip_grid_plan_destroy(pisa_hip_grid_plan *p) {
     if (!p) return PISA_HIP_OK;
     void *ptrs[] = {p->d_item_u, p->d_item_p0, p->d_item_cnt, p->d_pair_dist, p->d_row_start,
-                    p->d_row_cnt, p->d_row_pairs, p->d_rho, p->d_amp, p->d_pair_u, p->d_terms};
+                    p->d_row_cnt, p->d_row_pairs, p->d_rho, p->d_amp, p->d_pair_u, p->d_terms,
+                    p->d_chain_u, p->d_chain_dist};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete[] p->h_pair_u;
@@ -427,6 +435,16 @@ PISA_API int pisa_hip_grid_plan_create(const double *d_densities, const double *
         if (!rc) rc = check_hip(hipMalloc(&p->d_row_cnt, (size_t)n_cz * 4), "hipMalloc");
         if (!rc) rc = check_hip(hipMalloc(&p->d_row_pairs, nca * 4), "hipMalloc");
         if (!rc) rc = check_hip(hipMalloc(&p->d_rho, (size_t)p->n_unique * 8), "hipMalloc");
+        if (!rc) rc = check_hip(hipMalloc(&p->d_chain_u, nca * 4), "hipMalloc");
+        if (!rc) rc = check_hip(hipMalloc(&p->d_chain_dist, nca * 8), "hipMalloc");
+        if (!rc && nc > 0) {
+            int32_t *cu = new int32_t[nc];
+            double *cd = new double[nc];
+            for (int k = 0; k < nc; k++) { cu[k] = p->h_pair_u[chain[k]]; cd[k] = sdist[chain[k]]; }
+            rc = check_hip(hipMemcpy(p->d_chain_u, cu, (size_t)nc * 4, hipMemcpyHostToDevice), "h2d");
+            if (!rc) rc = check_hip(hipMemcpy(p->d_chain_dist, cd, (size_t)nc * 8, hipMemcpyHostToDevice), "h2d");
+            delete[] cu; delete[] cd;
+        }
         if (!rc) rc = check_hip(hipMalloc(&p->d_pair_u, npa * 4), "hipMalloc");
         if (!rc && np > 0) rc = check_hip(hipMemcpy(p->d_pair_u, p->h_pair_u, (size_t)np * 4, hipMemcpyHostToDevice), "h2d");
         if (!rc && np > 0) rc = check_hip(hipMemcpy(p->d_pair_dist, sdist, (size_t)np * 8, hipMemcpyHostToDevice), "h2d");
@@ -478,8 +496,8 @@ PISA_API int pisa_hip_prob3_grid_planned(const pisa_hip_prob3_params *h_params,
         PISA_CHECK_LAUNCH("prob3_terms_kernel");
 #define CHAIN(G, A) hipLaunchKernelGGL((prob3_chain_kernel<G, A>), cgrid, cblock, 0, s, c, (int)n_e, plan->d_row_start, \
                        plan->d_row_cnt, plan->d_row_pairs, plan->n_cz, plan->n_pairs, plan->d_terms,              \
-                       (int)e_major, d_prob_nu, d_prob_nubar, (double2 *)d_pepmu, d_energy, plan->d_pair_u,       \
-                       plan->d_pair_dist, plan->n_unique)
+                       (int)e_major, d_prob_nu, d_prob_nubar, (double2 *)d_pepmu, d_energy, plan->d_chain_u,      \
+                       plan->d_chain_dist, plan->n_unique)
         if (c.decay) { if (groups == 1) CHAIN(1, 2); else if (groups == 4) CHAIN(4, 2); else CHAIN(2, 2); }
         else { if (groups == 1) CHAIN(1, 1); else if (groups == 4) CHAIN(4, 1); else CHAIN(2, 1); }
 #undef CHAIN
