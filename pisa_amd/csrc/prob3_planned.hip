@@ -133,32 +133,51 @@ __device__ __forceinline__ void mat_mul_fma(const mat3 &A, const mat3 &B, mat3 &
 // from the stage-A records `terms` of the layer's density (a pair belongs to one row, so nothing
 // is computed twice, and the records -- 2 x n_unique x 26 x n_e doubles -- stay in the L2 where
 // the amplitudes, 12-18 doubles per pair and energy, had to travel through HBM).
+// G = 0: PACKED launch.  Every workgroup has four waves and holds rows by their length -- one long
+// row split over four waves, two medium rows over two waves each, or four short rows with a
+// wave each (`blk`, built with the plan): what bounds this kernel is the dependent sequence of
+// layer matrices per wave of the longest rows (13 for a 24-layer row, ~2 us each), and
+// four-wave workgroups for EVERY row do not fit the chip at once (250 VGPRs: two workgroups per
+// CU).  Packed, the ~360 workgroups of a 200 x 100 grid are all resident and a 24-layer row has
+// four matrices per wave instead of seven.
 template <int G, int AMP>
-__global__ void __launch_bounds__(64 * G)
+__global__ void __launch_bounds__(G ? 64 * G : 256)
 prob3_chain_kernel(const Prob3Consts c, int n_e, const int32_t *__restrict__ row_start,
                     const int32_t *__restrict__ row_cnt, const int32_t *__restrict__ row_pairs,
                     int n_cz, int n_pairs, const double *__restrict__ amp, int e_major,
                     double *__restrict__ prob_nu, double *__restrict__ prob_nubar,
                     double2 *__restrict__ pepmu, const double *__restrict__ energy,
                     const int32_t *__restrict__ pair_u, const double *__restrict__ pair_dist,
-                    int n_unique) {
+                    int n_unique, const int32_t *__restrict__ blk) {
     auto MM = [](const mat3 &A_, const mat3 &B_, mat3 &C_) { mat_mul_fma(A_, B_, C_); };
-    __shared__ double s_part[(G > 1 ? G - 1 : 1) * 2 * 18 * 64];  // [group-1][L|R][18][lane]
-    const int jcz = blockIdx.x;
-    const int side = blockIdx.y;
+    constexpr bool PACKED = G == 0;
+    __shared__ double s_part[(PACKED ? 3 : (G > 1 ? G - 1 : 1)) * 2 * 18 * 64];  // [partial][L|R][18][lane]
     const int lane = threadIdx.x & 63;
-    const int g = threadIdx.x >> 6;
+    // wave index: uniform within a wave, which the compiler cannot see -- without this the loop
+    // bounds derived from it are 'divergent' and every index look-up becomes a vector load
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // row, group of this wave within the row, groups of the row; partial slot of a writer wave
+    int jcz = blockIdx.x, g = wv, Gr = G;
+    if (PACKED) {
+        const int32_t code = __builtin_amdgcn_readfirstlane(blk[blockIdx.x * 4 + wv]);  // row | g << 16 | groups << 24, -1: idle wave
+        jcz = code < 0 ? -1 : (code & 0xffff);
+        g = code < 0 ? 0 : ((code >> 16) & 0xff);
+        Gr = code < 0 ? 1 : ((code >> 24) & 0xff);
+    }
+    const int part_w = PACKED ? wv - 1 : g - 1;   // where a wave with g > 0 leaves its partials
+    const int part_0 = PACKED ? wv : 0;           // leader: partner h reads slot part_0 + h - 1
+    const int side = blockIdx.y;
     const bool decay = AMP == 0 ? c.decay != 0 : AMP == 2;  // full 3x3 matrices stored / formed
     const int ie = blockIdx.z * 64 + lane;
-    const bool live = ie < n_e;
+    const bool live = ie < n_e && jcz >= 0;
     double *out = side == 0 ? prob_nu : prob_nubar;
     const Prob3Side &S = c.side[side];
-    const int k0 = row_start[jcz];
-    const int cnt = row_cnt[jcz];
+    const int k0 = jcz >= 0 ? row_start[jcz] : 0;
+    const int cnt = jcz >= 0 ? row_cnt[jcz] : 0;
     const int mid = cnt >> 1;
     const int n_steps = mid;  // steps s = 1..mid (out-going side may be one shorter)
-    const int s0 = 1 + (int)(((int64_t)n_steps * g) / G);
-    const int s1 = 1 + (int)(((int64_t)n_steps * (g + 1)) / G);
+    const int s0 = 1 + (int)(((int64_t)n_steps * g) / Gr);
+    const int s1 = 1 + (int)(((int64_t)n_steps * (g + 1)) / Gr);
     const int64_t ns = (int64_t)gridDim.z * 64;
     // 1/E once per lane: L/E as a product (one rounding more than the quotient, 1e-16 on a phase)
     const double inv_e = (AMP != 0 && live) ? 1.0 / energy[ie] : 1.0;
@@ -201,7 +220,7 @@ prob3_chain_kernel(const Prob3Consts c, int n_e, const int32_t *__restrict__ row
         }
     }
     if (g > 0 && live) {
-        double *o = s_part + (size_t)(g - 1) * 2 * 18 * 64 + lane;
+        double *o = s_part + (size_t)part_w * 2 * 18 * 64 + lane;
         if (have_l) {
 #pragma unroll
             for (int i = 0; i < 3; i++)
@@ -224,11 +243,11 @@ prob3_chain_kernel(const Prob3Consts c, int n_e, const int32_t *__restrict__ row
     __syncthreads();
     if (g != 0 || !live) return;
     // wave 0: T_right = R_0 . R_1 .. (later groups further right), T_left = .. L_1 . L_0
-    for (int h = 1; h < G; h++) {
-        const int h0 = 1 + (int)(((int64_t)n_steps * h) / G);
-        const int h1 = 1 + (int)(((int64_t)n_steps * (h + 1)) / G);
-        if (h1 <= h0 || cnt == 0) continue;  // workgroup-uniform: group h had no steps
-        const double *o = s_part + (size_t)(h - 1) * 2 * 18 * 64 + lane;
+    for (int h = 1; h < Gr; h++) {
+        const int h0 = 1 + (int)(((int64_t)n_steps * h) / Gr);
+        const int h1 = 1 + (int)(((int64_t)n_steps * (h + 1)) / Gr);
+        if (h1 <= h0 || cnt == 0) continue;  // wave-uniform: group h had no steps
+        const double *o = s_part + (size_t)(part_0 + h - 1) * 2 * 18 * 64 + lane;
         mat3 Ph;
         // right part of group h always exists when it had steps
 #pragma unroll
@@ -296,6 +315,9 @@ struct pisa_hip_grid_plan {
     double *d_amp;         // stage-AB amplitudes [2][n_pairs][18][n_e]
     int n_e_alloc;
     int32_t *d_pair_u;     // [n_pairs] distinct-density index of each pair
+    int32_t *d_blk;        // [4 * n_blk] packed launch: row | group << 16 | groups << 24 per wave, -1 idle
+    int n_blk;
+    int chain_packed;      // 1 (default): packed chain launch; PISA_HIP_CHAIN_MODE=split: one row per workgroup
     int32_t *d_chain_u;    // [n_chain] the same per chain entry (position in d_row_pairs)
     double *d_chain_dist;  // [n_chain] layer length per chain entry
     double *d_terms;       // stage-A records [2][n_unique][PROB3_NF][n_e] (AMP mode)
@@ -312,7 +334,7 @@ PISA_API int pisa_hip_grid_plan_destroy(pisa_hip_grid_plan *p) {
     if (!p) return PISA_HIP_OK;
     void *ptrs[] = {p->d_item_u, p->d_item_p0, p->d_item_cnt, p->d_pair_dist, p->d_row_start,
                     p->d_row_cnt, p->d_row_pairs, p->d_rho, p->d_amp, p->d_pair_u, p->d_terms,
-                    p->d_chain_u, p->d_chain_dist};
+                    p->d_chain_u, p->d_chain_dist, p->d_blk};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete[] p->h_pair_u;
@@ -435,6 +457,36 @@ PISA_API int pisa_hip_grid_plan_create(const double *d_densities, const double *
         if (!rc) rc = check_hip(hipMalloc(&p->d_row_cnt, (size_t)n_cz * 4), "hipMalloc");
         if (!rc) rc = check_hip(hipMalloc(&p->d_row_pairs, nca * 4), "hipMalloc");
         if (!rc) rc = check_hip(hipMalloc(&p->d_rho, (size_t)p->n_unique * 8), "hipMalloc");
+        {
+            // packed chain launch: rows by length, longest first; 4 waves per workgroup =
+            // one long row x 4 groups | two medium rows x 2 | four short rows x 1
+            const char *m = getenv("PISA_HIP_CHAIN_MODE");
+            p->chain_packed = (m && strcmp(m, "split") == 0) ? 0 : 1;
+            int32_t *code = new int32_t[(size_t)4 * n_cz + 4];
+            int nb = 0;
+            int t4 = 14, t2 = 0;  // crossed layers from which a row gets four / two waves (measured: 22.1 us; 14/6: 23.4; one row per workgroup: 24.4)
+            if (const char *v = getenv("PISA_HIP_PACK_T4")) t4 = atoi(v);  // development probes
+            if (const char *v = getenv("PISA_HIP_PACK_T2")) t2 = atoi(v);
+            auto groups_of = [&](int c_) { return c_ >= t4 ? 4 : (c_ >= t2 ? 2 : 1); };
+            for (int want = 4; want >= 1; want >>= 1) {
+                int fill = 0;  // wave slots used in the open workgroup
+                for (int r = 0; r < n_cz && n_cz <= 0xffff; r++) {
+                    if (groups_of(rcnt[r]) != want) continue;
+                    for (int gi = 0; gi < want; gi++) code[nb * 4 + fill + gi] = r | (gi << 16) | (want << 24);
+                    fill += want;
+                    if (fill == 4) { nb++; fill = 0; }
+                }
+                if (fill > 0) {
+                    for (int k = fill; k < 4; k++) code[nb * 4 + k] = -1;
+                    nb++;
+                }
+            }
+            if (n_cz > 0xffff) p->chain_packed = 0;
+            p->n_blk = nb;
+            if (!rc) rc = check_hip(hipMalloc(&p->d_blk, (size_t)(nb > 0 ? nb : 1) * 16), "hipMalloc");
+            if (!rc && nb > 0) rc = check_hip(hipMemcpy(p->d_blk, code, (size_t)nb * 16, hipMemcpyHostToDevice), "h2d");
+            delete[] code;
+        }
         if (!rc) rc = check_hip(hipMalloc(&p->d_chain_u, nca * 4), "hipMalloc");
         if (!rc) rc = check_hip(hipMalloc(&p->d_chain_dist, nca * 8), "hipMalloc");
         if (!rc && nc > 0) {
@@ -497,8 +549,12 @@ PISA_API int pisa_hip_prob3_grid_planned(const pisa_hip_prob3_params *h_params,
 #define CHAIN(G, A) hipLaunchKernelGGL((prob3_chain_kernel<G, A>), cgrid, cblock, 0, s, c, (int)n_e, plan->d_row_start, \
                        plan->d_row_cnt, plan->d_row_pairs, plan->n_cz, plan->n_pairs, plan->d_terms,              \
                        (int)e_major, d_prob_nu, d_prob_nubar, (double2 *)d_pepmu, d_energy, plan->d_chain_u,      \
-                       plan->d_chain_dist, plan->n_unique)
-        if (c.decay) { if (groups == 1) CHAIN(1, 2); else if (groups == 4) CHAIN(4, 2); else CHAIN(2, 2); }
+                       plan->d_chain_dist, plan->n_unique, plan->d_blk)
+        if (plan->chain_packed && plan->n_blk > 0) {
+            cblock = dim3(256);
+            cgrid = dim3((unsigned)plan->n_blk, 2, tiles);
+            if (c.decay) CHAIN(0, 2); else CHAIN(0, 1);
+        } else if (c.decay) { if (groups == 1) CHAIN(1, 2); else if (groups == 4) CHAIN(4, 2); else CHAIN(2, 2); }
         else { if (groups == 1) CHAIN(1, 1); else if (groups == 4) CHAIN(4, 1); else CHAIN(2, 1); }
 #undef CHAIN
         PISA_CHECK_LAUNCH("prob3_chain_kernel");
@@ -527,7 +583,7 @@ PISA_API int pisa_hip_prob3_grid_planned(const pisa_hip_prob3_params *h_params,
 #define CHAIN(G) hipLaunchKernelGGL((prob3_chain_kernel<G, 0>), cgrid, cblock, 0, s, c, (int)n_e, plan->d_row_start, \
                        plan->d_row_cnt, plan->d_row_pairs, plan->n_cz, plan->n_pairs, plan->d_amp,          \
                        (int)e_major, d_prob_nu, d_prob_nubar, (double2 *)d_pepmu, d_energy, plan->d_pair_u,  \
-                       plan->d_pair_dist, plan->n_unique)
+                       plan->d_pair_dist, plan->n_unique, plan->d_blk)
     if (groups == 1) CHAIN(1); else if (groups == 4) CHAIN(4); else CHAIN(2);
 #undef CHAIN
     PISA_CHECK_LAUNCH("prob3_chain_kernel");

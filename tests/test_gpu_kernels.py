@@ -104,7 +104,7 @@ def test_prob3_grid_golden_and_oracle(K, L, oracle):
             np.testing.assert_allclose(nubar, g[name + "::prob_nubar"], err_msg=name, **AC)
 
 
-@pytest.mark.parametrize("fused_amp", ["1", "0"])
+@pytest.mark.parametrize("fused_amp", ["1", "0", "split"])
 def test_prob3_grid_planned(K, L, fused_amp, monkeypatch):
     """both variants of the planned form (layer matrices formed inside the chain kernel from the
     per-density records / stored by stage AB and read back);
@@ -115,7 +115,11 @@ def test_prob3_grid_planned(K, L, fused_amp, monkeypatch):
     g = load_golden("prob3_grid_prem12.npz")
     e, dens, dist = K.to_device(g["energy"]), K.to_device(g["densities"]), K.to_device(g["distances"])
     n_e, n_cz = len(g["energy"]), g["densities"].shape[0]
-    monkeypatch.setenv("PISA_HIP_PROB3_FUSED_AMP", fused_amp)  # read when the plan is created
+    # variant of the planned form, read when the plan is created: "1" layer matrices formed in the
+    # chain kernel, rows packed by length into 4-wave workgroups (default); "split" the same with
+    # one row per workgroup; "0" layer matrices stored by stage AB and read back
+    monkeypatch.setenv("PISA_HIP_PROB3_FUSED_AMP", "0" if fused_amp == "0" else "1")
+    monkeypatch.setenv("PISA_HIP_CHAIN_MODE", "split" if fused_amp == "split" else "packed")
     plan = K.GridPlan(dens, dist)
     # "io": the vacuum ordering of the eigenvalues (resolved on the host in this form) differs
     for name in ("no", "io", "nsi", "decay"):
