@@ -109,13 +109,17 @@ def cpu_baseline(wl, sample_events):
         sub.append(d)
     wl.osc_params()
     oracle_eval(wl, containers=[])  # warm-up (loads the library, touches the grid)
-    t0 = time.perf_counter()
-    ref = oracle_eval(wl, containers=sub)
-    t_all = time.perf_counter() - t0
-    # split: grid part is independent of the number of events
-    t0 = time.perf_counter()
-    oracle_eval(wl, containers=[])
-    t_grid = time.perf_counter() - t0
+    # median of five repetitions each (the host is shared and the sample is short)
+    t_all, t_grid = [], []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        ref = oracle_eval(wl, containers=sub)
+        t_all.append(time.perf_counter() - t0)
+        # split: grid part is independent of the number of events
+        t0 = time.perf_counter()
+        oracle_eval(wl, containers=[])
+        t_grid.append(time.perf_counter() - t0)
+    t_all, t_grid = float(np.median(t_all)), float(np.median(t_grid))
     t_events = max(t_all - t_grid, 1e-9)
     n_sub = n_per * len(sub)
     t_full = t_grid + t_events * (wl.n_events / n_sub)
@@ -127,7 +131,7 @@ def cpu_baseline(wl, sample_events):
         "kind": "port",
         "sample": "full %dx%dx2-node prob3 grid (%.3f s) + %d of %d events through "
                   "lookup/reweight/hist (%.3f s), event part scaled to all events; "
-                  "OpenMP over %d threads (histogram loop sequential)"
+                  "OpenMP over %d threads (histogram loop sequential); medians of 5 repetitions"
                   % (wl.grid.n_e, wl.grid.n_cz, t_grid, n_sub, wl.n_events, t_events, cores),
     }
 
