@@ -46,6 +46,10 @@ def _worker(rank, world, port, out_path):
         for j, v in enumerate(float_to_limbs(x)):
             limbs[b, j] += v
     t = torch.tensor(limbs.astype(np.int64))
+    # the direct RCCL path is only taken on an RCCL ("nccl") group: on gloo every rank gets None
+    from pisa_amd import rccl
+
+    assert rccl.LimbAllReduce.create(torch.device("cpu")) is None
     allreduce_limbs(t, world)
     vals = [limbs_to_float(t[b].tolist()) for b in range(5)]
     covered = torch.tensor([hi - lo], dtype=torch.int64)
@@ -64,6 +68,12 @@ def test_limb_allreduce_is_exact_and_world_size_independent(tmp_path, world):
     assert res[-1] == len(w)  # every event in exactly one shard
     exact = [math.fsum(w[bins == b]) for b in range(5)]
     np.testing.assert_array_equal(res[:5], exact)  # bit identical to the exact sum
+
+
+def test_direct_rccl_needs_a_process_group():
+    from pisa_amd import rccl
+
+    assert rccl.LimbAllReduce.create(torch.device("cpu")) is None  # torch.distributed not initialised
 
 
 def test_single_rank_equals_multi_rank_bits():
