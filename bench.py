@@ -68,7 +68,7 @@ def parse():
                          "1e7 events in the time of a few kernel launches, so only the per-GPU-constant regime "
                          "has anything to scale (DESIGN.md section 6)")
     ap.add_argument("--weak-scaling", action="store_true", help="(default for N > 1; kept for compatibility)")
-    ap.add_argument("--event-order", default="auto", choices=["auto", "node", "bin"],
+    ap.add_argument("--event-order", default="auto", choices=["auto", "node", "bin", "part"],
                     help="resident event order: sorted by calc-grid node, or by (output bin, node)")
     return ap.parse_args()
 

@@ -718,7 +718,9 @@ static int run_hist(const ContDev *conts, int n_cont, int mode, const DevBinning
     int window = 0;
     if (!lds && (mode == 3 || mode == 5) && !env_int("PISA_HIP_HIST_NO_WINDOW", 0)) {
         // binning too large for LDS: accumulate a window of it (see the kernel)
-        window = (int)(LDS_ACC_BYTES_MAX / lds_acc_bytes(1));
+        // a multiple of 32 bins: the LDS bank pair of an accumulator is then (bin - bin_lo) mod 32
+        // whatever the slab and quantity, which the bank-aware event order relies on
+        window = (int)(LDS_ACC_BYTES_MAX / lds_acc_bytes(1)) / 32 * 32;
         lds_bytes = lds_acc_bytes(window);
         lds = true;
     }

@@ -58,6 +58,82 @@ metric_kernel(int kind, const double *__restrict__ actual, const double *__restr
     }
 }
 
+// Two-stage form for maps too large for one workgroup to walk (> METRIC_ONE_WG_MAX bins): one
+// bin per thread, the per-workgroup sums (the same tree as above) go to scratch, and a second
+// single-workgroup kernel adds them in index order with the same tree.  Deterministic for a
+// given n_bins; the association of the total differs from the one-workgroup form, which is
+// why small maps keep that one (it is what the fused tail kernel of hist.hip reproduces).
+constexpr int64_t METRIC_ONE_WG_MAX = 4096;  // = PISA_HIP_FINALIZE_METRIC_MAX: every map the fused tail can take
+
+__global__ void __launch_bounds__(256)
+metric_partial_kernel(int kind, const double *__restrict__ actual, const double *__restrict__ expected,
+                      const double *__restrict__ sigma2, int n_maps, int64_t n_bins,
+                      double *__restrict__ per_bin, double *__restrict__ partial,
+                      int32_t *__restrict__ flags) {
+    __shared__ double s_sum[256];
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double acc = 0.0;
+    if (b < n_bins) {
+        double k = actual[b];
+        double lam = 0.0, s2 = 0.0;
+        for (int m = 0; m < n_maps; m++) {
+            lam = (m == 0) ? expected[b] : lam + expected[(int64_t)m * n_bins + b];
+            if (sigma2) s2 = (m == 0) ? sigma2[b] : s2 + sigma2[(int64_t)m * n_bins + b];
+        }
+        double v;
+        bool finite = (k == k) && (lam == lam) && !isinf(k) && !isinf(lam);
+        if (!finite) {
+            v = __longlong_as_double(0x7ff8000000000000LL);
+        } else {
+            if (k < 0.0 || lam < 0.0) atomicOr(&flags[0], 1);
+            if (kind == PISA_HIP_METRIC_CHI2) {
+                double lc = lam < SMALL_POS ? SMALL_POS : lam;
+                if (!(fabs(k - lc) < 5 * FTYPE_PREC)) atomicOr(&flags[1], 1);
+            }
+            v = metric_bin(kind, k, lam, s2);
+        }
+        if (per_bin) per_bin[b] = v;
+        if (v == v) acc = v;  // np.nansum
+    }
+    s_sum[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) s_sum[threadIdx.x] += s_sum[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = s_sum[0];
+}
+
+__global__ void __launch_bounds__(256)
+metric_final_kernel(int kind, const double *__restrict__ partial, int n_part,
+                    int32_t *__restrict__ flags, double *__restrict__ per_bin, int64_t n_bins,
+                    double *__restrict__ total, int32_t *__restrict__ status) {
+    __shared__ double s_sum[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n_part; i += 256) acc += partial[i];
+    s_sum[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) s_sum[threadIdx.x] += s_sum[threadIdx.x + off];
+        __syncthreads();
+    }
+    const bool chi2_zero = (kind == PISA_HIP_METRIC_CHI2) && flags[1] == 0;  // stats.py:160-161
+    if (chi2_zero && per_bin) {
+        for (int64_t b = threadIdx.x; b < n_bins; b += 256) per_bin[b] = 0.0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        total[0] = chi2_zero ? 0.0 : s_sum[0];
+        if (status && flags[0]) status[0] = PISA_HIP_ERR_NEGATIVE;
+        flags[0] = flags[1] = 0;  // ready for the next call
+    }
+}
+
+// scratch of the two-stage form (grown on demand; one per process, like the rest of the state)
+static double *g_metric_partial = nullptr;
+static int32_t *g_metric_flags = nullptr;
+static int64_t g_metric_parts = 0;
+
 // ------------------------------------------------ binned post-histogram stages
 // out = x * scale[i] * scalar, optionally floored (`v < floor ? floor : v`, so NaN
 // stays NaN like np.clip / apply_floor_gufunc): hypersurfaces.py:243-257,
@@ -180,6 +256,28 @@ PISA_API int pisa_hip_metric(int32_t kind, const double *d_actual, const double 
                              double *d_per_bin, double *d_total, int32_t *d_status, void *stream) {
     if (kind < 0 || kind > 3 || n_maps < 1 || n_bins < 0 || !d_total) return PISA_HIP_ERR_INVALID;
     if (n_bins > 0 && (!d_actual || !d_expected)) return PISA_HIP_ERR_INVALID;
+    if (n_bins > METRIC_ONE_WG_MAX) {
+        const int64_t n_part = (n_bins + 255) / 256;
+        if (n_part > g_metric_parts || !g_metric_flags) {
+            if (g_metric_partial) (void)hipFree(g_metric_partial);
+            g_metric_partial = nullptr;
+            g_metric_parts = 0;
+            PISA_TRY_HIP(hipMalloc(&g_metric_partial, (size_t)n_part * sizeof(double)));
+            g_metric_parts = n_part;
+            if (!g_metric_flags) {
+                PISA_TRY_HIP(hipMalloc(&g_metric_flags, 2 * sizeof(int32_t)));
+                PISA_TRY_HIP(hipMemsetAsync(g_metric_flags, 0, 2 * sizeof(int32_t), as_stream(stream)));
+            }
+        }
+        hipLaunchKernelGGL(metric_partial_kernel, dim3((unsigned)n_part), dim3(256), 0, as_stream(stream),
+                           (int)kind, d_actual, d_expected, d_sigma2, (int)n_maps, n_bins, d_per_bin,
+                           g_metric_partial, g_metric_flags);
+        PISA_CHECK_LAUNCH("metric_partial_kernel");
+        hipLaunchKernelGGL(metric_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), (int)kind,
+                           g_metric_partial, (int)n_part, g_metric_flags, d_per_bin, n_bins, d_total, d_status);
+        PISA_CHECK_LAUNCH("metric_final_kernel");
+        return PISA_HIP_OK;
+    }
     hipLaunchKernelGGL(metric_kernel, dim3(1), dim3(256), 0, as_stream(stream), (int)kind, d_actual,
                        d_expected, d_sigma2, (int)n_maps, n_bins, d_per_bin, d_total, d_status);
     PISA_CHECK_LAUNCH("metric_kernel");

@@ -99,6 +99,24 @@ def bin_window_order(obin, n_bins, lds_window=682):
     return perm1[torch.argsort(key, stable=True)]
 
 
+def bin_partition_order(obin, node, n_bins, width=672):
+    """Event order for binnings too large for LDS accumulators, second form ("part").
+
+    The binning is cut into partitions of `width` consecutive bins (one LDS window of the fused
+    kernel each, hist.hip); an event goes to the partition of its bin, the events outside the
+    binning -- which deposit nothing -- are spread evenly over the partitions, and inside a
+    partition the events are sorted by calc-grid node.  A workgroup's chunk then lies in one
+    partition (all of its deposits are LDS deposits), every chunk carries the same share of
+    depositing events, the table gathers keep their locality, and `lds_bank_order` can take
+    the bank conflicts out as for small binnings.  Returns the permutation (device int64)."""
+    n = obin.numel()
+    n_win = max(1, -(-int(n_bins) // width))
+    idx = torch.arange(n, device=obin.device)
+    win = torch.where(obin >= 0, obin.long() // width, idx % n_win)
+    key = win * (int(node.max().item()) + 3 if n else 1) + (node.long() + 1)
+    return torch.argsort(key, stable=True)
+
+
 def lds_bank_order(obin, window=4096, banks=32, per=2):
     """Second-level event order (applied on top of the node sort) that takes the LDS bank
     conflicts out of the deposits.
@@ -192,7 +210,7 @@ class HotPathEngine:
         if sort_events is True:
             # LDS accumulators (96 B per bin, <= 64 KiB) take events in any order, so
             # order them for the table gathers; larger binnings need runs of equal bin
-            sort_events = "node" if self.n_bins * 96 <= 65536 else "bin"
+            sort_events = "node" if self.n_bins * 96 <= 65536 else "part"
         self.rank, self.world_size, self.group = rank, world_size, group
         self._rccl = None  # direct RCCL limb all-reduce, created at the first use
         self.names = [c["name"] for c in containers]
@@ -261,9 +279,12 @@ class HotPathEngine:
                     # instead of 64 different ones.
                     if sort_events == "bin":
                         perm = bin_window_order(obin, self.n_bins)
+                    elif sort_events == "part":
+                        perm = bin_partition_order(obin, node, self.n_bins)
                     else:
                         perm = torch.argsort(node, stable=True)
-                if lds_order and perm is not None and sort_events != "bin" and self.n_bins * 96 <= 65536:
+                if lds_order and perm is not None and (sort_events == "part" or (
+                        sort_events != "bin" and self.n_bins * 96 <= 65536)):
                     import os  # development overrides (scripts/dev)
                     perm = perm[lds_bank_order(obin[perm], window=int(os.environ.get("PISA_LDS_WINDOW", 4096)),
                                                banks=int(os.environ.get("PISA_LDS_BANKS", 32)),

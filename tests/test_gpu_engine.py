@@ -52,17 +52,18 @@ def test_bin_run_order_is_bit_identical(n_events):
 
 
 def test_large_binning_matches_oracle_in_any_order():
-    """4800 output bins do not fit LDS accumulators: events are kept in (bin, node)
-    order and a lane flushes its register sums straight to the global limbs at
-    the end of a run; node order falls back to per-event global atomics.  Same
-    bits either way, and the oracle's maps within 1e-10 relative."""
+    """4800 output bins do not fit LDS accumulators: the kernel keeps a window of the binning in
+    LDS and the events are stored by bin partition (default, "part": one LDS window per
+    partition, node-sorted inside) or by bin ("bin"); node order and the unsorted sample fall
+    back to per-event global atomics.  Same bits in every order, and the oracle's maps within
+    1e-10 relative."""
     from oracle import pipeline_oracle
     from pisa_amd import synthetic
 
     wl = synthetic.Workload(n_events=120000, grid=(40, 30), out_binning="fine3d", seed=3)
     p = wl.osc_params(theta23_deg=44.0)
     res = []
-    for order in (True, "node", False):
+    for order in (True, "part", "bin", "node", False):
         st = synthetic.DeviceState(wl, sort_events=order)
         st.accumulate(p)
         st.check_status()
