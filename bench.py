@@ -68,6 +68,10 @@ def parse():
                          "1e7 events in the time of a few kernel launches, so only the per-GPU-constant regime "
                          "has anything to scale (DESIGN.md section 6)")
     ap.add_argument("--weak-scaling", action="store_true", help="(default for N > 1; kept for compatibility)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="test aid: take the N > 1 code path (RCCL process group, limb all-reduce, barriers, "
+                         "max over ranks) with the ranks that are there, e.g. one rank under "
+                         "torch.distributed.run on a single-GPU box")
     ap.add_argument("--event-order", default="auto", choices=["auto", "node", "bin", "part"],
                     help="resident event order: sorted by calc-grid node, or by (output bin, node)")
     return ap.parse_args()
@@ -166,7 +170,8 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -174,7 +179,7 @@ def main():
     from pisa_amd import _lib, synthetic
 
     n_e, n_cz = (int(v) for v in args.grid.split("x"))
-    weak = world > 1 and not args.strong_scaling
+    weak = dist_on and not args.strong_scaling
     compact = not (args.exact_association or args.coordinate_form)
     index16 = compact and not args.wide_index
     wl = synthetic.Workload(n_events=int(args.events), grid=(n_e, n_cz), out_binning=args.binning,
@@ -184,13 +189,15 @@ def main():
                                sort_events=True if args.event_order == "auto" else args.event_order,
                                compact=compact, index16=index16)
     if weak:
-        st.world_size = world  # whole local sample per rank; the limb all-reduce still spans all ranks
+        # whole local sample per rank; the limb all-reduce still spans all ranks (>= 2 so that
+        # --force-dist on one rank goes through the collective as well)
+        st.world_size = max(world, 2) if args.force_dist else world
     nominal = wl.osc_params()
     st.make_pseudo_data(nominal, seed=0)
     plist = param_list(wl, args.warmup + args.steps)
 
     def barrier():
-        if world > 1:
+        if dist_on:
             import torch.distributed as dist
 
             dist.barrier()
@@ -298,7 +305,7 @@ def main():
         del st2
 
     # max over ranks
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
 
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -360,7 +367,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_sample_events)
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
 
         st.close()

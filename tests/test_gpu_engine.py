@@ -300,3 +300,25 @@ def test_rccl_limb_allreduce_single_rank(tmp_path, monkeypatch):
         st.check_status()
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_multi_rank_code_path_on_one_rank():
+    """bench.py's N > 1 flow (RCCL process group from the launcher's environment, direct limb
+    all-reduce inside every evaluation, barriers, max over ranks, communicator teardown) run
+    end to end with the one rank a single-GPU box has."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+           "--gpus", "1", "--force-dist", "--events", "1.2e6", "--steps", "40", "--warmup", "5",
+           "--no-cpu-baseline", "--no-drop-probe"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["scaling"] == "weak" and line["value"] > 0
+    assert "weak scaling, PER GPU" in line["config"]["workload"]
+    assert np.isfinite(line["last_llh"])
