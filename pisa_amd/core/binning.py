@@ -228,11 +228,13 @@ class MultiDimBinning:
         self.mask = mask
         self._hash = None
         self._shape = tuple(d.num_bins for d in dims)
+        self._names = tuple(d.name for d in dims)
+        self._name_set = frozenset(self._names)
         self._size = int(np.prod(self._shape)) if dims else 1
 
     dimensions = property(lambda self: self._dimensions)
     dims = dimensions
-    names = property(lambda self: [d.name for d in self._dimensions])
+    names = property(lambda self: list(self._names))
     num_dims = property(lambda self: len(self._dimensions))
     shape = property(lambda self: self._shape)
     num_bins = shape

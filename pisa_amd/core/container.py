@@ -118,6 +118,7 @@ class Container:
     def __init__(self, name, representation="events"):
         self.name = name
         self._representation = None
+        self._is_map = False
         self.linked = False
         self._aux_data = {}
         self.validity = defaultdict(dict)
@@ -179,6 +180,7 @@ class Container:
                 if representation not in self.array_representations:
                     raise ValueError("Unknown representation '%s'" % representation)
         self._representation = representation
+        self._is_map = isinstance(representation, MultiDimBinning)
         self.current_data = self.data[key]
 
     representations = property(lambda self: tuple(self._representations.values()))
@@ -186,7 +188,7 @@ class Container:
 
     @property
     def is_map(self):
-        return isinstance(self._representation, MultiDimBinning)
+        return self._is_map
 
     @property
     def shape(self):
@@ -253,7 +255,7 @@ class Container:
     def _get(self, key):
         if key in self.pending:
             self._flush_pending(key)
-        if self.is_map and key in self._representation.names:
+        if self._is_map and key in self._representation._name_set:
             return DualArray(self.unroll_binning(key, self._representation))
         if key not in self.current_data:
             if key in self.validity:
@@ -267,7 +269,7 @@ class Container:
         return self.current_data[key]
 
     def __setitem__(self, key, data):
-        if self.is_map and key in self._representation.names:
+        if self._is_map and key in self._representation._name_set:
             raise Exception("Cannot add variable %s, as it is a binning dimension" % key)
         self.pending.pop(key, None)  # overwritten
         self._add_data(key, data)
