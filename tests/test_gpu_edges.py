@@ -1,6 +1,8 @@
 """Edge cases the reference tests or implies, on the GPU path: container
 round trips (pisa/core/container.py:1043-1189), empty / ragged containers,
 NaN and out-of-range coordinates, weights of extreme magnitude."""
+import os
+
 import numpy as np
 import pytest
 
@@ -89,3 +91,38 @@ def test_fused_kernel_empty_ragged_nan_out_of_range(oracle):
     st3.finalize()
     with pytest.raises(OverflowError):
         st3.check_status()
+
+
+def test_planned_prob3_odd_row_sets():
+    """the packed launch of the planned grid form (rows grouped by length into four-wave
+    workgroups) on row sets that do not fill the groups: 1..33 rows, empty paths, paths with
+    holes, single-layer paths -- equal to the one-kernel grid form to rounding"""
+    import numpy as np
+
+    from pisa_amd import _lib as L
+    from pisa_amd import kernels as K
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "prob3_grid_prem12.npz"))
+    e = K.to_device(g["energy"])
+    rs = np.random.RandomState(5)
+    p = L.make_prob3_params(g["no::dm"], g["no::mix"], g["no::mat_pot"], int(g["no::decay_flag"]),
+                            g["no::mat_decay"], g["no::lri_pot"])
+    for trial in range(12):
+        n_cz = int(rs.choice([1, 2, 3, 5, 7, 24, 33]))
+        rows = rs.randint(0, g["densities"].shape[0], n_cz)
+        dens, dist = g["densities"][rows].copy(), g["distances"][rows].copy()
+        for r in range(n_cz):
+            k = rs.rand()
+            if k < 0.15:
+                dist[r] = 0.0                                # empty path
+            elif k < 0.3:
+                dist[r, rs.randint(0, dist.shape[1], 5)] = 0.0   # holes
+            elif k < 0.4:
+                dist[r, 1:] = 0.0                            # single layer
+        d_dens, d_dist = K.to_device(dens), K.to_device(dist)
+        plan = K.GridPlan(d_dens, d_dist)
+        for e_major in (True, False):
+            ref = K.prob3_grid(p, e, d_dens, d_dist, e_major=e_major, want_pepmu=True)
+            got = K.prob3_grid_planned(p, plan, e, e_major=e_major)
+            for a, b in zip(ref, got):
+                assert float((a - b).abs().max()) < 3e-13
