@@ -212,7 +212,7 @@ def test_prob3_events_vs_oracle(K, L, oracle):
         lay.setElecFrac(yi, yo, ym)
         lay.calcLayers(cz)
         earth = L.make_earth(lay.radii, lay.rhos, lay.coszen_limit, lay.r_detector)
-        for name in ("no", "nsi"):
+        for name in ("no", "io", "nsi", "decay"):
             pa = [gg[name + "::dm"], gg[name + "::mix"], gg[name + "::mat_pot"],
                   int(gg[name + "::decay_flag"]), gg[name + "::mat_decay"], gg[name + "::lri_pot"]]
             p = L.make_prob3_params(*pa)
