@@ -57,3 +57,38 @@ def test_missing_library_fails_loudly(monkeypatch, built):
     monkeypatch.setattr(built, "LIB_PATH", "/nonexistent/libpisa_hip.so")
     with pytest.raises(ImportError):
         built.lib()
+
+
+def test_header_is_plain_c_and_the_documented_call_sequence_type_checks(tmp_path):
+    """include/pisa_hip.h compiles as C99 without any HIP header, and the per-evaluation call
+    sequence shown in INTEGRATION.md matches the declared signatures (gcc -fsyntax-only)."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "seq.c"
+    src.write_text(r'''
+#include "pisa_hip.h"
+int one_evaluation(const pisa_hip_earth *earth, const double *d_cz, const double *d_energy, int32_t n_e,
+                   int32_t n_cz, int32_t max_layers, double *d_dens, double *d_dist,
+                   const pisa_hip_prob3_params *par, const pisa_hip_container *cont, int32_t n_cont,
+                   const pisa_hip_binning *calc_grid, const pisa_hip_binning *out_binning, int64_t n_bins,
+                   double *d_P_nu, double *d_P_nubar, double *d_pepmu, int64_t *d_limbs, double *d_hist,
+                   double *d_sumw2, const double *d_data, double *pinned_llh, int32_t *d_status,
+                   int32_t *d_mstatus, void *stream) {
+    pisa_hip_grid_plan *plan;
+    int rc = pisa_hip_calc_layers(earth, d_cz, n_cz, max_layers, 0, d_dens, d_dist, d_status, stream);
+    if (!rc) rc = pisa_hip_grid_plan_create(d_dens, d_dist, n_cz, max_layers, &plan);
+    if (!rc) rc = pisa_hip_prob3_grid_planned(par, plan, d_energy, n_e, 1, d_P_nu, d_P_nubar, d_pepmu, stream);
+    if (!rc) rc = pisa_hip_reweight_hist_acc(cont, n_cont, calc_grid, d_P_nu, d_P_nubar, d_pepmu, out_binning,
+                                             d_limbs, d_status, stream);
+    if (!rc) rc = pisa_hip_finalize_metric(d_limbs, n_cont, n_bins, d_hist, d_sumw2, PISA_HIP_METRIC_LLH, d_data,
+                                           pinned_llh, d_status, d_mstatus, 1, stream);
+    if (rc) (void)pisa_hip_strerror(rc);
+    return rc ? rc : pisa_hip_grid_plan_destroy(plan);
+}
+''')
+    cmd = ["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only",
+           "-I", os.path.join(root, "include"), str(src)]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
