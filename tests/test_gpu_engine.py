@@ -311,9 +311,14 @@ def test_bench_multi_rank_code_path_on_one_rank():
     import subprocess
     import sys
 
+    import socket
+
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:  # a free port for the rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
-           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
            "--gpus", "1", "--force-dist", "--events", "1.2e6", "--steps", "40", "--warmup", "5",
            "--no-cpu-baseline", "--no-drop-probe"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
