@@ -231,7 +231,7 @@ typedef struct {
                                         40-B form by rounding, <= 3 ulp per weight).  The caller
                                         refreshes it when nu_flux changes (flux systematics). */
     /* 16-BIT INDEX form of the compact columns (20 B per event), for calc grids below 65535
-     * nodes and output binnings below 65535 bins whose accumulators fit the LDS (<= 682 bins).
+     * nodes and output binnings below 65535 bins.
      * Given for every container it is the form used; it stands alone (d_node_bin and
      * d_weighted_flux may be NULL).  For a grid / binning it does not apply to these two
      * columns are ignored: the call uses the other forms if they are given as well and is

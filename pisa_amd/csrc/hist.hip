@@ -197,9 +197,9 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
     double2 awa = make_double2(0.0, 0.0), awb = awa, fa = awa, fb = awa;
     constexpr bool PACKED = MODE == 3 || MODE == 5;
     constexpr bool COMPACT = MODE == 5;
-    // MODE 7: quads of events, always swept together
-    const int64_t q_end = (C.n + 3) >> 2;  // columns padded to whole blocks of 64 quads
-    int64_t q = lb * nthreads + threadIdx.x;
+    // MODE 7: quads of events (columns padded to whole blocks of 64 quads)
+    const int64_t q_end = ((together ? C.n : end) + 3) >> 2;
+    int64_t q = (together ? lb * nthreads : (start >> 2)) + threadIdx.x;
     bool qhave = QUAD && q < q_end;
     uint4 qx = make_uint4(~0u, ~0u, ~0u, ~0u);
     double2 g0 = awa, g1 = awa;
@@ -220,16 +220,27 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
 
     if (LDS_ACC) {
         for (int k = threadIdx.x; k < n_acc * a.copies; k += nthreads) s_acc[k] = 0.0;
-        if (PACKED && a.window > 0) {
+        if ((PACKED || QUAD) && a.window > 0) {
             __shared__ int s_lo;
             if (threadIdx.x == 0) s_lo = 0x7fffffff;
             __syncthreads();
             int m = 0x7fffffff;
+            if (QUAD) {
+                const uint4 *idxq = reinterpret_cast<const uint4 *>(C.idx16);
+                for (int64_t qq = (start >> 2) + threadIdx.x; qq < q_end; qq += nthreads) {
+                    const uint4 v = idxq[qq];
+                    const int b[4] = {(int)(v.x >> 16), (int)(v.y >> 16), (int)(v.z >> 16), (int)(v.w >> 16)};
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (b[k] != 0xffff && b[k] < m) m = b[k];
+                }
+            } else {
             const int4 *idx4 = reinterpret_cast<const int4 *>(C.node_bin);
             for (int64_t p = (start >> 1) + threadIdx.x; p < (end >> 1); p += nthreads) {
                 const int4 ix = idx4[p];
                 if (ix.y >= 0 && ix.y < m) m = ix.y;
                 if (ix.w >= 0 && ix.w < m) m = ix.w;
+            }
             }
             for (int o = 32; o > 0; o >>= 1) {
                 const int other = __shfl_xor(m, o);
@@ -269,7 +280,7 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
         const double scale = C.scale;
         const uint4 *idxq = reinterpret_cast<const uint4 *>(C.idx16);
         const double2 *aw = C.wflux_q;
-        const int64_t qstep = n_wg * nthreads;
+        const int64_t qstep = together ? n_wg * nthreads : nthreads;
         const double2 zero2 = make_double2(0.0, 0.0);
         // The pair loop's software pipeline (see below), two half-sweeps per quad: while
         // events 0,1 of the quad are consumed the flux of events 2,3 is in flight, while 2,3
@@ -716,7 +727,7 @@ static int run_hist(const ContDev *conts, int n_cont, int mode, const DevBinning
     int64_t lds_bytes = lds_acc_bytes(n_bins);
     bool lds = lds_bytes <= LDS_ACC_BYTES_MAX;
     int window = 0;
-    if (!lds && (mode == 3 || mode == 5) && !env_int("PISA_HIP_HIST_NO_WINDOW", 0)) {
+    if (!lds && (mode == 3 || mode == 5 || mode == 7) && !env_int("PISA_HIP_HIST_NO_WINDOW", 0)) {
         // binning too large for LDS: accumulate a window of it (see the kernel)
         // a multiple of 32 bins: the LDS bank pair of an accumulator is then (bin - bin_lo) mod 32
         // whatever the slab and quantity, which the bank-aware event order relies on
@@ -823,9 +834,10 @@ static int reweight_hist_impl(const pisa_hip_container *h_containers, int32_t n_
     bool all_indexed = d_pepmu != nullptr;
     bool all_packed = any_table;
     bool all_compact = any_table;
-    // the 16-bit index form needs whole-binning LDS accumulators and 16-bit node / bin numbers;
-    // where it does not apply its columns are ignored (the other forms, if given, are used)
-    const bool ok16 = lds_acc_bytes(n_bins) <= LDS_ACC_BYTES_MAX && n_nodes < 0xffff && n_bins < 0xffff;
+    // the 16-bit index form needs 16-bit node / bin numbers; where it does not apply its columns
+    // are ignored (the other forms, if given, are used)
+    const bool ok16 = n_nodes < 0xffff && n_bins < 0xffff &&
+                      (lds_acc_bytes(n_bins) <= LDS_ACC_BYTES_MAX || !env_int("PISA_HIP_HIST_NO_WINDOW", 0));
     bool all_idx16 = any_table && ok16;
     for (int c = 0; c < n_containers; c++) {
         const pisa_hip_container &h = h_containers[c];

@@ -222,10 +222,10 @@ class HotPathEngine:
         self.compact = bool(compact)
         import os
         # 16-bit index form of the compact columns (20 B/event) where it applies: grid mode, calc
-        # grid below 65535 nodes, output binning whose accumulators fit the LDS
+        # grid below 65535 nodes, output binning below 65535 bins
         index16 = (bool(index16) and bool(int(os.environ.get("PISA_IDX16", "1"))) and self.compact
                    and packed and indexed and not self.osc_events and grid.size < 0xFFFF
-                   and self.n_bins * 96 <= 65536)
+                   and self.n_bins < 0xFFFF)
         self.index16 = index16
         self.n_local = 0
         for c in containers:

@@ -187,9 +187,9 @@ def torch_equal(a, b):
 
 
 def test_index16_form_needs_a_fallback_where_it_does_not_apply():
-    """ABI: for a binning whose accumulators do not fit the LDS the 16-bit columns are ignored:
-    the call falls back to the other forms of the container, and is refused when the 16-bit
-    form is all a container offers."""
+    """ABI: for a binning with 65535 bins or more the 16-bit columns are ignored: the call falls
+    back to the other forms of the container, and is refused when the 16-bit form is all a
+    container offers."""
     import ctypes
 
     import torch
@@ -197,17 +197,17 @@ def test_index16_form_needs_a_fallback_where_it_does_not_apply():
     from pisa_amd import _lib, synthetic
     from pisa_amd import kernels as K
 
-    wl = synthetic.Workload(n_events=12 * 500, grid=(20, 10), out_binning="fine3d", seed=3)
+    huge = _lib.make_binning([0.0, 0.0], [1.0, 1.0], [256, 256])  # 65536 bins: no 16-bit bin numbers
     small = _lib.make_binning(synthetic.DRAGON["mins"], synthetic.DRAGON["maxs"], synthetic.DRAGON["nbins"])
-    # engine on the small binning (16-bit form built), then asked for the 4800-bin one: the bin
+    # engine on the small binning (16-bit form built), then asked for the huge one: the bin
     # numbers of its index columns belong to the small binning, so only the status matters here
     wl_small = synthetic.Workload(n_events=12 * 500, grid=(20, 10), out_binning="dragon", seed=3)
     st = synthetic.DeviceState(wl_small, compact=True)
     assert st.index16
     st.compute_probs(wl_small.osc_params())
-    ws = K.HistWorkspace(len(st.cont), wl.n_bins, st.dev)
+    ws = K.HistWorkspace(len(st.cont), 65536, st.dev)
     K.reweight_hist(st._cont_arr, st.grid.binning, st.prob_nu, st.prob_nubar, st.pepmu,
-                    wl.out_binning, ws)  # falls back to the packed 40 B columns
+                    huge, ws)  # falls back to the packed 40 B columns
     only16 = []
     for c in st.cont:
         d = _lib.Container()
@@ -223,8 +223,7 @@ def test_index16_form_needs_a_fallback_where_it_does_not_apply():
     K.hist_finalize(ws_small)
     assert torch.equal(ws_small.hist, st.finalize()[0])  # the 16-bit form stands alone
     with pytest.raises(_lib.PisaHipError):
-        K.reweight_hist(only16, st.grid.binning, st.prob_nu, st.prob_nubar, st.pepmu,
-                        wl.out_binning, ws)
+        K.reweight_hist(only16, st.grid.binning, st.prob_nu, st.prob_nubar, st.pepmu, huge, ws)
     torch.cuda.synchronize()
 
 
