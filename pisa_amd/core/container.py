@@ -129,6 +129,13 @@ class Container:
         # deferred operations per key (see pisa_amd/stages/deferred.py)
         self.pending = {}
         self._pending_rep = {}
+        # change counter per key: bumped by every store and by `mark_changed`, so that a consumer
+        # holding a derived copy (the fused engine's folded flux column) can tell when its
+        # source moved -- object identity cannot (in-place edits + mark_changed keep the object)
+        self._version = defaultdict(int)
+        # operation chains a fused kernel consumed without writing the event-wise result
+        # (key -> (ops, representation)); materialised only if somebody reads it there
+        self._lazy = {}
         self.representation = representation
 
     def __repr__(self):
@@ -151,6 +158,22 @@ class Container:
 
     def device_raw(self, key):
         return self.current_data[key].get_dev()
+
+    def keep_lazy(self, key, ops, representation):
+        """`key` in `representation` is the result of `ops` (a deferred chain that a fused kernel
+        has consumed): valid there, computed on first access."""
+        self._lazy[key] = (ops, representation)
+        self.validity[key][hash(representation)] = True
+
+    def _materialize_lazy(self, key):
+        ops, rep = self._lazy.pop(key)
+        others = {h: ok for h, ok in self.validity[key].items() if h != hash(rep)}
+        version = self._version[key]
+        self.pending[key] = list(ops)
+        self._pending_rep[key] = rep
+        self._flush_pending(key)
+        self.validity[key].update(others)   # the values of the other representations still hold
+        self._version[key] = version
 
     def _flush_pending(self, key):
         if self.pending.get(key):
@@ -223,7 +246,13 @@ class Container:
         self._aux_data[key] = val
 
     # -- validity --------------------------------------------------------------
+    def version(self, key):
+        """number of times `key` was stored or marked changed (any representation)"""
+        return self._version[key]
+
     def mark_changed(self, key):
+        self._version[key] += 1
+        self._lazy.pop(key, None)
         for rep in self.validity[key]:
             self.validity[key][rep] = False
         if key in self.current_data:
@@ -234,6 +263,8 @@ class Container:
         self.validity[key][hash(self._representation)] = True
 
     def _invalidate_others(self, key):
+        self._version[key] += 1
+        self._lazy.pop(key, None)
         for rep in self.validity[key]:
             self.validity[key][rep] = False
         self.mark_valid(key)
@@ -255,6 +286,8 @@ class Container:
     def _get(self, key):
         if key in self.pending:
             self._flush_pending(key)
+        elif key in self._lazy and hash(self._lazy[key][1]) == hash(self._representation):
+            self._materialize_lazy(key)
         if self._is_map and key in self._representation._name_set:
             return DualArray(self.unroll_binning(key, self._representation))
         if key not in self.current_data:

@@ -18,11 +18,32 @@ class DistributionMaker:
         self._pipelines = [p if isinstance(p, Pipeline) else Pipeline(p, profile=profile)
                            for p in pipelines]
         self._profile = profile
+        self._unify_params()
 
     pipelines = property(lambda self: self._pipelines)
 
     def __iter__(self):
         return iter(self._pipelines)
+
+    def _unify_params(self):
+        """Same-named params become ONE object in every pipeline, for every selection
+        (distribution_maker.py:183-196), so that a value set through one pipeline -- or through
+        the merged `self.params` -- is seen by all of them."""
+        original = self.param_selections
+        selections = set()
+        for p in self._pipelines:
+            for s in p.stages:
+                selections.update(s._param_selector._selector_sets.keys())
+        for sel in sorted(selections):
+            self.select_params(sel)
+            merged = self.params
+            for p in self._pipelines:
+                p.update_params(merged, existing_must_match=True, extend=False)
+        if original:
+            self.select_params(original)
+        merged = self.params
+        for p in self._pipelines:
+            p.update_params(merged, existing_must_match=True, extend=False)
 
     @property
     def params(self):
@@ -30,6 +51,13 @@ class DistributionMaker:
         for p in self._pipelines:
             params.update(p.params, existing_must_match=False, extend=True)
         return params
+
+    @property
+    def param_selections(self):
+        sel = set()
+        for p in self._pipelines:
+            sel.update(p.param_selections)
+        return sorted(sel)
 
     def select_params(self, selections, error_on_missing=True):
         for p in self._pipelines:
@@ -39,24 +67,54 @@ class DistributionMaker:
         for p in self._pipelines:
             p.update_params(params)
 
+    def _for_each_free(self, values, setter):
+        """distribution_maker.py:420-436, 462-476: every pipeline that has the parameter free gets
+        the value; a parameter that is free somewhere and fixed elsewhere is an error."""
+        names = self.params.free.names
+        assert len(values) == len(names)
+        for pipeline in self._pipelines:
+            pp = pipeline.params
+            free = set(pp.free.names)
+            for name, value in zip(names, values):
+                if name in free:
+                    setter(pp[name], value)
+                elif name in pp.names:
+                    raise AttributeError('Trying to set value for "%s", a parameter that is fixed in '
+                                         "at least one pipeline" % name)
+
     def set_free_params(self, values):
-        free = self.params.free
-        assert len(values) == len(free)
-        for prm, v in zip(free, values):
-            prm.value = v
+        self._for_each_free(values, lambda prm, v: setattr(prm, "value", v))
 
     def _set_rescaled_free_params(self, rvalues):
-        """free params from their [0,1]-rescaled values (distribution_maker.py:462)"""
-        free = self.params.free
-        assert len(rvalues) == len(free)
-        for prm, r in zip(free, rvalues):
-            prm._rescaled_value = float(r)
+        """free params from their [0,1]-rescaled values (distribution_maker.py:462-476)"""
+        self._for_each_free(rvalues, lambda prm, r: setattr(prm, "_rescaled_value", float(r)))
 
     def randomize_free_params(self, random_state=None):
-        self.params.randomize_free(random_state)
+        import numpy as np
+
+        rs = random_state if isinstance(random_state, np.random.RandomState) \
+            else np.random.RandomState(random_state)
+        self._set_rescaled_free_params(rs.rand(len(self.params.free)))
+
+    def reset_all(self):
+        for p in self._pipelines:
+            p.params.reset_all()
 
     def reset_free(self):
-        self.params.reset_free()
+        for p in self._pipelines:
+            p.params.reset_free()
+
+    def set_nominal_by_current_values(self):
+        for p in self._pipelines:
+            p.params.set_nominal_by_current_values()
+
+    def run(self):
+        for p in self._pipelines:
+            p.run()
+
+    def setup(self):
+        for p in self._pipelines:
+            p.setup()
 
     def get_outputs(self, return_sum=False, sum_map_name="total", **kwargs):
         outputs = [p.get_outputs(**kwargs) for p in self._pipelines]

@@ -36,7 +36,7 @@ class hist(Stage):  # pylint: disable=invalid-name
         self.apply_unc_weights = apply_unc_weights
         self.unweighted = unweighted
         self._engine = None
-        self._engine_flux_ids = None
+        self._engine_versions = None
         self.fused_last_eval = False
 
     def setup_function(self):
@@ -73,13 +73,22 @@ class hist(Stage):  # pylint: disable=invalid-name
         osc = self._find_prob3()
         if osc is None:
             return False
+        cm = osc.calc_mode
+        e_dim, cz_dim = cm["true_energy"], cm["true_coszen"]
+        # the engine's event -> node index assumes the usual oscillogram grid (log-uniform
+        # energy, lin-uniform coszen, `GridSpec`); any other calc grid takes the unfused path,
+        # whose lookups go through `regularized()` and handle every binning
+        if (e_dim.is_irregular or cz_dim.is_irregular or not e_dim.is_log or not cz_dim.is_lin):
+            return False
         from pisa_amd.engine import GridSpec, HotPathEngine
 
         flux_key = chains[0][0]
+        static_keys = ("weighted_aeff", "initial_weights", "true_energy", "true_coszen")
+        if self._engine is not None and any(
+                c.version(k) != v[k] for c, v in zip(conts, self._engine_versions) for k in static_keys):
+            self._engine = None   # a column folded / digitised at engine build was rewritten
         if self._engine is None:
             g = osc.grid
-            cm = osc.calc_mode
-            e_dim, cz_dim = cm["true_energy"], cm["true_coszen"]
             grid = GridSpec(tuple(e_dim.domain.m_as("GeV")), e_dim.num_bins,
                             tuple(cz_dim.domain.magnitude), cz_dim.num_bins, energy_first=g["e_major"])
             import torch.distributed as dist
@@ -98,14 +107,17 @@ class hist(Stage):  # pylint: disable=invalid-name
             # (refreshed by update_flux below whenever a flux systematic moved)
             self._engine = HotPathEngine(evs, grid, self._reg_binning, None, 0, rank=rank,
                                          world_size=world, external_tables=True, compact=True)
-            self._engine_flux_ids = [id(c.current_data[flux_key]) for c in conts]
+            self._engine_versions = [{k: c.version(k) for k in static_keys + (flux_key,)}
+                                     for c in conts]
         eng = self._engine
         for i, (c, ch) in enumerate(zip(conts, chains)):
             c.representation = "events"
             eng.set_scale(c.name, ch[1])
-            if id(c.current_data[flux_key]) != self._engine_flux_ids[i]:
+            # the container's change counter, not object identity: a stage that edits the flux in
+            # place and calls mark_changed (container.py:638-649) keeps the same array object
+            if c.version(flux_key) != self._engine_versions[i][flux_key]:
                 eng.update_flux(i, c.device(flux_key))   # flux systematics changed
-                self._engine_flux_ids[i] = id(c.current_data[flux_key])
+                self._engine_versions[i][flux_key] = c.version(flux_key)
         eng.pepmu = osc.pepmu
         eng.accumulate()
         eng.allreduce()
@@ -116,9 +128,12 @@ class hist(Stage):  # pylint: disable=invalid-name
         both = torch.stack((hist_d, torch.sqrt(sumw2_d), hist_d)) if sumw2 else hist_d[None]
         both_h = both.cpu().numpy()
         for i, c in enumerate(conts):
-            c.pending.pop(deferred.KEY, None)  # consumed by the fused kernel
+            ops = c.pending.pop(deferred.KEY, None)  # consumed by the fused kernel
             c.representation = self.apply_mode
             c.set_mirrored("weights", both[0, i], both_h[0, i])
+            # histogramming does not invalidate the event-wise weights (hist.py:213): they are
+            # what the consumed chain gives, computed if anybody reads them
+            c.keep_lazy("weights", ops, "events")
             if sumw2:
                 c.set_mirrored("errors", both[1, i], both_h[1, i])
                 c.set_mirrored("bin_unc2", both[2, i], both_h[2, i])  # sum(1^2 * w), hist.py:207-209

@@ -211,3 +211,69 @@ def test_minimizer_settings_formats():
     assert load_minimizer_settings({"method": "SLSQP"}) == {"method": "SLSQP"}
     nested = {"method": {"value": "TNC", "desc": "x"}, "options": {"value": {"maxiter": 3}, "desc": {}}}
     assert load_minimizer_settings(nested) == {"method": "TNC", "options": {"maxiter": 3}}
+
+
+def _toy_pipeline(name, scale_fixed=False, extra=None):
+    """a Pipeline of parameter-only stages (no kernels): what DistributionMaker needs"""
+    from collections import OrderedDict
+
+    from pisa_amd.core.pipeline import Pipeline
+    from pisa_amd.core.stage import Stage
+
+    class svc(Stage):  # pylint: disable=invalid-name
+        def __init__(self, **kw):
+            super().__init__(expected_params=[p.name for p in kw["params"]], **kw)
+
+    prm = [Param(name="aeff_scale", value=1.0, prior=None, range=[0.0, 2.0], is_fixed=scale_fixed),
+           Param(name="livetime", value=2.5 * ureg.common_year, prior=None, range=None, is_fixed=True)]
+    prm += list(extra or [])
+    pl = Pipeline.__new__(Pipeline)
+    pl.name, pl.detector_name, pl._profile = name, None, False
+    pl._stages = [svc(params=ParamSet(prm))]
+    pl._config = OrderedDict()
+    return pl
+
+
+def test_distribution_maker_sets_shared_free_params_in_every_pipeline():
+    """a free parameter shared by name across pipelines must move in ALL of
+    them (distribution_maker.py:183-196, 420-436, 462-476)."""
+    from pisa_amd.core.distribution_maker import DistributionMaker
+
+    a = _toy_pipeline("a", extra=[Param(name="only_a", value=3.0, prior=None, range=[0.0, 6.0], is_fixed=False)])
+    b = _toy_pipeline("b")
+    dm = DistributionMaker([a, b])
+    assert dm.params.free.names == ("aeff_scale", "only_a")
+    # one Param object per name after construction
+    assert a.params.aeff_scale is b.params.aeff_scale
+    dm._set_rescaled_free_params([0.25, 0.5])
+    assert [p.params.aeff_scale.value.m for p in dm] == [0.5, 0.5]
+    assert a.params.only_a.value.m == 3.0
+    dm.set_free_params([1.5 * ureg.dimensionless, 1.0 * ureg.dimensionless])
+    assert [p.params.aeff_scale.value.m for p in dm] == [1.5, 1.5] and a.params.only_a.value.m == 1.0
+    dm.reset_free()
+    assert [p.params.aeff_scale.value.m for p in dm] == [1.0, 1.0] and a.params.only_a.value.m == 3.0
+    dm.randomize_free_params(random_state=0)
+    assert a.params.aeff_scale.value.m == b.params.aeff_scale.value.m != 1.0
+    dm.set_nominal_by_current_values()
+    v = a.params.aeff_scale.value.m
+    dm.set_free_params([0.1 * ureg.dimensionless, 0.2 * ureg.dimensionless])
+    dm.reset_all()
+    assert b.params.aeff_scale.value.m == v
+    # even if the objects were distinct (pipelines built separately and modified later), every
+    # pipeline is addressed by name
+    b._stages[0]._param_selector.update(Param(name="aeff_scale", value=v, prior=None, range=[0.0, 2.0],
+                                              is_fixed=False))
+    assert a.params.aeff_scale is not b.params.aeff_scale
+    dm._set_rescaled_free_params([0.75, 0.5])
+    assert [p.params.aeff_scale.value.m for p in dm] == [1.5, 1.5]
+
+
+def test_distribution_maker_refuses_param_free_in_one_pipeline_fixed_in_another():
+    from pisa_amd.core.distribution_maker import DistributionMaker
+
+    dm = DistributionMaker.__new__(DistributionMaker)
+    dm._pipelines, dm.label, dm._profile = [_toy_pipeline("a", scale_fixed=True), _toy_pipeline("b")], None, False
+    with pytest.raises(AttributeError):
+        dm._set_rescaled_free_params([0.3])
+    with pytest.raises(AttributeError):
+        dm.set_free_params([0.3 * ureg.dimensionless])

@@ -1,0 +1,57 @@
+"""CPU tests of the PRODUCT's host-side parameter matrices (SURVEY §8 a1-a3:
+`pisa_amd/stages/osc/{osc,nsi,decay,lri}_params.py`) against values produced by the
+reference's own classes (`tests/golden/params_ref.npz`, made by `oracle/gen_golden.py:gen_params`
+from pisa/stages/osc/osc_params.py:174-292, nsi_params.py:168-181, 326-385,
+decay_params.py, lri_params.py).  Bit-exact: the same numpy operations in the same order."""
+import numpy as np
+
+from tests.conftest import load_golden
+
+
+def test_osc_params_bit_exact():
+    from pisa_amd.stages.osc.osc_params import OscParams
+
+    g = load_golden("params_ref.npz")
+    inputs = g["osc::inputs"]
+    assert inputs.shape == (8, 6)
+    for i, (t12, t13, t23, dcp, dm21, dm31) in enumerate(inputs):
+        o = OscParams()
+        o.theta12, o.theta13, o.theta23, o.deltacp, o.dm21, o.dm31 = t12, t13, t23, dcp, dm21, dm31
+        np.testing.assert_array_equal(o.mix_matrix_complex, g["osc%d::mix" % i])
+        np.testing.assert_array_equal(o.mix_matrix_reparam_complex, g["osc%d::mix_reparam" % i])
+        np.testing.assert_array_equal(o.dm_matrix, g["osc%d::dm" % i])
+        # unitarity as a sanity property of the golden itself
+        u = o.mix_matrix_complex
+        np.testing.assert_allclose(u @ u.conj().T, np.eye(3), atol=1e-15)
+
+
+def test_nsi_params_bit_exact():
+    from pisa_amd.stages.osc.nsi_params import StdNSIParams, VacuumLikeNSIParams
+
+    g = load_golden("params_ref.npz")
+    for i, v in enumerate(g["stdnsi::inputs"]):
+        n = StdNSIParams()
+        n.eps_ee, n.eps_emu, n.eps_etau = v[0], (v[1], v[2]), (v[3], v[4])
+        n.eps_mumu, n.eps_mutau, n.eps_tautau = v[5], (v[6], v[7]), v[8]
+        eps = n.eps_matrix
+        np.testing.assert_array_equal(eps, g["stdnsi%d::eps" % i])
+        np.testing.assert_array_equal(eps, eps.conj().T)  # Hermitian
+    for i, v in enumerate(g["vacnsi::inputs"]):
+        n = VacuumLikeNSIParams()
+        (n.eps_scale, n.eps_prime, n.phi12, n.phi13, n.phi23, n.alpha1, n.alpha2, n.deltansi) = v
+        np.testing.assert_array_equal(n.eps_matrix, g["vacnsi%d::eps" % i])
+
+
+def test_decay_and_lri_params_bit_exact():
+    from pisa_amd.stages.osc.decay_params import DecayParams
+    from pisa_amd.stages.osc.lri_params import LRIParams
+
+    g = load_golden("params_ref.npz")
+    d = DecayParams()
+    d.decay_alpha3 = float(g["decay::alpha3"])
+    np.testing.assert_array_equal(d.decay_matrix, g["decay::matrix"])
+    l = LRIParams()
+    l.v_lri = float(g["lri::v"])
+    np.testing.assert_array_equal(l.potential_matrix_emu, g["lri::emu"])
+    np.testing.assert_array_equal(l.potential_matrix_etau, g["lri::etau"])
+    np.testing.assert_array_equal(l.potential_matrix_mutau, g["lri::mutau"])
