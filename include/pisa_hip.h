@@ -312,15 +312,62 @@ int pisa_hip_finalize_metric(int64_t *d_limbs, int32_t n_containers, int64_t n_b
 
 /* --------------------------------------------------------------------- KDE */
 
-/* Gaussian kernel sums of the KDE stage (pisa/utils/kde_hist.py:110-120 calls the
- * external, un-vendored `kde.gaussian_kde`; parity of this core is UNPINNED):
+/* The density estimator behind the KDE stage.  pisa/utils/kde_hist.py:110-120 calls
+ *     k = kde.gaussian_kde(x[D,N], weights=, bw_method=, adaptive=, alpha=);  k(points[D,M])
+ * from the external, un-vendored `kde` package (parity of this core is UNPINNED); the
+ * estimator object below is what that binding would be replaced by.
+ *
+ * All-pairs Gaussian kernel sums, no cut-off (the plain O(N*M) double loop):
  *   out[j] = sum_i coef[i] * exp(-0.5 * s2[i] * (q_j - x_i)^T inv_cov (q_j - x_i))
  * d_src[dim][n_src], d_qry[dim][n_qry] (dimension-major), h_inv_cov[dim*dim]
- * row-major symmetric, dim <= 3.  Used for the pilot estimate (s2 = 1) and for
- * the adaptive evaluation on the oversampled bin centres. */
+ * row-major symmetric, dim <= 3. */
 int pisa_hip_kde_eval(int32_t dim, const double *d_src, const double *d_coef, const double *d_s2,
                       int64_t n_src, const double *d_qry, int64_t n_qry, const double *h_inv_cov,
                       double *d_out, void *stream);
+
+#define PISA_HIP_KDE_SILVERMAN 0   /* factor = (n (d+2) / 4)^(-1/(d+4)) */
+#define PISA_HIP_KDE_SCOTT 1       /* factor = n^(-1/(d+4))             */
+
+typedef struct pisa_hip_kde pisa_hip_kde;   /* opaque (host object; device data live in the caller's workspace) */
+
+typedef struct pisa_hip_kde_info_t {
+    int32_t dim, cells[3];
+    int64_t n_src, n_cells;
+    double factor;          /* Silverman / Scott factor                         */
+    double norm;            /* sqrt(det(2 pi covariance))                       */
+    double sum_w;           /* sum of the weights as given                      */
+    double mean[3];         /* weighted mean                                    */
+    double covariance[9];   /* weighted data covariance * factor^2 (3x3 row-major, zero padded) */
+    double inv_cov[9];
+    double r_cut;           /* cut-off radius in kernel sigmas (inf: none)      */
+    double cell;            /* cell side in kernel sigmas                       */
+    int64_t pairs_pilot;    /* kernel evaluations of the pilot estimate         */
+    int64_t pairs_eval;     /* kernel evaluations of the last pisa_hip_kde_evaluate */
+} pisa_hip_kde_info_t;
+
+/* `gaussian_kde(x, weights, bw_method, adaptive, alpha)`: weighted mean / covariance, bandwidth
+ * matrix, and -- if adaptive -- the pilot densities at the sources and the local bandwidths
+ * lambda_i = (pilot_i / geometric mean)^-alpha.  d_x[dim][n] dimension-major; d_w[n] may be NULL
+ * (equal weights).  `tol` > 0: kernel values below tol are dropped (cell list, cost O(N k));
+ * tol = 0: all pairs.  The caller owns `d_work` (>= pisa_hip_kde_workspace_bytes(dim, n) bytes)
+ * and must keep its first pisa_hip_kde_resident_bytes(k) bytes untouched while the estimator
+ * is in use; the rest may be reused after the call returns.  Synchronises the stream. */
+int64_t pisa_hip_kde_workspace_bytes(int32_t dim, int64_t n_src);
+int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d_w, int64_t n,
+                        int32_t bw_method, int32_t adaptive, double alpha, double tol,
+                        void *d_work, int64_t work_bytes, pisa_hip_kde **out, void *stream);
+int64_t pisa_hip_kde_resident_bytes(const pisa_hip_kde *k);
+/* `k(points)`: densities (normalised to integral 1) at d_qry[dim][m] -> d_out[m].  d_work: scratch of
+ * >= pisa_hip_kde_eval_workspace_bytes(k, m) bytes, free again on return. */
+int64_t pisa_hip_kde_eval_workspace_bytes(const pisa_hip_kde *k, int64_t n_qry);
+int pisa_hip_kde_evaluate(pisa_hip_kde *k, const double *d_qry, int64_t m, void *d_work,
+                          int64_t work_bytes, double *d_out, void *stream);
+int pisa_hip_kde_info(const pisa_hip_kde *k, pisa_hip_kde_info_t *info);
+/* device pointers into the resident workspace, in the estimator's (cell-sorted) source order:
+ * whitened coordinates ys[dim][n], kernel coefficients coef[n], squared inverse local bandwidths s2[n] */
+int pisa_hip_kde_arrays(const pisa_hip_kde *k, const double **d_ys, const double **d_coef,
+                        const double **d_s2);
+int pisa_hip_kde_destroy(pisa_hip_kde *k);
 
 /* ------------------------------------------------------------------ metric */
 

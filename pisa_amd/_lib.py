@@ -106,6 +106,17 @@ class FluxTable(C.Structure):
     ]
 
 
+class KdeInfo(C.Structure):
+    _fields_ = [
+        ("dim", C.c_int32), ("cells", C.c_int32 * 3),
+        ("n_src", C.c_int64), ("n_cells", C.c_int64),
+        ("factor", C.c_double), ("norm", C.c_double), ("sum_w", C.c_double),
+        ("mean", C.c_double * 3), ("covariance", C.c_double * 9), ("inv_cov", C.c_double * 9),
+        ("r_cut", C.c_double), ("cell", C.c_double),
+        ("pairs_pilot", C.c_int64), ("pairs_eval", C.c_int64),
+    ]
+
+
 _SIGS = {
     "pisa_hip_strerror": (C.c_char_p, [C.c_int]),
     "pisa_hip_last_hip_error": (C.c_char_p, []),
@@ -132,6 +143,14 @@ _SIGS = {
     "pisa_hip_apply_aeff": (C.c_int, [C.c_void_p, C.c_double, C.c_int64, C.c_void_p, C.c_void_p]),
     "pisa_hip_hist_finalize": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pisa_hip_kde_eval": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pisa_hip_kde_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int64]),
+    "pisa_hip_kde_create": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.c_void_p]),
+    "pisa_hip_kde_resident_bytes": (C.c_int64, [C.c_void_p]),
+    "pisa_hip_kde_eval_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int64]),
+    "pisa_hip_kde_evaluate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "pisa_hip_kde_info": (C.c_int, [C.c_void_p, C.POINTER(KdeInfo)]),
+    "pisa_hip_kde_arrays": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "pisa_hip_kde_destroy": (C.c_int, [C.c_void_p]),
     "pisa_hip_metric": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pisa_hip_bin_scale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_int32, C.c_double, C.c_int64, C.c_void_p, C.c_void_p]),
     "pisa_hip_bin_sqrt": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

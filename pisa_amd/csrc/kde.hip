@@ -1,23 +1,49 @@
-// kde.hip -- all-pairs Gaussian kernel sums for the KDE smoothing stage
+// kde.hip -- Gaussian kernel density estimator of the KDE smoothing stage
 // (pisa/stages/utils/kde.py -> pisa/utils/kde_hist.py:35-217 -> external
 // `kde.gaussian_kde`, whose source is NOT in the reference tree: parity of the
 // KDE core is UNPINNED).
 //
-//   out[j] = sum_i coef[i] * exp(-0.5 * s2[i] * (q_j - x_i)^T inv_cov (q_j - x_i))
+// The estimator (call contract of kde_hist.py:110-120):
+//   f(q)  = sum_i coef_i * exp(-0.5 * s2_i * (q - x_i)^T inv_cov (q - x_i))
+//   pilot:  coef_i = w_i / norm, s2_i = 1            (fixed bandwidth, evaluated at the x_i)
+//   final:  lam_i = (pilot_i / g)^alpha, g = geometric mean of the pilot densities,
+//           coef_i = w_i lam_i^d / norm, s2_i = lam_i^2
 //
-// with per-source squared inverse local bandwidth s2[i] (1 for the pilot
-// estimate) and coef[i] = w_i * s_i^d / norm.  One thread owns one query point
-// and keeps its partial sum in a register; sources are streamed through LDS in
-// tiles (every lane reads the same source -> LDS broadcast, no bank conflicts).
-// With few query points (the evaluation grid of a map is ~10^4 points, 40 workgroups) the
-// sources are additionally split over blockIdx.y so that the launch fills the chip; the
-// per-split partial sums are added in split order by a second kernel.
-// Summation order per query point is fixed => bit-reproducible.
-// Roofline: FP64 VALU + one exp per pair (compute bound; N*M pairs, 40 B/source).
+// Two families of entry points:
+//
+// * `pisa_hip_kde_eval`        all pairs, no cut-off: O(N*M).  The plain double loop, kept as the
+//                              exact form (small problems, and the GPU-side cross-check of the
+//                              cut-off form).
+// * `pisa_hip_kde_create/evaluate/destroy`   the estimator object.  Everything is done in
+//   WHITENED coordinates y = U (x - mean), U^T U = inv_cov, where the quadratic form is the
+//   plain Euclidean |y_q - y_i|^2, and with a CELL LIST: the sources are radix-sorted
+//   (hipCUB) into a uniform grid of cells of side r_cut / 8, the query points into tiles of
+//   cells; a workgroup owns up to 512 queries of one tile and streams through LDS only the
+//   cells that can hold a pair with kernel value above the cut-off:
+//       pair dropped  =>  exp(-0.5 s2_i r^2) < tol     (r_cut^2 = 2 ln(1/tol))
+//   so the truncation error of every density value is below tol * sum_i coef_i.  The cell
+//   test uses the smallest s2 (widest kernel) of the cell, so variable bandwidths keep the
+//   guarantee.  Cost O(N * k), k = sources within the cut-off (7-20 % of N for the
+//   Silverman bandwidth at N = 10^5..10^7 in 2-D).  Fixed summation order (sorted cells,
+//   sorted sources, split partial sums added in split order) => bit-reproducible.
+//   `exp` is an own routine for non-positive arguments (one rint, two-term Cody-Waite
+//   reduction, degree-13 polynomial, ldexp: 19 instructions instead of the library's ~35).
+// Roofline: FP64 VALU, 23 instructions per pair in 2-D (compute bound; 32 B of LDS per pair
+// and pair of queries).
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include <hipcub/hipcub.hpp>
+
 #include "common.hpp"
 
 namespace pisa {
 
+// ------------------------------------------------------------------ all pairs (exact) form
 constexpr int KDE_TILE = 1024;
 constexpr int KDE_THREADS = 256;
 
@@ -82,9 +108,856 @@ kde_reduce_kernel(const double *__restrict__ partial, int n_split, int64_t n_qry
 static double *g_kde_scratch = nullptr;
 static size_t g_kde_scratch_bytes = 0;
 
+// =================================================================== estimator object
+constexpr int RED_BLOCKS = 256;   // fixed reduction geometry => fixed summation order
+constexpr int RED_THREADS = 256;
+constexpr int Q_PER_THREAD = 2;
+constexpr int Q_CHUNK = KDE_THREADS * Q_PER_THREAD;   // queries per workgroup
+constexpr int SRC_TILE = 512;                          // sources per LDS tile
+constexpr int64_t KEY_OFF = 1 << 20;                   // tile coordinates are stored + 2^20
+constexpr int MAX_CELLS = 1 << 22;
+// the cell grid never has more than max(4096, 4 n) cells (larger cells beyond that: less pruning,
+// same results), so that the workspace scales with the number of sources
+static inline int64_t cells_cap(int64_t n) { return std::min<int64_t>(MAX_CELLS, std::max<int64_t>(4096, 4 * n)); }
+
+struct KdeGeom {
+    int32_t dim;
+    int32_t nc[3];       // cells per dimension (1 for unused dimensions)
+    double ylo[3];       // lower corner of the cell grid in whitened coordinates
+    double cell, inv_cell;
+    double rcut2;        // 2 ln(1/tol); <= 0: no cut-off
+    double U[9];         // whitening: y = U (x - mean), upper triangular, row-major 3x3
+    double mean[3];
+};
+
+struct KdeBlock {        // one workgroup of the pair kernel
+    int32_t q_begin, q_count;
+    int32_t c0[3], c1[3];   // cell bounds of the queries' tile (inclusive; may lie outside the grid)
+};
+
+__device__ inline double block_sum(double v, double *lds) {
+    const int t = threadIdx.x;
+    __syncthreads();
+    lds[t] = v;
+    __syncthreads();
+    for (int s = RED_THREADS / 2; s > 0; s >>= 1) {
+        if (t < s) lds[t] += lds[t + s];
+        __syncthreads();
+    }
+    return lds[0];
+}
+__device__ inline double block_min(double v, double *lds) {
+    const int t = threadIdx.x;
+    __syncthreads();
+    lds[t] = v;
+    __syncthreads();
+    for (int s = RED_THREADS / 2; s > 0; s >>= 1) {
+        if (t < s) lds[t] = fmin(lds[t], lds[t + s]);
+        __syncthreads();
+    }
+    return lds[0];
+}
+
+// pass 1: sum w, sum w x_d, min x_d, max x_d   -> partial[block][1 + 3 D]
+template <int D>
+__global__ void __launch_bounds__(RED_THREADS)
+kde_moments1_kernel(const double *__restrict__ x, const double *__restrict__ w, int64_t n,
+                    double *__restrict__ partial) {
+    __shared__ double lds[RED_THREADS];
+    double sw = 0.0, sx[D], mn[D], mx[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) { sx[d] = 0.0; mn[d] = INFINITY; mx[d] = -INFINITY; }
+    for (int64_t i = (int64_t)blockIdx.x * RED_THREADS + threadIdx.x; i < n;
+         i += (int64_t)RED_BLOCKS * RED_THREADS) {
+        const double wi = w ? w[i] : 1.0;
+        sw += wi;
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const double v = x[(int64_t)d * n + i];
+            sx[d] += wi * v;
+            mn[d] = fmin(mn[d], v);
+            mx[d] = fmax(mx[d], v);
+        }
+    }
+    double *out = partial + (int64_t)blockIdx.x * (1 + 3 * D);
+    double r = block_sum(sw, lds);
+    if (threadIdx.x == 0) out[0] = r;
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        r = block_sum(sx[d], lds);
+        if (threadIdx.x == 0) out[1 + d] = r;
+        r = block_min(mn[d], lds);
+        if (threadIdx.x == 0) out[1 + D + d] = r;
+        r = -block_min(-mx[d], lds);
+        if (threadIdx.x == 0) out[1 + 2 * D + d] = r;
+    }
+}
+
+// pass 2 (about the weighted mean): sum w^2, sum w xc_d xc_e (d <= e) -> partial[block][1 + 6]
+template <int D>
+__global__ void __launch_bounds__(RED_THREADS)
+kde_moments2_kernel(const double *__restrict__ x, const double *__restrict__ w, int64_t n,
+                    double m0, double m1, double m2, double *__restrict__ partial) {
+    __shared__ double lds[RED_THREADS];
+    const double mean[3] = {m0, m1, m2};
+    double sww = 0.0, c[6] = {0, 0, 0, 0, 0, 0};
+    for (int64_t i = (int64_t)blockIdx.x * RED_THREADS + threadIdx.x; i < n;
+         i += (int64_t)RED_BLOCKS * RED_THREADS) {
+        const double wi = w ? w[i] : 1.0;
+        sww += wi * wi;
+        double xc[3] = {0, 0, 0};
+#pragma unroll
+        for (int d = 0; d < D; d++) xc[d] = x[(int64_t)d * n + i] - mean[d];
+        int k = 0;
+#pragma unroll
+        for (int d = 0; d < D; d++)
+#pragma unroll
+            for (int e = d; e < D; e++) c[k++] += wi * xc[d] * xc[e];
+    }
+    double *out = partial + (int64_t)blockIdx.x * 7;
+    double r = block_sum(sww, lds);
+    if (threadIdx.x == 0) out[0] = r;
+    for (int k = 0; k < 6; k++) {
+        r = block_sum(c[k], lds);
+        if (threadIdx.x == 0) out[1 + k] = r;
+    }
+}
+
+// columns [0, n_sum) of partial[RED_BLOCKS][width] are summed, [n_sum, n_sum+n_min) minimised,
+// the rest maximised, in block order
+__global__ void __launch_bounds__(RED_THREADS)
+kde_final_reduce_kernel(const double *__restrict__ partial, int width, int n_sum, int n_min,
+                        double *__restrict__ out) {
+    __shared__ double lds[RED_THREADS];
+    for (int k = 0; k < width; k++) {
+        const double v = partial[(int64_t)threadIdx.x * width + k];
+        double r;
+        if (k < n_sum) r = block_sum(v, lds);
+        else if (k < n_sum + n_min) r = block_min(v, lds);
+        else r = -block_min(-v, lds);
+        if (threadIdx.x == 0) out[k] = r;
+    }
+}
+
+__device__ inline uint64_t tile_key(const double *y, const KdeGeom &g, int tile) {
+    uint64_t key = 0;
+#pragma unroll
+    for (int d = 2; d >= 0; d--) {
+        int64_t c = 0;
+        if (d < g.dim) {
+            double f = floor((y[d] - g.ylo[d]) * g.inv_cell);
+            // NaN or far outside: parked in the outermost tile (contributes / receives nothing)
+            if (!(f > -(double)(KEY_OFF - 2) * tile)) f = -(double)(KEY_OFF - 2) * tile;
+            if (f > (double)(KEY_OFF - 2) * tile) f = (double)(KEY_OFF - 2) * tile;
+            c = (int64_t)f;
+            c = (c >= 0 ? c / tile : -((-c + tile - 1) / tile));   // floor division
+        }
+        key = (key << 21) | (uint64_t)(c + KEY_OFF);
+    }
+    return key;
+}
+
+// whitened coordinates + tile key of every point; `clamp`: sources are put inside the cell grid
+template <int D>
+__global__ void __launch_bounds__(256)
+kde_whiten_key_kernel(const double *__restrict__ x, int64_t n, KdeGeom g, int tile, int clamp,
+                      double *__restrict__ y, uint64_t *__restrict__ keys, uint32_t *__restrict__ idx) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double xc[3] = {0, 0, 0}, yy[3] = {0, 0, 0};
+#pragma unroll
+    for (int d = 0; d < D; d++) xc[d] = x[(int64_t)d * n + i] - g.mean[d];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        double a = 0.0;
+#pragma unroll
+        for (int e = d; e < D; e++) a += g.U[d * 3 + e] * xc[e];
+        yy[d] = a;
+        if (clamp) {   // rounding may put a point a hair outside the transformed bounding box
+            const double lo = g.ylo[d], hi = g.ylo[d] + (g.nc[d] - 0.5) * g.cell;
+            const double v = fmin(fmax(a, lo), hi);
+            yy[d] = (a == a) ? v : a;
+        }
+        y[(int64_t)d * n + i] = a;
+    }
+    keys[i] = tile_key(yy, g, tile);
+    idx[i] = (uint32_t)i;
+}
+
+// sorted copies: ys[d][k] = y[d][perm[k]], ws[k] = w[perm[k]] * scale
+template <int D>
+__global__ void __launch_bounds__(256)
+kde_gather_kernel(const double *__restrict__ y, const double *__restrict__ w, double scale,
+                  const uint32_t *__restrict__ perm, int64_t n, double *__restrict__ ys,
+                  double *__restrict__ ws) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t i = perm[k];
+#pragma unroll
+    for (int d = 0; d < D; d++) ys[(int64_t)d * n + k] = y[(int64_t)d * n + i];
+    if (ws) ws[k] = (w ? w[i] : 1.0) * scale;
+}
+
+__device__ inline int64_t flat_cell(uint64_t key, const KdeGeom &g) {
+    const int64_t cx = (int64_t)(key & 0x1FFFFF) - KEY_OFF;
+    const int64_t cy = (int64_t)((key >> 21) & 0x1FFFFF) - KEY_OFF;
+    const int64_t cz = (int64_t)((key >> 42) & 0x1FFFFF) - KEY_OFF;
+    return (cz * g.nc[1] + cy) * g.nc[0] + cx;
+}
+
+// cell_start[c] = first sorted source of cell c (sources sorted by key == sorted by flat cell)
+__global__ void __launch_bounds__(256)
+kde_cell_start_kernel(const uint64_t *__restrict__ keys, int64_t n, KdeGeom g, int64_t n_cells,
+                      int32_t *__restrict__ cell_start) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k > n) return;
+    const int64_t prev = k == 0 ? -1 : flat_cell(keys[k - 1], g);
+    const int64_t cur = k == n ? n_cells : flat_cell(keys[k], g);
+    for (int64_t c = prev + 1; c <= cur; c++) cell_start[c] = (int32_t)k;
+}
+
+// heads of runs of equal key
+__global__ void __launch_bounds__(256)
+kde_heads_kernel(const uint64_t *__restrict__ keys, int64_t n, uint8_t *__restrict__ flags) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    flags[k] = (k == 0 || keys[k] != keys[k - 1]) ? 1 : 0;
+}
+__global__ void __launch_bounds__(256)
+kde_head_keys_kernel(const uint64_t *__restrict__ keys, const int32_t *__restrict__ starts,
+                     const int32_t *__restrict__ n_heads, uint64_t *__restrict__ out) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k < *n_heads) out[k] = keys[starts[k]];
+}
+
+// exp(t) for t <= 0: |rel. error| < 2 ulp down to the subnormal range (where ldexp rounds)
+__device__ inline double exp_nonpos(double t) {
+    t = fmax(t, -800.0);
+    const double k = __builtin_rint(t * 1.4426950408889634074);
+    double r = __builtin_fma(k, -6.93147180369123816490e-01, t);
+    r = __builtin_fma(k, -1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;                       // 1/13!
+    p = __builtin_fma(p, r, 2.08767569878680989792e-09);     // 1/12!
+    p = __builtin_fma(p, r, 2.50521083854417187751e-08);     // 1/11!
+    p = __builtin_fma(p, r, 2.75573192239858906526e-07);     // 1/10!
+    p = __builtin_fma(p, r, 2.75573192239858906526e-06);     // 1/9!
+    p = __builtin_fma(p, r, 2.48015873015873015873e-05);     // 1/8!
+    p = __builtin_fma(p, r, 1.98412698412698412698e-04);     // 1/7!
+    p = __builtin_fma(p, r, 1.38888888888888888889e-03);     // 1/6!
+    p = __builtin_fma(p, r, 8.33333333333333333333e-03);     // 1/5!
+    p = __builtin_fma(p, r, 4.16666666666666666667e-02);     // 1/4!
+    p = __builtin_fma(p, r, 1.66666666666666666667e-01);     // 1/3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)k);
+}
+
+// The pair kernel.  Workgroup = one KdeBlock (<= 512 queries of one tile, two per thread) x
+// one share `blockIdx.y` of the visited cells.  Sources, coef and s2h = -0.5 s2 come sorted by
+// cell; VAR_BW = false: s2 = 1 for every source (pilot estimate).
+template <int D, bool VAR_BW>
+__global__ void __launch_bounds__(KDE_THREADS)
+kde_pairs_kernel(KdeGeom g, const KdeBlock *__restrict__ blocks, const double *__restrict__ qy,
+                 int64_t n_qry, const double *__restrict__ sy, int64_t n_src,
+                 const double *__restrict__ coef, const double *__restrict__ s2,
+                 const int32_t *__restrict__ cell_start, const double *__restrict__ cell_s2min,
+                 const double *__restrict__ s2min_glob, int n_split, double *__restrict__ out,
+                 unsigned long long *__restrict__ pair_count) {
+    constexpr int W = (D == 3) ? 6 : 4;   // doubles per staged source: y[D], coef, s2h (+ pad)
+    __shared__ double t_src[SRC_TILE * W];
+    const KdeBlock b = blocks[blockIdx.x];
+    const int split = blockIdx.y;
+    double q[Q_PER_THREAD][D], acc[Q_PER_THREAD];
+#pragma unroll
+    for (int u = 0; u < Q_PER_THREAD; u++) {
+        const int jq = threadIdx.x + u * KDE_THREADS;
+        const int64_t j = b.q_begin + (jq < b.q_count ? jq : 0);
+#pragma unroll
+        for (int d = 0; d < D; d++) q[u][d] = qy[(int64_t)d * n_qry + j];
+        acc[u] = 0.0;
+    }
+    // candidate cells: everything within the widest kernel's reach of the tile
+    const double s2min = VAR_BW ? *s2min_glob : 1.0;
+    const bool cut = g.rcut2 > 0.0;
+    int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        lo[d] = 0;
+        hi[d] = g.nc[d] - 1;
+        if (cut) {
+            const double reach = ceil(sqrt(g.rcut2 / s2min) * g.inv_cell);
+            const double l = (double)b.c0[d] - reach, h = (double)b.c1[d] + reach;
+            lo[d] = l > 0.0 ? (int)l : 0;
+            hi[d] = h < (double)(g.nc[d] - 1) ? (int)h : g.nc[d] - 1;
+        }
+    }
+    unsigned long long pairs = 0;
+    int visited = 0;
+    for (int cz = lo[2]; cz <= hi[2]; cz++) {
+        double gz = 0.0;
+        if (D > 2) {
+            const int gap = cz < b.c0[2] ? b.c0[2] - cz - 1 : (cz > b.c1[2] ? cz - b.c1[2] - 1 : 0);
+            gz = gap * g.cell;
+        }
+        for (int cy = lo[1]; cy <= hi[1]; cy++) {
+            double gy = 0.0;
+            if (D > 1) {
+                const int gap = cy < b.c0[1] ? b.c0[1] - cy - 1 : (cy > b.c1[1] ? cy - b.c1[1] - 1 : 0);
+                gy = gap * g.cell;
+            }
+            const int64_t row = ((int64_t)cz * g.nc[1] + cy) * g.nc[0];
+            for (int cx = lo[0]; cx <= hi[0]; cx++) {
+                const int64_t c = row + cx;
+                const int begin = cell_start[c], end = cell_start[c + 1];
+                if (end == begin) continue;
+                if (cut) {
+                    const int gap = cx < b.c0[0] ? b.c0[0] - cx - 1 : (cx > b.c1[0] ? cx - b.c1[0] - 1 : 0);
+                    const double gx = gap * g.cell;
+                    const double d2 = gx * gx + gy * gy + gz * gz;
+                    if (d2 * (VAR_BW ? cell_s2min[c] : 1.0) > g.rcut2) continue;
+                }
+                if ((visited++) % n_split != split) continue;
+                pairs += (unsigned long long)(end - begin) * b.q_count;
+                for (int base = begin; base < end; base += SRC_TILE) {
+                    const int cnt = end - base < SRC_TILE ? end - base : SRC_TILE;
+                    __syncthreads();
+                    for (int k = threadIdx.x; k < cnt; k += KDE_THREADS) {
+#pragma unroll
+                        for (int d = 0; d < D; d++) t_src[k * W + d] = sy[(int64_t)d * n_src + base + k];
+                        t_src[k * W + D] = coef[base + k];
+                        t_src[k * W + D + 1] = VAR_BW ? -0.5 * s2[base + k] : -0.5;
+                    }
+                    __syncthreads();
+#pragma unroll 2
+                    for (int k = 0; k < cnt; k++) {
+                        const double *s = t_src + k * W;
+                        const double cf = s[D], sh = s[D + 1];
+#pragma unroll
+                        for (int u = 0; u < Q_PER_THREAD; u++) {
+                            double d0 = q[u][0] - s[0];
+                            double r2 = d0 * d0;
+                            if (D > 1) { const double d1 = q[u][D > 1 ? 1 : 0] - s[D > 1 ? 1 : 0]; r2 = __builtin_fma(d1, d1, r2); }
+                            if (D > 2) { const double d2 = q[u][D > 2 ? 2 : 0] - s[D > 2 ? 2 : 0]; r2 = __builtin_fma(d2, d2, r2); }
+                            acc[u] = __builtin_fma(cf, exp_nonpos(r2 * sh), acc[u]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    out += (int64_t)split * n_qry;
+#pragma unroll
+    for (int u = 0; u < Q_PER_THREAD; u++) {
+        const int jq = threadIdx.x + u * KDE_THREADS;
+        if (jq < b.q_count) out[b.q_begin + jq] = acc[u];
+    }
+    if (pair_count && threadIdx.x == 0 && pairs) atomicAdd(pair_count, pairs);
+}
+
+// out[dst] = sum over splits (split order); dst = perm[k] (scatter back to the caller's order) or k
+__global__ void __launch_bounds__(256)
+kde_combine_kernel(const double *__restrict__ partial, int n_split, int64_t n,
+                   const uint32_t *__restrict__ perm, double *__restrict__ out) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    double acc = partial[k];
+    for (int s = 1; s < n_split; s++) acc += partial[(int64_t)s * n + k];
+    out[perm ? perm[k] : k] = acc;
+}
+
+// sum of log(pilot) -> partial[block]
+__global__ void __launch_bounds__(RED_THREADS)
+kde_logsum_kernel(const double *__restrict__ pilot, int64_t n, double *__restrict__ partial) {
+    __shared__ double lds[RED_THREADS];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * RED_THREADS + threadIdx.x; i < n;
+         i += (int64_t)RED_BLOCKS * RED_THREADS)
+        s += log(pilot[i]);
+    const double r = block_sum(s, lds);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+// local bandwidths: lam = (pilot / g)^alpha, s2 = lam^2, coef = wn lam^d / norm; per-block min s2
+__global__ void __launch_bounds__(RED_THREADS)
+kde_bandwidth_kernel(const double *__restrict__ pilot, const double *__restrict__ wn, int64_t n,
+                     const double *__restrict__ logsum, double alpha, int dim, double inv_norm,
+                     double *__restrict__ coef, double *__restrict__ s2, double *__restrict__ partial_min) {
+    __shared__ double lds[RED_THREADS];
+    const double glob = exp(*logsum / (double)n);
+    double mn = INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * RED_THREADS + threadIdx.x; i < n;
+         i += (int64_t)RED_BLOCKS * RED_THREADS) {
+        const double lam = pow(pilot[i] / glob, alpha);
+        const double l2 = lam * lam;
+        s2[i] = l2;
+        coef[i] = wn[i] * (dim == 1 ? lam : (dim == 2 ? l2 : l2 * lam)) * inv_norm;
+        mn = fmin(mn, l2);   // NaN (pilot <= 0 cannot happen: own term) is ignored by fmin
+    }
+    const double r = block_min(mn, lds);
+    if (threadIdx.x == 0) partial_min[blockIdx.x] = r;
+}
+
+// fixed bandwidth: coef = wn / norm, s2 = 1
+__global__ void __launch_bounds__(256)
+kde_fixed_bandwidth_kernel(const double *__restrict__ wn, int64_t n, double inv_norm,
+                           double *__restrict__ coef, double *__restrict__ s2) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    coef[i] = wn[i] * inv_norm;
+    if (s2) s2[i] = 1.0;
+}
+
+__global__ void __launch_bounds__(256)
+kde_cell_s2min_kernel(const double *__restrict__ s2, const int32_t *__restrict__ cell_start,
+                      int64_t n_cells, double *__restrict__ cell_s2min) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_cells) return;
+    double mn = INFINITY;
+    for (int k = cell_start[c]; k < cell_start[c + 1]; k++) mn = fmin(mn, s2[k]);
+    cell_s2min[c] = mn;
+}
+
+// ------------------------------------------------------------------ host side
+struct Arena {   // carves the caller's workspace
+    char *base;
+    size_t size, used;
+    bool ok;
+    Arena(void *p, size_t n) : base((char *)p), size(n), used(0), ok(true) {}
+    template <class T> T *take(size_t count) {
+        size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+        if (used + bytes > size) { ok = false; return nullptr; }
+        T *r = (T *)(base + used);
+        used += bytes;
+        return r;
+    }
+};
+
+static size_t sort_temp_bytes(int64_t n) {
+    size_t bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (uint64_t *)nullptr, (uint64_t *)nullptr,
+                                       (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, 0, 63, 0);
+    size_t b2 = 0;
+    (void)hipcub::DeviceSelect::Flagged(nullptr, b2, hipcub::CountingInputIterator<int32_t>(0),
+                                  (uint8_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int)n, 0);
+    return std::max(bytes, b2) + 256;
+}
+
 }  // namespace pisa
 
 using namespace pisa;
+
+struct pisa_hip_kde {
+    int dim;
+    int64_t n;
+    int adaptive;
+    double alpha, tol, factor, norm, sum_w, r_cut;
+    double mean[3], cov[9], inv_cov[9];
+    KdeGeom g;
+    int64_t n_cells;
+    // device (inside the caller's workspace)
+    double *ys, *wn, *coef, *s2, *cell_s2min, *scalars;   // scalars: [0] log-sum, [1] min s2
+    int32_t *cell_start;
+    unsigned long long *pair_count;
+    unsigned long long pairs_pilot, pairs_eval;
+};
+
+namespace pisa {
+
+static int query_blocks(const uint64_t *d_keys, int64_t m, int tile, char *d_temp, size_t temp_bytes,
+                        uint8_t *d_flags, int32_t *d_starts, int32_t *d_count, uint64_t *d_head_keys,
+                        std::vector<KdeBlock> &blocks, hipStream_t s) {
+    hipLaunchKernelGGL(kde_heads_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, d_keys, m, d_flags);
+    PISA_CHECK_LAUNCH("kde_heads_kernel");
+    PISA_TRY_HIP(hipcub::DeviceSelect::Flagged(d_temp, temp_bytes, hipcub::CountingInputIterator<int32_t>(0),
+                                               d_flags, d_starts, d_count, (int)m, s));
+    int32_t n_heads = 0;
+    PISA_TRY_HIP(hipMemcpyAsync(&n_heads, d_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    PISA_TRY_HIP(hipStreamSynchronize(s));
+    if (n_heads <= 0) return PISA_HIP_ERR_INVALID;
+    hipLaunchKernelGGL(kde_head_keys_kernel, dim3((unsigned)((n_heads + 255) / 256)), dim3(256), 0, s,
+                       d_keys, d_starts, d_count, d_head_keys);
+    PISA_CHECK_LAUNCH("kde_head_keys_kernel");
+    std::vector<int32_t> starts(n_heads);
+    std::vector<uint64_t> hk(n_heads);
+    PISA_TRY_HIP(hipMemcpyAsync(starts.data(), d_starts, n_heads * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    PISA_TRY_HIP(hipMemcpyAsync(hk.data(), d_head_keys, n_heads * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    PISA_TRY_HIP(hipStreamSynchronize(s));
+    blocks.clear();
+    for (int32_t h = 0; h < n_heads; h++) {
+        const int64_t begin = starts[h], end = h + 1 < n_heads ? starts[h + 1] : m;
+        KdeBlock b;
+        for (int d = 0; d < 3; d++) {
+            const int64_t t = (int64_t)((hk[h] >> (21 * d)) & 0x1FFFFF) - KEY_OFF;
+            b.c0[d] = (int32_t)(t * tile);
+            b.c1[d] = (int32_t)(t * tile + tile - 1);
+        }
+        for (int64_t q = begin; q < end; q += Q_CHUNK) {
+            b.q_begin = (int32_t)q;
+            b.q_count = (int32_t)std::min<int64_t>(Q_CHUNK, end - q);
+            blocks.push_back(b);
+        }
+    }
+    return PISA_HIP_OK;
+}
+
+template <bool VAR_BW>
+static int launch_pairs(const pisa_hip_kde *k, const KdeBlock *d_blocks, int n_blocks, int n_split,
+                        const double *qy, int64_t m, double *partial, hipStream_t s) {
+    dim3 grid((unsigned)n_blocks, (unsigned)n_split), block(KDE_THREADS);
+#define KDE_PAIRS(DD) hipLaunchKernelGGL((kde_pairs_kernel<DD, VAR_BW>), grid, block, 0, s, k->g, d_blocks, qy, m, k->ys, k->n, k->coef, k->s2, k->cell_start, k->cell_s2min, k->scalars + 1, n_split, partial, k->pair_count)
+    if (k->dim == 1) KDE_PAIRS(1);
+    else if (k->dim == 2) KDE_PAIRS(2);
+    else KDE_PAIRS(3);
+#undef KDE_PAIRS
+    PISA_CHECK_LAUNCH("kde_pairs_kernel");
+    return PISA_HIP_OK;
+}
+
+static int pick_split(int n_blocks) {
+    int n_split = 1;
+    if (n_blocks < 1024) n_split = std::min(32, (1024 + n_blocks - 1) / n_blocks);
+    return n_split;
+}
+
+// bytes of the create-time workspace that stay in use for the lifetime of the estimator
+static size_t resident_bytes(int dim, int64_t n, int64_t n_cells) {
+    auto r = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    return r((size_t)dim * n * 8) + 3 * r((size_t)n * 8) + r((size_t)(n_cells + 1) * 4) +
+           r((size_t)n_cells * 8) + r(64) + r(64);
+}
+
+}  // namespace pisa
+
+// split partial sums exist only below 1024 workgroups, i.e. below 2^19 queries
+static size_t split_bytes(int64_t m) { return (size_t)32 * 8 * (size_t)std::min<int64_t>(m, 1 << 19); }
+
+PISA_API int64_t pisa_hip_kde_workspace_bytes(int32_t dim, int64_t n_src) {
+    if (dim < 1 || dim > 3 || n_src < 1 || n_src > 0x7FFFFFF0LL) return -1;
+    const size_t n = (size_t)n_src;
+    size_t total = resident_bytes(dim, n_src, cells_cap(n_src)) + (size_t)RED_BLOCKS * 16 * 8;
+    total += dim * n * 8 + 2 * n * 8 + 2 * n * 4;        // y, keys x2, idx x2
+    total += n + n * 4 + n * 8;                          // flags, starts, head keys
+    total += n * 8 + split_bytes(n_src);                 // pilot, split partials
+    total += sort_temp_bytes(n_src) + (n / Q_CHUNK + (size_t)cells_cap(n_src)) * sizeof(KdeBlock);
+    return (int64_t)(total + 64 * 256);
+}
+
+PISA_API int pisa_hip_kde_destroy(pisa_hip_kde *k) {
+    if (k) free(k);
+    return PISA_HIP_OK;
+}
+
+PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d_w, int64_t n,
+                                 int32_t bw_method, int32_t adaptive, double alpha, double tol,
+                                 void *d_work, int64_t work_bytes, pisa_hip_kde **out, void *stream) {
+    if (!out) return PISA_HIP_ERR_INVALID;
+    *out = nullptr;
+    if (dim < 1 || dim > 3 || n < 2 || n > 0x7FFFFFF0LL || !d_x || !d_work || work_bytes <= 0 ||
+        (bw_method != 0 && bw_method != 1) || !(tol >= 0.0) || tol >= 1.0)
+        return PISA_HIP_ERR_INVALID;
+    hipStream_t s = as_stream(stream);
+    Arena ar(d_work, (size_t)work_bytes);
+    pisa_hip_kde *k = (pisa_hip_kde *)calloc(1, sizeof(pisa_hip_kde));
+    if (!k) return PISA_HIP_ERR_NOMEM;
+    k->dim = dim; k->n = n; k->adaptive = adaptive; k->alpha = alpha; k->tol = tol;
+#define KDE_FAIL(rc) do { free(k); return (rc); } while (0)
+#define KDE_TRY(expr) do { int _rc = (expr); if (_rc != PISA_HIP_OK) KDE_FAIL(_rc); } while (0)
+#define KDE_TRY_HIP(expr) do { int _rc = ::pisa::check_hip((expr), #expr); if (_rc != PISA_HIP_OK) KDE_FAIL(_rc); } while (0)
+    // ---- resident part of the workspace (a first guess of the cell count is fixed up below)
+    double *partial = ar.take<double>((size_t)RED_BLOCKS * 16);
+    double *red = ar.take<double>(16);
+    if (!ar.ok) KDE_FAIL(PISA_HIP_ERR_NOMEM);
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    // ---- moments
+    double h1[10], h2[7];
+#define KDE_D(KERNEL, ...) do { if (dim == 1) hipLaunchKernelGGL(KERNEL<1>, __VA_ARGS__); else if (dim == 2) hipLaunchKernelGGL(KERNEL<2>, __VA_ARGS__); else hipLaunchKernelGGL(KERNEL<3>, __VA_ARGS__); } while (0)
+    KDE_D(kde_moments1_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, d_x, d_w, n, partial);
+    hipLaunchKernelGGL(kde_final_reduce_kernel, dim3(1), dim3(RED_THREADS), 0, s, partial, 1 + 3 * dim,
+                       1 + dim, dim, red);
+    KDE_TRY_HIP(hipMemcpyAsync(h1, red, (1 + 3 * dim) * sizeof(double), hipMemcpyDeviceToHost, s));
+    KDE_TRY_HIP(hipStreamSynchronize(s));
+    const double sw = h1[0];
+    if (!(sw > 0.0) || !std::isfinite(sw)) KDE_FAIL(PISA_HIP_ERR_INVALID);
+    double xmin[3] = {0, 0, 0}, xmax[3] = {0, 0, 0};
+    for (int d = 0; d < dim; d++) {
+        k->mean[d] = h1[1 + d] / sw;
+        xmin[d] = h1[1 + dim + d];
+        xmax[d] = h1[1 + 2 * dim + d];
+    }
+    KDE_D(kde_moments2_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, d_x, d_w, n, k->mean[0],
+          k->mean[1], k->mean[2], partial);
+    hipLaunchKernelGGL(kde_final_reduce_kernel, dim3(1), dim3(RED_THREADS), 0, s, partial, 7, 7, 0, red);
+    KDE_TRY_HIP(hipMemcpyAsync(h2, red, 7 * sizeof(double), hipMemcpyDeviceToHost, s));
+    KDE_TRY_HIP(hipStreamSynchronize(s));
+    // ---- bandwidth matrix (unbiased weighted covariance x factor^2), its inverse, whitening
+    k->sum_w = sw;
+    const double denom = 1.0 - h2[0] / (sw * sw);
+    double cov[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    {
+        int idx = 1;
+        for (int d = 0; d < dim; d++)
+            for (int e = d; e < dim; e++) {
+                cov[d][e] = cov[e][d] = h2[idx] / sw / denom;
+                idx++;
+            }
+    }
+    k->factor = bw_method == 0 ? pow((double)n * (dim + 2) / 4.0, -1.0 / (dim + 4))   // silverman
+                               : pow((double)n, -1.0 / (dim + 4));                      // scott
+    double H[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int d = 0; d < dim; d++)
+        for (int e = 0; e < dim; e++) H[d][e] = cov[d][e] * k->factor * k->factor;
+    const double det = H[0][0] * (H[1][1] * H[2][2] - H[1][2] * H[2][1]) -
+                       H[0][1] * (H[1][0] * H[2][2] - H[1][2] * H[2][0]) +
+                       H[0][2] * (H[1][0] * H[2][1] - H[1][1] * H[2][0]);
+    if (!(det > 0.0) || !std::isfinite(det)) KDE_FAIL(PISA_HIP_ERR_INVALID);
+    double inv[3][3];
+    inv[0][0] = (H[1][1] * H[2][2] - H[1][2] * H[2][1]) / det;
+    inv[0][1] = (H[0][2] * H[2][1] - H[0][1] * H[2][2]) / det;
+    inv[0][2] = (H[0][1] * H[1][2] - H[0][2] * H[1][1]) / det;
+    inv[1][0] = (H[1][2] * H[2][0] - H[1][0] * H[2][2]) / det;
+    inv[1][1] = (H[0][0] * H[2][2] - H[0][2] * H[2][0]) / det;
+    inv[1][2] = (H[0][2] * H[1][0] - H[0][0] * H[1][2]) / det;
+    inv[2][0] = (H[1][0] * H[2][1] - H[1][1] * H[2][0]) / det;
+    inv[2][1] = (H[0][1] * H[2][0] - H[0][0] * H[2][1]) / det;
+    inv[2][2] = (H[0][0] * H[1][1] - H[0][1] * H[1][0]) / det;
+    k->norm = sqrt(pow(2.0 * M_PI, dim) * det);
+    for (int d = 0; d < 3; d++)
+        for (int e = 0; e < 3; e++) {
+            k->cov[d * 3 + e] = (d < dim && e < dim) ? H[d][e] : 0.0;
+            k->inv_cov[d * 3 + e] = (d < dim && e < dim) ? inv[d][e] : 0.0;
+        }
+    // Cholesky inv = L L^T, U = L^T  =>  |U v|^2 = v^T inv v
+    double L[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int i = 0; i < dim; i++)
+        for (int j = 0; j <= i; j++) {
+            double sum = inv[i][j];
+            for (int p = 0; p < j; p++) sum -= L[i][p] * L[j][p];
+            if (i == j) {
+                if (!(sum > 0.0)) KDE_FAIL(PISA_HIP_ERR_INVALID);
+                L[i][i] = sqrt(sum);
+            } else L[i][j] = sum / L[j][j];
+        }
+    KdeGeom &g = k->g;
+    memset(&g, 0, sizeof(g));
+    g.dim = dim;
+    for (int d = 0; d < 3; d++) {
+        g.mean[d] = k->mean[d];
+        for (int e = 0; e < 3; e++) g.U[d * 3 + e] = (d < dim && e < dim) ? L[e][d] : 0.0;
+    }
+    // ---- cell grid over the whitened bounding box (image of the corners of the x box)
+    double ylo[3] = {0, 0, 0}, yhi[3] = {0, 0, 0};
+    for (int d = 0; d < dim; d++) { ylo[d] = INFINITY; yhi[d] = -INFINITY; }
+    for (int corner = 0; corner < (1 << dim); corner++) {
+        double xc[3] = {0, 0, 0};
+        for (int d = 0; d < dim; d++) xc[d] = ((corner >> d) & 1 ? xmax[d] : xmin[d]) - k->mean[d];
+        for (int d = 0; d < dim; d++) {
+            double a = 0.0;
+            for (int e = d; e < dim; e++) a += g.U[d * 3 + e] * xc[e];
+            ylo[d] = std::min(ylo[d], a);
+            yhi[d] = std::max(yhi[d], a);
+        }
+    }
+    const bool cut = tol > 0.0;
+    g.rcut2 = cut ? 2.0 * log(1.0 / tol) : 0.0;
+    k->r_cut = cut ? sqrt(g.rcut2) : INFINITY;
+    double extent = 0.0;
+    for (int d = 0; d < dim; d++) extent = std::max(extent, yhi[d] - ylo[d]);
+    if (!std::isfinite(extent)) KDE_FAIL(PISA_HIP_ERR_INVALID);
+    double cell = cut ? k->r_cut / (dim == 3 ? 4.0 : 8.0) : (extent > 0 ? 2.0 * extent : 1.0);
+    for (;;) {   // keep the grid below MAX_CELLS and every coordinate below 2^20
+        double total = 1.0;
+        bool ok = true;
+        for (int d = 0; d < dim; d++) {
+            const double c = floor((yhi[d] - ylo[d]) / cell) + 1.0;
+            total *= c;
+            ok = ok && c < (double)(KEY_OFF / 16);
+        }
+        if (ok && total <= (double)cells_cap(n)) break;
+        cell *= 1.25;
+    }
+    g.cell = cell;
+    g.inv_cell = 1.0 / cell;
+    k->n_cells = 1;
+    for (int d = 0; d < 3; d++) {
+        g.nc[d] = d < dim ? (int)(floor((yhi[d] - ylo[d]) / cell) + 1.0) : 1;
+        g.ylo[d] = d < dim ? ylo[d] : 0.0;
+        k->n_cells *= g.nc[d];
+    }
+    // ---- resident arrays
+    k->ys = ar.take<double>((size_t)dim * n);
+    k->wn = ar.take<double>(n);
+    k->coef = ar.take<double>(n);
+    k->s2 = ar.take<double>(n);
+    k->cell_start = ar.take<int32_t>(k->n_cells + 1);
+    k->cell_s2min = ar.take<double>(k->n_cells);
+    k->scalars = ar.take<double>(8);
+    k->pair_count = ar.take<unsigned long long>(8);
+    // ---- transient arrays
+    double *y = ar.take<double>((size_t)dim * n);
+    uint64_t *keys_a = ar.take<uint64_t>(n), *keys_b = ar.take<uint64_t>(n);
+    uint32_t *idx_a = ar.take<uint32_t>(n), *idx_b = ar.take<uint32_t>(n);
+    const size_t temp_bytes = sort_temp_bytes(n);
+    char *temp = ar.take<char>(temp_bytes);
+    if (!ar.ok) KDE_FAIL(PISA_HIP_ERR_NOMEM);
+    KDE_TRY_HIP(hipMemsetAsync(k->pair_count, 0, 64, s));
+    // ---- whiten, sort by cell, cell table
+    KDE_D(kde_whiten_key_kernel, dim3(nb), dim3(256), 0, s, d_x, n, g, 1, 1, y, keys_a, idx_a);
+    size_t tb = temp_bytes;
+    KDE_TRY_HIP(hipcub::DeviceRadixSort::SortPairs(temp, tb, keys_a, keys_b, idx_a, idx_b, (int)n, 0, 63, s));
+    KDE_D(kde_gather_kernel, dim3(nb), dim3(256), 0, s, y, d_w, 1.0 / sw, idx_b, n, k->ys, k->wn);
+    hipLaunchKernelGGL(kde_cell_start_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, s, keys_b, n,
+                       g, k->n_cells, k->cell_start);
+    KDE_TRY(check_hip(hipGetLastError(), "kde setup kernels"));
+    if (!adaptive) {
+        hipLaunchKernelGGL(kde_fixed_bandwidth_kernel, dim3(nb), dim3(256), 0, s, k->wn, n, 1.0 / k->norm,
+                           k->coef, k->s2);
+        const double one = 1.0;
+        KDE_TRY_HIP(hipMemcpyAsync(k->scalars + 1, &one, sizeof(double), hipMemcpyHostToDevice, s));
+    } else {
+        // pilot estimate at the sources themselves: queries = sorted sources, tiles = cells
+        hipLaunchKernelGGL(kde_fixed_bandwidth_kernel, dim3(nb), dim3(256), 0, s, k->wn, n, 1.0 / k->norm,
+                           k->coef, (double *)nullptr);
+        uint8_t *flags = ar.take<uint8_t>(n);
+        int32_t *starts = ar.take<int32_t>(n);
+        uint64_t *head_keys = ar.take<uint64_t>(n);
+        int32_t *d_count = (int32_t *)(k->scalars + 4);
+        std::vector<KdeBlock> blocks;
+        if (!ar.ok) KDE_FAIL(PISA_HIP_ERR_NOMEM);
+        KDE_TRY(query_blocks(keys_b, n, 1, temp, temp_bytes, flags, starts, d_count, head_keys, blocks, s));
+        const int n_blocks = (int)blocks.size();
+        const int n_split = pick_split(n_blocks);
+        KdeBlock *d_blocks = ar.take<KdeBlock>(blocks.size());
+        double *pilot = ar.take<double>(n);
+        double *part = n_split > 1 ? ar.take<double>((size_t)n_split * n) : pilot;
+        if (!ar.ok) KDE_FAIL(PISA_HIP_ERR_NOMEM);
+        KDE_TRY_HIP(hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(KdeBlock),
+                                   hipMemcpyHostToDevice, s));
+        KDE_TRY(launch_pairs<false>(k, d_blocks, n_blocks, n_split, k->ys, n, part, s));
+        if (n_split > 1)
+            hipLaunchKernelGGL(kde_combine_kernel, dim3(nb), dim3(256), 0, s, part, n_split, n,
+                               (const uint32_t *)nullptr, pilot);
+        hipLaunchKernelGGL(kde_logsum_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, pilot, n, partial);
+        hipLaunchKernelGGL(kde_final_reduce_kernel, dim3(1), dim3(RED_THREADS), 0, s, partial, 1, 1, 0, k->scalars);
+        hipLaunchKernelGGL(kde_bandwidth_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, pilot, k->wn, n,
+                           k->scalars, alpha, dim, 1.0 / k->norm, k->coef, k->s2, partial);
+        hipLaunchKernelGGL(kde_final_reduce_kernel, dim3(1), dim3(RED_THREADS), 0, s, partial, 1, 0, 1,
+                           k->scalars + 1);
+        KDE_TRY(check_hip(hipGetLastError(), "kde pilot kernels"));
+        // the host copy of the blocks must outlive the asynchronous upload
+        KDE_TRY_HIP(hipMemcpyAsync(&k->pairs_pilot, k->pair_count, sizeof(unsigned long long),
+                                   hipMemcpyDeviceToHost, s));
+        KDE_TRY_HIP(hipStreamSynchronize(s));
+        KDE_TRY_HIP(hipMemsetAsync(k->pair_count, 0, 64, s));
+    }
+    hipLaunchKernelGGL(kde_cell_s2min_kernel, dim3((unsigned)((k->n_cells + 255) / 256)), dim3(256), 0, s,
+                       k->s2, k->cell_start, k->n_cells, k->cell_s2min);
+    KDE_TRY(check_hip(hipGetLastError(), "kde_cell_s2min_kernel"));
+    KDE_TRY_HIP(hipStreamSynchronize(s));
+#undef KDE_FAIL
+#undef KDE_TRY
+#undef KDE_TRY_HIP
+    *out = k;
+    return PISA_HIP_OK;
+}
+
+PISA_API int64_t pisa_hip_kde_resident_bytes(const pisa_hip_kde *k) {
+    if (!k) return -1;
+    return (int64_t)(resident_bytes(k->dim, k->n, k->n_cells) + (size_t)RED_BLOCKS * 16 * 8 + 4096);
+}
+
+PISA_API int64_t pisa_hip_kde_eval_workspace_bytes(const pisa_hip_kde *k, int64_t n_qry) {
+    if (!k || n_qry < 1 || n_qry > 0x7FFFFFF0LL) return -1;
+    const int64_t m = n_qry;
+    size_t total = 2 * (size_t)k->dim * m * 8 + 2 * (size_t)m * 8 + 2 * (size_t)m * 4 + (size_t)m +
+                   (size_t)m * 4 + (size_t)m * 8 + split_bytes(m) + (size_t)m * 8 + sort_temp_bytes(m) +
+                   ((size_t)m / Q_CHUNK + (size_t)std::min<int64_t>(m, 1 << 22) + 16) * sizeof(KdeBlock);
+    return (int64_t)(total + 64 * 256);
+}
+
+PISA_API int pisa_hip_kde_evaluate(pisa_hip_kde *k, const double *d_qry, int64_t m, void *d_work,
+                                   int64_t work_bytes, double *d_out, void *stream) {
+    if (!k || m < 0) return PISA_HIP_ERR_INVALID;
+    if (m == 0) return PISA_HIP_OK;
+    if (!d_qry || !d_out || !d_work || m > 0x7FFFFFF0LL) return PISA_HIP_ERR_INVALID;
+    hipStream_t s = as_stream(stream);
+    Arena ar(d_work, (size_t)work_bytes);
+    const int dim = k->dim;
+    const KdeGeom &g = k->g;
+    // tile size: at least ~128 queries per tile if the queries cover the source grid evenly
+    int tile = 1;
+    {
+        const double per_cell = (double)m / (double)k->n_cells;
+        while (tile < 64 && per_cell * pow((double)tile, dim) < 128.0) tile *= 2;
+        if (!(g.rcut2 > 0.0)) tile = 1;   // one cell holds everything
+    }
+    double *qy = ar.take<double>((size_t)dim * m), *qys = ar.take<double>((size_t)dim * m);
+    uint64_t *keys_a = ar.take<uint64_t>(m), *keys_b = ar.take<uint64_t>(m);
+    uint32_t *idx_a = ar.take<uint32_t>(m), *idx_b = ar.take<uint32_t>(m);
+    uint8_t *flags = ar.take<uint8_t>(m);
+    int32_t *starts = ar.take<int32_t>(m);
+    uint64_t *head_keys = ar.take<uint64_t>(m);
+    int32_t *d_count = ar.take<int32_t>(8);
+    const size_t temp_bytes = sort_temp_bytes(m);
+    char *temp = ar.take<char>(temp_bytes);
+    if (!ar.ok) return PISA_HIP_ERR_NOMEM;
+    const unsigned nb = (unsigned)((m + 255) / 256);
+    KDE_D(kde_whiten_key_kernel, dim3(nb), dim3(256), 0, s, d_qry, m, g, tile, 0, qy, keys_a, idx_a);
+    size_t tb = temp_bytes;
+    PISA_TRY_HIP(hipcub::DeviceRadixSort::SortPairs(temp, tb, keys_a, keys_b, idx_a, idx_b, (int)m, 0, 63, s));
+    KDE_D(kde_gather_kernel, dim3(nb), dim3(256), 0, s, qy, (const double *)nullptr, 1.0, idx_b, m, qys,
+          (double *)nullptr);
+    PISA_CHECK_LAUNCH("kde evaluate setup");
+    std::vector<KdeBlock> blocks;
+    int rc = query_blocks(keys_b, m, tile, temp, temp_bytes, flags, starts, d_count, head_keys, blocks, s);
+    if (rc != PISA_HIP_OK) return rc;
+    const int n_blocks = (int)blocks.size();
+    const int n_split = pick_split(n_blocks);
+    KdeBlock *d_blocks = ar.take<KdeBlock>(blocks.size());
+    double *part = ar.take<double>((size_t)n_split * m);
+    if (!ar.ok) return PISA_HIP_ERR_NOMEM;
+    PISA_TRY_HIP(hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(KdeBlock),
+                                hipMemcpyHostToDevice, s));
+    rc = launch_pairs<true>(k, d_blocks, n_blocks, n_split, qys, m, part, s);
+    if (rc != PISA_HIP_OK) return rc;
+    hipLaunchKernelGGL(kde_combine_kernel, dim3(nb), dim3(256), 0, s, part, n_split, m, idx_b, d_out);
+    PISA_CHECK_LAUNCH("kde_combine_kernel");
+    PISA_TRY_HIP(hipMemcpyAsync(&k->pairs_eval, k->pair_count, sizeof(unsigned long long),
+                                hipMemcpyDeviceToHost, s));
+    PISA_TRY_HIP(hipStreamSynchronize(s));   // `blocks` (host) is read by the upload above
+    PISA_TRY_HIP(hipMemsetAsync(k->pair_count, 0, 64, s));
+    return PISA_HIP_OK;
+}
+#undef KDE_D
+
+PISA_API int pisa_hip_kde_info(const pisa_hip_kde *k, pisa_hip_kde_info_t *info) {
+    if (!k || !info) return PISA_HIP_ERR_INVALID;
+    memset(info, 0, sizeof(*info));
+    info->dim = k->dim;
+    info->n_src = k->n;
+    info->factor = k->factor;
+    info->norm = k->norm;
+    info->sum_w = k->sum_w;
+    info->r_cut = k->r_cut;
+    info->cell = k->g.cell;
+    info->n_cells = k->n_cells;
+    for (int d = 0; d < 3; d++) { info->mean[d] = k->mean[d]; info->cells[d] = k->g.nc[d]; }
+    for (int i = 0; i < 9; i++) { info->covariance[i] = k->cov[i]; info->inv_cov[i] = k->inv_cov[i]; }
+    info->pairs_pilot = (int64_t)k->pairs_pilot;
+    info->pairs_eval = (int64_t)k->pairs_eval;
+    return PISA_HIP_OK;
+}
+
+/* device pointers into the estimator's resident workspace (sorted source order): for tests and
+ * for callers that need the local bandwidths */
+PISA_API int pisa_hip_kde_arrays(const pisa_hip_kde *k, const double **d_ys, const double **d_coef,
+                                 const double **d_s2) {
+    if (!k) return PISA_HIP_ERR_INVALID;
+    if (d_ys) *d_ys = k->ys;
+    if (d_coef) *d_coef = k->coef;
+    if (d_s2) *d_s2 = k->s2;
+    return PISA_HIP_OK;
+}
 
 PISA_API int pisa_hip_kde_eval(int32_t dim, const double *d_src, const double *d_coef,
                                const double *d_s2, int64_t n_src, const double *d_qry,

@@ -301,6 +301,88 @@ def kde_eval(src, coef, s2, qry, inv_cov):
     return out
 
 
+KDE_BW = {"silverman": 0, "scott": 1}
+KDE_DEFAULT_TOL = 1e-14
+
+
+class KdeEstimator:
+    """`gaussian_kde(x, weights, bw_method, adaptive, alpha)` on the device
+    (`pisa_hip_kde_create` / `_evaluate`; cell-list cut-off at kernel value `tol`, 0 = all pairs).
+    x [dim, n] device tensor (dimension-major), weights [n] or None."""
+
+    def __init__(self, x, weights=None, bw_method="silverman", adaptive=True, alpha=0.3,
+                 tol=KDE_DEFAULT_TOL):
+        import ctypes as C
+
+        lib = _lib.lib()
+        if bw_method not in KDE_BW:
+            raise ValueError("`bw_method` should be 'scott' or 'silverman'")
+        x = x.contiguous()
+        self.dim, self.n = int(x.shape[0]), int(x.shape[1])
+        need = int(lib.pisa_hip_kde_workspace_bytes(self.dim, self.n))
+        if need < 0:
+            raise ValueError("KDE of %d points in %d dimensions not supported" % (self.n, self.dim))
+        work = torch.empty(need, dtype=torch.uint8, device=x.device)
+        w = None if weights is None else weights.contiguous()
+        h = C.c_void_p()
+        _lib.check(lib.pisa_hip_kde_create(self.dim, _ptr(x), None if w is None else _ptr(w), self.n,
+                                           KDE_BW[bw_method], 1 if adaptive else 0, float(alpha),
+                                           float(tol), _ptr(work), need, C.byref(h), _stream()))
+        self._h, self._lib = h, lib
+        self._work = work   # holds the estimator's device arrays (torch's caching allocator reuses it)
+        info = _lib.KdeInfo()
+        _lib.check(lib.pisa_hip_kde_info(h, C.byref(info)))
+        d = self.dim
+        self.factor, self.norm, self.sum_w = info.factor, info.norm, info.sum_w
+        self.covariance = np.array(info.covariance).reshape(3, 3)[:d, :d].copy()
+        self.inv_cov = np.array(info.inv_cov).reshape(3, 3)[:d, :d].copy()
+        self.mean = np.array(info.mean)[:d].copy()
+        self.r_cut, self.cell, self.n_cells = info.r_cut, info.cell, info.n_cells
+        self.pairs_pilot = info.pairs_pilot
+        self.pairs_eval = 0
+
+    def __call__(self, points):
+        import ctypes as C
+
+        q = points.contiguous()
+        m = int(q.shape[1])
+        out = torch.empty(m, dtype=F8, device=q.device)
+        if m == 0:
+            return out
+        need = int(self._lib.pisa_hip_kde_eval_workspace_bytes(self._h, m))
+        work = torch.empty(need, dtype=torch.uint8, device=q.device)
+        _lib.check(self._lib.pisa_hip_kde_evaluate(self._h, _ptr(q), m, _ptr(work), need, _ptr(out),
+                                                   _stream()))
+        info = _lib.KdeInfo()
+        _lib.check(self._lib.pisa_hip_kde_info(self._h, C.byref(info)))
+        self.pairs_eval = info.pairs_eval
+        return out
+
+    def arrays(self):
+        """(ys [dim, n], coef [n], s2 [n]) in the estimator's cell-sorted source order (copies)"""
+        import ctypes as C
+
+        p = [C.c_void_p() for _ in range(3)]
+        _lib.check(self._lib.pisa_hip_kde_arrays(self._h, *[C.byref(v) for v in p]))
+        base = self._work.data_ptr()
+        out = []
+        for v, cnt in zip(p, (self.dim * self.n, self.n, self.n)):
+            off = v.value - base
+            out.append(self._work[off:off + 8 * cnt].view(F8).clone())
+        return out[0].view(self.dim, self.n), out[1], out[2]
+
+    def close(self):
+        if self._h is not None:
+            self._lib.pisa_hip_kde_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # --------------------------------------------------------------- metric
 METRIC_KIND = {"llh": 0, "poisson_llh": 1, "chi2": 2, "mod_chi2": 3}
 

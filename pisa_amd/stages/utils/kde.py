@@ -3,10 +3,19 @@
 Same constructor kwargs and defaults as the reference (:52-66); log dimensions
 are smoothed in ln-space (`linearize_log_dims`, :106-130); the event weights are
 whatever the previous stages produced (a deferred reweighting chain is
-materialised first).  `stash_hists` memoises the maps (:157-164, 280-293).
-Bootstrap errors are not part of this build.
+materialised first).  `stash_hists` memoises the maps (:157-164, 280-293);
+`bootstrap` gives per-bin errors from `bootstrap_niter` resampled estimates
+(:189-258: the same `numpy.random.default_rng(seed).integers` / `bincount` draws,
+so the same seed resamples the same events).
+
+The sample columns never change between evaluations: they -- and, with
+`stack_pid`, the per-channel event indices -- are kept in HBM from the first
+evaluation on; per evaluation only the weights move.  The estimator itself is
+native code (`csrc/kde.hip`: cell-list Gaussian cut-off at kernel value `tol`,
+extra kwarg of this build, default 1e-14, 0 = all pairs).
 """
 import numpy as np
+import torch
 
 from pisa_amd import FTYPE
 from pisa_amd.core.binning import MultiDimBinning, OneDimBinning
@@ -20,9 +29,7 @@ class kde(Stage):  # pylint: disable=invalid-name
     def __init__(self, bw_method="silverman", coszen_name="reco_coszen", oversample=10,
                  coszen_reflection=0.25, adaptive=True, alpha=0.1, stack_pid=True,
                  stash_hists=False, bootstrap=False, bootstrap_niter=10, bootstrap_seed=None,
-                 linearize_log_dims=True, **std_kargs):
-        if bootstrap:
-            raise NotImplementedError("bootstrap KDE errors are not part of this build")
+                 linearize_log_dims=True, tol=None, **std_kargs):
         self.bw_method = bw_method
         self.coszen_name = coszen_name
         self.oversample = int(oversample)
@@ -33,13 +40,25 @@ class kde(Stage):  # pylint: disable=invalid-name
         self.stash_hists = stash_hists
         self.stash_valid = False
         self.stashed_hists = None
+        self.stashed_errors = None
         self.linearize_log_dims = linearize_log_dims
+        self.bootstrap = bootstrap
+        self.bootstrap_niter = int(bootstrap_niter)
+        self.bootstrap_seed = int(bootstrap_seed) if bootstrap_seed is not None else None
+        self.tol = None if tol is None else float(tol)
+        if self.bootstrap and self.oversample > 1:
+            # errors inside a bin are highly correlated (kde_hist.py:67-70)
+            raise ValueError("Bootstrapping cannot be combined with oversampling.")
         super().__init__(expected_params=(), expected_container_keys=(),
                          supported_reps={"calc_mode": "events", "apply_mode": MultiDimBinning},
                          **std_kargs)
         self.regularized_apply_mode = None
+        self._static = {}
+        self.stats = {}
 
     def setup_function(self):
+        self._static = {}
+        self.stash_valid = False
         if not self.linearize_log_dims:
             self.regularized_apply_mode = self.apply_mode
             return
@@ -54,30 +73,84 @@ class kde(Stage):  # pylint: disable=invalid-name
                                           num_bins=dim.num_bins))
         self.regularized_apply_mode = MultiDimBinning(dims)
 
+    def _static_sample(self, container):
+        """device sample [N, D] (+ pid channels) of a container; rebuilt when a column changed"""
+        names = [d.name for d in self.regularized_apply_mode]
+        versions = tuple(container.version(n) for n in names)
+        hit = self._static.get(container.name)
+        if hit is not None and hit["versions"] == versions:
+            return hit
+        cols = []
+        for dim, orig in zip(self.regularized_apply_mode, self.apply_mode):
+            container.representation = ("log_events" if (orig.is_log and self.linearize_log_dims)
+                                        else "events")
+            cols.append(container.device(dim.name))
+        container.representation = "events"
+        sample = torch.stack(cols, dim=1).contiguous()
+        chans = kde_hist.pid_channels(sample, self.regularized_apply_mode) if self.stack_pid else None
+        hit = dict(versions=versions, sample=sample, channels=chans)
+        self._static[container.name] = hit
+        return hit
+
+    def _bootstrap_weights(self, rng, st, size):
+        """how often each event is drawn when the sample (each pid channel, if stacking) is
+        resampled with replacement (stages/utils/kde.py:197-238)"""
+        if self.stack_pid:
+            sw = torch.zeros(size, dtype=torch.float64, device=st["sample"].device)
+            for idx, _ in st["channels"][2]:
+                n_ch = int(idx.numel())
+                draws = np.bincount(rng.integers(n_ch, size=n_ch), minlength=n_ch)
+                sw[idx] += torch.as_tensor(draws, dtype=torch.float64).to(sw.device)
+            return sw
+        draws = np.bincount(rng.integers(size, size=size), minlength=size)
+        return torch.as_tensor(draws, dtype=torch.float64).to(st["sample"].device)
+
     def apply_function(self):
+        self.stats = {}
         for container in self.data:
             if self.stash_valid:
                 self.data.representation = self.apply_mode
                 container["weights"] = self.stashed_hists[container.name].copy()
+                if self.bootstrap:
+                    container["errors"] = self.stashed_errors[container.name].copy()
                 continue
-            sample = []
-            for dim, orig in zip(self.regularized_apply_mode, self.apply_mode):
-                container.representation = ("log_events" if (orig.is_log and self.linearize_log_dims)
-                                            else "events")
-                sample.append(container[dim.name])
+            st = self._static_sample(container)
             container.representation = "events"
-            sample = np.stack(sample).T
-            weights = container["weights"]
-            kde_map = kde_hist.kde_histogramdd(
-                sample=sample, binning=self.regularized_apply_mode, weights=weights,
-                bw_method=self.bw_method, coszen_name=self.coszen_name,
-                coszen_reflection=self.coszen_reflection, adaptive=self.adaptive, alpha=self.alpha,
-                oversample=self.oversample, stack_pid=self.stack_pid)
+            weights = container.device("weights")   # materialises a deferred reweighting chain
+            kw = dict(sample=st["sample"], binning=self.regularized_apply_mode,
+                      bw_method=self.bw_method, coszen_name=self.coszen_name,
+                      coszen_reflection=self.coszen_reflection, adaptive=self.adaptive,
+                      alpha=self.alpha, oversample=self.oversample, stack_pid=self.stack_pid,
+                      tol=self.tol, stats=self.stats, channels=st["channels"])
+            if self.bootstrap:
+                rng = np.random.default_rng(self.bootstrap_seed)
+                maps = []
+                for _ in range(self.bootstrap_niter):
+                    sw = self._bootstrap_weights(rng, st, int(weights.numel()))
+                    try:
+                        m = kde_hist.kde_histogramdd(weights=weights * sw, **kw)
+                    except Exception as exc:
+                        raise RuntimeError(
+                            "Could not calculate KDE with the given sample. This can happen if the "
+                            "bootstrap selects too few distinct events in one of the PID channels."
+                        ) from exc
+                    if not np.all(np.isfinite(m)):
+                        raise RuntimeError("Could not calculate KDE with the given sample (non-finite map).")
+                    maps.append(m)
+                maps = np.stack(maps)
+                kde_map = np.mean(maps, axis=0)
+                kde_errors = np.ascontiguousarray(np.std(maps, axis=0).ravel(), dtype=FTYPE)
+            else:
+                kde_map = kde_hist.kde_histogramdd(weights=weights, **kw)
             kde_map = np.ascontiguousarray(kde_map.ravel(), dtype=FTYPE)
             self.data.representation = self.apply_mode
             container["weights"] = kde_map
+            if self.bootstrap:
+                container["errors"] = kde_errors
             if self.stash_hists:
                 if self.stashed_hists is None:
-                    self.stashed_hists = {}
+                    self.stashed_hists, self.stashed_errors = {}, {}
                 self.stashed_hists[container.name] = kde_map.copy()
+                if self.bootstrap:
+                    self.stashed_errors[container.name] = kde_errors.copy()
         self.stash_valid = self.stash_hists

@@ -12,8 +12,11 @@ reference tree, so the numerical details below are this build's choices
 (PARITY UNPINNED): weighted full-covariance Gaussian
 kernel, Silverman / Scott bandwidth factor on the sample count, Abramson
 adaptive bandwidths lambda_i = (f(x_i)/g)^-alpha with g the geometric mean of
-the fixed-bandwidth pilot densities.  The O(N^2) pilot and the O(N*M)
-evaluation run on the GPU (`pisa_hip_kde_eval`).
+the fixed-bandwidth pilot densities.  The whole estimator -- moments, bandwidth
+matrix, pilot, local bandwidths, evaluation -- is native code behind
+`pisa_hip_kde_create/evaluate` (`csrc/kde.hip`): a cell list with a Gaussian
+cut-off at kernel value `tol` (default 1e-14) makes the pilot and the
+evaluation O(N k) instead of O(N^2) / O(N M).
 """
 import copy
 
@@ -23,66 +26,54 @@ import torch
 from pisa_amd import kernels as K
 from pisa_amd.core.binning import MultiDimBinning
 
-__all__ = ["gaussian_kde", "get_hist", "kde_histogramdd"]
+__all__ = ["gaussian_kde", "get_hist", "kde_histogramdd", "pid_channels"]
 
 
 class gaussian_kde:  # pylint: disable=invalid-name
+    """Call contract of `kde.gaussian_kde` (kde_hist.py:110-120).  `tol`: kernel values below it
+    are dropped (cell-list cut-off, `csrc/kde.hip`); 0 evaluates all pairs."""
+
     def __init__(self, dataset, weights=None, bw_method="silverman", adaptive=True, alpha=0.3,
-                 use_cuda=False):  # pylint: disable=unused-argument
+                 use_cuda=False, tol=None):  # pylint: disable=unused-argument
         x = dataset if torch.is_tensor(dataset) else K.to_device(np.atleast_2d(dataset))
-        self.dataset = x.contiguous()
-        self.d, self.n = x.shape
         if weights is None or len(weights) == 0:
-            w = torch.full((self.n,), 1.0 / self.n, dtype=torch.float64, device=x.device)
+            w = None
         else:
             w = weights if torch.is_tensor(weights) else K.to_device(np.asarray(weights))
-            w = w / w.sum()
-        self.weights = w
-        if bw_method == "silverman":
-            self.factor = (self.n * (self.d + 2) / 4.0) ** (-1.0 / (self.d + 4))
-        elif bw_method == "scott":
-            self.factor = self.n ** (-1.0 / (self.d + 4))
-        else:
-            raise ValueError("`bw_method` should be 'scott' or 'silverman'")
-        mean = (x * w).sum(dim=1, keepdim=True)
-        xc = x - mean
-        cov = (xc * w) @ xc.T / (1.0 - float((w * w).sum()))  # unbiased weighted covariance
-        self._data_covariance = cov.cpu().numpy()
-        self.covariance = self._data_covariance * self.factor ** 2
-        self.inv_cov = np.linalg.inv(self.covariance)
-        self._norm = float(np.sqrt(np.linalg.det(2 * np.pi * self.covariance)))
-        ones = torch.ones(self.n, dtype=torch.float64, device=x.device)
-        if adaptive:
-            pilot = K.kde_eval(self.dataset, (w / self._norm).contiguous(), ones, self.dataset,
-                               self.inv_cov)
-            glob = torch.exp(torch.log(pilot).mean())
-            self.inv_loc_bw = torch.pow(pilot / glob, alpha)
-        else:
-            self.inv_loc_bw = ones
-        self._coef = (w * torch.pow(self.inv_loc_bw, self.d) / self._norm).contiguous()
-        self._s2 = (self.inv_loc_bw * self.inv_loc_bw).contiguous()
+        self.d, self.n = x.shape
+        self._est = K.KdeEstimator(x, w, bw_method=bw_method, adaptive=adaptive, alpha=alpha,
+                                   tol=K.KDE_DEFAULT_TOL if tol is None else tol)
+        self.factor = self._est.factor
+        self.covariance = self._est.covariance
+        self.inv_cov = self._est.inv_cov
+        self._norm = self._est.norm
 
     def __call__(self, points):
         q = points if torch.is_tensor(points) else K.to_device(np.atleast_2d(points))
-        return K.kde_eval(self.dataset, self._coef, self._s2, q.contiguous(), self.inv_cov)
+        return self._est(q)
 
     evaluate = __call__
+
+    pairs = property(lambda self: (self._est.pairs_pilot, self._est.pairs_eval))
 
 
 def get_hist(sample, binning, weights=None, bw_method="scott", adaptive=True, alpha=0.3,
              use_cuda=False, coszen_reflection=0.25, coszen_name="coszen", oversample=1,
-             bootstrap=False, bootstrap_niter=10):
-    """kde_hist.py:35-217.  `sample` [N, D] host array (or device tensor)."""
+             bootstrap=False, bootstrap_niter=10, tol=None, stats=None):
+    """kde_hist.py:35-217.  `sample` [N, D] host array or device tensor; `weights` [N] likewise."""
     if bootstrap:
-        raise NotImplementedError("bootstrap KDE errors are not part of this build")
-    sample_h = sample.cpu().numpy() if torch.is_tensor(sample) else np.asarray(sample)
+        # kde_hist.py:108-109 delegates to the external package's `bootstrap_kde`; the KDE
+        # *stage*'s own bootstrap (stages/utils/kde.py:189-258) is what this build provides
+        raise NotImplementedError("get_hist(bootstrap=True) needs the external kde.bootstrap_kde; "
+                                  "use the utils.kde stage's bootstrap option")
+    on_dev = torch.is_tensor(sample)
     if weights is None or len(weights) == 0:
-        weights_h, norm = None, sample_h.shape[0]
+        weights_d, norm = None, sample.shape[0]
     else:
-        weights_h = np.nan_to_num(weights.cpu().numpy() if torch.is_tensor(weights) else np.asarray(weights))
-        norm = np.sum(weights_h)
+        weights_d = torch.nan_to_num(weights if torch.is_tensor(weights) else K.to_device(np.asarray(weights)))
+        norm = float(weights_d.sum())
     binning = binning.oversample(oversample)
-    x = np.array(sample_h.T)
+    x = (sample.T if on_dev else K.to_device(np.ascontiguousarray(np.asarray(sample).T))).clone()
     assert x.shape[0] == len(binning)
     cz_bin = binning.index(coszen_name)
     if cz_bin != 0:
@@ -91,7 +82,8 @@ def get_hist(sample, binning, weights=None, bw_method="scott", adaptive=True, al
     edges = binning[coszen_name].edge_magnitudes
     reflect_lower = edges[0] == -1
     reflect_upper = edges[-1] == 1
-    kernel = gaussian_kde(x, weights=weights_h, bw_method=bw_method, adaptive=adaptive, alpha=alpha)
+    kernel = gaussian_kde(x.contiguous(), weights=weights_d, bw_method=bw_method, adaptive=adaptive,
+                          alpha=alpha, tol=tol)
     bin_points = []
     l = 0
     for b in binning:
@@ -107,6 +99,10 @@ def get_hist(sample, binning, weights=None, bw_method="scott", adaptive=True, al
     grid = np.meshgrid(*bin_points, indexing="ij")
     points = np.array([g.ravel() for g in grid])
     hist = kernel(points).cpu().numpy().reshape(megashape)
+    if stats is not None:
+        stats["pairs_pilot"] = stats.get("pairs_pilot", 0) + kernel.pairs[0]
+        stats["pairs_eval"] = stats.get("pairs_eval", 0) + kernel.pairs[1]
+        stats["all_pairs"] = stats.get("all_pairs", 0) + kernel.n * (kernel.n * bool(adaptive) + points.shape[1])
     if reflect_lower:
         hist0 = np.flipud(np.concatenate([np.zeros(minishape), hist[0:l, :]]))
         hist = hist[l:, :]
@@ -127,21 +123,11 @@ def get_hist(sample, binning, weights=None, bw_method="scott", adaptive=True, al
     return hist * norm
 
 
-def kde_histogramdd(sample, binning, weights=None, bw_method="scott", adaptive=True, alpha=0.3,
-                    use_cuda=False, coszen_reflection=0.25, coszen_name="coszen", oversample=1,
-                    stack_pid=True, bootstrap=False, bootstrap_niter=10):
-    """kde_hist.py:220-387"""
-    sample = sample.cpu().numpy() if torch.is_tensor(sample) else np.asarray(sample)
-    if weights is not None:
-        weights = weights.cpu().numpy() if torch.is_tensor(weights) else np.asarray(weights)
-        if len(weights) != sample.shape[0]:
-            raise ValueError("Length of sample (%s) and weights (%s) incompatible"
-                             % (sample.shape[0], len(weights)))
-    kw = dict(bw_method=bw_method, adaptive=adaptive, alpha=alpha, coszen_reflection=coszen_reflection,
-              coszen_name=coszen_name, oversample=oversample, bootstrap=bootstrap,
-              bootstrap_niter=bootstrap_niter)
-    if not stack_pid:
-        return get_hist(sample=sample, binning=binning, weights=weights, **kw)
+def pid_channels(sample, binning):
+    """stack_pid: per pid bin the device indices of its events and their [2, n] sample in the
+    other two dimensions (kde_hist.py:303-372).  Depends on the (static) sample only, so callers
+    that re-weight the same events every evaluation keep the result."""
+    s = sample if torch.is_tensor(sample) else K.to_device(np.asarray(sample))
     names = copy.copy(binning.names)
     pid_bin = names.index("pid")
     other = [0, 1, 2]
@@ -150,12 +136,36 @@ def kde_histogramdd(sample, binning, weights=None, bw_method="scott", adaptive=T
     assert len(names) == 2
     pid_edges = binning["pid"].edge_magnitudes
     d2d = MultiDimBinning([b for b in binning if b.name != "pid"])
-    stack = []
+    chans = []
     for pid in range(len(pid_edges) - 1):
-        mask = (sample.T[pid_bin] >= pid_edges[pid]) & (sample.T[pid_bin] < pid_edges[pid + 1])
-        data = np.array([sample.T[other[0]][mask], sample.T[other[1]][mask]])
-        w = None if weights is None else weights[mask]
-        stack.append(get_hist(sample=data.T, weights=w, binning=d2d, **kw))
+        mask = (s[:, pid_bin] >= pid_edges[pid]) & (s[:, pid_bin] < pid_edges[pid + 1])
+        idx = torch.nonzero(mask).reshape(-1)
+        chans.append((idx, s[idx][:, other].contiguous()))
+    return pid_bin, d2d, chans
+
+
+def kde_histogramdd(sample, binning, weights=None, bw_method="scott", adaptive=True, alpha=0.3,
+                    use_cuda=False, coszen_reflection=0.25, coszen_name="coszen", oversample=1,
+                    stack_pid=True, bootstrap=False, bootstrap_niter=10, tol=None, stats=None,
+                    channels=None):
+    """kde_hist.py:220-387.  `sample` [N, D], `weights` [N]: host arrays or device tensors.
+    `channels`: result of `pid_channels(sample, binning)` if the caller kept it."""
+    if weights is not None and len(weights) != sample.shape[0]:
+        raise ValueError("Length of sample (%s) and weights (%s) incompatible"
+                         % (sample.shape[0], len(weights)))
+    kw = dict(bw_method=bw_method, adaptive=adaptive, alpha=alpha, coszen_reflection=coszen_reflection,
+              coszen_name=coszen_name, oversample=oversample, bootstrap=bootstrap,
+              bootstrap_niter=bootstrap_niter, tol=tol, stats=stats)
+    if not stack_pid:
+        return get_hist(sample=sample, binning=binning, weights=weights, **kw)
+    pid_bin, d2d, chans = channels if channels is not None else pid_channels(sample, binning)
+    w_d = None
+    if weights is not None:
+        w_d = weights if torch.is_tensor(weights) else K.to_device(np.asarray(weights))
+    stack = []
+    for idx, data in chans:
+        w = None if w_d is None else w_d[idx]
+        stack.append(get_hist(sample=data, weights=w, binning=d2d, **kw))
     hist = np.dstack(stack)
     if pid_bin != 2:
         hist = np.swapaxes(hist, pid_bin, 2)

