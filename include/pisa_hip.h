@@ -341,8 +341,10 @@ typedef struct pisa_hip_kde_info_t {
     double inv_cov[9];
     double r_cut;           /* cut-off radius in kernel sigmas (inf: none)      */
     double cell;            /* cell side in kernel sigmas                       */
-    int64_t pairs_pilot;    /* kernel evaluations of the pilot estimate         */
+    int64_t pairs_pilot;    /* kernel evaluations of the pilot estimate (cells summed through their
+                             * Hermite series count P^2/23 + 1 per target: same instruction count) */
     int64_t pairs_eval;     /* kernel evaluations of the last pisa_hip_kde_evaluate */
+    int32_t n_dense;        /* cells summed through a Hermite series in the pilot estimate */
 } pisa_hip_kde_info_t;
 
 /* `gaussian_kde(x, weights, bw_method, adaptive, alpha)`: weighted mean / covariance, bandwidth
@@ -368,6 +370,10 @@ int pisa_hip_kde_info(const pisa_hip_kde *k, pisa_hip_kde_info_t *info);
 int pisa_hip_kde_arrays(const pisa_hip_kde *k, const double **d_ys, const double **d_coef,
                         const double **d_s2);
 int pisa_hip_kde_destroy(pisa_hip_kde *k);
+/* use_expansion: 1 (default) = in 2-D the fixed-bandwidth pilot sums cells of >= 24 sources through
+ * a truncated Hermite series (fast Gauss transform; truncation error below the cut-off tolerance),
+ * 0 = every pair directly; < 0 = query.  Returns the previous setting. */
+int pisa_hip_kde_configure(int32_t use_expansion);
 
 /* ------------------------------------------------------------------ metric */
 

@@ -113,7 +113,7 @@ class KdeInfo(C.Structure):
         ("factor", C.c_double), ("norm", C.c_double), ("sum_w", C.c_double),
         ("mean", C.c_double * 3), ("covariance", C.c_double * 9), ("inv_cov", C.c_double * 9),
         ("r_cut", C.c_double), ("cell", C.c_double),
-        ("pairs_pilot", C.c_int64), ("pairs_eval", C.c_int64),
+        ("pairs_pilot", C.c_int64), ("pairs_eval", C.c_int64), ("n_dense", C.c_int32),
     ]
 
 
@@ -151,6 +151,7 @@ _SIGS = {
     "pisa_hip_kde_info": (C.c_int, [C.c_void_p, C.POINTER(KdeInfo)]),
     "pisa_hip_kde_arrays": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "pisa_hip_kde_destroy": (C.c_int, [C.c_void_p]),
+    "pisa_hip_kde_configure": (C.c_int, [C.c_int32]),
     "pisa_hip_metric": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pisa_hip_bin_scale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_int32, C.c_double, C.c_int64, C.c_void_p, C.c_void_p]),
     "pisa_hip_bin_sqrt": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -518,6 +518,196 @@ kde_cell_s2min_kernel(const double *__restrict__ s2, const int32_t *__restrict__
     cell_s2min[c] = mn;
 }
 
+
+// ------------------------------------------------------------------ Hermite expansion of dense cells
+// Fixed-bandwidth sums (the pilot estimate) in 2-D: in u = y / sqrt(2) the kernel is exp(-|dt|^2)
+// and the sources of one cell (centre c, half side rho = cell / (2 sqrt 2) = 0.355) act on a
+// target t through the Hermite series  (Greengard & Strain 1991)
+//     sum_j q_j exp(-|t - s_j|^2) = sum_{n,m} A_nm h_n(t1 - c1) h_m(t2 - c2),
+//     A_nm = sum_j q_j (s_j1 - c1)^n (s_j2 - c2)^m / (n! m!),   h_n(x) = (-1)^n d^n/dx^n exp(-x^2).
+// Truncated at n, m < P the error per cell is below  2.3 K^2 (rho sqrt2)^P / sqrt(P!) * sum_j q_j
+// (K = 1.09): 1e-13 for P = 18, 1.5e-15 for P = 20 -- relative to the cell's total weight, i.e.
+// at or below the cut-off tolerance.  A target then costs P^2 + 4 P + 40 multiply-adds per dense
+// cell within the cut-off instead of 23 per SOURCE: N * 250 cells * 500 instead of N * 0.2 N * 23
+// (x 90 at N = 4e5).  Cells with fewer than HERMITE_MIN sources are summed directly.
+constexpr int HERMITE_MIN = 24;
+constexpr double RSQRT2 = 0.70710678118654752440;
+
+__global__ void __launch_bounds__(256)
+kde_slot_scatter_kernel(const int32_t *__restrict__ dense_cells, int n_dense, int32_t *__restrict__ slot) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_dense) slot[dense_cells[i]] = i;
+}
+
+// A[slot][n][m] of one dense cell per workgroup; fixed source order => reproducible
+template <int P>
+__global__ void __launch_bounds__(256)
+kde_hermite_coef_kernel(KdeGeom g, const int32_t *__restrict__ dense_cells,
+                        const int32_t *__restrict__ cell_start, const double *__restrict__ sy,
+                        int64_t n_src, const double *__restrict__ coef, double *__restrict__ herm) {
+    constexpr int TJ = 32;
+    __shared__ double pa[TJ][P + 1], pb[TJ][P + 1];
+    const int c = dense_cells[blockIdx.x];
+    const int cx = c % g.nc[0], cy = c / g.nc[0];
+    const double c1 = g.ylo[0] + (cx + 0.5) * g.cell, c2 = g.ylo[1] + (cy + 0.5) * g.cell;
+    const int begin = cell_start[c], end = cell_start[c + 1];
+    double acc[2] = {0.0, 0.0};
+    for (int base = begin; base < end; base += TJ) {
+        const int cnt = end - base < TJ ? end - base : TJ;
+        __syncthreads();
+        if (threadIdx.x < 2 * TJ) {
+            const int j = threadIdx.x % TJ, which = threadIdx.x / TJ;
+            if (j < cnt) {
+                const double d = (sy[(int64_t)which * n_src + base + j] - (which ? c2 : c1)) * RSQRT2;
+                double v = which ? coef[base + j] : 1.0;   // the weight rides on the second factor
+                double *dst = which ? pb[j] : pa[j];
+                for (int n = 0; n < P; n++) {
+                    dst[n] = v;
+                    v = v * d / (double)(n + 1);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int t = threadIdx.x + u * 256;
+            if (t < P * P) {
+                const int n = t / P, m = t % P;
+                double a = acc[u];
+                for (int j = 0; j < cnt; j++) a = __builtin_fma(pa[j][n], pb[j][m], a);
+                acc[u] = a;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int t = threadIdx.x + u * 256;
+        if (t < P * P) herm[(int64_t)blockIdx.x * (P * P) + t] = acc[u];
+    }
+}
+
+// pilot densities at the (cell-sorted) sources: dense cells through their Hermite series, sparse
+// ones directly.  Workgroup = one KdeBlock (<= 512 targets of ONE cell) x one share of the cells.
+template <int P>
+__global__ void __launch_bounds__(KDE_THREADS)
+kde_hermite_pilot_kernel(KdeGeom g, const KdeBlock *__restrict__ blocks, const double *__restrict__ sy,
+                         int64_t n_src, const double *__restrict__ coef,
+                         const int32_t *__restrict__ cell_start, const int32_t *__restrict__ slot,
+                         const double *__restrict__ herm, int n_split, double *__restrict__ out,
+                         unsigned long long *__restrict__ pair_count) {
+    constexpr int W = 4;
+    __shared__ double t_src[SRC_TILE * W];
+    const KdeBlock b = blocks[blockIdx.x];
+    const int split = blockIdx.y;
+    double q[Q_PER_THREAD][2], acc[Q_PER_THREAD];
+#pragma unroll
+    for (int u = 0; u < Q_PER_THREAD; u++) {
+        const int jq = threadIdx.x + u * KDE_THREADS;
+        const int64_t j = b.q_begin + (jq < b.q_count ? jq : 0);
+        q[u][0] = sy[j];
+        q[u][1] = sy[n_src + j];
+        acc[u] = 0.0;
+    }
+    int lo[2], hi[2];
+    const double reach = ceil(sqrt(g.rcut2) * g.inv_cell);
+#pragma unroll
+    for (int d = 0; d < 2; d++) {
+        const double l = (double)b.c0[d] - reach, h = (double)b.c1[d] + reach;
+        lo[d] = l > 0.0 ? (int)l : 0;
+        hi[d] = h < (double)(g.nc[d] - 1) ? (int)h : g.nc[d] - 1;
+    }
+    unsigned long long work = 0;
+    int visited = 0;
+    for (int cy = lo[1]; cy <= hi[1]; cy++) {
+        const int gapy = cy < b.c0[1] ? b.c0[1] - cy - 1 : (cy > b.c1[1] ? cy - b.c1[1] - 1 : 0);
+        const double gy = gapy * g.cell;
+        const int64_t row = (int64_t)cy * g.nc[0];
+        for (int cx = lo[0]; cx <= hi[0]; cx++) {
+            const int64_t c = row + cx;
+            const int begin = cell_start[c], end = cell_start[c + 1];
+            if (end == begin) continue;
+            const int gapx = cx < b.c0[0] ? b.c0[0] - cx - 1 : (cx > b.c1[0] ? cx - b.c1[0] - 1 : 0);
+            const double gx = gapx * g.cell;
+            if (gx * gx + gy * gy > g.rcut2) continue;
+            if ((visited++) % n_split != split) continue;
+            const int sl = slot[c];
+            if (sl >= 0) {
+                // Hermite series of the cell; coefficient addresses are wave-uniform (scalar loads)
+                const double *__restrict__ A = herm + (int64_t)sl * (P * P);
+                const double c1 = g.ylo[0] + (cx + 0.5) * g.cell, c2 = g.ylo[1] + (cy + 0.5) * g.cell;
+                work += (unsigned long long)(P * P / 23 + 1) * b.q_count;
+                // both targets of the thread go through the series together: every coefficient is
+                // loaded once (a row of P at a time lives in scalar registers) and used twice
+                double hm[Q_PER_THREAD][P], t1x2[Q_PER_THREAD], hp[Q_PER_THREAD], hn[Q_PER_THREAD],
+                    sum[Q_PER_THREAD];
+#pragma unroll
+                for (int u = 0; u < Q_PER_THREAD; u++) {
+                    const double t1 = (q[u][0] - c1) * RSQRT2, t2 = (q[u][1] - c2) * RSQRT2;
+                    hm[u][0] = exp_nonpos(-t2 * t2);
+                    hm[u][1] = 2.0 * t2 * hm[u][0];
+#pragma unroll
+                    for (int m = 1; m + 1 < P; m++)
+                        hm[u][m + 1] = __builtin_fma(2.0 * t2, hm[u][m], -2.0 * m * hm[u][m - 1]);
+                    t1x2[u] = 2.0 * t1;
+                    hp[u] = 0.0;
+                    hn[u] = exp_nonpos(-t1 * t1);
+                    sum[u] = 0.0;
+                }
+#pragma unroll 1
+                for (int n = 0; n < P; n++) {
+                    const double *__restrict__ row = A + n * P;
+                    double inner[Q_PER_THREAD];
+#pragma unroll
+                    for (int u = 0; u < Q_PER_THREAD; u++) inner[u] = 0.0;
+#pragma unroll
+                    for (int m = 0; m < P; m++) {
+                        const double a = row[m];
+#pragma unroll
+                        for (int u = 0; u < Q_PER_THREAD; u++) inner[u] = __builtin_fma(a, hm[u][m], inner[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < Q_PER_THREAD; u++) {
+                        sum[u] = __builtin_fma(hn[u], inner[u], sum[u]);
+                        const double nx = __builtin_fma(t1x2[u], hn[u], -2.0 * n * hp[u]);
+                        hp[u] = hn[u];
+                        hn[u] = nx;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < Q_PER_THREAD; u++) acc[u] += sum[u];
+                continue;
+            }
+            work += (unsigned long long)(end - begin) * b.q_count;
+            for (int base = begin; base < end; base += SRC_TILE) {
+                const int cnt = end - base < SRC_TILE ? end - base : SRC_TILE;
+                __syncthreads();
+                for (int k = threadIdx.x; k < cnt; k += KDE_THREADS) {
+                    t_src[k * W + 0] = sy[base + k];
+                    t_src[k * W + 1] = sy[n_src + base + k];
+                    t_src[k * W + 2] = coef[base + k];
+                }
+                __syncthreads();
+                for (int k = 0; k < cnt; k++) {
+                    const double *s = t_src + k * W;
+#pragma unroll
+                    for (int u = 0; u < Q_PER_THREAD; u++) {
+                        const double d0 = q[u][0] - s[0], d1 = q[u][1] - s[1];
+                        const double r2 = __builtin_fma(d1, d1, d0 * d0);
+                        acc[u] = __builtin_fma(s[2], exp_nonpos(-0.5 * r2), acc[u]);
+                    }
+                }
+            }
+        }
+    }
+    out += (int64_t)split * n_src;
+#pragma unroll
+    for (int u = 0; u < Q_PER_THREAD; u++) {
+        const int jq = threadIdx.x + u * KDE_THREADS;
+        if (jq < b.q_count) out[b.q_begin + jq] = acc[u];
+    }
+    if (pair_count && threadIdx.x == 0 && work) atomicAdd(pair_count, work);
+}
+
 // ------------------------------------------------------------------ host side
 struct Arena {   // carves the caller's workspace
     char *base;
@@ -547,6 +737,8 @@ static size_t sort_temp_bytes(int64_t n) {
 
 using namespace pisa;
 
+static int g_kde_expansion = 1;   // Hermite expansion of dense cells in the 2-D pilot estimate
+
 struct pisa_hip_kde {
     int dim;
     int64_t n;
@@ -560,13 +752,15 @@ struct pisa_hip_kde {
     int32_t *cell_start;
     unsigned long long *pair_count;
     unsigned long long pairs_pilot, pairs_eval;
+    int n_dense;   // cells summed through their Hermite series in the pilot estimate
 };
 
 namespace pisa {
 
 static int query_blocks(const uint64_t *d_keys, int64_t m, int tile, char *d_temp, size_t temp_bytes,
                         uint8_t *d_flags, int32_t *d_starts, int32_t *d_count, uint64_t *d_head_keys,
-                        std::vector<KdeBlock> &blocks, hipStream_t s) {
+                        std::vector<KdeBlock> &blocks, hipStream_t s,
+                        std::vector<int32_t> *starts_out = nullptr, std::vector<uint64_t> *keys_out = nullptr) {
     hipLaunchKernelGGL(kde_heads_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, d_keys, m, d_flags);
     PISA_CHECK_LAUNCH("kde_heads_kernel");
     PISA_TRY_HIP(hipcub::DeviceSelect::Flagged(d_temp, temp_bytes, hipcub::CountingInputIterator<int32_t>(0),
@@ -598,6 +792,8 @@ static int query_blocks(const uint64_t *d_keys, int64_t m, int tile, char *d_tem
             blocks.push_back(b);
         }
     }
+    if (starts_out) starts_out->swap(starts);
+    if (keys_out) keys_out->swap(hk);
     return PISA_HIP_OK;
 }
 
@@ -640,7 +836,15 @@ PISA_API int64_t pisa_hip_kde_workspace_bytes(int32_t dim, int64_t n_src) {
     total += n + n * 4 + n * 8;                          // flags, starts, head keys
     total += n * 8 + split_bytes(n_src);                 // pilot, split partials
     total += sort_temp_bytes(n_src) + (n / Q_CHUNK + (size_t)cells_cap(n_src)) * sizeof(KdeBlock);
+    if (dim == 2)   // Hermite coefficients of the dense cells, cell -> slot map, list of dense cells
+        total += (n / HERMITE_MIN + 1) * (size_t)(20 * 20 * 8 + 4) + (size_t)cells_cap(n_src) * 4 + 1024;
     return (int64_t)(total + 64 * 256);
+}
+
+PISA_API int pisa_hip_kde_configure(int32_t use_expansion) {
+    const int old = g_kde_expansion;
+    if (use_expansion >= 0) g_kde_expansion = use_expansion ? 1 : 0;
+    return old;
 }
 
 PISA_API int pisa_hip_kde_destroy(pisa_hip_kde *k) {
@@ -824,7 +1028,10 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
         int32_t *d_count = (int32_t *)(k->scalars + 4);
         std::vector<KdeBlock> blocks;
         if (!ar.ok) KDE_FAIL(PISA_HIP_ERR_NOMEM);
-        KDE_TRY(query_blocks(keys_b, n, 1, temp, temp_bytes, flags, starts, d_count, head_keys, blocks, s));
+        std::vector<int32_t> h_starts;
+        std::vector<uint64_t> h_keys;
+        KDE_TRY(query_blocks(keys_b, n, 1, temp, temp_bytes, flags, starts, d_count, head_keys, blocks, s,
+                             &h_starts, &h_keys));
         const int n_blocks = (int)blocks.size();
         const int n_split = pick_split(n_blocks);
         KdeBlock *d_blocks = ar.take<KdeBlock>(blocks.size());
@@ -833,7 +1040,46 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
         if (!ar.ok) KDE_FAIL(PISA_HIP_ERR_NOMEM);
         KDE_TRY_HIP(hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(KdeBlock),
                                    hipMemcpyHostToDevice, s));
-        KDE_TRY(launch_pairs<false>(k, d_blocks, n_blocks, n_split, k->ys, n, part, s));
+        // dense cells get a Hermite series (2-D, with a cut-off, enough sources to pay)
+        std::vector<int32_t> dense;
+        const int P = tol >= 1e-12 ? 18 : 20;
+        if (g_kde_expansion && dim == 2 && cut && n >= 20000) {
+            for (size_t h = 0; h < h_starts.size(); h++) {
+                const int64_t end = h + 1 < h_starts.size() ? h_starts[h + 1] : n;
+                if (end - h_starts[h] < HERMITE_MIN) continue;
+                const int64_t cx = (int64_t)(h_keys[h] & 0x1FFFFF) - KEY_OFF;
+                const int64_t cy = (int64_t)((h_keys[h] >> 21) & 0x1FFFFF) - KEY_OFF;
+                dense.push_back((int32_t)(cy * g.nc[0] + cx));
+            }
+        }
+        if (!dense.empty()) {
+            int32_t *d_dense = ar.take<int32_t>(dense.size());
+            int32_t *slot = ar.take<int32_t>(k->n_cells);
+            double *herm = ar.take<double>(dense.size() * (size_t)(P * P));
+            if (!ar.ok) KDE_FAIL(PISA_HIP_ERR_NOMEM);
+            KDE_TRY_HIP(hipMemcpyAsync(d_dense, dense.data(), dense.size() * sizeof(int32_t),
+                                       hipMemcpyHostToDevice, s));
+            KDE_TRY_HIP(hipMemsetAsync(slot, 0xFF, (size_t)k->n_cells * sizeof(int32_t), s));
+            const int nd = (int)dense.size();
+            hipLaunchKernelGGL(kde_slot_scatter_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s,
+                               d_dense, nd, slot);
+            dim3 grid((unsigned)n_blocks, (unsigned)n_split);
+            if (P == 18) {
+                hipLaunchKernelGGL(kde_hermite_coef_kernel<18>, dim3((unsigned)nd), dim3(256), 0, s, g, d_dense,
+                                   k->cell_start, k->ys, n, k->coef, herm);
+                hipLaunchKernelGGL(kde_hermite_pilot_kernel<18>, grid, dim3(KDE_THREADS), 0, s, g, d_blocks,
+                                   k->ys, n, k->coef, k->cell_start, slot, herm, n_split, part, k->pair_count);
+            } else {
+                hipLaunchKernelGGL(kde_hermite_coef_kernel<20>, dim3((unsigned)nd), dim3(256), 0, s, g, d_dense,
+                                   k->cell_start, k->ys, n, k->coef, herm);
+                hipLaunchKernelGGL(kde_hermite_pilot_kernel<20>, grid, dim3(KDE_THREADS), 0, s, g, d_blocks,
+                                   k->ys, n, k->coef, k->cell_start, slot, herm, n_split, part, k->pair_count);
+            }
+            KDE_TRY(check_hip(hipGetLastError(), "kde hermite kernels"));
+            k->n_dense = nd;
+        } else {
+            KDE_TRY(launch_pairs<false>(k, d_blocks, n_blocks, n_split, k->ys, n, part, s));
+        }
         if (n_split > 1)
             hipLaunchKernelGGL(kde_combine_kernel, dim3(nb), dim3(256), 0, s, part, n_split, n,
                                (const uint32_t *)nullptr, pilot);
@@ -945,6 +1191,7 @@ PISA_API int pisa_hip_kde_info(const pisa_hip_kde *k, pisa_hip_kde_info_t *info)
     for (int i = 0; i < 9; i++) { info->covariance[i] = k->cov[i]; info->inv_cov[i] = k->inv_cov[i]; }
     info->pairs_pilot = (int64_t)k->pairs_pilot;
     info->pairs_eval = (int64_t)k->pairs_eval;
+    info->n_dense = k->n_dense;
     return PISA_HIP_OK;
 }
 

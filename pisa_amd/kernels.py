@@ -338,7 +338,7 @@ class KdeEstimator:
         self.inv_cov = np.array(info.inv_cov).reshape(3, 3)[:d, :d].copy()
         self.mean = np.array(info.mean)[:d].copy()
         self.r_cut, self.cell, self.n_cells = info.r_cut, info.cell, info.n_cells
-        self.pairs_pilot = info.pairs_pilot
+        self.pairs_pilot, self.n_dense = info.pairs_pilot, info.n_dense
         self.pairs_eval = 0
 
     def __call__(self, points):

@@ -80,6 +80,39 @@ def test_kde_estimator_vs_oracle(oracle, dim, n, m, adaptive, bw, alpha, tol):
         assert est.pairs_pilot == n * n and est.pairs_eval == n * m
 
 
+def test_kde_hermite_expansion_matches_direct_sums():
+    """the 2-D pilot sums dense cells through a truncated Hermite series (fast Gauss transform);
+    with the expansion switched off every pair is evaluated.  Both must agree far below the
+    parity bar, on the pilot-derived bandwidths and on the final densities."""
+    from pisa_amd import _lib
+    from pisa_amd import kernels as K
+
+    lib = _lib.lib()
+    rs = np.random.RandomState(8)
+    n = 150000
+    x = np.stack([np.clip(rs.rand(n) * 2 - 1 + rs.randn(n) * 0.15, -1, 1), rs.gamma(4.0, 0.5, n) + 0.6 * rs.rand(n)])
+    w = rs.rand(n) * 2 + 0.05
+    q = np.array([g.ravel() for g in np.meshgrid(np.linspace(-1.4, 1.4, 90), np.linspace(0.0, 7.0, 80), indexing="ij")])
+    xd, wd, qd = K.to_device(x), K.to_device(w), K.to_device(q)
+    out = {}
+    old = lib.pisa_hip_kde_configure(-1)
+    try:
+        for tol in (1e-14, 1e-12):
+            for flag in (1, 0):
+                lib.pisa_hip_kde_configure(flag)
+                est = K.KdeEstimator(xd, wd, adaptive=True, alpha=0.3, tol=tol)
+                assert (est.n_dense > 100) == bool(flag)
+                ys, coef, s2 = est.arrays()
+                out[tol, flag] = (s2.cpu().numpy(), est(qd).cpu().numpy(), est.pairs_pilot)
+            s2a, fa, wa = out[tol, 1]
+            s2b, fb, wb = out[tol, 0]
+            np.testing.assert_allclose(s2a, s2b, rtol=3e-12 if tol < 1e-13 else 3e-11)
+            np.testing.assert_allclose(fa, fb, rtol=1e-11 if tol < 1e-13 else 1e-10, atol=1e-13 * fb.max())
+            assert wa < 0.2 * wb      # and it is what makes the pilot cheap
+    finally:
+        lib.pisa_hip_kde_configure(old)
+
+
 def test_kde_estimator_properties():
     """bit-reproducible; unweighted == unit weights; scaling the weights changes nothing (the
     density is normalised); integral over a fine grid = 1"""
