@@ -353,10 +353,10 @@ __device__ inline double exp_nonpos(double t) {
     return __builtin_ldexp(p, (int)k);
 }
 
-// The pair kernel.  Workgroup = one KdeBlock (<= 512 queries of one tile, two per thread) x
+// The pair kernel.  Workgroup = one KdeBlock (<= 256 QPT queries of one tile, QPT per thread) x
 // one share `blockIdx.y` of the visited cells.  Sources, coef and s2h = -0.5 s2 come sorted by
 // cell; VAR_BW = false: s2 = 1 for every source (pilot estimate).
-template <int D, bool VAR_BW>
+template <int D, bool VAR_BW, int QPT>
 __global__ void __launch_bounds__(KDE_THREADS)
 kde_pairs_kernel(KdeGeom g, const KdeBlock *__restrict__ blocks, const double *__restrict__ qy,
                  int64_t n_qry, const double *__restrict__ sy, int64_t n_src,
@@ -368,9 +368,9 @@ kde_pairs_kernel(KdeGeom g, const KdeBlock *__restrict__ blocks, const double *_
     __shared__ double t_src[SRC_TILE * W];
     const KdeBlock b = blocks[blockIdx.x];
     const int split = blockIdx.y;
-    double q[Q_PER_THREAD][D], acc[Q_PER_THREAD];
+    double q[QPT][D], acc[QPT];
 #pragma unroll
-    for (int u = 0; u < Q_PER_THREAD; u++) {
+    for (int u = 0; u < QPT; u++) {
         const int jq = threadIdx.x + u * KDE_THREADS;
         const int64_t j = b.q_begin + (jq < b.q_count ? jq : 0);
 #pragma unroll
@@ -434,7 +434,7 @@ kde_pairs_kernel(KdeGeom g, const KdeBlock *__restrict__ blocks, const double *_
                         const double *s = t_src + k * W;
                         const double cf = s[D], sh = s[D + 1];
 #pragma unroll
-                        for (int u = 0; u < Q_PER_THREAD; u++) {
+                        for (int u = 0; u < QPT; u++) {
                             double d0 = q[u][0] - s[0];
                             double r2 = d0 * d0;
                             if (D > 1) { const double d1 = q[u][D > 1 ? 1 : 0] - s[D > 1 ? 1 : 0]; r2 = __builtin_fma(d1, d1, r2); }
@@ -448,7 +448,7 @@ kde_pairs_kernel(KdeGeom g, const KdeBlock *__restrict__ blocks, const double *_
     }
     out += (int64_t)split * n_qry;
 #pragma unroll
-    for (int u = 0; u < Q_PER_THREAD; u++) {
+    for (int u = 0; u < QPT; u++) {
         const int jq = threadIdx.x + u * KDE_THREADS;
         if (jq < b.q_count) out[b.q_begin + jq] = acc[u];
     }
@@ -757,7 +757,7 @@ struct pisa_hip_kde {
 
 namespace pisa {
 
-static int query_blocks(const uint64_t *d_keys, int64_t m, int tile, char *d_temp, size_t temp_bytes,
+static int query_blocks(const uint64_t *d_keys, int64_t m, int tile, int chunk, char *d_temp, size_t temp_bytes,
                         uint8_t *d_flags, int32_t *d_starts, int32_t *d_count, uint64_t *d_head_keys,
                         std::vector<KdeBlock> &blocks, hipStream_t s,
                         std::vector<int32_t> *starts_out = nullptr, std::vector<uint64_t> *keys_out = nullptr) {
@@ -786,9 +786,12 @@ static int query_blocks(const uint64_t *d_keys, int64_t m, int tile, char *d_tem
             b.c0[d] = (int32_t)(t * tile);
             b.c1[d] = (int32_t)(t * tile + tile - 1);
         }
-        for (int64_t q = begin; q < end; q += Q_CHUNK) {
-            b.q_begin = (int32_t)q;
-            b.q_count = (int32_t)std::min<int64_t>(Q_CHUNK, end - q);
+        // equal shares: a tile of 300 queries becomes 150 + 150, not 256 + 44
+        const int64_t parts = (end - begin + chunk - 1) / chunk;
+        for (int64_t p = 0; p < parts; p++) {
+            const int64_t q0 = begin + (end - begin) * p / parts, q1 = begin + (end - begin) * (p + 1) / parts;
+            b.q_begin = (int32_t)q0;
+            b.q_count = (int32_t)(q1 - q0);
             blocks.push_back(b);
         }
     }
@@ -797,11 +800,11 @@ static int query_blocks(const uint64_t *d_keys, int64_t m, int tile, char *d_tem
     return PISA_HIP_OK;
 }
 
-template <bool VAR_BW>
+template <bool VAR_BW, int QPT>
 static int launch_pairs(const pisa_hip_kde *k, const KdeBlock *d_blocks, int n_blocks, int n_split,
                         const double *qy, int64_t m, double *partial, hipStream_t s) {
     dim3 grid((unsigned)n_blocks, (unsigned)n_split), block(KDE_THREADS);
-#define KDE_PAIRS(DD) hipLaunchKernelGGL((kde_pairs_kernel<DD, VAR_BW>), grid, block, 0, s, k->g, d_blocks, qy, m, k->ys, k->n, k->coef, k->s2, k->cell_start, k->cell_s2min, k->scalars + 1, n_split, partial, k->pair_count)
+#define KDE_PAIRS(DD) hipLaunchKernelGGL((kde_pairs_kernel<DD, VAR_BW, QPT>), grid, block, 0, s, k->g, d_blocks, qy, m, k->ys, k->n, k->coef, k->s2, k->cell_start, k->cell_s2min, k->scalars + 1, n_split, partial, k->pair_count)
     if (k->dim == 1) KDE_PAIRS(1);
     else if (k->dim == 2) KDE_PAIRS(2);
     else KDE_PAIRS(3);
@@ -1030,7 +1033,7 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
         if (!ar.ok) KDE_FAIL(PISA_HIP_ERR_NOMEM);
         std::vector<int32_t> h_starts;
         std::vector<uint64_t> h_keys;
-        KDE_TRY(query_blocks(keys_b, n, 1, temp, temp_bytes, flags, starts, d_count, head_keys, blocks, s,
+        KDE_TRY(query_blocks(keys_b, n, 1, Q_CHUNK, temp, temp_bytes, flags, starts, d_count, head_keys, blocks, s,
                              &h_starts, &h_keys));
         const int n_blocks = (int)blocks.size();
         const int n_split = pick_split(n_blocks);
@@ -1078,7 +1081,7 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
             KDE_TRY(check_hip(hipGetLastError(), "kde hermite kernels"));
             k->n_dense = nd;
         } else {
-            KDE_TRY(launch_pairs<false>(k, d_blocks, n_blocks, n_split, k->ys, n, part, s));
+            KDE_TRY((launch_pairs<false, Q_PER_THREAD>(k, d_blocks, n_blocks, n_split, k->ys, n, part, s)));
         }
         if (n_split > 1)
             hipLaunchKernelGGL(kde_combine_kernel, dim3(nb), dim3(256), 0, s, part, n_split, n,
@@ -1117,7 +1120,7 @@ PISA_API int64_t pisa_hip_kde_eval_workspace_bytes(const pisa_hip_kde *k, int64_
     const int64_t m = n_qry;
     size_t total = 2 * (size_t)k->dim * m * 8 + 2 * (size_t)m * 8 + 2 * (size_t)m * 4 + (size_t)m +
                    (size_t)m * 4 + (size_t)m * 8 + split_bytes(m) + (size_t)m * 8 + sort_temp_bytes(m) +
-                   ((size_t)m / Q_CHUNK + (size_t)std::min<int64_t>(m, 1 << 22) + 16) * sizeof(KdeBlock);
+                   ((size_t)m / 128 + (size_t)std::min<int64_t>(m, 1 << 22) + 16) * sizeof(KdeBlock);
     return (int64_t)(total + 64 * 256);
 }
 
@@ -1130,12 +1133,20 @@ PISA_API int pisa_hip_kde_evaluate(pisa_hip_kde *k, const double *d_qry, int64_t
     Arena ar(d_work, (size_t)work_bytes);
     const int dim = k->dim;
     const KdeGeom &g = k->g;
-    // tile size: at least ~128 queries per tile if the queries cover the source grid evenly
+    // Tile size (cells per side).  A tile's queries are cut into equal workgroups of <= 256 (one
+    // query per thread); per query the cost is ~ (cells within reach of the tile) / (share of the
+    // 256 lanes in use).  Assumes the queries cover the source grid evenly (a map's bin centres).
     int tile = 1;
-    {
+    if (g.rcut2 > 0.0) {
         const double per_cell = (double)m / (double)k->n_cells;
-        while (tile < 64 && per_cell * pow((double)tile, dim) < 128.0) tile *= 2;
-        if (!(g.rcut2 > 0.0)) tile = 1;   // one cell holds everything
+        const double reach = 1.5 * sqrt(g.rcut2) * g.inv_cell;
+        double best = INFINITY;
+        for (int t = 1; t <= 64; t++) {
+            const double cnt = per_cell * pow((double)t, dim);
+            const double util = cnt / (KDE_THREADS * ceil(cnt / KDE_THREADS));
+            const double cost = pow(t + 2.0 * reach, dim) / util;
+            if (cost < best) { best = cost; tile = t; }
+        }
     }
     double *qy = ar.take<double>((size_t)dim * m), *qys = ar.take<double>((size_t)dim * m);
     uint64_t *keys_a = ar.take<uint64_t>(m), *keys_b = ar.take<uint64_t>(m);
@@ -1155,7 +1166,7 @@ PISA_API int pisa_hip_kde_evaluate(pisa_hip_kde *k, const double *d_qry, int64_t
           (double *)nullptr);
     PISA_CHECK_LAUNCH("kde evaluate setup");
     std::vector<KdeBlock> blocks;
-    int rc = query_blocks(keys_b, m, tile, temp, temp_bytes, flags, starts, d_count, head_keys, blocks, s);
+    int rc = query_blocks(keys_b, m, tile, KDE_THREADS, temp, temp_bytes, flags, starts, d_count, head_keys, blocks, s);
     if (rc != PISA_HIP_OK) return rc;
     const int n_blocks = (int)blocks.size();
     const int n_split = pick_split(n_blocks);
@@ -1164,7 +1175,7 @@ PISA_API int pisa_hip_kde_evaluate(pisa_hip_kde *k, const double *d_qry, int64_t
     if (!ar.ok) return PISA_HIP_ERR_NOMEM;
     PISA_TRY_HIP(hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(KdeBlock),
                                 hipMemcpyHostToDevice, s));
-    rc = launch_pairs<true>(k, d_blocks, n_blocks, n_split, qys, m, part, s);
+    rc = launch_pairs<true, 1>(k, d_blocks, n_blocks, n_split, qys, m, part, s);
     if (rc != PISA_HIP_OK) return rc;
     hipLaunchKernelGGL(kde_combine_kernel, dim3(nb), dim3(256), 0, s, part, n_split, m, idx_b, d_out);
     PISA_CHECK_LAUNCH("kde_combine_kernel");

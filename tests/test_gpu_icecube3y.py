@@ -43,6 +43,52 @@ def test_muon_template_and_data_cfgs_unmodified():
     np.testing.assert_array_equal(dm[0].hist.ravel(), _release_table("data")["count"].values)
 
 
+def _oracle_event_weights(oracle, pipe, mc, names, barr, theta23_deg, nc_norm):
+    """the reference chain (honda flux on the grid -> Barr systematics -> prob3 on the grid ->
+    lookups -> osc * aeff reweighting) with the oracle, per container: (weights, [ln reco_E, reco_cz, pid])"""
+    from oracle import flux_oracle
+    from pisa_amd.utils.resources import find_resource
+
+    cm = pipe["prob3"].calc_mode
+    e_n = cm["true_energy"].weighted_centers.m_as("GeV")
+    cz_n = cm["true_coszen"].weighted_centers.magnitude
+    n_e, n_cz = len(e_n), len(cz_n)
+    splines = flux_oracle.load_2d_honda_table(find_resource("flux/honda-2015-spl-solmin-aa.d"))
+    nom = {p: flux_oracle.grid_flux(e_n, cz_n, splines[p]).ravel() for p in ("nue", "numu", "nuebar", "numubar")}
+    nu_nom = np.stack([nom["nue"], nom["numu"]], axis=1)
+    nubar_nom = np.stack([nom["nuebar"], nom["numubar"]], axis=1)
+    ee, cc = np.repeat(e_n, n_cz), np.tile(cz_n, n_e)
+    flux_grid = {s: oracle.barr_simple(ee, cc, nu_nom, nubar_nom, s, *barr) for s in (1, -1)}
+    prem = np.loadtxt(find_resource("osc/PREM_12layer.dat"))
+    lay = oracle.Layers(prem, 2.0, 20.0)
+    lay.setElecFrac(0.4656, 0.4656, 0.4957)
+    lay.calcLayers(cz_n)
+    mix = oracle.mix_matrix(np.deg2rad(33.48), np.deg2rad(8.5), np.deg2rad(theta23_deg), 0.0)
+    dm = oracle.dm_matrix(7.5e-5, 2.457e-3)
+    zero = np.zeros((3, 3))
+    prob = {s: oracle.propagate_array(dm, mix, np.diag([1.0, 0, 0]).astype(complex), -1, zero.astype(complex),
+                                       zero, s, ee, np.tile(lay.density, (n_e, 1)), np.tile(lay.distance, (n_e, 1)))
+            for s in (1, -1)}
+    lo, hi = cm["true_energy"].domain.m_as("GeV")
+    gmin, gmax, gnb = [np.log(lo), -1.0], [np.log(hi), 1.0], [n_e, n_cz]
+    out = {}
+    for name in names:
+        nubar = -1 if "bar" in name else 1
+        flav = 0 if "nue" in name else (1 if "numu" in name else 2)
+        sel = (mc["pdg"] == nubar * (12 + 2 * flav)) & ((mc["type"] >= 1) if "cc" in name else (mc["type"] == 0))
+        ev = mc[sel]
+        e, cz = ev["true_energy"].values, ev["true_coszen"].values
+        coords = [np.log(e), cz]
+        flux = np.stack([oracle.lookup_regular(coords, np.ascontiguousarray(flux_grid[nubar][:, k]), gmin, gmax, gnb)
+                         for k in (0, 1)], axis=1)
+        pe = oracle.lookup_regular(coords, np.ascontiguousarray(prob[nubar][:, 0, flav]), gmin, gmax, gnb)
+        pmu = oracle.lookup_regular(coords, np.ascontiguousarray(prob[nubar][:, 1, flav]), gmin, gmax, gnb)
+        scale = LIVETIME_S * (nc_norm if "nc" in name else 1.0)  # aeff.py:78-86 (nu_nc_norm)
+        w = oracle.reweight(np.ones(len(ev)), flux, pe, pmu, ev["weight"].values, scale)
+        out[name] = (w, [np.log(ev["reco_energy"].values), ev["reco_coszen"].values, ev["pid"].values])
+    return out
+
+
 def test_neutrino_cfg_unmodified_vs_oracle(oracle, tmp_path, monkeypatch):
     from oracle import flux_oracle
     from pisa_amd.core.pipeline import Pipeline
@@ -68,45 +114,10 @@ def test_neutrino_cfg_unmodified_vs_oracle(oracle, tmp_path, monkeypatch):
 
     # ---------------- oracle chain on the same file
     mc = pd.read_csv(os.path.join(str(tmp_path), "events/IceCube_3y_oscillations/neutrino_mc.csv.bz2"))
-    cm = pipe["prob3"].calc_mode
-    e_n = cm["true_energy"].weighted_centers.m_as("GeV")
-    cz_n = cm["true_coszen"].weighted_centers.magnitude
-    n_e, n_cz = len(e_n), len(cz_n)
-    splines = flux_oracle.load_2d_honda_table(find_resource("flux/honda-2015-spl-solmin-aa.d"))
-    nom = {p: flux_oracle.grid_flux(e_n, cz_n, splines[p]).ravel() for p in ("nue", "numu", "nuebar", "numubar")}
-    nu_nom = np.stack([nom["nue"], nom["numu"]], axis=1)
-    nubar_nom = np.stack([nom["nuebar"], nom["numubar"]], axis=1)
-    ee, cc = np.repeat(e_n, n_cz), np.tile(cz_n, n_e)
-    barr = (1.02, 1.0, 0.03, 0.0, 0.0)  # nue_numu, nu_nubar, delta_index, uphor, nu_nubar shape
-    flux_grid = {s: oracle.barr_simple(ee, cc, nu_nom, nubar_nom, s, *barr) for s in (1, -1)}
-    prem = np.loadtxt(find_resource("osc/PREM_12layer.dat"))
-    lay = oracle.Layers(prem, 2.0, 20.0)
-    lay.setElecFrac(0.4656, 0.4656, 0.4957)
-    lay.calcLayers(cz_n)
-    mix = oracle.mix_matrix(np.deg2rad(33.48), np.deg2rad(8.5), np.deg2rad(46.0), 0.0)
-    dm = oracle.dm_matrix(7.5e-5, 2.457e-3)
-    zero = np.zeros((3, 3))
-    prob = {s: oracle.propagate_array(dm, mix, np.diag([1.0, 0, 0]).astype(complex), -1, zero.astype(complex),
-                                       zero, s, ee, np.tile(lay.density, (n_e, 1)), np.tile(lay.distance, (n_e, 1)))
-            for s in (1, -1)}
-    lo, hi = cm["true_energy"].domain.m_as("GeV")
-    gmin, gmax, gnb = [np.log(lo), -1.0], [np.log(hi), 1.0], [n_e, n_cz]
     omin, omax, onb = [np.log(5.62341325), -1.0, -0.5], [np.log(56.23413252), 1.0, 1.5], [8, 8, 2]
     hists, errs = {}, {}
-    for name in maps.names:
-        nubar = -1 if "bar" in name else 1
-        flav = 0 if "nue" in name else (1 if "numu" in name else 2)
-        sel = (mc["pdg"] == nubar * (12 + 2 * flav)) & ((mc["type"] >= 1) if "cc" in name else (mc["type"] == 0))
-        ev = mc[sel]
-        e, cz = ev["true_energy"].values, ev["true_coszen"].values
-        coords = [np.log(e), cz]
-        flux = np.stack([oracle.lookup_regular(coords, np.ascontiguousarray(flux_grid[nubar][:, k]), gmin, gmax, gnb)
-                         for k in (0, 1)], axis=1)
-        pe = oracle.lookup_regular(coords, np.ascontiguousarray(prob[nubar][:, 0, flav]), gmin, gmax, gnb)
-        pmu = oracle.lookup_regular(coords, np.ascontiguousarray(prob[nubar][:, 1, flav]), gmin, gmax, gnb)
-        scale = LIVETIME_S * (1.1 if "nc" in name else 1.0)  # aeff.py:78-86 (nu_nc_norm)
-        w = oracle.reweight(np.ones(len(ev)), flux, pe, pmu, ev["weight"].values, scale)
-        sample = [np.log(ev["reco_energy"].values), ev["reco_coszen"].values, ev["pid"].values]
+    for name, (w, sample) in _oracle_event_weights(oracle, pipe, mc, maps.names, barr=(1.02, 1.0, 0.03, 0.0, 0.0),
+                                                   theta23_deg=46.0, nc_norm=1.1).items():
         hists[name] = oracle.histogram_regular(sample, w, omin, omax, onb)
         errs[name] = np.sqrt(oracle.histogram_regular(sample, w * w, omin, omax, onb))
     groups = {"nue_cc": "nue_cc", "nuebar_cc": "nue_cc", "numu_cc": "numu_cc", "numubar_cc": "numu_cc",
@@ -156,3 +167,66 @@ def test_published_analysis_template_and_metrics(oracle, tmp_path, monkeypatch):
         got = data.metric_total(expected_values=total, metric=kind)
         _, ref = oracle.metric(kind, data.hist.ravel(), total.hist.ravel(), (total.std_devs ** 2).ravel())
         np.testing.assert_allclose(got, ref, rtol=1e-10, err_msg=kind)
+
+
+def test_neutrino_cfg_with_kde_stage_vs_oracle(oracle, tmp_path, monkeypatch):
+    """config C3 in its real shape: the published 3-year neutrino pipeline with `utils.kde` in place
+    of `utils.hist` (csv_loader -> honda_ip -> barr_simple -> prob3 -> aeff -> kde -> hypersurfaces).
+    The KDE maps of the product (cell-list cut-off + Hermite pilot on the GPU) against the oracle's
+    plain double-loop KDE of the oracle chain's event weights.  KDE core: parity unpinned."""
+    from collections import OrderedDict
+
+    from oracle import kde_oracle
+    from pisa_amd.core.config_parser import parse_pipeline_config
+    from pisa_amd.core.pipeline import Pipeline
+    from pisa_amd.core.units import ureg
+    from pisa_amd.utils.resources import find_resource
+
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "make_synthetic_3y_mc.py"),
+                           str(tmp_path), "60000", "5"])
+    monkeypatch.setenv("PISA_RESOURCES", str(tmp_path))
+    cfg = parse_pipeline_config("settings/pipeline/IceCube_3y_neutrinos.cfg")
+    cfg2 = OrderedDict()
+    for k, v in cfg.items():
+        if k == ("utils", "hist"):
+            cfg2[("utils", "kde")] = OrderedDict(calc_mode="events", apply_mode=v["apply_mode"], oversample=5,
+                                                 bw_method="silverman", alpha=0.1, coszen_reflection=0.25)
+        else:
+            cfg2[k] = v
+    cfg2[("discr_sys", "hypersurfaces")]["error_method"] = None
+    cfg2["pipeline"]["output_key"] = "weights"
+    pipe = Pipeline(cfg2)
+    assert pipe.service_names[5] == "kde"
+    pipe.params.theta23.value = 47.0 * ureg.degree
+    pipe.params.delta_index.value = -0.04 * ureg.dimensionless
+    maps = pipe.get_outputs()
+    stats = pipe["kde"].stats
+    assert 0 < stats["pairs_pilot"] + stats["pairs_eval"] < 0.5 * stats["all_pairs"]
+
+    mc = pd.read_csv(os.path.join(str(tmp_path), "events/IceCube_3y_oscillations/neutrino_mc.csv.bz2"))
+    ob = pipe.output_binning
+    dims = [(d.name, np.log(d.edge_magnitudes) if d.is_log else d.edge_magnitudes, False) for d in ob]
+    assert [d[0] for d in dims] == ["reco_energy", "reco_coszen", "pid"]
+    groups = {"nue_cc": "nue_cc", "nuebar_cc": "nue_cc", "numu_cc": "numu_cc", "numubar_cc": "numu_cc",
+              "nutau_cc": "nutau_cc", "nutaubar_cc": "nutau_cc"}
+    order = ["ice_absorption", "ice_scattering", "opt_eff_headon", "opt_eff_lateral", "opt_eff_overall"]
+    nominal = {p: pipe.params[p].value.m for p in order}
+    ow = _oracle_event_weights(oracle, pipe, mc, maps.names, barr=(1.0, 1.0, -0.04, 0.0, 0.0), theta23_deg=47.0,
+                               nc_norm=1.0)
+    tot_k = tot_w = 0.0
+    for m in maps:
+        w, sample = ow[m.name]
+        want = kde_oracle.kde_histogramdd(np.stack(sample).T, dims, w, bw_method="silverman", adaptive=True,
+                                          alpha=0.1, coszen_reflection=0.25, coszen_name="reco_coszen",
+                                          oversample=5)
+        t = pd.read_csv(find_resource("events/IceCube_3y_oscillations/hyperplanes_%s.csv.bz2"
+                                      % groups.get(m.name, "all_nc")))
+        scales = t["offset"].values.copy()
+        for p in order:
+            scales += t[p].values * nominal[p]
+        want = np.clip(want.ravel() * scales, 0, np.inf)
+        np.testing.assert_allclose(m.hist.ravel(), want, rtol=1e-9, atol=1e-12 * want.max(), err_msg=m.name)
+        inside = ((sample[0] >= dims[0][1][0]) & (sample[0] < dims[0][1][-1]))
+        tot_k += m.hist.sum()
+        tot_w += w[inside].sum()
+    assert abs(tot_k / tot_w - 1.0) < 0.15
