@@ -111,6 +111,9 @@ def regularized(binning, get_column):
 
 
 class Container:
+    # counts every store / mark_changed of every container of the process: lets an evaluation
+    # plan (core/fastplan.py) notice with one comparison that SOMEBODY wrote a container
+    clock = 0
     valid_translation_modes = ("average", "sum")
     sum_mode_keys = ()
     array_representations = ("events", "log_events")
@@ -252,6 +255,7 @@ class Container:
 
     def mark_changed(self, key):
         self._version[key] += 1
+        Container.clock += 1
         self._lazy.pop(key, None)
         for rep in self.validity[key]:
             self.validity[key][rep] = False
@@ -264,6 +268,7 @@ class Container:
 
     def _invalidate_others(self, key):
         self._version[key] += 1
+        Container.clock += 1
         self._lazy.pop(key, None)
         for rep in self.validity[key]:
             self.validity[key][rep] = False

@@ -1,0 +1,183 @@
+"""Replay of a pipeline evaluation without the per-container Stage bookkeeping.
+
+`Pipeline.get_outputs()` of the reference runs every stage's `compute()` / `apply()` on host
+arrays (pisa/core/pipeline.py:537-558, stage.py:536-586).  This build's stages do the same through
+device columns and deferred operations -- ~6 000 Python calls, 0.8 ms per evaluation -- although,
+for the chain  loader -> [flux ...] -> osc.prob3 (2-D calc grid) -> aeff.aeff -> utils.hist,  an
+evaluation in which only oscillation / aeff parameters moved is three kernel launches.
+
+After one ordinary evaluation that took the fused path, `FastPlan` replays exactly those
+launches: it compares the parameter change counters (`Param.clock`, `Param._ver`) with what it
+saw last, rebuilds the prob3 matrices through the stage's own `_matrices()`, refreshes the aeff
+scales through the stage's own `scale_for()`, launches the planned prob3 kernels and the fused
+kernel, and hands out device-backed Maps (`DeviceMapBlock`).  Anything else -- a flux or loader
+parameter moved, a Ye value moved, another output key or binning is asked for, profiling is on,
+somebody reads `pipeline.data` -- goes through the ordinary Stage protocol, which stays the
+source of truth (the plan is rebuilt afterwards).  The bypassed stages' compute memos are
+invalidated, so the ordinary path never trusts tables the plan has overwritten.
+"""
+import ctypes as C
+import weakref
+
+import numpy as np
+
+from pisa_amd import _lib
+from pisa_amd import kernels as K
+from pisa_amd.core.container import Container
+from pisa_amd.core.map import Map, MapSet
+from pisa_amd.core.param import Param
+
+__all__ = ["FastPlan", "DeviceMapBlock"]
+
+
+class DeviceMapBlock:
+    """The maps (and sum of squared weights) of all containers of ONE evaluation, still in HBM."""
+
+    def __init__(self, engine, with_errors):
+        self.engine = engine
+        self.with_errors = with_errors
+        self.full = (1 << len(engine.cont)) - 1
+        self._host = None
+        self._live = True   # the engine still holds this evaluation
+
+    def detach(self):
+        """the engine is about to start another evaluation"""
+        if self._host is None and self._live:
+            self._fetch()
+        self._live = False
+
+    def _fetch(self):
+        eng = self.engine
+        hist, sumw2 = eng.finalize()
+        if self.with_errors:
+            import torch
+
+            both = torch.stack((hist, sumw2)).cpu().numpy()
+            self._host = (both[0], both[1])
+        else:
+            self._host = (hist.cpu().numpy(), None)
+        eng.check_status()
+
+    def host_sum(self, mask, shape):
+        if self._host is None:
+            if not self._live:
+                raise RuntimeError("device-backed maps outlived their evaluation")
+            self._fetch()
+        hist, sumw2 = self._host
+        rows = [i for i in range(hist.shape[0]) if mask >> i & 1]
+        h = hist[rows[0]].copy()
+        v = None if sumw2 is None else sumw2[rows[0]].copy()
+        for i in rows[1:]:       # index order = the order in which sum() adds Maps
+            h += hist[i]
+            if v is not None:
+                v += sumw2[i]
+        return h.reshape(shape), None if v is None else v.reshape(shape)
+
+    def metric(self, mask, kind, data_hist):
+        """metric of the TOTAL template against `data_hist` on the device, or None if this block
+        cannot provide it (partial sum, already fetched, no longer the engine's evaluation)"""
+        if mask != self.full or not self._live or self._host is not None:
+            return None
+        if kind == "mod_chi2" and not self.with_errors:
+            return None
+        eng = self.engine
+        eng.set_data_cached(np.ascontiguousarray(data_hist, dtype=np.float64).ravel())
+        val = eng.tail_host(kind)
+        if val != val:   # NaN: a negative input sets the status word too (stats.py:231-240 raises)
+            st = eng.metric_status_host()
+            if st != 0:
+                _lib.check(st)
+        return val
+
+
+class FastPlan:
+    @classmethod
+    def build(cls, pipeline):
+        """a plan for `pipeline`, or None if its last evaluation did not have the replayable shape"""
+        stages = pipeline._stages
+        if not stages or pipeline._profile:
+            return None
+        hist = stages[-1]
+        if hist.service_name != "hist" or not getattr(hist, "fused_last_eval", False):
+            return None
+        osc = [s for s in stages if s.service_name == "prob3"]
+        aeff = [s for s in stages if s.service_name == "aeff" and s.stage_name == "aeff"]
+        if len(osc) != 1 or len(aeff) != 1 or osc[0].grid is None or hist._engine is None:
+            return None
+        if hist._engine.world_size > 1 and hist._engine.n_bins * len(hist._engine.cont) > K.FINALIZE_METRIC_MAX:
+            return None
+        key = pipeline.output_key
+        if key not in ("weights", ("weights", "errors")):
+            return None
+        if key != "weights" and hist.error_method != "sumw2":
+            return None
+        return cls(pipeline, osc[0], aeff[0], hist)
+
+    def __init__(self, pipeline, osc, aeff, hist):
+        self.pipeline, self.osc, self.aeff, self.hist = pipeline, osc, aeff, hist
+        self.engine = hist._engine
+        self.with_errors = pipeline.output_key != "weights"
+        self.binning = pipeline.output_binning
+        self.names = [c.name for c in hist.data.containers]
+        self.stage_params = [(s, list(s.params)) for s in pipeline._stages]
+        self.seen = [[p._ver for p in ps] for _, ps in self.stage_params]
+        self.ids = [[id(p) for p in ps] for _, ps in self.stage_params]
+        self.clock = Param.clock
+        self.container_clock = Container.clock
+        self.ye = (osc.YeI, osc.YeO, osc.YeM)
+        g = osc.grid
+        self._osc_args = None
+        self._grid = g
+        self._lib = _lib.lib()
+
+    def _changed(self):
+        """stages with a moved parameter; None if a stage's parameter OBJECTS were exchanged"""
+        out = []
+        for k, (stage, _) in enumerate(self.stage_params):
+            cur = list(stage.params)
+            if [id(p) for p in cur] != self.ids[k]:
+                return None
+            vers = [p._ver for p in cur]
+            if vers != self.seen[k]:
+                out.append(stage)
+                self.seen[k] = vers
+        return out
+
+    def run(self):
+        """device-backed output MapSet, or None: take the ordinary path"""
+        osc, eng = self.osc, self.engine
+        if self.hist._engine is not eng or osc.pepmu is None:
+            return None
+        if Container.clock != self.container_clock:
+            return None   # somebody wrote a container (e.g. edited a flux column in place)
+        if Param.clock != self.clock:
+            changed = self._changed()
+            if changed is None or any(s is not osc and s is not self.aeff for s in changed):
+                return None
+            self.clock = Param.clock
+            if osc in changed:
+                p = osc.params
+                ye = (p.YeI.value.m_as("dimensionless"), p.YeO.value.m_as("dimensionless"),
+                      p.YeM.value.m_as("dimensionless"))
+                if ye != self.ye:
+                    return None          # new layers, new plan: ordinary path
+                params = osc._matrices()
+                osc.param_hash = None    # its tables no longer belong to the memoised values
+                a = self._osc_args
+                if a is None or a[0] is not osc.pepmu:
+                    g = osc.grid
+                    a = self._osc_args = (
+                        osc.pepmu, g["plan"].handle, C.c_void_p(g["energy"].data_ptr()), g["energy"].numel(),
+                        1 if g["e_major"] else 0, C.c_void_p(osc.prob_tables[0].data_ptr()),
+                        C.c_void_p(osc.prob_tables[1].data_ptr()), C.c_void_p(osc.pepmu.data_ptr()))
+                _lib.check(self._lib.pisa_hip_prob3_grid_planned(
+                    C.byref(params), a[1], a[2], a[3], a[4], a[5], a[6], a[7], K._stream()))
+            if self.aeff in changed:
+                for name in self.names:
+                    eng.set_scale(name, self.aeff.scale_for(name))
+        eng.front(osc.pepmu)
+        block = DeviceMapBlock(eng, self.with_errors)
+        eng._out_block = weakref.ref(block)
+        self.pipeline._containers_stale = True
+        maps = [Map.device_backed(n, self.binning, block, 1 << i) for i, n in enumerate(self.names)]
+        return MapSet(maps, name=self.pipeline.name)

@@ -21,6 +21,12 @@ ALL_METRICS = ("llh", "poisson_llh", "chi2", "mod_chi2")
 
 
 class Map:
+    """A Map may be *device backed*: `_lazy = (block, mask)` names rows of a table of maps that
+    still lives in HBM (`core/fastplan.py:DeviceMapBlock`); its host arrays are fetched -- for
+    all maps of the block in ONE transfer -- the first time anything asks for them.  Sums of
+    such maps stay device backed, and `metric` of a device-backed total runs on the device
+    without the maps ever travelling to the host."""
+
     def __init__(self, name, hist, binning, error_hist=None, hash=None, parent_indexer=None,
                  tex=None, full_comparison=False):
         if not isinstance(binning, MultiDimBinning):
@@ -32,15 +38,50 @@ class Map:
         self.name = name
         self.tex = tex
         self.binning = binning
-        self._hist = hist
-        self._var = None
+        self._lazy = None
+        self._h = hist
+        self._v = None
         if error_hist is not None:
             self.set_errors(error_hist)
+
+    @classmethod
+    def device_backed(cls, name, binning, block, mask):
+        m = cls.__new__(cls)
+        m.name, m.tex, m.binning = name, None, binning
+        m._lazy, m._h, m._v = (block, mask), None, None
+        return m
+
+    def _fetch(self):
+        block, mask = self._lazy
+        self._h, self._v = block.host_sum(mask, self.binning.shape)
+        self._lazy = None
+
+    @property
+    def _hist(self):
+        if self._lazy is not None:
+            self._fetch()
+        return self._h
+
+    @_hist.setter
+    def _hist(self, h):
+        self._h = h
+
+    @property
+    def _var(self):
+        if self._lazy is not None:
+            self._fetch()
+        return self._v
+
+    @_var.setter
+    def _var(self, v):
+        if self._lazy is not None:
+            self._fetch()
+        self._v = v
 
     # -- values -------------------------------------------------------------
     hist = property(lambda self: self._hist)
     nominal_values = hist
-    shape = property(lambda self: self._hist.shape)
+    shape = property(lambda self: self.binning.shape)
 
     @property
     def std_devs(self):
@@ -69,6 +110,11 @@ class Map:
 
     def __add__(self, other):
         if isinstance(other, Map):
+            if (self._lazy is not None and other._lazy is not None and self._lazy[0] is other._lazy[0]
+                    and not (self._lazy[1] & other._lazy[1])):
+                # rows of one device table: the sum stays on the device
+                return Map.device_backed("(%s + %s)" % (self.name, other.name), self.binning,
+                                         self._lazy[0], self._lazy[1] | other._lazy[1])
             assert other.binning == self.binning
             var = None
             if self._var is not None or other._var is not None:
@@ -133,6 +179,14 @@ class Map:
 
         if isinstance(expected_values, MapSet):
             expected_values = sum(expected_values)
+        if isinstance(expected_values, Map) and expected_values._lazy is not None and not binned:
+            block, mask = expected_values._lazy
+            if expected_values.binning.shape != self._hist.shape:
+                raise ValueError("Shape mismatch: actual %s, expected %s"
+                                 % (self._hist.shape, expected_values.binning.shape))
+            val = block.metric(mask, metric, self._hist)
+            if val is not None:
+                return val
         if isinstance(expected_values, Map):
             exp_hist, exp_var = expected_values.hist, expected_values._var
         else:
@@ -163,6 +217,8 @@ class Map:
         return self.metric(expected_values, "mod_chi2", binned)
 
     def __repr__(self):
+        if self._lazy is not None:
+            return "Map(name=%r, shape=%s, on device)" % (self.name, self.shape)
         return "Map(name=%r, shape=%s, sum=%.6g)" % (self.name, self.shape, self._hist.sum())
 
 

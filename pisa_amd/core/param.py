@@ -83,7 +83,13 @@ class Prior:
 
 
 class Param:
-    """One named quantity with prior, range and fixed flag (param.py:60-330)."""
+    """One named quantity with prior, range and fixed flag (param.py:60-330).
+
+    `Param.clock` counts value changes of ALL params of the process and `_ver` those of one
+    param: evaluation plans that skip the per-stage hashing (core/fastplan.py) compare these
+    instead of re-deriving `values_hash` (a value set to what it already was counts as a change)."""
+
+    clock = 0
 
     def __init__(self, name, value, prior=None, range=None, is_fixed=True, unique_id=None,
                  is_discrete=False, nominal_value=None, tex=None, help="", scales_as_log=False):
@@ -94,6 +100,7 @@ class Param:
         self.is_fixed = bool(is_fixed)
         self.is_discrete = bool(is_discrete)
         self.scales_as_log = bool(scales_as_log)
+        self._ver = 0
         self._value = _as_quantity(value)
         self._units = self._value.units if isinstance(self._value, Quantity) else None
         self.prior = prior if (prior is None or isinstance(prior, Prior)) else Prior(**prior)
@@ -117,6 +124,11 @@ class Param:
             val = val.to(self._units)
         self.validate_value(val)
         self._value = val
+        self._touch()
+
+    def _touch(self):
+        self._ver += 1
+        Param.clock += 1
 
     def validate_value(self, val):
         if self._range is not None and isinstance(val, Quantity):
@@ -164,6 +176,7 @@ class Param:
 
     def reset(self):
         self._value = self._nominal_value
+        self._touch()
 
     def set_nominal_to_current_value(self):
         self._nominal_value = self._value
@@ -202,6 +215,7 @@ class Param:
             v = r0 + (r1 - r0) * rval
         v = min(max(v, min(r0, r1)), max(r0, r1))
         self._value = Quantity(v, self._units)
+        self._touch()
 
     def prior_penalty(self, metric):
         metric = metric.strip().lower()

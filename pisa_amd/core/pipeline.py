@@ -31,10 +31,13 @@ class Pipeline:
                             "or OrderedDict" % type(config).__name__)
         self.name = config["pipeline"]["name"]
         self.detector_name = config["pipeline"].get("detector_name")
-        self.data = ContainerSet(self.name)
-        self.data["output_binning"] = config["pipeline"]["output_binning"]
+        self._data = ContainerSet(self.name)
+        self._data["output_binning"] = config["pipeline"]["output_binning"]
         self.output_key = config["pipeline"]["output_key"]
         self._profile = profile
+        self._plan = None               # core/fastplan.py: replay of the fused evaluation
+        self._containers_stale = False  # the plan ran since the containers were last written
+        self.fast_path = True
         self._setup_times, self._run_times, self._get_outputs_times = [], [], []
         self._stages = []
         self._config = config
@@ -87,16 +90,38 @@ class Pipeline:
     stage_names = property(lambda self: [s.stage_name for s in self._stages])
     service_names = property(lambda self: [s.service_name for s in self._stages])
     config = property(lambda self: self._config)
-    profile = property(lambda self: self._profile)
+
+    @property
+    def data(self):
+        """the ContainerSet; if evaluations were replayed by the fast plan since the stages last
+        wrote it, the stages are run first so that a reader sees the current parameters' data"""
+        if self._containers_stale:
+            self.run()
+        return self._data
+
+    @data.setter
+    def data(self, value):
+        self._data = value
 
     @property
     def output_binning(self):
-        return self.data["output_binning"]
+        return self._data["output_binning"]
 
     @output_binning.setter
     def output_binning(self, binning):
-        self.data["output_binning"] = binning
+        self._data["output_binning"] = binning
         self.setup()
+
+    @property
+    def profile(self):
+        return self._profile
+
+    @profile.setter
+    def profile(self, value):
+        self._profile = bool(value)
+        self._plan = None
+        for s in self._stages:
+            s.profile = self._profile
 
     # -- params ----------------------------------------------------------------------
     @property
@@ -131,17 +156,19 @@ class Pipeline:
     # -- execution --------------------------------------------------------------------
     def setup(self):
         t0 = time()
-        output_binning = self.data["output_binning"]
-        self.data = ContainerSet(self.name)
-        self.data["output_binning"] = output_binning
+        self._plan, self._containers_stale = None, False
+        output_binning = self._data["output_binning"]
+        self._data = ContainerSet(self.name)
+        self._data["output_binning"] = output_binning
         for s in self._stages:
-            s.data = self.data
+            s.data = self._data
             s.setup()
         if self._profile:
             self._setup_times.append(time() - t0)
 
     def run(self):
         t0 = time()
+        self._containers_stale = False
         for s in self._stages:
             s.run()
         if self._profile:
@@ -149,18 +176,29 @@ class Pipeline:
 
     def get_outputs(self, output_binning=None, output_key=None):
         t0 = time()
+        default = output_binning is None and output_key is None
+        if default and self.fast_path and not self._profile:
+            if self._plan is not None:
+                outputs = self._plan.run()
+                if outputs is not None:
+                    return outputs
+                self._plan = None
         self.run()
         if output_binning is None:
             output_binning = self.output_binning
         if output_key is None:
             output_key = self.output_key
         assert isinstance(output_binning, MultiDimBinning)
-        self.data.representation = output_binning
+        self._data.representation = output_binning
         if isinstance(output_key, tuple):
             assert len(output_key) == 2
-            outputs = self.data.get_mapset(output_key[0], error=output_key[1])
+            outputs = self._data.get_mapset(output_key[0], error=output_key[1])
         else:
-            outputs = self.data.get_mapset(output_key)
+            outputs = self._data.get_mapset(output_key)
+        if default and self.fast_path and not self._profile:
+            from pisa_amd.core.fastplan import FastPlan
+
+            self._plan = FastPlan.build(self)
         if self._profile:
             self._get_outputs_times.append(time() - t0)
         return outputs

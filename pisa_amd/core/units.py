@@ -321,12 +321,17 @@ class UnitRegistry:
             return self._units["dimensionless"]
         if expr in self._units:
             return self._units[expr]
+        cache = self.__dict__.setdefault("_parsed", {})
+        hit = cache.get(expr)
+        if hit is not None:
+            return hit
         q = self.parse_expression(expr)
         if isinstance(q, Quantity):
-            return Unit(q.units.scale * float(q.magnitude), q.units.dims, expr)
-        if isinstance(q, Unit):
-            return q
-        return Unit(float(q), None, expr)
+            q = Unit(q.units.scale * float(q.magnitude), q.units.dims, expr)
+        elif not isinstance(q, Unit):
+            q = Unit(float(q), None, expr)
+        cache[expr] = q   # compound expressions ("eV**2", "g/cm**3") are parsed once
+        return q
 
     def parse_expression(self, expr):
         """Evaluate e.g. '2.5 * common_year', 'eV**2', 'g/cm**3', '1e-3 eV ** 2'."""

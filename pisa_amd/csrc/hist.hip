@@ -644,8 +644,11 @@ finalize_metric_kernel(long long *__restrict__ limbs, int n_cont, int n_bins,
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
         if (threadIdx.x == 0) {
             const bool chi2_zero = (kind == PISA_HIP_METRIC_CHI2) && s_flag[1] == 0;  // stats.py:160-161
-            total[0] = chi2_zero ? 0.0 : v;
-            if (mstatus && s_flag[0]) mstatus[0] = PISA_HIP_ERR_NEGATIVE;
+            // negative input (stats.py:231-240 raises): the value is NaN as well, so that a host
+            // that polls `total` in pinned memory needs to read the status word only then
+            const bool negative = mstatus && s_flag[0];
+            total[0] = negative ? __builtin_nan("") : (chi2_zero ? 0.0 : v);
+            if (negative) mstatus[0] = PISA_HIP_ERR_NEGATIVE;
         }
     }
 }

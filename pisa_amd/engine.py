@@ -374,6 +374,8 @@ class HotPathEngine:
         self._limbs_zero = self._maps_valid = False
         self._lean = None
         self.data = None
+        self._data_src = None
+        self._out_block = None   # weak reference to the device-backed maps handed out last
 
     def _up(self, a):
         t = K.to_device(a)
@@ -420,7 +422,17 @@ class HotPathEngine:
                          e_major=self.grid.energy_first, out_nu=self.prob_nu,
                          out_nubar=self.prob_nubar, out_pepmu=self.pepmu)
 
+    def _release_outputs(self):
+        """device-backed maps of the previous evaluation that are still referenced are brought
+        to the host before the next launch overwrites them"""
+        if self._out_block is not None:
+            b = self._out_block()
+            if b is not None:
+                b.detach()
+            self._out_block = None
+
     def accumulate(self, params=None):
+        self._release_outputs()
         if params is not None:
             self.compute_probs(params)
         K.reweight_hist(self._cont_arr, self.grid.binning, self.prob_nu, self.prob_nubar,
@@ -462,6 +474,71 @@ class HotPathEngine:
 
     def set_data(self, data_hist):
         self.data = K.to_device(np.asarray(data_hist, dtype=np.float64).ravel())
+        self._data_src = None
+
+    def set_data_cached(self, data_hist):
+        """`set_data` unless `data_hist` holds what was uploaded last (a fit loop compares every
+        template with the same data map)"""
+        src = self._data_src
+        if src is not None and src.shape == data_hist.shape and np.array_equal(src, data_hist):
+            return
+        self.set_data(data_hist)
+        self._data_src = np.array(data_hist, dtype=np.float64, copy=True)
+
+    # -- two-phase evaluation for callers that hand out maps before a metric is asked for ------
+    def front(self, tables=None):
+        """phase A: fused lookup + reweight + histogram (+ all-reduce) with the probability
+        tables of the caller; asynchronous.  Device-backed maps of the previous evaluation that
+        are still referenced are brought to the host first (the launch overwrites them)."""
+        self._release_outputs()
+        import ctypes as C
+
+        a = self._lean
+        if a is None or a.get("front_pepmu") is not tables:
+            lib = _lib.lib()
+            pep = tables if tables is not None else self.pepmu
+            a = self._lean = dict(
+                front_pepmu=tables, tabs=None, lib=lib, cont=self._cont_arr, n_cont=len(self._cont_arr),
+                nu=C.c_void_p(self.prob_nu.data_ptr()) if self.prob_nu is not None else None,
+                nubar=C.c_void_p(self.prob_nubar.data_ptr()) if self.prob_nubar is not None else None,
+                pepmu=C.c_void_p(pep.data_ptr()), grid=C.byref(self.grid.binning),
+                outb=C.byref(self.out_binning), limbs=C.c_void_p(self.ws.limbs.data_ptr()),
+                status=C.c_void_p(self.ws.status.data_ptr()), hist=C.c_void_p(self.ws.hist.data_ptr()),
+                sumw2=C.c_void_p(self.ws.sumw2.data_ptr()), data=None, data_t=None,
+                out=C.c_void_p(self.metric_host.data_ptr()),
+                mstatus=C.c_void_p(self.metric_status.data_ptr()), keep=pep)
+        lib = a["lib"]
+        fn = lib.pisa_hip_reweight_hist_acc if self._limbs_zero else lib.pisa_hip_reweight_hist
+        rc = fn(a["cont"], a["n_cont"], a["grid"], a["nu"], a["nubar"], a["pepmu"], a["outb"],
+                a["limbs"], a["status"], K._stream())
+        self._limbs_zero = self._maps_valid = False
+        _lib.check(rc)
+        self.allreduce()
+
+    def tail_host(self, kind):
+        """phase B: maps + metric against `self.data` of the accumulated limbs, value on the host"""
+        if (self.fused_tail and not self._maps_valid
+                and len(self.cont) * self.n_bins <= K.FINALIZE_METRIC_MAX):
+            import ctypes as C
+
+            a = self._lean
+            if a["data_t"] is not self.data:
+                a["data"], a["data_t"] = C.c_void_p(self.data.data_ptr()), self.data
+            h = self._metric_host_np
+            h[0] = np.nan
+            rc = a["lib"].pisa_hip_finalize_metric(a["limbs"], a["n_cont"], self.n_bins, a["hist"],
+                                                   a["sumw2"], K.METRIC_KIND[kind], a["data"], a["out"],
+                                                   a["status"], a["mstatus"], 1, K._stream())
+            self._limbs_zero = self._maps_valid = rc == 0
+            _lib.check(rc)
+            for _ in range(self.spin_wait):
+                v = h[0]
+                if v == v:
+                    return float(v)
+        else:
+            self._tail(kind, self.metric_host)
+        torch.cuda.current_stream().synchronize()
+        return float(self.metric_host[0])
 
     def metric(self, kind="llh"):
         return K.metric(kind, self.data, self.ws.hist, self.ws.sumw2, total_out=self.metric_out,
@@ -544,6 +621,7 @@ class HotPathEngine:
                 mstatus=C.c_void_p(self.metric_status.data_ptr()))
         if a["data_t"] is not self.data:  # new pseudo-data
             a["data"], a["data_t"] = C.c_void_p(self.data.data_ptr()), self.data
+        self._release_outputs()
         lib, s = a["lib"], K._stream()
         rc = lib.pisa_hip_prob3_grid_planned(C.byref(params), a["plan"], a["energy"], a["n_e"],
                                              a["e_major"], a["nu"], a["nubar"], a["pepmu"], s)
@@ -598,6 +676,13 @@ class HotPathEngine:
             self._tail(kind, out[k:k + 1])
         self.prob_nu, self.prob_nubar, self.pepmu = self._tables[(n - 1) % 2] if n else self._tables[0]
         return out
+
+    def metric_status_host(self):
+        """status word of the metric kernels (negative inputs) -- one 4-byte read"""
+        st = int(self.metric_status.item())
+        if st != 0:
+            self.metric_status.zero_()
+        return st
 
     def check_status(self):
         if int(self.ws.status.item()) != 0:

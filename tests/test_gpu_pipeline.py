@@ -200,3 +200,96 @@ def test_fit_with_reference_minimizer_settings_file():
                               minimizer_settings="settings/minimizer/slsqp_ftol1e-6_eps1e-4_maxiter1000.json")
     assert res.minimizer_metadata["success"], res.minimizer_metadata
     np.testing.assert_allclose(res.params.theta23.value.m_as("deg"), 45.2, atol=0.2)
+
+
+def _scan(pipe, fast, data, points):
+    pipe.fast_path = fast
+    pipe._plan = None
+    out = []
+    from pisa_amd.core.units import ureg
+
+    for t23, dm31, scale, didx in points:
+        pipe.params.theta23.value = t23 * ureg.degree
+        pipe.params.deltam31.value = dm31 * ureg.eV ** 2
+        pipe.params.aeff_scale.value = scale * ureg.dimensionless
+        pipe.params.delta_index.value = didx * ureg.dimensionless
+        ms = pipe.get_outputs()
+        llh = data.metric_total(expected_values=sum(ms), metric="llh")
+        chi = data.metric_total(expected_values=sum(ms), metric="mod_chi2")
+        out.append((llh, chi, [m.hist.copy() for m in ms], [m.std_devs.copy() for m in ms]))
+    return out
+
+
+def test_fast_plan_replays_the_stage_protocol_bit_for_bit():
+    """`Pipeline.get_outputs()` after the first fused evaluation replays three kernel launches
+    (core/fastplan.py) instead of running every stage over every container.  Same maps, errors
+    and metrics, bit for bit, as the ordinary Stage protocol -- for osc and aeff parameter moves
+    (replayed) and for flux parameter moves (which fall back to the stages)."""
+    from pisa_amd.core.pipeline import Pipeline
+
+    pipe = Pipeline("settings/pipeline/example_hip.cfg")
+    data = sum(pipe.get_outputs()).fluctuate("poisson", random_state=0)
+    points = [(42.3, 2.457e-3, 1.0, 0.0), (47.0, 2.6e-3, 1.0, 0.0), (47.0, 2.6e-3, 1.4, 0.0),
+              (44.0, 2.3e-3, 0.9, 0.0), (44.0, 2.3e-3, 0.9, 0.05), (51.0, 2.5e-3, 0.9, 0.05),
+              (51.0, 2.5e-3, 0.9, 0.05), (42.3, 2.457e-3, 1.0, 0.0)]
+    slow = _scan(pipe, False, data, points)
+    fast = _scan(pipe, True, data, points)
+    assert pipe._plan is not None, "the plan must have been built and kept"
+    for (l0, c0, h0, e0), (l1, c1, h1, e1) in zip(slow, fast):
+        assert l0 == l1 and c0 == c1
+        for a, b in zip(h0 + e0, h1 + e1):
+            np.testing.assert_array_equal(a, b)
+    # the metric of a device-backed total is the metric of its host copy
+    from pisa_amd.core.units import ureg
+
+    pipe.params.theta23.value = 45.5 * ureg.degree
+    ms = pipe.get_outputs()
+    total = sum(ms)
+    assert total._lazy is not None
+    on_device = data.metric_total(expected_values=total, metric="llh")
+    assert total._lazy is not None, "the maps must not have travelled for the metric"
+    host = sum(m for m in pipe.get_outputs())
+    host.hist  # materialise
+    assert host._lazy is None
+    assert data.metric_total(expected_values=host, metric="llh") == on_device
+    # negative data raise as in the reference (stats.py:231-240)
+    bad = data * 1.0
+    bad._hist[0, 0, 0] = -1.0
+    with pytest.raises(ValueError):
+        bad.metric_total(expected_values=sum(pipe.get_outputs()), metric="llh")
+
+
+def test_fast_plan_outputs_survive_the_next_evaluation_and_containers_stay_truthful():
+    from pisa_amd.core.pipeline import Pipeline
+    from pisa_amd.core.units import ureg
+
+    pipe = Pipeline("settings/pipeline/example_hip.cfg")
+    pipe.get_outputs()
+    pipe.params.theta23.value = 46.0 * ureg.degree
+    kept = pipe.get_outputs()            # replayed, still on the device
+    assert kept[0]._lazy is not None
+    pipe.params.theta23.value = 50.0 * ureg.degree
+    later = pipe.get_outputs()           # the engine moves on; `kept` must be brought home first
+    ref = Pipeline("settings/pipeline/example_hip.cfg")
+    ref.fast_path = False
+    ref.params.theta23.value = 46.0 * ureg.degree
+    want46 = ref.get_outputs()
+    ref.params.theta23.value = 50.0 * ureg.degree
+    want50 = ref.get_outputs()
+    for a, b, c, d in zip(kept, want46, later, want50):
+        np.testing.assert_array_equal(a.hist, b.hist)
+        np.testing.assert_array_equal(c.hist, d.hist)
+    # a reader of pipeline.data sees the CURRENT parameters' arrays, not those of the last
+    # evaluation that went through the stages
+    c = pipe.data["numu_cc"]
+    c.representation = pipe.output_binning
+    np.testing.assert_array_equal(c["weights"].reshape(want50["numu_cc"].hist.shape), want50["numu_cc"].hist)
+    c.representation = "events"
+    c2 = ref.data["numu_cc"]
+    c2.representation = "events"
+    np.testing.assert_array_equal(c["weights"], c2["weights"])
+    # Ye moves the Earth layers: not replayable, falls back, and gives the stages' answer
+    for p in (pipe, ref):
+        p.params.YeM.value = 0.48 * ureg.dimensionless
+    for a, b in zip(pipe.get_outputs(), ref.get_outputs()):
+        np.testing.assert_array_equal(a.hist, b.hist)
