@@ -15,10 +15,17 @@ pisa/scripts/benchmark_pipeline_performance.py:196-223):
     [integer all-reduce of the histogram limbs if N > 1]
     fixed point -> fp64 maps, Poisson LLH against pseudo-data
 and the host reads the LLH back (a fit loop needs it to choose the next point).
-N > 1: every rank holds 1e7 events of its own and the int64 histogram limbs are all-reduced
-(weak scaling; `value` counts 1e7-event evaluation units, N per step); `--strong-scaling` shards
-one 1e7-event sample instead.
-Prints ONE JSON line on rank 0.
+
+N > 1 (north star): ONE 1e7-event sample, its events sharded over the N GPUs, the int64
+histogram limbs all-reduced over RCCL -- strong scaling; `value` is the evaluation rate of that
+one sample.  The weak-scaling rate (every rank holds 1e7 events of its own, N samples per step)
+is measured in the same run and reported as `weak_value`.
+
+Prints ONE JSON line on rank 0.  Besides the headline it carries, at N = 1, the `legs`:
+bounded extra measurements of the same hot path (larger-than-L3 sample, the reference-order and
+the coordinate-form kernels, flux systematics moving every evaluation, the evaluation through
+the Pipeline/cfg boundary, event-by-event oscillation for configs C2 / C5, the KDE stage for
+config C3) and the CPU baseline at one thread and at all cores.
 """
 import argparse
 import json
@@ -30,7 +37,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+L3_BYTES = 256 * 2 ** 20
+ALL_LEGS = ("l3_exceeding", "exact_association", "coordinate_form", "update_flux", "pipeline_boundary",
+            "events_c2", "events_c5", "kde_c3")
 
 
 def parse():
@@ -45,29 +56,24 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="skip the HIP-event measurement of the dominant kernel (use under rocprofv3 --pmc)")
     ap.add_argument("--coordinate-form", action="store_true",
-                    help="bin event coordinates on the fly (72 B/event) instead of the pre-digitised "
-                         "index columns (40 B/event)")
+                    help="headline with the SURVEY 8(d)-shaped kernel: event coordinates binned on the fly "
+                         "(72 B/event) instead of the pre-digitised index columns")
     ap.add_argument("--cpu-sample-events", type=float, default=2.4e6)
     ap.add_argument("--exact-association", action="store_true",
-                    help="stream the 40 B/event columns (initial_weights, weighted_aeff, nu_flux kept separate, "
-                         "the reference's operation order) instead of the compact form in which the "
-                         "static per-event factors are folded into the flux pair once")
+                    help="headline with the 40 B/event columns (initial_weights, weighted_aeff, nu_flux kept "
+                         "separate, the reference's operation order)")
     ap.add_argument("--wide-index", action="store_true",
-                    help="compact form with 32-bit node and bin indices (24 B/event) instead of the "
-                         "16-bit ones (20 B/event; same weights, same arithmetic, identical results)")
+                    help="compact form with 32-bit node and bin indices (24 B/event)")
+    ap.add_argument("--legs", default="all",
+                    help="comma list of extra measurements at N = 1 (%s), 'all' or 'none'" % ", ".join(ALL_LEGS))
     ap.add_argument("--no-batch-probe", action="store_true",
-                    help="skip the informational stream-overlapped batch evaluation (keeps a rocprofv3 "
-                         "kernel average free of launches that share the chip with another stream)")
+                    help="skip the informational stream-overlapped batch evaluation")
     ap.add_argument("--no-drop-probe", action="store_true",
                     help="skip the informational second engine without the events outside the binning")
-    ap.add_argument("--strong-scaling", action="store_true",
-                    help="N > 1: shard ONE sample of --events events over the ranks (fixed total work).  The "
-                         "default for N > 1 is weak scaling: every rank holds --events events of its own "
-                         "(seed = rank), the histograms of all ranks are all-reduced, and `value` counts "
-                         "evaluations of --events-sized units (N per step) -- one MI355X already evaluates "
-                         "1e7 events in the time of a few kernel launches, so only the per-GPU-constant regime "
-                         "has anything to scale (DESIGN.md section 6)")
-    ap.add_argument("--weak-scaling", action="store_true", help="(default for N > 1; kept for compatibility)")
+    ap.add_argument("--weak-scaling", action="store_true",
+                    help="N > 1: make the weak-scaling rate the headline `value` (default: strong, as the "
+                         "north star words it; the other one is reported beside it either way)")
+    ap.add_argument("--strong-scaling", action="store_true", help="(default for N > 1; kept for compatibility)")
     ap.add_argument("--force-dist", action="store_true",
                     help="test aid: take the N > 1 code path (RCCL process group, limb all-reduce, barriers, "
                          "max over ranks) with the ranks that are there, e.g. one rank under "
@@ -77,86 +83,363 @@ def parse():
     return ap.parse_args()
 
 
-def param_list(wl, n):
+def param_list(wl, n, **kw):
     """fixed seeded scan of (theta23, dm31) over the ranges of SURVEY 8d (C4)"""
     import numpy as np
 
     rs = np.random.RandomState(2024)
     out = []
     for _ in range(n):
-        out.append(wl.osc_params(theta23_deg=31.0 + 28.0 * rs.rand(), dm31=1e-3 + 6e-3 * rs.rand()))
+        out.append(wl.osc_params(theta23_deg=31.0 + 28.0 * rs.rand(), dm31=1e-3 + 6e-3 * rs.rand(), **kw))
     return out
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(wl, sample_events):
-    """The oracle (C restatement of the reference algorithms) timed on this
-    box's host cores on a bounded sample: the full calc grid + a subsample of
-    the events, scaled to the full event count."""
+    """The oracle (C restatement of the reference algorithms) timed on this box's host cores on a
+    bounded sample: the full calc grid + a subsample of the events, scaled to the full event count;
+    once with ONE thread (the reference's TARGET='cpu') and once with all cores of the affinity mask
+    up to 64 (TARGET='parallel')."""
     import numpy as np
 
     from oracle import oracle as orc
-    from oracle.pipeline_oracle import oracle_eval
+    from oracle.pipeline_oracle import oracle_eval, oracle_eval_parallel
 
     orc.build()
-    # one thread per physical core of one socket at most: the event loops are
-    # memory bound and the histogram loop is sequential, more threads only add
-    # OpenMP overhead (measured: 256 SMT threads ran 10x slower than 8)
-    cores = min(len(os.sched_getaffinity(0)), 64)
-    orc.set_num_threads(cores)
+    avail = len(os.sched_getaffinity(0))
     n_per = max(1, int(sample_events) // len(wl.events))
-    sub = []
-    for ev in wl.events:
-        d = dict(ev)
-        for k in ("true_energy", "true_coszen", "nu_flux", "weighted_aeff", "initial_weights"):
-            d[k] = ev[k][:n_per]
-        d["sample"] = [s[:n_per] for s in ev["sample"]]
-        sub.append(d)
-    wl.osc_params()
-    oracle_eval(wl, containers=[])  # warm-up (loads the library, touches the grid)
-    # median of five repetitions each (the host is shared and the sample is short)
-    t_all, t_grid = [], []
-    for _ in range(5):
-        t0 = time.perf_counter()
-        ref = oracle_eval(wl, containers=sub)
-        t_all.append(time.perf_counter() - t0)
-        # split: grid part is independent of the number of events
-        t0 = time.perf_counter()
-        oracle_eval(wl, containers=[])
-        t_grid.append(time.perf_counter() - t0)
-    t_all, t_grid = float(np.median(t_all)), float(np.median(t_grid))
-    t_events = max(t_all - t_grid, 1e-9)
-    n_sub = n_per * len(sub)
-    t_full = t_grid + t_events * (wl.n_events / n_sub)
-    orc.metric("llh", ref["hist"].sum(axis=0) + 1, ref["hist"].sum(axis=0) + 1)
+
+    def subsample(n):
+        sub = []
+        for ev in wl.events:
+            d = dict(ev)
+            for k in ("true_energy", "true_coszen", "nu_flux", "weighted_aeff", "initial_weights"):
+                d[k] = ev[k][:n]
+            d["sample"] = [s[:n] for s in ev["sample"]]
+            sub.append(d)
+        return sub
+
+    def run(threads, n, reps):
+        sub = subsample(n)
+        wl.osc_params()
+
+        def evaluate(containers):
+            if threads == 1:
+                orc.set_num_threads(1)
+                return oracle_eval(wl, containers=containers)
+            return oracle_eval_parallel(wl, containers, threads)
+
+        evaluate([])  # warm-up (loads the library, touches the grid)
+        t_all, t_grid = [], []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            evaluate(sub)
+            t_all.append(time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            evaluate([])      # the grid part does not depend on the events
+            t_grid.append(time.perf_counter() - t0)
+        t_all, t_grid = float(np.median(t_all)), float(np.median(t_grid))
+        t_events = max(t_all - t_grid, 1e-9)
+        n_sub = n * len(sub)
+        return 1.0 / (t_grid + t_events * (wl.n_events / n_sub)), t_grid, t_events, n_sub
+
+    # one thread per core of one socket at most (the box shows 256 logical CPUs and is shared)
+    cores = min(avail, 64)
+    v_all, g_all, e_all, n_all = run(cores, n_per, 5)
+    v_one, g_one, e_one, n_one = run(1, max(1, n_per // 8), 1)
     return {
-        "value": 1.0 / t_full,
+        "value": v_all,
         "unit": "evals/s",
         "cores": cores,
         "kind": "port",
-        "sample": "full %dx%dx2-node prob3 grid (%.3f s) + %d of %d events through "
-                  "lookup/reweight/hist (%.3f s), event part scaled to all events; "
-                  "OpenMP over %d threads (histogram loop sequential); medians of 5 repetitions"
-                  % (wl.grid.n_e, wl.grid.n_cz, t_grid, n_sub, wl.n_events, t_events, cores),
+        "cpu_model": cpu_model(),
+        "cores_available": avail,
+        "sample": "full %dx%dx2-node prob3 grid (%.3f s) + %d of %d events through lookup/reweight/hist "
+                  "(%.3f s), event part scaled to all events; prob3 grid under OpenMP, events as (container, "
+                  "50k-event chunk) tasks on %d host threads; medians of 5 repetitions"
+                  % (wl.grid.n_e, wl.grid.n_cz, g_all, n_all, wl.n_events, e_all, cores),
+        "single_thread": {
+            "value": v_one, "unit": "evals/s", "cores": 1,
+            "sample": "full prob3 grid (%.3f s) + %d of %d events (%.3f s), scaled; one repetition"
+                      % (g_one, n_one, wl.n_events, e_one)},
     }
 
 
-def pmc_traffic(args):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3
-    PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; collected by
-    separate `rocprofv3 --pmc` runs of this same command, see profiles/*/traffic.json).
-    Only valid for the default workload."""
-    if args.coordinate_form or args.exact_association or args.wide_index or int(args.events) != 10000000 or args.binning != "dragon":
-        return None
+def latest_profile(name):
+    """newest committed profiles/r*/<name> (json), with the directory it came from"""
     import glob
-
     import re
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")),
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)),
                    key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(os.path.dirname(f)))])
     if not files:
-        return None
+        return None, None
     with open(files[-1]) as fh:
-        return json.load(fh).get("hbm_bytes")
+        return json.load(fh), os.path.relpath(os.path.dirname(files[-1]), ROOT)
+
+
+def pmc_traffic(args):
+    """HBM bytes per launch of the dominant kernel from the newest COMMITTED rocprofv3 PMC passes
+    (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; separate `rocprofv3 --pmc` runs of this same
+    command, scripts/profile_round.sh).  Not measured in this run: `traffic_source` says where it
+    comes from.  Only valid for the default workload."""
+    if (args.coordinate_form or args.exact_association or args.wide_index or int(args.events) != 10000000
+            or args.binning != "dragon"):
+        return None, None
+    d, src = latest_profile("traffic.json")
+    if d is None:
+        return None, None
+    return d.get("hbm_bytes"), "%s/traffic.json (committed rocprofv3 --pmc passes, not this run)" % src
+
+
+def time_fused(st, plist, lib, torch, k=30):
+    """average duration of the fused accumulate kernel, HIP events on the launch stream"""
+    import numpy as np
+
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(k)]
+    torch.cuda.synchronize()
+    for (a, b), p in zip(pairs, (plist * (k // len(plist) + 1))[:k]):
+        a.record(); b.record()  # materialise the hipEvent handles
+        lib.pisa_hip_profile_events(a.cuda_event, b.cuda_event)
+        st.eval(p, "llh")
+    lib.pisa_hip_profile_events(None, None)
+    torch.cuda.synchronize()
+    return float(np.mean([a.elapsed_time(b) for a, b in pairs])) * 1e-3
+
+
+def bytes_per_event(st, coordinate_form, compact, d_out):
+    if coordinate_form:
+        return 8 * (2 + 2 + 1 + 1 + d_out)   # SURVEY 8(d): 48 + 8 D = 72 B (D=3), 64 B (D=2)
+    if not compact:
+        return 4 + 4 + 16 + 8 + 8            # node, bin (int32) + flux(2) + aeff + w0 = 40 B
+    return (2 + 2 + 16) if st.index16 else (4 + 4 + 16)
+
+
+def hbm_leg(synthetic, lib, torch, n_events, n_e, n_cz, binning, steps, coordinate_form=False, compact=True):
+    """one engine variant: whole-evaluation rate + roofline of its fused kernel"""
+    wl = synthetic.Workload(n_events=int(n_events), grid=(n_e, n_cz), out_binning=binning, seed=0)
+    st = synthetic.DeviceState(wl, indexed=not coordinate_form, compact=compact and not coordinate_form)
+    st.make_pseudo_data(wl.osc_params(), seed=0)
+    plist = param_list(wl, 10 + steps)
+    for p in plist[:10]:
+        st.eval_host(p, "llh")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for p in plist[10:]:
+        st.eval_host(p, "llh")
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    t_k = time_fused(st, plist[:10], lib, torch)
+    bpe = bytes_per_event(st, coordinate_form, compact and not coordinate_form, len(wl.ob["nbins"]))
+    resident = bpe * st.n_local
+    out = {
+        "events": wl.n_events, "bytes_per_event": bpe, "resident_column_bytes": resident,
+        "exceeds_l3": bool(resident > L3_BYTES), "evals_per_s": 1.0 / dt, "ms_per_step": dt * 1e3,
+        "roofline": {"bound": "hbm", "achieved": resident / t_k / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": resident / t_k / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": t_k * 1e3,
+                     "kernel": "hist_accumulate_kernel<%d, true>" % (1 if coordinate_form else
+                                                                    ((7 if st.index16 else 5) if compact else 3))},
+    }
+    del st, wl
+    torch.cuda.empty_cache()
+    return out
+
+
+def leg_update_flux(synthetic, torch, wl, st, steps):
+    """every evaluation a Barr / spectral-index systematic moves as well (as in the 3-y fit):
+    barr_simple kernel for the 12 containers + refresh of the folded flux columns + evaluation"""
+    import numpy as np
+
+    from pisa_amd import kernels as K
+
+    cols = []
+    for ev in wl.events:
+        cols.append((K.to_device(ev["true_energy"]), K.to_device(ev["true_coszen"]), K.to_device(ev["nu_flux"]),
+                     K.to_device(ev["nu_flux"] * 0.7), ev["nubar"]))
+    plist = param_list(wl, 5 + steps)
+    rs = np.random.RandomState(5)
+
+    def one(p):
+        didx, ratio = 0.1 * (rs.rand() - 0.5), 1.0 + 0.05 * (rs.rand() - 0.5)
+        for i, (e, cz, nom, nom_bar, nubar) in enumerate(cols):
+            st.update_flux(i, K.barr_simple(e, cz, nom, nom_bar, nubar, ratio, 1.0, didx, 0.0, 0.0))
+        return st.eval_host(p, "llh")
+
+    for p in plist[:5]:
+        one(p)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for p in plist[5:]:
+        one(p)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    # restore the nominal columns for whatever runs after this leg
+    for i, ev in enumerate(wl.events):
+        st.update_flux(i, K.to_device(ev["nu_flux"]))
+    return {"evals_per_s": 1.0 / dt, "ms_per_step": dt * 1e3,
+            "what": "flux.barr_simple (nue/numu ratio + spectral index moved) for all events + refresh of the "
+                    "folded (w0*aeff*flux) columns + the headline evaluation, every step"}
+
+
+def _pipeline_cfg(n_events, kde=False):
+    from collections import OrderedDict
+
+    from pisa_amd.core.config_parser import parse_pipeline_config
+
+    cfg = parse_pipeline_config("settings/pipeline/example_hip.cfg")
+    cfg[("data", "synthetic_events")]["params"].params.n_events.value = n_events
+    if not kde:
+        return cfg
+    out = OrderedDict()
+    for k, v in cfg.items():
+        if k == ("utils", "hist"):
+            out[("utils", "kde")] = OrderedDict(calc_mode="events", apply_mode=v["apply_mode"])
+        else:
+            out[k] = v
+    out["pipeline"]["output_key"] = "weights"
+    return out
+
+
+def leg_pipeline_boundary(torch, n_events, steps):
+    """the same kind of evaluation through the reference's API: cfg text -> Pipeline.get_outputs()
+    -> Map.metric_total (what `Analysis._minimizer_callable` does per point)"""
+    import numpy as np
+
+    from pisa_amd.core.pipeline import Pipeline
+    from pisa_amd.core.units import ureg
+
+    pipe = Pipeline(_pipeline_cfg(n_events))
+    data = sum(pipe.get_outputs()).fluctuate("poisson", random_state=0)
+    rs = np.random.RandomState(2024)
+    pts = [(31.0 + 28.0 * rs.rand(), 1e-3 + 6e-3 * rs.rand()) for _ in range(10 + steps)]
+
+    def one(pt):
+        pipe.params.theta23.value = pt[0] * ureg.degree
+        pipe.params.deltam31.value = pt[1] * ureg.eV ** 2
+        return data.metric_total(expected_values=sum(pipe.get_outputs()), metric="llh")
+
+    for pt in pts[:10]:
+        one(pt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for pt in pts[10:]:
+        llh = one(pt)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    pipe.fast_path = False
+    pipe._plan = None
+    for pt in pts[:3]:
+        one(pt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for pt in pts[10:10 + max(20, steps // 10)]:
+        one(pt)
+    torch.cuda.synchronize()
+    dt_slow = (time.perf_counter() - t0) / max(20, steps // 10)
+    cm = pipe["prob3"].calc_mode
+    return {"evals_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "last_llh": llh,
+            "stage_protocol_every_step_evals_per_s": 1.0 / dt_slow,
+            "workload": "settings/pipeline/example_hip.cfg (cfg text): %d events, prob3 on the %s calc grid, "
+                        "aeff, hist into %s with sumw2; theta23/dm31 set through pipeline.params every step, "
+                        "Pipeline.get_outputs() + Map.metric_total('llh') read back every step"
+                        % (int(n_events) // 12 * 12, "x".join(str(n) for n in cm.shape),
+                           "x".join(str(n) for n in pipe.output_binning.shape))}
+
+
+def leg_events(synthetic, torch, n_events, steps, nsi):
+    """configs C2 / C5 (per-GPU share): prob3 EVENT BY EVENT (layers rebuilt per event in-kernel from the
+    PREM table in LDS) + fused reweight + 10x10 histogram + LLH"""
+    import numpy as np
+
+    wl = synthetic.Workload(n_events=int(n_events), grid=(10, 10), out_binning="example2d", seed=0)
+    st = synthetic.DeviceState(wl, osc_mode="events")
+    mat_pot = None
+    if nsi:
+        from pisa_amd.stages.osc.nsi_params import StdNSIParams
+
+        n = StdNSIParams()
+        n.eps_emu, n.eps_etau, n.eps_mutau = ((0.07, np.deg2rad(340)), (0.06, np.deg2rad(35)),
+                                              (0.003, np.deg2rad(175)))  # numba_osc_tests.py:129-136
+        mat_pot = np.diag([1.0, 0, 0]).astype(complex) + n.eps_matrix
+    st.make_pseudo_data(wl.osc_params(mat_pot=mat_pot), seed=0)
+    plist = param_list(wl, 3 + steps, mat_pot=mat_pot)
+    for p in plist[:3]:
+        st.eval(p).item()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for p in plist[3:]:
+        llh = st.eval(p).item()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    st.check_status()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for p in plist[3:]:
+        st.compute_probs(p)
+    e1.record()
+    torch.cuda.synchronize()
+    t_osc = e0.elapsed_time(e1) / steps * 1e-3
+    out = {"events": wl.n_events, "evals_per_s": 1.0 / dt, "ms_per_step": dt * 1e3,
+           "event_evals_per_s": wl.n_events / dt, "prob3_events_kernel_ms": t_osc * 1e3, "last_llh": llh,
+           "workload": "%d events, prob3 event by event (PREM-12%s) + fused reweight + 10x10 hist + LLH"
+                       % (wl.n_events, ", std NSI" if nsi else "")}
+    # executed fp64 flops per event of prob3_events_kernel from the committed SQ_INSTS_VALU_*_F64
+    # counter passes (scripts/profile_round.sh); not measured in this run
+    cal, src = latest_profile("events_flops.json")
+    key = "nsi" if nsi else "std"
+    if cal is not None and key in cal:
+        fpe = cal[key]["flop_per_event"]
+        ach = fpe * wl.n_events / t_osc / 1e12
+        out["roofline"] = {"bound": "fp64 valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / FP64_VALU_PEAK_TFLOPS, "flop_per_event": fpe,
+                           "flop_source": "%s/events_flops.json (executed fp64 FMA x2 + ADD + MUL + TRANS lane "
+                                          "operations of prob3_events_kernel from committed rocprofv3 "
+                                          "SQ_INSTS_VALU_*_F64 passes, not this run)" % src}
+    del st, wl
+    torch.cuda.empty_cache()
+    return out
+
+
+def leg_kde(torch, n_events, steps):
+    """config C3: the event pipeline with the KDE stage ON (reference defaults: adaptive Silverman
+    bandwidths, oversample 10, coszen reflection, pid stacking)"""
+    from pisa_amd.core.pipeline import Pipeline
+    from pisa_amd.core.units import ureg
+
+    pipe = Pipeline(_pipeline_cfg(n_events, kde=True))
+    pipe.get_outputs()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        pipe.params.theta23.value = (40.0 + i) * ureg.degree
+        maps = pipe.get_outputs()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    st = pipe["kde"].stats
+    work = st["pairs_pilot"] + st["pairs_eval"]
+    # 23 fp64 VALU instructions per kernel evaluation (2 sub, mul, fma, mul, own exp = 1 max + 1 rint +
+    # 1 mul + 2 fma + 13 fma + cvt + ldexp, 1 fma to accumulate): 17 of them FMA -> 40 flop
+    flop = 40.0 * work
+    return {"events": int(n_events) // 12 * 12, "evals_per_s": 1.0 / dt, "ms_per_step": dt * 1e3,
+            "kernel_evaluations_per_step": work, "all_pairs_would_be": st["all_pairs"],
+            "total_of_maps": float(sum(m.hist.sum() for m in maps)),
+            "roofline": {"bound": "fp64 valu", "achieved": flop / dt / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": flop / dt / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                         "note": "whole stage time (24 estimators: sorts, pilot through Hermite series, adaptive "
+                                 "evaluation, host glue) against 40 flop per counted kernel evaluation"},
+            "workload": "settings/pipeline/example_hip.cfg with utils.kde in place of utils.hist: 12 containers x 2 "
+                        "pid channels = 24 adaptive 2-D KDEs per evaluation, 80 x 120 evaluation points each; "
+                        "theta23 changed every step; KDE core parity unpinned (un-vendored `kde` package)"}
 
 
 def main():
@@ -179,22 +462,9 @@ def main():
     from pisa_amd import _lib, synthetic
 
     n_e, n_cz = (int(v) for v in args.grid.split("x"))
-    weak = dist_on and not args.strong_scaling
     compact = not (args.exact_association or args.coordinate_form)
     index16 = compact and not args.wide_index
-    wl = synthetic.Workload(n_events=int(args.events), grid=(n_e, n_cz), out_binning=args.binning,
-                            seed=rank if weak else 0)
-    st = synthetic.DeviceState(wl, rank=0 if weak else rank, world_size=1 if weak else world,
-                               indexed=not args.coordinate_form,
-                               sort_events=True if args.event_order == "auto" else args.event_order,
-                               compact=compact, index16=index16)
-    if weak:
-        # whole local sample per rank; the limb all-reduce still spans all ranks (>= 2 so that
-        # --force-dist on one rank goes through the collective as well)
-        st.world_size = max(world, 2) if args.force_dist else world
-    nominal = wl.osc_params()
-    st.make_pseudo_data(nominal, seed=0)
-    plist = param_list(wl, args.warmup + args.steps)
+    order = True if args.event_order == "auto" else args.event_order
 
     def barrier():
         if dist_on:
@@ -203,55 +473,48 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    llh = 0.0
-    for p in plist[: args.warmup]:
-        llh = st.eval_host(p, "llh")
-    st.check_status()
+    def max_over_ranks(x):
+        if not dist_on:
+            return x
+        import torch.distributed as dist
 
-    # ---- timed region: exactly K evaluations, LLH read back every time
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    fused_ms = []
-    barrier()
-    t0 = time.perf_counter()
-    for p in plist[args.warmup:]:
-        llh = st.eval_host(p, "llh")
-    barrier()
-    dt = time.perf_counter() - t0
-    st.check_status()
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    # ---- dominant kernel, measured live with HIP events on the launch stream
+    def timed_loop(st, plist):
+        llh = 0.0
+        for p in plist[: args.warmup]:
+            llh = st.eval_host(p, "llh")
+        st.check_status()
+        barrier()
+        t0 = time.perf_counter()
+        for p in plist[args.warmup:]:
+            llh = st.eval_host(p, "llh")
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        st.check_status()
+        return dt, llh
+
+    # ---- headline: ONE sample of --events events, sharded over the ranks (strong scaling)
+    wl = synthetic.Workload(n_events=int(args.events), grid=(n_e, n_cz), out_binning=args.binning, seed=0)
+    st = synthetic.DeviceState(wl, rank=rank, world_size=world, indexed=not args.coordinate_form,
+                               sort_events=order, compact=compact, index16=index16)
+    if args.force_dist and world == 1:
+        st.world_size = 2   # one rank, but through the collective
+    nominal = wl.osc_params()
+    st.make_pseudo_data(nominal, seed=0)
+    plist = param_list(wl, args.warmup + args.steps)
+    dt, llh = timed_loop(st, plist)
     lib = _lib.lib()
-    k_meas = max(10, min(args.steps, 50))
-    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-             for _ in range(k_meas)]
-    torch.cuda.synchronize()
     d_out = len(wl.ob["nbins"])
-    if args.coordinate_form:
-        bytes_per_event = 8 * (2 + 2 + 1 + 1 + d_out)  # 72 B (D=3), 64 B (D=2)
-    else:
-        bytes_per_event = 4 + 4 + 16 + 8 + 8  # node, bin (int32) + flux(2) + aeff + w0 = 40 B
-        if compact:
-            bytes_per_event = 4 + 4 + 16  # node, bin + (w0*aeff*f_e, w0*aeff*f_mu) = 24 B
-            if st.index16:
-                bytes_per_event = 2 + 2 + 16  # both indices in 16 bits = 20 B
-    if args.no_kernel_timing:
-        fused_avg_s = float("nan")
-    else:
-        for (a, b), p in zip(pairs, plist[args.warmup:] + plist):
-            a.record(); b.record()  # materialise the hipEvent handles
-            lib.pisa_hip_profile_events(a.cuda_event, b.cuda_event)
-            st.eval(p, "llh")
-        lib.pisa_hip_profile_events(None, None)
-        torch.cuda.synchronize()
-        fused_ms = [a.elapsed_time(b) for a, b in pairs]
-        fused_avg_s = float(np.mean(fused_ms)) * 1e-3
-    achieved = bytes_per_event * st.n_local / fused_avg_s / 1e9
+    bpe = bytes_per_event(st, args.coordinate_form, compact, d_out)
+    fused_avg_s = float("nan") if args.no_kernel_timing else time_fused(st, plist[args.warmup:], lib, torch,
+                                                                         k=max(10, min(args.steps, 50)))
+    achieved = bpe * st.n_local / fused_avg_s / 1e9
 
     # per-phase device times (extra information, not part of the contract)
     def time_phase(fn, n=30):
-        # median of individually timed calls: a single slow call (the chip dropping its clocks
-        # after the host-side pause between phases) does not distort it
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
         for _ in range(3):
             fn()
@@ -264,34 +527,52 @@ def main():
         return float(np.median([a.elapsed_time(b) for a, b in evs]))
 
     t_prob3 = time_phase(lambda: st.compute_probs(nominal))
+
     def tail():
         st._maps_valid = False
         st._tail("llh", st.metric_out)
 
     t_tail = time_phase(tail)
+    t_allreduce = time_phase(st.allreduce) if dist_on else None
+    n_comm = None
+    if dist_on and st._rccl:
+        n_comm = st._rccl.count()
 
-    # stream-overlapped evaluation of independent points (e.g. finite-difference
-    # gradient stencils): prob3 of point k+1 runs beside the fused kernel of point k
+    # ---- weak scaling beside it: every rank a sample of its own, limbs all-reduced, N samples per step
+    weak = None
+    if dist_on:
+        wl_w = synthetic.Workload(n_events=int(args.events), grid=(n_e, n_cz), out_binning=args.binning, seed=rank)
+        st_w = synthetic.DeviceState(wl_w, rank=0, world_size=1, indexed=not args.coordinate_form,
+                                     sort_events=order, compact=compact, index16=index16)
+        st_w.world_size = max(world, 2) if args.force_dist else world
+        st_w.group, st_w._rccl = st.group, st._rccl          # same communicator
+        st_w.make_pseudo_data(nominal, seed=0)
+        dt_w, _ = timed_loop(st_w, plist)
+        weak = {"value": args.steps / dt_w * world, "ms_per_step": 1e3 * dt_w / args.steps,
+                "events_per_gpu": wl_w.n_events, "samples_per_step": world}
+        st_w._rccl = None
+        del st_w, wl_w
+
+    # stream-overlapped evaluation of independent points (e.g. finite-difference gradient
+    # stencils): prob3 of point k+1 runs beside the fused kernel of point k
     bsz = 10
     pipelined = None
-    if not args.no_batch_probe:
+    if not args.no_batch_probe and not dist_on:
         st.eval_batch(plist[:bsz]).cpu()
-        barrier()
+        torch.cuda.synchronize()
         t0b = time.perf_counter()
         nb = 0
         for i in range(args.warmup, args.warmup + args.steps - bsz + 1, bsz):
             st.eval_batch(plist[i:i + bsz]).cpu()
             nb += bsz
-        barrier()
-        dtb = time.perf_counter() - t0b
-        pipelined = nb / dtb if nb else None
+        torch.cuda.synchronize()
+        pipelined = nb / (time.perf_counter() - t0b) if nb else None
 
     # for information: the same evaluations with the events that can never land in a bin
     # (static reco coordinates outside the output binning) not kept resident
     dropped = None
-    if world == 1 and not args.coordinate_form and not args.no_drop_probe:
-        st2 = synthetic.DeviceState(wl, sort_events=True if args.event_order == "auto" else args.event_order,
-                                    drop_unbinned=True, compact=compact, index16=index16)
+    if not dist_on and not args.coordinate_form and not args.no_drop_probe:
+        st2 = synthetic.DeviceState(wl, sort_events=order, drop_unbinned=True, compact=compact, index16=index16)
         st2.set_data(st.data.cpu().numpy())
         for p in plist[: args.warmup]:
             st2.eval_host(p, "llh")
@@ -300,56 +581,86 @@ def main():
         for p in plist[args.warmup:]:
             llh2 = st2.eval_host(p, "llh")
         dtd = time.perf_counter() - t0d
-        dropped = {"evals_per_s": args.steps / dtd, "events_resident": st2.n_local,
-                   "same_llh": bool(llh2 == llh)}
+        dropped = {"evals_per_s": args.steps / dtd, "events_resident": st2.n_local, "same_llh": bool(llh2 == llh)}
         del st2
 
-    # max over ranks
-    if dist_on:
-        import torch.distributed as dist
-
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # ---- legs (N = 1 only)
+    legs = {}
+    want = [] if (dist_on or args.legs == "none") else (list(ALL_LEGS) if args.legs == "all" else
+                                                         [x.strip() for x in args.legs.split(",") if x.strip()])
+    leg_steps = max(20, min(args.steps, 200))
+    for name in want:
+        t0 = time.perf_counter()
+        try:
+            if name == "l3_exceeding":
+                legs[name] = hbm_leg(synthetic, lib, torch, 4 * args.events, n_e, n_cz, args.binning, leg_steps // 2)
+            elif name == "exact_association":
+                legs[name] = hbm_leg(synthetic, lib, torch, args.events, n_e, n_cz, args.binning, leg_steps,
+                                     compact=False)
+            elif name == "coordinate_form":
+                legs[name] = hbm_leg(synthetic, lib, torch, args.events, n_e, n_cz, args.binning, leg_steps,
+                                     coordinate_form=True)
+            elif name == "update_flux":
+                legs[name] = leg_update_flux(synthetic, torch, wl, st, leg_steps) if compact else None
+            elif name == "pipeline_boundary":
+                legs[name] = leg_pipeline_boundary(torch, args.events, leg_steps)
+            elif name == "events_c2":
+                legs[name] = leg_events(synthetic, torch, 1e6, 20, nsi=False)
+            elif name == "events_c5":
+                legs[name] = leg_events(synthetic, torch, 1.25e7, 6, nsi=True)
+            elif name == "kde_c3":
+                legs[name] = leg_kde(torch, args.events, 4)
+            else:
+                raise ValueError("unknown leg %r" % name)
+        except Exception as exc:  # a leg must not take the headline down with it
+            legs[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        if isinstance(legs.get(name), dict):
+            legs[name]["leg_wall_s"] = time.perf_counter() - t0
 
     if rank == 0:
         evals_per_s = args.steps / dt
-        units = world if weak else 1  # weak scaling: one step evaluates `world` samples of --events events
+        headline_weak = dist_on and args.weak_scaling
+        traffic, traffic_src = pmc_traffic(args) if not dist_on else (None, None)
         out = {
             "metric": "pipeline evals/sec (osc+reweight+hist+LLH) on 1e7 MC events",
-            "value": evals_per_s * units,
+            "value": weak["value"] if headline_weak else evals_per_s,
             "unit": "evals/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps,
+            "ms_per_step": weak["ms_per_step"] if headline_weak else 1e3 * dt / args.steps,
             "higher_is_better": True,
-            "scaling": "strong" if args.strong_scaling else "weak",  # identical workloads at N = 1
+            "scaling": "weak" if (headline_weak or not dist_on) else "strong",  # identical workloads at N = 1
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic (toy_event_generator-style E/coszen, builder-defined reco/flux/aeff; see pisa_amd/synthetic.py)",
             "config": {
-                "workload": ("weak scaling, PER GPU: " if weak else "") + "%d events in 12 containers, prob3 on %dx%d (E,coszen) PREM-12 calc grid "
-                            "(nu+nubar), fused lookup+reweight+%s hist with sumw2, Poisson LLH; "
-                            "theta23/dm31 changed every eval, LLH read back every eval; %s"
-                            % (wl.n_events, n_e, n_cz, "x".join(str(b) for b in wl.ob["nbins"]),
-                               "event columns %d B/event (%s)" % (
-                                   bytes_per_event,
-                                   ("static factors initial_weights*weighted_aeff folded into the flux pair"
-                                    + (", 16-bit node and bin indices" if st.index16 else ""))
-                                   if compact else "reference operation order")),
+                "workload": "%d events in 12 containers%s, prob3 on %dx%d (E,coszen) PREM-12 calc grid (nu+nubar), fused "
+                            "lookup+reweight+%s hist with sumw2, Poisson LLH; theta23/dm31 changed every eval, LLH "
+                            "read back every eval; event columns %d B/event (%s)"
+                            % (wl.n_events, (", sharded over %d GPUs" % world) if world > 1 else "", n_e, n_cz,
+                               "x".join(str(b) for b in wl.ob["nbins"]), bpe,
+                               ("static factors initial_weights*weighted_aeff folded into the flux pair"
+                                + (", 16-bit node and bin indices" if st.index16 else "")) if compact
+                               else ("coordinates binned on the fly, SURVEY 8(d) form" if args.coordinate_form
+                                     else "reference operation order")),
                 "events": wl.n_events,
                 "calc_grid": [n_e, n_cz],
                 "out_bins": wl.ob["nbins"],
-                "parallelism": ("%d GPU(s) x %d events each, int64 limb all-reduce" % (world, wl.n_events)) if weak
-                               else "events sharded over %d GPU(s), int64 limb all-reduce" % world,
+                "parallelism": "events sharded over %d GPU(s), int64 limb all-reduce over RCCL, prob3 grid and "
+                               "metric replicated" % world,
             },
-            "event_evals_per_s": evals_per_s * wl.n_events * units,
+            "event_evals_per_s": evals_per_s * wl.n_events,
+            "strong_value": evals_per_s,
+            "weak_value": weak["value"] if weak else None,
+            "weak": weak,
+            "allreduce_ms": t_allreduce,
+            "nccl_comm_count": n_comm,
             "last_llh": llh,
             "pipelined_evals_per_s": pipelined,
             "unbinned_events_dropped": dropped,
-            "phase_ms": {"prob3_grid": t_prob3, "fused_reweight_hist": 1e3 * fused_avg_s,
-                         "finalize_metric": t_tail},
+            "phase_ms": {"prob3_grid": t_prob3, "fused_reweight_hist": 1e3 * fused_avg_s, "finalize_metric": t_tail,
+                         "allreduce": t_allreduce, "events_this_rank": st.n_local},
             "roofline": {
                 "bound": "hbm",
                 "kernel": "hist_accumulate_kernel<%d, true>" % (1 if args.coordinate_form else
@@ -358,11 +669,15 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "bytes_per_event": bytes_per_event,
+                "bytes_per_event": bpe,
                 "events_per_launch": st.n_local,
                 "avg_launch_ms": 1e3 * fused_avg_s,
-                "traffic": pmc_traffic(args) if world == 1 else None,
+                "resident_column_bytes": bpe * st.n_local,
+                "fits_l3": bool(bpe * st.n_local <= L3_BYTES),
+                "traffic": traffic,
+                "traffic_source": traffic_src,
             },
+            "legs": legs,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_sample_events)

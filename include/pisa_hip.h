@@ -437,6 +437,17 @@ int pisa_hip_flux_2d(const pisa_hip_flux_table *h_table, const double *d_true_en
                      const double *d_true_coszen, int64_t n, double *d_nu_flux,
                      double *d_nubar_flux, int32_t *d_status, void *stream);
 
+/* Refresh of the fused kernel's folded flux column after a flux stage rewrote `nu_flux`
+ * (flux stages write container['nu_flux'], pisa/stages/flux/barr_simple.py:100; the reference then
+ * multiplies it in every evaluation, prob3.py:621-622):
+ *   out[e] = d_static_w[e] * d_flux[d_perm ? d_perm[e] : e][0..1]
+ * d_flux[.][2] in the container's own event order, d_perm[n] (int64, may be NULL) the resident
+ * order of the engine, d_static_w[n] = initial_weights*weighted_aeff in resident order.
+ * layout 0: d_out[n][2] (pisa_hip_container.d_weighted_flux); layout 1: the quad-blocked
+ * d_weighted_flux_q (padding entries are left untouched). */
+int pisa_hip_fold_flux(const double *d_flux, const int64_t *d_perm, const double *d_static_w,
+                       int64_t n, int32_t layout, double *d_out, void *stream);
+
 /* `apply_sys_vectorized` (pisa/stages/flux/barr_simple.py:147-233). Flux arrays [n][2]. */
 int pisa_hip_barr_simple(const double *d_true_energy, const double *d_true_coszen,
                          const double *d_nu_flux_nominal, const double *d_nubar_flux_nominal,

@@ -70,3 +70,62 @@ def oracle_eval(wl, matrices=None, containers=None):
         weights.append(w)
     return dict(prob_nu=probs[1], prob_nubar=probs[-1], hist=np.array(hists),
                 sumw2=np.array(sumw2s), weights=weights)
+
+
+def oracle_eval_parallel(wl, containers, workers, chunk=50000, matrices=None):
+    """`oracle_eval` with coarse-grained parallelism for the CPU-baseline timing of bench.py: the
+    prob3 grid under OpenMP (`workers` threads), the per-event part (lookup, reweight, histogram +
+    sumw2) as independent (container, chunk-of-events) tasks on a pool of `workers` host threads,
+    each task single-threaded inside; chunk histograms are added per container.  This is how an
+    all-core run of the reference's elementwise kernels divides the work (numba `prange` over
+    events); results equal `oracle_eval` up to the order of the histogram additions."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    m = matrices or wl.last_matrices
+    g = wl.grid
+    orc.set_num_threads(workers)
+    lay = orc.Layers(wl.layers.prem, wl.layers.detector_depth, wl.layers.prop_height)
+    lay.rhos = np.array(wl.layers.rhos)
+    lay.calcLayers(g.coszen)
+    ee = np.repeat(g.energy, g.n_cz)
+    rho = np.tile(lay.density, (g.n_e, 1))
+    dist = np.tile(lay.distance, (g.n_e, 1))
+    probs = {nubar: orc.propagate_array(m["dm"], m["mix"], m["mat_pot"], m["decay_flag"], m["mat_decay"],
+                                        m["lri_pot"], nubar, ee, rho, dist) for nubar in (1, -1)}
+    mins = [g.binning.mins[0], g.binning.mins[1]]
+    maxs = [g.binning.maxs[0], g.binning.maxs[1]]
+    nb = [g.binning.nbins[0], g.binning.nbins[1]]
+    ob = wl.ob
+    tables = {}
+    for ci, ev in enumerate(containers):
+        P = probs[ev["nubar"]]
+        tables[ci] = (orc.fill_probs(P, 0, ev["flav"]), orc.fill_probs(P, 1, ev["flav"]))
+
+    def task(args):
+        ci, lo, hi = args
+        orc.set_num_threads(1)   # the OpenMP thread count is per calling thread
+        ev = containers[ci]
+        pe_grid, pmu_grid = tables[ci]
+        sl = slice(lo, hi)
+        sample = [np.log(ev["true_energy"][sl]), ev["true_coszen"][sl]]
+        pe = orc.lookup_regular(sample, pe_grid, mins, maxs, nb)
+        pmu = orc.lookup_regular(sample, pmu_grid, mins, maxs, nb)
+        w = orc.reweight(np.ascontiguousarray(ev["initial_weights"][sl]), np.ascontiguousarray(ev["nu_flux"][sl]),
+                         pe, pmu, np.ascontiguousarray(ev["weighted_aeff"][sl]), ev["scale"])
+        cols = [np.ascontiguousarray(c[sl]) for c in ev["sample"]]
+        return ci, (orc.histogram_regular(cols, w, ob["mins"], ob["maxs"], ob["nbins"]),
+                    orc.histogram_regular(cols, np.square(w), ob["mins"], ob["maxs"], ob["nbins"]))
+
+    tasks = []
+    for ci, ev in enumerate(containers):
+        n = len(ev["true_energy"])
+        tasks += [(ci, lo, min(n, lo + chunk)) for lo in range(0, n, chunk)]
+    n_bins = int(np.prod(ob["nbins"]))
+    hist = np.zeros((len(containers), n_bins))
+    sumw2 = np.zeros((len(containers), n_bins))
+    if tasks:
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            for ci, (h, s) in pool.map(task, tasks):
+                hist[ci] += np.ravel(h)
+                sumw2[ci] += np.ravel(s)
+    return dict(hist=hist, sumw2=sumw2)

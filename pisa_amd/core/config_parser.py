@@ -184,7 +184,18 @@ def parse_param(config, section, selector, fullname, pname, value):
         elif prior == "none":
             kwargs["prior"] = None
         elif prior == "spline":
-            raise NotImplementedError("spline priors are outside the hot path of this build")
+            # config_parser.py:541-553: knots / coeffs / deg from a JSON resource, entry
+            # "<name>[_<selector>]", knots converted to the parameter's units
+            import json
+
+            from pisa_amd.utils.resources import find_resource
+
+            priorname = pname if selector is None else pname + "_" + selector
+            with open(find_resource(config.get(section, fullname + ".prior.data"))) as fh:
+                data = json.load(fh)[priorname]
+            knots = Quantity(np.asarray(data["knots"], dtype=np.float64), data["units"]).to(kwargs["value"].units)
+            kwargs["prior"] = Prior(kind="spline", knots=knots, coeffs=np.asarray(data["coeffs"], dtype=np.float64),
+                                    deg=int(data["deg"]))
         else:
             raise Exception("Prior type unknown")
     elif uq is not None and not math.isnan(uq.std_dev):

@@ -55,9 +55,23 @@ class Prior:
             self.A = _as_quantity(kwargs["A"])
             self.B = _as_quantity(kwargs["B"]).to(self.A.units)
             self.units = self.A.units
+        elif self.kind == "spline":
+            # prior.py:285-318: scipy.interpolate.splev(x, (knots, coeffs, deg), ext=2)
+            self.knots = _as_quantity(kwargs["knots"])
+            if kwargs.get("units") is not None:
+                u = ureg.parse_units(kwargs["units"])
+                self.knots = (Quantity(self.knots.magnitude, u) if self.knots.units == ureg.dimensionless
+                              else self.knots.to(u))
+            self.coeffs = np.asarray(kwargs["coeffs"], dtype=np.float64)
+            self.deg = int(kwargs["deg"])
+            self.units = self.knots.units
+        elif self.kind == "linterp":
+            # prior.py:262-283: linear interpolation, error outside the tabulated range
+            self.param_vals = _as_quantity(kwargs["param_vals"])
+            self.llh_vals = np.asarray(kwargs["llh_vals"], dtype=np.float64)
+            self.units = self.param_vals.units
         else:
-            raise ValueError("prior kind '%s' not supported by this build (uniform, gaussian, "
-                             "jeffreys)" % kind)
+            raise ValueError("prior kind '%s' unknown (uniform, gaussian, jeffreys, spline, linterp)" % kind)
 
     def _strip(self, x):
         x = _as_quantity(x)
@@ -70,6 +84,16 @@ class Prior:
         if self.kind == "gaussian":
             m, s = self.mean.magnitude, self.stddev.magnitude
             return -(v - m) ** 2 / (2 * s ** 2)
+        if self.kind == "spline":
+            from scipy.interpolate import splev
+
+            return splev(v, tck=(self.knots.magnitude, self.coeffs, self.deg), ext=2)
+        if self.kind == "linterp":
+            xs, ys = np.asarray(self.param_vals.magnitude, dtype=np.float64), self.llh_vals
+            if np.any(np.asarray(v) < xs.min()) or np.any(np.asarray(v) > xs.max()):
+                raise ValueError("A value in x_new is outside the interpolation range.")
+            order = np.argsort(xs)
+            return np.interp(v, xs[order], ys[order])
         a, b = self.A.magnitude, self.B.magnitude
         return -np.log(v) + np.log(np.log(b) - np.log(a))
 
@@ -79,6 +103,8 @@ class Prior:
     def __repr__(self):
         if self.kind == "gaussian":
             return "Prior(gaussian, mean=%s, stddev=%s)" % (self.mean, self.stddev)
+        if self.kind == "spline":
+            return "Prior(spline, deg=%d, %d knots)" % (self.deg, len(self.knots.magnitude))
         return "Prior(%s)" % self.kind
 
 

@@ -284,6 +284,43 @@ PISA_API int pisa_hip_metric(int32_t kind, const double *d_actual, const double 
     return PISA_HIP_OK;
 }
 
+
+// Folds the static per-event factors into a new flux column, in the fused kernel's resident
+// event order and column layout:  out[e] = static_w[e] * flux[perm ? perm[e] : e][0..1].
+// layout 0: out[n][2];  layout 1: quad-blocked out[n_pad/256][4][64][2], event 4q+k at
+// [q/64][k][q%64] (hist.hip, 16-bit index form).  Runs whenever a flux systematic moved
+// (`HotPathEngine.update_flux`): 16 B gathered + 8 B + 8 B index read, 16 B written per event.
+namespace pisa {
+__global__ void __launch_bounds__(256)
+fold_flux_kernel(const double2 *__restrict__ flux, const int64_t *__restrict__ perm,
+                 const double *__restrict__ static_w, int64_t n, int layout, double2 *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const double2 f = flux[perm ? perm[e] : e];
+    const double w = static_w[e];
+    double2 r;
+    r.x = w * f.x;
+    r.y = w * f.y;
+    if (layout == 0) {
+        out[e] = r;
+    } else {
+        const int64_t q = e >> 2;
+        out[(((q >> 6) * 4 + (e & 3)) << 6) + (q & 63)] = r;
+    }
+}
+}  // namespace pisa
+
+PISA_API int pisa_hip_fold_flux(const double *d_flux, const int64_t *d_perm, const double *d_static_w,
+                                int64_t n, int32_t layout, double *d_out, void *stream) {
+    if (n < 0 || (layout != 0 && layout != 1)) return PISA_HIP_ERR_INVALID;
+    if (n == 0) return PISA_HIP_OK;
+    if (!d_flux || !d_static_w || !d_out) return PISA_HIP_ERR_INVALID;
+    hipLaunchKernelGGL(fold_flux_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       (const double2 *)d_flux, d_perm, d_static_w, n, (int)layout, (double2 *)d_out);
+    PISA_CHECK_LAUNCH("fold_flux_kernel");
+    return PISA_HIP_OK;
+}
+
 PISA_API int pisa_hip_barr_simple(const double *d_true_energy, const double *d_true_coszen,
                                   const double *d_nu_flux_nominal,
                                   const double *d_nubar_flux_nominal, int64_t nubar,

@@ -383,19 +383,25 @@ class HotPathEngine:
         return t
 
     def update_flux(self, i, flux):
-        """new nu_flux column for container i (flux systematics changed): written in
-        place, in this engine's event order"""
+        """new nu_flux column for container i (flux systematics changed): `flux` [n, 2] device
+        tensor in the container's own event order.  One kernel gathers it into this engine's
+        resident order and folds the static factors in (`pisa_hip_fold_flux`)."""
         lo, hi = self._slices[i]
-        f = flux[lo:hi]
-        if self._perm[i] is not None:
-            f = f[self._perm[i]]
-        self._flux[i].copy_(f)
+        f = flux[lo:hi] if (lo != 0 or hi != flux.shape[0]) else flux
+        f = f.contiguous()
+        perm = self._perm[i]
         if self._wflux[i] is not None:
-            self._fill_wflux(self._wflux[i], self._static_w[i], self._flux[i])
+            out = self._wflux[i]
+            _lib.check(_lib.lib().pisa_hip_fold_flux(
+                K._ptr(f), None if perm is None else K._ptr(perm), K._ptr(self._static_w[i]),
+                int(self._static_w[i].numel()), 0 if out.dim() == 2 else 1, K._ptr(out), K._stream()))
+            # (the separate resident nu_flux column is not read by the compact kernels)
+        else:
+            self._flux[i].copy_(f if perm is None else f[perm])
 
     @staticmethod
     def _fill_wflux(out, static_w, flux):
-        """static_w * (f_e, f_mu) into the plain [n][2] column or the quad-blocked one"""
+        """static_w * (f_e, f_mu) into the plain [n][2] column or the quad-blocked one (set-up)"""
         if out.dim() == 2:
             torch.mul(static_w[:, None], flux, out=out)
         else:

@@ -34,6 +34,8 @@ def _load():
                                   C.c_void_p]
     lib.ncclCommDestroy.restype = C.c_int
     lib.ncclCommDestroy.argtypes = [C.c_void_p]
+    lib.ncclCommCount.restype = C.c_int
+    lib.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     lib.ncclGetErrorString.restype = C.c_char_p
     lib.ncclGetErrorString.argtypes = [C.c_int]
     return lib
@@ -92,6 +94,14 @@ class LimbAllReduce:
         if rc != 0:
             raise RuntimeError("ncclAllReduce: " + self.lib.ncclGetErrorString(rc).decode())
         return limbs
+
+    def count(self):
+        """`ncclCommCount`: the number of ranks the communicator really spans"""
+        n = C.c_int(-1)
+        rc = self.lib.ncclCommCount(self.comm, C.byref(n))
+        if rc != 0:
+            raise RuntimeError("ncclCommCount: " + self.lib.ncclGetErrorString(rc).decode())
+        return int(n.value)
 
     def destroy(self):
         if self.comm:

@@ -1,43 +1,86 @@
 # Full measurement set of the default bench for profiles/<tag> (run on the GPU box):
-#   bench.json                  plain bench.py run (the judged line)
-#   kernel_stats.csv            rocprofv3 --kernel-trace --stats of the same command
-#   bench_under_rocprof.json    the bench line printed under the profiler
+#   bench.json                  plain bench.py run (the judged line, with all legs)
+#   kernel_stats.csv            rocprofv3 --kernel-trace --stats of the headline loop (bench.py --legs none)
+#   kernels_by_phase.json       per-kernel mean over the timed loop from the same trace
 #   pmc_FETCH_SIZE.csv / pmc_WRITE_SIZE.csv   separate --pmc passes (bench.py --steps 3 --no-kernel-timing)
 #   traffic.json                HBM bytes per launch of the dominant kernel derived from them
+#   traffic_l3_exceeding.json / traffic_coordinate_form.json   the same for two of the legs
+#   events_flops.json           executed fp64 lane operations per event of prob3_events_kernel
+#                               (SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 pass over scripts/bench_events.py)
+#   kde_kernel_stats.csv        kernel trace statistics of the C3 (KDE on) pipeline
 TAG=$1
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; rm -rf $OUT; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.stderr
-tail -c 600 $OUT/bench.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --no-cpu-baseline --no-drop-probe --no-batch-probe > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
+tail -c 400 $OUT/bench.json
+LEAN="--no-cpu-baseline --no-drop-probe --no-batch-probe --legs none"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py $LEAN > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
 cp $OUT/stats/bench_kernel_stats.csv $OUT/kernel_stats.csv
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-drop-probe --no-batch-probe > /dev/null 2> $OUT/pmc_$c.log
-  cp $OUT/pmc_$c/p_counter_collection.csv $OUT/pmc_$c.csv
+pmc_pair () {  # name, extra bench args
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$1_$c -o p -- python3 bench.py --steps 3 --warmup 1 --no-kernel-timing $LEAN $2 > /dev/null 2> $OUT/pmc_$1_$c.log
+    cp $OUT/pmc_$1_$c/p_counter_collection.csv $OUT/pmc_$1_$c.csv
+  done
+}
+pmc_pair main ""
+pmc_pair l3 "--events 4e7"
+pmc_pair coord "--coordinate-form"
+for v in std nsi; do
+  F=""; [ $v = nsi ] && F="--nsi"
+  rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/pmc_events_$v -o p -- python3 scripts/bench_events.py --events 1e6 --steps 3 --warmup 1 $F > $OUT/events_$v.json 2> $OUT/pmc_events_$v.log
+  cp $OUT/pmc_events_$v/p_counter_collection.csv $OUT/pmc_events_$v.csv
 done
+rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/pmc_kde -o p -- python3 scripts/bench_kde.py 2e5 > $OUT/kde_pmc_run.json 2> $OUT/pmc_kde.log
+cp $OUT/pmc_kde/p_counter_collection.csv $OUT/pmc_kde.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kde_stats -o kde -- python3 scripts/dev/c3_probe.py 1e7 > $OUT/c3_probe.log 2> $OUT/kde_stats.log
+cp $OUT/kde_stats/kde_kernel_stats.csv $OUT/kde_kernel_stats.csv
 python3 - <<PY
 import csv, json
-def per_launch(path, name):
+OUT = "$OUT"
+def per_launch(path, kernel, name):
     v = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
-         if "hist_accumulate_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name]
-    return sum(v) / len(v), len(v)
-f, nf = per_launch("$OUT/pmc_FETCH_SIZE.csv", "FETCH_SIZE")
-w, nw = per_launch("$OUT/pmc_WRITE_SIZE.csv", "WRITE_SIZE")
-d = {"kernel": "hist_accumulate_kernel<7,true> (16-bit index layout, 20 B/event)", "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "launches": [nf, nw],
-     "fetch_bytes_corrected": f * 1024 * 2, "write_bytes": w * 1024,
-     "hbm_bytes": f * 1024 * 2 + w * 1024,
-     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (bench.py --steps 3 --no-kernel-timing); "
-               "FETCH_SIZE is in KiB and on gfx950 reports half of the bytes of 16-B/lane coalesced streams "
-               "(MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE exact",
-     "algorithmic_bytes": 20 * 9999996}
-json.dump(d, open("$OUT/traffic.json", "w"), indent=1)
-print(d["hbm_bytes"], d["launches"])
-for r in list(csv.reader(open("$OUT/kernel_stats.csv")))[:8]:
+         if kernel in r["Kernel_Name"] and r["Counter_Name"] == name]
+    return (sum(v) / len(v), len(v)) if v else (float("nan"), 0)
+METHOD = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (bench.py --steps 3 --no-kernel-timing); "
+          "FETCH_SIZE is in KiB and on gfx950 reports half of the bytes of 16-B/lane coalesced streams "
+          "(MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE exact")
+def traffic(tag, label, alg, fname):
+    f, nf = per_launch("%s/pmc_%s_FETCH_SIZE.csv" % (OUT, tag), "hist_accumulate_kernel", "FETCH_SIZE")
+    w, nw = per_launch("%s/pmc_%s_WRITE_SIZE.csv" % (OUT, tag), "hist_accumulate_kernel", "WRITE_SIZE")
+    d = {"kernel": label, "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "launches": [nf, nw],
+         "fetch_bytes_corrected": f * 1024 * 2, "write_bytes": w * 1024, "hbm_bytes": f * 1024 * 2 + w * 1024,
+         "method": METHOD, "algorithmic_bytes": alg, "ratio_to_algorithmic": (f * 1024 * 2 + w * 1024) / alg}
+    json.dump(d, open("%s/%s" % (OUT, fname), "w"), indent=1)
+    print(fname, d["hbm_bytes"], d["ratio_to_algorithmic"], d["launches"])
+traffic("main", "hist_accumulate_kernel<7,true> (16-bit index layout, 20 B/event), 9999996 events", 20 * 9999996, "traffic.json")
+traffic("l3", "hist_accumulate_kernel<7,true>, 39999996 events (800 MB resident: beyond the 256 MiB Infinity Cache)", 20 * 39999996, "traffic_l3_exceeding.json")
+traffic("coord", "hist_accumulate_kernel<1,true> (coordinate form, SURVEY 8(d) 72 B/event), 9999996 events", 72 * 9999996, "traffic_coordinate_form.json")
+# executed fp64 lane operations of prob3_events_kernel
+ev = {}
+for v in ("std", "nsi"):
+    c = {}
+    for name in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU"):
+        c[name], n = per_launch("%s/pmc_events_%s.csv" % (OUT, v), "prob3_events", name)
+    n_events = 999996
+    flop = 64.0 * (2 * c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_TRANS_F64"])
+    ev[v] = {"wave_instructions_per_launch": c, "launches": n, "events": n_events, "flop_per_event": flop / n_events,
+             "valu_instructions_per_event_lane": c["SQ_INSTS_VALU"] * 64.0 / n_events}
+ev["method"] = ("rocprofv3 --pmc SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 SQ_INSTS_VALU over scripts/bench_events.py --events 1e6; "
+                "wave-level instruction counts x 64 lanes (inactive lanes of partially filled or divergent waves "
+                "are counted: an upper bound of the useful lane operations), FMA = 2 flop")
+json.dump(ev, open(OUT + "/events_flops.json", "w"), indent=1)
+print({k: (v["flop_per_event"] if isinstance(v, dict) else None) for k, v in ev.items()})
+# calibration of the same counters on a kernel with a known instruction mix: kde_pairs_kernel
+k = {}
+for name in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU"):
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(OUT + "/pmc_kde.csv"))
+            if "kde_pairs_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name]
+    k[name] = sum(vals)
+json.dump({"kde_pairs_kernel_totals": k, "run": open(OUT + "/kde_pmc_run.json").read()[-1500:]}, open(OUT + "/kde_counter_check.json", "w"), indent=1)
+for r in list(csv.reader(open(OUT + "/kernel_stats.csv")))[:8]:
     print(r[0][:60].ljust(60), r[1:5])
-# per-kernel mean over the timed loop only (launches after the pseudo-data evaluation and the
-# 20 warm-up evaluations), from the kernel trace of the same rocprofv3 run
-rows = sorted(csv.DictReader(open("$OUT/stats/bench_kernel_trace.csv")), key=lambda r: int(r["Start_Timestamp"]))
+rows = sorted(csv.DictReader(open(OUT + "/stats/bench_kernel_trace.csv")), key=lambda r: int(r["Start_Timestamp"]))
 phase = {}
 for key in ("hist_accumulate_kernel", "prob3_terms_kernel", "prob3_chain_kernel", "finalize_metric_kernel"):
     d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if key in r["Kernel_Name"]]
@@ -45,8 +88,9 @@ for key in ("hist_accumulate_kernel", "prob3_terms_kernel", "prob3_chain_kernel"
     phase[key] = {"timed_loop_mean_us": sum(loop) / len(loop) / 1e3, "all_launches_mean_us": sum(d) / len(d) / 1e3,
                   "launches": len(d)}
 phase["note"] = ("from bench_kernel_trace.csv of the rocprofv3 run of bench.py --no-cpu-baseline --no-drop-probe "
-                 "--no-batch-probe; timed loop = launches 22..521 (after pseudo-data and 20 warm-up evaluations)")
-json.dump(phase, open("$OUT/kernels_by_phase.json", "w"), indent=1)
+                 "--no-batch-probe --legs none; timed loop = launches 22..521 (after pseudo-data and 20 warm-up evaluations)")
+json.dump(phase, open(OUT + "/kernels_by_phase.json", "w"), indent=1)
 print({k: round(v["timed_loop_mean_us"], 2) for k, v in phase.items() if k != "note"})
 PY
-rm -rf $OUT/stats/*.db $OUT/pmc_*/ 2>/dev/null
+rm -rf $OUT/stats $OUT/pmc_*_FETCH_SIZE $OUT/pmc_*_WRITE_SIZE $OUT/pmc_events_std $OUT/pmc_events_nsi $OUT/pmc_kde $OUT/kde_stats
+ls $OUT

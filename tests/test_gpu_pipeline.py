@@ -71,9 +71,9 @@ def test_osc_example_cfg_unmodified(oracle):
 
 
 def _oracle_event_pipeline(oracle, pipe, flux_params=(1.0, 1.0, 0.0, 0.0, 0.0), theta23_deg=42.3,
-                           aeff_scale=1.0):
+                           aeff_scale=1.0, dm31=2.457e-3):
     """reference chain on the pipeline's own input columns"""
-    grid = _oracle_grid(oracle, pipe["prob3"].calc_mode, theta23_deg=theta23_deg)
+    grid = _oracle_grid(oracle, pipe["prob3"].calc_mode, theta23_deg=theta23_deg, dm31=dm31)
     cm = pipe["prob3"].calc_mode
     lo, hi = cm["true_energy"].domain.m_as("GeV")
     mins, maxs, nb = [np.log(lo), -1.0], [np.log(hi), 1.0], [cm["true_energy"].num_bins, cm["true_coszen"].num_bins]
@@ -293,3 +293,49 @@ def test_fast_plan_outputs_survive_the_next_evaluation_and_containers_stay_truth
         p.params.YeM.value = 0.48 * ureg.dimensionless
     for a, b in zip(pipe.get_outputs(), ref.get_outputs()):
         np.testing.assert_array_equal(a.hist, b.hist)
+
+
+def test_minimizer_callable_x_to_metric_pins(oracle):
+    """captured (x -> metric) pairs of the minimiser callable
+    (pisa/analysis/analysis.py:2493-2670): [0,1]-rescaled free parameters -> parameter values
+    (param.py:358-400) -> template -> metric + priors penalty (param.py:1372-1396) -> sign.
+    The expected numbers come from the CPU oracle chain evaluated at the hand-rescaled values."""
+    from pisa_amd.analysis.analysis import Analysis, Counter
+    from pisa_amd.core.distribution_maker import DistributionMaker
+    from pisa_amd.core.units import ureg
+
+    dm = DistributionMaker("settings/pipeline/example_hip.cfg")
+    pipe = dm.pipelines[0]
+    names = dm.params.free.names
+    assert set(names) == {"delta_index", "theta23", "deltam31", "aeff_scale"}
+    ranges = {"theta23": (0.0, 90.0), "deltam31": (0.001, 0.007), "aeff_scale": (0.0, 3.0),
+              "delta_index": (-0.5, 0.5)}                      # example_hip.cfg, in the cfg's units
+    dm.params.theta23.value = 45.0 * ureg.degree
+    dm.params.deltam31.value = 2.5e-3 * ureg.eV ** 2
+    data = dm.get_outputs(return_sum=True)                     # Asimov data at this truth
+    data_h = data[0].hist.copy()
+    dm.reset_free()
+    rs = np.random.RandomState(12)
+    xs = np.column_stack([0.3 + 0.4 * rs.rand(5), 0.2 + 0.3 * rs.rand(5), 0.2 + 0.5 * rs.rand(5),
+                          0.3 + 0.4 * rs.rand(5)])
+    ana = Analysis()
+    for metric, sign in (("mod_chi2", +1), ("llh", -1), ("chi2", +1)):
+        hist, counter = [], Counter()
+        for x in xs:
+            got = ana._minimizer_callable(x, dm, data, metric, counter, hist)
+            val = {n: ranges[n][0] + (ranges[n][1] - ranges[n][0]) * xi for n, xi in zip(names, x)}
+            ref_h, ref_e = _oracle_event_pipeline(
+                oracle, pipe, flux_params=(1.0, 1.0, val["delta_index"], 0.0, 0.0),
+                theta23_deg=val["theta23"], aeff_scale=val["aeff_scale"], dm31=val["deltam31"])
+            total = sum(ref_h[n] for n in NAMES)
+            var = sum(ref_e[n] ** 2 for n in NAMES)
+            _, m = oracle.metric(metric, data_h, total, var)
+            prior_llh = -(val["delta_index"] - 0.0) ** 2 / (2 * 0.1 ** 2)   # delta_index = 0.0 +/- 0.1
+            penalty = prior_llh if metric == "llh" else -2 * prior_llh
+            np.testing.assert_allclose(got, sign * (m + penalty), rtol=1e-10, err_msg="%s %s" % (metric, x))
+        assert counter.count == len(xs) and len(hist) == len(xs)
+        # fit history rows: [metric_val, *free values] (analysis.py:2636-2646)
+        np.testing.assert_allclose(hist[-1][1:], [ranges[n][0] + (ranges[n][1] - ranges[n][0]) * xi
+                                                   for n, xi in zip(names, xs[-1])], rtol=1e-14)
+    # and the loop went through the replayed evaluation for osc / aeff moves
+    assert pipe._plan is not None

@@ -277,3 +277,53 @@ def test_distribution_maker_refuses_param_free_in_one_pipeline_fixed_in_another(
         dm._set_rescaled_free_params([0.3])
     with pytest.raises(AttributeError):
         dm.set_free_params([0.3 * ureg.dimensionless])
+
+
+def test_spline_and_linterp_priors():
+    """prior.py:262-318: `spline` priors are scipy splev of (knots, coeffs, deg) with ext=2
+    (error outside the knots); read from the JSON resource the cfg names, entry
+    '<param>_<selector>' (config_parser.py:541-553).  example.cfg's theta23 uses one."""
+    import json
+
+    from scipy.interpolate import splev
+
+    from pisa_amd.utils.resources import find_resource
+
+    data = json.load(open(find_resource("priors/nufitv20shiftedtheta23splines.json")))["theta23_nh"]
+    pr = Prior(kind="spline", knots=np.array(data["knots"]) * ureg.parse_units(data["units"]),
+               coeffs=data["coeffs"], deg=data["deg"])
+    for deg in (38.0, 42.3, 47.5, 51.0):
+        want = splev(np.deg2rad(deg), (np.array(data["knots"]), np.array(data["coeffs"]), data["deg"]), ext=2)
+        assert pr.llh(deg * ureg.degree) == want
+        assert pr.chi2(deg * ureg.degree) == -2 * want
+    with pytest.raises(ValueError):
+        pr.llh(5.0 * ureg.degree)
+    p = Param(name="theta23", value=42.3 * ureg.degree, prior=pr, range=[31, 59] * ureg.degree, is_fixed=False)
+    assert p.prior_penalty("llh") == pr.llh(42.3 * ureg.degree)
+    li = Prior(kind="linterp", param_vals=[0.0, 1.0, 3.0] * ureg.eV, llh_vals=[0.0, -1.0, -9.0])
+    assert li.llh(2.0 * ureg.eV) == -5.0
+    with pytest.raises(ValueError):
+        li.llh(4.0 * ureg.eV)
+
+
+def test_spline_prior_from_cfg(tmp_path):
+    """the reference's own cfg lines for a spline prior (settings/osc/nufitv20.cfg:13-14 through
+    ${osc:...} interpolation, as pisa_examples' example.cfg does)"""
+    from scipy.interpolate import splev
+    import json
+
+    from pisa_amd.utils.resources import find_resource
+
+    text = open(find_resource("settings/pipeline/example_hip.cfg")).read()
+    text = text.replace("param.nh.theta23.prior = uniform",
+                        "param.nh.theta23.prior = ${osc:theta23_nh.prior}\n"
+                        "param.nh.theta23.prior.data = ${osc:theta23_nh.prior.data}")
+    path = tmp_path / "spline.cfg"
+    path.write_text(text)
+    cfg = parse_pipeline_config(str(path))
+    p = cfg[("osc", "prob3")]["params"].params.theta23
+    assert p.prior.kind == "spline" and p.prior.units == ureg.degree
+    d = json.load(open(find_resource("priors/nufitv20shiftedtheta23splines.json")))["theta23_nh"]
+    knots_deg = (np.array(d["knots"]) * ureg.parse_units(d["units"])).m_as("deg")
+    np.testing.assert_array_equal(p.prior.knots.magnitude, knots_deg)
+    assert p.prior_penalty("chi2") == -2 * splev(42.3, (knots_deg, np.array(d["coeffs"]), d["deg"]), ext=2)
