@@ -347,7 +347,28 @@ def leg_pipeline_boundary(torch, n_events, steps):
     torch.cuda.synchronize()
     dt_slow = (time.perf_counter() - t0) / max(20, steps // 10)
     cm = pipe["prob3"].calc_mode
+    del pipe
+    torch.cuda.empty_cache()
+    # the engine alone on the same workload (same events, calc grid and binning): what the
+    # boundary costs on top
+    from pisa_amd import synthetic
+
+    wl = synthetic.Workload(n_events=int(n_events), grid=tuple(cm.shape), out_binning="example3d", seed=0)
+    st = synthetic.DeviceState(wl, compact=True)
+    st.make_pseudo_data(wl.osc_params(), seed=0)
+    plist = param_list(wl, 10 + steps)
+    for p in plist[:10]:
+        st.eval_host(p, "llh")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for p in plist[10:]:
+        st.eval_host(p, "llh")
+    torch.cuda.synchronize()
+    dt_eng = (time.perf_counter() - t0) / steps
+    del st, wl
+    torch.cuda.empty_cache()
     return {"evals_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "last_llh": llh,
+            "engine_same_workload_evals_per_s": 1.0 / dt_eng, "boundary_over_engine": dt / dt_eng,
             "stage_protocol_every_step_evals_per_s": 1.0 / dt_slow,
             "workload": "settings/pipeline/example_hip.cfg (cfg text): %d events, prob3 on the %s calc grid, "
                         "aeff, hist into %s with sumw2; theta23/dm31 set through pipeline.params every step, "

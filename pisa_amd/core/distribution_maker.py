@@ -119,7 +119,9 @@ class DistributionMaker:
     def get_outputs(self, return_sum=False, sum_map_name="total", **kwargs):
         outputs = [p.get_outputs(**kwargs) for p in self._pipelines]
         if return_sum:
-            total = sum(sum(ms) for ms in outputs)   # distribution_maker.py:274-281
+            # distribution_maker.py:274-281: sum([sum(x) for x in outputs]); `total()` is that sum
+            # over one pipeline's maps -- for device-backed outputs without bringing them home
+            total = sum(ms.total(sum_map_name) for ms in outputs)
             total.name = sum_map_name
             return MapSet([total], name=self.label)
         return outputs

@@ -25,9 +25,9 @@ from pisa_amd import _lib
 from pisa_amd import kernels as K
 from pisa_amd.core.container import Container
 from pisa_amd.core.map import Map, MapSet
-from pisa_amd.core.param import Param
+from pisa_amd.core.param import Param, ParamSet
 
-__all__ = ["FastPlan", "DeviceMapBlock"]
+__all__ = ["FastPlan", "DeviceMapBlock", "DeviceMapSet"]
 
 
 class DeviceMapBlock:
@@ -90,6 +90,39 @@ class DeviceMapBlock:
         return val
 
 
+class DeviceMapSet(MapSet):
+    """MapSet over the rows of a `DeviceMapBlock`; the Map objects are made when first asked for,
+    and `total()` -- what `sum(mapset)` gives -- is available without making them"""
+
+    def __init__(self, names, binning, block, name=None):
+        self._names, self._binning, self._block = list(names), binning, block
+        self._maps = None
+        self.name, self.tex, self.collate_by_name = name, None, True
+
+    @property
+    def maps(self):
+        if self._maps is None:
+            self._maps = [Map.device_backed(n, self._binning, self._block, 1 << i)
+                          for i, n in enumerate(self._names)]
+        return self._maps
+
+    @maps.setter
+    def maps(self, value):
+        self._maps = list(value)
+
+    names = property(lambda self: list(self._names) if self._maps is None else [m.name for m in self._maps])
+
+    def __len__(self):
+        return len(self._names) if self._maps is None else len(self._maps)
+
+    def total(self, name="total"):
+        if self._maps is None:
+            return Map.device_backed(name, self._binning, self._block, self._block.full)
+        out = sum(self._maps)
+        out.name = name
+        return out
+
+
 class FastPlan:
     @classmethod
     def build(cls, pipeline):
@@ -119,9 +152,11 @@ class FastPlan:
         self.with_errors = pipeline.output_key != "weights"
         self.binning = pipeline.output_binning
         self.names = [c.name for c in hist.data.containers]
-        self.stage_params = [(s, list(s.params)) for s in pipeline._stages]
-        self.seen = [[p._ver for p in ps] for _, ps in self.stage_params]
-        self.ids = [[id(p) for p in ps] for _, ps in self.stage_params]
+        # one flat list of (param, index of its stage); a parameter shared by stages appears once
+        # per stage, so every stage that uses it is seen to change
+        self.flat = [(p, k) for k, s in enumerate(pipeline._stages) for p in s.params]
+        self.seen = [p._ver for p, _ in self.flat]
+        self.struct_clock = ParamSet.struct_clock
         self.clock = Param.clock
         self.container_clock = Container.clock
         self.ye = (osc.YeI, osc.YeO, osc.YeM)
@@ -131,16 +166,18 @@ class FastPlan:
         self._lib = _lib.lib()
 
     def _changed(self):
-        """stages with a moved parameter; None if a stage's parameter OBJECTS were exchanged"""
-        out = []
-        for k, (stage, _) in enumerate(self.stage_params):
-            cur = list(stage.params)
-            if [id(p) for p in cur] != self.ids[k]:
-                return None
-            vers = [p._ver for p in cur]
-            if vers != self.seen[k]:
-                out.append(stage)
-                self.seen[k] = vers
+        """stages with a moved parameter; None if parameter OBJECTS were exchanged somewhere
+        (select_params, update_params): the plan is rebuilt by the ordinary path then"""
+        if ParamSet.struct_clock != self.struct_clock:
+            return None
+        stages = self.pipeline._stages
+        out, seen = [], self.seen
+        for i, (p, k) in enumerate(self.flat):
+            v = p._ver
+            if v != seen[i]:
+                seen[i] = v
+                if stages[k] not in out:
+                    out.append(stages[k])
         return out
 
     def run(self):
@@ -179,5 +216,4 @@ class FastPlan:
         block = DeviceMapBlock(eng, self.with_errors)
         eng._out_block = weakref.ref(block)
         self.pipeline._containers_stale = True
-        maps = [Map.device_backed(n, self.binning, block, 1 << i) for i, n in enumerate(self.names)]
-        return MapSet(maps, name=self.pipeline.name)
+        return DeviceMapSet(self.names, self.binning, block, self.pipeline.name)

@@ -245,6 +245,14 @@ class MapSet:
     def __contains__(self, name):
         return name in self.names
 
+    def total(self, name="total"):
+        """sum of all maps (what `sum(mapset)` gives), named"""
+        out = sum(self.maps)
+        if out is self.maps[0] and len(self.maps) == 1:
+            out = out._new(out._hist, out._var)
+        out.name = name
+        return out
+
     def combine_wildcard(self, expr):
         import fnmatch
 

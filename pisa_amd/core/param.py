@@ -271,7 +271,12 @@ class Param:
 
 
 class ParamSet(Sequence):
-    """Ordered set of `Param`s with name access (param.py:776-1600)."""
+    """Ordered set of `Param`s with name access (param.py:776-1600).
+
+    `ParamSet.struct_clock` counts structural changes (a Param object added, replaced) of ALL sets
+    of the process: merged views (`Pipeline.params`) and evaluation plans are rebuilt when it moved."""
+
+    struct_clock = 0
 
     def __init__(self, *args):
         params = []
@@ -289,6 +294,7 @@ class ParamSet(Sequence):
             raise ValueError("duplicate parameter names: %s" % sorted(n for n in names if names.count(n) > 1))
         object.__setattr__(self, "_params", params)
         object.__setattr__(self, "normalize_values", True)
+        object.__setattr__(self, "_index", None)   # name -> position, rebuilt after structural changes
 
     # sequence protocol
     def __len__(self):
@@ -304,23 +310,37 @@ class ParamSet(Sequence):
 
     def __contains__(self, item):
         name = item.name if isinstance(item, Param) else item
-        return name in self.names
+        return self._pos(name) is not None
+
+    def _pos(self, name):
+        idx = self._index
+        if idx is None or len(idx) != len(self._params):
+            idx = {p.name: i for i, p in enumerate(self._params)}
+            object.__setattr__(self, "_index", idx)
+        i = idx.get(name)
+        if i is not None and self._params[i].name == name:
+            return i
+        # the list was changed in place (replace / update): rebuild once
+        idx = {p.name: i for i, p in enumerate(self._params)}
+        object.__setattr__(self, "_index", idx)
+        return idx.get(name)
 
     def __getattr__(self, attr):
         if attr.startswith("_"):
             raise AttributeError(attr)
-        try:
-            return self._params[self.names.index(attr)]
-        except ValueError:
+        i = self._pos(attr)
+        if i is None:
             raise AttributeError("no parameter named '%s'" % attr)
+        return self._params[i]
 
     def __setattr__(self, attr, val):
         if attr in self.__dict__ or attr in type(self).__dict__:
             object.__setattr__(self, attr, val)
             return
-        try:
-            self._params[self.names.index(attr)].value = val
-        except ValueError:
+        i = self._pos(attr)
+        if i is not None:
+            self._params[i].value = val
+        else:
             object.__setattr__(self, attr, val)
 
     names = property(lambda self: tuple(p.name for p in self._params))
@@ -336,10 +356,10 @@ class ParamSet(Sequence):
             name = name.name
         if isinstance(name, (int, np.integer)):
             return int(name)
-        try:
-            return self.names.index(name)
-        except ValueError:
+        i = self._pos(name)
+        if i is None:
             raise ValueError("'%s' is not a parameter of this set" % name)
+        return i
 
     def fix(self, x):
         for n in ([x] if isinstance(x, (str, Param)) else x):
@@ -355,21 +375,27 @@ class ParamSet(Sequence):
             if p.name in self.names:
                 raise ValueError("parameter '%s' already present" % p.name)
         self._params.extend(new)
+        ParamSet.struct_clock += 1
 
     def replace(self, new):
         self._params[self.index(new.name)] = new
+        ParamSet.struct_clock += 1
 
     def update(self, obj, existing_must_match=False, extend=True):
         """param.py:1221-1260"""
         new = [obj] if isinstance(obj, Param) else list(obj)
         for p in new:
-            if p.name in self.names:
-                if existing_must_match and p._hashable() != self[p.name]._hashable():
+            i = self._pos(p.name)
+            if i is not None:
+                if existing_must_match and p._hashable() != self._params[i]._hashable():
                     raise ValueError("Param '%s' specified in multiple stages with different values"
                                      % p.name)
-                self._params[self.index(p.name)] = p
+                if self._params[i] is not p:
+                    self._params[i] = p
+                    ParamSet.struct_clock += 1
             elif extend:
                 self._params.append(p)
+                ParamSet.struct_clock += 1
 
     def reset_all(self):
         for p in self._params:

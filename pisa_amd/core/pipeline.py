@@ -126,9 +126,15 @@ class Pipeline:
     # -- params ----------------------------------------------------------------------
     @property
     def params(self):
+        """merged ParamSet of all stages (same Param objects); rebuilt only when a stage's
+        selected parameter objects changed (select_params / update_params)"""
+        hit = self.__dict__.get("_params_cache")
+        if hit is not None and hit[0] == ParamSet.struct_clock:
+            return hit[1]
         params = ParamSet()
         for s in self._stages:
             params.update(s.params, existing_must_match=False, extend=True)
+        self.__dict__["_params_cache"] = (ParamSet.struct_clock, params)
         return params
 
     @property

@@ -131,7 +131,20 @@ class Quantity:
                         units)
 
     def m_as(self, units):
-        return self.to(units).magnitude
+        # same arithmetic as `to(units).magnitude`, without building the intermediate Quantity
+        if isinstance(units, str):
+            units = ureg.parse_units(units)
+        elif isinstance(units, Quantity):
+            units = units.units
+        mine = self._u
+        if units is mine:
+            return self._m
+        if units.dims != mine.dims:
+            raise DimensionalityError("Cannot convert from '%s' to '%s'" % (mine, units))
+        factor = mine.scale / units.scale
+        if factor == 1.0:
+            return self._m
+        return np.asarray(self._m) * factor if not np.isscalar(self._m) else self._m * factor
 
     def ito(self, units):
         q = self.to(units)

@@ -31,7 +31,11 @@ EXAMPLE2D = dict(mins=[np.log(5.0), -1.0], maxs=[np.log(100.0), 1.0], nbins=[10,
 # a fine analysis binning (40 x 40 x 3 = 4800 bins): too large for LDS accumulators
 FINE3D = dict(mins=[np.log(5.0), -1.0, -0.5], maxs=[np.log(100.0), 1.0, 2.5], nbins=[40, 40, 3],
               log=[True, False, False])
-BINNINGS = dict(dragon=DRAGON, example2d=EXAMPLE2D, fine3d=FINE3D)
+# settings/binning/example.cfg reco_binning (10 x 10 x 2): same bin populations as the pipeline's
+# pid = -1 / +1 in edges [-1000, 0, 1000] with this module's pid = 0 / 1
+EXAMPLE3D = dict(mins=[np.log(5.0), -1.0, -0.5], maxs=[np.log(100.0), 1.0, 1.5], nbins=[10, 10, 2],
+                 log=[True, False, False])
+BINNINGS = dict(dragon=DRAGON, example2d=EXAMPLE2D, fine3d=FINE3D, example3d=EXAMPLE3D)
 
 LIVETIME_S = 2.5 * 365 * 86400.0  # 2.5 common_year (example.cfg aeff.livetime)
 
