@@ -159,6 +159,12 @@ def lds_bank_order(obin, window=4096, banks=32, per=2):
     return perm
 
 
+def local_slices(sizes, rank, world_size):
+    """[(lo, hi)] of this rank's shard of every container (`sizes` = events per container): the
+    partition `HotPathEngine` uses -- contiguous, equal to within one event, disjoint, complete"""
+    return [shard_bounds(int(n), rank, world_size) for n in sizes]
+
+
 LIMB_BITS, LIMB_LSB, N_LIMBS = 32, 116, 6
 
 
@@ -228,9 +234,8 @@ class HotPathEngine:
                    and self.n_bins < 0xFFFF)
         self.index16 = index16
         self.n_local = 0
-        for c in containers:
-            n = len(c["true_energy"])
-            lo, hi = shard_bounds(n, rank, world_size)
+        shards = local_slices([len(c["true_energy"]) for c in containers], rank, world_size)
+        for c, (lo, hi) in zip(containers, shards):
             sl = slice(lo, hi)
             self._slices.append((lo, hi))
             d = _lib.Container()

@@ -97,3 +97,95 @@ def test_single_rank_equals_multi_rank_bits():
         assert seen == len(w)
         parts.append(limbs_to_float(tot))
     assert len(set(parts)) == 1 and parts[0] == limbs_to_float(full) == math.fsum(w)
+
+
+# ---- the engine's OWN multi-rank control flow (sharding, eval -> accumulate -> allreduce -> tail)
+#      on CPU ranks: only the two kernels are replaced by host stand-ins
+def _toy_containers():
+    rs = np.random.RandomState(5)
+    out = []
+    for k, n in enumerate((1001, 7, 640, 1)):      # ragged sizes, one container smaller than the world
+        out.append(dict(true_energy=rs.rand(n), w0=rs.rand(n) * 10 ** (rs.rand(n) * 12 - 6),
+                        bins=rs.randint(0, 6, size=n), sign=-1.0 if k == 2 else 1.0))
+    return out
+
+
+def _make_cpu_engine(rank, world):
+    from types import SimpleNamespace
+
+    from pisa_amd.engine import HotPathEngine, float_to_limbs, limbs_to_float, local_slices
+
+    class CpuEngine(HotPathEngine):
+        """HotPathEngine with its device kernels replaced: `accumulate` sums this rank's shard in
+        exact fixed point on the host, `_tail` decodes the (all-reduced) limbs and evaluates a chi2.
+        `eval`, `allreduce` and the sharding rule are the product's own code."""
+
+        def __init__(self):  # pylint: disable=super-init-not-called
+            self.dev = torch.device("cpu")
+            self.rank, self.world_size, self.group, self._rccl = rank, world, None, None
+            self.containers = _toy_containers()
+            self._slices = local_slices([len(c["w0"]) for c in self.containers], rank, world)
+            self.n_bins = 6
+            self.ws = SimpleNamespace(limbs=torch.zeros((len(self.containers), 6, 2, 6), dtype=torch.int64))
+            self.data = np.full(6, 3.0)
+            self.metric_out = torch.zeros(1, dtype=torch.float64)
+            self._out_block = None
+            self.tail_calls = 0
+
+        def accumulate(self, params=None):
+            acc = np.zeros((len(self.containers), 6, 2, 6), dtype=object)
+            for ci, (c, (lo, hi)) in enumerate(zip(self.containers, self._slices)):
+                w = c["sign"] * c["w0"][lo:hi] * (1.0 + params * c["true_energy"][lo:hi])
+                for x, b in zip(w, c["bins"][lo:hi]):
+                    for j, v in enumerate(float_to_limbs(float(x))):
+                        acc[ci, b, 0, j] += v
+                    for j, v in enumerate(float_to_limbs(float(x) * float(x))):
+                        acc[ci, b, 1, j] += v
+            self.ws.limbs.copy_(torch.tensor(acc.astype(np.int64)))
+
+        def _tail(self, kind, out):
+            self.tail_calls += 1
+            lim = self.ws.limbs
+            hist = np.array([[limbs_to_float(lim[c, b, 0].tolist()) for b in range(6)]
+                             for c in range(lim.shape[0])])
+            total = hist.sum(axis=0)
+            out[0] = float(np.sum((self.data - total) ** 2))
+            self.hist = hist
+            return out
+
+    return CpuEngine()
+
+
+def _engine_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng = _make_cpu_engine(rank, world)
+    vals = [float(eng.eval(p, "chi2")[0]) for p in (0.0, 0.37, 1.9)]
+    assert eng._rccl is False          # gloo group: all ranks agreed on torch.distributed
+    assert eng.tail_calls == 3
+    n_local = torch.tensor([sum(hi - lo for lo, hi in eng._slices)], dtype=torch.int64)
+    dist.all_reduce(n_local)
+    # every rank holds the same maps and the same metric after the all-reduce
+    mine = torch.tensor(vals + list(eng.hist.ravel()), dtype=torch.float64)
+    ref = mine.clone()
+    dist.broadcast(ref, src=0)
+    assert torch.equal(mine, ref)
+    if rank == 0:
+        np.save(out_path, np.array(vals + [float(n_local.item())] + list(eng.hist.ravel())))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_engine_eval_control_flow_on_gloo_ranks(tmp_path, world):
+    """HotPathEngine.eval / .allreduce / the shard partition run by `world` CPU processes give,
+    bit for bit, what a single rank gives (the all-reduce adds integers)."""
+    out = str(tmp_path / "eng.npy")
+    mp.spawn(_engine_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    res = np.load(out)
+    single = _make_cpu_engine(0, 1)
+    want = [float(single.eval(p, "chi2")[0]) for p in (0.0, 0.37, 1.9)]
+    assert single._rccl is None        # world_size 1: no collective at all
+    assert res[3] == sum(len(c["w0"]) for c in _toy_containers())
+    np.testing.assert_array_equal(res[:3], want)
+    np.testing.assert_array_equal(res[4:], single.hist.ravel())
