@@ -437,6 +437,15 @@ int pisa_hip_flux_2d(const pisa_hip_flux_table *h_table, const double *d_true_en
                      const double *d_true_coszen, int64_t n, double *d_nu_flux,
                      double *d_nubar_flux, int32_t *d_status, void *stream);
 
+/* `hist.apply_function` with a binned calc_mode (pisa/stages/utils/hist.py:132-160):
+ *   hist = (unc*w) @ T, sumw2 = (unc*w)^2 @ T, bin_unc2 = (unc^2*w) @ T
+ * d_weights[n_calc], d_unc_weights[n_calc] (NULL = 1); T = `hist_transform` (:69-84, event counts
+ * per (calc bin, output bin)) given by its non-zeros grouped by output bin: d_ptr[n_out+1],
+ * d_col[nnz] (calc bin), d_val[nnz] (count).  Outputs [n_out], any may be NULL. */
+int pisa_hip_transform_apply(const double *d_weights, const double *d_unc_weights, const int32_t *d_ptr,
+                             const int32_t *d_col, const double *d_val, int64_t n_out, double *d_hist,
+                             double *d_sumw2, double *d_bin_unc2, void *stream);
+
 /* Refresh of the fused kernel's folded flux column after a flux stage rewrote `nu_flux`
  * (flux stages write container['nu_flux'], pisa/stages/flux/barr_simple.py:100; the reference then
  * multiplies it in every evaluation, prob3.py:621-622):

@@ -137,6 +137,8 @@ class FastPlan:
         aeff = [s for s in stages if s.service_name == "aeff" and s.stage_name == "aeff"]
         if len(osc) != 1 or len(aeff) != 1 or osc[0].grid is None or hist._engine is None:
             return None
+        if osc[0].tomography_type is not None:
+            return None   # may rebuild the layer plan inside _matrices(): ordinary path only
         if hist._engine.world_size > 1 and hist._engine.n_bins * len(hist._engine.cont) > K.FINALIZE_METRIC_MAX:
             return None
         key = pipeline.output_key

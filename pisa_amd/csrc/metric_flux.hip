@@ -310,6 +310,60 @@ fold_flux_kernel(const double2 *__restrict__ flux, const int64_t *__restrict__ p
 }
 }  // namespace pisa
 
+
+namespace pisa {
+// hist.apply_function with a binned calc_mode (pisa/stages/utils/hist.py:132-160):
+//   hist = (unc*w) @ T,  sumw2 = (unc*w)^2 @ T,  bin_unc2 = (unc^2*w) @ T
+// with T[i][j] = number of events in calc bin i and output bin j (`hist_transform`, :69-84).  T is
+// kept as its non-zeros, grouped by OUTPUT bin (CSR over j): one workgroup per output bin, every
+// thread sums the entries t, t+256, ... in index order, fixed reduction tree => reproducible.
+__global__ void __launch_bounds__(256)
+transform_apply_kernel(const double *__restrict__ w, const double *__restrict__ unc,
+                       const int32_t *__restrict__ ptr, const int32_t *__restrict__ col,
+                       const double *__restrict__ val, double *__restrict__ hist,
+                       double *__restrict__ sumw2, double *__restrict__ bin_unc2) {
+    __shared__ double s[3][256];
+    const int j = blockIdx.x;
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int k = ptr[j] + threadIdx.x; k < ptr[j + 1]; k += 256) {
+        const int i = col[k];
+        const double u = unc ? unc[i] : 1.0, wi = w[i], t = val[k];
+        const double uw = u * wi;
+        a += uw * t;
+        b += (uw * uw) * t;
+        c += ((u * u) * wi) * t;
+    }
+    s[0][threadIdx.x] = a; s[1][threadIdx.x] = b; s[2][threadIdx.x] = c;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            s[0][threadIdx.x] += s[0][threadIdx.x + off];
+            s[1][threadIdx.x] += s[1][threadIdx.x + off];
+            s[2][threadIdx.x] += s[2][threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (hist) hist[j] = s[0][0];
+        if (sumw2) sumw2[j] = s[1][0];
+        if (bin_unc2) bin_unc2[j] = s[2][0];
+    }
+}
+}  // namespace pisa
+
+PISA_API int pisa_hip_transform_apply(const double *d_weights, const double *d_unc_weights,
+                                      const int32_t *d_ptr, const int32_t *d_col, const double *d_val,
+                                      int64_t n_out, double *d_hist, double *d_sumw2, double *d_bin_unc2,
+                                      void *stream) {
+    if (n_out < 0 || n_out > 0x7FFFFFFF) return PISA_HIP_ERR_INVALID;
+    if (n_out == 0) return PISA_HIP_OK;
+    if (!d_weights || !d_ptr || !d_col || !d_val) return PISA_HIP_ERR_INVALID;
+    hipLaunchKernelGGL(transform_apply_kernel, dim3((unsigned)n_out), dim3(256), 0, as_stream(stream),
+                       d_weights, d_unc_weights, d_ptr, d_col, d_val, d_hist, d_sumw2, d_bin_unc2);
+    PISA_CHECK_LAUNCH("transform_apply_kernel");
+    return PISA_HIP_OK;
+}
+
 PISA_API int pisa_hip_fold_flux(const double *d_flux, const int64_t *d_perm, const double *d_static_w,
                                 int64_t n, int32_t layout, double *d_out, void *stream) {
     if (n < 0 || (layout != 0 && layout != 1)) return PISA_HIP_ERR_INVALID;

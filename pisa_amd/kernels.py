@@ -213,6 +213,19 @@ def histogram_regular(sample, weights, binning, averaged=False):
     return out
 
 
+def transform_apply(weights, unc_weights, ptr, col, val, n_out, errors=True):
+    """(hist, sumw2, bin_unc2) = weights-in-calc-bins applied to a `hist_transform` given as CSR over
+    the output bins (see pisa_hip_transform_apply)"""
+    lib = _lib.lib()
+    dev = weights.device
+    hist = torch.empty(n_out, dtype=F8, device=dev)
+    sumw2 = torch.empty(n_out, dtype=F8, device=dev) if errors else None
+    unc2 = torch.empty(n_out, dtype=F8, device=dev) if errors else None
+    _lib.check(lib.pisa_hip_transform_apply(_ptr(weights), _ptr(unc_weights), _ptr(ptr), _ptr(col), _ptr(val),
+                                            int(n_out), _ptr(hist), _ptr(sumw2), _ptr(unc2), _stream()))
+    return hist, sumw2, unc2
+
+
 def event_indices(sample, binning):
     """flat bin index (int32, -1 outside) of every event in a regular binning"""
     lib = _lib.lib()

@@ -89,8 +89,7 @@ class Layers:
         # as in the reference, `rhos_unweighted` is NOT touched: a following setElecFrac
         # (which prob3.compute_function always issues, prob3.py:533) re-derives `rhos` from
         # the unscaled densities (layers.py:433-439), i.e. in this version of the reference
-        # the scaling does not reach the propagation.  The prob3 stage of this build
-        # therefore refuses tomography_type instead of reproducing that.
+        # the scaling does not reach the propagation (see `prob3._apply_tomography`).
 
     def earth_struct(self):
         """`pisa_hip_earth` block for the C ABI."""

@@ -45,8 +45,8 @@ class hist(Stage):  # pylint: disable=invalid-name
         else:
             assert self.apply_mode == self.data["output_binning"]
         if isinstance(self.calc_mode, MultiDimBinning):
-            raise NotImplementedError("binned calc_mode (hist_transform) is not part of this build; "
-                                      "use calc_mode = events")
+            self._setup_transforms()
+            return
         # regularised binning + per-container sample columns (device), once
         self._samples = {}
         for container in self.data.containers:
@@ -57,6 +57,56 @@ class hist(Stage):  # pylint: disable=invalid-name
         self._reg_binning = binning
         self.data["regularized_output_binning"] = binning
         self._engine = None
+
+    # ------------------------------------------------------------------ binned calc_mode
+    def _setup_transforms(self):
+        """hist.py:69-84: `hist_transform[i, j]` = number of events in calc bin i and output bin j
+        (the histogram of the events in the joint binning calc_mode + apply_mode).  Kept dense in
+        the container, as the reference does, and as its non-zeros grouped by output bin for
+        `pisa_hip_transform_apply`."""
+        assert len(set(self.calc_mode.names) & set(self.apply_mode.names)) == 0, \
+            "calc_mode and apply_mode must not share dimensions"
+        n_calc, n_out = self.calc_mode.size, self.apply_mode.size
+        self._csr = {}
+        for container in self.data.containers:
+            container.representation = "events"
+            getcol = lambda n, log, c=container: (np.log(c[n]) if log else c[n])  # noqa: E731
+            b_calc, c_calc = regularized(self.calc_mode, getcol)
+            b_out, c_out = regularized(self.apply_mode, getcol)
+            i = K.event_indices([K.to_device(np.asarray(x, dtype=FTYPE)) for x in c_calc], b_calc).long()
+            j = K.event_indices([K.to_device(np.asarray(x, dtype=FTYPE)) for x in c_out], b_out).long()
+            ok = (i >= 0) & (j >= 0)
+            keys, counts = torch.unique(j[ok] * n_calc + i[ok], return_counts=True)   # sorted: by j, then i
+            col = (keys % n_calc).to(torch.int32).contiguous()
+            rows = keys // n_calc
+            ptr = torch.zeros(n_out + 1, dtype=torch.int64, device=keys.device)
+            ptr[1:] = torch.cumsum(torch.bincount(rows, minlength=n_out), 0)
+            val = counts.to(torch.float64).contiguous()
+            self._csr[container.name] = (ptr.to(torch.int32).contiguous(), col, val)
+            dense = torch.zeros(n_calc * n_out, dtype=torch.float64, device=keys.device)
+            dense[(keys % n_calc) * n_out + rows] = val
+            container.representation = self.calc_mode
+            container["hist_transform"] = dense.view(n_calc, n_out)
+
+    def _apply_transforms(self):
+        """hist.py:132-160"""
+        if self.unweighted:
+            raise NotImplementedError("Unweighted hist only implemented in event-wise calculation")
+        sumw2 = self.error_method == "sumw2"
+        for container in self.data.containers:
+            container.representation = self.calc_mode
+            weights = container.device("weights")
+            if "astro_weights" in container.keys:
+                weights = weights + container.device("astro_weights")
+            unc = container.device("unc_weights") if self.apply_unc_weights else None
+            ptr, col, val = self._csr[container.name]
+            h, s2, u2 = K.transform_apply(weights.contiguous(), unc, ptr, col, val, self.apply_mode.size,
+                                          errors=sumw2)
+            container.representation = self.apply_mode
+            container["weights"] = h
+            if sumw2:
+                container["errors"] = torch.sqrt(s2)
+                container["bin_unc2"] = u2
 
     # ------------------------------------------------------------------ fused
     def _find_prob3(self):
@@ -141,6 +191,10 @@ class hist(Stage):  # pylint: disable=invalid-name
 
     # ------------------------------------------------------------------ apply
     def apply_function(self):
+        if isinstance(self.calc_mode, MultiDimBinning):
+            self.fused_last_eval = False
+            self._apply_transforms()
+            return
         self.fused_last_eval = self._fused()
         if self.fused_last_eval:
             return

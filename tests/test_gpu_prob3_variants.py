@@ -12,11 +12,14 @@ pytestmark = pytest.mark.gpu
 AC = dict(rtol=PROB3_RTOL, atol=PROB3_ATOL)
 
 
-def _cfg_with(tmp_path, extra_lines, name="variant.cfg", base="settings/pipeline/osc_example.cfg"):
+def _cfg_with(tmp_path, extra_lines, name="variant.cfg", base="settings/pipeline/osc_example.cfg", replace=None):
     """the reference's cfg text + extra keys appended to its last section ([osc.prob3])"""
     from pisa_amd.utils.resources import find_resource
 
     text = open(find_resource(base)).read()
+    for old, new in (replace or {}).items():
+        assert old in text
+        text = text.replace(old, new)
     path = tmp_path / name
     path.write_text(text + "\n" + "\n".join(extra_lines) + "\n")
     return str(path)
@@ -250,3 +253,54 @@ def test_linear_energy_calc_grid_takes_unfused_path(oracle, tmp_path):
         sample = [np.log(c["reco_energy"]), c["reco_coszen"], c["pid"]]
         want = oracle.histogram_regular(sample, w, omin, omax, onb).reshape(ob.shape)
         np.testing.assert_allclose(maps[c.name].hist, want, rtol=1e-11, atol=1e-300, err_msg=c.name)
+
+
+def test_prob3_tomography_follows_the_reference_call_for_call(oracle, tmp_path):
+    """prob3.py:278-300, 378-395, 519-536 + layers.py:291-306, 411-439.  In this version of the
+    reference `Layers.scaling` is followed by `setElecFrac`, which re-derives the shell densities
+    from the UNSCALED table: the tomography parameters are validated (Earth-model check, sign
+    assertions) but do not move the oscillograms.  The product does the same."""
+    from pisa_amd.core.pipeline import Pipeline
+    from pisa_amd.core.units import ureg
+
+    prem5 = tmp_path / "osc"
+    prem5.mkdir()
+    (prem5 / "PREM_5layer_tomo.dat").write_text(
+        "0.0 13.0\n1221.5 13.0\n3480.0 10.96\n5701.0 5.03\n6151.0 3.7\n6371.0 2.5\n")
+    import os
+
+    os.environ["PISA_RESOURCES"] = str(tmp_path)
+    try:
+        five = {"param.earth_model = osc/PREM_12layer.dat": "param.earth_model = osc/PREM_5layer_tomo.dat"}
+        ref_maps = Pipeline(_cfg_with(tmp_path, [], name="plain5.cfg", replace=five)).get_outputs()
+        pipe = Pipeline(_cfg_with(tmp_path, [
+            "tomography_type = mass_of_core_w_constrain", "param.core_density_scale = 1.1",
+            "param.core_density_scale.fixed = False", "param.core_density_scale.range = [0.5, 1.5]"],
+            name="tomo.cfg", replace=five))
+        maps = pipe.get_outputs()
+        osc = pipe["prob3"]
+        # scaling() saw the factors ...
+        want = np.concatenate(([1.0], np.array([2.5, 3.7, 5.03, 10.96, 13.0, 13.0]) * osc.tomography_params.scaling_array))
+        np.testing.assert_allclose(osc.scaled_rhos, want, rtol=1e-14)
+        assert osc.tomography_params.scaling_array[3] == 1.1
+        # ... and setElecFrac restored the Ye-weighted unscaled table, as in the reference
+        for a, b in zip(maps, ref_maps):
+            np.testing.assert_array_equal(a.hist, b.hist)
+        pipe.params.core_density_scale.value = 0.9 * ureg.dimensionless
+        n = len(osc.calc_times) if osc.profile else None
+        maps2 = pipe.get_outputs()
+        for a, b in zip(maps2, ref_maps):
+            np.testing.assert_array_equal(a.hist, b.hist)
+        del n
+        # one global factor works with any Earth model; the core types insist on the five-shell Earth
+        p12 = Pipeline(_cfg_with(tmp_path, ["tomography_type = mass_of_earth", "param.density_scale = 1.2",
+                                            "param.density_scale.fixed = True"], name="mass.cfg"))
+        _check(p12.get_outputs(), _oracle_maps(oracle, p12.output_binning, STD))
+        with pytest.raises(ValueError):
+            Pipeline(_cfg_with(tmp_path, ["tomography_type = mass_of_core_wo_constrain",
+                                          "param.core_density_scale = 1.0", "param.innermantle_density_scale = 1.0",
+                                          "param.middlemantle_density_scale = 1.0"], name="bad.cfg"))
+        with pytest.raises(ValueError):
+            Pipeline(_cfg_with(tmp_path, ["tomography_type = nonsense"], name="bad2.cfg"))
+    finally:
+        del os.environ["PISA_RESOURCES"]
