@@ -1,9 +1,10 @@
 """Per-bin scale factors from hypersurface fits to discrete systematics sets
 (counterpart of pisa/stages/discr_sys/hypersurfaces.py:39-257).
 
-`compute_function` evaluates the hyperplanes for the current detector-systematics
-parameters (a [n_bins x n_params] product per linked container class, on the host:
-it depends only on parameters); `apply_function` scales the binned `weights`,
+`compute_function` evaluates the hypersurfaces (data-release hyperplanes or `fit_hypersurfaces`
+JSON files; optional uncertainty from the fit covariance, optional fluctuation) for the current
+detector-systematics parameters -- per linked container class, on the host: it depends only on
+parameters and a few hundred bins; `apply_function` scales the binned `weights`,
 `errors` and `bin_unc2` on the device (`pisa_hip_bin_scale`).
 """
 import ast
@@ -23,11 +24,15 @@ __all__ = ["hypersurfaces"]
 class hypersurfaces(Stage):  # pylint: disable=invalid-name
     def __init__(self, fit_results_file, propagate_uncertainty=False, interpolated=False,
                  links=None, fluctuate=False, fluctuate_seed=12345, **std_kwargs):
-        if interpolated or fluctuate or propagate_uncertainty:
-            raise NotImplementedError("interpolated / fluctuated hypersurfaces and their uncertainty "
-                                      "propagation are not part of this build")
+        if interpolated:
+            raise NotImplementedError("interpolated hypersurfaces (hyper_interpolator.py) are not part "
+                                      "of this build")
         self.fit_results_file = fit_results_file
-        self.propagate_uncertainty = False
+        self.propagate_uncertainty = bool(propagate_uncertainty)
+        self.fluctuate = bool(fluctuate)
+        self.fluctuate_seed = fluctuate_seed
+        if self.fluctuate:
+            assert self.fluctuate_seed is not None
         self.hypersurfaces = hs.load_hypersurfaces(fit_results_file,
                                                    expected_binning=std_kwargs["calc_mode"])
         self.hypersurface_param_names = list(self.hypersurfaces.values())[0].param_names
@@ -50,6 +55,8 @@ class hypersurfaces(Stage):  # pylint: disable=invalid-name
         self._link()
         for container in self.data:
             container["hs_scales"] = np.empty(container.size, dtype=FTYPE)
+            if self.propagate_uncertainty:
+                container["hs_scales_uncertainty"] = np.empty(container.size, dtype=FTYPE)
         for container in self.data:
             assert container.name in self.hypersurfaces, \
                 f"No match for map {container.name} found in the hypersurfaces"
@@ -58,11 +65,25 @@ class hypersurfaces(Stage):  # pylint: disable=invalid-name
     def compute_function(self):
         self._link()
         param_values = {n: float(self.params[n].m) for n in self.hypersurface_param_names}
+        # the same fluctuation on every call (:176-178)
+        rs = np.random.RandomState(self.fluctuate_seed) if self.fluctuate else None
         for container in self.data:
-            scales = self.hypersurfaces[container.name].evaluate(param_values).reshape(container.size)
-            scales[~np.isfinite(scales)] = 1.0  # empty bins (:201-208)
+            surface = self.hypersurfaces[container.name]
+            if self.fluctuate:
+                surface = surface.fluctuate(random_state=rs)
+            if self.propagate_uncertainty:
+                scales, unc = surface.evaluate(param_values, return_uncertainty=True)
+                scales, unc = scales.reshape(container.size), unc.reshape(container.size)
+            else:
+                scales = surface.evaluate(param_values).reshape(container.size)
+            empty = ~np.isfinite(scales)     # empty bins (:201-210)
+            scales[empty] = 1.0
             container["hs_scales"] = scales
             container.mark_valid("hs_scales")
+            if self.propagate_uncertainty:
+                unc[empty] = 0.0
+                container["hs_scales_uncertainty"] = unc
+                container.mark_valid("hs_scales_uncertainty")
         self.data.unlink_containers()
 
     def apply_function(self):
@@ -81,7 +102,17 @@ class hypersurfaces(Stage):  # pylint: disable=invalid-name
                 c.set_mirrored(key, out[i], host[i])
 
         if self.error_method == "sumw2":
-            if self.data.representation != "events":
+            if self.data.representation == "events":
+                pass                                       # error propagation skipped in events mode (:243-246)
+            elif self.propagate_uncertainty:
+                # errors = weights * hs_scales_uncertainty, with the UNSCALED weights (:248-249)
+                w = torch.stack([c.device("weights") for c in conts])
+                u = torch.stack([c.device("hs_scales_uncertainty") for c in conts])
+                out = K.bin_scale(w.reshape(-1), u.reshape(-1), floor=None).reshape(w.shape)
+                host = out.cpu().numpy()
+                for i, c in enumerate(conts):
+                    c.set_mirrored("errors", out[i], host[i])
+            else:
                 scaled("errors", None)                     # errors *= hs_scales (:251)
             if all("bin_unc2" in c.keys for c in conts):
                 scaled("bin_unc2", 0.0)                    # clip(bin_unc2 * hs_scales, 0, inf) (:254-256)

@@ -1,52 +1,246 @@
-"""Hypersurface fits of discrete-systematics sets (the part of
-pisa/utils/hypersurface/hypersurface.py that the published IceCube 3-year
-analysis chain uses): the CSV files of the public data release
-(`_load_hypersurfaces_data_release`, :2065-2173) with linear terms
-(`linear_hypersurface_func`, :81-100) and `Hypersurface.evaluate` (:356-461) for
-them.  Fit files written by `fit_hypersurfaces` (json), interpolated
-hypersurfaces and uncertainty propagation (needs the fit covariance, which the
-data release does not contain) are not part of this build.
+"""Hypersurface fits of discrete-systematics sets (counterpart of the evaluation side of
+pisa/utils/hypersurface/hypersurface.py; fitting -- `Hypersurface.fit`, `fit_hypersurfaces` -- is
+an offline tool outside the hot path and not part of this build).
+
+    scale[bin] = intercept[bin] + sum_p f_p(value_p - nominal_p; coefficients_p[bin])     (:430-433)
+    scale      = exp(scale)  if the fit was done in log mode                              (:435)
+
+with the functional forms of :81-205 (`linear`, `quadratic`, `exponential`,
+`exponential_scaled`, `logarithmic`), the uncertainty of the scale from the per-bin fit
+covariance (:437-470), and `fluctuate` (:1285-1322).
+
+Sources (`load_hypersurfaces`, :1877-1964):
+* fit files written by `fit_hypersurfaces` -- JSON (optionally .bz2) holding
+  {map name: Hypersurface.serializable_state} (:1182-1215, 1529-1552);
+* the CSV hyperplanes of the public IceCube 3-year data release
+  (`_load_hypersurfaces_data_release`, :2065-2173): linear terms in the RAW parameter values
+  (`using_legacy_data`, :432).
+Interpolated hypersurfaces (hyper_interpolator.py) are not part of this build.
 """
+import bz2
+import copy
+import json
 from collections import OrderedDict
+from collections.abc import Mapping
 
 import numpy as np
 import pandas as pd
 
+from pisa_amd import FTYPE
 from pisa_amd.utils.resources import find_resource
 
-__all__ = ["Hypersurface", "load_hypersurfaces"]
+__all__ = ["Hypersurface", "HypersurfaceParam", "HYPERSURFACE_PARAM_FUNCTIONS", "load_hypersurfaces"]
+
+
+# functional forms: name -> (number of coefficients, f(p, *coeffts), gradient wrt the coefficients)
+def _lin(p, m):
+    return m * p
+
+
+def _lin_grad(p, m):
+    return np.broadcast_to(p, np.shape(m * p))[..., np.newaxis]
+
+
+def _quad(p, m1, m2):
+    return m1 * p + m2 * p ** 2
+
+
+def _quad_grad(p, m1, m2):
+    shape = np.shape(m1 * p)
+    return np.stack([np.broadcast_to(p, shape), np.broadcast_to(p ** 2, shape)], axis=-1)
+
+
+def _exp(p, b):
+    return np.exp(b * p) - 1.0
+
+
+def _exp_grad(p, b):
+    return (p * np.exp(b * p))[..., np.newaxis]
+
+
+def _exp_scaled(p, a, b):
+    return (a + 1.0) * (np.exp(b * p) - 1.0)
+
+
+def _exp_scaled_grad(p, a, b):
+    return np.stack([np.exp(b * p) - 1.0, (a + 1.0) * p * np.exp(b * p)], axis=-1)
+
+
+def _log(p, m):
+    return np.log(1 + m * p)
+
+
+def _log_grad(p, m):
+    return (p / (1 + m * p))[..., np.newaxis]
+
+
+HYPERSURFACE_PARAM_FUNCTIONS = OrderedDict([
+    ("linear", (1, _lin, _lin_grad)),
+    ("quadratic", (2, _quad, _quad_grad)),
+    ("exponential", (1, _exp, _exp_grad)),
+    ("exponential_scaled", (2, _exp_scaled, _exp_scaled_grad)),
+    ("logarithmic", (1, _log, _log_grad)),
+])
+
+
+class HypersurfaceParam:
+    """one systematic parameter of a hypersurface: functional form + per-bin coefficients
+    `fit_coeffts[binning..., num_fit_coeffts]` (hypersurface.py:1325-1583)"""
+
+    def __init__(self, name, func_name, fit_coeffts, nominal_value=0.0, fit_coeffts_sigma=None):
+        if func_name not in HYPERSURFACE_PARAM_FUNCTIONS:
+            raise ValueError("Hypersurface function '%s' not known; choose from %s"
+                             % (func_name, list(HYPERSURFACE_PARAM_FUNCTIONS)))
+        self.name, self.func_name = name, func_name
+        self.num_fit_coeffts, self._func, self._grad = HYPERSURFACE_PARAM_FUNCTIONS[func_name]
+        self.fit_coeffts = np.asarray(fit_coeffts, dtype=FTYPE)
+        assert self.fit_coeffts.shape[-1] == self.num_fit_coeffts
+        self.fit_coeffts_sigma = fit_coeffts_sigma
+        self.nominal_value = nominal_value
+
+    def _coeffts(self):
+        return [self.fit_coeffts[..., i] for i in range(self.num_fit_coeffts)]
+
+    def evaluate(self, param):
+        return self._func(param, *self._coeffts())
+
+    def gradient(self, param):
+        return self._grad(param, *self._coeffts())
+
+    @property
+    def serializable_state(self):
+        return OrderedDict(name=self.name, func_name=self.func_name, num_fit_coeffts=self.num_fit_coeffts,
+                           fit_coeffts=self.fit_coeffts.tolist(),
+                           fit_coeffts_sigma=None if self.fit_coeffts_sigma is None
+                           else np.asarray(self.fit_coeffts_sigma).tolist(),
+                           initial_fit_coeffts=None, fitted=True, fit_param_values=None,
+                           binning_shape=list(self.fit_coeffts.shape[:-1]),
+                           nominal_value=self.nominal_value, bounds=None, coeff_prior_sigma=None)
+
+    @classmethod
+    def from_state(cls, state):
+        return cls(state["name"], state["func_name"], np.asarray(state["fit_coeffts"], dtype=FTYPE),
+                   nominal_value=state.get("nominal_value", 0.0),
+                   fit_coeffts_sigma=state.get("fit_coeffts_sigma"))
 
 
 class Hypersurface:
-    """scale[bin] = intercept[bin] + sum_p gradient_p[bin] * value_p (raw parameter
-    values: `using_legacy_data`, hypersurface.py:432)."""
-
-    def __init__(self, binning, param_names, intercept, gradients):
+    def __init__(self, binning, params, intercept, log=False, fit_cov_mat=None, using_legacy_data=False):
         self.binning = binning
-        self.param_names = list(param_names)
-        self.intercept = np.asarray(intercept, dtype=np.float64).reshape(binning.shape)
-        self.gradients = OrderedDict(
-            (n, np.asarray(g, dtype=np.float64).reshape(binning.shape)) for n, g in zip(param_names, gradients))
-        self.using_legacy_data = True
+        self.params = OrderedDict((p.name, p) for p in params)
+        shape = binning.shape if binning is not None else np.shape(intercept)
+        self.intercept = np.asarray(intercept, dtype=FTYPE).reshape(shape)
+        for p in self.params.values():
+            p.fit_coeffts = p.fit_coeffts.reshape(tuple(shape) + (p.num_fit_coeffts,))
+        self.log = bool(log)
+        self.fit_cov_mat = None if fit_cov_mat is None else np.asarray(fit_cov_mat, dtype=FTYPE)
+        self.using_legacy_data = bool(using_legacy_data)
+
+    param_names = property(lambda self: list(self.params.keys()))
+    nominal_values = property(lambda self: OrderedDict((n, p.nominal_value) for n, p in self.params.items()))
+
+    @property
+    def num_fit_coeffts(self):
+        return int(1 + sum(p.num_fit_coeffts for p in self.params.values()))
+
+    @property
+    def fit_coeffts(self):
+        """all coefficients of all bins, [binning..., intercept + params' coefficients] (:1144-1157)"""
+        cols = [self.intercept]
+        for p in self.params.values():
+            cols += [p.fit_coeffts[..., i] for i in range(p.num_fit_coeffts)]
+        return np.stack(cols, axis=-1)
 
     def evaluate(self, param_values, return_uncertainty=False):
-        if return_uncertainty:
-            raise NotImplementedError("the data-release hyperplanes carry no fit covariance")
-        out = np.array(self.intercept, dtype=np.float64)
-        for name in self.param_names:  # same accumulation order as :430-433
+        """scale factors of all bins for one scalar value per parameter (:356-475, the all-bins
+        case the stage uses)"""
+        out = np.array(self.intercept, dtype=FTYPE)
+        deltas = OrderedDict()
+        for name, p in self.params.items():
             value = param_values[name]
             assert np.isscalar(value), "sys param values must be a scalar when evaluating all bins simultaneously"
-            out += self.gradients[name] * value
-        return out
+            deltas[name] = value if self.using_legacy_data else value - p.nominal_value
+            out += p.evaluate(deltas[name])
+        factors = np.exp(out) if self.log else out
+        if not return_uncertainty:
+            return factors
+        if self.fit_cov_mat is None:
+            raise ValueError("this hypersurface carries no fit covariance (e.g. the data-release hyperplanes)")
+        grad = np.full(out.shape + (self.num_fit_coeffts,), np.nan, dtype=FTYPE)
+        grad[..., 0] = 1.0     # intercept
+        i = 1
+        for name, p in self.params.items():
+            g = p.gradient(deltas[name])
+            for j in range(p.num_fit_coeffts):
+                grad[..., i] = g[..., j]
+                i += 1
+        if self.log:
+            grad = factors[..., np.newaxis] * grad
+        tj = np.einsum("...j,...kj->...k", grad, self.fit_cov_mat)
+        variance = np.einsum("...j,...j", tj, grad)
+        assert np.all(variance[np.isfinite(variance)] >= 0.0), "invalid covariance"
+        return factors, np.sqrt(variance)
+
+    def fluctuate(self, random_state=None):
+        """a copy with every bin's coefficients drawn from N(fit, covariance) (:1285-1322)"""
+        if self.fit_cov_mat is None:
+            raise ValueError("this hypersurface carries no fit covariance")
+        rs = random_state if random_state is not None else np.random.RandomState(12345)
+        new = copy.deepcopy(self)
+        coeffts = self.fit_coeffts
+        for idx in np.ndindex(*self.intercept.shape):
+            if np.all(np.isfinite(coeffts[idx])):
+                draw = rs.multivariate_normal(coeffts[idx], self.fit_cov_mat[idx])
+                new.intercept[idx] = draw[0]
+                n = 1
+                for p in new.params.values():
+                    for i in range(p.num_fit_coeffts):
+                        p.fit_coeffts[idx + (i,)] = draw[n]
+                        n += 1
+        return new
+
+    @property
+    def serializable_state(self):
+        """the keys `Hypersurface.from_state` of the reference reads (:1182-1283); fit bookkeeping
+        that only the fitter fills (`fit_maps_*`, `fit_chi2`, ...) is written as None"""
+        state = OrderedDict()
+        state["_initialized"] = True
+        state["binning"] = None if self.binning is None else getattr(self.binning, "serializable_state", None)
+        state["initial_intercept"] = None
+        state["log"] = self.log
+        state["intercept"] = self.intercept.tolist()
+        state["intercept_sigma"] = None
+        state["fit_complete"] = True
+        state["fit_info_stored"] = False
+        state["fit_maps_norm"] = state["fit_maps_smooth"] = state["fit_maps_raw"] = None
+        state["fit_chi2"] = None
+        state["fit_cov_mat"] = None if self.fit_cov_mat is None else self.fit_cov_mat.tolist()
+        state["fit_method"] = None
+        state["fit_pipeline_param_values"] = None
+        state["using_legacy_data"] = self.using_legacy_data
+        state["params"] = OrderedDict((n, p.serializable_state) for n, p in self.params.items())
+        return state
+
+    @classmethod
+    def from_state(cls, state, binning=None):
+        if not isinstance(state, Mapping):
+            state = _read_json(state)
+        params = [HypersurfaceParam.from_state(s) for s in state["params"].values()]
+        return cls(binning, params, np.asarray(state["intercept"], dtype=FTYPE), log=state.get("log", False),
+                   fit_cov_mat=state.get("fit_cov_mat"), using_legacy_data=state.get("using_legacy_data", False))
 
 
-def load_hypersurfaces(input_file, expected_binning=None):
-    """{map name: Hypersurface}; `input_file` = '<dir>/hyperplanes_*.csv[.bz2]'"""
-    assert isinstance(input_file, str)
-    if not (input_file.endswith("csv") or input_file.endswith("csv.bz2")):
-        raise NotImplementedError("only the data-release CSV hyperplanes are part of this build")
-    assert expected_binning is not None, "Must provide binning when loading data release hypersurfaces"
-    binning = expected_binning
+def _read_json(path):
+    path = find_resource(path)
+    opener = bz2.open if path.endswith(".bz2") else open
+    with opener(path, "rt") as fh:
+        return json.load(fh, object_pairs_hook=OrderedDict)
+
+
+def _load_data_release(input_file, binning):
+    """hypersurface.py:2065-2173: one CSV per map class, columns = bin midpoints, `offset`, one
+    gradient per parameter; evaluated with the RAW parameter values"""
+    assert binning is not None, "Must provide binning when loading data release hypersurfaces"
     files = OrderedDict([("nue_cc+nuebar_cc", "nue_cc"), ("numu_cc+numubar_cc", "numu_cc"),
                          ("nutau_cc+nutaubar_cc", "nutau_cc"), ("nu_nc+nubar_nc", "all_nc")])
     out = OrderedDict()
@@ -63,6 +257,30 @@ def load_hypersurfaces(input_file, expected_binning=None):
         else:
             assert param_names == table.columns.tolist(), \
                 "Mismatch between hypersurface params in different files"
-        out[map_name] = Hypersurface(binning, param_names, offset.values,
-                                     [table[n].values for n in param_names])
+        params = [HypersurfaceParam(n, "linear", table[n].values.reshape(binning.shape + (1,)))
+                  for n in param_names]
+        out[map_name] = Hypersurface(binning, params, offset.values, using_legacy_data=True)
     return out
+
+
+def load_hypersurfaces(input_file, expected_binning=None):
+    """{map name: Hypersurface} from a fit file (json / json.bz2) or from the data-release CSVs
+    ('<dir>/hyperplanes_*.csv[.bz2]'); hypersurface.py:1877-1964"""
+    assert isinstance(input_file, str)
+    if input_file.endswith("json") or input_file.endswith("json.bz2"):
+        data = _read_json(input_file)
+        assert isinstance(data, Mapping)
+        if "sys_list" in data:
+            raise NotImplementedError("hyperplane fit files of pre-hypersurface PISA versions "
+                                      "(_load_hypersurfaces_legacy) are not supported")
+        out = OrderedDict()
+        for map_name, state in data.items():
+            hsf = Hypersurface.from_state(state, binning=expected_binning)
+            if expected_binning is not None and hsf.intercept.shape != tuple(expected_binning.shape):
+                raise AssertionError("Incompatible binning: hypersurface %s, expected %s"
+                                     % (hsf.intercept.shape, expected_binning.shape))
+            out[map_name] = hsf
+        return out
+    if input_file.endswith("csv") or input_file.endswith("csv.bz2"):
+        return _load_data_release(input_file, expected_binning)
+    raise Exception("Unknown file format : %s" % input_file)

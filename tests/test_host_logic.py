@@ -327,3 +327,72 @@ def test_spline_prior_from_cfg(tmp_path):
     knots_deg = (np.array(d["knots"]) * ureg.parse_units(d["units"])).m_as("deg")
     np.testing.assert_array_equal(p.prior.knots.magnitude, knots_deg)
     assert p.prior_penalty("chi2") == -2 * splev(42.3, (knots_deg, np.array(d["coeffs"]), d["deg"]), ext=2)
+
+
+def test_hypersurface_forms_state_roundtrip_and_uncertainty(tmp_path):
+    """pisa/utils/hypersurface/hypersurface.py:81-205 (functional forms), 356-475 (evaluate with
+    the fit covariance), 1182-1283 (state round trip), 1285-1322 (fluctuate)."""
+    import json
+
+    from pisa_amd.utils.hypersurface import (HYPERSURFACE_PARAM_FUNCTIONS, Hypersurface, HypersurfaceParam,
+                                             load_hypersurfaces)
+
+    assert list(HYPERSURFACE_PARAM_FUNCTIONS) == ["linear", "quadratic", "exponential", "exponential_scaled",
+                                                  "logarithmic"]
+    rs = np.random.RandomState(3)
+    b = MultiDimBinning([OneDimBinning("reco_energy", num_bins=4, is_log=True, domain=[5.0, 80.0]),
+                         OneDimBinning("reco_coszen", num_bins=3, is_lin=True, domain=[-1, 1])])
+    shape = b.shape
+    params = [HypersurfaceParam("dom_eff", "linear", rs.randn(*shape, 1) * 0.1, nominal_value=1.0),
+              HypersurfaceParam("hole_ice", "quadratic", rs.randn(*shape, 2) * 0.05, nominal_value=25.0),
+              HypersurfaceParam("abs", "exponential", rs.randn(*shape, 1) * 0.1, nominal_value=0.0),
+              HypersurfaceParam("scat", "exponential_scaled", rs.randn(*shape, 2) * 0.1, nominal_value=1.0),
+              HypersurfaceParam("bulk", "logarithmic", np.abs(rs.randn(*shape, 1)) * 0.1, nominal_value=0.0)]
+    n_c = 1 + sum(p.num_fit_coeffts for p in params)
+    a = rs.randn(*shape, n_c, n_c) * 0.01
+    cov = np.einsum("...ij,...kj->...ik", a, a)
+    icpt = 1.0 + rs.randn(*shape) * 0.02
+    hsf = Hypersurface(b, params, icpt, log=False, fit_cov_mat=cov)
+    assert hsf.num_fit_coeffts == n_c == 8 and hsf.fit_coeffts.shape == shape + (8,)
+    vals = dict(dom_eff=1.07, hole_ice=22.0, abs=0.3, scat=0.9, bulk=0.5)
+    got, unc = hsf.evaluate(vals, return_uncertainty=True)
+    # by hand, bin by bin
+    c = {p.name: p.fit_coeffts for p in params}
+    d = {n: vals[n] - p.nominal_value for n, p in zip(vals, params)}
+    want = (icpt + c["dom_eff"][..., 0] * d["dom_eff"]
+            + c["hole_ice"][..., 0] * d["hole_ice"] + c["hole_ice"][..., 1] * d["hole_ice"] ** 2
+            + (np.exp(c["abs"][..., 0] * d["abs"]) - 1)
+            + (c["scat"][..., 0] + 1) * (np.exp(c["scat"][..., 1] * d["scat"]) - 1)
+            + np.log(1 + c["bulk"][..., 0] * d["bulk"]))
+    np.testing.assert_allclose(got, want, rtol=1e-14)
+    grad = np.stack([np.ones(shape), np.full(shape, d["dom_eff"]), np.full(shape, d["hole_ice"]),
+                     np.full(shape, d["hole_ice"] ** 2), d["abs"] * np.exp(c["abs"][..., 0] * d["abs"]),
+                     np.exp(c["scat"][..., 1] * d["scat"]) - 1,
+                     (c["scat"][..., 0] + 1) * d["scat"] * np.exp(c["scat"][..., 1] * d["scat"]),
+                     d["bulk"] / (1 + c["bulk"][..., 0] * d["bulk"])], axis=-1)
+    want_unc = np.sqrt(np.einsum("...i,...ij,...j", grad, cov, grad))
+    np.testing.assert_allclose(unc, want_unc, rtol=1e-12)
+    # at the nominal point only the intercept is left
+    np.testing.assert_allclose(hsf.evaluate({p.name: p.nominal_value for p in params}), icpt, rtol=1e-15)
+    # log mode exponentiates (and scales the gradient)
+    lg = Hypersurface(b, [HypersurfaceParam("dom_eff", "linear", c["dom_eff"], nominal_value=1.0)],
+                      icpt - 1.0, log=True, fit_cov_mat=cov[..., :2, :2])
+    f, u = lg.evaluate(dict(dom_eff=1.07), return_uncertainty=True)
+    np.testing.assert_allclose(f, np.exp(icpt - 1.0 + c["dom_eff"][..., 0] * 0.07), rtol=1e-14)
+    g2 = f[..., None] * np.stack([np.ones(shape), np.full(shape, 0.07)], axis=-1)
+    np.testing.assert_allclose(u, np.sqrt(np.einsum("...i,...ij,...j", g2, cov[..., :2, :2], g2)), rtol=1e-12)
+    # fit-file round trip through load_hypersurfaces
+    path = tmp_path / "fits.json"
+    path.write_text(json.dumps({"nue_cc+nuebar_cc": hsf.serializable_state, "nu_nc+nubar_nc": lg.serializable_state}))
+    loaded = load_hypersurfaces(str(path), expected_binning=b)
+    assert list(loaded) == ["nue_cc+nuebar_cc", "nu_nc+nubar_nc"] and loaded["nu_nc+nubar_nc"].log
+    g2_, u2_ = loaded["nue_cc+nuebar_cc"].evaluate(vals, return_uncertainty=True)
+    np.testing.assert_array_equal(g2_, got)
+    np.testing.assert_array_equal(u2_, unc)
+    # fluctuate: reproducible for a seed, different from the fit, same shape
+    f1 = hsf.fluctuate(np.random.RandomState(5)).evaluate(vals)
+    f2 = hsf.fluctuate(np.random.RandomState(5)).evaluate(vals)
+    np.testing.assert_array_equal(f1, f2)
+    assert np.abs(f1 - got).max() > 0
+    with pytest.raises(ValueError):
+        Hypersurface(b, [params[0]], icpt).evaluate(dict(dom_eff=1.0), return_uncertainty=True)
