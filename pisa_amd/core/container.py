@@ -407,8 +407,10 @@ class Container:
         if mode not in self.valid_translation_modes:
             raise ValueError("Unknown translation mode for variable '%s': '%s'!" % (key, mode))
         if from_map and to_map:
-            raise NotImplementedError("map -> map resampling is not part of this build")
-        if to_map:
+            if mode == "sum":
+                raise NotImplementedError("Map to Map in sum mode needs to integrate over bins.")
+            out = self.resample(key, src_representation, dest)
+        elif to_map:
             out = self.array_to_binned(key, src_representation, dest, averaged=(mode == "average"))
         elif mode == "sum":
             raise NotImplementedError("Translating %s to %s in 'sum' mode!" % (src_representation, dest))
@@ -426,6 +428,32 @@ class Container:
         self._add_data(key, out)
         self.validity[key][hash(dest)] = True
         self.validity[key][hash(src_representation)] = True
+
+    def resample(self, key, src_representation, dest_representation):
+        """map -> map (container.py:906-931 -> translation.resample, translation.py:49-85) on the
+        GPU: the old bins' centres are histogrammed, weighted with the old values, into the new
+        binning; a new bin that received more than one old bin takes their average, any other
+        one the old value looked up at its own centre."""
+        import torch
+
+        from pisa_amd import kernels as K
+
+        if src_representation.names != dest_representation.names:
+            raise ValueError("cannot translate betwen %s and %s" % (src_representation, dest_representation))
+        self.representation = src_representation
+        weights = self.device(key)
+        if weights.dim() != 1:
+            raise NotImplementedError("resampling of vector-valued binned data")
+        old_centres = {n: self.unroll_binning(n, src_representation) for n in src_representation.names}
+        b_new, cols = regularized(dest_representation, lambda n, log: (np.log(old_centres[n]) if log else old_centres[n]))
+        cols = [K.to_device(np.asarray(c, dtype=FTYPE)) for c in cols]
+        flat = K.histogram_regular(cols, weights, b_new)
+        counts = K.histogram_regular(cols, None, b_new)
+        new_centres = {n: self.unroll_binning(n, dest_representation) for n in dest_representation.names}
+        b_old, cols_new = regularized(src_representation, lambda n, log: (np.log(new_centres[n]) if log else new_centres[n]))
+        looked_up = K.lookup_regular([K.to_device(np.asarray(c, dtype=FTYPE)) for c in cols_new], weights, b_old)
+        self.representation = dest_representation
+        return torch.where(counts > 1, torch.nan_to_num(flat / counts), looked_up)
 
     def array_to_binned(self, key, src_representation, dest_representation, averaged=True):
         """events -> map (container.py:933-979) on the GPU"""

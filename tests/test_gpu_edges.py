@@ -126,3 +126,37 @@ def test_planned_prob3_odd_row_sets():
             got = K.prob3_grid_planned(p, plan, e, e_major=e_major)
             for a, b in zip(ref, got):
                 assert float((a - b).abs().max()) < 3e-13
+
+
+def test_container_map_to_map_resampling():
+    """container.py:906-931 -> translation.py:49-85: coarse <-> fine binnings of the same dimensions"""
+    from pisa_amd.core.binning import MultiDimBinning, OneDimBinning
+    from pisa_amd.core.container import Container
+    from pisa_amd.core.units import ureg
+
+    fine = MultiDimBinning([OneDimBinning("true_energy", num_bins=40, is_log=True, domain=[1.0, 100.0] * ureg.GeV),
+                            OneDimBinning("true_coszen", num_bins=20, is_lin=True, domain=[-1, 1])])
+    coarse = MultiDimBinning([OneDimBinning("true_energy", num_bins=10, is_log=True, domain=[1.0, 100.0] * ureg.GeV),
+                              OneDimBinning("true_coszen", num_bins=5, is_lin=True, domain=[-1, 1])])
+    c = Container("x", representation=fine)
+    rs = np.random.RandomState(0)
+    vals = rs.rand(40, 20)
+    c["prob"] = vals.ravel()
+    # fine -> coarse: every coarse bin holds 4 x 4 fine bins: their plain average
+    c.representation = coarse
+    got = c["prob"].reshape(10, 5)
+    want = vals.reshape(10, 4, 5, 4).mean(axis=(1, 3))
+    np.testing.assert_allclose(got, want, rtol=1e-13)
+    # coarse -> fine: no fine bin receives more than one coarse centre: nearest-bin lookup
+    d = Container("y", representation=coarse)
+    cv = rs.rand(10, 5)
+    d["prob"] = cv.ravel()
+    d.representation = fine
+    np.testing.assert_array_equal(d["prob"].reshape(40, 20), np.repeat(np.repeat(cv, 4, axis=0), 4, axis=1))
+    # different dimensions cannot be resampled
+    other = MultiDimBinning([OneDimBinning("reco_energy", num_bins=4, is_lin=True, domain=[0.0, 1.0])])
+    e = Container("z", representation=coarse)
+    e["prob"] = cv.ravel()
+    e.representation = other
+    with pytest.raises(ValueError):
+        e["prob"]
