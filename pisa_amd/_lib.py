@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpisa_hip.so")
+# PISA_HIP_LIB: development override (A/B of two builds of the library, scripts/dev)
+LIB_PATH = os.environ.get("PISA_HIP_LIB") or os.path.join(_HERE, "libpisa_hip.so")
 
 MAX_SHELLS = 64
 MAX_DIMS = 3

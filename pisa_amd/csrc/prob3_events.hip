@@ -1,0 +1,216 @@
+// prob3_events.hip -- event-by-event oscillation probabilities (configs C2 / C5): every event's
+// path through the Earth is rebuilt from its coszen with the PREM shell table in LDS
+// (layers.py:86-159 evaluated lazily; no densities/distances[N][L] arrays in HBM), the
+// reference's layer-matrix cache (numba_osc_kernels.py:230-249) is resolved once per path, and
+// mirrored layers share one amplitude.
+//
+// This translation unit is compiled with -ffp-contract=fast (the Makefile's FLAGS_prob3_events):
+// the kernel is bound by the issue rate of dependent fp64 instructions at 2 waves / SIMD, and
+// fusing multiply-add pairs removes a third of them (0.289 -> 0.255 ms per 1e6 events).  The
+// results move by rounding only (LLH of the 1e6-event workload: 4e-13 relative) and stay inside
+// the prob3 tolerance of the oracle comparison (tests/test_gpu_kernels.py).  The array / grid
+// kernels and calc_layers_kernel (prob3.hip) keep the reference's unfused operation order.
+#include <string.h>
+
+#include "common.hpp"
+#include "prob3_device.hpp"
+#include "prob3_paths.hpp"
+
+namespace pisa {
+
+// ---------------------------------------------------------------- event mode
+// Per-thread path staged in LDS as [layer][lane] (conflict free): length (f64)
+// and shell index (u8).  Dynamic LDS = blockDim.x * max_seg * 9 bytes + table.
+constexpr int EV_MAX_CONT = 16;
+struct EvCont {
+    int64_t n;
+    const double *energy, *coszen;
+    double *prob;      // [n][3][3] or NULL
+    double2 *pepmu;    // [n] (P[e->flav], P[mu->flav]) or NULL
+    int32_t side, flav;
+};
+struct EvArgs {
+    int32_t n_cont;
+    int32_t blk_start[EV_MAX_CONT + 1];
+    EvCont cont[EV_MAX_CONT];
+};
+
+// SIDE (0 nu / 1 nubar) is a template parameter: indexing the by-value constants with a run-time
+// side made the compiler copy them to scratch (2.3 KB per lane) and read them back into VGPRs
+template <bool DECAY, int SIDE>
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
+prob3_events_kernel(const Prob3Consts c, const EarthDev earth, const EvArgs ev, int max_seg,
+                    int32_t *__restrict__ status) {
+    // Workgroups are dealt to the containers round-robin (workgroup b = chunk b / n_cont of
+    // container b % n_cont).  Every container's events are sorted by coszen, longest paths
+    // first, so the long paths of ALL containers run first and the short ones fill the tail
+    // (container-major order left each later container's long paths for the end).
+    const int ci = (int)(blockIdx.x % (unsigned)ev.n_cont);  // workgroup-uniform
+    const int chunk = (int)(blockIdx.x / (unsigned)ev.n_cont);
+    const EvCont &C = ev.cont[ci];
+    constexpr int side = SIDE;
+    const double *__restrict__ energy = C.energy;
+    const double *__restrict__ coszen = C.coszen;
+    const int64_t n = C.n;
+    double *__restrict__ prob = C.prob;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // shell table in LDS (radii, rhos, coszen_limit)
+    double *s_radii = reinterpret_cast<double *>(smem);
+    double *s_rhos = s_radii + PISA_HIP_MAX_SHELLS;
+    double *s_lim = s_rhos + PISA_HIP_MAX_SHELLS;
+    double *s_len = s_lim + PISA_HIP_MAX_SHELLS;                       // [max_seg][blockDim]
+    unsigned char *s_shell = reinterpret_cast<unsigned char *>(s_len + (size_t)max_seg * blockDim.x);
+    unsigned char *s_src = s_shell + (size_t)max_seg * blockDim.x;
+    for (int k = threadIdx.x; k < earth.n_shell; k += blockDim.x) {
+        s_radii[k] = earth.radii[k];
+        s_rhos[k] = earth.rhos[k];
+        s_lim[k] = earth.coszen_limit[k];
+    }
+    __syncthreads();
+    struct LdsEarth {
+        int32_t n_shell, idx;
+        double r_detector;
+        const double *radii, *rhos, *coszen_limit;
+    } e{earth.n_shell, earth.idx, earth.r_detector, s_radii, s_rhos, s_lim};
+
+    int64_t i = (int64_t)chunk * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int lane = threadIdx.x;
+    const int bd = blockDim.x;
+    PathGeom g = make_path(e, coszen[i]);
+    bool ok = path_valid(e, g);
+    int nseg = ok ? g.nseg : 0;
+    if (!ok && status) atomicOr(status, 1);
+    for (int l = 0; l < nseg; l++) {
+        double rho, len;
+        path_segment(e, g, l, rho, len);
+        int shell = g.tangent_free ? l : (l < g.m ? l : 2 * g.m - 2 - l);
+        if (!(len == len)) { len = 0.0; if (status) atomicOr(status, 1); }
+        s_len[(size_t)l * bd + lane] = len;
+        s_shell[(size_t)l * bd + lane] = (unsigned char)shell;
+    }
+    auto layer = [&](int l, double &rho, double &dist) {
+        dist = s_len[(size_t)l * bd + lane];
+        rho = s_rhos[s_shell[(size_t)l * bd + lane]] * (dist > 0. ? 1.0 : 0.0);
+    };
+    // the reference's layer-matrix cache, resolved once per path: src[l] = the layer whose
+    // matrix layer l uses (numba_osc_kernels.py:236-249: the LAST earlier layer within 1e-5 in
+    // density and length, followed through its own matches)
+    for (int l = 0; l < nseg; l++) {
+        double rho_l, d_l;
+        layer(l, rho_l, d_l);
+        int sl = l;
+        if (d_l > 0.0) {
+            int found = -1;
+            for (int j = 0; j < l; j++) {
+                double rj, dj;
+                layer(j, rj, dj);
+                if (dj > 0.0 && fabs(rj - rho_l) < 1e-5 && fabs(dj - d_l) < 1e-5) found = j;
+            }
+            if (found >= 0) sl = s_src[(size_t)found * bd + lane];
+        }
+        s_src[(size_t)l * bd + lane] = (unsigned char)sl;
+    }
+    auto src = [&](int l) { return (int)s_src[(size_t)l * bd + lane]; };
+    double P[9];
+    // through-going paths: in 0..m-2, innermost m-1, out m..2m-3 (path_segment)
+    const int32_t vac_order[3] = {c.vac_order[0], c.vac_order[1], c.vac_order[2]};
+    propagate_path_nested<DECAY>(c.side[side], c.dm, vac_order, energy[i], nseg,
+                                 (ok && !g.tangent_free) ? g.m - 1 : -1, layer, src, P);
+    if (prob) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) prob[9 * i + k] = P[k];
+    }
+    if (C.pepmu) C.pepmu[i] = make_double2(P[C.flav], P[3 + C.flav]);
+}
+
+}  // namespace pisa
+
+using namespace pisa;
+
+static int launch_events(const Prob3Consts &c, const EarthDev &e, const EvCont *conts, int n_cont,
+                         int32_t *d_status, hipStream_t s) {
+    int max_seg = 2 * e.n_shell;
+    if (max_seg > PISA_HIP_MAX_LAYERS + 8) return PISA_HIP_ERR_LAYERS;
+    const int threads = 64;
+    size_t lds = 3 * PISA_HIP_MAX_SHELLS * sizeof(double) + (size_t)max_seg * threads * 10 + 16;
+    // one launch per sign (see the kernel) and per EV_MAX_CONT containers
+    for (int side = 0; side < 2; side++) {
+        EvArgs a;
+        a.n_cont = 0;
+        a.blk_start[0] = 0;
+        auto flush = [&]() -> int {
+            if (a.n_cont == 0 || a.blk_start[a.n_cont] == 0) { a.n_cont = 0; return PISA_HIP_OK; }
+            int max_blocks = 0;
+            for (int k = 0; k < a.n_cont; k++) {
+                const int nb = a.blk_start[k + 1] - a.blk_start[k];
+                max_blocks = nb > max_blocks ? nb : max_blocks;
+            }
+            dim3 block(threads), grid((unsigned)max_blocks * (unsigned)a.n_cont);
+#define LAUNCH_EV(D, S_) hipLaunchKernelGGL((prob3_events_kernel<D, S_>), grid, block, lds, s, c, e, a, max_seg, d_status)
+            if (c.decay) { if (side == 0) LAUNCH_EV(true, 0); else LAUNCH_EV(true, 1); }
+            else { if (side == 0) LAUNCH_EV(false, 0); else LAUNCH_EV(false, 1); }
+#undef LAUNCH_EV
+            PISA_CHECK_LAUNCH("prob3_events_kernel");
+            a.n_cont = 0;
+            return PISA_HIP_OK;
+        };
+        for (int k = 0; k < n_cont; k++) {
+            if (conts[k].side != side) continue;
+            a.cont[a.n_cont] = conts[k];
+            a.blk_start[a.n_cont + 1] = a.blk_start[a.n_cont] + (int)((conts[k].n + threads - 1) / threads);
+            a.n_cont++;
+            if (a.n_cont == EV_MAX_CONT) {
+                int rc = flush();
+                if (rc) return rc;
+            }
+        }
+        int rc = flush();
+        if (rc) return rc;
+    }
+    return PISA_HIP_OK;
+}
+
+PISA_API int pisa_hip_prob3_events(const pisa_hip_prob3_params *h_params,
+                                   const pisa_hip_earth *h_earth, int64_t nubar,
+                                   const double *d_energy, const double *d_coszen, int64_t n,
+                                   double *d_probability, int32_t *d_status, void *stream) {
+    if (n < 0 || (nubar != 1 && nubar != -1)) return PISA_HIP_ERR_INVALID;
+    EarthDev e;
+    int rc = make_earth_dev(h_earth, e);
+    if (rc) return rc;
+    Prob3Consts c;
+    if ((rc = make_consts(h_params, c))) return rc;
+    if (n == 0) return PISA_HIP_OK;
+    if (!d_energy || !d_coszen || !d_probability) return PISA_HIP_ERR_INVALID;
+    EvCont ec;
+    ec.n = n; ec.energy = d_energy; ec.coszen = d_coszen; ec.prob = d_probability;
+    ec.pepmu = nullptr; ec.side = nubar > 0 ? 0 : 1; ec.flav = 0;
+    return launch_events(c, e, &ec, 1, d_status, as_stream(stream));
+}
+
+PISA_API int pisa_hip_prob3_events_multi(const pisa_hip_prob3_params *h_params,
+                                         const pisa_hip_earth *h_earth,
+                                         const pisa_hip_event_set *h_sets, int32_t n_sets,
+                                         int32_t *d_status, void *stream) {
+    if (!h_sets || n_sets < 1 || n_sets > 1024) return PISA_HIP_ERR_INVALID;
+    EarthDev e;
+    int rc = make_earth_dev(h_earth, e);
+    if (rc) return rc;
+    Prob3Consts c;
+    if ((rc = make_consts(h_params, c))) return rc;
+    EvCont *ec = new EvCont[n_sets];
+    for (int k = 0; k < n_sets; k++) {
+        const pisa_hip_event_set &h = h_sets[k];
+        bool bad = h.n_events < 0 || (h.nubar != 1 && h.nubar != -1) || h.flav < 0 || h.flav > 2 ||
+                   (h.n_events > 0 && (!h.d_energy || !h.d_coszen || (!h.d_probability && !h.d_pepmu)));
+        if (bad) { delete[] ec; return PISA_HIP_ERR_INVALID; }
+        ec[k].n = h.n_events; ec[k].energy = h.d_energy; ec[k].coszen = h.d_coszen;
+        ec[k].prob = h.d_probability; ec[k].pepmu = reinterpret_cast<double2 *>(h.d_pepmu);
+        ec[k].side = h.nubar > 0 ? 0 : 1; ec[k].flav = h.flav;
+    }
+    rc = launch_events(c, e, ec, n_sets, d_status, as_stream(stream));
+    delete[] ec;
+    return rc;
+}
+

@@ -53,20 +53,21 @@ for p in plist[args.warmup:]:
 e1.record()
 torch.cuda.synchronize()
 t_osc = e0.elapsed_time(e1) / args.steps * 1e-3
-# Reference-equivalent work: the reference evaluates ~2816 flop per crossed layer (+ ~700 per
-# event).  The kernel does LESS than that (mirrored layers share one amplitude, the vacuum
-# eigenvalues are computed once per event), so "fp64_tflops_ref_equiv" is a rate in units of
-# the reference's arithmetic, not the device's executed flops.
-lay = wl.layers
-cz = np.concatenate([ev["true_coszen"] for ev in wl.events])
-sub = cz[:: max(1, len(cz) // 200000)]
-lay.calcLayers(sub)
-mean_layers = float(lay.n_layers.mean())
-flop = wl.n_events * (700.0 + 2816.0 * mean_layers)
-print(json.dumps({
+# executed fp64 flops per event from the committed SQ_INSTS_VALU_*_F64 passes (scripts/profile_round.sh)
+import glob
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+cal = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "events_flops.json")),
+             key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(os.path.dirname(f)))])
+out = {
     "workload": "%d events, prob3 event-by-event (PREM-12%s) + fused reweight + 10x10 hist + LLH"
                 % (wl.n_events, ", std NSI" if args.nsi else ""),
     "evals_per_s": 1.0 / dt, "event_evals_per_s": wl.n_events / dt, "ms_per_eval": dt * 1e3,
-    "prob3_events_kernel_ms": t_osc * 1e3, "mean_crossed_layers": mean_layers,
-    "fp64_flop_per_eval_ref_equiv": flop, "fp64_tflops_ref_equiv": flop / t_osc / 1e12,
-    "fp64_vector_peak_tflops": 78.6, "last_llh": llh}))
+    "prob3_events_kernel_ms": t_osc * 1e3, "fp64_vector_peak_tflops": 78.6, "last_llh": llh}
+if cal:
+    d = json.load(open(cal[-1]))["nsi" if args.nsi else "std"]
+    out["executed_fp64_flop_per_event"] = d["flop_per_event"]
+    out["executed_fp64_tflops"] = d["flop_per_event"] * wl.n_events / t_osc / 1e12
+    out["flop_source"] = os.path.relpath(cal[-1], ROOT)
+print(json.dumps(out))
