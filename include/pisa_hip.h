@@ -370,8 +370,9 @@ int pisa_hip_kde_info(const pisa_hip_kde *k, pisa_hip_kde_info_t *info);
 int pisa_hip_kde_arrays(const pisa_hip_kde *k, const double **d_ys, const double **d_coef,
                         const double **d_s2);
 int pisa_hip_kde_destroy(pisa_hip_kde *k);
-/* use_expansion: 1 (default) = in 2-D the fixed-bandwidth pilot sums cells of >= 24 sources through
- * a truncated Hermite series (fast Gauss transform; truncation error below the cut-off tolerance),
+/* How the 2-D fixed-bandwidth pilot estimate sums cells of >= 24 sources (fast Gauss transform;
+ * truncation error below the cut-off tolerance): 2 (default) = Hermite series of the source cells
+ * translated into one local expansion per target cell, 1 = Hermite series evaluated target by target,
  * 0 = every pair directly; < 0 = query.  Returns the previous setting. */
 int pisa_hip_kde_configure(int32_t use_expansion);
 

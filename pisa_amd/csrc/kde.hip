@@ -133,6 +133,7 @@ struct KdeGeom {
 struct KdeBlock {        // one workgroup of the pair kernel
     int32_t q_begin, q_count;
     int32_t c0[3], c1[3];   // cell bounds of the queries' tile (inclusive; may lie outside the grid)
+    int32_t head;           // index of the tile among the non-empty tiles (sorted order)
 };
 
 __device__ inline double block_sum(double v, double *lds) {
@@ -708,6 +709,189 @@ kde_hermite_pilot_kernel(KdeGeom g, const KdeBlock *__restrict__ blocks, const d
     if (pair_count && threadIdx.x == 0 && work) atomicAdd(pair_count, work);
 }
 
+
+// ------------------------------------------------------------------ Hermite -> local (Taylor) translation
+// With many targets per cell the Hermite series of the ~250 dense cells in range need not be
+// evaluated target by target: they are first translated into ONE local expansion about the
+// target cell's centre c_C (x = t - c_C, |x| <= rho),
+//     sum_B sum_{a,b} A^B_ab h_a(t1 - c_B1) h_b(t2 - c_B2)  =  sum_{k,l} L_kl x1^k x2^l,
+//     L = D (sum_B H(d1) A^B H(d2)^T) D,   H(d)[k][a] = h_{a+k}(d),  d = c_C - c_B,  D = diag((-1)^k / k!)
+// (h_a(d + x) = sum_k (-1)^k h_{a+k}(d) x^k / k!), and a target then costs P^2 multiply-adds in
+// all.  The sum over the source cells of one column (same d1) is formed first, W = sum_B A^B H(d2)^T,
+// and multiplied by H(d1) once per column: (cells + columns) P^3 multiply-adds per target cell.
+// Truncation at k, l < P costs the same (rho sqrt2)^P / sqrt(P!) as the Hermite series.  The Hankel
+// entries h_n(j * cell / sqrt2), n < 2P - 1, |j| <= reach, come from the host (long double recurrence).
+constexpr int H2L_MAX_REACH = 12;
+
+// The translation is done in two separable passes over the cell grid (like a separable
+// convolution), with the SQUARE |d1|, |d2| <= reach of source cells instead of the disc -- the cells
+// of the square outside the cut-off disc only add their (correct, below-tolerance) contributions:
+//   pass 0   V[cy_C][cx_B] = sum_{cy_B} A^(cx_B, cy_B) H(d2)^T          one workgroup per (cx_B, cy_C)
+//   pass 1   L[C]          = D (sum_{cx_B} H(d1) V[cy_C][cx_B]) D       one workgroup per target cell
+// 2 (2 reach + 1) P^3 multiply-adds per cell instead of (cells in the disc + columns) P^3.
+template <int P, int PASS>
+__global__ void __launch_bounds__(512)
+kde_h2l_kernel(KdeGeom g, const int32_t *__restrict__ tcells, const int32_t *__restrict__ slot,
+               const double *__restrict__ herm, const double *__restrict__ hankel, int reach,
+               double *__restrict__ V, uint8_t *__restrict__ vflag, double *__restrict__ local) {
+    constexpr int NH = 2 * P - 1;
+    __shared__ double sA[P * P];
+    __shared__ double sH[(2 * H2L_MAX_REACH + 1) * NH];
+    const int t = threadIdx.x;
+    const bool act = t < P * P;
+    const int r0 = act ? t / P : 0, r1 = act ? t % P : 0;
+    for (int i = t; i < (2 * reach + 1) * NH; i += 512) sH[i] = hankel[i];
+    const int nx = g.nc[0], ny = g.nc[1];
+    const int c = PASS == 0 ? (int)blockIdx.x : tcells[blockIdx.x];
+    const int cx = c % nx, cy = c / nx;
+    double acc = 0.0;
+    bool any = false;
+    for (int o = -reach; o <= reach; o++) {
+        const double *src;
+        if (PASS == 0) {                 // source cell (cx, cy - o): d2 = o * cell_u
+            const int cyB = cy - o;
+            if (cyB < 0 || cyB >= ny) continue;
+            const int sl = slot[(int64_t)cyB * nx + cx];
+            if (sl < 0) continue;
+            src = herm + (int64_t)sl * (P * P);
+        } else {                         // column cx - o of row cy: d1 = o * cell_u
+            const int cxB = cx - o;
+            if (cxB < 0 || cxB >= nx) continue;
+            const int64_t cb = (int64_t)cy * nx + cxB;
+            if (!vflag[cb]) continue;
+            src = V + cb * (P * P);
+        }
+        any = true;                      // workgroup-uniform
+        __syncthreads();
+        if (act) sA[t] = src[t];
+        __syncthreads();
+        if (act) {
+            const double *hk = sH + (o + reach) * NH;
+            double w = acc;
+            if (PASS == 0) {             // W[alpha][l] += sum_beta A[alpha][beta] h_{beta + l}(d2)
+                const double *a = sA + r0 * P;
+#pragma unroll
+                for (int b = 0; b < P; b++) w = __builtin_fma(a[b], hk[r1 + b], w);
+            } else {                     // L[k][l] += sum_alpha h_{alpha + k}(d1) V[alpha][l]
+#pragma unroll
+                for (int a = 0; a < P; a++) w = __builtin_fma(hk[r0 + a], sA[a * P + r1], w);
+            }
+            acc = w;
+        }
+    }
+    if (PASS == 0) {
+        if (t == 0) vflag[c] = any ? 1 : 0;
+        if (act && any) V[(int64_t)c * (P * P) + t] = acc;
+    } else if (act) {
+        // D_k D_l = (-1)^(k+l) / (k! l!)
+        double fk = 1.0, fl = 1.0;
+        for (int i = 2; i <= r0; i++) fk *= (double)i;
+        for (int i = 2; i <= r1; i++) fl *= (double)i;
+        const double sgn = ((r0 + r1) & 1) ? -1.0 : 1.0;
+        local[(int64_t)blockIdx.x * (P * P) + t] = sgn * acc / (fk * fl);
+    }
+}
+
+// pilot densities at the (cell-sorted) sources: the local expansion of the target's cell for all
+// dense cells in range + direct sums over the sparse ones.
+template <int P>
+__global__ void __launch_bounds__(KDE_THREADS)
+kde_local_pilot_kernel(KdeGeom g, const KdeBlock *__restrict__ blocks, const double *__restrict__ sy,
+                       int64_t n_src, const double *__restrict__ coef,
+                       const int32_t *__restrict__ cell_start, const int32_t *__restrict__ slot,
+                       const double *__restrict__ local, double *__restrict__ out,
+                       unsigned long long *__restrict__ pair_count) {
+    constexpr int W = 4;
+    __shared__ double t_src[SRC_TILE * W];
+    const KdeBlock b = blocks[blockIdx.x];
+    double q[Q_PER_THREAD][2], acc[Q_PER_THREAD];
+#pragma unroll
+    for (int u = 0; u < Q_PER_THREAD; u++) {
+        const int jq = threadIdx.x + u * KDE_THREADS;
+        const int64_t j = b.q_begin + (jq < b.q_count ? jq : 0);
+        q[u][0] = sy[j];
+        q[u][1] = sy[n_src + j];
+        acc[u] = 0.0;
+    }
+    unsigned long long work = (unsigned long long)(P * P / 23 + 1) * b.q_count;
+    {
+        const double *__restrict__ L = local + (int64_t)b.head * (P * P);   // wave-uniform: scalar loads
+        const double c1 = g.ylo[0] + (b.c0[0] + 0.5) * g.cell, c2 = g.ylo[1] + (b.c0[1] + 0.5) * g.cell;
+        double x[Q_PER_THREAD], y[Q_PER_THREAD], sum[Q_PER_THREAD];
+#pragma unroll
+        for (int u = 0; u < Q_PER_THREAD; u++) {
+            x[u] = (q[u][0] - c1) * RSQRT2;
+            y[u] = (q[u][1] - c2) * RSQRT2;
+            sum[u] = 0.0;
+        }
+#pragma unroll 1
+        for (int k = P - 1; k >= 0; k--) {
+            const double *__restrict__ row = L + k * P;
+            double inner[Q_PER_THREAD];
+#pragma unroll
+            for (int u = 0; u < Q_PER_THREAD; u++) inner[u] = 0.0;
+#pragma unroll
+            for (int l = P - 1; l >= 0; l--) {
+                const double a = row[l];
+#pragma unroll
+                for (int u = 0; u < Q_PER_THREAD; u++) inner[u] = __builtin_fma(inner[u], y[u], a);
+            }
+#pragma unroll
+            for (int u = 0; u < Q_PER_THREAD; u++) sum[u] = __builtin_fma(sum[u], x[u], inner[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < Q_PER_THREAD; u++) acc[u] = sum[u];
+    }
+    // sparse cells in range: directly
+    int lo[2], hi[2];
+    const double reach = ceil(sqrt(g.rcut2) * g.inv_cell);
+#pragma unroll
+    for (int d = 0; d < 2; d++) {
+        const double l = (double)b.c0[d] - reach, h = (double)b.c1[d] + reach;
+        lo[d] = l > 0.0 ? (int)l : 0;
+        hi[d] = h < (double)(g.nc[d] - 1) ? (int)h : g.nc[d] - 1;
+    }
+    for (int cy = lo[1]; cy <= hi[1]; cy++) {
+        const int gapy = cy < b.c0[1] ? b.c0[1] - cy - 1 : (cy > b.c1[1] ? cy - b.c1[1] - 1 : 0);
+        const double gy = gapy * g.cell;
+        const int64_t row = (int64_t)cy * g.nc[0];
+        for (int cx = lo[0]; cx <= hi[0]; cx++) {
+            const int64_t c = row + cx;
+            const int begin = cell_start[c], end = cell_start[c + 1];
+            if (end == begin || slot[c] >= 0) continue;
+            const int gapx = cx < b.c0[0] ? b.c0[0] - cx - 1 : (cx > b.c1[0] ? cx - b.c1[0] - 1 : 0);
+            const double gx = gapx * g.cell;
+            if (gx * gx + gy * gy > g.rcut2) continue;
+            work += (unsigned long long)(end - begin) * b.q_count;
+            for (int base = begin; base < end; base += SRC_TILE) {
+                const int cnt = end - base < SRC_TILE ? end - base : SRC_TILE;
+                __syncthreads();
+                for (int k = threadIdx.x; k < cnt; k += KDE_THREADS) {
+                    t_src[k * W + 0] = sy[base + k];
+                    t_src[k * W + 1] = sy[n_src + base + k];
+                    t_src[k * W + 2] = coef[base + k];
+                }
+                __syncthreads();
+                for (int k = 0; k < cnt; k++) {
+                    const double *s = t_src + k * W;
+#pragma unroll
+                    for (int u = 0; u < Q_PER_THREAD; u++) {
+                        const double d0 = q[u][0] - s[0], d1 = q[u][1] - s[1];
+                        const double r2 = __builtin_fma(d1, d1, d0 * d0);
+                        acc[u] = __builtin_fma(s[2], exp_nonpos(-0.5 * r2), acc[u]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < Q_PER_THREAD; u++) {
+        const int jq = threadIdx.x + u * KDE_THREADS;
+        if (jq < b.q_count) out[b.q_begin + jq] = acc[u];
+    }
+    if (pair_count && threadIdx.x == 0 && work) atomicAdd(pair_count, work);
+}
+
 // ------------------------------------------------------------------ host side
 struct Arena {   // carves the caller's workspace
     char *base;
@@ -737,7 +921,7 @@ static size_t sort_temp_bytes(int64_t n) {
 
 using namespace pisa;
 
-static int g_kde_expansion = 1;   // Hermite expansion of dense cells in the 2-D pilot estimate
+static int g_kde_expansion = 2;   // 2-D pilot: 0 direct sums, 1 Hermite series per target, 2 + local expansions
 
 struct pisa_hip_kde {
     int dim;
@@ -781,6 +965,7 @@ static int query_blocks(const uint64_t *d_keys, int64_t m, int tile, int chunk, 
     for (int32_t h = 0; h < n_heads; h++) {
         const int64_t begin = starts[h], end = h + 1 < n_heads ? starts[h + 1] : m;
         KdeBlock b;
+        b.head = h;
         for (int d = 0; d < 3; d++) {
             const int64_t t = (int64_t)((hk[h] >> (21 * d)) & 0x1FFFFF) - KEY_OFF;
             b.c0[d] = (int32_t)(t * tile);
@@ -839,14 +1024,14 @@ PISA_API int64_t pisa_hip_kde_workspace_bytes(int32_t dim, int64_t n_src) {
     total += n + n * 4 + n * 8;                          // flags, starts, head keys
     total += n * 8 + split_bytes(n_src);                 // pilot, split partials
     total += sort_temp_bytes(n_src) + (n / Q_CHUNK + (size_t)cells_cap(n_src)) * sizeof(KdeBlock);
-    if (dim == 2)   // Hermite coefficients of the dense cells, cell -> slot map, list of dense cells
-        total += (n / HERMITE_MIN + 1) * (size_t)(20 * 20 * 8 + 4) + (size_t)cells_cap(n_src) * 4 + 1024;
+    if (dim == 2)   // cell -> slot map, lists of dense / non-empty cells (the coefficients live in library scratch)
+        total += (n / HERMITE_MIN + 1) * 4 + (size_t)cells_cap(n_src) * 8 + 4096;
     return (int64_t)(total + 64 * 256);
 }
 
 PISA_API int pisa_hip_kde_configure(int32_t use_expansion) {
     const int old = g_kde_expansion;
-    if (use_expansion >= 0) g_kde_expansion = use_expansion ? 1 : 0;
+    if (use_expansion >= 0) g_kde_expansion = use_expansion > 2 ? 2 : use_expansion;
     return old;
 }
 
@@ -1056,34 +1241,96 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
             }
         }
         if (!dense.empty()) {
+            const int nd = (int)dense.size();
+            const int n_heads = (int)h_starts.size();
+            const int reach = (int)ceil(sqrt(g.rcut2) * g.inv_cell);
+            // local expansions need the intermediate V of every cell of the grid: bounded
+            const bool local_exp = g_kde_expansion >= 2 && reach <= H2L_MAX_REACH &&
+                                   (double)k->n_cells * (P * P) * 8.0 < 2.0e9;
+            // Hermite / local coefficients live in a grow-only scratch of the library (up to
+            // 3.2 KB per cell: sized by what this call needs, not by the workspace's worst case)
+            const size_t pp = (size_t)(P * P);
+            const size_t need = (nd * pp + (local_exp ? (n_heads + (size_t)k->n_cells) * pp + (2 * reach + 1) * (2 * P - 1) : 0))
+                                * sizeof(double) + (local_exp ? (size_t)k->n_cells : 0) + 8192;
+            if (need > g_kde_scratch_bytes) {
+                KDE_TRY_HIP(hipStreamSynchronize(s));
+                if (g_kde_scratch) (void)hipFree(g_kde_scratch);
+                g_kde_scratch = nullptr;
+                g_kde_scratch_bytes = 0;
+                KDE_TRY_HIP(hipMalloc(&g_kde_scratch, need + need / 2));
+                g_kde_scratch_bytes = need + need / 2;
+            }
+            double *herm = g_kde_scratch;
+            double *local = herm + nd * pp;
+            double *d_hankel = local + (local_exp ? n_heads * pp : 0);
+            double *d_V = d_hankel + (2 * reach + 1) * (2 * P - 1);
+            uint8_t *d_vflag = (uint8_t *)(d_V + (local_exp ? (size_t)k->n_cells * pp : 0));
             int32_t *d_dense = ar.take<int32_t>(dense.size());
             int32_t *slot = ar.take<int32_t>(k->n_cells);
-            double *herm = ar.take<double>(dense.size() * (size_t)(P * P));
+            int32_t *d_tcells = ar.take<int32_t>(n_heads);
             if (!ar.ok) KDE_FAIL(PISA_HIP_ERR_NOMEM);
             KDE_TRY_HIP(hipMemcpyAsync(d_dense, dense.data(), dense.size() * sizeof(int32_t),
                                        hipMemcpyHostToDevice, s));
             KDE_TRY_HIP(hipMemsetAsync(slot, 0xFF, (size_t)k->n_cells * sizeof(int32_t), s));
-            const int nd = (int)dense.size();
             hipLaunchKernelGGL(kde_slot_scatter_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s,
                                d_dense, nd, slot);
-            dim3 grid((unsigned)n_blocks, (unsigned)n_split);
-            if (P == 18) {
-                hipLaunchKernelGGL(kde_hermite_coef_kernel<18>, dim3((unsigned)nd), dim3(256), 0, s, g, d_dense,
-                                   k->cell_start, k->ys, n, k->coef, herm);
-                hipLaunchKernelGGL(kde_hermite_pilot_kernel<18>, grid, dim3(KDE_THREADS), 0, s, g, d_blocks,
-                                   k->ys, n, k->coef, k->cell_start, slot, herm, n_split, part, k->pair_count);
-            } else {
-                hipLaunchKernelGGL(kde_hermite_coef_kernel<20>, dim3((unsigned)nd), dim3(256), 0, s, g, d_dense,
-                                   k->cell_start, k->ys, n, k->coef, herm);
-                hipLaunchKernelGGL(kde_hermite_pilot_kernel<20>, grid, dim3(KDE_THREADS), 0, s, g, d_blocks,
-                                   k->ys, n, k->coef, k->cell_start, slot, herm, n_split, part, k->pair_count);
+            std::vector<int32_t> tcells(n_heads);
+            std::vector<double> hankel;
+            if (local_exp) {
+                for (int h = 0; h < n_heads; h++) {
+                    const int64_t cx = (int64_t)(h_keys[h] & 0x1FFFFF) - KEY_OFF;
+                    const int64_t cy = (int64_t)((h_keys[h] >> 21) & 0x1FFFFF) - KEY_OFF;
+                    tcells[h] = (int32_t)(cy * g.nc[0] + cx);
+                }
+                const int nh = 2 * P - 1;
+                hankel.resize((size_t)(2 * reach + 1) * nh);
+                for (int j = -reach; j <= reach; j++) {
+                    // h_n(d), d = j * cell / sqrt 2: h_0 = exp(-d^2), h_1 = 2 d h_0, h_{n+1} = 2 d h_n - 2 n h_{n-1}
+                    const long double d = (long double)j * (long double)g.cell * 0.70710678118654752440084436210485L;
+                    long double h0 = expl(-d * d), h1 = 2.0L * d * h0;
+                    double *row = hankel.data() + (size_t)(j + reach) * nh;
+                    row[0] = (double)h0;
+                    row[1] = (double)h1;
+                    for (int m = 1; m + 1 < nh; m++) {
+                        const long double h2 = 2.0L * d * h1 - 2.0L * m * h0;
+                        row[m + 1] = (double)h2;
+                        h0 = h1;
+                        h1 = h2;
+                    }
+                }
+                KDE_TRY_HIP(hipMemcpyAsync(d_tcells, tcells.data(), tcells.size() * sizeof(int32_t),
+                                           hipMemcpyHostToDevice, s));
+                KDE_TRY_HIP(hipMemcpyAsync(d_hankel, hankel.data(), hankel.size() * sizeof(double),
+                                           hipMemcpyHostToDevice, s));
             }
-            KDE_TRY(check_hip(hipGetLastError(), "kde hermite kernels"));
+            dim3 grid((unsigned)n_blocks, (unsigned)n_split);
+#define KDE_FGT(PP) do { \
+                hipLaunchKernelGGL(kde_hermite_coef_kernel<PP>, dim3((unsigned)nd), dim3(256), 0, s, g, d_dense, \
+                                   k->cell_start, k->ys, n, k->coef, herm); \
+                if (local_exp) { \
+                    hipLaunchKernelGGL((kde_h2l_kernel<PP, 0>), dim3((unsigned)k->n_cells), dim3(512), 0, s, g, d_tcells, \
+                                       slot, herm, d_hankel, reach, d_V, d_vflag, local); \
+                    hipLaunchKernelGGL((kde_h2l_kernel<PP, 1>), dim3((unsigned)n_heads), dim3(512), 0, s, g, d_tcells, \
+                                       slot, herm, d_hankel, reach, d_V, d_vflag, local); \
+                    hipLaunchKernelGGL(kde_local_pilot_kernel<PP>, dim3((unsigned)n_blocks), dim3(KDE_THREADS), 0, s, g, \
+                                       d_blocks, k->ys, n, k->coef, k->cell_start, slot, local, pilot, k->pair_count); \
+                } else { \
+                    hipLaunchKernelGGL(kde_hermite_pilot_kernel<PP>, grid, dim3(KDE_THREADS), 0, s, g, d_blocks, \
+                                       k->ys, n, k->coef, k->cell_start, slot, herm, n_split, part, k->pair_count); \
+                } } while (0)
+            if (P == 18) KDE_FGT(18); else KDE_FGT(20);
+#undef KDE_FGT
+            KDE_TRY(check_hip(hipGetLastError(), "kde expansion kernels"));
             k->n_dense = nd;
+            if (local_exp) {
+                // the host tables must outlive their asynchronous uploads; `pilot` is complete (no split)
+                KDE_TRY_HIP(hipStreamSynchronize(s));
+                part = pilot;
+            }
         } else {
             KDE_TRY((launch_pairs<false, Q_PER_THREAD>(k, d_blocks, n_blocks, n_split, k->ys, n, part, s)));
         }
-        if (n_split > 1)
+        if (n_split > 1 && part != pilot)
             hipLaunchKernelGGL(kde_combine_kernel, dim3(nb), dim3(256), 0, s, part, n_split, n,
                                (const uint32_t *)nullptr, pilot);
         hipLaunchKernelGGL(kde_logsum_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, pilot, n, partial);

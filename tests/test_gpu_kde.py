@@ -98,17 +98,19 @@ def test_kde_hermite_expansion_matches_direct_sums():
     old = lib.pisa_hip_kde_configure(-1)
     try:
         for tol in (1e-14, 1e-12):
-            for flag in (1, 0):
+            for flag in (2, 1, 0):
                 lib.pisa_hip_kde_configure(flag)
                 est = K.KdeEstimator(xd, wd, adaptive=True, alpha=0.3, tol=tol)
                 assert (est.n_dense > 100) == bool(flag)
                 ys, coef, s2 = est.arrays()
                 out[tol, flag] = (s2.cpu().numpy(), est(qd).cpu().numpy(), est.pairs_pilot)
-            s2a, fa, wa = out[tol, 1]
             s2b, fb, wb = out[tol, 0]
-            np.testing.assert_allclose(s2a, s2b, rtol=3e-12 if tol < 1e-13 else 3e-11)
-            np.testing.assert_allclose(fa, fb, rtol=1e-11 if tol < 1e-13 else 1e-10, atol=1e-13 * fb.max())
-            assert wa < 0.2 * wb      # and it is what makes the pilot cheap
+            for flag in (2, 1):   # local expansions / Hermite series per target vs every pair
+                s2a, fa, wa = out[tol, flag]
+                np.testing.assert_allclose(s2a, s2b, rtol=3e-12 if tol < 1e-13 else 3e-11)
+                np.testing.assert_allclose(fa, fb, rtol=1e-11 if tol < 1e-13 else 1e-10, atol=1e-13 * fb.max())
+                assert wa < 0.2 * wb      # and it is what makes the pilot cheap
+            assert out[tol, 2][2] < 0.2 * out[tol, 1][2]
     finally:
         lib.pisa_hip_kde_configure(old)
 
