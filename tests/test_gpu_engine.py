@@ -329,3 +329,49 @@ def test_bench_multi_rank_code_path_on_one_rank():
     assert line["weak"]["samples_per_step"] == 1 and line["allreduce_ms"] > 0
     assert line["nccl_comm_count"] == 1      # ncclCommCount of the direct communicator
     assert line["legs"] == {} and np.isfinite(line["last_llh"])
+
+
+def _two_rank_worker(rank, world, port, out_dir):
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    from pisa_amd import synthetic
+
+    wl = synthetic.Workload(n_events=240000, grid=(60, 30))
+    st = synthetic.DeviceState(wl, rank=rank, world_size=world, compact=True)
+    st.make_pseudo_data(wl.osc_params(), seed=0)
+    vals = [st.eval_host(wl.osc_params(theta23_deg=t), "llh") for t in (38.0, 45.0, 51.0)]
+    assert st._rccl and st._rccl.count() == world
+    h, s2 = st.maps()
+    np.save(os.path.join(out_dir, "rank%d.npy" % rank), np.concatenate([vals, h.ravel(), s2.ravel()]))
+    st.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(__import__("torch").cuda.device_count() < 2, reason="needs two GPUs")
+def test_rccl_limb_allreduce_two_ranks(tmp_path):
+    """two processes, two GPUs: events sharded, limbs all-reduced over the direct RCCL communicator;
+    both ranks end with the single-GPU maps and LLH, bit for bit (skipped on 1-GPU boxes)"""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from pisa_amd import synthetic
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    wl = synthetic.Workload(n_events=240000, grid=(60, 30))
+    st = synthetic.DeviceState(wl, compact=True)
+    st.make_pseudo_data(wl.osc_params(), seed=0)
+    vals = [st.eval_host(wl.osc_params(theta23_deg=t), "llh") for t in (38.0, 45.0, 51.0)]
+    h, s2 = st.maps()
+    want = np.concatenate([vals, h.ravel(), s2.ravel()])
+    for r in range(2):
+        np.testing.assert_array_equal(np.load(str(tmp_path / ("rank%d.npy" % r))), want)
