@@ -347,6 +347,7 @@ def leg_pipeline_boundary(torch, n_events, steps):
     torch.cuda.synchronize()
     dt_slow = (time.perf_counter() - t0) / max(20, steps // 10)
     cm = pipe["prob3"].calc_mode
+    out_shape = tuple(pipe.output_binning.shape)
     del pipe
     torch.cuda.empty_cache()
     # the engine alone on the same workload (same events, calc grid and binning): what the
@@ -374,7 +375,7 @@ def leg_pipeline_boundary(torch, n_events, steps):
                         "aeff, hist into %s with sumw2; theta23/dm31 set through pipeline.params every step, "
                         "Pipeline.get_outputs() + Map.metric_total('llh') read back every step"
                         % (int(n_events) // 12 * 12, "x".join(str(n) for n in cm.shape),
-                           "x".join(str(n) for n in pipe.output_binning.shape))}
+                           "x".join(str(n) for n in out_shape))}
 
 
 def leg_events(synthetic, torch, n_events, steps, nsi):
