@@ -40,8 +40,8 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 L3_BYTES = 256 * 2 ** 20
-ALL_LEGS = ("l3_exceeding", "exact_association", "coordinate_form", "update_flux", "pipeline_boundary",
-            "events_c2", "events_c5", "kde_c3")
+ALL_LEGS = ("l3_exceeding", "exact_association", "coordinate_form", "fine_binning", "update_flux",
+            "pipeline_boundary", "events_c2", "events_c5", "kde_c3")
 
 
 def parse():
@@ -622,6 +622,9 @@ def main():
             elif name == "coordinate_form":
                 legs[name] = hbm_leg(synthetic, lib, torch, args.events, n_e, n_cz, args.binning, leg_steps,
                                      coordinate_form=True)
+            elif name == "fine_binning":
+                # 40 x 40 x 3 = 4 800 output bins: beyond the LDS accumulators, LDS-window path
+                legs[name] = hbm_leg(synthetic, lib, torch, args.events, n_e, n_cz, "fine3d", leg_steps)
             elif name == "update_flux":
                 legs[name] = leg_update_flux(synthetic, torch, wl, st, leg_steps) if compact else None
             elif name == "pipeline_boundary":

@@ -207,8 +207,8 @@ class FastPlan:
                     g = osc.grid
                     a = self._osc_args = (
                         osc.pepmu, g["plan"].handle, C.c_void_p(g["energy"].data_ptr()), g["energy"].numel(),
-                        1 if g["e_major"] else 0, C.c_void_p(osc.prob_tables[0].data_ptr()),
-                        C.c_void_p(osc.prob_tables[1].data_ptr()), C.c_void_p(osc.pepmu.data_ptr()))
+                        1 if g["e_major"] else 0, None, None,    # full P tables: written by the stages only
+                        C.c_void_p(osc.pepmu.data_ptr()))
                 _lib.check(self._lib.pisa_hip_prob3_grid_planned(
                     C.byref(params), a[1], a[2], a[3], a[4], a[5], a[6], a[7], K._stream()))
             if self.aeff in changed:

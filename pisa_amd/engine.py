@@ -634,8 +634,10 @@ class HotPathEngine:
             a["data"], a["data_t"] = C.c_void_p(self.data.data_ptr()), self.data
         self._release_outputs()
         lib, s = a["lib"], K._stream()
+        # the fused kernel reads the (P_e, P_mu) gather tables only: the full P[3][3] tables (72 B per
+        # node, poorly coalesced stores) are not written on this path (`compute_probs` writes them)
         rc = lib.pisa_hip_prob3_grid_planned(C.byref(params), a["plan"], a["energy"], a["n_e"],
-                                             a["e_major"], a["nu"], a["nubar"], a["pepmu"], s)
+                                             a["e_major"], None, None, a["pepmu"], s)
         if rc == 0:
             fn = lib.pisa_hip_reweight_hist_acc if self._limbs_zero else lib.pisa_hip_reweight_hist
             rc = fn(a["cont"], a["n_cont"], a["grid"], a["nu"], a["nubar"], a["pepmu"], a["outb"],
