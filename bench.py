@@ -40,7 +40,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 L3_BYTES = 256 * 2 ** 20
-ALL_LEGS = ("l3_exceeding", "exact_association", "coordinate_form", "fine_binning", "update_flux",
+ALL_LEGS = ("l3_exceeding", "exact_association", "coordinate_form", "fine_binning", "update_flux", "node_flux",
             "pipeline_boundary", "events_c2", "events_c5", "kde_c3")
 
 
@@ -289,6 +289,56 @@ def leg_update_flux(synthetic, torch, wl, st, steps):
     return {"evals_per_s": 1.0 / dt, "ms_per_step": dt * 1e3,
             "what": "flux.barr_simple (nue/numu ratio + spectral index moved) for all events + refresh of the "
                     "folded (w0*aeff*flux) columns + the headline evaluation, every step"}
+
+
+def leg_node_flux(synthetic, torch, args, n_e, n_cz, steps):
+    """the shape of the IceCube 3-year cfgs: the flux lives on the oscillation grid (flux stages with
+    osc.prob3's calc_mode).  Every step: barr_simple on the grid nodes of the 12 containers, new node
+    tables, oscillation, flux x probability per node (pisa_hip_flux_prob_tables), fused
+    lookup+histogram with the events' static factor, LLH."""
+    import numpy as np
+
+    from pisa_amd import kernels as K
+
+    wl = synthetic.Workload(n_events=int(args.events), grid=(n_e, n_cz), out_binning=args.binning, seed=0)
+    g = wl.grid
+    ee, cc = np.meshgrid(g.energy, g.coszen, indexing="ij")
+    f_mu = 1e4 * ee ** -2.7 * (1 + 0.5 * cc ** 2)
+    nodes = np.stack([f_mu * (0.5 - 0.2 * cc), f_mu], axis=-1).reshape(-1, 2)
+    for ev in wl.events:
+        ev["nu_flux_nodes"] = nodes
+    st = synthetic.DeviceState(wl, compact=True, node_flux=True)
+    st.make_pseudo_data(wl.osc_params(), seed=0)
+    e_d, cz_d = K.to_device(ee.ravel()), K.to_device(cc.ravel())
+    nom, nom_bar = K.to_device(nodes), K.to_device(nodes * 0.7)
+    nubars = [ev["nubar"] for ev in wl.events]
+    plist = param_list(wl, 5 + 2 * steps)
+    rs = np.random.RandomState(5)
+
+    def one(p, flux_moves):
+        if flux_moves:
+            didx, ratio = 0.1 * (rs.rand() - 0.5), 1.0 + 0.05 * (rs.rand() - 0.5)
+            for i, nubar in enumerate(nubars):
+                K.barr_simple(e_d, cz_d, nom, nom_bar, nubar, ratio, 1.0, didx, 0.0, 0.0, out=st._node_flux_t[i])
+        return st.eval_host(p, "llh")
+
+    out = {}
+    for key, moves, pts in (("osc_only", False, plist[5:5 + steps]), ("flux_moves", True, plist[5 + steps:])):
+        for p in plist[:5]:
+            one(p, moves)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for p in pts:
+            one(p, moves)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        out[key] = {"evals_per_s": 1.0 / dt, "ms_per_step": dt * 1e3}
+    out["what"] = ("flux on the %d x %d oscillation grid (IceCube 3-y cfg shape): per-node flux x probability tables "
+                   "+ 20 B/event fused kernel; flux_moves = flux.barr_simple on the nodes of all containers every "
+                   "step as well" % (n_e, n_cz))
+    del st, wl
+    torch.cuda.empty_cache()
+    return out
 
 
 def _pipeline_cfg(n_events, kde=False):
@@ -627,6 +677,8 @@ def main():
                 legs[name] = hbm_leg(synthetic, lib, torch, args.events, n_e, n_cz, "fine3d", leg_steps)
             elif name == "update_flux":
                 legs[name] = leg_update_flux(synthetic, torch, wl, st, leg_steps) if compact else None
+            elif name == "node_flux":
+                legs[name] = leg_node_flux(synthetic, torch, args, n_e, n_cz, leg_steps)
             elif name == "pipeline_boundary":
                 legs[name] = leg_pipeline_boundary(torch, args.events, leg_steps)
             elif name == "events_c2":

@@ -447,6 +447,18 @@ int pisa_hip_transform_apply(const double *d_weights, const double *d_unc_weight
                              const int32_t *d_col, const double *d_val, int64_t n_out, double *d_hist,
                              double *d_sumw2, double *d_bin_unc2, void *stream);
 
+/* Flux on the oscillation grid (flux stages whose calc_mode is osc.prob3's, e.g. the IceCube 3-year
+ * cfgs): the reference looks up nu_flux and prob_e / prob_mu at the same node for every event
+ * (container.py:981-1012) and multiplies them per event (prob3.py:621-622).  Here the products are
+ * formed per node,
+ *   d_out[c][node] = (f_e[c][node] * P_e[c][node], f_mu[c][node] * P_mu[c][node]),
+ * h_d_flux_nodes[c] = device pointer to container c's [n_nodes][2] flux, d_pepmu = the gather tables
+ * of pisa_hip_prob3_grid[_planned]; d_out[c] is then passed as pisa_hip_container.d_pepmu with the
+ * static pair (w0*aeff, w0*aeff) in d_weighted_flux[_q]: a flux systematic costs this launch. */
+int pisa_hip_flux_prob_tables(const double *const *h_d_flux_nodes, const int32_t *h_nubar,
+                              const int32_t *h_flav, int32_t n_containers, const double *d_pepmu,
+                              int64_t n_nodes, double *d_out, void *stream);
+
 /* Refresh of the fused kernel's folded flux column after a flux stage rewrote `nu_flux`
  * (flux stages write container['nu_flux'], pisa/stages/flux/barr_simple.py:100; the reference then
  * multiplies it in every evaluation, prob3.py:621-622):

@@ -158,6 +158,7 @@ _SIGS = {
     "pisa_hip_bin_sqrt": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "pisa_hip_flux_2d": (C.c_int, [C.POINTER(FluxTable), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pisa_hip_transform_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pisa_hip_flux_prob_tables": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "pisa_hip_fold_flux": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "pisa_hip_barr_simple": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_void_p, C.c_void_p]),
     "pisa_hip_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_int64]),

@@ -364,6 +364,57 @@ PISA_API int pisa_hip_transform_apply(const double *d_weights, const double *d_u
     return PISA_HIP_OK;
 }
 
+
+namespace pisa {
+// Where the flux lives on the oscillation grid (flux stages with the calc_mode of osc.prob3, as in
+// the IceCube 3-year cfgs) an event's  f_e P_e + f_mu P_mu  (prob3.py:621-622 after two nearest-node
+// lookups, container.py:981-1012) depends on its node only.  The products are formed per NODE,
+//   out[c][node] = (f_e[c][node] * P_e[side_c][flav_c][node],  f_mu[c][node] * P_mu[...][node]),
+// and handed to the fused kernel as the per-container gather table; the events then carry only the
+// static pair (w0*aeff, w0*aeff) and a flux systematic costs this launch instead of a pass over
+// the events.
+struct FluxProbArgs {
+    int32_t n_cont;
+    int32_t side[16], flav[16];
+    const double2 *flux[16];
+};
+__global__ void __launch_bounds__(256)
+flux_prob_tables_kernel(const FluxProbArgs a, const double2 *__restrict__ pepmu, int64_t n_nodes,
+                        double2 *__restrict__ out) {
+    const int64_t node = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y;
+    if (node >= n_nodes) return;
+    const double2 f = a.flux[c][node];
+    const double2 p = pepmu[((int64_t)a.side[c] * 3 + a.flav[c]) * n_nodes + node];
+    out[(int64_t)c * n_nodes + node] = make_double2(f.x * p.x, f.y * p.y);
+}
+}  // namespace pisa
+
+PISA_API int pisa_hip_flux_prob_tables(const double *const *h_d_flux_nodes, const int32_t *h_nubar,
+                                       const int32_t *h_flav, int32_t n_containers, const double *d_pepmu,
+                                       int64_t n_nodes, double *d_out, void *stream) {
+    if (n_containers < 0 || n_nodes < 0 || !h_d_flux_nodes || !h_nubar || !h_flav) return PISA_HIP_ERR_INVALID;
+    if (n_containers == 0 || n_nodes == 0) return PISA_HIP_OK;
+    if (!d_pepmu || !d_out) return PISA_HIP_ERR_INVALID;
+    for (int base = 0; base < n_containers; base += 16) {
+        FluxProbArgs a;
+        a.n_cont = n_containers - base < 16 ? n_containers - base : 16;
+        for (int k = 0; k < a.n_cont; k++) {
+            const int c = base + k;
+            if (!h_d_flux_nodes[c] || (h_nubar[c] != 1 && h_nubar[c] != -1) || h_flav[c] < 0 || h_flav[c] > 2)
+                return PISA_HIP_ERR_INVALID;
+            a.flux[k] = reinterpret_cast<const double2 *>(h_d_flux_nodes[c]);
+            a.side[k] = h_nubar[c] > 0 ? 0 : 1;
+            a.flav[k] = h_flav[c];
+        }
+        hipLaunchKernelGGL(flux_prob_tables_kernel, dim3((unsigned)((n_nodes + 255) / 256), (unsigned)a.n_cont),
+                           dim3(256), 0, as_stream(stream), a, reinterpret_cast<const double2 *>(d_pepmu), n_nodes,
+                           reinterpret_cast<double2 *>(d_out) + (int64_t)base * n_nodes);
+        PISA_CHECK_LAUNCH("flux_prob_tables_kernel");
+    }
+    return PISA_HIP_OK;
+}
+
 PISA_API int pisa_hip_fold_flux(const double *d_flux, const int64_t *d_perm, const double *d_static_w,
                                 int64_t n, int32_t layout, double *d_out, void *stream) {
     if (n < 0 || (layout != 0 && layout != 1)) return PISA_HIP_ERR_INVALID;

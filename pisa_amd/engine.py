@@ -202,9 +202,20 @@ class HotPathEngine:
     def __init__(self, containers, grid, out_binning, earth, max_layers, rank=0, world_size=1,
                  group=None, indexed=True, planned=True, packed=True, sort_events=True,
                  external_tables=False, osc_mode="grid", drop_unbinned=False, compact=False, index16=True,
-                 lds_order=True):
+                 lds_order=True, node_flux=False):
         self.dev = K.device()
         assert osc_mode in ("grid", "events")
+        # flux given on the calc grid (`nu_flux_nodes` [grid.size, 2] per container) instead of per
+        # event: the per-node products flux x probability become each container's own gather table
+        # (`pisa_hip_flux_prob_tables`) and the events keep only their static factor
+        self.node_flux = bool(node_flux)
+        if self.node_flux:
+            assert osc_mode == "grid" and indexed and packed and compact, \
+                "node_flux needs the indexed, packed, compact event columns"
+            self._own_tables = torch.empty((len(containers), grid.size, 2), dtype=torch.float64,
+                                           device=self.dev)
+            self._node_flux_t = []
+            self._flux_tab_args = None
         self.osc_events = osc_mode == "events"
         self._event_sets = []
         if self.osc_events:
@@ -244,7 +255,15 @@ class HotPathEngine:
             lnE = K.to_device(np.log(np.asarray(c["true_energy"], dtype=np.float64)[sl]))
             cz = K.to_device(np.asarray(c["true_coszen"], dtype=np.float64)[sl])
             gx, gy = (lnE, cz) if grid.energy_first else (cz, lnE)
-            flux_d = K.to_device(np.asarray(c["nu_flux"], dtype=np.float64)[sl])
+            if self.node_flux:
+                fn = c["nu_flux_nodes"]
+                fn = (fn.to(self.dev, torch.float64) if torch.is_tensor(fn)
+                      else K.to_device(np.asarray(fn, dtype=np.float64))).reshape(grid.size, 2).contiguous().clone()
+                self._node_flux_t.append(fn)
+                d.d_pepmu = self._own_tables[len(self.cont)].data_ptr()
+                flux_d = torch.ones((hi - lo, 2), dtype=torch.float64, device=self.dev)
+            else:
+                flux_d = K.to_device(np.asarray(c["nu_flux"], dtype=np.float64)[sl])
             aeff_d = K.to_device(np.asarray(c["weighted_aeff"])[sl])
             w0_d = K.to_device(np.asarray(c["initial_weights"])[sl])
             cols = [K.to_device(np.asarray(col)[sl]) for col in c["sample"]]
@@ -404,6 +423,25 @@ class HotPathEngine:
         else:
             self._flux[i].copy_(f if perm is None else f[perm])
 
+    def update_flux_nodes(self, i, flux_nodes):
+        """node_flux mode: new [grid.size, 2] flux of container i on the calc grid (device tensor)"""
+        self._node_flux_t[i].copy_(flux_nodes.reshape(self.grid.size, 2))
+
+    def _flux_tables(self, pepmu):
+        """per-container gather tables flux x probability from the shared (P_e, P_mu) tables"""
+        import ctypes as C
+
+        a = self._flux_tab_args
+        if a is None:
+            n = len(self.cont)
+            a = self._flux_tab_args = dict(
+                ptrs=(C.c_void_p * n)(*[t.data_ptr() for t in self._node_flux_t]),
+                nubar=(C.c_int32 * n)(*[int(d.nubar) for d in self.cont]),
+                flav=(C.c_int32 * n)(*[int(d.flav) for d in self.cont]), n=n,
+                out=C.c_void_p(self._own_tables.data_ptr()), fn=_lib.lib().pisa_hip_flux_prob_tables)
+        return a["fn"](a["ptrs"], a["nubar"], a["flav"], a["n"], C.c_void_p(pepmu.data_ptr()),
+                       self.grid.size, a["out"], K._stream())
+
     @staticmethod
     def _fill_wflux(out, static_w, flux):
         """static_w * (f_e, f_mu) into the plain [n][2] column or the quad-blocked one (set-up)"""
@@ -446,6 +484,8 @@ class HotPathEngine:
         self._release_outputs()
         if params is not None:
             self.compute_probs(params)
+        if self.node_flux:
+            _lib.check(self._flux_tables(self.pepmu))
         K.reweight_hist(self._cont_arr, self.grid.binning, self.prob_nu, self.prob_nubar,
                         self.pepmu if (self.indexed and not self.osc_events) else None,
                         self.out_binning, self.ws, clear=not self._limbs_zero)
@@ -519,6 +559,8 @@ class HotPathEngine:
                 out=C.c_void_p(self.metric_host.data_ptr()),
                 mstatus=C.c_void_p(self.metric_status.data_ptr()), keep=pep)
         lib = a["lib"]
+        if self.node_flux:
+            _lib.check(self._flux_tables(a["keep"]))
         fn = lib.pisa_hip_reweight_hist_acc if self._limbs_zero else lib.pisa_hip_reweight_hist
         rc = fn(a["cont"], a["n_cont"], a["grid"], a["nu"], a["nubar"], a["pepmu"], a["outb"],
                 a["limbs"], a["status"], K._stream())
@@ -638,6 +680,8 @@ class HotPathEngine:
         # node, poorly coalesced stores) are not written on this path (`compute_probs` writes them)
         rc = lib.pisa_hip_prob3_grid_planned(C.byref(params), a["plan"], a["energy"], a["n_e"],
                                              a["e_major"], None, None, a["pepmu"], s)
+        if rc == 0 and self.node_flux:
+            rc = self._flux_tables(self.pepmu)
         if rc == 0:
             fn = lib.pisa_hip_reweight_hist_acc if self._limbs_zero else lib.pisa_hip_reweight_hist
             rc = fn(a["cont"], a["n_cont"], a["grid"], a["nu"], a["nubar"], a["pepmu"], a["outb"],
@@ -680,6 +724,8 @@ class HotPathEngine:
                                      out_nu=tab[0], out_nubar=tab[1], out_pepmu=tab[2])
                 osc_done[k].record(self._osc_stream)
             main.wait_event(osc_done[k])
+            if self.node_flux:
+                _lib.check(self._flux_tables(tab[2]))
             K.reweight_hist(self._cont_arr, self.grid.binning, tab[0], tab[1], tab[2],
                             self.out_binning, self.ws, clear=not self._limbs_zero)
             used[k % 2] = torch.cuda.Event()

@@ -137,6 +137,21 @@ class hist(Stage):  # pylint: disable=invalid-name
         if self._engine is not None and any(
                 c.version(k) != v[k] for c, v in zip(conts, self._engine_versions) for k in static_keys):
             self._engine = None   # a column folded / digitised at engine build was rewritten
+        # flux computed on the oscillation grid (flux stages with calc_mode = osc.prob3's, e.g. the
+        # IceCube 3-year cfgs): every event would look up flux AND probabilities at the same node
+        # (container.py:981-1012), so the engine multiplies them per node instead of per event
+        cm_hash = hash(cm)
+        node_flux = all(c.validity[flux_key].get(cm_hash, False) for c in conts)
+        if self._engine is not None and self._engine.node_flux != node_flux:
+            self._engine = None
+
+        def flux_on_nodes(c):
+            c.representation = cm
+            try:
+                return c.device(flux_key)
+            finally:
+                c.representation = "events"
+
         if self._engine is None:
             g = osc.grid
             grid = GridSpec(tuple(e_dim.domain.m_as("GeV")), e_dim.num_bins,
@@ -148,15 +163,20 @@ class hist(Stage):  # pylint: disable=invalid-name
             evs = []
             for c in conts:
                 c.representation = "events"
-                evs.append(dict(name=c.name, flav=int(c["flav"]), nubar=int(c["nubar"]),
-                                true_energy=c["true_energy"], true_coszen=c["true_coszen"],
-                                nu_flux=c[flux_key], weighted_aeff=c["weighted_aeff"],
-                                initial_weights=c["initial_weights"],
-                                sample=[s.cpu().numpy() for s in self._samples[c.name]], scale=1.0))
+                ev = dict(name=c.name, flav=int(c["flav"]), nubar=int(c["nubar"]),
+                          true_energy=c["true_energy"], true_coszen=c["true_coszen"],
+                          weighted_aeff=c["weighted_aeff"], initial_weights=c["initial_weights"],
+                          sample=[s.cpu().numpy() for s in self._samples[c.name]], scale=1.0)
+                if node_flux:
+                    ev["nu_flux_nodes"] = flux_on_nodes(c)
+                else:
+                    ev["nu_flux"] = c[flux_key]
+                evs.append(ev)
             # compact columns: initial_weights*weighted_aeff folded into the flux pair once
             # (refreshed by update_flux below whenever a flux systematic moved)
             self._engine = HotPathEngine(evs, grid, self._reg_binning, None, 0, rank=rank,
-                                         world_size=world, external_tables=True, compact=True)
+                                         world_size=world, external_tables=True, compact=True,
+                                         node_flux=node_flux)
             self._engine_versions = [{k: c.version(k) for k in static_keys + (flux_key,)}
                                      for c in conts]
         eng = self._engine
@@ -166,7 +186,10 @@ class hist(Stage):  # pylint: disable=invalid-name
             # the container's change counter, not object identity: a stage that edits the flux in
             # place and calls mark_changed (container.py:638-649) keeps the same array object
             if c.version(flux_key) != self._engine_versions[i][flux_key]:
-                eng.update_flux(i, c.device(flux_key))   # flux systematics changed
+                if node_flux:                            # flux systematics changed
+                    eng.update_flux_nodes(i, flux_on_nodes(c))
+                else:
+                    eng.update_flux(i, c.device(flux_key))
                 self._engine_versions[i][flux_key] = c.version(flux_key)
         eng.pepmu = osc.pepmu
         eng.accumulate()

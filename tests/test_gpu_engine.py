@@ -180,6 +180,73 @@ def test_index16_form_is_bit_identical_to_compact(n_events):
     dropped.check_status()
 
 
+def test_node_flux_tables_match_per_event_flux():
+    """Flux living on the oscillation grid: the engine forms flux x probability per node
+    (`pisa_hip_flux_prob_tables`) and the events carry only w0*aeff.  Same maps and LLH as the
+    per-event form fed with the flux looked up at every event's node (different association of
+    the same three factors: a few ulp), through every entry point, and after a flux update."""
+    import torch
+
+    from pisa_amd import kernels as K
+    from pisa_amd import synthetic
+
+    wl = synthetic.Workload(n_events=60011, grid=(60, 40), out_binning="dragon", seed=33)
+    g = wl.grid
+    ee, cc = np.meshgrid(g.energy, g.coszen, indexing="ij")
+    rs = np.random.RandomState(2)
+    node_flux = []
+    for ev in wl.events:
+        f_mu = 1e4 * ee ** -2.7 * (1 + 0.5 * cc ** 2) * (0.8 + 0.4 * rs.rand(*ee.shape))
+        fn = np.stack([f_mu * (0.5 - 0.2 * cc), f_mu], axis=-1).reshape(-1, 2)
+        gx, gy = K.to_device(np.log(ev["true_energy"])), K.to_device(ev["true_coszen"])
+        node = K.event_indices([gx, gy], g.binning).cpu().numpy()
+        assert node.min() >= 0
+        ev["nu_flux"] = fn[node]
+        ev["nu_flux_nodes"] = fn
+        node_flux.append(fn)
+    p = wl.osc_params(theta23_deg=47.0, deltacp_deg=120.0)
+    per_event = synthetic.DeviceState(wl, compact=True)
+    on_nodes = synthetic.DeviceState(wl, compact=True, node_flux=True)
+    assert on_nodes.index16 and on_nodes.cont[0].d_pepmu
+    per_event.make_pseudo_data(wl.osc_params(), seed=0)
+    on_nodes.set_data(per_event.data.cpu().numpy())
+
+    def same(a, b, rtol=1e-13):
+        np.testing.assert_allclose(a, b, rtol=rtol, atol=0)
+
+    def same_llh(a, b):   # a sum of differences of the maps: conditioned worse than the maps
+        same(a, b, rtol=1e-11)
+
+    same_llh(on_nodes.eval_host(p), per_event.eval_host(p))             # lean path
+    for a, b in zip(on_nodes.maps(), per_event.maps()):
+        same(a, b)
+    assert per_event.maps()[1].sum() > 0
+    on_nodes.accumulate(p)                                              # generic entry points
+    per_event.accumulate(p)
+    for a, b in zip(on_nodes.finalize(), per_event.finalize()):
+        same(a.cpu().numpy(), b.cpu().numpy())
+    pts = [wl.osc_params(theta23_deg=t) for t in (40.0, 45.0, 50.0)]    # two-stream batch
+    same_llh(on_nodes.eval_batch(pts).cpu().numpy(), per_event.eval_batch(pts).cpu().numpy())
+    # a flux systematic: 640 kB per container instead of a pass over the events
+    i = 3
+    before = on_nodes.eval_host(p)
+    scaled = node_flux[i] * np.array([0.9, 1.3])
+    on_nodes.update_flux_nodes(i, K.to_device(scaled))
+    gx, gy = K.to_device(np.log(wl.events[i]["true_energy"])), K.to_device(wl.events[i]["true_coszen"])
+    node = K.event_indices([gx, gy], g.binning).long()
+    per_event.update_flux(i, K.to_device(scaled)[node])
+    after = on_nodes.eval_host(p)
+    same_llh(after, per_event.eval_host(p))
+    assert after != before
+    # bit-identical run to run and for any event order (exact accumulation)
+    assert on_nodes.eval_host(p) == after
+    unsorted = synthetic.DeviceState(wl, compact=True, node_flux=True, sort_events=False)
+    unsorted.set_data(per_event.data.cpu().numpy())
+    unsorted.update_flux_nodes(i, K.to_device(scaled))
+    assert unsorted.eval_host(p) == after
+    on_nodes.check_status()
+
+
 def torch_equal(a, b):
     import torch
 

@@ -111,6 +111,9 @@ def test_neutrino_cfg_unmodified_vs_oracle(oracle, tmp_path, monkeypatch):
     pipe.params.nu_nc_norm.value = 1.1 * ureg.dimensionless
     maps = pipe.get_outputs()
     assert pipe["hist"].fused_last_eval
+    # the cfg computes the flux on the oscillation grid (calc_mode = true_allsky_fine on both):
+    # the engine forms flux x probability per node instead of per event
+    assert pipe["hist"]._engine.node_flux
 
     # ---------------- oracle chain on the same file
     mc = pd.read_csv(os.path.join(str(tmp_path), "events/IceCube_3y_oscillations/neutrino_mc.csv.bz2"))
@@ -138,6 +141,20 @@ def test_neutrino_cfg_unmodified_vs_oracle(oracle, tmp_path, monkeypatch):
         np.testing.assert_allclose(m.hist.ravel(), want_w, rtol=1e-10, atol=1e-300, err_msg=m.name)
         np.testing.assert_allclose(m.std_devs.ravel(), want_e, rtol=1e-10, atol=1e-300, err_msg=m.name)
     assert sum(m.hist.sum() for m in maps) > 0
+
+    # a flux systematic moves: the resident engine takes the new node tables (no new engine) and
+    # gives what a pipeline built at those values gives
+    eng = pipe["hist"]._engine
+    pipe.params.delta_index.value = -0.04 * ureg.dimensionless
+    pipe.params.theta23.value = 43.0 * ureg.degree
+    moved = pipe.get_outputs()
+    assert pipe["hist"]._engine is eng
+    fresh = Pipeline("settings/pipeline/IceCube_3y_neutrinos.cfg")
+    for q in pipe.params:
+        fresh.params[q.name].value = q.value
+    for a, b in zip(moved, fresh.get_outputs()):
+        assert np.array_equal(a.hist, b.hist) and np.array_equal(a.std_devs, b.std_devs), a.name
+    assert not np.array_equal(moved[2].hist, maps[2].hist)
 
 
 def test_published_analysis_template_and_metrics(oracle, tmp_path, monkeypatch):
