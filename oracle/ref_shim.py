@@ -2,8 +2,8 @@
 Python kernels (read in place from /root/reference) without numba/pint.
 
 TEST INFRASTRUCTURE ONLY.  Used by ``oracle/gen_golden.py`` to produce the
-fixtures under ``tests/golden/`` and by ``tests/test_oracle_vs_reference.py``
-(skipped when /root/reference is absent, e.g. on the GPU box).  Nothing of the
+fixtures under ``tests/golden/`` (run in this container, where /root/reference exists; the
+tests themselves read only the committed fixtures).  Nothing of the
 reference is copied: the modules are imported by path and run as plain Python
 after pre-seeding ``sys.modules`` with inert stand-ins for the compiled /
 unit-system dependencies (SURVEY.md Appendix B recipe).

@@ -434,3 +434,48 @@ def test_event_mode_engine_vs_oracle(K, L, oracle):
     np.testing.assert_allclose(hist, ref["hist"], rtol=1e-10, atol=1e-300)
     np.testing.assert_allclose(sumw2, ref["sumw2"], rtol=1e-10, atol=1e-300)
     assert hist.sum() > 0
+
+
+def test_profile_hook_is_per_host_thread():
+    """`pisa_hip_profile_events` (include/pisa_hip.h): the event pair belongs to the calling host
+    thread.  A launch from another thread neither records the pair nor clears it; the next launch
+    of the owning thread does."""
+    import threading
+
+    import torch
+
+    from pisa_amd import _lib
+    from pisa_amd import kernels as K
+
+    lib = _lib.lib()
+    x = K.to_device(np.random.RandomState(0).rand(200000))
+    w = K.to_device(np.ones(200000))
+    b = _lib.make_binning([0.0], [1.0], [10])
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record(); stop.record()          # materialise the handles
+    torch.cuda.synchronize()
+    assert start.elapsed_time(stop) < 1.0  # back to back: nothing in between
+    assert lib.pisa_hip_profile_events(start.cuda_event, stop.cuda_event) == 0
+    res = {}
+
+    def other():
+        with torch.cuda.stream(torch.cuda.Stream()):
+            big = K.to_device(np.random.RandomState(1).rand(4000000))
+            for _ in range(20):
+                res["h"] = K.histogram_regular([big], torch.ones_like(big), b)
+            torch.cuda.synchronize()
+
+    t = threading.Thread(target=other)
+    t.start(); t.join()
+    torch.cuda.synchronize()
+    assert abs(float(res["h"].sum()) - 4000000) < 1e-6
+    assert start.elapsed_time(stop) < 1.0  # the other thread's launches did not touch the pair
+    h = K.histogram_regular([x], w, b)     # this thread's launch records it
+    torch.cuda.synchronize()
+    assert lib.pisa_hip_profile_events(None, None) == 0
+    assert abs(float(h.sum()) - 200000) < 1e-9
+    dt = start.elapsed_time(stop)
+    assert 0.0 < dt < 50.0
+    K.histogram_regular([x], w, b)         # disabled: the pair keeps its last recording
+    torch.cuda.synchronize()
+    assert start.elapsed_time(stop) == dt
