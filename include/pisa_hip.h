@@ -364,6 +364,18 @@ int64_t pisa_hip_kde_resident_bytes(const pisa_hip_kde *k);
 int64_t pisa_hip_kde_eval_workspace_bytes(const pisa_hip_kde *k, int64_t n_qry);
 int pisa_hip_kde_evaluate(pisa_hip_kde *k, const double *d_qry, int64_t m, void *d_work,
                           int64_t work_bytes, double *d_out, void *stream);
+/* `k(points)` for the points of a lattice  x[d] = h_origin[d] + i_d h_step[d], 0 <= i_d < h_count[d]
+ * (host arrays of length dim), d_out[(i_0 n_1 + i_1) n_2 + i_2] -- numpy.meshgrid(indexing="ij")
+ * order, the shape in which get_hist evaluates a map (kde_hist.py:122-190: oversampled bin centres
+ * of a regular binning, coszen reflection included).  Same values as pisa_hip_kde_evaluate on the
+ * written-out points to rounding (<= 1e-12 relative); in 2-D with a cut-off the kernel values along
+ * a lattice line come from a two-multiplication recurrence instead of one exponential each.
+ * d_work >= pisa_hip_kde_lattice_workspace_bytes(k, h_step, h_count) bytes. */
+int64_t pisa_hip_kde_lattice_workspace_bytes(const pisa_hip_kde *k, const double *h_step,
+                                             const int64_t *h_count);
+int pisa_hip_kde_evaluate_lattice(pisa_hip_kde *k, const double *h_origin, const double *h_step,
+                                  const int64_t *h_count, void *d_work, int64_t work_bytes,
+                                  double *d_out, void *stream);
 int pisa_hip_kde_info(const pisa_hip_kde *k, pisa_hip_kde_info_t *info);
 /* device pointers into the resident workspace, in the estimator's (cell-sorted) source order:
  * whitened coordinates ys[dim][n], kernel coefficients coef[n], squared inverse local bandwidths s2[n] */

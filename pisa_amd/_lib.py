@@ -148,6 +148,8 @@ _SIGS = {
     "pisa_hip_kde_create": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.c_void_p]),
     "pisa_hip_kde_resident_bytes": (C.c_int64, [C.c_void_p]),
     "pisa_hip_kde_eval_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int64]),
+    "pisa_hip_kde_lattice_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pisa_hip_kde_evaluate_lattice": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "pisa_hip_kde_evaluate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "pisa_hip_kde_info": (C.c_int, [C.c_void_p, C.POINTER(KdeInfo)]),
     "pisa_hip_kde_arrays": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),

@@ -467,6 +467,214 @@ kde_combine_kernel(const double *__restrict__ partial, int n_split, int64_t n,
     out[perm ? perm[k] : k] = acc;
 }
 
+// ------------------------------------------------------------------ evaluation on a lattice
+// A map's evaluation points are a tensor grid with uniform steps (oversampled bin centres,
+// kde_hist.py:122-190).  In whitened coordinates (U upper triangular) lattice index 0 moves y_a
+// only, by da = U00 step0, and index 1 moves (y_a, y_b) by (sa, db) = (U01, U11) step1: along a
+// line of constant index 1 the kernel values of one source are a Gaussian sampled at equal steps,
+//   g_{k+1} = g_k r_k,  r_{k+1} = r_k q,  q = exp(-s2 da^2),
+// two multiplications per point instead of an exponential.  A thread owns a strip of R
+// consecutive points of one line and starts at the strip's middle point (three exponentials per
+// source and strip: the middle value and the first ratio in either direction).  The host admits
+// R only if R da sqrt(max s2) <= 50: the middle point of a strip within reach of a source is then
+// at most (sqrt(rcut2) + 25) kernel widths away, its value >= exp(-600), and no ratio leaves the
+// double range.  Rounding: g_k carries the error of k^2 / 2 multiplications and of exponents up
+// to a few hundred, < 3e-13 relative for R = 32.  A strip is skipped for a source only if every
+// one of its points is beyond the cut-off, so the stated tolerance holds.  Fixed order (sources
+// in sorted order inside a share, shares added in order): bit-reproducible.
+struct KdeLattice {
+    double ya0, yb0;   // whitened coordinates of lattice point (0, 0)
+    double da;         // y_a step of index 0 (> 0)
+    double sa, db;     // (y_a, y_b) step of index 1
+    int32_t n0, n1, strips_a;   // strips_a = ceil(n0 / R)
+};
+
+// exp(t), |t| <~ 700
+__device__ inline double exp_any(double t) {
+    t = fmin(fmax(t, -800.0), 700.0);
+    const double k = __builtin_rint(t * 1.4426950408889634074);
+    double r = __builtin_fma(k, -6.93147180369123816490e-01, t);
+    r = __builtin_fma(k, -1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;
+    p = __builtin_fma(p, r, 2.08767569878680989792e-09);
+    p = __builtin_fma(p, r, 2.50521083854417187751e-08);
+    p = __builtin_fma(p, r, 2.75573192239858906526e-07);
+    p = __builtin_fma(p, r, 2.75573192239858906526e-06);
+    p = __builtin_fma(p, r, 2.48015873015873015873e-05);
+    p = __builtin_fma(p, r, 1.98412698412698412698e-04);
+    p = __builtin_fma(p, r, 1.38888888888888888889e-03);
+    p = __builtin_fma(p, r, 8.33333333333333333333e-03);
+    p = __builtin_fma(p, r, 4.16666666666666666667e-02);
+    p = __builtin_fma(p, r, 1.66666666666666666667e-01);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)k);
+}
+
+constexpr int LAT_REC = 6;   // doubles per source record: y_a, y_b, coef, -s2/2, q, -s2 da
+constexpr int LAT_SHARE = 64;   // sources per share
+__global__ void __launch_bounds__(256)
+kde_lattice_prep_kernel(const double *__restrict__ ys, const double *__restrict__ coef,
+                        const double *__restrict__ s2, int64_t n, double da, double *__restrict__ rec) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const double v = s2[k];
+    double *r = rec + k * LAT_REC;
+    r[0] = ys[k];
+    r[1] = ys[n + k];
+    r[2] = coef[k];
+    r[3] = -0.5 * v;
+    r[4] = exp_nonpos(-v * da * da);
+    r[5] = -v * da;
+}
+
+// per share of the sorted sources: the y_b interval outside which no lattice line is within the
+// cut-off of any of its sources (sources are sorted by cell row, so a share is a narrow band)
+__global__ void __launch_bounds__(64)
+kde_lattice_band_kernel(const double *__restrict__ rec, int64_t n_src, int64_t share, double rcut2,
+                        double *__restrict__ band) {
+    const int64_t k0 = (int64_t)blockIdx.x * share;
+    const int64_t k1 = k0 + share < n_src ? k0 + share : n_src;
+    double lo = INFINITY, hi = -INFINITY;
+    for (int64_t k = k0 + threadIdx.x; k < k1; k += 64) {
+        const double yb = rec[k * LAT_REC + 1];
+        const double reach = sqrt(rcut2 / (-2.0 * rec[k * LAT_REC + 3]));
+        lo = fmin(lo, yb - reach);
+        hi = fmax(hi, yb + reach);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = fmin(lo, __shfl_down(lo, off));
+        hi = fmax(hi, __shfl_down(hi, off));
+    }
+    if (threadIdx.x == 0) {
+        band[2 * blockIdx.x] = lo;
+        band[2 * blockIdx.x + 1] = hi;
+    }
+}
+
+// Workgroup = one wavefront = 64 strips (t fastest: 64 / strips_a whole lattice lines, all
+// their strips) x one share of the sources.  partial[share][m][strip]: lane-contiguous stores.
+template <int R>
+__global__ void __launch_bounds__(64)
+kde_lattice_kernel(const KdeLattice L, double rcut2, const double *__restrict__ rec, int64_t n_src,
+                   int64_t share, const double *__restrict__ band, double *__restrict__ partial,
+                   unsigned long long *__restrict__ pair_count) {
+    constexpr int C = R / 2;   // the strip's middle point
+    const int n_strips = L.strips_a * L.n1;
+    const int sid = (int)blockIdx.x * 64 + (int)threadIdx.x;   // strip (j, t), t fastest
+    const bool live = sid < n_strips;
+    const int j = live ? sid / L.strips_a : 0, t = live ? sid - j * L.strips_a : 0;
+    const double yb = L.yb0 + j * L.db;
+    const double ya_c = L.ya0 + j * L.sa + (double)(t * R + C) * L.da;
+    const double ext_lo = C * L.da, ext_hi = (R - 1 - C) * L.da;
+    double acc[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) acc[k] = 0.0;
+    unsigned long long strips = 0;
+    // The sorted sources are cut into shares of `share` sources (narrow bands in y_b); this
+    // wavefront takes the shares blockIdx.y, blockIdx.y + gridDim.y, ...: every wavefront sees a
+    // sample of all regions, so the work is balanced without a dynamic queue.
+    const int64_t n_shares = (n_src + share - 1) / share;
+    for (int64_t sub = blockIdx.y; sub < n_shares; sub += gridDim.y) {
+        // whole share out of reach of every line of this wavefront?
+        const double b_lo = band[2 * sub], b_hi = band[2 * sub + 1];
+        if (!__builtin_amdgcn_ballot_w64(live && yb >= b_lo && yb <= b_hi)) continue;
+        const int64_t k0 = sub * share;
+        const int64_t k1 = k0 + share < n_src ? k0 + share : n_src;
+        const double *__restrict__ s = rec + k0 * LAT_REC;   // wave-uniform: scalar loads
+        double sya = s[0], syb = s[1], cf = s[2], sh = s[3], q = s[4], shd2 = s[5];
+        for (int64_t k = k0; k < k1; k++) {
+            // next record requested before this one is used (the last one reads itself again)
+            const double *__restrict__ nx = rec + (k + 1 < k1 ? k + 1 : k) * LAT_REC;
+            const double n0 = nx[0], n1 = nx[1], n2 = nx[2], n3 = nx[3], n4 = nx[4], n5 = nx[5];
+            const double xc = ya_c - sya, dbb = yb - syb;
+            const double dn = fmax(fmax(xc - ext_lo, -(xc + ext_hi)), 0.0);   // nearest point of the strip
+            const bool in = live && (dbb * dbb + dn * dn) * sh * -2.0 <= rcut2;
+            if (__builtin_amdgcn_ballot_w64(in)) {
+#ifdef KDE_LATTICE_DEBUG
+                if (threadIdx.x == 0) atomicAdd(pair_count + 1, 1ULL);
+#endif
+                if (in) {
+                    strips++;
+                    const double gc = cf * exp_nonpos(sh * __builtin_fma(xc, xc, dbb * dbb));
+                    const double e = shd2 * L.da * 0.5;                        // -s2 da^2 / 2
+                    const double r_up = exp_any(__builtin_fma(shd2, xc, e));    // g(c+1) / g(c)
+                    const double r_dn = exp_any(__builtin_fma(-shd2, xc, e));   // g(c-1) / g(c)
+                    double g = gc, r = r_up;
+                    double g2 = gc * r_dn, r2 = r_dn * q;
+#pragma unroll
+                    for (int m = 0; m < R - C; m++) {   // both directions interleaved: two independent chains
+                        acc[C + m] += g;
+                        g *= r;
+                        r *= q;
+                        if (C - 1 - m >= 0) {
+                            acc[C - 1 - m] += g2;
+                            g2 *= r2;
+                            r2 *= q;
+                        }
+                    }
+                }
+            }
+            sya = n0; syb = n1; cf = n2; sh = n3; q = n4; shd2 = n5;
+        }
+#ifdef KDE_LATTICE_DEBUG
+        if (threadIdx.x == 0) atomicAdd(pair_count + 2, (unsigned long long)(k1 - k0));
+#endif
+    }
+    if (live) {
+        double *out = partial + (int64_t)blockIdx.y * R * n_strips + sid;
+#pragma unroll
+        for (int m = 0; m < R; m++) out[(int64_t)m * n_strips] = acc[m];
+    }
+    if (pair_count) {
+        strips *= R;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) strips += __shfl_down(strips, off);
+        if (threadIdx.x == 0 && strips) atomicAdd(pair_count, strips);
+    }
+}
+
+// out[i0 n1 + i1] = sum over the shares of partial[share][m][strip], strip = i1 strips_a + i0 / R,
+// m = i0 % R.  256 threads = 16 entries x 16 share groups; a group adds its shares (g, g + 16, ...) in
+// order, the 16 group sums are added in order: fixed association, bit-reproducible.
+__global__ void __launch_bounds__(256)
+kde_lattice_combine_kernel(const double *__restrict__ partial, int n_split, int R, int strips_a, int n0, int n1,
+                           double *__restrict__ out) {
+    __shared__ double lds[16][17];
+    const int n_strips = strips_a * n1;
+    const int64_t per = (int64_t)R * n_strips;
+    const int e_loc = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int64_t e = (int64_t)blockIdx.x * 16 + e_loc;    // entry of the [m][strip] layout
+    double acc = 0.0;
+    if (e < per)
+        for (int sp = grp; sp < n_split; sp += 16) acc += partial[(int64_t)sp * per + e];
+    lds[grp][e_loc] = acc;
+    __syncthreads();
+    if (grp == 0 && e < per) {
+        double v = lds[0][e_loc];
+#pragma unroll
+        for (int g = 1; g < 16; g++) v += lds[g][e_loc];
+        const int m = (int)(e / n_strips), sid = (int)(e - (int64_t)m * n_strips);
+        const int j = sid / strips_a, t = sid - j * strips_a;
+        const int i0 = t * R + m;
+        if (i0 < n0) out[(int64_t)i0 * n1 + j] = v;
+    }
+}
+
+// lattice -> explicit points x[d][i0 * n1 * n2 + i1 * n2 + i2] (for the general evaluation)
+__global__ void __launch_bounds__(256)
+kde_lattice_points_kernel(int dim, double o0, double o1, double o2, double s0, double s1, double s2_,
+                          int n1, int n2, int64_t m, double *__restrict__ x) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const int64_t i2 = i % n2, i1 = (i / n2) % n1, i0 = i / ((int64_t)n1 * n2);
+    x[i] = o0 + (double)i0 * s0;
+    if (dim > 1) x[m + i] = o1 + (double)i1 * s1;
+    if (dim > 2) x[2 * m + i] = o2 + (double)i2 * s2_;
+}
+
 // sum of log(pilot) -> partial[block]
 __global__ void __launch_bounds__(RED_THREADS)
 kde_logsum_kernel(const double *__restrict__ pilot, int64_t n, double *__restrict__ partial) {
@@ -486,7 +694,7 @@ kde_bandwidth_kernel(const double *__restrict__ pilot, const double *__restrict_
                      double *__restrict__ coef, double *__restrict__ s2, double *__restrict__ partial_min) {
     __shared__ double lds[RED_THREADS];
     const double glob = exp(*logsum / (double)n);
-    double mn = INFINITY;
+    double mn = INFINITY, mx = -INFINITY;
     for (int64_t i = (int64_t)blockIdx.x * RED_THREADS + threadIdx.x; i < n;
          i += (int64_t)RED_BLOCKS * RED_THREADS) {
         const double lam = pow(pilot[i] / glob, alpha);
@@ -494,9 +702,14 @@ kde_bandwidth_kernel(const double *__restrict__ pilot, const double *__restrict_
         s2[i] = l2;
         coef[i] = wn[i] * (dim == 1 ? lam : (dim == 2 ? l2 : l2 * lam)) * inv_norm;
         mn = fmin(mn, l2);   // NaN (pilot <= 0 cannot happen: own term) is ignored by fmin
+        mx = fmax(mx, l2);
     }
     const double r = block_min(mn, lds);
-    if (threadIdx.x == 0) partial_min[blockIdx.x] = r;
+    const double r2 = -block_min(-mx, lds);
+    if (threadIdx.x == 0) {   // [block][2]: smallest and largest s2 (widest and narrowest kernel)
+        partial_min[blockIdx.x * 2] = r;
+        partial_min[blockIdx.x * 2 + 1] = r2;
+    }
 }
 
 // fixed bandwidth: coef = wn / norm, s2 = 1
@@ -932,7 +1145,8 @@ struct pisa_hip_kde {
     KdeGeom g;
     int64_t n_cells;
     // device (inside the caller's workspace)
-    double *ys, *wn, *coef, *s2, *cell_s2min, *scalars;   // scalars: [0] log-sum, [1] min s2
+    double *ys, *wn, *coef, *s2, *cell_s2min, *scalars;   // scalars: [0] log-sum, [1] min s2, [2] max s2
+    double s2_range[2];   // host copy of scalars[1..2]
     int32_t *cell_start;
     unsigned long long *pair_count;
     unsigned long long pairs_pilot, pairs_eval;
@@ -1204,8 +1418,8 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
     if (!adaptive) {
         hipLaunchKernelGGL(kde_fixed_bandwidth_kernel, dim3(nb), dim3(256), 0, s, k->wn, n, 1.0 / k->norm,
                            k->coef, k->s2);
-        const double one = 1.0;
-        KDE_TRY_HIP(hipMemcpyAsync(k->scalars + 1, &one, sizeof(double), hipMemcpyHostToDevice, s));
+        k->s2_range[0] = k->s2_range[1] = 1.0;
+        KDE_TRY_HIP(hipMemcpyAsync(k->scalars + 1, k->s2_range, 2 * sizeof(double), hipMemcpyHostToDevice, s));
     } else {
         // pilot estimate at the sources themselves: queries = sorted sources, tiles = cells
         hipLaunchKernelGGL(kde_fixed_bandwidth_kernel, dim3(nb), dim3(256), 0, s, k->wn, n, 1.0 / k->norm,
@@ -1337,9 +1551,10 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
         hipLaunchKernelGGL(kde_final_reduce_kernel, dim3(1), dim3(RED_THREADS), 0, s, partial, 1, 1, 0, k->scalars);
         hipLaunchKernelGGL(kde_bandwidth_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, pilot, k->wn, n,
                            k->scalars, alpha, dim, 1.0 / k->norm, k->coef, k->s2, partial);
-        hipLaunchKernelGGL(kde_final_reduce_kernel, dim3(1), dim3(RED_THREADS), 0, s, partial, 1, 0, 1,
-                           k->scalars + 1);
+        hipLaunchKernelGGL(kde_final_reduce_kernel, dim3(1), dim3(RED_THREADS), 0, s, partial, 2, 0, 1,
+                           k->scalars + 1);   // [1] min s2, [2] max s2
         KDE_TRY(check_hip(hipGetLastError(), "kde pilot kernels"));
+        KDE_TRY_HIP(hipMemcpyAsync(k->s2_range, k->scalars + 1, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
         // the host copy of the blocks must outlive the asynchronous upload
         KDE_TRY_HIP(hipMemcpyAsync(&k->pairs_pilot, k->pair_count, sizeof(unsigned long long),
                                    hipMemcpyDeviceToHost, s));
@@ -1433,6 +1648,119 @@ PISA_API int pisa_hip_kde_evaluate(pisa_hip_kde *k, const double *d_qry, int64_t
     return PISA_HIP_OK;
 }
 #undef KDE_D
+
+// ---- evaluation on a lattice of points  x[d] = origin[d] + i_d step[d],  0 <= i_d < count[d],
+//      out[(i_0 n_1 + i_1) n_2 + i_2]  (numpy.meshgrid(indexing="ij") order)
+static int lattice_strip(const pisa_hip_kde *k, const double *step, const int64_t *count) {
+    if (k->dim != 2 || !(k->g.rcut2 > 0.0) || count[0] * count[1] > 0x7FFFFFF0LL) return 0;
+    const double da = k->g.U[0] * step[0];
+    if (!(da > 0.0) || !std::isfinite(da) || !(k->s2_range[1] > 0.0)) return 0;
+    static const int forced = [] { const char *v = getenv("PISA_HIP_KDE_LATTICE_R"); return v ? atoi(v) : -1; }();
+    if (forced == 0) return 0;
+    const double lim = 50.0 / (da * sqrt(k->s2_range[1]));
+    for (int R : {32, 16, 8})
+        if ((double)R <= lim && (forced < 0 || R <= forced)) return R;
+    return 0;
+}
+
+static int lattice_split(int R, const int64_t *count, int64_t n) {
+    const int64_t strips = ((count[0] + R - 1) / R) * count[1];
+    const int64_t blocks = (strips + 63) / 64;
+    static const int waves = [] { const char *v = getenv("PISA_HIP_KDE_LATTICE_WAVES"); return v ? atoi(v) : 4096; }();
+    int64_t n_split = std::max<int64_t>(1, waves / blocks);
+    n_split = std::min<int64_t>(n_split, std::max<int64_t>(1, n / (4 * LAT_SHARE)));
+    n_split = std::min<int64_t>(n_split, std::max<int64_t>(1, (int64_t)(128 << 20) / (blocks * 64 * R * 8)));
+    return (int)std::min<int64_t>(n_split, 4096);
+}
+
+PISA_API int64_t pisa_hip_kde_lattice_workspace_bytes(const pisa_hip_kde *k, const double *h_step,
+                                                      const int64_t *h_count) {
+    if (!k || !h_step || !h_count) return -1;
+    int64_t m = 1;
+    for (int d = 0; d < k->dim; d++) {
+        if (h_count[d] < 1 || h_count[d] > 0x7FFFFFF0LL / m) return -1;
+        m *= h_count[d];
+    }
+    const int R = lattice_strip(k, h_step, h_count);
+    if (R)
+    {
+        const size_t n_split = (size_t)lattice_split(R, h_count, k->n);
+        const size_t per = (size_t)R * (size_t)((h_count[0] + R - 1) / R) * (size_t)h_count[1];
+        return (int64_t)((size_t)k->n * LAT_REC * 8 + n_split * per * 8 + ((size_t)k->n / LAT_SHARE + 1) * 16 + 4096);
+    }
+    const int64_t general = pisa_hip_kde_eval_workspace_bytes(k, m);
+    return general < 0 ? -1 : general + (int64_t)k->dim * m * 8 + 4096;
+}
+
+PISA_API int pisa_hip_kde_evaluate_lattice(pisa_hip_kde *k, const double *h_origin, const double *h_step,
+                                           const int64_t *h_count, void *d_work, int64_t work_bytes,
+                                           double *d_out, void *stream) {
+    if (!k || !h_origin || !h_step || !h_count || !d_out || !d_work) return PISA_HIP_ERR_INVALID;
+    const int dim = k->dim;
+    int64_t m = 1;
+    for (int d = 0; d < dim; d++) {
+        if (h_count[d] < 1 || h_count[d] > 0x7FFFFFF0LL / m || !std::isfinite(h_origin[d]) ||
+            !std::isfinite(h_step[d]))
+            return PISA_HIP_ERR_INVALID;
+        m *= h_count[d];
+    }
+    hipStream_t s = as_stream(stream);
+    Arena ar(d_work, (size_t)work_bytes);
+    const int R = lattice_strip(k, h_step, h_count);
+    if (!R) {   // not a 2-D lattice this form covers: the points written out, general evaluation
+        double *x = ar.take<double>((size_t)dim * m);
+        if (!ar.ok) return PISA_HIP_ERR_NOMEM;
+        hipLaunchKernelGGL(kde_lattice_points_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, dim,
+                           h_origin[0], dim > 1 ? h_origin[1] : 0.0, dim > 2 ? h_origin[2] : 0.0, h_step[0],
+                           dim > 1 ? h_step[1] : 0.0, dim > 2 ? h_step[2] : 0.0,
+                           dim > 1 ? (int)h_count[1] : 1, dim > 2 ? (int)h_count[2] : 1, m, x);
+        PISA_CHECK_LAUNCH("kde_lattice_points_kernel");
+        const size_t used = ((size_t)dim * m * 8 + 255) & ~(size_t)255;
+        return pisa_hip_kde_evaluate(k, x, m, (char *)d_work + used, work_bytes - (int64_t)used, d_out, stream);
+    }
+    const KdeGeom &g = k->g;
+    KdeLattice L;
+    const double dx0 = h_origin[0] - g.mean[0], dx1 = h_origin[1] - g.mean[1];
+    L.ya0 = g.U[0] * dx0 + g.U[1] * dx1;
+    L.yb0 = g.U[4] * dx1;
+    L.da = g.U[0] * h_step[0];
+    L.sa = g.U[1] * h_step[1];
+    L.db = g.U[4] * h_step[1];
+    L.n0 = (int32_t)h_count[0];
+    L.n1 = (int32_t)h_count[1];
+    L.strips_a = (L.n0 + R - 1) / R;
+    const int n_split = lattice_split(R, h_count, k->n);   // wavefronts per group of 64 strips = partial sums per point
+    const int64_t share = LAT_SHARE;
+    const int64_t n_shares = (k->n + share - 1) / share;
+    const int64_t n_strips = (int64_t)L.strips_a * L.n1;
+    const int64_t per = (int64_t)R * n_strips;
+    double *rec = ar.take<double>((size_t)k->n * LAT_REC);
+    double *part = ar.take<double>((size_t)n_split * per);
+    double *band = ar.take<double>((size_t)n_shares * 2);
+    if (!ar.ok) return PISA_HIP_ERR_NOMEM;
+    hipLaunchKernelGGL(kde_lattice_prep_kernel, dim3((unsigned)((k->n + 255) / 256)), dim3(256), 0, s, k->ys,
+                       k->coef, k->s2, k->n, L.da, rec);
+    hipLaunchKernelGGL(kde_lattice_band_kernel, dim3((unsigned)n_shares), dim3(64), 0, s, rec, k->n, share, g.rcut2, band);
+    const dim3 grid((unsigned)((n_strips + 63) / 64), (unsigned)n_split);
+#define KDE_LAT(RR) hipLaunchKernelGGL(kde_lattice_kernel<RR>, grid, dim3(64), 0, s, L, g.rcut2, rec, k->n, share, band, part, k->pair_count)
+    if (R == 32) KDE_LAT(32); else if (R == 16) KDE_LAT(16); else KDE_LAT(8);
+#undef KDE_LAT
+    hipLaunchKernelGGL(kde_lattice_combine_kernel, dim3((unsigned)((per + 15) / 16)), dim3(256), 0, s, part, n_split, R,
+                       L.strips_a, L.n0, L.n1, d_out);
+    PISA_CHECK_LAUNCH("kde lattice kernels");
+    PISA_TRY_HIP(hipMemcpyAsync(&k->pairs_eval, k->pair_count, sizeof(unsigned long long),
+                                hipMemcpyDeviceToHost, s));
+#ifdef KDE_LATTICE_DEBUG
+    unsigned long long dbg[3];
+    PISA_TRY_HIP(hipMemcpyAsync(dbg, k->pair_count, sizeof(dbg), hipMemcpyDeviceToHost, s));
+    PISA_TRY_HIP(hipStreamSynchronize(s));
+    fprintf(stderr, "lattice R=%d strips=%lld blocks=%u shares=%d: lane-iterations %llu, executing wave-iterations %llu (%.1f lanes), loop iterations %llu\n",
+            R, (long long)n_strips, grid.x, n_split, dbg[0] / R, dbg[1], (double)(dbg[0] / R) / (double)(dbg[1] ? dbg[1] : 1), dbg[2]);
+#endif
+    PISA_TRY_HIP(hipStreamSynchronize(s));
+    PISA_TRY_HIP(hipMemsetAsync(k->pair_count, 0, 64, s));
+    return PISA_HIP_OK;
+}
 
 PISA_API int pisa_hip_kde_info(const pisa_hip_kde *k, pisa_hip_kde_info_t *info) {
     if (!k || !info) return PISA_HIP_ERR_INVALID;

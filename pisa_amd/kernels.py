@@ -371,6 +371,31 @@ class KdeEstimator:
         self.pairs_eval = info.pairs_eval
         return out
 
+    def evaluate_lattice(self, origin, step, count):
+        """densities at the points origin[d] + i_d step[d], 0 <= i_d < count[d], as a flat device
+        tensor in numpy.meshgrid(indexing="ij") order (`pisa_hip_kde_evaluate_lattice`)"""
+        import ctypes as C
+
+        d = self.dim
+        assert len(origin) == len(step) == len(count) == d
+        o = (C.c_double * d)(*[float(v) for v in origin])
+        st = (C.c_double * d)(*[float(v) for v in step])
+        cnt = (C.c_int64 * d)(*[int(v) for v in count])
+        if min(int(v) for v in count) < 1:
+            raise ValueError("empty lattice %r" % (list(count),))
+        m = int(np.prod([int(v) for v in count]))
+        out = torch.empty(m, dtype=F8, device=self._work.device)
+        need = int(self._lib.pisa_hip_kde_lattice_workspace_bytes(self._h, st, cnt))
+        if need < 0:
+            raise ValueError("invalid lattice %r x %r" % (list(step), list(count)))
+        work = torch.empty(need, dtype=torch.uint8, device=out.device)
+        _lib.check(self._lib.pisa_hip_kde_evaluate_lattice(self._h, o, st, cnt, _ptr(work), need, _ptr(out),
+                                                           _stream()))
+        info = _lib.KdeInfo()
+        _lib.check(self._lib.pisa_hip_kde_info(self._h, C.byref(info)))
+        self.pairs_eval = info.pairs_eval
+        return out
+
     def arrays(self):
         """(ys [dim, n], coef [n], s2 [n]) in the estimator's cell-sorted source order (copies)"""
         import ctypes as C

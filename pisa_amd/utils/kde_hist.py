@@ -54,6 +54,19 @@ class gaussian_kde:  # pylint: disable=invalid-name
 
     evaluate = __call__
 
+    def evaluate_grid(self, axes):
+        """`self(points)` for points = meshgrid(*axes, indexing="ij") flattened: axes with uniform
+        steps go through the lattice entry point (the steps of a regular binning's oversampled
+        centres, the coszen reflection included, are uniform), anything else is written out"""
+        axes = [np.asarray(a, dtype=np.float64) for a in axes]
+        uniform = all(len(a) >= 2 and np.allclose(np.diff(a), (a[-1] - a[0]) / (len(a) - 1), rtol=1e-9, atol=0.0)
+                      and a[-1] > a[0] for a in axes)
+        if uniform:
+            return self._est.evaluate_lattice([a[0] for a in axes], [(a[-1] - a[0]) / (len(a) - 1) for a in axes],
+                                              [len(a) for a in axes])
+        grid = np.meshgrid(*axes, indexing="ij")
+        return self(np.array([g.ravel() for g in grid]))
+
     pairs = property(lambda self: (self._est.pairs_pilot, self._est.pairs_eval))
 
 
@@ -96,13 +109,12 @@ def get_hist(sample, binning, weights=None, bw_method="scott", adaptive=True, al
         bin_points.append(c)
     megashape = (binning.shape[0] + (int(reflect_upper) + int(reflect_lower)) * l, binning.shape[1])
     minishape = (binning.shape[0] - l, binning.shape[1])
-    grid = np.meshgrid(*bin_points, indexing="ij")
-    points = np.array([g.ravel() for g in grid])
-    hist = kernel(points).cpu().numpy().reshape(megashape)
+    n_points = int(np.prod([len(c) for c in bin_points]))
+    hist = kernel.evaluate_grid(bin_points).cpu().numpy().reshape(megashape)
     if stats is not None:
         stats["pairs_pilot"] = stats.get("pairs_pilot", 0) + kernel.pairs[0]
         stats["pairs_eval"] = stats.get("pairs_eval", 0) + kernel.pairs[1]
-        stats["all_pairs"] = stats.get("all_pairs", 0) + kernel.n * (kernel.n * bool(adaptive) + points.shape[1])
+        stats["all_pairs"] = stats.get("all_pairs", 0) + kernel.n * (kernel.n * bool(adaptive) + n_points)
     if reflect_lower:
         hist0 = np.flipud(np.concatenate([np.zeros(minishape), hist[0:l, :]]))
         hist = hist[l:, :]

@@ -115,6 +115,61 @@ def test_kde_hermite_expansion_matches_direct_sums():
         lib.pisa_hip_kde_configure(old)
 
 
+@pytest.mark.parametrize("alpha,counts,span", [
+    (0.1, (120, 80), 1.0),      # a map's shape: oversampled 8 x 8 bins with reflection; strips of 32
+    (0.3, (333, 47), 1.0),      # count not a multiple of the strip, strongly varying bandwidths
+    (0.3, (41, 300), 3.0),      # coarser lattice in dimension 0: shorter strips
+    (0.5, (7, 9), 6.0),         # lattice far coarser than the narrowest kernels: written-out points
+])
+def test_kde_lattice_evaluation_matches_point_evaluation(alpha, counts, span):
+    """`pisa_hip_kde_evaluate_lattice` (Gaussian recurrence along lattice lines) against
+    `pisa_hip_kde_evaluate` on the same points written out: far below the parity bar, and far fewer
+    instructions.  Also 1-D and 3-D lattices (always written out) and bit-reproducibility."""
+    from pisa_amd import kernels as K
+
+    rs = np.random.RandomState(11)
+    n = 120000
+    x = np.stack([np.clip(rs.rand(n) * 2 - 1 + rs.randn(n) * 0.1, -1, 1), rs.gamma(4.0, 0.5, n) + 0.6 * rs.rand(n)])
+    w = rs.rand(n) * 2 + 0.05
+    est = K.KdeEstimator(K.to_device(x), K.to_device(w), adaptive=True, alpha=alpha, tol=1e-14)
+    n0, n1 = counts
+    a0 = np.linspace(-1.45 * span, 1.45 * span, n0)
+    a1 = np.linspace(0.2, 6.5, n1)
+    origin, step = [a0[0], a1[0]], [(a0[-1] - a0[0]) / (n0 - 1), (a1[-1] - a1[0]) / (n1 - 1)]
+    lat = est.evaluate_lattice(origin, step, counts).cpu().numpy()
+    pairs_lat = est.pairs_eval
+    pts = np.array([g.ravel() for g in np.meshgrid(origin[0] + step[0] * np.arange(n0),
+                                                   origin[1] + step[1] * np.arange(n1), indexing="ij")])
+    direct = est(K.to_device(pts)).cpu().numpy()
+    assert direct.max() > 0
+    np.testing.assert_allclose(lat, direct, rtol=2e-12, atol=1e-13 * direct.max())
+    assert pairs_lat > 0
+    again = est.evaluate_lattice(origin, step, counts).cpu().numpy()
+    np.testing.assert_array_equal(lat, again)
+
+
+def test_kde_lattice_other_dimensions_and_no_cutoff():
+    from pisa_amd import kernels as K
+
+    rs = np.random.RandomState(12)
+    for dim, n, counts in ((1, 5000, (200,)), (3, 4000, (9, 8, 7))):
+        x = rs.randn(dim, n)
+        est = K.KdeEstimator(K.to_device(x), None, adaptive=True, alpha=0.3)
+        origin, step = [-2.0] * dim, [4.0 / (c - 1) for c in counts]
+        lat = est.evaluate_lattice(origin, step, counts).cpu().numpy()
+        axes = [origin[d] + step[d] * np.arange(counts[d]) for d in range(dim)]
+        pts = np.array([g.ravel() for g in np.meshgrid(*axes, indexing="ij")])
+        np.testing.assert_array_equal(lat, est(K.to_device(pts)).cpu().numpy())
+    # tol = 0 (every pair): the lattice form is not used, identical bits
+    x = rs.randn(2, 3000)
+    est = K.KdeEstimator(K.to_device(x), None, adaptive=True, alpha=0.3, tol=0.0)
+    lat = est.evaluate_lattice([-2.0, -2.0], [0.1, 0.1], (41, 41)).cpu().numpy()
+    pts = np.array([g.ravel() for g in np.meshgrid(-2.0 + 0.1 * np.arange(41), -2.0 + 0.1 * np.arange(41), indexing="ij")])
+    np.testing.assert_array_equal(lat, est(K.to_device(pts)).cpu().numpy())
+    with pytest.raises(ValueError):
+        est.evaluate_lattice([0.0, 0.0], [0.1, 0.1], (0, 5))
+
+
 def test_kde_estimator_properties():
     """bit-reproducible; unweighted == unit weights; scaling the weights changes nothing (the
     density is normalised); integral over a fine grid = 1"""
