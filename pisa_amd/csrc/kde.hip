@@ -103,10 +103,11 @@ kde_reduce_kernel(const double *__restrict__ partial, int n_split, int64_t n_qry
     out[j] = acc;
 }
 
-// scratch for the per-split partial sums (grown on demand; one per process, like the rest
-// of the library not meant for concurrent calls from several host threads)
-static double *g_kde_scratch = nullptr;
-static size_t g_kde_scratch_bytes = 0;
+// scratch for the per-split partial sums and the expansion coefficients (grown on demand).  One
+// per host thread: estimators may be built and evaluated from several host threads at once, each
+// on its own stream (the utils.kde stage does), and a thread's calls are ordered on its stream.
+static thread_local double *g_kde_scratch = nullptr;
+static thread_local size_t g_kde_scratch_bytes = 0;
 
 // =================================================================== estimator object
 constexpr int RED_BLOCKS = 256;   // fixed reduction geometry => fixed summation order
@@ -1147,6 +1148,7 @@ struct pisa_hip_kde {
     // device (inside the caller's workspace)
     double *ys, *wn, *coef, *s2, *cell_s2min, *scalars;   // scalars: [0] log-sum, [1] min s2, [2] max s2
     double s2_range[2];   // host copy of scalars[1..2]
+    int cell_s2min_valid;
     int32_t *cell_start;
     unsigned long long *pair_count;
     unsigned long long pairs_pilot, pairs_eval;
@@ -1561,9 +1563,7 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
         KDE_TRY_HIP(hipStreamSynchronize(s));
         KDE_TRY_HIP(hipMemsetAsync(k->pair_count, 0, 64, s));
     }
-    hipLaunchKernelGGL(kde_cell_s2min_kernel, dim3((unsigned)((k->n_cells + 255) / 256)), dim3(256), 0, s,
-                       k->s2, k->cell_start, k->n_cells, k->cell_s2min);
-    KDE_TRY(check_hip(hipGetLastError(), "kde_cell_s2min_kernel"));
+    k->cell_s2min_valid = 0;   // per-cell widest kernel: only the point evaluation needs it
     KDE_TRY_HIP(hipStreamSynchronize(s));
 #undef KDE_FAIL
 #undef KDE_TRY
@@ -1637,6 +1637,12 @@ PISA_API int pisa_hip_kde_evaluate(pisa_hip_kde *k, const double *d_qry, int64_t
     if (!ar.ok) return PISA_HIP_ERR_NOMEM;
     PISA_TRY_HIP(hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(KdeBlock),
                                 hipMemcpyHostToDevice, s));
+    if (!k->cell_s2min_valid) {
+        hipLaunchKernelGGL(kde_cell_s2min_kernel, dim3((unsigned)((k->n_cells + 255) / 256)), dim3(256), 0, s,
+                           k->s2, k->cell_start, k->n_cells, k->cell_s2min);
+        PISA_CHECK_LAUNCH("kde_cell_s2min_kernel");
+        k->cell_s2min_valid = 1;
+    }
     rc = launch_pairs<true, 1>(k, d_blocks, n_blocks, n_split, qys, m, part, s);
     if (rc != PISA_HIP_OK) return rc;
     hipLaunchKernelGGL(kde_combine_kernel, dim3(nb), dim3(256), 0, s, part, n_split, m, idx_b, d_out);

@@ -14,6 +14,8 @@ evaluation on; per evaluation only the weights move.  The estimator itself is
 native code (`csrc/kde.hip`: cell-list Gaussian cut-off at kernel value `tol`,
 extra kwarg of this build, default 1e-14, 0 = all pairs).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -105,8 +107,39 @@ class kde(Stage):  # pylint: disable=invalid-name
         draws = np.bincount(rng.integers(size, size=size), minlength=size)
         return torch.as_tensor(draws, dtype=torch.float64).to(st["sample"].device)
 
+    # -- the estimators of one evaluation are independent (one per container and pid channel) and
+    #    each is a chain of small launches with a few host round trips (moments, cell counts,
+    #    bandwidth range): `kde_workers` host threads, each with its own HIP stream, keep the GPU
+    #    busy during the round trips of the others.  Every estimator is deterministic by itself, so
+    #    the maps do not depend on the interleaving.
+    kde_workers = int(os.environ.get("PISA_KDE_WORKERS", "4"))
+
+    def _pool(self):
+        if getattr(self, "_executor", None) is None:
+            import threading
+            from concurrent.futures import ThreadPoolExecutor
+
+            self._executor = ThreadPoolExecutor(max_workers=self.kde_workers, thread_name_prefix="kde")
+            self._tls = threading.local()
+        return self._executor
+
+    def _kde_task(self, main_stream, weights, kw):
+        tls = self._tls
+        if getattr(tls, "stream", None) is None:
+            tls.stream = torch.cuda.Stream(device=weights.device)
+        stats = {}
+        with torch.cuda.stream(tls.stream):
+            tls.stream.wait_stream(main_stream)       # the weights were produced on the caller's stream
+            kde_map = kde_hist.kde_histogramdd(weights=weights, stats=stats, **kw)
+            tls.stream.synchronize()
+        return kde_map, stats
+
     def apply_function(self):
         self.stats = {}
+        if not (self.stash_valid or self.bootstrap) and self.kde_workers > 1 and len(self.data.containers) > 1:
+            self._apply_concurrent()
+            self.stash_valid = self.stash_hists
+            return
         for container in self.data:
             if self.stash_valid:
                 self.data.representation = self.apply_mode
@@ -154,3 +187,29 @@ class kde(Stage):  # pylint: disable=invalid-name
                 if self.bootstrap:
                     self.stashed_errors[container.name] = kde_errors.copy()
         self.stash_valid = self.stash_hists
+
+    def _apply_concurrent(self):
+        pool = self._pool()
+        main = torch.cuda.current_stream()
+        jobs = []
+        for container in self.data:
+            st = self._static_sample(container)
+            container.representation = "events"
+            weights = container.device("weights")   # materialises a deferred reweighting chain
+            kw = dict(sample=st["sample"], binning=self.regularized_apply_mode,
+                      bw_method=self.bw_method, coszen_name=self.coszen_name,
+                      coszen_reflection=self.coszen_reflection, adaptive=self.adaptive,
+                      alpha=self.alpha, oversample=self.oversample, stack_pid=self.stack_pid,
+                      tol=self.tol, channels=st["channels"])
+            jobs.append((container, weights, pool.submit(self._kde_task, main, weights, kw)))
+        for container, _weights, fut in jobs:
+            kde_map, stats = fut.result()
+            for key, val in stats.items():
+                self.stats[key] = self.stats.get(key, 0) + val
+            kde_map = np.ascontiguousarray(kde_map.ravel(), dtype=FTYPE)
+            self.data.representation = self.apply_mode
+            container["weights"] = kde_map
+            if self.stash_hists:
+                if self.stashed_hists is None:
+                    self.stashed_hists, self.stashed_errors = {}, {}
+                self.stashed_hists[container.name] = kde_map.copy()
