@@ -562,6 +562,7 @@ __device__ __forceinline__ void layer_amplitude(const Prob3Side &S, const double
 // the same operands as layer_amplitude() except that the quotients are formed with
 // one reciprocal per eigenvalue: equal to rounding (~1e-16), not bit for bit.
 constexpr int PROB3_NF = 60;  // fields per record, decay form: M[3] (re,im) + Q[3][3][3] (re,im)
+constexpr int PROB3_NF_REDUCED = 18;  // without decay (see eigen_terms)
 
 // field(f) = value callback; f in [0, PROB3_NF)
 template <bool DECAY, class StoreFn>
@@ -621,7 +622,11 @@ __device__ __forceinline__ void eigen_terms(const Prob3Side &S, const double (&d
     // is in SU(3): its third row is the conjugate cross product of the first two and is neither
     // computed nor stored.  With the projectors summing to the identity (sum_k Q_k = 1),
     //     A' = e_0 + (e_1 - e_0) Q_1 + (e_2 - e_0) Q_2,  e_k = exp(-i G_k t),  e_0 = conj(e_1 e_2),
-    // G_k = M_k - Mbar: fields G_1, G_2, then rows 0 and 1 of Q_1, Q_2 ([i][j] (re, im)): 26 fields.
+    // G_k = M_k - Mbar.  Without decay X is Hermitian (the eigenvalue formulas above already rely
+    // on it) and so are the projectors Q_k = (X - M_a)(X - M_b) / den_k: their rows 0 and 1 are
+    // the two real diagonal entries Q00, Q11 and the three complex entries Q01, Q02, Q12
+    // (Q10 = conj Q01).  Fields: G_1, G_2, then for Q_1 and Q_2
+    // (Q00, Q11, Re Q01, Im Q01, Re Q02, Im Q02, Re Q12, Im Q12): PROB3_NF_REDUCED = 18.
     if (DECAY) {
 #pragma unroll
         for (int k = 0; k < 3; k++) {
@@ -632,49 +637,60 @@ __device__ __forceinline__ void eigen_terms(const Prob3Side &S, const double (&d
         const double d1 = M[1].re - M[0].re, d2 = M[2].re - M[0].re;
         store(0, (2.0 * d1 - d2) * (1.0 / 3.0));
         store(1, (2.0 * d2 - d1) * (1.0 / 3.0));
-    }
-    double inv_den[3] = {1.0, 1.0, 1.0};
-    if (!DECAY) {
+        // X = [[x0, u, v], [conj u, x1, w], [conj v, conj w, x2]]
+        const double x0 = X.m[0][0].re, x1 = X.m[1][1].re, x2 = X.m[2][2].re;
+        const cplx u = X.m[0][1], v = X.m[0][2], w = X.m[1][2];
+        // parts of (X - a)(X - b) that do not depend on the shifts a, b
+        const double uu = u.re * u.re + u.im * u.im, vv = v.re * v.re + v.im * v.im,
+                     ww = w.re * w.re + w.im * w.im;
+        const cplx vw = cmake(v.re * w.re + v.im * w.im, v.im * w.re - v.re * w.im);   // v conj(w)
+        const cplx uw = cmul(u, w);
+        const cplx uv = cmake(u.re * v.re + u.im * v.im, u.re * v.im - u.im * v.re);   // conj(u) v
 #pragma unroll
-        for (int k = 1; k < 3; k++) inv_den[k] = 1.0 / den[k].re;
+        for (int k = 1; k < 3; k++) {
+            // Q_1 = (X - M_2)(X - M_0) / den_1,  Q_2 = (X - M_0)(X - M_1) / den_2
+            const double a = k == 1 ? M[2].re : M[0].re, b = k == 1 ? M[0].re : M[1].re;
+            const double inv = 1.0 / den[k].re;   // one reciprocal per eigenvalue
+            const double a0 = x0 - a, a1 = x1 - a, b0 = x0 - b, b1 = x1 - b, b2 = x2 - b;
+            const int base = 2 + 8 * (k - 1);
+            store(base + 0, (a0 * b0 + uu + vv) * inv);
+            store(base + 1, (uu + a1 * b1 + ww) * inv);
+            const double s01 = a0 + b1, s02 = a0 + b2, s12 = a1 + b2;
+            store(base + 2, (u.re * s01 + vw.re) * inv);
+            store(base + 3, (u.im * s01 + vw.im) * inv);
+            store(base + 4, (v.re * s02 + uw.re) * inv);
+            store(base + 5, (v.im * s02 + uw.im) * inv);
+            store(base + 6, (w.re * s12 + uv.re) * inv);
+            store(base + 7, (w.im * s12 + uv.im) * inv);
+        }
+        return;
     }
     cplx Xd[3][3];
 #pragma unroll
     for (int k = 0; k < 3; k++)
 #pragma unroll
-        for (int i = 0; i < 3; i++)
-            Xd[k][i] = DECAY ? csub(X.m[i][i], M[k]) : cmake(X.m[i][i].re - M[k].re, X.m[i][i].im);
+        for (int i = 0; i < 3; i++) Xd[k][i] = csub(X.m[i][i], M[k]);
 #define HMM(i_, j_, k_) (((i_) == (j_)) ? Xd[k_][i_] : X.m[i_][j_])
 #pragma unroll
-    for (int i = 0; i < (DECAY ? 3 : 2); i++)
+    for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int j = 0; j < 3; j++) {
+            cplx p0 = cmul(HMM(i, 0, 1), HMM(0, j, 2));
+            p0 = cadd(p0, cmul(HMM(i, 1, 1), HMM(1, j, 2)));
+            p0 = cadd(p0, cmul(HMM(i, 2, 1), HMM(2, j, 2)));
             cplx p1 = cmul(HMM(i, 0, 2), HMM(0, j, 0));
             p1 = cadd(p1, cmul(HMM(i, 1, 2), HMM(1, j, 0)));
             p1 = cadd(p1, cmul(HMM(i, 2, 2), HMM(2, j, 0)));
             cplx p2 = cmul(HMM(i, 0, 0), HMM(0, j, 1));
             p2 = cadd(p2, cmul(HMM(i, 1, 0), HMM(1, j, 1)));
             p2 = cadd(p2, cmul(HMM(i, 2, 0), HMM(2, j, 1)));
-            if (!DECAY) {
-                // one reciprocal per eigenvalue instead of 36 fp64 divisions; differs from
-                // p/den by <= 1 ulp
-                p1 = cmake(p1.re * inv_den[1], p1.im * inv_den[1]);
-                p2 = cmake(p2.re * inv_den[2], p2.im * inv_den[2]);
-                const int base = 2 + 4 * (3 * i + j);
-                store(base + 0, p1.re); store(base + 1, p1.im);
-                store(base + 2, p2.re); store(base + 3, p2.im);
-            } else {
-                cplx p0 = cmul(HMM(i, 0, 1), HMM(0, j, 2));
-                p0 = cadd(p0, cmul(HMM(i, 1, 1), HMM(1, j, 2)));
-                p0 = cadd(p0, cmul(HMM(i, 2, 1), HMM(2, j, 2)));
-                p0 = cdiv(p0, den[0]);
-                p1 = cdiv(p1, den[1]);
-                p2 = cdiv(p2, den[2]);
-                const int base = 6 + 6 * (3 * i + j);
-                store(base + 0, p0.re); store(base + 1, p0.im);
-                store(base + 2, p1.re); store(base + 3, p1.im);
-                store(base + 4, p2.re); store(base + 5, p2.im);
-            }
+            p0 = cdiv(p0, den[0]);
+            p1 = cdiv(p1, den[1]);
+            p2 = cdiv(p2, den[2]);
+            const int base = 6 + 6 * (3 * i + j);
+            store(base + 0, p0.re); store(base + 1, p0.im);
+            store(base + 2, p1.re); store(base + 3, p1.im);
+            store(base + 4, p2.re); store(base + 5, p2.im);
         }
 #undef HMM
 }
@@ -697,16 +713,27 @@ __device__ __forceinline__ void amplitude_from_terms(const LoadFn &load, double 
         e[0] = cmul(e[1], e[2]);
         e[0].im = -e[0].im;
         const cplx f1 = csub(e[1], e[0]), f2 = csub(e[2], e[0]);
+        // diagonal entries: real projector entries
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < 2; i++) {
+            const double q1 = load(2 + i), q2 = load(10 + i);
+            A.m[i][i] = cmake(e[0].re + f1.re * q1 + f2.re * q2, e[0].im + f1.im * q1 + f2.im * q2);
+        }
+        // off-diagonal entries (0,1), (0,2), (1,2); (1,0) from the conjugate of Q01
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
-                const int base = 2 + 4 * (3 * i + j);
-                cplx acc = cmul(f1, cmake(load(base + 0), load(base + 1)));
-                acc = cadd(acc, cmul(f2, cmake(load(base + 2), load(base + 3))));
-                if (i == j) acc = cadd(acc, e[0]);
-                A.m[i][j] = acc;
+        for (int t = 0; t < 3; t++) {
+            const cplx q1 = cmake(load(4 + 2 * t), load(5 + 2 * t));
+            const cplx q2 = cmake(load(12 + 2 * t), load(13 + 2 * t));
+            const cplx acc = cadd(cmul(f1, q1), cmul(f2, q2));
+            if (t == 0) {
+                A.m[0][1] = acc;
+                A.m[1][0] = cadd(cmul(f1, cmake(q1.re, -q1.im)), cmul(f2, cmake(q2.re, -q2.im)));
+            } else if (t == 1) {
+                A.m[0][2] = acc;
+            } else {
+                A.m[1][2] = acc;
             }
+        }
         return;
     }
     cplx ph[3];
@@ -862,7 +889,7 @@ __device__ __forceinline__ void propagate_path_nested(const Prob3Side &S, const 
         if (DECAY) {
             layer_amplitude<DECAY, true>(S, dm, energy, rho, dist, A, mv);
         } else {
-            double rec[26];
+            double rec[PROB3_NF_REDUCED];
             auto store = [&](int f, double v) { rec[f] = v; };
             eigen_terms<false>(S, dm, vac_order, energy, rho, store);
             auto load = [&](int f) { return rec[f]; };

@@ -304,7 +304,8 @@ class HotPathEngine:
                     if sort_events == "bin":
                         perm = bin_window_order(obin, self.n_bins)
                     elif sort_events == "part":
-                        perm = bin_partition_order(obin, node, self.n_bins)
+                        perm = bin_partition_order(obin, node, self.n_bins,
+                                                   width=int(os.environ.get("PISA_BIN_PARTITION", 672)))
                     else:
                         perm = torch.argsort(node, stable=True)
                 if lds_order and perm is not None and (sort_events == "part" or (
