@@ -572,86 +572,74 @@ __device__ __forceinline__ void eigen_terms(const Prob3Side &S, const double (&d
     const double tworttwoGf = 1.52588e-4;
     double a = 0.5 * rho * tworttwoGf;
     double sa = S.a_sign * a;
-    double one_over_two_e = 0.5 / energy;
-    mat3 Hf;
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            cplx hm = cscale(sa, S.V.m[i][j]);
-            hm.re = hm.re + S.lri[i][j];
-            Hf.m[i][j] = cadd(cscale(one_over_two_e, S.Hvd.m[i][j]), hm);
-        }
-    // 2E.U^dagger.Hf.U is linear in the layer's potential a: it is assembled from three
-    // matrices prepared once on the host instead of two 3x3 complex products per (E, rho)
-    // (planned form only; same matrix to rounding)
-    mat3 X;
     double two_e = 2.0 * energy;
     const double ka = two_e * sa;
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++)
-            X.m[i][j] = cadd(S.X0.m[i][j], cadd(cscale(ka, S.XV.m[i][j]), cscale(two_e, S.XL.m[i][j])));
-
-    cplx M[3], den[3];
     if (!DECAY) {
-        double mu[3], Mr[3];
-        get_dms_matter_roots<true>(energy, Hf, dm, mu);
-#pragma unroll
-        for (int k = 0; k < 3; k++)  // vacuum ordering, resolved on the host (Prob3Consts::vac_order)
-            Mr[k] = vac_order[k] == 0 ? mu[0] : (vac_order[k] == 1 ? mu[1] : mu[2]);
-#pragma unroll
-        for (int k = 0; k < 3; k++) M[k] = cmake(Mr[k], 0.0);
-        den[0] = cmake((Mr[0] - Mr[1]) * (Mr[0] - Mr[2]), 0.0);
-        den[1] = cmake((Mr[1] - Mr[2]) * (Mr[1] - Mr[0]), 0.0);
-        den[2] = cmake((Mr[2] - Mr[0]) * (Mr[2] - Mr[1]), 0.0);
-    } else {
-        cplx lam[3];
-        eigvals3_general(Hf, lam);
-#pragma unroll
-        for (int k = 0; k < 3; k++) M[k] = cscale(two_e, lam[k]);
-        den[0] = cmul(csub(M[0], M[1]), csub(M[0], M[2]));
-        den[1] = cmul(csub(M[1], M[2]), csub(M[1], M[0]));
-        den[2] = cmul(csub(M[2], M[0]), csub(M[2], M[1]));
-    }
-    // Record layout.  DECAY: M[3] (re, im) then Q_k[i][j] (re, im), k fastest: 60 fields.
-    // Otherwise the REDUCED form.  A unit phase common to a layer's amplitude drops out of every
-    // probability (the chain product only collects a global phase), so the layer matrix may be
-    // taken as  A' = exp(+i Mbar t) A = exp(-i (H - tr H / 3) t),  Mbar = (M_0+M_1+M_2)/3, which
-    // is in SU(3): its third row is the conjugate cross product of the first two and is neither
-    // computed nor stored.  With the projectors summing to the identity (sum_k Q_k = 1),
-    //     A' = e_0 + (e_1 - e_0) Q_1 + (e_2 - e_0) Q_2,  e_k = exp(-i G_k t),  e_0 = conj(e_1 e_2),
-    // G_k = M_k - Mbar.  Without decay X is Hermitian (the eigenvalue formulas above already rely
-    // on it) and so are the projectors Q_k = (X - M_a)(X - M_b) / den_k: their rows 0 and 1 are
-    // the two real diagonal entries Q00, Q11 and the three complex entries Q01, Q02, Q12
-    // (Q10 = conj Q01).  Fields: G_1, G_2, then for Q_1 and Q_2
-    // (Q00, Q11, Re Q01, Im Q01, Re Q02, Im Q02, Re Q12, Im Q12): PROB3_NF_REDUCED = 18.
-    if (DECAY) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            store(2 * k, M[k].re);
-            store(2 * k + 1, M[k].im);
-        }
-    } else {
-        const double d1 = M[1].re - M[0].re, d2 = M[2].re - M[0].re;
-        store(0, (2.0 * d1 - d2) * (1.0 / 3.0));
-        store(1, (2.0 * d2 - d1) * (1.0 / 3.0));
-        // X = [[x0, u, v], [conj u, x1, w], [conj v, conj w, x2]]
-        const double x0 = X.m[0][0].re, x1 = X.m[1][1].re, x2 = X.m[2][2].re;
-        const cplx u = X.m[0][1], v = X.m[0][2], w = X.m[1][2];
-        // parts of (X - a)(X - b) that do not depend on the shifts a, b
+        // ---- REDUCED form.  X = 2E.U^dagger.H.U is linear in the layer's potential a and is assembled
+        // from three matrices prepared once on the host (X0 + (2E a) XV + 2E XL) instead of two 3x3
+        // complex products per (E, rho).  Without decay X is Hermitian:
+        //     X = [[x0, u, v], [conj u, x1, w], [conj v, conj w, x2]],
+        // nine real numbers, and everything below works on them.
+        const double x0 = S.X0.m[0][0].re + (ka * S.XV.m[0][0].re + two_e * S.XL.m[0][0].re);
+        const double x1 = S.X0.m[1][1].re + (ka * S.XV.m[1][1].re + two_e * S.XL.m[1][1].re);
+        const double x2 = S.X0.m[2][2].re + (ka * S.XV.m[2][2].re + two_e * S.XL.m[2][2].re);
+        const cplx u = cadd(S.X0.m[0][1], cadd(cscale(ka, S.XV.m[0][1]), cscale(two_e, S.XL.m[0][1])));
+        const cplx v = cadd(S.X0.m[0][2], cadd(cscale(ka, S.XV.m[0][2]), cscale(two_e, S.XL.m[0][2])));
+        const cplx w = cadd(S.X0.m[1][2], cadd(cscale(ka, S.XV.m[1][2]), cscale(two_e, S.XL.m[1][2])));
         const double uu = u.re * u.re + u.im * u.im, vv = v.re * v.re + v.im * v.im,
                      ww = w.re * w.re + w.im * w.im;
         const cplx vw = cmake(v.re * w.re + v.im * w.im, v.im * w.re - v.re * w.im);   // v conj(w)
         const cplx uw = cmul(u, w);
         const cplx uv = cmake(u.re * v.re + u.im * v.im, u.re * v.im - u.im * v.re);   // conj(u) v
+        // Eigenvalues of X = 2E x those of the flavour-basis Hamiltonian: get_dms' trigonometric
+        // solution (numba_osc_kernels.py:776-815) on the characteristic polynomial of X itself --
+        // the same invariants (trace, second invariant, determinant) from the mass-basis entries,
+        // which are already at hand for the projectors.  Root order as in the reference (the
+        // coefficients scale by powers of 2E > 0, the angle is unchanged).
+        double mu[3];
+        {
+            const double c2 = -(x0 + x1 + x2);
+            const double c1 = x0 * (x1 + x2) + x1 * x2 - uu - ww - vv;
+            const double c0 = x0 * ww + x1 * vv + x2 * uu - 2.0 * (uw.re * v.re + uw.im * v.im) - x0 * x1 * x2;
+            double p = c2 * c2 - 3.0 * c1;
+            p = fmax(0.0, p);
+            const double q = -13.5 * c0 - c2 * (c2 * c2) + 4.5 * c1 * c2;
+            double tmp = 27 * (0.25 * (c1 * c1) * (p - c1) + c0 * (q + 6.75 * c0));
+            tmp = fmax(0.0, tmp);
+            const double res = atan2(sqrt(tmp), q) * (1.0 / 3.0);
+            const double b = (2.0 / 3.0) * sqrt(p);
+            double sn, cs;
+            sincos_phase(res, &sn, &cs);
+            const double ca = -0.5, sb = 0.86602540378443864676;  // cos, sin of 2pi/3
+            const double shift = two_e * dm[0][0] - c2 * (1.0 / 3.0);
+            mu[0] = b * (cs * ca - sn * sb) + shift;
+            mu[1] = b * (cs * ca + sn * sb) + shift;
+            mu[2] = b * cs + shift;
+        }
+        double Mr[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++)  // vacuum ordering, resolved on the host (Prob3Consts::vac_order)
+            Mr[k] = vac_order[k] == 0 ? mu[0] : (vac_order[k] == 1 ? mu[1] : mu[2]);
+        // A unit phase common to a layer's amplitude drops out of every probability (the chain
+        // product only collects a global phase), so the layer matrix may be taken as
+        //     A' = exp(+i Mbar t) A = exp(-i (H - tr H / 3) t),  Mbar = (M_0+M_1+M_2)/3,
+        // which is in SU(3): its third row is the conjugate cross product of the first two and is
+        // neither computed nor stored.  With the projectors summing to the identity,
+        //     A' = e_0 + (e_1 - e_0) Q_1 + (e_2 - e_0) Q_2,  e_k = exp(-i G_k t),  e_0 = conj(e_1 e_2),
+        // G_k = M_k - Mbar.  The projectors Q_k = (X - M_a)(X - M_b) / den_k are Hermitian like X:
+        // their rows 0 and 1 are the real entries Q00, Q11 and the complex entries Q01, Q02, Q12
+        // (Q10 = conj Q01).  Fields: G_1, G_2, then for Q_1 and Q_2
+        // (Q00, Q11, Re Q01, Im Q01, Re Q02, Im Q02, Re Q12, Im Q12): PROB3_NF_REDUCED = 18.
+        const double d1 = Mr[1] - Mr[0], d2 = Mr[2] - Mr[0];
+        store(0, (2.0 * d1 - d2) * (1.0 / 3.0));
+        store(1, (2.0 * d2 - d1) * (1.0 / 3.0));
 #pragma unroll
         for (int k = 1; k < 3; k++) {
             // Q_1 = (X - M_2)(X - M_0) / den_1,  Q_2 = (X - M_0)(X - M_1) / den_2
-            const double a = k == 1 ? M[2].re : M[0].re, b = k == 1 ? M[0].re : M[1].re;
-            const double inv = 1.0 / den[k].re;   // one reciprocal per eigenvalue
-            const double a0 = x0 - a, a1 = x1 - a, b0 = x0 - b, b1 = x1 - b, b2 = x2 - b;
+            const double sa_ = k == 1 ? Mr[2] : Mr[0], sb_ = k == 1 ? Mr[0] : Mr[1];
+            const double den = k == 1 ? (Mr[1] - Mr[2]) * (Mr[1] - Mr[0]) : (Mr[2] - Mr[0]) * (Mr[2] - Mr[1]);
+            const double inv = 1.0 / den;   // one reciprocal per eigenvalue
+            const double a0 = x0 - sa_, a1 = x1 - sa_, b0 = x0 - sb_, b1 = x1 - sb_, b2 = x2 - sb_;
             const int base = 2 + 8 * (k - 1);
             store(base + 0, (a0 * b0 + uu + vv) * inv);
             store(base + 1, (uu + a1 * b1 + ww) * inv);
@@ -664,6 +652,40 @@ __device__ __forceinline__ void eigen_terms(const Prob3Side &S, const double (&d
             store(base + 7, (w.im * s12 + uv.im) * inv);
         }
         return;
+    }
+    // ---- general (decay) form
+    double one_over_two_e = 0.5 / energy;
+    mat3 Hf;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            cplx hm = cscale(sa, S.V.m[i][j]);
+            hm.re = hm.re + S.lri[i][j];
+            Hf.m[i][j] = cadd(cscale(one_over_two_e, S.Hvd.m[i][j]), hm);
+        }
+    mat3 X;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            X.m[i][j] = cadd(S.X0.m[i][j], cadd(cscale(ka, S.XV.m[i][j]), cscale(two_e, S.XL.m[i][j])));
+
+    cplx M[3], den[3];
+    {
+        cplx lam[3];
+        eigvals3_general(Hf, lam);
+#pragma unroll
+        for (int k = 0; k < 3; k++) M[k] = cscale(two_e, lam[k]);
+        den[0] = cmul(csub(M[0], M[1]), csub(M[0], M[2]));
+        den[1] = cmul(csub(M[1], M[2]), csub(M[1], M[0]));
+        den[2] = cmul(csub(M[2], M[0]), csub(M[2], M[1]));
+    }
+    // Record layout: M[3] (re, im) then Q_k[i][j] (re, im), k fastest: 60 fields.
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        store(2 * k, M[k].re);
+        store(2 * k + 1, M[k].im);
     }
     cplx Xd[3][3];
 #pragma unroll
