@@ -37,8 +37,18 @@ struct EvArgs {
 
 // SIDE (0 nu / 1 nubar) is a template parameter: indexing the by-value constants with a run-time
 // side made the compiler copy them to scratch (2.3 KB per lane) and read them back into VGPRs
-template <bool DECAY, int SIDE>
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
+//
+// STAGED = false (every pair of crossable shell densities differs by >= 1e-5, checked on the host):
+// the reference's cache can then only ever hand an out-going layer the matrix of its own mirror
+// image, so nothing is tabulated -- a segment's length is recomputed from the shell radii where it
+// is needed (two square roots) and the per-lane path tables (10 bytes per segment and lane of LDS)
+// disappear: 0.220 -> 0.209 ms per 1e6 events.  STAGED = true is the general form (path, shell and
+// cache source of every segment staged in LDS).
+// Two wavefronts per SIMD is where the register allocation has no spills (201-221 VGPRs); builds for
+// three and four (168 / 128 VGPRs: 52-61 / 141-158 spilled registers, with or without the running
+// product parked in LDS) ran at 0.236 and 0.430 ms.
+template <bool DECAY, int SIDE, bool STAGED>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 prob3_events_kernel(const Prob3Consts c, const EarthDev earth, const EvArgs ev, int max_seg,
                     int32_t *__restrict__ status) {
     // Workgroups are dealt to the containers round-robin (workgroup b = chunk b / n_cont of
@@ -58,9 +68,9 @@ prob3_events_kernel(const Prob3Consts c, const EarthDev earth, const EvArgs ev, 
     double *s_radii = reinterpret_cast<double *>(smem);
     double *s_rhos = s_radii + PISA_HIP_MAX_SHELLS;
     double *s_lim = s_rhos + PISA_HIP_MAX_SHELLS;
-    double *s_len = s_lim + PISA_HIP_MAX_SHELLS;                       // [max_seg][blockDim]
-    unsigned char *s_shell = reinterpret_cast<unsigned char *>(s_len + (size_t)max_seg * blockDim.x);
-    unsigned char *s_src = s_shell + (size_t)max_seg * blockDim.x;
+    double *s_len = s_lim + PISA_HIP_MAX_SHELLS;                       // [max_seg][blockDim] (STAGED)
+    unsigned char *s_shell = reinterpret_cast<unsigned char *>(s_len + (size_t)(STAGED ? max_seg : 0) * blockDim.x);
+    unsigned char *s_src = s_shell + (size_t)(STAGED ? max_seg : 0) * blockDim.x;
     for (int k = threadIdx.x; k < earth.n_shell; k += blockDim.x) {
         s_radii[k] = earth.radii[k];
         s_rhos[k] = earth.rhos[k];
@@ -81,42 +91,58 @@ prob3_events_kernel(const Prob3Consts c, const EarthDev earth, const EvArgs ev, 
     bool ok = path_valid(e, g);
     int nseg = ok ? g.nseg : 0;
     if (!ok && status) atomicOr(status, 1);
-    for (int l = 0; l < nseg; l++) {
-        double rho, len;
-        path_segment(e, g, l, rho, len);
-        int shell = g.tangent_free ? l : (l < g.m ? l : 2 * g.m - 2 - l);
-        if (!(len == len)) { len = 0.0; if (status) atomicOr(status, 1); }
-        s_len[(size_t)l * bd + lane] = len;
-        s_shell[(size_t)l * bd + lane] = (unsigned char)shell;
-    }
-    auto layer = [&](int l, double &rho, double &dist) {
-        dist = s_len[(size_t)l * bd + lane];
-        rho = s_rhos[s_shell[(size_t)l * bd + lane]] * (dist > 0. ? 1.0 : 0.0);
-    };
-    // the reference's layer-matrix cache, resolved once per path: src[l] = the layer whose
-    // matrix layer l uses (numba_osc_kernels.py:236-249: the LAST earlier layer within 1e-5 in
-    // density and length, followed through its own matches)
-    for (int l = 0; l < nseg; l++) {
-        double rho_l, d_l;
-        layer(l, rho_l, d_l);
-        int sl = l;
-        if (d_l > 0.0) {
-            int found = -1;
-            for (int j = 0; j < l; j++) {
-                double rj, dj;
-                layer(j, rj, dj);
-                if (dj > 0.0 && fabs(rj - rho_l) < 1e-5 && fabs(dj - d_l) < 1e-5) found = j;
-            }
-            if (found >= 0) sl = s_src[(size_t)found * bd + lane];
-        }
-        s_src[(size_t)l * bd + lane] = (unsigned char)sl;
-    }
-    auto src = [&](int l) { return (int)s_src[(size_t)l * bd + lane]; };
+    const int mid = (ok && !g.tangent_free) ? g.m - 1 : -1;
     double P[9];
-    // through-going paths: in 0..m-2, innermost m-1, out m..2m-3 (path_segment)
     const int32_t vac_order[3] = {c.vac_order[0], c.vac_order[1], c.vac_order[2]};
-    propagate_path_nested<DECAY>(c.side[side], c.dm, vac_order, energy[i], nseg,
-                                 (ok && !g.tangent_free) ? g.m - 1 : -1, layer, src, P);
+    if (STAGED) {
+        for (int l = 0; l < nseg; l++) {
+            double rho, len;
+            path_segment(e, g, l, rho, len);
+            int shell = g.tangent_free ? l : (l < g.m ? l : 2 * g.m - 2 - l);
+            if (!(len == len)) { len = 0.0; if (status) atomicOr(status, 1); }
+            s_len[(size_t)l * bd + lane] = len;
+            s_shell[(size_t)l * bd + lane] = (unsigned char)shell;
+        }
+        auto layer = [&](int l, double &rho, double &dist) {
+            dist = s_len[(size_t)l * bd + lane];
+            rho = s_rhos[s_shell[(size_t)l * bd + lane]] * (dist > 0. ? 1.0 : 0.0);
+        };
+        // the reference's layer-matrix cache, resolved once per path: src[l] = the layer whose
+        // matrix layer l uses (numba_osc_kernels.py:236-249: the LAST earlier layer within 1e-5 in
+        // density and length, followed through its own matches)
+        for (int l = 0; l < nseg; l++) {
+            double rho_l, d_l;
+            layer(l, rho_l, d_l);
+            int sl = l;
+            if (d_l > 0.0) {
+                int found = -1;
+                for (int j = 0; j < l; j++) {
+                    double rj, dj;
+                    layer(j, rj, dj);
+                    if (dj > 0.0 && fabs(rj - rho_l) < 1e-5 && fabs(dj - d_l) < 1e-5) found = j;
+                }
+                if (found >= 0) sl = s_src[(size_t)found * bd + lane];
+            }
+            s_src[(size_t)l * bd + lane] = (unsigned char)sl;
+        }
+        auto src = [&](int l) { return (int)s_src[(size_t)l * bd + lane]; };
+        propagate_path_nested<DECAY>(c.side[side], c.dm, vac_order, energy[i], nseg, mid, layer, src, P);
+    } else {
+        auto layer = [&](int l, double &rho, double &dist) {
+            path_segment(e, g, l, rho, dist);
+            if (!(dist == dist)) { dist = 0.0; rho = 0.0; if (status) atomicOr(status, 1); }
+        };
+        // distinct shell densities: only the mirror image (same shell) can match
+        auto src = [&](int l) {
+            const int mir = 2 * mid - l;
+            if (mid < 0 || l <= mid || mir < 0) return l;
+            double r1, d1, r2, d2;
+            layer(l, r1, d1);
+            layer(mir, r2, d2);
+            return (d2 > 0.0 && fabs(r2 - r1) < 1e-5 && fabs(d2 - d1) < 1e-5) ? mir : l;
+        };
+        propagate_path_nested<DECAY>(c.side[side], c.dm, vac_order, energy[i], nseg, mid, layer, src, P);
+    }
     if (prob) {
 #pragma unroll
         for (int k = 0; k < 9; k++) prob[9 * i + k] = P[k];
@@ -133,7 +159,17 @@ static int launch_events(const Prob3Consts &c, const EarthDev &e, const EvCont *
     int max_seg = 2 * e.n_shell;
     if (max_seg > PISA_HIP_MAX_LAYERS + 8) return PISA_HIP_ERR_LAYERS;
     const int threads = 64;
-    size_t lds = 3 * PISA_HIP_MAX_SHELLS * sizeof(double) + (size_t)max_seg * threads * 10 + 16;
+    // The direct form needs pairwise distinct densities among the shells a path can cross at all
+    // (coszen_limit > -1: make_path counts the shells with coszen_limit > coszen; the r = 0 entry of
+    // the PREM tables repeats the inner core's density)
+    bool staged = false;
+    for (int a = 0; a < e.n_shell; a++)
+        for (int b = a + 1; b < e.n_shell; b++)
+            if (e.coszen_limit[a] > -1.0 && e.coszen_limit[b] > -1.0 && fabs(e.rhos[a] - e.rhos[b]) < 1e-5)
+                staged = true;
+    static const int force_staged = [] { const char *v = getenv("PISA_HIP_EVENTS_STAGED"); return v ? atoi(v) : 0; }();
+    if (force_staged) staged = true;   // development / test switch: the general form
+    size_t lds = 3 * PISA_HIP_MAX_SHELLS * sizeof(double) + (staged ? (size_t)max_seg * threads * 10 : 0) + 16;
     // one launch per sign (see the kernel) and per EV_MAX_CONT containers
     for (int side = 0; side < 2; side++) {
         EvArgs a;
@@ -147,9 +183,12 @@ static int launch_events(const Prob3Consts &c, const EarthDev &e, const EvCont *
                 max_blocks = nb > max_blocks ? nb : max_blocks;
             }
             dim3 block(threads), grid((unsigned)max_blocks * (unsigned)a.n_cont);
-#define LAUNCH_EV(D, S_) hipLaunchKernelGGL((prob3_events_kernel<D, S_>), grid, block, lds, s, c, e, a, max_seg, d_status)
-            if (c.decay) { if (side == 0) LAUNCH_EV(true, 0); else LAUNCH_EV(true, 1); }
-            else { if (side == 0) LAUNCH_EV(false, 0); else LAUNCH_EV(false, 1); }
+#define LAUNCH_EV(D, S_, ST) hipLaunchKernelGGL((prob3_events_kernel<D, S_, ST>), grid, block, lds, s, c, e, a, max_seg, d_status)
+#define LAUNCH_SIDE(D, ST) do { if (side == 0) LAUNCH_EV(D, 0, ST); else LAUNCH_EV(D, 1, ST); } while (0)
+            if (c.decay) { if (staged) LAUNCH_SIDE(true, true); else LAUNCH_SIDE(true, false); }
+            else if (staged) LAUNCH_SIDE(false, true);
+            else LAUNCH_SIDE(false, false);
+#undef LAUNCH_SIDE
 #undef LAUNCH_EV
             PISA_CHECK_LAUNCH("prob3_events_kernel");
             a.n_cont = 0;

@@ -206,9 +206,16 @@ def test_prob3_events_vs_oracle(K, L, oracle):
     n = 3000
     e = 10 ** (rs.rand(n) * 3)
     cz = rs.rand(n) * 2 - 1
-    for tag in ("prem12", "prem4"):
-        depth, height, yi, yo, ym = gl[tag + "::args"]
-        lay = oracle.Layers(gl[tag + "::prem"], depth, height)
+    # "prem12_equal": two mantle shells given the same density -- the reference's layer cache may then
+    # hand a layer the matrix of a DIFFERENT shell, which the kernel's general (staged) form resolves;
+    # the other two models have pairwise distinct densities and take the direct form
+    for tag in ("prem12", "prem4", "prem12_equal"):
+        base = "prem12" if tag == "prem12_equal" else tag
+        depth, height, yi, yo, ym = gl[base + "::args"]
+        prem = np.array(gl[base + "::prem"], dtype=np.float64, copy=True)
+        if tag == "prem12_equal":
+            prem[6, 1] = prem[7, 1]
+        lay = oracle.Layers(prem, depth, height)
         lay.setElecFrac(yi, yo, ym)
         lay.calcLayers(cz)
         earth = L.make_earth(lay.radii, lay.rhos, lay.coszen_limit, lay.r_detector)
