@@ -134,82 +134,110 @@ class kde(Stage):  # pylint: disable=invalid-name
             tls.stream.synchronize()
         return kde_map, stats
 
+    def _job_kwargs(self, st):
+        return dict(sample=st["sample"], binning=self.regularized_apply_mode,
+                    bw_method=self.bw_method, coszen_name=self.coszen_name,
+                    coszen_reflection=self.coszen_reflection, adaptive=self.adaptive,
+                    alpha=self.alpha, oversample=self.oversample, stack_pid=self.stack_pid,
+                    tol=self.tol, channels=st["channels"])
+
+    def _bootstrap_map(self, st, weights, kw):
+        """mean and standard deviation of the maps of `bootstrap_niter` resampled samples
+        (stages/utils/kde.py:189-258)"""
+        rng = np.random.default_rng(self.bootstrap_seed)
+        maps = []
+        for _ in range(self.bootstrap_niter):
+            sw = self._bootstrap_weights(rng, st, int(weights.numel()))
+            try:
+                m = kde_hist.kde_histogramdd(weights=weights * sw, stats=self.stats, **kw)
+            except Exception as exc:
+                raise RuntimeError(
+                    "Could not calculate KDE with the given sample. This can happen if the "
+                    "bootstrap selects too few distinct events in one of the PID channels."
+                ) from exc
+            if not np.all(np.isfinite(m)):
+                raise RuntimeError("Could not calculate KDE with the given sample (non-finite map).")
+            maps.append(m)
+        maps = np.stack(maps)
+        return np.mean(maps, axis=0), np.std(maps, axis=0)
+
+    @staticmethod
+    def owned_containers(n_containers, rank, world_size):
+        """Multi-GPU: the estimators of one evaluation are independent objects (one per container
+        and pid channel), so the CONTAINERS are dealt round-robin to the ranks -- no event ever
+        crosses a rank, bandwidths and pilot densities stay exact -- and the finished maps
+        (n_bins doubles per container) are exchanged in one all-reduce in which every entry has
+        exactly one non-zero contribution: the same bits as on one GPU."""
+        return [i for i in range(n_containers) if i % world_size == rank]
+
+    @staticmethod
+    def exchange_maps(local, n_containers, n_bins, with_errors, group=None):
+        """`local`: {container index: (map[n_bins], errors[n_bins] or None)} of this rank ->
+        the same for all containers on every rank (all-reduce SUM; the ranks' entries are disjoint)"""
+        import torch.distributed as dist
+
+        buf = np.zeros((n_containers, 2 if with_errors else 1, n_bins), dtype=np.float64)
+        for i, (m, e) in local.items():
+            buf[i, 0] = np.asarray(m).ravel()
+            if with_errors:
+                buf[i, 1] = np.asarray(e).ravel()
+        t = torch.from_numpy(buf)
+        on_gpu = dist.get_backend(group) == "nccl"
+        if on_gpu:
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        out = t.cpu().numpy()
+        return {i: (out[i, 0].copy(), out[i, 1].copy() if with_errors else None) for i in range(n_containers)}
+
     def apply_function(self):
         self.stats = {}
-        if not (self.stash_valid or self.bootstrap) and self.kde_workers > 1 and len(self.data.containers) > 1:
-            self._apply_concurrent()
-            self.stash_valid = self.stash_hists
-            return
-        for container in self.data:
-            if self.stash_valid:
-                self.data.representation = self.apply_mode
+        conts = list(self.data)
+        if self.stash_valid:
+            self.data.representation = self.apply_mode
+            for container in conts:
                 container["weights"] = self.stashed_hists[container.name].copy()
                 if self.bootstrap:
                     container["errors"] = self.stashed_errors[container.name].copy()
-                continue
-            st = self._static_sample(container)
-            container.representation = "events"
-            weights = container.device("weights")   # materialises a deferred reweighting chain
-            kw = dict(sample=st["sample"], binning=self.regularized_apply_mode,
-                      bw_method=self.bw_method, coszen_name=self.coszen_name,
-                      coszen_reflection=self.coszen_reflection, adaptive=self.adaptive,
-                      alpha=self.alpha, oversample=self.oversample, stack_pid=self.stack_pid,
-                      tol=self.tol, stats=self.stats, channels=st["channels"])
-            if self.bootstrap:
-                rng = np.random.default_rng(self.bootstrap_seed)
-                maps = []
-                for _ in range(self.bootstrap_niter):
-                    sw = self._bootstrap_weights(rng, st, int(weights.numel()))
-                    try:
-                        m = kde_hist.kde_histogramdd(weights=weights * sw, **kw)
-                    except Exception as exc:
-                        raise RuntimeError(
-                            "Could not calculate KDE with the given sample. This can happen if the "
-                            "bootstrap selects too few distinct events in one of the PID channels."
-                        ) from exc
-                    if not np.all(np.isfinite(m)):
-                        raise RuntimeError("Could not calculate KDE with the given sample (non-finite map).")
-                    maps.append(m)
-                maps = np.stack(maps)
-                kde_map = np.mean(maps, axis=0)
-                kde_errors = np.ascontiguousarray(np.std(maps, axis=0).ravel(), dtype=FTYPE)
-            else:
-                kde_map = kde_hist.kde_histogramdd(weights=weights, **kw)
-            kde_map = np.ascontiguousarray(kde_map.ravel(), dtype=FTYPE)
-            self.data.representation = self.apply_mode
+            return
+        import torch.distributed as dist
+
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        rank = dist.get_rank() if world > 1 else 0
+        owned = self.owned_containers(len(conts), rank, world)
+        # deferred reweighting chains are materialised on the caller's thread and stream
+        inputs = {}
+        for i in owned:
+            st = self._static_sample(conts[i])
+            conts[i].representation = "events"
+            inputs[i] = (st, conts[i].device("weights"), self._job_kwargs(st))
+        results = {}
+        if self.bootstrap:
+            for i, (st, weights, kw) in inputs.items():
+                results[i] = self._bootstrap_map(st, weights, kw)
+        elif self.kde_workers > 1 and len(owned) > 1:
+            pool, main = self._pool(), torch.cuda.current_stream()
+            jobs = {i: pool.submit(self._kde_task, main, weights, kw) for i, (st, weights, kw) in inputs.items()}
+            for i, fut in jobs.items():
+                kde_map, stats = fut.result()
+                for key, val in stats.items():
+                    self.stats[key] = self.stats.get(key, 0) + val
+                results[i] = (kde_map, None)
+        else:
+            for i, (st, weights, kw) in inputs.items():
+                results[i] = (kde_hist.kde_histogramdd(weights=weights, stats=self.stats, **kw), None)
+        if world > 1:
+            results = self.exchange_maps(results, len(conts), int(self.apply_mode.size), self.bootstrap)
+        self.data.representation = self.apply_mode
+        if self.stash_hists:
+            self.stashed_hists, self.stashed_errors = {}, {}
+        for i, container in enumerate(conts):
+            kde_map = np.ascontiguousarray(np.asarray(results[i][0]).ravel(), dtype=FTYPE)
             container["weights"] = kde_map
             if self.bootstrap:
+                kde_errors = np.ascontiguousarray(np.asarray(results[i][1]).ravel(), dtype=FTYPE)
                 container["errors"] = kde_errors
             if self.stash_hists:
-                if self.stashed_hists is None:
-                    self.stashed_hists, self.stashed_errors = {}, {}
                 self.stashed_hists[container.name] = kde_map.copy()
                 if self.bootstrap:
                     self.stashed_errors[container.name] = kde_errors.copy()
         self.stash_valid = self.stash_hists
-
-    def _apply_concurrent(self):
-        pool = self._pool()
-        main = torch.cuda.current_stream()
-        jobs = []
-        for container in self.data:
-            st = self._static_sample(container)
-            container.representation = "events"
-            weights = container.device("weights")   # materialises a deferred reweighting chain
-            kw = dict(sample=st["sample"], binning=self.regularized_apply_mode,
-                      bw_method=self.bw_method, coszen_name=self.coszen_name,
-                      coszen_reflection=self.coszen_reflection, adaptive=self.adaptive,
-                      alpha=self.alpha, oversample=self.oversample, stack_pid=self.stack_pid,
-                      tol=self.tol, channels=st["channels"])
-            jobs.append((container, weights, pool.submit(self._kde_task, main, weights, kw)))
-        for container, _weights, fut in jobs:
-            kde_map, stats = fut.result()
-            for key, val in stats.items():
-                self.stats[key] = self.stats.get(key, 0) + val
-            kde_map = np.ascontiguousarray(kde_map.ravel(), dtype=FTYPE)
-            self.data.representation = self.apply_mode
-            container["weights"] = kde_map
-            if self.stash_hists:
-                if self.stashed_hists is None:
-                    self.stashed_hists, self.stashed_errors = {}, {}
-                self.stashed_hists[container.name] = kde_map.copy()

@@ -189,3 +189,41 @@ def test_engine_eval_control_flow_on_gloo_ranks(tmp_path, world):
     assert res[3] == sum(len(c["w0"]) for c in _toy_containers())
     np.testing.assert_array_equal(res[:3], want)
     np.testing.assert_array_equal(res[4:], single.hist.ravel())
+
+
+# ---- utils.kde on several ranks: containers dealt round-robin, one all-reduce of the finished maps
+def _fake_map(i, n_bins):
+    rs = np.random.RandomState(100 + i)
+    return rs.rand(n_bins) * 10 ** (rs.rand(n_bins) * 8 - 4), rs.rand(n_bins)
+
+
+def _kde_exchange_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pisa_amd.stages.utils.kde import kde as kde_stage
+
+    n_cont, n_bins = 12, 37
+    owned = kde_stage.owned_containers(n_cont, rank, world)
+    local = {i: _fake_map(i, n_bins) for i in owned}
+    full = kde_stage.exchange_maps(local, n_cont, n_bins, with_errors=True)
+    n_owned = torch.tensor([len(owned)])
+    dist.all_reduce(n_owned)
+    assert int(n_owned) == n_cont                      # every container has exactly one owner
+    assert sorted(full) == list(range(n_cont))
+    if rank == world - 1:                              # any rank holds everything afterwards
+        np.save(out_path, np.stack([np.stack(full[i]) for i in range(n_cont)]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 5])
+def test_kde_stage_map_exchange_on_gloo_ranks(tmp_path, world):
+    """the KDE stage's multi-GPU rule: estimators are independent, so containers are dealt to the
+    ranks and the finished maps exchanged -- bit-identical to what one rank computes"""
+    out = str(tmp_path / "kde.npy")
+    mp.spawn(_kde_exchange_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = np.load(out)
+    for i in range(12):
+        m, e = _fake_map(i, 37)
+        np.testing.assert_array_equal(got[i, 0], m)
+        np.testing.assert_array_equal(got[i, 1], e)
