@@ -499,19 +499,28 @@ def leg_kde(torch, n_events, steps):
     dt = (time.perf_counter() - t0) / steps
     st = pipe["kde"].stats
     work = st["pairs_pilot"] + st["pairs_eval"]
-    # 23 fp64 VALU instructions per kernel evaluation (2 sub, mul, fma, mul, own exp = 1 max + 1 rint +
-    # 1 mul + 2 fma + 13 fma + cvt + ldexp, 1 fma to accumulate): 17 of them FMA -> 40 flop
-    flop = 40.0 * work
-    return {"events": int(n_events) // 12 * 12, "evals_per_s": 1.0 / dt, "ms_per_step": dt * 1e3,
-            "kernel_evaluations_per_step": work, "all_pairs_would_be": st["all_pairs"],
-            "total_of_maps": float(sum(m.hist.sum() for m in maps)),
-            "roofline": {"bound": "fp64 valu", "achieved": flop / dt / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": flop / dt / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                         "note": "whole stage time (24 estimators: sorts, pilot through Hermite series, adaptive "
-                                 "evaluation, host glue) against 40 flop per counted kernel evaluation"},
-            "workload": "settings/pipeline/example_hip.cfg with utils.kde in place of utils.hist: 12 containers x 2 "
-                        "pid channels = 24 adaptive 2-D KDEs per evaluation, 80 x 120 evaluation points each; "
-                        "theta23 changed every step; KDE core parity unpinned (un-vendored `kde` package)"}
+    out = {"events": int(n_events) // 12 * 12, "evals_per_s": 1.0 / dt, "ms_per_step": dt * 1e3,
+           "kernel_evaluations_per_step": work, "all_pairs_would_be": st["all_pairs"],
+           "total_of_maps": float(sum(m.hist.sum() for m in maps)),
+           "workload": "settings/pipeline/example_hip.cfg with utils.kde in place of utils.hist: 12 containers x 2 "
+                       "pid channels = 24 adaptive 2-D KDEs per evaluation, 80 x 120 evaluation points each; "
+                       "theta23 changed every step; KDE core parity unpinned (un-vendored `kde` package)"}
+    # executed fp64 flops of ALL kde_* kernels of one evaluation from the committed SQ_INSTS_VALU_*_F64
+    # counter pass over scripts/dev/c3_probe.py (scripts/profile_round.sh); not measured in this run.
+    # (The map evaluation no longer spends one exponential per kernel value -- Gaussian recurrence along
+    # lattice lines -- so a flop count per counted kernel value would mean nothing.)
+    cal, src = latest_profile("kde_flops.json")
+    if cal is not None and cal.get("events") == out["events"]:
+        flop = cal["fp64_flop_per_evaluation"]
+        out["roofline"] = {"bound": "fp64 valu", "achieved": flop / dt / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": flop / dt / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                           "fp64_flop_per_evaluation": flop,
+                           "flop_source": "%s/kde_flops.json (executed fp64 FMA x2 + ADD + MUL + TRANS lane operations "
+                                          "of all kde_* kernels of one evaluation, committed rocprofv3 pass, not this "
+                                          "run)" % src,
+                           "note": "whole stage wall time (24 estimators on 4 host threads / streams: sorts, pilot "
+                                   "through local expansions, lattice evaluation, host glue)"}
+    return out
 
 
 def main():

@@ -8,6 +8,7 @@
 #   events_flops.json           executed fp64 lane operations per event of prob3_events_kernel
 #                               (SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 pass over scripts/bench_events.py)
 #   kde_kernel_stats.csv        kernel trace statistics of the C3 (KDE on) pipeline
+#   kde_flops.json              executed fp64 flops of all kde_* kernels of one C3 evaluation (counter pass)
 TAG=$1
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; rm -rf $OUT; mkdir -p $OUT
@@ -35,6 +36,8 @@ rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F6
 cp $OUT/pmc_kde/p_counter_collection.csv $OUT/pmc_kde.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kde_stats -o kde -- python3 scripts/dev/c3_probe.py 1e7 > $OUT/c3_probe.log 2> $OUT/kde_stats.log
 cp $OUT/kde_stats/kde_kernel_stats.csv $OUT/kde_kernel_stats.csv
+rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 --kernel-trace --output-format csv -d $OUT/pmc_c3 -o p -- python3 scripts/dev/c3_probe.py 1e7 > $OUT/c3_pmc_run.log 2> $OUT/pmc_c3.log
+cp $OUT/pmc_c3/p_counter_collection.csv $OUT/pmc_c3_full.csv
 python3 - <<PY
 import csv, json
 OUT = "$OUT"
@@ -77,6 +80,37 @@ for name in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MU
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(OUT + "/pmc_kde.csv"))
             if "kde_pairs_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name]
     k[name] = sum(vals)
+# executed fp64 flops of one C3 evaluation (all kde_* kernels; the probe runs 4 evaluations of 24 estimators)
+rows = list(csv.DictReader(open(OUT + "/pmc_c3_full.csv")))
+per_kernel = {}
+for r in rows:
+    name = r["Kernel_Name"]
+    if "kde_" not in name:
+        continue
+    short = name.split("(")[0].replace("void ", "").replace("pisa::", "")
+    wgt = {"SQ_INSTS_VALU_FMA_F64": 2.0, "SQ_INSTS_VALU_ADD_F64": 1.0, "SQ_INSTS_VALU_MUL_F64": 1.0,
+           "SQ_INSTS_VALU_TRANS_F64": 1.0}.get(r["Counter_Name"])
+    if wgt is None:
+        continue
+    d = per_kernel.setdefault(short, {"flop": 0.0, "dispatches": set()})
+    d["flop"] += 64.0 * wgt * float(r["Counter_Value"])
+    d["dispatches"].add(r["Dispatch_Id"])
+n_eval = 4
+tot = sum(d["flop"] for d in per_kernel.values())
+json.dump({"events": 9999996, "evaluations_in_run": n_eval, "fp64_flop_per_evaluation": tot / n_eval,
+           "per_kernel_flop_per_evaluation": {k_: v["flop"] / n_eval for k_, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["flop"])},
+           "launches_per_evaluation": {k_: len(v["dispatches"]) / n_eval for k_, v in per_kernel.items()},
+           "method": "rocprofv3 --pmc SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 over scripts/dev/c3_probe.py 1e7 (4 evaluations of the "
+                     "1e7-event pipeline with utils.kde); wave-level counts x 64 lanes, FMA = 2 flop, summed over every kernel "
+                     "whose name contains kde_"}, open(OUT + "/kde_flops.json", "w"), indent=1)
+print("kde flop per evaluation %.3e" % (tot / n_eval))
+# the raw rows of the KDE kernels only
+with open(OUT + "/pmc_c3.csv", "w", newline="") as f:
+    wr = csv.writer(f)
+    wr.writerow(list(rows[0].keys()))
+    for r in rows:
+        if "kde_lattice_kernel" in r["Kernel_Name"] or "kde_local_pilot" in r["Kernel_Name"] or "kde_h2l" in r["Kernel_Name"]:
+            wr.writerow(list(r.values()))
 json.dump({"kde_pairs_kernel_totals": k, "run": open(OUT + "/kde_pmc_run.json").read()[-1500:]}, open(OUT + "/kde_counter_check.json", "w"), indent=1)
 for r in list(csv.reader(open(OUT + "/kernel_stats.csv")))[:8]:
     print(r[0][:60].ljust(60), r[1:5])
@@ -92,5 +126,5 @@ phase["note"] = ("from bench_kernel_trace.csv of the rocprofv3 run of bench.py -
 json.dump(phase, open(OUT + "/kernels_by_phase.json", "w"), indent=1)
 print({k: round(v["timed_loop_mean_us"], 2) for k, v in phase.items() if k != "note"})
 PY
-rm -rf $OUT/stats $OUT/pmc_*_FETCH_SIZE $OUT/pmc_*_WRITE_SIZE $OUT/pmc_events_std $OUT/pmc_events_nsi $OUT/pmc_kde $OUT/kde_stats
+rm -rf $OUT/pmc_c3 $OUT/pmc_c3_full.csv $OUT/stats $OUT/pmc_*_FETCH_SIZE $OUT/pmc_*_WRITE_SIZE $OUT/pmc_events_std $OUT/pmc_events_nsi $OUT/pmc_kde $OUT/kde_stats
 ls $OUT
