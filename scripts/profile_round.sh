@@ -59,19 +59,27 @@ def traffic(tag, label, alg, fname):
 traffic("main", "hist_accumulate_kernel<7,true> (16-bit index layout, 20 B/event), 9999996 events", 20 * 9999996, "traffic.json")
 traffic("l3", "hist_accumulate_kernel<7,true>, 39999996 events (800 MB resident: beyond the 256 MiB Infinity Cache)", 20 * 39999996, "traffic_l3_exceeding.json")
 traffic("coord", "hist_accumulate_kernel<1,true> (coordinate form, SURVEY 8(d) 72 B/event), 9999996 events", 72 * 9999996, "traffic_coordinate_form.json")
-# executed fp64 lane operations of prob3_events_kernel
+# executed fp64 lane operations of prob3_events_kernel.  One evaluation = one launch per sign, each over
+# the events of that sign: the counters are summed over all launches and divided by the summed grid
+# sizes (threads = events, padded to whole wavefronts), i.e. per event of the launch it belongs to.
 ev = {}
 for v in ("std", "nsi"):
-    c = {}
-    for name in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU"):
-        c[name], n = per_launch("%s/pmc_events_%s.csv" % (OUT, v), "prob3_events", name)
-    n_events = 999996
-    flop = 64.0 * (2 * c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_TRANS_F64"])
-    ev[v] = {"wave_instructions_per_launch": c, "launches": n, "events": n_events, "flop_per_event": flop / n_events,
-             "valu_instructions_per_event_lane": c["SQ_INSTS_VALU"] * 64.0 / n_events}
+    tot, threads, launches = {}, {}, set()
+    for r in csv.DictReader(open("%s/pmc_events_%s.csv" % (OUT, v))):
+        if "prob3_events" not in r["Kernel_Name"]:
+            continue
+        tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        threads[r["Counter_Name"]] = threads.get(r["Counter_Name"], 0.0) + float(r["Grid_Size"])
+        launches.add(r["Dispatch_Id"])
+    per = {name: 64.0 * tot[name] / threads[name] for name in tot}   # per event and lane
+    flop = (2 * per["SQ_INSTS_VALU_FMA_F64"] + per["SQ_INSTS_VALU_ADD_F64"] + per["SQ_INSTS_VALU_MUL_F64"]
+            + per["SQ_INSTS_VALU_TRANS_F64"])
+    ev[v] = {"instructions_per_event_lane": per, "launches": len(launches), "flop_per_event": flop,
+             "valu_instructions_per_event_lane": per["SQ_INSTS_VALU"]}
 ev["method"] = ("rocprofv3 --pmc SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 SQ_INSTS_VALU over scripts/bench_events.py --events 1e6; "
-                "wave-level instruction counts x 64 lanes (inactive lanes of partially filled or divergent waves "
-                "are counted: an upper bound of the useful lane operations), FMA = 2 flop")
+                "wave-level instruction counts x 64 lanes summed over the launches, divided by the summed grid sizes "
+                "(each launch covers the events of one sign); inactive lanes of partially filled or divergent waves "
+                "are counted: an upper bound of the useful lane operations; FMA = 2 flop")
 json.dump(ev, open(OUT + "/events_flops.json", "w"), indent=1)
 print({k: (v["flop_per_event"] if isinstance(v, dict) else None) for k, v in ev.items()})
 # calibration of the same counters on a kernel with a known instruction mix: kde_pairs_kernel
