@@ -310,6 +310,19 @@ int pisa_hip_finalize_metric(int64_t *d_limbs, int32_t n_containers, int64_t n_b
                              const double *d_actual, double *total, int32_t *d_status,
                              int32_t *d_metric_status, int32_t clear_limbs, void *stream);
 
+/* pisa_hip_finalize_metric for a template that is not just the sum of the histogrammed maps:
+ * d_scale [n_containers][n_bins] (or NULL): per-bin factors of a stage that follows the histogram --
+ *   discr_sys.hypersurfaces, `weights = clip(weights * s, 0, inf)`, `errors *= s`
+ *   (hypersurfaces.py:251-259): the expectation of bin b is sum_c max(w_cb s_cb, 0), its variance
+ *   sum_c sumw2_cb s_cb^2.  d_hist / d_sumw2 are written UNscaled.
+ * d_extra [2][n_bins] (or NULL): expectation and variance of maps added to the template after the
+ *   containers, in that order (the other pipelines of a DistributionMaker, distribution_maker.py:274-281). */
+int pisa_hip_finalize_metric_scaled(int64_t *d_limbs, int32_t n_containers, int64_t n_bins,
+                                    double *d_hist, double *d_sumw2, int32_t kind,
+                                    const double *d_actual, const double *d_scale,
+                                    const double *d_extra, double *total, int32_t *d_status,
+                                    int32_t *d_metric_status, int32_t clear_limbs, void *stream);
+
 /* --------------------------------------------------------------------- KDE */
 
 /* The density estimator behind the KDE stage.  pisa/utils/kde_hist.py:110-120 calls

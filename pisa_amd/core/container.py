@@ -118,6 +118,9 @@ class Container:
     sum_mode_keys = ()
     array_representations = ("events", "log_events")
 
+    _unrolled = {}   # (hash(binning), dimension name) -> DualArray of the unrolled bin centres
+    writes = 0       # per container: stores / mark_changed of THIS container (class default: none yet)
+
     def __init__(self, name, representation="events"):
         self.name = name
         self._representation = None
@@ -256,6 +259,7 @@ class Container:
     def mark_changed(self, key):
         self._version[key] += 1
         Container.clock += 1
+        self.writes += 1
         self._lazy.pop(key, None)
         for rep in self.validity[key]:
             self.validity[key][rep] = False
@@ -269,6 +273,7 @@ class Container:
     def _invalidate_others(self, key):
         self._version[key] += 1
         Container.clock += 1
+        self.writes += 1
         self._lazy.pop(key, None)
         for rep in self.validity[key]:
             self.validity[key][rep] = False
@@ -294,7 +299,13 @@ class Container:
         elif key in self._lazy and hash(self._lazy[key][1]) == hash(self._representation):
             self._materialize_lazy(key)
         if self._is_map and key in self._representation._name_set:
-            return DualArray(self.unroll_binning(key, self._representation))
+            # the bin centres of a binning never change: one host array and one device copy per
+            # (binning, dimension) for all containers (a binned flux stage asks for them every evaluation)
+            ck = (hash(self._representation), key)
+            arr = Container._unrolled.get(ck)
+            if arr is None:
+                arr = Container._unrolled[ck] = DualArray(self.unroll_binning(key, self._representation))
+            return arr
         if key not in self.current_data:
             if key in self.validity:
                 self.auto_translate(key)

@@ -47,9 +47,16 @@ class DistributionMaker:
 
     @property
     def params(self):
+        """merged view of the pipelines' parameters (distribution_maker.py:310-317); the Param objects
+        are the pipelines' own, so the view is rebuilt only when some set changed structurally"""
+        hit = getattr(self, "_params_view", None)
+        if hit is not None and hit[0] == ParamSet.struct_clock:
+            return hit[1]
         params = ParamSet()
+        object.__setattr__(params, "_transient", True)
         for p in self._pipelines:
             params.update(p.params, existing_must_match=False, extend=True)
+        self._params_view = (ParamSet.struct_clock, params)
         return params
 
     @property

@@ -17,6 +17,7 @@ source of truth (the plan is rebuilt afterwards).  The bypassed stages' compute 
 invalidated, so the ordinary path never trusts tables the plan has overwritten.
 """
 import ctypes as C
+import os
 import weakref
 
 import numpy as np
@@ -29,13 +30,18 @@ from pisa_amd.core.param import Param, ParamSet
 
 __all__ = ["FastPlan", "DeviceMapBlock", "DeviceMapSet"]
 
+_DEBUG = bool(os.environ.get("PISA_PLAN_DEBUG"))
+
 
 class DeviceMapBlock:
     """The maps (and sum of squared weights) of all containers of ONE evaluation, still in HBM."""
 
-    def __init__(self, engine, with_errors):
+    def __init__(self, engine, with_errors, scales=None):
         self.engine = engine
         self.with_errors = with_errors
+        # per-(container, bin) factors of a stage behind the histogram (discr_sys.hypersurfaces):
+        # device tensor [n_cont, n_bins]; maps = clip(hist * s, 0, inf), errors = sqrt(sumw2) * s
+        self.scales = scales
         self.full = (1 << len(engine.cont)) - 1
         self._host = None
         self._live = True   # the engine still holds this evaluation
@@ -49,9 +55,14 @@ class DeviceMapBlock:
     def _fetch(self):
         eng = self.engine
         hist, sumw2 = eng.finalize()
-        if self.with_errors:
-            import torch
+        import torch
 
+        if self.scales is not None:
+            # as the stage does it: weights = clip(weights * s, 0, inf), errors = sqrt(sumw2) * s
+            sc = self.scales.reshape(hist.shape)
+            err = torch.sqrt(sumw2) * sc
+            hist, sumw2 = torch.clamp(hist * sc, min=0.0), err * err
+        if self.with_errors:
             both = torch.stack((hist, sumw2)).cpu().numpy()
             self._host = (both[0], both[1])
         else:
@@ -73,16 +84,25 @@ class DeviceMapBlock:
                 v += sumw2[i]
         return h.reshape(shape), None if v is None else v.reshape(shape)
 
-    def metric(self, mask, kind, data_hist):
+    def metric(self, mask, kind, data_hist, extra=None):
         """metric of the TOTAL template against `data_hist` on the device, or None if this block
-        cannot provide it (partial sum, already fetched, no longer the engine's evaluation)"""
+        cannot provide it (partial sum, already fetched, no longer the engine's evaluation).
+        `extra` = (hist, variances or None) host arrays added to the template after the containers."""
         if mask != self.full or not self._live or self._host is not None:
             return None
         if kind == "mod_chi2" and not self.with_errors:
             return None
         eng = self.engine
+        extra_d = None
+        if self.scales is not None or extra is not None:
+            if not eng.can_fuse_tail():
+                return None
+            if extra is not None:
+                eh = np.asarray(extra[0], dtype=np.float64).ravel()
+                ev = np.zeros_like(eh) if extra[1] is None else np.asarray(extra[1], dtype=np.float64).ravel()
+                extra_d = eng.upload_extra(np.stack((eh, ev)))
         eng.set_data_cached(np.ascontiguousarray(data_hist, dtype=np.float64).ravel())
-        val = eng.tail_host(kind)
+        val = eng.tail_host(kind, self.scales, extra_d)
         if val != val:   # NaN: a negative input sets the status word too (stats.py:231-240 raises)
             st = eng.metric_status_host()
             if st != 0:
@@ -123,49 +143,94 @@ class DeviceMapSet(MapSet):
         return out
 
 
+def _no(reason):
+    """ordinary path; PISA_PLAN_DEBUG=1 says why"""
+    if _DEBUG:
+        print("[evaluation plan] ordinary path:", reason)
+    return None
+
+
 class FastPlan:
     @classmethod
     def build(cls, pipeline):
-        """a plan for `pipeline`, or None if its last evaluation did not have the replayable shape"""
+        """a plan for `pipeline`, or None if its last evaluation did not have the replayable shape:
+        loader -> [flux ...] -> osc.prob3 -> aeff.aeff -> utils.hist [-> discr_sys.hypersurfaces]"""
         stages = pipeline._stages
         if not stages or pipeline._profile:
             return None
-        hist = stages[-1]
-        if hist.service_name != "hist" or not getattr(hist, "fused_last_eval", False):
-            return None
+        ih = [k for k, s in enumerate(stages) if s.service_name == "hist"]
+        if len(ih) != 1:
+            return _no("no single hist stage")
+        hist = stages[ih[0]]
+        if not getattr(hist, "fused_last_eval", False):
+            return _no("hist stage did not take the fused path")
+        post = stages[ih[0] + 1:]
+        for s in post:
+            # per-bin scale factors behind the histogram: weights = clip(weights * s, 0, inf),
+            # errors *= s (hypersurfaces.py:251-259); the uncertainty-propagating variant is not replayed
+            if s.service_name != "hypersurfaces" or s.propagate_uncertainty:
+                return _no("stage %s after the histogram" % s.service_name)
         osc = [s for s in stages if s.service_name == "prob3"]
         aeff = [s for s in stages if s.service_name == "aeff" and s.stage_name == "aeff"]
         if len(osc) != 1 or len(aeff) != 1 or osc[0].grid is None or hist._engine is None:
-            return None
+            return _no("no prob3 grid / aeff / engine")
         if osc[0].tomography_type is not None:
-            return None   # may rebuild the layer plan inside _matrices(): ordinary path only
+            return _no("tomography")   # may rebuild the layer plan inside _matrices(): ordinary path only
         if hist._engine.world_size > 1 and hist._engine.n_bins * len(hist._engine.cont) > K.FINALIZE_METRIC_MAX:
-            return None
+            return _no("maps too large for the fused tail on several ranks")
         key = pipeline.output_key
         if key not in ("weights", ("weights", "errors")):
-            return None
+            return _no("output key %r" % (key,))
         if key != "weights" and hist.error_method != "sumw2":
-            return None
-        return cls(pipeline, osc[0], aeff[0], hist)
+            return _no("errors without sumw2")
+        if post and (len(post) != 1 or key == "weights" or any(s.error_method != "sumw2" for s in post)):
+            return _no("post-histogram stages not in the supported shape")
+        return cls(pipeline, osc[0], aeff[0], hist, post)
 
-    def __init__(self, pipeline, osc, aeff, hist):
+    def __init__(self, pipeline, osc, aeff, hist, post=()):
         self.pipeline, self.osc, self.aeff, self.hist = pipeline, osc, aeff, hist
+        self.post = list(post)
         self.engine = hist._engine
         self.with_errors = pipeline.output_key != "weights"
         self.binning = pipeline.output_binning
         self.names = [c.name for c in hist.data.containers]
+        stages = pipeline._stages
+        # flux stages (between the loader and prob3) can be replayed when the flux lives on the
+        # oscillation grid: a stage run on 2e4 nodes per container and new node tables, no pass over
+        # the events (stages/utils/hist.py, engine.node_flux)
+        k_osc = stages.index(osc)
+        self.flux_stages = [s for s in stages[:k_osc] if s.stage_name == "flux"] if self.engine.node_flux else []
         # one flat list of (param, index of its stage); a parameter shared by stages appears once
         # per stage, so every stage that uses it is seen to change
-        self.flat = [(p, k) for k, s in enumerate(pipeline._stages) for p in s.params]
+        self.flat = [(p, k) for k, s in enumerate(stages) for p in s.params]
         self.seen = [p._ver for p, _ in self.flat]
         self.struct_clock = ParamSet.struct_clock
         self.clock = Param.clock
-        self.container_clock = Container.clock
+        self._conts = list(hist.data.containers)
+        self.container_clock = self._writes()
         self.ye = (osc.YeI, osc.YeO, osc.YeM)
-        g = osc.grid
         self._osc_args = None
-        self._grid = g
         self._lib = _lib.lib()
+        self.scales = self._read_scales() if self.post else None
+
+    def _writes(self):
+        """stores into THIS pipeline's containers (the other pipelines of a DistributionMaker write
+        their own)"""
+        return sum(c.writes for c in self._conts)
+
+    def _read_scales(self):
+        """the post-histogram stage's per-bin factors, [n_cont, n_bins] on the device"""
+        import torch
+
+        hs = self.post[0]
+        keep = [c.representation for c in self._conts]
+        try:
+            for c in self._conts:
+                c.representation = hs.calc_mode
+            return torch.stack([c.device("hs_scales") for c in self._conts]).contiguous()
+        finally:
+            for c, r in zip(self._conts, keep):
+                c.representation = r
 
     def _changed(self):
         """stages with a moved parameter; None if parameter OBJECTS were exchanged somewhere
@@ -186,20 +251,36 @@ class FastPlan:
         """device-backed output MapSet, or None: take the ordinary path"""
         osc, eng = self.osc, self.engine
         if self.hist._engine is not eng or osc.pepmu is None:
-            return None
-        if Container.clock != self.container_clock:
-            return None   # somebody wrote a container (e.g. edited a flux column in place)
+            return _no("engine replaced")
+        if self._writes() != self.container_clock:
+            return _no("a container was written")   # e.g. somebody edited a flux column in place
         if Param.clock != self.clock:
             changed = self._changed()
-            if changed is None or any(s is not osc and s is not self.aeff for s in changed):
-                return None
+            if changed is None:
+                return _no("parameter objects exchanged")
+            replayable = [osc, self.aeff] + self.flux_stages + self.post
+            for s in changed:
+                if all(s is not r for r in replayable):
+                    return _no("stage %s.%s moved" % (s.stage_name, s.service_name))
             self.clock = Param.clock
             if osc in changed:
                 p = osc.params
                 ye = (p.YeI.value.m_as("dimensionless"), p.YeO.value.m_as("dimensionless"),
                       p.YeM.value.m_as("dimensionless"))
                 if ye != self.ye:
-                    return None          # new layers, new plan: ordinary path
+                    return _no("Ye moved")          # new layers, new plan: ordinary path
+            flux_changed = [s for s in self.flux_stages if any(s is c for c in changed)]
+            if flux_changed:
+                # the stages' own compute on the grid nodes, in pipeline order from the first one
+                # that moved (a later flux stage reads what an earlier one wrote), then new node tables
+                first = self.flux_stages.index(flux_changed[0])
+                for s in self.flux_stages[first:]:
+                    if all(s is not c for c in flux_changed):
+                        s.param_hash = None      # reads what an earlier, moved flux stage wrote
+                    s.run()
+                self.hist.sync_node_flux()
+                self.container_clock = self._writes()   # our own writes
+            if osc in changed:
                 params = osc._matrices()
                 osc.param_hash = None    # its tables no longer belong to the memoised values
                 a = self._osc_args
@@ -214,8 +295,14 @@ class FastPlan:
             if self.aeff in changed:
                 for name in self.names:
                     eng.set_scale(name, self.aeff.scale_for(name))
+            post_changed = [s for s in self.post if any(s is c for c in changed)]
+            if post_changed:
+                for s in post_changed:
+                    s.compute()          # per-bin factors on the host (a few hundred bins)
+                self.scales = self._read_scales()
+                self.container_clock = self._writes()
         eng.front(osc.pepmu)
-        block = DeviceMapBlock(eng, self.with_errors)
+        block = DeviceMapBlock(eng, self.with_errors, self.scales)
         eng._out_block = weakref.ref(block)
         self.pipeline._containers_stale = True
         return DeviceMapSet(self.names, self.binning, block, self.pipeline.name)

@@ -39,21 +39,33 @@ class Map:
         self.tex = tex
         self.binning = binning
         self._lazy = None
+        self._extra = None
         self._h = hist
         self._v = None
         if error_hist is not None:
             self.set_errors(error_hist)
 
     @classmethod
-    def device_backed(cls, name, binning, block, mask):
+    def device_backed(cls, name, binning, block, mask, extra=None):
+        """`extra` = (hist, variances or None): host maps added AFTER the device rows (the other
+        pipelines of a DistributionMaker); the sum stays device backed and `metric` hands the
+        addend to the device tail"""
         m = cls.__new__(cls)
         m.name, m.tex, m.binning = name, None, binning
         m._lazy, m._h, m._v = (block, mask), None, None
+        m._extra = extra
         return m
 
     def _fetch(self):
         block, mask = self._lazy
         self._h, self._v = block.host_sum(mask, self.binning.shape)
+        extra = getattr(self, "_extra", None)
+        if extra is not None:
+            self._h = self._h + extra[0]
+            if self._v is not None or extra[1] is not None:
+                self._v = (np.zeros_like(self._h) if self._v is None else self._v) + \
+                          (np.zeros_like(self._h) if extra[1] is None else extra[1])
+            self._extra = None
         self._lazy = None
 
     @property
@@ -113,9 +125,22 @@ class Map:
             if (self._lazy is not None and other._lazy is not None and self._lazy[0] is other._lazy[0]
                     and not (self._lazy[1] & other._lazy[1])):
                 # rows of one device table: the sum stays on the device
-                return Map.device_backed("(%s + %s)" % (self.name, other.name), self.binning,
-                                         self._lazy[0], self._lazy[1] | other._lazy[1])
+                if getattr(self, "_extra", None) is None and getattr(other, "_extra", None) is None:
+                    return Map.device_backed("(%s + %s)" % (self.name, other.name), self.binning,
+                                             self._lazy[0], self._lazy[1] | other._lazy[1])
             assert other.binning == self.binning
+            if self._lazy is not None and other._lazy is None and self._lazy[1] == self._lazy[0].full:
+                # complete device template + a host map: the sum stays on the device, the host map is
+                # added behind the device rows (same order as the host sum below)
+                prev = getattr(self, "_extra", None)
+                oh, ov = other._h, other._v
+                if prev is not None:
+                    ph, pv = prev
+                    oh = ph + oh
+                    if pv is not None or ov is not None:
+                        ov = (np.zeros_like(oh) if pv is None else pv) + (np.zeros_like(oh) if ov is None else ov)
+                return Map.device_backed("(%s + %s)" % (self.name, other.name), self.binning,
+                                         self._lazy[0], self._lazy[1], extra=(oh, ov))
             var = None
             if self._var is not None or other._var is not None:
                 var = self.variances + other.variances
@@ -184,7 +209,7 @@ class Map:
             if expected_values.binning.shape != self._hist.shape:
                 raise ValueError("Shape mismatch: actual %s, expected %s"
                                  % (self._hist.shape, expected_values.binning.shape))
-            val = block.metric(mask, metric, self._hist)
+            val = block.metric(mask, metric, self._hist, getattr(expected_values, "_extra", None))
             if val is not None:
                 return val
         if isinstance(expected_values, Map):

@@ -294,7 +294,11 @@ class ParamSet(Sequence):
             raise ValueError("duplicate parameter names: %s" % sorted(n for n in names if names.count(n) > 1))
         object.__setattr__(self, "_params", params)
         object.__setattr__(self, "normalize_values", True)
-        object.__setattr__(self, "_index", None)   # name -> position, rebuilt after structural changes
+        # name -> position; every mutator below keeps it current (a Param's name never changes)
+        object.__setattr__(self, "_index", {p.name: i for i, p in enumerate(params)})
+        # a transient set (a merged VIEW built for one call, `DistributionMaker.params`) is owned by
+        # nobody: filling it is not a structural change of the process' parameter sets
+        object.__setattr__(self, "_transient", False)
 
     # sequence protocol
     def __len__(self):
@@ -313,17 +317,11 @@ class ParamSet(Sequence):
         return self._pos(name) is not None
 
     def _pos(self, name):
-        idx = self._index
-        if idx is None or len(idx) != len(self._params):
-            idx = {p.name: i for i, p in enumerate(self._params)}
-            object.__setattr__(self, "_index", idx)
-        i = idx.get(name)
-        if i is not None and self._params[i].name == name:
-            return i
-        # the list was changed in place (replace / update): rebuild once
-        idx = {p.name: i for i, p in enumerate(self._params)}
-        object.__setattr__(self, "_index", idx)
-        return idx.get(name)
+        return self._index.get(name)
+
+    def _bump(self):
+        if not self._transient:
+            ParamSet.struct_clock += 1
 
     def __getattr__(self, attr):
         if attr.startswith("_"):
@@ -374,12 +372,14 @@ class ParamSet(Sequence):
         for p in new:
             if p.name in self.names:
                 raise ValueError("parameter '%s' already present" % p.name)
-        self._params.extend(new)
-        ParamSet.struct_clock += 1
+        for p in new:
+            self._index[p.name] = len(self._params)
+            self._params.append(p)
+        self._bump()
 
     def replace(self, new):
         self._params[self.index(new.name)] = new
-        ParamSet.struct_clock += 1
+        self._bump()
 
     def update(self, obj, existing_must_match=False, extend=True):
         """param.py:1221-1260"""
@@ -392,10 +392,11 @@ class ParamSet(Sequence):
                                      % p.name)
                 if self._params[i] is not p:
                     self._params[i] = p
-                    ParamSet.struct_clock += 1
+                    self._bump()
             elif extend:
+                self._index[p.name] = len(self._params)
                 self._params.append(p)
-                ParamSet.struct_clock += 1
+                self._bump()
 
     def reset_all(self):
         for p in self._params:

@@ -559,7 +559,8 @@ __global__ void __launch_bounds__(1024)
 finalize_metric_kernel(long long *__restrict__ limbs, int n_cont, int n_bins,
                        double *__restrict__ hist, double *__restrict__ q1,
                        const double *__restrict__ actual, double *__restrict__ total,
-                       int32_t *__restrict__ status, int32_t *__restrict__ mstatus, int clear) {
+                       int32_t *__restrict__ status, int32_t *__restrict__ mstatus, int clear,
+                       const double *__restrict__ scale, const double *__restrict__ extra) {
     extern __shared__ __attribute__((aligned(16))) double s_map[];  // [2][n_cont][n_bins]
     __shared__ double s_sum[256];
     __shared__ int s_flag[2];
@@ -597,8 +598,17 @@ finalize_metric_kernel(long long *__restrict__ limbs, int n_cont, int n_bins,
                 }
                 const int i = it >> 1, q = it & 1;
                 const double d = limbs_to_double(w[u], ovf);
-                (q ? q1 : hist)[i] = d;
-                s_map[q * n_tot + i] = d;
+                (q ? q1 : hist)[i] = d;   // the maps are written as histogrammed
+                double v = d;
+                if (scale) {
+                    // per-bin scale factors of a stage that follows the histogram
+                    // (discr_sys.hypersurfaces: weights = clip(weights * s, 0, inf), errors *= s;
+                    // hypersurfaces.py:251-259) enter the metric's expectation only
+                    const double sc = scale[i];
+                    const double e = sqrt(d) * sc;   // errors = sqrt(sumw2) * s, variance = errors^2
+                    v = q ? e * e : fmax(d * sc, 0.0);
+                }
+                s_map[q * n_tot + i] = v;
             }
             // conversions one after the other: interleaved they exceed the 128-VGPR budget
             __builtin_amdgcn_sched_barrier(0);
@@ -615,6 +625,10 @@ finalize_metric_kernel(long long *__restrict__ limbs, int n_cont, int n_bins,
             for (int m = 0; m < n_cont; m++) {
                 lam = (m == 0) ? expected[b] : lam + expected[m * n_bins + b];
                 s2 = (m == 0) ? sigma2[b] : s2 + sigma2[m * n_bins + b];
+            }
+            if (extra) {   // maps of other pipelines added to the template (distribution_maker.py:274-281)
+                lam += extra[b];
+                s2 += extra[n_bins + b];
             }
             double v;
             const bool finite = (k == k) && (lam == lam) && !isinf(k) && !isinf(lam);
@@ -905,11 +919,12 @@ PISA_API int pisa_hip_reweight_hist_acc(const pisa_hip_container *h_containers,
                               d_pepmu, h_out_binning, d_limbs, d_status, stream, false);
 }
 
-PISA_API int pisa_hip_finalize_metric(int64_t *d_limbs, int32_t n_containers, int64_t n_bins,
-                                      double *d_hist, double *d_sumw2, int32_t kind,
-                                      const double *d_actual, double *total, int32_t *d_status,
-                                      int32_t *d_metric_status, int32_t clear_limbs,
-                                      void *stream) {
+PISA_API int pisa_hip_finalize_metric_scaled(int64_t *d_limbs, int32_t n_containers, int64_t n_bins,
+                                             double *d_hist, double *d_sumw2, int32_t kind,
+                                             const double *d_actual, const double *d_scale,
+                                             const double *d_extra, double *total, int32_t *d_status,
+                                             int32_t *d_metric_status, int32_t clear_limbs,
+                                             void *stream) {
     if (!d_limbs || !d_hist || !d_sumw2 || !d_actual || !total || n_containers < 1 || n_bins < 1)
         return PISA_HIP_ERR_INVALID;
     if (kind < PISA_HIP_METRIC_LLH || kind > PISA_HIP_METRIC_MOD_CHI2) return PISA_HIP_ERR_INVALID;
@@ -921,7 +936,7 @@ PISA_API int pisa_hip_finalize_metric(int64_t *d_limbs, int32_t n_containers, in
     auto launch = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(1), dim3(threads), (size_t)n_tot * 16, as_stream(stream),
                            (long long *)d_limbs, (int)n_containers, (int)n_bins, d_hist, d_sumw2,
-                           d_actual, total, d_status, d_metric_status, (int)clear_limbs);
+                           d_actual, total, d_status, d_metric_status, (int)clear_limbs, d_scale, d_extra);
     };
     switch (kind) {
     case PISA_HIP_METRIC_LLH: launch(finalize_metric_kernel<PISA_HIP_METRIC_LLH>); break;
@@ -931,6 +946,16 @@ PISA_API int pisa_hip_finalize_metric(int64_t *d_limbs, int32_t n_containers, in
     }
     PISA_CHECK_LAUNCH("finalize_metric_kernel");
     return PISA_HIP_OK;
+}
+
+PISA_API int pisa_hip_finalize_metric(int64_t *d_limbs, int32_t n_containers, int64_t n_bins,
+                                      double *d_hist, double *d_sumw2, int32_t kind,
+                                      const double *d_actual, double *total, int32_t *d_status,
+                                      int32_t *d_metric_status, int32_t clear_limbs,
+                                      void *stream) {
+    return pisa_hip_finalize_metric_scaled(d_limbs, n_containers, n_bins, d_hist, d_sumw2, kind, d_actual,
+                                           nullptr, nullptr, total, d_status, d_metric_status, clear_limbs,
+                                           stream);
 }
 
 PISA_API int pisa_hip_hist_finalize(const int64_t *d_limbs, int32_t n_containers, int64_t n_bins,

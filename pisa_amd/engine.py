@@ -537,6 +537,15 @@ class HotPathEngine:
         self.set_data(data_hist)
         self._data_src = np.array(data_hist, dtype=np.float64, copy=True)
 
+    def upload_extra(self, extra):
+        """[2, n_bins] host array (expectation and variance added to the template) -> device tensor;
+        re-uploaded only when the values changed"""
+        src = getattr(self, "_extra_src", None)
+        if src is None or src.shape != extra.shape or not np.array_equal(src, extra):
+            self._extra_d = K.to_device(np.ascontiguousarray(extra, dtype=np.float64))
+            self._extra_src = np.array(extra, dtype=np.float64, copy=True)
+        return self._extra_d
+
     # -- two-phase evaluation for callers that hand out maps before a metric is asked for ------
     def front(self, tables=None):
         """phase A: fused lookup + reweight + histogram (+ all-reduce) with the probability
@@ -569,10 +578,16 @@ class HotPathEngine:
         _lib.check(rc)
         self.allreduce()
 
-    def tail_host(self, kind):
-        """phase B: maps + metric against `self.data` of the accumulated limbs, value on the host"""
-        if (self.fused_tail and not self._maps_valid
-                and len(self.cont) * self.n_bins <= K.FINALIZE_METRIC_MAX):
+    def can_fuse_tail(self):
+        return (self.fused_tail and not self._maps_valid
+                and len(self.cont) * self.n_bins <= K.FINALIZE_METRIC_MAX)
+
+    def tail_host(self, kind, scale=None, extra=None):
+        """phase B: maps + metric against `self.data` of the accumulated limbs, value on the host.
+        `scale` [n_cont, n_bins] / `extra` [2, n_bins] (device tensors): per-bin factors of a stage after
+        the histogram and maps of other pipelines added to the template
+        (`pisa_hip_finalize_metric_scaled`); only with the fused tail (`can_fuse_tail()`)."""
+        if self.can_fuse_tail():
             import ctypes as C
 
             a = self._lean
@@ -580,9 +595,16 @@ class HotPathEngine:
                 a["data"], a["data_t"] = C.c_void_p(self.data.data_ptr()), self.data
             h = self._metric_host_np
             h[0] = np.nan
-            rc = a["lib"].pisa_hip_finalize_metric(a["limbs"], a["n_cont"], self.n_bins, a["hist"],
-                                                   a["sumw2"], K.METRIC_KIND[kind], a["data"], a["out"],
-                                                   a["status"], a["mstatus"], 1, K._stream())
+            if scale is None and extra is None:
+                rc = a["lib"].pisa_hip_finalize_metric(a["limbs"], a["n_cont"], self.n_bins, a["hist"],
+                                                       a["sumw2"], K.METRIC_KIND[kind], a["data"], a["out"],
+                                                       a["status"], a["mstatus"], 1, K._stream())
+            else:
+                rc = a["lib"].pisa_hip_finalize_metric_scaled(
+                    a["limbs"], a["n_cont"], self.n_bins, a["hist"], a["sumw2"], K.METRIC_KIND[kind], a["data"],
+                    None if scale is None else C.c_void_p(scale.data_ptr()),
+                    None if extra is None else C.c_void_p(extra.data_ptr()),
+                    a["out"], a["status"], a["mstatus"], 1, K._stream())
             self._limbs_zero = self._maps_valid = rc == 0
             _lib.check(rc)
             for _ in range(self.spin_wait):
@@ -590,6 +612,7 @@ class HotPathEngine:
                 if v == v:
                     return float(v)
         else:
+            assert scale is None and extra is None, "scaled tail needs the fused tail kernel"
             self._tail(kind, self.metric_host)
         torch.cuda.current_stream().synchronize()
         return float(self.metric_host[0])

@@ -179,6 +179,7 @@ class hist(Stage):  # pylint: disable=invalid-name
                                          node_flux=node_flux)
             self._engine_versions = [{k: c.version(k) for k in static_keys + (flux_key,)}
                                      for c in conts]
+            self._node_flux_src = (flux_key, cm) if node_flux else None
         eng = self._engine
         for i, (c, ch) in enumerate(zip(conts, chains)):
             c.representation = "events"
@@ -211,6 +212,21 @@ class hist(Stage):  # pylint: disable=invalid-name
                 c.set_mirrored("errors", both[1, i], both_h[1, i])
                 c.set_mirrored("bin_unc2", both[2, i], both_h[2, i])  # sum(1^2 * w), hist.py:207-209
         return True
+
+    def sync_node_flux(self):
+        """node-flux engine: hand over the flux of every container whose flux column was rewritten
+        since the engine saw it (used by the evaluation plan after it re-ran a flux stage)"""
+        key, cm = self._node_flux_src
+        eng = self._engine
+        for i, c in enumerate(self.data.containers):
+            if c.version(key) != self._engine_versions[i][key]:
+                keep = c.representation
+                c.representation = cm
+                try:
+                    eng.update_flux_nodes(i, c.device(key))
+                finally:
+                    c.representation = keep
+                self._engine_versions[i][key] = c.version(key)
 
     # ------------------------------------------------------------------ apply
     def apply_function(self):

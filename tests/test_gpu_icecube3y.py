@@ -301,3 +301,57 @@ def test_hypersurface_fit_file_with_uncertainty_propagation(oracle, tmp_path, mo
         np.testing.assert_allclose(m.hist.ravel(), np.clip(h * scale.ravel(), 0, np.inf), rtol=1e-10, atol=1e-300,
                                    err_msg=m.name)
         np.testing.assert_allclose(m.std_devs.ravel(), np.abs(h * sig.ravel()), rtol=1e-10, atol=1e-300, err_msg=m.name)
+
+
+def test_evaluation_plan_replays_the_published_analysis_chain(tmp_path, monkeypatch):
+    """The published 3-year template (neutrinos: csv_loader -> honda_ip -> barr_simple -> prob3 -> aeff
+    -> hist -> hypersurfaces; + muons) through `DistributionMaker.get_outputs(return_sum=True)` and
+    `Map.metric_total`: after the first evaluation the neutrino pipeline is replayed by the
+    evaluation plan (core/fastplan.py) -- flux stages on the grid nodes, oscillation, aeff scales,
+    hypersurface factors folded into the metric kernel, the muon map handed to it as an addend --
+    and gives, bit for bit, the maps, errors and metrics of the ordinary Stage protocol."""
+    from pisa_amd.core.distribution_maker import DistributionMaker
+    from pisa_amd.core.pipeline import Pipeline
+    from pisa_amd.core.units import ureg
+
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "make_synthetic_3y_mc.py"),
+                           str(tmp_path), "30000", "5"])
+    monkeypatch.setenv("PISA_RESOURCES", str(tmp_path))
+    cfgs = ["settings/pipeline/IceCube_3y_neutrinos.cfg", "settings/pipeline/IceCube_3y_muons.cfg"]
+    fast, slow = DistributionMaker(cfgs), DistributionMaker(cfgs)
+    for p in slow.pipelines:
+        p.fast_path = False
+    data = Pipeline("settings/pipeline/IceCube_3y_data.cfg").get_outputs()[0]
+    steps = [dict(),                                                       # first evaluation: stages
+             dict(theta23=44.0, deltam31=2.6e-3),                          # oscillation
+             dict(delta_index=0.04, nue_numu_ratio=1.03),                  # flux on the grid nodes
+             dict(opt_eff_overall=1.04, ice_absorption=-2.0),              # hypersurface factors
+             dict(aeff_scale=1.1, nu_nc_norm=0.9, nutau_norm=1.2),         # aeff scales
+             dict(atm_muon_scale=1.3),                                     # the other pipeline only
+             dict(theta23=48.0, delta_index=-0.02, opt_eff_lateral=18.0, atm_muon_scale=0.8, theta13=8.9),
+             dict()]                                                       # nothing moved
+    for k, moves in enumerate(steps):
+        got = []
+        for dm in (fast, slow):
+            for name, val in moves.items():
+                prm = dm.params[name]
+                prm.value = val * prm.value.units
+            total = dm.get_outputs(return_sum=True)[0]
+            if dm is fast and k > 0:
+                assert total._lazy is not None, "step %d: the template left the device" % k
+            metrics = [data.metric_total(expected_values=total, metric=kind) for kind in ("mod_chi2", "llh")]
+            if dm is fast and k > 0:
+                total = dm.get_outputs(return_sum=True)[0]   # (a metric consumes the device tail)
+            got.append((metrics, total.hist.copy(), total.std_devs.copy(),
+                        [(m.hist.copy(), m.std_devs.copy()) for m in dm.get_outputs()[0]]))
+        (mf, hf, ef, maps_f), (ms_, hs_, es_, maps_s) = got
+        assert mf == ms_, "step %d: metrics %r vs %r" % (k, mf, ms_)
+        np.testing.assert_array_equal(hf, hs_, err_msg="step %d" % k)
+        np.testing.assert_array_equal(ef, es_, err_msg="step %d" % k)
+        for (a, b), (c, d) in zip(maps_f, maps_s):
+            np.testing.assert_array_equal(a, c, err_msg="step %d" % k)
+            np.testing.assert_array_equal(b, d, err_msg="step %d" % k)
+    nu = fast.pipelines[0]
+    assert nu._plan is not None and nu._plan.flux_stages and nu._plan.post
+    assert nu["hist"]._engine.node_flux
+    assert np.isfinite(mf[0]) and mf[0] > 0
