@@ -132,6 +132,7 @@ class Pipeline:
         if hit is not None and hit[0] == ParamSet.struct_clock:
             return hit[1]
         params = ParamSet()
+        object.__setattr__(params, "_transient", True)   # a view: filling it changes no owned set
         for s in self._stages:
             params.update(s.params, existing_must_match=False, extend=True)
         self.__dict__["_params_cache"] = (ParamSet.struct_clock, params)
