@@ -41,7 +41,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB
 FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 L3_BYTES = 256 * 2 ** 20
 ALL_LEGS = ("l3_exceeding", "exact_association", "coordinate_form", "fine_binning", "update_flux", "node_flux",
-            "pipeline_boundary", "events_c2", "events_c5", "kde_c3")
+            "pipeline_boundary", "icecube3y_boundary", "events_c2", "events_c5", "kde_c3")
 
 
 def parse():
@@ -428,6 +428,68 @@ def leg_pipeline_boundary(torch, n_events, steps):
                            "x".join(str(n) for n in out_shape))}
 
 
+def leg_icecube3y(torch, n_events, steps):
+    """the published 3-year analysis through its own boundary: the unmodified cfgs
+    IceCube_3y_neutrinos.cfg (csv_loader -> honda_ip -> barr_simple -> prob3 -> aeff -> hist ->
+    hypersurfaces) + IceCube_3y_muons.cfg in a DistributionMaker, a synthetic stand-in for the MC file,
+    `get_outputs(return_sum=True)` + `Map.metric_total('mod_chi2')` against the released data histogram,
+    parameters set through `params[...]` every step"""
+    import subprocess
+    import tempfile
+
+    import numpy as np
+
+    tmp = tempfile.mkdtemp(prefix="pisa_hip_3y_")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "make_synthetic_3y_mc.py"), tmp,
+                           str(int(n_events)), "3"], stdout=subprocess.DEVNULL)
+    old = os.environ.get("PISA_RESOURCES")
+    os.environ["PISA_RESOURCES"] = tmp
+    try:
+        from pisa_amd.core.distribution_maker import DistributionMaker
+        from pisa_amd.core.pipeline import Pipeline
+
+        template = DistributionMaker(["settings/pipeline/IceCube_3y_neutrinos.cfg",
+                                      "settings/pipeline/IceCube_3y_muons.cfg"])
+        data = Pipeline("settings/pipeline/IceCube_3y_data.cfg").get_outputs()[0]
+        free = [p.name for p in template.params.free]
+        rs = np.random.RandomState(1)
+
+        def step(which):
+            for name in which:
+                p = template.params[name]
+                lo, hi = ((p.range[0].magnitude, p.range[1].magnitude) if p.range is not None
+                          else (p.value.magnitude * 0.9, p.value.magnitude * 1.1))
+                p.value = (p.nominal_value.magnitude + 0.05 * (hi - lo) * (rs.rand() - 0.5)) * p.value.units
+            total = template.get_outputs(return_sum=True)[0]
+            return data.metric_total(expected_values=total, metric="mod_chi2")
+
+        out = {"events": int(n_events), "free_parameters": free}
+        osc = [f for f in free if f in ("theta23", "deltam31", "theta13")]
+        for key, which in (("all_free", free), ("osc_only", osc)):
+            for _ in range(3):
+                step(which)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                val = step(which)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            out[key] = {"evals_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "last_mod_chi2": val}
+        nu = template.pipelines[0]
+        out["plan"] = bool(nu._plan is not None)
+        out["node_flux"] = bool(nu["hist"]._engine.node_flux)
+        out["workload"] = ("DistributionMaker(IceCube_3y_neutrinos.cfg + IceCube_3y_muons.cfg, unmodified) on %d "
+                           "synthetic MC events; every step moves the listed parameters (oscillation, Barr flux, "
+                           "aeff norms, hypersurface detector systematics, muon scale), sums the 13 maps and "
+                           "evaluates mod_chi2 against the released data histogram" % int(n_events))
+        return out
+    finally:
+        if old is None:
+            os.environ.pop("PISA_RESOURCES", None)
+        else:
+            os.environ["PISA_RESOURCES"] = old
+
+
 def leg_events(synthetic, torch, n_events, steps, nsi):
     """configs C2 / C5 (per-GPU share): prob3 EVENT BY EVENT (layers rebuilt per event in-kernel from the
     PREM table in LDS) + fused reweight + 10x10 histogram + LLH"""
@@ -690,6 +752,8 @@ def main():
                 legs[name] = leg_node_flux(synthetic, torch, args, n_e, n_cz, leg_steps)
             elif name == "pipeline_boundary":
                 legs[name] = leg_pipeline_boundary(torch, args.events, leg_steps)
+            elif name == "icecube3y_boundary":
+                legs[name] = leg_icecube3y(torch, 2e5, leg_steps)
             elif name == "events_c2":
                 legs[name] = leg_events(synthetic, torch, 1e6, 20, nsi=False)
             elif name == "events_c5":

@@ -220,14 +220,13 @@ class FastPlan:
 
     def _read_scales(self):
         """the post-histogram stage's per-bin factors, [n_cont, n_bins] on the device"""
-        import torch
-
         hs = self.post[0]
         keep = [c.representation for c in self._conts]
         try:
             for c in self._conts:
                 c.representation = hs.calc_mode
-            return torch.stack([c.device("hs_scales") for c in self._conts]).contiguous()
+            # the stage computes the factors on the host: one upload for all containers
+            return K.to_device(np.stack([np.asarray(c["hs_scales"], dtype=np.float64) for c in self._conts]))
         finally:
             for c, r in zip(self._conts, keep):
                 c.representation = r
