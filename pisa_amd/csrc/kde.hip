@@ -594,9 +594,6 @@ kde_lattice_kernel(const KdeLattice L, double rcut2, const double *__restrict__ 
             const double dn = fmax(fmax(xc - ext_lo, -(xc + ext_hi)), 0.0);   // nearest point of the strip
             const bool in = live && (dbb * dbb + dn * dn) * sh * -2.0 <= rcut2;
             if (__builtin_amdgcn_ballot_w64(in)) {
-#ifdef KDE_LATTICE_DEBUG
-                if (threadIdx.x == 0) atomicAdd(pair_count + 1, 1ULL);
-#endif
                 if (in) {
                     strips++;
                     const double gc = cf * exp_nonpos(sh * __builtin_fma(xc, xc, dbb * dbb));
@@ -620,9 +617,6 @@ kde_lattice_kernel(const KdeLattice L, double rcut2, const double *__restrict__ 
             }
             sya = n0; syb = n1; cf = n2; sh = n3; q = n4; shd2 = n5;
         }
-#ifdef KDE_LATTICE_DEBUG
-        if (threadIdx.x == 0) atomicAdd(pair_count + 2, (unsigned long long)(k1 - k0));
-#endif
     }
     if (live) {
         double *out = partial + (int64_t)blockIdx.y * R * n_strips + sid;
@@ -1756,13 +1750,6 @@ PISA_API int pisa_hip_kde_evaluate_lattice(pisa_hip_kde *k, const double *h_orig
     PISA_CHECK_LAUNCH("kde lattice kernels");
     PISA_TRY_HIP(hipMemcpyAsync(&k->pairs_eval, k->pair_count, sizeof(unsigned long long),
                                 hipMemcpyDeviceToHost, s));
-#ifdef KDE_LATTICE_DEBUG
-    unsigned long long dbg[3];
-    PISA_TRY_HIP(hipMemcpyAsync(dbg, k->pair_count, sizeof(dbg), hipMemcpyDeviceToHost, s));
-    PISA_TRY_HIP(hipStreamSynchronize(s));
-    fprintf(stderr, "lattice R=%d strips=%lld blocks=%u shares=%d: lane-iterations %llu, executing wave-iterations %llu (%.1f lanes), loop iterations %llu\n",
-            R, (long long)n_strips, grid.x, n_split, dbg[0] / R, dbg[1], (double)(dbg[0] / R) / (double)(dbg[1] ? dbg[1] : 1), dbg[2]);
-#endif
     PISA_TRY_HIP(hipStreamSynchronize(s));
     PISA_TRY_HIP(hipMemsetAsync(k->pair_count, 0, 64, s));
     return PISA_HIP_OK;
