@@ -304,3 +304,64 @@ def test_prob3_tomography_follows_the_reference_call_for_call(oracle, tmp_path):
             Pipeline(_cfg_with(tmp_path, ["tomography_type = nonsense"], name="bad2.cfg"))
     finally:
         del os.environ["PISA_RESOURCES"]
+
+
+def test_reduced_form_against_reference_order_over_random_parameters():
+    """The planned grid kernels and the event-mode kernel form the layer matrices from the
+    Hermitian mass-basis matrix (eigenvalues from ITS invariants, projectors as two real and three
+    complex entries); the one-kernel grid form follows the reference operation for operation.
+    120 random parameter points -- mixing angles anywhere, both orderings, small and near-degenerate
+    mass splittings, random Hermitian NSI potentials, LRI potentials, 0.1 GeV to 10 TeV -- must
+    agree to rounding on every probability."""
+    from pisa_amd import _lib as L
+    from pisa_amd import kernels as K
+    from pisa_amd.stages.osc.layers import Layers
+    from pisa_amd.stages.osc.osc_params import OscParams
+
+    lay = Layers("osc/PREM_12layer.dat", 2.0, 20.0)
+    lay.setElecFrac(0.4656, 0.4656, 0.4957)
+    cz = np.linspace(-1.0, 1.0, 24)
+    lay.calcLayers(cz)
+    _, dens, dist = lay.device_arrays
+    plan = K.GridPlan(dens, dist)
+    energy = np.logspace(-1, 4, 70)
+    e_d = K.to_device(energy)
+    earth = lay.earth_struct()
+    ee, cc = np.meshgrid(energy, cz, indexing="ij")
+    ev_e, ev_cz = K.to_device(ee.ravel()), K.to_device(cc.ravel())
+    rs = np.random.RandomState(77)
+    worst = 0.0
+    # the reference's own prob3 tolerance (numba_osc_tests.py:82, rtol 1e-10 on probabilities <= 1);
+    # typical differences are 1e-13, the largest (2e-11) at near-degenerate splittings and TeV
+    # energies, where the eigenvalue differences in the denominators are ill conditioned in either form
+    GATE = 1e-10
+    for k in range(120):
+        o = OscParams()
+        o.theta12, o.theta13, o.theta23 = rs.rand(3) * np.pi / 2
+        o.deltacp = rs.rand() * 2 * np.pi
+        o.dm21 = 10 ** rs.uniform(-6, -3.5)
+        o.dm31 = (1 if rs.rand() < 0.5 else -1) * 10 ** rs.uniform(-3.3, -2.2)
+        mat_pot = np.diag([1.0, 0.0, 0.0]).astype(np.complex128)
+        if k % 3 == 1:                        # Hermitian NSI
+            a = (rs.randn(3, 3) + 1j * rs.randn(3, 3)) * 0.2
+            mat_pot = mat_pot + (a + a.conj().T) / 2
+        lri = np.zeros((3, 3))
+        if k % 3 == 2:                        # long-range potential (real symmetric, eV)
+            b = rs.randn(3, 3) * 1e-13
+            lri = (b + b.T) / 2
+        p = L.make_prob3_params(o.dm_matrix, o.mix_matrix_complex, mat_pot, -1, np.zeros((3, 3), np.complex128), lri)
+        nu, nubar = K.prob3_grid(p, e_d, dens, dist, e_major=True)[:2]
+        nu2, nubar2, _ = K.prob3_grid_planned(p, plan, e_d, e_major=True)
+        for a_, b_ in ((nu, nu2), (nubar, nubar2)):
+            d = float((a_ - b_).abs().max())
+            worst = max(worst, d)
+            assert d < GATE, (k, d)
+        # event mode at the same nodes (its own path geometry, same reduced form)
+        for nubar_sign, ref in ((1, nu), (-1, nubar)):
+            got = K.prob3_events(p, earth, nubar_sign, ev_e, ev_cz)
+            d = float((got - ref).abs().max())
+            worst = max(worst, d)
+            assert d < GATE, (k, nubar_sign, d)
+        rows = (nu2.sum(dim=2) - 1.0).abs().max()          # unitarity of every row
+        assert float(rows) < 1e-11
+    assert worst < GATE
