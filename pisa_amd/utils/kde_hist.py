@@ -70,6 +70,43 @@ class gaussian_kde:  # pylint: disable=invalid-name
     pairs = property(lambda self: (self._est.pairs_pilot, self._est.pairs_eval))
 
 
+_GRIDS = {}
+
+
+def _evaluation_grid(binning, oversample, coszen_name, coszen_reflection):
+    """everything of `get_hist` that depends on the binning alone (kde_hist.py:82-102, 122-150):
+    the oversampled binning with coszen first, the evaluation axes with the reflected coszen
+    points, shapes and bin volumes.  Kept per binning: a fit evaluates the same maps every step."""
+    key = (hash(binning), int(oversample), coszen_name, float(coszen_reflection))
+    hit = _GRIDS.get(key)
+    if hit is not None:
+        return hit
+    over = binning.oversample(oversample)
+    cz_bin = over.index(coszen_name)
+    if cz_bin != 0:
+        over = MultiDimBinning([over[coszen_name]] + [b for b in over if b.name != coszen_name])
+    edges = over[coszen_name].edge_magnitudes
+    reflect_lower, reflect_upper = edges[0] == -1, edges[-1] == 1
+    bin_points, l = [], 0
+    for b in over:
+        c = np.asarray(b.weighted_centers.magnitude)
+        if b.name == coszen_name:
+            l = int(len(c) * float(coszen_reflection))
+            c0 = 2 * c[0] - c[1: l + 1][::-1] if reflect_lower else []
+            c1 = 2 * c[-1] - c[-l - 1: -1][::-1] if reflect_upper else []
+            c = np.concatenate([c0, c, c1])
+        bin_points.append(c)
+    hit = dict(binning=over, cz_bin=cz_bin, reflect_lower=reflect_lower, reflect_upper=reflect_upper, l=l,
+               bin_points=bin_points,
+               megashape=(over.shape[0] + (int(reflect_upper) + int(reflect_lower)) * l, over.shape[1]),
+               minishape=(over.shape[0] - l, over.shape[1]),
+               n_points=int(np.prod([len(c) for c in bin_points])),
+               volumes=over.bin_volumes(attach_units=False),
+               reduce_at=[np.arange(0, b.num_bins, oversample) for b in over])
+    _GRIDS[key] = hit
+    return hit
+
+
 def get_hist(sample, binning, weights=None, bw_method="scott", adaptive=True, alpha=0.3,
              use_cuda=False, coszen_reflection=0.25, coszen_name="coszen", oversample=1,
              bootstrap=False, bootstrap_niter=10, tol=None, stats=None):
@@ -85,51 +122,34 @@ def get_hist(sample, binning, weights=None, bw_method="scott", adaptive=True, al
     else:
         weights_d = torch.nan_to_num(weights if torch.is_tensor(weights) else K.to_device(np.asarray(weights)))
         norm = float(weights_d.sum())
-    binning = binning.oversample(oversample)
+    g = _evaluation_grid(binning, oversample, coszen_name, coszen_reflection)
     x = (sample.T if on_dev else K.to_device(np.ascontiguousarray(np.asarray(sample).T))).clone()
-    assert x.shape[0] == len(binning)
-    cz_bin = binning.index(coszen_name)
+    assert x.shape[0] == len(g["binning"])
+    cz_bin, l = g["cz_bin"], g["l"]
     if cz_bin != 0:
-        binning = MultiDimBinning([binning[coszen_name]] + [b for b in binning if b.name != coszen_name])
         x[[0, cz_bin]] = x[[cz_bin, 0]]
-    edges = binning[coszen_name].edge_magnitudes
-    reflect_lower = edges[0] == -1
-    reflect_upper = edges[-1] == 1
     kernel = gaussian_kde(x.contiguous(), weights=weights_d, bw_method=bw_method, adaptive=adaptive,
                           alpha=alpha, tol=tol)
-    bin_points = []
-    l = 0
-    for b in binning:
-        c = np.asarray(b.weighted_centers.magnitude)
-        if b.name == coszen_name:
-            l = int(len(c) * float(coszen_reflection))
-            c0 = 2 * c[0] - c[1: l + 1][::-1] if reflect_lower else []
-            c1 = 2 * c[-1] - c[-l - 1: -1][::-1] if reflect_upper else []
-            c = np.concatenate([c0, c, c1])
-        bin_points.append(c)
-    megashape = (binning.shape[0] + (int(reflect_upper) + int(reflect_lower)) * l, binning.shape[1])
-    minishape = (binning.shape[0] - l, binning.shape[1])
-    n_points = int(np.prod([len(c) for c in bin_points]))
-    hist = kernel.evaluate_grid(bin_points).cpu().numpy().reshape(megashape)
+    hist = kernel.evaluate_grid(g["bin_points"]).cpu().numpy().reshape(g["megashape"])
     if stats is not None:
         stats["pairs_pilot"] = stats.get("pairs_pilot", 0) + kernel.pairs[0]
         stats["pairs_eval"] = stats.get("pairs_eval", 0) + kernel.pairs[1]
-        stats["all_pairs"] = stats.get("all_pairs", 0) + kernel.n * (kernel.n * bool(adaptive) + n_points)
-    if reflect_lower:
-        hist0 = np.flipud(np.concatenate([np.zeros(minishape), hist[0:l, :]]))
+        stats["all_pairs"] = stats.get("all_pairs", 0) + kernel.n * (kernel.n * bool(adaptive) + g["n_points"])
+    if g["reflect_lower"]:
+        hist0 = np.flipud(np.concatenate([np.zeros(g["minishape"]), hist[0:l, :]]))
         hist = hist[l:, :]
     else:
         hist0 = 0
-    if reflect_upper:
-        hist1 = np.flipud(np.concatenate([hist[-l:, :], np.zeros(minishape)]))
+    if g["reflect_upper"]:
+        hist1 = np.flipud(np.concatenate([hist[-l:, :], np.zeros(g["minishape"])]))
         hist = hist[:-l, :]
     else:
         hist1 = 0
     hist = hist + hist1 + hist0
-    hist = hist * binning.bin_volumes(attach_units=False)
+    hist = hist * g["volumes"]
     if oversample != 1:
-        for i, b in enumerate(binning):
-            hist = np.add.reduceat(hist, np.arange(0, b.num_bins, oversample), axis=i)
+        for i, at in enumerate(g["reduce_at"]):
+            hist = np.add.reduceat(hist, at, axis=i)
     if cz_bin != 0:
         hist = np.swapaxes(hist, 0, cz_bin)
     return hist * norm
