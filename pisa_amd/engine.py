@@ -591,6 +591,15 @@ class HotPathEngine:
             import ctypes as C
 
             a = self._lean
+            if a is None:   # first use without `front` / `eval_host` having built the argument block
+                lib = _lib.lib()
+                a = object()   # matches no table: `front` / `_lean_eval` build their full block
+                a = self._lean = dict(
+                    front_pepmu=a, tabs=a, lib=lib, cont=self._cont_arr, n_cont=len(self._cont_arr),
+                    limbs=C.c_void_p(self.ws.limbs.data_ptr()), status=C.c_void_p(self.ws.status.data_ptr()),
+                    hist=C.c_void_p(self.ws.hist.data_ptr()), sumw2=C.c_void_p(self.ws.sumw2.data_ptr()),
+                    data=None, data_t=None, out=C.c_void_p(self.metric_host.data_ptr()),
+                    mstatus=C.c_void_p(self.metric_status.data_ptr()))
             if a["data_t"] is not self.data:
                 a["data"], a["data_t"] = C.c_void_p(self.data.data_ptr()), self.data
             h = self._metric_host_np

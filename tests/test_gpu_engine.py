@@ -442,3 +442,46 @@ def test_rccl_limb_allreduce_two_ranks(tmp_path):
     want = np.concatenate([vals, h.ravel(), s2.ravel()])
     for r in range(2):
         np.testing.assert_array_equal(np.load(str(tmp_path / ("rank%d.npy" % r))), want)
+
+
+def test_scaled_tail_kernel_matches_host_scaling(oracle):
+    """`pisa_hip_finalize_metric_scaled`: per-(container, bin) factors of a stage behind the histogram
+    (hypersurfaces.py:251-259: weights = clip(weights s, 0, inf), errors *= s) and an added map enter
+    the metric inside the tail kernel.  Same value as the oracle metric of the host-scaled maps; the
+    maps themselves are written unscaled; without factors and addend it is the plain tail, bit for bit."""
+    import torch
+
+    from pisa_amd import kernels as K
+    from pisa_amd import synthetic
+
+    wl = synthetic.Workload(n_events=60000, grid=(40, 30), out_binning="dragon", seed=4)
+    st = synthetic.DeviceState(wl, compact=True)
+    p = wl.osc_params(theta23_deg=44.0)
+    st.make_pseudo_data(wl.osc_params(), seed=1)
+    data = st.data.cpu().numpy()
+    rs = np.random.RandomState(3)
+    n_cont, n_bins = len(st.cont), st.n_bins
+    scale = 1.0 + 0.3 * rs.randn(n_cont, n_bins)
+    scale[0, :5] = -0.2                                  # negative factors: the weights clip at zero
+    extra = np.stack([rs.rand(n_bins) * 5.0, rs.rand(n_bins) * 2.0])
+    scale_d, extra_d = K.to_device(scale), K.to_device(extra)
+    st.accumulate(p)
+    hist, sumw2 = (t.cpu().numpy() for t in st.finalize())
+    lam = np.clip(hist * scale, 0, np.inf).sum(axis=0) + extra[0]
+    var = ((np.sqrt(sumw2) * scale) ** 2).sum(axis=0) + extra[1]
+    for kind in ("llh", "poisson_llh", "chi2", "mod_chi2"):
+        st.accumulate(p)
+        got = st.tail_host(kind, scale_d, extra_d)
+        _, want = oracle.metric(kind, data, lam, var)
+        np.testing.assert_allclose(got, want, rtol=1e-12, err_msg=kind)
+        h2, s2 = (t.cpu().numpy() for t in (st.ws.hist, st.ws.sumw2))
+        assert np.array_equal(h2, hist) and np.array_equal(s2, sumw2)      # maps as histogrammed
+        st.accumulate(p)
+        plain = st.tail_host(kind)
+        st.accumulate(p)
+        assert st.tail_host(kind, None, None) == plain
+        st.accumulate(p)
+        only_extra = st.tail_host(kind, None, extra_d)
+        _, want2 = oracle.metric(kind, data, hist.sum(axis=0) + extra[0], sumw2.sum(axis=0) + extra[1])
+        np.testing.assert_allclose(only_extra, want2, rtol=1e-12, err_msg=kind)
+    st.check_status()
