@@ -1652,7 +1652,8 @@ PISA_API int pisa_hip_kde_evaluate(pisa_hip_kde *k, const double *d_qry, int64_t
 // ---- evaluation on a lattice of points  x[d] = origin[d] + i_d step[d],  0 <= i_d < count[d],
 //      out[(i_0 n_1 + i_1) n_2 + i_2]  (numpy.meshgrid(indexing="ij") order)
 static int lattice_strip(const pisa_hip_kde *k, const double *step, const int64_t *count) {
-    if (k->dim != 2 || !(k->g.rcut2 > 0.0) || count[0] * count[1] > 0x7FFFFFF0LL) return 0;
+    // (rcut2 <= 138, i.e. tol >= 1e-30: the strip's middle value must stay a normal number, see the kernel)
+    if (k->dim != 2 || !(k->g.rcut2 > 0.0) || k->g.rcut2 > 138.0 || count[0] * count[1] > 0x7FFFFFF0LL) return 0;
     const double da = k->g.U[0] * step[0];
     if (!(da > 0.0) || !std::isfinite(da) || !(k->s2_range[1] > 0.0)) return 0;
     static const int forced = [] { const char *v = getenv("PISA_HIP_KDE_LATTICE_R"); return v ? atoi(v) : -1; }();
