@@ -486,3 +486,63 @@ def test_profile_hook_is_per_host_thread():
     K.histogram_regular([x], w, b)         # disabled: the pair keeps its last recording
     torch.cuda.synchronize()
     assert start.elapsed_time(stop) == dt
+
+
+def test_limb_decoder_is_correctly_rounded_on_adversarial_accumulators(K, L):
+    """`hist_finalize_kernel` / the tail kernel decode an accumulator (six un-normalised int64 limbs,
+    value = sum limb_j 2^(32 j - 116)) with ONE rounding to nearest-even.  Checked against exact
+    rational arithmetic on accumulators built to hurt: negative and mixed-sign limbs, carries that
+    ripple through every limb, values exactly halfway between two doubles (ties to even, both
+    directions, with and without a sticky bit far below), single bits at either end of the range,
+    zero, and random fills of every magnitude."""
+    import torch
+
+    from pisa_amd.engine import limbs_to_float
+
+    rs = np.random.RandomState(9)
+    cases = []
+    cases.append([0] * 6)
+    cases.append([1, 0, 0, 0, 0, 0])                     # 2^-116
+    cases.append([-1, 0, 0, 0, 0, 0])
+    cases.append([0, 0, 0, 0, 0, 1 << 30])               # near the top of the range
+    cases.append([0, 0, 0, 0, 0, -(1 << 30)])
+    cases.append([0xFFFFFFFF] * 5 + [0])                 # carries everywhere
+    cases.append([-0xFFFFFFFF] * 5 + [1])                # borrows everywhere
+    cases.append([(1 << 62) - 1] * 6)                    # heavily un-normalised sums
+    cases.append([-(1 << 62)] * 5 + [1 << 20])
+    # ties: a 54-bit pattern whose lowest bit is exactly half an ulp, placed at several offsets
+    for shift in (0, 5, 31, 32, 40, 63, 64, 77, 100):
+        for mant in ((1 << 53) | 1, (1 << 53) | 3, (1 << 54) - 1, (1 << 53) + 2 + 1):
+            for sticky in (0, 1):
+                for sign in (1, -1):
+                    total = sign * ((mant << (shift + 1)) + (sticky if shift > 0 else 0))
+                    limbs, t = [], total
+                    for _ in range(5):
+                        limbs.append(t & 0xFFFFFFFF)
+                        t >>= 32
+                    limbs.append(t)
+                    if abs(limbs[5]) < (1 << 62):
+                        cases.append(limbs)
+    for _ in range(3000):
+        bits = rs.randint(1, 63, size=6)
+        vals = [int(rs.randint(0, 2 ** 31)) << 31 | int(rs.randint(0, 2 ** 31)) for _ in range(6)]
+        limbs = [(v & ((1 << int(b)) - 1)) * (1 if rs.rand() < 0.6 else -1) for v, b in zip(vals, bits)]
+        if rs.rand() < 0.3:
+            for k in rs.choice(6, size=rs.randint(1, 5), replace=False):
+                limbs[k] = 0
+        cases.append(limbs)
+    n = len(cases)
+    want = np.array([limbs_to_float(c) for c in cases])
+    ok = np.isfinite(want) & (np.abs(want) < 2.0 ** 139)     # inside the decoder's range (7 x 32 - 116 + ...)
+    ws = K.HistWorkspace(1, n)
+    arr = np.zeros((1, n, 2, 6), dtype=np.int64)
+    arr[0, :, 0, :] = np.array(cases, dtype=object).astype(np.int64)
+    arr[0, :, 1, :] = arr[0, ::-1, 0, :]                     # the second quantity: the same cases reversed
+    ws.limbs.copy_(torch.from_numpy(arr))
+    hist, sumw2 = K.hist_finalize(ws)
+    got, got2 = hist.cpu().numpy()[0], sumw2.cpu().numpy()[0]
+    bad = np.nonzero(ok & (got != want))[0]
+    assert bad.size == 0, [(cases[i], got[i], want[i]) for i in bad[:5]]
+    bad2 = np.nonzero(ok[::-1] & (got2 != want[::-1]))[0]
+    assert bad2.size == 0
+    assert ok.sum() > 3000
