@@ -515,25 +515,28 @@ __device__ __forceinline__ double limbs_to_double(const long long *in, bool &ovf
         L[NL] = ~L[NL] + c2;
     }
     if (L[NL] != 0) ovf = true;
-    int t = -1;
-#pragma unroll
-    for (int k = 0; k <= NL; k++)
-        if (L[k] != 0) t = k;
-    if (t < 0) return 0.0;
-    unsigned long long hi = (unsigned long long)L[t];
-    unsigned long long mid = t >= 1 ? (unsigned long long)L[t - 1] : 0ULL;
-    unsigned long long low = t >= 2 ? (unsigned long long)L[t - 2] : 0ULL;
-    bool sticky = false;
-    for (int k = 0; k + 3 <= t; k++) sticky = sticky || (L[k] != 0);
-    // value = (hi*2^64 + mid*2^32 + low) * 2^(32*(t-2) - FX_LSB)
-    int hb = 64 - __clzll(hi);  // significant bits of hi (>= 1)
-    unsigned long long ml = (mid << 32) | low;
-    unsigned long long top, lost;
-    if (hb >= 64) { top = hi; lost = ml; }
-    else { top = (hi << (64 - hb)) | (ml >> hb); lost = ml << (64 - hb); }
-    if (lost != 0 || sticky) top |= 1ULL;  // sticky bit sits below the rounding position
-    double d = (double)top;                 // u64 -> f64 is round-to-nearest-even
-    d = ldexp(d, hb + 32 * (t - 2) - FX_LSB);
+    // the NL digits as three 64-bit words; the highest non-zero word and the two below it, shifted so
+    // that the value's leading bit is bit 63 of `top`: 64 significant bits and a sticky bit for the rest
+    // (no indexing of the digit array with a run-time index: that costs a select chain per access)
+    static_assert(NL == 6, "three 64-bit words");
+    const unsigned long long w0 = (unsigned long long)L[0] | ((unsigned long long)L[1] << 32);
+    const unsigned long long w1 = (unsigned long long)L[2] | ((unsigned long long)L[3] << 32);
+    const unsigned long long w2 = (unsigned long long)L[4] | ((unsigned long long)L[5] << 32);
+    if ((w0 | w1 | w2) == 0ULL) return 0.0;
+    unsigned long long a_, b_, c_;
+    int base;
+    if (w2) { a_ = w2; b_ = w1; c_ = w0; base = 128; }
+    else if (w1) { a_ = w1; b_ = w0; c_ = 0ULL; base = 64; }
+    else { a_ = w0; b_ = 0ULL; c_ = 0ULL; base = 0; }
+    const int s_ = __clzll(a_);   // 0 .. 63
+    unsigned long long top = a_, lost = b_ | c_;
+    if (s_) {
+        top = (a_ << s_) | (b_ >> (64 - s_));
+        lost = (b_ << s_) | c_;   // (only whether anything is left matters)
+    }
+    if (lost != 0ULL) top |= 1ULL;   // sticky bit: sits below the rounding position (bit 11 of `top`)
+    double d = (double)top;           // u64 -> f64 is round-to-nearest-even
+    d = ldexp(d, base - s_ - FX_LSB);
     return neg ? -d : d;
 }
 
