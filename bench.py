@@ -23,9 +23,11 @@ is measured in the same run and reported as `weak_value`.
 
 Prints ONE JSON line on rank 0.  Besides the headline it carries, at N = 1, the `legs`:
 bounded extra measurements of the same hot path (larger-than-L3 sample, the reference-order and
-the coordinate-form kernels, flux systematics moving every evaluation, the evaluation through
-the Pipeline/cfg boundary, event-by-event oscillation for configs C2 / C5, the KDE stage for
-config C3) and the CPU baseline at one thread and at all cores.
+the coordinate-form kernels, a 4 800-bin output binning, flux systematics moving every evaluation
+with the flux per event and on the oscillation grid, the evaluation through the Pipeline/cfg
+boundary, the published IceCube 3-year analysis through DistributionMaker / metric_total,
+event-by-event oscillation for configs C2 / C5, the KDE stage for config C3) and the CPU baseline
+at one thread and at all cores.
 """
 import argparse
 import json
