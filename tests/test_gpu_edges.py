@@ -160,3 +160,57 @@ def test_container_map_to_map_resampling():
     e.representation = other
     with pytest.raises(ValueError):
         e["prob"]
+
+
+def test_node_flux_engine_empty_ragged_and_out_of_grid(oracle):
+    """flux on the oscillation grid (`node_flux`) with the awkward inputs of the test above: an empty
+    container, a one-event container, NaN / out-of-range coordinates (outside the grid both the flux
+    and the probabilities look up as zero, container.py:981-1012), and two shards of the events.
+    Reference: the oracle chain fed with the flux looked up at every event's node."""
+    from oracle.pipeline_oracle import oracle_eval
+    from pisa_amd import kernels as K
+    from pisa_amd import synthetic
+
+    wl = synthetic.Workload(n_events=12 * 701, grid=(16, 12), out_binning="dragon", seed=19)
+    ev, g = wl.events, wl.grid
+    for k in ("true_energy", "true_coszen", "nu_flux", "weighted_aeff", "initial_weights"):
+        ev[0][k] = ev[0][k][:0]
+        ev[1][k] = ev[1][k][:1]
+    ev[0]["sample"] = [s[:0] for s in ev[0]["sample"]]
+    ev[1]["sample"] = [s[:1] for s in ev[1]["sample"]]
+    ev[3]["true_coszen"][:5] = [np.nan, 1.0, -1.0, 2.0, -3.0]
+    ev[3]["true_energy"][5:8] = [0.5, 1000.0, 1e5]
+    ev[3]["sample"][0][8:10] = [np.nan, np.inf]
+    rs = np.random.RandomState(4)
+    ee, cc = np.meshgrid(g.energy, g.coszen, indexing="ij")
+    for e in ev:
+        fn = np.stack([1e4 * ee ** -2.7 * (0.6 + rs.rand(*ee.shape)), 2e4 * ee ** -2.6 * (1 + 0.3 * cc)],
+                      axis=-1).reshape(-1, 2)
+        e["nu_flux_nodes"] = fn
+        n = len(e["true_energy"])
+        if n:
+            with np.errstate(invalid="ignore", divide="ignore"):
+                gx, gy = K.to_device(np.log(e["true_energy"])), K.to_device(e["true_coszen"])
+            node = K.event_indices([gx, gy], g.binning).cpu().numpy()
+            e["nu_flux"] = np.where(node[:, None] >= 0, fn[np.maximum(node, 0)], 0.0)   # lookup: 0 outside
+        else:
+            e["nu_flux"] = np.zeros((0, 2))
+    st = synthetic.DeviceState(wl, compact=True, node_flux=True)
+    st.accumulate(wl.osc_params())
+    ref = oracle_eval(wl)   # (uses the matrices of the last wl.osc_params() call: nominal)
+    st.finalize()
+    st.check_status()
+    hist, sumw2 = st.maps()
+    assert np.all(hist[0] == 0) and hist[3].sum() > 0
+    np.testing.assert_allclose(hist, ref["hist"], rtol=1e-11, atol=1e-300)
+    np.testing.assert_allclose(sumw2, ref["sumw2"], rtol=1e-11, atol=1e-300)
+    # shards of the events: integer limbs add up to the same maps
+    p = wl.osc_params(theta23_deg=47.0)
+    parts = []
+    for rank in (0, 1):
+        sh = synthetic.DeviceState(wl, rank=rank, world_size=2, compact=True, node_flux=True)
+        sh.accumulate(p)
+        parts.append(sh.ws.limbs.clone())
+    one = synthetic.DeviceState(wl, compact=True, node_flux=True)
+    one.accumulate(p)
+    assert bool((parts[0] + parts[1] == one.ws.limbs).all())
