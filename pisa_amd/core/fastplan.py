@@ -3,18 +3,26 @@
 `Pipeline.get_outputs()` of the reference runs every stage's `compute()` / `apply()` on host
 arrays (pisa/core/pipeline.py:537-558, stage.py:536-586).  This build's stages do the same through
 device columns and deferred operations -- ~6 000 Python calls, 0.8 ms per evaluation -- although,
-for the chain  loader -> [flux ...] -> osc.prob3 (2-D calc grid) -> aeff.aeff -> utils.hist,  an
-evaluation in which only oscillation / aeff parameters moved is three kernel launches.
+for the chain
+    loader -> [flux ...] -> osc.prob3 (2-D calc grid) -> aeff.aeff -> utils.hist [-> discr_sys.hypersurfaces]
+an evaluation is a handful of kernel launches.
 
 After one ordinary evaluation that took the fused path, `FastPlan` replays exactly those
 launches: it compares the parameter change counters (`Param.clock`, `Param._ver`) with what it
-saw last, rebuilds the prob3 matrices through the stage's own `_matrices()`, refreshes the aeff
-scales through the stage's own `scale_for()`, launches the planned prob3 kernels and the fused
-kernel, and hands out device-backed Maps (`DeviceMapBlock`).  Anything else -- a flux or loader
-parameter moved, a Ye value moved, another output key or binning is asked for, profiling is on,
-somebody reads `pipeline.data` -- goes through the ordinary Stage protocol, which stays the
-source of truth (the plan is rebuilt afterwards).  The bypassed stages' compute memos are
-invalidated, so the ordinary path never trusts tables the plan has overwritten.
+saw last and, per stage that moved,
+  * osc.prob3: rebuilds the matrices through the stage's own `_matrices()` and launches the planned
+    prob3 kernels;
+  * aeff.aeff: refreshes the containers' scales through the stage's own `scale_for()`;
+  * flux stages, when the flux lives on the oscillation grid (engine.node_flux): runs the moved
+    stage(s) on the grid nodes and hands the new node fluxes to the engine (`hist.sync_node_flux`);
+  * discr_sys.hypersurfaces behind the histogram: runs its `compute()` (per-bin factors on the
+    host) and passes the factors to the tail kernel (`pisa_hip_finalize_metric_scaled`);
+then launches the fused kernel and hands out device-backed Maps (`DeviceMapBlock`).  Anything else
+-- a loader parameter or a per-event flux moved, a Ye value moved, another output key or binning is
+asked for, profiling is on, somebody wrote one of the pipeline's containers or reads `pipeline.data`
+-- goes through the ordinary Stage protocol, which stays the source of truth (the plan is rebuilt
+afterwards).  The bypassed stages' compute memos are invalidated, so the ordinary path never trusts
+tables the plan has overwritten.  `PISA_PLAN_DEBUG=1` prints why an evaluation was not replayed.
 """
 import ctypes as C
 import os
