@@ -396,3 +396,38 @@ def test_hypersurface_forms_state_roundtrip_and_uncertainty(tmp_path):
     assert np.abs(f1 - got).max() > 0
     with pytest.raises(ValueError):
         Hypersurface(b, [params[0]], icpt).evaluate(dict(dom_eff=1.0), return_uncertainty=True)
+
+
+def test_param_views_are_cached_and_do_not_count_as_structural_changes():
+    """`Pipeline.params` / `DistributionMaker.params` are merged VIEWS of the stages' own sets: asking
+    for them must not move `ParamSet.struct_clock` (evaluation plans and the other pipelines' views
+    key on it), they are rebuilt only after a real structural change, and a set's name index follows
+    extend / replace / update."""
+    from pisa_amd.core.distribution_maker import DistributionMaker
+    from pisa_amd.core.param import ParamSet
+
+    a, b = _toy_pipeline("a"), _toy_pipeline("b")
+    dm = DistributionMaker([a, b])
+    clock = ParamSet.struct_clock
+    views = (a.params, b.params, dm.params)
+    for _ in range(3):                                   # (round 2: every access rebuilt AND bumped)
+        assert (a.params, b.params, dm.params) == views
+        assert all(x is y for x, y in zip((a.params, b.params, dm.params), views))
+    assert ParamSet.struct_clock == clock
+    # a real change: a Param object replaced in a stage's own set
+    new = Param(name="aeff_scale", value=1.2, prior=None, range=[0.0, 2.0], is_fixed=False)
+    b._stages[0]._param_selector.update(new)
+    assert ParamSet.struct_clock > clock
+    assert b.params is not views[1] and b.params.aeff_scale is new
+    assert dm.params is not views[2]
+    # the name index of an owned set
+    ps = ParamSet(Param(name="x", value=1.0, prior=None, range=None, is_fixed=True))
+    ps.extend(Param(name="y", value=2.0, prior=None, range=None, is_fixed=True))
+    assert ps.names == ("x", "y") and ps.y.value.m == 2.0 and "z" not in ps
+    y2 = Param(name="y", value=5.0, prior=None, range=None, is_fixed=True)
+    ps.replace(y2)
+    assert ps["y"] is y2 and ps.index("y") == 1
+    ps.update([Param(name="z", value=7.0, prior=None, range=None, is_fixed=True), y2])
+    assert ps.names == ("x", "y", "z") and ps.z.value.m == 7.0 and ps["y"] is y2
+    with pytest.raises(ValueError):
+        ps.extend(Param(name="x", value=0.0, prior=None, range=None, is_fixed=True))
