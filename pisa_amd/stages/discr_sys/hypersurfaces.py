@@ -24,20 +24,26 @@ __all__ = ["hypersurfaces"]
 class hypersurfaces(Stage):  # pylint: disable=invalid-name
     def __init__(self, fit_results_file, propagate_uncertainty=False, interpolated=False,
                  links=None, fluctuate=False, fluctuate_seed=12345, **std_kwargs):
-        if interpolated:
-            raise NotImplementedError("interpolated hypersurfaces (hyper_interpolator.py) are not part "
-                                      "of this build")
         self.fit_results_file = fit_results_file
         self.propagate_uncertainty = bool(propagate_uncertainty)
+        self.interpolated = bool(interpolated)
         self.fluctuate = bool(fluctuate)
         self.fluctuate_seed = fluctuate_seed
         if self.fluctuate:
             assert self.fluctuate_seed is not None
-        self.hypersurfaces = hs.load_hypersurfaces(fit_results_file,
-                                                   expected_binning=std_kwargs["calc_mode"])
+        # the expected parameters depend on the file: the hypersurfaces' own parameters and, for
+        # interpolated hypersurfaces, the parameters they are interpolated in (:97-106)
+        self.inter_params = []
+        if self.interpolated:
+            self.hypersurfaces = hs.load_interpolated_hypersurfaces(fit_results_file,
+                                                                    expected_binning=std_kwargs["calc_mode"])
+            self.inter_params = list(self.hypersurfaces.values())[0].interpolation_param_names
+        else:
+            self.hypersurfaces = hs.load_hypersurfaces(fit_results_file,
+                                                       expected_binning=std_kwargs["calc_mode"])
         self.hypersurface_param_names = list(self.hypersurfaces.values())[0].param_names
         keys = ["weights"] + (["errors"] if std_kwargs.get("error_method") else [])
-        super().__init__(expected_params=self.hypersurface_param_names,
+        super().__init__(expected_params=self.hypersurface_param_names + self.inter_params,
                          expected_container_keys=keys,
                          supported_reps={"calc_mode": MultiDimBinning}, **std_kwargs)
         if links is None:
@@ -67,8 +73,12 @@ class hypersurfaces(Stage):  # pylint: disable=invalid-name
         param_values = {n: float(self.params[n].m) for n in self.hypersurface_param_names}
         # the same fluctuation on every call (:176-178)
         rs = np.random.RandomState(self.fluctuate_seed) if self.fluctuate else None
+        inter = {n: self.params[n].value for n in self.inter_params}
         for container in self.data:
             surface = self.hypersurfaces[container.name]
+            if self.interpolated:
+                # the hypersurface at the current values of the interpolation parameters (:186-189)
+                surface = surface.get_hypersurface(**inter)
             if self.fluctuate:
                 surface = surface.fluctuate(random_state=rs)
             if self.propagate_uncertainty:

@@ -29,7 +29,7 @@ import pandas as pd
 from pisa_amd import FTYPE
 from pisa_amd.utils.resources import find_resource
 
-__all__ = ["Hypersurface", "HypersurfaceParam", "HYPERSURFACE_PARAM_FUNCTIONS", "load_hypersurfaces"]
+__all__ = ["HypersurfaceInterpolator", "load_interpolated_hypersurfaces", "Hypersurface", "HypersurfaceParam", "HYPERSURFACE_PARAM_FUNCTIONS", "load_hypersurfaces"]
 
 
 # functional forms: name -> (number of coefficients, f(p, *coeffts), gradient wrt the coefficients)
@@ -284,3 +284,186 @@ def load_hypersurfaces(input_file, expected_binning=None):
     if input_file.endswith("csv") or input_file.endswith("csv.bz2"):
         return _load_data_release(input_file, expected_binning)
     raise Exception("Unknown file format : %s" % input_file)
+
+
+# ------------------------------------------------------------------ interpolated hypersurfaces
+def _quantity(v):
+    """a value of an interpolation grid: Quantity, plain number, or the JSON image of a pint quantity
+    `[magnitude, [[unit, exponent], ...]]` (jsons.py:300-301, 448-474) -> (magnitude, unit string)"""
+    if hasattr(v, "m_as"):
+        return float(v.magnitude), str(v.units)
+    if isinstance(v, (list, tuple)) and len(v) == 2 and isinstance(v[1], (list, tuple)):
+        units = " * ".join("%s**%r" % (u, float(e)) for u, e in v[1]) or "dimensionless"
+        return float(v[0]), units
+    return float(v), "dimensionless"
+
+
+def is_psd(m):
+    """positive semi-definite by attempted Cholesky factorisation (matrix.py:31-56)"""
+    try:
+        np.linalg.cholesky(m)
+        return True
+    except np.linalg.LinAlgError:
+        return False
+
+
+def frobenius_nearest_psd(m):
+    """the PSD matrix closest to `m` in the Frobenius norm (Higham 1988; matrix.py:58-117, there
+    spelled `fronebius_nearest_psd`)"""
+    from scipy import linalg as lin
+
+    b = (m + m.T) / 2.0
+    _, h = lin.polar(b)
+    x = (b + h) / 2.0
+    x = (x + x.T) / 2.0
+    if not is_psd(x):
+        spacing = np.spacing(lin.norm(x))
+        eye, k = np.eye(x.shape[0]), 1
+        while not is_psd(x):
+            mineig = np.min(np.real(lin.eigvals(x)))
+            x += eye * (-mineig * k ** 2 + spacing)
+            k += 1
+    return x
+
+
+class HypersurfaceInterpolator:
+    """Hypersurfaces fitted at the points of a rectilinear grid of (e.g. oscillation) parameters,
+    their coefficients and fit covariances interpolated piecewise-linearly in between
+    (hyper_interpolator.py:48-265; `scipy.interpolate.RegularGridInterpolator`).  Requests outside
+    the grid are clipped to its bounds; parameters flagged `scales_log` are interpolated in log10."""
+
+    def __init__(self, interpolation_param_spec, hs_fits, ignore_nan=True):
+        from scipy import interpolate
+
+        assert isinstance(interpolation_param_spec, OrderedDict), \
+            "interpolation params must be specified as a dict with ordered keys"
+        self.interp_param_spec = OrderedDict()
+        for name, spec in interpolation_param_spec.items():
+            assert set(spec.keys()) == {"values", "scales_log"}
+            vals = [_quantity(v) for v in spec["values"]]
+            assert len({u for _, u in vals}) == 1, "grid values of %s in different units" % name
+            self.interp_param_spec[name] = dict(values=np.array([m for m, _ in vals]), units=vals[0][1],
+                                                scales_log=bool(spec["scales_log"]))
+        self.ndim = len(self.interp_param_spec)
+        reference = hs_fits[0]["hs_fit"]
+        self._reference = reference
+        self.coeff_shape = reference.fit_coeffts.shape
+        self.covars_shape = None if reference.fit_cov_mat is None else reference.fit_cov_mat.shape
+        self.interp_shape = tuple(len(v["values"]) for v in self.interp_param_spec.values())
+        assert len(hs_fits) == int(np.prod(self.interp_shape)), "one fit per grid point"
+        coeff_z = np.zeros(self.interp_shape + self.coeff_shape)
+        covar_z = None if self.covars_shape is None else np.zeros(self.interp_shape + self.covars_shape)
+        for i, idx in enumerate(np.ndindex(self.interp_shape)):
+            # the fits are stored in C order of the grid; their parameter values must say so (:139-150)
+            for j, (name, spec) in enumerate(self.interp_param_spec.items()):
+                got = _quantity(hs_fits[i]["param_values"][name])[0]
+                assert got == spec["values"][idx[j]], \
+                    "The stored values where hypersurfaces were fit do not match those in the interpolation grid."
+            coeff_z[idx] = hs_fits[i]["hs_fit"].fit_coeffts
+            if covar_z is not None:
+                covar_z[idx] = hs_fits[i]["hs_fit"].fit_cov_mat
+        grid = [np.array(spec["values"], dtype=FTYPE) for spec in self.interp_param_spec.values()]
+        self.param_bounds = [(np.min(g), np.max(g)) for g in grid]
+        for i, spec in enumerate(self.interp_param_spec.values()):
+            if spec["scales_log"]:
+                grid[i] = np.log10(grid[i])
+        self.coefficients = interpolate.RegularGridInterpolator(grid, coeff_z, bounds_error=True, fill_value=None)
+        self.covars = None if covar_z is None else \
+            interpolate.RegularGridInterpolator(grid, covar_z, bounds_error=True, fill_value=None)
+        self.ignore_nan = ignore_nan
+
+    interpolation_param_names = property(lambda self: list(self.interp_param_spec.keys()))
+    param_names = property(lambda self: self._reference.param_names)
+    binning = property(lambda self: self._reference.binning)
+    num_interp_params = property(lambda self: self.ndim)
+
+    def _point(self, param_kw):
+        assert set(param_kw.keys()) == set(self.interp_param_spec.keys()), "invalid parameters"
+        x = np.empty(self.ndim)
+        for i, (name, spec) in enumerate(self.interp_param_spec.items()):
+            v = param_kw[name]
+            x[i] = v.m_as(spec["units"]) if hasattr(v, "m_as") else float(v)
+            x[i] = np.clip(x[i], *self.param_bounds[i])
+            if spec["scales_log"]:
+                if x[i] <= 0:
+                    raise RuntimeError("A log-scaling parameter cannot become zero or negative!")
+                x[i] = np.log10(x[i])
+        return x
+
+    def get_hypersurface(self, **param_kw):
+        """the Hypersurface at the given values of the interpolation parameters (Quantities or
+        magnitudes in the grid's units); hyper_interpolator.py:194-265"""
+        x = self._point(param_kw)
+        hsf = copy.deepcopy(self._reference)
+        if self.covars is not None:
+            cov = np.squeeze(self.covars(x), axis=0)
+            assert cov.shape == self.covars_shape
+            for bin_idx in np.ndindex(cov.shape[:-2]):
+                m = cov[bin_idx]
+                if np.any(~np.isfinite(m)):
+                    assert self.ignore_nan, "invalid cov matrix element encountered in bin %s" % (bin_idx,)
+                    cov[bin_idx] = m = np.identity(m.shape[0])
+                assert np.allclose(m, m.T, rtol=1e-11), "cov matrix not symmetric in bin %s" % (bin_idx,)
+                if not is_psd(m):
+                    cov[bin_idx] = frobenius_nearest_psd(m)
+            hsf.fit_cov_mat = cov
+        coeffts = np.squeeze(self.coefficients(x), axis=0)
+        assert coeffts.shape == self.coeff_shape
+        bad = ~np.isfinite(coeffts)
+        if np.any(bad):
+            assert self.ignore_nan, "invalid coeff encountered"
+            default = np.zeros(self.coeff_shape)
+            default[..., 0] = 1.0          # empty bins: intercept 1, slopes 0
+            coeffts = np.where(bad, default, coeffts)
+        hsf.intercept = coeffts[..., 0].copy()
+        i = 1
+        for p in hsf.params.values():
+            p.fit_coeffts = coeffts[..., i: i + p.num_fit_coeffts].copy()
+            i += p.num_fit_coeffts
+        return hsf
+
+
+def load_interpolated_hypersurfaces(input_file, expected_binning=None):
+    """{map name: HypersurfaceInterpolator} from a file of `fit_hypersurfaces` run with interpolation
+    parameters (hyper_interpolator.py:920-1039):
+        {"interpolation_param_spec": {name: {"values": [...], "scales_log": bool}, ...},
+         "hs_fits": [{"param_values": {name: value}, "hs_fit": {map name: hypersurface state}}, ...]}
+    and the older layout with "interp_params" / "kind": "linear" and one hypersurface file per point."""
+    assert isinstance(input_file, str)
+    data = _read_json(input_file)
+    if "interpolation_param_spec" not in data:
+        assert "interp_params" in data and "hs_fits" in data and "kind" in data
+        assert data["kind"] == "linear", "Only linear interpolation supported (input file specifies '%s')" % data["kind"]
+        spec = OrderedDict()
+        for param_def in data["interp_params"]:
+            name = param_def["name"]
+            values = [fit["param_values"][name] for fit in data["hs_fits"]]
+            uniq = []
+            for v in values:
+                if not any(_quantity(v) == _quantity(u) for u in uniq):
+                    uniq.append(v)
+            spec[name] = {"scales_log": False, "values": uniq}
+        data["interpolation_param_spec"] = spec
+        for fit in data["hs_fits"]:
+            fit["hs_fit"] = load_hypersurfaces(fit["file"], expected_binning=expected_binning)
+    assert {"interpolation_param_spec", "hs_fits"}.issubset(data.keys()), "missing keys"
+    map_names = None
+    for fit in data["hs_fits"]:
+        maps = fit["hs_fit"]
+        if map_names is None:
+            map_names = list(maps.keys())
+        else:
+            assert set(map_names) == set(maps.keys()), "inconsistent maps"
+        for name in map_names:
+            if not isinstance(maps[name], Hypersurface):
+                maps[name] = Hypersurface.from_state(maps[name], binning=expected_binning)
+            if expected_binning is not None and maps[name].intercept.shape != tuple(expected_binning.shape):
+                raise AssertionError("Binning of loaded hypersurfaces does not match the expected binning")
+    spec = data["interpolation_param_spec"]
+    if not isinstance(spec, OrderedDict):
+        spec = OrderedDict(spec)
+    out = OrderedDict()
+    for name in map_names:
+        fits = [{"param_values": fit["param_values"], "hs_fit": fit["hs_fit"][name]} for fit in data["hs_fits"]]
+        out[name] = HypersurfaceInterpolator(spec, fits)
+    return out

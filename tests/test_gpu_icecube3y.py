@@ -43,7 +43,7 @@ def test_muon_template_and_data_cfgs_unmodified():
     np.testing.assert_array_equal(dm[0].hist.ravel(), _release_table("data")["count"].values)
 
 
-def _oracle_event_weights(oracle, pipe, mc, names, barr, theta23_deg, nc_norm):
+def _oracle_event_weights(oracle, pipe, mc, names, barr, theta23_deg, nc_norm, dm31=2.457e-3):
     """the reference chain (honda flux on the grid -> Barr systematics -> prob3 on the grid ->
     lookups -> osc * aeff reweighting) with the oracle, per container: (weights, [ln reco_E, reco_cz, pid])"""
     from oracle import flux_oracle
@@ -64,7 +64,7 @@ def _oracle_event_weights(oracle, pipe, mc, names, barr, theta23_deg, nc_norm):
     lay.setElecFrac(0.4656, 0.4656, 0.4957)
     lay.calcLayers(cz_n)
     mix = oracle.mix_matrix(np.deg2rad(33.48), np.deg2rad(8.5), np.deg2rad(theta23_deg), 0.0)
-    dm = oracle.dm_matrix(7.5e-5, 2.457e-3)
+    dm = oracle.dm_matrix(7.5e-5, dm31)
     zero = np.zeros((3, 3))
     prob = {s: oracle.propagate_array(dm, mix, np.diag([1.0, 0, 0]).astype(complex), -1, zero.astype(complex),
                                        zero, s, ee, np.tile(lay.density, (n_e, 1)), np.tile(lay.distance, (n_e, 1)))
@@ -399,3 +399,83 @@ def test_fit_of_the_published_analysis_recovers_injected_values(tmp_path, monkey
     np.testing.assert_allclose(got["atm_muon_scale"], truth["atm_muon_scale"], atol=5e-2)
     nu = dm.pipelines[0]
     assert nu._plan is not None and res.num_distributions_generated > 30
+
+
+def test_interpolated_hypersurfaces_in_the_3y_pipeline(oracle, tmp_path, monkeypatch):
+    """`discr_sys.hypersurfaces(interpolated=True)` (hypersurfaces.py:97-106, 174-189): the per-bin
+    factors come from hypersurfaces interpolated in (deltam31, theta23), so the stage moves with the
+    oscillation parameters as well.  Maps against the oracle histogram times the factors of the
+    hypersurface interpolated by hand; and the evaluation plan, which now has to re-run the stage
+    when an oscillation parameter moves, against the ordinary Stage protocol bit for bit."""
+    import json
+    from collections import OrderedDict
+
+    from scipy.interpolate import RegularGridInterpolator
+
+    from pisa_amd.core.config_parser import parse_pipeline_config
+    from pisa_amd.core.pipeline import Pipeline
+    from pisa_amd.core.units import ureg
+    from pisa_amd.utils.hypersurface import Hypersurface, HypersurfaceParam
+
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "make_synthetic_3y_mc.py"),
+                           str(tmp_path), "30000", "13"])
+    monkeypatch.setenv("PISA_RESOURCES", str(tmp_path))
+    cfg = parse_pipeline_config("settings/pipeline/IceCube_3y_neutrinos.cfg")
+    ob = cfg["pipeline"]["output_binning"]
+    rs = np.random.RandomState(23)
+    names = ["opt_eff_overall", "opt_eff_lateral", "opt_eff_headon", "ice_scattering", "ice_absorption"]
+    nominal = dict(opt_eff_overall=1.0, opt_eff_lateral=25.0, opt_eff_headon=0.0, ice_scattering=0.0, ice_absorption=0.0)
+    keys = ("nue_cc+nuebar_cc", "numu_cc+numubar_cc", "nutau_cc+nutaubar_cc", "nu_nc+nubar_nc")
+    dm_vals, th_vals = [2.0e-3, 2.5e-3, 3.0e-3], [38.0, 45.0, 52.0]
+    fits, coeff = [], {}
+    for i, dm in enumerate(dm_vals):
+        for j, th in enumerate(th_vals):
+            maps = OrderedDict()
+            for key in keys:
+                params = [HypersurfaceParam(n, "linear", rs.randn(*ob.shape, 1) * 0.02, nominal_value=nominal[n])
+                          for n in names]
+                h = Hypersurface(ob, params, 1.0 + rs.randn(*ob.shape) * 0.02)
+                maps[key] = h.serializable_state
+                coeff[key, i, j] = h.fit_coeffts
+            fits.append({"param_values": {"deltam31": [dm, [["electron_volt", 2.0]]], "theta23": [th, [["degree", 1.0]]]},
+                         "hs_fit": maps})
+    spec = OrderedDict([("deltam31", {"values": [[v, [["electron_volt", 2.0]]] for v in dm_vals], "scales_log": False}),
+                        ("theta23", {"values": [[v, [["degree", 1.0]]] for v in th_vals], "scales_log": False})])
+    (tmp_path / "interp.json").write_text(json.dumps({"interpolation_param_spec": spec, "hs_fits": fits}))
+    cfg[("discr_sys", "hypersurfaces")]["fit_results_file"] = str(tmp_path / "interp.json")
+    cfg[("discr_sys", "hypersurfaces")]["interpolated"] = True
+    # the stage needs the interpolation parameters among its own: the objects of the oscillation stage
+    osc_params = cfg[("osc", "prob3")]["params"]
+    for n in ("deltam31", "theta23"):
+        cfg[("discr_sys", "hypersurfaces")]["params"].update(osc_params.params[n], extend=True)
+    pipe, slow = Pipeline(cfg), Pipeline(cfg)
+    slow.fast_path = False
+    assert pipe["hypersurfaces"].inter_params == ["deltam31", "theta23"]
+    vals = dict(opt_eff_overall=1.03, opt_eff_lateral=22.0, opt_eff_headon=-0.3, ice_scattering=2.0, ice_absorption=-1.0)
+    mc = pd.read_csv(os.path.join(str(tmp_path), "events/IceCube_3y_oscillations/neutrino_mc.csv.bz2"))
+    omin, omax, onb = [np.log(5.62341325), -1.0, -0.5], [np.log(56.23413252), 1.0, 1.5], [8, 8, 2]
+    groups = {"nue_cc": keys[0], "nuebar_cc": keys[0], "numu_cc": keys[1], "numubar_cc": keys[1],
+              "nutau_cc": keys[2], "nutaubar_cc": keys[2]}
+    for step, (th, dm) in enumerate(((42.3, 2.457e-3), (47.5, 2.8e-3), (58.0, 2.2e-3))):
+        for p in (pipe, slow):
+            for k, v in vals.items():
+                p.params[k].value = v * ureg.dimensionless
+            p.params.theta23.value = th * ureg.degree
+            p.params.deltam31.value = dm * ureg.eV ** 2
+        maps, want = pipe.get_outputs(), slow.get_outputs()
+        if step > 0:
+            assert maps[0]._lazy is not None, "the evaluation plan must replay the stage"
+        ow = _oracle_event_weights(oracle, slow, mc, want.names, barr=(1.0, 1.0, 0.0, 0.0, 0.0), theta23_deg=th,
+                                   nc_norm=1.0, dm31=dm) if step == 1 else None
+        for m, ref in zip(maps, want):
+            np.testing.assert_array_equal(m.hist, ref.hist, err_msg="%s step %d" % (m.name, step))
+            np.testing.assert_array_equal(m.std_devs, ref.std_devs, err_msg="%s step %d" % (m.name, step))
+            if ow is not None:
+                key = groups.get(m.name, keys[3])
+                cz = np.stack([np.stack([coeff[key, i, j] for j in range(3)]) for i in range(3)])
+                c = RegularGridInterpolator([dm_vals, th_vals], cz)([dm, min(th, 52.0)])[0]
+                scale = c[..., 0] + sum(c[..., 1 + q] * (vals[n] - nominal[n]) for q, n in enumerate(names))
+                w, sample = ow[m.name]
+                h = oracle.histogram_regular(sample, w, omin, omax, onb)
+                np.testing.assert_allclose(m.hist.ravel(), np.clip(h * scale.ravel(), 0, np.inf), rtol=1e-10,
+                                           atol=1e-300, err_msg=m.name)

@@ -431,3 +431,80 @@ def test_param_views_are_cached_and_do_not_count_as_structural_changes():
     assert ps.names == ("x", "y", "z") and ps.z.value.m == 7.0 and ps["y"] is y2
     with pytest.raises(ValueError):
         ps.extend(Param(name="x", value=0.0, prior=None, range=None, is_fixed=True))
+
+
+def test_interpolated_hypersurfaces(tmp_path):
+    """hyper_interpolator.py:48-265, 920-1039: hypersurfaces fitted on a rectilinear grid of oscillation
+    parameters (file layout of `fit_hypersurfaces`, quantities as `[magnitude, [[unit, exponent]]]`),
+    coefficients and covariances interpolated piecewise-linearly, `scales_log` axes in log10, requests
+    clipped to the grid, empty bins (NaN) -> intercept 1 / slopes 0, non-PSD covariances repaired."""
+    import json
+    from collections import OrderedDict
+
+    from scipy.interpolate import RegularGridInterpolator
+
+    from pisa_amd.utils.hypersurface import (Hypersurface, HypersurfaceParam, frobenius_nearest_psd, is_psd,
+                                             load_interpolated_hypersurfaces)
+
+    rs = np.random.RandomState(8)
+    b = MultiDimBinning([OneDimBinning("reco_energy", num_bins=3, is_log=True, domain=[5.0, 80.0]),
+                         OneDimBinning("reco_coszen", num_bins=2, is_lin=True, domain=[-1, 1])])
+    shape = b.shape
+    dm_vals, th_vals = [1.0e-3, 2.0e-3, 4.0e-3, 8.0e-3], [35.0, 45.0, 55.0]
+    fits, coeff, covs = [], {}, {}
+    for i, dm in enumerate(dm_vals):
+        for j, th in enumerate(th_vals):
+            maps = OrderedDict()
+            for name in ("nue_cc+nuebar_cc", "nu_nc+nubar_nc"):
+                lin = rs.randn(*shape, 1) * 0.1
+                quad = rs.randn(*shape, 2) * 0.05
+                icpt = 1.0 + rs.randn(*shape) * 0.02
+                if name.startswith("nu_nc") and (i, j) == (1, 1):
+                    icpt[0, 0] = np.nan                      # an empty bin at one grid point
+                a = rs.randn(*shape, 4, 4) * 0.02
+                cov = np.einsum("...ij,...kj->...ik", a, a)
+                h = Hypersurface(b, [HypersurfaceParam("dom_eff", "linear", lin, nominal_value=1.0),
+                                     HypersurfaceParam("hole_ice", "quadratic", quad, nominal_value=25.0)],
+                                 icpt, fit_cov_mat=cov)
+                maps[name] = h.serializable_state
+                coeff[name, i, j], covs[name, i, j] = h.fit_coeffts, cov
+            fits.append({"param_values": {"deltam31": [dm, [["electron_volt", 2.0]]], "theta23": [th, [["degree", 1.0]]]},
+                         "hs_fit": maps})
+    spec = OrderedDict([("deltam31", {"values": [[v, [["electron_volt", 2.0]]] for v in dm_vals], "scales_log": True}),
+                        ("theta23", {"values": [[v, [["degree", 1.0]]] for v in th_vals], "scales_log": False})])
+    path = tmp_path / "interp.json"
+    path.write_text(json.dumps({"interpolation_param_spec": spec, "hs_fits": fits},
+                               default=lambda o: None if isinstance(o, float) and o != o else o).replace("NaN", "NaN"))
+    loaded = load_interpolated_hypersurfaces(str(path), expected_binning=b)
+    assert list(loaded) == ["nue_cc+nuebar_cc", "nu_nc+nubar_nc"]
+    hi = loaded["nue_cc+nuebar_cc"]
+    assert hi.interpolation_param_names == ["deltam31", "theta23"] and hi.param_names == ["dom_eff", "hole_ice"]
+    # at a grid point: the stored fit
+    at = hi.get_hypersurface(deltam31=2.0e-3 * ureg.eV ** 2, theta23=55.0 * ureg.degree)
+    np.testing.assert_allclose(at.fit_coeffts, coeff["nue_cc+nuebar_cc", 1, 2], rtol=1e-13)
+    # in between: linear in (log10 deltam31, theta23), also through other units of the request
+    cz = np.stack([np.stack([coeff["nue_cc+nuebar_cc", i, j] for j in range(3)]) for i in range(4)])
+    ref = RegularGridInterpolator([np.log10(dm_vals), th_vals], cz)
+    mid = hi.get_hypersurface(deltam31=2.9e-3 * ureg.eV ** 2, theta23=(np.deg2rad(41.0)) * ureg.rad)
+    np.testing.assert_allclose(mid.fit_coeffts, ref([np.log10(2.9e-3), 41.0])[0], rtol=1e-12)
+    vals = dict(dom_eff=1.05, hole_ice=23.0)
+    want = (mid.fit_coeffts[..., 0] + mid.fit_coeffts[..., 1] * 0.05 + mid.fit_coeffts[..., 2] * -2.0
+            + mid.fit_coeffts[..., 3] * 4.0)
+    got, unc = mid.evaluate(vals, return_uncertainty=True)
+    np.testing.assert_allclose(got, want, rtol=1e-13)
+    assert np.all(unc > 0) and all(is_psd(m) for m in mid.fit_cov_mat.reshape(-1, 4, 4))
+    # outside the grid: clipped to its bounds
+    out = hi.get_hypersurface(deltam31=1.0 * ureg.eV ** 2, theta23=10.0 * ureg.degree)
+    np.testing.assert_allclose(out.fit_coeffts, coeff["nue_cc+nuebar_cc", 3, 0], rtol=1e-13)
+    # the empty bin: a NaN coefficient anywhere in the interpolation cell -> that coefficient becomes its
+    # default (intercept 1, slopes 0), element by element as in the reference (:252-257)
+    nc = loaded["nu_nc+nubar_nc"].get_hypersurface(deltam31=2.5e-3 * ureg.eV ** 2, theta23=46.0 * ureg.degree)
+    assert nc.fit_coeffts[0, 0, 0] == 1.0 and np.all(np.isfinite(nc.fit_coeffts))
+    assert np.all(np.isfinite(nc.evaluate(vals)))
+    with pytest.raises(AssertionError):
+        hi.get_hypersurface(deltam31=2e-3 * ureg.eV ** 2)
+    # the covariance repair
+    m = np.array([[1.0, 2.0], [2.0, 1.0]])
+    assert not is_psd(m)
+    fixed = frobenius_nearest_psd(m)
+    assert is_psd(fixed) and np.allclose(fixed, fixed.T) and np.abs(fixed - m).max() < 1.1
