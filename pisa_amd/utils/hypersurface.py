@@ -263,6 +263,27 @@ def _load_data_release(input_file, binning):
     return out
 
 
+def _load_legacy(data, expected_binning):
+    """hyperplane (linear) fit files of older PISA versions (hypersurface.py:1967-2062):
+    `sys_list` = parameter names, `map_names`, and per map an array [binning..., 1 + n_sys] of intercept
+    and gradients -- either `data[map_name]` or `data["hyperplanes"][map_name]["fit_params"]`.  The
+    nominal values are unknown in such files: evaluated with the RAW parameter values."""
+    names = list(data["sys_list"])
+    out = OrderedDict()
+    for map_name in data["map_names"]:
+        coeffts = np.asarray(data["hyperplanes"][map_name]["fit_params"] if "hyperplanes" in data
+                             else data[map_name], dtype=FTYPE)
+        assert coeffts.shape[-1] == 1 + len(names), "one intercept and one gradient per parameter"
+        shape = coeffts.shape[:-1]
+        if expected_binning is not None and shape != tuple(expected_binning.shape):
+            raise AssertionError("Incompatible binning: hypersurface %s, expected %s"
+                                 % (shape, expected_binning.shape))
+        params = [HypersurfaceParam(n, "linear", coeffts[..., i + 1: i + 2].copy(), nominal_value=np.nan)
+                  for i, n in enumerate(names)]
+        out[map_name] = Hypersurface(expected_binning, params, coeffts[..., 0].copy(), using_legacy_data=True)
+    return out
+
+
 def load_hypersurfaces(input_file, expected_binning=None):
     """{map name: Hypersurface} from a fit file (json / json.bz2) or from the data-release CSVs
     ('<dir>/hyperplanes_*.csv[.bz2]'); hypersurface.py:1877-1964"""
@@ -271,8 +292,7 @@ def load_hypersurfaces(input_file, expected_binning=None):
         data = _read_json(input_file)
         assert isinstance(data, Mapping)
         if "sys_list" in data:
-            raise NotImplementedError("hyperplane fit files of pre-hypersurface PISA versions "
-                                      "(_load_hypersurfaces_legacy) are not supported")
+            return _load_legacy(data, expected_binning)
         out = OrderedDict()
         for map_name, state in data.items():
             hsf = Hypersurface.from_state(state, binning=expected_binning)

@@ -508,3 +508,37 @@ def test_interpolated_hypersurfaces(tmp_path):
     assert not is_psd(m)
     fixed = frobenius_nearest_psd(m)
     assert is_psd(fixed) and np.allclose(fixed, fixed.T) and np.abs(fixed - m).max() < 1.1
+
+
+def test_legacy_hyperplane_fit_files(tmp_path):
+    """hypersurface.py:1967-2062: fit files of pre-hypersurface PISA versions (`sys_list`, `map_names`, one
+    [binning..., 1 + n_sys] array per map, in either of the two layouts); linear, evaluated with the raw
+    parameter values because such files carry no nominal values"""
+    import json
+
+    from pisa_amd.utils.hypersurface import load_hypersurfaces
+
+    rs = np.random.RandomState(1)
+    b = MultiDimBinning([OneDimBinning("reco_energy", num_bins=4, is_log=True, domain=[5.0, 80.0]),
+                         OneDimBinning("reco_coszen", num_bins=3, is_lin=True, domain=[-1, 1])])
+    arrs = {m: np.concatenate([1.0 + rs.randn(4, 3, 1) * 0.02, rs.randn(4, 3, 2) * 0.1], axis=-1)
+            for m in ("nue_cc", "numu_cc")}
+    vals = dict(dom_eff=1.1, hole_ice=0.4)
+    for layout in (0, 1):
+        data = {"sys_list": ["dom_eff", "hole_ice"], "map_names": list(arrs)}
+        if layout == 0:
+            data.update({m: a.tolist() for m, a in arrs.items()})
+        else:
+            data["hyperplanes"] = {m: {"fit_params": a.tolist()} for m, a in arrs.items()}
+        path = tmp_path / ("legacy%d.json" % layout)
+        path.write_text(json.dumps(data))
+        loaded = load_hypersurfaces(str(path), expected_binning=b)
+        assert list(loaded) == ["nue_cc", "numu_cc"]
+        for m, a in arrs.items():
+            assert loaded[m].using_legacy_data and loaded[m].param_names == ["dom_eff", "hole_ice"]
+            np.testing.assert_allclose(loaded[m].evaluate(vals), a[..., 0] + a[..., 1] * 1.1 + a[..., 2] * 0.4,
+                                       rtol=1e-15)
+    with pytest.raises(AssertionError):
+        load_hypersurfaces(str(path), expected_binning=MultiDimBinning(
+            [OneDimBinning("reco_energy", num_bins=5, is_log=True, domain=[5.0, 80.0]),
+             OneDimBinning("reco_coszen", num_bins=3, is_lin=True, domain=[-1, 1])]))
