@@ -344,6 +344,17 @@ def gen_flux():
     for prim in ("nue", "numu", "nuebar", "numubar"):
         out[prim] = fw.calculate_2d_flux_weights(e, cz, splines[prim])
     save("flux_ref.npz", **out)
+    # the Bartol table (Honda-like layout, coarser energy steps above 10 GeV; flux_weights.py:133-203)
+    table = "flux/bartol-2004-sno-solmax-aa.d"
+    splines = fw.load_2d_table(table)
+    e = 10 ** (rs.rand(n) * 5 - 1)
+    cz = rs.rand(n) * 2 - 1
+    e[:6] = [0.05, 0.09, 0.1, 1.0e4, 1.2e4, 3.0e4]
+    cz[6:12] = [-1.0, 1.0, -0.95, 0.95, 0.0, -0.9]
+    out = dict(table=np.array(table), true_energy=e, true_coszen=cz)
+    for prim in ("nue", "numu", "nuebar", "numubar"):
+        out[prim] = fw.calculate_2d_flux_weights(e, cz, splines[prim])
+    save("flux_bartol_ref.npz", **out)
 
 
 if __name__ == "__main__":

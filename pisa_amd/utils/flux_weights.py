@@ -62,6 +62,30 @@ class FluxTable2D(dict):
         self.struct = s
 
 
+def _load_2d_bartol_table(flux_file, enpow=1):
+    """flux_weights.py:133-203: Bartol tables rewritten in the Honda layout -- 20 coszen bands, energy
+    steps of 0.05 in log10 below 10 GeV and 0.1 above, hence the two-part knot vector and bin widths"""
+    cols = ["energy"] + PRIMARIES
+    with open(find_resource(flux_file)) as fh:
+        table = np.genfromtxt(fh, usecols=list(range(len(cols))))
+    header = np.all(np.isnan(table) | np.equal(table, 0), axis=1)
+    table = table[~header].T
+    flux = {c: np.array(np.split(col, N_CZ)) for c, col in zip(cols, table)}
+    energy = flux["energy"][0]
+    log_knots = np.concatenate([np.linspace(-1, 1, 41), np.linspace(1.1, 4, 30)])
+    spline_dict = {}
+    for prim in PRIMARIES:
+        splines = {}
+        for band_no, band in enumerate(flux[prim], start=1):
+            running, integral = 0.0, [0.0]
+            for val, e in zip(band, energy):
+                running += val * np.power(e, enpow) * (0.05 if e < 10.0 else 0.1)
+                integral.append(running)
+            splines["%.2f" % (1.05 - band_no * 0.1)] = interpolate.splrep(log_knots, integral, s=0)
+        spline_dict[prim] = splines
+    return spline_dict
+
+
 def _load_2d_honda_table(flux_file, enpow=1):
     """flux_weights.py:50-131 (Honda layout: 20 coszen bands of 101 energies)"""
     cols = ["energy"] + PRIMARIES
@@ -94,12 +118,18 @@ def load_2d_table(flux_file, enpow=1, return_table=False):
         raise NotImplementedError("return_table is a plotting aid of the reference, not part of this build")
     if "aa" not in flux_file:
         raise ValueError("Azimuth-averaged tables are expected")
-    if "honda" not in flux_file:
-        if "hillas" in flux_file or "bartol" in flux_file:
-            raise NotImplementedError("only Honda-format 2-D tables are part of this build")
+    # (:229-260: the group is read off the file name)
+    if "honda" in flux_file:
+        spline_dict = _load_2d_honda_table(flux_file, enpow=enpow)
+        spline_dict["name"] = "honda"
+    elif "bartol" in flux_file:
+        spline_dict = _load_2d_bartol_table(flux_file, enpow=enpow)
+        spline_dict["name"] = "bartol"
+    elif "hillas" in flux_file:
+        raise NotImplementedError("Hillas-Gaisser tables with tau-neutrino columns (hg_taumode) are not "
+                                  "part of this build")
+    else:
         raise ValueError("Flux file must be from the Honda, Hillas, or Bartol groups")
-    spline_dict = _load_2d_honda_table(flux_file, enpow=enpow)
-    spline_dict["name"] = "honda"
     return FluxTable2D(spline_dict, enpow)
 
 

@@ -51,3 +51,20 @@ def test_flux_2d_matches_oracle_and_rejects_bad_coszen():
         fw.calculate_2d_flux_weights(e, cz, table)
     with pytest.raises(ValueError):
         fw.load_2d_table("flux/honda-2015-spl-solmin.d")  # not azimuth averaged
+
+
+def test_bartol_table_matches_reference_goldens():
+    """`load_2d_table` on a Bartol table (flux_weights.py:133-203: Honda-like layout, two energy step
+    widths) -> the band splines have non-uniform knots; same kernel.  Against values produced by the
+    reference's own code (tests/golden/flux_bartol_ref.npz, oracle/gen_golden.py:gen_flux)."""
+    from pisa_amd.utils import flux_weights as fw
+
+    g = np.load(os.path.join(GOLD, "flux_bartol_ref.npz"))
+    table = fw.load_2d_table(str(g["table"]))
+    assert table["name"] == "bartol"
+    nu, nubar = fw.calculate_2d_flux_weights(g["true_energy"], g["true_coszen"], table)
+    nu, nubar = nu.cpu().numpy(), nubar.cpu().numpy()
+    np.testing.assert_allclose(nu[:, 0], g["nue"], **TOL)
+    np.testing.assert_allclose(nu[:, 1], g["numu"], **TOL)
+    np.testing.assert_allclose(nubar[:, 0], g["nuebar"], **TOL)
+    np.testing.assert_allclose(nubar[:, 1], g["numubar"], **TOL)
