@@ -12,6 +12,8 @@ The metric itself is evaluated on the GPU (`pisa_hip_metric`).
 """
 from collections import OrderedDict
 
+from copy import deepcopy
+
 import numpy as np
 
 from pisa_amd.core.param import CHI2_METRICS, LLH_METRICS
@@ -32,7 +34,10 @@ class HypoFitResult:
     def __init__(self, metric, metric_val, params, hypo_asimov_dist, fit_history, minimizer_result,
                  num_distributions_generated):
         self.metric, self.metric_val = metric, metric_val
-        self.params = params
+        # a snapshot (analysis.py:356-372 deep-copies too): later fits move the maker's own objects
+        self.params = deepcopy(params)
+        for m in (hypo_asimov_dist if hypo_asimov_dist is not None else ()):
+            m.hist   # device-backed maps are brought home: the engine's buffers are reused by the next fit
         self.hypo_asimov_dist = hypo_asimov_dist
         self.fit_history = fit_history
         self.minimizer_metadata = minimizer_result
@@ -125,3 +130,63 @@ class Analysis:
         meta = OrderedDict(success=bool(res.success), nit=int(getattr(res, "nit", -1)),
                            nfev=int(res.nfev), message=str(res.message))
         return HypoFitResult(metric, val, hypo_maker.params, hypo, history, meta, counter.count)
+
+    # -- a simple global scheme: both octants of a mixing angle (analysis.py:974-1088) ------------
+    @staticmethod
+    def get_separate_octant_params(hypo_maker, angle_name, inflection_point, tolerance=None):
+        """the angle parameter as it is, confined to the octant of its nominal value, and confined to
+        the other octant with the value mirrored at `inflection_point` (manipulate_params.py:44-123)"""
+        from pisa_amd.core.units import ureg
+
+        angle = hypo_maker.params[angle_name]
+        angle.reset()
+        angle_orig = angle            # the maker's own object: it is put back after the octant fits
+        octants = ((angle.range[0], inflection_point), (inflection_point, angle.range[1]))
+        if tolerance is None:
+            tolerance = 0.1 * ureg.degree
+        dist = (angle.value - inflection_point).m_as("rad")
+        if abs(dist) < tolerance.m_as("rad"):
+            angle.value = inflection_point + (-1.0 if dist < 0.0 else 1.0) * tolerance
+        case1, case2 = deepcopy(angle), deepcopy(angle)
+        first = 0 if case1.value.m_as("rad") < inflection_point.m_as("rad") else 1
+        case1.range = octants[first]
+        case1.nominal_value = case1.value
+        mirrored = (2 * inflection_point - case2.value).to(case2.value.units)
+        # range before value: a Param validates its value against its range
+        case2.range = octants[1 - first]
+        case2.value = mirrored
+        case2.nominal_value = case2.value
+        return angle_orig, case1, case2
+
+    def fit_octants(self, data_dist, hypo_maker, metric, angle="theta23", inflection_point=None,
+                    tolerance=None, minimizer_settings=None, reset_free=True):
+        """Fit with `angle` confined to either octant and keep the better fit (`_fit_octants`,
+        analysis.py:974-1088: the local minimiser does not cross the octant degeneracy of theta23 by
+        itself).  The maker ends with its original parameter OBJECT at the best-fit values."""
+        from pisa_amd.core.units import ureg
+
+        if angle not in hypo_maker.params.free.names:
+            return self.fit_hypo(data_dist, hypo_maker, metric, minimizer_settings, reset_free=reset_free)
+        if inflection_point is None:
+            inflection_point = 45.0 * ureg.degree
+        if reset_free:
+            hypo_maker.reset_free()
+        start = [(p.name, p.value) for p in hypo_maker.params.free]
+        orig, case1, case2 = self.get_separate_octant_params(hypo_maker, angle, inflection_point, tolerance)
+        hypo_maker.update_params(case1)
+        best = self.fit_hypo(data_dist, hypo_maker, metric, minimizer_settings, reset_free=False)
+        for name, value in start:
+            if name != angle:
+                hypo_maker.params[name].value = value
+        hypo_maker.update_params(case2)
+        other = self.fit_hypo(data_dist, hypo_maker, metric, minimizer_settings, reset_free=False)
+        sign = self._sign(metric)   # +1: smaller is better
+        if sign * other.metric_val < sign * best.metric_val:
+            best, other = other, best
+        best.alternate_fit = other
+        for res in (best, other):   # the results carry the original range, not an octant's
+            res.params[angle].range = deepcopy(orig.range)
+        hypo_maker.update_params(orig)
+        for p in best.params.free:
+            hypo_maker.params[p.name].value = p.value
+        return best
