@@ -120,6 +120,18 @@ class Analysis:
         x0 = np.array(free._rescaled_values, dtype=np.float64)
         bounds = [(0.0, 1.0)] * len(x0)
         counter, history = Counter(), []
+        # a perfect match of data and template at the starting point (pseudo-data generated at the
+        # nominal values): no fit (analysis.py:1746-1786; comparisons.ALLCLOSE_KW)
+        hypo = hypo_maker.get_outputs(return_sum=True)
+        data_maps = list(data_dist) if hasattr(data_dist, "maps") else [data_dist]
+        if len(data_maps) == len(hypo) and all(
+                d.hist.shape == h.hist.shape
+                and np.allclose(d.hist, h.hist, rtol=1e-12, atol=np.finfo(np.float64).eps, equal_nan=True)
+                for d, h in zip(data_maps, hypo)):
+            val = (data_dist.metric_total(expected_values=hypo, metric=metric)
+                   + hypo_maker.params.priors_penalty(metric=metric))
+            meta = OrderedDict(success=True, nit=0, nfev=0, message="Initial hypo matches data, no need for fit")
+            return HypoFitResult(metric, val, hypo_maker.params, hypo, None, meta, 0)
         res = optimize.minimize(
             fun=self._minimizer_callable, x0=x0, args=(hypo_maker, data_dist, metric, counter, history),
             bounds=bounds if ms["method"].lower() in ("l-bfgs-b", "slsqp", "tnc", "trust-constr") else None,

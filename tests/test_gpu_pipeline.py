@@ -432,3 +432,18 @@ def test_octant_fit_finds_the_other_octant():
     dm.params.fix("theta23")
     plain = ana.fit_octants(data, dm, "mod_chi2")
     assert not hasattr(plain, "alternate_fit")
+
+
+def test_fit_returns_at_once_when_the_start_matches_the_data():
+    """analysis.py:1746-1786: pseudo-data generated at the nominal values -> the template at the starting
+    point equals the data -> no minimisation"""
+    from pisa_amd.analysis.analysis import Analysis
+    from pisa_amd.core.distribution_maker import DistributionMaker
+
+    dm = DistributionMaker("settings/pipeline/example_hip.cfg")
+    data = dm.get_outputs(return_sum=True)
+    data[0].hist
+    res = Analysis().fit_hypo(data, dm, "mod_chi2")
+    assert res.num_distributions_generated == 0 and res.minimizer_metadata["nit"] == 0
+    assert res.minimizer_metadata["success"] and abs(res.metric_val) < 1e-20
+    assert res.params.theta23.value == dm.params.theta23.nominal_value
