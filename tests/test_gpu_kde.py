@@ -311,3 +311,33 @@ def test_kde_stage_bootstrap():
         sel = ma.hist > 0.05 * ma.hist.max()
         assert np.median(ma.std_devs[sel] / ma.hist[sel]) < 0.5
     del plain_cfg
+
+
+def test_kde_stage_concurrent_estimators_are_bit_identical_to_sequential():
+    """`utils.kde` runs the estimators of one evaluation from four host threads on their own streams;
+    every estimator is deterministic by itself, so the maps must not depend on the interleaving:
+    repeated concurrent evaluations and a single-thread evaluation give the same bits."""
+    from collections import OrderedDict
+
+    from pisa_amd.core.config_parser import parse_pipeline_config
+    from pisa_amd.core.pipeline import Pipeline
+
+    cfg = OrderedDict()
+    for k, v in parse_pipeline_config("settings/pipeline/example_hip.cfg").items():
+        cfg[("utils", "kde") if k == ("utils", "hist") else k] = (
+            OrderedDict(calc_mode="events", apply_mode=v["apply_mode"]) if k == ("utils", "hist") else v)
+    cfg["pipeline"]["output_key"] = "weights"
+    cfg[("data", "synthetic_events")]["params"].params.n_events.value = 4.8e5
+    pipe = Pipeline(cfg)
+    stage = pipe["kde"]
+    assert stage.kde_workers > 1
+    runs = []
+    for workers in (stage.kde_workers, stage.kde_workers, 1, stage.kde_workers):
+        stage.kde_workers = workers
+        for s in pipe.stages:
+            s.param_hash = None        # evaluate again at the same parameters
+        runs.append([m.hist.copy() for m in pipe.get_outputs()])
+    for other in runs[1:]:
+        for a, b in zip(runs[0], other):
+            np.testing.assert_array_equal(a, b)
+    assert sum(m.sum() for m in runs[0]) > 0
