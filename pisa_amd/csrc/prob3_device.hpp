@@ -967,6 +967,123 @@ __device__ __forceinline__ void propagate_path_nested(const Prob3Side &S, const 
             P[3 * i + j] = Tf.m[j][i].re * Tf.m[j][i].re + Tf.m[j][i].im * Tf.m[j][i].im;
 }
 
+// Event-mode variant with the running product T in LDS ([18][lanes], one column of doubles per lane):
+// T is not needed while a layer matrix is formed, and a product  A.T  acts on T's columns (T.A on its
+// rows) independently, so it is done in place one column (row) at a time -- the registers hold one layer
+// matrix and six numbers of T instead of three matrices.
+struct TLds {
+    double *base;   // &lds[lane]
+    int stride;     // lanes
+    __device__ __forceinline__ cplx get(int i, int j) const {
+        return cmake(base[(6 * i + 2 * j) * stride], base[(6 * i + 2 * j + 1) * stride]);
+    }
+    __device__ __forceinline__ void put(int i, int j, cplx v) {
+        base[(6 * i + 2 * j) * stride] = v.re;
+        base[(6 * i + 2 * j + 1) * stride] = v.im;
+    }
+};
+
+template <bool DECAY, class LayerFn, class SrcFn>
+__device__ __forceinline__ void propagate_path_nested_lds(const Prob3Side &S, const double (&dm)[3][3],
+                                                          const int32_t (&vac_order)[3],
+                                                          double energy, int n_layers, int mid,
+                                                          const LayerFn &layer, const SrcFn &src,
+                                                          TLds T, double (&P)[9]) {
+    const double mv[3] = {0.0, 0.0, 0.0};
+    bool have = false;
+    auto amplitude = [&](int l, mat3 &A) {
+        double rho, dist;
+        layer(src(l), rho, dist);
+        if (DECAY) {
+            layer_amplitude<DECAY, true>(S, dm, energy, rho, dist, A, mv);
+        } else {
+            double rec[PROB3_NF_REDUCED];
+            auto store = [&](int f, double v) { rec[f] = v; };
+            eigen_terms<false>(S, dm, vac_order, energy, rho, store);
+            auto load = [&](int f) { return rec[f]; };
+            amplitude_from_terms<false>(load, dist / energy, A);
+            su3_complete(A);
+        }
+    };
+    auto set = [&](const mat3 &A) {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) T.put(i, j, A.m[i][j]);
+        have = true;
+    };
+    auto left = [&](const mat3 &A) {   // T <- A . T, column by column
+        if (!have) { set(A); return; }
+#pragma unroll 1
+        for (int j = 0; j < 3; j++) {
+            const cplx t0 = T.get(0, j), t1 = T.get(1, j), t2 = T.get(2, j);
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                cplx acc = cmul(A.m[i][0], t0);
+                acc = cadd(acc, cmul(A.m[i][1], t1));
+                acc = cadd(acc, cmul(A.m[i][2], t2));
+                T.put(i, j, acc);
+            }
+        }
+    };
+    auto right = [&](const mat3 &A) {  // T <- T . A, row by row
+        if (!have) { set(A); return; }
+#pragma unroll 1
+        for (int i = 0; i < 3; i++) {
+            const cplx t0 = T.get(i, 0), t1 = T.get(i, 1), t2 = T.get(i, 2);
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                cplx acc = cmul(t0, A.m[0][j]);
+                acc = cadd(acc, cmul(t1, A.m[1][j]));
+                acc = cadd(acc, cmul(t2, A.m[2][j]));
+                T.put(i, j, acc);
+            }
+        }
+    };
+    if (mid < 0) {
+        for (int l = 0; l < n_layers; l++) {
+            double rho, dist;
+            layer(l, rho, dist);
+            if (dist > 0.0) { mat3 A; amplitude(l, A); left(A); }
+        }
+    } else {
+        {
+            double rho, dist;
+            layer(mid, rho, dist);
+            if (dist > 0.0) { mat3 A; amplitude(mid, A); left(A); }
+        }
+        for (int s = 1; mid - s >= 0 || mid + s < n_layers; s++) {
+            const int li = mid - s, lo = mid + s;
+            double rho_i = 0.0, d_i = 0.0, rho_o = 0.0, d_o = 0.0;
+            if (li >= 0) layer(li, rho_i, d_i);
+            if (lo < n_layers) layer(lo, rho_o, d_o);
+            mat3 A;
+            const bool in_ok = li >= 0 && d_i > 0.0, out_ok = lo < n_layers && d_o > 0.0;
+            if (in_ok) {
+                amplitude(li, A);
+                right(A);
+            }
+            if (out_ok) {
+                const bool same = in_ok && src(lo) == src(li);
+                if (!same) amplitude(lo, A);
+                left(A);
+            }
+        }
+    }
+    mat3 Tm, t2, Tf;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Tm.m[i][j] = have ? T.get(i, j) : cmake(0.0, 0.0);
+    mat_mul(Tm, S.Ud, t2);
+    mat_mul(S.U, t2, Tf);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            P[3 * i + j] = Tf.m[j][i].re * Tf.m[j][i].re + Tf.m[j][i].im * Tf.m[j][i].im;
+}
+
 // P[init][final] of one node -> full matrix and/or the compact gather tables
 // pepmu[side][flav][node] = (P[e->flav], P[mu->flav]) read by the fused kernel
 __device__ __forceinline__ void store_node(const double (&P)[9], int64_t node, int64_t n_nodes,

@@ -44,11 +44,15 @@ struct EvArgs {
 // is needed (two square roots) and the per-lane path tables (10 bytes per segment and lane of LDS)
 // disappear: 0.220 -> 0.209 ms per 1e6 events.  STAGED = true is the general form (path, shell and
 // cache source of every segment staged in LDS).
-// Two wavefronts per SIMD is where the register allocation has no spills (201-221 VGPRs); builds for
-// three and four (168 / 128 VGPRs: 52-61 / 141-158 spilled registers, with or without the running
-// product parked in LDS) ran at 0.236 and 0.430 ms.
-template <bool DECAY, int SIDE, bool STAGED>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// WAVES = wavefronts per SIMD the registers are allocated for.  With everything in registers two is
+// where the allocation has no spills (201-221 VGPRs; builds for three and four -- 168 / 128 VGPRs, 52-61 /
+// 141-158 spilled registers -- ran at 0.236 and 0.430 ms).  WAVES = 3 (direct form, default) keeps the
+// running product T in LDS, [18][64] doubles per wavefront, and multiplies in place -- A.T acts on the
+// columns of T, T.A on its rows, one at a time (propagate_path_nested_lds): one layer matrix and six
+// numbers of T in registers instead of three matrices, 8 spilled registers at 168, 0.211 -> 0.202 ms;
+// four wavefronts still spill 97 (0.277 ms).
+template <bool DECAY, int SIDE, bool STAGED, int WAVES = 2>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 prob3_events_kernel(const Prob3Consts c, const EarthDev earth, const EvArgs ev, int max_seg,
                     int32_t *__restrict__ status) {
     // Workgroups are dealt to the containers round-robin (workgroup b = chunk b / n_cont of
@@ -141,7 +145,12 @@ prob3_events_kernel(const Prob3Consts c, const EarthDev earth, const EvArgs ev, 
             layer(mir, r2, d2);
             return (d2 > 0.0 && fabs(r2 - r1) < 1e-5 && fabs(d2 - d1) < 1e-5) ? mir : l;
         };
-        propagate_path_nested<DECAY>(c.side[side], c.dm, vac_order, energy[i], nseg, mid, layer, src, P);
+        if (WAVES > 2) {
+            TLds T{s_len + lane, bd};
+            propagate_path_nested_lds<DECAY>(c.side[side], c.dm, vac_order, energy[i], nseg, mid, layer, src, T, P);
+        } else {
+            propagate_path_nested<DECAY>(c.side[side], c.dm, vac_order, energy[i], nseg, mid, layer, src, P);
+        }
     }
     if (prob) {
 #pragma unroll
@@ -169,7 +178,10 @@ static int launch_events(const Prob3Consts &c, const EarthDev &e, const EvCont *
                 staged = true;
     static const int force_staged = [] { const char *v = getenv("PISA_HIP_EVENTS_STAGED"); return v ? atoi(v) : 0; }();
     if (force_staged) staged = true;   // development / test switch: the general form
-    size_t lds = 3 * PISA_HIP_MAX_SHELLS * sizeof(double) + (staged ? (size_t)max_seg * threads * 10 : 0) + 16;
+    // direct form: 3 wavefronts per SIMD with the running product in LDS (see the kernel); 2: product in registers
+    static const int waves_cfg = [] { const char *v = getenv("PISA_HIP_EVENTS_WAVES"); return v ? atoi(v) : 3; }();
+    size_t lds = 3 * PISA_HIP_MAX_SHELLS * sizeof(double) +
+                 (staged ? (size_t)max_seg * threads * 10 : (waves_cfg > 2 ? (size_t)18 * threads * 8 : 0)) + 16;
     // one launch per sign (see the kernel) and per EV_MAX_CONT containers
     for (int side = 0; side < 2; side++) {
         EvArgs a;
@@ -187,6 +199,7 @@ static int launch_events(const Prob3Consts &c, const EarthDev &e, const EvCont *
 #define LAUNCH_SIDE(D, ST) do { if (side == 0) LAUNCH_EV(D, 0, ST); else LAUNCH_EV(D, 1, ST); } while (0)
             if (c.decay) { if (staged) LAUNCH_SIDE(true, true); else LAUNCH_SIDE(true, false); }
             else if (staged) LAUNCH_SIDE(false, true);
+            else if (waves_cfg == 3) { if (side == 0) hipLaunchKernelGGL((prob3_events_kernel<false, 0, false, 3>), grid, block, lds, s, c, e, a, max_seg, d_status); else hipLaunchKernelGGL((prob3_events_kernel<false, 1, false, 3>), grid, block, lds, s, c, e, a, max_seg, d_status); }
             else LAUNCH_SIDE(false, false);
 #undef LAUNCH_SIDE
 #undef LAUNCH_EV
