@@ -91,8 +91,9 @@ prob3_terms_kernel(const Prob3Consts c, const double *__restrict__ energy, int n
     const int ie = blockIdx.z * 64 + threadIdx.x;
     if (ie >= n_e) return;
     const int64_t ns = (int64_t)gridDim.z * 64;
-    double *o = terms + ((int64_t)(side * n_unique + u) * PROB3_NF) * ns + ie;
-    auto store = [&](int f, double v) { o[(int64_t)f * ns] = v; };
+    // fields in pairs, [field / 2][E][2]: the chain kernel reads a record with 16-byte loads
+    double *o = terms + ((int64_t)(side * n_unique + u) * PROB3_NF) * ns + 2 * (int64_t)ie;
+    auto store = [&](int f, double v) { o[(int64_t)(f >> 1) * (2 * ns) + (f & 1)] = v; };
     eigen_terms<DECAY>(c.side[side], c.dm, c.vac_order, energy[ie], rho_unique[u], store);
 }
 
@@ -187,8 +188,8 @@ prob3_chain_kernel(const Prob3Consts c, int n_e, const int32_t *__restrict__ row
     auto load_pair = [&](int pos, mat3 &A) {
         if (AMP != 0) {
             // `amp` holds the stage-A records here
-            const double *r = amp + ((int64_t)(side * n_unique + pair_u[pos]) * PROB3_NF) * ns + ie;
-            auto load = [&](int f) { return r[(int64_t)f * ns]; };
+            const double *r = amp + ((int64_t)(side * n_unique + pair_u[pos]) * PROB3_NF) * ns + 2 * (int64_t)ie;
+            auto load = [&](int f) { return r[(int64_t)(f >> 1) * (2 * ns) + (f & 1)]; };
             amplitude_from_terms<AMP == 2>(load, pair_dist[pos] * inv_e, A);
             if (AMP == 1) su3_complete(A);
             return;
