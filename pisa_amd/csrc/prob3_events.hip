@@ -51,6 +51,118 @@ struct EvArgs {
 // columns of T, T.A on its rows, one at a time (propagate_path_nested_lds): one layer matrix and six
 // numbers of T in registers instead of three matrices, 8 spilled registers at 168, 0.211 -> 0.202 ms;
 // four wavefronts still spill 97 (0.277 ms).
+// Direct form of the nested walk (no decay, pairwise distinct shell densities, running product T in
+// LDS): the path geometry is unrolled into the loop instead of being asked for segment by segment.
+// Walking outwards from the innermost chord, shell k is crossed once on the way in (segment
+// l_k - l_{k+1}) and once on the way out (s_{k+1} - s_k), and both lengths are differences of the
+// SAME two root terms sqrt(base + r^2) -- the inner one is carried over from the previous step, so a
+// step costs one square root where path_segment() through the layer / cache-source callbacks cost
+// up to twelve (each 18 instructions).  Lengths, densities, the cache rule (the out-going segment
+// takes the in-going one's matrix iff their lengths agree to 1e-5, numba_osc_kernels.py:236-249) and
+// the order of the products are those of propagate_path_nested_lds: results are bit-identical.
+template <class E>
+__device__ __forceinline__ void propagate_path_direct_lds(const Prob3Side &S, const double (&dm)[3][3],
+                                                          const int32_t (&vac_order)[3], double energy,
+                                                          const E &e, const PathGeom &g, bool ok,
+                                                          TLds T, double (&P)[9], int32_t *status) {
+    bool have = false;
+    auto amplitude = [&](double rho, double dist, mat3 &A) {
+        double rec[PROB3_NF_REDUCED];
+        auto store = [&](int f, double v) { rec[f] = v; };
+        eigen_terms<false>(S, dm, vac_order, energy, rho, store);
+        auto load = [&](int f) { return rec[f]; };
+        amplitude_from_terms<false>(load, dist / energy, A);
+        su3_complete(A);
+    };
+    auto set = [&](const mat3 &A) {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) T.put(i, j, A.m[i][j]);
+        have = true;
+    };
+    auto left = [&](const mat3 &A) {   // T <- A . T, column by column
+        if (!have) { set(A); return; }
+#pragma unroll 1
+        for (int j = 0; j < 3; j++) {
+            const cplx t0 = T.get(0, j), t1 = T.get(1, j), t2 = T.get(2, j);
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                cplx acc = cmul(A.m[i][0], t0);
+                acc = cadd(acc, cmul(A.m[i][1], t1));
+                acc = cadd(acc, cmul(A.m[i][2], t2));
+                T.put(i, j, acc);
+            }
+        }
+    };
+    auto right = [&](const mat3 &A) {  // T <- T . A, row by row
+        if (!have) { set(A); return; }
+#pragma unroll 1
+        for (int i = 0; i < 3; i++) {
+            const cplx t0 = T.get(i, 0), t1 = T.get(i, 1), t2 = T.get(i, 2);
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                cplx acc = cmul(t0, A.m[0][j]);
+                acc = cadd(acc, cmul(t1, A.m[1][j]));
+                acc = cadd(acc, cmul(t2, A.m[2][j]));
+                T.put(i, j, acc);
+            }
+        }
+    };
+    auto checked = [&](double len) {   // a NaN length (the reference's construction broke down): flag, skip
+        if (!(len == len)) { len = 0.0; if (status) atomicOr(status, 1); }
+        return len;
+    };
+    // One loop for both geometries, two amplitude sites.  Up-going (case B of layers.py:94): step t
+    // takes shell k = m-1-t, the innermost chord first (in-going "segment" = the whole chord, nothing
+    // out-going), then the pairs outwards.  Down-going (case A): the shells above the detector in path
+    // order, each a lone out-going segment (layers.py:95-101).  r_c carries the root term of the
+    // previous step.
+    const bool tf = g.tangent_free;
+    const int m = g.m;
+    const int n_steps = ok ? (tf ? e.idx : m) : 0;
+    double r_c = tf ? root_term(e, g, 0) : 0.0;
+    for (int t = 0; t < n_steps; t++) {
+        const int k = tf ? t : m - 1 - t;
+        const bool last_tf = t == e.idx - 1;
+        const double r_n = (tf && last_tf) ? 0.0 : root_term(e, g, tf ? t + 1 : k);
+        double d_i = 0.0, d_o = 0.0;
+        if (tf) {
+            d_o = checked((g.neg_rd_cz + r_c) - (last_tf ? 0.0 : (g.neg_rd_cz + r_n)));
+        } else if (t == 0) {
+            d_i = checked((g.neg_rd_cz + r_n) - (g.neg_rd_cz - r_n));
+        } else {
+            d_i = checked((g.neg_rd_cz + r_n) - (g.neg_rd_cz + r_c));
+            if (k >= 1) d_o = checked((g.neg_rd_cz - r_c) - (k >= e.idx ? (g.neg_rd_cz - r_n) : 0.0));
+        }
+        const double rho = e.rhos[k];
+        mat3 A;
+        const bool in_ok = d_i > 0.0, out_ok = d_o > 0.0;
+        if (in_ok) {
+            amplitude(rho, d_i, A);
+            right(A);
+        }
+        if (out_ok) {
+            const bool same = in_ok && fabs(d_o - d_i) < 1e-5;
+            if (!same) amplitude(rho, d_o, A);
+            left(A);
+        }
+        r_c = r_n;
+    }
+    mat3 Tm, t2, Tf;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Tm.m[i][j] = have ? T.get(i, j) : cmake(0.0, 0.0);
+    mat_mul(Tm, S.Ud, t2);
+    mat_mul(S.U, t2, Tf);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            P[3 * i + j] = Tf.m[j][i].re * Tf.m[j][i].re + Tf.m[j][i].im * Tf.m[j][i].im;
+}
+
 template <bool DECAY, int SIDE, bool STAGED, int WAVES = 2>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 prob3_events_kernel(const Prob3Consts c, const EarthDev earth, const EvArgs ev, int max_seg,
@@ -145,7 +257,10 @@ prob3_events_kernel(const Prob3Consts c, const EarthDev earth, const EvArgs ev, 
             layer(mir, r2, d2);
             return (d2 > 0.0 && fabs(r2 - r1) < 1e-5 && fabs(d2 - d1) < 1e-5) ? mir : l;
         };
-        if (WAVES > 2) {
+        if (WAVES > 2 && !DECAY) {
+            TLds T{s_len + lane, bd};
+            propagate_path_direct_lds(c.side[side], c.dm, vac_order, energy[i], e, g, ok, T, P, status);
+        } else if (WAVES > 2) {
             TLds T{s_len + lane, bd};
             propagate_path_nested_lds<DECAY>(c.side[side], c.dm, vac_order, energy[i], nseg, mid, layer, src, T, P);
         } else {
