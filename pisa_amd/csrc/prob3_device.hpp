@@ -565,7 +565,29 @@ constexpr int PROB3_NF = 60;  // fields per record, decay form: M[3] (re,im) + Q
 constexpr int PROB3_NF_REDUCED = 18;  // without decay (see eigen_terms)
 
 // field(f) = value callback; f in [0, PROB3_NF)
-template <bool DECAY, class StoreFn>
+// Reciprocal and square root without the range scaling of the IEEE-complete library forms (12 and
+// 18 instructions): hardware estimate (23 bits) + Newton steps in fused arithmetic, <= 1 ulp for
+// arguments in the normal range; fast_sqrt(0) = 0.  Event mode only (eigen_terms<false, true>), where
+// the kernel is bound by instruction issue.
+__device__ __forceinline__ double fast_rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double r = __builtin_fma(-x, y, 1.0);
+    y = __builtin_fma(y, r, y);
+    r = __builtin_fma(-x, y, 1.0);
+    return __builtin_fma(y, r, y);
+}
+__device__ __forceinline__ double fast_sqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return x == 0.0 ? 0.0 : g;
+}
+
+template <bool DECAY, bool FAST = false, class StoreFn>
 __device__ __forceinline__ void eigen_terms(const Prob3Side &S, const double (&dm)[3][3],
                                             const int32_t (&vac_order)[3], double energy, double rho,
                                             const StoreFn &store) {
@@ -606,8 +628,8 @@ __device__ __forceinline__ void eigen_terms(const Prob3Side &S, const double (&d
             const double q = -13.5 * c0 - c2 * (c2 * c2) + 4.5 * c1 * c2;
             double tmp = 27 * (0.25 * (c1 * c1) * (p - c1) + c0 * (q + 6.75 * c0));
             tmp = fmax(0.0, tmp);
-            const double res = atan2(sqrt(tmp), q) * (1.0 / 3.0);
-            const double b = (2.0 / 3.0) * sqrt(p);
+            const double res = atan2(FAST ? fast_sqrt(tmp) : sqrt(tmp), q) * (1.0 / 3.0);
+            const double b = (2.0 / 3.0) * (FAST ? fast_sqrt(p) : sqrt(p));
             double sn, cs;
             sincos_phase(res, &sn, &cs);
             const double ca = -0.5, sb = 0.86602540378443864676;  // cos, sin of 2pi/3
@@ -638,7 +660,7 @@ __device__ __forceinline__ void eigen_terms(const Prob3Side &S, const double (&d
             // Q_1 = (X - M_2)(X - M_0) / den_1,  Q_2 = (X - M_0)(X - M_1) / den_2
             const double sa_ = k == 1 ? Mr[2] : Mr[0], sb_ = k == 1 ? Mr[0] : Mr[1];
             const double den = k == 1 ? (Mr[1] - Mr[2]) * (Mr[1] - Mr[0]) : (Mr[2] - Mr[0]) * (Mr[2] - Mr[1]);
-            const double inv = 1.0 / den;   // one reciprocal per eigenvalue
+            const double inv = FAST ? fast_rcp(den) : 1.0 / den;   // one reciprocal per eigenvalue
             const double a0 = x0 - sa_, a1 = x1 - sa_, b0 = x0 - sb_, b1 = x1 - sb_, b2 = x2 - sb_;
             const int base = 2 + 8 * (k - 1);
             store(base + 0, (a0 * b0 + uu + vv) * inv);

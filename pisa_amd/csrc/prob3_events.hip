@@ -66,12 +66,13 @@ __device__ __forceinline__ void propagate_path_direct_lds(const Prob3Side &S, co
                                                           const E &e, const PathGeom &g, bool ok,
                                                           TLds T, double (&P)[9], int32_t *status) {
     bool have = false;
+    const double inv_energy = fast_rcp(energy);
     auto amplitude = [&](double rho, double dist, mat3 &A) {
         double rec[PROB3_NF_REDUCED];
         auto store = [&](int f, double v) { rec[f] = v; };
-        eigen_terms<false>(S, dm, vac_order, energy, rho, store);
+        eigen_terms<false, true>(S, dm, vac_order, energy, rho, store);
         auto load = [&](int f) { return rec[f]; };
-        amplitude_from_terms<false>(load, dist / energy, A);
+        amplitude_from_terms<false>(load, dist * inv_energy, A);
         su3_complete(A);
     };
     auto set = [&](const mat3 &A) {
@@ -118,14 +119,15 @@ __device__ __forceinline__ void propagate_path_direct_lds(const Prob3Side &S, co
     // out-going), then the pairs outwards.  Down-going (case A): the shells above the detector in path
     // order, each a lone out-going segment (layers.py:95-101).  r_c carries the root term of the
     // previous step.
+    auto root = [&](int k) { return fast_sqrt(g.base + e.radii[k] * e.radii[k]); };   // root_term()
     const bool tf = g.tangent_free;
     const int m = g.m;
     const int n_steps = ok ? (tf ? e.idx : m) : 0;
-    double r_c = tf ? root_term(e, g, 0) : 0.0;
+    double r_c = tf ? root(0) : 0.0;
     for (int t = 0; t < n_steps; t++) {
         const int k = tf ? t : m - 1 - t;
         const bool last_tf = t == e.idx - 1;
-        const double r_n = (tf && last_tf) ? 0.0 : root_term(e, g, tf ? t + 1 : k);
+        const double r_n = (tf && last_tf) ? 0.0 : root(tf ? t + 1 : k);
         double d_i = 0.0, d_o = 0.0;
         if (tf) {
             d_o = checked((g.neg_rd_cz + r_c) - (last_tf ? 0.0 : (g.neg_rd_cz + r_n)));
