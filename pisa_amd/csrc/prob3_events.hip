@@ -50,7 +50,7 @@ struct EvArgs {
 // running product T in LDS, [18][64] doubles per wavefront, and multiplies in place -- A.T acts on the
 // columns of T, T.A on its rows, one at a time (propagate_path_nested_lds): one layer matrix and six
 // numbers of T in registers instead of three matrices, 8 spilled registers at 168, 0.211 -> 0.202 ms;
-// four wavefronts still spill 97 (0.277 ms).
+// four wavefronts still spill 97 (0.277 ms; with the direct walk of propagate_path_direct_lds 36, 0.200 against 0.158 ms).
 // Direct form of the nested walk (no decay, pairwise distinct shell densities, running product T in
 // LDS): the path geometry is unrolled into the loop instead of being asked for segment by segment.
 // Walking outwards from the innermost chord, shell k is crossed once on the way in (segment
