@@ -67,39 +67,56 @@ __device__ __forceinline__ void propagate_path_direct_lds(const Prob3Side &S, co
                                                           TLds T, double (&P)[9], int32_t *status) {
     bool have = false;
     const double inv_energy = fast_rcp(energy);
-    auto amplitude = [&](double rho, double dist, mat3 &A) {
+    // Every layer matrix A' is in SU(3) (eigen_terms), so the running product T is as well: its third
+    // row is the conjugate cross product of the first two.  Only rows 0 and 1 of T are kept ([12][64]
+    // doubles of LDS per wavefront).  T.A needs those two rows and all of A (su3_complete); A.T needs
+    // rows 0 and 1 of A and all of T (one cross product): 48 complex products per shell pair
+    // instead of 60, and two thirds of the LDS traffic.
+    auto amplitude = [&](double rho, double dist, mat3 &A) {   // rows 0 and 1
         double rec[PROB3_NF_REDUCED];
         auto store = [&](int f, double v) { rec[f] = v; };
         eigen_terms<false, true>(S, dm, vac_order, energy, rho, store);
         auto load = [&](int f) { return rec[f]; };
         amplitude_from_terms<false>(load, dist * inv_energy, A);
-        su3_complete(A);
+    };
+    auto third_row = [](const cplx (&r0)[3], const cplx (&r1)[3], cplx (&r2)[3]) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int k = (j + 1) % 3, l = (j + 2) % 3;
+            const cplx c = csub(cmul(r0[k], r1[l]), cmul(r0[l], r1[k]));
+            r2[j] = cmake(c.re, -c.im);
+        }
     };
     auto set = [&](const mat3 &A) {
 #pragma unroll
-        for (int i = 0; i < 3; i++)
+        for (int i = 0; i < 2; i++)
 #pragma unroll
             for (int j = 0; j < 3; j++) T.put(i, j, A.m[i][j]);
         have = true;
     };
-    auto left = [&](const mat3 &A) {   // T <- A . T, column by column
+    auto left = [&](const mat3 &A) {   // T <- A . T  (rows 0, 1 of A)
         if (!have) { set(A); return; }
-#pragma unroll 1
-        for (int j = 0; j < 3; j++) {
-            const cplx t0 = T.get(0, j), t1 = T.get(1, j), t2 = T.get(2, j);
+        cplx t[3][3];
 #pragma unroll
-            for (int i = 0; i < 3; i++) {
-                cplx acc = cmul(A.m[i][0], t0);
-                acc = cadd(acc, cmul(A.m[i][1], t1));
-                acc = cadd(acc, cmul(A.m[i][2], t2));
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) t[i][j] = T.get(i, j);
+        third_row(t[0], t[1], t[2]);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                cplx acc = cmul(A.m[i][0], t[0][j]);
+                acc = cadd(acc, cmul(A.m[i][1], t[1][j]));
+                acc = cadd(acc, cmul(A.m[i][2], t[2][j]));
                 T.put(i, j, acc);
             }
-        }
     };
-    auto right = [&](const mat3 &A) {  // T <- T . A, row by row
+    auto right = [&](mat3 &A) {  // T <- T . A, row by row (completes A)
+        su3_complete(A);
         if (!have) { set(A); return; }
 #pragma unroll 1
-        for (int i = 0; i < 3; i++) {
+        for (int i = 0; i < 2; i++) {
             const cplx t0 = T.get(i, 0), t1 = T.get(i, 1), t2 = T.get(i, 2);
 #pragma unroll
             for (int j = 0; j < 3; j++) {
@@ -153,9 +170,10 @@ __device__ __forceinline__ void propagate_path_direct_lds(const Prob3Side &S, co
     }
     mat3 Tm, t2, Tf;
 #pragma unroll
-    for (int i = 0; i < 3; i++)
+    for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int j = 0; j < 3; j++) Tm.m[i][j] = have ? T.get(i, j) : cmake(0.0, 0.0);
+    third_row(Tm.m[0], Tm.m[1], Tm.m[2]);
     mat_mul(Tm, S.Ud, t2);
     mat_mul(S.U, t2, Tf);
 #pragma unroll
@@ -298,7 +316,7 @@ static int launch_events(const Prob3Consts &c, const EarthDev &e, const EvCont *
     // direct form: 3 wavefronts per SIMD with the running product in LDS (see the kernel); 2: product in registers
     static const int waves_cfg = [] { const char *v = getenv("PISA_HIP_EVENTS_WAVES"); return v ? atoi(v) : 3; }();
     size_t lds = 3 * PISA_HIP_MAX_SHELLS * sizeof(double) +
-                 (staged ? (size_t)max_seg * threads * 10 : (waves_cfg > 2 ? (size_t)18 * threads * 8 : 0)) + 16;
+                 (staged ? (size_t)max_seg * threads * 10 : (waves_cfg > 2 ? (size_t)12 * threads * 8 : 0)) + 16;
     // one launch per sign (see the kernel) and per EV_MAX_CONT containers
     for (int side = 0; side < 2; side++) {
         EvArgs a;
