@@ -200,6 +200,8 @@ def test_calc_layers_bit_exact(K, L, oracle, tag):
 
 def test_prob3_events_vs_oracle(K, L, oracle):
     """event mode: in-kernel layers == oracle layers + oracle propagate"""
+    import torch
+
     gl = load_golden("layers_ref.npz")
     gg = load_golden("prob3_grid_prem12.npz")
     rs = np.random.RandomState(5)
@@ -227,6 +229,18 @@ def test_prob3_events_vs_oracle(K, L, oracle):
                 ref = oracle.propagate_array(*pa, nubar, e, lay.density, lay.distance)
                 out = K.prob3_events(p, earth, nubar, K.to_device(e), K.to_device(cz)).cpu().numpy()
                 np.testing.assert_allclose(out, ref, err_msg="%s %s %d" % (tag, name, nubar), **AC)
+                # the gather pair alone (what the fused reweighting asks for: P[e -> flav], P[mu -> flav]):
+                # the same bits as the full matrices
+                d_e, d_cz = K.to_device(e), K.to_device(cz)
+                pairs = [torch.full((n, 2), np.nan, dtype=torch.float64, device="cuda") for _ in range(3)]
+                sets = [L.EventSet(n, d_e.data_ptr(), d_cz.data_ptr(), None, pairs[f].data_ptr(), nubar, f)
+                        for f in range(3)]
+                status = torch.zeros(1, dtype=torch.int32, device="cuda")
+                K.prob3_events_multi(p, earth, sets, status)
+                assert int(status.item()) == 0
+                for f in range(3):
+                    np.testing.assert_array_equal(pairs[f].cpu().numpy(), out[:, :2, f],
+                                                  err_msg="%s %s %d pair %d" % (tag, name, nubar, f))
 
 
 # ------------------------------------------------------------ translation
