@@ -254,8 +254,10 @@ typedef struct {
  * the call) -- exact sums in 192-bit fixed point spread over six 32-bit-spaced
  * limbs, safe to SUM-all-reduce across ranks (integer addition is associative
  * => bit-reproducible for any workgroup schedule and any GPU count).
- * d_pepmu: gather tables of pisa_hip_prob3_grid (required for the indexed form,
- * else d_prob_nu / d_prob_nubar are read).
+ * d_pepmu: gather tables of pisa_hip_prob3_grid (required for the indexed forms; the coordinate
+ * form reads them too when they are given -- one 16-byte gather per event instead of two 8-byte ones
+ * from the 72-byte records of d_prob_nu / d_prob_nubar, 25 % of that kernel -- and the full matrices
+ * otherwise; both hold the same numbers).
  * d_status: int32 flag, set non-zero if a weight is not finite or >= 2^76. */
 int pisa_hip_reweight_hist(const pisa_hip_container *h_containers, int32_t n_containers,
                            const pisa_hip_binning *h_calc_grid, const double *d_prob_nu,

@@ -99,6 +99,32 @@ __device__ __forceinline__ bool bin_index(const DevBinning &b, double x, double 
     return true;
 }
 
+// bin_index without early exits and with the number of dimensions known at compile time: `flat` is
+// always a valid index (0 for a point outside), the return value says whether the point is inside --
+// same comparisons, same arithmetic (the flat index fits 32 bits: checked by the launcher)
+template <int ND>
+__device__ __forceinline__ bool bin_index_flat(const DevBinning &b, double x, double y, double z,
+                                               int &flat) {
+    bool ok = x >= b.mins[0] && x < b.maxs[0];
+    int ix = (int)((x - b.mins[0]) * b.norm[0]);
+    ix = ix < b.nb[0] ? ix : b.nb[0] - 1;
+    int f = ix;
+    if (ND > 1) {
+        ok = ok && (y >= b.mins[1] && y < b.maxs[1]);
+        int iy = (int)((y - b.mins[1]) * b.norm[1]);
+        iy = iy < b.nb[1] ? iy : b.nb[1] - 1;
+        f = f * b.nb[1] + iy;
+    }
+    if (ND > 2) {
+        ok = ok && (z >= b.mins[2] && z < b.maxs[2]);
+        int iz = (int)((z - b.mins[2]) * b.norm[2]);
+        iz = iz < b.nb[2] ? iz : b.nb[2] - 1;
+        f = f * b.nb[2] + iz;
+    }
+    flat = ok ? f : 0;
+    return ok;
+}
+
 __global__ void __launch_bounds__(256)
 event_indices_kernel(const DevBinning b, const double *__restrict__ x,
                      const double *__restrict__ y, const double *__restrict__ z, int64_t n,
@@ -153,7 +179,8 @@ struct HistArgs {
 //         factors associated first; differs from MODE 3 by rounding only (<= 3 ulp per weight)
 // MODE 7: MODE 5 with the two indices in 16 bits each (grids and binnings below 65535 entries):
 //         20 B per event, four events per thread and sweep so that every load stays 16 bytes
-template <int MODE, bool LDS_ACC>
+// DIMS (MODE 1 only) = 4 * (dimensions of the calc grid) + (dimensions of the output binning)
+template <int MODE, bool LDS_ACC, int DIMS = 0>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
 hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limbs,
                        int32_t *__restrict__ status) {
@@ -439,30 +466,92 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
         const double *prob = MODE == 1 ? a.prob[C.side] : nullptr;
         const int po_e = 0 * 3 + C.flav;   // P[e  -> flav]
         const int po_mu = 1 * 3 + C.flav;  // P[mu -> flav]
-        for (int64_t i = start + threadIdx.x; i < end; i += nthreads) {
-            double w;
-            if (MODE == 1) {
+        if (MODE == 1) {
+            // SURVEY section 8(d)'s unit of work: 72 B per event in eight column streams, both
+            // digitisations in the kernel.  All streaming loads of an event are issued before anything
+            // depends on one of them and nothing branches in between (an event outside the calc grid
+            // gathers node 0 and multiplies by 0): one HBM round trip + one gather per sweep.  With the
+            // lookup's early exits between the loads a sweep was three to four dependent round trips
+            // (204 us for 10^7 events).
+            constexpr int GD = DIMS >> 2, OD = DIMS & 3;
+            constexpr bool g2 = GD > 1;
+            const double2 *__restrict__ flux2 = reinterpret_cast<const double2 *>(C.flux);
+            const double cscale = C.scale;
+            // The gather is what this kernel waits for when it goes to the full matrices: 2.9 MB of
+            // 72-byte records that the 720 MB column stream keeps pushing out of the L2 (all gathers
+            // forced to one node: 202 -> 139 us for 10^7 events); the compact tables, 320 KB per class
+            // and one 16-byte gather per event, are used whenever the caller provides them.
+            const double2 *__restrict__ tab =
+                a.pepmu ? a.pepmu + ((int64_t)C.side * 3 + C.flav) * a.n_nodes : nullptr;
+            auto event = [&](double gx, double gy, double2 f, double w0, double ae, double x, double y, double z) {
                 // grid -> event lookup of prob_e, prob_mu (container.py:981-1012,
                 // translation.py:427-438): 0 outside the grid
-                double pe = 0.0, pmu = 0.0;
-                int64_t node;
-                if (bin_index(a.grid, C.gx[i], a.grid.ndim > 1 ? C.gy[i] : 0.0, 0.0, node)) {
+                int node;
+                const bool in = bin_index_flat<GD>(a.grid, gx, gy, 0.0, node);
+                double pe, pmu;
+                if (tab) {   // compact (P_e, P_mu) table of this container's class: one 16-byte gather
+                    const double2 pp = tab[node];
+                    pe = pp.x;
+                    pmu = pp.y;
+                } else {     // two 8-byte gathers from the 72-byte-stride P[node][3][3] table
                     pe = prob[9 * node + po_e];
                     pmu = prob[9 * node + po_mu];
                 }
-                double2 f = reinterpret_cast<const double2 *>(C.flux)[i];
-                w = C.w0[i];
-                w = w * ((f.x * pe) + (f.y * pmu));   // prob3.py:622
-                w = w * (C.aeff[i] * C.scale);        // aeff.py:87
+                pe = in ? pe : 0.0;
+                pmu = in ? pmu : 0.0;
+                double w = w0 * ((f.x * pe) + (f.y * pmu));   // prob3.py:622
+                w = w * (ae * cscale);                        // aeff.py:87
+                int bin;
+                if (bin_index_flat<OD>(a.outb, x, y, z, bin)) accumulate(bin, w, w * w);
+            };
+            // every column 16-byte aligned (checked per workgroup, uniform): two consecutive events per
+            // thread and sweep with 16-byte loads, the workgroups of a container sweeping its columns
+            // together like the packed forms
+            uintptr_t bits = (uintptr_t)C.gx | (uintptr_t)C.flux | (uintptr_t)C.w0 | (uintptr_t)C.aeff | (uintptr_t)C.s[0];
+            if (g2) bits |= (uintptr_t)C.gy;
+            if (OD > 1) bits |= (uintptr_t)C.s[1];
+            if (OD > 2) bits |= (uintptr_t)C.s[2];
+            if ((bits & 15) == 0) {
+                const double2 *__restrict__ gx2 = reinterpret_cast<const double2 *>(C.gx);
+                const double2 *__restrict__ gy2 = reinterpret_cast<const double2 *>(C.gy);
+                const double2 *__restrict__ w02 = reinterpret_cast<const double2 *>(C.w0);
+                const double2 *__restrict__ ae2 = reinterpret_cast<const double2 *>(C.aeff);
+                const double2 *__restrict__ x2 = reinterpret_cast<const double2 *>(C.s[0]);
+                const double2 *__restrict__ y2 = reinterpret_cast<const double2 *>(C.s[1]);
+                const double2 *__restrict__ z2 = reinterpret_cast<const double2 *>(C.s[2]);
+                const double2 zero = make_double2(0.0, 0.0);
+                const int64_t n_wg1 = a.blk_start[c + 1] - a.blk_start[c];
+                for (int64_t q = lb * nthreads + threadIdx.x; q < (C.n >> 1); q += n_wg1 * nthreads) {
+                    const double2 gx = gx2[q];
+                    const double2 gy = g2 ? gy2[q] : zero;
+                    const double2 fa = flux2[2 * q], fb = flux2[2 * q + 1];
+                    const double2 w0 = w02[q], ae = ae2[q];
+                    const double2 x = x2[q];
+                    const double2 y = OD > 1 ? y2[q] : zero;
+                    const double2 z = OD > 2 ? z2[q] : zero;
+                    event(gx.x, gy.x, fa, w0.x, ae.x, x.x, y.x, z.x);
+                    event(gx.y, gy.y, fb, w0.y, ae.y, x.y, y.y, z.y);
+                }
+                if ((C.n & 1) && lb == 0 && threadIdx.x == 0) {  // odd tail of the container
+                    const int64_t i = C.n - 1;
+                    event(C.gx[i], g2 ? C.gy[i] : 0.0, flux2[i], C.w0[i], C.aeff[i], C.s[0][i],
+                          OD > 1 ? C.s[1][i] : 0.0, OD > 2 ? C.s[2][i] : 0.0);
+                }
             } else {
-                w = C.w0 ? C.w0[i] : 1.0;
+                for (int64_t i = start + threadIdx.x; i < end; i += nthreads)
+                    event(C.gx[i], g2 ? C.gy[i] : 0.0, flux2[i], C.w0[i], C.aeff[i], C.s[0][i],
+                          OD > 1 ? C.s[1][i] : 0.0, OD > 2 ? C.s[2][i] : 0.0);
             }
-            int64_t bin;
-            double x = C.s[0][i];
-            double y = a.outb.ndim > 1 ? C.s[1][i] : 0.0;
-            double z = a.outb.ndim > 2 ? C.s[2][i] : 0.0;
-            if (!bin_index(a.outb, x, y, z, bin)) continue;
-            accumulate((int)bin, w, MODE == 1 ? w * w : 1.0);
+        } else {
+            for (int64_t i = start + threadIdx.x; i < end; i += nthreads) {
+                const double w = C.w0 ? C.w0[i] : 1.0;
+                int64_t bin;
+                double x = C.s[0][i];
+                double y = a.outb.ndim > 1 ? C.s[1][i] : 0.0;
+                double z = a.outb.ndim > 2 ? C.s[2][i] : 0.0;
+                if (!bin_index(a.outb, x, y, z, bin)) continue;
+                accumulate((int)bin, w, 1.0);
+            }
         }
     }
     if (bad && status) atomicOr(status, 1);
@@ -796,7 +885,17 @@ static int run_hist(const ContDev *conts, int n_cont, int mode, const DevBinning
         else if (mode == 5) { if (lds) LAUNCH(5, true); else LAUNCH(5, false); }
         else if (mode == 3) { if (lds) LAUNCH(3, true); else LAUNCH(3, false); }
         else if (mode == 2) { if (lds) LAUNCH(2, true); else LAUNCH(2, false); }
-        else if (mode == 1) { if (lds) LAUNCH(1, true); else LAUNCH(1, false); }
+        else if (mode == 1) {
+            // dimensions as template parameters (uniform branches around the loads and 64-bit index
+            // arithmetic otherwise: 1 080 instructions per pair of events)
+            const int gd = a.grid.ndim, od = a.outb.ndim;
+            if (gd < 1 || gd > 2 || od < 1 || od > 3 || n_nodes >= (1LL << 31) / 9) return PISA_HIP_ERR_INVALID;
+#define LAUNCH1(G, O) do { if (lds) hipLaunchKernelGGL((hist_accumulate_kernel<1, true, 4 * G + O>), grid_dim, block, shmem, s, a, out, d_status); \
+                           else hipLaunchKernelGGL((hist_accumulate_kernel<1, false, 4 * G + O>), grid_dim, block, shmem, s, a, out, d_status); } while (0)
+            if (gd == 1) { if (od == 1) LAUNCH1(1, 1); else if (od == 2) LAUNCH1(1, 2); else LAUNCH1(1, 3); }
+            else { if (od == 1) LAUNCH1(2, 1); else if (od == 2) LAUNCH1(2, 2); else LAUNCH1(2, 3); }
+#undef LAUNCH1
+        }
         else { if (lds) LAUNCH(0, true); else LAUNCH(0, false); }
 #undef LAUNCH
         PISA_CHECK_LAUNCH("hist_accumulate_kernel");
