@@ -485,3 +485,62 @@ def test_scaled_tail_kernel_matches_host_scaling(oracle):
         _, want2 = oracle.metric(kind, data, hist.sum(axis=0) + extra[0], sumw2.sum(axis=0) + extra[1])
         np.testing.assert_allclose(only_extra, want2, rtol=1e-12, err_msg=kind)
     st.check_status()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("out_dims", [3, 1])
+def test_coordinate_form_paths_are_bit_identical(out_dims):
+    """the SURVEY 8(d)-shaped kernel (coordinates digitised in the kernel) has a pair path (16-byte
+    loads, all columns 16-byte aligned), a scalar path (any 8-byte aligned pointers: what a foreign
+    caller of the C-ABI may hand over) and two gather sources (compact tables when given, else the
+    full matrices): all of them, and the pre-digitised form, give the same limbs bit for bit"""
+    import ctypes
+
+    import torch
+
+    from pisa_amd import _lib, kernels as K, synthetic
+
+    wl = synthetic.Workload(n_events=12 * 4001, grid=(30, 20), out_binning="dragon", seed=11)   # odd containers
+    st = synthetic.DeviceState(wl, indexed=False)
+    p = wl.osc_params(theta23_deg=47.0)
+    st.compute_probs(p)
+    D = synthetic.DRAGON
+    out_b = st.out_binning if out_dims == 3 else _lib.make_binning(D["mins"][:1], D["maxs"][:1], D["nbins"][:1])
+    n_bins = int(np.prod(D["nbins"][:out_dims]))
+
+    def run(cs, pepmu):
+        ws = K.HistWorkspace(len(cs), n_bins, st.dev)
+        K.reweight_hist(cs, st.grid.binning, st.prob_nu, st.prob_nubar, pepmu, out_b, ws)
+        assert int(ws.status.item()) == 0
+        return ws.limbs.clone()
+
+    pairs = run(st._cont_arr, st.pepmu)
+    assert int(pairs.abs().sum().item()) > 0
+    if out_dims == 3:
+        ref = synthetic.DeviceState(wl, indexed=True, compact=False)
+        ref.accumulate(p)
+        assert torch.equal(pairs, ref.ws.limbs)
+    assert torch.equal(run(st._cont_arr, None), pairs)   # gathers from the full matrices
+    # the same columns moved by one element: 8-byte aligned only -> scalar path
+    keep, shifted = [], []
+    per = 5 + 3
+    for ci, c in enumerate(st.cont):
+        d = _lib.Container()
+        ctypes.memmove(ctypes.byref(d), ctypes.byref(c), ctypes.sizeof(d))
+        cols = st._keep[per * ci:per * (ci + 1)]
+        assert cols[0].data_ptr() == c.d_grid_x and cols[4].data_ptr() == c.d_initial_weights \
+            and cols[7].data_ptr() == c.d_sample[2]
+        moved = []
+        for t in cols:
+            buf = torch.empty(t.numel() + 1, dtype=torch.float64, device=st.dev)
+            buf[1:] = t.reshape(-1)
+            assert buf[1:].data_ptr() % 16 == 8
+            keep.append(buf)
+            moved.append(buf[1:].data_ptr())
+        d.d_grid_x, d.d_grid_y, d.d_nu_flux, d.d_weighted_aeff, d.d_initial_weights = moved[:5]
+        for k in range(3):
+            d.d_sample[k] = moved[5 + k]
+        shifted.append(d)
+    assert torch.equal(run(shifted, st.pepmu), pairs)
+    assert torch.equal(run(shifted, None), pairs)
+    torch.cuda.synchronize()
