@@ -203,6 +203,54 @@ __device__ __forceinline__ void get_dms_vacuum(double energy, const double (&dm)
         mv[i] = 2.0 * energy * (b_v * cos(thv[i]) - c2_v * one_third + dm[0][0]);
 }
 
+// Reciprocal and square root without the range scaling of the IEEE-complete library forms (12 and
+// 18 instructions): hardware estimate (23 bits) + Newton steps in fused arithmetic, <= 1 ulp for
+// arguments in the normal range; fast_sqrt(0) = 0.  Event mode only (eigen_terms<false, true>), where
+// the kernel is bound by instruction issue.
+__device__ __forceinline__ double fast_rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double r = __builtin_fma(-x, y, 1.0);
+    y = __builtin_fma(y, r, y);
+    r = __builtin_fma(-x, y, 1.0);
+    return __builtin_fma(y, r, y);
+}
+__device__ __forceinline__ double fast_sqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return x == 0.0 ? 0.0 : g;
+}
+
+// fdlibm kernel polynomials on |r| <= pi/4 with the low part rl of the reduced argument
+__device__ __forceinline__ void sincos_kernel(double r, double rl, double *sn_, double *cs_) {
+    const double z = r * r;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double v = z * r;
+    double ps = __builtin_fma(z, S6, S5);
+    ps = __builtin_fma(z, ps, S4);
+    ps = __builtin_fma(z, ps, S3);
+    ps = __builtin_fma(z, ps, S2);
+    *sn_ = r - ((z * (0.5 * rl - v * ps) - rl) - v * S1);
+    double pc = __builtin_fma(z, C6, C5);
+    pc = __builtin_fma(z, pc, C4);
+    pc = __builtin_fma(z, pc, C3);
+    pc = __builtin_fma(z, pc, C2);
+    pc = __builtin_fma(z, pc, C1);
+    pc = z * pc;
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    *cs_ = w + (((1.0 - w) - hz) + (z * pc - r * rl));
+}
+
 // sin and cos of a phase of moderate size.  The phases of the reduced form are
 // (M_k - Mbar) L/E 2.534, a few hundred radians at most; the library sincos carries the machinery
 // for arguments up to 1e308 and is a fifth of the chain kernel.  Three-term Cody-Waite reduction
@@ -221,34 +269,64 @@ __device__ __forceinline__ void sincos_phase(double x, double *s, double *c) {
     const double r = __builtin_fma(-k, p2, r0);
     double rl = __builtin_fma(-k, p2, r0 - r);     // what the second step rounded away
     rl = __builtin_fma(-k, p3, rl);
-    const double z = r * r;
-    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
-                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
-                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
-                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
-                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    const double v = z * r;
-    double ps = __builtin_fma(z, S6, S5);
-    ps = __builtin_fma(z, ps, S4);
-    ps = __builtin_fma(z, ps, S3);
-    ps = __builtin_fma(z, ps, S2);
-    const double sn = r - ((z * (0.5 * rl - v * ps) - rl) - v * S1);
-    double pc = __builtin_fma(z, C6, C5);
-    pc = __builtin_fma(z, pc, C4);
-    pc = __builtin_fma(z, pc, C3);
-    pc = __builtin_fma(z, pc, C2);
-    pc = __builtin_fma(z, pc, C1);
-    pc = z * pc;
-    const double hz = 0.5 * z;
-    const double w = 1.0 - hz;
-    const double cs = w + (((1.0 - w) - hz) + (z * pc - r * rl));
+    double sn, cs;
+    sincos_kernel(r, rl, &sn, &cs);
     const int q = (int)((long long)k & 3);
     double ss = (q & 1) ? cs : sn, cc = (q & 1) ? sn : cs;
     if (q == 1 || q == 2) cc = -cc;
     if (q >= 2) ss = -ss;
     *s = ss;
     *c = cc;
+}
+
+// sin and cos of atan2(y, q) / 3 for y >= 0 (the angle of the trigonometric cubic solution, in
+// [0, pi/3]) without the library's atan2 (105 instructions: signs, infinities, an IEEE division) and
+// the general range reduction: fdlibm's atan on [0, 1] (one of two argument reductions, 11-term
+// polynomial, 0.7 ulp) on min/max of (|q|, y) with Newton reciprocals, and the kernel polynomials
+// on the angle itself or, beyond pi/4, on angle - pi/2.  The angle is within 2 ulp of the
+// library's.  Event mode only (eigen_terms<false, true>).
+__device__ __forceinline__ void sincos_third_angle(double y, double q, double *s, double *c) {
+    const double ax = fabs(q);
+    const double big = fmax(ax, y), small = fmin(ax, y);
+    double t = small * fast_rcp(big);
+    t = big > 0.0 ? t : 0.0;                    // atan2(0, 0) = 0
+    const bool id1 = t >= 0.6875, red = t >= 0.4375;
+    const double num = id1 ? t - 1.0 : __builtin_fma(2.0, t, -1.0), den = id1 ? t + 1.0 : 2.0 + t;
+    const double x = red ? num * fast_rcp(den) : t;
+    const double z = x * x, w = z * z;
+    const double a0 = 3.33333333333329318027e-01, a1 = -1.99999999998764832476e-01,
+                 a2 = 1.42857142725034663711e-01, a3 = -1.11111104054623557880e-01,
+                 a4 = 9.09088713343650656196e-02, a5 = -7.69187620504482999495e-02,
+                 a6 = 6.66107313738753120669e-02, a7 = -5.83357013379057348645e-02,
+                 a8 = 4.97687799461593236017e-02, a9 = -3.65315727442169155270e-02,
+                 a10 = 1.62858201153657823623e-02;
+    double s1 = __builtin_fma(w, a10, a8);
+    s1 = __builtin_fma(w, s1, a6);
+    s1 = __builtin_fma(w, s1, a4);
+    s1 = __builtin_fma(w, s1, a2);
+    s1 = __builtin_fma(w, s1, a0);
+    s1 = z * s1;
+    double s2 = __builtin_fma(w, a9, a7);
+    s2 = __builtin_fma(w, s2, a5);
+    s2 = __builtin_fma(w, s2, a3);
+    s2 = __builtin_fma(w, s2, a1);
+    s2 = w * s2;
+    const double hi = id1 ? 7.85398163397448278999e-01 : 4.63647609000806093515e-01;   // atan(1), atan(1/2)
+    const double lo = id1 ? 3.06161699786838301793e-17 : 2.26987774529616870924e-17;
+    const double xs = x * (s1 + s2);
+    double ang = red ? hi - ((xs - lo) - x) : x - xs;
+    const double p1 = 1.57079632679489655800e+00, p2 = 6.12323399573676603587e-17;     // pi/2
+    ang = ax >= y ? ang : (p1 - ang) + p2;
+    ang = q < 0.0 ? (2.0 * p1 - ang) + 2.0 * p2 : ang;
+    const double res = ang * (1.0 / 3.0);
+    const bool far = res > 0.78539816339744830962;
+    const double r0 = res - p1;                 // exact (res >= pi/4)
+    const double rr = r0 - p2;
+    const double r = far ? rr : res, rl = far ? (r0 - rr) - p2 : 0.0;
+    double sn, cs;
+    sincos_kernel(r, rl, &sn, &cs);
+    *s = far ? cs : sn;                         // sin(r + pi/2) = cos r
+    *c = far ? -sn : cs;                        // cos(r + pi/2) = -sin r
 }
 
 // matter half of get_dms: the three roots 2E.lambda of the characteristic cubic of H, in the
@@ -565,28 +643,6 @@ constexpr int PROB3_NF = 60;  // fields per record, decay form: M[3] (re,im) + Q
 constexpr int PROB3_NF_REDUCED = 18;  // without decay (see eigen_terms)
 
 // field(f) = value callback; f in [0, PROB3_NF)
-// Reciprocal and square root without the range scaling of the IEEE-complete library forms (12 and
-// 18 instructions): hardware estimate (23 bits) + Newton steps in fused arithmetic, <= 1 ulp for
-// arguments in the normal range; fast_sqrt(0) = 0.  Event mode only (eigen_terms<false, true>), where
-// the kernel is bound by instruction issue.
-__device__ __forceinline__ double fast_rcp(double x) {
-    double y = __builtin_amdgcn_rcp(x);
-    double r = __builtin_fma(-x, y, 1.0);
-    y = __builtin_fma(y, r, y);
-    r = __builtin_fma(-x, y, 1.0);
-    return __builtin_fma(y, r, y);
-}
-__device__ __forceinline__ double fast_sqrt(double x) {
-    const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y, h = 0.5 * y;
-    const double r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    h = __builtin_fma(h, r, h);
-    const double d = __builtin_fma(-g, g, x);
-    g = __builtin_fma(d, h, g);
-    return x == 0.0 ? 0.0 : g;
-}
-
 template <bool DECAY, bool FAST = false, class StoreFn>
 __device__ __forceinline__ void eigen_terms(const Prob3Side &S, const double (&dm)[3][3],
                                             const int32_t (&vac_order)[3], double energy, double rho,
@@ -628,10 +684,14 @@ __device__ __forceinline__ void eigen_terms(const Prob3Side &S, const double (&d
             const double q = -13.5 * c0 - c2 * (c2 * c2) + 4.5 * c1 * c2;
             double tmp = 27 * (0.25 * (c1 * c1) * (p - c1) + c0 * (q + 6.75 * c0));
             tmp = fmax(0.0, tmp);
-            const double res = atan2(FAST ? fast_sqrt(tmp) : sqrt(tmp), q) * (1.0 / 3.0);
             const double b = (2.0 / 3.0) * (FAST ? fast_sqrt(p) : sqrt(p));
             double sn, cs;
-            sincos_phase(res, &sn, &cs);
+            if (FAST) {
+                sincos_third_angle(fast_sqrt(tmp), q, &sn, &cs);
+            } else {
+                const double res = atan2(sqrt(tmp), q) * (1.0 / 3.0);
+                sincos_phase(res, &sn, &cs);
+            }
             const double ca = -0.5, sb = 0.86602540378443864676;  // cos, sin of 2pi/3
             const double shift = two_e * dm[0][0] - c2 * (1.0 / 3.0);
             mu[0] = b * (cs * ca - sn * sb) + shift;
