@@ -179,7 +179,7 @@ struct HistArgs {
 //         factors associated first; differs from MODE 3 by rounding only (<= 3 ulp per weight)
 // MODE 7: MODE 5 with the two indices in 16 bits each (grids and binnings below 65535 entries):
 //         20 B per event, four events per thread and sweep so that every load stays 16 bytes
-// DIMS (MODE 1 only) = 4 * (dimensions of the calc grid) + (dimensions of the output binning)
+// DIMS (MODE 0, 1) = 4 * (dimensions of the calc grid, MODE 1) + (dimensions of the output binning)
 template <int MODE, bool LDS_ACC, int DIMS = 0>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
 hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limbs,
@@ -543,14 +543,39 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
                           OD > 1 ? C.s[1][i] : 0.0, OD > 2 ? C.s[2][i] : 0.0);
             }
         } else {
-            for (int64_t i = start + threadIdx.x; i < end; i += nthreads) {
-                const double w = C.w0 ? C.w0[i] : 1.0;
-                int64_t bin;
-                double x = C.s[0][i];
-                double y = a.outb.ndim > 1 ? C.s[1][i] : 0.0;
-                double z = a.outb.ndim > 2 ? C.s[2][i] : 0.0;
-                if (!bin_index(a.outb, x, y, z, bin)) continue;
-                accumulate((int)bin, w, 1.0);
+            // MODE 0, generic histogram (DIMS = dimensions of the binning): like the coordinate form,
+            // pairs of events with 16-byte loads in the together sweep when the columns allow it
+            constexpr int OD = DIMS & 3;
+            const bool weighted = C.w0 != nullptr;
+            auto event = [&](double w, double x, double y, double z) {
+                int bin;
+                if (bin_index_flat<OD>(a.outb, x, y, z, bin)) accumulate(bin, w, 1.0);
+            };
+            uintptr_t bits = (uintptr_t)C.w0 | (uintptr_t)C.s[0];
+            if (OD > 1) bits |= (uintptr_t)C.s[1];
+            if (OD > 2) bits |= (uintptr_t)C.s[2];
+            if ((bits & 15) == 0) {
+                const double2 *__restrict__ w2 = reinterpret_cast<const double2 *>(C.w0);
+                const double2 *__restrict__ x2 = reinterpret_cast<const double2 *>(C.s[0]);
+                const double2 *__restrict__ y2 = reinterpret_cast<const double2 *>(C.s[1]);
+                const double2 *__restrict__ z2 = reinterpret_cast<const double2 *>(C.s[2]);
+                const double2 zero = make_double2(0.0, 0.0), one = make_double2(1.0, 1.0);
+                const int64_t n_wg1 = a.blk_start[c + 1] - a.blk_start[c];
+                for (int64_t q = lb * nthreads + threadIdx.x; q < (C.n >> 1); q += n_wg1 * nthreads) {
+                    const double2 w = weighted ? w2[q] : one;
+                    const double2 x = x2[q];
+                    const double2 y = OD > 1 ? y2[q] : zero;
+                    const double2 z = OD > 2 ? z2[q] : zero;
+                    event(w.x, x.x, y.x, z.x);
+                    event(w.y, x.y, y.y, z.y);
+                }
+                if ((C.n & 1) && lb == 0 && threadIdx.x == 0) {  // odd tail
+                    const int64_t i = C.n - 1;
+                    event(weighted ? C.w0[i] : 1.0, C.s[0][i], OD > 1 ? C.s[1][i] : 0.0, OD > 2 ? C.s[2][i] : 0.0);
+                }
+            } else {
+                for (int64_t i = start + threadIdx.x; i < end; i += nthreads)
+                    event(weighted ? C.w0[i] : 1.0, C.s[0][i], OD > 1 ? C.s[1][i] : 0.0, OD > 2 ? C.s[2][i] : 0.0);
             }
         }
     }
@@ -831,7 +856,8 @@ static thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
 static int run_hist(const ContDev *conts, int n_cont, int mode, const DevBinning *grid,
                     int64_t n_nodes, const double *prob_nu, const double *prob_nubar,
                     const double *pepmu, const DevBinning &outb, int64_t n_bins,
-                    long long *d_limbs, int32_t *d_status, hipStream_t s, bool clear_first = true) {
+                    long long *d_limbs, int32_t *d_status, hipStream_t s, bool clear_first = true,
+                    bool second_quantity = true) {
     if (n_bins > (1 << 28)) return PISA_HIP_ERR_INVALID;
     int64_t lds_bytes = lds_acc_bytes(n_bins);
     bool lds = lds_bytes <= LDS_ACC_BYTES_MAX;
@@ -846,7 +872,9 @@ static int run_hist(const ContDev *conts, int n_cont, int mode, const DevBinning
     }
     // two replicas: level with one for events in the LDS-bank-aware order (no same-address
     // deposits left to spread) and with four for node-sorted events (49.6 / 53 / 49 us)
-    int copies = window ? 1 : env_int("PISA_HIP_HIST_COPIES", 2);
+    // events in arbitrary order (modes 0 and 1: no bank-aware order, neighbouring lanes often in the
+    // same bin): up to eight replicas, as LDS allows
+    int copies = window ? 1 : env_int("PISA_HIP_HIST_COPIES", mode <= 1 ? 8 : 2);
     while (copies > 1 && (copies & (copies - 1))) copies--;
     while (copies > 1 && lds_bytes * copies > LDS_ACC_BYTES_MAX) copies >>= 1;
     if (copies < 1) copies = 1;
@@ -867,6 +895,7 @@ static int run_hist(const ContDev *conts, int n_cont, int mode, const DevBinning
         {
             const char *dbg = getenv("PISA_HIP_HIST_DBG");
             a.dbg = dbg ? atoi(dbg) : 0;
+            if (!second_quantity) a.dbg |= 1;   // the caller has no use for it (plain histogram: no counts)
         }
         int64_t nev[MAX_CONT];
         for (int c = 0; c < nc; c++) { a.cont[c] = conts[base + c]; nev[c] = conts[base + c].n; }
@@ -896,7 +925,14 @@ static int run_hist(const ContDev *conts, int n_cont, int mode, const DevBinning
             else { if (od == 1) LAUNCH1(2, 1); else if (od == 2) LAUNCH1(2, 2); else LAUNCH1(2, 3); }
 #undef LAUNCH1
         }
-        else { if (lds) LAUNCH(0, true); else LAUNCH(0, false); }
+        else {
+            const int od = a.outb.ndim;
+            if (od < 1 || od > 3) return PISA_HIP_ERR_INVALID;
+#define LAUNCH0(O) do { if (lds) hipLaunchKernelGGL((hist_accumulate_kernel<0, true, O>), grid_dim, block, shmem, s, a, out, d_status); \
+                        else hipLaunchKernelGGL((hist_accumulate_kernel<0, false, O>), grid_dim, block, shmem, s, a, out, d_status); } while (0)
+            if (od == 1) LAUNCH0(1); else if (od == 2) LAUNCH0(2); else LAUNCH0(3);
+#undef LAUNCH0
+        }
 #undef LAUNCH
         PISA_CHECK_LAUNCH("hist_accumulate_kernel");
         if (g_prof_stop) PISA_TRY_HIP(hipEventRecord(g_prof_stop, s));
@@ -1072,8 +1108,12 @@ PISA_API int pisa_hip_hist_finalize(const int64_t *d_limbs, int32_t n_containers
     return PISA_HIP_OK;
 }
 
-// Generic histogram: needs scratch; allocated per call (setup-time use only:
-// container translations, hist_transform construction), not on the hot loop.
+// Generic histogram.  Its scratch (limbs, counts, status word) lives in a grow-only buffer per host
+// thread: three hipMalloc / hipFree pairs per call cost more than the kernels (72 us for a call that
+// moves 80 MB).  The call still ends with a stream synchronisation -- it returns the status.
+static thread_local char *g_hist_scratch = nullptr;
+static thread_local size_t g_hist_scratch_bytes = 0;
+
 PISA_API int pisa_hip_histogram_regular(const pisa_hip_binning *h_binning,
                                         const double *const *h_d_sample, int64_t n,
                                         const double *d_weights, int32_t averaged, double *d_hist,
@@ -1086,22 +1126,31 @@ PISA_API int pisa_hip_histogram_regular(const pisa_hip_binning *h_binning,
     for (int k = 0; k < outb.ndim; k++)
         if (n > 0 && !h_d_sample[k]) return PISA_HIP_ERR_INVALID;
     hipStream_t s = as_stream(stream);
-    int64_t limb_bytes = n_bins * 2 * NL * 8;
-    long long *limbs = nullptr;
-    double *cnt = nullptr;
-    int32_t *st = nullptr;
-    rc = check_hip(hipMalloc(&limbs, (size_t)limb_bytes), "hipMalloc");
-    if (!rc) rc = check_hip(hipMalloc(&cnt, (size_t)n_bins * 8), "hipMalloc");
-    if (!rc) rc = check_hip(hipMalloc(&st, 4), "hipMalloc");
-    if (!rc) rc = check_hip(hipMemsetAsync(st, 0, 4, s), "memset");
+    const size_t limb_bytes = (size_t)n_bins * 2 * NL * 8, cnt_bytes = (size_t)n_bins * 8;
+    const size_t need = limb_bytes + cnt_bytes + 256;
+    if (need > g_hist_scratch_bytes) {
+        if (g_hist_scratch) (void)hipFree(g_hist_scratch);
+        g_hist_scratch = nullptr;
+        g_hist_scratch_bytes = 0;
+        rc = check_hip(hipMalloc(&g_hist_scratch, need), "hipMalloc");
+        if (rc) return rc;
+        g_hist_scratch_bytes = need;
+    }
+    long long *limbs = reinterpret_cast<long long *>(g_hist_scratch);
+    double *cnt = reinterpret_cast<double *>(g_hist_scratch + limb_bytes);
+    int32_t *st = reinterpret_cast<int32_t *>(g_hist_scratch + limb_bytes + cnt_bytes);
+    rc = check_hip(hipMemsetAsync(st, 0, 4, s), "memset");
     if (!rc) {
         ContDev c;
         c.n = n; c.gx = c.gy = c.flux = c.aeff = nullptr; c.w0 = d_weights;
         for (int k = 0; k < 3; k++) c.s[k] = k < outb.ndim ? h_d_sample[k] : nullptr;
         c.node = c.bin = nullptr;
         c.node_bin = nullptr; c.aeff_w0 = nullptr; c.pepmu_own = nullptr; c.wflux = nullptr;
+        c.idx16 = nullptr; c.wflux_q = nullptr;
         c.scale = 1.0; c.flav = 0; c.side = 0;
-        rc = run_hist(&c, 1, 0, nullptr, 0, nullptr, nullptr, nullptr, outb, n_bins, limbs, st, s);
+        // the per-bin counts (second quantity) are needed for the average only
+        rc = run_hist(&c, 1, 0, nullptr, 0, nullptr, nullptr, nullptr, outb, n_bins, limbs, st, s, true,
+                      averaged != 0);
     }
     if (!rc) rc = pisa_hip_hist_finalize((const int64_t *)limbs, 1, n_bins, d_hist, cnt, st, s);
     if (!rc && averaged) {
@@ -1112,9 +1161,6 @@ PISA_API int pisa_hip_histogram_regular(const pisa_hip_binning *h_binning,
     int32_t h_st = 0;
     if (!rc) rc = check_hip(hipMemcpyAsync(&h_st, st, 4, hipMemcpyDeviceToHost, s), "d2h");
     if (!rc) rc = check_hip(hipStreamSynchronize(s), "sync");
-    if (limbs) (void)hipFree(limbs);
-    if (cnt) (void)hipFree(cnt);
-    if (st) (void)hipFree(st);
     if (!rc && h_st) rc = PISA_HIP_ERR_OVERFLOW;
     return rc;
 }
