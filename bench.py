@@ -158,7 +158,9 @@ def cpu_baseline(wl, sample_events):
     # one thread per core of one socket at most (the box shows 256 logical CPUs and is shared)
     cores = min(avail, 64)
     v_all, g_all, e_all, n_all = run(cores, n_per, 5)
-    v_one, g_one, e_one, n_one = run(1, max(1, n_per // 8), 1)
+    # single thread: a sample large enough for the event part (a difference of two timings) to stand
+    # clear of the timing noise of the 0.1 s grid part
+    v_one, g_one, e_one, n_one = run(1, max(1, n_per // 2), 3)
     return {
         "value": v_all,
         "unit": "evals/s",
@@ -172,7 +174,7 @@ def cpu_baseline(wl, sample_events):
                   % (wl.grid.n_e, wl.grid.n_cz, g_all, n_all, wl.n_events, e_all, cores),
         "single_thread": {
             "value": v_one, "unit": "evals/s", "cores": 1,
-            "sample": "full prob3 grid (%.3f s) + %d of %d events (%.3f s), scaled; one repetition"
+            "sample": "full prob3 grid (%.3f s) + %d of %d events (%.3f s), scaled; medians of 3 repetitions"
                       % (g_one, n_one, wl.n_events, e_one)},
     }
 
