@@ -180,11 +180,20 @@ struct HistArgs {
 // MODE 7: MODE 5 with the two indices in 16 bits each (grids and binnings below 65535 entries):
 //         20 B per event, four events per thread and sweep so that every load stays 16 bytes
 // DIMS (MODE 0, 1) = 4 * (dimensions of the calc grid, MODE 1) + (dimensions of the output binning)
+// Development build (make EXTRA=-DPISA_HIST_STAMPS, scripts/dev/hist_stamps.py): wall-clock stamps of
+// thread 0 of every workgroup at six points of the kernel.
+#ifdef PISA_HIST_STAMPS
+__device__ unsigned long long g_hist_stamps[8 * 1024];
+#define STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_hist_stamps[8 * blockIdx.x + (k)] = wall_clock64(); } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
 template <int MODE, bool LDS_ACC, int DIMS = 0>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
 hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limbs,
                        int32_t *__restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double s_acc[];  // [slab][quantity][bin]
+    STAMP(0);
     const int nthreads = blockDim.x;
     int c = 0;
     const int bid = blockIdx.x;
@@ -245,6 +254,7 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
         }
     }
 
+    STAMP(1);
     if (LDS_ACC) {
         for (int k = threadIdx.x; k < n_acc * a.copies; k += nthreads) s_acc[k] = 0.0;
         if ((PACKED || QUAD) && a.window > 0) {
@@ -280,6 +290,7 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
         __syncthreads();
     }
     bool bad = false;
+    STAMP(2);
 
     auto accumulate = [&](int bin, double w, double w2) {
         const int rel = bin - bin_lo;
@@ -580,9 +591,11 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
         }
     }
     if (bad && status) atomicOr(status, 1);
+    STAMP(3);
 
     if (LDS_ACC && !(a.dbg & 4)) {
         __syncthreads();
+        STAMP(4);
         // slab accumulators -> integer units, added to the global limbs.  The loop runs in
         // GLOBAL order (limb fastest): a wave's 64 atomics fall into 512 contiguous bytes,
         // which the L2 atomic units take at full rate (scattered 96 B apart they do not).
@@ -603,7 +616,14 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
                 atomicAdd(&g_out[(int64_t)bin_lo * 2 * NL + g], (unsigned long long)slab_to_units(v, j));
         }
     }
+    STAMP(5);
 }
+
+#ifdef PISA_HIST_STAMPS
+PISA_API int pisa_hip_debug_hist_stamps(unsigned long long *h_out) {
+    return check_hip(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_hist_stamps), sizeof(g_hist_stamps)), "stamps");
+}
+#endif
 
 // limbs (possibly summed over workgroups and ranks, un-normalised) -> fp64,
 // rounded once (RNE).  Sets *ovf if the value does not fit the format.
