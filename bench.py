@@ -318,12 +318,12 @@ def leg_node_flux(synthetic, torch, args, n_e, n_cz, steps):
     nubars = [ev["nubar"] for ev in wl.events]
     plist = param_list(wl, 5 + 2 * steps)
     rs = np.random.RandomState(5)
+    barr_sets = K.barr_sets([(e_d, cz_d, nom, nom_bar, nubar, st._node_flux_t[i]) for i, nubar in enumerate(nubars)])
 
     def one(p, flux_moves):
         if flux_moves:
             didx, ratio = 0.1 * (rs.rand() - 0.5), 1.0 + 0.05 * (rs.rand() - 0.5)
-            for i, nubar in enumerate(nubars):
-                K.barr_simple(e_d, cz_d, nom, nom_bar, nubar, ratio, 1.0, didx, 0.0, 0.0, out=st._node_flux_t[i])
+            K.barr_simple_multi(barr_sets, ratio, 1.0, didx, 0.0, 0.0)   # as the stage does: one launch
         return st.eval_host(p, "llh")
 
     out = {}
@@ -338,8 +338,8 @@ def leg_node_flux(synthetic, torch, args, n_e, n_cz, steps):
         dt = (time.perf_counter() - t0) / steps
         out[key] = {"evals_per_s": 1.0 / dt, "ms_per_step": dt * 1e3}
     out["what"] = ("flux on the %d x %d oscillation grid (IceCube 3-y cfg shape): per-node flux x probability tables "
-                   "+ 20 B/event fused kernel; flux_moves = flux.barr_simple on the nodes of all containers every "
-                   "step as well" % (n_e, n_cz))
+                   "+ 20 B/event fused kernel; flux_moves = flux.barr_simple on the nodes of all containers (one "
+                   "launch, pisa_hip_barr_simple_multi) every step as well" % (n_e, n_cz))
     del st, wl
     torch.cuda.empty_cache()
     return out

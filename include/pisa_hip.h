@@ -504,6 +504,25 @@ int pisa_hip_barr_simple(const double *d_true_energy, const double *d_true_cosze
                          double delta_index, double Barr_uphor_ratio, double Barr_nu_nubar_ratio,
                          int64_t n, double *d_out, void *stream);
 
+/* The same for all containers of a pipeline in one launch (the stage's loop over containers,
+ * pisa/stages/flux/barr_simple.py:83-104, with one set of parameter values): set k is evaluated exactly
+ * like pisa_hip_barr_simple(set k) -- same bits.  On the oscillation grid (calc_mode = the binning of
+ * osc.prob3, as in the IceCube 3-year cfgs) a container is a few 10^4 nodes and the launches, not the
+ * arithmetic, are what a flux systematic costs. */
+typedef struct {
+    int64_t n;                          /* elements of this container */
+    const double *d_true_energy;        /* [n] */
+    const double *d_true_coszen;        /* [n] */
+    const double *d_nu_flux_nominal;    /* [n][2] */
+    const double *d_nubar_flux_nominal; /* [n][2] */
+    double *d_out;                      /* [n][2] nu_flux */
+    int32_t nubar;                      /* +1 / -1 */
+    int32_t reserved;
+} pisa_hip_barr_set;
+int pisa_hip_barr_simple_multi(const pisa_hip_barr_set *h_sets, int32_t n_sets,
+                               double nue_numu_ratio, double nu_nubar_ratio, double delta_index,
+                               double Barr_uphor_ratio, double Barr_nu_nubar_ratio, void *stream);
+
 /* ------------------------------------------------------- raw device memory */
 /* Thin wrappers so hosts without torch (a cgo/ctypes binding of the
  * reference) can own device buffers. */

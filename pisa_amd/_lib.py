@@ -93,6 +93,19 @@ class Container(C.Structure):
     ]
 
 
+class BarrSet(C.Structure):
+    _fields_ = [
+        ("n", C.c_int64),
+        ("d_true_energy", C.c_void_p),
+        ("d_true_coszen", C.c_void_p),
+        ("d_nu_flux_nominal", C.c_void_p),
+        ("d_nubar_flux_nominal", C.c_void_p),
+        ("d_out", C.c_void_p),
+        ("nubar", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
 class FluxTable(C.Structure):
     _fields_ = [
         ("n_bands", C.c_int32),
@@ -164,6 +177,7 @@ _SIGS = {
     "pisa_hip_flux_prob_tables": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "pisa_hip_fold_flux": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "pisa_hip_barr_simple": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_void_p, C.c_void_p]),
+    "pisa_hip_barr_simple_multi": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     "pisa_hip_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_int64]),
     "pisa_hip_free": (C.c_int, [C.c_void_p]),
     "pisa_hip_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -81,6 +81,9 @@ class DualArray:
     def host_changed(self):
         self.dev_valid = False
 
+    def dev_changed(self):
+        self.host_valid, self.dev_valid = False, True
+
 
 def regularized(binning, get_column):
     """Linear, regular stand-in for `binning` plus matching sample columns.
@@ -266,6 +269,18 @@ class Container:
         if key in self.current_data:
             self.mark_valid(key)
             self.current_data[key].host_changed()
+
+    def mark_dev_changed(self, key):
+        """`mark_changed` for a kernel that rewrote the DEVICE array of `key` in place (the host
+        mirror, if any, is what went stale)"""
+        self._version[key] += 1
+        Container.clock += 1
+        self.writes += 1
+        self._lazy.pop(key, None)
+        for rep in self.validity[key]:
+            self.validity[key][rep] = False
+        self.mark_valid(key)
+        self.current_data[key].dev_changed()
 
     def mark_valid(self, key):
         self.validity[key][hash(self._representation)] = True

@@ -220,16 +220,9 @@ __device__ __forceinline__ void apply_ratio_scale(double ratio_scale, double in1
     o1 = nw;
 }
 
-__global__ void __launch_bounds__(256)
-barr_simple_kernel(const double *__restrict__ true_energy, const double *__restrict__ true_coszen,
-                   const double *__restrict__ nu_nom, const double *__restrict__ nubar_nom,
-                   int nubar, double nue_numu_ratio, double nu_nubar_ratio, double delta_index,
-                   double uphor, double barr_nu_nubar, int64_t n, double *__restrict__ out) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double e = true_energy[i], cz = true_coszen[i];
-    double2 fn = reinterpret_cast<const double2 *>(nu_nom)[i];
-    double2 fb = reinterpret_cast<const double2 *>(nubar_nom)[i];
+__device__ __forceinline__ double2 barr_one(double e, double cz, double2 fn, double2 fb, int nubar,
+                                            double nue_numu_ratio, double nu_nubar_ratio, double delta_index,
+                                            double uphor, double barr_nu_nubar) {
     double nu0, nu1, nb0, nb1;
     apply_ratio_scale(nue_numu_ratio, fn.x, fn.y, nu0, nu1);
     apply_ratio_scale(nue_numu_ratio, fb.x, fb.y, nb0, nb1);
@@ -244,7 +237,39 @@ barr_simple_kernel(const double *__restrict__ true_energy, const double *__restr
     o1 *= modRatioNuBar(nubar, 1, e, cz, barr_nu_nubar);
     o0 *= modRatioUpHor(0, e, cz, uphor);
     o1 *= modRatioUpHor(1, e, cz, uphor);
-    reinterpret_cast<double2 *>(out)[i] = make_double2(o0, o1);
+    return make_double2(o0, o1);
+}
+
+__global__ void __launch_bounds__(256)
+barr_simple_kernel(const double *__restrict__ true_energy, const double *__restrict__ true_coszen,
+                   const double *__restrict__ nu_nom, const double *__restrict__ nubar_nom,
+                   int nubar, double nue_numu_ratio, double nu_nubar_ratio, double delta_index,
+                   double uphor, double barr_nu_nubar, int64_t n, double *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    reinterpret_cast<double2 *>(out)[i] =
+        barr_one(true_energy[i], true_coszen[i], reinterpret_cast<const double2 *>(nu_nom)[i],
+                 reinterpret_cast<const double2 *>(nubar_nom)[i], nubar, nue_numu_ratio, nu_nubar_ratio,
+                 delta_index, uphor, barr_nu_nubar);
+}
+
+// all containers of a pipeline in one launch (blockIdx.y = container): on the oscillation grid a
+// container is 2*10^4 nodes -- twelve launches of a 4 us kernel cost more than the arithmetic
+constexpr int BARR_MAX_SETS = 16;
+struct BarrSets {
+    pisa_hip_barr_set s[BARR_MAX_SETS];
+};
+__global__ void __launch_bounds__(256)
+barr_simple_multi_kernel(const BarrSets sets, double nue_numu_ratio, double nu_nubar_ratio,
+                         double delta_index, double uphor, double barr_nu_nubar) {
+    const pisa_hip_barr_set &S = sets.s[blockIdx.y];
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S.n) return;
+    reinterpret_cast<double2 *>(S.d_out)[i] =
+        barr_one(S.d_true_energy[i], S.d_true_coszen[i],
+                 reinterpret_cast<const double2 *>(S.d_nu_flux_nominal)[i],
+                 reinterpret_cast<const double2 *>(S.d_nubar_flux_nominal)[i], S.nubar, nue_numu_ratio,
+                 nu_nubar_ratio, delta_index, uphor, barr_nu_nubar);
 }
 
 }  // namespace pisa
@@ -442,6 +467,34 @@ PISA_API int pisa_hip_barr_simple(const double *d_true_energy, const double *d_t
                        nue_numu_ratio, nu_nubar_ratio, delta_index, Barr_uphor_ratio,
                        Barr_nu_nubar_ratio, n, d_out);
     PISA_CHECK_LAUNCH("barr_simple_kernel");
+    return PISA_HIP_OK;
+}
+
+PISA_API int pisa_hip_barr_simple_multi(const pisa_hip_barr_set *h_sets, int32_t n_sets,
+                                        double nue_numu_ratio, double nu_nubar_ratio, double delta_index,
+                                        double Barr_uphor_ratio, double Barr_nu_nubar_ratio, void *stream) {
+    if (n_sets < 0 || (n_sets > 0 && !h_sets)) return PISA_HIP_ERR_INVALID;
+    for (int k = 0; k < n_sets; k++) {
+        const pisa_hip_barr_set &h = h_sets[k];
+        if (h.n < 0 || (h.nubar != 1 && h.nubar != -1)) return PISA_HIP_ERR_INVALID;
+        if (h.n > 0 && (!h.d_true_energy || !h.d_true_coszen || !h.d_nu_flux_nominal ||
+                        !h.d_nubar_flux_nominal || !h.d_out))
+            return PISA_HIP_ERR_INVALID;
+    }
+    for (int base = 0; base < n_sets; base += BARR_MAX_SETS) {
+        const int nc = n_sets - base < BARR_MAX_SETS ? n_sets - base : BARR_MAX_SETS;
+        BarrSets sets;
+        int64_t n_max = 0;
+        for (int k = 0; k < nc; k++) {
+            sets.s[k] = h_sets[base + k];
+            n_max = h_sets[base + k].n > n_max ? h_sets[base + k].n : n_max;
+        }
+        if (n_max == 0) continue;
+        dim3 block(256), grid((unsigned)((n_max + 255) / 256), (unsigned)nc);
+        hipLaunchKernelGGL(barr_simple_multi_kernel, grid, block, 0, as_stream(stream), sets, nue_numu_ratio,
+                           nu_nubar_ratio, delta_index, Barr_uphor_ratio, Barr_nu_nubar_ratio);
+        PISA_CHECK_LAUNCH("barr_simple_multi_kernel");
+    }
     return PISA_HIP_OK;
 }
 

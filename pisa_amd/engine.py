@@ -425,8 +425,19 @@ class HotPathEngine:
             self._flux[i].copy_(f if perm is None else f[perm])
 
     def update_flux_nodes(self, i, flux_nodes):
-        """node_flux mode: new [grid.size, 2] flux of container i on the calc grid (device tensor)"""
-        self._node_flux_t[i].copy_(flux_nodes.reshape(self.grid.size, 2))
+        """node_flux mode: new [grid.size, 2] flux of container i on the calc grid (device tensor).
+        A contiguous fp64 tensor on this device is adopted as it is -- the table kernel reads it
+        through its pointer at the next evaluation, so a flux stage that rewrites its own array in
+        place costs nothing here -- anything else is copied."""
+        t = flux_nodes.reshape(self.grid.size, 2)
+        cur = self._node_flux_t[i]
+        if t.dtype == torch.float64 and t.device == cur.device and t.is_contiguous():
+            if t.data_ptr() != cur.data_ptr():
+                self._node_flux_t[i] = t
+                if self._flux_tab_args is not None:
+                    self._flux_tab_args["ptrs"][i] = t.data_ptr()
+        else:
+            cur.copy_(t)
 
     def _flux_tables(self, pepmu):
         """per-container gather tables flux x probability from the shared (P_e, P_mu) tables"""

@@ -488,6 +488,28 @@ def flux_2d(table, true_energy, true_coszen, out_nu=None, out_nubar=None):
     return out_nu, out_nubar
 
 
+def barr_sets(columns):
+    """argument block of `barr_simple_multi`: one (true_energy, true_coszen, nu_flux_nominal,
+    nubar_flux_nominal, nubar, out) tuple of device tensors per container.  The block holds raw
+    pointers: the caller keeps the tensors alive."""
+    arr = (_lib.BarrSet * len(columns))()
+    for d, (e, cz, nu, nub, nubar, out) in zip(arr, columns):
+        d.n = e.numel()
+        assert cz.numel() == d.n and nu.numel() == 2 * d.n and nub.numel() == 2 * d.n and out.numel() == 2 * d.n
+        d.d_true_energy, d.d_true_coszen = _ptr(e), _ptr(cz)
+        d.d_nu_flux_nominal, d.d_nubar_flux_nominal, d.d_out = _ptr(nu), _ptr(nub), _ptr(out)
+        d.nubar = int(nubar)
+    return arr
+
+
+def barr_simple_multi(sets, nue_numu_ratio, nu_nubar_ratio, delta_index, Barr_uphor_ratio,
+                      Barr_nu_nubar_ratio):
+    """`apply_sys_vectorized` for every container of a pipeline in one launch (flux/barr_simple.py:83-104)."""
+    _lib.check(_lib.lib().pisa_hip_barr_simple_multi(
+        sets, len(sets), float(nue_numu_ratio), float(nu_nubar_ratio), float(delta_index),
+        float(Barr_uphor_ratio), float(Barr_nu_nubar_ratio), _stream()))
+
+
 def barr_simple(true_energy, true_coszen, nu_flux_nominal, nubar_flux_nominal, nubar,
                 nue_numu_ratio, nu_nubar_ratio, delta_index, Barr_uphor_ratio,
                 Barr_nu_nubar_ratio, out=None):

@@ -435,6 +435,20 @@ def test_barr_flux_golden(K):
         for nubar, tag in ((1, "nu"), (-1, "nubar")):
             out = K.barr_simple(*args, nubar, *ps).cpu().numpy()
             np.testing.assert_allclose(out, g["out%d_%s" % (ip, tag)], rtol=1e-12, atol=1e-300)
+    # all containers of a pipeline in one launch (what the stage calls): ragged, one of them empty,
+    # more sets than one launch holds -- every set bit-identical to the single-container call
+    import torch
+
+    n = args[0].numel()
+    sizes = [n, 1, 0, n - 3] + [7 + k for k in range(16)]
+    signs = [1, -1, 1, -1] + [(-1) ** k for k in range(16)]
+    cols = [tuple(a[:m].contiguous() for a in args) + (sg, torch.full((m, 2), np.nan, dtype=torch.float64, device="cuda"))
+            for m, sg in zip(sizes, signs)]
+    ps = g["params"][-1]
+    K.barr_simple_multi(K.barr_sets(cols), *ps)
+    for (e, cz, nu, nub, sg, out), m in zip(cols, sizes):
+        if m:
+            assert torch.equal(out, K.barr_simple(e, cz, nu, nub, sg, *ps))
 
 
 def test_event_mode_engine_vs_oracle(K, L, oracle):
