@@ -6,6 +6,8 @@ from sqrt(1 - s^2), osc_params.py:178-184), so results are bit identical; the
 matrices are 72+144 bytes and are rebuilt per parameter point on the host,
 then travel in the kernel-argument block of the prob3 kernels.
 """
+import math
+
 import numpy as np
 
 from pisa_amd import CTYPE, FTYPE
@@ -17,6 +19,7 @@ class OscParams:
     def __init__(self):
         self._s = {"12": 0.0, "13": 0.0, "23": 0.0, "14": 0.0}
         self._deltacp = 0.0
+        self._trig_delta = (None, 0.0, 1.0)
         self.dm21 = 0.0
         self.dm31 = 0.0
         self.dm41 = 0.0
@@ -52,25 +55,29 @@ class OscParams:
         self._deltacp = value
 
     def _trig(self):
-        s12, s13, s23 = self.sin12, self.sin13, self.sin23
-        return (s12, s13, s23, np.sqrt(1.0 - s12 ** 2), np.sqrt(1.0 - s13 ** 2),
-                np.sqrt(1.0 - s23 ** 2), np.sin(self.deltacp), np.cos(self.deltacp))
+        """(s12, s13, s23, c12, c13, c23, sin delta, cos delta) as Python floats.  Python-float
+        arithmetic is the IEEE arithmetic of numpy's float64 scalars (`**` is libm's pow in both,
+        `math.sqrt` and `np.sqrt` are correctly rounded), at a third of the call overhead: the
+        matrices below are bit-identical to the numpy-scalar formulation
+        (tests/test_host_params.py) and are rebuilt at every point of a fit."""
+        s12, s13, s23 = float(self.sin12), float(self.sin13), float(self.sin23)
+        d = self.deltacp
+        if self._trig_delta[0] != d:
+            self._trig_delta = (d, float(np.sin(d)), float(np.cos(d)))
+        return (s12, s13, s23, math.sqrt(1.0 - s12 ** 2), math.sqrt(1.0 - s13 ** 2),
+                math.sqrt(1.0 - s23 ** 2), self._trig_delta[1], self._trig_delta[2])
 
     @property
     def mix_matrix_complex(self):
         """PDG parameterisation (osc_params.py:174-211)."""
         s12, s13, s23, c12, c13, c23, sd, cd = self._trig()
-        re = np.array([
-            [c12 * c13, s12 * c13, s13 * cd],
-            [-s12 * c23 - c12 * s23 * s13 * cd, c12 * c23 - s12 * s23 * s13 * cd, s23 * c13],
-            [s12 * s23 - c12 * c23 * s13 * cd, -c12 * s23 - s12 * c23 * s13 * cd, c23 * c13],
-        ], dtype=FTYPE)
-        im = np.array([
-            [0.0, 0.0, -s13 * sd],
-            [-c12 * s23 * s13 * sd, -s12 * s23 * s13 * sd, 0.0],
-            [-c12 * c23 * s13 * sd, -s12 * c23 * s13 * sd, 0.0],
-        ], dtype=FTYPE)
-        return re + im * 1.0j
+        return np.array([
+            [complex(c12 * c13, 0.0), complex(s12 * c13, 0.0), complex(s13 * cd, -s13 * sd)],
+            [complex(-s12 * c23 - c12 * s23 * s13 * cd, -c12 * s23 * s13 * sd),
+             complex(c12 * c23 - s12 * s23 * s13 * cd, -s12 * s23 * s13 * sd), complex(s23 * c13, 0.0)],
+            [complex(s12 * s23 - c12 * c23 * s13 * cd, -c12 * c23 * s13 * sd),
+             complex(-c12 * s23 - s12 * c23 * s13 * cd, -s12 * c23 * s13 * sd), complex(c23 * c13, 0.0)],
+        ], dtype=CTYPE)
 
     @property
     def mix_matrix(self):
@@ -81,17 +88,13 @@ class OscParams:
     def mix_matrix_reparam_complex(self):
         """diag(e^{i delta},1,1) U diag(e^{-i delta},1,1) (osc_params.py:213-258)."""
         s12, s13, s23, c12, c13, c23, sd, cd = self._trig()
-        re = np.array([
-            [c12 * c13, s12 * c13 * cd, s13],
-            [-s12 * c23 * cd - c12 * s23 * s13, c12 * c23 - s12 * s23 * s13 * cd, s23 * c13],
-            [s12 * s23 * cd - c12 * c23 * s13, -c12 * s23 - s12 * c23 * s13 * cd, c23 * c13],
-        ], dtype=FTYPE)
-        im = np.array([
-            [0.0, s12 * c13 * sd, 0.0],
-            [s12 * c23 * sd, -s12 * s23 * s13 * sd, 0.0],
-            [-s12 * s23 * sd, -s12 * c23 * s13 * sd, 0.0],
-        ], dtype=FTYPE)
-        return re + im * 1.0j
+        return np.array([
+            [complex(c12 * c13, 0.0), complex(s12 * c13 * cd, s12 * c13 * sd), complex(s13, 0.0)],
+            [complex(-s12 * c23 * cd - c12 * s23 * s13, s12 * c23 * sd),
+             complex(c12 * c23 - s12 * s23 * s13 * cd, -s12 * s23 * s13 * sd), complex(s23 * c13, 0.0)],
+            [complex(s12 * s23 * cd - c12 * c23 * s13, -s12 * s23 * sd),
+             complex(-c12 * s23 - s12 * c23 * s13 * cd, -s12 * c23 * s13 * sd), complex(c23 * c13, 0.0)],
+        ], dtype=CTYPE)
 
     @property
     def mix_matrix_reparam(self):
@@ -101,14 +104,11 @@ class OscParams:
     @property
     def dm_matrix(self):
         """dm[i, j] = m_i - m_j with the degeneracy nudges of osc_params.py:265-292."""
-        m = np.array([0.0, self.dm21, self.dm31], dtype=FTYPE)
+        m0, m1, m2 = 0.0, float(self.dm21), float(self.dm31)
         delta = 5.0e-9
-        if m[1] == 0.0:
-            m[0] -= delta
-        if m[2] == 0.0:
-            m[2] += delta
-        dm = np.zeros((3, 3), dtype=FTYPE)
-        for i, j in ((0, 1), (0, 2), (1, 2)):
-            dm[i, j] = m[i] - m[j]
-            dm[j, i] = -dm[i, j]
-        return dm
+        if m1 == 0.0:
+            m0 -= delta
+        if m2 == 0.0:
+            m2 += delta
+        d01, d02, d12 = m0 - m1, m0 - m2, m1 - m2
+        return np.array([[0.0, d01, d02], [-d01, 0.0, d12], [-d02, -d12, 0.0]], dtype=FTYPE)

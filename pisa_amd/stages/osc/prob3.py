@@ -178,15 +178,22 @@ class prob3(Stage):  # pylint: disable=invalid-name
             n.eps_mutau = (p.eps_mutau_magn.value.m_as("dimensionless"), p.eps_mutau_phase.value.m_as("rad"))
             n.eps_tautau = p.eps_tautau.value.m_as("dimensionless")
         # generalised matter potential (prob3.py:539-557)
-        std = np.zeros((3, 3), dtype=FTYPE) + 1.0j * np.zeros((3, 3), dtype=FTYPE)
-        std[0, 0] += 1.020 if self.include_nlo else 1.0
+        # (the constant matrices are built once: this runs at every point of a fit)
+        const = getattr(self, "_const_matrices", None)
+        if const is None:
+            std = np.zeros((3, 3), dtype=FTYPE) + 1.0j * np.zeros((3, 3), dtype=FTYPE)
+            std[0, 0] += 1.020 if self.include_nlo else 1.0
+            const = self._const_matrices = (std, np.zeros((3, 3), dtype=CTYPE), np.zeros((3, 3), dtype=FTYPE))
+            for m in const:
+                m.setflags(write=False)
+        std = const[0]
         self.gen_mat_pot_matrix_complex = std + self.nsi_params.eps_matrix if self.nsi_type else std
         if self.neutrino_decay:
             self.decay_params.decay_alpha3 = p.decay_alpha3.value.m_as("eV**2")
             self.decay_matrix = self.decay_params.decay_matrix
         else:
-            self.decay_matrix = np.zeros((3, 3), dtype=CTYPE)
-        self.lri_pot = np.zeros((3, 3), dtype=FTYPE)
+            self.decay_matrix = const[1]
+        self.lri_pot = const[2]
         if self.lri_type is not None:
             self.lri_params.v_lri = p.v_lri.value.m_as("eV")
             self.lri_pot = getattr(self.lri_params, "potential_matrix_" + self.lri_type.split("-")[0])

@@ -90,3 +90,48 @@ def test_tomography_scaling_arrays():
     assert m.density_scale == 1.3
     with pytest.raises(AssertionError):
         m.density_scale = -0.1
+
+
+def test_mixing_matrices_equal_the_numpy_scalar_formulation_bit_for_bit():
+    """`OscParams` does its scalar arithmetic with Python floats (a third of the call overhead of
+    numpy scalars, and the matrices are rebuilt at every point of a fit); the reference does it with
+    numpy float64 scalars (osc_params.py:174-258).  Same IEEE operations in the same order: the
+    results must not differ in any bit, whatever the parameter values."""
+    from pisa_amd.stages.osc.osc_params import OscParams
+
+    def numpy_form(s12, s13, s23, dcp, reparam):
+        c12, c13, c23 = np.sqrt(1.0 - s12 ** 2), np.sqrt(1.0 - s13 ** 2), np.sqrt(1.0 - s23 ** 2)
+        sd, cd = np.sin(dcp), np.cos(dcp)
+        if not reparam:
+            re = np.array([[c12 * c13, s12 * c13, s13 * cd],
+                           [-s12 * c23 - c12 * s23 * s13 * cd, c12 * c23 - s12 * s23 * s13 * cd, s23 * c13],
+                           [s12 * s23 - c12 * c23 * s13 * cd, -c12 * s23 - s12 * c23 * s13 * cd, c23 * c13]])
+            im = np.array([[0.0, 0.0, -s13 * sd],
+                           [-c12 * s23 * s13 * sd, -s12 * s23 * s13 * sd, 0.0],
+                           [-c12 * c23 * s13 * sd, -s12 * c23 * s13 * sd, 0.0]])
+        else:
+            re = np.array([[c12 * c13, s12 * c13 * cd, s13],
+                           [-s12 * c23 * cd - c12 * s23 * s13, c12 * c23 - s12 * s23 * s13 * cd, s23 * c13],
+                           [s12 * s23 * cd - c12 * c23 * s13, -c12 * s23 - s12 * c23 * s13 * cd, c23 * c13]])
+            im = np.array([[0.0, s12 * c13 * sd, 0.0],
+                           [s12 * c23 * sd, -s12 * s23 * s13 * sd, 0.0],
+                           [-s12 * s23 * sd, -s12 * c23 * s13 * sd, 0.0]])
+        return re + im * 1.0j
+
+    rs = np.random.RandomState(12)
+    o = OscParams()
+    for _ in range(3000):
+        th = rs.rand(3) * np.pi / 2
+        dcp = rs.rand() * 2 * np.pi
+        o.theta12, o.theta13, o.theta23, o.deltacp = th[0], th[1], th[2], dcp
+        for reparam in (False, True):
+            want = numpy_form(np.sin(th[0]), np.sin(th[1]), np.sin(th[2]), dcp, reparam)
+            got = o.mix_matrix_reparam_complex if reparam else o.mix_matrix_complex
+            assert got.dtype == np.complex128 and got.shape == (3, 3)
+            assert np.array_equal(got.view(np.float64), want.view(np.float64)) or \
+                np.array_equal(got, want), (th, dcp, reparam)
+            assert np.array_equal(got, want)
+    # sines set directly (osc_params.py:86-152), as Python floats and as numpy scalars
+    for val in (0.3, np.float64(0.3)):
+        o.sin12 = o.sin13 = o.sin23 = val
+        assert np.array_equal(o.mix_matrix_complex, numpy_form(val, val, val, dcp, False))
