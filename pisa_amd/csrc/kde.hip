@@ -954,24 +954,34 @@ kde_h2l_kernel(KdeGeom g, const int32_t *__restrict__ tcells, const int32_t *__r
     const int cx = c % nx, cy = c / nx;
     double acc = 0.0;
     bool any = false;
-    for (int o = -reach; o <= reach; o++) {
-        const double *src;
+    // source matrix of offset o, or nullptr (workgroup-uniform)
+    auto source = [&](int o) -> const double * {
+        if (o > reach) return nullptr;
         if (PASS == 0) {                 // source cell (cx, cy - o): d2 = o * cell_u
             const int cyB = cy - o;
-            if (cyB < 0 || cyB >= ny) continue;
+            if (cyB < 0 || cyB >= ny) return nullptr;
             const int sl = slot[(int64_t)cyB * nx + cx];
-            if (sl < 0) continue;
-            src = herm + (int64_t)sl * (P * P);
-        } else {                         // column cx - o of row cy: d1 = o * cell_u
-            const int cxB = cx - o;
-            if (cxB < 0 || cxB >= nx) continue;
-            const int64_t cb = (int64_t)cy * nx + cxB;
-            if (!vflag[cb]) continue;
-            src = V + cb * (P * P);
+            return sl < 0 ? nullptr : herm + (int64_t)sl * (P * P);
         }
+        const int cxB = cx - o;          // column cx - o of row cy: d1 = o * cell_u
+        if (cxB < 0 || cxB >= nx) return nullptr;
+        const int64_t cb = (int64_t)cy * nx + cxB;
+        return vflag[cb] ? V + cb * (P * P) : nullptr;
+    };
+    // The matrices are 3.2 KB each and come from the L2 / HBM: the next one is requested before the
+    // current one is multiplied (one exposed round trip per workgroup instead of one per offset).
+    int o = -reach;
+    const double *src = source(o);
+    while (!src && o <= reach) src = source(++o);
+    double mine = (src && act) ? src[t] : 0.0;
+    while (src) {
+        int on = o + 1;
+        const double *nxt = source(on);
+        while (!nxt && on <= reach) nxt = source(++on);
+        const double ahead = (nxt && act) ? nxt[t] : 0.0;
         any = true;                      // workgroup-uniform
         __syncthreads();
-        if (act) sA[t] = src[t];
+        if (act) sA[t] = mine;
         __syncthreads();
         if (act) {
             const double *hk = sH + (o + reach) * NH;
@@ -986,6 +996,9 @@ kde_h2l_kernel(KdeGeom g, const int32_t *__restrict__ tcells, const int32_t *__r
             }
             acc = w;
         }
+        src = nxt;
+        o = on;
+        mine = ahead;
     }
     if (PASS == 0) {
         if (t == 0) vflag[c] = any ? 1 : 0;
