@@ -1452,7 +1452,9 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
         KDE_TRY_HIP(hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(KdeBlock),
                                    hipMemcpyHostToDevice, s));
         // dense cells get a Hermite series (2-D, with a cut-off, enough sources to pay)
-        std::vector<int32_t> dense;
+        // host tables uploaded asynchronously below: they live until the synchronisation at the end
+        std::vector<int32_t> dense, tcells;
+        std::vector<double> hankel;
         const int P = tol >= 1e-12 ? 18 : 20;
         if (g_kde_expansion && dim == 2 && cut && n >= 20000) {
             for (size_t h = 0; h < h_starts.size(); h++) {
@@ -1497,8 +1499,8 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
             KDE_TRY_HIP(hipMemsetAsync(slot, 0xFF, (size_t)k->n_cells * sizeof(int32_t), s));
             hipLaunchKernelGGL(kde_slot_scatter_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s,
                                d_dense, nd, slot);
-            std::vector<int32_t> tcells(n_heads);
-            std::vector<double> hankel;
+            tcells.assign(n_heads, 0);
+            hankel.clear();
             if (local_exp) {
                 for (int h = 0; h < n_heads; h++) {
                     const int64_t cx = (int64_t)(h_keys[h] & 0x1FFFFF) - KEY_OFF;
@@ -1545,11 +1547,7 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
 #undef KDE_FGT
             KDE_TRY(check_hip(hipGetLastError(), "kde expansion kernels"));
             k->n_dense = nd;
-            if (local_exp) {
-                // the host tables must outlive their asynchronous uploads; `pilot` is complete (no split)
-                KDE_TRY_HIP(hipStreamSynchronize(s));
-                part = pilot;
-            }
+            if (local_exp) part = pilot;   // complete (no split)
         } else {
             KDE_TRY((launch_pairs<false, Q_PER_THREAD>(k, d_blocks, n_blocks, n_split, k->ys, n, part, s)));
         }
@@ -1567,11 +1565,12 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
         // the host copy of the blocks must outlive the asynchronous upload
         KDE_TRY_HIP(hipMemcpyAsync(&k->pairs_pilot, k->pair_count, sizeof(unsigned long long),
                                    hipMemcpyDeviceToHost, s));
-        KDE_TRY_HIP(hipStreamSynchronize(s));
         KDE_TRY_HIP(hipMemsetAsync(k->pair_count, 0, 64, s));
+        // one synchronisation for the uploads of this block, the two read-backs and the reset
+        KDE_TRY_HIP(hipStreamSynchronize(s));
     }
+    if (!adaptive) KDE_TRY_HIP(hipStreamSynchronize(s));
     k->cell_s2min_valid = 0;   // per-cell widest kernel: only the point evaluation needs it
-    KDE_TRY_HIP(hipStreamSynchronize(s));
 #undef KDE_FAIL
 #undef KDE_TRY
 #undef KDE_TRY_HIP
