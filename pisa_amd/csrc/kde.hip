@@ -1167,23 +1167,43 @@ namespace pisa {
 static int query_blocks(const uint64_t *d_keys, int64_t m, int tile, int chunk, char *d_temp, size_t temp_bytes,
                         uint8_t *d_flags, int32_t *d_starts, int32_t *d_count, uint64_t *d_head_keys,
                         std::vector<KdeBlock> &blocks, hipStream_t s,
-                        std::vector<int32_t> *starts_out = nullptr, std::vector<uint64_t> *keys_out = nullptr) {
+                        std::vector<int32_t> *starts_out = nullptr, std::vector<uint64_t> *keys_out = nullptr,
+                        int64_t max_heads = 0) {
     hipLaunchKernelGGL(kde_heads_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, d_keys, m, d_flags);
     PISA_CHECK_LAUNCH("kde_heads_kernel");
     PISA_TRY_HIP(hipcub::DeviceSelect::Flagged(d_temp, temp_bytes, hipcub::CountingInputIterator<int32_t>(0),
                                                d_flags, d_starts, d_count, (int)m, s));
     int32_t n_heads = 0;
+    std::vector<int32_t> starts;
+    std::vector<uint64_t> hk;
     PISA_TRY_HIP(hipMemcpyAsync(&n_heads, d_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    PISA_TRY_HIP(hipStreamSynchronize(s));
-    if (n_heads <= 0) return PISA_HIP_ERR_INVALID;
-    hipLaunchKernelGGL(kde_head_keys_kernel, dim3((unsigned)((n_heads + 255) / 256)), dim3(256), 0, s,
-                       d_keys, d_starts, d_count, d_head_keys);
-    PISA_CHECK_LAUNCH("kde_head_keys_kernel");
-    std::vector<int32_t> starts(n_heads);
-    std::vector<uint64_t> hk(n_heads);
-    PISA_TRY_HIP(hipMemcpyAsync(starts.data(), d_starts, n_heads * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    PISA_TRY_HIP(hipMemcpyAsync(hk.data(), d_head_keys, n_heads * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-    PISA_TRY_HIP(hipStreamSynchronize(s));
+    if (max_heads > 0 && max_heads <= 65536) {
+        // the caller bounds the number of tiles (cells of the grid): the kernel takes the count from the
+        // device and everything comes back behind ONE synchronisation
+        const int64_t cap = std::min<int64_t>(max_heads, m);
+        hipLaunchKernelGGL(kde_head_keys_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, s,
+                           d_keys, d_starts, d_count, d_head_keys);
+        PISA_CHECK_LAUNCH("kde_head_keys_kernel");
+        starts.resize(cap);
+        hk.resize(cap);
+        PISA_TRY_HIP(hipMemcpyAsync(starts.data(), d_starts, cap * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        PISA_TRY_HIP(hipMemcpyAsync(hk.data(), d_head_keys, cap * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        PISA_TRY_HIP(hipStreamSynchronize(s));
+        if (n_heads <= 0 || n_heads > cap) return PISA_HIP_ERR_INVALID;
+        starts.resize(n_heads);
+        hk.resize(n_heads);
+    } else {
+        PISA_TRY_HIP(hipStreamSynchronize(s));
+        if (n_heads <= 0) return PISA_HIP_ERR_INVALID;
+        hipLaunchKernelGGL(kde_head_keys_kernel, dim3((unsigned)((n_heads + 255) / 256)), dim3(256), 0, s,
+                           d_keys, d_starts, d_count, d_head_keys);
+        PISA_CHECK_LAUNCH("kde_head_keys_kernel");
+        starts.resize(n_heads);
+        hk.resize(n_heads);
+        PISA_TRY_HIP(hipMemcpyAsync(starts.data(), d_starts, n_heads * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        PISA_TRY_HIP(hipMemcpyAsync(hk.data(), d_head_keys, n_heads * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        PISA_TRY_HIP(hipStreamSynchronize(s));
+    }
     blocks.clear();
     for (int32_t h = 0; h < n_heads; h++) {
         const int64_t begin = starts[h], end = h + 1 < n_heads ? starts[h + 1] : m;
@@ -1442,7 +1462,7 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
         std::vector<int32_t> h_starts;
         std::vector<uint64_t> h_keys;
         KDE_TRY(query_blocks(keys_b, n, 1, Q_CHUNK, temp, temp_bytes, flags, starts, d_count, head_keys, blocks, s,
-                             &h_starts, &h_keys));
+                             &h_starts, &h_keys, k->n_cells));
         const int n_blocks = (int)blocks.size();
         const int n_split = pick_split(n_blocks);
         KdeBlock *d_blocks = ar.take<KdeBlock>(blocks.size());
