@@ -500,7 +500,7 @@ def leg_events(synthetic, torch, n_events, steps, nsi):
     import numpy as np
 
     wl = synthetic.Workload(n_events=int(n_events), grid=(10, 10), out_binning="example2d", seed=0)
-    st = synthetic.DeviceState(wl, osc_mode="events")
+    st = synthetic.DeviceState(wl, osc_mode="events", compact=True)
     mat_pot = None
     if nsi:
         from pisa_amd.stages.osc.nsi_params import StdNSIParams
@@ -511,12 +511,13 @@ def leg_events(synthetic, torch, n_events, steps, nsi):
         mat_pot = np.diag([1.0, 0, 0]).astype(complex) + n.eps_matrix
     st.make_pseudo_data(wl.osc_params(mat_pot=mat_pot), seed=0)
     plist = param_list(wl, 3 + steps, mat_pot=mat_pot)
+    # eval_host: the LLH arrives in pinned host memory (what a fit loop reads), as in the headline loop
     for p in plist[:3]:
-        st.eval(p).item()
+        st.eval_host(p, "llh")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for p in plist[3:]:
-        llh = st.eval(p).item()
+        llh = st.eval_host(p, "llh")
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     st.check_status()

@@ -24,7 +24,7 @@ from pisa_amd import kernels as K
 from pisa_amd import synthetic
 
 wl = synthetic.Workload(n_events=int(args.events), grid=(10, 10), out_binning="example2d", seed=0)
-st = synthetic.DeviceState(wl, osc_mode="events")
+st = synthetic.DeviceState(wl, osc_mode="events", compact=True)
 mat_pot = None
 if args.nsi:
     from pisa_amd.stages.osc.nsi_params import StdNSIParams
@@ -38,11 +38,11 @@ rs = np.random.RandomState(7)
 plist = [wl.osc_params(theta23_deg=31 + 28 * rs.rand(), dm31=1e-3 + 6e-3 * rs.rand(), mat_pot=mat_pot)
          for _ in range(args.warmup + args.steps)]
 for p in plist[: args.warmup]:
-    st.eval(p).item()
+    st.eval_host(p, "llh")
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for p in plist[args.warmup:]:
-    llh = st.eval(p).item()
+    llh = st.eval_host(p, "llh")
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / args.steps
 st.check_status()
