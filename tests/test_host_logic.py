@@ -542,3 +542,34 @@ def test_legacy_hyperplane_fit_files(tmp_path):
         load_hypersurfaces(str(path), expected_binning=MultiDimBinning(
             [OneDimBinning("reco_energy", num_bins=5, is_log=True, domain=[5.0, 80.0]),
              OneDimBinning("reco_coszen", num_bins=3, is_lin=True, domain=[-1, 1])]))
+
+
+def test_device_side_in_place_rewrite_is_announced_like_a_host_side_one():
+    """a kernel that rewrites a variable's DEVICE array in place (the one-launch flux stage) calls
+    `mark_dev_changed`: the host mirror is what went stale, every other representation is invalidated and
+    the per-key version / per-container write counters move -- the counterpart of the reference's
+    `container[key][...] = ...; container.mark_changed(key)` (container.py:638-649) for host arrays"""
+    import torch
+
+    from pisa_amd.core.container import Container
+
+    c = Container("nue_cc")
+    t = torch.arange(6, dtype=torch.float64).reshape(3, 2)     # stands in for a device tensor
+    c["nu_flux"] = t
+    assert np.array_equal(c["nu_flux"], np.arange(6.0).reshape(3, 2))   # host mirror fetched
+    v0, w0 = c.version("nu_flux"), c.writes
+    arr = c.current_data["nu_flux"]
+    arr.host = arr.host.copy()       # (a CPU tensor and its numpy view share memory: make it a real mirror)
+    t.mul_(2.0)                                                 # "kernel" rewrites the array in place
+    assert np.array_equal(c["nu_flux"], np.arange(6.0).reshape(3, 2))   # stale mirror until announced
+    c.mark_dev_changed("nu_flux")
+    assert arr.dev_valid and not arr.host_valid
+    assert np.array_equal(c["nu_flux"], 2.0 * np.arange(6.0).reshape(3, 2))
+    assert c.device("nu_flux") is t
+    assert c.version("nu_flux") == v0 + 1 and c.writes == w0 + 1
+    # host-side edit, for symmetry: the device copy is what goes stale
+    arr.host = arr.host.copy()
+    c["nu_flux"][0, 0] = 7.0
+    c.mark_changed("nu_flux")
+    assert arr.host_valid and not arr.dev_valid
+    assert c.version("nu_flux") == v0 + 2
