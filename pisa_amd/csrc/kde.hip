@@ -937,22 +937,29 @@ constexpr int H2L_MAX_REACH = 12;
 //   pass 0   V[cy_C][cx_B] = sum_{cy_B} A^(cx_B, cy_B) H(d2)^T          one workgroup per (cx_B, cy_C)
 //   pass 1   L[C]          = D (sum_{cx_B} H(d1) V[cy_C][cx_B]) D       one workgroup per target cell
 // 2 (2 reach + 1) P^3 multiply-adds per cell instead of (cells in the disc + columns) P^3.
+// Each thread owns a 2 x 2 tile of the P x P result ((P/2)^2 threads of a 128-thread workgroup): a
+// multiply-add then costs 0.75 LDS reads instead of 2 (one element per thread: the kernel waited for
+// the LDS pipe, 3 TFLOP/s).  Every element is still summed in the same order (offsets ascending, inner
+// index ascending): same bits.
+constexpr int H2L_THREADS = 128;
 template <int P, int PASS>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(H2L_THREADS)
 kde_h2l_kernel(KdeGeom g, const int32_t *__restrict__ tcells, const int32_t *__restrict__ slot,
                const double *__restrict__ herm, const double *__restrict__ hankel, int reach,
                double *__restrict__ V, uint8_t *__restrict__ vflag, double *__restrict__ local) {
-    constexpr int NH = 2 * P - 1;
-    __shared__ double sA[P * P];
+    static_assert(P % 2 == 0, "2 x 2 tiles");
+    constexpr int NH = 2 * P - 1, H = P / 2, PP = P * P;
+    constexpr int PER = (PP + H2L_THREADS - 1) / H2L_THREADS;   // matrix elements a thread stages
+    __shared__ double sA[PP];
     __shared__ double sH[(2 * H2L_MAX_REACH + 1) * NH];
     const int t = threadIdx.x;
-    const bool act = t < P * P;
-    const int r0 = act ? t / P : 0, r1 = act ? t % P : 0;
-    for (int i = t; i < (2 * reach + 1) * NH; i += 512) sH[i] = hankel[i];
+    const bool act = t < H * H;
+    const int ti = act ? t / H : 0, tj = act ? t % H : 0;
+    for (int i = t; i < (2 * reach + 1) * NH; i += H2L_THREADS) sH[i] = hankel[i];
     const int nx = g.nc[0], ny = g.nc[1];
     const int c = PASS == 0 ? (int)blockIdx.x : tcells[blockIdx.x];
     const int cx = c % nx, cy = c / nx;
-    double acc = 0.0;
+    double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
     bool any = false;
     // source matrix of offset o, or nullptr (workgroup-uniform)
     auto source = [&](int o) -> const double * {
@@ -961,55 +968,92 @@ kde_h2l_kernel(KdeGeom g, const int32_t *__restrict__ tcells, const int32_t *__r
             const int cyB = cy - o;
             if (cyB < 0 || cyB >= ny) return nullptr;
             const int sl = slot[(int64_t)cyB * nx + cx];
-            return sl < 0 ? nullptr : herm + (int64_t)sl * (P * P);
+            return sl < 0 ? nullptr : herm + (int64_t)sl * PP;
         }
         const int cxB = cx - o;          // column cx - o of row cy: d1 = o * cell_u
         if (cxB < 0 || cxB >= nx) return nullptr;
         const int64_t cb = (int64_t)cy * nx + cxB;
-        return vflag[cb] ? V + cb * (P * P) : nullptr;
+        return vflag[cb] ? V + cb * PP : nullptr;
+    };
+    auto fetch = [&](const double *src, double (&buf)[PER]) {
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int e = t + u * H2L_THREADS;
+            buf[u] = (src && e < PP) ? src[e] : 0.0;
+        }
     };
     // The matrices are 3.2 KB each and come from the L2 / HBM: the next one is requested before the
-    // current one is multiplied (one exposed round trip per workgroup instead of one per offset).
+    // current one is multiplied.
     int o = -reach;
     const double *src = source(o);
     while (!src && o <= reach) src = source(++o);
-    double mine = (src && act) ? src[t] : 0.0;
+    double mine[PER], ahead[PER];
+    fetch(src, mine);
     while (src) {
         int on = o + 1;
         const double *nxt = source(on);
         while (!nxt && on <= reach) nxt = source(++on);
-        const double ahead = (nxt && act) ? nxt[t] : 0.0;
+        fetch(nxt, ahead);
         any = true;                      // workgroup-uniform
         __syncthreads();
-        if (act) sA[t] = mine;
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int e = t + u * H2L_THREADS;
+            if (e < PP) sA[e] = mine[u];
+        }
         __syncthreads();
         if (act) {
             const double *hk = sH + (o + reach) * NH;
-            double w = acc;
             if (PASS == 0) {             // W[alpha][l] += sum_beta A[alpha][beta] h_{beta + l}(d2)
-                const double *a = sA + r0 * P;
+                const double *r0 = sA + (2 * ti) * P, *r1 = r0 + P, *h = hk + 2 * tj;
 #pragma unroll
-                for (int b = 0; b < P; b++) w = __builtin_fma(a[b], hk[r1 + b], w);
+                for (int b = 0; b < P; b++) {
+                    const double A0 = r0[b], A1 = r1[b], h0 = h[b], h1 = h[b + 1];
+                    a00 = __builtin_fma(A0, h0, a00);
+                    a01 = __builtin_fma(A0, h1, a01);
+                    a10 = __builtin_fma(A1, h0, a10);
+                    a11 = __builtin_fma(A1, h1, a11);
+                }
             } else {                     // L[k][l] += sum_alpha h_{alpha + k}(d1) V[alpha][l]
+                const double *h = hk + 2 * ti, *v = sA + 2 * tj;
 #pragma unroll
-                for (int a = 0; a < P; a++) w = __builtin_fma(hk[r0 + a], sA[a * P + r1], w);
+                for (int a = 0; a < P; a++) {
+                    const double h0 = h[a], h1 = h[a + 1], v0 = v[a * P], v1 = v[a * P + 1];
+                    a00 = __builtin_fma(h0, v0, a00);
+                    a01 = __builtin_fma(h0, v1, a01);
+                    a10 = __builtin_fma(h1, v0, a10);
+                    a11 = __builtin_fma(h1, v1, a11);
+                }
             }
-            acc = w;
         }
         src = nxt;
         o = on;
-        mine = ahead;
+#pragma unroll
+        for (int u = 0; u < PER; u++) mine[u] = ahead[u];
     }
+    const double acc[2][2] = {{a00, a01}, {a10, a11}};
     if (PASS == 0) {
         if (t == 0) vflag[c] = any ? 1 : 0;
-        if (act && any) V[(int64_t)c * (P * P) + t] = acc;
+        if (act && any) {
+#pragma unroll
+            for (int di = 0; di < 2; di++)
+#pragma unroll
+                for (int dj = 0; dj < 2; dj++)
+                    V[(int64_t)c * PP + (2 * ti + di) * P + 2 * tj + dj] = acc[di][dj];
+        }
     } else if (act) {
-        // D_k D_l = (-1)^(k+l) / (k! l!)
-        double fk = 1.0, fl = 1.0;
-        for (int i = 2; i <= r0; i++) fk *= (double)i;
-        for (int i = 2; i <= r1; i++) fl *= (double)i;
-        const double sgn = ((r0 + r1) & 1) ? -1.0 : 1.0;
-        local[(int64_t)blockIdx.x * (P * P) + t] = sgn * acc / (fk * fl);
+#pragma unroll
+        for (int di = 0; di < 2; di++)
+#pragma unroll
+            for (int dj = 0; dj < 2; dj++) {
+                const int r0 = 2 * ti + di, r1 = 2 * tj + dj;
+                // D_k D_l = (-1)^(k+l) / (k! l!)
+                double fk = 1.0, fl = 1.0;
+                for (int i = 2; i <= r0; i++) fk *= (double)i;
+                for (int i = 2; i <= r1; i++) fl *= (double)i;
+                const double sgn = ((r0 + r1) & 1) ? -1.0 : 1.0;
+                local[(int64_t)blockIdx.x * PP + r0 * P + r1] = sgn * acc[di][dj] / (fk * fl);
+            }
     }
 }
 
@@ -1553,9 +1597,9 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
                 hipLaunchKernelGGL(kde_hermite_coef_kernel<PP>, dim3((unsigned)nd), dim3(256), 0, s, g, d_dense, \
                                    k->cell_start, k->ys, n, k->coef, herm); \
                 if (local_exp) { \
-                    hipLaunchKernelGGL((kde_h2l_kernel<PP, 0>), dim3((unsigned)k->n_cells), dim3(512), 0, s, g, d_tcells, \
+                    hipLaunchKernelGGL((kde_h2l_kernel<PP, 0>), dim3((unsigned)k->n_cells), dim3(H2L_THREADS), 0, s, g, d_tcells, \
                                        slot, herm, d_hankel, reach, d_V, d_vflag, local); \
-                    hipLaunchKernelGGL((kde_h2l_kernel<PP, 1>), dim3((unsigned)n_heads), dim3(512), 0, s, g, d_tcells, \
+                    hipLaunchKernelGGL((kde_h2l_kernel<PP, 1>), dim3((unsigned)n_heads), dim3(H2L_THREADS), 0, s, g, d_tcells, \
                                        slot, herm, d_hankel, reach, d_V, d_vflag, local); \
                     hipLaunchKernelGGL(kde_local_pilot_kernel<PP>, dim3((unsigned)n_blocks), dim3(KDE_THREADS), 0, s, g, \
                                        d_blocks, k->ys, n, k->coef, k->cell_start, slot, local, pilot, k->pair_count); \
