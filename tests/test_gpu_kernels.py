@@ -307,6 +307,20 @@ def test_histogram_edges_empty_negative_and_large(K, L, oracle):
     h2 = K.histogram_regular([K.to_device(xs), K.to_device(ys)], K.to_device(ww), b2).cpu().numpy()
     ref = oracle.histogram_regular([xs, ys], ww, [0.0, 0.0], [1.0, 1.0], nb)
     np.testing.assert_allclose(h2, ref, rtol=1e-13)
+    # columns that are only 8-byte aligned (views one element into a buffer) take the kernel's scalar
+    # path instead of the 16-byte pair loads: same bits, odd and even lengths, 1-3 dimensions
+    cols3 = [rs.rand(n + 1) for _ in range(3)]
+    w3 = rs.rand(n + 1)
+    for nd in (1, 2, 3):
+        b3 = L.make_binning([0.0] * nd, [1.0] * nd, [5, 4, 3][:nd])
+        for m in (n, n - 1):
+            aligned = K.histogram_regular([K.to_device(c[1:m + 1]) for c in cols3[:nd]], K.to_device(w3[1:m + 1]), b3)
+            shifted = K.histogram_regular([K.to_device(c)[1:m + 1] for c in cols3[:nd]], K.to_device(w3)[1:m + 1], b3)
+            assert K.to_device(cols3[0])[1:m + 1].data_ptr() % 16 == 8
+            assert torch.equal(aligned, shifted)
+            ref3 = oracle.histogram_regular([c[1:m + 1] for c in cols3[:nd]], w3[1:m + 1], [0.0] * nd, [1.0] * nd,
+                                            [5, 4, 3][:nd])
+            np.testing.assert_allclose(aligned.cpu().numpy(), ref3.reshape(-1), rtol=1e-13)
     # non-finite weight is an error, not a silent NaN bin
     with pytest.raises(OverflowError):
         K.histogram_regular([K.to_device([0.1])], K.to_device([np.inf]), b)
