@@ -272,11 +272,15 @@ def leg_update_flux(synthetic, torch, wl, st, steps):
                      K.to_device(ev["nu_flux"] * 0.7), ev["nubar"]))
     plist = param_list(wl, 5 + steps)
     rs = np.random.RandomState(5)
+    # as the stages do it: one Barr launch for all containers into arrays the stage owns, one fold launch
+    outs = [torch.empty((e.numel(), 2), dtype=torch.float64, device=e.device) for e, *_ in cols]
+    sets = K.barr_sets([(e, cz, nom, nom_bar, nubar, out) for (e, cz, nom, nom_bar, nubar), out in zip(cols, outs)])
+    items = list(enumerate(outs))
 
     def one(p):
         didx, ratio = 0.1 * (rs.rand() - 0.5), 1.0 + 0.05 * (rs.rand() - 0.5)
-        for i, (e, cz, nom, nom_bar, nubar) in enumerate(cols):
-            st.update_flux(i, K.barr_simple(e, cz, nom, nom_bar, nubar, ratio, 1.0, didx, 0.0, 0.0))
+        K.barr_simple_multi(sets, ratio, 1.0, didx, 0.0, 0.0)
+        st.update_flux_many(items)
         return st.eval_host(p, "llh")
 
     for p in plist[:5]:
@@ -291,8 +295,8 @@ def leg_update_flux(synthetic, torch, wl, st, steps):
     for i, ev in enumerate(wl.events):
         st.update_flux(i, K.to_device(ev["nu_flux"]))
     return {"evals_per_s": 1.0 / dt, "ms_per_step": dt * 1e3,
-            "what": "flux.barr_simple (nue/numu ratio + spectral index moved) for all events + refresh of the "
-                    "folded (w0*aeff*flux) columns + the headline evaluation, every step"}
+            "what": "flux.barr_simple (nue/numu ratio + spectral index moved) for all events (one launch) + refresh "
+                    "of the folded (w0*aeff*flux) columns (one launch) + the headline evaluation, every step"}
 
 
 def leg_node_flux(synthetic, torch, args, n_e, n_cz, steps):

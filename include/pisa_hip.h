@@ -497,6 +497,19 @@ int pisa_hip_flux_prob_tables(const double *const *h_d_flux_nodes, const int32_t
 int pisa_hip_fold_flux(const double *d_flux, const int64_t *d_perm, const double *d_static_w,
                        int64_t n, int32_t layout, double *d_out, void *stream);
 
+/* pisa_hip_fold_flux for all containers in one launch; set k is folded exactly like
+ * pisa_hip_fold_flux(set k). */
+typedef struct {
+    int64_t n;
+    const double *d_flux;       /* [.][2] container order */
+    const int64_t *d_perm;      /* [n] or NULL */
+    const double *d_static_w;   /* [n] resident order */
+    double *d_out;              /* layout 0: [n][2]; layout 1: quad-blocked */
+    int32_t layout;
+    int32_t reserved;
+} pisa_hip_fold_set;
+int pisa_hip_fold_flux_multi(const pisa_hip_fold_set *h_sets, int32_t n_sets, void *stream);
+
 /* `apply_sys_vectorized` (pisa/stages/flux/barr_simple.py:147-233). Flux arrays [n][2]. */
 int pisa_hip_barr_simple(const double *d_true_energy, const double *d_true_coszen,
                          const double *d_nu_flux_nominal, const double *d_nubar_flux_nominal,

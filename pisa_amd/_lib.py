@@ -93,6 +93,18 @@ class Container(C.Structure):
     ]
 
 
+class FoldSet(C.Structure):
+    _fields_ = [
+        ("n", C.c_int64),
+        ("d_flux", C.c_void_p),
+        ("d_perm", C.c_void_p),
+        ("d_static_w", C.c_void_p),
+        ("d_out", C.c_void_p),
+        ("layout", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
 class BarrSet(C.Structure):
     _fields_ = [
         ("n", C.c_int64),
@@ -177,6 +189,7 @@ _SIGS = {
     "pisa_hip_flux_prob_tables": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "pisa_hip_fold_flux": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "pisa_hip_barr_simple": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_void_p, C.c_void_p]),
+    "pisa_hip_fold_flux_multi": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "pisa_hip_barr_simple_multi": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     "pisa_hip_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_int64]),
     "pisa_hip_free": (C.c_int, [C.c_void_p]),

@@ -333,6 +333,31 @@ fold_flux_kernel(const double2 *__restrict__ flux, const int64_t *__restrict__ p
         out[(((q >> 6) * 4 + (e & 3)) << 6) + (q & 63)] = r;
     }
 }
+
+// all containers in one launch (blockIdx.y = container): what a flux systematic costs per evaluation
+// when the flux is held per event is two passes over the events (Barr, fold), not 24 launches
+constexpr int FOLD_MAX_SETS = 16;
+struct FoldSets {
+    pisa_hip_fold_set s[FOLD_MAX_SETS];
+};
+__global__ void __launch_bounds__(256)
+fold_flux_multi_kernel(const FoldSets sets) {
+    const pisa_hip_fold_set &S = sets.s[blockIdx.y];
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= S.n) return;
+    const double2 f = reinterpret_cast<const double2 *>(S.d_flux)[S.d_perm ? S.d_perm[e] : e];
+    const double w = S.d_static_w[e];
+    double2 r;
+    r.x = w * f.x;
+    r.y = w * f.y;
+    double2 *out = reinterpret_cast<double2 *>(S.d_out);
+    if (S.layout == 0) {
+        out[e] = r;
+    } else {
+        const int64_t q = e >> 2;
+        out[(((q >> 6) * 4 + (e & 3)) << 6) + (q & 63)] = r;
+    }
+}
 }  // namespace pisa
 
 
@@ -448,6 +473,29 @@ PISA_API int pisa_hip_fold_flux(const double *d_flux, const int64_t *d_perm, con
     hipLaunchKernelGGL(fold_flux_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream),
                        (const double2 *)d_flux, d_perm, d_static_w, n, (int)layout, (double2 *)d_out);
     PISA_CHECK_LAUNCH("fold_flux_kernel");
+    return PISA_HIP_OK;
+}
+
+PISA_API int pisa_hip_fold_flux_multi(const pisa_hip_fold_set *h_sets, int32_t n_sets, void *stream) {
+    if (n_sets < 0 || (n_sets > 0 && !h_sets)) return PISA_HIP_ERR_INVALID;
+    for (int k = 0; k < n_sets; k++) {
+        const pisa_hip_fold_set &h = h_sets[k];
+        if (h.n < 0 || (h.layout != 0 && h.layout != 1)) return PISA_HIP_ERR_INVALID;
+        if (h.n > 0 && (!h.d_flux || !h.d_static_w || !h.d_out)) return PISA_HIP_ERR_INVALID;
+    }
+    for (int base = 0; base < n_sets; base += FOLD_MAX_SETS) {
+        const int nc = n_sets - base < FOLD_MAX_SETS ? n_sets - base : FOLD_MAX_SETS;
+        FoldSets sets;
+        int64_t n_max = 0;
+        for (int k = 0; k < nc; k++) {
+            sets.s[k] = h_sets[base + k];
+            n_max = h_sets[base + k].n > n_max ? h_sets[base + k].n : n_max;
+        }
+        if (n_max == 0) continue;
+        hipLaunchKernelGGL(fold_flux_multi_kernel, dim3((unsigned)((n_max + 255) / 256), (unsigned)nc), dim3(256), 0,
+                           as_stream(stream), sets);
+        PISA_CHECK_LAUNCH("fold_flux_multi_kernel");
+    }
     return PISA_HIP_OK;
 }
 

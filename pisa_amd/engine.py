@@ -424,6 +424,34 @@ class HotPathEngine:
         else:
             self._flux[i].copy_(f if perm is None else f[perm])
 
+    def update_flux_many(self, items):
+        """`update_flux` for several containers -- `items` = [(i, flux tensor), ...] -- in ONE launch
+        (`pisa_hip_fold_flux_multi`); the argument block is reused while the same tensors come back
+        (a flux stage that rewrites its arrays in place)."""
+        if not items:
+            return
+        if any(self._wflux[i] is None for i, _ in items):
+            for i, f in items:
+                self.update_flux(i, f)
+            return
+        prepared = []
+        for i, flux in items:
+            lo, hi = self._slices[i]
+            f = flux[lo:hi] if (lo != 0 or hi != flux.shape[0]) else flux
+            prepared.append((i, f.contiguous()))
+        key = tuple((i, f.data_ptr()) for i, f in prepared)
+        blk = getattr(self, "_fold_block", None)
+        if blk is None or blk["key"] != key:
+            arr = (_lib.FoldSet * len(prepared))()
+            for d, (i, f) in zip(arr, prepared):
+                out, perm = self._wflux[i], self._perm[i]
+                d.n = int(self._static_w[i].numel())
+                d.d_flux, d.d_static_w, d.d_out = f.data_ptr(), self._static_w[i].data_ptr(), out.data_ptr()
+                d.d_perm = None if perm is None else perm.data_ptr()
+                d.layout = 0 if out.dim() == 2 else 1
+            blk = self._fold_block = dict(key=key, arr=arr, keep=[f for _, f in prepared])
+        _lib.check(_lib.lib().pisa_hip_fold_flux_multi(blk["arr"], len(blk["arr"]), K._stream()))
+
     def update_flux_nodes(self, i, flux_nodes):
         """node_flux mode: new [grid.size, 2] flux of container i on the calc grid (device tensor).
         A contiguous fp64 tensor on this device is adopted as it is -- the table kernel reads it

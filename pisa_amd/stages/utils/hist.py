@@ -181,6 +181,7 @@ class hist(Stage):  # pylint: disable=invalid-name
                                      for c in conts]
             self._node_flux_src = (flux_key, cm) if node_flux else None
         eng = self._engine
+        moved = []
         for i, (c, ch) in enumerate(zip(conts, chains)):
             c.representation = "events"
             eng.set_scale(c.name, ch[1])
@@ -190,8 +191,9 @@ class hist(Stage):  # pylint: disable=invalid-name
                 if node_flux:                            # flux systematics changed
                     eng.update_flux_nodes(i, flux_on_nodes(c))
                 else:
-                    eng.update_flux(i, c.device(flux_key))
+                    moved.append((i, c.device(flux_key)))
                 self._engine_versions[i][flux_key] = c.version(flux_key)
+        eng.update_flux_many(moved)                      # one launch for all rewritten columns
         eng.pepmu = osc.pepmu
         eng.accumulate()
         eng.allreduce()

@@ -544,3 +544,39 @@ def test_coordinate_form_paths_are_bit_identical(out_dims):
     assert torch.equal(run(shifted, st.pepmu), pairs)
     assert torch.equal(run(shifted, None), pairs)
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("index16", [True, False])
+def test_flux_refresh_of_several_containers_in_one_launch(index16):
+    """`update_flux_many` (pisa_hip_fold_flux_multi) folds the rewritten flux columns of several
+    containers exactly like `update_flux` container by container, for a subset as well, and follows
+    arrays that are rewritten in place (the argument block is reused)"""
+    import torch
+
+    from pisa_amd import kernels as K, synthetic
+
+    wl = synthetic.Workload(n_events=12 * 3001, grid=(30, 20), out_binning="dragon", seed=4)
+    a = synthetic.DeviceState(wl, compact=True, index16=index16)
+    b = synthetic.DeviceState(wl, compact=True, index16=index16)
+    assert a.index16 == index16
+    p = wl.osc_params(theta23_deg=43.0)
+    rs = np.random.RandomState(3)
+    fluxes = [K.to_device(ev["nu_flux"] * (0.5 + rs.rand(*ev["nu_flux"].shape))) for ev in wl.events]
+    for i, f in enumerate(fluxes):
+        a.update_flux(i, f)
+    b.update_flux_many(list(enumerate(fluxes)))
+    a.accumulate(p)
+    b.accumulate(p)
+    assert torch.equal(a.ws.limbs, b.ws.limbs)
+    # in place, same tensors: only a subset announced
+    for f in fluxes[:5]:
+        f.mul_(1.25)
+    for i in range(5):
+        a.update_flux(i, fluxes[i])
+    b.update_flux_many([(i, fluxes[i]) for i in range(5)])
+    a.accumulate(p)
+    b.accumulate(p)
+    assert torch.equal(a.ws.limbs, b.ws.limbs)
+    assert int(a.ws.limbs.abs().sum().item()) > 0
+    b.update_flux_many([])      # nothing moved: no launch
