@@ -92,3 +92,34 @@ int one_evaluation(const pisa_hip_earth *earth, const double *d_cz, const double
            "-I", os.path.join(root, "include"), str(src)]
     out = subprocess.run(cmd, capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
+
+
+def test_every_struct_of_the_header_has_the_layout_of_its_binding(built, tmp_path):
+    """sizeof and every member offset of the POD blocks in include/pisa_hip.h, as gcc lays them out,
+    against the ctypes classes of pisa_amd/_lib.py (the same member names on both sides)"""
+    import json
+    import subprocess
+
+    pairs = [("pisa_hip_prob3_params", built.Prob3Params), ("pisa_hip_earth", built.Earth),
+             ("pisa_hip_event_set", built.EventSet), ("pisa_hip_binning", built.Binning),
+             ("pisa_hip_container", built.Container), ("pisa_hip_kde_info_t", built.KdeInfo),
+             ("pisa_hip_flux_table", built.FluxTable), ("pisa_hip_fold_set", built.FoldSet),
+             ("pisa_hip_barr_set", built.BarrSet)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "pisa_hip.h"', 'int main(void) {', 'printf("{");']
+    for k, (cname, cls) in enumerate(pairs):
+        lines.append('printf("%s\\"%s\\": {\\"sizeof\\": %%zu", sizeof(%s));' % (", " if k else "", cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('printf(", \\"%s\\": %%zu", offsetof(%s, %s));' % (fname, cname, fname))
+        lines.append('printf("}");')
+    lines += ['printf("}\\n");', 'return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    out = subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr      # a member missing on either side fails here
+    got = json.loads(subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout)
+    for cname, cls in pairs:
+        assert got[cname]["sizeof"] == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert got[cname][fname] == getattr(cls, fname).offset, (cname, fname)
