@@ -580,3 +580,38 @@ def test_flux_refresh_of_several_containers_in_one_launch(index16):
     assert torch.equal(a.ws.limbs, b.ws.limbs)
     assert int(a.ws.limbs.abs().sum().item()) > 0
     b.update_flux_many([])      # nothing moved: no launch
+
+
+@pytest.mark.gpu
+def test_bench_line_contract_single_gpu():
+    """`python bench.py` prints ONE JSON line with the fields the driver and the judge read: the
+    metric of BASELINE.json, whole-job value, the roofline of the dominant kernel (measured with HIP
+    events in this run; `frac` = achieved / peak) and the CPU baseline of the oracle port"""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--events", "1.2e6", "--steps", "30", "--warmup", "5",
+           "--legs", "none", "--no-drop-probe", "--no-batch-probe"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    base = json.load(open(os.path.join(root, "BASELINE.json")))
+    assert d["metric"].split(",")[0] in base["metric"]
+    assert d["unit"] == "evals/s" and d["n_gpus"] == 1 and d["steps"] == 30 and d["warmup"] == 5
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "f64"
+    assert d["data"].startswith("synthetic") and "workload" in d["config"]
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 1.0) < 1e-6
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.0 < r["frac"] < 1.0
+    assert abs(r["achieved"] - r["bytes_per_event"] * r["events_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert "traffic" in r and "traffic_source" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["sample"] and c["cpu_model"]
+    assert c["single_thread"]["cores"] == 1 and c["single_thread"]["value"] > 0
+    assert c["value"] < d["value"]
