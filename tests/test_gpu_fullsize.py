@@ -48,6 +48,13 @@ def test_full_size_properties(workload):
     assert float(((he - h).abs() / he.abs().clamp_min(1e-300)).max()) < 1e-14
     assert float(((se - s2).abs() / se.abs().clamp_min(1e-300)).max()) < 1e-14
     del plain
+    # the coordinate form (SURVEY 8(d)'s unit of work: both digitisations in the kernel, 72 B/event)
+    # computes the reference-order weights from the raw columns: the very limbs of the 40 B form
+    coord = synthetic.DeviceState(wl, indexed=False)
+    coord.compute_probs(p)
+    coord.accumulate()
+    assert bool((coord.ws.limbs == exact.ws.limbs).all())
+    del coord
 
     # (3) linear in the per-container scale: a factor 2 is exact in binary floating point
     exact.set_scale(wl.events[3]["name"], 2.0 * wl.events[3]["scale"])
