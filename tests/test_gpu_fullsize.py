@@ -121,6 +121,37 @@ def test_full_grid_probabilities_are_unitary(workload):
         assert float((st.prob_nu - st.prob_nubar).abs().max()) > 1e-3
 
 
+def test_event_mode_probabilities_are_unitary_at_full_size():
+    """configs C2 / C5: 2e6 events, every path rebuilt in the kernel (PREM-12 shells in LDS), standard
+    and NSI matter potentials, nu and nubar: every row and column of every event's P sums to one (the
+    kernel multiplies SU(3) layer matrices, keeps two rows of the running product and restores the
+    third), entries stay in [0, 1]; the same events evaluated in two halves give the same bits (no
+    dependence on the position in the launch)"""
+    from pisa_amd import kernels as K
+    from pisa_amd import synthetic
+    from pisa_amd.stages.osc.nsi_params import StdNSIParams
+
+    wl = synthetic.Workload(n_events=1200, grid=(20, 10), out_binning="dragon", seed=2)
+    rs = np.random.RandomState(8)
+    n = 2_000_000
+    e = K.to_device(10 ** (rs.rand(n) * 3))
+    cz = K.to_device(rs.rand(n) * 2 - 1)
+    nsi = StdNSIParams()
+    nsi.eps_emu, nsi.eps_etau, nsi.eps_mutau = (0.07, np.deg2rad(340)), (0.06, np.deg2rad(35)), (0.003, np.deg2rad(175))
+    earth = wl.layers.earth_struct()
+    for mat_pot in (None, np.diag([1.0, 0, 0]).astype(complex) + nsi.eps_matrix):
+        p = wl.osc_params(theta23_deg=48.0, deltacp_deg=200.0, mat_pot=mat_pot)
+        for nubar in (1, -1):
+            P = K.prob3_events(p, earth, nubar, e, cz)
+            assert float((P.sum(dim=2) - 1.0).abs().max()) < 2e-12
+            assert float((P.sum(dim=1) - 1.0).abs().max()) < 2e-12
+            assert float(P.min()) > -1e-14 and float(P.max()) < 1.0 + 1e-12
+            half = n // 2
+            P2 = torch.cat([K.prob3_events(p, earth, nubar, e[:half].contiguous(), cz[:half].contiguous()),
+                            K.prob3_events(p, earth, nubar, e[half:].contiguous(), cz[half:].contiguous())])
+            assert torch.equal(P, P2)
+
+
 def test_c3_kde_pipeline_full_size():
     """config C3 at full size: 1e7 events in the 12 containers, prob3 on the calc grid, osc + aeff
     reweighting, KDE stage ON (adaptive, Silverman, oversample 10, coszen reflection, pid stacking:
