@@ -221,12 +221,20 @@ def test_prob3_events_vs_oracle(K, L, oracle):
         lay.setElecFrac(yi, yo, ym)
         lay.calcLayers(cz)
         earth = L.make_earth(lay.radii, lay.rhos, lay.coszen_limit, lay.r_detector)
-        for name in ("no", "io", "nsi", "decay"):
-            pa = [gg[name + "::dm"], gg[name + "::mix"], gg[name + "::mat_pot"],
-                  int(gg[name + "::decay_flag"]), gg[name + "::mat_decay"], gg[name + "::lri_pot"]]
+        gp = load_golden("params_ref.npz")
+        for name in ("no", "io", "nsi", "decay", "lri"):
+            src = "no" if name == "lri" else name
+            pa = [gg[src + "::dm"], gg[src + "::mix"], gg[src + "::mat_pot"],
+                  int(gg[src + "::decay_flag"]), gg[src + "::mat_decay"], gg[src + "::lri_pot"]]
+            if name == "lri":      # long-range-interaction potential (lri_params.py:31-108): the XL matrix
+                pa[5] = np.array(gp["lri::mutau"], dtype=np.float64)
+                assert np.abs(pa[5]).max() > 0
             p = L.make_prob3_params(*pa)
             for nubar in (1, -1):
                 ref = oracle.propagate_array(*pa, nubar, e, lay.density, lay.distance)
+                if name == "lri":   # the potential is not a no-op at these energies
+                    plain = oracle.propagate_array(*(pa[:5] + [np.zeros((3, 3))]), nubar, e, lay.density, lay.distance)
+                    assert np.abs(ref - plain).max() > 1e-4
                 out = K.prob3_events(p, earth, nubar, K.to_device(e), K.to_device(cz)).cpu().numpy()
                 np.testing.assert_allclose(out, ref, err_msg="%s %s %d" % (tag, name, nubar), **AC)
                 # the gather pair alone (what the fused reweighting asks for: P[e -> flav], P[mu -> flav]):
