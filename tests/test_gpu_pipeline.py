@@ -447,3 +447,49 @@ def test_fit_returns_at_once_when_the_start_matches_the_data():
     assert res.num_distributions_generated == 0 and res.minimizer_metadata["nit"] == 0
     assert res.minimizer_metadata["success"] and abs(res.metric_val) < 1e-20
     assert res.params.theta23.value == dm.params.theta23.nominal_value
+
+
+@pytest.mark.gpu
+def test_flux_stage_argument_block_follows_replaced_inputs():
+    """`flux.barr_simple` evaluates all containers in one launch with a cached argument block (device
+    pointers of its inputs and of the `nu_flux` arrays it owns).  The block is reused while the
+    containers hold those very arrays -- `nu_flux` is then rewritten in place -- and rebuilt when an
+    input was replaced; either way every container's `nu_flux` equals the single-container kernel on
+    the current inputs, bit for bit."""
+    import torch
+
+    from pisa_amd import kernels as K
+    from pisa_amd.core.pipeline import Pipeline
+    from pisa_amd.core.units import ureg
+
+    pipe = Pipeline("settings/pipeline/osc_example.cfg")
+    stage = pipe["barr_simple"]
+    names = ("nue_numu_ratio", "nu_nubar_ratio", "delta_index", "Barr_uphor_ratio", "Barr_nu_nubar_ratio")
+
+    def check():
+        vals = [float(stage.params[n].value.m_as("dimensionless")) for n in names]
+        for c in pipe.data.containers:
+            c.representation = stage.calc_mode
+            want = K.barr_simple(c.device("true_energy"), c.device("true_coszen"), c.device("nu_flux_nominal"),
+                                 c.device("nubar_flux_nominal"), c["nubar"], *vals)
+            assert bool(torch.isfinite(want).all())
+            assert torch.equal(c.device("nu_flux"), want), c.name
+            assert np.array_equal(c["nu_flux"], want.cpu().numpy())      # host mirror follows
+
+    pipe.get_outputs()
+    check()
+    first = [c.current_data["nu_flux"] for c in pipe.data.containers]
+    pipe.params.delta_index.value = 0.05 * ureg.dimensionless
+    pipe.get_outputs()
+    check()
+    for c, arr in zip(pipe.data.containers, first):
+        c.representation = stage.calc_mode
+        assert c.current_data["nu_flux"] is arr                          # rewritten in place
+    # an input replaced by a new array: the block is rebuilt at the next evaluation of the stage
+    for c in pipe.data.containers:
+        c.representation = stage.calc_mode
+        c["nu_flux_nominal"] = c["nu_flux_nominal"] * 1.5 + 0.25
+        c["nubar_flux_nominal"] = c["nubar_flux_nominal"] * 1.25 + 0.125
+    pipe.params.delta_index.value = -0.03 * ureg.dimensionless
+    pipe.get_outputs()
+    check()
