@@ -260,6 +260,25 @@ def reweight(initial_weights, nu_flux, prob_e, prob_mu, weighted_aeff, scale):
     return out
 
 
+def container_chain(gx, gy, gmins, gmaxs, gnb, pe_grid, pmu_grid, initial_weights, nu_flux, weighted_aeff,
+                    scale, sample, mins, maxs, nbins):
+    """lookup (translation.py:427-438) + prob3.apply (prob3.py:621-622) + aeff.apply (aeff.py:78-88) +
+    histogram of w and w^2 (hist.py:163-218) of one container in ONE OpenMP loop over its events
+    (per-thread private histograms, added in thread order).  Returns (hist, sumw2)."""
+    cols, arr = _sample_ptrs(sample)
+    n = cols[0].size
+    nb = np.ascontiguousarray(nbins, dtype=np.int64)
+    gnb_ = np.ascontiguousarray(gnb, dtype=np.int64)
+    hist, sumw2 = np.zeros(int(np.prod(nb))), np.zeros(int(np.prod(nb)))
+    rc = lib().oracle_container_chain(
+        C.c_int64(n), _p(_f8(gx)), _p(_f8(gy)), _p(_f8(gmins)), _p(_f8(gmaxs)), _p(gnb_), _p(_f8(pe_grid)),
+        _p(_f8(pmu_grid)), _p(_f8(initial_weights)), _p(_f8(nu_flux)), _p(_f8(weighted_aeff)),
+        C.c_double(scale), C.c_int(len(cols)), arr, _p(_f8(mins)), _p(_f8(maxs)), _p(nb), _p(hist), _p(sumw2))
+    if rc:
+        raise RuntimeError("oracle_container_chain: %d" % rc)
+    return hist, sumw2
+
+
 METRIC_KIND = {"llh": 0, "poisson_llh": 1, "chi2": 2, "mod_chi2": 3}
 
 

@@ -72,6 +72,44 @@ def oracle_eval(wl, matrices=None, containers=None):
                 sumw2=np.array(sumw2s), weights=weights)
 
 
+def oracle_eval_allcore(wl, containers=None, threads=None, matrices=None, ln_energy=None):
+    """`oracle_eval` for the all-core CPU baseline of bench.py (the reference's TARGET='parallel':
+    numba prange over the elements): the prob3 grid under OpenMP, and each container's per-event
+    chain -- lookup, reweight, histogram of w and w^2 -- as ONE OpenMP loop over its events inside
+    the C file (`oracle_container_chain`: contiguous slice and private histograms per thread, merged
+    in thread order).  Same arithmetic per event as `oracle_eval`; the maps differ from it only by
+    the order of the histogram additions.  `ln_energy`: per-container ln(true_energy), prepared by
+    the caller once (the reference keeps the log-regularised lookup coordinates as well)."""
+    m = matrices or wl.last_matrices
+    g = wl.grid
+    if threads:
+        orc.set_num_threads(threads)
+    lay = orc.Layers(wl.layers.prem, wl.layers.detector_depth, wl.layers.prop_height)
+    lay.rhos = np.array(wl.layers.rhos)
+    lay.calcLayers(g.coszen)
+    ee = np.repeat(g.energy, g.n_cz)
+    rho = np.tile(lay.density, (g.n_e, 1))
+    dist = np.tile(lay.distance, (g.n_e, 1))
+    probs = {nubar: orc.propagate_array(m["dm"], m["mix"], m["mat_pot"], m["decay_flag"], m["mat_decay"],
+                                        m["lri_pot"], nubar, ee, rho, dist) for nubar in (1, -1)}
+    mins = [g.binning.mins[0], g.binning.mins[1]]
+    maxs = [g.binning.maxs[0], g.binning.maxs[1]]
+    nb = [g.binning.nbins[0], g.binning.nbins[1]]
+    ob = wl.ob
+    hists, sumw2s = [], []
+    conts = wl.events if containers is None else containers
+    for ci, ev in enumerate(conts):
+        P = probs[ev["nubar"]]
+        lnE = np.log(ev["true_energy"]) if ln_energy is None else ln_energy[ci]
+        h, s2 = orc.container_chain(lnE, ev["true_coszen"], mins, maxs, nb, orc.fill_probs(P, 0, ev["flav"]),
+                                    orc.fill_probs(P, 1, ev["flav"]), ev["initial_weights"], ev["nu_flux"],
+                                    ev["weighted_aeff"], ev["scale"], ev["sample"], ob["mins"], ob["maxs"],
+                                    ob["nbins"])
+        hists.append(h)
+        sumw2s.append(s2)
+    return dict(prob_nu=probs[1], prob_nubar=probs[-1], hist=np.array(hists), sumw2=np.array(sumw2s))
+
+
 def oracle_eval_parallel(wl, containers, workers, chunk=50000, matrices=None):
     """`oracle_eval` with coarse-grained parallelism for the CPU-baseline timing of bench.py: the
     prob3 grid under OpenMP (`workers` threads), the per-event part (lookup, reweight, histogram +

@@ -150,6 +150,18 @@ class DeviceMapSet(MapSet):
         out.name = name
         return out
 
+    # copies and pickles are ordinary host MapSets (see Map.__getstate__): the block -- and through
+    # it the engine with its HBM tensors and ctypes pointers -- is never copied
+    def __reduce_ex__(self, protocol):
+        return (MapSet, (list(self.maps), self.name))
+
+    def __deepcopy__(self, memo):
+        import copy
+
+        out = MapSet([copy.deepcopy(m, memo) for m in self.maps], name=self.name)
+        memo[id(self)] = out
+        return out
+
 
 def _no(reason):
     """ordinary path; PISA_PLAN_DEBUG=1 says why"""
@@ -253,6 +265,12 @@ class FastPlan:
                 if stages[k] not in out:
                     out.append(stages[k])
         return out
+
+    def invalidate(self):
+        """forget the compute memos of every stage this plan replays (the plan is being dropped after
+        an error: whatever it had half applied must be recomputed by the ordinary path)"""
+        for s in [self.osc, self.aeff] + self.flux_stages + self.post:
+            s.param_hash = None
 
     def run(self):
         """device-backed output MapSet, or None: take the ordinary path"""

@@ -68,6 +68,28 @@ class Map:
             self._extra = None
         self._lazy = None
 
+    # -- copying / pickling: host arrays only.  A device-backed map references the evaluation
+    # engine (HBM tensors, ctypes argument blocks): `deepcopy(maker.get_outputs(...))`, a standard
+    # pattern with the reference, must neither clone that nor trip over its raw pointers, so the maps
+    # are brought to the host first and the copy is an ordinary host map.
+    def __getstate__(self):
+        if self._lazy is not None:
+            self._fetch()
+        state = dict(self.__dict__)
+        state["_lazy"] = state["_extra"] = None
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+
+    def __deepcopy__(self, memo):
+        import copy
+
+        m = Map.__new__(Map)
+        memo[id(self)] = m
+        m.__dict__.update(copy.deepcopy(self.__getstate__(), memo))
+        return m
+
     @property
     def _hist(self):
         if self._lazy is not None:

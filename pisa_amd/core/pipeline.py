@@ -186,7 +186,16 @@ class Pipeline:
         default = output_binning is None and output_key is None
         if default and self.fast_path and not self._profile:
             if self._plan is not None:
-                outputs = self._plan.run()
+                try:
+                    outputs = self._plan.run()
+                except BaseException:
+                    # the replay marks parameter changes as seen before it has applied all of them:
+                    # a plan that raised half way (a kernel status, a value out of range in a stage's
+                    # compute, an allocation) must not be replayed with its stale tables -- the next
+                    # evaluation takes the ordinary Stage path with every bypassed memo invalidated
+                    plan, self._plan = self._plan, None
+                    plan.invalidate()
+                    raise
                 if outputs is not None:
                     return outputs
                 self._plan = None

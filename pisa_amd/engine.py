@@ -594,11 +594,11 @@ class HotPathEngine:
         import ctypes as C
 
         a = self._lean
-        if a is None or a.get("front_pepmu") is not tables:
+        if a is None or a.get("kind") != "front" or a.get("front_pepmu") is not tables:
             lib = _lib.lib()
             pep = tables if tables is not None else self.pepmu
             a = self._lean = dict(
-                front_pepmu=tables, tabs=None, lib=lib, cont=self._cont_arr, n_cont=len(self._cont_arr),
+                kind="front", front_pepmu=tables, tabs=None, lib=lib, cont=self._cont_arr, n_cont=len(self._cont_arr),
                 nu=C.c_void_p(self.prob_nu.data_ptr()) if self.prob_nu is not None else None,
                 nubar=C.c_void_p(self.prob_nubar.data_ptr()) if self.prob_nubar is not None else None,
                 pepmu=C.c_void_p(pep.data_ptr()), grid=C.byref(self.grid.binning),
@@ -634,7 +634,7 @@ class HotPathEngine:
                 lib = _lib.lib()
                 a = object()   # matches no table: `front` / `_lean_eval` build their full block
                 a = self._lean = dict(
-                    front_pepmu=a, tabs=a, lib=lib, cont=self._cont_arr, n_cont=len(self._cont_arr),
+                    kind="tail", front_pepmu=a, tabs=a, lib=lib, cont=self._cont_arr, n_cont=len(self._cont_arr),
                     limbs=C.c_void_p(self.ws.limbs.data_ptr()), status=C.c_void_p(self.ws.status.data_ptr()),
                     hist=C.c_void_p(self.ws.hist.data_ptr()), sumw2=C.c_void_p(self.ws.sumw2.data_ptr()),
                     data=None, data_t=None, out=C.c_void_p(self.metric_host.data_ptr()),
@@ -731,10 +731,10 @@ class HotPathEngine:
 
         a = self._lean
         tabs = (self.prob_nu, self.prob_nubar, self.pepmu)
-        if a is None or a["tabs"] is not tabs[2]:
+        if a is None or a.get("kind") != "eval" or a["tabs"] is not tabs[2]:
             lib = _lib.lib()
             a = self._lean = dict(
-                tabs=self.pepmu, lib=lib, cont=self._cont_arr, n_cont=len(self._cont_arr),
+                kind="eval", tabs=self.pepmu, lib=lib, cont=self._cont_arr, n_cont=len(self._cont_arr),
                 plan=self.plan.handle, energy=C.c_void_p(self.energy_d.data_ptr()),
                 n_e=self.energy_d.numel(), e_major=1 if self.grid.energy_first else 0,
                 nu=C.c_void_p(self.prob_nu.data_ptr()), nubar=C.c_void_p(self.prob_nubar.data_ptr()),
@@ -775,6 +775,7 @@ class HotPathEngine:
         are identical to calling `eval` point by point; one host sync at the
         end.  Returns a device tensor with one metric value per point."""
         assert not self.osc_events and self.plan is not None and self.data is not None
+        self._release_outputs()   # device-backed maps of the previous evaluation: home before the limbs are reused
         n = len(params_list)
         out = torch.empty(n, dtype=torch.float64, device=self.dev)
         if not hasattr(self, "_osc_stream"):

@@ -1,5 +1,7 @@
-"""BASELINE.json's full-size workload (1e7 events, 200x100 calc grid, 8x8x2 binning) checked
-through size-independent properties: the oracle would need minutes here, the properties do not."""
+"""BASELINE.json's full-size workloads: the headline (1e7 events, 200x100 calc grid, 8x8x2 binning),
+C2 (1e6 events, prob3 event by event) and a 1e6-event slice of C5 (standard NSI) compared DIRECTLY with
+the CPU oracle on the very inputs the bench times (a few seconds of oracle each), and the
+size-independent properties of the accumulation (order, shards, linearity, conservation)."""
 import numpy as np
 import pytest
 import torch
@@ -214,3 +216,92 @@ def test_c3_kde_pipeline_full_size():
     pipe.params.theta23.value = 49.0 * ureg.degree
     moved = pipe.get_outputs()
     assert np.abs(moved["numu_cc"].hist - a["numu_cc"]).max() > 1e-3 * a["numu_cc"].max()
+
+
+# ----------------------------------------------------------------- direct oracle parity at full size
+def _oracle_llh(orc, data, ref):
+    """Poisson llh of the summed oracle maps against `data` (stats.py:169-253; np.nansum, map.py:1604)"""
+    lam = np.asarray(ref["hist"]).reshape(len(ref["hist"]), -1).sum(axis=0)
+    return float(orc.metric("llh", data, lam)[1])
+
+
+def test_headline_workload_against_the_oracle(workload, oracle):
+    """The bench's headline workload, maps of all 12 containers and the LLH against `oracle_eval` on
+    identical inputs: the 20 B (16-bit index, folded), 40 B (reference operation order) and 72 B
+    (coordinate) forms of the fused kernel.  north_star gate: <= 1e-10 relative."""
+    from oracle import pipeline_oracle
+    from pisa_amd import synthetic
+
+    wl = workload
+    nominal = wl.osc_params()
+    p = wl.osc_params(theta23_deg=47.5, dm31=2.6e-3)
+    ref = pipeline_oracle.oracle_eval(wl, dict(wl.last_matrices))
+    ref_h = np.asarray(ref["hist"]).reshape(len(wl.events), -1)
+    ref_s2 = np.asarray(ref["sumw2"]).reshape(len(wl.events), -1)
+    assert ref_h.min() > 0          # every bin of every container is populated at this size
+    data = None
+    for kw in (dict(compact=True), dict(compact=False), dict(indexed=False)):
+        st = synthetic.DeviceState(wl, **kw)
+        if data is None:
+            data = st.make_pseudo_data(nominal, seed=0)
+        else:
+            st.set_data(data)
+        llh = st.eval_host(p, "llh")
+        st.check_status()
+        h, s2 = st.maps()
+        np.testing.assert_allclose(h, ref_h, rtol=1e-10, atol=0, err_msg=str(kw))
+        np.testing.assert_allclose(s2, ref_s2, rtol=1e-10, atol=0, err_msg=str(kw))
+        # the planned grid form of prob3 against the oracle's reference-order propagate_array, on
+        # all 2 x 20 000 nodes, at the reference's own tolerance (numba_osc_tests.py:82)
+        st.compute_probs(p)
+        np.testing.assert_allclose(st.prob_nu.cpu().numpy(), ref["prob_nu"], rtol=1e-10, atol=1e-14)
+        np.testing.assert_allclose(st.prob_nubar.cpu().numpy(), ref["prob_nubar"], rtol=1e-10, atol=1e-14)
+        want = _oracle_llh(oracle, data, ref)
+        assert abs(llh - want) <= 1e-10 * abs(want), (kw, llh, want)
+        del st
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("nsi", [False, True], ids=["C2_std", "C5_slice_std_nsi"])
+def test_event_mode_workloads_against_the_oracle(oracle, nsi):
+    """C2 (1e6 events, prob3 event by event, 10x10 histogram) and a 1e6-event slice of C5's
+    workload (standard NSI, numba_osc_tests.py:129-136): per-event probabilities against
+    `oracle.propagate_array` on the oracle's own per-event layers (prob3.py:406-409) at the
+    reference's tolerance, maps and LLH of the whole chain against `oracle_eval_events`."""
+    from oracle import pipeline_oracle
+    from pisa_amd import kernels as K
+    from pisa_amd import synthetic
+    from pisa_amd.stages.osc.nsi_params import StdNSIParams
+
+    wl = synthetic.Workload(n_events=1_000_000, grid=(10, 10), out_binning="example2d", seed=0)
+    mat_pot = None
+    if nsi:
+        n = StdNSIParams()
+        n.eps_emu, n.eps_etau, n.eps_mutau = (0.07, np.deg2rad(340)), (0.06, np.deg2rad(35)), (0.003, np.deg2rad(175))
+        mat_pot = np.diag([1.0, 0, 0]).astype(complex) + n.eps_matrix
+    nominal = wl.osc_params(mat_pot=mat_pot)
+    st = synthetic.DeviceState(wl, osc_mode="events", compact=True)
+    data = st.make_pseudo_data(nominal, seed=0)
+    p = wl.osc_params(theta23_deg=47.5, dm31=2.6e-3, mat_pot=mat_pot)
+    m = dict(wl.last_matrices)
+    llh = st.eval_host(p, "llh")
+    st.check_status()
+    ref = pipeline_oracle.oracle_eval_events(wl, m)
+    ref_h = np.asarray(ref["hist"]).reshape(len(wl.events), -1)
+    ref_s2 = np.asarray(ref["sumw2"]).reshape(len(wl.events), -1)
+    h, s2 = st.maps()
+    np.testing.assert_allclose(h, ref_h, rtol=1e-10, atol=1e-13 * np.abs(ref_h).max())
+    np.testing.assert_allclose(s2, ref_s2, rtol=1e-10, atol=1e-13 * np.abs(ref_s2).max())
+    want = _oracle_llh(oracle, data, ref)
+    assert abs(llh - want) <= 1e-10 * abs(want), (llh, want)
+    # the probabilities themselves, every event of two containers (nu and nubar)
+    lay = oracle.Layers(wl.layers.prem, wl.layers.detector_depth, wl.layers.prop_height)
+    lay.rhos = np.array(wl.layers.rhos)
+    for c in (1, 8):
+        ev = wl.events[c]
+        lay.calcLayers(ev["true_coszen"])
+        want_p = oracle.propagate_array(m["dm"], m["mix"], m["mat_pot"], m["decay_flag"], m["mat_decay"],
+                                        m["lri_pot"], ev["nubar"], ev["true_energy"], lay.density, lay.distance)
+        got = K.prob3_events(p, wl.layers.earth_struct(), ev["nubar"], K.to_device(ev["true_energy"]),
+                             K.to_device(ev["true_coszen"])).cpu().numpy()
+        np.testing.assert_allclose(got, want_p, rtol=1e-10, atol=1e-14)

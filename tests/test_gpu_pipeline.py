@@ -493,3 +493,79 @@ def test_flux_stage_argument_block_follows_replaced_inputs():
     pipe.params.delta_index.value = -0.03 * ureg.dimensionless
     pipe.get_outputs()
     check()
+
+
+def test_device_backed_outputs_deepcopy_and_pickle_as_host_maps():
+    """`deepcopy(maker.get_outputs(return_sum=True))` is a standard pattern with the reference.  From
+    the second evaluation on the outputs are device backed (they reference the engine: HBM tensors,
+    ctypes argument blocks); copies and pickles must be plain host maps with the same numbers, and
+    must not clone the engine"""
+    import copy
+    import pickle
+
+    from pisa_amd.core.map import Map, MapSet
+    from pisa_amd.core.pipeline import Pipeline
+    from pisa_amd.core.units import ureg
+
+    pipe = Pipeline("settings/pipeline/example_hip.cfg")
+    pipe.get_outputs()
+    pipe.params.theta23.value = 46.0 * ureg.degree
+    ms = pipe.get_outputs()
+    assert ms[0]._lazy is not None
+    total = sum(pipe.get_outputs())
+    assert total._lazy is not None
+    tc = copy.deepcopy(total)
+    assert type(tc) is Map and tc._lazy is None
+    ms = pipe.get_outputs()
+    mc = copy.deepcopy(ms)
+    assert type(mc) is MapSet and all(m._lazy is None for m in mc)
+    mp = pickle.loads(pickle.dumps(pipe.get_outputs()))
+    tp = pickle.loads(pickle.dumps(sum(pipe.get_outputs())))
+    ref = Pipeline("settings/pipeline/example_hip.cfg")
+    ref.fast_path = False
+    ref.params.theta23.value = 46.0 * ureg.degree
+    want = ref.get_outputs()
+    for a, b, c in zip(mc, mp, want):
+        assert a.name == b.name == c.name
+        np.testing.assert_array_equal(a.hist, c.hist)
+        np.testing.assert_array_equal(b.hist, c.hist)
+        np.testing.assert_array_equal(a.std_devs, c.std_devs)
+    np.testing.assert_array_equal(tc.hist, sum(want).hist)
+    np.testing.assert_array_equal(tp.hist, sum(want).hist)
+    # the copy is independent of the engine: the next evaluation does not touch it
+    before = tc.hist.copy()
+    pipe.params.theta23.value = 51.0 * ureg.degree
+    pipe.get_outputs()[0].hist
+    np.testing.assert_array_equal(tc.hist, before)
+
+
+def test_a_replay_that_raises_is_not_replayed_again(monkeypatch):
+    """`FastPlan.run` marks parameter changes as seen before it has applied them; if one of its steps
+    raises, the plan is dropped and the next evaluation goes through the Stage protocol with fresh
+    tables (it must not replay with the stale ones)"""
+    from pisa_amd.core.pipeline import Pipeline
+    from pisa_amd.core.units import ureg
+
+    pipe = Pipeline("settings/pipeline/example_hip.cfg")
+    pipe.get_outputs()
+    pipe.params.theta23.value = 44.0 * ureg.degree
+    pipe.get_outputs()
+    assert pipe._plan is not None
+    osc = pipe["prob3"]
+    real = osc._matrices
+
+    def boom():
+        raise RuntimeError("matrices failed")
+
+    monkeypatch.setattr(osc, "_matrices", boom)
+    pipe.params.theta23.value = 49.0 * ureg.degree
+    with pytest.raises(RuntimeError):
+        pipe.get_outputs()
+    assert pipe._plan is None
+    monkeypatch.setattr(osc, "_matrices", real)
+    got = pipe.get_outputs()           # same parameter values: must be theta23 = 49 deg maps
+    ref = Pipeline("settings/pipeline/example_hip.cfg")
+    ref.fast_path = False
+    ref.params.theta23.value = 49.0 * ureg.degree
+    for a, b in zip(got, ref.get_outputs()):
+        np.testing.assert_array_equal(a.hist, b.hist)
