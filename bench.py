@@ -39,6 +39,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The CPU baseline's OpenMP team (oracle/liboracle.so, libgomp) is pinned one thread per core; the
+# runtime reads these when it is first loaded, i.e. with `import torch`, so they are set here.  They
+# touch host threads only.
+os.environ.setdefault("OMP_PLACES", "cores")
+os.environ.setdefault("OMP_PROC_BIND", "close")
+
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 L3_BYTES = 256 * 2 ** 20
@@ -141,14 +147,31 @@ def cpu_baseline(wl, data, matrices, device_llh):
 
     orc.build()
     cores, logical = physical_cores()
-    ln_e = [np.log(ev["true_energy"]) for ev in wl.events]
+    # columns placed for the all-core run: pages first touched by the thread that reads them (two
+    # sockets: a column allocated by the main thread sits in ONE NUMA node and caps the event loop at
+    # that node's bandwidth -- 64 threads were no faster than 32)
+    orc.set_num_threads(cores)
+    keep = []
+
+    def placed(a):
+        keep.append(orc.PartitionedCopy(a))
+        return keep[-1].array
+
+    events = []
+    for ev in wl.events:
+        d = dict(ev)
+        for k in ("true_coszen", "nu_flux", "weighted_aeff", "initial_weights"):
+            d[k] = placed(ev[k])
+        d["sample"] = [placed(c) for c in ev["sample"]]
+        events.append(d)
+    ln_e = [placed(np.log(ev["true_energy"])) for ev in wl.events]
 
     def run(threads, reps):
-        oracle_eval_allcore(wl, threads=threads, matrices=matrices, ln_energy=ln_e)      # warm-up
+        oracle_eval_allcore(wl, events, threads=threads, matrices=matrices, ln_energy=ln_e)      # warm-up
         ts, tg = [], []
         for _ in range(reps):
             t0 = time.perf_counter()
-            res = oracle_eval_allcore(wl, threads=threads, matrices=matrices, ln_energy=ln_e)
+            res = oracle_eval_allcore(wl, events, threads=threads, matrices=matrices, ln_energy=ln_e)
             ts.append(time.perf_counter() - t0)
             t0 = time.perf_counter()
             oracle_eval_allcore(wl, containers=[], threads=threads, matrices=matrices)
@@ -164,6 +187,13 @@ def cpu_baseline(wl, data, matrices, device_llh):
             t, g, _ = run(th, 3)
             scan[str(th)] = {"evals_per_s": 1.0 / t, "grid_s": g, "events_s": t - g}
     scan[str(cores)] = {"evals_per_s": 1.0 / t_all, "grid_s": g_all, "events_s": t_all - g_all}
+    # the box is shared and the container may not own all of its cores: if a smaller team is faster,
+    # that is the baseline (the better number for the CPU), with its thread count as `cores`
+    best = max(scan, key=lambda k: scan[k]["evals_per_s"])
+    if int(best) != cores:
+        t_all, g_all, cores_used = 1.0 / scan[best]["evals_per_s"], scan[best]["grid_s"], int(best)
+    else:
+        cores_used = cores
     # one thread, stage by stage (what the reference's TARGET='cpu' runs)
     orc.set_num_threads(1)
     oracle_eval(wl, matrices, containers=[])
@@ -176,14 +206,17 @@ def cpu_baseline(wl, data, matrices, device_llh):
     return {
         "value": 1.0 / t_all,
         "unit": "evals/s",
-        "cores": cores,
+        "cores": cores_used,
         "kind": "port",
         "cpu_model": cpu_model(),
+        "physical_cores_available": cores,
         "logical_cpus_available": logical,
+        "omp": {k: os.environ.get(k) for k in ("OMP_PLACES", "OMP_PROC_BIND")},
         "sample": "all %d events and the full %dx%dx2-node prob3 grid, nothing scaled: grid %.4f s + events "
-                  "%.4f s per evaluation on %d OpenMP threads (one per physical core; events = one loop per "
-                  "container with per-thread private histograms merged in thread order); median of 7"
-                  % (wl.n_events, wl.grid.n_e, wl.grid.n_cz, g_all, t_all - g_all, cores),
+                  "%.4f s per evaluation on %d OpenMP threads pinned to cores (events = one loop per container, "
+                  "columns first-touched by the reading thread, per-thread private histograms merged in thread "
+                  "order); best of the thread scan, medians"
+                  % (wl.n_events, wl.grid.n_e, wl.grid.n_cz, g_all, t_all - g_all, cores_used),
         "thread_scan": scan,
         "single_thread": {
             "value": 1.0 / t_one, "unit": "evals/s", "cores": 1,

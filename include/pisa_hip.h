@@ -42,6 +42,7 @@ extern "C" {
 #define PISA_HIP_MAX_SHELLS 64      /* PREM-59 + atmosphere = 61 */
 #define PISA_HIP_MAX_DIMS 3         /* translation.py:252 "can only do up to 3D" */
 #define PISA_HIP_ACC_LIMBS 6        /* 6 x 32-bit payload limbs, see DESIGN.md */
+#define PISA_HIP_MAX_POINTS 16      /* parameter points per multi-point call */
 
 const char *pisa_hip_strerror(int status);
 const char *pisa_hip_last_hip_error(void);
@@ -324,6 +325,52 @@ int pisa_hip_finalize_metric_scaled(int64_t *d_limbs, int32_t n_containers, int6
                                     const double *d_actual, const double *d_scale,
                                     const double *d_extra, double *total, int32_t *d_status,
                                     int32_t *d_metric_status, int32_t clear_limbs, void *stream);
+
+/* ------------------------------------------------ several parameter points in one sweep
+ * What a fit loop asks of the path: the minimiser settings of the reference are finite-difference
+ * methods (settings/minimizer/l-bfgs-b_*.json, slsqp_*.json, driven from
+ * pisa/analysis/analysis.py:2493-2670), i.e. n + 1 INDEPENDENT parameter points per gradient, and its
+ * own timing protocol evaluates independent points as well
+ * (pisa/scripts/benchmark_pipeline_performance.py:196-223).  The three calls below evaluate K points
+ * where the reference -- and the single-point calls above -- would run K whole template evaluations
+ * one after the other; per point the results are BIT-IDENTICAL to the single-point calls
+ * (tests/test_gpu_multipoint.py). */
+
+/* pisa_hip_prob3_grid_planned (osc.prob3 compute_function, prob3.py:581-608) for n_points parameter
+ * blocks h_params[n_points] in one pair of launches.  Only the gather tables are written, the points
+ * interleaved:  d_pepmu_points[2][3][n_e*n_cz][n_points][2]  (n_points == 1: the layout of d_pepmu).
+ * All points must agree in decay_flag.  n_points <= PISA_HIP_MAX_POINTS. */
+int pisa_hip_prob3_grid_planned_multi(const pisa_hip_prob3_params *h_params, int32_t n_points,
+                                      pisa_hip_grid_plan *plan, const double *d_energy, int32_t n_e,
+                                      int32_t e_major, double *d_pepmu_points, void *stream);
+
+/* pisa_hip_reweight_hist (prob3.py:621-622 + aeff.py:78-88 + utils/hist.py:163-218) for n_points
+ * parameter points in ONE pass over the event columns: the 20 B per event are read once, an event's
+ * (P_e, P_mu) pairs of all points come from one contiguous run of d_pepmu_points (layout above) and
+ * each point has its own accumulators.  Containers must carry the 16-bit index form (d_node_bin16,
+ * d_weighted_flux_q) and use the shared grid tables (d_pepmu == NULL); PISA_HIP_ERR_INVALID otherwise
+ * (the caller then evaluates point by point).
+ * h_scales[n_points][n_containers] (or NULL = every point uses container.scale): aeff.py:78-86 scale
+ * of each container at each point.
+ * d_limbs[n_points][n_containers][n_bins][2][PISA_HIP_ACC_LIMBS], zeroed by the call.
+ * A batch larger than pisa_hip_multi_points_per_pass(n_bins) is split into several sweeps. */
+int pisa_hip_reweight_hist_multi(const pisa_hip_container *h_containers, int32_t n_containers,
+                                 const pisa_hip_binning *h_calc_grid, const double *d_pepmu_points,
+                                 int32_t n_points, const double *h_scales,
+                                 const pisa_hip_binning *h_out_binning, int64_t *d_limbs,
+                                 int32_t *d_status, void *stream);
+int pisa_hip_multi_points_per_pass(int64_t n_bins);
+
+/* pisa_hip_finalize_metric_scaled for n_points sets of limbs, one workgroup per point:
+ * d_limbs as pisa_hip_reweight_hist_multi leaves them, d_hist / d_sumw2 [n_points][n_containers][n_bins],
+ * total[n_points] (device or device-mapped pinned host memory); d_actual and d_extra are shared by the
+ * points, d_scale (may be NULL) is read at d_scale + point * scale_point_stride (0: shared). */
+int pisa_hip_finalize_metric_multi(int64_t *d_limbs, int32_t n_points, int32_t n_containers,
+                                   int64_t n_bins, double *d_hist, double *d_sumw2, int32_t kind,
+                                   const double *d_actual, const double *d_scale,
+                                   int64_t scale_point_stride, const double *d_extra, double *total,
+                                   int32_t *d_status, int32_t *d_metric_status, int32_t clear_limbs,
+                                   void *stream);
 
 /* --------------------------------------------------------------------- KDE */
 

@@ -260,6 +260,28 @@ def reweight(initial_weights, nu_flux, prob_e, prob_mu, weighted_aeff, scale):
     return out
 
 
+class PartitionedCopy:
+    """numpy view of a copy of `a` whose pages were first touched by the OpenMP threads that read them
+    in `container_chain` (NUMA placement for the all-core baseline); frees the copy with the object"""
+
+    def __init__(self, a):
+        a = _f8(a)
+        rows = a.shape[0]
+        row_bytes = a.strides[0] if a.ndim > 1 else a.itemsize
+        fn = lib().oracle_partitioned_copy
+        fn.restype = C.c_void_p
+        self._ptr = fn(_p(a), C.c_int64(rows), C.c_int64(row_bytes))
+        if not self._ptr:
+            raise MemoryError("oracle_partitioned_copy")
+        buf = (C.c_double * a.size).from_address(self._ptr)
+        self.array = np.frombuffer(buf, dtype=np.float64).reshape(a.shape)
+
+    def __del__(self):
+        if getattr(self, "_ptr", None):
+            lib().oracle_free(C.c_void_p(self._ptr))
+            self._ptr = None
+
+
 def container_chain(gx, gy, gmins, gmaxs, gnb, pe_grid, pmu_grid, initial_weights, nu_flux, weighted_aeff,
                     scale, sample, mins, maxs, nbins):
     """lookup (translation.py:427-438) + prob3.apply (prob3.py:621-622) + aeff.apply (aeff.py:78-88) +

@@ -28,6 +28,7 @@
 // and the coordinate form reads 8 B x (2 lookup coords + D sample coords) more
 // = 72 B (D=3).  The (P_e, P_mu) gather tables (<= 3.8 MB) stay in L2.
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.hpp"
 #include "metric_device.hpp"
@@ -619,6 +620,138 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
     STAMP(5);
 }
 
+
+// ---------------------------------------------------------------------------
+// SEVERAL PARAMETER POINTS IN ONE SWEEP OF THE EVENTS (pisa_hip_reweight_hist_multi).
+// A fit with a finite-difference minimiser asks for n + 1 independent points per gradient
+// (pisa/analysis/analysis.py:2493-2670 driven by settings/minimizer/l-bfgs-b_*; the reference's own
+// benchmark protocol, pisa/scripts/benchmark_pipeline_performance.py:196-223, times independent points
+// as well).  The 20 B per event of the 16-bit index form do not depend on the point: this kernel reads
+// them ONCE, fetches the event's (P_e, P_mu) pairs of all KP points in one contiguous run of the
+// interleaved tables [sign][flavour][node][point], and deposits KP weights into KP sets of LDS
+// accumulators.  Per point the weight and its exact three-piece deposit are the single-point kernel's
+// (`deposit`, `slab_to_units`), so the limbs of every point are bit-identical to a
+// pisa_hip_reweight_hist call at that point (tests/test_gpu_multipoint.py).
+constexpr int MULTI_KP_MAX = 8;   // points per launch (a larger batch is split into passes)
+
+struct MultiCont {
+    int64_t n;
+    const uint32_t *idx16;
+    const double2 *wflux_q;
+    int32_t flav, side;
+};
+
+struct MultiArgs {
+    int32_t n_cont, cont_base;
+    int32_t n_bins, k_stride;   // k_stride: points interleaved in the tables
+    int64_t n_nodes;
+    int64_t limb_stride;        // limbs of one point (in 8-byte words)
+    const double2 *pepmu;       // tables + index of this launch's first point
+    MultiCont cont[MAX_CONT];
+    int32_t blk_start[MAX_CONT + 1];
+    int32_t pad;
+    double scale[MULTI_KP_MAX][MAX_CONT];   // aeff scale per (point, container)
+};
+
+template <int KP>
+__global__ void __launch_bounds__(1024)
+hist_accumulate_multi_kernel(const MultiArgs a, unsigned long long *__restrict__ g_limbs,
+                             int32_t *__restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) double s_acc[];  // [point][slab][quantity][bin]
+    const int nthreads = blockDim.x;
+    int c = 0;
+    const int bid = blockIdx.x;
+    while (c + 1 < a.n_cont && bid >= a.blk_start[c + 1]) c++;  // workgroup-uniform
+    const MultiCont &C = a.cont[c];
+    const int64_t lb = bid - a.blk_start[c];
+    const int n_bins = a.n_bins;
+    const int n_acc = NL * 2 * n_bins;
+    // the workgroups of a container sweep its columns together (see hist_accumulate_kernel)
+    const int64_t n_wg = a.blk_start[c + 1] - a.blk_start[c];
+    const int64_t qstep = n_wg * nthreads;
+    const int64_t q_end = (C.n + 3) >> 2;
+    int64_t q = lb * nthreads + threadIdx.x;
+    const uint4 *idxq = reinterpret_cast<const uint4 *>(C.idx16);
+    uint4 qx = make_uint4(~0u, ~0u, ~0u, ~0u);
+    const double2 zero2 = make_double2(0.0, 0.0);
+    double2 g[4] = {zero2, zero2, zero2, zero2};
+    bool have = q < q_end;
+    if (have) {   // first sweep requested before the accumulators are cleared
+        qx = idxq[q];
+        const double2 *gq = C.wflux_q + ((q >> 6) * 256 + (q & 63));
+        g[0] = gq[0]; g[1] = gq[64]; g[2] = gq[128]; g[3] = gq[192];
+    }
+    for (int k = threadIdx.x; k < n_acc * KP; k += nthreads) s_acc[k] = 0.0;
+    __syncthreads();
+    double sc[KP];
+#pragma unroll
+    for (int k = 0; k < KP; k++) sc[k] = a.scale[k][c];
+    const double2 *tab = a.pepmu + ((int64_t)C.side * 3 + C.flav) * a.n_nodes * a.k_stride;
+    const int ks = a.k_stride;
+    bool bad = false;
+    while (have) {
+        // next quad in flight while this one is consumed
+        const int64_t qn = q + qstep;
+        const bool have_n = qn < q_end;
+        const int64_t ql = have_n ? qn : q;
+        const uint4 qxn = idxq[ql];
+        const double2 *gn = C.wflux_q + ((ql >> 6) * 256 + (ql & 63));
+        const double2 gn0 = gn[0], gn1 = gn[64], gn2 = gn[128], gn3 = gn[192];
+        const unsigned w4[4] = {qx.x, qx.y, qx.z, qx.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const unsigned node = w4[e] & 0xffffu, bin = w4[e] >> 16;
+            if (bin != 0xffffu) {     // outside the binning: w = 0 for every point, nothing to deposit
+                double2 p[KP];
+                if (node != 0xffffu) {
+                    const double2 *tp = tab + (int64_t)node * ks;
+#pragma unroll
+                    for (int k = 0; k < KP; k++) p[k] = tp[k];
+                } else {
+                    // outside the calc grid: P = 0; the products are still formed, as in the single-point
+                    // kernel (a non-finite flux is flagged there too)
+#pragma unroll
+                    for (int k = 0; k < KP; k++) p[k] = zero2;
+                }
+#pragma unroll
+                for (int k = 0; k < KP; k++) {
+                    const double w = ((g[e].x * p[k].x) + (g[e].y * p[k].y)) * sc[k];
+                    double *acc = s_acc + k * n_acc;
+                    auto add0 = [&](int j, double piece) { atomicAdd(&acc[(j * 2 + 0) * n_bins + (int)bin], piece); };
+                    auto add1 = [&](int j, double piece) { atomicAdd(&acc[(j * 2 + 1) * n_bins + (int)bin], piece); };
+                    bool ok = deposit(w, add0);
+                    ok = deposit(w * w, add1) && ok;
+                    if (!ok) bad = true;
+                }
+            }
+        }
+        qx = qxn; g[0] = gn0; g[1] = gn1; g[2] = gn2; g[3] = gn3;
+        q = qn;
+        have = have_n;
+    }
+    if (bad && status) atomicOr(status, 1);
+    __syncthreads();
+    // slab accumulators -> integer units, added to the points' global limbs (global order, rotated
+    // start: see hist_accumulate_kernel)
+    const int rot = (int)((lb * 7 * 64) % n_acc);
+#pragma unroll 1
+    for (int k = 0; k < KP; k++) {
+        unsigned long long *g_out = g_limbs + (int64_t)k * a.limb_stride +
+                                    (int64_t)(a.cont_base + c) * n_bins * 2 * NL;
+        const double *acc = s_acc + k * n_acc;
+        for (int g0 = threadIdx.x; g0 < n_acc; g0 += nthreads) {
+            int gi = g0 + rot;
+            if (gi >= n_acc) gi -= n_acc;
+            const int bin = gi / (2 * NL);
+            const int rem = gi - bin * 2 * NL;
+            const int qq = rem / NL;
+            const int j = rem - qq * NL;
+            const double v = acc[(j * 2 + qq) * n_bins + bin];
+            if (v != 0.0) atomicAdd(&g_out[gi], (unsigned long long)slab_to_units(v, j));
+        }
+    }
+}
+
 #ifdef PISA_HIST_STAMPS
 PISA_API int pisa_hip_debug_hist_stamps(unsigned long long *h_out) {
     return check_hip(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_hist_stamps), sizeof(g_hist_stamps)), "stamps");
@@ -697,12 +830,22 @@ finalize_metric_kernel(long long *__restrict__ limbs, int n_cont, int n_bins,
                        double *__restrict__ hist, double *__restrict__ q1,
                        const double *__restrict__ actual, double *__restrict__ total,
                        int32_t *__restrict__ status, int32_t *__restrict__ mstatus, int clear,
-                       const double *__restrict__ scale, const double *__restrict__ extra) {
+                       const double *__restrict__ scale, const double *__restrict__ extra,
+                       int64_t limb_stride, int64_t scale_stride) {
     extern __shared__ __attribute__((aligned(16))) double s_map[];  // [2][n_cont][n_bins]
     __shared__ double s_sum[256];
     __shared__ int s_flag[2];
     constexpr int kind = KIND;
     const int n_tot = n_cont * n_bins;
+    {
+        // one workgroup per parameter point (pisa_hip_finalize_metric_multi; a single point: blockIdx.x = 0)
+        const int64_t pt = blockIdx.x;
+        limbs += pt * limb_stride;
+        hist += pt * n_tot;
+        q1 += pt * n_tot;
+        total += pt;
+        if (scale) scale += pt * scale_stride;
+    }
     if (threadIdx.x < 2) s_flag[threadIdx.x] = 0;
     // first bin's observed count: requested before anything else, used after the barrier
     double k_first = 0.0;
@@ -1077,13 +1220,131 @@ PISA_API int pisa_hip_reweight_hist_acc(const pisa_hip_container *h_containers,
                               d_pepmu, h_out_binning, d_limbs, d_status, stream, false);
 }
 
-PISA_API int pisa_hip_finalize_metric_scaled(int64_t *d_limbs, int32_t n_containers, int64_t n_bins,
-                                             double *d_hist, double *d_sumw2, int32_t kind,
-                                             const double *d_actual, const double *d_scale,
-                                             const double *d_extra, double *total, int32_t *d_status,
-                                             int32_t *d_metric_status, int32_t clear_limbs,
-                                             void *stream) {
-    if (!d_limbs || !d_hist || !d_sumw2 || !d_actual || !total || n_containers < 1 || n_bins < 1)
+
+static int plan_blocks_target(const int64_t *n_events, int n_cont, int threads, int64_t target_blocks,
+                              int64_t &chunk, int32_t *blk_start) {
+    int64_t total = 0;
+    for (int c = 0; c < n_cont; c++) total += n_events[c];
+    chunk = (total + target_blocks - 1) / target_blocks;
+    if (chunk < 4096) chunk = 4096;
+    if (chunk > (1 << 18)) chunk = 1 << 18;  // keeps every slab accumulator exact (< 2^53 units)
+    const int64_t q = 2 * threads;
+    chunk = ((chunk + q - 1) / q) * q;
+    blk_start[0] = 0;
+    for (int c = 0; c < n_cont; c++) {
+        int64_t nb = (n_events[c] + chunk - 1) / chunk;
+        blk_start[c + 1] = blk_start[c] + (int32_t)nb;
+    }
+    return blk_start[n_cont];
+}
+
+template <int KP>
+static int launch_multi(const MultiArgs &a, int nblocks, size_t shmem, unsigned long long *out,
+                        int32_t *d_status, hipStream_t s) {
+    static bool attr_set = false;   // LDS beyond the default 64 KiB has to be asked for once per kernel
+    if (!attr_set && shmem > 64 * 1024) {
+        PISA_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hist_accumulate_multi_kernel<KP>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((hist_accumulate_multi_kernel<KP>), dim3((unsigned)nblocks), dim3(HIST_THREADS), shmem, s,
+                       a, out, d_status);
+    PISA_CHECK_LAUNCH("hist_accumulate_multi_kernel");
+    return PISA_HIP_OK;
+}
+
+PISA_API int pisa_hip_multi_points_per_pass(int64_t n_bins) {
+    if (n_bins < 1) return 0;
+    const int64_t lds_max = (int64_t)env_int("PISA_HIP_MULTI_LDS_KB", 128) * 1024;
+    int64_t kp = lds_max / lds_acc_bytes(n_bins);
+    if (kp > MULTI_KP_MAX) kp = MULTI_KP_MAX;
+    return (int)kp;
+}
+
+PISA_API int pisa_hip_reweight_hist_multi(const pisa_hip_container *h_containers, int32_t n_containers,
+                                          const pisa_hip_binning *h_calc_grid, const double *d_pepmu_points,
+                                          int32_t n_points, const double *h_scales,
+                                          const pisa_hip_binning *h_out_binning, int64_t *d_limbs,
+                                          int32_t *d_status, void *stream) {
+    if (!h_containers || n_containers < 1 || n_containers > 1024 || !d_limbs || !d_pepmu_points ||
+        n_points < 1 || n_points > PISA_HIP_MAX_POINTS)
+        return PISA_HIP_ERR_INVALID;
+    DevBinning grid, outb;
+    int64_t n_nodes, n_bins;
+    int rc = make_dev_binning(h_calc_grid, grid, n_nodes);
+    if (rc) return rc;
+    if ((rc = make_dev_binning(h_out_binning, outb, n_bins))) return rc;
+    if (n_nodes >= 0xffff || n_bins >= 0xffff) return PISA_HIP_ERR_INVALID;
+    const int kp_max = pisa_hip_multi_points_per_pass(n_bins);
+    if (kp_max < 1) return PISA_HIP_ERR_INVALID;   // binning beyond the LDS accumulators: point by point
+    for (int c = 0; c < n_containers; c++) {
+        const pisa_hip_container &h = h_containers[c];
+        if (h.n_events < 0 || h.flav < 0 || h.flav > 2 || (h.nubar != 1 && h.nubar != -1)) return PISA_HIP_ERR_INVALID;
+        // the 16-bit index form with the shared grid tables only
+        if (h.n_events > 0 && (!h.d_node_bin16 || !h.d_weighted_flux_q || h.d_pepmu)) return PISA_HIP_ERR_INVALID;
+    }
+    hipStream_t s = as_stream(stream);
+    const int64_t limb_stride = (int64_t)n_containers * n_bins * 2 * NL;
+    PISA_TRY_HIP(hipMemsetAsync(d_limbs, 0, (size_t)n_points * limb_stride * 8, s));
+    const int n_pass = (n_points + kp_max - 1) / kp_max;
+    const int64_t target_blocks = env_int("PISA_HIP_MULTI_BLOCKS", 512);
+    for (int pass = 0, k0 = 0; pass < n_pass; pass++) {
+        const int kp = (n_points - k0 + (n_pass - pass) - 1) / (n_pass - pass);   // passes of equal size
+        for (int base = 0; base < n_containers; base += MAX_CONT) {
+            const int nc = n_containers - base < MAX_CONT ? n_containers - base : MAX_CONT;
+            MultiArgs a;
+            memset(&a, 0, sizeof(a));
+            a.n_cont = nc;
+            a.cont_base = base;
+            a.n_bins = (int32_t)n_bins;
+            a.k_stride = n_points;
+            a.n_nodes = n_nodes;
+            a.limb_stride = limb_stride;
+            a.pepmu = reinterpret_cast<const double2 *>(d_pepmu_points) + k0;
+            int64_t nev[MAX_CONT];
+            for (int c = 0; c < nc; c++) {
+                const pisa_hip_container &h = h_containers[base + c];
+                a.cont[c].n = h.n_events;
+                a.cont[c].idx16 = h.d_node_bin16;
+                a.cont[c].wflux_q = reinterpret_cast<const double2 *>(h.d_weighted_flux_q);
+                a.cont[c].flav = h.flav;
+                a.cont[c].side = h.nubar > 0 ? 0 : 1;
+                nev[c] = h.n_events;
+                for (int k = 0; k < kp; k++)
+                    a.scale[k][c] = h_scales ? h_scales[(size_t)(k0 + k) * n_containers + base + c] : h.scale;
+            }
+            int64_t chunk;
+            const int nblocks = plan_blocks_target(nev, nc, HIST_THREADS, target_blocks, chunk, a.blk_start);
+            if (nblocks <= 0) continue;
+            const size_t shmem = (size_t)lds_acc_bytes(n_bins) * kp;
+            unsigned long long *out = reinterpret_cast<unsigned long long *>(d_limbs) + (int64_t)k0 * limb_stride;
+            if (g_prof_start) PISA_TRY_HIP(hipEventRecord(g_prof_start, s));
+            switch (kp) {
+            case 1: rc = launch_multi<1>(a, nblocks, shmem, out, d_status, s); break;
+            case 2: rc = launch_multi<2>(a, nblocks, shmem, out, d_status, s); break;
+            case 3: rc = launch_multi<3>(a, nblocks, shmem, out, d_status, s); break;
+            case 4: rc = launch_multi<4>(a, nblocks, shmem, out, d_status, s); break;
+            case 5: rc = launch_multi<5>(a, nblocks, shmem, out, d_status, s); break;
+            case 6: rc = launch_multi<6>(a, nblocks, shmem, out, d_status, s); break;
+            case 7: rc = launch_multi<7>(a, nblocks, shmem, out, d_status, s); break;
+            default: rc = launch_multi<8>(a, nblocks, shmem, out, d_status, s); break;
+            }
+            if (rc) return rc;
+            if (g_prof_stop) PISA_TRY_HIP(hipEventRecord(g_prof_stop, s));
+        }
+        k0 += kp;
+    }
+    return PISA_HIP_OK;
+}
+
+PISA_API int pisa_hip_finalize_metric_multi(int64_t *d_limbs, int32_t n_points, int32_t n_containers,
+                                            int64_t n_bins, double *d_hist, double *d_sumw2, int32_t kind,
+                                            const double *d_actual, const double *d_scale,
+                                            int64_t scale_point_stride, const double *d_extra, double *total,
+                                            int32_t *d_status, int32_t *d_metric_status,
+                                            int32_t clear_limbs, void *stream) {
+    if (!d_limbs || !d_hist || !d_sumw2 || !d_actual || !total || n_containers < 1 || n_bins < 1 ||
+        n_points < 1 || n_points > PISA_HIP_MAX_POINTS)
         return PISA_HIP_ERR_INVALID;
     if (kind < PISA_HIP_METRIC_LLH || kind > PISA_HIP_METRIC_MOD_CHI2) return PISA_HIP_ERR_INVALID;
     if ((int64_t)n_containers * n_bins > PISA_HIP_FINALIZE_METRIC_MAX) return PISA_HIP_ERR_INVALID;
@@ -1091,10 +1352,12 @@ PISA_API int pisa_hip_finalize_metric_scaled(int64_t *d_limbs, int32_t n_contain
     int threads = ((n_tot + 63) / 64) * 64;
     if (threads < 256) threads = 256;  // the metric reduction tree is 256 wide
     if (threads > 1024) threads = 1024;
+    const int64_t limb_stride = (int64_t)n_tot * 2 * NL;
     auto launch = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3(1), dim3(threads), (size_t)n_tot * 16, as_stream(stream),
+        hipLaunchKernelGGL(kern, dim3((unsigned)n_points), dim3(threads), (size_t)n_tot * 16, as_stream(stream),
                            (long long *)d_limbs, (int)n_containers, (int)n_bins, d_hist, d_sumw2,
-                           d_actual, total, d_status, d_metric_status, (int)clear_limbs, d_scale, d_extra);
+                           d_actual, total, d_status, d_metric_status, (int)clear_limbs, d_scale, d_extra,
+                           limb_stride, (int64_t)scale_point_stride);
     };
     switch (kind) {
     case PISA_HIP_METRIC_LLH: launch(finalize_metric_kernel<PISA_HIP_METRIC_LLH>); break;
@@ -1104,6 +1367,17 @@ PISA_API int pisa_hip_finalize_metric_scaled(int64_t *d_limbs, int32_t n_contain
     }
     PISA_CHECK_LAUNCH("finalize_metric_kernel");
     return PISA_HIP_OK;
+}
+
+PISA_API int pisa_hip_finalize_metric_scaled(int64_t *d_limbs, int32_t n_containers, int64_t n_bins,
+                                             double *d_hist, double *d_sumw2, int32_t kind,
+                                             const double *d_actual, const double *d_scale,
+                                             const double *d_extra, double *total, int32_t *d_status,
+                                             int32_t *d_metric_status, int32_t clear_limbs,
+                                             void *stream) {
+    return pisa_hip_finalize_metric_multi(d_limbs, 1, n_containers, n_bins, d_hist, d_sumw2, kind, d_actual,
+                                          d_scale, 0, d_extra, total, d_status, d_metric_status, clear_limbs,
+                                          stream);
 }
 
 PISA_API int pisa_hip_finalize_metric(int64_t *d_limbs, int32_t n_containers, int64_t n_bins,

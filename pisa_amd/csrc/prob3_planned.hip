@@ -44,6 +44,26 @@ namespace pisa {
 // (<= 3e-13 absolute on the probabilities), not bit for bit.
 constexpr int CHAIN_GROUPS_DEFAULT = 2;
 
+// Where a kernel finds the per-evaluation constants.  One parameter point: by value in the
+// kernel-argument segment (2.3 KB, scalar loads).  SEVERAL independent parameter points in one launch
+// (pisa_hip_prob3_grid_planned_multi: blockIdx.y = 2 * point + sign): an array in device memory, the
+// point's block read through the constant address space -- the same scalar loads, from another
+// address -- so both forms run the same instructions on the same numbers.
+struct ConstsByValue {
+    Prob3Consts c;
+    __device__ __forceinline__ const Prob3Consts &at(int) const { return c; }
+};
+struct ConstsByPointer {
+    const Prob3Consts *__restrict__ p;
+    __device__ __forceinline__ const Prob3Consts &at(int k) const { return p[k]; }
+};
+
+// host-mapped staging block -> device array of the points' constants (one small launch per batch)
+__global__ void __launch_bounds__(256)
+prob3_stage_consts_kernel(const unsigned long long *__restrict__ src, unsigned long long *__restrict__ dst, int n_words) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 template <bool DECAY>
 __global__ void __launch_bounds__(64)
 prob3_terms_amp_kernel(const Prob3Consts c, const double *__restrict__ energy, int n_e,
@@ -81,18 +101,20 @@ prob3_terms_amp_kernel(const Prob3Consts c, const double *__restrict__ energy, i
 // Stage A alone: the terms of every (distinct density, sign, energy), field-major so that the
 // lanes of a wave (64 energies) read and write contiguously.  Used with the chain kernel's
 // AMP mode, which forms each layer matrix from these records where it multiplies it.
-template <bool DECAY>
+template <bool DECAY, class CS>
 __global__ void __launch_bounds__(64)
-prob3_terms_kernel(const Prob3Consts c, const double *__restrict__ energy, int n_e,
+prob3_terms_kernel(const CS cs, const double *__restrict__ energy, int n_e,
                    const double *__restrict__ rho_unique, int n_unique,
                    double *__restrict__ terms) {
     const int u = blockIdx.x;
-    const int side = blockIdx.y;
+    const int side = blockIdx.y & 1;
+    const int pt = blockIdx.y >> 1;     // parameter point (0 in the one-point form)
+    const Prob3Consts &c = cs.at(pt);
     const int ie = blockIdx.z * 64 + threadIdx.x;
     if (ie >= n_e) return;
     const int64_t ns = (int64_t)gridDim.z * 64;
     // fields in pairs, [field / 2][E][2]: the chain kernel reads a record with 16-byte loads
-    double *o = terms + ((int64_t)(side * n_unique + u) * PROB3_NF) * ns + 2 * (int64_t)ie;
+    double *o = terms + ((int64_t)((pt * 2 + side) * n_unique + u) * PROB3_NF) * ns + 2 * (int64_t)ie;
     auto store = [&](int f, double v) { o[(int64_t)(f >> 1) * (2 * ns) + (f & 1)] = v; };
     eigen_terms<DECAY>(c.side[side], c.dm, c.vac_order, energy[ie], rho_unique[u], store);
 }
@@ -141,16 +163,18 @@ __device__ __forceinline__ void mat_mul_fma(const mat3 &A, const mat3 &B, mat3 &
 // four-wave workgroups for EVERY row do not fit the chip at once (250 VGPRs: two workgroups per
 // CU).  Packed, the ~360 workgroups of a 200 x 100 grid are all resident and a 24-layer row has
 // four matrices per wave instead of seven.
-template <int G, int AMP>
+template <int G, int AMP, class CS = ConstsByValue>
 __global__ void __launch_bounds__(G ? 64 * G : 256)
-prob3_chain_kernel(const Prob3Consts c, int n_e, const int32_t *__restrict__ row_start,
+prob3_chain_kernel(const CS cs, int n_e, const int32_t *__restrict__ row_start,
                     const int32_t *__restrict__ row_cnt, const int32_t *__restrict__ row_pairs,
                     int n_cz, int n_pairs, const double *__restrict__ amp, int e_major,
                     double *__restrict__ prob_nu, double *__restrict__ prob_nubar,
                     double2 *__restrict__ pepmu, const double *__restrict__ energy,
                     const int32_t *__restrict__ pair_u, const double *__restrict__ pair_dist,
-                    int n_unique, const int32_t *__restrict__ blk) {
+                    int n_unique, const int32_t *__restrict__ blk, int n_points) {
     auto MM = [](const mat3 &A_, const mat3 &B_, mat3 &C_) { mat_mul_fma(A_, B_, C_); };
+    const int pt = blockIdx.y >> 1;     // parameter point (0 in the one-point form)
+    const Prob3Consts &c = cs.at(pt);
     constexpr bool PACKED = G == 0;
     __shared__ double s_part[(PACKED ? 3 : (G > 1 ? G - 1 : 1)) * 2 * 18 * 64];  // [partial][L|R][18][lane]
     const int lane = threadIdx.x & 63;
@@ -167,7 +191,7 @@ prob3_chain_kernel(const Prob3Consts c, int n_e, const int32_t *__restrict__ row
     }
     const int part_w = PACKED ? wv - 1 : g - 1;   // where a wave with g > 0 leaves its partials
     const int part_0 = PACKED ? wv : 0;           // leader: partner h reads slot part_0 + h - 1
-    const int side = blockIdx.y;
+    const int side = blockIdx.y & 1;
     const bool decay = AMP == 0 ? c.decay != 0 : AMP == 2;  // full 3x3 matrices stored / formed
     const int ie = blockIdx.z * 64 + lane;
     const bool live = ie < n_e && jcz >= 0;
@@ -188,7 +212,7 @@ prob3_chain_kernel(const Prob3Consts c, int n_e, const int32_t *__restrict__ row
     auto load_pair = [&](int pos, mat3 &A) {
         if (AMP != 0) {
             // `amp` holds the stage-A records here
-            const double *r = amp + ((int64_t)(side * n_unique + pair_u[pos]) * PROB3_NF) * ns + 2 * (int64_t)ie;
+            const double *r = amp + ((int64_t)((pt * 2 + side) * n_unique + pair_u[pos]) * PROB3_NF) * ns + 2 * (int64_t)ie;
             auto load = [&](int f) { return r[(int64_t)(f >> 1) * (2 * ns) + (f & 1)]; };
             amplitude_from_terms<AMP == 2>(load, pair_dist[pos] * inv_e, A);
             if (AMP == 1) su3_complete(A);
@@ -289,6 +313,14 @@ prob3_chain_kernel(const Prob3Consts c, int n_e, const int32_t *__restrict__ row
         for (int j = 0; j < 3; j++)
             P[3 * i + j] = Tf.m[j][i].re * Tf.m[j][i].re + Tf.m[j][i].im * Tf.m[j][i].im;
     int64_t node = e_major ? (int64_t)ie * n_cz + jcz : (int64_t)jcz * n_e + ie;
+    if (n_points > 1) {
+        // several points: the gather tables of the points interleaved, [sign][flavour][node][point], so
+        // that the multi-point fused kernel fetches an event's pairs of all points in one contiguous run
+#pragma unroll
+        for (int f = 0; f < 3; f++)
+            pepmu[(((int64_t)side * 3 + f) * ((int64_t)n_e * n_cz) + node) * n_points + pt] = make_double2(P[f], P[3 + f]);
+        return;
+    }
     store_node(P, node, (int64_t)n_e * n_cz, side, out, pepmu);
 }
 
@@ -321,8 +353,13 @@ struct pisa_hip_grid_plan {
     int chain_packed;      // 1 (default): packed chain launch; PISA_HIP_CHAIN_MODE=split: one row per workgroup
     int32_t *d_chain_u;    // [n_chain] the same per chain entry (position in d_row_pairs)
     double *d_chain_dist;  // [n_chain] layer length per chain entry
-    double *d_terms;       // stage-A records [2][n_unique][PROB3_NF][n_e] (AMP mode)
+    double *d_terms;       // stage-A records [points][2][n_unique][PROB3_NF][n_e] (AMP mode)
     int n_e_terms;
+    int n_pt_terms;        // parameter points d_terms has room for
+    // several parameter points in one launch (pisa_hip_prob3_grid_planned_multi)
+    Prob3Consts *d_consts;   // [PISA_HIP_MAX_POINTS] the points' constants in device memory
+    Prob3Consts *h_consts;   // [MULTI_RING][PISA_HIP_MAX_POINTS] pinned, device-mapped staging blocks
+    int consts_slot;
     int fused_amp;         // 1 (default): stage A + chain kernel forming the layer matrices itself;
                            // 0 (PISA_HIP_PROB3_FUSED_AMP=0 when the plan is created): stage AB
                            // stores the layer matrices, the chain kernel reads them
@@ -338,6 +375,8 @@ PISA_API int pisa_hip_grid_plan_destroy(pisa_hip_grid_plan *p) {
                     p->d_chain_u, p->d_chain_dist, p->d_blk};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
+    if (p->d_consts) (void)hipFree(p->d_consts);
+    if (p->h_consts) (void)hipHostFree(p->h_consts);
     delete[] p->h_pair_u;
     delete p;
     return PISA_HIP_OK;
@@ -513,12 +552,58 @@ PISA_API int pisa_hip_grid_plan_create(const double *d_densities, const double *
     return rc;
 }
 
+// the two launches of the fused-amplitude form for `n_points` parameter points whose constants `cs`
+// provides (by value: one point; by pointer: the plan's device array)
+template <class CS>
+static int launch_planned(const CS &cs, bool decay, int n_points, pisa_hip_grid_plan *plan, const double *d_energy,
+                          int32_t n_e, int32_t e_major, double *d_prob_nu, double *d_prob_nubar, double *d_pepmu,
+                          hipStream_t s) {
+    const unsigned tiles = (unsigned)((n_e + 63) / 64);
+    static const int groups = []() {
+        const char *v = getenv("PISA_HIP_CHAIN_GROUPS");
+        int g = v ? atoi(v) : CHAIN_GROUPS_DEFAULT;
+        return (g == 1 || g == 2 || g == 4) ? g : CHAIN_GROUPS_DEFAULT;
+    }();
+    if (plan->n_e_terms < n_e || plan->n_pt_terms < n_points) {
+        if (plan->d_terms) (void)hipFree(plan->d_terms);
+        plan->d_terms = nullptr;
+        plan->n_e_terms = plan->n_pt_terms = 0;
+        size_t bytes = (size_t)n_points * 2 * plan->n_unique * PROB3_NF * ((size_t)tiles * 64) * sizeof(double);
+        PISA_TRY_HIP(hipMalloc(&plan->d_terms, bytes));
+        plan->n_e_terms = n_e;
+        plan->n_pt_terms = n_points;
+    }
+    dim3 tblock(64), tgrid((unsigned)plan->n_unique, 2u * n_points, tiles);
+    if (decay)
+        hipLaunchKernelGGL((prob3_terms_kernel<true, CS>), tgrid, tblock, 0, s, cs, d_energy, (int)n_e,
+                           plan->d_rho, plan->n_unique, plan->d_terms);
+    else
+        hipLaunchKernelGGL((prob3_terms_kernel<false, CS>), tgrid, tblock, 0, s, cs, d_energy, (int)n_e,
+                           plan->d_rho, plan->n_unique, plan->d_terms);
+    PISA_CHECK_LAUNCH("prob3_terms_kernel");
+    dim3 cblock(64 * groups), cgrid((unsigned)plan->n_cz, 2u * n_points, tiles);
+#define CHAIN(G, A) hipLaunchKernelGGL((prob3_chain_kernel<G, A, CS>), cgrid, cblock, 0, s, cs, (int)n_e, plan->d_row_start, \
+                       plan->d_row_cnt, plan->d_row_pairs, plan->n_cz, plan->n_pairs, plan->d_terms,              \
+                       (int)e_major, d_prob_nu, d_prob_nubar, (double2 *)d_pepmu, d_energy, plan->d_chain_u,      \
+                       plan->d_chain_dist, plan->n_unique, plan->d_blk, n_points)
+    if (plan->chain_packed && plan->n_blk > 0) {
+        cblock = dim3(256);
+        cgrid = dim3((unsigned)plan->n_blk, 2u * n_points, tiles);
+        if (decay) CHAIN(0, 2); else CHAIN(0, 1);
+    } else if (decay) { if (groups == 1) CHAIN(1, 2); else if (groups == 4) CHAIN(4, 2); else CHAIN(2, 2); }
+    else { if (groups == 1) CHAIN(1, 1); else if (groups == 4) CHAIN(4, 1); else CHAIN(2, 1); }
+#undef CHAIN
+    PISA_CHECK_LAUNCH("prob3_chain_kernel");
+    return PISA_HIP_OK;
+}
+
 PISA_API int pisa_hip_prob3_grid_planned(const pisa_hip_prob3_params *h_params,
                                          pisa_hip_grid_plan *plan, const double *d_energy,
                                          int32_t n_e, int32_t e_major, double *d_prob_nu,
                                          double *d_prob_nubar, double *d_pepmu, void *stream) {
     if (!plan || n_e < 1 || !d_energy) return PISA_HIP_ERR_INVALID;
-    Prob3Consts c;
+    ConstsByValue cv;
+    Prob3Consts &c = cv.c;
     int rc = make_consts(h_params, c);
     if (rc) return rc;
     hipStream_t s = as_stream(stream);
@@ -530,37 +615,7 @@ PISA_API int pisa_hip_prob3_grid_planned(const pisa_hip_prob3_params *h_params,
     }();
     const int fused_amp = plan->fused_amp;
     dim3 cblock(64 * groups), cgrid((unsigned)plan->n_cz, 2, tiles);
-    if (fused_amp) {
-        if (plan->n_e_terms < n_e) {
-            if (plan->d_terms) (void)hipFree(plan->d_terms);
-            plan->d_terms = nullptr;
-            plan->n_e_terms = 0;
-            size_t bytes = (size_t)2 * plan->n_unique * PROB3_NF * ((size_t)tiles * 64) * sizeof(double);
-            PISA_TRY_HIP(hipMalloc(&plan->d_terms, bytes));
-            plan->n_e_terms = n_e;
-        }
-        dim3 tblock(64), tgrid((unsigned)plan->n_unique, 2, tiles);
-        if (c.decay)
-            hipLaunchKernelGGL(prob3_terms_kernel<true>, tgrid, tblock, 0, s, c, d_energy, (int)n_e,
-                               plan->d_rho, plan->n_unique, plan->d_terms);
-        else
-            hipLaunchKernelGGL(prob3_terms_kernel<false>, tgrid, tblock, 0, s, c, d_energy, (int)n_e,
-                               plan->d_rho, plan->n_unique, plan->d_terms);
-        PISA_CHECK_LAUNCH("prob3_terms_kernel");
-#define CHAIN(G, A) hipLaunchKernelGGL((prob3_chain_kernel<G, A>), cgrid, cblock, 0, s, c, (int)n_e, plan->d_row_start, \
-                       plan->d_row_cnt, plan->d_row_pairs, plan->n_cz, plan->n_pairs, plan->d_terms,              \
-                       (int)e_major, d_prob_nu, d_prob_nubar, (double2 *)d_pepmu, d_energy, plan->d_chain_u,      \
-                       plan->d_chain_dist, plan->n_unique, plan->d_blk)
-        if (plan->chain_packed && plan->n_blk > 0) {
-            cblock = dim3(256);
-            cgrid = dim3((unsigned)plan->n_blk, 2, tiles);
-            if (c.decay) CHAIN(0, 2); else CHAIN(0, 1);
-        } else if (c.decay) { if (groups == 1) CHAIN(1, 2); else if (groups == 4) CHAIN(4, 2); else CHAIN(2, 2); }
-        else { if (groups == 1) CHAIN(1, 1); else if (groups == 4) CHAIN(4, 1); else CHAIN(2, 1); }
-#undef CHAIN
-        PISA_CHECK_LAUNCH("prob3_chain_kernel");
-        return PISA_HIP_OK;
-    }
+    if (fused_amp) return launch_planned(cv, c.decay != 0, 1, plan, d_energy, n_e, e_major, d_prob_nu, d_prob_nubar, d_pepmu, s);
     if (plan->n_e_alloc < n_e) {
         if (plan->d_amp) (void)hipFree(plan->d_amp);
         plan->d_amp = nullptr;
@@ -581,12 +636,56 @@ PISA_API int pisa_hip_prob3_grid_planned(const pisa_hip_prob3_params *h_params,
                                plan->d_rho, plan->d_item_u, plan->d_item_p0, plan->d_item_cnt,
                                plan->d_pair_dist, plan->n_pairs, plan->d_amp);
     }
-#define CHAIN(G) hipLaunchKernelGGL((prob3_chain_kernel<G, 0>), cgrid, cblock, 0, s, c, (int)n_e, plan->d_row_start, \
+#define CHAIN(G) hipLaunchKernelGGL((prob3_chain_kernel<G, 0, ConstsByValue>), cgrid, cblock, 0, s, cv, (int)n_e, plan->d_row_start, \
                        plan->d_row_cnt, plan->d_row_pairs, plan->n_cz, plan->n_pairs, plan->d_amp,          \
                        (int)e_major, d_prob_nu, d_prob_nubar, (double2 *)d_pepmu, d_energy, plan->d_pair_u,  \
-                       plan->d_pair_dist, plan->n_unique, plan->d_blk)
+                       plan->d_pair_dist, plan->n_unique, plan->d_blk, 1)
     if (groups == 1) CHAIN(1); else if (groups == 4) CHAIN(4); else CHAIN(2);
 #undef CHAIN
     PISA_CHECK_LAUNCH("prob3_chain_kernel");
     return PISA_HIP_OK;
+}
+
+// Staging blocks for the constants of a batch: the host fills one (pinned, device-mapped) and a small
+// kernel copies it into the device array the batch kernels read.  A ring, so that a caller that queues
+// a second batch before the first has started does not overwrite what the first copy has yet to read.
+constexpr int MULTI_RING = 8;
+
+PISA_API int pisa_hip_prob3_grid_planned_multi(const pisa_hip_prob3_params *h_params, int32_t n_points,
+                                               pisa_hip_grid_plan *plan, const double *d_energy,
+                                               int32_t n_e, int32_t e_major, double *d_pepmu_points,
+                                               void *stream) {
+    if (!plan || n_e < 1 || !d_energy || !h_params || !d_pepmu_points || n_points < 1 ||
+        n_points > PISA_HIP_MAX_POINTS)
+        return PISA_HIP_ERR_INVALID;
+    if (!plan->fused_amp) return PISA_HIP_ERR_INVALID;   // the stored-amplitude option has no batch form
+    hipStream_t s = as_stream(stream);
+    if (!plan->d_consts) {
+        PISA_TRY_HIP(hipMalloc(&plan->d_consts, sizeof(Prob3Consts) * PISA_HIP_MAX_POINTS));
+        PISA_TRY_HIP(hipHostMalloc(&plan->h_consts, sizeof(Prob3Consts) * PISA_HIP_MAX_POINTS * MULTI_RING,
+                                   hipHostMallocMapped));
+        plan->consts_slot = 0;
+    }
+    Prob3Consts *hc = plan->h_consts + (size_t)plan->consts_slot * PISA_HIP_MAX_POINTS;
+    plan->consts_slot = (plan->consts_slot + 1) % MULTI_RING;
+    bool decay = false;
+    for (int k = 0; k < n_points; k++) {
+        int rc = make_consts(h_params + k, hc[k]);
+        if (rc) return rc;
+        if (k == 0) decay = hc[k].decay != 0;
+        else if ((hc[k].decay != 0) != decay) return PISA_HIP_ERR_INVALID;   // one kernel variant per batch
+    }
+    static_assert(sizeof(Prob3Consts) % 8 == 0, "copied in 8-byte words");
+    const int n_words = (int)(sizeof(Prob3Consts) / 8) * n_points;
+    hipLaunchKernelGGL(prob3_stage_consts_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s,
+                       reinterpret_cast<const unsigned long long *>(hc),
+                       reinterpret_cast<unsigned long long *>(plan->d_consts), n_words);
+    PISA_CHECK_LAUNCH("prob3_stage_consts_kernel");
+    ConstsByPointer cp{plan->d_consts};
+    if (n_points == 1) {
+        // a batch of one writes the ordinary [sign][flavour][node] tables
+        return launch_planned(cp, decay, 1, plan, d_energy, n_e, e_major, nullptr, nullptr, d_pepmu_points, s);
+    }
+    return launch_planned(cp, decay, (int)n_points, plan, d_energy, n_e, e_major, nullptr, nullptr,
+                          d_pepmu_points, s);
 }

@@ -538,17 +538,21 @@ class HotPathEngine:
         if self.world_size <= 1:
             return
         if self._rccl is None:
-            import os
-
-            from . import rccl
-
-            self._rccl = False
-            if int(os.environ.get("PISA_HIP_DIRECT_RCCL", "1")):
-                self._rccl = rccl.LimbAllReduce.create(self.dev, self.group) or False
+            self.allreduce_setup()
         if self._rccl:
             self._rccl.all_reduce_(self.ws.limbs, K._stream())
         else:
             allreduce_limbs(self.ws.limbs, self.world_size, self.group)
+
+    def allreduce_setup(self):
+        """direct RCCL communicator where the group runs on RCCL (all ranks agree), else False"""
+        import os
+
+        from . import rccl
+
+        self._rccl = False
+        if int(os.environ.get("PISA_HIP_DIRECT_RCCL", "1")):
+            self._rccl = rccl.LimbAllReduce.create(self.dev, self.group) or False
 
     def close(self):
         """release the direct RCCL communicator (before the process group is destroyed)"""
@@ -808,6 +812,106 @@ class HotPathEngine:
             self._tail(kind, out[k:k + 1])
         self.prob_nu, self.prob_nubar, self.pepmu = self._tables[(n - 1) % 2] if n else self._tables[0]
         return out
+
+    # -- several independent parameter points in one sweep of the events ---------------------------
+    def multi_capable(self):
+        """whether `eval_many` can take its one-sweep path: planned grid oscillation, 16-bit index
+        columns read through the shared grid tables, all maps in one tail workgroup, LDS room for at
+        least two points"""
+        return (self.plan is not None and self.indexed and self.index16 and not self.osc_events
+                and not self.node_flux and self.fused_tail and self.data is not None
+                and len(self.cont) * self.n_bins <= K.FINALIZE_METRIC_MAX
+                and _lib.lib().pisa_hip_multi_points_per_pass(self.n_bins) >= 2)
+
+    def _multi_ws(self, k):
+        ws = getattr(self, "_multi", None)
+        if ws is None:
+            ws = self._multi = {}
+        w = ws.get(k)
+        if w is None:
+            import ctypes as C
+
+            n_c = len(self.cont)
+            w = ws[k] = dict(
+                tables=torch.empty((2, 3, self.grid.size, k, 2), dtype=torch.float64, device=self.dev),
+                limbs=torch.zeros((k, n_c, self.n_bins, 2, _lib.ACC_LIMBS), dtype=torch.int64, device=self.dev),
+                hist=torch.empty((k, n_c, self.n_bins), dtype=torch.float64, device=self.dev),
+                sumw2=torch.empty((k, n_c, self.n_bins), dtype=torch.float64, device=self.dev),
+                host=torch.zeros(k, dtype=torch.float64).pin_memory(),
+                params=(_lib.Prob3Params * k)(), scales=(C.c_double * (k * n_c))())
+            w["host_np"] = w["host"].numpy()
+        return w
+
+    def eval_many(self, params_list, kind="llh", scales=None):
+        """K INDEPENDENT parameter points (the n + 1 points of a finite-difference gradient, a scan)
+        in one sweep of the events: one pair of prob3 launches for all points
+        (`pisa_hip_prob3_grid_planned_multi`), one fused launch that reads the event columns once
+        and keeps K sets of accumulators (`pisa_hip_reweight_hist_multi`), one all-reduce of the K
+        limb sets, one tail launch with a workgroup per point (`pisa_hip_finalize_metric_multi`);
+        the K metric values arrive in pinned host memory.  Per point the limbs, maps and metric are
+        bit-identical to `eval_host` at that point.  `scales` [K][n_containers] (optional): the
+        containers' aeff scales per point.  Returns a list of K floats; the maps of the points stay in
+        `last_many` (device tensors hist / sumw2 [K, n_cont, n_bins])."""
+        import ctypes as C
+
+        n = len(params_list)
+        if n == 0:
+            return []
+        if n == 1 or not self.multi_capable():
+            out = []
+            for i, p in enumerate(params_list):
+                if scales is not None:
+                    for name, sc in zip(self.names, scales[i]):
+                        self.set_scale(name, sc)
+                out.append(self.eval_host(p, kind))
+            return out
+        if n > _lib.MAX_POINTS:
+            out = []
+            for i in range(0, n, _lib.MAX_POINTS):
+                out += self.eval_many(params_list[i:i + _lib.MAX_POINTS], kind,
+                                      None if scales is None else scales[i:i + _lib.MAX_POINTS])
+            return out
+        w = self._multi_ws(n)
+        lib, s = _lib.lib(), K._stream()
+        arr = w["params"]
+        for i, p in enumerate(params_list):
+            arr[i] = p
+        sc_ptr = None
+        if scales is not None:
+            flat = np.ascontiguousarray(scales, dtype=np.float64).reshape(n * len(self.cont))
+            C.memmove(w["scales"], flat.ctypes.data, flat.nbytes)
+            sc_ptr = C.cast(w["scales"], C.c_void_p)
+        self._release_outputs()
+        g = self.grid
+        rc = lib.pisa_hip_prob3_grid_planned_multi(
+            C.cast(arr, C.c_void_p), n, self.plan.handle, C.c_void_p(self.energy_d.data_ptr()),
+            self.energy_d.numel(), 1 if g.energy_first else 0, C.c_void_p(w["tables"].data_ptr()), s)
+        if rc == 0:
+            rc = lib.pisa_hip_reweight_hist_multi(
+                self._cont_arr, len(self._cont_arr), C.byref(g.binning), C.c_void_p(w["tables"].data_ptr()), n,
+                sc_ptr, C.byref(self.out_binning), C.c_void_p(w["limbs"].data_ptr()),
+                C.c_void_p(self.ws.status.data_ptr()), s)
+        _lib.check(rc)
+        if self.world_size > 1:
+            if self._rccl is None:
+                self.allreduce_setup()
+            if self._rccl:
+                self._rccl.all_reduce_(w["limbs"], s)
+            else:
+                allreduce_limbs(w["limbs"], self.world_size, self.group)
+        h = w["host_np"]
+        h[:] = np.nan
+        _lib.check(lib.pisa_hip_finalize_metric_multi(
+            C.c_void_p(w["limbs"].data_ptr()), n, len(self.cont), self.n_bins, C.c_void_p(w["hist"].data_ptr()),
+            C.c_void_p(w["sumw2"].data_ptr()), K.METRIC_KIND[kind], C.c_void_p(self.data.data_ptr()), None, 0, None,
+            C.c_void_p(w["host"].data_ptr()), C.c_void_p(self.ws.status.data_ptr()),
+            C.c_void_p(self.metric_status.data_ptr()), 0, s))
+        self.last_many = w
+        for _ in range(self.spin_wait):
+            if not np.isnan(h).any():
+                return [float(v) for v in h]
+        torch.cuda.current_stream().synchronize()
+        return [float(v) for v in h]
 
     def metric_status_host(self):
         """status word of the metric kernels (negative inputs) -- one 4-byte read"""
