@@ -352,13 +352,15 @@ int pisa_hip_prob3_grid_planned_multi(const pisa_hip_prob3_params *h_params, int
  * (the caller then evaluates point by point).
  * h_scales[n_points][n_containers] (or NULL = every point uses container.scale): aeff.py:78-86 scale
  * of each container at each point.
- * d_limbs[n_points][n_containers][n_bins][2][PISA_HIP_ACC_LIMBS], zeroed by the call.
+ * d_limbs[n_points][n_containers][n_bins][2][PISA_HIP_ACC_LIMBS]; clear_first != 0: zeroed by the
+ * call, else the sums are ADDED to what they hold (the zeros pisa_hip_finalize_metric_multi leaves
+ * behind with clear_limbs = 1, as pisa_hip_reweight_hist_acc).
  * A batch larger than pisa_hip_multi_points_per_pass(n_bins) is split into several sweeps. */
 int pisa_hip_reweight_hist_multi(const pisa_hip_container *h_containers, int32_t n_containers,
                                  const pisa_hip_binning *h_calc_grid, const double *d_pepmu_points,
                                  int32_t n_points, const double *h_scales,
                                  const pisa_hip_binning *h_out_binning, int64_t *d_limbs,
-                                 int32_t *d_status, void *stream);
+                                 int32_t clear_first, int32_t *d_status, void *stream);
 int pisa_hip_multi_points_per_pass(int64_t n_bins);
 
 /* pisa_hip_finalize_metric_scaled for n_points sets of limbs, one workgroup per point:

@@ -77,6 +77,61 @@ __device__ __forceinline__ long long slab_to_units(double v, int j) {
     return (long long)(v * s);  // exact
 }
 
+// The same exact decomposition in integer arithmetic: x = +-m * 2^(ex-1075), m the 53-bit significand,
+// is truncated to a multiple of 2^-116 and cut into the (at most three) 32-bit digits it occupies,
+//   digit[jj] = (|x| / 2^-116 >> 32 jj) & 0xffffffff,  jj = j, j-1, j-2,  j = slab of the leading bit,
+// each handed to add(jj, +-digit) as a signed 64-bit count of units 2^(32jj-116).  Integer additions are
+// associative, so sums of these counts are exact in any order as long as they fit 64 bits (2^31 events
+// per accumulator).  Two 64-bit shifts instead of three rounded add/subtract pairs: a third of the
+// instructions of `deposit`, which is what bounds the multi-point kernel.  |x| < 2^-116 deposits nothing;
+// digits below slab 0 are dropped (truncation towards zero; `deposit` rounds to nearest there -- the two
+// differ by less than 2^-116 per event).
+template <class F>
+__device__ __forceinline__ bool deposit_units_general(double x, F &&add) {
+    const unsigned hi = (unsigned)__double2hiint(x);
+    const int ex = (hi >> 20) & 0x7ff;
+    if (ex == 0x7ff) return false;        // Inf / NaN
+    const int t = ex - 1023 + FX_LSB;     // position of the leading bit above the LSB of the format
+    if (t < 0) return true;               // below 2^-116 (incl. zero / subnormals)
+    const int j = t >> 5;
+    if (j >= NL) return false;            // |x| >= 2^76
+    const int sh = t & 31;                // position of the leading bit inside digit j
+    const unsigned long long m =
+        ((unsigned long long)((hi & 0xfffffu) | 0x100000u) << 32) | (unsigned)__double2loint(x);
+    const unsigned long long low = m << (sh + 12);     // digits j-1 (high word) and j-2 (low word)
+    long long d0 = (long long)(m >> (52 - sh));
+    long long d1 = (long long)(low >> 32);
+    long long d2 = (long long)(low & 0xffffffffull);
+    if ((int)hi < 0) { d0 = -d0; d1 = -d1; d2 = -d2; }
+    add(j, d0);
+    if (j >= 1 && d1 != 0) add(j - 1, d1);
+    if (j >= 2 && d2 != 0) add(j - 2, d2);
+    return true;
+}
+
+// The case that occurs: x positive, 2^-52 <= x < 2^76 (leading bit in digit 2 or above), where the three
+// digits exist and none needs a sign -- no branch inside, `add3(j, d0, d1, d2)` receives the digits of
+// slabs j, j-1, j-2 at once.  Anything else (negative, tiny, non-finite, too large) takes the general
+// form above; the wavefront decides once (`__any`), so the rare path costs nothing when nobody needs it.
+template <class F3, class F>
+__device__ __forceinline__ bool deposit_units(double x, F3 &&add3, F &&add) {
+    const unsigned hi = (unsigned)__double2hiint(x);
+    const unsigned t = (hi >> 20) - (1023u - FX_LSB);          // sign bit set: huge -> not `fast`
+    const bool fast = (t - 64u) < (unsigned)(NL * 32 - 64);
+    bool ok = true;
+    if (__any(!fast)) {
+        if (!fast) ok = deposit_units_general(x, add);
+    }
+    if (fast) {
+        const unsigned sh = t & 31u;
+        const unsigned long long m =
+            ((unsigned long long)((hi & 0xfffffu) | 0x100000u) << 32) | (unsigned)__double2loint(x);
+        const unsigned long long low = m << (sh + 12u);
+        add3((int)(t >> 5), m >> (52u - sh), low >> 32, low & 0xffffffffull);
+    }
+    return ok;
+}
+
 __device__ __forceinline__ bool bin_index(const DevBinning &b, double x, double y, double z,
                                           int64_t &flat) {
     // half-open [min, max) per dimension, bin = (int)((x - min) * norm)
@@ -657,7 +712,7 @@ template <int KP>
 __global__ void __launch_bounds__(1024)
 hist_accumulate_multi_kernel(const MultiArgs a, unsigned long long *__restrict__ g_limbs,
                              int32_t *__restrict__ status) {
-    extern __shared__ __attribute__((aligned(16))) double s_acc[];  // [point][slab][quantity][bin]
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_units[];  // [point][slab][quantity][bin], integer units
     const int nthreads = blockDim.x;
     int c = 0;
     const int bid = blockIdx.x;
@@ -672,62 +727,107 @@ hist_accumulate_multi_kernel(const MultiArgs a, unsigned long long *__restrict__
     const int64_t q_end = (C.n + 3) >> 2;
     int64_t q = lb * nthreads + threadIdx.x;
     const uint4 *idxq = reinterpret_cast<const uint4 *>(C.idx16);
-    uint4 qx = make_uint4(~0u, ~0u, ~0u, ~0u);
+    const uint4 none = make_uint4(~0u, ~0u, ~0u, ~0u);
     const double2 zero2 = make_double2(0.0, 0.0);
+    const double2 *tab = a.pepmu + ((int64_t)C.side * 3 + C.flav) * a.n_nodes * a.k_stride;
+    const int ks = a.k_stride;
+    // A wavefront takes 256 consecutive events per sweep (a quad per lane).  In the engine's resident
+    // order (engine.deposit_block_order) such a block either holds depositing events or none at all, so
+    // "does any lane of this wavefront have an event inside the binning" is the wave-uniform question
+    // that decides whether the block's flux pairs and table entries are needed at all.
+    auto any_in = [](const uint4 &v) {
+        const bool in = ((v.x >> 16) != 0xffffu) | ((v.y >> 16) != 0xffffu) | ((v.z >> 16) != 0xffffu) |
+                        ((v.w >> 16) != 0xffffu);
+        return __any(in) != 0;
+    };
+    auto gather = [&](unsigned word, double2 (&p)[KP]) {
+        // node 0xffff (outside the calc grid): entry 0 is read and replaced by P = 0 when it is used
+        const unsigned node = word & 0xffffu;
+        const double2 *tp = tab + (int64_t)(node == 0xffffu ? 0u : node) * ks;
+#pragma unroll
+        for (int k = 0; k < KP; k++) p[k] = tp[k];
+    };
+    auto load_flux = [&](int64_t qq, double2 (&gg)[4]) {
+        const double2 *gq = C.wflux_q + ((qq >> 6) * 256 + (qq & 63));
+        gg[0] = gq[0]; gg[1] = gq[64]; gg[2] = gq[128]; gg[3] = gq[192];
+    };
+    // Software pipeline over the sweeps i = 0, 1, ... of this thread (what a wavefront waits for is
+    // memory -- 16 wavefronts per CU, nothing else to switch to): while sweep i is deposited, the index
+    // words of sweep i + 2, the flux pairs of sweep i + 1 and the table entries of the NEXT event are in
+    // flight.  qx / g / p: sweep i (p: its first event); qx1: sweep i + 1.
+    uint4 qx = none, qx1 = none;
     double2 g[4] = {zero2, zero2, zero2, zero2};
+    double2 p[KP];
+#pragma unroll
+    for (int k = 0; k < KP; k++) p[k] = zero2;
     bool have = q < q_end;
-    if (have) {   // first sweep requested before the accumulators are cleared
-        qx = idxq[q];
-        const double2 *gq = C.wflux_q + ((q >> 6) * 256 + (q & 63));
-        g[0] = gq[0]; g[1] = gq[64]; g[2] = gq[128]; g[3] = gq[192];
+    if (have) qx = idxq[q];
+    if (q + qstep < q_end) qx1 = idxq[q + qstep];
+    bool in0 = any_in(qx);
+    if (in0) {
+        load_flux(q, g);
+        gather(qx.x, p);
     }
-    for (int k = threadIdx.x; k < n_acc * KP; k += nthreads) s_acc[k] = 0.0;
+    for (int k = threadIdx.x; k < n_acc * KP; k += nthreads) s_units[k] = 0ull;
     __syncthreads();
     double sc[KP];
 #pragma unroll
     for (int k = 0; k < KP; k++) sc[k] = a.scale[k][c];
-    const double2 *tab = a.pepmu + ((int64_t)C.side * 3 + C.flav) * a.n_nodes * a.k_stride;
-    const int ks = a.k_stride;
     bool bad = false;
     while (have) {
-        // next quad in flight while this one is consumed
-        const int64_t qn = q + qstep;
-        const bool have_n = qn < q_end;
-        const int64_t ql = have_n ? qn : q;
-        const uint4 qxn = idxq[ql];
-        const double2 *gn = C.wflux_q + ((ql >> 6) * 256 + (ql & 63));
-        const double2 gn0 = gn[0], gn1 = gn[64], gn2 = gn[128], gn3 = gn[192];
-        const unsigned w4[4] = {qx.x, qx.y, qx.z, qx.w};
+        const int64_t q1 = q + qstep, q2 = q1 + qstep;
+        uint4 qx2 = none;
+        if (q2 < q_end) qx2 = idxq[q2];
+        const bool in1 = any_in(qx1);      // (lanes beyond the end hold `none`)
+        double2 gn[4] = {zero2, zero2, zero2, zero2};
+        if (in1) load_flux(q1, gn);
+        if (in0) {
+            const unsigned w4[5] = {qx.x, qx.y, qx.z, qx.w, qx1.x};
+            double2 pn[KP];
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const unsigned node = w4[e] & 0xffffu, bin = w4[e] >> 16;
-            if (bin != 0xffffu) {     // outside the binning: w = 0 for every point, nothing to deposit
-                double2 p[KP];
-                if (node != 0xffffu) {
-                    const double2 *tp = tab + (int64_t)node * ks;
+            for (int e = 0; e < 4; e++) {
+                // table entries of the next event (for e = 3: the first event of the next sweep)
+                if (e < 3 || in1) gather(w4[e + 1], pn);
+                const unsigned node = w4[e] & 0xffffu, bin = w4[e] >> 16;
+                if (bin != 0xffffu) {     // outside the binning: w = 0 for every point, nothing to deposit
 #pragma unroll
-                    for (int k = 0; k < KP; k++) p[k] = tp[k];
-                } else {
-                    // outside the calc grid: P = 0; the products are still formed, as in the single-point
-                    // kernel (a non-finite flux is flagged there too)
-#pragma unroll
-                    for (int k = 0; k < KP; k++) p[k] = zero2;
+                    for (int k = 0; k < KP; k++) {
+                        // outside the calc grid: P = 0; the products are still formed, as in the single-point
+                        // kernel (a non-finite flux is flagged there too)
+                        const double2 pk = node != 0xffffu ? p[k] : zero2;
+                        const double w = ((g[e].x * pk.x) + (g[e].y * pk.y)) * sc[k];
+                        unsigned long long *acc = s_units + k * n_acc + (int)bin;
+                        auto add0 = [&](int j, long long d) { atomicAdd(&acc[(j * 2 + 0) * n_bins], (unsigned long long)d); };
+                        auto add1 = [&](int j, long long d) { atomicAdd(&acc[(j * 2 + 1) * n_bins], (unsigned long long)d); };
+                        auto add30 = [&](int j, unsigned long long d0, unsigned long long d1, unsigned long long d2) {
+                            unsigned long long *t0 = acc + __mul24(j * 2 + 0, n_bins);
+                            atomicAdd(t0, d0);
+                            atomicAdd(t0 - 2 * n_bins, d1);
+                            atomicAdd(t0 - 4 * n_bins, d2);
+                        };
+                        auto add31 = [&](int j, unsigned long long d0, unsigned long long d1, unsigned long long d2) {
+                            unsigned long long *t0 = acc + __mul24(j * 2 + 1, n_bins);
+                            atomicAdd(t0, d0);
+                            atomicAdd(t0 - 2 * n_bins, d1);
+                            atomicAdd(t0 - 4 * n_bins, d2);
+                        };
+                        bool ok = deposit_units(w, add30, add0);
+                        ok = deposit_units(w * w, add31, add1) && ok;
+                        if (!ok) bad = true;
+                    }
                 }
 #pragma unroll
-                for (int k = 0; k < KP; k++) {
-                    const double w = ((g[e].x * p[k].x) + (g[e].y * p[k].y)) * sc[k];
-                    double *acc = s_acc + k * n_acc;
-                    auto add0 = [&](int j, double piece) { atomicAdd(&acc[(j * 2 + 0) * n_bins + (int)bin], piece); };
-                    auto add1 = [&](int j, double piece) { atomicAdd(&acc[(j * 2 + 1) * n_bins + (int)bin], piece); };
-                    bool ok = deposit(w, add0);
-                    ok = deposit(w * w, add1) && ok;
-                    if (!ok) bad = true;
-                }
+                for (int k = 0; k < KP; k++) p[k] = pn[k];
             }
+        } else if (in1) {
+            gather(qx1.x, p);
         }
-        qx = qxn; g[0] = gn0; g[1] = gn1; g[2] = gn2; g[3] = gn3;
-        q = qn;
-        have = have_n;
+        qx = qx1; qx1 = qx2;
+#pragma unroll
+        for (int e = 0; e < 4; e++) g[e] = gn[e];
+        in0 = in1;
+        q = q1;
+        have = q < q_end;
     }
     if (bad && status) atomicOr(status, 1);
     __syncthreads();
@@ -738,7 +838,7 @@ hist_accumulate_multi_kernel(const MultiArgs a, unsigned long long *__restrict__
     for (int k = 0; k < KP; k++) {
         unsigned long long *g_out = g_limbs + (int64_t)k * a.limb_stride +
                                     (int64_t)(a.cont_base + c) * n_bins * 2 * NL;
-        const double *acc = s_acc + k * n_acc;
+        const unsigned long long *acc = s_units + k * n_acc;
         for (int g0 = threadIdx.x; g0 < n_acc; g0 += nthreads) {
             int gi = g0 + rot;
             if (gi >= n_acc) gi -= n_acc;
@@ -746,8 +846,8 @@ hist_accumulate_multi_kernel(const MultiArgs a, unsigned long long *__restrict__
             const int rem = gi - bin * 2 * NL;
             const int qq = rem / NL;
             const int j = rem - qq * NL;
-            const double v = acc[(j * 2 + qq) * n_bins + bin];
-            if (v != 0.0) atomicAdd(&g_out[gi], (unsigned long long)slab_to_units(v, j));
+            const unsigned long long v = acc[(j * 2 + qq) * n_bins + bin];
+            if (v != 0ull) atomicAdd(&g_out[gi], v);
         }
     }
 }
@@ -1265,7 +1365,7 @@ PISA_API int pisa_hip_reweight_hist_multi(const pisa_hip_container *h_containers
                                           const pisa_hip_binning *h_calc_grid, const double *d_pepmu_points,
                                           int32_t n_points, const double *h_scales,
                                           const pisa_hip_binning *h_out_binning, int64_t *d_limbs,
-                                          int32_t *d_status, void *stream) {
+                                          int32_t clear_first, int32_t *d_status, void *stream) {
     if (!h_containers || n_containers < 1 || n_containers > 1024 || !d_limbs || !d_pepmu_points ||
         n_points < 1 || n_points > PISA_HIP_MAX_POINTS)
         return PISA_HIP_ERR_INVALID;
@@ -1285,11 +1385,14 @@ PISA_API int pisa_hip_reweight_hist_multi(const pisa_hip_container *h_containers
     }
     hipStream_t s = as_stream(stream);
     const int64_t limb_stride = (int64_t)n_containers * n_bins * 2 * NL;
-    PISA_TRY_HIP(hipMemsetAsync(d_limbs, 0, (size_t)n_points * limb_stride * 8, s));
+    if (clear_first) PISA_TRY_HIP(hipMemsetAsync(d_limbs, 0, (size_t)n_points * limb_stride * 8, s));
     const int n_pass = (n_points + kp_max - 1) / kp_max;
-    const int64_t target_blocks = env_int("PISA_HIP_MULTI_BLOCKS", 512);
     for (int pass = 0, k0 = 0; pass < n_pass; pass++) {
         const int kp = (n_points - k0 + (n_pass - pass) - 1) / (n_pass - pass);   // passes of equal size
+        // workgroups: what is resident at once.  From two points on the kernel needs more than 64 VGPRs,
+        // a CU holds ONE 1024-thread workgroup, and a second round of workgroups would only add a tail
+        const bool two_per_cu = kp <= 1 && lds_acc_bytes(n_bins) * kp <= 80 * 1024;
+        const int64_t target_blocks = env_int("PISA_HIP_MULTI_BLOCKS", two_per_cu ? 512 : 256);
         for (int base = 0; base < n_containers; base += MAX_CONT) {
             const int nc = n_containers - base < MAX_CONT ? n_containers - base : MAX_CONT;
             MultiArgs a;

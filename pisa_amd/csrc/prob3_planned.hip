@@ -171,9 +171,23 @@ prob3_chain_kernel(const CS cs, int n_e, const int32_t *__restrict__ row_start,
                     double *__restrict__ prob_nu, double *__restrict__ prob_nubar,
                     double2 *__restrict__ pepmu, const double *__restrict__ energy,
                     const int32_t *__restrict__ pair_u, const double *__restrict__ pair_dist,
-                    int n_unique, const int32_t *__restrict__ blk, int n_points) {
+                    int n_unique, const int32_t *__restrict__ blk, int n_points, int n_tiles) {
     auto MM = [](const mat3 &A_, const mat3 &B_, mat3 &C_) { mat_mul_fma(A_, B_, C_); };
-    const int pt = blockIdx.y >> 1;     // parameter point (0 in the one-point form)
+    // Several points, packed launch (n_tiles > 0): a 1-D grid in which the (point, sign, energy tile)
+    // index runs FASTEST and the row-block index slowest -- the plan lists the row blocks longest rows
+    // first, so the long rows of every point, sign and tile start first and the short ones fill the tail
+    // (with several points the workgroups no longer fit the chip at once).  The fast index is rotated by
+    // the row block: consecutive workgroups go to consecutive XCDs, and without the rotation an XCD would
+    // see the same few (point, sign, tile) records from all of its CUs at the same moment.  One point:
+    // the 3-D grid (row block fastest), all workgroups resident at once.
+    const bool lin = G == 0 && n_tiles > 0;
+    const int n_yz = lin ? 2 * n_points * n_tiles : 1;
+    const int bx = lin ? (int)(blockIdx.x / n_yz) : (int)blockIdx.x;
+    const int byz = lin ? (int)((blockIdx.x + bx) % n_yz) : 0;
+    const int by = lin ? byz % (2 * n_points) : (int)blockIdx.y;
+    const int bz = lin ? byz / (2 * n_points) : (int)blockIdx.z;
+    if (!lin) n_tiles = gridDim.z;
+    const int pt = by >> 1;     // parameter point (0 in the one-point form)
     const Prob3Consts &c = cs.at(pt);
     constexpr bool PACKED = G == 0;
     __shared__ double s_part[(PACKED ? 3 : (G > 1 ? G - 1 : 1)) * 2 * 18 * 64];  // [partial][L|R][18][lane]
@@ -182,18 +196,18 @@ prob3_chain_kernel(const CS cs, int n_e, const int32_t *__restrict__ row_start,
     // bounds derived from it are 'divergent' and every index look-up becomes a vector load
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // row, group of this wave within the row, groups of the row; partial slot of a writer wave
-    int jcz = blockIdx.x, g = wv, Gr = G;
+    int jcz = bx, g = wv, Gr = G;
     if (PACKED) {
-        const int32_t code = __builtin_amdgcn_readfirstlane(blk[blockIdx.x * 4 + wv]);  // row | g << 16 | groups << 24, -1: idle wave
+        const int32_t code = __builtin_amdgcn_readfirstlane(blk[bx * 4 + wv]);  // row | g << 16 | groups << 24, -1: idle wave
         jcz = code < 0 ? -1 : (code & 0xffff);
         g = code < 0 ? 0 : ((code >> 16) & 0xff);
         Gr = code < 0 ? 1 : ((code >> 24) & 0xff);
     }
     const int part_w = PACKED ? wv - 1 : g - 1;   // where a wave with g > 0 leaves its partials
     const int part_0 = PACKED ? wv : 0;           // leader: partner h reads slot part_0 + h - 1
-    const int side = blockIdx.y & 1;
+    const int side = by & 1;
     const bool decay = AMP == 0 ? c.decay != 0 : AMP == 2;  // full 3x3 matrices stored / formed
-    const int ie = blockIdx.z * 64 + lane;
+    const int ie = bz * 64 + lane;
     const bool live = ie < n_e && jcz >= 0;
     double *out = side == 0 ? prob_nu : prob_nubar;
     const Prob3Side &S = c.side[side];
@@ -203,7 +217,7 @@ prob3_chain_kernel(const CS cs, int n_e, const int32_t *__restrict__ row_start,
     const int n_steps = mid;  // steps s = 1..mid (out-going side may be one shorter)
     const int s0 = 1 + (int)(((int64_t)n_steps * g) / Gr);
     const int s1 = 1 + (int)(((int64_t)n_steps * (g + 1)) / Gr);
-    const int64_t ns = (int64_t)gridDim.z * 64;
+    const int64_t ns = (int64_t)n_tiles * 64;
     // 1/E once per lane: L/E as a product (one rounding more than the quotient, 1e-16 on a phase)
     const double inv_e = (AMP != 0 && live) ? 1.0 / energy[ie] : 1.0;
     // `pos` = position in the row-pairs list.  In the AMP modes the density index and the length of
@@ -585,10 +599,15 @@ static int launch_planned(const CS &cs, bool decay, int n_points, pisa_hip_grid_
 #define CHAIN(G, A) hipLaunchKernelGGL((prob3_chain_kernel<G, A, CS>), cgrid, cblock, 0, s, cs, (int)n_e, plan->d_row_start, \
                        plan->d_row_cnt, plan->d_row_pairs, plan->n_cz, plan->n_pairs, plan->d_terms,              \
                        (int)e_major, d_prob_nu, d_prob_nubar, (double2 *)d_pepmu, d_energy, plan->d_chain_u,      \
-                       plan->d_chain_dist, plan->n_unique, plan->d_blk, n_points)
+                       plan->d_chain_dist, plan->n_unique, plan->d_blk, n_points, lin_tiles)
+    int lin_tiles = 0;
     if (plan->chain_packed && plan->n_blk > 0) {
         cblock = dim3(256);
         cgrid = dim3((unsigned)plan->n_blk, 2u * n_points, tiles);
+        if (n_points > 1) {
+            lin_tiles = (int)tiles;
+            cgrid = dim3((unsigned)plan->n_blk * 2u * n_points * tiles, 1, 1);
+        }
         if (decay) CHAIN(0, 2); else CHAIN(0, 1);
     } else if (decay) { if (groups == 1) CHAIN(1, 2); else if (groups == 4) CHAIN(4, 2); else CHAIN(2, 2); }
     else { if (groups == 1) CHAIN(1, 1); else if (groups == 4) CHAIN(4, 1); else CHAIN(2, 1); }
@@ -639,7 +658,7 @@ PISA_API int pisa_hip_prob3_grid_planned(const pisa_hip_prob3_params *h_params,
 #define CHAIN(G) hipLaunchKernelGGL((prob3_chain_kernel<G, 0, ConstsByValue>), cgrid, cblock, 0, s, cv, (int)n_e, plan->d_row_start, \
                        plan->d_row_cnt, plan->d_row_pairs, plan->n_cz, plan->n_pairs, plan->d_amp,          \
                        (int)e_major, d_prob_nu, d_prob_nubar, (double2 *)d_pepmu, d_energy, plan->d_pair_u,  \
-                       plan->d_pair_dist, plan->n_unique, plan->d_blk, 1)
+                       plan->d_pair_dist, plan->n_unique, plan->d_blk, 1, 0)
     if (groups == 1) CHAIN(1); else if (groups == 4) CHAIN(4); else CHAIN(2);
 #undef CHAIN
     PISA_CHECK_LAUNCH("prob3_chain_kernel");

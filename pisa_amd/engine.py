@@ -159,6 +159,41 @@ def lds_bank_order(obin, window=4096, banks=32, per=2):
     return perm
 
 
+def deposit_block_order(obin, node, block=256, window=4096, banks=32):
+    """Resident order of the 16-bit index form: the events that can deposit (inside the output binning
+    AND the calc grid) are gathered into whole blocks of `block` = 256 events -- what ONE wavefront
+    takes per sweep (64 lanes x a quad) -- and those blocks are spread evenly among the blocks of events
+    that deposit nothing.  A wavefront then either deposits with all of its lanes or skips the deposit
+    code altogether (wave-uniform branch), instead of every wavefront running it with the third of its
+    lanes that happen to be inside the binning: the fused kernel issues a third of the LDS atomics and
+    of the split arithmetic, which is what bounds the multi-point kernel (`eval_many`).  Inside the
+    depositing events: sorted by calc-grid node, then the LDS-bank-aware order (`lds_bank_order`);
+    blocks move whole, so both survive.  The sums are exact, so the order is free to choose.
+    Returns a permutation (device int64)."""
+    n = obin.numel()
+    dev = obin.device
+    dep = (obin >= 0) & (node >= 0)
+    idx_b = torch.nonzero(dep).reshape(-1)
+    idx_u = torch.nonzero(~dep).reshape(-1)
+    pb = idx_b[torch.argsort(node[idx_b], stable=True)]
+    if pb.numel():
+        pb = pb[lds_bank_order(obin[pb], window=window, banks=banks, per=4)]
+    pu = idx_u[torch.argsort(node[idx_u], stable=True)]
+    seq = torch.cat((pb, pu))       # the last depositing block is topped up with the first idle events
+    t_full = n // block
+    nbb = min(-(-int(pb.numel()) // block), t_full)
+    if nbb == 0 or nbb == t_full:
+        return seq
+    pos_b = (torch.arange(nbb, device=dev) * t_full) // nbb      # distinct: t_full >= nbb
+    is_b = torch.zeros(t_full, dtype=torch.bool, device=dev)
+    is_b[pos_b] = True
+    src = torch.empty(t_full, dtype=torch.int64, device=dev)
+    src[is_b] = torch.arange(nbb, device=dev)
+    src[~is_b] = torch.arange(nbb, t_full, device=dev)
+    body = seq[: t_full * block].view(t_full, block)[src].reshape(-1)
+    return torch.cat((body, seq[t_full * block:]))
+
+
 def local_slices(sizes, rank, world_size):
     """[(lo, hi)] of this rank's shard of every container (`sizes` = events per container): the
     partition `HotPathEngine` uses -- contiguous, equal to within one event, disjoint, complete"""
@@ -202,7 +237,7 @@ class HotPathEngine:
     def __init__(self, containers, grid, out_binning, earth, max_layers, rank=0, world_size=1,
                  group=None, indexed=True, planned=True, packed=True, sort_events=True,
                  external_tables=False, osc_mode="grid", drop_unbinned=False, compact=False, index16=True,
-                 lds_order=True, node_flux=False):
+                 lds_order=True, node_flux=False, block_order=True):
         self.dev = K.device()
         assert osc_mode in ("grid", "events")
         # flux given on the calc grid (`nu_flux_nodes` [grid.size, 2] per container) instead of per
@@ -308,7 +343,12 @@ class HotPathEngine:
                                                    width=int(os.environ.get("PISA_BIN_PARTITION", 672)))
                     else:
                         perm = torch.argsort(node, stable=True)
-                if lds_order and perm is not None and (sort_events == "part" or (
+                blocked = (index16 and lds_order and block_order and perm is not None and sort_events == "node"
+                           and self.n_bins * 96 <= 65536 and bool(int(os.environ.get("PISA_BLOCK_ORDER", "1"))))
+                if blocked:
+                    perm = deposit_block_order(obin, node, window=int(os.environ.get("PISA_LDS_WINDOW", 4096)),
+                                               banks=int(os.environ.get("PISA_LDS_BANKS", 32)))
+                elif lds_order and perm is not None and (sort_events == "part" or (
                         sort_events != "bin" and self.n_bins * 96 <= 65536)):
                     import os  # development overrides (scripts/dev)
                     perm = perm[lds_bank_order(obin[perm], window=int(os.environ.get("PISA_LDS_WINDOW", 4096)),
@@ -838,7 +878,7 @@ class HotPathEngine:
                 hist=torch.empty((k, n_c, self.n_bins), dtype=torch.float64, device=self.dev),
                 sumw2=torch.empty((k, n_c, self.n_bins), dtype=torch.float64, device=self.dev),
                 host=torch.zeros(k, dtype=torch.float64).pin_memory(),
-                params=(_lib.Prob3Params * k)(), scales=(C.c_double * (k * n_c))())
+                params=(_lib.Prob3Params * k)(), scales=(C.c_double * (k * n_c))(), zero=True)
             w["host_np"] = w["host"].numpy()
         return w
 
@@ -889,8 +929,9 @@ class HotPathEngine:
         if rc == 0:
             rc = lib.pisa_hip_reweight_hist_multi(
                 self._cont_arr, len(self._cont_arr), C.byref(g.binning), C.c_void_p(w["tables"].data_ptr()), n,
-                sc_ptr, C.byref(self.out_binning), C.c_void_p(w["limbs"].data_ptr()),
+                sc_ptr, C.byref(self.out_binning), C.c_void_p(w["limbs"].data_ptr()), 0 if w["zero"] else 1,
                 C.c_void_p(self.ws.status.data_ptr()), s)
+        w["zero"] = False
         _lib.check(rc)
         if self.world_size > 1:
             if self._rccl is None:
@@ -905,7 +946,8 @@ class HotPathEngine:
             C.c_void_p(w["limbs"].data_ptr()), n, len(self.cont), self.n_bins, C.c_void_p(w["hist"].data_ptr()),
             C.c_void_p(w["sumw2"].data_ptr()), K.METRIC_KIND[kind], C.c_void_p(self.data.data_ptr()), None, 0, None,
             C.c_void_p(w["host"].data_ptr()), C.c_void_p(self.ws.status.data_ptr()),
-            C.c_void_p(self.metric_status.data_ptr()), 0, s))
+            C.c_void_p(self.metric_status.data_ptr()), 1, s))
+        w["zero"] = True      # the tail leaves the limbs zeroed for the next sweep
         self.last_many = w
         for _ in range(self.spin_wait):
             if not np.isnan(h).any():
