@@ -101,9 +101,95 @@ class Analysis:
                                        " ".join("%12.5e" % p.value.m for p in hypo_maker.params.free)))
         return sign * metric_val
 
-    def fit_hypo(self, data_dist, hypo_maker, metric, minimizer_settings=None, reset_free=True):
+    @staticmethod
+    def _forward_stencil(x0, eps, lb, ub):
+        """The points scipy's '2-point' finite differences evaluate around `x0` for an absolute step
+        `eps` inside the bounds [lb, ub] -- what L-BFGS-B and SLSQP do when no Jacobian is given
+        (scipy.optimize._numdiff.approx_derivative: step eps, replaced by sqrt(machine eps) * max(1, |x|)
+        where x + eps == x; the sign of a step flips where the forward point would leave the bounds, and
+        where neither direction has room the step shrinks to the wider side).  Returns (points, dx):
+        points[0] = x0, points[1 + i] = x0 with coordinate i moved, dx[i] the step actually taken
+        (recomputed as the representable difference, as scipy does)."""
+        x0 = np.asarray(x0, dtype=np.float64)
+        sign = (x0 >= 0).astype(np.float64) * 2 - 1
+        h = np.full_like(x0, eps)
+        h = np.where((x0 + h) - x0 == 0, np.sqrt(np.finfo(np.float64).eps) * sign * np.maximum(1.0, np.abs(x0)), h)
+        lower, upper = x0 - lb, ub - x0
+        x = x0 + h
+        violated = (x < lb) | (x > ub)
+        fitting = np.abs(h) <= np.maximum(lower, upper)
+        h = np.where(violated & fitting, -h, h)
+        forward = (upper >= lower) & ~fitting
+        h = np.where(forward, upper, h)
+        backward = (upper < lower) & ~fitting
+        h = np.where(backward, -lower, h)
+        pts, dx = [x0.copy()], np.empty_like(x0)
+        for i in range(x0.size):
+            x1 = x0.copy()
+            x1[i] += h[i]
+            dx[i] = x1[i] - x0[i]
+            pts.append(x1)
+        return pts, dx
+
+    def _minimizer_callable_with_gradient(self, scaled_param_vals, hypo_maker, data_dist, metric, counter,
+                                          fit_history, eps, bounds):
+        """`_minimizer_callable` together with the forward-difference gradient the minimiser would
+        otherwise take point by point: the n + 1 points of the stencil are INDEPENDENT template
+        evaluations and go through `hypo_maker.metric_many` -- one sweep of the events where the
+        pipeline allows it.  Same points, same metric values, same differences and quotients as scipy's
+        own finite differences, so the fit follows the same trajectory; the fit history lists the
+        points in the order scipy would have asked for them."""
+        sign = self._sign(metric)
+        x0 = np.asarray(scaled_param_vals, dtype=np.float64)
+        lb = np.array([b[0] for b in bounds], dtype=np.float64)
+        ub = np.array([b[1] for b in bounds], dtype=np.float64)
+        pts, dx = self._forward_stencil(x0, eps, lb, ub)
+        free = hypo_maker.params.free
+        at = {}
+        vals = hypo_maker.metric_many(pts, data_dist, metric,
+                                      on_point=lambda i: at.setdefault(i, [p.value.m for p in free]))
+        for i, (x, v) in enumerate(zip(pts, vals)):
+            counter += 1
+            if fit_history is not None:
+                fit_history.append([v] + at[i])
+            if self.pprint:
+                print("%6d %12.5e | %s" % (counter.count, v, " ".join("%12.5e" % xi for xi in x)))
+        f = np.array([sign * v for v in vals])
+        return f[0], (f[1:] - f[0]) / dx
+
+    def _gradient_only_callable(self, scaled_param_vals, hypo_maker, data_dist, metric, counter, fit_history,
+                                eps, bounds, last):
+        """The forward-difference gradient alone, for a method whose line search asks for function
+        values without gradients (SLSQP): the value at `x` is the one the minimiser has just been given
+        by `_minimizer_callable` (`last` = [x, sign * metric]), only the n moved points are evaluated --
+        together.  Evaluates the central point as well if it is not the last one seen."""
+        x0 = np.asarray(scaled_param_vals, dtype=np.float64)
+        if last[0] is None or not np.array_equal(last[0], x0):
+            f0, g = self._minimizer_callable_with_gradient(x0, hypo_maker, data_dist, metric, counter,
+                                                           fit_history, eps, bounds)
+            last[0], last[1] = x0.copy(), f0
+            return g
+        sign = self._sign(metric)
+        lb = np.array([b[0] for b in bounds], dtype=np.float64)
+        ub = np.array([b[1] for b in bounds], dtype=np.float64)
+        pts, dx = self._forward_stencil(x0, eps, lb, ub)
+        free = hypo_maker.params.free
+        at = {}
+        vals = hypo_maker.metric_many(pts[1:], data_dist, metric,
+                                      on_point=lambda i: at.setdefault(i, [p.value.m for p in free]))
+        for i, v in enumerate(vals):
+            counter += 1
+            if fit_history is not None:
+                fit_history.append([v] + at[i])
+        return (np.array([sign * v for v in vals]) - last[1]) / dx
+
+    def fit_hypo(self, data_dist, hypo_maker, metric, minimizer_settings=None, reset_free=True,
+                 batched_gradient=True):
         """scipy.optimize.minimize over the free params (L-BFGS-B by default, as
-        settings/minimizer/l-bfgs-b_ftol2e-5_gtol1e-5_eps1e-4_maxiter200.json)."""
+        settings/minimizer/l-bfgs-b_ftol2e-5_gtol1e-5_eps1e-4_maxiter200.json).
+        `batched_gradient` (L-BFGS-B / SLSQP without a user Jacobian): the finite-difference stencil of
+        every iterate is evaluated in one call (`_minimizer_callable_with_gradient`); the fit is the
+        same fit, point for point."""
         from scipy import optimize
 
         if reset_free:
@@ -132,10 +218,39 @@ class Analysis:
                    + hypo_maker.params.priors_penalty(metric=metric))
             meta = OrderedDict(success=True, nit=0, nfev=0, message="Initial hypo matches data, no need for fit")
             return HypoFitResult(metric, val, hypo_maker.params, hypo, None, meta, 0)
-        res = optimize.minimize(
-            fun=self._minimizer_callable, x0=x0, args=(hypo_maker, data_dist, metric, counter, history),
-            bounds=bounds if ms["method"].lower() in ("l-bfgs-b", "slsqp", "tnc", "trust-constr") else None,
-            method=ms["method"], options=ms.get("options", {}))
+        method = ms["method"].lower()
+        options = dict(ms.get("options", {}))
+        if (batched_gradient and method in ("l-bfgs-b", "slsqp") and hasattr(hypo_maker, "metric_many")
+                and "jac" not in ms and "finite_diff_rel_step" not in options):
+            # the step the method would use itself: `eps` (L-BFGS-B default 1e-8, SLSQP default sqrt(eps))
+            eps = options.get("eps", 1e-8 if method == "l-bfgs-b" else np.sqrt(np.finfo(np.float64).eps))
+            if method == "l-bfgs-b":
+                # every point the method visits needs value AND gradient: n + 1 points per call
+                res = optimize.minimize(
+                    fun=self._minimizer_callable_with_gradient, x0=x0, jac=True,
+                    args=(hypo_maker, data_dist, metric, counter, history, eps, bounds),
+                    bounds=bounds, method=ms["method"], options=options)
+            else:
+                # SLSQP's line search asks for values alone: single points as before, the n moved
+                # points of a gradient together
+                last = [None, None]
+
+                def fun(x):
+                    f = self._minimizer_callable(x, hypo_maker, data_dist, metric, counter, history)
+                    last[0], last[1] = np.array(x, dtype=np.float64), f
+                    return f
+
+                def jac(x):
+                    return self._gradient_only_callable(x, hypo_maker, data_dist, metric, counter, history,
+                                                        eps, bounds, last)
+
+                res = optimize.minimize(fun=fun, x0=x0, jac=jac, bounds=bounds, method=ms["method"],
+                                        options=options)
+        else:
+            res = optimize.minimize(
+                fun=self._minimizer_callable, x0=x0, args=(hypo_maker, data_dist, metric, counter, history),
+                bounds=bounds if method in ("l-bfgs-b", "slsqp", "tnc", "trust-constr") else None,
+                method=ms["method"], options=options)
         hypo_maker._set_rescaled_free_params(np.clip(res.x, 0.0, 1.0))  # pylint: disable=protected-access
         hypo = hypo_maker.get_outputs(return_sum=True)
         val = self._sign(metric) * res.fun

@@ -96,6 +96,47 @@ class DistributionMaker:
         """free params from their [0,1]-rescaled values (distribution_maker.py:462-476)"""
         self._for_each_free(rvalues, lambda prm, r: setattr(prm, "_rescaled_value", float(r)))
 
+    def metric_many(self, rescaled_points, data_dist, metric, on_point=None):
+        """[data_dist.metric_total(template at x, metric) + priors penalty at x  for x in points]:
+        the template evaluated at several INDEPENDENT points of the [0,1]-rescaled free parameters.
+        With one pipeline of the replayable shape whose moving parameters belong to osc.prob3 / aeff.aeff
+        the points share one sweep of the events (`FastPlan.metric_many`); otherwise, and with identical
+        results, point by point.  `on_point(i)` is called while the parameters sit at point i (a fit history
+        reads the values there; it may be called again for a point if the sweep had to be abandoned).  The parameters are left at the last point."""
+        import numpy as np
+
+        from pisa_amd.core.map import Map
+
+        pts = [np.clip(np.asarray(x, dtype=np.float64), 0.0, 1.0) for x in rescaled_points]
+        data_map = data_dist if isinstance(data_dist, Map) else (data_dist.maps[0] if len(data_dist) == 1 else None)
+        plan = self._pipelines[0]._plan if len(self._pipelines) == 1 and self._pipelines[0].fast_path else None
+        if plan is not None and data_map is not None and len(pts) > 1:
+            pens = []
+
+            def set_point(i):
+                self._set_rescaled_free_params(pts[i])
+                pens.append(self.params.priors_penalty(metric=metric))
+                if on_point is not None:
+                    on_point(i)
+
+            try:
+                vals = plan.metric_many(set_point, len(pts), data_map.hist, metric)
+            except BaseException:
+                self._pipelines[0]._plan = None
+                plan.invalidate()
+                raise
+            if vals is not None:
+                return [v + p for v, p in zip(vals, pens)]
+        out = []
+        for i, x in enumerate(pts):
+            self._set_rescaled_free_params(x)
+            if on_point is not None:
+                on_point(i)
+            hypo = self.get_outputs(return_sum=True)
+            out.append(data_dist.metric_total(expected_values=hypo, metric=metric)
+                       + self.params.priors_penalty(metric=metric))
+        return out
+
     def randomize_free_params(self, random_state=None):
         import numpy as np
 

@@ -232,6 +232,7 @@ class FastPlan:
         self._osc_args = None
         self._lib = _lib.lib()
         self.scales = self._read_scales() if self.post else None
+        self._dirty = False     # a multi-point sweep has left the single-point tables / scales behind
 
     def _writes(self):
         """stores into THIS pipeline's containers (the other pipelines of a DistributionMaker write
@@ -272,6 +273,62 @@ class FastPlan:
         for s in [self.osc, self.aeff] + self.flux_stages + self.post:
             s.param_hash = None
 
+    def metric_many(self, set_point, n_points, data_hist, kind):
+        """The metric of the total template against `data_hist` at `n_points` INDEPENDENT parameter
+        points in one sweep of the events (`HotPathEngine.eval_many`) -- what a finite-difference
+        minimiser asks for per gradient (pisa/analysis/analysis.py:2493-2670 with the l-bfgs-b / slsqp
+        settings).  `set_point(i)` moves the pipeline's parameters to point i.  Per point the value is
+        the very number `run()` + `Map.metric_total` give there.  Returns the list of values, or None
+        when the points cannot be taken together (a stage other than osc.prob3 / aeff.aeff moves, the
+        flux lives on the grid, stages behind the histogram, ...): the caller then goes point by point.
+        The pipeline's parameters are left at the last point."""
+        osc, eng = self.osc, self.engine
+        if self.post or self.flux_stages or self.hist._engine is not eng or osc.pepmu is None:
+            return None
+        g = osc.grid
+        if (self._writes() != self.container_clock or n_points < 2
+                or bool(g["e_major"]) != bool(eng.grid.energy_first)):
+            return None
+        eng.set_data_cached(np.ascontiguousarray(data_hist, dtype=np.float64).ravel())
+        if not eng.multi_capable(g["plan"]):
+            return None
+        params_list, scales = [], []
+        self._dirty = True           # from here on the change counters are consumed point by point
+
+        def abandon():
+            # counters of stages this plan cannot take in a sweep have been consumed: forget what was
+            # seen, so that the next evaluation finds every stage moved and goes through the Stage
+            # protocol (whose own memos compare parameter VALUES)
+            self.seen = [None] * len(self.seen)
+            return None
+
+        for i in range(n_points):
+            set_point(i)
+            changed = self._changed()
+            if changed is None:
+                return abandon()
+            for s in changed:
+                if s is not osc and s is not self.aeff:
+                    return abandon()
+            p = osc.params
+            ye = (p.YeI.value.m_as("dimensionless"), p.YeO.value.m_as("dimensionless"),
+                  p.YeM.value.m_as("dimensionless"))
+            if ye != self.ye:
+                return abandon()
+            params_list.append(_lib.Prob3Params.from_buffer_copy(osc._matrices()))
+            scales.append([self.aeff.scale_for(name) for name in self.names])
+        osc.param_hash = None
+        self.clock = Param.clock
+        vals = eng.eval_many(params_list, kind, np.asarray(scales, dtype=np.float64), plan=g["plan"],
+                             energy=g["energy"])
+        if any(v != v for v in vals):
+            st = eng.metric_status_host()
+            if st != 0:
+                _lib.check(st)
+        # the engine's own per-container scales may have been moved by a point-by-point fallback
+        self.pipeline._containers_stale = True
+        return vals
+
     def run(self):
         """device-backed output MapSet, or None: take the ordinary path"""
         osc, eng = self.osc, self.engine
@@ -279,10 +336,15 @@ class FastPlan:
             return _no("engine replaced")
         if self._writes() != self.container_clock:
             return _no("a container was written")   # e.g. somebody edited a flux column in place
-        if Param.clock != self.clock:
+        if Param.clock != self.clock or self._dirty:
             changed = self._changed()
             if changed is None:
                 return _no("parameter objects exchanged")
+            if self._dirty:
+                # `metric_many` evaluated other points through its own tables: whatever the counters
+                # say, the oscillation tables and the containers' scales are those of an older point
+                changed = list(changed) + [s for s in (osc, self.aeff) if all(s is not c for c in changed)]
+                self._dirty = False
             replayable = [osc, self.aeff] + self.flux_stages + self.post
             for s in changed:
                 if all(s is not r for r in replayable):

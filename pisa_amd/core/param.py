@@ -240,6 +240,10 @@ class Param:
         else:
             v = r0 + (r1 - r0) * rval
         v = min(max(v, min(r0, r1)), max(r0, r1))
+        if isinstance(self._value, Quantity) and self._value.units == self._units and self._value.magnitude == v:
+            # the very value it has: nothing changed, no stage needs to recompute (a minimiser sets ALL
+            # free parameters at every point, although a finite-difference step moves one of them)
+            return
         self._value = Quantity(v, self._units)
         self._touch()
 

@@ -86,6 +86,16 @@ __device__ __forceinline__ long long slab_to_units(double v, int j) {
 // instructions of `deposit`, which is what bounds the multi-point kernel.  |x| < 2^-116 deposits nothing;
 // digits below slab 0 are dropped (truncation towards zero; `deposit` rounds to nearest there -- the two
 // differ by less than 2^-116 per event).
+// LDS and global integer atomics with their own memory scopes: apart from being what is meant, the
+// different scopes keep the optimiser from merging an `in LDS ? ... : ...` pair of atomics into one
+// atomic on a generic pointer (which this compiler then fails to select).
+__device__ __forceinline__ void lds_add(unsigned long long *p, unsigned long long v) {
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void glb_add(unsigned long long *p, unsigned long long v) {
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <class F>
 __device__ __forceinline__ bool deposit_units_general(double x, F &&add) {
     const unsigned hi = (unsigned)__double2hiint(x);
@@ -248,7 +258,7 @@ template <int MODE, bool LDS_ACC, int DIMS = 0>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
 hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limbs,
                        int32_t *__restrict__ status) {
-    extern __shared__ __attribute__((aligned(16))) double s_acc[];  // [slab][quantity][bin]
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_acc[];  // [slab][quantity][bin], integer units
     STAMP(0);
     const int nthreads = blockDim.x;
     int c = 0;
@@ -268,7 +278,7 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
     const int n_acc = NL * 2 * n_bins;
     // replica used by this lane: neighbouring lanes (neighbouring, i.e. correlated,
     // events) add into different copies, which cuts same-address serialisation
-    double *my_acc = s_acc + (LDS_ACC ? (int)(threadIdx.x & (a.copies - 1)) * n_acc : 0);
+    unsigned long long *my_acc = s_acc + (LDS_ACC ? (int)(threadIdx.x & (a.copies - 1)) * n_acc : 0);
     unsigned long long *g_out = g_limbs + (int64_t)(a.cont_base + c) * a.n_bins * 2 * NL;
     int bin_lo = 0;
 
@@ -312,7 +322,7 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
 
     STAMP(1);
     if (LDS_ACC) {
-        for (int k = threadIdx.x; k < n_acc * a.copies; k += nthreads) s_acc[k] = 0.0;
+        for (int k = threadIdx.x; k < n_acc * a.copies; k += nthreads) s_acc[k] = 0ull;
         if ((PACKED || QUAD) && a.window > 0) {
             __shared__ int s_lo;
             if (threadIdx.x == 0) s_lo = 0x7fffffff;
@@ -351,20 +361,38 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
     auto accumulate = [&](int bin, double w, double w2) {
         const int rel = bin - bin_lo;
         const bool in_lds = LDS_ACC && (unsigned)rel < (unsigned)n_bins;
-        auto add0 = [&](int j, double q) {
-            if (in_lds) atomicAdd(&my_acc[(j * 2 + 0) * n_bins + rel], q);
-            else atomicAdd(&g_out[((int64_t)bin * 2 + 0) * NL + j], (unsigned long long)slab_to_units(q, j));
+        // digits of slabs j, j-1, j-2 of one weight (deposit_units): LDS accumulators of this workgroup,
+        // or -- bins outside the LDS window, binnings without LDS accumulators -- the global limbs
+        auto put = [&](int qn, int j, unsigned long long d) {
+            if (in_lds) lds_add(&my_acc[__mul24(j * 2 + qn, n_bins) + rel], d);
+            else glb_add(&g_out[((int64_t)bin * 2 + qn) * NL + j], d);
         };
-        auto add1 = [&](int j, double q) {
-            if (in_lds) atomicAdd(&my_acc[(j * 2 + 1) * n_bins + rel], q);
-            else atomicAdd(&g_out[((int64_t)bin * 2 + 1) * NL + j], (unsigned long long)slab_to_units(q, j));
+        auto add0 = [&](int j, long long d) { put(0, j, (unsigned long long)d); };
+        auto add1 = [&](int j, long long d) { put(1, j, (unsigned long long)d); };
+        auto add30 = [&](int j, unsigned long long d0, unsigned long long d1, unsigned long long d2) {
+            if (in_lds) {
+                const int i0 = __mul24(j * 2 + 0, n_bins) + rel;
+                lds_add(&my_acc[i0], d0); lds_add(&my_acc[i0 - 2 * n_bins], d1); lds_add(&my_acc[i0 - 4 * n_bins], d2);
+            } else {
+                const int64_t i0 = ((int64_t)bin * 2 + 0) * NL + j;
+                glb_add(&g_out[i0], d0); glb_add(&g_out[i0 - 1], d1); glb_add(&g_out[i0 - 2], d2);
+            }
+        };
+        auto add31 = [&](int j, unsigned long long d0, unsigned long long d1, unsigned long long d2) {
+            if (in_lds) {
+                const int i0 = __mul24(j * 2 + 1, n_bins) + rel;
+                lds_add(&my_acc[i0], d0); lds_add(&my_acc[i0 - 2 * n_bins], d1); lds_add(&my_acc[i0 - 4 * n_bins], d2);
+            } else {
+                const int64_t i0 = ((int64_t)bin * 2 + 1) * NL + j;
+                glb_add(&g_out[i0], d0); glb_add(&g_out[i0 - 1], d1); glb_add(&g_out[i0 - 2], d2);
+            }
         };
         if (a.dbg & 2) {  // probe: keep the loads and the weight chain alive, no atomics
             if (w == 1.2345e-300 || w2 == 1.2345e-300) bad = true;
             return;
         }
-        bool ok = deposit(w, add0);
-        if (!(a.dbg & 1)) ok = deposit(w2, add1) && ok;
+        bool ok = deposit_units(w, add30, add0);
+        if (!(a.dbg & 1)) ok = deposit_units(w2, add31, add1) && ok;
         if (!ok) bad = true;
     };
 
@@ -666,10 +694,9 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
             const int q = rem / NL;
             const int j = rem - q * NL;
             const int k = (j * 2 + q) * n_bins + bin;
-            double v = s_acc[k];
-            for (int r = 1; r < a.copies; r++) v += s_acc[r * n_acc + k];  // exact
-            if (v != 0.0)
-                atomicAdd(&g_out[(int64_t)bin_lo * 2 * NL + g], (unsigned long long)slab_to_units(v, j));
+            unsigned long long v = s_acc[k];
+            for (int r = 1; r < a.copies; r++) v += s_acc[r * n_acc + k];  // integer: exact
+            if (v != 0ull) atomicAdd(&g_out[(int64_t)bin_lo * 2 * NL + g], v);
         }
     }
     STAMP(5);

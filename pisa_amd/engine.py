@@ -854,11 +854,11 @@ class HotPathEngine:
         return out
 
     # -- several independent parameter points in one sweep of the events ---------------------------
-    def multi_capable(self):
-        """whether `eval_many` can take its one-sweep path: planned grid oscillation, 16-bit index
-        columns read through the shared grid tables, all maps in one tail workgroup, LDS room for at
-        least two points"""
-        return (self.plan is not None and self.indexed and self.index16 and not self.osc_events
+    def multi_capable(self, plan=None):
+        """whether `eval_many` can take its one-sweep path: planned grid oscillation (the engine's own
+        plan or the caller's, e.g. the osc.prob3 stage's), 16-bit index columns read through the shared
+        grid tables, all maps in one tail workgroup, LDS room for at least two points"""
+        return ((plan or self.plan) is not None and self.indexed and self.index16 and not self.osc_events
                 and not self.node_flux and self.fused_tail and self.data is not None
                 and len(self.cont) * self.n_bins <= K.FINALIZE_METRIC_MAX
                 and _lib.lib().pisa_hip_multi_points_per_pass(self.n_bins) >= 2)
@@ -882,7 +882,7 @@ class HotPathEngine:
             w["host_np"] = w["host"].numpy()
         return w
 
-    def eval_many(self, params_list, kind="llh", scales=None):
+    def eval_many(self, params_list, kind="llh", scales=None, plan=None, energy=None):
         """K INDEPENDENT parameter points (the n + 1 points of a finite-difference gradient, a scan)
         in one sweep of the events: one pair of prob3 launches for all points
         (`pisa_hip_prob3_grid_planned_multi`), one fused launch that reads the event columns once
@@ -890,14 +890,18 @@ class HotPathEngine:
         limb sets, one tail launch with a workgroup per point (`pisa_hip_finalize_metric_multi`);
         the K metric values arrive in pinned host memory.  Per point the limbs, maps and metric are
         bit-identical to `eval_host` at that point.  `scales` [K][n_containers] (optional): the
-        containers' aeff scales per point.  Returns a list of K floats; the maps of the points stay in
+        containers' aeff scales per point.  `plan` / `energy`: grid plan and node energies of the caller when the
+        oscillation tables are not the engine's own (a Pipeline: osc.prob3 holds them).  Returns a list of K floats; the maps of the points stay in
         `last_many` (device tensors hist / sumw2 [K, n_cont, n_bins])."""
         import ctypes as C
 
         n = len(params_list)
         if n == 0:
             return []
-        if n == 1 or not self.multi_capable():
+        plan = plan or self.plan
+        energy = energy if energy is not None else getattr(self, "energy_d", None)
+        if n == 1 or not self.multi_capable(plan):
+            assert self.plan is not None, "point-by-point evaluation needs the engine's own oscillation tables"
             out = []
             for i, p in enumerate(params_list):
                 if scales is not None:
@@ -909,7 +913,7 @@ class HotPathEngine:
             out = []
             for i in range(0, n, _lib.MAX_POINTS):
                 out += self.eval_many(params_list[i:i + _lib.MAX_POINTS], kind,
-                                      None if scales is None else scales[i:i + _lib.MAX_POINTS])
+                                      None if scales is None else scales[i:i + _lib.MAX_POINTS], plan, energy)
             return out
         w = self._multi_ws(n)
         lib, s = _lib.lib(), K._stream()
@@ -924,8 +928,8 @@ class HotPathEngine:
         self._release_outputs()
         g = self.grid
         rc = lib.pisa_hip_prob3_grid_planned_multi(
-            C.cast(arr, C.c_void_p), n, self.plan.handle, C.c_void_p(self.energy_d.data_ptr()),
-            self.energy_d.numel(), 1 if g.energy_first else 0, C.c_void_p(w["tables"].data_ptr()), s)
+            C.cast(arr, C.c_void_p), n, plan.handle, C.c_void_p(energy.data_ptr()),
+            energy.numel(), 1 if g.energy_first else 0, C.c_void_p(w["tables"].data_ptr()), s)
         if rc == 0:
             rc = lib.pisa_hip_reweight_hist_multi(
                 self._cont_arr, len(self._cont_arr), C.byref(g.binning), C.c_void_p(w["tables"].data_ptr()), n,

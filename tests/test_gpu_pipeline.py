@@ -569,3 +569,90 @@ def test_a_replay_that_raises_is_not_replayed_again(monkeypatch):
     ref.params.theta23.value = 49.0 * ureg.degree
     for a, b in zip(got, ref.get_outputs()):
         np.testing.assert_array_equal(a.hist, b.hist)
+
+
+@pytest.mark.parametrize("settings", [None, "settings/minimizer/slsqp_ftol1e-6_eps1e-4_maxiter1000.json"],
+                         ids=["l-bfgs-b", "slsqp"])
+def test_fit_with_the_stencil_in_one_sweep_is_the_same_fit(settings):
+    """config C4: 2 free parameters (theta23, deltam31).  With `batched_gradient` every iterate's
+    finite-difference stencil (n + 1 independent points) goes through `DistributionMaker.metric_many`
+    -> `FastPlan.metric_many` -> `HotPathEngine.eval_many` (one sweep of the events); the minimiser sees
+    the same function values and the same gradient quotients as when it takes the differences itself,
+    so history, iterates and result are identical."""
+    from pisa_amd.analysis.analysis import Analysis
+    from pisa_amd.core.distribution_maker import DistributionMaker
+    from pisa_amd.core.units import ureg
+
+    def make():
+        dm = DistributionMaker("settings/pipeline/example_hip.cfg")
+        for name in dm.params.free.names:
+            if name not in ("theta23", "deltam31"):
+                dm.params.fix(name)
+        return dm
+
+    dm = make()
+    dm.params.theta23.value = 47.5 * ureg.degree
+    dm.params.deltam31.value = 2.55e-3 * ureg.eV ** 2
+    data = dm.get_outputs(return_sum=True).fluctuate("poisson", random_state=3)
+    results = []
+    for batched in (False, True):
+        dm = make()
+        res = Analysis().fit_hypo(data, dm, "llh", minimizer_settings=settings, batched_gradient=batched)
+        results.append((res, dm))
+    (a, dm_a), (b, dm_b) = results
+    assert a.minimizer_metadata["nit"] == b.minimizer_metadata["nit"] and a.minimizer_metadata["nit"] >= 2
+    assert a.num_distributions_generated == b.num_distributions_generated
+    assert a.fit_history == b.fit_history
+    assert a.metric_val == b.metric_val
+    for p, q in zip(a.params.free, b.params.free):
+        assert p.value == q.value
+    # the batched fit did take the sweep, the other one did not
+    assert getattr(dm_b.pipelines[0]["hist"]._engine, "last_many", None) is not None
+    assert getattr(dm_a.pipelines[0]["hist"]._engine, "last_many", None) is None
+    # and the maker is left consistent: outputs at the best fit equal a fresh evaluation there
+    fresh = make()
+    for p in b.params.free:
+        fresh.params[p.name].value = p.value
+    np.testing.assert_array_equal(dm_b.get_outputs(return_sum=True)[0].hist, fresh.get_outputs(return_sum=True)[0].hist)
+
+
+def test_metric_many_matches_point_by_point_and_falls_back():
+    """`DistributionMaker.metric_many`: osc + aeff parameters moving -> one sweep; a flux parameter moving
+    as well -> point by point; identical numbers either way, priors included"""
+    from pisa_amd.core.distribution_maker import DistributionMaker
+
+    dm = DistributionMaker("settings/pipeline/example_hip.cfg")
+    keep = ("theta23", "deltam31", "aeff_scale", "delta_index")
+    for name in dm.params.free.names:
+        if name not in keep:
+            dm.params.fix(name)
+    data = dm.get_outputs(return_sum=True).fluctuate("poisson", random_state=1)
+    dm.get_outputs(return_sum=True)
+    assert dm.pipelines[0]._plan is not None
+    names = dm.params.free.names
+    rs = np.random.RandomState(4)
+    x0 = np.array(dm.params.free._rescaled_values)
+    pts = [np.clip(x0 + 0.05 * (rs.rand(len(x0)) - 0.5), 0, 1) for _ in range(4)]
+    i_flux = names.index("delta_index")
+    osc_only = [p.copy() for p in pts]
+    for p in osc_only:
+        p[i_flux] = x0[i_flux]
+
+    def serial(points):
+        out = []
+        for x in points:
+            dm._set_rescaled_free_params(x)
+            hypo = dm.get_outputs(return_sum=True)
+            out.append(data.metric_total(expected_values=hypo, metric="mod_chi2") + dm.params.priors_penalty(metric="mod_chi2"))
+        return out
+
+    eng = dm.pipelines[0]["hist"]._engine
+    want = serial(osc_only)
+    assert getattr(eng, "last_many", None) is None
+    assert dm.metric_many(osc_only, data, "mod_chi2") == want
+    assert eng.last_many is not None
+    eng.last_many = None
+    want = serial(pts)
+    assert dm.metric_many(pts, data, "mod_chi2") == want      # delta_index moves: the flux stage, no sweep
+    assert eng.last_many is None
+    assert serial(osc_only[:2]) == dm.metric_many(osc_only[:2], data, "mod_chi2")
