@@ -39,20 +39,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# The CPU baseline's OpenMP team (oracle/liboracle.so, libgomp) is pinned one thread per core; the
-# runtime reads these when it is first loaded, i.e. with `import torch`, so they are set here.  They
-# touch host threads only.
-os.environ.setdefault("OMP_PLACES", "cores")
-os.environ.setdefault("OMP_PROC_BIND", "close")
-
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 L3_BYTES = 256 * 2 ** 20
-ALL_LEGS = ("l3_exceeding", "exact_association", "coordinate_form", "fine_binning", "update_flux", "node_flux",
-            "pipeline_boundary", "icecube3y_boundary", "events_c2", "events_c5", "kde_c3")
+ALL_LEGS = ("multi_point", "fit_c4_engine", "fit_c4", "l3_exceeding", "exact_association", "coordinate_form", "fine_binning",
+            "update_flux", "node_flux", "pipeline_boundary", "icecube3y_boundary", "events_c2", "events_c5", "kde_c3")
+# the legs that also run with N > 1 (every rank takes part: configs C4 and C5, the multi-point sweep)
+DIST_LEGS = ("multi_point", "fit_c4_engine", "fit_c4", "events_c5")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
@@ -85,12 +81,13 @@ def parse():
                     help="test aid: take the N > 1 code path (RCCL process group, limb all-reduce, barriers, "
                          "max over ranks) with the ranks that are there, e.g. one rank under "
                          "torch.distributed.run on a single-GPU box")
+    ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--min-timed-s", type=float, default=0.2,
                     help="repeat the block of --steps timed steps until this much timed work has been seen "
                          "(0: exactly one block)")
     ap.add_argument("--event-order", default="auto", choices=["auto", "node", "bin", "part"],
                     help="resident event order: sorted by calc-grid node, or by (output bin, node)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def param_list(wl, n, **kw):
@@ -129,7 +126,41 @@ def physical_cores():
     return max(1, len(firsts)), len(avail)
 
 
-def cpu_baseline(wl, data, matrices, device_llh):
+def cpu_baseline_subprocess(args, n_e, n_cz, data, matrices, device_llh):
+    """`cpu_baseline` in a process of its own: its OpenMP team is pinned one thread per core
+    (OMP_PLACES=cores, OMP_PROC_BIND=close), which must not reach this process -- the runtime would pin
+    the main thread as well and every helper thread the HIP runtime starts afterwards inherits that mask
+    (measured: the Pipeline-boundary legs went from 126 to 223 us per evaluation)."""
+    import subprocess
+    import tempfile
+
+    import numpy as np
+
+    with tempfile.TemporaryDirectory(prefix="pisa_cpu_baseline_") as tmp:
+        path = os.path.join(tmp, "in.npz")
+        np.savez(path, data=data, device_llh=device_llh, events=int(args.events), grid=[n_e, n_cz],
+                 cores=list(physical_cores()),     # counted here: the worker's main thread is pinned
+                 **{"m_" + k: np.asarray(v) for k, v in matrices.items()})
+        env = dict(os.environ, OMP_PLACES="cores", OMP_PROC_BIND="close")
+        res = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", path,
+                              "--binning", args.binning], env=env, stdout=subprocess.PIPE, check=True)
+    return json.loads(res.stdout.decode().strip().splitlines()[-1])
+
+
+def cpu_baseline_worker(path, binning):
+    import numpy as np
+
+    from pisa_amd import synthetic
+
+    z = np.load(path)
+    wl = synthetic.Workload(n_events=int(z["events"]), grid=tuple(int(v) for v in z["grid"]), out_binning=binning,
+                            seed=0)
+    m = {k[2:]: z[k] for k in z.files if k.startswith("m_")}
+    m["decay_flag"] = int(m["decay_flag"])
+    print(json.dumps(cpu_baseline(wl, z["data"], m, float(z["device_llh"]), tuple(int(v) for v in z["cores"]))))
+
+
+def cpu_baseline(wl, data, matrices, device_llh, cores_logical=None):
     """The oracle (C restatement of the reference algorithms) timed on this box's host cores on the
     WHOLE workload -- full calc grid and all events, nothing scaled from a sample:
       * all physical cores (the reference's TARGET='parallel'): prob3 grid under OpenMP + every
@@ -146,7 +177,7 @@ def cpu_baseline(wl, data, matrices, device_llh):
     from oracle.pipeline_oracle import oracle_eval, oracle_eval_allcore
 
     orc.build()
-    cores, logical = physical_cores()
+    cores, logical = cores_logical or physical_cores()
     # columns placed for the all-core run: pages first touched by the thread that reads them (two
     # sockets: a column allocated by the main thread sits in ONE NUMA node and caps the event loop at
     # that node's bandwidth -- 64 threads were no faster than 32)
@@ -548,13 +579,18 @@ def leg_icecube3y(torch, n_events, steps):
             os.environ["PISA_RESOURCES"] = old
 
 
-def leg_events(synthetic, torch, n_events, steps, nsi):
+def leg_events(synthetic, torch, n_events, steps, nsi, rank=0, world=1, share=None, sync=None, reduce_max=None):
     """configs C2 / C5 (per-GPU share): prob3 EVENT BY EVENT (layers rebuilt per event in-kernel from the
-    PREM table in LDS) + fused reweight + 10x10 histogram + LLH"""
+    PREM table in LDS) + fused reweight + 10x10 histogram + LLH.  N > 1 (C5: 1e8 events on 8 GPUs): every
+    rank holds `n_events` events of its own (seed = rank), the limbs are all-reduced over the ranks
+    (`share` = an engine whose communicator is reused), every rank evaluates the same LLH."""
     import numpy as np
 
-    wl = synthetic.Workload(n_events=int(n_events), grid=(10, 10), out_binning="example2d", seed=0)
+    wl = synthetic.Workload(n_events=int(n_events), grid=(10, 10), out_binning="example2d", seed=rank)
     st = synthetic.DeviceState(wl, osc_mode="events", compact=True)
+    if world > 1 or share is not None:
+        st.world_size = share.world_size
+        st.group, st._rccl = share.group, share._rccl
     mat_pot = None
     if nsi:
         from pisa_amd.stages.osc.nsi_params import StdNSIParams
@@ -566,14 +602,16 @@ def leg_events(synthetic, torch, n_events, steps, nsi):
     st.make_pseudo_data(wl.osc_params(mat_pot=mat_pot), seed=0)
     plist = param_list(wl, 3 + steps, mat_pot=mat_pot)
     # eval_host: the LLH arrives in pinned host memory (what a fit loop reads), as in the headline loop
+    sync = sync or torch.cuda.synchronize
+    reduce_max = reduce_max or (lambda x: x)
     for p in plist[:3]:
         st.eval_host(p, "llh")
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for p in plist[3:]:
         llh = st.eval_host(p, "llh")
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    sync()
+    dt = reduce_max(time.perf_counter() - t0) / steps
     st.check_status()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -582,10 +620,20 @@ def leg_events(synthetic, torch, n_events, steps, nsi):
     e1.record()
     torch.cuda.synchronize()
     t_osc = e0.elapsed_time(e1) / steps * 1e-3
-    out = {"events": wl.n_events, "evals_per_s": 1.0 / dt, "ms_per_step": dt * 1e3,
-           "event_evals_per_s": wl.n_events / dt, "prob3_events_kernel_ms": t_osc * 1e3, "last_llh": llh,
-           "workload": "%d events, prob3 event by event (PREM-12%s) + fused reweight + 10x10 hist + LLH"
-                       % (wl.n_events, ", std NSI" if nsi else "")}
+    out = {"events": wl.n_events * world, "events_per_gpu": wl.n_events, "evals_per_s": 1.0 / dt,
+           "ms_per_step": dt * 1e3, "event_evals_per_s": wl.n_events * world / dt,
+           "prob3_events_kernel_ms": t_osc * 1e3, "last_llh": llh,
+           "workload": "%d events%s, prob3 event by event (PREM-12%s) + fused reweight + 10x10 hist + LLH"
+                       % (wl.n_events * world, (" on %d GPUs (%d each, limbs all-reduced)" % (world, wl.n_events))
+                          if world > 1 else "", ", std NSI" if nsi else "")}
+    if world > 1:
+        import torch.distributed as dist
+
+        v = torch.tensor([llh], dtype=torch.float64, device="cuda")
+        allv = [torch.zeros_like(v) for _ in range(world)]
+        dist.all_gather(allv, v)
+        out["same_llh_bits_on_all_ranks"] = bool(all(bool((a.view(torch.int64) == v.view(torch.int64)).all()) for a in allv))
+    st._rccl = None
     # executed fp64 flops per event of prob3_events_kernel from the committed SQ_INSTS_VALU_*_F64
     # counter passes (scripts/profile_round.sh); not measured in this run
     cal, src = latest_profile("events_flops.json")
@@ -599,6 +647,164 @@ def leg_events(synthetic, torch, n_events, steps, nsi):
                                           "operations of prob3_events_kernel from committed rocprofv3 "
                                           "SQ_INSTS_VALU_*_F64 passes, not this run)" % src}
     del st, wl
+    torch.cuda.empty_cache()
+    return out
+
+
+def leg_multi_point(torch, st, wl, sync, reduce_max):
+    """K independent parameter points per sweep of the events (`HotPathEngine.eval_many`: batched prob3,
+    one fused launch with K accumulator sets, one tail workgroup per point) on the headline workload:
+    evaluations per second for K = 3, 5, 9, beside the point-by-point `value`.  Per point the LLH is
+    the same bits as `eval_host` (checked here on the last batch)."""
+    out = {}
+    serial_last = None
+    plist = param_list(wl, 45)
+    for k in (3, 5, 9):
+        batches = [plist[i:i + k] for i in range(0, len(plist) - k + 1, k)]
+        for b in batches[:3]:
+            st.eval_many(b, "llh")
+        sync()
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            for b in batches:
+                vals = st.eval_many(b, "llh")
+                n += k
+            sync()
+            dt = reduce_max(time.perf_counter() - t0)
+            if dt > 0.15:
+                break
+        serial_last = [st.eval_host(p, "llh") for p in batches[-1]]
+        out["K%d" % k] = {"evals_per_s": n / dt, "us_per_point": 1e6 * dt / n, "points_per_sweep": k,
+                          "same_bits_as_point_by_point": bool(vals == serial_last)}
+    st.check_status()
+    out["what"] = ("K independent parameter points per sweep of the events (finite-difference stencils, scans): "
+                   "prob3 for K points in one pair of launches, ONE pass over the 20 B/event columns with K "
+                   "accumulator sets, one tail workgroup per point, K LLH values read back; per point bit-identical "
+                   "to the point-by-point evaluation")
+    return out
+
+
+def leg_fit_engine(torch, st, wl, sync, reduce_max):
+    """The C4 fit loop on the engine itself (no Pipeline / Param layer in between): scipy L-BFGS-B
+    (eps 1e-4, ftol 2e-5, gtol 1e-5: the reference's l-bfgs-b settings) over (theta23, deltam31) rescaled
+    to [0, 1], -LLH against the headline pseudo-data, several starting points until >= 50 evaluations.
+    `point_by_point`: scipy takes its forward differences through `eval_host`; `stencil_in_one_sweep`:
+    value and gradient from one `eval_many` of the same n + 1 points (Analysis._forward_stencil).  Same
+    trajectory, point for point."""
+    import numpy as np
+    from scipy import optimize
+
+    from pisa_amd.analysis.analysis import Analysis
+
+    lo, hi = np.array([31.0, 1e-3]), np.array([59.0, 7e-3])
+    bounds = [(0.0, 1.0), (0.0, 1.0)]
+    opts = dict(ftol=2e-5, gtol=1e-5, eps=1e-4, maxiter=200)
+
+    def point(x):
+        v = lo + (hi - lo) * np.clip(x, 0.0, 1.0)
+        return wl.osc_params(theta23_deg=float(v[0]), dm31=float(v[1]))
+
+    trace = {}
+
+    def serial(x):
+        f = -st.eval_host(point(x), "llh")
+        trace["pts"].append((tuple(x), f))
+        return f
+
+    def swept(x):
+        pts, dx = Analysis._forward_stencil(x, opts["eps"], np.zeros(2), np.ones(2))
+        f = [-v for v in st.eval_many([point(q) for q in pts], "llh")]
+        trace["pts"] += [(tuple(q), v) for q, v in zip(pts, f)]
+        return f[0], (np.array(f[1:]) - f[0]) / dx
+
+    starts = [(0.40, 0.24), (0.25, 0.20), (0.71, 0.30), (0.46, 0.33), (0.64, 0.22), (0.32, 0.28)]
+    out, traces = {}, {}
+    for key, fun, jac in (("point_by_point", serial, None), ("stencil_in_one_sweep", swept, True)):
+        for _ in range(2):
+            trace["pts"] = []
+            evals, fits = 0, []
+            sync()
+            t0 = time.perf_counter()
+            for x0 in starts:
+                res = optimize.minimize(fun, np.array(x0), jac=jac, bounds=bounds, method="L-BFGS-B", options=opts)
+                evals = len(trace["pts"])
+                fits.append((float(res.fun), [float(v) for v in lo + (hi - lo) * res.x]))
+                if evals >= 50 and len(fits) >= 2:
+                    break
+            sync()
+            dt = reduce_max(time.perf_counter() - t0)
+        traces[key] = list(trace["pts"])
+        out[key] = {"wall_s": dt, "llh_evaluations": evals, "fits": len(fits), "evals_per_s": evals / dt,
+                    "best_fit": {"neg_llh": fits[0][0], "theta23_deg": fits[0][1][0], "deltam31_eV2": fits[0][1][1]}}
+    out["same_history"] = bool(traces["point_by_point"] == traces["stencil_in_one_sweep"])
+    out["speedup"] = out["point_by_point"]["wall_s"] / out["stencil_in_one_sweep"]["wall_s"]
+    out["workload"] = ("scipy L-BFGS-B (eps 1e-4) on HotPathEngine directly: free theta23, deltam31; the headline "
+                       "workload (%d events, 200x100 grid, 8x8x2 bins), -llh against its pseudo-data" % wl.n_events)
+    st.check_status()
+    return out
+
+
+def leg_fit_c4(torch, n_events, dist_on, sync, reduce_max):
+    """BASELINE config C4: the fit loop.  Analysis.fit_hypo (scipy L-BFGS-B, the reference's
+    l-bfgs-b_ftol2e-5_gtol1e-5_eps1e-4_maxiter200 settings) over 2 free parameters (theta23, deltam31) on
+    the cfg-text pipeline with `n_events` events (sharded over the ranks when N > 1: every rank runs the
+    same minimiser on its shard, the limbs are all-reduced per evaluation), pseudo-data = Poisson-fluctuated
+    template at an injected truth; repeated from several starting points until >= 50 LLH evaluations have
+    been made.  Timed twice: the minimiser taking its finite differences point by point (the reference's
+    flow), and with every iterate's stencil in one sweep (`batched_gradient`) -- the same fit, point for
+    point (`same_history`)."""
+    import numpy as np
+
+    from pisa_amd.analysis.analysis import Analysis
+    from pisa_amd.core.distribution_maker import DistributionMaker
+    from pisa_amd.core.units import ureg
+
+    dm = DistributionMaker(_pipeline_cfg(n_events))
+    for name in dm.params.free.names:
+        if name not in ("theta23", "deltam31"):
+            dm.params.fix(name)
+    dm.params.theta23.value = 47.5 * ureg.degree
+    dm.params.deltam31.value = 2.55e-3 * ureg.eV ** 2
+    data = dm.get_outputs(return_sum=True).fluctuate("poisson", random_state=0)
+    starts = [(42.3, 2.457e-3), (38.0, 2.2e-3), (51.0, 2.8e-3), (44.0, 3.0e-3), (49.0, 2.3e-3), (40.0, 2.7e-3)]
+    ana = Analysis()
+    out = {}
+    hist = {}
+    for key, batched in (("point_by_point", False), ("stencil_in_one_sweep", True)):
+        for _ in range(2):       # first round warms every code path up
+            evals, fits, hist[key] = 0, [], []
+            sync()
+            t0 = time.perf_counter()
+            for t23, dm31 in starts:
+                dm.params.theta23.value = t23 * ureg.degree
+                dm.params.deltam31.value = dm31 * ureg.eV ** 2
+                res = ana.fit_hypo(data, dm, "llh", reset_free=False, batched_gradient=batched)
+                evals += res.num_distributions_generated
+                fits.append((res.metric_val, res.params.theta23.value.m_as("deg"),
+                             res.params.deltam31.value.m_as("eV**2")))
+                hist[key] += res.fit_history
+                if evals >= 50 and len(fits) >= 2:
+                    break
+            sync()
+            dt = reduce_max(time.perf_counter() - t0)
+        out[key] = {"wall_s": dt, "llh_evaluations": evals, "fits": len(fits), "evals_per_s": evals / dt,
+                    "best_fit": {"llh": fits[0][0], "theta23_deg": fits[0][1], "deltam31_eV2": fits[0][2]}}
+    out["same_history"] = bool(hist["point_by_point"] == hist["stencil_in_one_sweep"])
+    out["speedup"] = out["point_by_point"]["wall_s"] / out["stencil_in_one_sweep"]["wall_s"]
+    if dist_on:
+        import torch.distributed as dist
+
+        # every rank ran the same minimiser on all-reduced limbs: the LLH bits must agree
+        v = torch.tensor([out["stencil_in_one_sweep"]["best_fit"]["llh"]], dtype=torch.float64, device="cuda")
+        allv = [torch.zeros_like(v) for _ in range(dist.get_world_size())]
+        dist.all_gather(allv, v)
+        out["same_llh_bits_on_all_ranks"] = bool(all(bool((a.view(torch.int64) == v.view(torch.int64)).all()) for a in allv))
+    out["workload"] = ("Analysis.fit_hypo, L-BFGS-B (eps 1e-4), free: theta23, deltam31; %d events through "
+                       "settings/pipeline/example_hip.cfg (cfg text), llh against Poisson pseudo-data at (47.5 deg, "
+                       "2.55e-3 eV^2); fits from successive starting points until >= 50 LLH evaluations"
+                       % (int(n_events) // 12 * 12))
+    del dm
     torch.cuda.empty_cache()
     return out
 
@@ -644,24 +850,40 @@ def leg_kde(torch, n_events, steps):
     return out
 
 
-def main():
-    args = parse()
+def main(argv=None, hooks=None):
+    """`hooks` (tests only, tests/test_distributed_cpu.py): run this very control flow -- N > 1 process
+    group, barriers, max over ranks, the legs that run on several ranks, the JSON line -- on CPU ranks over
+    gloo, with `hooks["device_state"]` in place of the HIP-backed engine.  Nothing in the product or in the
+    driver's invocation passes hooks."""
+    args = parse(argv)
+    if args.cpu_baseline_worker:
+        return cpu_baseline_worker(args.cpu_baseline_worker, args.binning)
     import numpy as np
     import torch
 
+    cuda = hooks is None
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    torch.cuda.set_device(local_rank)
+    if cuda:
+        torch.cuda.set_device(local_rank)
     dist_on = world > 1 or args.force_dist
     if dist_on:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if cuda:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from pisa_amd import _lib, synthetic
+
+    make_state = synthetic.DeviceState if cuda else hooks["device_state"]
+    dev_sync = torch.cuda.synchronize if cuda else (lambda: None)
+    if not cuda:
+        args.no_kernel_timing = args.no_batch_probe = args.no_drop_probe = args.no_cpu_baseline = True
 
     n_e, n_cz = (int(v) for v in args.grid.split("x"))
     compact = not (args.exact_association or args.coordinate_form)
@@ -673,14 +895,14 @@ def main():
             import torch.distributed as dist
 
             dist.barrier()
-        torch.cuda.synchronize()
+        dev_sync()
 
     def max_over_ranks(x):
         if not dist_on:
             return x
         import torch.distributed as dist
 
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if cuda else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -711,8 +933,8 @@ def main():
 
     # ---- headline: ONE sample of --events events, sharded over the ranks (strong scaling)
     wl = synthetic.Workload(n_events=int(args.events), grid=(n_e, n_cz), out_binning=args.binning, seed=0)
-    st = synthetic.DeviceState(wl, rank=rank, world_size=world, indexed=not args.coordinate_form,
-                               sort_events=order, compact=compact, index16=index16)
+    st = make_state(wl, rank=rank, world_size=world, indexed=not args.coordinate_form,
+                    sort_events=order, compact=compact, index16=index16)
     if args.force_dist and world == 1:
         st.world_size = 2   # one rank, but through the collective
     nominal = wl.osc_params()
@@ -721,7 +943,7 @@ def main():
     mats_last = dict(wl.last_matrices)     # of plist[-1], the point whose LLH the line reports
     dt, llh = timed_loop(st, plist)
     headline_blocks = timed_loop.blocks
-    lib = _lib.lib()
+    lib = _lib.lib() if cuda else None
     d_out = len(wl.ob["nbins"])
     bpe = bytes_per_event(st, args.coordinate_form, compact, d_out)
     fused_avg_s = float("nan") if args.no_kernel_timing else time_fused(st, plist[args.warmup:], lib, torch,
@@ -741,14 +963,13 @@ def main():
         torch.cuda.synchronize()
         return float(np.median([a.elapsed_time(b) for a, b in evs]))
 
-    t_prob3 = time_phase(lambda: st.compute_probs(nominal))
-
     def tail():
         st._maps_valid = False
         st._tail("llh", st.metric_out)
 
-    t_tail = time_phase(tail)
-    t_allreduce = time_phase(st.allreduce) if dist_on else None
+    t_prob3 = time_phase(lambda: st.compute_probs(nominal)) if cuda else None
+    t_tail = time_phase(tail) if cuda else None
+    t_allreduce = time_phase(st.allreduce) if (dist_on and cuda) else None
     n_comm = None
     if dist_on and st._rccl:
         n_comm = st._rccl.count()
@@ -757,8 +978,8 @@ def main():
     weak = None
     if dist_on:
         wl_w = synthetic.Workload(n_events=int(args.events), grid=(n_e, n_cz), out_binning=args.binning, seed=rank)
-        st_w = synthetic.DeviceState(wl_w, rank=0, world_size=1, indexed=not args.coordinate_form,
-                                     sort_events=order, compact=compact, index16=index16)
+        st_w = make_state(wl_w, rank=0, world_size=1, indexed=not args.coordinate_form,
+                          sort_events=order, compact=compact, index16=index16)
         st_w.world_size = max(world, 2) if args.force_dist else world
         st_w.group, st_w._rccl = st.group, st._rccl          # same communicator
         st_w.make_pseudo_data(nominal, seed=0)
@@ -801,13 +1022,24 @@ def main():
 
     # ---- legs (N = 1 only)
     legs = {}
-    want = [] if (dist_on or args.legs == "none") else (list(ALL_LEGS) if args.legs == "all" else
-                                                         [x.strip() for x in args.legs.split(",") if x.strip()])
+    want = [] if args.legs == "none" else (list(ALL_LEGS) if args.legs == "all" else
+                                           [x.strip() for x in args.legs.split(",") if x.strip()])
+    if dist_on:
+        want = [x for x in want if x in DIST_LEGS]
+    if not cuda:
+        want = [x for x in want if x in hooks.get("legs", ("multi_point",))]
     leg_steps = max(20, min(args.steps, 200))
     for name in want:
         t0 = time.perf_counter()
         try:
-            if name == "l3_exceeding":
+            if name == "multi_point":
+                legs[name] = leg_multi_point(torch, st, wl, barrier, max_over_ranks) \
+                    if (compact and index16 and not args.coordinate_form) else None
+            elif name == "fit_c4_engine":
+                legs[name] = leg_fit_engine(torch, st, wl, barrier, max_over_ranks)
+            elif name == "fit_c4":
+                legs[name] = leg_fit_c4(torch, args.events, dist_on, barrier, max_over_ranks)
+            elif name == "l3_exceeding":
                 legs[name] = hbm_leg(synthetic, lib, torch, 4 * args.events, n_e, n_cz, args.binning, leg_steps // 2)
             elif name == "exact_association":
                 legs[name] = hbm_leg(synthetic, lib, torch, args.events, n_e, n_cz, args.binning, leg_steps,
@@ -829,12 +1061,15 @@ def main():
             elif name == "events_c2":
                 legs[name] = leg_events(synthetic, torch, 1e6, 20, nsi=False)
             elif name == "events_c5":
-                legs[name] = leg_events(synthetic, torch, 1.25e7, 6, nsi=True)
+                legs[name] = leg_events(synthetic, torch, 1.25e7, 6, nsi=True, rank=rank, world=world,
+                                        share=st if dist_on else None, sync=barrier, reduce_max=max_over_ranks)
             elif name == "kde_c3":
                 legs[name] = leg_kde(torch, args.events, 4)
             else:
                 raise ValueError("unknown leg %r" % name)
         except Exception as exc:  # a leg must not take the headline down with it
+            if dist_on:
+                raise   # the other ranks are inside a collective: better the launcher ends them all
             legs[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         if isinstance(legs.get(name), dict):
             legs[name]["leg_wall_s"] = time.perf_counter() - t0
@@ -884,6 +1119,9 @@ def main():
             "nccl_comm_count": n_comm,
             "last_llh": llh,
             "pipelined_evals_per_s": pipelined,
+            "batched_evals_per_s3": (legs.get("multi_point") or {}).get("K3", {}).get("evals_per_s"),
+            "batched_evals_per_s5": (legs.get("multi_point") or {}).get("K5", {}).get("evals_per_s"),
+            "batched_evals_per_s9": (legs.get("multi_point") or {}).get("K9", {}).get("evals_per_s"),
             "unbinned_events_dropped": dropped,
             "phase_ms": {"prob3_grid": t_prob3, "fused_reweight_hist": 1e3 * fused_avg_s, "finalize_metric": t_tail,
                          "allreduce": t_allreduce, "events_this_rank": st.n_local},
@@ -906,11 +1144,13 @@ def main():
             "legs": legs,
         }
         if not args.no_cpu_baseline and world == 1:
-            cb = cpu_baseline(wl, st.data.cpu().numpy(), mats_last, llh)
+            cb = cpu_baseline_subprocess(args, n_e, n_cz, st.data.cpu().numpy(), mats_last, llh)
             out["cpu_baseline"] = cb
             # the bench's last headline point against the oracle on identical inputs (north star: <= 1e-10)
             out["oracle_llh"], out["llh_rel_diff"] = cb["oracle_llh"], cb["llh_rel_diff"]
         print(json.dumps(out))
+        if hooks is not None and "result" in hooks:
+            hooks["result"](out)
     if dist_on:
         import torch.distributed as dist
 

@@ -4,7 +4,7 @@
 from collections.abc import Sequence
 
 from pisa_amd.core.map import MapSet
-from pisa_amd.core.param import ParamSet
+from pisa_amd.core.param import Param, ParamSet
 from pisa_amd.core.pipeline import Pipeline
 
 __all__ = ["DistributionMaker"]
@@ -93,8 +93,21 @@ class DistributionMaker:
         self._for_each_free(values, lambda prm, v: setattr(prm, "value", v))
 
     def _set_rescaled_free_params(self, rvalues):
-        """free params from their [0,1]-rescaled values (distribution_maker.py:462-476)"""
-        self._for_each_free(rvalues, lambda prm, r: setattr(prm, "_rescaled_value", float(r)))
+        """free params from their [0,1]-rescaled values (distribution_maker.py:462-476).  The list of
+        parameter objects behind every free name (one per pipeline that has it free; after
+        `_unify_params` usually ONE shared object) is kept until a set changes structurally or a
+        parameter is fixed / freed: a minimiser calls this at every point."""
+        key = (ParamSet.struct_clock, Param.fix_clock)
+        c = getattr(self, "_free_targets", None)
+        if c is None or c[0] != key:
+            targets = [[] for _ in self.params.free.names]
+            self._for_each_free(targets, lambda prm, t: t.append(prm) if all(prm is not q for q in t) else None)
+            c = self._free_targets = (key, targets)
+        assert len(rvalues) == len(c[1])
+        for targets, r in zip(c[1], rvalues):
+            r = float(r)
+            for prm in targets:
+                prm._rescaled_value = r
 
     def metric_many(self, rescaled_points, data_dist, metric, on_point=None):
         """[data_dist.metric_total(template at x, metric) + priors penalty at x  for x in points]:

@@ -294,6 +294,7 @@ class FastPlan:
             return None
         params_list, scales = [], []
         self._dirty = True           # from here on the change counters are consumed point by point
+        self._many_scales = None     # the containers' aeff scales, recomputed when an aeff parameter moves
 
         def abandon():
             # counters of stages this plan cannot take in a sweep have been consumed: forget what was
@@ -311,12 +312,13 @@ class FastPlan:
                 if s is not osc and s is not self.aeff:
                     return abandon()
             p = osc.params
-            ye = (p.YeI.value.m_as("dimensionless"), p.YeO.value.m_as("dimensionless"),
-                  p.YeM.value.m_as("dimensionless"))
+            ye = (p.YeI.m_in("dimensionless"), p.YeO.m_in("dimensionless"), p.YeM.m_in("dimensionless"))
             if ye != self.ye:
                 return abandon()
             params_list.append(_lib.Prob3Params.from_buffer_copy(osc._matrices()))
-            scales.append([self.aeff.scale_for(name) for name in self.names])
+            if self._many_scales is None or any(s is self.aeff for s in changed):
+                self._many_scales = [self.aeff.scale_for(name) for name in self.names]
+            scales.append(self._many_scales)
         osc.param_hash = None
         self.clock = Param.clock
         vals = eng.eval_many(params_list, kind, np.asarray(scales, dtype=np.float64), plan=g["plan"],

@@ -116,6 +116,25 @@ class Param:
     instead of re-deriving `values_hash` (a value set to what it already was counts as a change)."""
 
     clock = 0
+    fix_clock = 0      # counts fixed <-> free changes of ALL params (cached free-parameter views)
+
+    is_fixed = property(lambda self: self._is_fixed)
+
+    @is_fixed.setter
+    def is_fixed(self, flag):
+        self._is_fixed = bool(flag)
+        Param.fix_clock += 1
+
+    def m_in(self, units):
+        """magnitude of the value in `units`, converted once per value (a fit reads the same few
+        parameters at every point; the conversion through the units registry costs more than the
+        arithmetic it feeds)"""
+        c = self.__dict__.get("_m_cache")
+        if c is not None and c[0] == self._ver and c[1] == units:
+            return c[2]
+        m = self._value.m_as(units)
+        self._m_cache = (self._ver, units, m)
+        return m
 
     def __init__(self, name, value, prior=None, range=None, is_fixed=True, unique_id=None,
                  is_discrete=False, nominal_value=None, tex=None, help="", scales_as_log=False):
@@ -246,6 +265,15 @@ class Param:
             return
         self._value = Quantity(v, self._units)
         self._touch()
+
+    def prior_penalty_cached(self, metric):
+        """`prior_penalty`, evaluated once per (value, prior, metric)"""
+        c = self.__dict__.get("_pen_cache")
+        if c is not None and c[0] == self._ver and c[1] is self.prior and c[2] == metric:
+            return c[3]
+        v = self.prior_penalty(metric)
+        self._pen_cache = (self._ver, self.prior, metric, v)
+        return v
 
     def prior_penalty(self, metric):
         metric = metric.strip().lower()
@@ -431,7 +459,9 @@ class ParamSet(Sequence):
             p._rescaled_value = v
 
     def priors_penalty(self, metric):
-        return np.sum([p.prior_penalty(metric=metric) for p in self._params])
+        # the same sum over the same terms in the same order (param.py:1372-1396); a term is re-evaluated
+        # only when its parameter moved
+        return np.sum([p.prior_penalty_cached(metric) for p in self._params])
 
     @property
     def values_hash(self):

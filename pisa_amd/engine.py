@@ -916,6 +916,24 @@ class HotPathEngine:
                                       None if scales is None else scales[i:i + _lib.MAX_POINTS], plan, energy)
             return out
         w = self._multi_ws(n)
+        self._release_outputs()
+        self._many_sweep(w, params_list, scales, plan, energy)
+        if self.world_size > 1:
+            if self._rccl is None:
+                self.allreduce_setup()
+            if self._rccl:
+                self._rccl.all_reduce_(w["limbs"], K._stream())
+            else:
+                allreduce_limbs(w["limbs"], self.world_size, self.group)
+        out = self._many_tail(w, n, kind)
+        self.last_many = w
+        return out
+
+    def _many_sweep(self, w, params_list, scales, plan, energy):
+        """prob3 of all points + ONE pass over the events into the points' limb sets (asynchronous)"""
+        import ctypes as C
+
+        n = len(params_list)
         lib, s = _lib.lib(), K._stream()
         arr = w["params"]
         for i, p in enumerate(params_list):
@@ -925,7 +943,6 @@ class HotPathEngine:
             flat = np.ascontiguousarray(scales, dtype=np.float64).reshape(n * len(self.cont))
             C.memmove(w["scales"], flat.ctypes.data, flat.nbytes)
             sc_ptr = C.cast(w["scales"], C.c_void_p)
-        self._release_outputs()
         g = self.grid
         rc = lib.pisa_hip_prob3_grid_planned_multi(
             C.cast(arr, C.c_void_p), n, plan.handle, C.c_void_p(energy.data_ptr()),
@@ -937,13 +954,13 @@ class HotPathEngine:
                 C.c_void_p(self.ws.status.data_ptr()), s)
         w["zero"] = False
         _lib.check(rc)
-        if self.world_size > 1:
-            if self._rccl is None:
-                self.allreduce_setup()
-            if self._rccl:
-                self._rccl.all_reduce_(w["limbs"], s)
-            else:
-                allreduce_limbs(w["limbs"], self.world_size, self.group)
+
+    def _many_tail(self, w, n, kind):
+        """maps + metric of the (all-reduced) limb sets, one workgroup per point; the values arrive in
+        pinned host memory"""
+        import ctypes as C
+
+        lib, s = _lib.lib(), K._stream()
         h = w["host_np"]
         h[:] = np.nan
         _lib.check(lib.pisa_hip_finalize_metric_multi(
@@ -952,7 +969,6 @@ class HotPathEngine:
             C.c_void_p(w["host"].data_ptr()), C.c_void_p(self.ws.status.data_ptr()),
             C.c_void_p(self.metric_status.data_ptr()), 1, s))
         w["zero"] = True      # the tail leaves the limbs zeroed for the next sweep
-        self.last_many = w
         for _ in range(self.spin_wait):
             if not np.isnan(h).any():
                 return [float(v) for v in h]

@@ -18,13 +18,13 @@ class aeff(Stage):  # pylint: disable=invalid-name
 
     def scale_for(self, name):
         p = self.params
-        scale = p.aeff_scale.m_as("dimensionless") * p.livetime.m_as("sec")
+        scale = p.aeff_scale.m_in("dimensionless") * p.livetime.m_in("sec")
         if name in ("nutau_cc", "nutaubar_cc"):
-            scale *= p.nutau_cc_norm.m_as("dimensionless")
+            scale *= p.nutau_cc_norm.m_in("dimensionless")
         if "nutau" in name:
-            scale *= p.nutau_norm.m_as("dimensionless")
+            scale *= p.nutau_norm.m_in("dimensionless")
         if "nc" in name:
-            scale *= p.nu_nc_norm.m_as("dimensionless")
+            scale *= p.nu_nc_norm.m_in("dimensionless")
         return scale
 
     def apply_function(self):

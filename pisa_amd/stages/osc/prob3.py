@@ -153,16 +153,25 @@ class prob3(Stage):  # pylint: disable=invalid-name
     # ---------------------------------------------------------------- compute
     def _matrices(self):
         p = self.params
-        for name in ("theta12", "theta13", "theta23", "deltacp"):
-            if p[name].value.units == ureg.dimensionless:
-                raise ValueError("%s is dimensionless, but needs units rad or deg!" % name)
+        # the six parameter objects, looked up once per structural state of the sets (this runs at every
+        # point of a fit); units converted once per value (`Param.m_in`)
+        from pisa_amd.core.param import ParamSet
+
+        std6 = getattr(self, "_std6", None)
+        if std6 is None or std6[0] != ParamSet.struct_clock:
+            std6 = self._std6 = (ParamSet.struct_clock,
+                                 tuple(p[n] for n in ("theta12", "theta13", "theta23", "deltacp", "deltam21", "deltam31")))
+        t12, t13, t23, dcp, d21, d31 = std6[1]
+        for prm in (t12, t13, t23, dcp):
+            if prm.value.units == ureg.dimensionless:
+                raise ValueError("%s is dimensionless, but needs units rad or deg!" % prm.name)
         o = self.osc_params
-        o.theta12 = p.theta12.value.m_as("rad")
-        o.theta13 = p.theta13.value.m_as("rad")
-        o.theta23 = p.theta23.value.m_as("rad")
-        o.dm21 = p.deltam21.value.m_as("eV**2")
-        o.dm31 = p.deltam31.value.m_as("eV**2")
-        o.deltacp = p.deltacp.value.m_as("rad")
+        o.theta12 = t12.m_in("rad")
+        o.theta13 = t13.m_in("rad")
+        o.theta23 = t23.m_in("rad")
+        o.dm21 = d21.m_in("eV**2")
+        o.dm31 = d31.m_in("eV**2")
+        o.deltacp = dcp.m_in("rad")
         if self.nsi_type == "vacuum-like":
             n = self.nsi_params
             n.eps_scale = p.eps_scale.value.m_as("dimensionless")

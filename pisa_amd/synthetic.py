@@ -114,16 +114,24 @@ class Workload:
         o.deltacp = np.deg2rad(deltacp_deg)
         o.dm21, o.dm31 = dm21, dm31
         if mat_pot is None:
-            mat_pot = np.diag([1.0, 0.0, 0.0]).astype(np.complex128)  # prob3.py:539-543
-        mat_decay = np.zeros((3, 3), np.complex128)
+            mat_pot = _STD_POT  # prob3.py:539-543
+        mat_decay = _ZERO_C
         flag = -1
         if decay_alpha3 is not None:
+            mat_decay = np.zeros((3, 3), np.complex128)
             mat_decay[2, 2] = 0 - decay_alpha3 * 1j
             flag = 1
-        self.last_matrices = dict(dm=o.dm_matrix, mix=o.mix_matrix_complex, mat_pot=mat_pot,
-                                  decay_flag=flag, mat_decay=mat_decay, lri_pot=np.zeros((3, 3)))
-        return _lib.make_prob3_params(o.dm_matrix, o.mix_matrix_complex, mat_pot, flag, mat_decay,
-                                      np.zeros((3, 3)))
+        dm, mix = o.dm_matrix, o.mix_matrix_complex      # each assembled once per point (a fit loop calls this)
+        self.last_matrices = dict(dm=dm, mix=mix, mat_pot=mat_pot, decay_flag=flag, mat_decay=mat_decay,
+                                  lri_pot=_ZERO_R)
+        return _lib.make_prob3_params(dm, mix, mat_pot, flag, mat_decay, _ZERO_R)
+
+
+_STD_POT = np.diag([1.0, 0.0, 0.0]).astype(np.complex128)
+_ZERO_C = np.zeros((3, 3), np.complex128)
+_ZERO_R = np.zeros((3, 3))
+for _m in (_STD_POT, _ZERO_C, _ZERO_R):
+    _m.setflags(write=False)
 
 
 class DeviceState(HotPathEngine):

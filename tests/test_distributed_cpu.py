@@ -227,3 +227,150 @@ def test_kde_stage_map_exchange_on_gloo_ranks(tmp_path, world):
         m, e = _fake_map(i, 37)
         np.testing.assert_array_equal(got[i, 0], m)
         np.testing.assert_array_equal(got[i, 1], e)
+
+
+# ---- bench.py's own N > 1 control flow (process group, barriers, max over ranks, the legs that run on
+#      several ranks, the JSON line) and HotPathEngine.eval_many's (one all-reduce of K limb sets, chunking)
+#      on CPU ranks over gloo: the HIP launches are replaced by host stand-ins, everything else is the
+#      product's / the bench's code
+def _make_bench_state(wl, rank=0, world_size=1, **_kw):
+    from pisa_amd.engine import HotPathEngine, allreduce_limbs, float_to_limbs, limbs_to_float, local_slices
+
+    class CpuState(HotPathEngine):
+        def __init__(self):  # pylint: disable=super-init-not-called
+            self.dev = torch.device("cpu")
+            self.rank, self.world_size, self.group, self._rccl = rank, world_size, None, None
+            self.wl = wl
+            self.names = [ev["name"] for ev in wl.events]
+            self.cont = list(wl.events)
+            self.n_bins = 5
+            self._slices = local_slices([len(ev["true_energy"]) for ev in wl.events], rank, world_size)
+            self.n_local = sum(hi - lo for lo, hi in self._slices)
+            self.index16, self.indexed, self.osc_events, self.node_flux, self.fused_tail = True, True, False, False, True
+            self.plan, self.energy_d = object(), None
+            n_c = len(self.cont)
+            from types import SimpleNamespace
+
+            self.ws = SimpleNamespace(limbs=torch.zeros((n_c, self.n_bins, 2, 6), dtype=torch.int64))
+            self.metric_out = torch.zeros(1, dtype=torch.float64)
+            self.data = None
+            self._out_block = None
+            self.sweeps = 0
+
+        @staticmethod
+        def _knob(params):
+            return 100.0 * params.dm[6] + params.mix[8]
+
+        def _limbs_of(self, params):
+            acc = np.zeros((len(self.cont), self.n_bins, 2, 6), dtype=object)
+            k = self._knob(params)
+            for ci, (ev, (lo, hi)) in enumerate(zip(self.cont, self._slices)):
+                w = ev["initial_weights"][lo:hi] * (1.0 + k * ev["true_coszen"][lo:hi] ** 2)
+                b = np.minimum((ev["true_energy"][lo:hi] ** 0.3).astype(int), self.n_bins - 1)
+                for x, bb in zip(w, b):
+                    for j, v in enumerate(float_to_limbs(float(x))):
+                        acc[ci, bb, 0, j] += v
+                    for j, v in enumerate(float_to_limbs(float(x) * float(x))):
+                        acc[ci, bb, 1, j] += v
+            return torch.tensor(acc.astype(np.int64))
+
+        def _metric_of(self, limbs):
+            hist = np.array([[limbs_to_float(limbs[c, b, 0].tolist()) for b in range(self.n_bins)]
+                             for c in range(limbs.shape[0])])
+            total = hist.sum(axis=0)
+            lam = np.maximum(total, 1e-10)
+            return float(np.sum(self.data * np.log(lam) - lam)) if self.data is not None else float(total.sum())
+
+        def accumulate(self, params=None):
+            self.ws.limbs.copy_(self._limbs_of(params))
+
+        def _tail(self, kind, out):
+            out[0] = self._metric_of(self.ws.limbs)
+            return out
+
+        def eval_host(self, params, kind="llh"):
+            self.accumulate(params)
+            self.allreduce()
+            return float(self._tail(kind, self.metric_out)[0])
+
+        def make_pseudo_data(self, params, seed=0):
+            self.data = None
+            total = self.eval_host(params)
+            self.data = np.full(self.n_bins, max(1.0, round(total / self.n_bins)))
+
+        def check_status(self):
+            pass
+
+        # eval_many: the product's control flow around these two stand-ins
+        def multi_capable(self, plan=None):
+            return True
+
+        def _multi_ws(self, k):
+            return dict(limbs=torch.zeros((k, len(self.cont), self.n_bins, 2, 6), dtype=torch.int64), zero=True)
+
+        def _many_sweep(self, w, params_list, scales, plan, energy):
+            self.sweeps += 1
+            for i, p in enumerate(params_list):
+                w["limbs"][i] = self._limbs_of(p)
+
+        def _many_tail(self, w, n, kind):
+            return [self._metric_of(w["limbs"][i]) for i in range(n)]
+
+    return CpuState()
+
+
+def _bench_worker(rank, world, port, out_path):
+    import json
+    import sys
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    got = {}
+    bench.main(["--gpus", str(world), "--events", "360", "--steps", "3", "--warmup", "1", "--min-timed-s", "0",
+                "--grid", "12x8", "--legs", "all"],
+               hooks=dict(device_state=_make_bench_state, legs=("multi_point", "fit_c4_engine"), result=got.update))
+    if rank == 0:
+        with open(out_path, "w") as fh:
+            json.dump(got, fh)
+
+
+def test_bench_multi_gpu_control_flow_on_gloo_ranks(tmp_path):
+    """`bench.py --gpus 2` end to end on two CPU ranks: the strong-scaling headline (events sharded, limbs
+    all-reduced, MAX over ranks), the weak-scaling pass beside it, the multi-point leg (eval_many's
+    all-reduce of K limb sets), one JSON line on rank 0 with the contract's fields -- and the LLH the two
+    ranks report equals the one a single rank computes on the whole sample"""
+    import json
+    import sys
+
+    out = str(tmp_path / "bench.json")
+    mp.spawn(_bench_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    line = json.load(open(out))
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["steps"] == 3 and line["warmup"] == 1
+    assert line["unit"] == "evals/s" and line["value"] > 0 and line["weak_value"] > 0
+    assert set(line["legs"]) == {"multi_point", "fit_c4_engine"}
+    fit = line["legs"]["fit_c4_engine"]
+    assert fit["same_history"] and fit["point_by_point"]["llh_evaluations"] == fit["stencil_in_one_sweep"]["llh_evaluations"]
+    mpt = line["legs"]["multi_point"]
+    assert all(mpt["K%d" % k]["same_bits_as_point_by_point"] for k in (3, 5, 9))
+    assert line["batched_evals_per_s5"] == mpt["K5"]["evals_per_s"]
+    # the same sample on ONE rank: the same LLH bits (integer limbs: the shard count does not matter)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from pisa_amd import synthetic
+
+    wl = synthetic.Workload(n_events=360, grid=(12, 8), out_binning="dragon", seed=0)
+    single = _make_bench_state(wl)
+    single.make_pseudo_data(wl.osc_params(), seed=0)
+    last = bench.param_list(wl, 4)[-1]
+    assert single.eval_host(last, "llh") == line["last_llh"]
+    # eval_many on one rank: same values, one sweep per batch, batches beyond MAX_POINTS are split
+    from pisa_amd import _lib
+
+    pts = bench.param_list(wl, _lib.MAX_POINTS + 2)
+    assert single.eval_many(pts, "llh") == [single.eval_host(p, "llh") for p in pts]
+    assert single.sweeps == 2
