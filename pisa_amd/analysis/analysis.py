@@ -110,25 +110,29 @@ class Analysis:
         where neither direction has room the step shrinks to the wider side).  Returns (points, dx):
         points[0] = x0, points[1 + i] = x0 with coordinate i moved, dx[i] the step actually taken
         (recomputed as the representable difference, as scipy does)."""
-        x0 = np.asarray(x0, dtype=np.float64)
-        sign = (x0 >= 0).astype(np.float64) * 2 - 1
-        h = np.full_like(x0, eps)
-        h = np.where((x0 + h) - x0 == 0, np.sqrt(np.finfo(np.float64).eps) * sign * np.maximum(1.0, np.abs(x0)), h)
-        lower, upper = x0 - lb, ub - x0
-        x = x0 + h
-        violated = (x < lb) | (x > ub)
-        fitting = np.abs(h) <= np.maximum(lower, upper)
-        h = np.where(violated & fitting, -h, h)
-        forward = (upper >= lower) & ~fitting
-        h = np.where(forward, upper, h)
-        backward = (upper < lower) & ~fitting
-        h = np.where(backward, -lower, h)
-        pts, dx = [x0.copy()], np.empty_like(x0)
-        for i in range(x0.size):
-            x1 = x0.copy()
-            x1[i] += h[i]
-            dx[i] = x1[i] - x0[i]
-            pts.append(x1)
+        # plain Python floats (IEEE doubles, the same operations as scipy's array code): for the handful
+        # of free parameters of a fit the array version costs more than the arithmetic
+        x0 = [float(v) for v in x0]
+        n = len(x0)
+        root_eps = float(np.sqrt(np.finfo(np.float64).eps))
+        pts, dx = [np.array(x0, dtype=np.float64)], np.empty(n)
+        for i in range(n):
+            xi, lo, hi = x0[i], float(lb[i]), float(ub[i])
+            h = float(eps)
+            if (xi + h) - xi == 0:
+                h = root_eps * (1.0 if xi >= 0 else -1.0) * max(1.0, abs(xi))
+            lower, upper = xi - lo, hi - xi
+            x = xi + h
+            violated = x < lo or x > hi
+            fitting = abs(h) <= max(lower, upper)
+            if violated and fitting:
+                h = -h
+            elif not fitting:
+                h = upper if upper >= lower else -lower
+            x1 = list(x0)
+            x1[i] = xi + h
+            dx[i] = x1[i] - xi
+            pts.append(np.array(x1, dtype=np.float64))
         return pts, dx
 
     def _minimizer_callable_with_gradient(self, scaled_param_vals, hypo_maker, data_dist, metric, counter,
