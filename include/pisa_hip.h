@@ -585,6 +585,33 @@ int pisa_hip_barr_simple_multi(const pisa_hip_barr_set *h_sets, int32_t n_sets,
                                double nue_numu_ratio, double nu_nubar_ratio, double delta_index,
                                double Barr_uphor_ratio, double Barr_nu_nubar_ratio, void *stream);
 
+/* A flux systematic moved and the flux is held per event (flux.barr_simple in an event representation,
+ * pisa/stages/flux/barr_simple.py:83-104, then multiplied in every evaluation, prob3.py:621-622): ONE pass
+ * over the events instead of pisa_hip_barr_simple_multi + pisa_hip_fold_flux_multi.
+ * pisa_hip_barr_factors (once per event set): the parts of apply_sys_vectorized (:147-233) that depend on
+ *   (E, coszen) only -- d_factors[5][n] = ModFlux(nue), ModFlux(numu), the energy and the zenith factor of
+ *   the up/horizontal Gaussian, log(E / E_pivot); d_status (int32, may be NULL) is set if an energy is not
+ *   positive (such a set must use the two-pass calls, which keep the reference's answers there).
+ * pisa_hip_barr_fold_multi (per moved systematic): every array of a set in the SAME order and layout as
+ *   d_out -- the engine's resident order, e.g. the quad-blocked d_weighted_flux_q --
+ *   d_out[p] = d_static_w[p] * apply_sys(nominal fluxes[p], factors[p]; parameters): the bits of the two
+ *   calls it replaces. */
+typedef struct {
+    int64_t n;                          /* positions (padding included) */
+    const double *d_nu_flux_nominal;    /* [n][2] */
+    const double *d_nubar_flux_nominal; /* [n][2] */
+    const double *d_factors;            /* [5][n] from pisa_hip_barr_factors */
+    const double *d_static_w;           /* [n] initial_weights*weighted_aeff (0 at padding) */
+    double *d_out;                      /* [n][2] */
+    int32_t nubar;                      /* +1 / -1 */
+    int32_t reserved;
+} pisa_hip_barr_fold_set;
+int pisa_hip_barr_factors(const double *d_true_energy, const double *d_true_coszen, int64_t n,
+                          double *d_factors, int32_t *d_status, void *stream);
+int pisa_hip_barr_fold_multi(const pisa_hip_barr_fold_set *h_sets, int32_t n_sets, double nue_numu_ratio,
+                             double nu_nubar_ratio, double delta_index, double Barr_uphor_ratio,
+                             double Barr_nu_nubar_ratio, void *stream);
+
 /* ------------------------------------------------------- raw device memory */
 /* Thin wrappers so hosts without torch (a cgo/ctypes binding of the
  * reference) can own device buffers. */

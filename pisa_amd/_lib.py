@@ -119,6 +119,19 @@ class BarrSet(C.Structure):
     ]
 
 
+class BarrFoldSet(C.Structure):
+    _fields_ = [
+        ("n", C.c_int64),
+        ("d_nu_flux_nominal", C.c_void_p),
+        ("d_nubar_flux_nominal", C.c_void_p),
+        ("d_factors", C.c_void_p),
+        ("d_static_w", C.c_void_p),
+        ("d_out", C.c_void_p),
+        ("nubar", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
 class FluxTable(C.Structure):
     _fields_ = [
         ("n_bands", C.c_int32),
@@ -196,6 +209,8 @@ _SIGS = {
     "pisa_hip_barr_simple": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_void_p, C.c_void_p]),
     "pisa_hip_fold_flux_multi": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "pisa_hip_barr_simple_multi": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
+    "pisa_hip_barr_factors": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pisa_hip_barr_fold_multi": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     "pisa_hip_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_int64]),
     "pisa_hip_free": (C.c_int, [C.c_void_p]),
     "pisa_hip_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -222,28 +222,107 @@ __device__ __forceinline__ void apply_ratio_scale(double ratio_scale, double in1
     o1 = nw;
 }
 
-__device__ __forceinline__ double2 barr_one(double e, double cz, double2 fn, double2 fb, int nubar,
-                                            double nue_numu_ratio, double nu_nubar_ratio, double delta_index,
-                                            double uphor, double barr_nu_nubar) {
+// The parts of apply_sys_vectorized (barr_simple.py:147-233) that depend on the event only, not on the
+// systematics: ModFlux of both flavours (modRatioNuBar = max(0, 1 +- 0.5 sys ModFlux)), the energy and
+// the zenith factor of modRatioUpHor's Gaussian (A_shape = |uphor| LL, norm = A_shape / sqrt(2 pi s^2) *
+// EX) and log(E / E_pivot) of the spectral tilt -- ten of the kernel's eleven transcendentals.
+struct BarrFactors {
+    double mf0, mf1;   // ModFlux(0 / 1, E, cz)
+    double ll_uh;      // LogLogParam(E, 0.9, 10, 0.5, 2, cutoff 650)
+    double ex_uh;      // exp(-cz^2 / (2 * 0.35^2))
+    double lx;         // log(E / 24.0900951261)
+};
+__device__ __forceinline__ BarrFactors barr_factors(double e, double cz) {
+    const double z1max_mu = 0.6, z2max_mu = 5., z1max_e = 0.3, z2max_e = 5.;
+    const double nue_cutoff = 650.;
+    const double x1z = 0.5, x2z = 2.;
+    BarrFactors f;
+    f.mf0 = ModFlux(0, e, cz);
+    f.mf1 = ModFlux(1, e, cz);
+    f.ll_uh = LogLogParam(e, (z1max_e + z1max_mu), (z2max_e + z2max_mu), x1z, x2z, true, nue_cutoff);
+    const double sigma = 0.35;
+    f.ex_uh = exp(-(cz * cz) / (2 * (sigma * sigma)));
+    f.lx = log(e / 24.0900951261);
+    return f;
+}
+// apply_sys_vectorized from the event's factors: operation for operation what the reference does once
+// the factors are there (flux stage output; tests/test_gpu_flux.py against the reference's goldens)
+__device__ __forceinline__ double2 barr_from_factors(const BarrFactors &F, double x_piv, double2 fn, double2 fb,
+                                                     int nubar, double nue_numu_ratio, double nu_nubar_ratio,
+                                                     double delta_index, double uphor, double barr_nu_nubar) {
     double nu0, nu1, nb0, nb1;
     apply_ratio_scale(nue_numu_ratio, fn.x, fn.y, nu0, nu1);
     apply_ratio_scale(nue_numu_ratio, fb.x, fb.y, nb0, nb1);
     // (E / E_pivot)^delta_index (barr_simple.py:39-45): exp(delta log x) for the energies that exist
     // (same value to two ulp, a third cheaper than the general pow); pow keeps the reference's answers
     // for E <= 0 and NaN
-    const double x_piv = e / 24.0900951261;
-    double idx_scale = x_piv > 0.0 ? exp(delta_index * log(x_piv)) : pow(x_piv, delta_index);
+    double idx_scale = x_piv > 0.0 ? exp(delta_index * F.lx) : pow(x_piv, delta_index);
     nu0 *= idx_scale; nu1 *= idx_scale; nb0 *= idx_scale; nb1 *= idx_scale;
     double e0, e1, m0, m1;
     apply_ratio_scale(nu_nubar_ratio, nu0, nb0, e0, e1);  // nue: (nu, nubar)
     apply_ratio_scale(nu_nubar_ratio, nu1, nb1, m0, m1);  // numu
     double o0 = nubar < 0 ? e1 : e0;
     double o1 = nubar < 0 ? m1 : m0;
-    o0 *= modRatioNuBar(nubar, 0, e, cz, barr_nu_nubar);
-    o1 *= modRatioNuBar(nubar, 1, e, cz, barr_nu_nubar);
-    o0 *= modRatioUpHor(0, e, cz, uphor);
-    o1 *= modRatioUpHor(1, e, cz, uphor);
+    // modRatioNuBar (barr_parameterization.py:106-113)
+    const double mod0 = barr_nu_nubar * F.mf0, mod1 = barr_nu_nubar * F.mf1;
+    o0 *= nubar < 0 ? fmax(0., 1. / (1 + 0.5 * mod0)) : fmax(0., 1. + 0.5 * mod0);
+    o1 *= nubar < 0 ? fmax(0., 1. / (1 + 0.5 * mod1)) : fmax(0., 1. + 0.5 * mod1);
+    // modRatioUpHor (:84-103): nue only; norm_fcn(cz, A_shape, 0.35) with its exponential from the factors
+    {
+        const double pi = 3.14159265358979323846;
+        const double sigma = 0.35;
+        const double A_shape = 1. * fabs(uphor) * F.ll_uh;
+        const double norm = A_shape / sqrt(2 * pi * (sigma * sigma)) * F.ex_uh;
+        o0 *= 1 - 0.3 * sign_(uphor) * norm;
+    }
+    o1 *= 1.;
     return make_double2(o0, o1);
+}
+
+__device__ __forceinline__ double2 barr_one(double e, double cz, double2 fn, double2 fb, int nubar,
+                                            double nue_numu_ratio, double nu_nubar_ratio, double delta_index,
+                                            double uphor, double barr_nu_nubar) {
+    const BarrFactors F = barr_factors(e, cz);
+    return barr_from_factors(F, e / 24.0900951261, fn, fb, nubar, nue_numu_ratio, nu_nubar_ratio, delta_index,
+                             uphor, barr_nu_nubar);
+}
+
+// ONE pass for a moved flux systematic when the flux is held per event: every input in the fused
+// kernel's own resident order and column layout (the engine keeps such copies), the event's
+// parameter-free factors from `barr_factors_kernel`, and the static factor folded in on the way out:
+//   out[p] = static_w[p] * apply_sys(...)[p]      -- pisa_hip_barr_simple_multi followed by
+// pisa_hip_fold_flux_multi, bit for bit, without the second pass and its gather.
+__global__ void __launch_bounds__(256)
+barr_factors_kernel(const double *__restrict__ e, const double *__restrict__ cz, int64_t n,
+                    double *__restrict__ out, int32_t *__restrict__ status) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double ei = e[i];
+    if (!(ei > 0.0) && status) atomicOr(status, 1);   // the one-pass form is for energies that exist
+    const BarrFactors f = barr_factors(ei, cz[i]);
+    out[i] = f.mf0; out[n + i] = f.mf1; out[2 * n + i] = f.ll_uh; out[3 * n + i] = f.ex_uh; out[4 * n + i] = f.lx;
+}
+
+constexpr int BARR_FOLD_MAX_SETS = 16;
+struct BarrFoldSets {
+    pisa_hip_barr_fold_set s[BARR_FOLD_MAX_SETS];
+};
+__global__ void __launch_bounds__(256)
+barr_fold_multi_kernel(const BarrFoldSets sets, double nue_numu_ratio, double nu_nubar_ratio,
+                       double delta_index, double uphor, double barr_nu_nubar) {
+    const pisa_hip_barr_fold_set &S = sets.s[blockIdx.y];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = S.n;
+    if (i >= n) return;
+    BarrFactors F;
+    const double *f = S.d_factors;
+    F.mf0 = f[i]; F.mf1 = f[n + i]; F.ll_uh = f[2 * n + i]; F.ex_uh = f[3 * n + i]; F.lx = f[4 * n + i];
+    const double2 r = barr_from_factors(F, 1.0 /* energies checked positive when the factors were made */,
+                                        reinterpret_cast<const double2 *>(S.d_nu_flux_nominal)[i],
+                                        reinterpret_cast<const double2 *>(S.d_nubar_flux_nominal)[i], S.nubar,
+                                        nue_numu_ratio, nu_nubar_ratio, delta_index, uphor, barr_nu_nubar);
+    const double w = S.d_static_w[i];
+    reinterpret_cast<double2 *>(S.d_out)[i] = make_double2(w * r.x, w * r.y);
 }
 
 __global__ void __launch_bounds__(256)
@@ -521,6 +600,44 @@ PISA_API int pisa_hip_barr_simple(const double *d_true_energy, const double *d_t
                        nue_numu_ratio, nu_nubar_ratio, delta_index, Barr_uphor_ratio,
                        Barr_nu_nubar_ratio, n, d_out);
     PISA_CHECK_LAUNCH("barr_simple_kernel");
+    return PISA_HIP_OK;
+}
+
+PISA_API int pisa_hip_barr_factors(const double *d_true_energy, const double *d_true_coszen, int64_t n,
+                                   double *d_factors, int32_t *d_status, void *stream) {
+    if (n < 0) return PISA_HIP_ERR_INVALID;
+    if (n == 0) return PISA_HIP_OK;
+    if (!d_true_energy || !d_true_coszen || !d_factors) return PISA_HIP_ERR_INVALID;
+    hipLaunchKernelGGL(barr_factors_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       d_true_energy, d_true_coszen, n, d_factors, d_status);
+    PISA_CHECK_LAUNCH("barr_factors_kernel");
+    return PISA_HIP_OK;
+}
+
+PISA_API int pisa_hip_barr_fold_multi(const pisa_hip_barr_fold_set *h_sets, int32_t n_sets,
+                                      double nue_numu_ratio, double nu_nubar_ratio, double delta_index,
+                                      double Barr_uphor_ratio, double Barr_nu_nubar_ratio, void *stream) {
+    if (n_sets < 0 || (n_sets > 0 && !h_sets)) return PISA_HIP_ERR_INVALID;
+    for (int k = 0; k < n_sets; k++) {
+        const pisa_hip_barr_fold_set &h = h_sets[k];
+        if (h.n < 0 || (h.nubar != 1 && h.nubar != -1)) return PISA_HIP_ERR_INVALID;
+        if (h.n > 0 && (!h.d_nu_flux_nominal || !h.d_nubar_flux_nominal || !h.d_factors || !h.d_static_w || !h.d_out))
+            return PISA_HIP_ERR_INVALID;
+    }
+    for (int base = 0; base < n_sets; base += BARR_FOLD_MAX_SETS) {
+        const int nc = n_sets - base < BARR_FOLD_MAX_SETS ? n_sets - base : BARR_FOLD_MAX_SETS;
+        BarrFoldSets sets;
+        int64_t n_max = 0;
+        for (int k = 0; k < nc; k++) {
+            sets.s[k] = h_sets[base + k];
+            if (sets.s[k].n > n_max) n_max = sets.s[k].n;
+        }
+        if (n_max == 0) continue;
+        hipLaunchKernelGGL(barr_fold_multi_kernel, dim3((unsigned)((n_max + 255) / 256), (unsigned)nc), dim3(256), 0,
+                           as_stream(stream), sets, nue_numu_ratio, nu_nubar_ratio, delta_index, Barr_uphor_ratio,
+                           Barr_nu_nubar_ratio);
+        PISA_CHECK_LAUNCH("barr_fold_multi_kernel");
+    }
     return PISA_HIP_OK;
 }
 

@@ -492,6 +492,64 @@ class HotPathEngine:
             blk = self._fold_block = dict(key=key, arr=arr, keep=[f for _, f in prepared])
         _lib.check(_lib.lib().pisa_hip_fold_flux_multi(blk["arr"], len(blk["arr"]), K._stream()))
 
+    def enable_barr(self, columns):
+        """Prepare the ONE-pass refresh of the folded flux columns for `flux.barr_simple` systematics
+        (`update_flux_barr`).  `columns`: per container (true_energy[n], true_coszen[n],
+        nu_flux_nominal[n, 2], nubar_flux_nominal[n, 2]) device tensors in the container's own event
+        order.  The engine keeps copies in its resident order AND column layout (for the 20 B form the
+        quad-blocked one), with the event's parameter-free factors of apply_sys_vectorized
+        (`pisa_hip_barr_factors`: ten of its eleven transcendentals), so that a moved systematic costs one
+        elementwise pass that writes the folded column directly -- no Barr output in container order, no
+        gather into the resident order."""
+        assert all(w is not None for w in self._wflux), "needs the compact (folded) event columns"
+        lib = _lib.lib()
+        arr = (_lib.BarrFoldSet * len(self.cont))()
+        keep = []
+        status = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        for i, (e, cz, nu, nub) in enumerate(columns):
+            lo, hi = self._slices[i]
+            perm, out, sw = self._perm[i], self._wflux[i], self._static_w[i]
+            n_ev = int(sw.numel())
+            if out.dim() == 2:       # plain [n][2] column: position = resident event
+                n_pos = n_ev
+                ev = torch.arange(n_pos, device=self.dev)
+            else:                    # quad-blocked: event 4q + k at [q / 64][k][q % 64]
+                n_pos = out.shape[0] * 256
+                pos = torch.arange(n_pos, device=self.dev)
+                q = (pos // 256) * 64 + pos % 64
+                ev = 4 * q + (pos // 64) % 4
+            valid = ev < n_ev
+            evc = torch.where(valid, ev, torch.zeros_like(ev))
+            src = evc if perm is None else perm[evc]
+
+            def take(col, fill):
+                t = col[lo:hi][src]
+                t[~valid] = fill
+                return t.contiguous()
+
+            e_b, cz_b = take(e, 1.0), take(cz, 0.0)
+            nu_b, nub_b = take(nu, 0.0), take(nub, 0.0)
+            w_b = torch.where(valid, sw[evc], torch.zeros_like(sw[evc])).contiguous()
+            fac = torch.empty((5, n_pos), dtype=torch.float64, device=self.dev)
+            _lib.check(lib.pisa_hip_barr_factors(K._ptr(e_b), K._ptr(cz_b), n_pos, K._ptr(fac), K._ptr(status),
+                                                 K._stream()))
+            d = arr[i]
+            d.n = n_pos
+            d.d_nu_flux_nominal, d.d_nubar_flux_nominal = nu_b.data_ptr(), nub_b.data_ptr()
+            d.d_factors, d.d_static_w, d.d_out = fac.data_ptr(), w_b.data_ptr(), out.data_ptr()
+            d.nubar = int(self.cont[i].nubar)
+            keep += [nu_b, nub_b, fac, w_b]
+        if int(status.item()) != 0:
+            raise ValueError("true_energy must be positive for the one-pass flux refresh")
+        self._barr = dict(arr=arr, keep=keep, fn=lib.pisa_hip_barr_fold_multi)
+
+    def update_flux_barr(self, nue_numu_ratio, nu_nubar_ratio, delta_index, Barr_uphor_ratio, Barr_nu_nubar_ratio):
+        """new folded flux columns of ALL containers for these `flux.barr_simple` parameter values
+        (barr_simple.py:83-104 + the fold of `update_flux`): one launch, one pass, the same bits"""
+        b = self._barr
+        _lib.check(b["fn"](b["arr"], len(b["arr"]), float(nue_numu_ratio), float(nu_nubar_ratio), float(delta_index),
+                           float(Barr_uphor_ratio), float(Barr_nu_nubar_ratio), K._stream()))
+
     def update_flux_nodes(self, i, flux_nodes):
         """node_flux mode: new [grid.size, 2] flux of container i on the calc grid (device tensor).
         A contiguous fp64 tensor on this device is adopted as it is -- the table kernel reads it

@@ -615,3 +615,48 @@ def test_bench_line_contract_single_gpu():
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["sample"] and c["cpu_model"]
     assert c["single_thread"]["cores"] == 1 and c["single_thread"]["value"] > 0
     assert c["value"] < d["value"]
+
+
+@pytest.mark.parametrize("index16", [True, False])
+def test_one_pass_flux_refresh_is_the_two_pass_refresh(index16):
+    """A `flux.barr_simple` systematic with the flux per event: `update_flux_barr` (resident-order
+    nominal fluxes + parameter-free factors -> the folded column, one elementwise pass) leaves the very
+    bits of `pisa_hip_barr_simple_multi` in container order followed by `update_flux_many` (gather into
+    the resident order + fold) -- in the quad-blocked 20 B layout and the plain 24 B one, ragged event
+    counts, padding untouched by garbage, and the evaluation that follows agrees as well"""
+    import torch
+
+    from pisa_amd import kernels as K
+    from pisa_amd import synthetic
+
+    wl = synthetic.Workload(n_events=12 * 10007, grid=(40, 30), out_binning="dragon", seed=12)
+    a = synthetic.DeviceState(wl, compact=True, index16=index16)
+    b = synthetic.DeviceState(wl, compact=True, index16=index16)
+    assert a.index16 == index16
+    a.make_pseudo_data(wl.osc_params(), seed=0)
+    b.set_data(a.data.cpu().numpy())
+    cols = []
+    for ev in wl.events:
+        cols.append((K.to_device(ev["true_energy"]), K.to_device(ev["true_coszen"]), K.to_device(ev["nu_flux"]),
+                     K.to_device(ev["nu_flux"] * 0.7)))
+    b.enable_barr(cols)
+    outs = [torch.empty((c[0].numel(), 2), dtype=torch.float64, device="cuda") for c in cols]
+    sets = K.barr_sets([(e, cz, nu, nub, ev["nubar"], out) for (e, cz, nu, nub), ev, out in zip(cols, wl.events, outs)])
+    p = wl.osc_params(theta23_deg=46.0)
+    for ps in ((1.03, 0.97, 0.04, 0.3, -0.2), (0.95, 1.08, -0.06, -0.7, 0.5), (1.0, 1.0, 0.0, 0.0, 0.0)):
+        K.barr_simple_multi(sets, *ps)
+        a.update_flux_many(list(enumerate(outs)))
+        b.update_flux_barr(*ps)
+        for wa, wb in zip(a._wflux, b._wflux):
+            assert torch.equal(wa, wb)
+        assert a.eval_host(p, "llh") == b.eval_host(p, "llh")
+    a.check_status()
+    b.check_status()
+    # an energy that is not positive has no place in the one-pass form (the two-pass calls keep the
+    # reference's answers there)
+    bad = list(cols)
+    e0 = cols[0][0].clone()
+    e0[3] = -1.0
+    bad[0] = (e0,) + cols[0][1:]
+    with pytest.raises(ValueError):
+        b.enable_barr(bad)
