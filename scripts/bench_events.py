@@ -18,6 +18,8 @@ ap.add_argument("--events", type=float, default=1e6)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--nsi", action="store_true", help="standard-NSI matter potential (config C5)")
+ap.add_argument("--decay", action="store_true", help="neutrino decay on (decay_alpha3 = 1e-4 eV^2): the decay "
+                                                     "instantiation of the event kernel")
 args = ap.parse_args()
 
 from pisa_amd import kernels as K
@@ -33,9 +35,10 @@ if args.nsi:
     n.eps_emu, n.eps_etau, n.eps_mutau = ((0.07, np.deg2rad(340)), (0.06, np.deg2rad(35)),
                                           (0.003, np.deg2rad(175)))  # numba_osc_tests.py:129-136
     mat_pot = np.diag([1.0, 0, 0]).astype(complex) + n.eps_matrix
-st.make_pseudo_data(wl.osc_params(mat_pot=mat_pot), seed=0)
+dec = 1e-4 if args.decay else None
+st.make_pseudo_data(wl.osc_params(mat_pot=mat_pot, decay_alpha3=dec), seed=0)
 rs = np.random.RandomState(7)
-plist = [wl.osc_params(theta23_deg=31 + 28 * rs.rand(), dm31=1e-3 + 6e-3 * rs.rand(), mat_pot=mat_pot)
+plist = [wl.osc_params(theta23_deg=31 + 28 * rs.rand(), dm31=1e-3 + 6e-3 * rs.rand(), mat_pot=mat_pot, decay_alpha3=dec)
          for _ in range(args.warmup + args.steps)]
 for p in plist[: args.warmup]:
     st.eval_host(p, "llh")
@@ -62,10 +65,10 @@ cal = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "events_flops.json")
              key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(os.path.dirname(f)))])
 out = {
     "workload": "%d events, prob3 event-by-event (PREM-12%s) + fused reweight + 10x10 hist + LLH"
-                % (wl.n_events, ", std NSI" if args.nsi else ""),
+                % (wl.n_events, (", std NSI" if args.nsi else "") + (", decay" if args.decay else "")),
     "evals_per_s": 1.0 / dt, "event_evals_per_s": wl.n_events / dt, "ms_per_eval": dt * 1e3,
     "prob3_events_kernel_ms": t_osc * 1e3, "fp64_vector_peak_tflops": 78.6, "last_llh": llh}
-if cal:
+if cal and not args.decay:
     d = json.load(open(cal[-1]))["nsi" if args.nsi else "std"]
     out["executed_fp64_flop_per_event"] = d["flop_per_event"]
     out["executed_fp64_tflops"] = d["flop_per_event"] * wl.n_events / t_osc / 1e12

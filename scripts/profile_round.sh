@@ -38,6 +38,57 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kde_stats -o kde --
 cp $OUT/kde_stats/kde_kernel_stats.csv $OUT/kde_kernel_stats.csv
 rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 --kernel-trace --output-format csv -d $OUT/pmc_c3 -o p -- python3 scripts/dev/c3_probe.py 1e7 > $OUT/c3_pmc_run.log 2> $OUT/pmc_c3.log
 cp $OUT/pmc_c3/p_counter_collection.csv $OUT/pmc_c3_full.csv
+# ---- round 3: kernel-trace durations for every leg's kernel (the legs' roofline fractions were HIP-event
+# numbers without a trace counterpart), the event kernel (C2 / C5 sizes, default and decay instantiation)
+# with its SQ counters, the multi-point kernels, the one-pass flux refresh
+trace () {  # name, command...
+  name=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tr_$name -o t -- "$@" > $OUT/run_$name.json 2> $OUT/tr_$name.log
+  cp $OUT/tr_$name/t_kernel_stats.csv $OUT/kernel_stats_$name.csv
+  rm -rf $OUT/tr_$name
+}
+trace l3 python3 bench.py $LEAN --no-kernel-timing --steps 100 --events 4e7
+trace exact python3 bench.py $LEAN --no-kernel-timing --steps 200 --exact-association
+trace coord python3 bench.py $LEAN --no-kernel-timing --steps 100 --coordinate-form
+trace fine python3 bench.py $LEAN --no-kernel-timing --steps 200 --binning fine3d
+trace update_flux python3 bench.py --no-cpu-baseline --no-drop-probe --no-batch-probe --no-kernel-timing --steps 50 --legs update_flux
+trace events_c2 python3 scripts/bench_events.py --events 1e6 --steps 20
+trace events_c5 python3 scripts/bench_events.py --events 1.25e7 --nsi --steps 6
+trace events_c2_decay python3 scripts/bench_events.py --events 1e6 --steps 20 --decay
+trace events_c5_decay python3 scripts/bench_events.py --events 1.25e7 --nsi --steps 6 --decay
+for K in 3 5 9; do trace multi_K$K python3 scripts/dev/multi_probe.py 1e7 $K; done
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_events_sq -o p -- python3 scripts/bench_events.py --events 1.25e7 --nsi --steps 3 --warmup 1 > /dev/null 2> $OUT/pmc_events_sq.log
+cp $OUT/pmc_events_sq/p_counter_collection.csv $OUT/pmc_events_sq.csv
+rm -rf $OUT/pmc_events_sq
+python3 - <<PY
+import csv, json
+OUT = "$OUT"
+# SQ counters of prob3_events_kernel (C5 size): issue utilisation of the kernel
+acc = {}
+for r in csv.DictReader(open(OUT + "/pmc_events_sq.csv")):
+    if "prob3_events_kernel" in r["Kernel_Name"]:
+        acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+sq = {k: sum(v) / len(v) for k, v in acc.items()}
+if sq:
+    sq["launches"] = len(next(iter(acc.values())))
+    # SQ_WAVE_CYCLES / SQ_BUSY_CYCLES are in units of 4 clocks per the counter definitions of this tool; ratios are unit free
+    sq["valu_issue_fraction_of_wave_cycles"] = sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"]
+    sq["waiting_fraction_of_wave_cycles"] = sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"]
+    sq["valu_instructions_per_wave"] = sq["SQ_INSTS_VALU"] / sq["SQ_WAVES"]
+    sq["method"] = ("rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY "
+                    "over scripts/bench_events.py --events 1.25e7 --nsi; mean per launch of prob3_events_kernel")
+json.dump(sq, open(OUT + "/events_sq_counters.json", "w"), indent=1)
+print("events SQ", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in sq.items() if k != "method"})
+# one table of trace durations: kernel -> mean us, per run
+table = {}
+import glob, os
+for f in sorted(glob.glob(OUT + "/kernel_stats_*.csv")):
+    name = os.path.basename(f)[len("kernel_stats_"):-4]
+    rows = [r for r in csv.DictReader(open(f)) if "pisa::" in r["Name"]]
+    table[name] = {r["Name"].split("(")[0].replace("void ", ""): {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3}
+                   for r in rows}
+json.dump(table, open(OUT + "/trace_durations.json", "w"), indent=1)
+PY
 python3 - <<PY
 import csv, json
 OUT = "$OUT"
