@@ -446,6 +446,12 @@ int pisa_hip_kde_info(const pisa_hip_kde *k, pisa_hip_kde_info_t *info);
 int pisa_hip_kde_arrays(const pisa_hip_kde *k, const double **d_ys, const double **d_coef,
                         const double **d_s2);
 int pisa_hip_kde_destroy(pisa_hip_kde *k);
+/* The Hermite / local-expansion coefficients and split partial sums live in a grow-only scratch buffer of
+ * the library, one per HOST THREAD (an evaluation with several worker threads holds one per worker, up to a
+ * few GB each at 1e7 events).  A thread that changes streams waits for the previous stream before the
+ * buffer is reused.  This call frees the calling thread's buffer. */
+int pisa_hip_kde_release_scratch(void);
+
 /* How the 2-D fixed-bandwidth pilot estimate sums cells of >= 24 sources (fast Gauss transform;
  * truncation error below the cut-off tolerance): 2 (default) = Hermite series of the source cells
  * translated into one local expansion per target cell, 1 = Hermite series evaluated target by target,

@@ -199,6 +199,7 @@ _SIGS = {
     "pisa_hip_kde_arrays": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "pisa_hip_kde_destroy": (C.c_int, [C.c_void_p]),
     "pisa_hip_kde_configure": (C.c_int, [C.c_int32]),
+    "pisa_hip_kde_release_scratch": (C.c_int, []),
     "pisa_hip_metric": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pisa_hip_bin_scale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_int32, C.c_double, C.c_int64, C.c_void_p, C.c_void_p]),
     "pisa_hip_bin_sqrt": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

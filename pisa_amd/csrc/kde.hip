@@ -108,6 +108,34 @@ kde_reduce_kernel(const double *__restrict__ partial, int n_split, int64_t n_qry
 // on its own stream (the utils.kde stage does), and a thread's calls are ordered on its stream.
 static thread_local double *g_kde_scratch = nullptr;
 static thread_local size_t g_kde_scratch_bytes = 0;
+static thread_local hipStream_t g_kde_scratch_stream = nullptr;
+static thread_local bool g_kde_scratch_used = false;
+
+// The scratch is keyed by host thread, not by stream: a thread that moves to another stream waits for
+// the kernels of the previous one, which may still be reading it.  Returns the buffer (>= `bytes`).
+static int kde_scratch(size_t bytes, hipStream_t s, double **out) {
+    if (g_kde_scratch_used && g_kde_scratch_stream != s) {
+        int rc = check_hip(hipStreamSynchronize(g_kde_scratch_stream), "hipStreamSynchronize");
+        if (rc) return rc;
+    }
+    if (bytes > g_kde_scratch_bytes) {
+        if (g_kde_scratch) {
+            // kernels of this thread's stream may still use the old buffer
+            int rc = check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");
+            if (rc) return rc;
+            (void)hipFree(g_kde_scratch);
+        }
+        g_kde_scratch = nullptr;
+        g_kde_scratch_bytes = 0;
+        int rc = check_hip(hipMalloc(&g_kde_scratch, bytes), "hipMalloc");
+        if (rc) return rc;
+        g_kde_scratch_bytes = bytes;
+    }
+    g_kde_scratch_stream = s;
+    g_kde_scratch_used = true;
+    *out = g_kde_scratch;
+    return PISA_HIP_OK;
+}
 
 // =================================================================== estimator object
 constexpr int RED_BLOCKS = 256;   // fixed reduction geometry => fixed summation order
@@ -1316,6 +1344,19 @@ PISA_API int64_t pisa_hip_kde_workspace_bytes(int32_t dim, int64_t n_src) {
     return (int64_t)(total + 64 * 256);
 }
 
+PISA_API int pisa_hip_kde_release_scratch(void) {
+    // frees the calling host thread's grow-only scratch (per thread: call it from the thread that built
+    // / evaluated the estimators, after its stream has drained)
+    if (g_kde_scratch) {
+        if (g_kde_scratch_used) (void)hipStreamSynchronize(g_kde_scratch_stream);
+        (void)hipFree(g_kde_scratch);
+    }
+    g_kde_scratch = nullptr;
+    g_kde_scratch_bytes = 0;
+    g_kde_scratch_used = false;
+    return PISA_HIP_OK;
+}
+
 PISA_API int pisa_hip_kde_configure(int32_t use_expansion) {
     const int old = g_kde_expansion;
     if (use_expansion >= 0) g_kde_expansion = use_expansion > 2 ? 2 : use_expansion;
@@ -1541,15 +1582,8 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
             const size_t pp = (size_t)(P * P);
             const size_t need = (nd * pp + (local_exp ? (n_heads + (size_t)k->n_cells) * pp + (2 * reach + 1) * (2 * P - 1) : 0))
                                 * sizeof(double) + (local_exp ? (size_t)k->n_cells : 0) + 8192;
-            if (need > g_kde_scratch_bytes) {
-                KDE_TRY_HIP(hipStreamSynchronize(s));
-                if (g_kde_scratch) (void)hipFree(g_kde_scratch);
-                g_kde_scratch = nullptr;
-                g_kde_scratch_bytes = 0;
-                KDE_TRY_HIP(hipMalloc(&g_kde_scratch, need + need / 2));
-                g_kde_scratch_bytes = need + need / 2;
-            }
-            double *herm = g_kde_scratch;
+            double *herm = nullptr;
+            KDE_TRY(kde_scratch(need > g_kde_scratch_bytes ? need + need / 2 : need, s, &herm));
             double *local = herm + nd * pp;
             double *d_hankel = local + (local_exp ? n_heads * pp : 0);
             double *d_V = d_hankel + (2 * reach + 1) * (2 * P - 1);
@@ -1890,15 +1924,8 @@ PISA_API int pisa_hip_kde_eval(int32_t dim, const double *d_src, const double *d
         src_chunk = ((n_src + n_split - 1) / n_split + KDE_TILE - 1) / KDE_TILE * KDE_TILE;
         n_split = (int)((n_src + src_chunk - 1) / src_chunk);
         const size_t need = (size_t)n_split * n_qry * sizeof(double);
-        if (need > g_kde_scratch_bytes) {
-            PISA_TRY_HIP(hipStreamSynchronize(s));
-            if (g_kde_scratch) (void)hipFree(g_kde_scratch);
-            g_kde_scratch = nullptr;
-            g_kde_scratch_bytes = 0;
-            PISA_TRY_HIP(hipMalloc(&g_kde_scratch, need));
-            g_kde_scratch_bytes = need;
-        }
-        dst = g_kde_scratch;
+        int rc_s = kde_scratch(need, s, &dst);
+        if (rc_s) return rc_s;
     }
     dim3 block(KDE_THREADS), grid(qblocks, (unsigned)n_split);
 #define KDE_LAUNCH(DD) hipLaunchKernelGGL(kde_eval_kernel<DD>, grid, block, 0, s, d_src, d_coef, d_s2, n_src, d_qry, n_qry, c00, c01, c02, c11, c12, c22, src_chunk, dst)

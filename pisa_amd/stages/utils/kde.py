@@ -114,13 +114,20 @@ class kde(Stage):  # pylint: disable=invalid-name
     #    the maps do not depend on the interleaving.
     kde_workers = int(os.environ.get("PISA_KDE_WORKERS", "4"))
 
+    # ONE executor (and one HIP stream per worker thread) for all utils.kde stages of the process: the
+    # native estimator keeps a grow-only scratch buffer per host thread (pisa_hip_kde_release_scratch),
+    # so a pool per stage would multiply those
+    _shared_pool = None
+
     def _pool(self):
-        if getattr(self, "_executor", None) is None:
+        cls = type(self)
+        if cls._shared_pool is None:
             import threading
             from concurrent.futures import ThreadPoolExecutor
 
-            self._executor = ThreadPoolExecutor(max_workers=self.kde_workers, thread_name_prefix="kde")
-            self._tls = threading.local()
+            cls._shared_pool = (ThreadPoolExecutor(max_workers=self.kde_workers, thread_name_prefix="kde"),
+                                threading.local())
+        self._executor, self._tls = cls._shared_pool
         return self._executor
 
     def _kde_task(self, main_stream, weights, kw):
@@ -162,13 +169,27 @@ class kde(Stage):  # pylint: disable=invalid-name
         return np.mean(maps, axis=0), np.std(maps, axis=0)
 
     @staticmethod
-    def owned_containers(n_containers, rank, world_size):
+    def owned_containers(n_containers, rank, world_size, sizes=None):
         """Multi-GPU: the estimators of one evaluation are independent objects (one per container
-        and pid channel), so the CONTAINERS are dealt round-robin to the ranks -- no event ever
-        crosses a rank, bandwidths and pilot densities stay exact -- and the finished maps
-        (n_bins doubles per container) are exchanged in one all-reduce in which every entry has
-        exactly one non-zero contribution: the same bits as on one GPU."""
-        return [i for i in range(n_containers) if i % world_size == rank]
+        and pid channel), so the CONTAINERS are dealt to the ranks -- no event ever crosses a rank,
+        bandwidths and pilot densities stay exact -- and the finished maps (n_bins doubles per
+        container) are exchanged in one all-reduce in which every entry has exactly one non-zero
+        contribution: the same bits as on one GPU.
+        `sizes` (events per container): longest-processing-time assignment -- containers in order of
+        decreasing size, each to the rank with the least events so far (ties: lowest rank), the
+        estimator's cost growing with its sample; a real sample is far from balanced (nu_mu CC >>
+        nu_tau NC) and 12 containers on 8 ranks dealt round-robin leave a 2:1 imbalance even for equal
+        sizes.  Without sizes: round-robin.  Every rank computes the same assignment."""
+        if sizes is None:
+            return [i for i in range(n_containers) if i % world_size == rank]
+        assert len(sizes) == n_containers
+        load = [0] * world_size
+        owner = [0] * n_containers
+        for i in sorted(range(n_containers), key=lambda j: (-int(sizes[j]), j)):
+            r = min(range(world_size), key=lambda q: (load[q], q))
+            owner[i] = r
+            load[r] += int(sizes[i])
+        return [i for i in range(n_containers) if owner[i] == rank]
 
     @staticmethod
     def exchange_maps(local, n_containers, n_bins, with_errors, group=None):
@@ -203,7 +224,7 @@ class kde(Stage):  # pylint: disable=invalid-name
 
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         rank = dist.get_rank() if world > 1 else 0
-        owned = self.owned_containers(len(conts), rank, world)
+        owned = self.owned_containers(len(conts), rank, world, sizes=[c.size for c in conts] if world > 1 else None)
         # deferred reweighting chains are materialised on the caller's thread and stream
         inputs = {}
         for i in owned:

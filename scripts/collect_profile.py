@@ -6,7 +6,8 @@ import os
 import shutil
 import sys
 
-KEEP = ("hist_accumulate_kernel", "prob3_events_kernel", "kde_pairs_kernel", "kde_lattice_kernel")
+KEEP = ("hist_accumulate_kernel", "hist_accumulate_multi_kernel", "prob3_events_kernel", "kde_pairs_kernel",
+        "kde_lattice_kernel", "barr_fold_multi_kernel")
 
 
 def main(tag):
@@ -16,6 +17,13 @@ def main(tag):
     for name in sorted(os.listdir(src)):
         p = os.path.join(src, name)
         if not os.path.isfile(p) or name.endswith((".log", ".stderr")) and name != "c3_probe.log":
+            continue
+        if name.startswith("run_") and name.endswith(".json"):
+            # stdout of a traced run: keep the JSON line only (RCCL / tool banners precede it)
+            lines = [ln for ln in open(p).read().splitlines() if ln.startswith("{")]
+            if lines:
+                with open(os.path.join(dst, name), "w") as f:
+                    f.write(lines[-1] + "\n")
             continue
         if name.startswith("pmc_") and name.endswith(".csv"):
             rows = list(csv.reader(open(p)))

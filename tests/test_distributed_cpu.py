@@ -216,6 +216,27 @@ def _kde_exchange_worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
+def test_kde_containers_are_dealt_by_longest_processing_time():
+    """utils.kde on several ranks: containers in order of decreasing event count, each to the least
+    loaded rank -- complete, disjoint, the same on every rank, and balanced where round-robin is not"""
+    from pisa_amd.stages.utils.kde import kde as kde_stage
+
+    sizes = [900000, 40000, 30000, 850000, 20000, 10000, 870000, 35000, 25000, 860000, 15000, 5000]
+    for world in (1, 2, 3, 8, 16):
+        owned = [kde_stage.owned_containers(len(sizes), r, world, sizes=sizes) for r in range(world)]
+        assert sorted(i for o in owned for i in o) == list(range(len(sizes)))
+        loads = [sum(sizes[i] for i in o) for o in owned]
+        if world <= 4:
+            # the four large containers land on different ranks (as far as there are ranks)
+            assert max(loads) <= sum(sizes) / world + max(sizes) * (1 - 1 / world) + 1
+            assert max(loads) - min(loads) <= max(sizes)
+    rr = [sum(sizes[i] for i in kde_stage.owned_containers(12, r, 3)) for r in range(3)]
+    lpt = [sum(sizes[i] for i in kde_stage.owned_containers(12, r, 3, sizes=sizes)) for r in range(3)]
+    assert max(lpt) < max(rr)       # round-robin puts all four large containers on rank 0
+    eq = [len(kde_stage.owned_containers(12, r, 8, sizes=[1000] * 12)) for r in range(8)]
+    assert sorted(eq) == [1, 1, 1, 1, 2, 2, 2, 2]
+
+
 @pytest.mark.parametrize("world", [2, 5])
 def test_kde_stage_map_exchange_on_gloo_ranks(tmp_path, world):
     """the KDE stage's multi-GPU rule: estimators are independent, so containers are dealt to the
