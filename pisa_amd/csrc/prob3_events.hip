@@ -280,7 +280,9 @@ prob3_events_kernel(const Prob3Consts c, const EarthDev earth, const EvArgs ev, 
         if (WAVES > 2 && !DECAY) {
             TLds T{s_len + lane, bd};
             propagate_path_direct_lds(c.side[side], c.dm, vac_order, energy[i], e, g, ok, T, P, status);
-        } else if (WAVES > 2) {
+        } else if (WAVES > 2 || DECAY) {
+            // decay: the reference-order layer matrices (layer_amplitude: complex eigenvalues, three full
+            // projectors) need every register there is; the running product waits in LDS meanwhile
             TLds T{s_len + lane, bd};
             propagate_path_nested_lds<DECAY>(c.side[side], c.dm, vac_order, energy[i], nseg, mid, layer, src, T, P);
         } else {
@@ -316,7 +318,8 @@ static int launch_events(const Prob3Consts &c, const EarthDev &e, const EvCont *
     // direct form: 3 wavefronts per SIMD with the running product in LDS (see the kernel); 2: product in registers
     static const int waves_cfg = [] { const char *v = getenv("PISA_HIP_EVENTS_WAVES"); return v ? atoi(v) : 3; }();
     size_t lds = 3 * PISA_HIP_MAX_SHELLS * sizeof(double) +
-                 (staged ? (size_t)max_seg * threads * 10 : (waves_cfg > 2 ? (size_t)12 * threads * 8 : 0)) + 16;
+                 (staged ? (size_t)max_seg * threads * 10
+                         : (c.decay ? (size_t)18 * threads * 8 : (waves_cfg > 2 ? (size_t)12 * threads * 8 : 0))) + 16;
     // one launch per sign (see the kernel) and per EV_MAX_CONT containers
     for (int side = 0; side < 2; side++) {
         EvArgs a;
