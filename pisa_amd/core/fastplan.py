@@ -15,10 +15,13 @@ saw last and, per stage that moved,
   * aeff.aeff: refreshes the containers' scales through the stage's own `scale_for()`;
   * flux stages, when the flux lives on the oscillation grid (engine.node_flux): runs the moved
     stage(s) on the grid nodes and hands the new node fluxes to the engine (`hist.sync_node_flux`);
+  * ONE flux.barr_simple stage with the flux per event (example.cfg's shape): the engine's one-pass
+    refresh of the folded flux columns (`HotPathEngine.update_flux_barr`), the stage's own `nu_flux`
+    arrays being recomputed only if somebody reads them;
   * discr_sys.hypersurfaces behind the histogram: runs its `compute()` (per-bin factors on the
     host) and passes the factors to the tail kernel (`pisa_hip_finalize_metric_scaled`);
 then launches the fused kernel and hands out device-backed Maps (`DeviceMapBlock`).  Anything else
--- a loader parameter or a per-event flux moved, a Ye value moved, another output key or binning is
+-- a loader parameter or a per-event flux of another shape moved, a Ye value moved, another output key or binning is
 asked for, profiling is on, somebody wrote one of the pipeline's containers or reads `pipeline.data`
 -- goes through the ordinary Stage protocol, which stays the source of truth (the plan is rebuilt
 afterwards).  The bypassed stages' compute memos are invalidated, so the ordinary path never trusts
@@ -220,6 +223,17 @@ class FastPlan:
         # the events (stages/utils/hist.py, engine.node_flux)
         k_osc = stages.index(osc)
         self.flux_stages = [s for s in stages[:k_osc] if s.stage_name == "flux"] if self.engine.node_flux else []
+        # flux held per event and ONE flux.barr_simple stage in an event representation in front of the
+        # oscillation (example.cfg's shape): a moved Barr parameter is replayed as the engine's one-pass
+        # refresh of the folded flux columns (`update_flux_barr`: nominal fluxes and parameter-free factors
+        # in resident order -> folded column, the bits of the stage's launch + the hist stage's fold)
+        self.barr_stage, self._barr_ready = None, False
+        if not self.engine.node_flux:
+            fl = [s for s in stages[:k_osc] if s.stage_name == "flux"]
+            if (len(fl) == 1 and fl[0].service_name == "barr_simple" and fl[0].calc_mode == "events"
+                    and all(w is not None for w in self.engine._wflux)
+                    and not bool(int(os.environ.get("PISA_PLAN_NO_BARR", "0")))):
+                self.barr_stage = fl[0]
         # one flat list of (param, index of its stage); a parameter shared by stages appears once
         # per stage, so every stage that uses it is seen to change
         self.flat = [(p, k) for k, s in enumerate(stages) for p in s.params]
@@ -266,6 +280,33 @@ class FastPlan:
                 if stages[k] not in out:
                     out.append(stages[k])
         return out
+
+    def _replay_barr(self):
+        """the moved flux.barr_simple parameters -> the engine's folded flux columns, one pass"""
+        st, eng = self.barr_stage, self.engine
+        if not self._barr_ready:
+            cols = []
+            keep = [c.representation for c in self._conts]
+            try:
+                for c in self._conts:
+                    c.representation = "events"
+                    cols.append((c.device("true_energy"), c.device("true_coszen"), c.device("nu_flux_nominal"),
+                                 c.device("nubar_flux_nominal")))
+            finally:
+                for c, r in zip(self._conts, keep):
+                    c.representation = r
+            try:
+                eng.enable_barr(cols)
+            except ValueError:          # an energy that is not positive: the stages keep the reference's answers
+                self.barr_stage = None
+                return False
+            self._barr_ready = True
+        p = st.params
+        vals = [float(p[n].value.m_as("dimensionless")) for n in
+                ("nue_numu_ratio", "nu_nubar_ratio", "delta_index", "Barr_uphor_ratio", "Barr_nu_nubar_ratio")]
+        eng.update_flux_barr(*vals)
+        st.param_hash = None      # its own nu_flux arrays are those of older values: recomputed if anybody asks
+        return True
 
     def invalidate(self):
         """forget the compute memos of every stage this plan replays (the plan is being dropped after
@@ -347,7 +388,7 @@ class FastPlan:
                 # say, the oscillation tables and the containers' scales are those of an older point
                 changed = list(changed) + [s for s in (osc, self.aeff) if all(s is not c for c in changed)]
                 self._dirty = False
-            replayable = [osc, self.aeff] + self.flux_stages + self.post
+            replayable = [osc, self.aeff] + self.flux_stages + self.post + ([self.barr_stage] if self.barr_stage else [])
             for s in changed:
                 if all(s is not r for r in replayable):
                     return _no("stage %s.%s moved" % (s.stage_name, s.service_name))
@@ -358,6 +399,9 @@ class FastPlan:
                       p.YeM.value.m_as("dimensionless"))
                 if ye != self.ye:
                     return _no("Ye moved")          # new layers, new plan: ordinary path
+            if self.barr_stage is not None and any(self.barr_stage is c for c in changed):
+                if not self._replay_barr():
+                    return _no("per-event flux refresh not available")
             flux_changed = [s for s in self.flux_stages if any(s is c for c in changed)]
             if flux_changed:
                 # the stages' own compute on the grid nodes, in pipeline order from the first one

@@ -386,7 +386,7 @@ def test_bench_multi_rank_code_path_on_one_rank():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
            "--gpus", "1", "--force-dist", "--events", "1.2e6", "--steps", "40", "--warmup", "5",
-           "--no-cpu-baseline", "--no-drop-probe"]
+           "--no-cpu-baseline", "--no-drop-probe", "--legs", "multi_point,fit_c4_engine,l3_exceeding"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
@@ -395,7 +395,10 @@ def test_bench_multi_rank_code_path_on_one_rank():
     assert line["value"] == line["strong_value"] and line["weak_value"] > 0
     assert line["weak"]["samples_per_step"] == 1 and line["allreduce_ms"] > 0
     assert line["nccl_comm_count"] == 1      # ncclCommCount of the direct communicator
-    assert line["legs"] == {} and np.isfinite(line["last_llh"])
+    # the legs that run on several ranks do, through the all-reduce of K limb sets (the others are N = 1 only)
+    assert set(line["legs"]) == {"multi_point", "fit_c4_engine"} and np.isfinite(line["last_llh"])
+    assert all(line["legs"]["multi_point"]["K%d" % k]["same_bits_as_point_by_point"] for k in (3, 5, 9))
+    assert line["legs"]["fit_c4_engine"]["same_history"]
 
 
 def _two_rank_worker(rank, world, port, out_dir):

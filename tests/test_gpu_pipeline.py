@@ -223,8 +223,9 @@ def _scan(pipe, fast, data, points):
 def test_fast_plan_replays_the_stage_protocol_bit_for_bit():
     """`Pipeline.get_outputs()` after the first fused evaluation replays three kernel launches
     (core/fastplan.py) instead of running every stage over every container.  Same maps, errors
-    and metrics, bit for bit, as the ordinary Stage protocol -- for osc and aeff parameter moves
-    (replayed) and for flux parameter moves (which fall back to the stages)."""
+    and metrics, bit for bit, as the ordinary Stage protocol -- for osc and aeff parameter moves and for
+    moves of a flux.barr_simple parameter with the flux per event (replayed as the engine's one-pass
+    refresh of the folded flux columns)."""
     from pisa_amd.core.pipeline import Pipeline
 
     pipe = Pipeline("settings/pipeline/example_hip.cfg")
@@ -235,6 +236,7 @@ def test_fast_plan_replays_the_stage_protocol_bit_for_bit():
     slow = _scan(pipe, False, data, points)
     fast = _scan(pipe, True, data, points)
     assert pipe._plan is not None, "the plan must have been built and kept"
+    assert pipe._plan._barr_ready, "the flux moves must have been replayed, not sent through the stages"
     for (l0, c0, h0, e0), (l1, c1, h1, e1) in zip(slow, fast):
         assert l0 == l1 and c0 == c1
         for a, b in zip(h0 + e0, h1 + e1):
@@ -257,6 +259,20 @@ def test_fast_plan_replays_the_stage_protocol_bit_for_bit():
     bad._hist[0, 0, 0] = -1.0
     with pytest.raises(ValueError):
         bad.metric_total(expected_values=sum(pipe.get_outputs()), metric="llh")
+    # a replayed flux move and the containers: a reader sees the flux of the CURRENT parameters (the
+    # bypassed stage recomputes on demand)
+    pipe.params.delta_index.value = -0.03 * ureg.dimensionless
+    pipe.get_outputs()
+    ref = Pipeline("settings/pipeline/example_hip.cfg")
+    ref.fast_path = False
+    for name in ("theta23", "deltam31", "aeff_scale", "delta_index"):
+        ref.params[name].value = pipe.params[name].value
+    want = ref.get_outputs()
+    a, b = pipe.data["numu_cc"], ref.data["numu_cc"]
+    a.representation = b.representation = "events"
+    np.testing.assert_array_equal(a["nu_flux"], b["nu_flux"])
+    for m, w in zip(pipe.get_outputs(), want):
+        np.testing.assert_array_equal(m.hist, w.hist)
 
 
 def test_fast_plan_outputs_survive_the_next_evaluation_and_containers_stay_truthful():
