@@ -509,6 +509,25 @@ def leg_pipeline_boundary(torch, n_events, steps):
         llh = one(pt)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    # the same with a flux.barr_simple parameter (flux per event in this cfg) moving every step as well:
+    # replayed as the engine's one-pass refresh of the folded flux columns
+    rsf = np.random.RandomState(3)
+
+    def one_flux(pt):
+        pipe.params.delta_index.value = 0.1 * (rsf.rand() - 0.5) * ureg.dimensionless
+        return one(pt)
+
+    for pt in pts[:5]:
+        one_flux(pt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_flux = max(20, steps // 4)
+    for pt in pts[10:10 + n_flux]:
+        one_flux(pt)
+    torch.cuda.synchronize()
+    dt_flux = (time.perf_counter() - t0) / n_flux
+    flux_replayed = bool(pipe._plan is not None and getattr(pipe._plan, "_barr_ready", False))
+    pipe.params.delta_index.value = 0.0 * ureg.dimensionless
     pipe.fast_path = False
     pipe._plan = None
     for pt in pts[:3]:
@@ -544,6 +563,7 @@ def leg_pipeline_boundary(torch, n_events, steps):
     return {"evals_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "last_llh": llh,
             "engine_same_workload_evals_per_s": 1.0 / dt_eng, "boundary_over_engine": dt / dt_eng,
             "stage_protocol_every_step_evals_per_s": 1.0 / dt_slow,
+            "flux_per_event_moves_evals_per_s": 1.0 / dt_flux, "flux_per_event_moves_replayed": flux_replayed,
             "workload": "settings/pipeline/example_hip.cfg (cfg text): %d events, prob3 on the %s calc grid, "
                         "aeff, hist into %s with sumw2; theta23/dm31 set through pipeline.params every step, "
                         "Pipeline.get_outputs() + Map.metric_total('llh') read back every step"

@@ -26,7 +26,7 @@ import torch
 from pisa_amd import kernels as K
 from pisa_amd.core.binning import MultiDimBinning
 
-__all__ = ["gaussian_kde", "get_hist", "kde_histogramdd", "pid_channels"]
+__all__ = ["gaussian_kde", "bootstrap_kde", "get_hist", "kde_histogramdd", "pid_channels"]
 
 
 class gaussian_kde:  # pylint: disable=invalid-name
@@ -70,6 +70,41 @@ class gaussian_kde:  # pylint: disable=invalid-name
     pairs = property(lambda self: (self._est.pairs_pilot, self._est.pairs_eval))
 
 
+class bootstrap_kde:  # pylint: disable=invalid-name
+    """Call contract of `kde.bootstrap_kde` as `get_hist(bootstrap=True)` uses it (kde_hist.py:108-109,
+    155-158): `k = bootstrap_kde(x[D,N], niter=, weights=, bw_method=, adaptive=, alpha=)`;
+    `mean, errors = k(points)`.  The package is not part of the reference tree (PARITY UNPINNED); this
+    build's form: `niter` estimators, each built on the sample resampled with replacement -- expressed as
+    multiplicities on the weights (`numpy.random.default_rng(seed).integers` / `bincount`, the draws of the
+    KDE stage's own bootstrap, stages/utils/kde.py:197-238) -- evaluated at the points; mean and standard
+    deviation (ddof = 0) over the iterations.  The reference's KDE stage does not call this path (its call
+    is commented out, utils/kde.py:195-196); the stage-level bootstrap is the one pipelines use."""
+
+    def __init__(self, dataset, niter=10, weights=None, bw_method="silverman", adaptive=True, alpha=0.3,
+                 use_cuda=False, tol=None, seed=0):  # pylint: disable=unused-argument
+        x = dataset if torch.is_tensor(dataset) else K.to_device(np.atleast_2d(dataset))
+        n = x.shape[1]
+        w = None
+        if weights is not None and len(weights) != 0:
+            w = weights if torch.is_tensor(weights) else K.to_device(np.asarray(weights))
+        rng = np.random.default_rng(seed)
+        self.kernels = []
+        for _ in range(int(niter)):
+            draws = K.to_device(np.bincount(rng.integers(n, size=n), minlength=n).astype(np.float64))
+            self.kernels.append(gaussian_kde(x, weights=draws if w is None else w * draws, bw_method=bw_method,
+                                             adaptive=adaptive, alpha=alpha, tol=tol))
+
+    def _stats(self, values):
+        stack = torch.stack(values)
+        return stack.mean(dim=0), stack.std(dim=0, unbiased=False)
+
+    def __call__(self, points):
+        return self._stats([k(points) for k in self.kernels])
+
+    def evaluate_grid(self, axes):
+        return self._stats([k.evaluate_grid(axes) for k in self.kernels])
+
+
 _GRIDS = {}
 
 
@@ -111,11 +146,9 @@ def get_hist(sample, binning, weights=None, bw_method="scott", adaptive=True, al
              use_cuda=False, coszen_reflection=0.25, coszen_name="coszen", oversample=1,
              bootstrap=False, bootstrap_niter=10, tol=None, stats=None):
     """kde_hist.py:35-217.  `sample` [N, D] host array or device tensor; `weights` [N] likewise."""
-    if bootstrap:
-        # kde_hist.py:108-109 delegates to the external package's `bootstrap_kde`; the KDE
-        # *stage*'s own bootstrap (stages/utils/kde.py:189-258) is what this build provides
-        raise NotImplementedError("get_hist(bootstrap=True) needs the external kde.bootstrap_kde; "
-                                  "use the utils.kde stage's bootstrap option")
+    if bootstrap and oversample > 1:
+        # errors within a bin are highly correlated (kde_hist.py:67-70)
+        raise ValueError("Bootstrapping cannot be combined with oversampling.")
     on_dev = torch.is_tensor(sample)
     if weights is None or len(weights) == 0:
         weights_d, norm = None, sample.shape[0]
@@ -128,30 +161,48 @@ def get_hist(sample, binning, weights=None, bw_method="scott", adaptive=True, al
     cz_bin, l = g["cz_bin"], g["l"]
     if cz_bin != 0:
         x[[0, cz_bin]] = x[[cz_bin, 0]]
-    kernel = gaussian_kde(x.contiguous(), weights=weights_d, bw_method=bw_method, adaptive=adaptive,
-                          alpha=alpha, tol=tol)
-    hist = kernel.evaluate_grid(g["bin_points"]).cpu().numpy().reshape(g["megashape"])
+    variances = None
+    if bootstrap:
+        kernel = bootstrap_kde(x.contiguous(), niter=bootstrap_niter, weights=weights_d, bw_method=bw_method,
+                               adaptive=adaptive, alpha=alpha, tol=tol)
+        mean_d, err_d = kernel.evaluate_grid(g["bin_points"])
+        hist = mean_d.cpu().numpy().reshape(g["megashape"])
+        variances = (err_d.cpu().numpy() ** 2).reshape(g["megashape"])   # variances add under the reflection
+        kernel = kernel.kernels[0]
+    else:
+        kernel = gaussian_kde(x.contiguous(), weights=weights_d, bw_method=bw_method, adaptive=adaptive,
+                              alpha=alpha, tol=tol)
+        hist = kernel.evaluate_grid(g["bin_points"]).cpu().numpy().reshape(g["megashape"])
     if stats is not None:
         stats["pairs_pilot"] = stats.get("pairs_pilot", 0) + kernel.pairs[0]
         stats["pairs_eval"] = stats.get("pairs_eval", 0) + kernel.pairs[1]
         stats["all_pairs"] = stats.get("all_pairs", 0) + kernel.n * (kernel.n * bool(adaptive) + g["n_points"])
-    if g["reflect_lower"]:
-        hist0 = np.flipud(np.concatenate([np.zeros(g["minishape"]), hist[0:l, :]]))
-        hist = hist[l:, :]
-    else:
-        hist0 = 0
-    if g["reflect_upper"]:
-        hist1 = np.flipud(np.concatenate([hist[-l:, :], np.zeros(g["minishape"])]))
-        hist = hist[:-l, :]
-    else:
-        hist1 = 0
-    hist = hist + hist1 + hist0
-    hist = hist * g["volumes"]
+    def reflect(h):   # kde_hist.py:168-190
+        if g["reflect_lower"]:
+            h0 = np.flipud(np.concatenate([np.zeros(g["minishape"]), h[0:l, :]]))
+            h = h[l:, :]
+        else:
+            h0 = 0
+        if g["reflect_upper"]:
+            h1 = np.flipud(np.concatenate([h[-l:, :], np.zeros(g["minishape"])]))
+            h = h[:-l, :]
+        else:
+            h1 = 0
+        return h + h1 + h0
+
+    hist = reflect(hist) * g["volumes"]
+    errors = None
+    if variances is not None:
+        errors = np.sqrt(reflect(variances)) * g["volumes"]
     if oversample != 1:
         for i, at in enumerate(g["reduce_at"]):
             hist = np.add.reduceat(hist, at, axis=i)
     if cz_bin != 0:
         hist = np.swapaxes(hist, 0, cz_bin)
+        if errors is not None:
+            errors = np.swapaxes(errors, 0, cz_bin)
+    if errors is not None:
+        return hist * norm, errors * norm
     return hist * norm
 
 
@@ -194,11 +245,19 @@ def kde_histogramdd(sample, binning, weights=None, bw_method="scott", adaptive=T
     w_d = None
     if weights is not None:
         w_d = weights if torch.is_tensor(weights) else K.to_device(np.asarray(weights))
-    stack = []
+    stack, err_stack = [], []
     for idx, data in chans:
         w = None if w_d is None else w_d[idx]
-        stack.append(get_hist(sample=data, weights=w, binning=d2d, **kw))
+        res = get_hist(sample=data, weights=w, binning=d2d, **kw)
+        if bootstrap:
+            stack.append(res[0])
+            err_stack.append(res[1])
+        else:
+            stack.append(res)
     hist = np.dstack(stack)
+    errors = np.dstack(err_stack) if bootstrap else None
     if pid_bin != 2:
         hist = np.swapaxes(hist, pid_bin, 2)
-    return hist
+        if errors is not None:
+            errors = np.swapaxes(errors, pid_bin, 2)
+    return (hist, errors) if bootstrap else hist

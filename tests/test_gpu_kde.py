@@ -341,3 +341,39 @@ def test_kde_stage_concurrent_estimators_are_bit_identical_to_sequential():
         for a, b in zip(runs[0], other):
             np.testing.assert_array_equal(a, b)
     assert sum(m.sum() for m in runs[0]) > 0
+
+
+def test_get_hist_bootstrap_through_bootstrap_kde():
+    """`get_hist(bootstrap=True)` / `kde_histogramdd(bootstrap=True)` (kde_hist.py:108-109, 155-217: the
+    external package's `bootstrap_kde`; parity unpinned, this build's form documented at the class):
+    mean map close to the plain KDE map, errors positive and of the bootstrap's size, reproducible,
+    oversampling refused, pid stacking handled"""
+    from pisa_amd.core.binning import MultiDimBinning, OneDimBinning
+    from pisa_amd.utils import kde_hist
+
+    rs = np.random.RandomState(3)
+    n = 20000
+    cz = rs.rand(n) * 2 - 1
+    e = rs.randn(n) * 0.5 + 2.0
+    pid = (rs.rand(n) < 0.4).astype(float)
+    b2 = MultiDimBinning([OneDimBinning("coszen", domain=[-1, 1], num_bins=10, is_lin=True),
+                          OneDimBinning("energy", domain=[0.5, 3.5], num_bins=8, is_lin=True)])
+    w = rs.rand(n) + 0.5
+    kw = dict(binning=b2, weights=w, bw_method="silverman", coszen_name="coszen", oversample=1, alpha=0.1)
+    plain = kde_hist.get_hist(np.stack([cz, e], axis=1), **kw)
+    mean, err = kde_hist.get_hist(np.stack([cz, e], axis=1), bootstrap=True, bootstrap_niter=8, **kw)
+    mean2, err2 = kde_hist.get_hist(np.stack([cz, e], axis=1), bootstrap=True, bootstrap_niter=8, **kw)
+    np.testing.assert_array_equal(mean, mean2)
+    np.testing.assert_array_equal(err, err2)
+    assert mean.shape == plain.shape == err.shape
+    assert np.all(err > 0) and np.all(err < 0.2 * mean.max())
+    assert np.abs(mean - plain).max() < 5 * err.max()
+    np.testing.assert_allclose(mean.sum(), plain.sum(), rtol=2e-2)
+    with pytest.raises(ValueError):
+        kde_hist.get_hist(np.stack([cz, e], axis=1), bootstrap=True, **dict(kw, oversample=2))
+    b3 = MultiDimBinning(list(b2) + [OneDimBinning("pid", bin_edges=[-0.5, 0.5, 1.5])])
+    h3, e3 = kde_hist.kde_histogramdd(np.stack([cz, e, pid], axis=1), b3, weights=w, bw_method="silverman",
+                                      coszen_name="coszen", oversample=1, alpha=0.1, stack_pid=True,
+                                      bootstrap=True, bootstrap_niter=4)
+    assert h3.shape == (10, 8, 2) == e3.shape and np.all(e3 > 0)
+    np.testing.assert_allclose(h3.sum(), w.sum() * plain.sum() / w.sum(), rtol=5e-2)
