@@ -745,56 +745,68 @@ def leg_fit_engine(torch, st, wl, sync, reduce_max):
     to [0, 1], -LLH against the headline pseudo-data, several starting points until >= 50 evaluations.
     `point_by_point`: scipy takes its forward differences through `eval_host`; `stencil_in_one_sweep`:
     value and gradient from one `eval_many` of the same n + 1 points (Analysis._forward_stencil).  Same
-    trajectory, point for point."""
+    trajectory, point for point.  `four_free` repeats it with theta13 and deltacp free as well (stencils
+    of five points)."""
     import numpy as np
     from scipy import optimize
 
     from pisa_amd.analysis.analysis import Analysis
 
-    lo, hi = np.array([31.0, 1e-3]), np.array([59.0, 7e-3])
-    bounds = [(0.0, 1.0), (0.0, 1.0)]
     opts = dict(ftol=2e-5, gtol=1e-5, eps=1e-4, maxiter=200)
+    names = ("theta23_deg", "dm31", "theta13_deg", "deltacp_deg")
+    lo_all, hi_all = np.array([31.0, 1e-3, 7.0, 0.0]), np.array([59.0, 7e-3, 10.0, 360.0])
+    starts_all = [(0.40, 0.24, 0.5, 0.1), (0.25, 0.20, 0.4, 0.3), (0.71, 0.30, 0.6, 0.2), (0.46, 0.33, 0.45, 0.5),
+                  (0.64, 0.22, 0.55, 0.4), (0.32, 0.28, 0.5, 0.6)]
 
-    def point(x):
-        v = lo + (hi - lo) * np.clip(x, 0.0, 1.0)
-        return wl.osc_params(theta23_deg=float(v[0]), dm31=float(v[1]))
+    def run(n_free):
+        lo, hi = lo_all[:n_free], hi_all[:n_free]
+        bounds = [(0.0, 1.0)] * n_free
 
-    trace = {}
+        def point(x):
+            v = lo + (hi - lo) * np.clip(x, 0.0, 1.0)
+            return wl.osc_params(**{k: float(a) for k, a in zip(names, v)})
 
-    def serial(x):
-        f = -st.eval_host(point(x), "llh")
-        trace["pts"].append((tuple(x), f))
-        return f
+        trace = {}
 
-    def swept(x):
-        pts, dx = Analysis._forward_stencil(x, opts["eps"], np.zeros(2), np.ones(2))
-        f = [-v for v in st.eval_many([point(q) for q in pts], "llh")]
-        trace["pts"] += [(tuple(q), v) for q, v in zip(pts, f)]
-        return f[0], (np.array(f[1:]) - f[0]) / dx
+        def serial(x):
+            f = -st.eval_host(point(x), "llh")
+            trace["pts"].append((tuple(x), f))
+            return f
 
-    starts = [(0.40, 0.24), (0.25, 0.20), (0.71, 0.30), (0.46, 0.33), (0.64, 0.22), (0.32, 0.28)]
-    out, traces = {}, {}
-    for key, fun, jac in (("point_by_point", serial, None), ("stencil_in_one_sweep", swept, True)):
-        for _ in range(2):
-            trace["pts"] = []
-            evals, fits = 0, []
-            sync()
-            t0 = time.perf_counter()
-            for x0 in starts:
-                res = optimize.minimize(fun, np.array(x0), jac=jac, bounds=bounds, method="L-BFGS-B", options=opts)
-                evals = len(trace["pts"])
-                fits.append((float(res.fun), [float(v) for v in lo + (hi - lo) * res.x]))
-                if evals >= 50 and len(fits) >= 2:
-                    break
-            sync()
-            dt = reduce_max(time.perf_counter() - t0)
-        traces[key] = list(trace["pts"])
-        out[key] = {"wall_s": dt, "llh_evaluations": evals, "fits": len(fits), "evals_per_s": evals / dt,
-                    "best_fit": {"neg_llh": fits[0][0], "theta23_deg": fits[0][1][0], "deltam31_eV2": fits[0][1][1]}}
-    out["same_history"] = bool(traces["point_by_point"] == traces["stencil_in_one_sweep"])
-    out["speedup"] = out["point_by_point"]["wall_s"] / out["stencil_in_one_sweep"]["wall_s"]
-    out["workload"] = ("scipy L-BFGS-B (eps 1e-4) on HotPathEngine directly: free theta23, deltam31; the headline "
-                       "workload (%d events, 200x100 grid, 8x8x2 bins), -llh against its pseudo-data" % wl.n_events)
+        def swept(x):
+            pts, dx = Analysis._forward_stencil(x, opts["eps"], np.zeros(n_free), np.ones(n_free))
+            f = [-v for v in st.eval_many([point(q) for q in pts], "llh")]
+            trace["pts"] += [(tuple(q), v) for q, v in zip(pts, f)]
+            return f[0], (np.array(f[1:]) - f[0]) / dx
+
+        out, traces = {}, {}
+        for key, fun, jac in (("point_by_point", serial, None), ("stencil_in_one_sweep", swept, True)):
+            for _ in range(2):
+                trace["pts"] = []
+                evals, fits = 0, []
+                sync()
+                t0 = time.perf_counter()
+                for x0 in starts_all:
+                    res = optimize.minimize(fun, np.array(x0[:n_free]), jac=jac, bounds=bounds, method="L-BFGS-B",
+                                            options=opts)
+                    evals = len(trace["pts"])
+                    fits.append((float(res.fun), [float(v) for v in lo + (hi - lo) * res.x]))
+                    if evals >= 50 and len(fits) >= 2:
+                        break
+                sync()
+                dt = reduce_max(time.perf_counter() - t0)
+            traces[key] = list(trace["pts"])
+            out[key] = {"wall_s": dt, "llh_evaluations": evals, "fits": len(fits), "evals_per_s": evals / dt,
+                        "best_fit": dict(zip(("neg_llh",) + names[:n_free], [fits[0][0]] + fits[0][1]))}
+        out["same_history"] = bool(traces["point_by_point"] == traces["stencil_in_one_sweep"])
+        out["speedup"] = out["point_by_point"]["wall_s"] / out["stencil_in_one_sweep"]["wall_s"]
+        return out
+
+    out = run(2)
+    out["four_free"] = run(4)
+    out["workload"] = ("scipy L-BFGS-B (eps 1e-4) on HotPathEngine directly: free theta23, deltam31 (four_free: + "
+                       "theta13, deltacp); the headline workload (%d events, 200x100 grid, 8x8x2 bins), -llh against "
+                       "its pseudo-data" % wl.n_events)
     st.check_status()
     return out
 

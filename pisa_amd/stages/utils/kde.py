@@ -112,7 +112,7 @@ class kde(Stage):  # pylint: disable=invalid-name
     #    bandwidth range): `kde_workers` host threads, each with its own HIP stream, keep the GPU
     #    busy during the round trips of the others.  Every estimator is deterministic by itself, so
     #    the maps do not depend on the interleaving.
-    kde_workers = int(os.environ.get("PISA_KDE_WORKERS", "4"))
+    kde_workers = int(os.environ.get("PISA_KDE_WORKERS", "6"))   # 1 / 2 / 4 / 6 / 8: 43 / 31 / 27 / 25 / 27 ms per C3 evaluation
 
     # ONE executor (and one HIP stream per worker thread) for all utils.kde stages of the process: the
     # native estimator keeps a grow-only scratch buffer per host thread (pisa_hip_kde_release_scratch),
