@@ -42,7 +42,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 L3_BYTES = 256 * 2 ** 20
-ALL_LEGS = ("multi_point", "fit_c4_engine", "fit_c4", "l3_exceeding", "exact_association", "coordinate_form", "fine_binning",
+ALL_LEGS = ("multi_point", "fit_c4_engine", "fit_c4", "osc_example_c1", "l3_exceeding", "exact_association", "coordinate_form", "fine_binning",
             "update_flux", "node_flux", "pipeline_boundary", "icecube3y_boundary", "events_c2", "events_c5", "kde_c3")
 # the legs that also run with N > 1 (every rank takes part: configs C4 and C5, the multi-point sweep)
 DIST_LEGS = ("multi_point", "fit_c4_engine", "fit_c4", "events_c5")
@@ -875,6 +875,44 @@ def leg_fit_c4(torch, n_events, dist_on, sync, reduce_max):
     return out
 
 
+def leg_osc_example(torch, steps):
+    """BASELINE config C1: the unmodified `settings/pipeline/osc_example.cfg` (toy generator on the calc
+    grid -> flux.barr_simple -> osc.prob3, 200 x 200 (E, coszen) PREM-12 grid, 12 output maps = the README's
+    oscillograms), `Pipeline.get_outputs()` with theta23 changed every step, maps read on the host.  The one
+    number the reference publishes for this path is osc.prob3's compute on this grid: mean 0.887 s per call,
+    ~11 us per node, unstated CPU, one thread."""
+    from pisa_amd.core.pipeline import Pipeline
+    from pisa_amd.core.units import ureg
+
+    pipe = Pipeline("settings/pipeline/osc_example.cfg")
+    pipe.get_outputs()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    total = 0.0
+    for i in range(steps):
+        pipe.params.theta23.value = (40.0 + 0.05 * i) * ureg.degree
+        maps = pipe.get_outputs()
+        total += float(maps[1].hist[0, 0])     # the maps are on the host
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    osc = pipe["prob3"]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(50):
+        pipe.params.theta23.value = (41.0 + 0.05 * i) * ureg.degree
+        osc.compute()
+    e1.record()
+    torch.cuda.synchronize()
+    t_osc = e0.elapsed_time(e1) / 50 * 1e-3
+    n_nodes = 2 * int(osc.calc_mode.size)
+    return {"evals_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "maps": len(maps), "map_shape": list(maps[0].hist.shape),
+            "prob3_compute_ms": t_osc * 1e3, "prob3_nodes_per_s": n_nodes / t_osc, "prob3_us_per_node": t_osc / n_nodes * 1e6,
+            "reference_published": {"prob3_compute_s": 0.887, "us_per_node": 11.0, "hardware": "unstated CPU, 1 thread",
+                                    "source": "pisa_examples/IceCube_3y_oscillations_example.ipynb:987 (BASELINE.md)"},
+            "workload": "settings/pipeline/osc_example.cfg (unmodified text): prob3 on the 200x200 calc grid for nu and "
+                        "nubar (%d nodes), 12 oscillogram maps brought to the host every step" % n_nodes}
+
+
 def leg_kde(torch, n_events, steps):
     """config C3: the event pipeline with the KDE stage ON (reference defaults: adaptive Silverman
     bandwidths, oversample 10, coszen reflection, pid stacking)"""
@@ -1105,6 +1143,8 @@ def main(argv=None, hooks=None):
                 legs[name] = leg_fit_engine(torch, st, wl, barrier, max_over_ranks)
             elif name == "fit_c4":
                 legs[name] = leg_fit_c4(torch, args.events, dist_on, barrier, max_over_ranks)
+            elif name == "osc_example_c1":
+                legs[name] = leg_osc_example(torch, leg_steps)
             elif name == "l3_exceeding":
                 legs[name] = hbm_leg(synthetic, lib, torch, 4 * args.events, n_e, n_cz, args.binning, leg_steps // 2)
             elif name == "exact_association":
