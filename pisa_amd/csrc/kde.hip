@@ -516,173 +516,300 @@ struct KdeLattice {
     double da;         // y_a step of index 0 (> 0)
     double sa, db;     // (y_a, y_b) step of index 1
     int32_t n0, n1, strips_a;   // strips_a = ceil(n0 / R)
+    int32_t sw, lpw, n_colblk;  // a wavefront's patch: sw strips of lpw = 64 / sw consecutive lines; column blocks per line
 };
 
-// exp(t), |t| <~ 700
-__device__ inline double exp_any(double t) {
-    t = fmin(fmax(t, -800.0), 700.0);
+// up = h exp(t), dn = h exp(-t), |t| <= 700: one range reduction and the even / odd halves of the same
+// degree-13 polynomial serve both (exp(+-r) = C(r^2) +- r S(r^2))
+__device__ inline void exp_pair(double t, double h, double &up, double &dn) {
+    t = fmin(fmax(t, -700.0), 700.0);
     const double k = __builtin_rint(t * 1.4426950408889634074);
     double r = __builtin_fma(k, -6.93147180369123816490e-01, t);
     r = __builtin_fma(k, -1.90821492927058770002e-10, r);
-    double p = 1.6059043836821613e-10;
-    p = __builtin_fma(p, r, 2.08767569878680989792e-09);
-    p = __builtin_fma(p, r, 2.50521083854417187751e-08);
-    p = __builtin_fma(p, r, 2.75573192239858906526e-07);
-    p = __builtin_fma(p, r, 2.75573192239858906526e-06);
-    p = __builtin_fma(p, r, 2.48015873015873015873e-05);
-    p = __builtin_fma(p, r, 1.98412698412698412698e-04);
-    p = __builtin_fma(p, r, 1.38888888888888888889e-03);
-    p = __builtin_fma(p, r, 8.33333333333333333333e-03);
-    p = __builtin_fma(p, r, 4.16666666666666666667e-02);
-    p = __builtin_fma(p, r, 1.66666666666666666667e-01);
-    p = __builtin_fma(p, r, 0.5);
-    p = __builtin_fma(p, r, 1.0);
-    p = __builtin_fma(p, r, 1.0);
-    return __builtin_ldexp(p, (int)k);
+    const double r2 = r * r;
+    double ce = 2.08767569878680989792e-09;                     // 1/12!
+    double co = 1.6059043836821613e-10;                         // 1/13!
+    ce = __builtin_fma(ce, r2, 2.75573192239858906526e-07);     // 1/10!
+    co = __builtin_fma(co, r2, 2.50521083854417187751e-08);     // 1/11!
+    ce = __builtin_fma(ce, r2, 2.48015873015873015873e-05);     // 1/8!
+    co = __builtin_fma(co, r2, 2.75573192239858906526e-06);     // 1/9!
+    ce = __builtin_fma(ce, r2, 1.38888888888888888889e-03);     // 1/6!
+    co = __builtin_fma(co, r2, 1.98412698412698412698e-04);     // 1/7!
+    ce = __builtin_fma(ce, r2, 4.16666666666666666667e-02);     // 1/4!
+    co = __builtin_fma(co, r2, 8.33333333333333333333e-03);     // 1/5!
+    ce = __builtin_fma(ce, r2, 0.5);
+    co = __builtin_fma(co, r2, 1.66666666666666666667e-01);     // 1/3!
+    ce = __builtin_fma(ce, r2, 1.0);
+    co = __builtin_fma(co, r2, 1.0);
+    const double so = r * co;
+    const int ki = (int)k;
+    up = __builtin_ldexp(ce + so, ki) * h;
+    dn = __builtin_ldexp(ce - so, -ki) * h;
 }
 
-constexpr int LAT_REC = 6;   // doubles per source record: y_a, y_b, coef, -s2/2, q, -s2 da
+// Source record (192 B, read with scalar loads): [0] y_a  [1] y_b  [2] coef  [3] -s2 / 2  [4] -s2 da
+// [5] h = exp(-s2 da^2 / 2)  [8 + k - 2] Q_k = exp(-s2 da^2 k (k - 1) / 2), k = 2 .. 16.
+// With the strip's middle value g_c and the ratios r_up = g_{c+1} / g_c, r_dn = g_{c-1} / g_c the
+// values along the line are  g_{c +- k} = g_c r^k Q_k : one multiplication (p <- p r) and one
+// multiply-add (acc += p Q_k, Q_k a scalar operand) per point.
+constexpr int LAT_REC = 24;
+constexpr int LAT_Q0 = 8;
+constexpr int LAT_QMAX = 16;
 constexpr int LAT_SHARE = 64;   // sources per share
 __global__ void __launch_bounds__(256)
 kde_lattice_prep_kernel(const double *__restrict__ ys, const double *__restrict__ coef,
                         const double *__restrict__ s2, int64_t n, double da, double *__restrict__ rec) {
-    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one record entry per thread: coalesced stores
+    const int64_t k = e / LAT_REC;
     if (k >= n) return;
+    const int slot = (int)(e - k * LAT_REC);
     const double v = s2[k];
-    double *r = rec + k * LAT_REC;
-    r[0] = ys[k];
-    r[1] = ys[n + k];
-    r[2] = coef[k];
-    r[3] = -0.5 * v;
-    r[4] = exp_nonpos(-v * da * da);
-    r[5] = -v * da;
+    double out = 0.0;
+    if (slot == 0) out = ys[k];
+    else if (slot == 1) out = ys[n + k];
+    else if (slot == 2) out = coef[k];
+    else if (slot == 3) out = -0.5 * v;
+    else if (slot == 4) out = -v * da;
+    else if (slot == 5) out = exp_nonpos(-0.5 * v * da * da);
+    else if (slot >= LAT_Q0 && slot <= LAT_Q0 + LAT_QMAX - 2) {
+        const int kk = slot - LAT_Q0 + 2;
+        out = exp_nonpos(-v * da * da * (double)(kk * (kk - 1) / 2));
+    }
+    rec[e] = out;
 }
 
-// per share of the sorted sources: the y_b interval outside which no lattice line is within the
-// cut-off of any of its sources (sources are sorted by cell row, so a share is a narrow band)
+// per share of the sorted sources: the (y_a, y_b) box outside which no lattice point is within the
+// cut-off of any of its sources (sources are sorted by cell row, then cell column: a share is compact)
 __global__ void __launch_bounds__(64)
-kde_lattice_band_kernel(const double *__restrict__ rec, int64_t n_src, int64_t share, double rcut2,
-                        double *__restrict__ band) {
+kde_lattice_box_kernel(const double *__restrict__ rec, int64_t n_src, int64_t share, double rcut2,
+                       double *__restrict__ box) {
     const int64_t k0 = (int64_t)blockIdx.x * share;
     const int64_t k1 = k0 + share < n_src ? k0 + share : n_src;
-    double lo = INFINITY, hi = -INFINITY;
+    double alo = INFINITY, ahi = -INFINITY, blo = INFINITY, bhi = -INFINITY;
     for (int64_t k = k0 + threadIdx.x; k < k1; k += 64) {
-        const double yb = rec[k * LAT_REC + 1];
+        const double ya = rec[k * LAT_REC], yb = rec[k * LAT_REC + 1];
         const double reach = sqrt(rcut2 / (-2.0 * rec[k * LAT_REC + 3]));
-        lo = fmin(lo, yb - reach);
-        hi = fmax(hi, yb + reach);
+        alo = fmin(alo, ya - reach);
+        ahi = fmax(ahi, ya + reach);
+        blo = fmin(blo, yb - reach);
+        bhi = fmax(bhi, yb + reach);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        lo = fmin(lo, __shfl_down(lo, off));
-        hi = fmax(hi, __shfl_down(hi, off));
+        alo = fmin(alo, __shfl_down(alo, off));
+        ahi = fmax(ahi, __shfl_down(ahi, off));
+        blo = fmin(blo, __shfl_down(blo, off));
+        bhi = fmax(bhi, __shfl_down(bhi, off));
     }
     if (threadIdx.x == 0) {
-        band[2 * blockIdx.x] = lo;
-        band[2 * blockIdx.x + 1] = hi;
+        box[4 * blockIdx.x] = alo;
+        box[4 * blockIdx.x + 1] = ahi;
+        box[4 * blockIdx.x + 2] = blo;
+        box[4 * blockIdx.x + 3] = bhi;
     }
 }
 
-// Workgroup = one wavefront = 64 strips (t fastest: 64 / strips_a whole lattice lines, all
-// their strips) x one share of the sources.  partial[share][m][strip]: lane-contiguous stores.
-template <int R>
+// bounding box of patch p in (y_a, y_b)
+__device__ inline void lattice_patch_box(const KdeLattice &L, int R, int p, double &pa_lo, double &pa_hi,
+                                         double &pb_lo, double &pb_hi) {
+    const int cb = p % L.n_colblk, rb = p / L.n_colblk;
+    const int t_f = cb * L.sw, j_f = rb * L.lpw;
+    const int t_l = (t_f + L.sw < L.strips_a ? t_f + L.sw : L.strips_a) - 1;
+    const int j_l = (j_f + L.lpw < L.n1 ? j_f + L.lpw : L.n1) - 1;
+    const double pb0 = L.yb0 + j_f * L.db, pb1 = L.yb0 + j_l * L.db;
+    pb_lo = fmin(pb0, pb1);
+    pb_hi = fmax(pb0, pb1);
+    pa_lo = L.ya0 + fmin(j_f * L.sa, j_l * L.sa) + (double)(t_f * R) * L.da;
+    pa_hi = L.ya0 + fmax(j_f * L.sa, j_l * L.sa) + (double)((t_l + 1) * R - 1) * L.da;
+}
+
+// The patches see very different numbers of sources (margins of the lattice against its centre), and a
+// launch lasts as long as its slowest wavefront: the wavefronts are dealt to the patches in proportion to
+// the shares within reach.  load[p] = number of shares whose box meets patch p (one workgroup per patch).
+__global__ void __launch_bounds__(256)
+kde_lattice_load_kernel(const KdeLattice L, int R, const double *__restrict__ box, int64_t n_shares,
+                        unsigned int *__restrict__ load) {
+    __shared__ unsigned int lds[256];
+    double pa_lo, pa_hi, pb_lo, pb_hi;
+    lattice_patch_box(L, R, (int)blockIdx.x, pa_lo, pa_hi, pb_lo, pb_hi);
+    unsigned int cnt = 0;
+    for (int64_t sub = threadIdx.x; sub < n_shares; sub += 256) {
+        const double *__restrict__ bx = box + 4 * sub;
+        cnt += !(bx[0] > pa_hi || bx[1] < pa_lo || bx[2] > pb_hi || bx[3] < pb_lo);
+    }
+    lds[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) lds[threadIdx.x] += lds[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) load[blockIdx.x] = lds[0];
+}
+
+// wstart[p] .. wstart[p + 1]: the wavefronts of patch p; every patch gets one, the remaining
+// n_waves - n_patches go by load (integer arithmetic: the same plan for the same data)
 __global__ void __launch_bounds__(64)
+kde_lattice_plan_kernel(const unsigned int *__restrict__ load, int n_patches, int n_waves,
+                        int32_t *__restrict__ wstart) {
+    if (threadIdx.x != 0) return;
+    unsigned long long total = 0;
+    for (int p = 0; p < n_patches; p++) total += load[p];
+    const unsigned long long spare = (unsigned long long)(n_waves - n_patches);
+    int32_t w = 0;
+    for (int p = 0; p < n_patches; p++) {
+        wstart[p] = w;
+        unsigned long long extra = total ? spare * load[p] / total : 0;
+        if (4 * (extra + 1) > load[p]) extra = load[p] >= 4 ? load[p] / 4 - 1 : 0;   // >= 4 shares per wavefront
+        w += 1 + (int32_t)extra;
+    }
+    wstart[n_patches] = w;
+}
+
+// Workgroup = one wavefront = one patch of the lattice (sw strips x lpw lines) x every n-th share of the
+// sources, n = the patch's number of wavefronts (wstart).  partial[wavefront][m][lane].
+//
+// The records of a share reach the wavefront through its own LDS ring: 16 records (3 KB) per piece, every lane
+// fetching 48 B of the next piece (three 16-B loads, coalesced) while the current one is worked through, then
+// storing them to LDS, from where the wave-uniform values are read back as broadcasts.  Scalar loads, one record
+// ahead, left ~900 cycles of memory latency per source exposed: the oldest wavefront of a SIMD runs at its own
+// pace, the youngest ran alone at 40 % issue rate for the last third of the launch.
+constexpr int LAT_PIECE = 16;   // records per piece
+template <int R>
+__global__ void __launch_bounds__(64, 4)
 kde_lattice_kernel(const KdeLattice L, double rcut2, const double *__restrict__ rec, int64_t n_src,
-                   int64_t share, const double *__restrict__ band, double *__restrict__ partial,
-                   unsigned long long *__restrict__ pair_count) {
+                   int64_t share, const double *__restrict__ box, const int32_t *__restrict__ wstart,
+                   int n_patches, double *__restrict__ partial, unsigned long long *__restrict__ pair_count) {
     constexpr int C = R / 2;   // the strip's middle point
-    const int n_strips = L.strips_a * L.n1;
-    const int sid = (int)blockIdx.x * 64 + (int)threadIdx.x;   // strip (j, t), t fastest
-    const bool live = sid < n_strips;
-    const int j = live ? sid / L.strips_a : 0, t = live ? sid - j * L.strips_a : 0;
+    static_assert(C <= LAT_QMAX, "Q table");
+    static_assert(LAT_PIECE * LAT_REC * 8 == 3 * 64 * 16, "a piece is three 16-byte loads per lane");
+    __shared__ __attribute__((aligned(16))) double ring[2][LAT_PIECE * LAT_REC];
+    const int w = (int)blockIdx.x;
+    const int lane = (int)threadIdx.x;
+    if (w >= wstart[n_patches]) return;
+    int p = 0;
+    {
+        int hi = n_patches;
+        while (p + 1 < hi) {
+            const int mid = (p + hi) >> 1;
+            if (wstart[mid] <= w) p = mid; else hi = mid;
+        }
+    }
+    const int split = w - wstart[p], n_split = wstart[p + 1] - wstart[p];
+    const int cb = p % L.n_colblk, rb = p / L.n_colblk;
+    const int ls = lane % L.sw, ll = lane / L.sw;
+    const int t_f = cb * L.sw, j_f = rb * L.lpw;
+    const bool live = ll < L.lpw && t_f + ls < L.strips_a && j_f + ll < L.n1;
+    const int t = live ? t_f + ls : t_f, j = live ? j_f + ll : j_f;
     const double yb = L.yb0 + j * L.db;
     const double ya_c = L.ya0 + j * L.sa + (double)(t * R + C) * L.da;
     const double ext_lo = C * L.da, ext_hi = (R - 1 - C) * L.da;
+    double pa_lo, pa_hi, pb_lo, pb_hi;   // the patch's bounding box (wave-uniform)
+    lattice_patch_box(L, R, p, pa_lo, pa_hi, pb_lo, pb_hi);
     double acc[R];
 #pragma unroll
     for (int k = 0; k < R; k++) acc[k] = 0.0;
     unsigned long long strips = 0;
-    // The sorted sources are cut into shares of `share` sources (narrow bands in y_b); this
-    // wavefront takes the shares blockIdx.y, blockIdx.y + gridDim.y, ...: every wavefront sees a
-    // sample of all regions, so the work is balanced without a dynamic queue.
+    // The sorted sources are cut into shares of `share` sources (compact in y_a and y_b); this
+    // wavefront takes every n_split-th share: every wavefront sees a sample of all regions, so the work is
+    // balanced without a dynamic queue.
+    typedef double __attribute__((ext_vector_type(2))) d2;
     const int64_t n_shares = (n_src + share - 1) / share;
-    for (int64_t sub = blockIdx.y; sub < n_shares; sub += gridDim.y) {
-        // whole share out of reach of every line of this wavefront?
-        const double b_lo = band[2 * sub], b_hi = band[2 * sub + 1];
-        if (!__builtin_amdgcn_ballot_w64(live && yb >= b_lo && yb <= b_hi)) continue;
+    for (int64_t sub = split; sub < n_shares; sub += n_split) {
+        // whole share out of reach of the patch?
+        const double *__restrict__ bx = box + 4 * sub;
+        if (bx[0] > pa_hi || bx[1] < pa_lo || bx[2] > pb_hi || bx[3] < pb_lo) continue;
         const int64_t k0 = sub * share;
-        const int64_t k1 = k0 + share < n_src ? k0 + share : n_src;
-        const double *__restrict__ s = rec + k0 * LAT_REC;   // wave-uniform: scalar loads
-        double sya = s[0], syb = s[1], cf = s[2], sh = s[3], q = s[4], shd2 = s[5];
-        for (int64_t k = k0; k < k1; k++) {
-            // next record requested before this one is used (the last one reads itself again)
-            const double *__restrict__ nx = rec + (k + 1 < k1 ? k + 1 : k) * LAT_REC;
-            const double n0 = nx[0], n1 = nx[1], n2 = nx[2], n3 = nx[3], n4 = nx[4], n5 = nx[5];
-            const double xc = ya_c - sya, dbb = yb - syb;
-            const double dn = fmax(fmax(xc - ext_lo, -(xc + ext_hi)), 0.0);   // nearest point of the strip
-            const bool in = live && (dbb * dbb + dn * dn) * sh * -2.0 <= rcut2;
-            if (__builtin_amdgcn_ballot_w64(in)) {
-                if (in) {
-                    strips++;
-                    const double gc = cf * exp_nonpos(sh * __builtin_fma(xc, xc, dbb * dbb));
-                    const double e = shd2 * L.da * 0.5;                        // -s2 da^2 / 2
-                    const double r_up = exp_any(__builtin_fma(shd2, xc, e));    // g(c+1) / g(c)
-                    const double r_dn = exp_any(__builtin_fma(-shd2, xc, e));   // g(c-1) / g(c)
-                    double g = gc, r = r_up;
-                    double g2 = gc * r_dn, r2 = r_dn * q;
+        const int n_rec = (int)((k0 + share < n_src ? k0 + share : n_src) - k0);
+        const int n_piece = (n_rec + LAT_PIECE - 1) / LAT_PIECE;
+        // (the record array is padded to whole pieces: the loads of a last, partial piece stay inside it)
+        const d2 *__restrict__ src = reinterpret_cast<const d2 *>(rec + k0 * LAT_REC) + lane;
+        d2 a0 = src[0], a1 = src[64], a2 = src[128];
+        for (int c = 0; c < n_piece; c++) {
+            d2 b0 = a0, b1 = a1, b2 = a2;
+            if (c + 1 < n_piece) {
+                const d2 *__restrict__ nx = src + (c + 1) * 192;
+                b0 = nx[0]; b1 = nx[64]; b2 = nx[128];
+            }
+            double *slot = ring[c & 1];
+            {
+                d2 *dst = reinterpret_cast<d2 *>(slot) + lane;
+                dst[0] = a0; dst[64] = a1; dst[128] = a2;
+            }
+            __syncthreads();   // one wavefront: orders the stores above against the broadcast reads below
+            const int nr = n_rec - c * LAT_PIECE < LAT_PIECE ? n_rec - c * LAT_PIECE : LAT_PIECE;
+            const double *s = slot;
+            double sya = s[0], syb = s[1], cf = s[2], sh = s[3], shd = s[4], h = s[5];
+            for (int r = 0; r < nr; r++) {
+                const double *cur = slot + r * LAT_REC;
+                // next record read before this one is used (the last one reads itself again)
+                const double *nxr = slot + (r + 1 < nr ? r + 1 : r) * LAT_REC;
+                const double n0 = nxr[0], n1 = nxr[1], n2 = nxr[2], n3 = nxr[3], n4 = nxr[4], n5 = nxr[5];
+                const double xc = ya_c - sya, dbb = yb - syb;
+                const double dn = fmax(fmax(xc - ext_lo, -(xc + ext_hi)), 0.0);   // nearest point of the strip
+                const bool in = live && (dbb * dbb + dn * dn) * sh * -2.0 <= rcut2;
+                if (__builtin_amdgcn_ballot_w64(in)) {
+                    if (in) {
+                        strips++;
+                        const double gc = cf * exp_nonpos(sh * __builtin_fma(xc, xc, dbb * dbb));
+                        double r_up, r_dn;
+                        exp_pair(shd * xc, h, r_up, r_dn);   // g(c+1) / g(c), g(c-1) / g(c)
+                        double pu = gc, pd = gc * r_dn;
 #pragma unroll
-                    for (int m = 0; m < R - C; m++) {   // both directions interleaved: two independent chains
-                        acc[C + m] += g;
-                        g *= r;
-                        r *= q;
-                        if (C - 1 - m >= 0) {
-                            acc[C - 1 - m] += g2;
-                            g2 *= r2;
-                            r2 *= q;
+                        for (int kk = 0; kk < C; kk++) {   // both directions interleaved: two independent chains
+                            // up: point C + kk (k = kk); down: point C - 1 - kk (k = kk + 1)
+                            acc[C + kk] = kk < 2 ? acc[C + kk] + pu : __builtin_fma(pu, cur[LAT_Q0 + kk - 2], acc[C + kk]);
+                            if (kk + 1 < R - C) pu *= r_up;
+                            acc[C - 1 - kk] = kk + 1 < 2 ? acc[C - 1 - kk] + pd
+                                                         : __builtin_fma(pd, cur[LAT_Q0 + kk + 1 - 2], acc[C - 1 - kk]);
+                            if (kk + 1 < C) pd *= r_dn;
                         }
                     }
                 }
+                sya = n0; syb = n1; cf = n2; sh = n3; shd = n4; h = n5;
             }
-            sya = n0; syb = n1; cf = n2; sh = n3; q = n4; shd2 = n5;
+            __syncthreads();   // the slot is overwritten two pieces later: its reads are done
+            a0 = b0; a1 = b1; a2 = b2;
         }
     }
-    if (live) {
-        double *out = partial + (int64_t)blockIdx.y * R * n_strips + sid;
+    {
+        double *out = partial + (int64_t)w * (R * 64) + lane;
 #pragma unroll
-        for (int m = 0; m < R; m++) out[(int64_t)m * n_strips] = acc[m];
+        for (int m = 0; m < R; m++) out[m * 64] = acc[m];
     }
     if (pair_count) {
         strips *= R;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) strips += __shfl_down(strips, off);
-        if (threadIdx.x == 0 && strips) atomicAdd(pair_count, strips);
+        if (lane == 0 && strips) atomicAdd(pair_count, strips);
     }
 }
 
-// out[i0 n1 + i1] = sum over the shares of partial[share][m][strip], strip = i1 strips_a + i0 / R,
-// m = i0 % R.  256 threads = 16 entries x 16 share groups; a group adds its shares (g, g + 16, ...) in
-// order, the 16 group sums are added in order: fixed association, bit-reproducible.
+// out[i0 n1 + i1] = sum over the wavefronts of the point's patch of partial[wavefront][m][lane].  256 threads =
+// 16 entries x 16 groups; a group adds its wavefronts (g, g + 16, ...) in order, the 16 group sums are added in
+// order: fixed association, bit-reproducible.
 __global__ void __launch_bounds__(256)
-kde_lattice_combine_kernel(const double *__restrict__ partial, int n_split, int R, int strips_a, int n0, int n1,
-                           double *__restrict__ out) {
+kde_lattice_combine_kernel(const double *__restrict__ partial, const KdeLattice L, int R,
+                           const int32_t *__restrict__ wstart, double *__restrict__ out) {
     __shared__ double lds[16][17];
-    const int n_strips = strips_a * n1;
-    const int64_t per = (int64_t)R * n_strips;
     const int e_loc = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    const int64_t e = (int64_t)blockIdx.x * 16 + e_loc;    // entry of the [m][strip] layout
+    // blockIdx.x = (patch * R + m) * 4 + quarter of the 64 lanes
+    const int quarter = (int)blockIdx.x & 3, pm = (int)blockIdx.x >> 2;
+    const int m = pm % R, p = pm / R;
+    const int lane = quarter * 16 + e_loc;
+    const int ws = wstart[p], we = wstart[p + 1];
     double acc = 0.0;
-    if (e < per)
-        for (int sp = grp; sp < n_split; sp += 16) acc += partial[(int64_t)sp * per + e];
+    for (int w = ws + grp; w < we; w += 16) acc += partial[(int64_t)w * (R * 64) + m * 64 + lane];
     lds[grp][e_loc] = acc;
     __syncthreads();
-    if (grp == 0 && e < per) {
+    if (grp == 0) {
         double v = lds[0][e_loc];
 #pragma unroll
         for (int g = 1; g < 16; g++) v += lds[g][e_loc];
-        const int m = (int)(e / n_strips), sid = (int)(e - (int64_t)m * n_strips);
-        const int j = sid / strips_a, t = sid - j * strips_a;
+        const int cb = p % L.n_colblk, rb = p / L.n_colblk;
+        const int ls = lane % L.sw, ll = lane / L.sw;
+        const int t = cb * L.sw + ls, j = rb * L.lpw + ll;
         const int i0 = t * R + m;
-        if (i0 < n0) out[(int64_t)i0 * n1 + j] = v;
+        if (ll < L.lpw && t < L.strips_a && j < L.n1 && i0 < L.n0) out[(int64_t)i0 * L.n1 + j] = v;
     }
 }
 
@@ -766,8 +893,13 @@ kde_cell_s2min_kernel(const double *__restrict__ s2, const int32_t *__restrict__
 // (K = 1.09): 1e-13 for P = 18, 1.5e-15 for P = 20 -- relative to the cell's total weight, i.e.
 // at or below the cut-off tolerance.  A target then costs P^2 + 4 P + 40 multiply-adds per dense
 // cell within the cut-off instead of 23 per SOURCE: N * 250 cells * 500 instead of N * 0.2 N * 23
-// (x 90 at N = 4e5).  Cells with fewer than HERMITE_MIN sources are summed directly.
-constexpr int HERMITE_MIN = 24;
+// (x 90 at N = 4e5).  Without local expansions, cells with fewer than HERMITE_MIN_SERIES sources are summed directly.
+constexpr int HERMITE_MIN_DEFAULT = 1;   // with local expansions (see pisa_hip_kde_create)
+constexpr int HERMITE_MIN_SERIES = 24;   // series evaluated per target
+static int hermite_min() {
+    static const int v = [] { const char *e = getenv("PISA_HIP_KDE_HERMITE_MIN"); const int x = e ? atoi(e) : 0; return x > 0 ? x : HERMITE_MIN_DEFAULT; }();
+    return v;
+}
 constexpr double RSQRT2 = 0.70710678118654752440;
 
 __global__ void __launch_bounds__(256)
@@ -1087,7 +1219,7 @@ kde_h2l_kernel(KdeGeom g, const int32_t *__restrict__ tcells, const int32_t *__r
 
 // pilot densities at the (cell-sorted) sources: the local expansion of the target's cell for all
 // dense cells in range + direct sums over the sparse ones.
-template <int P>
+template <int P, bool SPARSE>
 __global__ void __launch_bounds__(KDE_THREADS)
 kde_local_pilot_kernel(KdeGeom g, const KdeBlock *__restrict__ blocks, const double *__restrict__ sy,
                        int64_t n_src, const double *__restrict__ coef,
@@ -1135,7 +1267,7 @@ kde_local_pilot_kernel(KdeGeom g, const KdeBlock *__restrict__ blocks, const dou
 #pragma unroll
         for (int u = 0; u < Q_PER_THREAD; u++) acc[u] = sum[u];
     }
-    // sparse cells in range: directly
+    // sparse cells in range: directly (SPARSE = false: every non-empty cell has a series, nothing to look for)
     int lo[2], hi[2];
     const double reach = ceil(sqrt(g.rcut2) * g.inv_cell);
 #pragma unroll
@@ -1144,6 +1276,7 @@ kde_local_pilot_kernel(KdeGeom g, const KdeBlock *__restrict__ blocks, const dou
         lo[d] = l > 0.0 ? (int)l : 0;
         hi[d] = h < (double)(g.nc[d] - 1) ? (int)h : g.nc[d] - 1;
     }
+    if (!SPARSE) hi[1] = lo[1] - 1;
     for (int cy = lo[1]; cy <= hi[1]; cy++) {
         const int gapy = cy < b.c0[1] ? b.c0[1] - cy - 1 : (cy > b.c1[1] ? cy - b.c1[1] - 1 : 0);
         const double gy = gapy * g.cell;
@@ -1340,7 +1473,7 @@ PISA_API int64_t pisa_hip_kde_workspace_bytes(int32_t dim, int64_t n_src) {
     total += n * 8 + split_bytes(n_src);                 // pilot, split partials
     total += sort_temp_bytes(n_src) + (n / Q_CHUNK + (size_t)cells_cap(n_src)) * sizeof(KdeBlock);
     if (dim == 2)   // cell -> slot map, lists of dense / non-empty cells (the coefficients live in library scratch)
-        total += (n / HERMITE_MIN + 1) * 4 + (size_t)cells_cap(n_src) * 8 + 4096;
+        total += (n / hermite_min() + 1) * 4 + (size_t)cells_cap(n_src) * 8 + 4096;   // dense list: one entry per cell at most
     return (int64_t)(total + 64 * 256);
 }
 
@@ -1561,10 +1694,17 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
         std::vector<int32_t> dense, tcells;
         std::vector<double> hankel;
         const int P = tol >= 1e-12 ? 18 : 20;
+        // local expansions need the intermediate V of every cell of the grid: bounded
+        const bool local_ok = g_kde_expansion >= 2 && ceil(sqrt(g.rcut2) * g.inv_cell) <= (double)H2L_MAX_REACH &&
+                              (double)k->n_cells * (P * P) * 8.0 < 2.0e9;
+        // with local expansions a series costs its cell 400 multiply-adds per source and nothing per
+        // target, so every non-empty cell gets one; evaluated target by target (no local expansions) a
+        // series pays from ~24 sources
+        const int dense_min = local_ok ? hermite_min() : std::max(hermite_min(), HERMITE_MIN_SERIES);
         if (g_kde_expansion && dim == 2 && cut && n >= 20000) {
             for (size_t h = 0; h < h_starts.size(); h++) {
                 const int64_t end = h + 1 < h_starts.size() ? h_starts[h + 1] : n;
-                if (end - h_starts[h] < HERMITE_MIN) continue;
+                if (end - h_starts[h] < dense_min) continue;
                 const int64_t cx = (int64_t)(h_keys[h] & 0x1FFFFF) - KEY_OFF;
                 const int64_t cy = (int64_t)((h_keys[h] >> 21) & 0x1FFFFF) - KEY_OFF;
                 dense.push_back((int32_t)(cy * g.nc[0] + cx));
@@ -1574,9 +1714,7 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
             const int nd = (int)dense.size();
             const int n_heads = (int)h_starts.size();
             const int reach = (int)ceil(sqrt(g.rcut2) * g.inv_cell);
-            // local expansions need the intermediate V of every cell of the grid: bounded
-            const bool local_exp = g_kde_expansion >= 2 && reach <= H2L_MAX_REACH &&
-                                   (double)k->n_cells * (P * P) * 8.0 < 2.0e9;
+            const bool local_exp = local_ok;
             // Hermite / local coefficients live in a grow-only scratch of the library (up to
             // 3.2 KB per cell: sized by what this call needs, not by the workspace's worst case)
             const size_t pp = (size_t)(P * P);
@@ -1635,8 +1773,12 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
                                        slot, herm, d_hankel, reach, d_V, d_vflag, local); \
                     hipLaunchKernelGGL((kde_h2l_kernel<PP, 1>), dim3((unsigned)n_heads), dim3(H2L_THREADS), 0, s, g, d_tcells, \
                                        slot, herm, d_hankel, reach, d_V, d_vflag, local); \
-                    hipLaunchKernelGGL(kde_local_pilot_kernel<PP>, dim3((unsigned)n_blocks), dim3(KDE_THREADS), 0, s, g, \
-                                       d_blocks, k->ys, n, k->coef, k->cell_start, slot, local, pilot, k->pair_count); \
+                    if (nd < n_heads) \
+                        hipLaunchKernelGGL((kde_local_pilot_kernel<PP, true>), dim3((unsigned)n_blocks), dim3(KDE_THREADS), 0, s, g, \
+                                           d_blocks, k->ys, n, k->coef, k->cell_start, slot, local, pilot, k->pair_count); \
+                    else \
+                        hipLaunchKernelGGL((kde_local_pilot_kernel<PP, false>), dim3((unsigned)n_blocks), dim3(KDE_THREADS), 0, s, g, \
+                                           d_blocks, k->ys, n, k->coef, k->cell_start, slot, local, pilot, k->pair_count); \
                 } else { \
                     hipLaunchKernelGGL(kde_hermite_pilot_kernel<PP>, grid, dim3(KDE_THREADS), 0, s, g, d_blocks, \
                                        k->ys, n, k->coef, k->cell_start, slot, herm, n_split, part, k->pair_count); \
@@ -1774,14 +1916,46 @@ static int lattice_strip(const pisa_hip_kde *k, const double *step, const int64_
     return 0;
 }
 
-static int lattice_split(int R, const int64_t *count, int64_t n) {
-    const int64_t strips = ((count[0] + R - 1) / R) * count[1];
-    const int64_t blocks = (strips + 63) / 64;
+// Patch of a wavefront: sw strips of lpw = 64 / sw consecutive lines.  A source costs one pass per
+// patch within its reach, whatever the number of strips it reaches there, so the patch should be
+// as compact as the kernel discs: the expected number of patches a unit-bandwidth source
+// touches (sources spread evenly over the lattice and its margin) picks sw.
+static int lattice_shape(const pisa_hip_kde *k, int R, const double *step, const int64_t *count) {
+    const int strips_a = (int)((count[0] + R - 1) / R);
+    static const int forced = [] { const char *v = getenv("PISA_HIP_KDE_LATTICE_SW"); return v ? atoi(v) : 0; }();
+    if (forced > 0) return std::min(std::min(forced, strips_a), 64);
+    const double rp = sqrt(k->g.rcut2) / fabs(k->g.U[0] * step[0]), rl = sqrt(k->g.rcut2) / fabs(k->g.U[4] * step[1]);
+    const double n0 = (double)count[0], n1 = (double)count[1];
+    int best = 1;
+    double best_cost = INFINITY;
+    for (int sw : {1, 2, 4, 8, 16, 32, 64, strips_a}) {
+        if (sw > strips_a || sw > 64) continue;
+        const int lpw = 64 / sw;
+        double rows = 0.0, cols = 0.0;
+        for (int64_t j = 0; j < count[1]; j += lpw)
+            rows += std::min(1.0, (2.0 * rl + (double)std::min<int64_t>(lpw, count[1] - j)) / (n1 + 2.0 * rl));
+        for (int64_t i = 0; i < count[0]; i += (int64_t)sw * R)
+            cols += std::min(1.0, (2.0 * rp + (double)std::min<int64_t>((int64_t)sw * R, count[0] - i)) / (n0 + 2.0 * rp));
+        const double cost = rows * cols;
+        if (cost < best_cost * (1.0 - 1e-9)) { best_cost = cost; best = sw; }
+    }
+    return best;
+}
+
+static int64_t lattice_patches(int R, int sw, const int64_t *count) {
+    const int64_t strips_a = (count[0] + R - 1) / R;
+    const int lpw = 64 / sw;
+    return ((strips_a + sw - 1) / sw) * ((count[1] + lpw - 1) / lpw);
+}
+
+// number of wavefronts of the lattice kernel (>= one per patch)
+static int64_t lattice_waves(int R, int sw, const int64_t *count, int64_t n) {
+    const int64_t patches = lattice_patches(R, sw, count);
     static const int waves = [] { const char *v = getenv("PISA_HIP_KDE_LATTICE_WAVES"); return v ? atoi(v) : 4096; }();
-    int64_t n_split = std::max<int64_t>(1, waves / blocks);
-    n_split = std::min<int64_t>(n_split, std::max<int64_t>(1, n / (4 * LAT_SHARE)));
-    n_split = std::min<int64_t>(n_split, std::max<int64_t>(1, (int64_t)(128 << 20) / (blocks * 64 * R * 8)));
-    return (int)std::min<int64_t>(n_split, 4096);
+    int64_t w = std::max<int64_t>(patches, waves);
+    w = std::min<int64_t>(w, std::max<int64_t>(patches, (int64_t)(128 << 20) / (R * 64 * 8)));     // partial sums <= 128 MB
+    (void)n;   // (the plan gives a patch no more wavefronts than it has shares within reach)
+    return w;
 }
 
 PISA_API int64_t pisa_hip_kde_lattice_workspace_bytes(const pisa_hip_kde *k, const double *h_step,
@@ -1795,9 +1969,11 @@ PISA_API int64_t pisa_hip_kde_lattice_workspace_bytes(const pisa_hip_kde *k, con
     const int R = lattice_strip(k, h_step, h_count);
     if (R)
     {
-        const size_t n_split = (size_t)lattice_split(R, h_count, k->n);
-        const size_t per = (size_t)R * (size_t)((h_count[0] + R - 1) / R) * (size_t)h_count[1];
-        return (int64_t)((size_t)k->n * LAT_REC * 8 + n_split * per * 8 + ((size_t)k->n / LAT_SHARE + 1) * 16 + 4096);
+        const int sw = lattice_shape(k, R, h_step, h_count);
+        const size_t waves = (size_t)lattice_waves(R, sw, h_count, k->n);
+        const size_t patches = (size_t)lattice_patches(R, sw, h_count);
+        return (int64_t)(((size_t)k->n + LAT_PIECE) * LAT_REC * 8 + waves * R * 64 * 8 + ((size_t)k->n / LAT_SHARE + 1) * 32 +
+                         (patches + 1) * 8 + 4096);
     }
     const int64_t general = pisa_hip_kde_eval_workspace_bytes(k, m);
     return general < 0 ? -1 : general + (int64_t)k->dim * m * 8 + 4096;
@@ -1840,24 +2016,28 @@ PISA_API int pisa_hip_kde_evaluate_lattice(pisa_hip_kde *k, const double *h_orig
     L.n0 = (int32_t)h_count[0];
     L.n1 = (int32_t)h_count[1];
     L.strips_a = (L.n0 + R - 1) / R;
-    const int n_split = lattice_split(R, h_count, k->n);   // wavefronts per group of 64 strips = partial sums per point
+    L.sw = lattice_shape(k, R, h_step, h_count);
+    L.lpw = 64 / L.sw;
+    L.n_colblk = (L.strips_a + L.sw - 1) / L.sw;
+    const int n_patches = (int)lattice_patches(R, L.sw, h_count);
+    const int n_waves = (int)lattice_waves(R, L.sw, h_count, k->n);
     const int64_t share = LAT_SHARE;
     const int64_t n_shares = (k->n + share - 1) / share;
-    const int64_t n_strips = (int64_t)L.strips_a * L.n1;
-    const int64_t per = (int64_t)R * n_strips;
-    double *rec = ar.take<double>((size_t)k->n * LAT_REC);
-    double *part = ar.take<double>((size_t)n_split * per);
-    double *band = ar.take<double>((size_t)n_shares * 2);
+    double *rec = ar.take<double>(((size_t)k->n + LAT_PIECE) * LAT_REC);   // padded to whole pieces of records
+    double *part = ar.take<double>((size_t)n_waves * R * 64);
+    double *box = ar.take<double>((size_t)n_shares * 4);
+    unsigned int *load = ar.take<unsigned int>((size_t)n_patches);
+    int32_t *wstart = ar.take<int32_t>((size_t)n_patches + 1);
     if (!ar.ok) return PISA_HIP_ERR_NOMEM;
-    hipLaunchKernelGGL(kde_lattice_prep_kernel, dim3((unsigned)((k->n + 255) / 256)), dim3(256), 0, s, k->ys,
+    hipLaunchKernelGGL(kde_lattice_prep_kernel, dim3((unsigned)((k->n * LAT_REC + 255) / 256)), dim3(256), 0, s, k->ys,
                        k->coef, k->s2, k->n, L.da, rec);
-    hipLaunchKernelGGL(kde_lattice_band_kernel, dim3((unsigned)n_shares), dim3(64), 0, s, rec, k->n, share, g.rcut2, band);
-    const dim3 grid((unsigned)((n_strips + 63) / 64), (unsigned)n_split);
-#define KDE_LAT(RR) hipLaunchKernelGGL(kde_lattice_kernel<RR>, grid, dim3(64), 0, s, L, g.rcut2, rec, k->n, share, band, part, k->pair_count)
+    hipLaunchKernelGGL(kde_lattice_box_kernel, dim3((unsigned)n_shares), dim3(64), 0, s, rec, k->n, share, g.rcut2, box);
+    hipLaunchKernelGGL(kde_lattice_load_kernel, dim3((unsigned)n_patches), dim3(256), 0, s, L, R, box, n_shares, load);
+    hipLaunchKernelGGL(kde_lattice_plan_kernel, dim3(1), dim3(64), 0, s, load, n_patches, n_waves, wstart);
+#define KDE_LAT(RR) hipLaunchKernelGGL(kde_lattice_kernel<RR>, dim3((unsigned)n_waves), dim3(64), 0, s, L, g.rcut2, rec, k->n, share, box, wstart, n_patches, part, k->pair_count)
     if (R == 32) KDE_LAT(32); else if (R == 16) KDE_LAT(16); else KDE_LAT(8);
 #undef KDE_LAT
-    hipLaunchKernelGGL(kde_lattice_combine_kernel, dim3((unsigned)((per + 15) / 16)), dim3(256), 0, s, part, n_split, R,
-                       L.strips_a, L.n0, L.n1, d_out);
+    hipLaunchKernelGGL(kde_lattice_combine_kernel, dim3((unsigned)(n_patches * R * 4)), dim3(256), 0, s, part, L, R, wstart, d_out);
     PISA_CHECK_LAUNCH("kde lattice kernels");
     PISA_TRY_HIP(hipMemcpyAsync(&k->pairs_eval, k->pair_count, sizeof(unsigned long long),
                                 hipMemcpyDeviceToHost, s));
