@@ -452,9 +452,32 @@ int pisa_hip_kde_destroy(pisa_hip_kde *k);
  * buffer is reused.  This call frees the calling thread's buffer. */
 int pisa_hip_kde_release_scratch(void);
 
-/* How the 2-D fixed-bandwidth pilot estimate sums cells of >= 24 sources (fast Gauss transform;
- * truncation error below the cut-off tolerance): 2 (default) = Hermite series of the source cells
- * translated into one local expansion per target cell, 1 = Hermite series evaluated target by target,
+/* The estimators of one KDE-stage evaluation in one call (pisa/stages/utils/kde.py:154-293 loops over the
+ * containers, kde_hist.py:303-372 over the pid channels: 24 independent estimators at the C3 size, all
+ * evaluated on the same lattice of oversampled bin centres).  Job by job the result is that of
+ * pisa_hip_kde_create(d_x, w, ...) + pisa_hip_kde_evaluate_lattice(...) with
+ * w[k] = nan_to_num(d_weights[d_index ? d_index[k] : k]) (kde_hist.py:104-108); the jobs run side by side on
+ * `n_threads` host threads of the library (each with its own stream and grow-only workspace; <= 0: 8), longest
+ * first, after everything queued on `stream`; on return all d_out are complete.  Returns the first job error. */
+typedef struct pisa_hip_kde_job {
+    const double *d_x;        /* [dim][n] sample, dimension-major */
+    const double *d_weights;  /* weights of the parent sample, or NULL (unit weights) */
+    const int64_t *d_index;   /* n indices into d_weights, or NULL (d_weights has n entries) */
+    int64_t n;
+    double *d_out;            /* densities at the lattice points, numpy.meshgrid(indexing="ij") order */
+    double sum_w;             /* out: sum of the weights used (the map's normalisation, kde_hist.py:107) */
+    int64_t pairs_pilot;      /* out: as pisa_hip_kde_info_t */
+    int64_t pairs_eval;
+    int32_t status;           /* out: PISA_HIP_OK or the job's error */
+    int32_t reserved;
+} pisa_hip_kde_job;
+int pisa_hip_kde_lattice_batch(pisa_hip_kde_job *jobs, int32_t n_jobs, int32_t dim, int32_t bw_method,
+                               int32_t adaptive, double alpha, double tol, const double *h_origin,
+                               const double *h_step, const int64_t *h_count, int32_t n_threads, void *stream);
+
+/* How the 2-D fixed-bandwidth pilot estimate sums its cells (fast Gauss transform; truncation error below
+ * the cut-off tolerance): 2 (default) = Hermite series of ALL non-empty source cells translated into one
+ * local expansion per target cell, 1 = Hermite series of the cells of >= 24 sources evaluated target by target,
  * 0 = every pair directly; < 0 = query.  Returns the previous setting. */
 int pisa_hip_kde_configure(int32_t use_expansion);
 

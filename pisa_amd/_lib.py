@@ -132,6 +132,21 @@ class BarrFoldSet(C.Structure):
     ]
 
 
+class KdeJob(C.Structure):
+    _fields_ = [
+        ("d_x", C.c_void_p),
+        ("d_weights", C.c_void_p),
+        ("d_index", C.c_void_p),
+        ("n", C.c_int64),
+        ("d_out", C.c_void_p),
+        ("sum_w", C.c_double),
+        ("pairs_pilot", C.c_int64),
+        ("pairs_eval", C.c_int64),
+        ("status", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
 class FluxTable(C.Structure):
     _fields_ = [
         ("n_bands", C.c_int32),
@@ -196,6 +211,8 @@ _SIGS = {
     "pisa_hip_kde_evaluate_lattice": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "pisa_hip_kde_evaluate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "pisa_hip_kde_info": (C.c_int, [C.c_void_p, C.POINTER(KdeInfo)]),
+    "pisa_hip_kde_lattice_batch": (C.c_int, [C.POINTER(KdeJob), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "pisa_hip_kde_arrays": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "pisa_hip_kde_destroy": (C.c_int, [C.c_void_p]),
     "pisa_hip_kde_configure": (C.c_int, [C.c_int32]),

@@ -38,6 +38,7 @@
 #include <vector>
 
 #include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 
 #include "common.hpp"
 
@@ -333,6 +334,23 @@ __device__ inline int64_t flat_cell(uint64_t key, const KdeGeom &g) {
     const int64_t cy = (int64_t)((key >> 21) & 0x1FFFFF) - KEY_OFF;
     const int64_t cz = (int64_t)((key >> 42) & 0x1FFFFF) - KEY_OFF;
     return (cz * g.nc[1] + cy) * g.nc[0] + cx;
+}
+
+// The sources are sorted by their FLAT cell index (a 32-bit key of ceil(log2 n_cells) significant bits: three
+// 8-bit radix passes at C3 sizes) instead of the 63-bit tile key (a 64-bit merge sort below 2^20 items): both
+// orders are the same (cz, cy, cx lexicographic, stable), so the sorted order is what it was.
+__global__ void __launch_bounds__(256)
+kde_flat_key_kernel(const uint64_t *__restrict__ keys, int64_t n, KdeGeom g, uint32_t *__restrict__ flat) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k < n) flat[k] = (uint32_t)flat_cell(keys[k], g);
+}
+__global__ void __launch_bounds__(256)
+kde_tile_key_kernel(const uint32_t *__restrict__ flat, int64_t n, KdeGeom g, uint64_t *__restrict__ keys) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const int64_t c = flat[k];
+    const int64_t cx = c % g.nc[0], cy = (c / g.nc[0]) % g.nc[1], cz = c / ((int64_t)g.nc[0] * g.nc[1]);
+    keys[k] = ((uint64_t)(cz + KEY_OFF) << 42) | ((uint64_t)(cy + KEY_OFF) << 21) | (uint64_t)(cx + KEY_OFF);
 }
 
 // cell_start[c] = first sorted source of cell c (sources sorted by key == sorted by flat cell)
@@ -1333,10 +1351,17 @@ struct Arena {   // carves the caller's workspace
     }
 };
 
+// radix passes always (rocprim's default switches to a merge sort below 2^20 items)
+using FlatSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
+
 static size_t sort_temp_bytes(int64_t n) {
     size_t bytes = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (uint64_t *)nullptr, (uint64_t *)nullptr,
                                        (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, 0, 63, 0);
+    size_t b3 = 0;
+    (void)rocprim::radix_sort_pairs<FlatSortConfig>(nullptr, b3, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                                                    (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, 0u, 32u);
+    bytes = std::max(bytes, b3);
     size_t b2 = 0;
     (void)hipcub::DeviceSelect::Flagged(nullptr, b2, hipcub::CountingInputIterator<int32_t>(0),
                                   (uint8_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int)n, 0);
@@ -1657,7 +1682,16 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
     // ---- whiten, sort by cell, cell table
     KDE_D(kde_whiten_key_kernel, dim3(nb), dim3(256), 0, s, d_x, n, g, 1, 1, y, keys_a, idx_a);
     size_t tb = temp_bytes;
-    KDE_TRY_HIP(hipcub::DeviceRadixSort::SortPairs(temp, tb, keys_a, keys_b, idx_a, idx_b, (int)n, 0, 63, s));
+    {
+        uint32_t *flat_a = (uint32_t *)keys_b, *flat_b = flat_a + n;   // keys_b is written by kde_tile_key_kernel below
+        unsigned bits = 1;
+        while (bits < 32 && ((int64_t)1 << bits) < k->n_cells) bits++;
+        hipLaunchKernelGGL(kde_flat_key_kernel, dim3(nb), dim3(256), 0, s, keys_a, n, g, flat_a);
+        KDE_TRY_HIP(rocprim::radix_sort_pairs<FlatSortConfig>(temp, tb, flat_a, flat_b, idx_a, idx_b, (size_t)n, 0u, bits, s));
+        // the unsorted tile keys are no longer needed: their array takes the sorted ones
+        hipLaunchKernelGGL(kde_tile_key_kernel, dim3(nb), dim3(256), 0, s, flat_b, n, g, keys_a);
+        std::swap(keys_a, keys_b);   // keys_b = sorted 63-bit tile keys (in the former keys_a)
+    }
     KDE_D(kde_gather_kernel, dim3(nb), dim3(256), 0, s, y, d_w, 1.0 / sw, idx_b, n, k->ys, k->wn);
     hipLaunchKernelGGL(kde_cell_start_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, s, keys_b, n,
                        g, k->n_cells, k->cell_start);

@@ -425,6 +425,54 @@ class KdeEstimator:
 METRIC_KIND = {"llh": 0, "poisson_llh": 1, "chi2": 2, "mod_chi2": 3}
 
 
+def kde_lattice_batch(jobs, origin, step, count, bw_method="silverman", adaptive=True, alpha=0.3,
+                      tol=KDE_DEFAULT_TOL, n_threads=0):
+    """The estimators of one KDE-stage evaluation in one native call (`pisa_hip_kde_lattice_batch`).
+    jobs: [(x [dim, n] device tensor, weights device tensor or None, index int64 device tensor or None)];
+    weights are those of the parent sample when an index is given.  Returns (densities [n_jobs, m] device
+    tensor, [sum of the weights used per job], (pairs_pilot, pairs_eval) summed over the jobs)."""
+    import ctypes as C
+
+    lib = _lib.lib()
+    if bw_method not in KDE_BW:
+        raise ValueError("`bw_method` should be 'scott' or 'silverman'")
+    d = len(origin)
+    assert len(step) == len(count) == d
+    if min(int(v) for v in count) < 1:
+        raise ValueError("empty lattice %r" % (list(count),))
+    m = int(np.prod([int(v) for v in count]))
+    n_jobs = len(jobs)
+    dev = jobs[0][0].device if n_jobs else device()
+    out = torch.empty((n_jobs, m), dtype=F8, device=dev)
+    arr = (_lib.KdeJob * max(n_jobs, 1))()
+    keep = []
+    for i, (x, w, idx) in enumerate(jobs):
+        x = x.contiguous()
+        assert int(x.shape[0]) == d
+        keep.append(x)
+        j = arr[i]
+        j.d_x, j.n = _ptr(x), int(x.shape[1])
+        if w is not None:
+            w = w.contiguous()
+            keep.append(w)
+            j.d_weights = _ptr(w)
+            if idx is not None:
+                idx = idx.contiguous()
+                assert idx.dtype == torch.int64 and int(idx.numel()) == j.n
+                keep.append(idx)
+                j.d_index = _ptr(idx)
+            else:
+                assert int(w.numel()) == j.n
+        j.d_out = _ptr(out[i])
+    o = (C.c_double * d)(*[float(v) for v in origin])
+    st = (C.c_double * d)(*[float(v) for v in step])
+    cnt = (C.c_int64 * d)(*[int(v) for v in count])
+    _lib.check(lib.pisa_hip_kde_lattice_batch(arr, n_jobs, d, KDE_BW[bw_method], 1 if adaptive else 0, float(alpha),
+                                              float(tol), o, st, cnt, int(n_threads), _stream()))
+    return (out, [arr[i].sum_w for i in range(n_jobs)],
+            (sum(arr[i].pairs_pilot for i in range(n_jobs)), sum(arr[i].pairs_eval for i in range(n_jobs))))
+
+
 def metric(kind, actual, expected, sigma2=None, per_bin=False, total_out=None, status=None):
     """Map.metric + nansum (map.py:1572-1604) on device.  `expected` (and
     `sigma2`) may be [n_maps, n_bins]; maps are summed in index order first.

@@ -108,38 +108,12 @@ class kde(Stage):  # pylint: disable=invalid-name
         return torch.as_tensor(draws, dtype=torch.float64).to(st["sample"].device)
 
     # -- the estimators of one evaluation are independent (one per container and pid channel) and
-    #    each is a chain of small launches with a few host round trips (moments, cell counts,
-    #    bandwidth range): `kde_workers` host threads, each with its own HIP stream, keep the GPU
-    #    busy during the round trips of the others.  Every estimator is deterministic by itself, so
-    #    the maps do not depend on the interleaving.
-    kde_workers = int(os.environ.get("PISA_KDE_WORKERS", "6"))   # 1 / 2 / 4 / 6 / 8: 43 / 31 / 27 / 25 / 27 ms per C3 evaluation
-
-    # ONE executor (and one HIP stream per worker thread) for all utils.kde stages of the process: the
-    # native estimator keeps a grow-only scratch buffer per host thread (pisa_hip_kde_release_scratch),
-    # so a pool per stage would multiply those
-    _shared_pool = None
-
-    def _pool(self):
-        cls = type(self)
-        if cls._shared_pool is None:
-            import threading
-            from concurrent.futures import ThreadPoolExecutor
-
-            cls._shared_pool = (ThreadPoolExecutor(max_workers=self.kde_workers, thread_name_prefix="kde"),
-                                threading.local())
-        self._executor, self._tls = cls._shared_pool
-        return self._executor
-
-    def _kde_task(self, main_stream, weights, kw):
-        tls = self._tls
-        if getattr(tls, "stream", None) is None:
-            tls.stream = torch.cuda.Stream(device=weights.device)
-        stats = {}
-        with torch.cuda.stream(tls.stream):
-            tls.stream.wait_stream(main_stream)       # the weights were produced on the caller's stream
-            kde_map = kde_hist.kde_histogramdd(weights=weights, stats=stats, **kw)
-            tls.stream.synchronize()
-        return kde_map, stats
+    #    each is a chain of small launches with a few host round trips (moments, cell heads,
+    #    bandwidth range): they go to the library in ONE call (`kde_hist.kde_histogramdd_batch` ->
+    #    `pisa_hip_kde_lattice_batch`), which runs them side by side on `kde_workers` threads of its
+    #    own, each with its own HIP stream.  Every estimator is deterministic by itself, so the maps
+    #    do not depend on the interleaving.
+    kde_workers = int(os.environ.get("PISA_KDE_WORKERS", "8"))
 
     def _job_kwargs(self, st):
         return dict(sample=st["sample"], binning=self.regularized_apply_mode,
@@ -235,17 +209,20 @@ class kde(Stage):  # pylint: disable=invalid-name
         if self.bootstrap:
             for i, (st, weights, kw) in inputs.items():
                 results[i] = self._bootstrap_map(st, weights, kw)
-        elif self.kde_workers > 1 and len(owned) > 1:
-            pool, main = self._pool(), torch.cuda.current_stream()
-            jobs = {i: pool.submit(self._kde_task, main, weights, kw) for i, (st, weights, kw) in inputs.items()}
-            for i, fut in jobs.items():
-                kde_map, stats = fut.result()
-                for key, val in stats.items():
-                    self.stats[key] = self.stats.get(key, 0) + val
-                results[i] = (kde_map, None)
         else:
-            for i, (st, weights, kw) in inputs.items():
-                results[i] = (kde_hist.kde_histogramdd(weights=weights, stats=self.stats, **kw), None)
+            order = list(inputs)
+            if all(torch.is_tensor(inputs[i][1]) for i in order):
+                kw = dict(self._job_kwargs(inputs[order[0]][0])) if order else {}
+                for key in ("sample", "channels"):
+                    kw.pop(key, None)
+                samples = [dict(sample=inputs[i][0]["sample"], weights=inputs[i][1], channels=inputs[i][0]["channels"])
+                           for i in order]
+                maps = kde_hist.kde_histogramdd_batch(samples, stats=self.stats, n_threads=self.kde_workers, **kw)
+                for i, m in zip(order, maps):
+                    results[i] = (m, None)
+            else:
+                for i, (st, weights, kw) in inputs.items():
+                    results[i] = (kde_hist.kde_histogramdd(weights=weights, stats=self.stats, **kw), None)
         if world > 1:
             results = self.exchange_maps(results, len(conts), int(self.apply_mode.size), self.bootstrap)
         self.data.representation = self.apply_mode

@@ -26,7 +26,7 @@ import torch
 from pisa_amd import kernels as K
 from pisa_amd.core.binning import MultiDimBinning
 
-__all__ = ["gaussian_kde", "bootstrap_kde", "get_hist", "kde_histogramdd", "pid_channels"]
+__all__ = ["gaussian_kde", "bootstrap_kde", "get_hist", "kde_histogramdd", "kde_histogramdd_batch", "pid_channels"]
 
 
 class gaussian_kde:  # pylint: disable=invalid-name
@@ -44,6 +44,7 @@ class gaussian_kde:  # pylint: disable=invalid-name
         self._est = K.KdeEstimator(x, w, bw_method=bw_method, adaptive=adaptive, alpha=alpha,
                                    tol=K.KDE_DEFAULT_TOL if tol is None else tol)
         self.factor = self._est.factor
+        self.sum_w = self._est.sum_w
         self.covariance = self._est.covariance
         self.inv_cov = self._est.inv_cov
         self._norm = self._est.norm
@@ -59,11 +60,9 @@ class gaussian_kde:  # pylint: disable=invalid-name
         steps go through the lattice entry point (the steps of a regular binning's oversampled
         centres, the coszen reflection included, are uniform), anything else is written out"""
         axes = [np.asarray(a, dtype=np.float64) for a in axes]
-        uniform = all(len(a) >= 2 and np.allclose(np.diff(a), (a[-1] - a[0]) / (len(a) - 1), rtol=1e-9, atol=0.0)
-                      and a[-1] > a[0] for a in axes)
-        if uniform:
-            return self._est.evaluate_lattice([a[0] for a in axes], [(a[-1] - a[0]) / (len(a) - 1) for a in axes],
-                                              [len(a) for a in axes])
+        lat = _lattice_of(axes)
+        if lat is not None:
+            return self._est.evaluate_lattice(*lat)
         grid = np.meshgrid(*axes, indexing="ij")
         return self(np.array([g.ravel() for g in grid]))
 
@@ -154,7 +153,7 @@ def get_hist(sample, binning, weights=None, bw_method="scott", adaptive=True, al
         weights_d, norm = None, sample.shape[0]
     else:
         weights_d = torch.nan_to_num(weights if torch.is_tensor(weights) else K.to_device(np.asarray(weights)))
-        norm = float(weights_d.sum())
+        norm = float(weights_d.sum()) if bootstrap else None   # (plain: the estimator's own sum, below)
     g = _evaluation_grid(binning, oversample, coszen_name, coszen_reflection)
     x = (sample.T if on_dev else K.to_device(np.ascontiguousarray(np.asarray(sample).T))).clone()
     assert x.shape[0] == len(g["binning"])
@@ -173,10 +172,22 @@ def get_hist(sample, binning, weights=None, bw_method="scott", adaptive=True, al
         kernel = gaussian_kde(x.contiguous(), weights=weights_d, bw_method=bw_method, adaptive=adaptive,
                               alpha=alpha, tol=tol)
         hist = kernel.evaluate_grid(g["bin_points"]).cpu().numpy().reshape(g["megashape"])
+        norm = kernel.sum_w    # sum of the weights as the estimator formed it (what `kde_histogramdd_batch` uses)
     if stats is not None:
         stats["pairs_pilot"] = stats.get("pairs_pilot", 0) + kernel.pairs[0]
         stats["pairs_eval"] = stats.get("pairs_eval", 0) + kernel.pairs[1]
         stats["all_pairs"] = stats.get("all_pairs", 0) + kernel.n * (kernel.n * bool(adaptive) + g["n_points"])
+    hist, errors = _finish_hist(g, hist, variances, oversample)
+    if errors is not None:
+        return hist * norm, errors * norm
+    return hist * norm
+
+
+def _finish_hist(g, hist, variances, oversample):
+    """from the densities at the evaluation points to the map (kde_hist.py:168-217): reflection at
+    coszen = -1 / +1, bin volumes, block sums of the oversampling, coszen back to its axis"""
+    l, cz_bin = g["l"], g["cz_bin"]
+
     def reflect(h):   # kde_hist.py:168-190
         if g["reflect_lower"]:
             h0 = np.flipud(np.concatenate([np.zeros(g["minishape"]), h[0:l, :]]))
@@ -201,9 +212,7 @@ def get_hist(sample, binning, weights=None, bw_method="scott", adaptive=True, al
         hist = np.swapaxes(hist, 0, cz_bin)
         if errors is not None:
             errors = np.swapaxes(errors, 0, cz_bin)
-    if errors is not None:
-        return hist * norm, errors * norm
-    return hist * norm
+    return hist, errors
 
 
 def pid_channels(sample, binning):
@@ -261,3 +270,83 @@ def kde_histogramdd(sample, binning, weights=None, bw_method="scott", adaptive=T
         if errors is not None:
             errors = np.swapaxes(errors, pid_bin, 2)
     return (hist, errors) if bootstrap else hist
+
+
+def _lattice_of(axes):
+    """(origin, step, count) if every axis has >= 2 ascending points at uniform steps, else None"""
+    axes = [np.asarray(a, dtype=np.float64) for a in axes]
+    if all(len(a) >= 2 and a[-1] > a[0] and np.allclose(np.diff(a), (a[-1] - a[0]) / (len(a) - 1), rtol=1e-9, atol=0.0)
+           for a in axes):
+        return [a[0] for a in axes], [(a[-1] - a[0]) / (len(a) - 1) for a in axes], [len(a) for a in axes]
+    return None
+
+
+def _job_sample(data, cz_bin):
+    """[n, D] device sample -> [D, n] contiguous with coszen first; kept on the tensor (static per channel)"""
+    cache = getattr(data, "_kde_x", None)
+    if cache is None:
+        cache = data._kde_x = {}
+    x = cache.get(cz_bin)
+    if x is None:
+        x = data.T.clone()
+        if cz_bin != 0:
+            x[[0, cz_bin]] = x[[cz_bin, 0]]
+        x = cache[cz_bin] = x.contiguous()
+    return x
+
+
+def kde_histogramdd_batch(samples, binning, bw_method="scott", adaptive=True, alpha=0.3, coszen_reflection=0.25,
+                          coszen_name="coszen", oversample=1, stack_pid=True, tol=None, stats=None, n_threads=0):
+    """`[kde_histogramdd(sample=s["sample"], weights=s["weights"], channels=s.get("channels"), ...) for s in
+    samples]` with all the estimators (one per sample and pid channel) built and evaluated by ONE native call
+    (`pisa_hip_kde_lattice_batch`, the estimators side by side on the library's own threads and streams) and
+    one copy of the densities to the host.  Device tensors only; without bootstrap.  The maps are those of the
+    one-by-one path bit for bit."""
+    jobs, owner = [], []
+    g = None
+    for si, smp in enumerate(samples):
+        sample, weights = smp["sample"], smp.get("weights")
+        if weights is not None and len(weights) != sample.shape[0]:
+            raise ValueError("Length of sample (%s) and weights (%s) incompatible" % (sample.shape[0], len(weights)))
+        if stack_pid:
+            pid_bin, d2d, chans = smp.get("channels") or pid_channels(sample, binning)
+            g = _evaluation_grid(d2d, oversample, coszen_name, coszen_reflection)
+            for idx, data in chans:
+                jobs.append((_job_sample(data, g["cz_bin"]), weights, idx if weights is not None else None))
+                owner.append((si, pid_bin))
+        else:
+            g = _evaluation_grid(binning, oversample, coszen_name, coszen_reflection)
+            jobs.append((_job_sample(sample, g["cz_bin"]), weights, None))
+            owner.append((si, None))
+    if not jobs:
+        return []
+    lat = _lattice_of(g["bin_points"])
+    if lat is None:   # evaluation points not on a lattice (an irregular binning): one by one, points written out
+        return [kde_histogramdd(sample=smp["sample"], binning=binning, weights=smp.get("weights"), bw_method=bw_method,
+                                adaptive=adaptive, alpha=alpha, coszen_reflection=coszen_reflection,
+                                coszen_name=coszen_name, oversample=oversample, stack_pid=stack_pid, tol=tol,
+                                stats=stats, channels=smp.get("channels")) for smp in samples]
+    dens, sums, pairs = K.kde_lattice_batch(jobs, lat[0], lat[1], lat[2], bw_method=bw_method, adaptive=adaptive, alpha=alpha,
+                                            tol=K.KDE_DEFAULT_TOL if tol is None else tol, n_threads=n_threads)
+    dens = dens.cpu().numpy()
+    if stats is not None:
+        stats["pairs_pilot"] = stats.get("pairs_pilot", 0) + pairs[0]
+        stats["pairs_eval"] = stats.get("pairs_eval", 0) + pairs[1]
+        stats["all_pairs"] = stats.get("all_pairs", 0) + sum(
+            int(j[0].shape[1]) * (int(j[0].shape[1]) * bool(adaptive) + g["n_points"]) for j in jobs)
+    per_sample = [[] for _ in samples]
+    pid_of = [None] * len(samples)
+    for k, (si, pid_bin) in enumerate(owner):
+        hist, _ = _finish_hist(g, dens[k].reshape(g["megashape"]), None, oversample)
+        per_sample[si].append(hist * sums[k])
+        pid_of[si] = pid_bin
+    out = []
+    for si, stack in enumerate(per_sample):
+        if not stack_pid:
+            out.append(stack[0])
+            continue
+        hist = np.dstack(stack)
+        if pid_of[si] != 2:
+            hist = np.swapaxes(hist, pid_of[si], 2)
+        out.append(hist)
+    return out

@@ -377,3 +377,37 @@ def test_get_hist_bootstrap_through_bootstrap_kde():
                                       bootstrap=True, bootstrap_niter=4)
     assert h3.shape == (10, 8, 2) == e3.shape and np.all(e3 > 0)
     np.testing.assert_allclose(h3.sum(), w.sum() * plain.sum() / w.sum(), rtol=5e-2)
+
+
+def test_kde_histogramdd_batch_equals_one_by_one():
+    """`kde_histogramdd_batch` (all estimators of several samples in one `pisa_hip_kde_lattice_batch` call, on the
+    library's own threads and streams) returns the maps of `kde_histogramdd` sample by sample, bit for bit --
+    with and without weights, NaN weights zeroed, with and without pid stacking, whatever the thread count"""
+    from pisa_amd import kernels as K
+    from pisa_amd.core.binning import MultiDimBinning, OneDimBinning
+    from pisa_amd.utils import kde_hist
+
+    rs = np.random.RandomState(11)
+    b3 = MultiDimBinning([OneDimBinning("energy", domain=[0.5, 3.5], num_bins=6, is_lin=True),
+                          OneDimBinning("coszen", domain=[-1, 1], num_bins=8, is_lin=True),
+                          OneDimBinning("pid", bin_edges=[0.0, 0.5, 1.0], is_lin=True)])
+    samples = []
+    for n in (30000, 21000, 45000):
+        s = np.stack([rs.randn(n) * 0.6 + 2.0, np.clip(rs.rand(n) * 2.2 - 1.1, -1, 1), (rs.rand(n) < 0.35) * 0.75], axis=1)
+        w = rs.rand(n) + 0.05
+        w[rs.rand(n) < 0.01] = np.nan
+        samples.append(dict(sample=K.to_device(s), weights=K.to_device(w)))
+    samples.append(dict(sample=samples[0]["sample"], weights=None))
+    kw = dict(bw_method="silverman", adaptive=True, alpha=0.3, coszen_name="coszen", coszen_reflection=0.25, oversample=5)
+    for stack_pid, binning in ((True, b3), (False, MultiDimBinning(list(b3)[:2]))):
+        smp = [dict(sample=s["sample"] if stack_pid else s["sample"][:, :2].contiguous(), weights=s["weights"]) for s in samples]
+        ref = [kde_hist.kde_histogramdd(sample=s["sample"], weights=s["weights"], binning=binning, stack_pid=stack_pid, **kw)
+               for s in smp]
+        for threads in (1, 3, 8):
+            got = kde_hist.kde_histogramdd_batch(smp, binning, stack_pid=stack_pid, n_threads=threads, **kw)
+            assert len(got) == len(ref)
+            for a, b in zip(got, ref):
+                assert a.shape == b.shape and np.all(np.isfinite(a))
+                np.testing.assert_array_equal(a, b)
+    with pytest.raises(ValueError):
+        kde_hist.kde_histogramdd_batch([dict(sample=samples[0]["sample"], weights=samples[1]["weights"])], b3, **kw)
