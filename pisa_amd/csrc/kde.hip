@@ -577,10 +577,11 @@ constexpr int LAT_SHARE = 64;   // sources per share
 __global__ void __launch_bounds__(256)
 kde_lattice_prep_kernel(const double *__restrict__ ys, const double *__restrict__ coef,
                         const double *__restrict__ s2, int64_t n, double da, double *__restrict__ rec) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one record entry per thread: coalesced stores
-    const int64_t k = e / LAT_REC;
-    if (k >= n) return;
-    const int slot = (int)(e - k * LAT_REC);
+    // 32 threads per record (24 entries + 8 idle: shifts instead of a 64-bit division by 24): a workgroup
+    // writes the 1 536 contiguous bytes of 8 records
+    const int64_t k = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int slot = threadIdx.x & 31;
+    if (k >= n || slot >= LAT_REC) return;
     const double v = s2[k];
     double out = 0.0;
     if (slot == 0) out = ys[k];
@@ -593,7 +594,7 @@ kde_lattice_prep_kernel(const double *__restrict__ ys, const double *__restrict_
         const int kk = slot - LAT_Q0 + 2;
         out = exp_nonpos(-v * da * da * (double)(kk * (kk - 1) / 2));
     }
-    rec[e] = out;
+    rec[k * LAT_REC + slot] = out;
 }
 
 // per share of the sorted sources: the (y_a, y_b) box outside which no lattice point is within the
@@ -693,7 +694,7 @@ kde_lattice_plan_kernel(const unsigned int *__restrict__ load, int n_patches, in
 // pace, the youngest ran alone at 40 % issue rate for the last third of the launch.
 constexpr int LAT_PIECE = 16;   // records per piece
 template <int R>
-__global__ void __launch_bounds__(64, 4)
+__global__ void __launch_bounds__(64, 3)   // <= 168 VGPRs: at four wavefronts per SIMD (128) the record loop spills
 kde_lattice_kernel(const KdeLattice L, double rcut2, const double *__restrict__ rec, int64_t n_src,
                    int64_t share, const double *__restrict__ box, const int32_t *__restrict__ wstart,
                    int n_patches, double *__restrict__ partial, unsigned long long *__restrict__ pair_count) {
@@ -768,17 +769,25 @@ kde_lattice_kernel(const KdeLattice L, double rcut2, const double *__restrict__ 
                 if (__builtin_amdgcn_ballot_w64(in)) {
                     if (in) {
                         strips++;
+                        // the first half of the Q table is requested before the exponentials, the second half
+                        // while the first is used (LDS broadcast reads)
+                        double Q[C + 1];
+#pragma unroll
+                        for (int kk = 2; kk <= C / 2; kk++) Q[kk] = cur[LAT_Q0 + kk - 2];
+                        __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink the reads to their first use)
                         const double gc = cf * exp_nonpos(sh * __builtin_fma(xc, xc, dbb * dbb));
                         double r_up, r_dn;
                         exp_pair(shd * xc, h, r_up, r_dn);   // g(c+1) / g(c), g(c-1) / g(c)
+#pragma unroll
+                        for (int kk = C / 2 + 1; kk <= C; kk++) Q[kk] = cur[LAT_Q0 + kk - 2];
+                        __builtin_amdgcn_sched_barrier(0);
                         double pu = gc, pd = gc * r_dn;
 #pragma unroll
                         for (int kk = 0; kk < C; kk++) {   // both directions interleaved: two independent chains
                             // up: point C + kk (k = kk); down: point C - 1 - kk (k = kk + 1)
-                            acc[C + kk] = kk < 2 ? acc[C + kk] + pu : __builtin_fma(pu, cur[LAT_Q0 + kk - 2], acc[C + kk]);
+                            acc[C + kk] = kk < 2 ? acc[C + kk] + pu : __builtin_fma(pu, Q[kk], acc[C + kk]);
                             if (kk + 1 < R - C) pu *= r_up;
-                            acc[C - 1 - kk] = kk + 1 < 2 ? acc[C - 1 - kk] + pd
-                                                         : __builtin_fma(pd, cur[LAT_Q0 + kk + 1 - 2], acc[C - 1 - kk]);
+                            acc[C - 1 - kk] = kk + 1 < 2 ? acc[C - 1 - kk] + pd : __builtin_fma(pd, Q[kk + 1], acc[C - 1 - kk]);
                             if (kk + 1 < C) pd *= r_dn;
                         }
                     }
@@ -948,9 +957,10 @@ kde_hermite_coef_kernel(KdeGeom g, const int32_t *__restrict__ dense_cells,
                 const double d = (sy[(int64_t)which * n_src + base + j] - (which ? c2 : c1)) * RSQRT2;
                 double v = which ? coef[base + j] : 1.0;   // the weight rides on the second factor
                 double *dst = which ? pb[j] : pa[j];
+#pragma unroll
                 for (int n = 0; n < P; n++) {
                     dst[n] = v;
-                    v = v * d / (double)(n + 1);
+                    v = v * d * (1.0 / (double)(n + 1));   // (the reciprocal is a compile-time constant)
                 }
             }
         }
@@ -1235,6 +1245,167 @@ kde_h2l_kernel(KdeGeom g, const int32_t *__restrict__ tcells, const int32_t *__r
     }
 }
 
+// The same two passes with FOUR consecutive targets of the convolution direction per workgroup and a 4 x 4
+// register tile per thread (25 tiles x 4 targets = 100 of 128 threads): a source matrix is staged to LDS once
+// for the up to four targets that use it (with four different Hankel rows), and a thread reads 5 LDS values per
+// 16 multiply-adds (the Hankel window slides in registers) instead of 3 per 4.  Every element is summed in the
+// order of the kernel above (offsets ascending = sources descending, inner index ascending): same bits.
+//   pass 0   grid (nx, ceil(ny / 4)):  V[cy_C][cx] for cy_C = 4 q .. 4 q + 3
+//   pass 1   grid (ceil(nx / 4), ny):  L[head of (cx_C, cy)] for cx_C = 4 q .. 4 q + 3 (cells with sources only)
+constexpr int H2L4_T = 4;
+template <int P, int PASS>
+__global__ void __launch_bounds__(H2L_THREADS)
+kde_h2l4_kernel(KdeGeom g, const int32_t *__restrict__ hslot, const int32_t *__restrict__ slot,
+                const double *__restrict__ herm, const double *__restrict__ hankel, int reach,
+                double *__restrict__ V, uint8_t *__restrict__ vflag, double *__restrict__ local) {
+    constexpr int NH = 2 * P - 1, PT = (P + 3) / 4, PR = PT * 4, PP = P * P;
+    constexpr int NHP = NH + 8;                                 // padded Hankel row (tiles beyond P read past NH)
+    constexpr int PER = (PP + H2L_THREADS - 1) / H2L_THREADS;   // matrix elements a thread stages
+    static_assert(PT * PT * H2L4_T <= H2L_THREADS, "tiles x targets must fit the workgroup");
+    __shared__ double sA[PR * PR];                              // [row][col], row stride PR, zero beyond P
+    __shared__ double sH[(2 * H2L_MAX_REACH + 1) * NHP];
+    const int t = threadIdx.x;
+    const int tg = t / (PT * PT), tile = t % (PT * PT);
+    const bool act = tg < H2L4_T;
+    const int ti = tile / PT, tj = tile % PT;
+    for (int i = t; i < (2 * reach + 1) * NHP; i += H2L_THREADS) {
+        const int row = i / NHP, col = i % NHP;
+        sH[i] = col < NH ? hankel[row * NH + col] : 0.0;
+    }
+    for (int i = t; i < PR * PR; i += H2L_THREADS) sA[i] = 0.0;
+    const int nx = g.nc[0], ny = g.nc[1];
+    // targets of this workgroup along the convolution direction: u0 .. u0 + 3; the fixed coordinate: w
+    const int u0 = (PASS == 0 ? (int)blockIdx.y : (int)blockIdx.x) * H2L4_T;
+    const int w = PASS == 0 ? (int)blockIdx.x : (int)blockIdx.y;
+    const int nu = PASS == 0 ? ny : nx;
+    const int my_u = u0 + tg;                                   // this thread's target
+    bool my_target = act && my_u < nu;
+    int my_head = -1;
+    if (PASS == 1 && my_target) {
+        my_head = hslot[(int64_t)w * nx + my_u];
+        my_target = my_head >= 0;
+    }
+    if (PASS == 1 && !__syncthreads_or(my_target)) return;     // no cell with sources among the four
+    double acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = 0.0;
+    bool any = false;
+    // source matrix at position v of the convolution direction, or nullptr (workgroup-uniform)
+    auto source = [&](int v) -> const double * {
+        if (v < 0 || v >= nu) return nullptr;
+        if (PASS == 0) {
+            const int sl = slot[(int64_t)v * nx + w];           // source cell (cx = w, cy_B = v)
+            return sl < 0 ? nullptr : herm + (int64_t)sl * PP;
+        }
+        const int64_t cb = (int64_t)w * nx + v;                 // V of (cx_B = v, cy = w)
+        return vflag[cb] ? V + cb * PP : nullptr;
+    };
+    auto fetch = [&](const double *src, double (&buf)[PER]) {
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int e = t + u * H2L_THREADS;
+            buf[u] = (src && e < PP) ? src[e] : 0.0;
+        }
+    };
+    // sources from the highest position down: for every target the offsets o = target - source ascend
+    const int v_hi = u0 + H2L4_T - 1 + reach < nu - 1 ? u0 + H2L4_T - 1 + reach : nu - 1;
+    const int v_lo = u0 - reach > 0 ? u0 - reach : 0;
+    int v = v_hi;
+    const double *src = source(v);
+    while (!src && v > v_lo) src = source(--v);
+    double mine[PER], ahead[PER];
+    fetch(src, mine);
+    while (src) {
+        int vn = v - 1;
+        const double *nxt = vn >= v_lo ? source(vn) : nullptr;
+        while (!nxt && vn > v_lo) nxt = source(--vn);
+        fetch(nxt, ahead);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int e = t + u * H2L_THREADS;
+            if (e < PP) sA[(e / P) * PR + e % P] = mine[u];
+        }
+        __syncthreads();
+        const int o = my_u - v;
+        if (my_target && o >= -reach && o <= reach) {
+            any = true;
+            const double *hk = sH + (o + reach) * NHP;
+            if (PASS == 0) {             // W[alpha][l] += sum_beta A[alpha][beta] h_{beta + l}(d2)
+                const double *r = sA + (4 * ti) * PR, *h = hk + 4 * tj;
+                double h0 = h[0], h1 = h[1], h2 = h[2];
+#pragma unroll
+                for (int b = 0; b < P; b++) {
+                    const double h3 = h[b + 3];
+                    const double a0 = r[b], a1 = r[PR + b], a2 = r[2 * PR + b], a3 = r[3 * PR + b];
+                    acc[0][0] = __builtin_fma(a0, h0, acc[0][0]); acc[0][1] = __builtin_fma(a0, h1, acc[0][1]);
+                    acc[0][2] = __builtin_fma(a0, h2, acc[0][2]); acc[0][3] = __builtin_fma(a0, h3, acc[0][3]);
+                    acc[1][0] = __builtin_fma(a1, h0, acc[1][0]); acc[1][1] = __builtin_fma(a1, h1, acc[1][1]);
+                    acc[1][2] = __builtin_fma(a1, h2, acc[1][2]); acc[1][3] = __builtin_fma(a1, h3, acc[1][3]);
+                    acc[2][0] = __builtin_fma(a2, h0, acc[2][0]); acc[2][1] = __builtin_fma(a2, h1, acc[2][1]);
+                    acc[2][2] = __builtin_fma(a2, h2, acc[2][2]); acc[2][3] = __builtin_fma(a2, h3, acc[2][3]);
+                    acc[3][0] = __builtin_fma(a3, h0, acc[3][0]); acc[3][1] = __builtin_fma(a3, h1, acc[3][1]);
+                    acc[3][2] = __builtin_fma(a3, h2, acc[3][2]); acc[3][3] = __builtin_fma(a3, h3, acc[3][3]);
+                    h0 = h1; h1 = h2; h2 = h3;
+                }
+            } else {                     // L[k][l] += sum_alpha h_{alpha + k}(d1) V[alpha][l]
+                const double *h = hk + 4 * ti, *c = sA + 4 * tj;
+                double h0 = h[0], h1 = h[1], h2 = h[2];
+#pragma unroll
+                for (int a = 0; a < P; a++) {
+                    const double h3 = h[a + 3];
+                    const double v0 = c[a * PR], v1 = c[a * PR + 1], v2 = c[a * PR + 2], v3 = c[a * PR + 3];
+                    acc[0][0] = __builtin_fma(h0, v0, acc[0][0]); acc[0][1] = __builtin_fma(h0, v1, acc[0][1]);
+                    acc[0][2] = __builtin_fma(h0, v2, acc[0][2]); acc[0][3] = __builtin_fma(h0, v3, acc[0][3]);
+                    acc[1][0] = __builtin_fma(h1, v0, acc[1][0]); acc[1][1] = __builtin_fma(h1, v1, acc[1][1]);
+                    acc[1][2] = __builtin_fma(h1, v2, acc[1][2]); acc[1][3] = __builtin_fma(h1, v3, acc[1][3]);
+                    acc[2][0] = __builtin_fma(h2, v0, acc[2][0]); acc[2][1] = __builtin_fma(h2, v1, acc[2][1]);
+                    acc[2][2] = __builtin_fma(h2, v2, acc[2][2]); acc[2][3] = __builtin_fma(h2, v3, acc[2][3]);
+                    acc[3][0] = __builtin_fma(h3, v0, acc[3][0]); acc[3][1] = __builtin_fma(h3, v1, acc[3][1]);
+                    acc[3][2] = __builtin_fma(h3, v2, acc[3][2]); acc[3][3] = __builtin_fma(h3, v3, acc[3][3]);
+                    h0 = h1; h1 = h2; h2 = h3;
+                }
+            }
+        }
+        src = nxt;
+        v = vn;
+#pragma unroll
+        for (int u = 0; u < PER; u++) mine[u] = ahead[u];
+    }
+    if (PASS == 0) {
+        if (act && my_u < nu) {
+            const int64_t c = (int64_t)my_u * nx + w;
+            if (tile == 0) vflag[c] = any ? 1 : 0;
+            if (any) {
+#pragma unroll
+                for (int di = 0; di < 4; di++)
+#pragma unroll
+                    for (int dj = 0; dj < 4; dj++) {
+                        const int r0 = 4 * ti + di, r1 = 4 * tj + dj;
+                        if (r0 < P && r1 < P) V[c * PP + r0 * P + r1] = acc[di][dj];
+                    }
+            }
+        }
+    } else if (my_target) {
+#pragma unroll
+        for (int di = 0; di < 4; di++)
+#pragma unroll
+            for (int dj = 0; dj < 4; dj++) {
+                const int r0 = 4 * ti + di, r1 = 4 * tj + dj;
+                if (r0 < P && r1 < P) {
+                    // D_k D_l = (-1)^(k+l) / (k! l!)
+                    double fk = 1.0, fl = 1.0;
+                    for (int i = 2; i <= r0; i++) fk *= (double)i;
+                    for (int i = 2; i <= r1; i++) fl *= (double)i;
+                    const double sgn = ((r0 + r1) & 1) ? -1.0 : 1.0;
+                    local[(int64_t)my_head * PP + r0 * P + r1] = sgn * acc[di][dj] / (fk * fl);
+                }
+            }
+    }
+}
+
 // pilot densities at the (cell-sorted) sources: the local expansion of the target's cell for all
 // dense cells in range + direct sums over the sparse ones.
 template <int P, bool SPARSE>
@@ -1498,7 +1669,7 @@ PISA_API int64_t pisa_hip_kde_workspace_bytes(int32_t dim, int64_t n_src) {
     total += n * 8 + split_bytes(n_src);                 // pilot, split partials
     total += sort_temp_bytes(n_src) + (n / Q_CHUNK + (size_t)cells_cap(n_src)) * sizeof(KdeBlock);
     if (dim == 2)   // cell -> slot map, lists of dense / non-empty cells (the coefficients live in library scratch)
-        total += (n / hermite_min() + 1) * 4 + (size_t)cells_cap(n_src) * 8 + 4096;   // dense list: one entry per cell at most
+        total += (n / hermite_min() + 1) * 4 + (size_t)cells_cap(n_src) * 12 + 4096;   // dense list: one entry per cell at most
     return (int64_t)(total + 64 * 256);
 }
 
@@ -1763,6 +1934,7 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
             int32_t *d_dense = ar.take<int32_t>(dense.size());
             int32_t *slot = ar.take<int32_t>(k->n_cells);
             int32_t *d_tcells = ar.take<int32_t>(n_heads);
+            int32_t *hslot = ar.take<int32_t>(k->n_cells);   // cell -> index among the non-empty cells
             if (!ar.ok) KDE_FAIL(PISA_HIP_ERR_NOMEM);
             KDE_TRY_HIP(hipMemcpyAsync(d_dense, dense.data(), dense.size() * sizeof(int32_t),
                                        hipMemcpyHostToDevice, s));
@@ -1797,16 +1969,27 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
                                            hipMemcpyHostToDevice, s));
                 KDE_TRY_HIP(hipMemcpyAsync(d_hankel, hankel.data(), hankel.size() * sizeof(double),
                                            hipMemcpyHostToDevice, s));
+                KDE_TRY_HIP(hipMemsetAsync(hslot, 0xFF, (size_t)k->n_cells * sizeof(int32_t), s));
+                hipLaunchKernelGGL(kde_slot_scatter_kernel, dim3((unsigned)((n_heads + 255) / 256)), dim3(256), 0, s,
+                                   d_tcells, n_heads, hslot);
             }
             dim3 grid((unsigned)n_blocks, (unsigned)n_split);
+            static const bool h2l_tiled = [] { const char *v = getenv("PISA_HIP_KDE_H2L_TILED"); return !v || atoi(v) != 0; }();
 #define KDE_FGT(PP) do { \
                 hipLaunchKernelGGL(kde_hermite_coef_kernel<PP>, dim3((unsigned)nd), dim3(256), 0, s, g, d_dense, \
                                    k->cell_start, k->ys, n, k->coef, herm); \
                 if (local_exp) { \
-                    hipLaunchKernelGGL((kde_h2l_kernel<PP, 0>), dim3((unsigned)k->n_cells), dim3(H2L_THREADS), 0, s, g, d_tcells, \
-                                       slot, herm, d_hankel, reach, d_V, d_vflag, local); \
-                    hipLaunchKernelGGL((kde_h2l_kernel<PP, 1>), dim3((unsigned)n_heads), dim3(H2L_THREADS), 0, s, g, d_tcells, \
-                                       slot, herm, d_hankel, reach, d_V, d_vflag, local); \
+                    if (h2l_tiled) { \
+                        hipLaunchKernelGGL((kde_h2l4_kernel<PP, 0>), dim3((unsigned)g.nc[0], (unsigned)((g.nc[1] + H2L4_T - 1) / H2L4_T)), \
+                                           dim3(H2L_THREADS), 0, s, g, hslot, slot, herm, d_hankel, reach, d_V, d_vflag, local); \
+                        hipLaunchKernelGGL((kde_h2l4_kernel<PP, 1>), dim3((unsigned)((g.nc[0] + H2L4_T - 1) / H2L4_T), (unsigned)g.nc[1]), \
+                                           dim3(H2L_THREADS), 0, s, g, hslot, slot, herm, d_hankel, reach, d_V, d_vflag, local); \
+                    } else { \
+                        hipLaunchKernelGGL((kde_h2l_kernel<PP, 0>), dim3((unsigned)k->n_cells), dim3(H2L_THREADS), 0, s, g, d_tcells, \
+                                           slot, herm, d_hankel, reach, d_V, d_vflag, local); \
+                        hipLaunchKernelGGL((kde_h2l_kernel<PP, 1>), dim3((unsigned)n_heads), dim3(H2L_THREADS), 0, s, g, d_tcells, \
+                                           slot, herm, d_hankel, reach, d_V, d_vflag, local); \
+                    } \
                     if (nd < n_heads) \
                         hipLaunchKernelGGL((kde_local_pilot_kernel<PP, true>), dim3((unsigned)n_blocks), dim3(KDE_THREADS), 0, s, g, \
                                            d_blocks, k->ys, n, k->coef, k->cell_start, slot, local, pilot, k->pair_count); \
@@ -1985,7 +2168,7 @@ static int64_t lattice_patches(int R, int sw, const int64_t *count) {
 // number of wavefronts of the lattice kernel (>= one per patch)
 static int64_t lattice_waves(int R, int sw, const int64_t *count, int64_t n) {
     const int64_t patches = lattice_patches(R, sw, count);
-    static const int waves = [] { const char *v = getenv("PISA_HIP_KDE_LATTICE_WAVES"); return v ? atoi(v) : 4096; }();
+    static const int waves = [] { const char *v = getenv("PISA_HIP_KDE_LATTICE_WAVES"); return v ? atoi(v) : 3072; }();
     int64_t w = std::max<int64_t>(patches, waves);
     w = std::min<int64_t>(w, std::max<int64_t>(patches, (int64_t)(128 << 20) / (R * 64 * 8)));     // partial sums <= 128 MB
     (void)n;   // (the plan gives a patch no more wavefronts than it has shares within reach)
@@ -2063,7 +2246,7 @@ PISA_API int pisa_hip_kde_evaluate_lattice(pisa_hip_kde *k, const double *h_orig
     unsigned int *load = ar.take<unsigned int>((size_t)n_patches);
     int32_t *wstart = ar.take<int32_t>((size_t)n_patches + 1);
     if (!ar.ok) return PISA_HIP_ERR_NOMEM;
-    hipLaunchKernelGGL(kde_lattice_prep_kernel, dim3((unsigned)((k->n * LAT_REC + 255) / 256)), dim3(256), 0, s, k->ys,
+    hipLaunchKernelGGL(kde_lattice_prep_kernel, dim3((unsigned)((k->n + 7) / 8)), dim3(256), 0, s, k->ys,
                        k->coef, k->s2, k->n, L.da, rec);
     hipLaunchKernelGGL(kde_lattice_box_kernel, dim3((unsigned)n_shares), dim3(64), 0, s, rec, k->n, share, g.rcut2, box);
     hipLaunchKernelGGL(kde_lattice_load_kernel, dim3((unsigned)n_patches), dim3(256), 0, s, L, R, box, n_shares, load);

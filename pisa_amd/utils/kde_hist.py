@@ -272,6 +272,27 @@ def kde_histogramdd(sample, binning, weights=None, bw_method="scott", adaptive=T
     return (hist, errors) if bootstrap else hist
 
 
+def _finish_hist_many(g, dens, oversample):
+    """`_finish_hist` for a stack of density arrays [k, megashape...]: the same element operations, once"""
+    l, cz_bin = g["l"], g["cz_bin"]
+    k = dens.shape[0]
+    h = dens
+    h0 = h1 = 0
+    if g["reflect_lower"]:
+        h0 = np.flip(np.concatenate([np.zeros((k,) + tuple(g["minishape"])), h[:, 0:l, :]], axis=1), axis=1)
+        h = h[:, l:, :]
+    if g["reflect_upper"]:
+        h1 = np.flip(np.concatenate([h[:, -l:, :], np.zeros((k,) + tuple(g["minishape"]))], axis=1), axis=1)
+        h = h[:, :-l, :]
+    hist = (h + h1 + h0) * g["volumes"]
+    if oversample != 1:
+        for i, at in enumerate(g["reduce_at"]):
+            hist = np.add.reduceat(hist, at, axis=i + 1)
+    if cz_bin != 0:
+        hist = np.swapaxes(hist, 1, cz_bin + 1)
+    return hist
+
+
 def _lattice_of(axes):
     """(origin, step, count) if every axis has >= 2 ascending points at uniform steps, else None"""
     axes = [np.asarray(a, dtype=np.float64) for a in axes]
@@ -336,9 +357,9 @@ def kde_histogramdd_batch(samples, binning, bw_method="scott", adaptive=True, al
             int(j[0].shape[1]) * (int(j[0].shape[1]) * bool(adaptive) + g["n_points"]) for j in jobs)
     per_sample = [[] for _ in samples]
     pid_of = [None] * len(samples)
+    hists = _finish_hist_many(g, dens.reshape((len(jobs),) + tuple(g["megashape"])), oversample) * np.asarray(sums)[:, None, None]
     for k, (si, pid_bin) in enumerate(owner):
-        hist, _ = _finish_hist(g, dens[k].reshape(g["megashape"]), None, oversample)
-        per_sample[si].append(hist * sums[k])
+        per_sample[si].append(hists[k])
         pid_of[si] = pid_bin
     out = []
     for si, stack in enumerate(per_sample):

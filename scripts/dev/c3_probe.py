@@ -20,11 +20,14 @@ out[("data", "synthetic_events")]["params"].params.n_events.value = n
 t0 = time.perf_counter()
 pipe = Pipeline(out, profile=True)
 print("setup %.2f s" % (time.perf_counter() - t0), flush=True)
-for it in range(4):
+times = []
+for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 4):
     pipe.params.theta23.value = (42.0 + it) * ureg.degree
     torch.cuda.synchronize(); t0 = time.perf_counter()
     maps = pipe.get_outputs()
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     st = pipe["kde"].stats
+    times.append(dt)
     print(json.dumps(dict(it=it, s=dt, total=float(sum(m.hist.sum() for m in maps)), **st)), flush=True)
+print(json.dumps(dict(median_ms=round(1e3 * float(np.median(times[1:])), 2), min_ms=round(1e3 * min(times[1:]), 2), n=len(times) - 1)))
 pipe.report_profile()

@@ -23,13 +23,14 @@ out[("data", "synthetic_events")]["params"].params.n_events.value = n
 pipe = Pipeline(out)
 stage = pipe["kde"]
 captured = []
-_orig = kde_hist.kde_histogramdd
-def _capture(weights=None, **kw):   # the event weights as the stage hands them over
-    captured.append((weights.clone(), kw))
-    return _orig(weights=weights, **kw)
-kde_hist.kde_histogramdd = _capture
+_orig = kde_hist.kde_histogramdd_batch
+def _capture(samples, *a, **kw):   # the event weights as the stage hands them over
+    for smp in samples:
+        captured.append((smp["weights"].clone(), dict(channels=smp["channels"])))
+    return _orig(samples, *a, **kw)
+kde_hist.kde_histogramdd_batch = _capture
 pipe.get_outputs()
-kde_hist.kde_histogramdd = _orig
+kde_hist.kde_histogramdd_batch = _orig
 jobs = []
 for w, kw in captured[:nc]:
     pid_bin, d2d, chans = kw["channels"]

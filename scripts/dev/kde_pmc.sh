@@ -10,7 +10,7 @@ pass () {  # tag, counters...
 }
 pass a SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY
 pass b SQ_INSTS_SMEM SQ_INSTS_SALU SQ_INST_CYCLES_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_WAIT_ANY
-pass c SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VALU SQ_INST_CYCLES_SALU SQ_IFETCH SQ_INST_LEVEL_SMEM SQ_LEVEL_WAVES
+pass c SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
 python3 - $OUT <<'PY'
 import csv, sys, collections
 out = sys.argv[1]
@@ -23,4 +23,10 @@ for tag in "abc":
                 acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for key, d in acc.items():
         print(tag, key, {c: "%.4g" % (sum(v) / len(v)) for c, v in d.items()})
+    if tag == "a":
+        for key, d in acc.items():
+            n = len(d["SQ_WAVES"])
+            valu = sum(d["SQ_ACTIVE_INST_VALU"]) / n / 1024 * 4; busy = sum(d["SQ_BUSY_CYCLES"]) / n / 32
+            print("   ", key, "VALU busy fraction %.2f, wait fraction of wave cycles %.2f, mean wave lifetime / launch %.2f" % (
+                valu / busy, sum(d["SQ_WAIT_INST_ANY"]) / sum(d["SQ_WAVE_CYCLES"]), sum(d["SQ_WAVE_CYCLES"]) / sum(d["SQ_WAVES"]) * 4 / busy))
 PY
