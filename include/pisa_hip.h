@@ -474,6 +474,14 @@ typedef struct pisa_hip_kde_job {
 int pisa_hip_kde_lattice_batch(pisa_hip_kde_job *jobs, int32_t n_jobs, int32_t dim, int32_t bw_method,
                                int32_t adaptive, double alpha, double tol, const double *h_origin,
                                const double *h_step, const int64_t *h_count, int32_t n_threads, void *stream);
+/* The same in two steps, for a caller that produces the inputs sample by sample (the stage materialises the
+ * event weights of one container while the estimators of the previous ones run): _submit queues the jobs and
+ * returns (the job array must stay alive and untouched), _wait returns when every job submitted so far is done;
+ * then each job's `status` says how it went. */
+int pisa_hip_kde_lattice_submit(pisa_hip_kde_job *jobs, int32_t n_jobs, int32_t dim, int32_t bw_method,
+                                int32_t adaptive, double alpha, double tol, const double *h_origin,
+                                const double *h_step, const int64_t *h_count, int32_t n_threads, void *stream);
+int pisa_hip_kde_lattice_wait(void);
 
 /* How the 2-D fixed-bandwidth pilot estimate sums its cells (fast Gauss transform; truncation error below
  * the cut-off tolerance): 2 (default) = Hermite series of ALL non-empty source cells translated into one

@@ -574,27 +574,36 @@ constexpr int LAT_REC = 24;
 constexpr int LAT_Q0 = 8;
 constexpr int LAT_QMAX = 16;
 constexpr int LAT_SHARE = 64;   // sources per share
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 kde_lattice_prep_kernel(const double *__restrict__ ys, const double *__restrict__ coef,
                         const double *__restrict__ s2, int64_t n, double da, double *__restrict__ rec) {
-    // 32 threads per record (24 entries + 8 idle: shifts instead of a 64-bit division by 24): a workgroup
-    // writes the 1 536 contiguous bytes of 8 records
-    const int64_t k = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
-    const int slot = threadIdx.x & 31;
-    if (k >= n || slot >= LAT_REC) return;
-    const double v = s2[k];
-    double out = 0.0;
-    if (slot == 0) out = ys[k];
-    else if (slot == 1) out = ys[n + k];
-    else if (slot == 2) out = coef[k];
-    else if (slot == 3) out = -0.5 * v;
-    else if (slot == 4) out = -v * da;
-    else if (slot == 5) out = exp_nonpos(-0.5 * v * da * da);
-    else if (slot >= LAT_Q0 && slot <= LAT_Q0 + LAT_QMAX - 2) {
-        const int kk = slot - LAT_Q0 + 2;
-        out = exp_nonpos(-v * da * da * (double)(kk * (kk - 1) / 2));
+    // one source per thread; the 64 records of a wavefront go through LDS so that they leave as 16-byte
+    // stores of consecutive lanes (12 KB contiguous per wavefront)
+    typedef double __attribute__((ext_vector_type(2))) d2;
+    __shared__ __attribute__((aligned(16))) double stage[64 * LAT_REC];
+    const int lane = threadIdx.x;
+    const int64_t k0 = (int64_t)blockIdx.x * 64, k = k0 + lane;
+    if (k < n) {
+        const double v = s2[k];
+        double *r = stage + lane * LAT_REC;
+        r[0] = ys[k];
+        r[1] = ys[n + k];
+        r[2] = coef[k];
+        r[3] = -0.5 * v;
+        r[4] = -v * da;
+        r[5] = exp_nonpos(-0.5 * v * da * da);
+        r[6] = 0.0;
+        r[7] = 0.0;
+#pragma unroll
+        for (int kk = 2; kk <= LAT_QMAX; kk++) r[LAT_Q0 + kk - 2] = exp_nonpos(-v * da * da * (double)(kk * (kk - 1) / 2));
+        r[LAT_Q0 + LAT_QMAX - 1] = 0.0;
     }
-    rec[k * LAT_REC + slot] = out;
+    __syncthreads();
+    const int64_t n_here = n - k0 < 64 ? n - k0 : 64;
+    const int n_d2 = (int)n_here * (LAT_REC / 2);
+    const d2 *src = reinterpret_cast<const d2 *>(stage);
+    d2 *dst = reinterpret_cast<d2 *>(rec + k0 * LAT_REC);
+    for (int i = lane; i < n_d2; i += 64) dst[i] = src[i];
 }
 
 // per share of the sorted sources: the (y_a, y_b) box outside which no lattice point is within the
@@ -2246,7 +2255,7 @@ PISA_API int pisa_hip_kde_evaluate_lattice(pisa_hip_kde *k, const double *h_orig
     unsigned int *load = ar.take<unsigned int>((size_t)n_patches);
     int32_t *wstart = ar.take<int32_t>((size_t)n_patches + 1);
     if (!ar.ok) return PISA_HIP_ERR_NOMEM;
-    hipLaunchKernelGGL(kde_lattice_prep_kernel, dim3((unsigned)((k->n + 7) / 8)), dim3(256), 0, s, k->ys,
+    hipLaunchKernelGGL(kde_lattice_prep_kernel, dim3((unsigned)((k->n + 63) / 64)), dim3(64), 0, s, k->ys,
                        k->coef, k->s2, k->n, L.da, rec);
     hipLaunchKernelGGL(kde_lattice_box_kernel, dim3((unsigned)n_shares), dim3(64), 0, s, rec, k->n, share, g.rcut2, box);
     hipLaunchKernelGGL(kde_lattice_load_kernel, dim3((unsigned)n_patches), dim3(256), 0, s, L, R, box, n_shares, load);

@@ -10,11 +10,13 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #include <algorithm>
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -60,6 +62,7 @@ static int grow(void **buf, size_t *have, size_t need, hipStream_t s) {
 
 class KdePool {
   public:
+    typedef std::function<void(KdeWorkerState &)> Task;
     ~KdePool() {
         {
             std::lock_guard<std::mutex> lk(m_);
@@ -68,38 +71,34 @@ class KdePool {
         cv_job_.notify_all();
         for (auto &t : threads_) t.join();
     }
-    // runs fn(i, state) for i in order[], on up to n_threads pool threads; returns when all are done
-    void run(const std::vector<int> &order, int n_threads, const std::function<void(int, KdeWorkerState &)> &fn) {
-        std::unique_lock<std::mutex> lk(m_);
+    // queues the tasks (in the given order) for up to n_threads pool threads and returns
+    void submit(std::vector<Task> &&tasks, int n_threads) {
+        std::lock_guard<std::mutex> lk(m_);
         while ((int)threads_.size() < n_threads) threads_.emplace_back([this] { loop(); });
-        // one batch at a time (a second caller waits here)
-        cv_done_.wait(lk, [this] { return pending_ == 0 && queue_.empty(); });
-        fn_ = &fn;
-        limit_ = n_threads;
-        for (int i : order) queue_.push_back(i);
-        pending_ = (int)order.size();
+        limit_ = std::max(limit_, n_threads);
+        pending_ += (int)tasks.size();
+        for (auto &t : tasks) queue_.push_back(std::move(t));
         cv_job_.notify_all();
+    }
+    // returns when everything submitted so far is done
+    void wait() {
+        std::unique_lock<std::mutex> lk(m_);
         cv_done_.wait(lk, [this] { return pending_ == 0; });
-        fn_ = nullptr;
+        limit_ = 0;
     }
 
   private:
     void loop() {
         KdeWorkerState st;
-        int my_id;
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            my_id = n_started_++;
-        }
         std::unique_lock<std::mutex> lk(m_);
+        const int my_id = n_started_++;
         for (;;) {
             cv_job_.wait(lk, [&] { return stop_ || (!queue_.empty() && my_id < limit_); });
             if (stop_) return;
-            const int i = queue_.front();
+            Task task = std::move(queue_.front());
             queue_.pop_front();
-            const auto *fn = fn_;
             lk.unlock();
-            (*fn)(i, st);
+            task(st);
             lk.lock();
             if (--pending_ == 0) cv_done_.notify_all();
         }
@@ -107,8 +106,7 @@ class KdePool {
     std::mutex m_;
     std::condition_variable cv_job_, cv_done_;
     std::vector<std::thread> threads_;
-    std::deque<int> queue_;
-    const std::function<void(int, KdeWorkerState &)> *fn_ = nullptr;
+    std::deque<Task> queue_;
     int pending_ = 0, limit_ = 0, n_started_ = 0;
     bool stop_ = false;
 };
@@ -122,10 +120,67 @@ static KdePool &pool() {
 
 using namespace pisa;
 
-PISA_API int pisa_hip_kde_lattice_batch(pisa_hip_kde_job *jobs, int32_t n_jobs, int32_t dim, int32_t bw_method,
-                                        int32_t adaptive, double alpha, double tol, const double *h_origin,
-                                        const double *h_step, const int64_t *h_count, int32_t n_threads,
-                                        void *stream) {
+namespace pisa {
+
+struct KdeBatchParams {
+    int32_t dim, bw_method, adaptive;
+    double alpha, tol;
+    double origin[3], step[3];
+    int64_t count[3];
+    int device;
+};
+
+static int run_job(pisa_hip_kde_job &job, const KdeBatchParams &P, hipEvent_t ready, KdeWorkerState &st) {
+    if (st.device != P.device) {
+        PISA_TRY_HIP(hipSetDevice(P.device));
+        if (st.stream) { (void)hipStreamDestroy(st.stream); st.stream = nullptr; }
+        if (st.work) { (void)hipFree(st.work); st.work = nullptr; st.work_bytes = 0; }
+        if (st.lwork) { (void)hipFree(st.lwork); st.lwork = nullptr; st.lwork_bytes = 0; }
+        PISA_TRY_HIP(hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking));
+        st.device = P.device;
+    }
+    hipStream_t s = st.stream;
+    PISA_TRY_HIP(hipStreamWaitEvent(s, ready, 0));
+    const int64_t need = pisa_hip_kde_workspace_bytes(P.dim, job.n);
+    if (need < 0) return PISA_HIP_ERR_INVALID;
+    const size_t wbytes = (((size_t)job.n * 8) + 255) & ~(size_t)255;
+    int rc = grow(&st.work, &st.work_bytes, (size_t)need + wbytes, s);
+    if (rc != PISA_HIP_OK) return rc;
+    const double *d_w = nullptr;
+    if (job.d_weights) {
+        double *w = (double *)st.work;
+        hipLaunchKernelGGL(kde_job_weights_kernel, dim3((unsigned)((job.n + 255) / 256)), dim3(256), 0, s,
+                           job.d_weights, job.d_index, job.n, w);
+        PISA_CHECK_LAUNCH("kde_job_weights_kernel");
+        d_w = w;
+    }
+    pisa_hip_kde *k = nullptr;
+    rc = pisa_hip_kde_create(P.dim, job.d_x, d_w, job.n, P.bw_method, P.adaptive, P.alpha, P.tol,
+                             (char *)st.work + wbytes, need, &k, s);
+    if (rc != PISA_HIP_OK) return rc;
+    const int64_t lneed = pisa_hip_kde_lattice_workspace_bytes(k, P.step, P.count);
+    rc = lneed < 0 ? PISA_HIP_ERR_INVALID : grow(&st.lwork, &st.lwork_bytes, (size_t)lneed, s);
+    if (rc == PISA_HIP_OK)
+        rc = pisa_hip_kde_evaluate_lattice(k, P.origin, P.step, P.count, st.lwork, lneed, job.d_out, s);
+    pisa_hip_kde_info_t info;
+    if (rc == PISA_HIP_OK) rc = pisa_hip_kde_info(k, &info);
+    if (rc == PISA_HIP_OK) {
+        job.sum_w = info.sum_w;
+        job.pairs_pilot = info.pairs_pilot;
+        job.pairs_eval = info.pairs_eval;
+    }
+    (void)pisa_hip_kde_destroy(k);
+    if (rc != PISA_HIP_OK) return rc;
+    PISA_TRY_HIP(hipStreamSynchronize(s));
+    return PISA_HIP_OK;
+}
+
+}  // namespace pisa
+
+PISA_API int pisa_hip_kde_lattice_submit(pisa_hip_kde_job *jobs, int32_t n_jobs, int32_t dim, int32_t bw_method,
+                                         int32_t adaptive, double alpha, double tol, const double *h_origin,
+                                         const double *h_step, const int64_t *h_count, int32_t n_threads,
+                                         void *stream) {
     if (n_jobs < 0 || (n_jobs > 0 && !jobs) || !h_origin || !h_step || !h_count || dim < 1 || dim > 3)
         return PISA_HIP_ERR_INVALID;
     if (n_jobs == 0) return PISA_HIP_OK;
@@ -135,67 +190,42 @@ PISA_API int pisa_hip_kde_lattice_batch(pisa_hip_kde_job *jobs, int32_t n_jobs, 
         jobs[i].status = PISA_HIP_ERR_INVALID;
         jobs[i].sum_w = 0.0;
     }
-    int device = 0;
-    PISA_TRY_HIP(hipGetDevice(&device));
+    KdeBatchParams P;
+    memset(&P, 0, sizeof(P));
+    P.dim = dim; P.bw_method = bw_method; P.adaptive = adaptive; P.alpha = alpha; P.tol = tol;
+    for (int d = 0; d < dim; d++) { P.origin[d] = h_origin[d]; P.step[d] = h_step[d]; P.count[d] = h_count[d]; }
+    PISA_TRY_HIP(hipGetDevice(&P.device));
     // the inputs were produced on the caller's stream
-    hipEvent_t ready;
-    PISA_TRY_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
-    int rc0 = check_hip(hipEventRecord(ready, as_stream(stream)), "hipEventRecord");
-    if (rc0 != PISA_HIP_OK) { (void)hipEventDestroy(ready); return rc0; }
+    hipEvent_t ev;
+    PISA_TRY_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    int rc0 = check_hip(hipEventRecord(ev, as_stream(stream)), "hipEventRecord");
+    if (rc0 != PISA_HIP_OK) { (void)hipEventDestroy(ev); return rc0; }
+    std::shared_ptr<void> ready(ev, [](void *e) { (void)hipEventDestroy((hipEvent_t)e); });
     std::vector<int> order(n_jobs);
     for (int i = 0; i < n_jobs; i++) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return jobs[a].n > jobs[b].n; });   // longest first
-    const int nt = std::max(1, std::min<int>(n_threads > 0 ? n_threads : 8, n_jobs));
-    auto run = [&](int i, KdeWorkerState &st) {
-        pisa_hip_kde_job &job = jobs[i];
-        auto body = [&]() -> int {
-            if (st.device != device) {
-                PISA_TRY_HIP(hipSetDevice(device));
-                if (st.stream) { (void)hipStreamDestroy(st.stream); st.stream = nullptr; }
-                if (st.work) { (void)hipFree(st.work); st.work = nullptr; st.work_bytes = 0; }
-                if (st.lwork) { (void)hipFree(st.lwork); st.lwork = nullptr; st.lwork_bytes = 0; }
-                PISA_TRY_HIP(hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking));
-                st.device = device;
-            }
-            hipStream_t s = st.stream;
-            PISA_TRY_HIP(hipStreamWaitEvent(s, ready, 0));
-            const int64_t need = pisa_hip_kde_workspace_bytes(dim, job.n);
-            if (need < 0) return PISA_HIP_ERR_INVALID;
-            const size_t wbytes = (((size_t)job.n * 8) + 255) & ~(size_t)255;
-            int rc = grow(&st.work, &st.work_bytes, (size_t)need + wbytes, s);
-            if (rc != PISA_HIP_OK) return rc;
-            const double *d_w = nullptr;
-            if (job.d_weights) {
-                double *w = (double *)st.work;
-                hipLaunchKernelGGL(kde_job_weights_kernel, dim3((unsigned)((job.n + 255) / 256)), dim3(256), 0, s,
-                                   job.d_weights, job.d_index, job.n, w);
-                PISA_CHECK_LAUNCH("kde_job_weights_kernel");
-                d_w = w;
-            }
-            pisa_hip_kde *k = nullptr;
-            rc = pisa_hip_kde_create(dim, job.d_x, d_w, job.n, bw_method, adaptive, alpha, tol, (char *)st.work + wbytes,
-                                     need, &k, s);
-            if (rc != PISA_HIP_OK) return rc;
-            const int64_t lneed = pisa_hip_kde_lattice_workspace_bytes(k, h_step, h_count);
-            rc = lneed < 0 ? PISA_HIP_ERR_INVALID : grow(&st.lwork, &st.lwork_bytes, (size_t)lneed, s);
-            if (rc == PISA_HIP_OK)
-                rc = pisa_hip_kde_evaluate_lattice(k, h_origin, h_step, h_count, st.lwork, lneed, job.d_out, s);
-            pisa_hip_kde_info_t info;
-            if (rc == PISA_HIP_OK) rc = pisa_hip_kde_info(k, &info);
-            if (rc == PISA_HIP_OK) {
-                job.sum_w = info.sum_w;
-                job.pairs_pilot = info.pairs_pilot;
-                job.pairs_eval = info.pairs_eval;
-            }
-            (void)pisa_hip_kde_destroy(k);
-            if (rc != PISA_HIP_OK) return rc;
-            PISA_TRY_HIP(hipStreamSynchronize(s));
-            return PISA_HIP_OK;
-        };
-        job.status = body();
-    };
-    pool().run(order, nt, run);
-    (void)hipEventDestroy(ready);
+    std::vector<KdePool::Task> tasks;
+    for (int i : order) {
+        pisa_hip_kde_job *job = jobs + i;
+        tasks.push_back([job, P, ready](KdeWorkerState &st) { job->status = run_job(*job, P, (hipEvent_t)ready.get(), st); });
+    }
+    pool().submit(std::move(tasks), n_threads > 0 ? n_threads : 8);
+    return PISA_HIP_OK;
+}
+
+PISA_API int pisa_hip_kde_lattice_wait(void) {
+    pool().wait();
+    return PISA_HIP_OK;
+}
+
+PISA_API int pisa_hip_kde_lattice_batch(pisa_hip_kde_job *jobs, int32_t n_jobs, int32_t dim, int32_t bw_method,
+                                        int32_t adaptive, double alpha, double tol, const double *h_origin,
+                                        const double *h_step, const int64_t *h_count, int32_t n_threads,
+                                        void *stream) {
+    int rc = pisa_hip_kde_lattice_submit(jobs, n_jobs, dim, bw_method, adaptive, alpha, tol, h_origin, h_step, h_count,
+                                         n_threads, stream);
+    if (rc != PISA_HIP_OK) return rc;
+    pool().wait();
     for (int i = 0; i < n_jobs; i++)
         if (jobs[i].status != PISA_HIP_OK) return jobs[i].status;
     return PISA_HIP_OK;

@@ -425,52 +425,90 @@ class KdeEstimator:
 METRIC_KIND = {"llh": 0, "poisson_llh": 1, "chi2": 2, "mod_chi2": 3}
 
 
+class KdeLatticeBatch:
+    """The estimators of one KDE-stage evaluation on the library's own threads and streams
+    (`pisa_hip_kde_lattice_submit` / `_wait`): `submit` queues jobs and returns -- the caller may go on
+    producing the inputs of the next ones --, `wait` returns (densities [n_jobs, m] device tensor, [sum of the
+    weights used per job], (pairs_pilot, pairs_eval) summed over the jobs).
+    A job: (x [dim, n] device tensor, weights device tensor or None, index int64 device tensor or None);
+    weights are those of the parent sample when an index is given."""
+
+    def __init__(self, n_jobs, origin, step, count, dev, bw_method="silverman", adaptive=True, alpha=0.3,
+                 tol=KDE_DEFAULT_TOL, n_threads=0):
+        import ctypes as C
+
+        if bw_method not in KDE_BW:
+            raise ValueError("`bw_method` should be 'scott' or 'silverman'")
+        d = len(origin)
+        assert len(step) == len(count) == d
+        if min(int(v) for v in count) < 1:
+            raise ValueError("empty lattice %r" % (list(count),))
+        self._lib = _lib.lib()
+        self.dim, self.capacity, self.n = d, int(n_jobs), 0
+        self.out = torch.empty((self.capacity, int(np.prod([int(v) for v in count]))), dtype=F8, device=dev)
+        self._arr = (_lib.KdeJob * max(self.capacity, 1))()
+        self._keep = []
+        self._o = (C.c_double * d)(*[float(v) for v in origin])
+        self._st = (C.c_double * d)(*[float(v) for v in step])
+        self._cnt = (C.c_int64 * d)(*[int(v) for v in count])
+        self._args = (KDE_BW[bw_method], 1 if adaptive else 0, float(alpha), float(tol))
+        self._threads = int(n_threads)
+        self._waited = False
+
+    def submit(self, jobs):
+        import ctypes as C
+
+        first = self.n
+        assert first + len(jobs) <= self.capacity and not self._waited
+        for x, w, idx in jobs:
+            x = x.contiguous()
+            assert int(x.shape[0]) == self.dim
+            self._keep.append(x)
+            j = self._arr[self.n]
+            j.d_x, j.n = _ptr(x), int(x.shape[1])
+            if w is not None:
+                w = w.contiguous()
+                self._keep.append(w)
+                j.d_weights = _ptr(w)
+                if idx is not None:
+                    idx = idx.contiguous()
+                    assert idx.dtype == torch.int64 and int(idx.numel()) == j.n
+                    self._keep.append(idx)
+                    j.d_index = _ptr(idx)
+                else:
+                    assert int(w.numel()) == j.n
+            j.d_out = _ptr(self.out[self.n])
+            self.n += 1
+        if self.n > first:
+            sub = C.cast(C.addressof(self._arr) + first * C.sizeof(_lib.KdeJob), C.POINTER(_lib.KdeJob))
+            _lib.check(self._lib.pisa_hip_kde_lattice_submit(sub, self.n - first, self.dim, self._args[0], self._args[1],
+                                                             self._args[2], self._args[3], self._o, self._st, self._cnt,
+                                                             self._threads, _stream()))
+
+    def wait(self):
+        _lib.check(self._lib.pisa_hip_kde_lattice_wait())
+        self._waited = True
+        for i in range(self.n):
+            _lib.check(self._arr[i].status)
+        a = self._arr
+        return (self.out[:self.n], [a[i].sum_w for i in range(self.n)],
+                (sum(a[i].pairs_pilot for i in range(self.n)), sum(a[i].pairs_eval for i in range(self.n))))
+
+    def __del__(self):   # the library holds pointers into this object's job array until the jobs are done
+        if self.n and not self._waited:
+            try:
+                self._lib.pisa_hip_kde_lattice_wait()
+            except Exception:   # pylint: disable=broad-except
+                pass
+
+
 def kde_lattice_batch(jobs, origin, step, count, bw_method="silverman", adaptive=True, alpha=0.3,
                       tol=KDE_DEFAULT_TOL, n_threads=0):
-    """The estimators of one KDE-stage evaluation in one native call (`pisa_hip_kde_lattice_batch`).
-    jobs: [(x [dim, n] device tensor, weights device tensor or None, index int64 device tensor or None)];
-    weights are those of the parent sample when an index is given.  Returns (densities [n_jobs, m] device
-    tensor, [sum of the weights used per job], (pairs_pilot, pairs_eval) summed over the jobs)."""
-    import ctypes as C
-
-    lib = _lib.lib()
-    if bw_method not in KDE_BW:
-        raise ValueError("`bw_method` should be 'scott' or 'silverman'")
-    d = len(origin)
-    assert len(step) == len(count) == d
-    if min(int(v) for v in count) < 1:
-        raise ValueError("empty lattice %r" % (list(count),))
-    m = int(np.prod([int(v) for v in count]))
-    n_jobs = len(jobs)
-    dev = jobs[0][0].device if n_jobs else device()
-    out = torch.empty((n_jobs, m), dtype=F8, device=dev)
-    arr = (_lib.KdeJob * max(n_jobs, 1))()
-    keep = []
-    for i, (x, w, idx) in enumerate(jobs):
-        x = x.contiguous()
-        assert int(x.shape[0]) == d
-        keep.append(x)
-        j = arr[i]
-        j.d_x, j.n = _ptr(x), int(x.shape[1])
-        if w is not None:
-            w = w.contiguous()
-            keep.append(w)
-            j.d_weights = _ptr(w)
-            if idx is not None:
-                idx = idx.contiguous()
-                assert idx.dtype == torch.int64 and int(idx.numel()) == j.n
-                keep.append(idx)
-                j.d_index = _ptr(idx)
-            else:
-                assert int(w.numel()) == j.n
-        j.d_out = _ptr(out[i])
-    o = (C.c_double * d)(*[float(v) for v in origin])
-    st = (C.c_double * d)(*[float(v) for v in step])
-    cnt = (C.c_int64 * d)(*[int(v) for v in count])
-    _lib.check(lib.pisa_hip_kde_lattice_batch(arr, n_jobs, d, KDE_BW[bw_method], 1 if adaptive else 0, float(alpha),
-                                              float(tol), o, st, cnt, int(n_threads), _stream()))
-    return (out, [arr[i].sum_w for i in range(n_jobs)],
-            (sum(arr[i].pairs_pilot for i in range(n_jobs)), sum(arr[i].pairs_eval for i in range(n_jobs))))
+    """all jobs of a `KdeLatticeBatch` submitted at once and waited for (`pisa_hip_kde_lattice_batch`)"""
+    b = KdeLatticeBatch(len(jobs), origin, step, count, jobs[0][0].device if jobs else device(), bw_method=bw_method,
+                        adaptive=adaptive, alpha=alpha, tol=tol, n_threads=n_threads)
+    b.submit(jobs)
+    return b.wait()
 
 
 def metric(kind, actual, expected, sigma2=None, per_bin=False, total_out=None, status=None):

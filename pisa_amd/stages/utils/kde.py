@@ -199,19 +199,24 @@ class kde(Stage):  # pylint: disable=invalid-name
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         rank = dist.get_rank() if world > 1 else 0
         owned = self.owned_containers(len(conts), rank, world, sizes=[c.size for c in conts] if world > 1 else None)
-        # deferred reweighting chains are materialised on the caller's thread and stream
+        # deferred reweighting chains are materialised on the caller's thread and stream -- with the batched path
+        # container by container while the estimators of the earlier ones already run (`weights` callables)
+        def event_weights(i):
+            conts[i].representation = "events"
+            return conts[i].device("weights")
+
         inputs = {}
         for i in owned:
             st = self._static_sample(conts[i])
-            conts[i].representation = "events"
-            inputs[i] = (st, conts[i].device("weights"), self._job_kwargs(st))
+            lazy = not self.bootstrap
+            inputs[i] = (st, (lambda i=i: event_weights(i)) if lazy else event_weights(i), self._job_kwargs(st))
         results = {}
         if self.bootstrap:
             for i, (st, weights, kw) in inputs.items():
                 results[i] = self._bootstrap_map(st, weights, kw)
         else:
             order = list(inputs)
-            if all(torch.is_tensor(inputs[i][1]) for i in order):
+            if order:
                 kw = dict(self._job_kwargs(inputs[order[0]][0])) if order else {}
                 for key in ("sample", "channels"):
                     kw.pop(key, None)
@@ -220,9 +225,6 @@ class kde(Stage):  # pylint: disable=invalid-name
                 maps = kde_hist.kde_histogramdd_batch(samples, stats=self.stats, n_threads=self.kde_workers, **kw)
                 for i, m in zip(order, maps):
                     results[i] = (m, None)
-            else:
-                for i, (st, weights, kw) in inputs.items():
-                    results[i] = (kde_hist.kde_histogramdd(weights=weights, stats=self.stats, **kw), None)
         if world > 1:
             results = self.exchange_maps(results, len(conts), int(self.apply_mode.size), self.bootstrap)
         self.data.representation = self.apply_mode

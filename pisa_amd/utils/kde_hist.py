@@ -275,16 +275,15 @@ def kde_histogramdd(sample, binning, weights=None, bw_method="scott", adaptive=T
 def _finish_hist_many(g, dens, oversample):
     """`_finish_hist` for a stack of density arrays [k, megashape...]: the same element operations, once"""
     l, cz_bin = g["l"], g["cz_bin"]
-    k = dens.shape[0]
-    h = dens
-    h0 = h1 = 0
-    if g["reflect_lower"]:
-        h0 = np.flip(np.concatenate([np.zeros((k,) + tuple(g["minishape"])), h[:, 0:l, :]], axis=1), axis=1)
-        h = h[:, l:, :]
+    lo = l if g["reflect_lower"] else 0
+    hi = dens.shape[1] - (l if g["reflect_upper"] else 0)
+    hist = dens[:, lo:hi, :].copy()
+    # h + h1 + h0 of `_finish_hist`: the upper mirror image first, then the lower one (adding its zeros changes nothing)
     if g["reflect_upper"]:
-        h1 = np.flip(np.concatenate([h[:, -l:, :], np.zeros((k,) + tuple(g["minishape"]))], axis=1), axis=1)
-        h = h[:, :-l, :]
-    hist = (h + h1 + h0) * g["volumes"]
+        hist[:, hist.shape[1] - l:, :] += dens[:, :hi - 1:-1, :]
+    if g["reflect_lower"]:
+        hist[:, :l, :] += dens[:, lo - 1::-1, :] if lo else 0
+    hist *= g["volumes"]
     if oversample != 1:
         for i, at in enumerate(g["reduce_at"]):
             hist = np.add.reduceat(hist, at, axis=i + 1)
@@ -319,45 +318,60 @@ def _job_sample(data, cz_bin):
 def kde_histogramdd_batch(samples, binning, bw_method="scott", adaptive=True, alpha=0.3, coszen_reflection=0.25,
                           coszen_name="coszen", oversample=1, stack_pid=True, tol=None, stats=None, n_threads=0):
     """`[kde_histogramdd(sample=s["sample"], weights=s["weights"], channels=s.get("channels"), ...) for s in
-    samples]` with all the estimators (one per sample and pid channel) built and evaluated by ONE native call
-    (`pisa_hip_kde_lattice_batch`, the estimators side by side on the library's own threads and streams) and
-    one copy of the densities to the host.  Device tensors only; without bootstrap.  The maps are those of the
-    one-by-one path bit for bit."""
-    jobs, owner = [], []
-    g = None
-    for si, smp in enumerate(samples):
-        sample, weights = smp["sample"], smp.get("weights")
-        if weights is not None and len(weights) != sample.shape[0]:
-            raise ValueError("Length of sample (%s) and weights (%s) incompatible" % (sample.shape[0], len(weights)))
+    samples]` with all the estimators (one per sample and pid channel) built and evaluated on the library's own
+    threads and streams (`K.KdeLatticeBatch`) and one copy of the densities to the host.  `weights` may be a
+    callable returning the tensor: it is called when the sample's turn comes, while the estimators of the earlier
+    samples already run.  Device tensors only; without bootstrap.  The maps are those of the one-by-one path bit
+    for bit."""
+    samples = list(samples)
+    plans, g, n_jobs = [], None, 0
+    for smp in samples:
+        sample = smp["sample"]
         if stack_pid:
             pid_bin, d2d, chans = smp.get("channels") or pid_channels(sample, binning)
             g = _evaluation_grid(d2d, oversample, coszen_name, coszen_reflection)
-            for idx, data in chans:
-                jobs.append((_job_sample(data, g["cz_bin"]), weights, idx if weights is not None else None))
-                owner.append((si, pid_bin))
+            plans.append((pid_bin, [(_job_sample(data, g["cz_bin"]), idx) for idx, data in chans]))
         else:
             g = _evaluation_grid(binning, oversample, coszen_name, coszen_reflection)
-            jobs.append((_job_sample(sample, g["cz_bin"]), weights, None))
-            owner.append((si, None))
-    if not jobs:
+            plans.append((None, [(_job_sample(sample, g["cz_bin"]), None)]))
+        n_jobs += len(plans[-1][1])
+    if not n_jobs:
         return []
+
+    def weights_of(smp):
+        w = smp.get("weights")
+        w = w() if callable(w) else w
+        if w is not None and not torch.is_tensor(w):
+            w = K.to_device(np.asarray(w))
+        if w is not None and len(w) != smp["sample"].shape[0]:
+            raise ValueError("Length of sample (%s) and weights (%s) incompatible" % (smp["sample"].shape[0], len(w)))
+        return w
+
     lat = _lattice_of(g["bin_points"])
     if lat is None:   # evaluation points not on a lattice (an irregular binning): one by one, points written out
-        return [kde_histogramdd(sample=smp["sample"], binning=binning, weights=smp.get("weights"), bw_method=bw_method,
+        return [kde_histogramdd(sample=smp["sample"], binning=binning, weights=weights_of(smp), bw_method=bw_method,
                                 adaptive=adaptive, alpha=alpha, coszen_reflection=coszen_reflection,
                                 coszen_name=coszen_name, oversample=oversample, stack_pid=stack_pid, tol=tol,
                                 stats=stats, channels=smp.get("channels")) for smp in samples]
-    dens, sums, pairs = K.kde_lattice_batch(jobs, lat[0], lat[1], lat[2], bw_method=bw_method, adaptive=adaptive, alpha=alpha,
-                                            tol=K.KDE_DEFAULT_TOL if tol is None else tol, n_threads=n_threads)
+    batch = K.KdeLatticeBatch(n_jobs, lat[0], lat[1], lat[2], samples[0]["sample"].device, bw_method=bw_method,
+                              adaptive=adaptive, alpha=alpha, tol=K.KDE_DEFAULT_TOL if tol is None else tol, n_threads=n_threads)
+    owner, sizes = [], []
+    try:
+        for si, (smp, (pid_bin, chans)) in enumerate(zip(samples, plans)):
+            w = weights_of(smp)
+            batch.submit([(x, w, idx if w is not None else None) for x, idx in chans])
+            owner += [(si, pid_bin)] * len(chans)
+            sizes += [int(x.shape[1]) for x, _ in chans]
+    finally:
+        dens, sums, pairs = batch.wait() if batch.n else (None, [], (0, 0))
     dens = dens.cpu().numpy()
     if stats is not None:
         stats["pairs_pilot"] = stats.get("pairs_pilot", 0) + pairs[0]
         stats["pairs_eval"] = stats.get("pairs_eval", 0) + pairs[1]
-        stats["all_pairs"] = stats.get("all_pairs", 0) + sum(
-            int(j[0].shape[1]) * (int(j[0].shape[1]) * bool(adaptive) + g["n_points"]) for j in jobs)
+        stats["all_pairs"] = stats.get("all_pairs", 0) + sum(n * (n * bool(adaptive) + g["n_points"]) for n in sizes)
     per_sample = [[] for _ in samples]
     pid_of = [None] * len(samples)
-    hists = _finish_hist_many(g, dens.reshape((len(jobs),) + tuple(g["megashape"])), oversample) * np.asarray(sums)[:, None, None]
+    hists = _finish_hist_many(g, dens.reshape((n_jobs,) + tuple(g["megashape"])), oversample) * np.asarray(sums)[:, None, None]
     for k, (si, pid_bin) in enumerate(owner):
         per_sample[si].append(hists[k])
         pid_of[si] = pid_bin

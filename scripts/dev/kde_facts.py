@@ -26,7 +26,8 @@ captured = []
 _orig = kde_hist.kde_histogramdd_batch
 def _capture(samples, *a, **kw):   # the event weights as the stage hands them over
     for smp in samples:
-        captured.append((smp["weights"].clone(), dict(channels=smp["channels"])))
+        w = smp["weights"]() if callable(smp["weights"]) else smp["weights"]
+        captured.append((w.clone(), dict(channels=smp["channels"])))
     return _orig(samples, *a, **kw)
 kde_hist.kde_histogramdd_batch = _capture
 pipe.get_outputs()
