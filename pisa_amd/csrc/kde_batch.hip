@@ -127,6 +127,7 @@ struct KdeBatchParams {
     double alpha, tol;
     double origin[3], step[3];
     int64_t count[3];
+    int64_t n_max;   // largest job of the submission: the workspaces are sized for it at once
     int device;
 };
 
@@ -142,9 +143,10 @@ static int run_job(pisa_hip_kde_job &job, const KdeBatchParams &P, hipEvent_t re
     hipStream_t s = st.stream;
     PISA_TRY_HIP(hipStreamWaitEvent(s, ready, 0));
     const int64_t need = pisa_hip_kde_workspace_bytes(P.dim, job.n);
-    if (need < 0) return PISA_HIP_ERR_INVALID;
+    const int64_t need_max = pisa_hip_kde_workspace_bytes(P.dim, std::max(job.n, P.n_max));
+    if (need < 0 || need_max < 0) return PISA_HIP_ERR_INVALID;
     const size_t wbytes = (((size_t)job.n * 8) + 255) & ~(size_t)255;
-    int rc = grow(&st.work, &st.work_bytes, (size_t)need + wbytes, s);
+    int rc = grow(&st.work, &st.work_bytes, (size_t)need_max + ((((size_t)std::max(job.n, P.n_max) * 8) + 255) & ~(size_t)255), s);
     if (rc != PISA_HIP_OK) return rc;
     const double *d_w = nullptr;
     if (job.d_weights) {
@@ -159,7 +161,9 @@ static int run_job(pisa_hip_kde_job &job, const KdeBatchParams &P, hipEvent_t re
                              (char *)st.work + wbytes, need, &k, s);
     if (rc != PISA_HIP_OK) return rc;
     const int64_t lneed = pisa_hip_kde_lattice_workspace_bytes(k, P.step, P.count);
-    rc = lneed < 0 ? PISA_HIP_ERR_INVALID : grow(&st.lwork, &st.lwork_bytes, (size_t)lneed, s);
+    // (the lattice workspace grows with the number of sources: scaled to the largest job of the submission)
+    const size_t lneed_max = lneed < 0 ? 0 : (size_t)((double)lneed * (double)std::max(job.n, P.n_max) / (double)job.n);
+    rc = lneed < 0 ? PISA_HIP_ERR_INVALID : grow(&st.lwork, &st.lwork_bytes, std::max((size_t)lneed, lneed_max), s);
     if (rc == PISA_HIP_OK)
         rc = pisa_hip_kde_evaluate_lattice(k, P.origin, P.step, P.count, st.lwork, lneed, job.d_out, s);
     pisa_hip_kde_info_t info;
@@ -194,6 +198,7 @@ PISA_API int pisa_hip_kde_lattice_submit(pisa_hip_kde_job *jobs, int32_t n_jobs,
     memset(&P, 0, sizeof(P));
     P.dim = dim; P.bw_method = bw_method; P.adaptive = adaptive; P.alpha = alpha; P.tol = tol;
     for (int d = 0; d < dim; d++) { P.origin[d] = h_origin[d]; P.step[d] = h_step[d]; P.count[d] = h_count[d]; }
+    for (int i = 0; i < n_jobs; i++) P.n_max = std::max(P.n_max, jobs[i].n);
     PISA_TRY_HIP(hipGetDevice(&P.device));
     // the inputs were produced on the caller's stream
     hipEvent_t ev;
