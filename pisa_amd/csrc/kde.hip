@@ -944,51 +944,81 @@ kde_slot_scatter_kernel(const int32_t *__restrict__ dense_cells, int n_dense, in
     if (i < n_dense) slot[dense_cells[i]] = i;
 }
 
-// A[slot][n][m] of one dense cell per workgroup; fixed source order => reproducible
+// A[slot][n][m] of one dense cell per workgroup; fixed order => reproducible.  The P x P coefficients are cut
+// into 4 x 4 register tiles; the sources of a staged tile of 64 are dealt to four thread groups (j = s, s + 4, ...),
+// each group holding a partial sum of every tile, added in group order at the end: 4 LDS reads (16 bytes each) per
+// 16 multiply-adds.
+constexpr int HC_THREADS = 128;
 template <int P>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(HC_THREADS)
 kde_hermite_coef_kernel(KdeGeom g, const int32_t *__restrict__ dense_cells,
                         const int32_t *__restrict__ cell_start, const double *__restrict__ sy,
                         int64_t n_src, const double *__restrict__ coef, double *__restrict__ herm) {
-    constexpr int TJ = 32;
-    __shared__ double pa[TJ][P + 1], pb[TJ][P + 1];
+    constexpr int TJ = 64, PT = (P + 3) / 4, PR = PT * 4, NG = 4;
+    static_assert(PT * PT * NG <= HC_THREADS, "tiles x groups must fit the workgroup");
+    typedef double __attribute__((ext_vector_type(2))) d2;
+    __shared__ __attribute__((aligned(16))) double stage[2][TJ][PR];   // powers of both coordinates, zero beyond P
+    static_assert(2 * TJ * PR >= NG * PR * PR, "the partial sums reuse the staging area");
+    double (*pa)[PR] = stage[0], (*pb)[PR] = stage[1];
+    const int t = threadIdx.x;
     const int c = dense_cells[blockIdx.x];
     const int cx = c % g.nc[0], cy = c / g.nc[0];
     const double c1 = g.ylo[0] + (cx + 0.5) * g.cell, c2 = g.ylo[1] + (cy + 0.5) * g.cell;
     const int begin = cell_start[c], end = cell_start[c + 1];
-    double acc[2] = {0.0, 0.0};
+    const int grp = t / (PT * PT), tile = t % (PT * PT);
+    const bool act = grp < NG;
+    const int ti = tile / PT, tj = tile % PT;
+    double acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = 0.0;
     for (int base = begin; base < end; base += TJ) {
         const int cnt = end - base < TJ ? end - base : TJ;
         __syncthreads();
-        if (threadIdx.x < 2 * TJ) {
-            const int j = threadIdx.x % TJ, which = threadIdx.x / TJ;
+        {
+            const int j = t % TJ, which = t / TJ;   // 128 threads = 64 sources x 2 coordinates
+            double *dst = which ? pb[j] : pa[j];
             if (j < cnt) {
                 const double d = (sy[(int64_t)which * n_src + base + j] - (which ? c2 : c1)) * RSQRT2;
                 double v = which ? coef[base + j] : 1.0;   // the weight rides on the second factor
-                double *dst = which ? pb[j] : pa[j];
 #pragma unroll
                 for (int n = 0; n < P; n++) {
                     dst[n] = v;
                     v = v * d * (1.0 / (double)(n + 1));   // (the reciprocal is a compile-time constant)
                 }
+#pragma unroll
+                for (int n = P; n < PR; n++) dst[n] = 0.0;
             }
         }
         __syncthreads();
+        if (act) {
+            for (int j = grp; j < cnt; j += NG) {
+                const d2 a01 = *reinterpret_cast<const d2 *>(&pa[j][4 * ti]), a23 = *reinterpret_cast<const d2 *>(&pa[j][4 * ti + 2]);
+                const d2 b01 = *reinterpret_cast<const d2 *>(&pb[j][4 * tj]), b23 = *reinterpret_cast<const d2 *>(&pb[j][4 * tj + 2]);
+                const double a[4] = {a01.x, a01.y, a23.x, a23.y}, bb[4] = {b01.x, b01.y, b23.x, b23.y};
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int t = threadIdx.x + u * 256;
-            if (t < P * P) {
-                const int n = t / P, m = t % P;
-                double a = acc[u];
-                for (int j = 0; j < cnt; j++) a = __builtin_fma(pa[j][n], pb[j][m], a);
-                acc[u] = a;
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) acc[i][k] = __builtin_fma(a[i], bb[k], acc[i][k]);
             }
         }
     }
+    __syncthreads();
+    double *red = &stage[0][0][0];   // [group][PR * PR]
+    if (act) {
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
-        const int t = threadIdx.x + u * 256;
-        if (t < P * P) herm[(int64_t)blockIdx.x * (P * P) + t] = acc[u];
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) red[grp * (PR * PR) + (4 * ti + i) * PR + 4 * tj + k] = acc[i][k];
+    }
+    __syncthreads();
+    for (int e = t; e < P * P; e += HC_THREADS) {
+        const int n = e / P, m = e % P;
+        double v = red[n * PR + m];
+#pragma unroll
+        for (int s = 1; s < NG; s++) v += red[s * (PR * PR) + n * PR + m];
+        herm[(int64_t)blockIdx.x * (P * P) + e] = v;
     }
 }
 
@@ -1437,8 +1467,11 @@ kde_local_pilot_kernel(KdeGeom g, const KdeBlock *__restrict__ blocks, const dou
         acc[u] = 0.0;
     }
     unsigned long long work = (unsigned long long)(P * P / 23 + 1) * b.q_count;
+    __shared__ double sL[P * P];   // the cell's local expansion: fetched once by the workgroup, read back as broadcasts
+    for (int i = threadIdx.x; i < P * P; i += KDE_THREADS) sL[i] = local[(int64_t)b.head * (P * P) + i];
+    __syncthreads();
     {
-        const double *__restrict__ L = local + (int64_t)b.head * (P * P);   // wave-uniform: scalar loads
+        const double *L = sL;
         const double c1 = g.ylo[0] + (b.c0[0] + 0.5) * g.cell, c2 = g.ylo[1] + (b.c0[1] + 0.5) * g.cell;
         double x[Q_PER_THREAD], y[Q_PER_THREAD], sum[Q_PER_THREAD];
 #pragma unroll
@@ -1449,7 +1482,7 @@ kde_local_pilot_kernel(KdeGeom g, const KdeBlock *__restrict__ blocks, const dou
         }
 #pragma unroll 1
         for (int k = P - 1; k >= 0; k--) {
-            const double *__restrict__ row = L + k * P;
+            const double *row = L + k * P;
             double inner[Q_PER_THREAD];
 #pragma unroll
             for (int u = 0; u < Q_PER_THREAD; u++) inner[u] = 0.0;
@@ -1985,7 +2018,7 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
             dim3 grid((unsigned)n_blocks, (unsigned)n_split);
             static const bool h2l_tiled = [] { const char *v = getenv("PISA_HIP_KDE_H2L_TILED"); return !v || atoi(v) != 0; }();
 #define KDE_FGT(PP) do { \
-                hipLaunchKernelGGL(kde_hermite_coef_kernel<PP>, dim3((unsigned)nd), dim3(256), 0, s, g, d_dense, \
+                hipLaunchKernelGGL(kde_hermite_coef_kernel<PP>, dim3((unsigned)nd), dim3(HC_THREADS), 0, s, g, d_dense, \
                                    k->cell_start, k->ys, n, k->coef, herm); \
                 if (local_exp) { \
                     if (h2l_tiled) { \
