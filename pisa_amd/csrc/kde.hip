@@ -706,7 +706,8 @@ template <int R>
 __global__ void __launch_bounds__(64, 3)   // <= 168 VGPRs: at four wavefronts per SIMD (128) the record loop spills
 kde_lattice_kernel(const KdeLattice L, double rcut2, const double *__restrict__ rec, int64_t n_src,
                    int64_t share, const double *__restrict__ box, const int32_t *__restrict__ wstart,
-                   int n_patches, double *__restrict__ partial, unsigned long long *__restrict__ pair_count) {
+                   int n_patches, int pairing, double *__restrict__ partial,
+                   unsigned long long *__restrict__ pair_count) {
     constexpr int C = R / 2;   // the strip's middle point
     static_assert(C <= LAT_QMAX, "Q table");
     static_assert(LAT_PIECE * LAT_REC * 8 == 3 * 64 * 16, "a piece is three 16-byte loads per lane");
@@ -740,71 +741,114 @@ kde_lattice_kernel(const KdeLattice L, double rcut2, const double *__restrict__ 
     // The sorted sources are cut into shares of `share` sources (compact in y_a and y_b); this
     // wavefront takes every n_split-th share: every wavefront sees a sample of all regions, so the work is
     // balanced without a dynamic queue.
+    //
+    // TWO shares are worked through side by side, record r of the one with record r of the other: a source
+    // reaches ~23 of the 64 strips of the patch, and the shares within reach of a patch come sorted by lattice
+    // line, so a share of the lower half of the list (A) and its partner of the upper half (B) mostly reach
+    // different strips.  A lane takes the record it is within reach of (A if both), one pass of the recurrence
+    // serves both sources; only the lanes within reach of both go through a second pass for B.  The order in which
+    // a strip receives its contributions is fixed by the lists: bit-reproducible.
     typedef double __attribute__((ext_vector_type(2))) d2;
+    constexpr int HP = LAT_PIECE / 2;          // records of one share per piece
+    constexpr int HD2 = HP * LAT_REC / 2;      // 16-byte units of one share's part of a piece
+    __shared__ int32_t lst[64];
     const int64_t n_shares = (n_src + share - 1) / share;
-    for (int64_t sub = split; sub < n_shares; sub += n_split) {
-        // whole share out of reach of the patch?
-        const double *__restrict__ bx = box + 4 * sub;
-        if (bx[0] > pa_hi || bx[1] < pa_lo || bx[2] > pb_hi || bx[3] < pb_lo) continue;
-        const int64_t k0 = sub * share;
-        const int n_rec = (int)((k0 + share < n_src ? k0 + share : n_src) - k0);
-        const int n_piece = (n_rec + LAT_PIECE - 1) / LAT_PIECE;
-        // (the record array is padded to whole pieces: the loads of a last, partial piece stay inside it)
-        const d2 *__restrict__ src = reinterpret_cast<const d2 *>(rec + k0 * LAT_REC) + lane;
-        d2 a0 = src[0], a1 = src[64], a2 = src[128];
-        for (int c = 0; c < n_piece; c++) {
-            d2 b0 = a0, b1 = a1, b2 = a2;
-            if (c + 1 < n_piece) {
-                const d2 *__restrict__ nx = src + (c + 1) * 192;
-                b0 = nx[0]; b1 = nx[64]; b2 = nx[128];
-            }
-            double *slot = ring[c & 1];
-            {
-                d2 *dst = reinterpret_cast<d2 *>(slot) + lane;
-                dst[0] = a0; dst[64] = a1; dst[128] = a2;
-            }
-            __syncthreads();   // one wavefront: orders the stores above against the broadcast reads below
-            const int nr = n_rec - c * LAT_PIECE < LAT_PIECE ? n_rec - c * LAT_PIECE : LAT_PIECE;
-            const double *s = slot;
-            double sya = s[0], syb = s[1], cf = s[2], sh = s[3], shd = s[4], h = s[5];
-            for (int r = 0; r < nr; r++) {
-                const double *cur = slot + r * LAT_REC;
-                // next record read before this one is used (the last one reads itself again)
-                const double *nxr = slot + (r + 1 < nr ? r + 1 : r) * LAT_REC;
-                const double n0 = nxr[0], n1 = nxr[1], n2 = nxr[2], n3 = nxr[3], n4 = nxr[4], n5 = nxr[5];
-                const double xc = ya_c - sya, dbb = yb - syb;
-                const double dn = fmax(fmax(xc - ext_lo, -(xc + ext_hi)), 0.0);   // nearest point of the strip
-                const bool in = live && (dbb * dbb + dn * dn) * sh * -2.0 <= rcut2;
-                if (__builtin_amdgcn_ballot_w64(in)) {
-                    if (in) {
-                        strips++;
-                        // the first half of the Q table is requested before the exponentials, the second half
-                        // while the first is used (LDS broadcast reads)
-                        double Q[C + 1];
+    const int half_id = lane >> 5, hl = lane & 31;
+
+    // one pass of the recurrence for the lane's record rp (LDS), at distance (xc, dbb) from the strip's middle
+    auto deposit = [&](const double *rp, double xc, double dbb) {
+        double Q[C + 1];
+        const double cf = rp[2], sh = rp[3], shd = rp[4], h = rp[5];
 #pragma unroll
-                        for (int kk = 2; kk <= C / 2; kk++) Q[kk] = cur[LAT_Q0 + kk - 2];
-                        __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink the reads to their first use)
-                        const double gc = cf * exp_nonpos(sh * __builtin_fma(xc, xc, dbb * dbb));
-                        double r_up, r_dn;
-                        exp_pair(shd * xc, h, r_up, r_dn);   // g(c+1) / g(c), g(c-1) / g(c)
+        for (int kk = 2; kk <= C / 2; kk++) Q[kk] = rp[LAT_Q0 + kk - 2];
+        __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink the reads to their first use)
+        const double gc = cf * exp_nonpos(sh * __builtin_fma(xc, xc, dbb * dbb));
+        double r_up, r_dn;
+        exp_pair(shd * xc, h, r_up, r_dn);   // g(c+1) / g(c), g(c-1) / g(c)
 #pragma unroll
-                        for (int kk = C / 2 + 1; kk <= C; kk++) Q[kk] = cur[LAT_Q0 + kk - 2];
-                        __builtin_amdgcn_sched_barrier(0);
-                        double pu = gc, pd = gc * r_dn;
+        for (int kk = C / 2 + 1; kk <= C; kk++) Q[kk] = rp[LAT_Q0 + kk - 2];
+        __builtin_amdgcn_sched_barrier(0);
+        double pu = gc, pd = gc * r_dn;
 #pragma unroll
-                        for (int kk = 0; kk < C; kk++) {   // both directions interleaved: two independent chains
-                            // up: point C + kk (k = kk); down: point C - 1 - kk (k = kk + 1)
-                            acc[C + kk] = kk < 2 ? acc[C + kk] + pu : __builtin_fma(pu, Q[kk], acc[C + kk]);
-                            if (kk + 1 < R - C) pu *= r_up;
-                            acc[C - 1 - kk] = kk + 1 < 2 ? acc[C - 1 - kk] + pd : __builtin_fma(pd, Q[kk + 1], acc[C - 1 - kk]);
-                            if (kk + 1 < C) pd *= r_dn;
+        for (int kk = 0; kk < C; kk++) {   // both directions interleaved: two independent chains
+            // up: point C + kk (k = kk); down: point C - 1 - kk (k = kk + 1)
+            acc[C + kk] = kk < 2 ? acc[C + kk] + pu : __builtin_fma(pu, Q[kk], acc[C + kk]);
+            if (kk + 1 < R - C) pu *= r_up;
+            acc[C - 1 - kk] = kk + 1 < 2 ? acc[C - 1 - kk] + pd : __builtin_fma(pd, Q[kk + 1], acc[C - 1 - kk]);
+            if (kk + 1 < C) pd *= r_dn;
+        }
+    };
+
+    int64_t sub = split;
+    while (sub < n_shares) {
+        // the next (at most 64) shares of this wavefront within reach of the patch
+        int nl = 0;
+        __syncthreads();
+        for (; sub < n_shares && nl < 64; sub += n_split) {
+            const double *__restrict__ bx = box + 4 * sub;
+            if (bx[0] > pa_hi || bx[1] < pa_lo || bx[2] > pb_hi || bx[3] < pb_lo) continue;
+            if (lane == 0) lst[nl] = (int32_t)sub;
+            nl++;
+        }
+        __syncthreads();
+        const int n_pair = pairing ? (nl + 1) / 2 : nl;
+        for (int i = 0; i < n_pair; i++) {
+            const int64_t sA = lst[i];
+            const int64_t sB = pairing && i + n_pair < nl ? lst[i + n_pair] : -1;
+            const int64_t kA = sA * share, kB = (sB >= 0 ? sB : sA) * share;
+            const int nA = (int)((kA + share < n_src ? kA + share : n_src) - kA);
+            const int nB = sB >= 0 ? (int)((kB + share < n_src ? kB + share : n_src) - kB) : 0;
+            const int n_piece = ((nA > nB ? nA : nB) + HP - 1) / HP;
+            // lanes 0-31 fetch A's half of a piece, lanes 32-63 B's (the record array is padded by a whole
+            // piece: the loads of a last, partial piece stay inside it)
+            const d2 *__restrict__ src = reinterpret_cast<const d2 *>(rec + (half_id ? kB : kA) * LAT_REC) + hl;
+            d2 a0 = src[0], a1 = src[32], a2 = src[64];
+            for (int c = 0; c < n_piece; c++) {
+                d2 b0 = a0, b1 = a1, b2 = a2;
+                if (c + 1 < n_piece) {
+                    const d2 *__restrict__ nx = src + (c + 1) * HD2;
+                    b0 = nx[0]; b1 = nx[32]; b2 = nx[64];
+                }
+                double *slot = ring[c & 1];
+                {
+                    d2 *dst = reinterpret_cast<d2 *>(slot) + half_id * HD2 + hl;
+                    dst[0] = a0; dst[32] = a1; dst[64] = a2;
+                }
+                __syncthreads();   // one wavefront: orders the stores above against the reads below
+                const int nrA = nA - c * HP < HP ? (nA - c * HP > 0 ? nA - c * HP : 0) : HP;
+                const int nrB = nB - c * HP < HP ? (nB - c * HP > 0 ? nB - c * HP : 0) : HP;
+                const int nr = nrA > nrB ? nrA : nrB;
+                // (y_a, y_b, -s2 / 2) of both records, read one iteration ahead
+                double ayA = slot[0], byA = slot[1], shA = slot[3];
+                double ayB = slot[HP * LAT_REC], byB = slot[HP * LAT_REC + 1], shB = slot[HP * LAT_REC + 3];
+                for (int r = 0; r < nr; r++) {
+                    const double *rA = slot + r * LAT_REC, *rB = slot + (HP + r) * LAT_REC;
+                    const int rn = r + 1 < nr ? r + 1 : r;
+                    const double *nA_ = slot + rn * LAT_REC, *nB_ = slot + (HP + rn) * LAT_REC;
+                    const double n0 = nA_[0], n1 = nA_[1], n3 = nA_[3], m0 = nB_[0], m1 = nB_[1], m3 = nB_[3];
+                    const double xcA = ya_c - ayA, dbA = yb - byA, xcB = ya_c - ayB, dbB = yb - byB;
+                    const double dnA = fmax(fmax(xcA - ext_lo, -(xcA + ext_hi)), 0.0);   // nearest point of the strip
+                    const double dnB = fmax(fmax(xcB - ext_lo, -(xcB + ext_hi)), 0.0);
+                    const bool inA = live && r < nrA && (dbA * dbA + dnA * dnA) * shA * -2.0 <= rcut2;
+                    const bool inB = live && r < nrB && (dbB * dbB + dnB * dnB) * shB * -2.0 <= rcut2;
+                    if (__builtin_amdgcn_ballot_w64(inA || inB)) {
+                        if (inA || inB) {
+                            strips++;
+                            deposit(inA ? rA : rB, inA ? xcA : xcB, inA ? dbA : dbB);
+                        }
+                        const bool both = inA && inB;
+                        if (__builtin_amdgcn_ballot_w64(both)) {
+                            if (both) {
+                                strips++;
+                                deposit(rB, xcB, dbB);
+                            }
                         }
                     }
+                    ayA = n0; byA = n1; shA = n3; ayB = m0; byB = m1; shB = m3;
                 }
-                sya = n0; syb = n1; cf = n2; sh = n3; shd = n4; h = n5;
+                __syncthreads();   // the slot is overwritten two pieces later: its reads are done
+                a0 = b0; a1 = b1; a2 = b2;
             }
-            __syncthreads();   // the slot is overwritten two pieces later: its reads are done
-            a0 = b0; a1 = b1; a2 = b2;
         }
     }
     {
@@ -2293,7 +2337,8 @@ PISA_API int pisa_hip_kde_evaluate_lattice(pisa_hip_kde *k, const double *h_orig
     hipLaunchKernelGGL(kde_lattice_box_kernel, dim3((unsigned)n_shares), dim3(64), 0, s, rec, k->n, share, g.rcut2, box);
     hipLaunchKernelGGL(kde_lattice_load_kernel, dim3((unsigned)n_patches), dim3(256), 0, s, L, R, box, n_shares, load);
     hipLaunchKernelGGL(kde_lattice_plan_kernel, dim3(1), dim3(64), 0, s, load, n_patches, n_waves, wstart);
-#define KDE_LAT(RR) hipLaunchKernelGGL(kde_lattice_kernel<RR>, dim3((unsigned)n_waves), dim3(64), 0, s, L, g.rcut2, rec, k->n, share, box, wstart, n_patches, part, k->pair_count)
+    static const int pairing = [] { const char *v = getenv("PISA_HIP_KDE_LATTICE_PAIR"); return v ? atoi(v) : 1; }();
+#define KDE_LAT(RR) hipLaunchKernelGGL(kde_lattice_kernel<RR>, dim3((unsigned)n_waves), dim3(64), 0, s, L, g.rcut2, rec, k->n, share, box, wstart, n_patches, pairing, part, k->pair_count)
     if (R == 32) KDE_LAT(32); else if (R == 16) KDE_LAT(16); else KDE_LAT(8);
 #undef KDE_LAT
     hipLaunchKernelGGL(kde_lattice_combine_kernel, dim3((unsigned)(n_patches * R * 4)), dim3(256), 0, s, part, L, R, wstart, d_out);
