@@ -39,8 +39,11 @@ def gaussian_kde_eval(x, weights, points, bw_method, adaptive, alpha):
     ones = np.ones(n)
     if adaptive:
         pilot = orc.kde_eval(x, w / norm, ones, x, inv_cov)
-        glob = np.exp(np.mean(np.log(pilot)))
-        s = (pilot / glob) ** alpha
+        # a weightless source without weighted neighbours has pilot 0: it contributes nothing, is left out of the
+        # geometric mean and keeps the global bandwidth (the choice of pisa_amd/csrc/kde.hip, kde_logsum_kernel)
+        pos = pilot > 0
+        glob = np.exp(np.mean(np.log(pilot[pos])))
+        s = np.where(pos, (np.where(pos, pilot, 1.0) / glob) ** alpha, 1.0)
     else:
         s = ones
     return orc.kde_eval(x, w * s ** d / norm, s * s, points, inv_cov)

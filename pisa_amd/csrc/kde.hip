@@ -905,33 +905,47 @@ kde_lattice_points_kernel(int dim, double o0, double o1, double o2, double s0, d
     if (dim > 2) x[2 * m + i] = o2 + (double)i2 * s2_;
 }
 
-// sum of log(pilot) -> partial[block]
+// sum of log(pilot) and the number of sources it runs over -> partial[block][2].  A source of weight zero with no
+// weighted neighbour within the cut-off has pilot density 0 (its own term is its weight): it contributes nothing to
+// any density, so it is left out of the geometric mean and keeps the global bandwidth -- otherwise one such event
+// would turn every local bandwidth, and with them the whole map, into NaN.
 __global__ void __launch_bounds__(RED_THREADS)
 kde_logsum_kernel(const double *__restrict__ pilot, int64_t n, double *__restrict__ partial) {
     __shared__ double lds[RED_THREADS];
-    double s = 0.0;
+    double s = 0.0, c = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * RED_THREADS + threadIdx.x; i < n;
-         i += (int64_t)RED_BLOCKS * RED_THREADS)
-        s += log(pilot[i]);
+         i += (int64_t)RED_BLOCKS * RED_THREADS) {
+        const double v = pilot[i];
+        if (v > 0.0) {
+            s += log(v);
+            c += 1.0;
+        }
+    }
     const double r = block_sum(s, lds);
-    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+    const double rc = block_sum(c, lds);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x * 2] = r;
+        partial[blockIdx.x * 2 + 1] = rc;
+    }
 }
 
 // local bandwidths: lam = (pilot / g)^alpha, s2 = lam^2, coef = wn lam^d / norm; per-block min s2
+// (logsum[0] = sum of log pilot over the logsum[1] sources of positive pilot density)
 __global__ void __launch_bounds__(RED_THREADS)
 kde_bandwidth_kernel(const double *__restrict__ pilot, const double *__restrict__ wn, int64_t n,
                      const double *__restrict__ logsum, double alpha, int dim, double inv_norm,
                      double *__restrict__ coef, double *__restrict__ s2, double *__restrict__ partial_min) {
     __shared__ double lds[RED_THREADS];
-    const double glob = exp(*logsum / (double)n);
+    const double glob = exp(logsum[0] / logsum[1]);
     double mn = INFINITY, mx = -INFINITY;
     for (int64_t i = (int64_t)blockIdx.x * RED_THREADS + threadIdx.x; i < n;
          i += (int64_t)RED_BLOCKS * RED_THREADS) {
-        const double lam = pow(pilot[i] / glob, alpha);
+        const double pv = pilot[i];
+        const double lam = pv > 0.0 ? pow(pv / glob, alpha) : 1.0;
         const double l2 = lam * lam;
         s2[i] = l2;
         coef[i] = wn[i] * (dim == 1 ? lam : (dim == 2 ? l2 : l2 * lam)) * inv_norm;
-        mn = fmin(mn, l2);   // NaN (pilot <= 0 cannot happen: own term) is ignored by fmin
+        mn = fmin(mn, l2);
         mx = fmax(mx, l2);
     }
     const double r = block_min(mn, lds);
@@ -2098,7 +2112,7 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
             hipLaunchKernelGGL(kde_combine_kernel, dim3(nb), dim3(256), 0, s, part, n_split, n,
                                (const uint32_t *)nullptr, pilot);
         hipLaunchKernelGGL(kde_logsum_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, pilot, n, partial);
-        hipLaunchKernelGGL(kde_final_reduce_kernel, dim3(1), dim3(RED_THREADS), 0, s, partial, 1, 1, 0, k->scalars);
+        hipLaunchKernelGGL(kde_final_reduce_kernel, dim3(1), dim3(RED_THREADS), 0, s, partial, 2, 2, 0, k->scalars);   // [0] sum, [1] count
         hipLaunchKernelGGL(kde_bandwidth_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, pilot, k->wn, n,
                            k->scalars, alpha, dim, 1.0 / k->norm, k->coef, k->s2, partial);
         hipLaunchKernelGGL(kde_final_reduce_kernel, dim3(1), dim3(RED_THREADS), 0, s, partial, 2, 0, 1,

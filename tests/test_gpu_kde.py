@@ -411,3 +411,74 @@ def test_kde_histogramdd_batch_equals_one_by_one():
                 np.testing.assert_array_equal(a, b)
     with pytest.raises(ValueError):
         kde_hist.kde_histogramdd_batch([dict(sample=samples[0]["sample"], weights=samples[1]["weights"])], b3, **kw)
+
+
+@pytest.mark.parametrize("rho,counts,zero_frac", [(0.85, (37, 11), 0.0), (-0.6, (200, 3), 0.0), (0.0, (301, 203), 0.3),
+                                                   (0.4, (64, 64), 0.0), (0.2, (33, 130), 0.0)])
+def test_kde_lattice_kernel_edge_shapes(rho, counts, zero_frac):
+    """The lattice kernel on shapes that stress its patch / share / pairing logic: strongly correlated samples (a large
+    shear between lattice lines in whitened coordinates), lattices smaller than one patch, long thin ones, more lines than
+    one row of patches, a third of the weights exactly zero -- always against the point evaluation of the same estimator,
+    plus bit-reproducibility."""
+    from pisa_amd import kernels as K
+
+    rs = np.random.RandomState(17)
+    n = 90000
+    z = rs.randn(2, n)
+    x = np.stack([z[0], rho * z[0] + np.sqrt(1 - rho * rho) * z[1]]) * np.array([[0.7], [1.3]])
+    x[:, : n // 10] *= 2.5                      # a sparse halo: wide local bandwidths
+    w = rs.rand(n) + 0.1
+    w[rs.rand(n) < zero_frac] = 0.0
+    est = K.KdeEstimator(K.to_device(x), K.to_device(w), adaptive=True, alpha=0.3)
+    n0, n1 = counts
+    a0, a1 = np.linspace(-2.6, 2.3, n0), np.linspace(-3.9, 4.4, n1)
+    origin, step = [a0[0], a1[0]], [(a0[-1] - a0[0]) / (n0 - 1), (a1[-1] - a1[0]) / (n1 - 1)]
+    lat = est.evaluate_lattice(origin, step, counts).cpu().numpy()
+    pts = np.array([g.ravel() for g in np.meshgrid(a0, a1, indexing="ij")])
+    direct = est(K.to_device(pts)).cpu().numpy()
+    assert direct.max() > 0 and np.all(np.isfinite(lat))
+    np.testing.assert_allclose(lat, direct, rtol=2e-12, atol=1e-13 * direct.max())
+    np.testing.assert_array_equal(lat, est.evaluate_lattice(origin, step, counts).cpu().numpy())
+
+
+def test_kde_lattice_short_strips_and_fallback():
+    """coarse lattices: the strip length drops from 32 to 16 and 8 points (R da sqrt(max s2) <= 50) and finally the
+    points are written out -- every form against the point evaluation"""
+    from pisa_amd import kernels as K
+
+    rs = np.random.RandomState(19)
+    n = 60000
+    x = rs.randn(2, n) * np.array([[1.0], [0.8]])
+    est = K.KdeEstimator(K.to_device(x), None, adaptive=True, alpha=0.5)
+    for n0 in (400, 60, 30, 16, 9):        # 0.02 ... 1 sample sigma per step: many to less than one kernel width
+        a0, a1 = np.linspace(-4.0, 4.0, n0), np.linspace(-3.0, 3.0, 70)
+        origin, step = [a0[0], a1[0]], [(a0[-1] - a0[0]) / (n0 - 1), (a1[-1] - a1[0]) / 69]
+        lat = est.evaluate_lattice(origin, step, (n0, 70)).cpu().numpy()
+        pts = np.array([g.ravel() for g in np.meshgrid(a0, a1, indexing="ij")])
+        direct = est(K.to_device(pts)).cpu().numpy()
+        np.testing.assert_allclose(lat, direct, rtol=2e-12, atol=1e-13 * direct.max())
+
+
+def test_kde_weightless_isolated_sources_do_not_poison_the_bandwidths():
+    """events of weight zero far from every weighted event have pilot density 0: they are left out of the geometric
+    mean of the pilot densities (device and oracle alike) instead of turning every local bandwidth into NaN"""
+    from oracle import kde_oracle
+
+    from pisa_amd import kernels as K
+
+    rs = np.random.RandomState(23)
+    n = 30000
+    x = rs.randn(2, n)
+    w = rs.rand(n) + 0.1
+    w[rs.rand(n) < 0.3] = 0.0
+    x[:, :5] = np.array([[40.0, -35.0, 60.0, 0.0, 0.0], [0.0, 0.0, 0.0, 55.0, -70.0]])   # far outliers ...
+    w[:5] = 0.0                                                                           # ... without weight
+    pts = np.array([g.ravel() for g in np.meshgrid(np.linspace(-3, 3, 40), np.linspace(-3, 3, 30), indexing="ij")])
+    for tol in (K.KDE_DEFAULT_TOL, 0.0):
+        est = K.KdeEstimator(K.to_device(x), K.to_device(w), adaptive=True, alpha=0.3, tol=tol)
+        got = est(K.to_device(pts)).cpu().numpy()
+        assert np.all(np.isfinite(got)) and got.max() > 0
+        want = kde_oracle.gaussian_kde_eval(x, w, pts, "silverman", True, 0.3)
+        np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-12 * want.max())
+    lat = est.evaluate_lattice([-3.0, -3.0], [6.0 / 39, 6.0 / 29], (40, 30)).cpu().numpy()
+    np.testing.assert_array_equal(lat, got)   # tol = 0: the lattice is written out
