@@ -2074,12 +2074,13 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
                                    d_tcells, n_heads, hslot);
             }
             dim3 grid((unsigned)n_blocks, (unsigned)n_split);
-            static const bool h2l_tiled = [] { const char *v = getenv("PISA_HIP_KDE_H2L_TILED"); return !v || atoi(v) != 0; }();
+            // translation passes: 1 = four targets per workgroup (default), 0 = one target per workgroup
+            static const int h2l_form = [] { const char *v = getenv("PISA_HIP_KDE_H2L_FORM"); return v ? atoi(v) : 1; }();
 #define KDE_FGT(PP) do { \
                 hipLaunchKernelGGL(kde_hermite_coef_kernel<PP>, dim3((unsigned)nd), dim3(HC_THREADS), 0, s, g, d_dense, \
                                    k->cell_start, k->ys, n, k->coef, herm); \
                 if (local_exp) { \
-                    if (h2l_tiled) { \
+                    if (h2l_form == 1) { \
                         hipLaunchKernelGGL((kde_h2l4_kernel<PP, 0>), dim3((unsigned)g.nc[0], (unsigned)((g.nc[1] + H2L4_T - 1) / H2L4_T)), \
                                            dim3(H2L_THREADS), 0, s, g, hslot, slot, herm, d_hankel, reach, d_V, d_vflag, local); \
                         hipLaunchKernelGGL((kde_h2l4_kernel<PP, 1>), dim3((unsigned)((g.nc[0] + H2L4_T - 1) / H2L4_T), (unsigned)g.nc[1]), \
