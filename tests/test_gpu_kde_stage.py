@@ -147,3 +147,43 @@ def test_kde_stash():
     _assert_correct_scaling(_pipe(c, ("gen", "aeff", "kde", "set_variance"), output_errors=True), fixed_errors=True)
     _assert_correct_scaling(_pipe(c, ("gen", "kde", "aeff", "set_variance"), kde={"stash_hists": True},
                                   aeff_binned=True, output_errors=True), fixed_errors=True)
+
+
+def test_kde_stage_many_evaluations_same_bits_and_no_memory_growth():
+    """the library's estimator pool over many evaluations: alternating two parameter points, every return to a point
+    reproduces its maps bit for bit, and neither torch's allocator nor the device's free memory (the pool's grow-only
+    workspaces) keeps moving after the first evaluations"""
+    from collections import OrderedDict
+
+    import torch
+
+    from pisa_amd.core.config_parser import parse_pipeline_config
+    from pisa_amd.core.pipeline import Pipeline
+    from pisa_amd.core.units import ureg
+
+    cfg = OrderedDict()
+    for k, v in parse_pipeline_config("settings/pipeline/example_hip.cfg").items():
+        cfg[("utils", "kde") if k == ("utils", "hist") else k] = (
+            OrderedDict(calc_mode="events", apply_mode=v["apply_mode"]) if k == ("utils", "hist") else v)
+    cfg["pipeline"]["output_key"] = "weights"
+    cfg[("data", "synthetic_events")]["params"].params.n_events.value = 6.0e5
+    pipe = Pipeline(cfg)
+    ref, free_after_warmup, alloc_after_warmup = {}, None, None
+    for it in range(40):
+        th = (42.0, 47.5)[it % 2]
+        pipe.params.theta23.value = th * ureg.degree
+        maps = [m.hist.copy() for m in pipe.get_outputs()]
+        assert all(np.all(np.isfinite(m)) for m in maps)
+        if th in ref:
+            for a, b in zip(ref[th], maps):
+                np.testing.assert_array_equal(a, b)
+        else:
+            ref[th] = maps
+        if it == 5:
+            torch.cuda.synchronize()
+            free_after_warmup = torch.cuda.mem_get_info()[0]
+            alloc_after_warmup = torch.cuda.memory_allocated()
+    torch.cuda.synchronize()
+    assert not np.array_equal(ref[42.0][0], ref[47.5][0])
+    assert torch.cuda.memory_allocated() <= alloc_after_warmup + (8 << 20)
+    assert torch.cuda.mem_get_info()[0] >= free_after_warmup - (64 << 20)
