@@ -482,3 +482,22 @@ def test_kde_weightless_isolated_sources_do_not_poison_the_bandwidths():
         np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-12 * want.max())
     lat = est.evaluate_lattice([-3.0, -3.0], [6.0 / 39, 6.0 / 29], (40, 30)).cpu().numpy()
     np.testing.assert_array_equal(lat, got)   # tol = 0: the lattice is written out
+
+
+def test_kde_batch_reports_a_failing_job_and_stays_usable():
+    """a job the estimator refuses (all weights zero: no finite moments) comes back as an error of the batch call;
+    the other jobs of the batch have run, and the library's pool takes the next batch"""
+    from pisa_amd import _lib
+    from pisa_amd import kernels as K
+
+    rs = np.random.RandomState(29)
+    good = K.to_device(rs.randn(2, 25000))
+    w_good = K.to_device(rs.rand(25000) + 0.1)
+    w_bad = K.to_device(np.zeros(25000))
+    origin, step, count = [-2.0, -2.0], [0.1, 0.1], (41, 41)
+    with pytest.raises(_lib.PisaHipError):
+        K.kde_lattice_batch([(good, w_good, None), (good, w_bad, None)], origin, step, count, n_threads=2)
+    dens, sums, _ = K.kde_lattice_batch([(good, w_good, None), (good, None, None)], origin, step, count, n_threads=2)
+    ref = K.KdeEstimator(good, w_good, alpha=0.3).evaluate_lattice(origin, step, count)
+    np.testing.assert_array_equal(dens[0].cpu().numpy(), ref.cpu().numpy())
+    assert sums[1] == 25000.0 and np.isclose(sums[0], float(w_good.sum()), rtol=1e-13)
