@@ -1349,6 +1349,8 @@ kde_h2l_kernel(KdeGeom g, const int32_t *__restrict__ tcells, const int32_t *__r
 // order of the kernel above (offsets ascending = sources descending, inner index ascending): same bits.
 //   pass 0   grid (nx, ceil(ny / 4)):  V[cy_C][cx] for cy_C = 4 q .. 4 q + 3
 //   pass 1   grid (ceil(nx / 4), ny):  L[head of (cx_C, cy)] for cx_C = 4 q .. 4 q + 3 (cells with sources only)
+// 1 / n!, n < 24 (the factorial scaling of the local expansion: two multiplications instead of two loops and a division per element)
+__device__ constexpr double INV_FACT[24] = {1.0, 1.0, 0.5, 0.16666666666666666, 0.041666666666666664, 0.008333333333333333, 0.001388888888888889, 0.0001984126984126984, 2.48015873015873e-05, 2.7557319223985893e-06, 2.755731922398589e-07, 2.505210838544172e-08, 2.08767569878681e-09, 1.6059043836821613e-10, 1.1470745597729725e-11, 7.647163731819816e-13, 4.779477332387385e-14, 2.8114572543455206e-15, 1.5619206968586225e-16, 8.22063524662433e-18, 4.110317623312165e-19, 1.9572941063391263e-20, 8.896791392450574e-22, 3.8681701706306835e-23};
 constexpr int H2L4_T = 4;
 template <int P, int PASS>
 __global__ void __launch_bounds__(H2L_THREADS)
@@ -1359,6 +1361,7 @@ kde_h2l4_kernel(KdeGeom g, const int32_t *__restrict__ hslot, const int32_t *__r
     constexpr int NHP = NH + 8;                                 // padded Hankel row (tiles beyond P read past NH)
     constexpr int PER = (PP + H2L_THREADS - 1) / H2L_THREADS;   // matrix elements a thread stages
     static_assert(PT * PT * H2L4_T <= H2L_THREADS, "tiles x targets must fit the workgroup");
+    static_assert(P <= 24, "INV_FACT");
     __shared__ double sA[PR * PR];                              // [row][col], row stride PR, zero beyond P
     __shared__ double sH[(2 * H2L_MAX_REACH + 1) * NHP];
     const int t = threadIdx.x;
@@ -1493,11 +1496,8 @@ kde_h2l4_kernel(KdeGeom g, const int32_t *__restrict__ hslot, const int32_t *__r
                 const int r0 = 4 * ti + di, r1 = 4 * tj + dj;
                 if (r0 < P && r1 < P) {
                     // D_k D_l = (-1)^(k+l) / (k! l!)
-                    double fk = 1.0, fl = 1.0;
-                    for (int i = 2; i <= r0; i++) fk *= (double)i;
-                    for (int i = 2; i <= r1; i++) fl *= (double)i;
                     const double sgn = ((r0 + r1) & 1) ? -1.0 : 1.0;
-                    local[(int64_t)my_head * PP + r0 * P + r1] = sgn * acc[di][dj] / (fk * fl);
+                    local[(int64_t)my_head * PP + r0 * P + r1] = sgn * acc[di][dj] * INV_FACT[r0] * INV_FACT[r1];
                 }
             }
     }
