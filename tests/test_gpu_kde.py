@@ -314,9 +314,9 @@ def test_kde_stage_bootstrap():
 
 
 def test_kde_stage_concurrent_estimators_are_bit_identical_to_sequential():
-    """`utils.kde` runs the estimators of one evaluation from four host threads on their own streams;
-    every estimator is deterministic by itself, so the maps must not depend on the interleaving:
-    repeated concurrent evaluations and a single-thread evaluation give the same bits."""
+    """`utils.kde` hands the estimators of one evaluation to the library's thread pool (`kde_workers` threads, each
+    with its own stream); every estimator is deterministic by itself, so the maps must not depend on the
+    interleaving: repeated concurrent evaluations and a single-thread evaluation give the same bits."""
     from collections import OrderedDict
 
     from pisa_amd.core.config_parser import parse_pipeline_config
