@@ -1358,11 +1358,12 @@ kde_h2l4_kernel(KdeGeom g, const int32_t *__restrict__ hslot, const int32_t *__r
                 const double *__restrict__ herm, const double *__restrict__ hankel, int reach,
                 double *__restrict__ V, uint8_t *__restrict__ vflag, double *__restrict__ local) {
     constexpr int NH = 2 * P - 1, PT = (P + 3) / 4, PR = PT * 4, PP = P * P;
+    constexpr int SR = PR + 1;                                  // row stride of the staged matrix: with 20 the four-row tiles of pass 0 fall on one bank
     constexpr int NHP = NH + 8;                                 // padded Hankel row (tiles beyond P read past NH)
     constexpr int PER = (PP + H2L_THREADS - 1) / H2L_THREADS;   // matrix elements a thread stages
     static_assert(PT * PT * H2L4_T <= H2L_THREADS, "tiles x targets must fit the workgroup");
     static_assert(P <= 24, "INV_FACT");
-    __shared__ double sA[PR * PR];                              // [row][col], row stride PR, zero beyond P
+    __shared__ double sA[PR * SR];                              // [row][col], row stride SR, zero beyond P
     __shared__ double sH[(2 * H2L_MAX_REACH + 1) * NHP];
     const int t = threadIdx.x;
     const int tg = t / (PT * PT), tile = t % (PT * PT);
@@ -1372,7 +1373,7 @@ kde_h2l4_kernel(KdeGeom g, const int32_t *__restrict__ hslot, const int32_t *__r
         const int row = i / NHP, col = i % NHP;
         sH[i] = col < NH ? hankel[row * NH + col] : 0.0;
     }
-    for (int i = t; i < PR * PR; i += H2L_THREADS) sA[i] = 0.0;
+    for (int i = t; i < PR * SR; i += H2L_THREADS) sA[i] = 0.0;
     const int nx = g.nc[0], ny = g.nc[1];
     // targets of this workgroup along the convolution direction: u0 .. u0 + 3; the fixed coordinate: w
     const int u0 = (PASS == 0 ? (int)blockIdx.y : (int)blockIdx.x) * H2L4_T;
@@ -1426,7 +1427,7 @@ kde_h2l4_kernel(KdeGeom g, const int32_t *__restrict__ hslot, const int32_t *__r
 #pragma unroll
         for (int u = 0; u < PER; u++) {
             const int e = t + u * H2L_THREADS;
-            if (e < PP) sA[(e / P) * PR + e % P] = mine[u];
+            if (e < PP) sA[(e / P) * SR + e % P] = mine[u];
         }
         __syncthreads();
         const int o = my_u - v;
@@ -1434,12 +1435,12 @@ kde_h2l4_kernel(KdeGeom g, const int32_t *__restrict__ hslot, const int32_t *__r
             any = true;
             const double *hk = sH + (o + reach) * NHP;
             if (PASS == 0) {             // W[alpha][l] += sum_beta A[alpha][beta] h_{beta + l}(d2)
-                const double *r = sA + (4 * ti) * PR, *h = hk + 4 * tj;
+                const double *r = sA + (4 * ti) * SR, *h = hk + 4 * tj;
                 double h0 = h[0], h1 = h[1], h2 = h[2];
 #pragma unroll
                 for (int b = 0; b < P; b++) {
                     const double h3 = h[b + 3];
-                    const double a0 = r[b], a1 = r[PR + b], a2 = r[2 * PR + b], a3 = r[3 * PR + b];
+                    const double a0 = r[b], a1 = r[SR + b], a2 = r[2 * SR + b], a3 = r[3 * SR + b];
                     acc[0][0] = __builtin_fma(a0, h0, acc[0][0]); acc[0][1] = __builtin_fma(a0, h1, acc[0][1]);
                     acc[0][2] = __builtin_fma(a0, h2, acc[0][2]); acc[0][3] = __builtin_fma(a0, h3, acc[0][3]);
                     acc[1][0] = __builtin_fma(a1, h0, acc[1][0]); acc[1][1] = __builtin_fma(a1, h1, acc[1][1]);
@@ -1456,7 +1457,7 @@ kde_h2l4_kernel(KdeGeom g, const int32_t *__restrict__ hslot, const int32_t *__r
 #pragma unroll
                 for (int a = 0; a < P; a++) {
                     const double h3 = h[a + 3];
-                    const double v0 = c[a * PR], v1 = c[a * PR + 1], v2 = c[a * PR + 2], v3 = c[a * PR + 3];
+                    const double v0 = c[a * SR], v1 = c[a * SR + 1], v2 = c[a * SR + 2], v3 = c[a * SR + 3];
                     acc[0][0] = __builtin_fma(h0, v0, acc[0][0]); acc[0][1] = __builtin_fma(h0, v1, acc[0][1]);
                     acc[0][2] = __builtin_fma(h0, v2, acc[0][2]); acc[0][3] = __builtin_fma(h0, v3, acc[0][3]);
                     acc[1][0] = __builtin_fma(h1, v0, acc[1][0]); acc[1][1] = __builtin_fma(h1, v1, acc[1][1]);

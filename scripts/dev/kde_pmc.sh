@@ -12,21 +12,30 @@ pass a SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU 
 pass b SQ_INSTS_SMEM SQ_INSTS_SALU SQ_INST_CYCLES_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_WAIT_ANY
 pass c SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
 python3 - $OUT <<'PY'
-import csv, sys, collections
+import csv, sys, collections, json
 out = sys.argv[1]
+keys = ("kde_lattice_kernel", "kde_local_pilot", "kde_h2l4_kernel<20, 0>", "kde_h2l4_kernel<20, 1>", "kde_hermite_coef")
+res = collections.defaultdict(dict)
 for tag in "abc":
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open("%s/pmc_%s.csv" % (out, tag))):
-        name = r["Kernel_Name"]
-        for key in ("kde_lattice_kernel", "kde_local_pilot", "kde_h2l_kernel<20, 0>", "kde_h2l_kernel<20, 1>", "kde_hermite_coef"):
-            if key in name:
+        for key in keys:
+            if key in r["Kernel_Name"]:
                 acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                if tag == "a" and r["Counter_Name"] == "SQ_WAVES":
+                    acc[key]["_dur_us"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     for key, d in acc.items():
-        print(tag, key, {c: "%.4g" % (sum(v) / len(v)) for c, v in d.items()})
-    if tag == "a":
-        for key, d in acc.items():
-            n = len(d["SQ_WAVES"])
-            valu = sum(d["SQ_ACTIVE_INST_VALU"]) / n / 1024 * 4; busy = sum(d["SQ_BUSY_CYCLES"]) / n / 32
-            print("   ", key, "VALU busy fraction %.2f, wait fraction of wave cycles %.2f, mean wave lifetime / launch %.2f" % (
-                valu / busy, sum(d["SQ_WAIT_INST_ANY"]) / sum(d["SQ_WAVE_CYCLES"]), sum(d["SQ_WAVE_CYCLES"]) / sum(d["SQ_WAVES"]) * 4 / busy))
+        for c, v in d.items():
+            res[key][c.lstrip("_")] = sum(v) / len(v)
+for key, d in res.items():
+    busy = d["SQ_BUSY_CYCLES"] / 32
+    d["derived"] = {"valu_busy_fraction_of_launch": d["SQ_ACTIVE_INST_VALU"] / 1024 * 4 / busy,
+                    "mean_wavefront_lifetime_fraction_of_launch": d["SQ_WAVE_CYCLES"] / d["SQ_WAVES"] * 4 / busy,
+                    "clock_GHz": busy / d["dur_us"] / 1e3,
+                    "lds_bank_conflict_cycles_per_lds_instruction": d.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(d.get("SQ_INSTS_LDS", 0.0), 1.0)}
+    print(key, {k: round(v, 3) for k, v in d["derived"].items()}, "dur_us %.1f" % d["dur_us"])
+json.dump({"per_launch_means": res,
+           "method": "scripts/dev/kde_pmc.sh: three separate rocprofv3 --pmc passes (with --kernel-trace) over scripts/dev/kde_facts.py 1e7 3 "
+                     "(the estimators of 3 containers of the C3 workload, one stream); SQ_BUSY_CYCLES / 32 = launch length in cycles, "
+                     "SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES in quad-cycles, 1 024 SIMDs"}, open(out + "/kde_sq_counters.json", "w"), indent=1)
 PY
