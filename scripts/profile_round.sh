@@ -9,6 +9,7 @@
 #                               (SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 pass over scripts/bench_events.py)
 #   kde_kernel_stats.csv        kernel trace statistics of the C3 (KDE on) pipeline
 #   kde_flops.json              executed fp64 flops of all kde_* kernels of one C3 evaluation (counter pass)
+#   kde_sq_counters.json        SQ counters of the lattice / pilot / translation / coefficient kernels (scripts/dev/kde_pmc.sh)
 TAG=$1
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; rm -rf $OUT; mkdir -p $OUT
@@ -38,6 +39,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kde_stats -o kde --
 cp $OUT/kde_stats/kde_kernel_stats.csv $OUT/kde_kernel_stats.csv
 rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 --kernel-trace --output-format csv -d $OUT/pmc_c3 -o p -- python3 scripts/dev/c3_probe.py 1e7 > $OUT/c3_pmc_run.log 2> $OUT/pmc_c3.log
 cp $OUT/pmc_c3/p_counter_collection.csv $OUT/pmc_c3_full.csv
+# SQ counters of the KDE kernels (VALU occupancy, wavefront lifetimes, LDS conflicts): kde_sq_counters.json
+bash scripts/dev/kde_pmc.sh > $OUT/kde_pmc.log 2>&1; cp gpurun_out/kde_pmc/kde_sq_counters.json $OUT/kde_sq_counters.json
 # ---- round 3: kernel-trace durations for every leg's kernel (the legs' roofline fractions were HIP-event
 # numbers without a trace counterpart), the event kernel (C2 / C5 sizes, default and decay instantiation)
 # with its SQ counters, the multi-point kernels, the one-pass flux refresh
