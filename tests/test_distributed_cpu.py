@@ -395,3 +395,72 @@ def test_bench_multi_gpu_control_flow_on_gloo_ranks(tmp_path):
     pts = bench.param_list(wl, _lib.MAX_POINTS + 2)
     assert single.eval_many(pts, "llh") == [single.eval_host(p, "llh") for p in pts]
     assert single.sweeps == 2
+
+
+# ---- utils.kde.apply_function itself on several ranks (CPU, gloo): the containers it owns, the lazily produced event
+#      weights, ONE batched estimator call per rank, the exchange of the finished maps -- with the native batch call
+#      replaced by a host stand-in (the stage's own code otherwise)
+class _FakeContainer(dict):
+    def __init__(self, name, size):
+        super().__init__()
+        self.name, self.size, self.representation, self.weights_asked = name, size, None, 0
+
+    def device(self, key):
+        assert key == "weights" and self.representation == "events"
+        self.weights_asked += 1
+        return torch.full((self.size,), float(len(self.name)), dtype=torch.float64)
+
+
+class _FakeData(list):
+    representation = None
+
+
+def _kde_stage_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pisa_amd.core.binning import MultiDimBinning, OneDimBinning
+    from pisa_amd.stages.utils import kde as kde_mod
+    from pisa_amd.utils import kde_hist
+
+    binning = MultiDimBinning([OneDimBinning("reco_energy", domain=[1.0, 10.0], num_bins=3, is_lin=True),
+                               OneDimBinning("reco_coszen", domain=[-1, 1], num_bins=2, is_lin=True),
+                               OneDimBinning("pid", bin_edges=[0.0, 0.5, 1.0], is_lin=True)])
+    stage = kde_mod.kde(calc_mode="events", apply_mode=binning)
+    stage.regularized_apply_mode = binning
+    sizes = [500, 40, 30, 450, 20, 10, 470, 35, 25, 460, 15, 5]
+    stage.data = _FakeData(_FakeContainer("c%02d" % i, n) for i, n in enumerate(sizes))
+    stage._static_sample = lambda c: dict(sample=torch.zeros((c.size, 3), dtype=torch.float64), channels=None, versions=())
+    calls = []
+
+    def fake_batch(samples, **kw):
+        calls.append(len(samples))
+        assert kw["n_threads"] == stage.kde_workers and kw["binning"] is binning
+        out = []
+        for s in samples:
+            w = s["weights"]()          # the stage hands over a callable: evaluated when the sample's turn comes
+            out.append(np.full(binning.shape, float(w.sum())))
+        return out
+
+    kde_hist_batch = kde_hist.kde_histogramdd_batch
+    kde_hist.kde_histogramdd_batch = fake_batch
+    try:
+        stage.apply_function()
+    finally:
+        kde_hist.kde_histogramdd_batch = kde_hist_batch
+    owned = kde_mod.kde.owned_containers(len(sizes), rank, world, sizes=sizes)
+    assert calls == [len(owned)]                                   # one batched call with exactly this rank's containers
+    assert [c.weights_asked for c in stage.data] == [1 if i in owned else 0 for i in range(len(sizes))]
+    for i, c in enumerate(stage.data):                             # every rank ends with every map
+        np.testing.assert_array_equal(c["weights"], np.full(int(np.prod(binning.shape)), float(sizes[i] * len(c.name))))
+    if rank == 0:
+        np.save(out_path, np.array([c["weights"][0] for c in stage.data]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_kde_stage_apply_function_on_gloo_ranks(tmp_path, world):
+    out = str(tmp_path / "stage.npy")
+    mp.spawn(_kde_stage_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    sizes = [500, 40, 30, 450, 20, 10, 470, 35, 25, 460, 15, 5]
+    np.testing.assert_array_equal(np.load(out), np.array([3.0 * n for n in sizes]))
