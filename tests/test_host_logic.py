@@ -603,3 +603,24 @@ def test_forward_stencil_is_scipys_two_point_scheme():
             assert len(asked) == len(pts) and all(np.array_equal(p, q) for p, q in zip(asked, pts))
             vals = np.array([f(p) for p in pts])
             np.testing.assert_array_equal((vals[1:] - vals[0]) / dx, g)
+
+
+def test_kde_map_postprocessing_of_a_stack_equals_map_by_map():
+    """`kde_hist._finish_hist_many` (reflection at coszen = -1 / +1 without concatenations, bin volumes, block sums of the
+    oversampling, vectorised over the estimators of an evaluation) gives, bit for bit, what `_finish_hist` -- the
+    reference's sequence (kde_hist.py:168-217) -- gives map by map: both reflections, one, none, coszen on either axis"""
+    from pisa_amd.core.binning import MultiDimBinning, OneDimBinning
+    from pisa_amd.utils import kde_hist as kh
+
+    for names in (("energy", "coszen"), ("coszen", "energy")):
+        for dom in ([-1, 1], [-1, 0.5], [-0.5, 1], [-0.8, 0.8]):
+            dims = dict(energy=OneDimBinning("energy", domain=[0.5, 3.5], num_bins=6, is_lin=True),
+                        coszen=OneDimBinning("coszen", domain=dom, num_bins=8, is_lin=True))
+            b = MultiDimBinning([dims[n] for n in names])
+            for refl, over in ((0.25, 5), (0.5, 1), (0.25, 1)):
+                g = kh._evaluation_grid(b, over, "coszen", refl)
+                d = np.random.RandomState(0).rand(7, *g["megashape"])
+                many = kh._finish_hist_many(g, d, over)
+                for k in range(7):
+                    one, _ = kh._finish_hist(g, d[k], None, over)
+                    np.testing.assert_array_equal(one, many[k])
