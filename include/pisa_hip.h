@@ -482,6 +482,10 @@ int pisa_hip_kde_lattice_submit(pisa_hip_kde_job *jobs, int32_t n_jobs, int32_t 
                                 int32_t adaptive, double alpha, double tol, const double *h_origin,
                                 const double *h_step, const int64_t *h_count, int32_t n_threads, void *stream);
 int pisa_hip_kde_lattice_wait(void);
+/* The pool threads keep their stream, workspaces and estimator scratch between calls (grow-only, a few hundred MB per
+ * thread at C3 sizes).  This call waits for the queued jobs, has every pool thread free what it holds and returns when
+ * all have; the next submission allocates again. */
+int pisa_hip_kde_pool_release(void);
 
 /* How the 2-D fixed-bandwidth pilot estimate sums its cells (fast Gauss transform; truncation error below
  * the cut-off tolerance): 2 (default) = Hermite series of ALL non-empty source cells translated into one

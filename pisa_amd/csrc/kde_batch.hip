@@ -60,6 +60,16 @@ static int grow(void **buf, size_t *have, size_t need, hipStream_t s) {
     return PISA_HIP_OK;
 }
 
+static void free_state(KdeWorkerState &st) {
+    if (st.device >= 0) (void)hipSetDevice(st.device);
+    if (st.stream) (void)hipStreamSynchronize(st.stream);
+    (void)pisa_hip_kde_release_scratch();      // the estimator's per-thread scratch (kde.hip)
+    if (st.work) (void)hipFree(st.work);
+    if (st.lwork) (void)hipFree(st.lwork);
+    if (st.stream) (void)hipStreamDestroy(st.stream);
+    st = KdeWorkerState();
+}
+
 class KdePool {
   public:
     typedef std::function<void(KdeWorkerState &)> Task;
@@ -86,15 +96,34 @@ class KdePool {
         cv_done_.wait(lk, [this] { return pending_ == 0; });
         limit_ = 0;
     }
+    // every pool thread frees its stream, workspaces and library scratch (they are grow-only otherwise); returns when
+    // all of them have
+    void release() {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_done_.wait(lk, [this] { return pending_ == 0; });
+        release_epoch_++;
+        released_ = 0;
+        cv_job_.notify_all();
+        cv_done_.wait(lk, [this] { return released_ == (int)threads_.size(); });
+    }
 
   private:
     void loop() {
         KdeWorkerState st;
         std::unique_lock<std::mutex> lk(m_);
         const int my_id = n_started_++;
+        int seen_epoch = release_epoch_;
         for (;;) {
-            cv_job_.wait(lk, [&] { return stop_ || (!queue_.empty() && my_id < limit_); });
+            cv_job_.wait(lk, [&] { return stop_ || seen_epoch != release_epoch_ || (!queue_.empty() && my_id < limit_); });
             if (stop_) return;
+            if (seen_epoch != release_epoch_) {
+                seen_epoch = release_epoch_;
+                lk.unlock();
+                free_state(st);
+                lk.lock();
+                if (++released_ == (int)threads_.size()) cv_done_.notify_all();
+                continue;
+            }
             Task task = std::move(queue_.front());
             queue_.pop_front();
             lk.unlock();
@@ -107,7 +136,7 @@ class KdePool {
     std::condition_variable cv_job_, cv_done_;
     std::vector<std::thread> threads_;
     std::deque<Task> queue_;
-    int pending_ = 0, limit_ = 0, n_started_ = 0;
+    int pending_ = 0, limit_ = 0, n_started_ = 0, release_epoch_ = 0, released_ = 0;
     bool stop_ = false;
 };
 
@@ -220,6 +249,11 @@ PISA_API int pisa_hip_kde_lattice_submit(pisa_hip_kde_job *jobs, int32_t n_jobs,
 
 PISA_API int pisa_hip_kde_lattice_wait(void) {
     pool().wait();
+    return PISA_HIP_OK;
+}
+
+PISA_API int pisa_hip_kde_pool_release(void) {
+    pool().release();
     return PISA_HIP_OK;
 }
 

@@ -501,3 +501,23 @@ def test_kde_batch_reports_a_failing_job_and_stays_usable():
     ref = K.KdeEstimator(good, w_good, alpha=0.3).evaluate_lattice(origin, step, count)
     np.testing.assert_array_equal(dens[0].cpu().numpy(), ref.cpu().numpy())
     assert sums[1] == 25000.0 and np.isclose(sums[0], float(w_good.sum()), rtol=1e-13)
+
+
+def test_kde_pool_release_returns_the_workspaces():
+    """`pisa_hip_kde_pool_release`: the pool threads' grow-only workspaces go back to the device, and the pool works again"""
+    import torch
+
+    from pisa_amd import _lib
+    from pisa_amd import kernels as K
+
+    rs = np.random.RandomState(31)
+    jobs = [(K.to_device(rs.randn(2, 200000)), None, None) for _ in range(4)]
+    origin, step, count = [-2.0, -2.0], [0.05, 0.05], (81, 81)
+    a = K.kde_lattice_batch(jobs, origin, step, count, n_threads=4)[0].cpu().numpy()
+    torch.cuda.synchronize()
+    held = torch.cuda.mem_get_info()[0]
+    _lib.check(_lib.lib().pisa_hip_kde_pool_release())
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] > held + (50 << 20)      # hundreds of MB come back
+    b = K.kde_lattice_batch(jobs, origin, step, count, n_threads=4)[0].cpu().numpy()
+    np.testing.assert_array_equal(a, b)
