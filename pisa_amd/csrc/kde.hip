@@ -2007,7 +2007,10 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
         // target, so every non-empty cell gets one; evaluated target by target (no local expansions) a
         // series pays from ~24 sources
         const int dense_min = local_ok ? hermite_min() : std::max(hermite_min(), HERMITE_MIN_SERIES);
-        if (g_kde_expansion && dim == 2 && cut && n >= 20000) {
+        static const int64_t expansion_min_n = [] { const char *v = getenv("PISA_HIP_KDE_EXPANSION_MIN_N"); return v ? (int64_t)atoll(v) : (int64_t)1000; }();
+        // (1 000: C3-shaped evaluations of 1e5 / 3e5 events take 11.5 / 27.5 ms with the round-2 threshold of 20 000 sources per
+        //  estimator -- direct pair sums below it --, 5.7 / 5.9 ms with this one)
+        if (g_kde_expansion && dim == 2 && cut && n >= expansion_min_n) {
             for (size_t h = 0; h < h_starts.size(); h++) {
                 const int64_t end = h + 1 < h_starts.size() ? h_starts[h + 1] : n;
                 if (end - h_starts[h] < dense_min) continue;
