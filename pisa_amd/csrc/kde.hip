@@ -30,6 +30,16 @@
 //   reduction, degree-13 polynomial, ldexp: 19 instructions instead of the library's ~35).
 // Roofline: FP64 VALU, 23 instructions per pair in 2-D (compute bound; 32 B of LDS per pair
 // and pair of queries).
+//
+// On top of the cell list, in 2-D with a cut-off (the KDE stage's case):
+// * the PILOT is a fast Gauss transform: Hermite series of every non-empty cell (`kde_hermite_coef_kernel`),
+//   translated into one local expansion per target cell in two separable passes over the cell grid
+//   (`kde_h2l4_kernel<P, 0 / 1>`), evaluated with P^2 multiply-adds per target (`kde_local_pilot_kernel`);
+// * a map is evaluated on the LATTICE of its points (`pisa_hip_kde_evaluate_lattice`, `kde_lattice_kernel`): along a
+//   lattice line the kernel values of a source follow g_{c+-k} = g_c r^k Q_k, one multiply and one multiply-add each;
+// * the estimators of one evaluation of the stage run as one job list on the library's own threads and streams
+//   (`kde_batch.hip`: `pisa_hip_kde_lattice_submit / _wait`).
+// History and the measurements behind every choice: EXPERIMENTS.md (section 4.4, R3-8).
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
