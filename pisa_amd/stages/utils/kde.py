@@ -126,19 +126,23 @@ class kde(Stage):  # pylint: disable=invalid-name
         """mean and standard deviation of the maps of `bootstrap_niter` resampled samples
         (stages/utils/kde.py:189-258)"""
         rng = np.random.default_rng(self.bootstrap_seed)
-        maps = []
+        # the resampled samples are independent: their estimators go to the library as one job list (the draws are
+        # made in the reference's order first); maps = those of kde_histogramdd one resample after the other
+        resampled = []
         for _ in range(self.bootstrap_niter):
             sw = self._bootstrap_weights(rng, st, int(weights.numel()))
-            try:
-                m = kde_hist.kde_histogramdd(weights=weights * sw, stats=self.stats, **kw)
-            except Exception as exc:
-                raise RuntimeError(
-                    "Could not calculate KDE with the given sample. This can happen if the "
-                    "bootstrap selects too few distinct events in one of the PID channels."
-                ) from exc
+            resampled.append(dict(sample=kw["sample"], weights=weights * sw, channels=kw.get("channels")))
+        bkw = {k: v for k, v in kw.items() if k not in ("sample", "channels")}
+        try:
+            maps = kde_hist.kde_histogramdd_batch(resampled, stats=self.stats, n_threads=self.kde_workers, **bkw)
+        except Exception as exc:
+            raise RuntimeError(
+                "Could not calculate KDE with the given sample. This can happen if the "
+                "bootstrap selects too few distinct events in one of the PID channels."
+            ) from exc
+        for m in maps:
             if not np.all(np.isfinite(m)):
                 raise RuntimeError("Could not calculate KDE with the given sample (non-finite map).")
-            maps.append(m)
         maps = np.stack(maps)
         return np.mean(maps, axis=0), np.std(maps, axis=0)
 
