@@ -416,20 +416,30 @@ __device__ __forceinline__ void get_dms(double energy, const mat3 &H, const doub
 // the reference calls LAPACK zgeev through np.linalg.eigvals,
 // numba_osc_kernels.py:655-685).  Closed-form cubic + Newton polishing; the
 // order of the eigenvalues is irrelevant to everything downstream.
+// FAST (event-mode kernel): the operands come from the cubic of a matrix scaled to unit size, so the modulus is a
+// plain square root of the sum of squares (no hypot scaling), and the cube root's angle uses sincos_third_angle
+// (no library atan2 + sincos: 260 instructions -> ~90); equal to a few ulp.
+template <bool FAST = false>
 __device__ __forceinline__ cplx csqrt_d(cplx z) {
-    double r = hypot(z.re, z.im);
+    double r = FAST ? sqrt(z.re * z.re + z.im * z.im) : hypot(z.re, z.im);
     if (r == 0.0) return cmake(0.0, 0.0);
     double t = sqrt(0.5 * (r + fabs(z.re)));
     if (z.re >= 0.0) return cmake(t, z.im / (2.0 * t));
     return cmake(fabs(z.im) / (2.0 * t), z.im >= 0.0 ? t : -t);
 }
+template <bool FAST = false>
 __device__ __forceinline__ cplx ccbrt_d(cplx z) {
-    double r = hypot(z.re, z.im);
+    double r = FAST ? sqrt(z.re * z.re + z.im * z.im) : hypot(z.re, z.im);
     if (r == 0.0) return cmake(0.0, 0.0);
-    double ang = atan2(z.im, z.re) / 3.0;
     double m = cbrt(r);
     double s, c;
-    sincos(ang, &s, &c);
+    if (FAST) {
+        sincos_third_angle(fabs(z.im), z.re, &s, &c);   // angle of (re, |im|) / 3, in [0, pi/3]
+        s = z.im < 0.0 ? -s : s;
+    } else {
+        double ang = atan2(z.im, z.re) / 3.0;
+        sincos(ang, &s, &c);
+    }
     return cmake(m * c, m * s);
 }
 template <bool FAST = false>
@@ -465,10 +475,10 @@ __device__ inline void eigvals3_general(const mat3 &H, cplx (&lam)[3]) {
     cplx q = cadd(csub(cscale(2.0 / 27.0, cmul(c2sq, c2)), cscale(1.0 / 3.0, cmul(c2, c1))), c0);
     cplx halfq = cscale(0.5, q);
     cplx disc = cadd(cmul(halfq, halfq), cscale(1.0 / 27.0, cmul(cmul(p, p), p)));
-    cplx sd = csqrt_d(disc);
+    cplx sd = csqrt_d<FAST>(disc);
     cplx u1 = csub(sd, halfq), u2 = csub(cscale(-1.0, sd), halfq);
     cplx u3 = (cabs2(u1) >= cabs2(u2)) ? u1 : u2;
-    cplx u = ccbrt_d(u3);
+    cplx u = ccbrt_d<FAST>(u3);
     const cplx w1 = {-0.5, 0.86602540378443864676}, w2 = {-0.5, -0.86602540378443864676};
     cplx us[3] = {u, cmul(u, w1), cmul(u, w2)};
     cplx shift = cscale(1.0 / 3.0, c2);
