@@ -27,4 +27,5 @@ for batched in (False, True):
         dt = time.perf_counter() - t0
         print("batched", batched, "evals", res.num_distributions_generated, "wall %.2f ms" % (dt * 1e3), "us/eval %.1f" % (1e6 * dt / res.num_distributions_generated))
         if pr:
-            pstats.Stats(pr).sort_stats(os.environ.get("SORT", "cumulative")).print_stats(28)
+            st_ = pstats.Stats(pr).sort_stats(os.environ.get("SORT", "cumulative")); st_.print_stats(28)
+            if os.environ.get("CALLERS"): st_.print_callers(os.environ["CALLERS"])
