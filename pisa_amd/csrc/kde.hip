@@ -346,32 +346,60 @@ __device__ inline int64_t flat_cell(uint64_t key, const KdeGeom &g) {
     return (cz * g.nc[1] + cy) * g.nc[0] + cx;
 }
 
-// The sources are sorted by their FLAT cell index (a 32-bit key of ceil(log2 n_cells) significant bits: three
+// The sources are sorted by their FLAT cell index (a 32-bit key of ceil(log2 n_cells) significant bits: two or three
 // 8-bit radix passes at C3 sizes) instead of the 63-bit tile key (a 64-bit merge sort below 2^20 items): both
 // orders are the same (cz, cy, cx lexicographic, stable), so the sorted order is what it was.
+// whitened coordinates + flat cell index of every source (put inside the cell grid like kde_whiten_key_kernel's clamp)
+template <int D>
 __global__ void __launch_bounds__(256)
-kde_flat_key_kernel(const uint64_t *__restrict__ keys, int64_t n, KdeGeom g, uint32_t *__restrict__ flat) {
-    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (k < n) flat[k] = (uint32_t)flat_cell(keys[k], g);
-}
-__global__ void __launch_bounds__(256)
-kde_tile_key_kernel(const uint32_t *__restrict__ flat, int64_t n, KdeGeom g, uint64_t *__restrict__ keys) {
-    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (k >= n) return;
-    const int64_t c = flat[k];
-    const int64_t cx = c % g.nc[0], cy = (c / g.nc[0]) % g.nc[1], cz = c / ((int64_t)g.nc[0] * g.nc[1]);
-    keys[k] = ((uint64_t)(cz + KEY_OFF) << 42) | ((uint64_t)(cy + KEY_OFF) << 21) | (uint64_t)(cx + KEY_OFF);
+kde_whiten_flat_kernel(const double *__restrict__ x, int64_t n, KdeGeom g, double *__restrict__ y,
+                       uint32_t *__restrict__ flat, uint32_t *__restrict__ idx) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double xc[3] = {0, 0, 0}, yy[3] = {0, 0, 0};
+#pragma unroll
+    for (int d = 0; d < D; d++) xc[d] = x[(int64_t)d * n + i] - g.mean[d];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        double a = 0.0;
+#pragma unroll
+        for (int e = d; e < D; e++) a += g.U[d * 3 + e] * xc[e];
+        const double lo = g.ylo[d], hi = g.ylo[d] + (g.nc[d] - 0.5) * g.cell;
+        const double v = fmin(fmax(a, lo), hi);   // rounding may put a point a hair outside the transformed bounding box
+        yy[d] = (a == a) ? v : a;
+        y[(int64_t)d * n + i] = a;
+    }
+    flat[i] = (uint32_t)flat_cell(tile_key(yy, g, 1), g);
+    idx[i] = (uint32_t)i;
 }
 
-// cell_start[c] = first sorted source of cell c (sources sorted by key == sorted by flat cell)
+// cell_start[c] = first sorted source of cell c, from the sorted flat cell indices
 __global__ void __launch_bounds__(256)
-kde_cell_start_kernel(const uint64_t *__restrict__ keys, int64_t n, KdeGeom g, int64_t n_cells,
-                      int32_t *__restrict__ cell_start) {
+kde_cell_start_flat_kernel(const uint32_t *__restrict__ flat, int64_t n, int64_t n_cells,
+                           int32_t *__restrict__ cell_start) {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (k > n) return;
-    const int64_t prev = k == 0 ? -1 : flat_cell(keys[k - 1], g);
-    const int64_t cur = k == n ? n_cells : flat_cell(keys[k], g);
+    const int64_t prev = k == 0 ? -1 : (int64_t)flat[k - 1];
+    const int64_t cur = k == n ? n_cells : (int64_t)flat[k];
     for (int64_t c = prev + 1; c <= cur; c++) cell_start[c] = (int32_t)k;
+}
+
+// sorted copies of the sources: ys[d][k] = y[d][perm[k]], wn[k] = w[perm[k]] / sum w, and the fixed-bandwidth
+// coefficients coef[k] = wn[k] / norm (s2[k] = 1 if given)
+template <int D>
+__global__ void __launch_bounds__(256)
+kde_gather_sources_kernel(const double *__restrict__ y, const double *__restrict__ w, double scale, double inv_norm,
+                          const uint32_t *__restrict__ perm, int64_t n, double *__restrict__ ys,
+                          double *__restrict__ wn, double *__restrict__ coef, double *__restrict__ s2) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t i = perm[k];
+#pragma unroll
+    for (int d = 0; d < D; d++) ys[(int64_t)d * n + k] = y[(int64_t)d * n + i];
+    const double v = (w ? w[i] : 1.0) * scale;
+    wn[k] = v;
+    coef[k] = v * inv_norm;
+    if (s2) s2[k] = 1.0;
 }
 
 // heads of runs of equal key
@@ -583,10 +611,11 @@ __device__ inline void exp_pair(double t, double h, double &up, double &dn) {
 constexpr int LAT_REC = 24;
 constexpr int LAT_Q0 = 8;
 constexpr int LAT_QMAX = 16;
-constexpr int LAT_SHARE = 64;   // sources per share
+constexpr int LAT_SHARE = 64;   // sources per share (= the workgroup of kde_lattice_prep_kernel, which writes the share's box)
 __global__ void __launch_bounds__(64)
 kde_lattice_prep_kernel(const double *__restrict__ ys, const double *__restrict__ coef,
-                        const double *__restrict__ s2, int64_t n, double da, double *__restrict__ rec) {
+                        const double *__restrict__ s2, int64_t n, double da, double rcut2, double *__restrict__ rec,
+                        double *__restrict__ box) {
     // one source per thread; the 64 records of a wavefront go through LDS so that they leave as 16-byte
     // stores of consecutive lanes (12 KB contiguous per wavefront)
     typedef double __attribute__((ext_vector_type(2))) d2;
@@ -608,43 +637,35 @@ kde_lattice_prep_kernel(const double *__restrict__ ys, const double *__restrict_
         for (int kk = 2; kk <= LAT_QMAX; kk++) r[LAT_Q0 + kk - 2] = exp_nonpos(-v * da * da * (double)(kk * (kk - 1) / 2));
         r[LAT_Q0 + LAT_QMAX - 1] = 0.0;
     }
+    // the share's (y_a, y_b) box: outside it no lattice point is within the cut-off of any of the 64 sources
+    // (sources are sorted by cell row, then cell column: a share is compact)
+    {
+        double alo = INFINITY, ahi = -INFINITY, blo = INFINITY, bhi = -INFINITY;
+        if (k < n) {
+            const double ya = ys[k], yb = ys[n + k];
+            const double reach = sqrt(rcut2 / s2[k]);
+            alo = ya - reach; ahi = ya + reach; blo = yb - reach; bhi = yb + reach;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            alo = fmin(alo, __shfl_down(alo, off));
+            ahi = fmax(ahi, __shfl_down(ahi, off));
+            blo = fmin(blo, __shfl_down(blo, off));
+            bhi = fmax(bhi, __shfl_down(bhi, off));
+        }
+        if (lane == 0) {
+            box[4 * blockIdx.x] = alo;
+            box[4 * blockIdx.x + 1] = ahi;
+            box[4 * blockIdx.x + 2] = blo;
+            box[4 * blockIdx.x + 3] = bhi;
+        }
+    }
     __syncthreads();
     const int64_t n_here = n - k0 < 64 ? n - k0 : 64;
     const int n_d2 = (int)n_here * (LAT_REC / 2);
     const d2 *src = reinterpret_cast<const d2 *>(stage);
     d2 *dst = reinterpret_cast<d2 *>(rec + k0 * LAT_REC);
     for (int i = lane; i < n_d2; i += 64) dst[i] = src[i];
-}
-
-// per share of the sorted sources: the (y_a, y_b) box outside which no lattice point is within the
-// cut-off of any of its sources (sources are sorted by cell row, then cell column: a share is compact)
-__global__ void __launch_bounds__(64)
-kde_lattice_box_kernel(const double *__restrict__ rec, int64_t n_src, int64_t share, double rcut2,
-                       double *__restrict__ box) {
-    const int64_t k0 = (int64_t)blockIdx.x * share;
-    const int64_t k1 = k0 + share < n_src ? k0 + share : n_src;
-    double alo = INFINITY, ahi = -INFINITY, blo = INFINITY, bhi = -INFINITY;
-    for (int64_t k = k0 + threadIdx.x; k < k1; k += 64) {
-        const double ya = rec[k * LAT_REC], yb = rec[k * LAT_REC + 1];
-        const double reach = sqrt(rcut2 / (-2.0 * rec[k * LAT_REC + 3]));
-        alo = fmin(alo, ya - reach);
-        ahi = fmax(ahi, ya + reach);
-        blo = fmin(blo, yb - reach);
-        bhi = fmax(bhi, yb + reach);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        alo = fmin(alo, __shfl_down(alo, off));
-        ahi = fmax(ahi, __shfl_down(ahi, off));
-        blo = fmin(blo, __shfl_down(blo, off));
-        bhi = fmax(bhi, __shfl_down(bhi, off));
-    }
-    if (threadIdx.x == 0) {
-        box[4 * blockIdx.x] = alo;
-        box[4 * blockIdx.x + 1] = ahi;
-        box[4 * blockIdx.x + 2] = blo;
-        box[4 * blockIdx.x + 3] = bhi;
-    }
 }
 
 // bounding box of patch p in (y_a, y_b)
@@ -964,16 +985,6 @@ kde_bandwidth_kernel(const double *__restrict__ pilot, const double *__restrict_
         partial_min[blockIdx.x * 2] = r;
         partial_min[blockIdx.x * 2 + 1] = r2;
     }
-}
-
-// fixed bandwidth: coef = wn / norm, s2 = 1
-__global__ void __launch_bounds__(256)
-kde_fixed_bandwidth_kernel(const double *__restrict__ wn, int64_t n, double inv_norm,
-                           double *__restrict__ coef, double *__restrict__ s2) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    coef[i] = wn[i] * inv_norm;
-    if (s2) s2[i] = 1.0;
 }
 
 __global__ void __launch_bounds__(256)
@@ -1962,41 +1973,54 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
     if (!ar.ok) KDE_FAIL(PISA_HIP_ERR_NOMEM);
     KDE_TRY_HIP(hipMemsetAsync(k->pair_count, 0, 64, s));
     // ---- whiten, sort by cell, cell table
-    KDE_D(kde_whiten_key_kernel, dim3(nb), dim3(256), 0, s, d_x, n, g, 1, 1, y, keys_a, idx_a);
+    uint32_t *flat_a = (uint32_t *)keys_a, *flat_b = flat_a + n;   // (the key arrays of the general form hold two 32-bit ones)
+    KDE_D(kde_whiten_flat_kernel, dim3(nb), dim3(256), 0, s, d_x, n, g, y, flat_a, idx_a);
     size_t tb = temp_bytes;
     {
-        uint32_t *flat_a = (uint32_t *)keys_b, *flat_b = flat_a + n;   // keys_b is written by kde_tile_key_kernel below
         unsigned bits = 1;
         while (bits < 32 && ((int64_t)1 << bits) < k->n_cells) bits++;
-        hipLaunchKernelGGL(kde_flat_key_kernel, dim3(nb), dim3(256), 0, s, keys_a, n, g, flat_a);
         KDE_TRY_HIP(rocprim::radix_sort_pairs<FlatSortConfig>(temp, tb, flat_a, flat_b, idx_a, idx_b, (size_t)n, 0u, bits, s));
-        // the unsorted tile keys are no longer needed: their array takes the sorted ones
-        hipLaunchKernelGGL(kde_tile_key_kernel, dim3(nb), dim3(256), 0, s, flat_b, n, g, keys_a);
-        std::swap(keys_a, keys_b);   // keys_b = sorted 63-bit tile keys (in the former keys_a)
     }
-    KDE_D(kde_gather_kernel, dim3(nb), dim3(256), 0, s, y, d_w, 1.0 / sw, idx_b, n, k->ys, k->wn);
-    hipLaunchKernelGGL(kde_cell_start_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, s, keys_b, n,
-                       g, k->n_cells, k->cell_start);
+    KDE_D(kde_gather_sources_kernel, dim3(nb), dim3(256), 0, s, y, d_w, 1.0 / sw, 1.0 / k->norm, idx_b, n, k->ys, k->wn,
+          k->coef, adaptive ? (double *)nullptr : k->s2);
+    hipLaunchKernelGGL(kde_cell_start_flat_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, s, flat_b, n,
+                       k->n_cells, k->cell_start);
     KDE_TRY(check_hip(hipGetLastError(), "kde setup kernels"));
+    (void)keys_b;
     if (!adaptive) {
-        hipLaunchKernelGGL(kde_fixed_bandwidth_kernel, dim3(nb), dim3(256), 0, s, k->wn, n, 1.0 / k->norm,
-                           k->coef, k->s2);
         k->s2_range[0] = k->s2_range[1] = 1.0;
         KDE_TRY_HIP(hipMemcpyAsync(k->scalars + 1, k->s2_range, 2 * sizeof(double), hipMemcpyHostToDevice, s));
     } else {
-        // pilot estimate at the sources themselves: queries = sorted sources, tiles = cells
-        hipLaunchKernelGGL(kde_fixed_bandwidth_kernel, dim3(nb), dim3(256), 0, s, k->wn, n, 1.0 / k->norm,
-                           k->coef, (double *)nullptr);
-        uint8_t *flags = ar.take<uint8_t>(n);
-        int32_t *starts = ar.take<int32_t>(n);
-        uint64_t *head_keys = ar.take<uint64_t>(n);
-        int32_t *d_count = (int32_t *)(k->scalars + 4);
+        // pilot estimate at the sources themselves: queries = sorted sources, tiles = cells.  The non-empty cells
+        // ("heads") and the workgroups over their sources come from the cell table, read back once.
         std::vector<KdeBlock> blocks;
-        if (!ar.ok) KDE_FAIL(PISA_HIP_ERR_NOMEM);
         std::vector<int32_t> h_starts;
         std::vector<uint64_t> h_keys;
-        KDE_TRY(query_blocks(keys_b, n, 1, Q_CHUNK, temp, temp_bytes, flags, starts, d_count, head_keys, blocks, s,
-                             &h_starts, &h_keys, k->n_cells));
+        {
+            std::vector<int32_t> cs((size_t)k->n_cells + 1);
+            KDE_TRY_HIP(hipMemcpyAsync(cs.data(), k->cell_start, cs.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            KDE_TRY_HIP(hipStreamSynchronize(s));
+            const int64_t nx = g.nc[0], nxy = (int64_t)g.nc[0] * g.nc[1];
+            for (int64_t c = 0; c < k->n_cells; c++) {
+                const int64_t begin = cs[c], end = cs[c + 1];
+                if (end <= begin) continue;
+                const int64_t cz = c / nxy, cy = (c - cz * nxy) / nx, cx = c - cz * nxy - cy * nx;
+                KdeBlock b;
+                b.head = (int32_t)h_starts.size();
+                b.c0[0] = b.c1[0] = (int32_t)cx; b.c0[1] = b.c1[1] = (int32_t)cy; b.c0[2] = b.c1[2] = (int32_t)cz;
+                h_starts.push_back((int32_t)begin);
+                h_keys.push_back(((uint64_t)(cz + KEY_OFF) << 42) | ((uint64_t)(cy + KEY_OFF) << 21) | (uint64_t)(cx + KEY_OFF));
+                // equal shares: a cell of 600 sources becomes 300 + 300, not 512 + 88
+                const int64_t parts = (end - begin + Q_CHUNK - 1) / Q_CHUNK;
+                for (int64_t pp = 0; pp < parts; pp++) {
+                    const int64_t q0 = begin + (end - begin) * pp / parts, q1 = begin + (end - begin) * (pp + 1) / parts;
+                    b.q_begin = (int32_t)q0;
+                    b.q_count = (int32_t)(q1 - q0);
+                    blocks.push_back(b);
+                }
+            }
+            if (h_starts.empty()) KDE_FAIL(PISA_HIP_ERR_INVALID);
+        }
         const int n_blocks = (int)blocks.size();
         const int n_split = pick_split(n_blocks);
         KdeBlock *d_blocks = ar.take<KdeBlock>(blocks.size());
@@ -2362,8 +2386,7 @@ PISA_API int pisa_hip_kde_evaluate_lattice(pisa_hip_kde *k, const double *h_orig
     int32_t *wstart = ar.take<int32_t>((size_t)n_patches + 1);
     if (!ar.ok) return PISA_HIP_ERR_NOMEM;
     hipLaunchKernelGGL(kde_lattice_prep_kernel, dim3((unsigned)((k->n + 63) / 64)), dim3(64), 0, s, k->ys,
-                       k->coef, k->s2, k->n, L.da, rec);
-    hipLaunchKernelGGL(kde_lattice_box_kernel, dim3((unsigned)n_shares), dim3(64), 0, s, rec, k->n, share, g.rcut2, box);
+                       k->coef, k->s2, k->n, L.da, g.rcut2, rec, box);
     hipLaunchKernelGGL(kde_lattice_load_kernel, dim3((unsigned)n_patches), dim3(256), 0, s, L, R, box, n_shares, load);
     hipLaunchKernelGGL(kde_lattice_plan_kernel, dim3(1), dim3(64), 0, s, load, n_patches, n_waves, wstart);
     static const int pairing = [] { const char *v = getenv("PISA_HIP_KDE_LATTICE_PAIR"); return v ? atoi(v) : 1; }();
