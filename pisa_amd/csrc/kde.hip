@@ -280,6 +280,20 @@ kde_final_reduce_kernel(const double *__restrict__ partial, int width, int n_sum
     }
 }
 
+// kde_final_reduce_kernel on the host: the same pairing (element t joined with element t + s, s = 128 .. 1)
+static void final_reduce_host(const double *partial, int width, int n_sum, int n_min, double *out) {
+    static_assert(RED_BLOCKS == RED_THREADS, "one partial per thread of the device form");
+    double v[RED_THREADS];
+    for (int k = 0; k < width; k++) {
+        for (int t = 0; t < RED_THREADS; t++) v[t] = partial[(size_t)t * width + k];
+        const bool is_max = k >= n_sum + n_min;
+        if (is_max) for (int t = 0; t < RED_THREADS; t++) v[t] = -v[t];
+        for (int st = RED_THREADS / 2; st > 0; st >>= 1)
+            for (int t = 0; t < st; t++) v[t] = k < n_sum ? v[t] + v[t + st] : fmin(v[t], v[t + st]);
+        out[k] = is_max ? -v[0] : v[0];
+    }
+}
+
 __device__ inline uint64_t tile_key(const double *y, const KdeGeom &g, int tile) {
     uint64_t key = 0;
 #pragma unroll
@@ -1837,17 +1851,19 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
 #define KDE_TRY_HIP(expr) do { int _rc = ::pisa::check_hip((expr), #expr); if (_rc != PISA_HIP_OK) KDE_FAIL(_rc); } while (0)
     // ---- resident part of the workspace (a first guess of the cell count is fixed up below)
     double *partial = ar.take<double>((size_t)RED_BLOCKS * 16);
-    double *red = ar.take<double>(16);
+    (void)ar.take<double>(16);   // (was the device-side join of the moment partials: the workspace layout is unchanged)
     if (!ar.ok) KDE_FAIL(PISA_HIP_ERR_NOMEM);
     const unsigned nb = (unsigned)((n + 255) / 256);
     // ---- moments
     double h1[10], h2[7];
 #define KDE_D(KERNEL, ...) do { if (dim == 1) hipLaunchKernelGGL(KERNEL<1>, __VA_ARGS__); else if (dim == 2) hipLaunchKernelGGL(KERNEL<2>, __VA_ARGS__); else hipLaunchKernelGGL(KERNEL<3>, __VA_ARGS__); } while (0)
+    // (the per-workgroup partial results come back and are joined here, in kde_final_reduce_kernel's order: one
+    //  launch less per pass on a chain that is launch-latency bound for small samples)
+    double hp[RED_BLOCKS * 10];
     KDE_D(kde_moments1_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, d_x, d_w, n, partial);
-    hipLaunchKernelGGL(kde_final_reduce_kernel, dim3(1), dim3(RED_THREADS), 0, s, partial, 1 + 3 * dim,
-                       1 + dim, dim, red);
-    KDE_TRY_HIP(hipMemcpyAsync(h1, red, (1 + 3 * dim) * sizeof(double), hipMemcpyDeviceToHost, s));
+    KDE_TRY_HIP(hipMemcpyAsync(hp, partial, (size_t)RED_BLOCKS * (1 + 3 * dim) * sizeof(double), hipMemcpyDeviceToHost, s));
     KDE_TRY_HIP(hipStreamSynchronize(s));
+    final_reduce_host(hp, 1 + 3 * dim, 1 + dim, dim, h1);
     const double sw = h1[0];
     if (!(sw > 0.0) || !std::isfinite(sw)) KDE_FAIL(PISA_HIP_ERR_INVALID);
     double xmin[3] = {0, 0, 0}, xmax[3] = {0, 0, 0};
@@ -1858,9 +1874,9 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
     }
     KDE_D(kde_moments2_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, d_x, d_w, n, k->mean[0],
           k->mean[1], k->mean[2], partial);
-    hipLaunchKernelGGL(kde_final_reduce_kernel, dim3(1), dim3(RED_THREADS), 0, s, partial, 7, 7, 0, red);
-    KDE_TRY_HIP(hipMemcpyAsync(h2, red, 7 * sizeof(double), hipMemcpyDeviceToHost, s));
+    KDE_TRY_HIP(hipMemcpyAsync(hp, partial, (size_t)RED_BLOCKS * 7 * sizeof(double), hipMemcpyDeviceToHost, s));
     KDE_TRY_HIP(hipStreamSynchronize(s));
+    final_reduce_host(hp, 7, 7, 0, h2);
     // ---- bandwidth matrix (unbiased weighted covariance x factor^2), its inverse, whitening
     k->sum_w = sw;
     const double denom = 1.0 - h2[0] / (sw * sw);
@@ -2103,13 +2119,20 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
                         h1 = h2;
                     }
                 }
-                KDE_TRY_HIP(hipMemcpyAsync(d_tcells, tcells.data(), tcells.size() * sizeof(int32_t),
-                                           hipMemcpyHostToDevice, s));
                 KDE_TRY_HIP(hipMemcpyAsync(d_hankel, hankel.data(), hankel.size() * sizeof(double),
                                            hipMemcpyHostToDevice, s));
-                KDE_TRY_HIP(hipMemsetAsync(hslot, 0xFF, (size_t)k->n_cells * sizeof(int32_t), s));
-                hipLaunchKernelGGL(kde_slot_scatter_kernel, dim3((unsigned)((n_heads + 255) / 256)), dim3(256), 0, s,
-                                   d_tcells, n_heads, hslot);
+                if (nd == n_heads) {
+                    // every non-empty cell has a series: its slot IS its index among the non-empty cells
+                    // (both lists are in cell order), and the list of target cells is the list of series
+                    hslot = slot;
+                    d_tcells = d_dense;
+                } else {
+                    KDE_TRY_HIP(hipMemcpyAsync(d_tcells, tcells.data(), tcells.size() * sizeof(int32_t),
+                                               hipMemcpyHostToDevice, s));
+                    KDE_TRY_HIP(hipMemsetAsync(hslot, 0xFF, (size_t)k->n_cells * sizeof(int32_t), s));
+                    hipLaunchKernelGGL(kde_slot_scatter_kernel, dim3((unsigned)((n_heads + 255) / 256)), dim3(256), 0, s,
+                                       d_tcells, n_heads, hslot);
+                }
             }
             dim3 grid((unsigned)n_blocks, (unsigned)n_split);
             // translation passes: 1 = four targets per workgroup (default), 0 = one target per workgroup
