@@ -699,10 +699,15 @@ __device__ inline void lattice_patch_box(const KdeLattice &L, int R, int p, doub
 // The patches see very different numbers of sources (margins of the lattice against its centre), and a
 // launch lasts as long as its slowest wavefront: the wavefronts are dealt to the patches in proportion to
 // the shares within reach.  load[p] = number of shares whose box meets patch p (one workgroup per patch).
+// wstart[p] .. wstart[p + 1] = the wavefronts of patch p: every patch gets one, the remaining n_waves - n_patches go
+// by load (integer arithmetic: the same plan for the same data).  The plan is made by the workgroup that finishes
+// last (`done`: a counter the estimator keeps at zero between launches).
 __global__ void __launch_bounds__(256)
 kde_lattice_load_kernel(const KdeLattice L, int R, const double *__restrict__ box, int64_t n_shares,
-                        unsigned int *__restrict__ load) {
+                        unsigned int *__restrict__ load, int n_patches, int n_waves, int32_t *__restrict__ wstart,
+                        unsigned long long *__restrict__ done) {
     __shared__ unsigned int lds[256];
+    __shared__ int last;
     double pa_lo, pa_hi, pb_lo, pb_hi;
     lattice_patch_box(L, R, (int)blockIdx.x, pa_lo, pa_hi, pb_lo, pb_hi);
     unsigned int cnt = 0;
@@ -716,26 +721,27 @@ kde_lattice_load_kernel(const KdeLattice L, int R, const double *__restrict__ bo
         if ((int)threadIdx.x < st) lds[threadIdx.x] += lds[threadIdx.x + st];
         __syncthreads();
     }
-    if (threadIdx.x == 0) load[blockIdx.x] = lds[0];
-}
-
-// wstart[p] .. wstart[p + 1]: the wavefronts of patch p; every patch gets one, the remaining
-// n_waves - n_patches go by load (integer arithmetic: the same plan for the same data)
-__global__ void __launch_bounds__(64)
-kde_lattice_plan_kernel(const unsigned int *__restrict__ load, int n_patches, int n_waves,
-                        int32_t *__restrict__ wstart) {
-    if (threadIdx.x != 0) return;
-    unsigned long long total = 0;
-    for (int p = 0; p < n_patches; p++) total += load[p];
-    const unsigned long long spare = (unsigned long long)(n_waves - n_patches);
-    int32_t w = 0;
-    for (int p = 0; p < n_patches; p++) {
-        wstart[p] = w;
-        unsigned long long extra = total ? spare * load[p] / total : 0;
-        if (4 * (extra + 1) > load[p]) extra = load[p] >= 4 ? load[p] / 4 - 1 : 0;   // >= 4 shares per wavefront
-        w += 1 + (int32_t)extra;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&load[blockIdx.x], lds[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last = atomicAdd(done, 1ull) == (unsigned long long)(n_patches - 1);
+        if (last) {
+            __threadfence();
+            *done = 0ull;   // back to zero for the next launch
+            unsigned long long total = 0;
+            for (int p = 0; p < n_patches; p++) total += __hip_atomic_load(&load[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long spare = (unsigned long long)(n_waves - n_patches);
+            int32_t w = 0;
+            for (int p = 0; p < n_patches; p++) {
+                wstart[p] = w;
+                const unsigned long long lp = __hip_atomic_load(&load[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned long long extra = total ? spare * lp / total : 0;
+                if (4 * (extra + 1) > lp) extra = lp >= 4 ? lp / 4 - 1 : 0;   // >= 4 shares per wavefront
+                w += 1 + (int32_t)extra;
+            }
+            wstart[n_patches] = w;
+        }
     }
-    wstart[n_patches] = w;
 }
 
 // Workgroup = one wavefront = one patch of the lattice (sw strips x lpw lines) x every n-th share of the
@@ -975,13 +981,16 @@ kde_logsum_kernel(const double *__restrict__ pilot, int64_t n, double *__restric
 }
 
 // local bandwidths: lam = (pilot / g)^alpha, s2 = lam^2, coef = wn lam^d / norm; per-block min s2
-// (logsum[0] = sum of log pilot over the logsum[1] sources of positive pilot density)
+// (logsum[block][2] = kde_logsum_kernel's partial results: sum of log pilot, number of sources of positive pilot density)
 __global__ void __launch_bounds__(RED_THREADS)
 kde_bandwidth_kernel(const double *__restrict__ pilot, const double *__restrict__ wn, int64_t n,
                      const double *__restrict__ logsum, double alpha, int dim, double inv_norm,
                      double *__restrict__ coef, double *__restrict__ s2, double *__restrict__ partial_min) {
     __shared__ double lds[RED_THREADS];
-    const double glob = exp(logsum[0] / logsum[1]);
+    // every workgroup joins kde_logsum_kernel's partial results itself (kde_final_reduce_kernel's pairing: one launch less)
+    const double lsum = block_sum(logsum[threadIdx.x * 2], lds);
+    const double lcnt = block_sum(logsum[threadIdx.x * 2 + 1], lds);
+    const double glob = exp(lsum / lcnt);
     double mn = INFINITY, mx = -INFINITY;
     for (int64_t i = (int64_t)blockIdx.x * RED_THREADS + threadIdx.x; i < n;
          i += (int64_t)RED_BLOCKS * RED_THREADS) {
@@ -2174,10 +2183,10 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
             hipLaunchKernelGGL(kde_combine_kernel, dim3(nb), dim3(256), 0, s, part, n_split, n,
                                (const uint32_t *)nullptr, pilot);
         hipLaunchKernelGGL(kde_logsum_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, pilot, n, partial);
-        hipLaunchKernelGGL(kde_final_reduce_kernel, dim3(1), dim3(RED_THREADS), 0, s, partial, 2, 2, 0, k->scalars);   // [0] sum, [1] count
+        double *partial_mm = partial + 2 * RED_BLOCKS;   // (its own region: the logsum partials are still being read)
         hipLaunchKernelGGL(kde_bandwidth_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, pilot, k->wn, n,
-                           k->scalars, alpha, dim, 1.0 / k->norm, k->coef, k->s2, partial);
-        hipLaunchKernelGGL(kde_final_reduce_kernel, dim3(1), dim3(RED_THREADS), 0, s, partial, 2, 0, 1,
+                           partial, alpha, dim, 1.0 / k->norm, k->coef, k->s2, partial_mm);
+        hipLaunchKernelGGL(kde_final_reduce_kernel, dim3(1), dim3(RED_THREADS), 0, s, partial_mm, 2, 0, 1,
                            k->scalars + 1);   // [1] min s2, [2] max s2
         KDE_TRY(check_hip(hipGetLastError(), "kde pilot kernels"));
         KDE_TRY_HIP(hipMemcpyAsync(k->s2_range, k->scalars + 1, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -2410,8 +2419,8 @@ PISA_API int pisa_hip_kde_evaluate_lattice(pisa_hip_kde *k, const double *h_orig
     if (!ar.ok) return PISA_HIP_ERR_NOMEM;
     hipLaunchKernelGGL(kde_lattice_prep_kernel, dim3((unsigned)((k->n + 63) / 64)), dim3(64), 0, s, k->ys,
                        k->coef, k->s2, k->n, L.da, g.rcut2, rec, box);
-    hipLaunchKernelGGL(kde_lattice_load_kernel, dim3((unsigned)n_patches), dim3(256), 0, s, L, R, box, n_shares, load);
-    hipLaunchKernelGGL(kde_lattice_plan_kernel, dim3(1), dim3(64), 0, s, load, n_patches, n_waves, wstart);
+    hipLaunchKernelGGL(kde_lattice_load_kernel, dim3((unsigned)n_patches), dim3(256), 0, s, L, R, box, n_shares, load,
+                       n_patches, n_waves, wstart, k->pair_count + 4);
     static const int pairing = [] { const char *v = getenv("PISA_HIP_KDE_LATTICE_PAIR"); return v ? atoi(v) : 1; }();
 #define KDE_LAT(RR) hipLaunchKernelGGL(kde_lattice_kernel<RR>, dim3((unsigned)n_waves), dim3(64), 0, s, L, g.rcut2, rec, k->n, share, box, wstart, n_patches, pairing, part, k->pair_count)
     if (R == 32) KDE_LAT(32); else if (R == 16) KDE_LAT(16); else KDE_LAT(8);
