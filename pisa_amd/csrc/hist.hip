@@ -6,17 +6,14 @@
 //   reweight_hist           fused prob3.apply + aeff.apply + hist.apply(sumw2)
 //   hist_finalize           fixed point -> fp64 maps
 //
-// ORDER-INDEPENDENT ACCUMULATION.  Every summand x is split EXACTLY into at most
-// three pieces, each an integer multiple of 2^(32j-116) for consecutive slabs j
-// (q = (x + M_j) - M_j with M_j = 1.5*2^(32j-116+52) rounds x to that grid, the
-// remainder goes to the next slab).  A piece is < 2^33 grid units, so fp64
-// additions of < 2^20 pieces per slab accumulator are exact: plain LDS fp64
-// atomics (ds_add_f64) then give the same sum whatever the event order.  At
-// the end of a workgroup the slab accumulators are converted to int64 and added
-// to the global limb array with integer atomics (associative => the result is
-// independent of workgroup scheduling, workgroup count and GPU count).  The
-// limbs [container][bin][quantity][6] can be SUM-all-reduced across ranks as
-// int64 and are rounded ONCE (round-to-nearest-even) to fp64 by hist_finalize.
+// ORDER-INDEPENDENT ACCUMULATION.  Every summand x = +-m 2^e is cut EXACTLY into the (at most
+// three) 32-bit digits it occupies in a fixed-point number of NL 32-bit slabs with LSB 2^-116
+// (`deposit_units`); the digits are added with integer LDS atomics (ds_add_u64) into slab
+// accumulators [slab][quantity][bin], which give the same sum whatever the event order.  At
+// the end of a workgroup the slab accumulators are added to the global limb array with integer
+// atomics (associative => the result is independent of workgroup scheduling, workgroup count
+// and GPU count).  The limbs [container][bin][quantity][6] can be SUM-all-reduced across ranks
+// as int64 and are rounded ONCE (round-to-nearest-even) to fp64 by hist_finalize.
 // Range: |x| < 2^76, resolution 2^-116; outside -> status flag.
 //
 // Roofline: HBM.  Per event the indexed fused kernel reads
@@ -28,6 +25,7 @@
 // and the coordinate form reads 8 B x (2 lookup coords + D sample coords) more
 // = 72 B (D=3).  The (P_e, P_mu) gather tables (<= 3.8 MB) stay in L2.
 #include <stdlib.h>
+#include <algorithm>
 #include <string.h>
 
 #include "common.hpp"
@@ -42,42 +40,10 @@ constexpr int HIST_THREADS = 1024;
 constexpr int64_t LDS_ACC_BYTES_MAX = 64 * 1024;
 
 // ---------------------------------------------------------------------------
-// exact 3-way split of x onto the slab grid; add(j, q) receives the pieces
-template <class F>
-__device__ __forceinline__ bool deposit(double x, F &&add) {
-    const int hi = __double2hiint(x);
-    const int ex = (hi >> 20) & 0x7ff;
-    if (ex == 0x7ff) return false;        // Inf / NaN
-    const int t = ex - 1023 + FX_LSB;     // MSB position above the LSB of the format
-    if (t < 0) return true;               // below 2^-116 (incl. zero / subnormals)
-    const int j = t >> 5;
-    if (j >= NL) return false;            // |x| >= 2^76
-    double r = x;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const int jj = j - k;
-        if (jj >= 0) {
-            const int e = 32 * jj - FX_LSB + 52 + 1023;  // biased exponent of M
-            const double M = __hiloint2double((e << 20) | 0x80000, 0);  // 1.5 * 2^(..)
-            const double q = (r + M) - M;  // r rounded to a multiple of 2^(32jj-116)
-            r = r - q;                     // exact
-            if (q != 0.0) add(jj, q);
-        }
-    }
-    return true;
-}
-
 // (Non-temporal streaming loads were measured A/B in one session: this kernel got 5 us SLOWER,
 // 92.3 vs 87.4 us, and the whole evaluation did not change; plain loads are used.)
 
-// slab accumulator (multiple of 2^(32j-116), |v| < 2^53 units) -> int64 units
-__device__ __forceinline__ long long slab_to_units(double v, int j) {
-    const int e = -(32 * j - FX_LSB) + 1023;  // 2^-(32j-116)
-    const double s = __hiloint2double(e << 20, 0);
-    return (long long)(v * s);  // exact
-}
-
-// The same exact decomposition in integer arithmetic: x = +-m * 2^(ex-1075), m the 53-bit significand,
+// The exact decomposition in integer arithmetic: x = +-m * 2^(ex-1075), m the 53-bit significand,
 // is truncated to a multiple of 2^-116 and cut into the (at most three) 32-bit digits it occupies,
 //   digit[jj] = (|x| / 2^-116 >> 32 jj) & 0xffffffff,  jj = j, j-1, j-2,  j = slab of the leading bit,
 // each handed to add(jj, +-digit) as a signed 64-bit count of units 2^(32jj-116).  Integer additions are
@@ -1120,23 +1086,65 @@ static int env_int(const char *name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
-static int plan_blocks(const int64_t *n_events, int n_cont, int threads, int64_t &chunk,
-                       int32_t *blk_start) {
-    int64_t total = 0;
-    for (int c = 0; c < n_cont; c++) total += n_events[c];
-    // a few workgroups per CU; a chunk is a whole number of two-event sweeps
-    const int64_t target_blocks = env_int("PISA_HIP_HIST_BLOCKS", 512);
-    chunk = (total + target_blocks - 1) / target_blocks;
-    if (chunk < 4096) chunk = 4096;
-    if (chunk > (1 << 18)) chunk = 1 << 18;  // keeps every slab accumulator exact (< 2^53 units)
-    const int64_t q = 2 * threads;
-    chunk = ((chunk + q - 1) / q) * q;
+// Workgroups of an accumulate launch.  ONE 1024-thread workgroup per CU (`target` = the device's CU count unless
+// PISA_HIP_HIST_BLOCKS says otherwise), never one more: with two per CU the SIMDs serve the older one first, the
+// younger ones finish 6-8 us later on their own at half the chip's request rate (10^7 events: 40.1 -> 37.0 us by
+// HIP events; 3 / 4 * 10^7 events beyond the Infinity Cache: 137 -> 111 / 157 -> 144 us), and a handful of workgroups
+// beyond what is resident run as a second round after everything else (264 workgroups: 50 us).  The workgroups are
+// dealt to the containers so that the largest share of a workgroup is as small as possible (greedy: the next
+// workgroup goes to the container with the most events per workgroup), a workgroup gets at least one sweep
+// (4 * threads events) and at most 2^28 events (the 64-bit accumulators take 2^31 32-bit digits).
+// chunk = the largest share, a whole number of sweeps: the forms that do not sweep together cut the columns by it.
+static int device_cus() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 256;
+        return v;
+    }();
+    return n;
+}
+
+static int plan_blocks_balanced(const int64_t *n_events, int n_cont, int threads, int64_t target, int64_t &chunk,
+                                int32_t *blk_start) {
+    const int64_t sweep = 4 * (int64_t)threads, wg_max = 1LL << 28;
+    int64_t nwg[MAX_CONT], cap[MAX_CONT], used = 0;
+    for (int c = 0; c < n_cont; c++) {
+        const int64_t n = n_events[c];
+        cap[c] = n > 0 ? (n + sweep - 1) / sweep : 0;
+        nwg[c] = n > 0 ? (n + wg_max - 1) / wg_max : 0;
+        used += nwg[c];
+    }
+    while (used < target) {
+        int best = -1;
+        double most = 0.0;
+        for (int c = 0; c < n_cont; c++) {
+            if (nwg[c] >= cap[c]) continue;
+            const double per = (double)n_events[c] / (double)nwg[c];
+            if (per > most) { most = per; best = c; }
+        }
+        if (best < 0) break;
+        nwg[best]++;
+        used++;
+    }
+    chunk = sweep;
     blk_start[0] = 0;
     for (int c = 0; c < n_cont; c++) {
-        int64_t nb = (n_events[c] + chunk - 1) / chunk;
-        blk_start[c + 1] = blk_start[c] + (int32_t)nb;
+        if (nwg[c] > 0) {
+            const int64_t per = (n_events[c] + nwg[c] - 1) / nwg[c];
+            chunk = std::max(chunk, ((per + sweep - 1) / sweep) * sweep);
+        }
+        blk_start[c + 1] = blk_start[c] + (int32_t)nwg[c];
     }
     return blk_start[n_cont];
+}
+
+static int plan_blocks(const int64_t *n_events, int n_cont, int threads, int64_t &chunk,
+                       int32_t *blk_start) {
+    const int env = env_int("PISA_HIP_HIST_BLOCKS", 0);
+    const int64_t target = env > 0 ? env : (int64_t)device_cus() * std::max(1, 1024 / threads);
+    return plan_blocks_balanced(n_events, n_cont, threads, target, chunk, blk_start);
 }
 
 // optional hipEvent pair recorded around the accumulate kernel of the next
@@ -1348,23 +1356,6 @@ PISA_API int pisa_hip_reweight_hist_acc(const pisa_hip_container *h_containers,
 }
 
 
-static int plan_blocks_target(const int64_t *n_events, int n_cont, int threads, int64_t target_blocks,
-                              int64_t &chunk, int32_t *blk_start) {
-    int64_t total = 0;
-    for (int c = 0; c < n_cont; c++) total += n_events[c];
-    chunk = (total + target_blocks - 1) / target_blocks;
-    if (chunk < 4096) chunk = 4096;
-    if (chunk > (1 << 18)) chunk = 1 << 18;  // keeps every slab accumulator exact (< 2^53 units)
-    const int64_t q = 2 * threads;
-    chunk = ((chunk + q - 1) / q) * q;
-    blk_start[0] = 0;
-    for (int c = 0; c < n_cont; c++) {
-        int64_t nb = (n_events[c] + chunk - 1) / chunk;
-        blk_start[c + 1] = blk_start[c] + (int32_t)nb;
-    }
-    return blk_start[n_cont];
-}
-
 template <int KP>
 static int launch_multi(const MultiArgs &a, int nblocks, size_t shmem, unsigned long long *out,
                         int32_t *d_status, hipStream_t s) {
@@ -1418,8 +1409,7 @@ PISA_API int pisa_hip_reweight_hist_multi(const pisa_hip_container *h_containers
         const int kp = (n_points - k0 + (n_pass - pass) - 1) / (n_pass - pass);   // passes of equal size
         // workgroups: what is resident at once.  From two points on the kernel needs more than 64 VGPRs,
         // a CU holds ONE 1024-thread workgroup, and a second round of workgroups would only add a tail
-        const bool two_per_cu = kp <= 1 && lds_acc_bytes(n_bins) * kp <= 80 * 1024;
-        const int64_t target_blocks = env_int("PISA_HIP_MULTI_BLOCKS", two_per_cu ? 512 : 256);
+        const int64_t target_blocks = env_int("PISA_HIP_MULTI_BLOCKS", device_cus());
         for (int base = 0; base < n_containers; base += MAX_CONT) {
             const int nc = n_containers - base < MAX_CONT ? n_containers - base : MAX_CONT;
             MultiArgs a;
@@ -1444,7 +1434,7 @@ PISA_API int pisa_hip_reweight_hist_multi(const pisa_hip_container *h_containers
                     a.scale[k][c] = h_scales ? h_scales[(size_t)(k0 + k) * n_containers + base + c] : h.scale;
             }
             int64_t chunk;
-            const int nblocks = plan_blocks_target(nev, nc, HIST_THREADS, target_blocks, chunk, a.blk_start);
+            const int nblocks = plan_blocks_balanced(nev, nc, HIST_THREADS, target_blocks, chunk, a.blk_start);
             if (nblocks <= 0) continue;
             const size_t shmem = (size_t)lds_acc_bytes(n_bins) * kp;
             unsigned long long *out = reinterpret_cast<unsigned long long *>(d_limbs) + (int64_t)k0 * limb_stride;
