@@ -374,6 +374,21 @@ int pisa_hip_finalize_metric_multi(int64_t *d_limbs, int32_t n_points, int32_t n
                                    int32_t *d_status, int32_t *d_metric_status, int32_t clear_limbs,
                                    void *stream);
 
+/* pisa_hip_finalize_metric_multi with FOUR workgroups per point, for a caller that reads the value from
+ * device-mapped pinned host memory in a fit loop (the conversions of the limbs are what the one-workgroup form
+ * spends its time on).  Workgroup k takes the bins b = k (mod 4) of every container and leaves the sum of the
+ * metric over its bins in partial[4 * point + k]; the caller adds
+ *       total = (partial[0] + partial[2]) + (partial[1] + partial[3])
+ * which is pisa_hip_finalize_metric_multi's value bit for bit (the same reduction tree, cut before its last two
+ * levels).  Maps, limb clearing and status words as there; a negative input makes the partial of its workgroup NaN.
+ * kind = PISA_HIP_METRIC_CHI2 is refused (stats.py:160-161: its all-bins-equal rule needs every bin). */
+int pisa_hip_finalize_metric_split(int64_t *d_limbs, int32_t n_points, int32_t n_containers,
+                                   int64_t n_bins, double *d_hist, double *d_sumw2, int32_t kind,
+                                   const double *d_actual, const double *d_scale,
+                                   int64_t scale_point_stride, const double *d_extra, double *partial,
+                                   int32_t *d_status, int32_t *d_metric_status, int32_t clear_limbs,
+                                   void *stream);
+
 /* --------------------------------------------------------------------- KDE */
 
 /* The density estimator behind the KDE stage.  pisa/utils/kde_hist.py:110-120 calls

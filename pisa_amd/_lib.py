@@ -198,6 +198,7 @@ _SIGS = {
     "pisa_hip_reweight_hist_multi": (C.c_int, [C.POINTER(Container), C.c_int32, C.POINTER(Binning), C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(Binning), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "pisa_hip_multi_points_per_pass": (C.c_int, [C.c_int64]),
     "pisa_hip_finalize_metric_multi": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "pisa_hip_finalize_metric_split": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "pisa_hip_profile_events": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pisa_hip_apply_osc_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "pisa_hip_apply_aeff": (C.c_int, [C.c_void_p, C.c_double, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -917,7 +917,14 @@ hist_finalize_kernel(const long long *__restrict__ limbs, int64_t n_total_bins,
 // repeats metric_kernel's loop and reduction tree exactly (first 256 threads).
 // One instantiation per metric: with a run-time `kind` the lgamma of poisson_llh sets the
 // register need of every variant and the 128-VGPR budget of a 1024-thread workgroup spills.
-template <int KIND>
+// SPLIT = 4: FOUR workgroups per point, workgroup k takes the bins b = k mod 4 of every container (a quarter of the
+// conversions -- what the one-workgroup form spends its time on: 3 per thread at the headline size) and leaves the
+// partial sum u_k of the metric over ITS bins in total[4 * point + k].  The reduction tree below adds thread t to
+// t + 128, t + 64, lane to lane + 32 .. + 4 -- all multiples of 4 -- before it joins the four residue classes with
+// lane + 2 and lane + 1: u_k is exactly what lane k holds in the one-workgroup form before those last two steps, and
+//       total = (u_0 + u_2) + (u_1 + u_3)
+// added by the caller is the one-workgroup result bit for bit.  Not for chi2 (its all-bins-equal rule needs every bin).
+template <int KIND, int SPLIT = 1>
 __global__ void __launch_bounds__(1024)
 finalize_metric_kernel(long long *__restrict__ limbs, int n_cont, int n_bins,
                        double *__restrict__ hist, double *__restrict__ q1,
@@ -930,13 +937,14 @@ finalize_metric_kernel(long long *__restrict__ limbs, int n_cont, int n_bins,
     __shared__ int s_flag[2];
     constexpr int kind = KIND;
     const int n_tot = n_cont * n_bins;
+    const int part = SPLIT > 1 ? (int)(blockIdx.x % SPLIT) : 0;   // this workgroup's bins: b = part mod SPLIT
     {
-        // one workgroup per parameter point (pisa_hip_finalize_metric_multi; a single point: blockIdx.x = 0)
-        const int64_t pt = blockIdx.x;
+        // one workgroup (SPLIT of them) per parameter point (pisa_hip_finalize_metric_multi; a single point: 0)
+        const int64_t pt = blockIdx.x / SPLIT;
         limbs += pt * limb_stride;
         hist += pt * n_tot;
         q1 += pt * n_tot;
-        total += pt;
+        total += pt * SPLIT;
         if (scale) scale += pt * scale_stride;
     }
     if (threadIdx.x < 2) s_flag[threadIdx.x] = 0;
@@ -948,22 +956,30 @@ finalize_metric_kernel(long long *__restrict__ limbs, int n_cont, int n_bins,
     // a wave reads one contiguous run.  The limbs were produced by device-scope atomics and
     // come from beyond the L2: every load of (up to) four items per thread is issued before
     // the first conversion, so the kernel pays that latency once.
-    const int n_items = 2 * n_tot;
+    // SPLIT > 1: the workgroup's items are numbered l = 2 (container * nb + j) + quantity over ITS nb bins j * SPLIT + part
+    const int nb = SPLIT > 1 ? (n_bins - part + SPLIT - 1) / SPLIT : n_bins;
+    const int n_items = 2 * n_cont * (nb > 0 ? nb : 0);
+    auto item_of = [&](int l) {
+        if (SPLIT == 1) return l;
+        const int jq = l >> 1, cont = jq / nb, j = jq - cont * nb;
+        return 2 * (cont * n_bins + j * SPLIT + part) + (l & 1);
+    };
     constexpr int UNR = 4;
     for (int base = 0; base < n_items; base += UNR * (int)blockDim.x) {
         long long w[UNR][NL];
 #pragma unroll
         for (int u = 0; u < UNR; u++) {
-            const int it = base + u * (int)blockDim.x + (int)threadIdx.x;
-            const long long *L = limbs + (int64_t)(it < n_items ? it : 0) * NL;
+            const int l = base + u * (int)blockDim.x + (int)threadIdx.x;
+            const long long *L = limbs + (int64_t)(l < n_items ? item_of(l) : 0) * NL;
 #pragma unroll
             for (int k = 0; k < NL; k++) w[u][k] = L[k];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < UNR; u++) {
-            const int it = base + u * (int)blockDim.x + (int)threadIdx.x;
-            if (it < n_items) {
+            const int l = base + u * (int)blockDim.x + (int)threadIdx.x;
+            const int it = l < n_items ? item_of(l) : 0;
+            if (l < n_items) {
                 if (clear) {
                     long long *L = limbs + (int64_t)it * NL;
 #pragma unroll
@@ -992,7 +1008,8 @@ finalize_metric_kernel(long long *__restrict__ limbs, int n_cont, int n_bins,
     const double *expected = s_map, *sigma2 = s_map + n_tot;
     double acc = 0.0;
     if (threadIdx.x < 256) {
-        for (int b = threadIdx.x; b < n_bins; b += 256) {
+        // (SPLIT > 1: b mod 4 = thread mod 4 -- the threads of the other residue classes have no bin here)
+        for (int b = threadIdx.x; b < n_bins && (SPLIT == 1 || (int)(threadIdx.x % SPLIT) == part); b += 256) {
             const double k = (b == (int)threadIdx.x) ? k_first : actual[b];
             double lam = 0.0, s2 = 0.0;
             for (int m = 0; m < n_cont; m++) {
@@ -1028,8 +1045,14 @@ finalize_metric_kernel(long long *__restrict__ limbs, int n_cont, int n_bins,
     if (threadIdx.x < 64) {
         double v = s_sum[threadIdx.x] + s_sum[threadIdx.x + 64];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-        if (threadIdx.x == 0) {
+        for (int off = 32; off >= SPLIT; off >>= 1) v += __shfl_down(v, off);
+        if (SPLIT > 1) {
+            if ((int)threadIdx.x == part) {
+                const bool negative = mstatus && s_flag[0];
+                total[part] = negative ? __builtin_nan("") : v;
+                if (negative) mstatus[0] = PISA_HIP_ERR_NEGATIVE;
+            }
+        } else if (threadIdx.x == 0) {
             const bool chi2_zero = (kind == PISA_HIP_METRIC_CHI2) && s_flag[1] == 0;  // stats.py:160-161
             // negative input (stats.py:231-240 raises): the value is NaN as well, so that a host
             // that polls `total` in pinned memory needs to read the status word only then
@@ -1457,36 +1480,66 @@ PISA_API int pisa_hip_reweight_hist_multi(const pisa_hip_container *h_containers
     return PISA_HIP_OK;
 }
 
+static int finalize_metric_impl(int64_t *d_limbs, int32_t n_points, int32_t n_containers,
+                                int64_t n_bins, double *d_hist, double *d_sumw2, int32_t kind,
+                                const double *d_actual, const double *d_scale,
+                                int64_t scale_point_stride, const double *d_extra, double *total,
+                                int32_t *d_status, int32_t *d_metric_status,
+                                int32_t clear_limbs, void *stream, bool split) {
+    if (!d_limbs || !d_hist || !d_sumw2 || !d_actual || !total || n_containers < 1 || n_bins < 1 ||
+        n_points < 1 || n_points > PISA_HIP_MAX_POINTS)
+        return PISA_HIP_ERR_INVALID;
+    if (kind < PISA_HIP_METRIC_LLH || kind > PISA_HIP_METRIC_MOD_CHI2) return PISA_HIP_ERR_INVALID;
+    if (split && kind == PISA_HIP_METRIC_CHI2) return PISA_HIP_ERR_INVALID;
+    if ((int64_t)n_containers * n_bins > PISA_HIP_FINALIZE_METRIC_MAX) return PISA_HIP_ERR_INVALID;
+    const int n_tot = (int)(n_containers * n_bins);
+    // a thread per accumulator of the workgroup's share where 1 024 threads allow it
+    int threads = (((split ? (2 * n_tot + 3) / 4 : n_tot) + 63) / 64) * 64;
+    if (threads < 256) threads = 256;  // the metric reduction tree is 256 wide
+    if (threads > 1024) threads = 1024;
+    const int64_t limb_stride = (int64_t)n_tot * 2 * NL;
+    auto launch = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3((unsigned)(n_points * (split ? 4 : 1))), dim3(threads), (size_t)n_tot * 16,
+                           as_stream(stream), (long long *)d_limbs, (int)n_containers, (int)n_bins, d_hist, d_sumw2,
+                           d_actual, total, d_status, d_metric_status, (int)clear_limbs, d_scale, d_extra,
+                           limb_stride, (int64_t)scale_point_stride);
+    };
+    if (split) {
+        switch (kind) {
+        case PISA_HIP_METRIC_LLH: launch(finalize_metric_kernel<PISA_HIP_METRIC_LLH, 4>); break;
+        case PISA_HIP_METRIC_POISSON_LLH: launch(finalize_metric_kernel<PISA_HIP_METRIC_POISSON_LLH, 4>); break;
+        default: launch(finalize_metric_kernel<PISA_HIP_METRIC_MOD_CHI2, 4>);
+        }
+    } else {
+        switch (kind) {
+        case PISA_HIP_METRIC_LLH: launch(finalize_metric_kernel<PISA_HIP_METRIC_LLH>); break;
+        case PISA_HIP_METRIC_POISSON_LLH: launch(finalize_metric_kernel<PISA_HIP_METRIC_POISSON_LLH>); break;
+        case PISA_HIP_METRIC_CHI2: launch(finalize_metric_kernel<PISA_HIP_METRIC_CHI2>); break;
+        default: launch(finalize_metric_kernel<PISA_HIP_METRIC_MOD_CHI2>);
+        }
+    }
+    PISA_CHECK_LAUNCH("finalize_metric_kernel");
+    return PISA_HIP_OK;
+}
+
 PISA_API int pisa_hip_finalize_metric_multi(int64_t *d_limbs, int32_t n_points, int32_t n_containers,
                                             int64_t n_bins, double *d_hist, double *d_sumw2, int32_t kind,
                                             const double *d_actual, const double *d_scale,
                                             int64_t scale_point_stride, const double *d_extra, double *total,
                                             int32_t *d_status, int32_t *d_metric_status,
                                             int32_t clear_limbs, void *stream) {
-    if (!d_limbs || !d_hist || !d_sumw2 || !d_actual || !total || n_containers < 1 || n_bins < 1 ||
-        n_points < 1 || n_points > PISA_HIP_MAX_POINTS)
-        return PISA_HIP_ERR_INVALID;
-    if (kind < PISA_HIP_METRIC_LLH || kind > PISA_HIP_METRIC_MOD_CHI2) return PISA_HIP_ERR_INVALID;
-    if ((int64_t)n_containers * n_bins > PISA_HIP_FINALIZE_METRIC_MAX) return PISA_HIP_ERR_INVALID;
-    const int n_tot = (int)(n_containers * n_bins);
-    int threads = ((n_tot + 63) / 64) * 64;
-    if (threads < 256) threads = 256;  // the metric reduction tree is 256 wide
-    if (threads > 1024) threads = 1024;
-    const int64_t limb_stride = (int64_t)n_tot * 2 * NL;
-    auto launch = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3((unsigned)n_points), dim3(threads), (size_t)n_tot * 16, as_stream(stream),
-                           (long long *)d_limbs, (int)n_containers, (int)n_bins, d_hist, d_sumw2,
-                           d_actual, total, d_status, d_metric_status, (int)clear_limbs, d_scale, d_extra,
-                           limb_stride, (int64_t)scale_point_stride);
-    };
-    switch (kind) {
-    case PISA_HIP_METRIC_LLH: launch(finalize_metric_kernel<PISA_HIP_METRIC_LLH>); break;
-    case PISA_HIP_METRIC_POISSON_LLH: launch(finalize_metric_kernel<PISA_HIP_METRIC_POISSON_LLH>); break;
-    case PISA_HIP_METRIC_CHI2: launch(finalize_metric_kernel<PISA_HIP_METRIC_CHI2>); break;
-    default: launch(finalize_metric_kernel<PISA_HIP_METRIC_MOD_CHI2>);
-    }
-    PISA_CHECK_LAUNCH("finalize_metric_kernel");
-    return PISA_HIP_OK;
+    return finalize_metric_impl(d_limbs, n_points, n_containers, n_bins, d_hist, d_sumw2, kind, d_actual, d_scale,
+                                scale_point_stride, d_extra, total, d_status, d_metric_status, clear_limbs, stream, false);
+}
+
+PISA_API int pisa_hip_finalize_metric_split(int64_t *d_limbs, int32_t n_points, int32_t n_containers,
+                                            int64_t n_bins, double *d_hist, double *d_sumw2, int32_t kind,
+                                            const double *d_actual, const double *d_scale,
+                                            int64_t scale_point_stride, const double *d_extra, double *partial,
+                                            int32_t *d_status, int32_t *d_metric_status,
+                                            int32_t clear_limbs, void *stream) {
+    return finalize_metric_impl(d_limbs, n_points, n_containers, n_bins, d_hist, d_sumw2, kind, d_actual, d_scale,
+                                scale_point_stride, d_extra, partial, d_status, d_metric_status, clear_limbs, stream, true);
 }
 
 PISA_API int pisa_hip_finalize_metric_scaled(int64_t *d_limbs, int32_t n_containers, int64_t n_bins,

@@ -16,6 +16,8 @@ the shape  loader -> [flux] -> osc.prob3 -> aeff.aeff -> utils.hist
 (pisa/core/pipeline.py:537-558 runs those stages one after another on host
 numpy arrays; here the three apply_functions are one pass over HBM).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -432,8 +434,11 @@ class HotPathEngine:
         self.ws = K.HistWorkspace(len(self.cont), self.n_bins, self.dev)
         self.metric_out = torch.zeros(1, dtype=torch.float64, device=self.dev)
         self.metric_status = torch.zeros(1, dtype=torch.int32, device=self.dev)
-        self.metric_host = torch.zeros(1, dtype=torch.float64).pin_memory()
+        # [0]: the metric as the tail kernel leaves it; [0:4]: the four partial sums of its split form
+        # (`pisa_hip_finalize_metric_split`: total = (p0 + p2) + (p1 + p3), the one-workgroup value bit for bit)
+        self.metric_host = torch.zeros(4, dtype=torch.float64).pin_memory()
         self._metric_host_np = self.metric_host.numpy()
+        self.split_tail = os.environ.get("PISA_HIP_SPLIT_TAIL", "1") != "0"
         self.spin_wait = 50000  # polls of the pinned result (~7 ms) before falling back to a stream sync
         self.fused_tail = True
         self._limbs_zero = self._maps_valid = False
@@ -723,6 +728,21 @@ class HotPathEngine:
         return (self.fused_tail and not self._maps_valid
                 and len(self.cont) * self.n_bins <= K.FINALIZE_METRIC_MAX)
 
+    def _split_ok(self, kind):
+        """the tail in its four-workgroup form (partial sums joined here): whenever the value is polled from
+        pinned memory anyway; not for chi2 (its all-bins-equal rule, stats.py:160-161, needs every bin)"""
+        return self.split_tail and self.spin_wait > 0 and kind != "chi2"
+
+    def _poll_split(self):
+        """(p0 + p2) + (p1 + p3) of the split tail's partial sums, as soon as all four have arrived"""
+        h = self._metric_host_np
+        for _ in range(self.spin_wait):
+            a, b, c, d = h[0], h[1], h[2], h[3]
+            if a == a and b == b and c == c and d == d:
+                return (float(a) + float(c)) + (float(b) + float(d))
+        torch.cuda.current_stream().synchronize()
+        return (float(h[0]) + float(h[2])) + (float(h[1]) + float(h[3]))
+
     def tail_host(self, kind, scale=None, extra=None):
         """phase B: maps + metric against `self.data` of the accumulated limbs, value on the host.
         `scale` [n_cont, n_bins] / `extra` [2, n_bins] (device tensors): per-bin factors of a stage after
@@ -744,6 +764,16 @@ class HotPathEngine:
             if a["data_t"] is not self.data:
                 a["data"], a["data_t"] = C.c_void_p(self.data.data_ptr()), self.data
             h = self._metric_host_np
+            if self._split_ok(kind):
+                h[:] = np.nan
+                rc = a["lib"].pisa_hip_finalize_metric_split(
+                    a["limbs"], 1, a["n_cont"], self.n_bins, a["hist"], a["sumw2"], K.METRIC_KIND[kind], a["data"],
+                    None if scale is None else C.c_void_p(scale.data_ptr()), 0,
+                    None if extra is None else C.c_void_p(extra.data_ptr()),
+                    a["out"], a["status"], a["mstatus"], 1, K._stream())
+                self._limbs_zero = self._maps_valid = rc == 0
+                _lib.check(rc)
+                return self._poll_split()
             h[0] = np.nan
             if scale is None and extra is None:
                 rc = a["lib"].pisa_hip_finalize_metric(a["limbs"], a["n_cont"], self.n_bins, a["hist"],
@@ -813,6 +843,10 @@ class HotPathEngine:
                 # stream-completion signal has travelled through the runtime: poll it.  NaN is
                 # the "not yet" marker (a genuine NaN result falls through to the stream sync).
                 h = self._metric_host_np
+                if self._split_ok(kind):
+                    h[:] = np.nan
+                    self._lean_eval(params, kind, split=True)
+                    return self._poll_split()
                 h[0] = np.nan
                 self._lean_eval(params, kind)
                 for _ in range(self.spin_wait):
@@ -828,7 +862,7 @@ class HotPathEngine:
         torch.cuda.current_stream().synchronize()
         return float(self.metric_host[0])
 
-    def _lean_eval(self, params, kind):
+    def _lean_eval(self, params, kind, split=False):
         import ctypes as C
 
         a = self._lean
@@ -863,9 +897,14 @@ class HotPathEngine:
         self._limbs_zero = self._maps_valid = False
         if rc == 0:
             self.allreduce()
-            rc = lib.pisa_hip_finalize_metric(a["limbs"], a["n_cont"], self.n_bins, a["hist"],
-                                              a["sumw2"], K.METRIC_KIND[kind], a["data"], a["out"],
-                                              a["status"], a["mstatus"], 1, s)
+            if split:
+                rc = lib.pisa_hip_finalize_metric_split(a["limbs"], 1, a["n_cont"], self.n_bins, a["hist"],
+                                                        a["sumw2"], K.METRIC_KIND[kind], a["data"], None, 0, None,
+                                                        a["out"], a["status"], a["mstatus"], 1, s)
+            else:
+                rc = lib.pisa_hip_finalize_metric(a["limbs"], a["n_cont"], self.n_bins, a["hist"],
+                                                  a["sumw2"], K.METRIC_KIND[kind], a["data"], a["out"],
+                                                  a["status"], a["mstatus"], 1, s)
             self._limbs_zero = self._maps_valid = rc == 0
         _lib.check(rc)
 
@@ -935,7 +974,7 @@ class HotPathEngine:
                 limbs=torch.zeros((k, n_c, self.n_bins, 2, _lib.ACC_LIMBS), dtype=torch.int64, device=self.dev),
                 hist=torch.empty((k, n_c, self.n_bins), dtype=torch.float64, device=self.dev),
                 sumw2=torch.empty((k, n_c, self.n_bins), dtype=torch.float64, device=self.dev),
-                host=torch.zeros(k, dtype=torch.float64).pin_memory(),
+                host=torch.zeros(4 * k, dtype=torch.float64).pin_memory(),   # k values, or 4 k partial sums (split tail)
                 params=(_lib.Prob3Params * k)(), scales=(C.c_double * (k * n_c))(), zero=True)
             w["host_np"] = w["host"].numpy()
         return w
@@ -1021,6 +1060,22 @@ class HotPathEngine:
         lib, s = _lib.lib(), K._stream()
         h = w["host_np"]
         h[:] = np.nan
+        if self._split_ok(kind):
+            _lib.check(lib.pisa_hip_finalize_metric_split(
+                C.c_void_p(w["limbs"].data_ptr()), n, len(self.cont), self.n_bins, C.c_void_p(w["hist"].data_ptr()),
+                C.c_void_p(w["sumw2"].data_ptr()), K.METRIC_KIND[kind], C.c_void_p(self.data.data_ptr()), None, 0, None,
+                C.c_void_p(w["host"].data_ptr()), C.c_void_p(self.ws.status.data_ptr()),
+                C.c_void_p(self.metric_status.data_ptr()), 1, s))
+            w["zero"] = True
+            h4 = h[:4 * n]
+            for _ in range(self.spin_wait):
+                if not np.isnan(h4).any():
+                    break
+            else:
+                torch.cuda.current_stream().synchronize()
+            p = h4.reshape(n, 4)
+            return [(float(q[0]) + float(q[2])) + (float(q[1]) + float(q[3])) for q in p]
+        h = h[:n]
         _lib.check(lib.pisa_hip_finalize_metric_multi(
             C.c_void_p(w["limbs"].data_ptr()), n, len(self.cont), self.n_bins, C.c_void_p(w["hist"].data_ptr()),
             C.c_void_p(w["sumw2"].data_ptr()), K.METRIC_KIND[kind], C.c_void_p(self.data.data_ptr()), None, 0, None,

@@ -602,3 +602,74 @@ def test_limb_decoder_is_correctly_rounded_on_adversarial_accumulators(K, L):
     ws2.limbs.copy_(torch.from_numpy(np.ascontiguousarray(arr[:, ok][:, :, [0, 0]])))
     K.hist_finalize(ws2)
     assert int(ws2.status.item()) == 0
+
+
+@pytest.mark.parametrize("n_cont,n_bins", [(12, 128), (3, 10), (1, 1), (2, 3), (5, 257), (4, 700), (1, 4096)])
+def test_split_tail_equals_one_workgroup_tail_bit_for_bit(K, L, n_cont, n_bins):
+    """`pisa_hip_finalize_metric_split` (four workgroups per point, bins k mod 4 each, partial sums joined by the
+    caller as (p0 + p2) + (p1 + p3)) against `pisa_hip_finalize_metric_multi` on the same limbs: metric value, maps,
+    cleared limbs and status identical, for every metric it takes, with and without the per-bin scales / extra maps,
+    one and three points, bin counts that are not multiples of four and that need several rounds of the 256-wide tree;
+    a negative expectation turns the sum into NaN with the status word set in both; chi2 is refused."""
+    import torch
+
+    lib = L.lib()
+    rs = np.random.RandomState(n_cont * 1000 + n_bins)
+    dev = K.device()
+    for n_pts in (1, 3):
+        shape = (n_pts, n_cont, n_bins, 2, 6)
+        fill = np.zeros(shape, dtype=np.int64)
+        fill[..., 1:5] = rs.randint(0, 2 ** 36, size=shape[:-1] + (4,))
+        fill[..., 3] += rs.randint(0, 2 ** 31, size=shape[:-1]) << 8
+        if n_bins > 2:
+            fill[:, 0, 1, :, :] = 0          # an empty bin
+        fill_d = torch.from_numpy(fill).to(dev)
+        data = torch.from_numpy(rs.poisson(40.0, n_bins).astype(np.float64)).to(dev)
+        scale = torch.from_numpy(rs.uniform(0.5, 1.5, size=(n_cont, n_bins))).to(dev)
+        extra = torch.from_numpy(rs.uniform(0.0, 3.0, size=(2, n_bins))).to(dev)
+        for kind in ("llh", "poisson_llh", "mod_chi2"):
+            for with_scale in (False, True):
+                res = []
+                for split in (False, True):
+                    limbs = fill_d.clone()
+                    hist = torch.full((n_pts, n_cont, n_bins), -7.0, dtype=torch.float64, device=dev)
+                    sumw2 = torch.full_like(hist, -7.0)
+                    tot = torch.full((n_pts * 4,), float("nan"), dtype=torch.float64, device=dev)
+                    st = torch.zeros(1, dtype=torch.int32, device=dev)
+                    mst = torch.zeros(1, dtype=torch.int32, device=dev)
+                    fn = lib.pisa_hip_finalize_metric_split if split else lib.pisa_hip_finalize_metric_multi
+                    rc = fn(limbs.data_ptr(), n_pts, n_cont, n_bins, hist.data_ptr(), sumw2.data_ptr(),
+                            K.METRIC_KIND[kind], data.data_ptr(), scale.data_ptr() if with_scale else None, 0,
+                            extra.data_ptr() if with_scale else None, tot.data_ptr(), st.data_ptr(), mst.data_ptr(), 1,
+                            None)
+                    assert rc == 0
+                    torch.cuda.synchronize()
+                    t = tot.cpu().numpy()
+                    if split:
+                        t = t.reshape(n_pts, 4)
+                        vals = [(float(p[0]) + float(p[2])) + (float(p[1]) + float(p[3])) for p in t]
+                    else:
+                        vals = [float(v) for v in t[:n_pts]]
+                    assert int(limbs.abs().sum().item()) == 0
+                    res.append((vals, hist.cpu().numpy(), sumw2.cpu().numpy(), int(st.item()), int(mst.item())))
+                (v0, h0, s0, st0, m0), (v1, h1, s1, st1, m1) = res
+                assert all(np.isfinite(v0)) and v0 == v1, (kind, with_scale, v0, v1)
+                assert np.array_equal(h0, h1) and np.array_equal(s0, s1) and (h0 != -7.0).all()
+                assert (st0, m0) == (st1, m1) == (0, 0)
+    # negative observed count: NaN + status in both forms
+    bad = data.clone(); bad[n_bins // 2] = -1.0
+    for split in (False, True):
+        limbs = fill_d[:1].clone()
+        hist = torch.empty((1, n_cont, n_bins), dtype=torch.float64, device=dev); sumw2 = torch.empty_like(hist)
+        tot = torch.zeros(4, dtype=torch.float64, device=dev)
+        st = torch.zeros(1, dtype=torch.int32, device=dev); mst = torch.zeros(1, dtype=torch.int32, device=dev)
+        fn = lib.pisa_hip_finalize_metric_split if split else lib.pisa_hip_finalize_metric_multi
+        assert fn(limbs.data_ptr(), 1, n_cont, n_bins, hist.data_ptr(), sumw2.data_ptr(), K.METRIC_KIND["llh"],
+                  bad.data_ptr(), None, 0, None, tot.data_ptr(), st.data_ptr(), mst.data_ptr(), 1, None) == 0
+        torch.cuda.synchronize()
+        t = tot.cpu().numpy()
+        v = (t[0] + t[2]) + (t[1] + t[3]) if split else t[0]
+        assert v != v and int(mst.item()) != 0
+    assert lib.pisa_hip_finalize_metric_split(limbs.data_ptr(), 1, n_cont, n_bins, hist.data_ptr(), sumw2.data_ptr(),
+                                            K.METRIC_KIND["chi2"], data.data_ptr(), None, 0, None, tot.data_ptr(),
+                                            st.data_ptr(), mst.data_ptr(), 1, None) != 0
