@@ -335,7 +335,11 @@ class FastPlan:
             return None
         params_list, scales = [], []
         self._dirty = True           # from here on the change counters are consumed point by point
-        self._many_scales = None     # the containers' aeff scales, recomputed when an aeff parameter moves
+        # the containers' aeff scales, recomputed when an aeff parameter moved since they were made (kept from
+        # sweep to sweep: twelve `scale_for` cost more host time than a point's launches)
+        aeff_key = (ParamSet.struct_clock,) + tuple(prm._ver for prm in self.aeff.params)
+        if getattr(self, "_many_scales_key", None) != aeff_key:
+            self._many_scales = None
 
         def abandon():
             # counters of stages this plan cannot take in a sweep have been consumed: forget what was
@@ -359,6 +363,7 @@ class FastPlan:
             params_list.append(_lib.Prob3Params.from_buffer_copy(osc._matrices()))
             if self._many_scales is None or any(s is self.aeff for s in changed):
                 self._many_scales = [self.aeff.scale_for(name) for name in self.names]
+                self._many_scales_key = (ParamSet.struct_clock,) + tuple(prm._ver for prm in self.aeff.params)
             scales.append(self._many_scales)
         osc.param_hash = None
         self.clock = Param.clock

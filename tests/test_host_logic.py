@@ -624,3 +624,33 @@ def test_kde_map_postprocessing_of_a_stack_equals_map_by_map():
                 for k in range(7):
                     one, _ = kh._finish_hist(g, d[k], None, over)
                     np.testing.assert_array_equal(one, many[k])
+
+
+def test_param_set_deepcopy_is_independent():
+    """`HypoFitResult` snapshots the parameter set after every fit (analysis.py:356-372): the copy has Param and Prior
+    objects, range lists and array magnitudes of its own; moving or fixing a copied parameter leaves the original (and the
+    process-wide change counters' consumers) alone."""
+    import copy
+
+    from pisa_amd.core.param import Param, ParamSet, Prior
+    from pisa_amd.core.units import ureg
+
+    ps = ParamSet([Param(name="p%d" % i, value=(1.0 + i) * ureg.degree,
+                         prior=Prior(kind="gaussian", mean=1.0 * ureg.degree, stddev=0.5 * ureg.degree),
+                         range=[0 * ureg.degree, 90 * ureg.degree], is_fixed=i % 2 == 0) for i in range(6)])
+    ps.extend(Param(name="arr", value=np.arange(3.0) * ureg.m, is_fixed=True))
+    ps.extend(Param(name="flag", value=True, is_fixed=True))
+    c = copy.deepcopy(ps)
+    assert c.names == ps.names and [p.is_fixed for p in c] == [p.is_fixed for p in ps]
+    assert all(a is not b and a.value == b.value for a, b in zip(c, ps) if a.name != "arr")
+    c.p1.value = 5 * ureg.degree
+    c.p1.range = [1 * ureg.degree, 10 * ureg.degree]
+    c.fix("p1")
+    assert ps.p1.value.m_as("degree") == 2.0 and not ps.p1.is_fixed and ps.p1.range[1].m_as("degree") == 90
+    assert c.p1.prior is not ps.p1.prior and c.p1.prior.mean == ps.p1.prior.mean
+    assert c.p1.prior_penalty("llh") != ps.p1.prior_penalty("llh")
+    c["arr"].value.magnitude[0] = 9.0
+    assert ps["arr"].value.magnitude[0] == 0.0
+    assert c.flag.value is True
+    # the free / fixed views of the copy are the copy's objects
+    assert all(p is c[p.name] for p in c.free)
