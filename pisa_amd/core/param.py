@@ -491,7 +491,23 @@ class ParamSet(Sequence):
     def priors_penalty(self, metric):
         # the same sum over the same terms in the same order (param.py:1372-1396); a term is re-evaluated
         # only when its parameter moved
-        return np.sum([p.prior_penalty_cached(metric) for p in self._params])
+        # (a fit asks at every point and moves one or two parameters between points: the terms live in an array,
+        # the entries of moved parameters are replaced, np.sum adds the same float64 terms in the same order)
+        params = self._params
+        c = self.__dict__.get("_pen_terms")
+        if c is None or c[0] != metric or c[1] != ParamSet.struct_clock or len(c[2]) != len(params):
+            c = (metric, ParamSet.struct_clock, [None] * len(params), np.zeros(len(params)), [None] * len(params))
+            object.__setattr__(self, "_pen_terms", c)
+        vers, arr, priors = c[2], c[3], c[4]
+        try:
+            for i, p in enumerate(params):
+                if vers[i] != p._ver or priors[i] is not p.prior:
+                    arr[i] = p.prior_penalty(metric)
+                    vers[i], priors[i] = p._ver, p.prior
+        except (TypeError, ValueError):     # a term that is not a scalar: the plain sum
+            object.__setattr__(self, "_pen_terms", None)
+            return np.sum([p.prior_penalty_cached(metric) for p in self._params])
+        return np.sum(arr)
 
     @property
     def values_hash(self):
