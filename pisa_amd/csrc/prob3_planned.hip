@@ -163,6 +163,15 @@ __device__ __forceinline__ void mat_mul_fma(const mat3 &A, const mat3 &B, mat3 &
 // four-wave workgroups for EVERY row do not fit the chip at once (250 VGPRs: two workgroups per
 // CU).  Packed, the ~360 workgroups of a 200 x 100 grid are all resident and a 24-layer row has
 // four matrices per wave instead of seven.
+// Development build (make EXTRA=-DPISA_CHAIN_STAMPS, scripts/dev/chain_stamps.py): wall-clock stamps of lane 0 of
+// every wavefront of the packed one-point launch at seven points of the kernel.
+#ifdef PISA_CHAIN_STAMPS
+__device__ unsigned long long g_chain_stamps[8 * 4096];
+#define CSTAMP(k) do { if (G == 0 && (threadIdx.x & 63) == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 1024) \
+        g_chain_stamps[8 * (blockIdx.x * 4 + (threadIdx.x >> 6)) + (k)] = wall_clock64(); } while (0)
+#else
+#define CSTAMP(k) do {} while (0)
+#endif
 template <int G, int AMP, class CS = ConstsByValue>
 __global__ void __launch_bounds__(G ? 64 * G : 256)
 prob3_chain_kernel(const CS cs, int n_e, const int32_t *__restrict__ row_start,
@@ -173,6 +182,7 @@ prob3_chain_kernel(const CS cs, int n_e, const int32_t *__restrict__ row_start,
                     const int32_t *__restrict__ pair_u, const double *__restrict__ pair_dist,
                     int n_unique, const int32_t *__restrict__ blk, int n_points, int n_tiles) {
     auto MM = [](const mat3 &A_, const mat3 &B_, mat3 &C_) { mat_mul_fma(A_, B_, C_); };
+    CSTAMP(0);
     // Several points, packed launch (n_tiles > 0): a 1-D grid in which the (point, sign, energy tile)
     // index runs FASTEST and the row-block index slowest -- the plan lists the row blocks longest rows
     // first, so the long rows of every point, sign and tile start first and the short ones fill the tail
@@ -197,8 +207,14 @@ prob3_chain_kernel(const CS cs, int n_e, const int32_t *__restrict__ row_start,
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // row, group of this wave within the row, groups of the row; partial slot of a writer wave
     int jcz = bx, g = wv, Gr = G;
+    int k0_blk = 0, cnt_blk = 0;
     if (PACKED) {
-        const int32_t code = __builtin_amdgcn_readfirstlane(blk[bx * 4 + wv]);  // row | g << 16 | groups << 24, -1: idle wave
+        // (row | g << 16 | groups << 24 (-1: idle wave), first position and length of the row's chain, 0): one 16-byte
+        // scalar load instead of the code and then row_start / row_cnt behind it
+        const int4 rec = reinterpret_cast<const int4 *>(blk)[bx * 4 + wv];
+        const int32_t code = __builtin_amdgcn_readfirstlane(rec.x);
+        k0_blk = __builtin_amdgcn_readfirstlane(rec.y);
+        cnt_blk = __builtin_amdgcn_readfirstlane(rec.z);
         jcz = code < 0 ? -1 : (code & 0xffff);
         g = code < 0 ? 0 : ((code >> 16) & 0xff);
         Gr = code < 0 ? 1 : ((code >> 24) & 0xff);
@@ -211,8 +227,8 @@ prob3_chain_kernel(const CS cs, int n_e, const int32_t *__restrict__ row_start,
     const bool live = ie < n_e && jcz >= 0;
     double *out = side == 0 ? prob_nu : prob_nubar;
     const Prob3Side &S = c.side[side];
-    const int k0 = jcz >= 0 ? row_start[jcz] : 0;
-    const int cnt = jcz >= 0 ? row_cnt[jcz] : 0;
+    const int k0 = PACKED ? k0_blk : (jcz >= 0 ? row_start[jcz] : 0);
+    const int cnt = PACKED ? cnt_blk : (jcz >= 0 ? row_cnt[jcz] : 0);
     const int mid = cnt >> 1;
     const int n_steps = mid;  // steps s = 1..mid (out-going side may be one shorter)
     const int s0 = 1 + (int)(((int64_t)n_steps * g) / Gr);
@@ -243,6 +259,11 @@ prob3_chain_kernel(const CS cs, int n_e, const int32_t *__restrict__ row_start,
     };
     mat3 L, R;
     bool have_l = false, have_r = false;
+    CSTAMP(1);
+#ifdef PISA_CHAIN_STAMPS
+    if (G == 0 && (threadIdx.x & 63) == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 1024)
+        g_chain_stamps[8 * (blockIdx.x * 4 + (threadIdx.x >> 6)) + 7] = (unsigned long long)cnt | ((unsigned long long)g << 16) | ((unsigned long long)Gr << 24) | ((unsigned long long)(s1 - s0) << 32) | (jcz >= 0 ? 1ull << 48 : 0ull);
+#endif
     if (live && cnt > 0 && s1 > s0) {
         mat3 A, An;
         load_pair(k0 + mid - s0, A);
@@ -258,6 +279,7 @@ prob3_chain_kernel(const CS cs, int n_e, const int32_t *__restrict__ row_start,
             A = An;
         }
     }
+    CSTAMP(2);
     if (g > 0 && live) {
         double *o = s_part + (size_t)part_w * 2 * 18 * 64 + lane;
         if (have_l) {
@@ -279,7 +301,11 @@ prob3_chain_kernel(const CS cs, int n_e, const int32_t *__restrict__ row_start,
                 }
         }
     }
+    // the leader forms the middle layer's matrix while it waits for its partners
+    mat3 T;
+    if (g == 0 && live && cnt > 0) load_pair(k0 + mid, T);
     __syncthreads();
+    CSTAMP(3);
     if (g != 0 || !live) return;
     // wave 0: T_right = R_0 . R_1 .. (later groups further right), T_left = .. L_1 . L_0
     for (int h = 1; h < Gr; h++) {
@@ -306,9 +332,8 @@ prob3_chain_kernel(const CS cs, int n_e, const int32_t *__restrict__ row_start,
             if (have_l) { mat3 t; MM(Ph, L, t); L = t; } else { L = Ph; have_l = true; }
         }
     }
-    mat3 T;
+    CSTAMP(4);
     if (cnt > 0) {
-        load_pair(k0 + mid, T);
         if (have_r) { mat3 t; MM(T, R, t); T = t; }
         if (have_l) { mat3 t; MM(L, T, t); T = t; }
     } else {
@@ -326,6 +351,7 @@ prob3_chain_kernel(const CS cs, int n_e, const int32_t *__restrict__ row_start,
 #pragma unroll
         for (int j = 0; j < 3; j++)
             P[3 * i + j] = Tf.m[j][i].re * Tf.m[j][i].re + Tf.m[j][i].im * Tf.m[j][i].im;
+    CSTAMP(5);
     int64_t node = e_major ? (int64_t)ie * n_cz + jcz : (int64_t)jcz * n_e + ie;
     if (n_points > 1) {
         // several points: the gather tables of the points interleaved, [sign][flavour][node][point], so
@@ -336,7 +362,14 @@ prob3_chain_kernel(const CS cs, int n_e, const int32_t *__restrict__ row_start,
         return;
     }
     store_node(P, node, (int64_t)n_e * n_cz, side, out, pepmu);
+    CSTAMP(6);
 }
+
+#ifdef PISA_CHAIN_STAMPS
+extern "C" __attribute__((visibility("default"))) int pisa_hip_debug_chain_stamps(unsigned long long *h_out) {
+    return check_hip(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_chain_stamps), sizeof(g_chain_stamps)), "stamps");
+}
+#endif
 
 static int make_consts(const pisa_hip_prob3_params *p, Prob3Consts &c) {
     if (!p) return PISA_HIP_ERR_INVALID;
@@ -362,7 +395,7 @@ struct pisa_hip_grid_plan {
     double *d_amp;         // stage-AB amplitudes [2][n_pairs][18][n_e]
     int n_e_alloc;
     int32_t *d_pair_u;     // [n_pairs] distinct-density index of each pair
-    int32_t *d_blk;        // [4 * n_blk] packed launch: row | group << 16 | groups << 24 per wave, -1 idle
+    int32_t *d_blk;        // [4 * n_blk][4] packed launch, per wave: row | group << 16 | groups << 24 (-1 idle), chain start, chain length, 0
     int n_blk;
     int chain_packed;      // 1 (default): packed chain launch; PISA_HIP_CHAIN_MODE=split: one row per workgroup
     int32_t *d_chain_u;    // [n_chain] the same per chain entry (position in d_row_pairs)
@@ -516,7 +549,7 @@ PISA_API int pisa_hip_grid_plan_create(const double *d_densities, const double *
             // one long row x 4 groups | two medium rows x 2 | four short rows x 1
             const char *m = getenv("PISA_HIP_CHAIN_MODE");
             p->chain_packed = (m && strcmp(m, "split") == 0) ? 0 : 1;
-            int32_t *code = new int32_t[(size_t)4 * n_cz + 4];
+            int32_t *code = new int32_t[((size_t)4 * n_cz + 4) * 4];   // per wave: code, chain start, chain length, 0
             int nb = 0;
             int t4 = 14, t2 = 0;  // crossed layers from which a row gets four / two waves (measured: 22.1 us; 14/6: 23.4; one row per workgroup: 24.4)
             if (const char *v = getenv("PISA_HIP_PACK_T4")) t4 = atoi(v);  // development probes
@@ -526,19 +559,25 @@ PISA_API int pisa_hip_grid_plan_create(const double *d_densities, const double *
                 int fill = 0;  // wave slots used in the open workgroup
                 for (int r = 0; r < n_cz && n_cz <= 0xffff; r++) {
                     if (groups_of(rcnt[r]) != want) continue;
-                    for (int gi = 0; gi < want; gi++) code[nb * 4 + fill + gi] = r | (gi << 16) | (want << 24);
+                    for (int gi = 0; gi < want; gi++) {
+                        int32_t *w = code + (size_t)(nb * 4 + fill + gi) * 4;
+                        w[0] = r | (gi << 16) | (want << 24); w[1] = rstart[r]; w[2] = rcnt[r]; w[3] = 0;
+                    }
                     fill += want;
                     if (fill == 4) { nb++; fill = 0; }
                 }
                 if (fill > 0) {
-                    for (int k = fill; k < 4; k++) code[nb * 4 + k] = -1;
+                    for (int k = fill; k < 4; k++) {
+                        int32_t *w = code + (size_t)(nb * 4 + k) * 4;
+                        w[0] = -1; w[1] = w[2] = w[3] = 0;
+                    }
                     nb++;
                 }
             }
             if (n_cz > 0xffff) p->chain_packed = 0;
             p->n_blk = nb;
-            if (!rc) rc = check_hip(hipMalloc(&p->d_blk, (size_t)(nb > 0 ? nb : 1) * 16), "hipMalloc");
-            if (!rc && nb > 0) rc = check_hip(hipMemcpy(p->d_blk, code, (size_t)nb * 16, hipMemcpyHostToDevice), "h2d");
+            if (!rc) rc = check_hip(hipMalloc(&p->d_blk, (size_t)(nb > 0 ? nb : 1) * 64), "hipMalloc");
+            if (!rc && nb > 0) rc = check_hip(hipMemcpy(p->d_blk, code, (size_t)nb * 64, hipMemcpyHostToDevice), "h2d");
             delete[] code;
         }
         if (!rc) rc = check_hip(hipMalloc(&p->d_chain_u, nca * 4), "hipMalloc");
