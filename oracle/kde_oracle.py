@@ -3,7 +3,8 @@
 Restates pisa/utils/kde_hist.py:35-387 (wrapper: oversampling, coszen
 reflection, bin volumes, pid stacking) on plain numpy edge arrays, with the
 density estimator of the un-vendored `kde` package restated from its call
-contract (PARITY UNPINNED: see oracle/pisa_oracle.c, KDE section).  Binnings are
+contract (PARITY UNPINNED: see oracle/pisa_oracle.c, KDE section -- except the fixed-bandwidth
+unweighted estimator, which tests/test_oracle.py checks against scipy.stats.gaussian_kde).  Binnings are
 passed as lists of (name, edges, is_log) so that nothing of the product's
 binning classes is needed.
 """

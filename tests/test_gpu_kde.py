@@ -521,3 +521,30 @@ def test_kde_pool_release_returns_the_workspaces():
     assert torch.cuda.mem_get_info()[0] > held + (50 << 20)      # hundreds of MB come back
     b = K.kde_lattice_batch(jobs, origin, step, count, n_threads=4)[0].cpu().numpy()
     np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("dim,n", [(1, 3000), (2, 20000), (3, 4000)])
+@pytest.mark.parametrize("bw", ["silverman", "scott"])
+def test_fixed_bandwidth_estimator_equals_scipy(dim, n, bw):
+    """The device estimator against scipy.stats.gaussian_kde -- an independent implementation of the same textbook
+    estimator for unweighted samples and a fixed bandwidth (tests/test_oracle.py pins the oracle to it as well): every
+    density to 1e-10 relative with the documented cut-off floor.  This is the part of the KDE core that HAS a second
+    implementation in this image; weights and adaptive bandwidths follow the `kde` package's contract and stay unpinned."""
+    from scipy import stats
+
+    from pisa_amd import kernels as K
+
+    rs = np.random.RandomState(100 * dim + len(bw))
+    x = np.empty((dim, n))
+    x[0] = rs.rand(n) * 2 - 1
+    if dim > 1:
+        x[1] = 1.5 + rs.gamma(3.0, 0.6, n) + 0.4 * x[0]
+    if dim > 2:
+        x[2] = rs.randn(n) * 0.3 + 0.2 * x[1]
+    lo, hi = x.min(axis=1, keepdims=True), x.max(axis=1, keepdims=True)
+    q = lo + (hi - lo) * (rs.rand(dim, 2000) * 1.2 - 0.1)
+    est = K.KdeEstimator(K.to_device(x), None, bw_method=bw, adaptive=False, alpha=0.0, tol=1e-14)
+    got = est(K.to_device(q)).cpu().numpy()
+    want = stats.gaussian_kde(x, bw_method=bw)(q)
+    np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-12 * want.max())
+    assert np.count_nonzero(want > 1e-6 * want.max()) > 500

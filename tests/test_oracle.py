@@ -303,3 +303,33 @@ def test_all_core_chain_is_the_staged_chain(oracle):
         np.testing.assert_array_equal(again["hist"], three["hist"])   # reproducible for a thread count
     finally:
         oracle.set_num_threads(2)
+
+
+@pytest.mark.parametrize("dim", [1, 2, 3])
+@pytest.mark.parametrize("bw", ["silverman", "scott"])
+def test_kde_oracle_fixed_bandwidth_equals_scipy(oracle, dim, bw):
+    """A partial pin of the KDE core (whose reference, the external `kde` package, is not vendored): for UNWEIGHTED
+    samples and a FIXED bandwidth the estimator is the textbook one -- sample covariance with 1 / (n - 1), Scott's or
+    Silverman's factor on n, Gaussian kernels of covariance factor^2 * cov -- of which scipy.stats.gaussian_kde is an
+    independent implementation.  The oracle's estimator (and through it the device estimator,
+    tests/test_gpu_kde.py) equals it to rounding.  Weighted samples differ by construction (scipy puts the effective
+    sample size into the factor, the `kde` package's contract the number of points) and the adaptive bandwidths have no
+    second implementation here: those stay unpinned."""
+    from scipy import stats
+
+    from oracle import kde_oracle
+
+    rs = np.random.RandomState(7 + dim)
+    n, m = 400, 150
+    x = np.empty((dim, n))
+    x[0] = rs.rand(n) * 2 - 1
+    if dim > 1:
+        x[1] = 1.5 + rs.gamma(3.0, 0.6, n) + 0.4 * x[0]
+    if dim > 2:
+        x[2] = rs.randn(n) * 0.3 + 0.2 * x[1]
+    lo, hi = x.min(axis=1, keepdims=True), x.max(axis=1, keepdims=True)
+    q = lo + (hi - lo) * (rs.rand(dim, m) * 1.2 - 0.1)
+    want = stats.gaussian_kde(x, bw_method=bw)(q)
+    got = kde_oracle.gaussian_kde_eval(x, None, q, bw, False, 0.0)
+    np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-300)
+    assert want.max() > 0
