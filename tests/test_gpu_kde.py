@@ -548,3 +548,10 @@ def test_fixed_bandwidth_estimator_equals_scipy(dim, n, bw):
     want = stats.gaussian_kde(x, bw_method=bw)(q)
     np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-12 * want.max())
     assert np.count_nonzero(want > 1e-6 * want.max()) > 500
+    # weighted samples, scipy given this estimator's factor (the convention the two do not share: number of points
+    # against effective sample size): weighted covariance and weighted kernel sums agree
+    w = rs.rand(n) * 2 + 0.1
+    est_w = K.KdeEstimator(K.to_device(x), K.to_device(w), bw_method=bw, adaptive=False, alpha=0.0, tol=1e-14)
+    got_w = est_w(K.to_device(q)).cpu().numpy()
+    want_w = stats.gaussian_kde(x, bw_method=est_w.factor, weights=w)(q)
+    np.testing.assert_allclose(got_w, want_w, rtol=1e-10, atol=1e-12 * want_w.max())

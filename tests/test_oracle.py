@@ -333,3 +333,10 @@ def test_kde_oracle_fixed_bandwidth_equals_scipy(oracle, dim, bw):
     got = kde_oracle.gaussian_kde_eval(x, None, q, bw, False, 0.0)
     np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-300)
     assert want.max() > 0
+    # WEIGHTED samples with scipy given the oracle's own factor (the one convention the two do not share): the
+    # weighted covariance, 1 / (1 - sum w^2), and the weighted kernel sums are the same estimator
+    w = rs.rand(n) * 2 + 0.1
+    factor = (n * (dim + 2) / 4.0) ** (-1.0 / (dim + 4)) if bw == "silverman" else n ** (-1.0 / (dim + 4))
+    want_w = stats.gaussian_kde(x, bw_method=factor, weights=w)(q)
+    got_w = kde_oracle.gaussian_kde_eval(x, w, q, bw, False, 0.0)
+    np.testing.assert_allclose(got_w, want_w, rtol=1e-11, atol=1e-300)
