@@ -672,3 +672,15 @@ def test_metric_many_matches_point_by_point_and_falls_back():
     assert dm.metric_many(pts, data, "mod_chi2") == want      # delta_index moves: the flux stage, no sweep
     assert eng.last_many is None
     assert serial(osc_only[:2]) == dm.metric_many(osc_only[:2], data, "mod_chi2")
+    # the containers' aeff scales are kept from sweep to sweep: an aeff parameter moved BETWEEN two sweeps (and fixed
+    # during them) must still reach the next one
+    i_aeff = names.index("aeff_scale")
+    same_aeff = [p.copy() for p in osc_only]
+    for p in same_aeff:
+        p[i_aeff] = x0[i_aeff]
+    first = dm.metric_many(same_aeff, data, "mod_chi2")
+    assert first == serial(same_aeff)
+    for p in same_aeff:
+        p[i_aeff] = min(1.0, x0[i_aeff] + 0.07)
+    second = dm.metric_many(same_aeff, data, "mod_chi2")
+    assert second == serial(same_aeff) and second != first

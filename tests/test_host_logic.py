@@ -654,3 +654,29 @@ def test_param_set_deepcopy_is_independent():
     assert c.flag.value is True
     # the free / fixed views of the copy are the copy's objects
     assert all(p is c[p.name] for p in c.free)
+
+
+def test_priors_penalty_keeps_terms_and_follows_every_change():
+    """`ParamSet.priors_penalty` keeps its terms in an array and re-evaluates those of moved parameters only: the
+    same number as the plain sum of `prior_penalty` after value changes, a prior exchanged, a parameter without prior,
+    another metric, and for a set built later from the same Param objects."""
+    from pisa_amd.core.param import Param, ParamSet, Prior
+    from pisa_amd.core.units import ureg
+
+    rs = np.random.RandomState(3)
+    ps = ParamSet([Param(name="p%d" % i, value=(1.0 + i) * ureg.degree,
+                         prior=Prior(kind="gaussian", mean=1.3 * ureg.degree, stddev=0.5 * ureg.degree) if i % 3 else None,
+                         range=[0 * ureg.degree, 90 * ureg.degree], is_fixed=False) for i in range(12)])
+    plain = lambda s_, m: np.sum([p.prior_penalty(m) for p in s_])
+    for step in range(40):
+        m = "llh" if step % 5 else "mod_chi2"
+        k = int(rs.randint(12))
+        ps["p%d" % k].value = float(rs.uniform(0.5, 80.0)) * ureg.degree
+        if step == 17:
+            ps.p4.prior = Prior(kind="gaussian", mean=20 * ureg.degree, stddev=3 * ureg.degree)
+        if step == 23:
+            ps.p5.prior = None
+        assert ps.priors_penalty(m) == plain(ps, m)
+    view = ParamSet([ps.p1, ps.p4, ps.p7])
+    ps.p4.value = 33 * ureg.degree
+    assert view.priors_penalty("llh") == plain(view, "llh") and ps.priors_penalty("llh") == plain(ps, "llh")
