@@ -127,6 +127,7 @@ class Container:
     def __init__(self, name, representation="events"):
         self.name = name
         self._representation = None
+        self._rep_hash = hash(None)
         self._is_map = False
         self.linked = False
         self._aux_data = {}
@@ -212,6 +213,7 @@ class Container:
                 if representation not in self.array_representations:
                     raise ValueError("Unknown representation '%s'" % representation)
         self._representation = representation
+        self._rep_hash = key      # (hashing a binning walks its dimensions: the stores and look-ups below use this)
         self._is_map = isinstance(representation, MultiDimBinning)
         self.current_data = self.data[key]
 
@@ -283,7 +285,7 @@ class Container:
         self.current_data[key].dev_changed()
 
     def mark_valid(self, key):
-        self.validity[key][hash(self._representation)] = True
+        self.validity[key][self._rep_hash] = True
 
     def _invalidate_others(self, key):
         self._version[key] += 1
@@ -311,12 +313,12 @@ class Container:
     def _get(self, key):
         if key in self.pending:
             self._flush_pending(key)
-        elif key in self._lazy and hash(self._lazy[key][1]) == hash(self._representation):
+        elif key in self._lazy and hash(self._lazy[key][1]) == self._rep_hash:
             self._materialize_lazy(key)
         if self._is_map and key in self._representation._name_set:
             # the bin centres of a binning never change: one host array and one device copy per
             # (binning, dimension) for all containers (a binned flux stage asks for them every evaluation)
-            ck = (hash(self._representation), key)
+            ck = (self._rep_hash, key)
             arr = Container._unrolled.get(ck)
             if arr is None:
                 arr = Container._unrolled[ck] = DualArray(self.unroll_binning(key, self._representation))
@@ -328,7 +330,7 @@ class Container:
                 return self._aux_data[key]
             else:
                 raise KeyError('Key "%s" not present in Container "%s"' % (key, self.name))
-        if not self.validity[key].get(hash(self._representation), False):
+        if not self.validity[key].get(self._rep_hash, False):
             self.auto_translate(key)
         return self.current_data[key]
 
@@ -350,13 +352,13 @@ class Container:
 
     def _add_data(self, key, data):
         if isinstance(data, Map):
-            assert hash(self._representation) == hash(data.binning)
+            assert self._rep_hash == hash(data.binning)
             self.current_data[key] = DualArray(data.hist.ravel())
             return
         if isinstance(data, Sequence) and not isinstance(data, np.ndarray) and len(data) == 2 \
                 and isinstance(data[0], MultiDimBinning):
             binning, data = data
-            assert hash(self._representation) == hash(binning)
+            assert self._rep_hash == hash(binning)
         if not (isinstance(data, np.ndarray) or _is_tensor(data)):
             raise TypeError("unknown dataformat")
         if self.is_map:
