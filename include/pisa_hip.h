@@ -276,6 +276,11 @@ int pisa_hip_profile_events(void *start_event, void *stop_event);
 int pisa_hip_apply_osc_weights(const double *d_nu_flux, const double *d_prob_e,
                                const double *d_prob_mu, int64_t n, double *d_weights,
                                void *stream); /* prob3.py:621-622 */
+/* the same with prob_e / prob_mu read at an element stride (columns of one table: the (P_e, P_mu) pairs of the
+ * gather tables have stride 2) -- a stage that publishes such columns as views need not compact them */
+int pisa_hip_apply_osc_weights_strided(const double *d_nu_flux, const double *d_prob_e,
+                                       const double *d_prob_mu, int64_t prob_stride, int64_t n,
+                                       double *d_weights, void *stream); /* prob3.py:621-622 */
 int pisa_hip_apply_aeff(const double *d_weighted_aeff, double scale, int64_t n,
                         double *d_weights, void *stream); /* aeff.py:87 */
 

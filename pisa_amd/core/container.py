@@ -310,6 +310,13 @@ class Container:
 
         return K.to_device(np.asarray(arr, dtype=FTYPE))
 
+    def device_view(self, key):
+        """`device(key)` without compacting a strided view that a stage published (for kernels that take a stride)"""
+        arr = self._get(key)
+        if isinstance(arr, DualArray) and arr.dev_valid:
+            return arr.dev
+        return self.device(key)
+
     def _get(self, key):
         if key in self.pending:
             self._flush_pending(key)

@@ -1093,6 +1093,17 @@ apply_osc_weights_kernel(const double *__restrict__ flux, const double *__restri
     w[i] = w[i] * ((f.x * pe[i]) + (f.y * pmu[i]));
 }
 
+// the same with the two probabilities read at an element stride (columns of one table, e.g. the (P_e, P_mu) pairs
+// of the gather tables: stride 2)
+__global__ void __launch_bounds__(256)
+apply_osc_weights_strided_kernel(const double *__restrict__ flux, const double *__restrict__ pe,
+                                 const double *__restrict__ pmu, int64_t stride, int64_t n, double *__restrict__ w) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double2 f = reinterpret_cast<const double2 *>(flux)[i];
+    w[i] = w[i] * ((f.x * pe[i * stride]) + (f.y * pmu[i * stride]));
+}
+
 __global__ void __launch_bounds__(256)
 apply_aeff_kernel(const double *__restrict__ aeff, double scale, int64_t n,
                   double *__restrict__ w) {
@@ -1663,6 +1674,19 @@ PISA_API int pisa_hip_apply_osc_weights(const double *d_nu_flux, const double *d
     hipLaunchKernelGGL(apply_osc_weights_kernel, grid, block, 0, as_stream(stream), d_nu_flux,
                        d_prob_e, d_prob_mu, n, d_weights);
     PISA_CHECK_LAUNCH("apply_osc_weights_kernel");
+    return PISA_HIP_OK;
+}
+
+PISA_API int pisa_hip_apply_osc_weights_strided(const double *d_nu_flux, const double *d_prob_e,
+                                                const double *d_prob_mu, int64_t prob_stride, int64_t n,
+                                                double *d_weights, void *stream) {
+    if (n < 0 || prob_stride < 1) return PISA_HIP_ERR_INVALID;
+    if (n == 0) return PISA_HIP_OK;
+    if (!d_nu_flux || !d_prob_e || !d_prob_mu || !d_weights) return PISA_HIP_ERR_INVALID;
+    dim3 block(256), grid((unsigned)((n + 255) / 256));
+    hipLaunchKernelGGL(apply_osc_weights_strided_kernel, grid, block, 0, as_stream(stream), d_nu_flux,
+                       d_prob_e, d_prob_mu, prob_stride, n, d_weights);
+    PISA_CHECK_LAUNCH("apply_osc_weights_strided_kernel");
     return PISA_HIP_OK;
 }
 

@@ -286,8 +286,15 @@ def finalize_metric(ws, kind, actual, total_out, metric_status, clear_limbs=True
 
 
 def apply_osc_weights(nu_flux, prob_e, prob_mu, weights):
-    """prob3.apply_function (prob3.py:621-622), in place on `weights`."""
+    """prob3.apply_function (prob3.py:621-622), in place on `weights`.  `prob_e` / `prob_mu` may be 1-D views with
+    the same element stride (columns of one table): read in place."""
     lib = _lib.lib()
+    if (prob_e.dim() == 1 and prob_mu.dim() == 1 and prob_e.stride(0) == prob_mu.stride(0) > 1
+            and prob_e.is_cuda and prob_mu.is_cuda and prob_e.dtype == prob_mu.dtype == F8
+            and prob_e.numel() == prob_mu.numel() == weights.numel()):
+        _lib.check(lib.pisa_hip_apply_osc_weights_strided(_ptr(nu_flux), prob_e.data_ptr(), prob_mu.data_ptr(),
+                                                          prob_e.stride(0), weights.numel(), _ptr(weights), _stream()))
+        return weights
     _lib.check(lib.pisa_hip_apply_osc_weights(_ptr(nu_flux), _ptr(prob_e), _ptr(prob_mu),
                                               weights.numel(), _ptr(weights), _stream()))
     return weights

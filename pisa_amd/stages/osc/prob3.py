@@ -282,6 +282,7 @@ class prob3(Stage):  # pylint: disable=invalid-name
                 deferred.osc(container, "nu_flux")
             else:
                 w = container.device("weights")
-                K.apply_osc_weights(container.device("nu_flux"), container.device("prob_e"),
-                                    container.device("prob_mu"), w)
+                # (prob_e / prob_mu may be columns of the gather tables, published as views: read at their stride)
+                K.apply_osc_weights(container.device("nu_flux"), container.device_view("prob_e"),
+                                    container.device_view("prob_mu"), w)
                 container["weights"] = w

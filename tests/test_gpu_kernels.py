@@ -673,3 +673,22 @@ def test_split_tail_equals_one_workgroup_tail_bit_for_bit(K, L, n_cont, n_bins):
     assert lib.pisa_hip_finalize_metric_split(limbs.data_ptr(), 1, n_cont, n_bins, hist.data_ptr(), sumw2.data_ptr(),
                                             K.METRIC_KIND["chi2"], data.data_ptr(), None, 0, None, tot.data_ptr(),
                                             st.data_ptr(), mst.data_ptr(), 1, None) != 0
+
+
+def test_apply_osc_weights_reads_strided_columns_in_place(K):
+    """prob_e / prob_mu handed over as columns of one table (the gather tables' (P_e, P_mu) pairs, stride 2; a 3 x 3
+    table's entries, stride 9): same bits as with compacted copies"""
+    import torch
+
+    rs = np.random.RandomState(2)
+    n = 40001
+    flux = K.to_device(rs.rand(n, 2))
+    for width, ce, cm in ((2, 0, 1), (9, 1, 4)):
+        tab = K.to_device(rs.rand(n, width))
+        w0 = K.to_device(rs.rand(n))
+        a, b = w0.clone(), w0.clone()
+        K.apply_osc_weights(flux, tab[:, ce], tab[:, cm], a)
+        K.apply_osc_weights(flux, tab[:, ce].contiguous(), tab[:, cm].contiguous(), b)
+        assert torch.equal(a, b) and not torch.equal(a, w0)
+        want = w0.cpu().numpy() * ((flux.cpu().numpy()[:, 0] * tab.cpu().numpy()[:, ce]) + (flux.cpu().numpy()[:, 1] * tab.cpu().numpy()[:, cm]))
+        assert np.array_equal(a.cpu().numpy(), want)
