@@ -295,6 +295,9 @@ def apply_osc_weights(nu_flux, prob_e, prob_mu, weights):
         _lib.check(lib.pisa_hip_apply_osc_weights_strided(_ptr(nu_flux), prob_e.data_ptr(), prob_mu.data_ptr(),
                                                           prob_e.stride(0), weights.numel(), _ptr(weights), _stream()))
         return weights
+    # (any other view -- different strides, more dimensions -- is compacted first)
+    prob_e = prob_e if prob_e.is_contiguous() else prob_e.contiguous()
+    prob_mu = prob_mu if prob_mu.is_contiguous() else prob_mu.contiguous()
     _lib.check(lib.pisa_hip_apply_osc_weights(_ptr(nu_flux), _ptr(prob_e), _ptr(prob_mu),
                                               weights.numel(), _ptr(weights), _stream()))
     return weights

@@ -692,3 +692,9 @@ def test_apply_osc_weights_reads_strided_columns_in_place(K):
         assert torch.equal(a, b) and not torch.equal(a, w0)
         want = w0.cpu().numpy() * ((flux.cpu().numpy()[:, 0] * tab.cpu().numpy()[:, ce]) + (flux.cpu().numpy()[:, 1] * tab.cpu().numpy()[:, cm]))
         assert np.array_equal(a.cpu().numpy(), want)
+    # columns of different strides: compacted, same numbers
+    t2, t9 = K.to_device(rs.rand(n, 2)), K.to_device(rs.rand(n, 9))
+    a, b = w0.clone(), w0.clone()
+    K.apply_osc_weights(flux, t2[:, 1], t9[:, 3], a)
+    K.apply_osc_weights(flux, t2[:, 1].contiguous(), t9[:, 3].contiguous(), b)
+    assert torch.equal(a, b)
