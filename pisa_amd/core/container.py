@@ -560,6 +560,9 @@ class VirtualContainer:
     def device(self, key):
         return self.containers[0].device(key)
 
+    def device_view(self, key):
+        return self.containers[0].device_view(key)
+
     def __setitem__(self, key, value):
         for c in self:
             c[key] = value
