@@ -858,6 +858,9 @@ class HotPathEngine:
         else:
             self.accumulate(params)
             self.allreduce()
+            if self.spin_wait and self.data is not None and self.can_fuse_tail():
+                # (event-by-event oscillations, unplanned grids: the same tail and the same polled value)
+                return self.tail_host(kind)
             self._tail(kind, self.metric_host)
         torch.cuda.current_stream().synchronize()
         return float(self.metric_host[0])
