@@ -93,6 +93,60 @@ def parse(argv=None):
     return ap.parse_args(argv)
 
 
+HOOKS_ENV = "PISA_BENCH_HOOKS"   # tests only: "module:function" returning the `hooks` dict of main()
+
+
+def _hooks_from_env():
+    spec = os.environ.get(HOOKS_ENV)
+    if not spec:
+        return None
+    import importlib
+
+    mod, _, fn = spec.partition(":")
+    return getattr(importlib.import_module(mod), fn)()
+
+
+def launch_ranks(args, argv, standin):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: this process -- which has NOT
+    touched the GPU and never will -- starts `torch.distributed.run` with N fresh rank processes on this
+    very command line, relays rank 0's JSON line on stdout (everything else the ranks print goes to
+    stderr) and returns the launcher's exit code.  `torch.cuda.device_count()` does not initialise HIP
+    on this image; the ranks check their own device again."""
+    import socket
+    import subprocess
+
+    if not standin:
+        import torch
+
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print("bench.py: --gpus %d asked for, %d HIP device(s) visible on this node" % (args.gpus, have),
+                  file=sys.stderr)
+            return 3
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, cwd=ROOT)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln.rstrip("\n")
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if rc == 0 and line is None:
+        print("bench.py: the ranks ended without a result line", file=sys.stderr)
+        return 4
+    if line is not None and rc == 0:
+        print(line, flush=True)
+    return rc
+
+
 def param_list(wl, n, **kw):
     """fixed seeded scan of (theta23, dm31) over the ranges of SURVEY 8d (C4)"""
     import numpy as np
@@ -970,9 +1024,15 @@ def main(argv=None, hooks=None):
     group, barriers, max over ranks, the legs that run on several ranks, the JSON line -- on CPU ranks over
     gloo, with `hooks["device_state"]` in place of the HIP-backed engine.  Nothing in the product or in the
     driver's invocation passes hooks."""
+    argv = list(sys.argv[1:] if argv is None else argv)
     args = parse(argv)
     if args.cpu_baseline_worker:
         return cpu_baseline_worker(args.cpu_baseline_worker, args.binning)
+    if hooks is None:
+        hooks = _hooks_from_env()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: become one (before anything touches the GPU)
+        return launch_ranks(args, argv, standin=hooks is not None)
     import numpy as np
     import torch
 
@@ -981,8 +1041,12 @@ def main(argv=None, hooks=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (--nproc-per-node %d wanted)"
+                         % (args.gpus, world, args.gpus))
     if cuda:
+        have = torch.cuda.device_count()
+        if have <= local_rank:
+            raise SystemExit("bench.py: rank %d wants HIP device %d, %d device(s) visible" % (rank, local_rank, have))
         torch.cuda.set_device(local_rank)
     dist_on = world > 1 or args.force_dist
     if dist_on:
@@ -1088,6 +1152,20 @@ def main(argv=None, hooks=None):
     n_comm = None
     if dist_on and st._rccl:
         n_comm = st._rccl.count()
+        if n_comm != world:
+            raise SystemExit("bench.py: the RCCL communicator spans %d rank(s), %d launched" % (n_comm, world))
+    # the LLH of the last timed point as every rank holds it: integer limbs summed over the ranks, the tail
+    # replicated -- the bits must be the same everywhere (north star: bit-reproducible across GPU counts)
+    llh_bits = None
+    if dist_on:
+        import torch.distributed as dist
+
+        mine = torch.tensor([int(np.float64(llh).view(np.int64))], dtype=torch.int64, device="cuda" if cuda else "cpu")
+        every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, mine)
+        llh_bits = ["%016x" % (int(t.item()) & 0xFFFFFFFFFFFFFFFF) for t in every]
+        if len(set(llh_bits)) != 1:
+            raise SystemExit("bench.py: the ranks hold different LLH bits: %s" % llh_bits)
 
     # ---- weak scaling beside it: every rank a sample of its own, limbs all-reduced, N samples per step
     weak = None
@@ -1240,6 +1318,8 @@ def main(argv=None, hooks=None):
             "allreduce_ms": t_allreduce,
             "nccl_comm_count": n_comm,
             "last_llh": llh,
+            "llh_bits_per_rank": llh_bits,
+            "llh_bits_identical": None if llh_bits is None else len(set(llh_bits)) == 1,
             "pipelined_evals_per_s": pipelined,
             "batched_evals_per_s3": (legs.get("multi_point") or {}).get("K3", {}).get("evals_per_s"),
             "batched_evals_per_s5": (legs.get("multi_point") or {}).get("K5", {}).get("evals_per_s"),
@@ -1281,4 +1361,4 @@ def main(argv=None, hooks=None):
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -326,6 +326,12 @@ class FastPlan:
         osc, eng = self.osc, self.engine
         if self.post or self.flux_stages or self.hist._engine is not eng or osc.pepmu is None:
             return None
+        if kind not in K.METRIC_KIND:
+            return None
+        if kind == "mod_chi2" and not self.with_errors:
+            # output_key='weights': the maps carry no errors and Map.metric uses zero variance
+            # (DeviceMapBlock.metric has the same guard); the one-sweep tail would hand sumw2 in
+            return None
         g = osc.grid
         if (self._writes() != self.container_clock or n_points < 2
                 or bool(g["e_major"]) != bool(eng.grid.energy_first)):

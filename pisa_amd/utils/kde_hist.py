@@ -371,7 +371,8 @@ def kde_histogramdd_batch(samples, binning, bw_method="scott", adaptive=True, al
         stats["all_pairs"] = stats.get("all_pairs", 0) + sum(n * (n * bool(adaptive) + g["n_points"]) for n in sizes)
     per_sample = [[] for _ in samples]
     pid_of = [None] * len(samples)
-    hists = _finish_hist_many(g, dens.reshape((n_jobs,) + tuple(g["megashape"])), oversample) * np.asarray(sums)[:, None, None]
+    hists = _finish_hist_many(g, dens.reshape((n_jobs,) + tuple(g["megashape"])), oversample)
+    hists = hists * np.asarray(sums, dtype=np.float64).reshape((-1,) + (1,) * (hists.ndim - 1))
     for k, (si, pid_bin) in enumerate(owner):
         per_sample[si].append(hists[k])
         pid_of[si] = pid_bin

@@ -397,6 +397,44 @@ def test_bench_multi_gpu_control_flow_on_gloo_ranks(tmp_path):
     assert single.sweeps == 2
 
 
+def bench_hooks():
+    """what `PISA_BENCH_HOOKS=tests.test_distributed_cpu:bench_hooks` hands to bench.main in every rank"""
+    return dict(device_state=_make_bench_state, legs=("multi_point",))
+
+
+def test_bench_gpus_2_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2 ...` as a PLAIN subprocess, the way the driver runs N = 1: the parent
+    starts torch.distributed.run with two fresh ranks itself (gloo stand-in selected by the environment
+    variable it forwards), relays ONE JSON line and the exit code; the line says that both ranks hold the
+    same LLH bits.  Without the stand-in and without two HIP devices it must end non-zero within seconds."""
+    import json
+    import subprocess
+    import sys
+    import time
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--events", "360", "--steps", "3",
+           "--warmup", "1", "--min-timed-s", "0", "--grid", "12x8", "--legs", "multi_point"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["PISA_BENCH_HOOKS"] = "tests.test_distributed_cpu:bench_hooks"
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0 and line["scaling"] == "strong"
+    assert line["llh_bits_identical"] is True and len(line["llh_bits_per_rank"]) == 2
+    assert set(line["legs"]) == {"multi_point"}
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        env.pop("PISA_BENCH_HOOKS")
+        t0 = time.time()
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        assert res.returncode != 0 and not res.stdout.strip()
+        assert "--gpus 2 asked for" in res.stderr
+        assert time.time() - t0 < 120
+
+
 # ---- utils.kde.apply_function itself on several ranks (CPU, gloo): the containers it owns, the lazily produced event
 #      weights, ONE batched estimator call per rank, the exchange of the finished maps -- with the native batch call
 #      replaced by a host stand-in (the stage's own code otherwise)
