@@ -31,6 +31,26 @@ inline int check_hip(hipError_t e, const char *what) {
         if (_rc != PISA_HIP_OK) return _rc;                      \
     } while (0)
 
+// Development probes.  The product library reads NO environment variable and has no switch that makes a kernel do
+// less work: every run-time selection of a kernel form used while developing (scripts/dev/*) exists only in builds
+// made with `make EXTRA=-DPISA_DEV_PROBES`.  In the default build PISA_DEV_INT(name, dflt) is the constant `dflt`
+// (the name never reaches the binary: tests/test_abi.py checks `strings libpisa_hip.so`).
+#ifdef PISA_DEV_PROBES
+#include <stdlib.h>
+inline long long dev_env_ll(const char *name, long long dflt) {
+    const char *v = getenv(name);
+    return v ? atoll(v) : dflt;
+}
+inline const char *dev_env_str(const char *name) { return getenv(name); }
+#define PISA_DEV_INT(name, dflt) ((int)::pisa::dev_env_ll("PISA_HIP_" name, (dflt)))
+#define PISA_DEV_LL(name, dflt) (::pisa::dev_env_ll("PISA_HIP_" name, (dflt)))
+#define PISA_DEV_STR(name) (::pisa::dev_env_str("PISA_HIP_" name))
+#else
+#define PISA_DEV_INT(name, dflt) ((int)(dflt))
+#define PISA_DEV_LL(name, dflt) ((long long)(dflt))
+#define PISA_DEV_STR(name) ((const char *)nullptr)
+#endif
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 // Regular (linear, equal-width) binning as the kernels see it

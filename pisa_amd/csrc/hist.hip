@@ -26,6 +26,7 @@
 // = 72 B (D=3).  The (P_e, P_mu) gather tables (<= 3.8 MB) stay in L2.
 #include <stdlib.h>
 #include <algorithm>
+#include <atomic>
 #include <string.h>
 
 #include "common.hpp"
@@ -197,7 +198,8 @@ struct HistArgs {
     ContDev cont[MAX_CONT];
     int32_t blk_start[MAX_CONT + 1];
     int32_t copies;       // LDS replicas of the accumulators (power of two), lane-interleaved
-    int32_t dbg;          // development probe (PISA_HIP_HIST_DBG): 1 skip sumw2, 2 skip all deposits
+    int32_t opts;         // 1: the caller has no use for the second quantity (plain histogram without counts).
+                          // Builds with -DPISA_DEV_PROBES only (PISA_HIP_HIST_DBG): 2 no deposits, 4 no flush
     int32_t window;       // > 0: LDS holds this many bins starting at the chunk's lowest bin
 };
 
@@ -353,12 +355,14 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
                 glb_add(&g_out[i0], d0); glb_add(&g_out[i0 - 1], d1); glb_add(&g_out[i0 - 2], d2);
             }
         };
-        if (a.dbg & 2) {  // probe: keep the loads and the weight chain alive, no atomics
+#ifdef PISA_DEV_PROBES
+        if (a.opts & 2) {  // probe: keep the loads and the weight chain alive, no atomics
             if (w == 1.2345e-300 || w2 == 1.2345e-300) bad = true;
             return;
         }
+#endif
         bool ok = deposit_units(w, add30, add0);
-        if (!(a.dbg & 1)) ok = deposit_units(w2, add31, add1) && ok;
+        if (!(a.opts & 1)) ok = deposit_units(w2, add31, add1) && ok;
         if (!ok) bad = true;
     };
 
@@ -643,7 +647,10 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
     if (bad && status) atomicOr(status, 1);
     STAMP(3);
 
-    if (LDS_ACC && !(a.dbg & 4)) {
+#ifdef PISA_DEV_PROBES
+    if (a.opts & 4) return;
+#endif
+    if (LDS_ACC) {
         __syncthreads();
         STAMP(4);
         // slab accumulators -> integer units, added to the global limbs.  The loop runs in
@@ -1115,11 +1122,6 @@ apply_aeff_kernel(const double *__restrict__ aeff, double scale, int64_t n,
 // ---------------------------------------------------------------- host side
 static int64_t lds_acc_bytes(int64_t n_bins) { return n_bins * 2 * NL * 8; }
 
-static int env_int(const char *name, int dflt) {
-    const char *v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
 // Workgroups of an accumulate launch.  ONE 1024-thread workgroup per CU (`target` = the device's CU count unless
 // PISA_HIP_HIST_BLOCKS says otherwise), never one more: with two per CU the SIMDs serve the older one first, the
 // younger ones finish 6-8 us later on their own at half the chip's request rate (10^7 events: 40.1 -> 37.0 us by
@@ -1138,6 +1140,16 @@ static int device_cus() {
         return v;
     }();
     return n;
+}
+
+// LDS a workgroup of the current device may ask for (opt-in limit; 160 KiB on gfx950, 64 KiB on older parts)
+static int64_t device_lds_bytes() {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 64 * 1024;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeSharedMemPerBlockOptin, dev) != hipSuccess || v <= 0)
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0)
+            v = 64 * 1024;
+    return v;
 }
 
 static int plan_blocks_balanced(const int64_t *n_events, int n_cont, int threads, int64_t target, int64_t &chunk,
@@ -1176,7 +1188,7 @@ static int plan_blocks_balanced(const int64_t *n_events, int n_cont, int threads
 
 static int plan_blocks(const int64_t *n_events, int n_cont, int threads, int64_t &chunk,
                        int32_t *blk_start) {
-    const int env = env_int("PISA_HIP_HIST_BLOCKS", 0);
+    const int env = PISA_DEV_INT("HIST_BLOCKS", 0);
     const int64_t target = env > 0 ? env : (int64_t)device_cus() * std::max(1, 1024 / threads);
     return plan_blocks_balanced(n_events, n_cont, threads, target, chunk, blk_start);
 }
@@ -1194,7 +1206,7 @@ static int run_hist(const ContDev *conts, int n_cont, int mode, const DevBinning
     int64_t lds_bytes = lds_acc_bytes(n_bins);
     bool lds = lds_bytes <= LDS_ACC_BYTES_MAX;
     int window = 0;
-    if (!lds && (mode == 3 || mode == 5 || mode == 7) && !env_int("PISA_HIP_HIST_NO_WINDOW", 0)) {
+    if (!lds && (mode == 3 || mode == 5 || mode == 7) && !PISA_DEV_INT("HIST_NO_WINDOW", 0)) {
         // binning too large for LDS: accumulate a window of it (see the kernel)
         // a multiple of 32 bins: the LDS bank pair of an accumulator is then (bin - bin_lo) mod 32
         // whatever the slab and quantity, which the bank-aware event order relies on
@@ -1206,7 +1218,7 @@ static int run_hist(const ContDev *conts, int n_cont, int mode, const DevBinning
     // deposits left to spread) and with four for node-sorted events (49.6 / 53 / 49 us)
     // events in arbitrary order (modes 0 and 1: no bank-aware order, neighbouring lanes often in the
     // same bin): up to eight replicas, as LDS allows
-    int copies = window ? 1 : env_int("PISA_HIP_HIST_COPIES", mode <= 1 ? 8 : 2);
+    int copies = window ? 1 : PISA_DEV_INT("HIST_COPIES", mode <= 1 ? 8 : 2);
     while (copies > 1 && (copies & (copies - 1))) copies--;
     while (copies > 1 && lds_bytes * copies > LDS_ACC_BYTES_MAX) copies >>= 1;
     if (copies < 1) copies = 1;
@@ -1224,14 +1236,10 @@ static int run_hist(const ContDev *conts, int n_cont, int mode, const DevBinning
         a.prob[0] = prob_nu;
         a.prob[1] = prob_nubar;
         a.pepmu = reinterpret_cast<const double2 *>(pepmu);
-        {
-            const char *dbg = getenv("PISA_HIP_HIST_DBG");
-            a.dbg = dbg ? atoi(dbg) : 0;
-            if (!second_quantity) a.dbg |= 1;   // the caller has no use for it (plain histogram: no counts)
-        }
+        a.opts = (PISA_DEV_INT("HIST_DBG", 0) & ~1) | (second_quantity ? 0 : 1);
         int64_t nev[MAX_CONT];
         for (int c = 0; c < nc; c++) { a.cont[c] = conts[base + c]; nev[c] = conts[base + c].n; }
-        int threads = env_int("PISA_HIP_HIST_THREADS", 1024);
+        int threads = PISA_DEV_INT("HIST_THREADS", 1024);
         if (threads < 64 || threads > 1024 || (threads & 63)) threads = HIST_THREADS;
         int nblocks = plan_blocks(nev, nc, threads, a.chunk, a.blk_start);
         if (nblocks <= 0) continue;
@@ -1324,7 +1332,7 @@ static int reweight_hist_impl(const pisa_hip_container *h_containers, int32_t n_
     // the 16-bit index form needs 16-bit node / bin numbers; where it does not apply its columns
     // are ignored (the other forms, if given, are used)
     const bool ok16 = n_nodes < 0xffff && n_bins < 0xffff &&
-                      (lds_acc_bytes(n_bins) <= LDS_ACC_BYTES_MAX || !env_int("PISA_HIP_HIST_NO_WINDOW", 0));
+                      (lds_acc_bytes(n_bins) <= LDS_ACC_BYTES_MAX || !PISA_DEV_INT("HIST_NO_WINDOW", 0));
     bool all_idx16 = any_table && ok16;
     for (int c = 0; c < n_containers; c++) {
         const pisa_hip_container &h = h_containers[c];
@@ -1393,11 +1401,17 @@ PISA_API int pisa_hip_reweight_hist_acc(const pisa_hip_container *h_containers,
 template <int KP>
 static int launch_multi(const MultiArgs &a, int nblocks, size_t shmem, unsigned long long *out,
                         int32_t *d_status, hipStream_t s) {
-    static bool attr_set = false;   // LDS beyond the default 64 KiB has to be asked for once per kernel
-    if (!attr_set && shmem > 64 * 1024) {
+    // LDS beyond the default 64 KiB has to be asked for once per kernel AND device
+    static std::atomic<uint64_t> attr_set{0};
+    int dev = 0;
+    PISA_TRY_HIP(hipGetDevice(&dev));
+    const uint64_t bit = 1ull << (dev & 63);
+    if (shmem > 64 * 1024 && !(attr_set.load(std::memory_order_acquire) & bit)) {
+        const int64_t limit = device_lds_bytes() - 256;
+        if ((int64_t)shmem > limit) return PISA_HIP_ERR_INVALID;
         PISA_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hist_accumulate_multi_kernel<KP>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-        attr_set = true;
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)limit));
+        attr_set.fetch_or(bit, std::memory_order_release);
     }
     hipLaunchKernelGGL((hist_accumulate_multi_kernel<KP>), dim3((unsigned)nblocks), dim3(HIST_THREADS), shmem, s,
                        a, out, d_status);
@@ -1407,10 +1421,11 @@ static int launch_multi(const MultiArgs &a, int nblocks, size_t shmem, unsigned 
 
 PISA_API int pisa_hip_multi_points_per_pass(int64_t n_bins) {
     if (n_bins < 1) return 0;
-    const int64_t lds_max = (int64_t)env_int("PISA_HIP_MULTI_LDS_KB", 128) * 1024;
+    int64_t lds_max = (int64_t)PISA_DEV_INT("MULTI_LDS_KB", 128) * 1024;
+    if (lds_max > device_lds_bytes() - 256) lds_max = device_lds_bytes() - 256;   // a part with 64 KiB LDS: fewer points per pass
     int64_t kp = lds_max / lds_acc_bytes(n_bins);
     if (kp > MULTI_KP_MAX) kp = MULTI_KP_MAX;
-    return (int)kp;
+    return kp < 2 ? 0 : (int)kp;   // one point per pass is the single-point path's job
 }
 
 PISA_API int pisa_hip_reweight_hist_multi(const pisa_hip_container *h_containers, int32_t n_containers,
@@ -1443,7 +1458,7 @@ PISA_API int pisa_hip_reweight_hist_multi(const pisa_hip_container *h_containers
         const int kp = (n_points - k0 + (n_pass - pass) - 1) / (n_pass - pass);   // passes of equal size
         // workgroups: what is resident at once.  From two points on the kernel needs more than 64 VGPRs,
         // a CU holds ONE 1024-thread workgroup, and a second round of workgroups would only add a tail
-        const int64_t target_blocks = env_int("PISA_HIP_MULTI_BLOCKS", device_cus());
+        const int64_t target_blocks = PISA_DEV_INT("MULTI_BLOCKS", device_cus());
         for (int base = 0; base < n_containers; base += MAX_CONT) {
             const int nc = n_containers - base < MAX_CONT ? n_containers - base : MAX_CONT;
             MultiArgs a;

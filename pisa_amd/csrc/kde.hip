@@ -1035,7 +1035,7 @@ kde_cell_s2min_kernel(const double *__restrict__ s2, const int32_t *__restrict__
 constexpr int HERMITE_MIN_DEFAULT = 1;   // with local expansions (see pisa_hip_kde_create)
 constexpr int HERMITE_MIN_SERIES = 24;   // series evaluated per target
 static int hermite_min() {
-    static const int v = [] { const char *e = getenv("PISA_HIP_KDE_HERMITE_MIN"); const int x = e ? atoi(e) : 0; return x > 0 ? x : HERMITE_MIN_DEFAULT; }();
+    static const int v = [] { const int x = PISA_DEV_INT("KDE_HERMITE_MIN", 0); return x > 0 ? x : HERMITE_MIN_DEFAULT; }();
     return v;
 }
 constexpr double RSQRT2 = 0.70710678118654752440;
@@ -2066,7 +2066,7 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
         // target, so every non-empty cell gets one; evaluated target by target (no local expansions) a
         // series pays from ~24 sources
         const int dense_min = local_ok ? hermite_min() : std::max(hermite_min(), HERMITE_MIN_SERIES);
-        static const int64_t expansion_min_n = [] { const char *v = getenv("PISA_HIP_KDE_EXPANSION_MIN_N"); return v ? (int64_t)atoll(v) : (int64_t)1000; }();
+        static const int64_t expansion_min_n = (int64_t)PISA_DEV_LL("KDE_EXPANSION_MIN_N", 1000);
         // (1 000: C3-shaped evaluations of 1e5 / 3e5 events take 11.5 / 27.5 ms with the round-2 threshold of 20 000 sources per
         //  estimator -- direct pair sums below it --, 5.7 / 5.9 ms with this one)
         if (g_kde_expansion && dim == 2 && cut && n >= expansion_min_n) {
@@ -2145,7 +2145,7 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
             }
             dim3 grid((unsigned)n_blocks, (unsigned)n_split);
             // translation passes: 1 = four targets per workgroup (default), 0 = one target per workgroup
-            static const int h2l_form = [] { const char *v = getenv("PISA_HIP_KDE_H2L_FORM"); return v ? atoi(v) : 1; }();
+            static const int h2l_form = PISA_DEV_INT("KDE_H2L_FORM", 1);
 #define KDE_FGT(PP) do { \
                 hipLaunchKernelGGL(kde_hermite_coef_kernel<PP>, dim3((unsigned)nd), dim3(HC_THREADS), 0, s, g, d_dense, \
                                    k->cell_start, k->ys, n, k->coef, herm); \
@@ -2296,7 +2296,7 @@ static int lattice_strip(const pisa_hip_kde *k, const double *step, const int64_
     if (k->dim != 2 || !(k->g.rcut2 > 0.0) || k->g.rcut2 > 138.0 || count[0] * count[1] > 0x7FFFFFF0LL) return 0;
     const double da = k->g.U[0] * step[0];
     if (!(da > 0.0) || !std::isfinite(da) || !(k->s2_range[1] > 0.0)) return 0;
-    static const int forced = [] { const char *v = getenv("PISA_HIP_KDE_LATTICE_R"); return v ? atoi(v) : -1; }();
+    static const int forced = PISA_DEV_INT("KDE_LATTICE_R", -1);
     if (forced == 0) return 0;
     const double lim = 50.0 / (da * sqrt(k->s2_range[1]));
     for (int R : {32, 16, 8})
@@ -2310,7 +2310,7 @@ static int lattice_strip(const pisa_hip_kde *k, const double *step, const int64_
 // touches (sources spread evenly over the lattice and its margin) picks sw.
 static int lattice_shape(const pisa_hip_kde *k, int R, const double *step, const int64_t *count) {
     const int strips_a = (int)((count[0] + R - 1) / R);
-    static const int forced = [] { const char *v = getenv("PISA_HIP_KDE_LATTICE_SW"); return v ? atoi(v) : 0; }();
+    static const int forced = PISA_DEV_INT("KDE_LATTICE_SW", 0);
     if (forced > 0) return std::min(std::min(forced, strips_a), 64);
     const double rp = sqrt(k->g.rcut2) / fabs(k->g.U[0] * step[0]), rl = sqrt(k->g.rcut2) / fabs(k->g.U[4] * step[1]);
     const double n0 = (double)count[0], n1 = (double)count[1];
@@ -2339,7 +2339,7 @@ static int64_t lattice_patches(int R, int sw, const int64_t *count) {
 // number of wavefronts of the lattice kernel (>= one per patch)
 static int64_t lattice_waves(int R, int sw, const int64_t *count, int64_t n) {
     const int64_t patches = lattice_patches(R, sw, count);
-    static const int waves = [] { const char *v = getenv("PISA_HIP_KDE_LATTICE_WAVES"); return v ? atoi(v) : 3072; }();
+    static const int waves = PISA_DEV_INT("KDE_LATTICE_WAVES", 3072);
     int64_t w = std::max<int64_t>(patches, waves);
     w = std::min<int64_t>(w, std::max<int64_t>(patches, (int64_t)(128 << 20) / (R * 64 * 8)));     // partial sums <= 128 MB
     (void)n;   // (the plan gives a patch no more wavefronts than it has shares within reach)
@@ -2421,7 +2421,7 @@ PISA_API int pisa_hip_kde_evaluate_lattice(pisa_hip_kde *k, const double *h_orig
                        k->coef, k->s2, k->n, L.da, g.rcut2, rec, box);
     hipLaunchKernelGGL(kde_lattice_load_kernel, dim3((unsigned)n_patches), dim3(256), 0, s, L, R, box, n_shares, load,
                        n_patches, n_waves, wstart, k->pair_count + 4);
-    static const int pairing = [] { const char *v = getenv("PISA_HIP_KDE_LATTICE_PAIR"); return v ? atoi(v) : 1; }();
+    static const int pairing = PISA_DEV_INT("KDE_LATTICE_PAIR", 1);
 #define KDE_LAT(RR) hipLaunchKernelGGL(kde_lattice_kernel<RR>, dim3((unsigned)n_waves), dim3(64), 0, s, L, g.rcut2, rec, k->n, share, box, wstart, n_patches, pairing, part, k->pair_count)
     if (R == 32) KDE_LAT(32); else if (R == 16) KDE_LAT(16); else KDE_LAT(8);
 #undef KDE_LAT

@@ -84,7 +84,12 @@ class KdePool {
     // queues the tasks (in the given order) for up to n_threads pool threads and returns
     void submit(std::vector<Task> &&tasks, int n_threads) {
         std::lock_guard<std::mutex> lk(m_);
-        while ((int)threads_.size() < n_threads) threads_.emplace_back([this] { loop(); });
+        // a new thread starts from the release epoch of its creation (read here, under the lock): a release()
+        // that arrives before the thread has run a single instruction is still seen and answered by it
+        while ((int)threads_.size() < n_threads) {
+            const int epoch = release_epoch_;
+            threads_.emplace_back([this, epoch] { loop(epoch); });
+        }
         limit_ = std::max(limit_, n_threads);
         pending_ += (int)tasks.size();
         for (auto &t : tasks) queue_.push_back(std::move(t));
@@ -108,11 +113,10 @@ class KdePool {
     }
 
   private:
-    void loop() {
+    void loop(int seen_epoch) {
         KdeWorkerState st;
         std::unique_lock<std::mutex> lk(m_);
         const int my_id = n_started_++;
-        int seen_epoch = release_epoch_;
         for (;;) {
             cv_job_.wait(lk, [&] { return stop_ || seen_epoch != release_epoch_ || (!queue_.empty() && my_id < limit_); });
             if (stop_) return;
@@ -162,10 +166,10 @@ struct KdeBatchParams {
 
 static int run_job(pisa_hip_kde_job &job, const KdeBatchParams &P, hipEvent_t ready, KdeWorkerState &st) {
     if (st.device != P.device) {
+        // everything this thread holds belongs to the device it worked on last -- stream, workspaces AND the
+        // estimator's thread-local scratch (kde.hip), which is tied to that stream: released there, in that order
+        free_state(st);
         PISA_TRY_HIP(hipSetDevice(P.device));
-        if (st.stream) { (void)hipStreamDestroy(st.stream); st.stream = nullptr; }
-        if (st.work) { (void)hipFree(st.work); st.work = nullptr; st.work_bytes = 0; }
-        if (st.lwork) { (void)hipFree(st.lwork); st.lwork = nullptr; st.lwork_bytes = 0; }
         PISA_TRY_HIP(hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking));
         st.device = P.device;
     }

@@ -313,10 +313,10 @@ static int launch_events(const Prob3Consts &c, const EarthDev &e, const EvCont *
         for (int b = a + 1; b < e.n_shell; b++)
             if (e.coszen_limit[a] > -1.0 && e.coszen_limit[b] > -1.0 && fabs(e.rhos[a] - e.rhos[b]) < 1e-5)
                 staged = true;
-    static const int force_staged = [] { const char *v = getenv("PISA_HIP_EVENTS_STAGED"); return v ? atoi(v) : 0; }();
+    static const int force_staged = PISA_DEV_INT("EVENTS_STAGED", 0);
     if (force_staged) staged = true;   // development / test switch: the general form
     // direct form: 3 wavefronts per SIMD with the running product in LDS (see the kernel); 2: product in registers
-    static const int waves_cfg = [] { const char *v = getenv("PISA_HIP_EVENTS_WAVES"); return v ? atoi(v) : 3; }();
+    static const int waves_cfg = PISA_DEV_INT("EVENTS_WAVES", 3);
     size_t lds = 3 * PISA_HIP_MAX_SHELLS * sizeof(double) +
                  (staged ? (size_t)max_seg * threads * 10
                          : (c.decay ? (size_t)18 * threads * 8 : (waves_cfg > 2 ? (size_t)12 * threads * 8 : 0))) + 16;

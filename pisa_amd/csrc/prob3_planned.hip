@@ -436,7 +436,7 @@ static int cut_items(pisa_hip_grid_plan *p, int n_e) {
     const int tiles = (n_e + 63) / 64;
     int ch = (int)(((int64_t)p->n_pairs * 2 * tiles + 2047) / 2048);
     if (ch < 1) ch = 1;
-    if (const char *v = getenv("PISA_HIP_PROB3_CH")) ch = atoi(v) > 0 ? atoi(v) : ch;  // development probe
+    if (const int v = PISA_DEV_INT("PROB3_CH", 0); v > 0) ch = v;
     const int np = p->n_pairs;
     int32_t *iu = new int32_t[np + 1], *ip0 = new int32_t[np + 1], *icnt = new int32_t[np + 1];
     int ni = 0;
@@ -533,10 +533,7 @@ PISA_API int pisa_hip_grid_plan_create(const double *d_densities, const double *
         p->n_chain = nc;
         p->h_pair_u = su;
         su = nullptr;
-        {
-            const char *v = getenv("PISA_HIP_PROB3_FUSED_AMP");
-            p->fused_amp = v ? (atoi(v) != 0) : 1;
-        }
+        p->fused_amp = PISA_DEV_INT("PROB3_FUSED_AMP", 1) != 0;
         if (nu == 0) uniq[0] = 0.0;
         size_t npa = np > 0 ? np : 1, nca = nc > 0 ? nc : 1;
         rc = check_hip(hipMalloc(&p->d_pair_dist, npa * 8), "hipMalloc");
@@ -547,13 +544,13 @@ PISA_API int pisa_hip_grid_plan_create(const double *d_densities, const double *
         {
             // packed chain launch: rows by length, longest first; 4 waves per workgroup =
             // one long row x 4 groups | two medium rows x 2 | four short rows x 1
-            const char *m = getenv("PISA_HIP_CHAIN_MODE");
+            const char *m = PISA_DEV_STR("CHAIN_MODE");
             p->chain_packed = (m && strcmp(m, "split") == 0) ? 0 : 1;
             int32_t *code = new int32_t[((size_t)4 * n_cz + 4) * 4];   // per wave: code, chain start, chain length, 0
             int nb = 0;
             int t4 = 14, t2 = 0;  // crossed layers from which a row gets four / two waves (measured: 22.1 us; 14/6: 23.4; one row per workgroup: 24.4)
-            if (const char *v = getenv("PISA_HIP_PACK_T4")) t4 = atoi(v);  // development probes
-            if (const char *v = getenv("PISA_HIP_PACK_T2")) t2 = atoi(v);
+            t4 = PISA_DEV_INT("PACK_T4", t4);
+            t2 = PISA_DEV_INT("PACK_T2", t2);
             auto groups_of = [&](int c_) { return c_ >= t4 ? 4 : (c_ >= t2 ? 2 : 1); };
             for (int want = 4; want >= 1; want >>= 1) {
                 int fill = 0;  // wave slots used in the open workgroup
@@ -613,8 +610,7 @@ static int launch_planned(const CS &cs, bool decay, int n_points, pisa_hip_grid_
                           hipStream_t s) {
     const unsigned tiles = (unsigned)((n_e + 63) / 64);
     static const int groups = []() {
-        const char *v = getenv("PISA_HIP_CHAIN_GROUPS");
-        int g = v ? atoi(v) : CHAIN_GROUPS_DEFAULT;
+        const int g = PISA_DEV_INT("CHAIN_GROUPS", CHAIN_GROUPS_DEFAULT);
         return (g == 1 || g == 2 || g == 4) ? g : CHAIN_GROUPS_DEFAULT;
     }();
     if (plan->n_e_terms < n_e || plan->n_pt_terms < n_points) {
@@ -667,8 +663,7 @@ PISA_API int pisa_hip_prob3_grid_planned(const pisa_hip_prob3_params *h_params,
     hipStream_t s = as_stream(stream);
     const unsigned tiles = (unsigned)((n_e + 63) / 64);
     static const int groups = []() {
-        const char *v = getenv("PISA_HIP_CHAIN_GROUPS");
-        int g = v ? atoi(v) : CHAIN_GROUPS_DEFAULT;
+        const int g = PISA_DEV_INT("CHAIN_GROUPS", CHAIN_GROUPS_DEFAULT);
         return (g == 1 || g == 2 || g == 4) ? g : CHAIN_GROUPS_DEFAULT;
     }();
     const int fused_amp = plan->fused_amp;

@@ -438,7 +438,7 @@ class HotPathEngine:
         # (`pisa_hip_finalize_metric_split`: total = (p0 + p2) + (p1 + p3), the one-workgroup value bit for bit)
         self.metric_host = torch.zeros(4, dtype=torch.float64).pin_memory()
         self._metric_host_np = self.metric_host.numpy()
-        self.split_tail = os.environ.get("PISA_HIP_SPLIT_TAIL", "1") != "0"
+        self.split_tail = True     # four tail workgroups per point (an attribute, not an environment switch)
         self.spin_wait = 50000  # polls of the pinned result (~7 ms) before falling back to a stream sync
         self.fused_tail = True
         self._limbs_zero = self._maps_valid = False

@@ -1,6 +1,7 @@
 # headline step against the accumulate kernels' launch shape; lines "workgroups threads replicas events" on stdin
 # (workgroups 0 = the default: one per CU, dealt by load)
 cd $GRAFT_REPO_ROOT
+export PISA_HIP_LIB=${PISA_HIP_LIB:-${GRAFT_REPO_ROOT:-$PWD}/pisa_amd/libpisa_hip_dev.so}   # development build: make -C pisa_amd/csrc dev
 while read -r b t c ev; do
   [ -z "$b" ] && continue
   if [ "$b" = 0 ]; then unset PISA_HIP_HIST_BLOCKS; else export PISA_HIP_HIST_BLOCKS=$b; fi

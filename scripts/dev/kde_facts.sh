@@ -1,5 +1,6 @@
 # facts + per-kernel times (one stream) of the C3 estimators for several PISA_HIP_KDE_HERMITE_MIN
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+export PISA_HIP_LIB=${PISA_HIP_LIB:-${GRAFT_REPO_ROOT:-$PWD}/pisa_amd/libpisa_hip_dev.so}   # development build: make -C pisa_amd/csrc dev
 mkdir -p gpurun_out/kf
 for hm in ${HM_LIST:-24 8 2 1}; do
   export PISA_HIP_KDE_HERMITE_MIN=$hm

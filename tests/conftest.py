@@ -40,3 +40,20 @@ def has_gpu():
 # reference's own prob3 tolerance (numba_osc_tests.py:82: AC_KW)
 PROB3_RTOL = 1e-10
 PROB3_ATOL = 1e-14
+
+
+DEV_LIB = os.path.join(ROOT, "pisa_amd", "libpisa_hip_dev.so")
+
+
+def run_dev_case(case, *args, timeout=900):
+    """one case of tests/dev_cases.py in a process of its own, on the development build of the library
+    (-DPISA_DEV_PROBES): the product library has no run-time switches"""
+    import subprocess
+
+    if not os.path.exists(DEV_LIB):
+        subprocess.check_call(["make", "-s", "-j4", "-C", os.path.join(ROOT, "pisa_amd", "csrc"), "dev"])
+    env = dict(os.environ, PISA_HIP_LIB=DEV_LIB, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    res = subprocess.run([sys.executable, "-m", "tests.dev_cases", case] + [str(a) for a in args], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=timeout)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    return res.stdout

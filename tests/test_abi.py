@@ -124,3 +124,28 @@ def test_every_struct_of_the_header_has_the_layout_of_its_binding(built, tmp_pat
         assert got[cname]["sizeof"] == ctypes.sizeof(cls), cname
         for fname, _ in cls._fields_:
             assert got[cname][fname] == getattr(cls, fname).offset, (cname, fname)
+
+
+def test_product_library_has_no_environment_switches(built):
+    """The product library reads no environment variable of its own and has no switch that makes a kernel do
+    less work (round-3 verdict): the names of the development probes reach the binary only in the
+    -DPISA_DEV_PROBES build (libpisa_hip_dev.so).  Checked on the bytes of the shipped file: no string that
+    IS an environment-variable name of ours, and none of the names the sources hand to PISA_DEV_INT/_LL/_STR.
+    (Python-level options that remain and are documented: PISA_HIP_LIB, PISA_HIP_DIRECT_RCCL.)"""
+    import glob
+    import re
+
+    from pisa_amd import _lib
+
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert not re.search(rb"(?<![A-Za-z0-9_ (*])PISA_HIP_[A-Z0-9_]+\x00", blob)
+    names = set()
+    src = os.path.join(ROOT, "pisa_amd", "csrc")
+    for path in glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.hpp")):
+        text = open(path).read()
+        names.update(re.findall(r'PISA_DEV_(?:INT|LL|STR)\("([A-Z0-9_]+)"', text))
+        if not path.endswith("common.hpp"):
+            assert "getenv" not in text, path
+    assert len(names) >= 15
+    for n in names:
+        assert ("PISA_HIP_" + n).encode() not in blob, n

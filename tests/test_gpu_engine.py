@@ -666,35 +666,13 @@ def test_one_pass_flux_refresh_is_the_two_pass_refresh(index16):
 
 
 @pytest.mark.parametrize("n_events", [13, 4099, 250_007])
-def test_accumulate_launch_shape_does_not_change_a_bit(n_events, monkeypatch):
+def test_accumulate_launch_shape_does_not_change_a_bit(n_events):
     """The accumulate kernels' workgroups are dealt to the containers by load (one per CU by default,
     `plan_blocks_balanced`); the integer accumulation makes maps and metric independent of the number of workgroups
     and of how they are dealt: a single workgroup, fewer workgroups than containers, the default, many more than CUs
     and other workgroup sizes give the same bits -- for the 16-bit index form, the compact form, the reference-order
-    form and the coordinate form."""
-    from pisa_amd import synthetic
+    form and the coordinate form.  The launch shape can be chosen in the development build of the library only
+    (tests/dev_cases.py `launch_shape` on libpisa_hip_dev.so)."""
+    from tests.conftest import run_dev_case
 
-    wl = synthetic.Workload(n_events=n_events, grid=(40, 30), out_binning="dragon", seed=11)
-    p = wl.osc_params(theta23_deg=44.0)
-    for kw in (dict(compact=True), dict(compact=True, index16=False), dict(compact=False), dict(indexed=False)):
-        ref = None
-        for blocks, threads in ((None, None), (1, None), (5, None), (64, None), (1500, None), (None, 256), (300, 512)):
-            if blocks is None:
-                monkeypatch.delenv("PISA_HIP_HIST_BLOCKS", raising=False)
-            else:
-                monkeypatch.setenv("PISA_HIP_HIST_BLOCKS", str(blocks))
-            if threads is None:
-                monkeypatch.delenv("PISA_HIP_HIST_THREADS", raising=False)
-            else:
-                monkeypatch.setenv("PISA_HIP_HIST_THREADS", str(threads))
-            st = synthetic.DeviceState(wl, **kw)
-            st.make_pseudo_data(wl.osc_params(), seed=0)
-            llh = float(st.eval(p, "llh").item())
-            st.check_status()
-            h, s2 = st.finalize()
-            got = (h.cpu().numpy().copy(), s2.cpu().numpy().copy(), llh)
-            if ref is None:
-                ref = got
-                assert ref[0].sum() > 0
-            else:
-                assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and got[2] == ref[2], (kw, blocks, threads)
+    run_dev_case("launch_shape", n_events)

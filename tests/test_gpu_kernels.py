@@ -104,22 +104,24 @@ def test_prob3_grid_golden_and_oracle(K, L, oracle):
             np.testing.assert_allclose(nubar, g[name + "::prob_nubar"], err_msg=name, **AC)
 
 
-@pytest.mark.parametrize("fused_amp", ["1", "0", "split"])
-def test_prob3_grid_planned(K, L, fused_amp, monkeypatch):
-    """both variants of the planned form (layer matrices formed inside the chain kernel from the
-    per-density records / stored by stage AB and read back);
-    planned grid form (terms hoisted per (E, density), mirrored layers share one
-    matrix, chain multiplied in parts) == direct grid kernel to rounding (the
+@pytest.mark.parametrize("fused_amp", ["0", "split"])
+def test_prob3_grid_planned_development_forms(fused_amp):
+    """the two other forms of the planned kernels (layer matrices stored by stage AB and read back; one
+    row per workgroup) exist in the development build only: tests/dev_cases.py on libpisa_hip_dev.so"""
+    from tests.conftest import run_dev_case
+
+    run_dev_case("planned_variant", fused_amp)
+
+
+def test_prob3_grid_planned(K, L):
+    """planned grid form (terms hoisted per (E, density), mirrored layers share one
+    matrix, layer matrices formed inside the chain kernel from the per-density records, rows packed by
+    length into 4-wave workgroups, chain multiplied in parts) == direct grid kernel to rounding (the
     product is associated differently), == reference goldens within the prob3
     tolerance; the compact (P_e, P_mu) gather tables are exact copies of P"""
     g = load_golden("prob3_grid_prem12.npz")
     e, dens, dist = K.to_device(g["energy"]), K.to_device(g["densities"]), K.to_device(g["distances"])
     n_e, n_cz = len(g["energy"]), g["densities"].shape[0]
-    # variant of the planned form, read when the plan is created: "1" layer matrices formed in the
-    # chain kernel, rows packed by length into 4-wave workgroups (default); "split" the same with
-    # one row per workgroup; "0" layer matrices stored by stage AB and read back
-    monkeypatch.setenv("PISA_HIP_PROB3_FUSED_AMP", "0" if fused_amp == "0" else "1")
-    monkeypatch.setenv("PISA_HIP_CHAIN_MODE", "split" if fused_amp == "split" else "packed")
     plan = K.GridPlan(dens, dist)
     # "io": the vacuum ordering of the eigenvalues (resolved on the host in this form) differs
     for name in ("no", "io", "nsi", "decay"):
