@@ -75,7 +75,10 @@ def _linearisation_ratio(c, **kde):
                    "estimator (weighted full-covariance Gaussian kernel, lambda_i = (pilot_i / geometric mean)^-alpha) "
                    "leaves 9.8 % between the totals of the linearised and the non-linearised map where the reference's "
                    "test allows 5 % -- the un-vendored `kde` package evidently adapts its bandwidths more strongly than "
-                   "this textbook form (the invariant holds here from alpha ~ 0.25 on, next test)")
+                   "this textbook form (the invariant holds here from alpha ~ 0.26 on, next test).  oracle/kde_variants.py "
+                   "(tests/test_oracle.py::test_kde_criterion_diagnosis_table) evaluates the criterion for 19 variants of "
+                   "the estimator on the reference's exact set-up: all weights are equal there, and no structural variant "
+                   "meets the 5 % at alpha = 0.1 -- nothing singles out a form to adopt")
 def test_linearisation_changes_the_total_by_less_than_5_percent_reference_criterion():
     """pisa_tests/test_kde_stage.py:136-153, verbatim criterion, the stage's defaults"""
     a, b = _linearisation_ratio(_configs())

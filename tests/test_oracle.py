@@ -340,3 +340,20 @@ def test_kde_oracle_fixed_bandwidth_equals_scipy(oracle, dim, bw):
     want_w = stats.gaussian_kde(x, bw_method=factor, weights=w)(q)
     got_w = kde_oracle.gaussian_kde_eval(x, w, q, bw, False, 0.0)
     np.testing.assert_allclose(got_w, want_w, rtol=1e-11, atol=1e-300)
+
+
+def test_kde_criterion_diagnosis_table():
+    """oracle/kde_variants.py: the reference's 5 % linearisation criterion (pisa_tests/test_kde_stage.py:136-153)
+    on its own set-up for every variant the adaptive estimator can differ by.  With all weights equal none of the
+    structural variants meets it at the stage's alpha = 0.1 (this build's textbook form: 9.8 %); only a stronger
+    adaptation does (alpha >= 0.26) -- no family is singled out, the KDE core stays parity-unpinned."""
+    from oracle import kde_variants as kv
+
+    rows = {name: (r, ok) for name, r, _, _, ok in kv.table()}
+    base = [v for k, v in rows.items() if k.startswith("this build")][0]
+    assert abs(base[0] + 0.0977) < 5e-4 and not base[1]
+    for name, (r, ok) in rows.items():
+        if name.startswith("alpha = 0.26") or name.startswith("alpha = 0.3") or name.startswith("alpha = 0.5"):
+            assert ok, name
+        else:
+            assert not ok, name
