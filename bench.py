@@ -43,7 +43,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB
 FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 L3_BYTES = 256 * 2 ** 20
 ALL_LEGS = ("multi_point", "fit_c4_engine", "fit_c4", "osc_example_c1", "l3_exceeding", "exact_association", "coordinate_form", "fine_binning",
-            "update_flux", "node_flux", "pipeline_boundary", "icecube3y_boundary", "events_c2", "events_c5", "kde_c3")
+            "update_flux", "node_flux", "pipeline_boundary", "icecube3y_boundary", "events_c2", "events_c5", "events_c5_full", "kde_c3")
 # the legs that also run with N > 1 (every rank takes part: configs C4 and C5, the multi-point sweep)
 DIST_LEGS = ("multi_point", "fit_c4_engine", "fit_c4", "events_c5")
 
@@ -690,15 +690,18 @@ def leg_icecube3y(torch, n_events, steps):
             os.environ["PISA_RESOURCES"] = old
 
 
-def leg_events(synthetic, torch, n_events, steps, nsi, rank=0, world=1, share=None, sync=None, reduce_max=None):
+def leg_events(synthetic, torch, n_events, steps, nsi, rank=0, world=1, share=None, sync=None, reduce_max=None,
+               on_device=False):
     """configs C2 / C5 (per-GPU share): prob3 EVENT BY EVENT (layers rebuilt per event in-kernel from the
     PREM table in LDS) + fused reweight + 10x10 histogram + LLH.  N > 1 (C5: 1e8 events on 8 GPUs): every
     rank holds `n_events` events of its own (seed = rank), the limbs are all-reduced over the ranks
     (`share` = an engine whose communicator is reused), every rank evaluates the same LLH."""
     import numpy as np
 
-    wl = synthetic.Workload(n_events=int(n_events), grid=(10, 10), out_binning="example2d", seed=rank)
+    wl = synthetic.Workload(n_events=int(n_events), grid=(10, 10), out_binning="example2d", seed=rank,
+                            on_device=on_device)
     st = synthetic.DeviceState(wl, osc_mode="events", compact=True)
+    device_bytes = torch.cuda.memory_allocated()
     if world > 1 or share is not None:
         st.world_size = share.world_size
         st.group, st._rccl = share.group, share._rccl
@@ -734,6 +737,9 @@ def leg_events(synthetic, torch, n_events, steps, nsi, rank=0, world=1, share=No
     out = {"events": wl.n_events * world, "events_per_gpu": wl.n_events, "evals_per_s": 1.0 / dt,
            "ms_per_step": dt * 1e3, "event_evals_per_s": wl.n_events * world / dt,
            "prob3_events_kernel_ms": t_osc * 1e3, "last_llh": llh,
+           "device_bytes_allocated": device_bytes,
+           "algorithmic_resident_bytes_per_event": 16 + 16 + 24,   # (E, coszen) + (P_e, P_mu) pair + 24 B index / folded flux
+           "events_generated": "in HBM (torch generator)" if on_device else "on the host (numpy RandomState)",
            "workload": "%d events%s, prob3 event by event (PREM-12%s) + fused reweight + 10x10 hist + LLH"
                        % (wl.n_events * world, (" on %d GPUs (%d each, limbs all-reduced)" % (world, wl.n_events))
                           if world > 1 else "", ", std NSI" if nsi else "")}
@@ -1243,6 +1249,9 @@ def main(argv=None, hooks=None):
             elif name == "events_c5":
                 legs[name] = leg_events(synthetic, torch, 1.25e7, 6, nsi=True, rank=rank, world=world,
                                         share=st if dist_on else None, sync=barrier, reduce_max=max_over_ranks)
+            elif name == "events_c5_full":
+                # C5 at the size BASELINE.json states, on ONE device: 1e8 std-NSI events, generated in HBM
+                legs[name] = leg_events(synthetic, torch, 1e8, 3, nsi=True, on_device=True)
             elif name == "kde_c3":
                 legs[name] = leg_kde(torch, args.events, 16)
             else:

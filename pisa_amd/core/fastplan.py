@@ -231,8 +231,7 @@ class FastPlan:
         if not self.engine.node_flux:
             fl = [s for s in stages[:k_osc] if s.stage_name == "flux"]
             if (len(fl) == 1 and fl[0].service_name == "barr_simple" and fl[0].calc_mode == "events"
-                    and all(w is not None for w in self.engine._wflux)
-                    and not bool(int(os.environ.get("PISA_PLAN_NO_BARR", "0")))):
+                    and all(w is not None for w in self.engine._wflux)):
                 self.barr_stage = fl[0]
         # one flat list of (param, index of its stage); a parameter shared by stages appears once
         # per stage, so every stage that uses it is seen to change

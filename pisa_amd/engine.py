@@ -254,7 +254,7 @@ class HotPathEngine:
             self._node_flux_t = []
             self._flux_tab_args = None
         self.osc_events = osc_mode == "events"
-        self._event_sets = []
+        self._event_sets, self._event_tables = [], []
         if self.osc_events:
             indexed = packed = True
             external_tables = True
@@ -277,20 +277,30 @@ class HotPathEngine:
         import os
         # 16-bit index form of the compact columns (20 B/event) where it applies: grid mode, calc
         # grid below 65535 nodes, output binning below 65535 bins
-        index16 = (bool(index16) and bool(int(os.environ.get("PISA_IDX16", "1"))) and self.compact
+        index16 = (bool(index16) and self.compact
                    and packed and indexed and not self.osc_events and grid.size < 0xFFFF
                    and self.n_bins < 0xFFFF)
         self.index16 = index16
         self.n_local = 0
         shards = local_slices([len(c["true_energy"]) for c in containers], rank, world_size)
+
+        def column(x, sl):
+            """this rank's slice of an event column -- host array or device tensor (a workload generated in
+            HBM: 1e8-event samples never exist on the host) -- as an fp64 device tensor of its own"""
+            if torch.is_tensor(x):
+                return x[sl].to(self.dev, torch.float64).clone()
+            return K.to_device(np.asarray(x, dtype=np.float64)[sl])
+
         for c, (lo, hi) in zip(containers, shards):
             sl = slice(lo, hi)
             self._slices.append((lo, hi))
             d = _lib.Container()
             d.n_events = hi - lo
             self.n_local += hi - lo
-            lnE = K.to_device(np.log(np.asarray(c["true_energy"], dtype=np.float64)[sl]))
-            cz = K.to_device(np.asarray(c["true_coszen"], dtype=np.float64)[sl])
+            e_col = column(c["true_energy"], sl)
+            lnE = torch.log(e_col) if torch.is_tensor(c["true_energy"]) else \
+                K.to_device(np.log(np.asarray(c["true_energy"], dtype=np.float64)[sl]))
+            cz = column(c["true_coszen"], sl)
             gx, gy = (lnE, cz) if grid.energy_first else (cz, lnE)
             if self.node_flux:
                 fn = c["nu_flux_nodes"]
@@ -300,10 +310,10 @@ class HotPathEngine:
                 d.d_pepmu = self._own_tables[len(self.cont)].data_ptr()
                 flux_d = torch.ones((hi - lo, 2), dtype=torch.float64, device=self.dev)
             else:
-                flux_d = K.to_device(np.asarray(c["nu_flux"], dtype=np.float64)[sl])
-            aeff_d = K.to_device(np.asarray(c["weighted_aeff"])[sl])
-            w0_d = K.to_device(np.asarray(c["initial_weights"])[sl])
-            cols = [K.to_device(np.asarray(col)[sl]) for col in c["sample"]]
+                flux_d = column(c["nu_flux"], sl)
+            aeff_d = column(c["weighted_aeff"], sl)
+            w0_d = column(c["initial_weights"], sl)
+            cols = [column(col, sl) for col in c["sample"]]
             node = obin = perm = None
             static_w = wflux = None
             if self.osc_events:
@@ -311,7 +321,7 @@ class HotPathEngine:
                 # is stored sorted by coszen so that the lanes of a wavefront cross the
                 # same number of Earth layers (3.4x faster than random order: no
                 # divergence in the layer loop)
-                e_true = K.to_device(np.asarray(c["true_energy"], dtype=np.float64)[sl])
+                e_true = e_col
                 obin = K.event_indices(cols, out_binning)
                 if sort_events and hi - lo > 1:
                     perm = torch.argsort(cz, stable=True)
@@ -326,6 +336,7 @@ class HotPathEngine:
                 es.d_probability, es.d_pepmu = None, own.data_ptr()
                 es.nubar, es.flav = int(c["nubar"]), int(c["flav"])
                 self._event_sets.append(es)
+                self._event_tables.append((e_true, cz, own))   # resident (coszen-sorted) order
                 self._keep += [e_true, cz, own]
                 d.d_pepmu = own.data_ptr()
             elif indexed:
@@ -342,19 +353,16 @@ class HotPathEngine:
                         perm = bin_window_order(obin, self.n_bins)
                     elif sort_events == "part":
                         perm = bin_partition_order(obin, node, self.n_bins,
-                                                   width=int(os.environ.get("PISA_BIN_PARTITION", 672)))
+                                                   width=672)
                     else:
                         perm = torch.argsort(node, stable=True)
                 blocked = (index16 and lds_order and block_order and perm is not None and sort_events == "node"
-                           and self.n_bins * 96 <= 65536 and bool(int(os.environ.get("PISA_BLOCK_ORDER", "1"))))
+                           and self.n_bins * 96 <= 65536)
                 if blocked:
-                    perm = deposit_block_order(obin, node, window=int(os.environ.get("PISA_LDS_WINDOW", 4096)),
-                                               banks=int(os.environ.get("PISA_LDS_BANKS", 32)))
+                    perm = deposit_block_order(obin, node, window=4096, banks=32)
                 elif lds_order and perm is not None and (sort_events == "part" or (
                         sort_events != "bin" and self.n_bins * 96 <= 65536)):
-                    import os  # development overrides (scripts/dev)
-                    perm = perm[lds_bank_order(obin[perm], window=int(os.environ.get("PISA_LDS_WINDOW", 4096)),
-                                               banks=int(os.environ.get("PISA_LDS_BANKS", 32)),
+                    perm = perm[lds_bank_order(obin[perm], window=4096, banks=32,
                                                per=4 if index16 else 2)]
                 if drop_unbinned:
                     # an event outside the output binning (or outside the calc grid: P = 0)

@@ -85,12 +85,46 @@ def make_events(n_per, seed=0, names=NAMES):
     return out
 
 
+def make_events_device(n_per, seed=0, names=NAMES, device=None):
+    """`make_events` with the columns generated IN HBM (torch generator on the device, one seed per
+    container): the same distributions, not the same numbers.  For samples that should never exist on the
+    host -- config C5 at its full size is 1e8 events, ~10 GB of host columns and a minute of numpy otherwise."""
+    import torch
+
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    out = []
+    for k, name in enumerate(names):
+        flav, nubar = flav_nubar(name)
+        g = torch.Generator(device=device)
+        g.manual_seed(1_000_003 * int(seed) + k)
+
+        def rand():
+            return torch.rand(n_per, generator=g, device=device, dtype=torch.float64)
+
+        def randn():
+            return torch.randn(n_per, generator=g, device=device, dtype=torch.float64)
+
+        e = torch.pow(10.0, rand() * 3)
+        cz = rand() * 2 - 1
+        reco_e = e * torch.exp(randn() * 0.2)
+        reco_cz = torch.clamp(cz + randn() * 0.15, -1, 1)
+        pid = (rand() < 0.3).to(torch.float64)
+        w0 = rand()
+        flux_mu = 1e4 * e ** -2.7 * (1 + 0.5 * cz ** 2)
+        flux = torch.stack([flux_mu * (0.5 - 0.2 * cz), flux_mu], dim=1)
+        aeff = 1e-9 * e ** 1.5 * (0.5 + rand())
+        out.append(dict(name=name, flav=flav, nubar=nubar, true_energy=e, true_coszen=cz,
+                        reco_energy=reco_e, reco_coszen=reco_cz, pid=pid, nu_flux=flux,
+                        weighted_aeff=aeff, initial_weights=w0))
+    return out
+
+
 class Workload:
     """Host-side description of one synthetic pipeline (inputs only)."""
 
     def __init__(self, n_events=1200000, grid=(200, 100), out_binning="dragon", seed=0,
                  earth_model="osc/PREM_12layer.dat", detector_depth=2.0, prop_height=20.0,
-                 ye=(0.4656, 0.4656, 0.4957)):
+                 ye=(0.4656, 0.4656, 0.4957), on_device=False):
         self.n_per = int(n_events) // len(NAMES)
         self.n_events = self.n_per * len(NAMES)
         self.grid = GridSpec((1.0, 1000.0), grid[0], (-1.0, 1.0), grid[1], energy_first=True)
@@ -99,10 +133,16 @@ class Workload:
         self.n_bins = int(np.prod(self.ob["nbins"]))
         self.layers = Layers(earth_model, detector_depth, prop_height)
         self.layers.setElecFrac(*ye)  # (YeI, YeO, YeM)
-        self.events = make_events(self.n_per, seed)
+        self.on_device = bool(on_device)
+        self.events = make_events_device(self.n_per, seed) if on_device else make_events(self.n_per, seed)
         cols = ("reco_energy", "reco_coszen", "pid")[: len(self.ob["nbins"])]
         for ev in self.events:
-            ev["sample"] = [np.log(ev[c]) if lg else ev[c] for c, lg in zip(cols, self.ob["log"])]
+            if on_device:
+                import torch
+
+                ev["sample"] = [torch.log(ev[c]) if lg else ev[c] for c, lg in zip(cols, self.ob["log"])]
+            else:
+                ev["sample"] = [np.log(ev[c]) if lg else ev[c] for c, lg in zip(cols, self.ob["log"])]
             ev["scale"] = aeff_scale_for(ev["name"])
 
     def osc_params(self, theta23_deg=42.0, dm31=2.457e-3, theta12_deg=33.48, theta13_deg=8.5,

@@ -320,3 +320,83 @@ def test_event_mode_workloads_against_the_oracle(oracle, nsi):
         got = K.prob3_events(p, wl.layers.earth_struct(), ev["nubar"], K.to_device(ev["true_energy"]),
                              K.to_device(ev["true_coszen"])).cpu().numpy()
         np.testing.assert_allclose(got, want_p, rtol=1e-10, atol=1e-14)
+
+
+def test_c5_at_its_full_size_on_one_gpu(oracle):
+    """Config C5 at the size BASELINE.json states -- 1e8 events, std-NSI prob3 EVENT BY EVENT
+    (pisa/stages/osc/prob3.py:406-409: the layers of every event's own coszen), one MI355X.  The sample is
+    generated in HBM (`Workload(on_device=True)`); checked:
+      * status flags clean, every deposited digit accounted for (histogram totals > 0 in every container);
+      * the int64 limbs of EIGHT contiguous shards (what eight ranks would hold, `local_slices`) summed as
+        integers == the limbs of the unsharded run, bit for bit -- the all-reduce of an 8-GPU run in one process;
+      * (P_e->f, P_mu->f) of a random 1e6-event subset, taken out of the FULL run's resident tables, against
+        `oracle.propagate_array` on the oracle's own per-event layers, at the reference's tolerance
+        (numba_osc_tests.py:82);
+      * rows / columns of P sum to one on a second subset through the [n,3,3] entry point at offset > 2^31 bytes."""
+    from pisa_amd import kernels as K
+    from pisa_amd import synthetic
+    from pisa_amd.stages.osc.nsi_params import StdNSIParams
+
+    n_events = 100_000_000
+    wl = synthetic.Workload(n_events=n_events, grid=(10, 10), out_binning="example2d", seed=5, on_device=True)
+    assert wl.n_events == 12 * (n_events // 12)
+    n = StdNSIParams()
+    n.eps_emu, n.eps_etau, n.eps_mutau = (0.07, np.deg2rad(340)), (0.06, np.deg2rad(35)), (0.003, np.deg2rad(175))
+    mat_pot = np.diag([1.0, 0, 0]).astype(complex) + n.eps_matrix
+    p = wl.osc_params(theta23_deg=47.5, dm31=2.6e-3, mat_pot=mat_pot)
+    m = dict(wl.last_matrices)
+    full = synthetic.DeviceState(wl, osc_mode="events", compact=True)
+    assert full.n_local == wl.n_events
+    full.accumulate(p)
+    full.check_status()
+    limbs_full = full.ws.limbs.clone()
+    h_full, s2_full = (t.clone() for t in full.finalize())
+    assert float(h_full.sum(dim=1).min()) > 0
+    # -- probabilities of a random subset of the full run's tables against the oracle
+    lay = oracle.Layers(wl.layers.prem, wl.layers.detector_depth, wl.layers.prop_height)
+    lay.rhos = np.array(wl.layers.rhos)
+    rs = np.random.RandomState(3)
+    per = 1_000_000 // len(wl.events)
+    for ev, (e_res, cz_res, own) in zip(wl.events, full._event_tables):
+        idx = torch.from_numpy(np.sort(rs.choice(wl.n_per, per, replace=False))).to(own.device)
+        e_h, cz_h, got = e_res[idx].cpu().numpy(), cz_res[idx].cpu().numpy(), own[idx].cpu().numpy()
+        lay.calcLayers(cz_h)
+        want = oracle.propagate_array(m["dm"], m["mix"], m["mat_pot"], m["decay_flag"], m["mat_decay"], m["lri_pot"],
+                                      ev["nubar"], e_h, lay.density, lay.distance)
+        np.testing.assert_allclose(got[:, 0], want[:, 0, ev["flav"]], rtol=1e-10, atol=1e-14)
+        np.testing.assert_allclose(got[:, 1], want[:, 1, ev["flav"]], rtol=1e-10, atol=1e-14)
+    # -- the 3x3 entry point on one whole container (8.3e6 x 72 B = 600 MB) and beyond 2^31 bytes of output:
+    #    four containers' worth of events in one call (2.4 GB of probabilities)
+    e_cat = torch.cat([t[0] for t in full._event_tables[:4]])
+    cz_cat = torch.cat([t[1] for t in full._event_tables[:4]])
+    P = K.prob3_events(p, wl.layers.earth_struct(), 1, e_cat, cz_cat)
+    assert P.numel() * 8 > 2 ** 31
+    assert float((P.sum(dim=2) - 1.0).abs().max()) < 2e-12 and float((P.sum(dim=1) - 1.0).abs().max()) < 2e-12
+    tail = P[-1000:].clone()
+    del P
+    P_tail = K.prob3_events(p, wl.layers.earth_struct(), 1, e_cat[-1000:].contiguous(), cz_cat[-1000:].contiguous())
+    assert torch.equal(tail, P_tail)      # the last events of the long launch == the same events alone
+    del e_cat, cz_cat, P_tail
+    resident = torch.cuda.memory_allocated()
+    del full
+    torch.cuda.empty_cache()
+    # -- eight contiguous shards, limbs summed as integers
+    total = torch.zeros_like(limbs_full)
+    seen = 0
+    for r in range(8):
+        st = synthetic.DeviceState(wl, rank=r, world_size=8, osc_mode="events", compact=True)
+        seen += st.n_local
+        st.accumulate(p)
+        st.check_status()
+        total += st.ws.limbs
+        del st
+        torch.cuda.empty_cache()
+    assert seen == wl.n_events
+    assert torch.equal(total, limbs_full)
+    one = synthetic.DeviceState(synthetic.Workload(n_events=1200, grid=(10, 10), out_binning="example2d", seed=1),
+                                osc_mode="events", compact=True)
+    one.ws.limbs.copy_(total)
+    one._limbs_zero = one._maps_valid = False
+    h8, s28 = one.finalize()
+    assert torch.equal(h8, h_full) and torch.equal(s28, s2_full)
+    print("C5 full size: %d events, %.1f GB allocated on the device during the unsharded run" % (wl.n_events, resident / 1e9))
