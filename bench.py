@@ -183,6 +183,41 @@ def physical_cores():
     return max(1, len(firsts)), len(avail)
 
 
+def sockets_of_team(n_threads):
+    """physical packages the first `n_threads` places of OMP_PLACES=cores / OMP_PROC_BIND=close fall on
+    (places are the cores of the affinity mask in ascending order)"""
+    firsts = {}
+    for cpu in sorted(os.sched_getaffinity(0)):
+        try:
+            base = "/sys/devices/system/cpu/cpu%d/topology/" % cpu
+            with open(base + "thread_siblings_list") as fh:
+                first = int(fh.read().strip().replace("-", ",").split(",")[0])
+            with open(base + "physical_package_id") as fh:
+                firsts.setdefault(first, int(fh.read().strip()))
+        except (OSError, ValueError):
+            firsts.setdefault(cpu, 0)
+    pk = [firsts[c] for c in sorted(firsts)][: max(1, n_threads)]
+    return sorted(set(pk))
+
+
+def llh_gate(data, lam, device_llh, oracle_llh):
+    """which gate the device LLH meets against the oracle's: the north star's pure 1e-10 relative one, or only
+    the rounding floor of the reference's formula  llh = sum_b k ln(lam) - lam - (k ln k - k)  (stats.py:169-253),
+    a difference of terms orders of magnitude larger than the total: 8 eps sum_b (|k ln lam| + lam + |k ln k| + k)"""
+    import numpy as np
+
+    k = np.asarray(data, dtype=np.float64).ravel()
+    lam = np.asarray(lam, dtype=np.float64).ravel()
+    with np.errstate(divide="ignore", invalid="ignore"):
+        klk = np.where(k > 0, np.abs(k * np.log(np.where(k > 0, k, 1.0))), 0.0)
+        terms = np.abs(k * np.log(lam)) + lam + klk + k
+    floor = 8 * np.finfo(np.float64).eps * float(terms.sum())
+    diff = abs(device_llh - oracle_llh)
+    pure = diff <= 1e-10 * abs(oracle_llh)
+    return {"abs_diff": diff, "pure_1e-10_relative_met": bool(pure), "term_floor": floor,
+            "applied": "1e-10 relative" if pure else ("term floor (8 eps sum |terms|)" if diff <= floor else "NONE MET")}
+
+
 def cpu_baseline_subprocess(args, n_e, n_cz, data, matrices, device_llh):
     """`cpu_baseline` in a process of its own: its OpenMP team is pinned one thread per core
     (OMP_PLACES=cores, OMP_PROC_BIND=close), which must not reach this process -- the runtime would pin
@@ -282,6 +317,14 @@ def cpu_baseline(wl, data, matrices, device_llh, cores_logical=None):
         t_all, g_all, cores_used = 1.0 / scan[best]["evals_per_s"], scan[best]["grid_s"], int(best)
     else:
         cores_used = cores
+    all_core_rate = scan[str(cores)]["evals_per_s"]
+    collapsed = cores_used != cores and all_core_rate < 0.67 / t_all
+    team_note = ""
+    if cores_used != cores:
+        team_note = ("; the %d-thread team gave %.1f evals/s%s -- the baseline is the best team of the scan, %d threads "
+                     "pinned close = package(s) %s" % (cores, all_core_rate,
+                                                        " (collapsed: the box's other socket is busy or its memory remote)"
+                                                        if collapsed else "", cores_used, sockets_of_team(cores_used)))
     # one thread, stage by stage (what the reference's TARGET='cpu' runs)
     orc.set_num_threads(1)
     oracle_eval(wl, matrices, containers=[])
@@ -303,8 +346,10 @@ def cpu_baseline(wl, data, matrices, device_llh, cores_logical=None):
         "sample": "all %d events and the full %dx%dx2-node prob3 grid, nothing scaled: grid %.4f s + events "
                   "%.4f s per evaluation on %d OpenMP threads pinned to cores (events = one loop per container, "
                   "columns first-touched by the reading thread, per-thread private histograms merged in thread "
-                  "order); best of the thread scan, medians"
-                  % (wl.n_events, wl.grid.n_e, wl.grid.n_cz, g_all, t_all - g_all, cores_used),
+                  "order); best of the thread scan, medians%s"
+                  % (wl.n_events, wl.grid.n_e, wl.grid.n_cz, g_all, t_all - g_all, cores_used, team_note),
+        "sockets_used": sockets_of_team(cores_used),
+        "all_core_team_collapsed": bool(collapsed),
         "thread_scan": scan,
         "single_thread": {
             "value": 1.0 / t_one, "unit": "evals/s", "cores": 1,
@@ -314,6 +359,7 @@ def cpu_baseline(wl, data, matrices, device_llh, cores_logical=None):
         "oracle_llh": oracle_llh,
         "device_llh": device_llh,
         "llh_rel_diff": abs(device_llh - oracle_llh) / abs(oracle_llh) if oracle_llh else None,
+        "llh_gate": llh_gate(data, lam, device_llh, oracle_llh),
     }
 
 
@@ -342,6 +388,23 @@ def pmc_traffic(args):
     if d is None:
         return None, None
     return d.get("hbm_bytes"), "%s/traffic.json (committed rocprofv3 --pmc passes, not this run)" % src
+
+
+def trace_roofline(args, bytes_per_launch):
+    """the dominant kernel's duration by the committed rocprofv3 kernel trace of this very command
+    (profiles/<newest>/kernels_by_phase.json, scripts/profile_round.sh) and the roofline fraction that follows
+    from it -- beside `roofline.frac`, which is this run's HIP-event time (events around one launch add ~3 us)"""
+    if (args.coordinate_form or args.exact_association or args.wide_index or int(args.events) != 10000000
+            or args.binning != "dragon" or args.gpus != 1):
+        return None
+    d, src = latest_profile("kernels_by_phase.json")
+    if d is None or "hist_accumulate_kernel" not in d:
+        return None
+    us = d["hist_accumulate_kernel"]["timed_loop_mean_us"]
+    ach = bytes_per_launch / (us * 1e-6) / 1e9
+    return {"avg_launch_us": us, "achieved": ach, "frac": ach / HBM_PEAK_GBS, "unit": "GB/s",
+            "source": "%s/kernels_by_phase.json + kernel_stats.csv (committed rocprofv3 --kernel-trace --stats of "
+                      "this command, not this run)" % src}
 
 
 def time_fused(st, plist, lib, torch, k=30):
@@ -1351,6 +1414,8 @@ def main(argv=None, hooks=None):
                 "fits_l3": bool(bpe * st.n_local <= L3_BYTES),
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                "timing": "HIP events recorded on the launch stream around the kernel, inside the library",
+                "by_kernel_trace": trace_roofline(args, bpe * st.n_local) if not dist_on else None,
             },
             "legs": legs,
         }
@@ -1359,6 +1424,7 @@ def main(argv=None, hooks=None):
             out["cpu_baseline"] = cb
             # the bench's last headline point against the oracle on identical inputs (north star: <= 1e-10)
             out["oracle_llh"], out["llh_rel_diff"] = cb["oracle_llh"], cb["llh_rel_diff"]
+            out["llh_gate"] = cb["llh_gate"]
         print(json.dumps(out))
         if hooks is not None and "result" in hooks:
             hooks["result"](out)

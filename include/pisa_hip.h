@@ -23,6 +23,7 @@
 #ifndef PISA_HIP_H
 #define PISA_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -393,6 +394,57 @@ int pisa_hip_finalize_metric_split(int64_t *d_limbs, int32_t n_points, int32_t n
                                    int64_t scale_point_stride, const double *d_extra, double *partial,
                                    int32_t *d_status, int32_t *d_metric_status, int32_t clear_limbs,
                                    void *stream);
+
+/* ------------------------------------------------ one template evaluation in ONE call
+ * What `Pipeline.get_outputs()` followed by `Map.metric_total` amount to for the chain
+ * osc.prob3 (calc grid) -> aeff.aeff -> utils.hist -> metric (pisa/core/pipeline.py:537-558 running
+ * stage.py:584-586 per stage; the minimiser's callable pisa/analysis/analysis.py:2493-2670 calls exactly
+ * that per point).  An evaluator is made once per pipeline from everything that does not change between
+ * parameter points (the event columns, the binnings, the grid plan, the output buffers); per point
+ *      pisa_hip_evaluator_eval(ev, params, kind, d_actual, ...)
+ * enqueues  pisa_hip_prob3_grid_planned (gather tables only) -> pisa_hip_reweight_hist[_acc] ->
+ * [all-reduce of the limbs] -> pisa_hip_finalize_metric_split (clear_limbs = 1)  -- the same launches,
+ * the same bits as those four calls -- and, if asked to, waits for the value: the metric's four partial
+ * sums arrive in device-mapped pinned host memory and are joined as pisa_hip_finalize_metric_split
+ * documents.  A host binding crosses its FFI once per evaluation instead of three or four times.
+ * kind = PISA_HIP_METRIC_CHI2 goes through the one-workgroup pisa_hip_finalize_metric.
+ *
+ * allreduce / comm (both NULL on one rank): the in-place int64 SUM of d_limbs over the ranks, called as
+ *      allreduce(d_limbs, d_limbs, count, 4 (ncclInt64), 0 (ncclSum), comm, stream)
+ * -- ncclAllReduce's own signature, so a binding passes RCCL's entry point and its communicator; the
+ * library itself does not link RCCL. */
+typedef struct pisa_hip_evaluator pisa_hip_evaluator;
+typedef int (*pisa_hip_allreduce_fn)(const void *sendbuf, void *recvbuf, size_t count, int datatype,
+                                     int op, void *comm, void *stream);
+typedef struct {
+    const pisa_hip_container *h_containers; /* copied */
+    int32_t n_containers;
+    int32_t n_e;                            /* energies of the calc grid */
+    int32_t e_major;
+    int32_t reserved;
+    const pisa_hip_binning *h_calc_grid;    /* copied */
+    const pisa_hip_binning *h_out_binning;  /* copied */
+    pisa_hip_grid_plan *plan;               /* borrowed: must outlive the evaluator */
+    const double *d_energy;                 /* [n_e] */
+    double *d_pepmu;                        /* [2][3][nodes][2] gather tables (written per point) */
+    int64_t *d_limbs;                       /* [n_containers][n_bins][2][PISA_HIP_ACC_LIMBS] */
+    double *d_hist, *d_sumw2;               /* [n_containers][n_bins] (written per point) */
+    double *partial;                        /* [4] device-mapped pinned host memory */
+    int32_t *d_status, *d_metric_status;
+    pisa_hip_allreduce_fn allreduce;
+    void *comm;
+} pisa_hip_evaluator_desc;
+int pisa_hip_evaluator_create(const pisa_hip_evaluator_desc *desc, pisa_hip_evaluator **out);
+int pisa_hip_evaluator_destroy(pisa_hip_evaluator *ev);
+/* aeff.py:78-86: the scale of one container (aeff_scale * livetime * norms) for the points to come */
+int pisa_hip_evaluator_set_scale(pisa_hip_evaluator *ev, int32_t container, double scale);
+/* limbs_zero != 0: d_limbs holds zeros (left by the previous evaluation's tail): no clearing pass.
+ * wait_us > 0: poll `partial` for up to that many microseconds, then synchronise the stream; *value
+ *   receives the metric.  wait_us == 0: enqueue only; the caller reads `partial` / synchronises itself.
+ * On return with PISA_HIP_OK the limbs are zero again (after the stream has passed the tail). */
+int pisa_hip_evaluator_eval(pisa_hip_evaluator *ev, const pisa_hip_prob3_params *h_params, int32_t kind,
+                            const double *d_actual, int32_t limbs_zero, int64_t wait_us, double *value,
+                            void *stream);
 
 /* --------------------------------------------------------------------- KDE */
 

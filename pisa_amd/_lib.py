@@ -161,6 +161,33 @@ class FluxTable(C.Structure):
     ]
 
 
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+
+
+class EvaluatorDesc(C.Structure):
+    """pisa_hip_evaluator_desc"""
+    _fields_ = [
+        ("h_containers", C.c_void_p),
+        ("n_containers", C.c_int32),
+        ("n_e", C.c_int32),
+        ("e_major", C.c_int32),
+        ("reserved", C.c_int32),
+        ("h_calc_grid", C.c_void_p),
+        ("h_out_binning", C.c_void_p),
+        ("plan", C.c_void_p),
+        ("d_energy", C.c_void_p),
+        ("d_pepmu", C.c_void_p),
+        ("d_limbs", C.c_void_p),
+        ("d_hist", C.c_void_p),
+        ("d_sumw2", C.c_void_p),
+        ("partial", C.c_void_p),
+        ("d_status", C.c_void_p),
+        ("d_metric_status", C.c_void_p),
+        ("allreduce", C.c_void_p),
+        ("comm", C.c_void_p),
+    ]
+
+
 class KdeInfo(C.Structure):
     _fields_ = [
         ("dim", C.c_int32), ("cells", C.c_int32 * 3),
@@ -200,6 +227,11 @@ _SIGS = {
     "pisa_hip_finalize_metric_multi": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "pisa_hip_finalize_metric_split": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "pisa_hip_profile_events": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pisa_hip_evaluator_create": (C.c_int, [C.POINTER(EvaluatorDesc), C.POINTER(C.c_void_p)]),
+    "pisa_hip_evaluator_destroy": (C.c_int, [C.c_void_p]),
+    "pisa_hip_evaluator_set_scale": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
+    "pisa_hip_evaluator_eval": (C.c_int, [C.c_void_p, C.POINTER(Prob3Params), C.c_int32, C.c_void_p, C.c_int32, C.c_int64,
+                                          C.POINTER(C.c_double), C.c_void_p]),
     "pisa_hip_apply_osc_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "pisa_hip_apply_osc_weights_strided": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "pisa_hip_apply_aeff": (C.c_int, [C.c_void_p, C.c_double, C.c_int64, C.c_void_p, C.c_void_p]),

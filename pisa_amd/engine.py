@@ -451,6 +451,8 @@ class HotPathEngine:
         self.fused_tail = True
         self._limbs_zero = self._maps_valid = False
         self._lean = None
+        self._evaluator = None     # pisa_hip_evaluator of the standard shape (`_evaluator_for`)
+        self.one_call = True       # eval_host through it; False: the three separate C-ABI calls (tests compare both)
         self.data = None
         self._data_src = None
         self._out_block = None   # weak reference to the device-backed maps handed out last
@@ -608,6 +610,65 @@ class HotPathEngine:
         i = self.names.index(name)
         self.cont[i].scale = float(scale)
         self._cont_arr[i].scale = float(scale)
+        ev = self._evaluator
+        if ev is not None:
+            _lib.check(_lib.lib().pisa_hip_evaluator_set_scale(ev["handle"], i, float(scale)))
+
+    # -- one evaluation per C-ABI call (`pisa_hip_evaluator_*`) --------------
+    def _evaluator_for(self):
+        """the evaluator of this engine's standard shape (planned grid oscillation, indexed columns, fused
+        tail, the value polled from pinned memory), made at the first use and again when one of the
+        buffers it was made from has been replaced; None where the shape does not apply (flux on the
+        grid nodes: a launch of its own between prob3 and the accumulation; several ranks without the
+        direct RCCL communicator: the all-reduce is torch.distributed's)"""
+        import ctypes as C
+
+        if self.node_flux or not self.spin_wait:
+            return None
+        fn = comm = None
+        if self.world_size > 1:
+            if self._rccl is None:
+                self.allreduce_setup()
+            if not self._rccl:
+                return None
+            fn = C.cast(self._rccl.lib.ncclAllReduce, C.c_void_p)
+            comm = self._rccl.comm
+        key = (self.pepmu.data_ptr(), self.ws.limbs.data_ptr(), self.ws.hist.data_ptr(), self.plan.handle.value
+               if hasattr(self.plan.handle, "value") else self.plan.handle, self.energy_d.data_ptr(),
+               None if comm is None else comm.value, self.world_size)
+        ev = self._evaluator
+        if ev is not None and ev["key"] == key:
+            return ev
+        if ev is not None:
+            _lib.lib().pisa_hip_evaluator_destroy(ev["handle"])
+            self._evaluator = None
+        d = _lib.EvaluatorDesc()
+        d.h_containers = C.cast(self._cont_arr, C.c_void_p)
+        d.n_containers, d.n_e, d.e_major = len(self._cont_arr), self.energy_d.numel(), 1 if self.grid.energy_first else 0
+        d.h_calc_grid = C.cast(C.pointer(self.grid.binning), C.c_void_p)
+        d.h_out_binning = C.cast(C.pointer(self.out_binning), C.c_void_p)
+        d.plan = self.plan.handle
+        d.d_energy, d.d_pepmu = self.energy_d.data_ptr(), self.pepmu.data_ptr()
+        d.d_limbs, d.d_hist, d.d_sumw2 = self.ws.limbs.data_ptr(), self.ws.hist.data_ptr(), self.ws.sumw2.data_ptr()
+        d.partial = self.metric_host.data_ptr()
+        d.d_status, d.d_metric_status = self.ws.status.data_ptr(), self.metric_status.data_ptr()
+        d.allreduce, d.comm = fn, comm
+        h = C.c_void_p()
+        _lib.check(_lib.lib().pisa_hip_evaluator_create(C.byref(d), C.byref(h)))
+        value = C.c_double()
+        ev = self._evaluator = dict(key=key, handle=h, value=value, value_ref=C.byref(value),
+                                    call=_lib.lib().pisa_hip_evaluator_eval, keep=(fn, comm))
+        return ev
+
+    def _eval_one_call(self, ev, params, kind):
+        """prob3 -> accumulate -> [all-reduce] -> tail, enqueued AND awaited inside one C-ABI call"""
+        self._release_outputs()
+        rc = ev["call"](ev["handle"], params, K.METRIC_KIND[kind], self.data.data_ptr(), 1 if self._limbs_zero else 0,
+                        20000, ev["value_ref"], K._stream())
+        self._limbs_zero = self._maps_valid = rc == 0
+        if rc:
+            _lib.check(rc)
+        return ev["value"].value
 
     # -- per-eval steps ----------------------------------------------------
     def compute_probs(self, params):
@@ -665,8 +726,20 @@ class HotPathEngine:
         if int(os.environ.get("PISA_HIP_DIRECT_RCCL", "1")):
             self._rccl = rccl.LimbAllReduce.create(self.dev, self.group) or False
 
+    def __del__(self):
+        ev = getattr(self, "_evaluator", None)
+        if ev is not None:
+            try:
+                _lib.lib().pisa_hip_evaluator_destroy(ev["handle"])
+            except Exception:  # interpreter shutdown
+                pass
+            self._evaluator = None
+
     def close(self):
         """release the direct RCCL communicator (before the process group is destroyed)"""
+        if self._evaluator is not None:
+            _lib.lib().pisa_hip_evaluator_destroy(self._evaluator["handle"])
+            self._evaluator = None
         if self._rccl:
             self._rccl.destroy()
         self._rccl = None
@@ -847,6 +920,9 @@ class HotPathEngine:
                 and self.data is not None
                 and len(self.cont) * self.n_bins <= K.FINALIZE_METRIC_MAX):
             if self.spin_wait:
+                ev = self._evaluator_for() if self.one_call else None
+                if ev is not None:
+                    return self._eval_one_call(ev, params, kind)
                 # The tail kernel's store into pinned host memory is visible a few us before the
                 # stream-completion signal has travelled through the runtime: poll it.  NaN is
                 # the "not yet" marker (a genuine NaN result falls through to the stream sync).

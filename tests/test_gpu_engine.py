@@ -676,3 +676,49 @@ def test_accumulate_launch_shape_does_not_change_a_bit(n_events):
     from tests.conftest import run_dev_case
 
     run_dev_case("launch_shape", n_events)
+
+
+@pytest.mark.parametrize("kw", [dict(compact=True), dict(compact=False), dict(compact=True, index16=False)],
+                         ids=["20B", "40B", "24B"])
+def test_one_call_evaluation_equals_the_separate_calls(kw):
+    """`pisa_hip_evaluator_eval` (prob3 -> accumulate -> tail enqueued and awaited inside ONE C-ABI call) against
+    the three separate calls of the same entry points: the same launches, so the same bits -- llh / mod_chi2 through
+    the four-workgroup tail, chi2 through the one-workgroup tail, after a change of a container's scale
+    (aeff.py:78-86), after new pseudo-data, and with the maps read back in between (limbs not zero)."""
+    from pisa_amd import synthetic
+
+    wl = synthetic.Workload(n_events=120_000, grid=(40, 30), out_binning="dragon", seed=4)
+    a = synthetic.DeviceState(wl, **kw)
+    b = synthetic.DeviceState(wl, **kw)
+    b.one_call = False
+    data = a.make_pseudo_data(wl.osc_params(), seed=0)
+    b.set_data(data)
+    rs = np.random.RandomState(2)
+    pts = [wl.osc_params(theta23_deg=38 + 14 * rs.rand(), dm31=2.2e-3 + 6e-4 * rs.rand()) for _ in range(6)]
+    for kind in ("llh", "mod_chi2", "chi2"):
+        for p in pts[:3]:
+            va, vb = a.eval_host(p, kind), b.eval_host(p, kind)
+            assert va == vb and np.isfinite(va), (kind, va, vb)
+    assert a._evaluator is not None and b._evaluator is None
+    ha, hb = a.maps(), b.maps()
+    assert np.array_equal(ha[0], hb[0]) and np.array_equal(ha[1], hb[1]) and ha[0].sum() > 0
+    a.set_scale("numu_cc", 0.7 * a.cont[1].scale)
+    b.set_scale("numu_cc", 0.7 * b.cont[1].scale)
+    assert a.eval_host(pts[3], "llh") == b.eval_host(pts[3], "llh")
+    data2 = np.random.RandomState(5).poisson(data + 3.0).astype(np.float64)
+    a.set_data(data2)
+    b.set_data(data2)
+    assert a.eval_host(pts[4], "llh") == b.eval_host(pts[4], "llh")
+    # a plain accumulate in between leaves limbs that are not zero: the next one-call evaluation clears them
+    a.accumulate(pts[5])
+    a.finalize()
+    assert a.eval_host(pts[4], "llh") == b.eval_host(pts[4], "llh")
+    a.check_status()
+    b.check_status()
+    # negative pseudo-data: NaN and the status word (stats.py:231-240 raises), on both paths
+    bad = data2.copy()
+    bad[3] = -1.0
+    for st in (a, b):
+        st.set_data(bad)
+        v = st.eval_host(pts[0], "llh")
+        assert v != v and st.metric_status_host() != 0

@@ -236,6 +236,36 @@ def _oracle_llh(orc, data, ref):
     return float(orc.metric("llh", data, lam)[1]), floor
 
 
+GATES = {}   # which LLH gate applied per comparison (written to gpurun_out/llh_gates.json at the end of the module)
+
+
+def _assert_llh(tag, llh, want, floor):
+    """north star: |dLLH| <= 1e-10 |LLH|.  The term floor is used only when that pure gate is not met AND the
+    difference is inside the rounding floor of the formula itself; which one applied is recorded."""
+    diff = abs(llh - want)
+    pure = diff <= 1e-10 * abs(want)
+    GATES[tag] = dict(device=llh, oracle=want, abs_diff=diff, rel_diff=diff / abs(want), term_floor=floor,
+                      applied="1e-10 relative" if pure else "term floor")
+    assert pure or diff <= floor, (tag, llh, want, floor)
+    if not pure:
+        import warnings
+
+        warnings.warn("LLH gate of %s: the term floor applied (rel diff %.2e)" % (tag, diff / abs(want)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _write_gates():
+    yield
+    import json
+    import os
+
+    if GATES:
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "llh_gates.json"), "w") as fh:
+            json.dump(GATES, fh, indent=1)
+
+
 def test_headline_workload_against_the_oracle(workload, oracle):
     """The bench's headline workload, maps of all 12 containers and the LLH against `oracle_eval` on
     identical inputs: the 20 B (16-bit index, folded), 40 B (reference operation order) and 72 B
@@ -268,7 +298,7 @@ def test_headline_workload_against_the_oracle(workload, oracle):
         np.testing.assert_allclose(st.prob_nu.cpu().numpy(), ref["prob_nu"], rtol=1e-10, atol=1e-14)
         np.testing.assert_allclose(st.prob_nubar.cpu().numpy(), ref["prob_nubar"], rtol=1e-10, atol=1e-14)
         want, floor = _oracle_llh(oracle, data, ref)
-        assert abs(llh - want) <= max(1e-10 * abs(want), floor), (kw, llh, want, floor)
+        _assert_llh("headline %s" % (kw,), llh, want, floor)
         # the metric kernel alone: the oracle's llh of the DEVICE maps (same expectation, so only the
         # two log implementations differ)
         same_lam = float(oracle.metric("llh", data, h.sum(axis=0))[1])
@@ -308,7 +338,7 @@ def test_event_mode_workloads_against_the_oracle(oracle, nsi):
     np.testing.assert_allclose(h, ref_h, rtol=1e-10, atol=1e-13 * np.abs(ref_h).max())
     np.testing.assert_allclose(s2, ref_s2, rtol=1e-10, atol=1e-13 * np.abs(ref_s2).max())
     want, floor = _oracle_llh(oracle, data, ref)
-    assert abs(llh - want) <= max(1e-10 * abs(want), floor), (llh, want, floor)
+    _assert_llh("events %s" % ("C5 slice std NSI" if nsi else "C2"), llh, want, floor)
     # the probabilities themselves, every event of two containers (nu and nubar)
     lay = oracle.Layers(wl.layers.prem, wl.layers.detector_depth, wl.layers.prop_height)
     lay.rhos = np.array(wl.layers.rhos)
