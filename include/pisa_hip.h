@@ -285,6 +285,26 @@ int pisa_hip_apply_osc_weights_strided(const double *d_nu_flux, const double *d_
 int pisa_hip_apply_aeff(const double *d_weighted_aeff, double scale, int64_t n,
                         double *d_weights, void *stream); /* aeff.py:87 */
 
+/* The whole weight chain of several containers in ONE launch (what the three stages' apply_functions do to
+ * `weights` one after the other, on events or on the bins of a map):
+ *   weights = copy(initial_weights)                   toy_event_generator.py:101-104 and the other loaders
+ *   weights *= flux[:,0]*prob_e + flux[:,1]*prob_mu   prob3.py:621-622   (skipped if d_nu_flux == NULL)
+ *   weights *= weighted_aeff * aeff_scale             aeff.py:87         (skipped if d_weighted_aeff == NULL)
+ * with every step rounded to fp64 as the one-step calls above round it: the same bits as
+ * copy -> pisa_hip_apply_osc_weights[_strided] -> pisa_hip_apply_aeff. */
+typedef struct {
+    int64_t n;
+    const double *d_initial_weights; /* [n] */
+    const double *d_nu_flux;         /* [n][2] or NULL */
+    const double *d_prob_e;          /* read at element stride prob_stride */
+    const double *d_prob_mu;
+    int64_t prob_stride;
+    const double *d_weighted_aeff;   /* [n] or NULL */
+    double aeff_scale;
+    double *d_weights;               /* [n] out */
+} pisa_hip_chain_set;
+int pisa_hip_weight_chain_multi(const pisa_hip_chain_set *h_sets, int32_t n_sets, void *stream);
+
 /* Converts all-reduced limbs to fp64 maps: d_hist / d_sumw2 [n_containers][n_bins]
  * (either may be NULL). `errors` = sqrt(sumw2) is left to the caller (hist.py:215). */
 int pisa_hip_hist_finalize(const int64_t *d_limbs, int32_t n_containers, int64_t n_bins,

@@ -161,6 +161,21 @@ class FluxTable(C.Structure):
     ]
 
 
+class ChainSet(C.Structure):
+    """pisa_hip_chain_set"""
+    _fields_ = [
+        ("n", C.c_int64),
+        ("d_initial_weights", C.c_void_p),
+        ("d_nu_flux", C.c_void_p),
+        ("d_prob_e", C.c_void_p),
+        ("d_prob_mu", C.c_void_p),
+        ("prob_stride", C.c_int64),
+        ("d_weighted_aeff", C.c_void_p),
+        ("aeff_scale", C.c_double),
+        ("d_weights", C.c_void_p),
+    ]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
 
 
@@ -227,6 +242,7 @@ _SIGS = {
     "pisa_hip_finalize_metric_multi": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "pisa_hip_finalize_metric_split": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "pisa_hip_profile_events": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pisa_hip_weight_chain_multi": (C.c_int, [C.POINTER(ChainSet), C.c_int32, C.c_void_p]),
     "pisa_hip_evaluator_create": (C.c_int, [C.POINTER(EvaluatorDesc), C.POINTER(C.c_void_p)]),
     "pisa_hip_evaluator_destroy": (C.c_int, [C.c_void_p]),
     "pisa_hip_evaluator_set_scale": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),

@@ -54,8 +54,11 @@ class DeviceMapBlock:
         # device tensor [n_cont, n_bins]; maps = clip(hist * s, 0, inf), errors = sqrt(sumw2) * s
         self.scales = scales
         self.full = (1 << len(engine.cont)) - 1
+        self.n_rows = len(engine.cont)
         self._host = None
         self._live = True   # the engine still holds this evaluation
+        self._views = {}
+        self.rows_published = False   # the hist stage handed rows of this block to the containers
 
     def detach(self):
         """the engine is about to start another evaluation"""
@@ -73,19 +76,52 @@ class DeviceMapBlock:
             sc = self.scales.reshape(hist.shape)
             err = torch.sqrt(sumw2) * sc
             hist, sumw2 = torch.clamp(hist * sc, min=0.0), err * err
-        if self.with_errors:
+        if self.with_errors or self._views or self.rows_published:
             both = torch.stack((hist, sumw2)).cpu().numpy()
             self._host = (both[0], both[1])
         else:
             self._host = (hist.cpu().numpy(), None)
         eng.check_status()
 
-    def host_sum(self, mask, shape):
+    # -- rows handed to the containers by the hist stage (core/container.py: BlockRow) ---------------
+    def row_host(self, row, which):
+        """host array of one container's map: which = 0 sum(w), 1 sqrt(sum(w^2)), 2 sum(1^2 w) = sum(w)
+        (utils/hist.py:198-209); all rows of the block come home in ONE transfer, at the first request"""
         if self._host is None:
             if not self._live:
                 raise RuntimeError("device-backed maps outlived their evaluation")
             self._fetch()
         hist, sumw2 = self._host
+        return np.sqrt(sumw2[row]) if which == 1 else hist[row].copy()
+
+    def row_dev(self, row, which):
+        """the same row as a device tensor: a view of the engine's finalized maps while the evaluation is
+        still the engine's, an upload of the host copy afterwards"""
+        import torch
+
+        if self._live and self._host is None:
+            hist, sumw2 = self.engine.finalize()
+            return torch.sqrt(sumw2[row]) if which == 1 else hist[row].clone()
+        return K.to_device(self.row_host(row, which))
+
+    def view(self, with_errors):
+        """this block as maps with / without variances (the pipeline's output_key decides, not the stage
+        that made the block): the block itself or a cached sibling sharing everything else"""
+        if bool(with_errors) == bool(self.with_errors):
+            return self
+        v = self._views.get(bool(with_errors))
+        if v is None:
+            v = self._views[bool(with_errors)] = _BlockView(self, bool(with_errors))
+        return v
+
+    def host_sum(self, mask, shape, with_errors=None):
+        if self._host is None:
+            if not self._live:
+                raise RuntimeError("device-backed maps outlived their evaluation")
+            self._fetch()
+        hist, sumw2 = self._host
+        if not (self.with_errors if with_errors is None else with_errors):
+            sumw2 = None
         rows = [i for i in range(hist.shape[0]) if mask >> i & 1]
         h = hist[rows[0]].copy()
         v = None if sumw2 is None else sumw2[rows[0]].copy()
@@ -95,13 +131,13 @@ class DeviceMapBlock:
                 v += sumw2[i]
         return h.reshape(shape), None if v is None else v.reshape(shape)
 
-    def metric(self, mask, kind, data_hist, extra=None):
+    def metric(self, mask, kind, data_hist, extra=None, with_errors=None):
         """metric of the TOTAL template against `data_hist` on the device, or None if this block
         cannot provide it (partial sum, already fetched, no longer the engine's evaluation).
         `extra` = (hist, variances or None) host arrays added to the template after the containers."""
         if mask != self.full or not self._live or self._host is not None:
             return None
-        if kind == "mod_chi2" and not self.with_errors:
+        if kind == "mod_chi2" and not (self.with_errors if with_errors is None else with_errors):
             return None
         eng = self.engine
         extra_d = None
@@ -119,6 +155,21 @@ class DeviceMapBlock:
             if st != 0:
                 _lib.check(st)
         return val
+
+
+class _BlockView:
+    """a DeviceMapBlock seen with the other setting of `with_errors` (see DeviceMapBlock.view)"""
+
+    __slots__ = ("block", "with_errors", "full")
+
+    def __init__(self, block, with_errors):
+        self.block, self.with_errors, self.full = block, with_errors, block.full
+
+    def host_sum(self, mask, shape):
+        return self.block.host_sum(mask, shape, with_errors=self.with_errors)
+
+    def metric(self, mask, kind, data_hist, extra=None):
+        return self.block.metric(mask, kind, data_hist, extra, with_errors=self.with_errors)
 
 
 class DeviceMapSet(MapSet):

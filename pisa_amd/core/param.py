@@ -316,6 +316,15 @@ class Param:
         raise ValueError('Metric "%s" is invalid' % metric)
 
     def _hashable(self):
+        """the value as it enters `values_hash`; computed once per change of the value (`_ver`)"""
+        c = self.__dict__.get("_hashable_cache")
+        if c is not None and c[0] == self._ver:
+            return c[1]
+        h = self._hashable_now()
+        self._hashable_cache = (self._ver, h)
+        return h
+
+    def _hashable_now(self):
         v = self._value
         if isinstance(v, Quantity):
             m = v.magnitude

@@ -1111,6 +1111,30 @@ apply_osc_weights_strided_kernel(const double *__restrict__ flux, const double *
     w[i] = w[i] * ((f.x * pe[i * stride]) + (f.y * pmu[i * stride]));
 }
 
+// The reference's event-wise (or bin-wise) weight chain of several containers in ONE launch:
+//   weights = copy(initial_weights)                        toy_event_generator.py:101-104 / the loaders
+//   weights *= flux[:,0]*prob_e + flux[:,1]*prob_mu        prob3.py:621-622
+//   weights *= weighted_aeff * scale                       aeff.py:87
+// each step rounded to fp64 exactly as the one-step kernels above do (this file is compiled with contraction off).
+constexpr int CHAIN_MAX_SETS = 24;
+struct ChainArgs {
+    pisa_hip_chain_set set[CHAIN_MAX_SETS];
+};
+
+__global__ void __launch_bounds__(256)
+weight_chain_multi_kernel(const ChainArgs a) {
+    const pisa_hip_chain_set &S = a.set[blockIdx.y];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S.n) return;
+    double w = S.d_initial_weights[i];
+    if (S.d_nu_flux) {
+        const double2 f = reinterpret_cast<const double2 *>(S.d_nu_flux)[i];
+        w = w * ((f.x * S.d_prob_e[i * S.prob_stride]) + (f.y * S.d_prob_mu[i * S.prob_stride]));
+    }
+    if (S.d_weighted_aeff) w = w * (S.d_weighted_aeff[i] * S.aeff_scale);
+    S.d_weights[i] = w;
+}
+
 __global__ void __launch_bounds__(256)
 apply_aeff_kernel(const double *__restrict__ aeff, double scale, int64_t n,
                   double *__restrict__ w) {
@@ -1702,6 +1726,27 @@ PISA_API int pisa_hip_apply_osc_weights_strided(const double *d_nu_flux, const d
     hipLaunchKernelGGL(apply_osc_weights_strided_kernel, grid, block, 0, as_stream(stream), d_nu_flux,
                        d_prob_e, d_prob_mu, prob_stride, n, d_weights);
     PISA_CHECK_LAUNCH("apply_osc_weights_strided_kernel");
+    return PISA_HIP_OK;
+}
+
+PISA_API int pisa_hip_weight_chain_multi(const pisa_hip_chain_set *h_sets, int32_t n_sets, void *stream) {
+    if (!h_sets || n_sets < 1 || n_sets > 4096) return PISA_HIP_ERR_INVALID;
+    for (int k = 0; k < n_sets; k++) {
+        const pisa_hip_chain_set &h = h_sets[k];
+        if (h.n < 0 || (h.n > 0 && (!h.d_initial_weights || !h.d_weights)) ||
+            (h.n > 0 && h.d_nu_flux && (!h.d_prob_e || !h.d_prob_mu || h.prob_stride < 1)))
+            return PISA_HIP_ERR_INVALID;
+    }
+    for (int base = 0; base < n_sets; base += CHAIN_MAX_SETS) {
+        const int nc = n_sets - base < CHAIN_MAX_SETS ? n_sets - base : CHAIN_MAX_SETS;
+        ChainArgs a;
+        int64_t n_max = 0;
+        for (int k = 0; k < nc; k++) { a.set[k] = h_sets[base + k]; n_max = std::max(n_max, h_sets[base + k].n); }
+        if (n_max == 0) continue;
+        dim3 block(256), grid((unsigned)((n_max + 255) / 256), (unsigned)nc);
+        hipLaunchKernelGGL(weight_chain_multi_kernel, grid, block, 0, as_stream(stream), a);
+        PISA_CHECK_LAUNCH("weight_chain_multi_kernel");
+    }
     return PISA_HIP_OK;
 }
 

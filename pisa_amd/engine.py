@@ -606,6 +606,8 @@ class HotPathEngine:
             torch.mul(static_w[:, None], flux, out=tmp[:n])
             out.permute(0, 2, 1, 3).copy_(tmp.view(out.shape[0], 64, 4, 2))
 
+    _evaluator = None
+
     def set_scale(self, name, scale):
         i = self.names.index(name)
         self.cont[i].scale = float(scale)
@@ -737,7 +739,7 @@ class HotPathEngine:
 
     def close(self):
         """release the direct RCCL communicator (before the process group is destroyed)"""
-        if self._evaluator is not None:
+        if getattr(self, "_evaluator", None) is not None:
             _lib.lib().pisa_hip_evaluator_destroy(self._evaluator["handle"])
             self._evaluator = None
         if self._rccl:

@@ -303,6 +303,32 @@ def apply_osc_weights(nu_flux, prob_e, prob_mu, weights):
     return weights
 
 
+def weight_chain_multi(items):
+    """The reset -> [osc] -> [aeff] chain of several containers in one launch (`pisa_hip_weight_chain_multi`).
+    items: (initial_weights, nu_flux or None, prob_e, prob_mu, weighted_aeff or None, scale) per container, device
+    tensors; prob_e / prob_mu may be equal-stride 1-D views.  Returns (flat block of all weights, list of its
+    per-container views)."""
+    lib = _lib.lib()
+    sizes = [int(it[0].numel()) for it in items]
+    block = torch.empty(sum(sizes), dtype=F8, device=items[0][0].device)
+    sets = (_lib.ChainSet * len(items))()
+    keep, views, off = [], [], 0
+    for s, (w0, flux, pe, pmu, aeff, scale), n in zip(sets, items, sizes):
+        out = block[off:off + n]
+        off += n
+        views.append(out)
+        s.n, s.d_initial_weights, s.d_weights = n, _ptr(w0), out.data_ptr()
+        if flux is not None:
+            if not (pe.dim() == 1 and pmu.dim() == 1 and pe.stride(0) == pmu.stride(0) >= 1 and pe.numel() == pmu.numel() == n):
+                pe, pmu = pe.contiguous().reshape(-1), pmu.contiguous().reshape(-1)
+                keep += [pe, pmu]
+            s.d_nu_flux, s.d_prob_e, s.d_prob_mu, s.prob_stride = _ptr(flux), pe.data_ptr(), pmu.data_ptr(), max(1, pe.stride(0))
+        if aeff is not None:
+            s.d_weighted_aeff, s.aeff_scale = _ptr(aeff), float(scale)
+    _lib.check(lib.pisa_hip_weight_chain_multi(sets, len(items), _stream()))
+    return block, views
+
+
 def apply_aeff(weighted_aeff, scale, weights):
     """aeff.apply_function (aeff.py:87), in place on `weights`."""
     lib = _lib.lib()

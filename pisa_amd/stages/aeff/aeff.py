@@ -27,10 +27,19 @@ class aeff(Stage):  # pylint: disable=invalid-name
             scale *= p.nu_nc_norm.m_in("dimensionless")
         return scale
 
+    def _scales(self):
+        """`scale_for` of every container, recomputed when one of this stage's parameters moved"""
+        key = tuple(p._ver for p in self.params) + (len(self.data.containers),)
+        c = getattr(self, "_scale_cache", None)
+        if c is None or c[0] != key or c[2] is not self.params:
+            c = self._scale_cache = (key, {cont.name: self.scale_for(cont.name) for cont in self.data}, self.params)
+        return c[1]
+
     def apply_function(self):
+        scales = self._scales()
         for container in self.data:
-            scale = self.scale_for(container.name)
-            if not container.is_map:
+            scale = scales[container.name]
+            if not container.is_map or deferred.chain_open(container):
                 deferred.aeff(container, scale)
             else:
                 w = container.device("weights")

@@ -20,12 +20,19 @@ def _ops(container):
 
 
 def reset_weights(container):
-    """weights = copy(initial_weights)  (toy_event_generator.py:101-104)"""
-    if container.is_map:
-        container[KEY] = container.device("initial_weights").clone()
-        return
+    """weights = copy(initial_weights)  (toy_event_generator.py:101-104); recorded in event AND in map
+    representations (a binned pipeline such as osc_example.cfg: `ContainerSet.get_mapset` runs the chains of
+    all containers in one launch, `pisa_hip_weight_chain_multi`)"""
     container.pending[KEY] = [("reset",)]
     container.touch_pending(KEY)
+
+
+def chain_open(container):
+    """a chain that started with `reset` in the container's CURRENT representation is pending: later steps can
+    be appended to it (anything else -- weights set some other way, or in another representation -- is
+    applied at once by the caller, through `container.device('weights')` and its automatic translation)"""
+    ops = container.pending.get(KEY)
+    return bool(ops) and ops[0][0] == "reset" and container._pending_hash.get(KEY) == container._rep_hash
 
 
 def osc(container, flux_key="nu_flux"):
@@ -57,6 +64,20 @@ def materialize(container, key=KEY):
             w = container.device_raw(key)
             K.apply_aeff(container.device("weighted_aeff"), op[1], w)
             container._store(key, w)
+
+
+def batch_chain(container):
+    """(flux_key or None, aeff scale or None) if the pending chain is reset [-> osc] [-> aeff] in the current
+    representation: the shape `pisa_hip_weight_chain_multi` runs for many containers at once"""
+    if not chain_open(container):
+        return None
+    ops = container.pending[KEY][1:]
+    flux = scale = None
+    if ops and ops[0][0] == "osc":
+        flux, ops = ops[0][1], ops[1:]
+    if ops and ops[0][0] == "aeff":
+        scale, ops = ops[0][1], ops[1:]
+    return None if ops else (flux, scale)
 
 
 def fusable_chain(container):

@@ -254,12 +254,21 @@ class prob3(Stage):  # pylint: disable=invalid-name
                 out_nubar=None if self.prob_tables is None else self.prob_tables[1],
                 out_pepmu=self.pepmu)
             self.prob_tables, self.pepmu = (P_nu, P_nubar), pepmu
-            for container in self.data.containers:
-                side = 0 if container["nubar"] > 0 else 1
-                flav = int(container["flav"])
-                container["probability"] = self.prob_tables[side]
-                container["prob_e"] = pepmu[side, flav, :, 0]    # strided views: compacted on access only
-                container["prob_mu"] = pepmu[side, flav, :, 1]
+            # the tables are rewritten in place every evaluation: the containers keep the same tensors /
+            # strided views (compacted on access only), only their bookkeeping moves (`refresh_dev`)
+            views = getattr(self, "_views", None)
+            if views is None or views["src"] is not pepmu or views["tabs"] is not P_nu:
+                views = self._views = {"src": pepmu, "tabs": P_nu, "of": {}, "cont": None}
+            if views["cont"] is None or len(views["cont"]) != len(self.data.containers):
+                views["cont"] = [(0 if c["nubar"] > 0 else 1, int(c["flav"])) for c in self.data.containers]
+            for container, (side, flav) in zip(self.data.containers, views["cont"]):
+                v = views["of"].get((side, flav))
+                if v is None:
+                    v = views["of"][(side, flav)] = (self.prob_tables[side], pepmu[side, flav, :, 0],
+                                                    pepmu[side, flav, :, 1])
+                container.refresh_dev("probability", v[0])
+                container.refresh_dev("prob_e", v[1])
+                container.refresh_dev("prob_mu", v[2])
         else:
             events = self.calc_mode == "events"
             earth = self.layers.earth_struct() if events else None
@@ -278,7 +287,7 @@ class prob3(Stage):  # pylint: disable=invalid-name
     # ---------------------------------------------------------------- apply
     def apply_function(self):
         for container in self.data:
-            if not container.is_map:
+            if not container.is_map or deferred.chain_open(container):
                 deferred.osc(container, "nu_flux")
             else:
                 w = container.device("weights")

@@ -37,6 +37,7 @@ class hist(Stage):  # pylint: disable=invalid-name
         self.unweighted = unweighted
         self._engine = None
         self._engine_versions = None
+        self._rows = []           # BlockRows handed to the containers by the last fused evaluation
         self.fused_last_eval = False
 
     def setup_function(self):
@@ -195,24 +196,44 @@ class hist(Stage):  # pylint: disable=invalid-name
                 self._engine_versions[i][flux_key] = c.version(flux_key)
         eng.update_flux_many(moved)                      # one launch for all rewritten columns
         eng.pepmu = osc.pepmu
+        # the rows handed out at the previous evaluation that nobody read are void from here on (their
+        # table is about to be overwritten; the containers get new rows below); Maps somebody still HOLDS
+        # keep the old block alive and are brought to the host by the engine before the launch
+        for row in self._rows:
+            if row.pristine:
+                row.block = None
+        self._rows = []
         eng.accumulate()
         eng.allreduce()
-        hist_d, sumw2_d = eng.finalize()
-        # one D2H for all containers' maps and errors (the caller reads them as
-        # Maps right away); the device rows stay available for later stages
+        # Nothing is finalised or copied here: the maps stay in HBM as the int64 limbs of this evaluation.
+        # The containers receive ROWS of that table (core/container.py: BlockRow) -- host arrays / device
+        # tensors on first access, device-backed Maps through `get_mapset`, whose total and metric run on the
+        # device (the tail kernel) without the maps travelling at all.
+        import weakref
+
+        from pisa_amd.core.container import BlockRow
+        from pisa_amd.core.fastplan import DeviceMapBlock
+
         sumw2 = self.error_method == "sumw2"
-        both = torch.stack((hist_d, torch.sqrt(sumw2_d), hist_d)) if sumw2 else hist_d[None]
-        both_h = both.cpu().numpy()
+        block = DeviceMapBlock(eng, sumw2)
+        block.rows_published = True
+        eng._out_block = weakref.ref(block)
+        n_bins = eng.n_bins
+        rows = self._rows
         for i, c in enumerate(conts):
             ops = c.pending.pop(deferred.KEY, None)  # consumed by the fused kernel
             c.representation = self.apply_mode
-            c.set_mirrored("weights", both[0, i], both_h[0, i])
+            r = BlockRow(block, i, 0, n_bins)
+            rows.append(r)
+            c.publish("weights", r)
             # histogramming does not invalidate the event-wise weights (hist.py:213): they are
             # what the consumed chain gives, computed if anybody reads them
             c.keep_lazy("weights", ops, "events")
             if sumw2:
-                c.set_mirrored("errors", both[1, i], both_h[1, i])
-                c.set_mirrored("bin_unc2", both[2, i], both_h[2, i])  # sum(1^2 * w), hist.py:207-209
+                r1, r2 = BlockRow(block, i, 1, n_bins), BlockRow(block, i, 2, n_bins)
+                rows += [r1, r2]
+                c.publish("errors", r1)
+                c.publish("bin_unc2", r2)          # sum(1^2 * w), hist.py:207-209
         return True
 
     def sync_node_flux(self):

@@ -684,3 +684,38 @@ def test_metric_many_matches_point_by_point_and_falls_back():
         p[i_aeff] = min(1.0, x0[i_aeff] + 0.07)
     second = dm.metric_many(same_aeff, data, "mod_chi2")
     assert second == serial(same_aeff) and second != first
+
+
+def test_binned_pipeline_runs_its_weight_chains_in_one_launch():
+    """osc_example.cfg applies every stage on 200 x 200 maps: the loader's reset and prob3's reweighting are
+    recorded per container and `get_mapset` runs all twelve chains in ONE launch (`pisa_hip_weight_chain_multi`);
+    the maps carry the bits of the one-step calls (copy -> pisa_hip_apply_osc_weights), a single container read
+    on its own materialises its chain alone with the same bits, and a second evaluation after a parameter
+    change does not alias the first one's maps."""
+    from pisa_amd import kernels as K
+    from pisa_amd.core.pipeline import Pipeline
+    from pisa_amd.core.units import ureg
+    from pisa_amd.stages import deferred
+
+    pipe = Pipeline("settings/pipeline/osc_example.cfg")
+    maps = pipe.get_outputs()
+    first = {m.name: m.hist.copy() for m in maps}
+    binning = pipe.output_binning
+    for c in pipe.data.containers:
+        assert not c.pending.get(deferred.KEY)
+        c.representation = binning
+        w = c.device("initial_weights").clone()
+        K.apply_osc_weights(c.device("nu_flux"), c.device_view("prob_e"), c.device_view("prob_mu"), w)
+        np.testing.assert_array_equal(first[c.name].ravel(), w.cpu().numpy())
+    # one container read on its own, before anybody asks for the map set: its chain alone, same bits
+    pipe.params.theta23.value = 47.0 * ureg.degree
+    pipe.run()
+    c = pipe.data["numu_cc"]
+    c.representation = binning
+    assert deferred.chain_open(c)
+    alone = c["weights"].copy()
+    assert not c.pending.get(deferred.KEY)
+    maps2 = pipe.get_outputs()
+    np.testing.assert_array_equal(maps2["numu_cc"].hist.ravel(), alone)
+    assert np.abs(maps2["numu_cc"].hist - first["numu_cc"]).max() > 1e-3
+    np.testing.assert_array_equal(maps["nue_cc"].hist, first["nue_cc"])      # the first evaluation's maps are intact
