@@ -35,16 +35,25 @@ def chain_open(container):
     return bool(ops) and ops[0][0] == "reset" and container._pending_hash.get(KEY) == container._rep_hash
 
 
+def _append(container, op):
+    ops = container.pending.get(KEY)
+    if ops and container._pending_hash.get(KEY) == container._rep_hash:
+        # a chain is already pending here: the first step has moved the change counters and the validity bits
+        # (`touch_pending`), and nobody has read the weights since (a read materialises and removes the chain)
+        ops.append(op)
+        return
+    _ops(container).append(op)
+    container.touch_pending(KEY)
+
+
 def osc(container, flux_key="nu_flux"):
     """weights *= flux[:,0]*prob_e + flux[:,1]*prob_mu  (prob3.py:621-622)"""
-    _ops(container).append(("osc", flux_key))
-    container.touch_pending(KEY)
+    _append(container, ("osc", flux_key))
 
 
 def aeff(container, scale):
     """weights *= weighted_aeff * scale  (aeff.py:87)"""
-    _ops(container).append(("aeff", float(scale)))
-    container.touch_pending(KEY)
+    _append(container, ("aeff", float(scale)))
 
 
 def materialize(container, key=KEY):

@@ -135,9 +135,13 @@ class hist(Stage):  # pylint: disable=invalid-name
 
         flux_key = chains[0][0]
         static_keys = ("weighted_aeff", "initial_weights", "true_energy", "true_coszen")
-        if self._engine is not None and any(
-                c.version(k) != v[k] for c, v in zip(conts, self._engine_versions) for k in static_keys):
-            self._engine = None   # a column folded / digitised at engine build was rewritten
+        if self._engine is not None:
+            for c, v in zip(conts, self._engine_versions):
+                cv = c._version
+                if (cv["weighted_aeff"] != v["weighted_aeff"] or cv["initial_weights"] != v["initial_weights"]
+                        or cv["true_energy"] != v["true_energy"] or cv["true_coszen"] != v["true_coszen"]):
+                    self._engine = None   # a column folded / digitised at engine build was rewritten
+                    break
         # flux computed on the oscillation grid (flux stages with calc_mode = osc.prob3's, e.g. the
         # IceCube 3-year cfgs): every event would look up flux AND probabilities at the same node
         # (container.py:981-1012), so the engine multiplies them per node instead of per event
@@ -184,11 +188,12 @@ class hist(Stage):  # pylint: disable=invalid-name
         eng = self._engine
         moved = []
         for i, (c, ch) in enumerate(zip(conts, chains)):
-            c.representation = "events"
-            eng.set_scale(c.name, ch[1])
+            if eng.cont[i].scale != ch[1]:
+                eng.set_scale(c.name, ch[1])
             # the container's change counter, not object identity: a stage that edits the flux in
             # place and calls mark_changed (container.py:638-649) keeps the same array object
-            if c.version(flux_key) != self._engine_versions[i][flux_key]:
+            if c._version[flux_key] != self._engine_versions[i][flux_key]:
+                c.representation = "events"
                 if node_flux:                            # flux systematics changed
                     eng.update_flux_nodes(i, flux_on_nodes(c))
                 else:
