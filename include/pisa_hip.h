@@ -244,7 +244,21 @@ typedef struct {
                                         quad of consecutive events e = 4q + k stored at
                                         [q / 64][k][q % 64], so that the 64 lanes of a wavefront
                                         (one quad each) read 16 contiguous bytes per lane */
+    /* PARTITIONED resident order (optional; 16-bit index form with an output binning beyond the LDS
+     * accumulators, pisa_hip_hist_window_bins(n_bins) = W > 0): the caller has ordered the events so that
+     * partition p = events [256 d_part_start[p], 256 d_part_start[p+1]) deposits only into bins
+     * [p W, (p+1) W) (events outside the binning may sit anywhere), d_part_start[0] = 0,
+     * d_part_start[n_part] = n_pad / 256.  The kernel then keeps every deposit in LDS and scans nothing.
+     * Ignored (the general window path is used) unless part_width == W.  The histogram does not depend on
+     * the order of the events: the same bits either way. */
+    const int32_t *d_part_start;     /* DEVICE array [n_part + 1], units of 256 events, or NULL */
+    int32_t n_part;
+    int32_t part_width;
 } pisa_hip_container;
+
+/* 0 if the fused kernels keep all n_bins accumulators of a container in LDS, else the number of
+ * consecutive bins W their LDS window holds (a multiple of 32). */
+int pisa_hip_hist_window_bins(int64_t n_bins);
 
 /* Fused  prob3.apply (prob3.py:621-622, with the grid->event lookup of
  * container.py:981-1012 / translation.py:427-438)  +  aeff.apply

@@ -183,6 +183,11 @@ struct ContDev {
     const double2 *wflux_q;     // wflux in quad-blocked order [q / 64][4][q % 64], padded to 256 events
     double scale;
     int32_t flav, side;
+    // optional, 16-bit index form with a binning beyond the LDS accumulators: the resident order is cut into
+    // n_part partitions, partition p = events [256 part_start[p], 256 part_start[p+1]) holding only deposits into
+    // bins [p W, (p+1) W), W = the LDS window (HistArgs::window)
+    const int32_t *part_start;
+    int32_t n_part, part_width;
 };
 
 struct HistArgs {
@@ -197,6 +202,7 @@ struct HistArgs {
     const double2 *pepmu;    // optional compact tables [side][flav][node] = (P_e->f, P_mu->f)
     ContDev cont[MAX_CONT];
     int32_t blk_start[MAX_CONT + 1];
+    int32_t cont_chunk[MAX_CONT];   // > 0: events per workgroup of this container / 256 (instead of `chunk`)
     int32_t copies;       // LDS replicas of the accumulators (power of two), lane-interleaved
     int32_t opts;         // 1: the caller has no use for the second quantity (plain histogram without counts).
                           // Builds with -DPISA_DEV_PROBES only (PISA_HIP_HIST_DBG): 2 no deposits, 4 no flush
@@ -234,8 +240,11 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
     while (c + 1 < a.n_cont && bid >= a.blk_start[c + 1]) c++;  // workgroup-uniform
     const ContDev &C = a.cont[c];
     const int64_t lb = bid - a.blk_start[c];
-    const int64_t start = lb * a.chunk;
-    int64_t end = start + a.chunk;
+    // events of this workgroup where the workgroups of a container do not sweep together: the container's own
+    // share (partitioned window order: multiples of 256 events), else the launch's largest share
+    const int64_t my_chunk = a.cont_chunk[c] > 0 ? (int64_t)a.cont_chunk[c] * 256 : a.chunk;
+    const int64_t start = lb * my_chunk;
+    int64_t end = start + my_chunk;
     if (end > C.n) end = C.n;
     // bins held in LDS: all of them, or (a.window > 0, MODE 3 only) the window
     // [bin_lo, bin_lo + window) that starts at the smallest bin of this workgroup's
@@ -291,7 +300,7 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
     STAMP(1);
     if (LDS_ACC) {
         for (int k = threadIdx.x; k < n_acc * a.copies; k += nthreads) s_acc[k] = 0ull;
-        if ((PACKED || QUAD) && a.window > 0) {
+        if ((PACKED || QUAD) && a.window > 0 && !(QUAD && C.part_start)) {
             __shared__ int s_lo;
             if (threadIdx.x == 0) s_lo = 0x7fffffff;
             __syncthreads();
@@ -366,14 +375,65 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
         if (!ok) bad = true;
     };
 
+    // slab accumulators -> integer units, added to the global limbs.  The loop runs in
+    // GLOBAL order (limb fastest): a wave's 64 atomics fall into 512 contiguous bytes,
+    // which the L2 atomic units take at full rate (scattered 96 B apart they do not).
+    // Workgroups of a container finish together; each starts at a different offset so
+    // that they do not all queue on the same limbs at the same moment.
+    auto flush_lds = [&]() {
+        const int rot = (int)((lb * 7 * 64) % n_acc);
+        for (int g0 = threadIdx.x; g0 < n_acc; g0 += nthreads) {
+            int g = g0 + rot;
+            if (g >= n_acc) g -= n_acc;
+            const int bin = g / (2 * NL);
+            const int rem = g - bin * 2 * NL;
+            const int q = rem / NL;
+            const int j = rem - q * NL;
+            const int k = (j * 2 + q) * n_bins + bin;
+            unsigned long long v = s_acc[k];
+            for (int r = 1; r < a.copies; r++) v += s_acc[r * n_acc + k];  // integer: exact
+            if (v != 0ull && bin_lo + bin < (int)a.n_bins) atomicAdd(&g_out[(int64_t)bin_lo * 2 * NL + g], v);
+        }
+    };
+
     if (QUAD) {
         const double2 *tab = C.pepmu_own ? C.pepmu_own
                                          : a.pepmu + ((int64_t)C.side * 3 + C.flav) * a.n_nodes;
         const double scale = C.scale;
         const uint4 *idxq = reinterpret_cast<const uint4 *>(C.idx16);
         const double2 *aw = C.wflux_q;
-        const int64_t qstep = together ? n_wg * nthreads : nthreads;
+        int64_t qstep = together ? n_wg * nthreads : nthreads;
         const double2 zero2 = make_double2(0.0, 0.0);
+        int64_t q_stop = q_end;
+        // Partitioned resident order (binning beyond the LDS accumulators, ContDev::part_start): the chunk is
+        // worked through partition by partition, each with the LDS window on that partition's bins -- every
+        // deposit is an LDS deposit, nothing is scanned for the window's position, and only a chunk that
+        // straddles a partition boundary flushes twice.  Partition boundaries are multiples of 256 events =
+        // one wavefront's sweep.
+        int part = -1;
+        if (LDS_ACC && a.window > 0 && C.part_start) {
+            part = 0;
+            while (part + 1 < C.n_part && (int64_t)C.part_start[part + 1] * 256 <= start) part++;
+        }
+      for (;;) {
+        if (part >= 0) {
+            const int64_t ps = (int64_t)C.part_start[part] * 256, pe = (int64_t)C.part_start[part + 1] * 256;
+            const int64_t lo = ps > start ? ps : start, hi = pe < end ? pe : end;
+            bin_lo = part * a.window;
+            q_stop = (hi + 3) >> 2;
+            if (lo > start) {     // a later partition of this chunk: its own first loads
+                q = (lo >> 2) + threadIdx.x;
+                qhave = q < q_stop;
+                if (qhave) {
+                    qx = idxq[q];
+                    const double2 *gq0 = aw + ((q >> 6) * 256 + (q & 63));
+                    g0 = gq0[0]; g1 = gq0[64];
+                }
+            } else {
+                qhave = q < q_stop;
+            }
+        }
+        const int64_t q_end = q_stop;   // (shadows the chunk's end inside the sweep below)
         // The pair loop's software pipeline (see below), two half-sweeps per quad: while
         // events 0,1 of the quad are consumed the flux of events 2,3 is in flight, while 2,3
         // are consumed the next quad's indices and the flux of its events 0,1.
@@ -417,6 +477,17 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
             q = qn;
             qhave = have_n;
         }
+        if (part < 0) break;
+        // next partition of this chunk, if any: flush this window, clear, move on
+        const int64_t pe = (int64_t)C.part_start[part + 1] * 256;
+        if (pe >= end || part + 1 >= C.n_part) break;
+        __syncthreads();
+        flush_lds();
+        __syncthreads();
+        for (int k = threadIdx.x; k < n_acc * a.copies; k += nthreads) s_acc[k] = 0ull;
+        __syncthreads();
+        part++;
+      }
     } else if (PACKED) {
         // packed columns: (node, bin) int2 and (aeff, w0) double2 per event; every load is 16 B
         const double2 *tab = C.pepmu_own ? C.pepmu_own
@@ -653,24 +724,7 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
     if (LDS_ACC) {
         __syncthreads();
         STAMP(4);
-        // slab accumulators -> integer units, added to the global limbs.  The loop runs in
-        // GLOBAL order (limb fastest): a wave's 64 atomics fall into 512 contiguous bytes,
-        // which the L2 atomic units take at full rate (scattered 96 B apart they do not).
-        // Workgroups of a container finish together; each starts at a different offset so
-        // that they do not all queue on the same limbs at the same moment.
-        const int rot = (int)((lb * 7 * 64) % n_acc);
-        for (int g0 = threadIdx.x; g0 < n_acc; g0 += nthreads) {
-            int g = g0 + rot;
-            if (g >= n_acc) g -= n_acc;
-            const int bin = g / (2 * NL);
-            const int rem = g - bin * 2 * NL;
-            const int q = rem / NL;
-            const int j = rem - q * NL;
-            const int k = (j * 2 + q) * n_bins + bin;
-            unsigned long long v = s_acc[k];
-            for (int r = 1; r < a.copies; r++) v += s_acc[r * n_acc + k];  // integer: exact
-            if (v != 0ull) atomicAdd(&g_out[(int64_t)bin_lo * 2 * NL + g], v);
-        }
+        flush_lds();
     }
     STAMP(5);
 }
@@ -1262,11 +1316,25 @@ static int run_hist(const ContDev *conts, int n_cont, int mode, const DevBinning
         a.pepmu = reinterpret_cast<const double2 *>(pepmu);
         a.opts = (PISA_DEV_INT("HIST_DBG", 0) & ~1) | (second_quantity ? 0 : 1);
         int64_t nev[MAX_CONT];
-        for (int c = 0; c < nc; c++) { a.cont[c] = conts[base + c]; nev[c] = conts[base + c].n; }
+        for (int c = 0; c < nc; c++) {
+            a.cont[c] = conts[base + c];
+            nev[c] = conts[base + c].n;
+            // the partitioned order is used where its partitions are this launch's LDS windows
+            if (!(window > 0 && mode == 7 && a.cont[c].part_width == window)) a.cont[c].part_start = nullptr;
+        }
         int threads = PISA_DEV_INT("HIST_THREADS", 1024);
         if (threads < 64 || threads > 1024 || (threads & 63)) threads = HIST_THREADS;
         int nblocks = plan_blocks(nev, nc, threads, a.chunk, a.blk_start);
         if (nblocks <= 0) continue;
+        for (int c = 0; c < nc; c++) {
+            a.cont_chunk[c] = 0;
+            const int64_t nwg_c = a.blk_start[c + 1] - a.blk_start[c];
+            // partitioned window order: equal shares of whole 256-event blocks per workgroup of the container
+            if (a.cont[c].part_start && nwg_c > 0) {
+                const int64_t blocks = (nev[c] + 255) / 256;
+                a.cont_chunk[c] = (int32_t)((blocks + nwg_c - 1) / nwg_c);
+            }
+        }
         dim3 grid_dim((unsigned)nblocks), block(threads);
         size_t shmem = lds ? (size_t)lds_bytes * copies : 0;
         a.copies = lds ? copies : 1;
@@ -1307,6 +1375,12 @@ static int run_hist(const ContDev *conts, int n_cont, int mode, const DevBinning
 }  // namespace pisa
 
 using namespace pisa;
+
+PISA_API int pisa_hip_hist_window_bins(int64_t n_bins) {
+    if (n_bins < 1) return -1;
+    if (lds_acc_bytes(n_bins) <= LDS_ACC_BYTES_MAX) return 0;
+    return (int)(LDS_ACC_BYTES_MAX / lds_acc_bytes(1)) / 32 * 32;
+}
 
 PISA_API int pisa_hip_profile_events(void *start_event, void *stop_event) {
     g_prof_start = reinterpret_cast<hipEvent_t>(start_event);
@@ -1392,6 +1466,9 @@ static int reweight_hist_impl(const pisa_hip_container *h_containers, int32_t n_
         d.wflux = reinterpret_cast<const double2 *>(h.d_weighted_flux);
         d.idx16 = h.d_node_bin16;
         d.wflux_q = reinterpret_cast<const double2 *>(h.d_weighted_flux_q);
+        d.part_start = (h.d_part_start && h.n_part >= 1 && h.part_width > 0) ? h.d_part_start : nullptr;
+        d.n_part = h.n_part;
+        d.part_width = h.part_width;
         d.scale = h.scale;
         d.flav = h.flav;
         d.side = h.nubar > 0 ? 0 : 1;

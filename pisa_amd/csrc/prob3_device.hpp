@@ -488,7 +488,9 @@ __device__ inline void eigvals3_general(const mat3 &H, cplx (&lam)[3]) {
                                        : csub(us[k], FAST ? cmul(p, crecip(cscale(3.0, us[k]))) : cdiv(p, cscale(3.0, us[k])));
         lam[k] = csub(t, shift);
     }
-    for (int it = 0; it < 4; it++)
+    // Newton polishing of the closed-form roots: quadratic convergence from ~1e-8 (nearly degenerate roots) or
+    // better, so two steps reach the conditioning of the cubic; the reference-order kernels keep four
+    for (int it = 0; it < (FAST ? 2 : 4); it++)
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             cplx xk = lam[k];
@@ -659,6 +661,64 @@ __device__ __forceinline__ void layer_amplitude(const Prob3Side &S, const double
             }
 #undef HMM
     }
+}
+
+// Event-mode layer matrix WITH decay (complex eigenvalues), polynomial form.  The reference builds
+//   A = sum_k e_k (X - M_a)(X - M_b) / ((M_k - M_a)(M_k - M_b)),   e_k = exp(-i M_k L/E 2.534),  X = 2E U^dagger H U
+// (numba_osc_kernels.py:432-467, 834-872: three full matrix products and 27 complex quotients per layer).
+// Expanded in powers of X -- the same Lagrange interpolation of exp on the spectrum, i.e. the same matrix --
+//   A = c0 I + c1 X + c2 X^2,  t_k = e_k / den_k,  c2 = sum t_k,  c1 = -sum t_k (M_a + M_b),  c0 = sum t_k M_a M_b
+// it costs ONE matrix product; X itself is assembled from the host-prepared mass-basis images (X0 + 2E a XV +
+// 2E XL, as the planned grid form does) instead of two products with U, and its eigenvalues are taken from X
+// directly (similar to 2E H: the same spectrum).  About half the instructions of layer_amplitude<true, true>
+// and far fewer live registers (no three sets of shifted diagonals, no 27 partial products); the result differs
+// from it by rounding (<= 1e-13 on the probabilities, tests/test_gpu_prob3_variants.py, decay goldens).
+__device__ __forceinline__ void layer_amplitude_decay_poly(const Prob3Side &S, double energy, double rho,
+                                                           double baseline, mat3 &A) {
+    const double tworttwoGf = 1.52588e-4;
+    const double two_e = 2.0 * energy;
+    const double ka = two_e * (S.a_sign * (0.5 * rho * tworttwoGf));
+    mat3 X;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            X.m[i][j] = cadd(S.X0.m[i][j], cadd(cscale(ka, S.XV.m[i][j]), cscale(two_e, S.XL.m[i][j])));
+    cplx M[3];
+    eigvals3_general<true>(X, M);
+    const double lf = (baseline * fast_rcp(energy)) * 2.534;
+    cplx t[3];
+    {
+        const cplx d01 = csub(M[0], M[1]), d02 = csub(M[0], M[2]), d12 = csub(M[1], M[2]);
+        const cplx den0 = cmul(d01, d02);
+        const cplx den1 = cscale(-1.0, cmul(d12, d01));
+        const cplx den2 = cmul(d02, d12);
+        const cplx den[3] = {den0, den1, den2};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            // exp(-i M_k lf) = exp(M_k.im lf) (cos(M_k.re lf) - i sin(M_k.re lf))
+            const double l = exp(M[k].im * lf);
+            double sn, cs;
+            sincos(-M[k].re * lf, &sn, &cs);
+            t[k] = cmul(cmake(l * cs, l * sn), crecip(den[k]));
+        }
+    }
+    const cplx s12 = cadd(M[1], M[2]), s20 = cadd(M[2], M[0]), s01 = cadd(M[0], M[1]);
+    const cplx p12 = cmul(M[1], M[2]), p20 = cmul(M[2], M[0]), p01 = cmul(M[0], M[1]);
+    const cplx c2 = cadd(cadd(t[0], t[1]), t[2]);
+    const cplx c1 = cscale(-1.0, cadd(cadd(cmul(t[0], s12), cmul(t[1], s20)), cmul(t[2], s01)));
+    const cplx c0 = cadd(cadd(cmul(t[0], p12), cmul(t[1], p20)), cmul(t[2], p01));
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            cplx x2 = cmul(X.m[i][0], X.m[0][j]);
+            x2 = cadd(x2, cmul(X.m[i][1], X.m[1][j]));
+            x2 = cadd(x2, cmul(X.m[i][2], X.m[2][j]));
+            cplx acc = cadd(cmul(c1, X.m[i][j]), cmul(c2, x2));
+            if (i == j) acc = cadd(acc, c0);
+            A.m[i][j] = acc;
+        }
 }
 
 // ---------------------------------------------------------------------------
@@ -1012,7 +1072,7 @@ __device__ __forceinline__ void propagate_path_nested(const Prob3Side &S, const 
                                                       double energy, int n_layers, int mid,
                                                       const LayerFn &layer, const SrcFn &src,
                                                       double (&P)[9]) {
-    const double mv[3] = {0.0, 0.0, 0.0};  // vacuum eigenvalues: not needed by either branch here
+
     mat3 T;
     bool have = false;
 #pragma unroll
@@ -1023,7 +1083,7 @@ __device__ __forceinline__ void propagate_path_nested(const Prob3Side &S, const 
         double rho, dist;
         layer(src(l), rho, dist);
         if (DECAY) {
-            layer_amplitude<DECAY, true>(S, dm, energy, rho, dist, A, mv);
+            layer_amplitude_decay_poly(S, energy, rho, dist, A);
         } else {
             double rec[PROB3_NF_REDUCED];
             auto store = [&](int f, double v) { rec[f] = v; };
@@ -1103,13 +1163,13 @@ __device__ __forceinline__ void propagate_path_nested_lds(const Prob3Side &S, co
                                                           double energy, int n_layers, int mid,
                                                           const LayerFn &layer, const SrcFn &src,
                                                           TLds T, double (&P)[9]) {
-    const double mv[3] = {0.0, 0.0, 0.0};
+
     bool have = false;
     auto amplitude = [&](int l, mat3 &A) {
         double rho, dist;
         layer(src(l), rho, dist);
         if (DECAY) {
-            layer_amplitude<DECAY, true>(S, dm, energy, rho, dist, A, mv);
+            layer_amplitude_decay_poly(S, energy, rho, dist, A);
         } else {
             double rec[PROB3_NF_REDUCED];
             auto store = [&](int f, double v) { rec[f] = v; };

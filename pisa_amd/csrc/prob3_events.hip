@@ -300,6 +300,11 @@ prob3_events_kernel(const Prob3Consts c, const EarthDev earth, const EvArgs ev, 
 
 using namespace pisa;
 
+// wavefronts per SIMD of the decay instantiation: two (248 VGPRs, no scratch) -- three (168 VGPRs, 73 spilled
+// dwords) ran 0.496 against 0.408 ms per 1e6 events (EXPERIMENTS R4-7)
+#ifndef DECAY_WAVES
+#define DECAY_WAVES 2
+#endif
 static int launch_events(const Prob3Consts &c, const EarthDev &e, const EvCont *conts, int n_cont,
                          int32_t *d_status, hipStream_t s) {
     int max_seg = 2 * e.n_shell;
@@ -335,7 +340,11 @@ static int launch_events(const Prob3Consts &c, const EarthDev &e, const EvCont *
             dim3 block(threads), grid((unsigned)max_blocks * (unsigned)a.n_cont);
 #define LAUNCH_EV(D, S_, ST) hipLaunchKernelGGL((prob3_events_kernel<D, S_, ST>), grid, block, lds, s, c, e, a, max_seg, d_status)
 #define LAUNCH_SIDE(D, ST) do { if (side == 0) LAUNCH_EV(D, 0, ST); else LAUNCH_EV(D, 1, ST); } while (0)
-            if (c.decay) { if (staged) LAUNCH_SIDE(true, true); else LAUNCH_SIDE(true, false); }
+            if (c.decay) {
+                if (staged) LAUNCH_SIDE(true, true);
+                else if (side == 0) hipLaunchKernelGGL((prob3_events_kernel<true, 0, false, DECAY_WAVES>), grid, block, lds, s, c, e, a, max_seg, d_status);
+                else hipLaunchKernelGGL((prob3_events_kernel<true, 1, false, DECAY_WAVES>), grid, block, lds, s, c, e, a, max_seg, d_status);
+            }
             else if (staged) LAUNCH_SIDE(false, true);
             else if (waves_cfg == 3) { if (side == 0) hipLaunchKernelGGL((prob3_events_kernel<false, 0, false, 3>), grid, block, lds, s, c, e, a, max_seg, d_status); else hipLaunchKernelGGL((prob3_events_kernel<false, 1, false, 3>), grid, block, lds, s, c, e, a, max_seg, d_status); }
             else LAUNCH_SIDE(false, false);

@@ -119,6 +119,72 @@ def bin_partition_order(obin, node, n_bins, width=672):
     return torch.argsort(key, stable=True)
 
 
+def window_partition_order(obin, node, n_bins, width, block=256):
+    """Resident order of the 16-bit index form for a binning beyond the LDS accumulators (`width` =
+    `pisa_hip_hist_window_bins`): the events are cut into partitions, partition p holding every event that
+    deposits into bins [p width, (p+1) width) -- sorted by calc-grid node and in the LDS-bank-aware order, as for
+    small binnings -- topped up with events that deposit nothing to a whole number of `block`-event blocks
+    (what one wavefront takes per sweep) and interleaved with further idle blocks so that every stretch of the
+    resident order carries the same share of depositing events.  The fused kernel then works a chunk through
+    partition by partition with its LDS window on that partition's bins (pisa_hip_container::d_part_start).
+    Returns (permutation, part_start in blocks [n_part + 1]), or None when the container has too few idle
+    events to top the partitions up (the caller keeps the general order)."""
+    n = int(obin.numel())
+    dev = obin.device
+    n_part = max(1, -(-int(n_bins) // int(width)))
+    dep = (obin >= 0) & (node >= 0)
+    idle = torch.nonzero(~dep).reshape(-1)
+    idle = idle[torch.argsort(node[idle], stable=True)]
+    part_of = torch.where(dep, obin.long() // int(width), torch.full_like(obin, -1, dtype=torch.int64))
+    deps = []
+    for p in range(n_part):
+        ip = torch.nonzero(part_of == p).reshape(-1)
+        ip = ip[torch.argsort(node[ip], stable=True)]
+        if ip.numel() >= 8192:
+            ip = ip[lds_bank_order(obin[ip], window=4096, banks=32, per=4)]
+        deps.append(ip)
+    n_dep = [int(d.numel()) for d in deps]
+    top = [(-k) % block for k in n_dep]                      # idle events that complete the last depositing block
+    spare = int(idle.numel()) - sum(top)
+    n_blocks = n // block                                    # (the tail beyond whole blocks stays idle, see below)
+    if spare < 0 or n_blocks == 0:
+        return None
+    dep_blocks = [(k + t) // block for k, t in zip(n_dep, top)]
+    idle_blocks = (n - sum(k + t for k, t in zip(n_dep, top))) // block
+    # idle blocks dealt to the partitions in proportion to their depositing blocks (largest remainder)
+    tot = max(1, sum(dep_blocks))
+    share = [idle_blocks * b // tot for b in dep_blocks]
+    rem = idle_blocks - sum(share)
+    for p in sorted(range(n_part), key=lambda p: -(idle_blocks * dep_blocks[p] % tot))[:rem]:
+        share[p] += 1
+    pieces, starts, at = [], [0], 0
+    for p in range(n_part):
+        body = torch.cat((deps[p], idle[at:at + top[p]]))
+        at += top[p]
+        filler = idle[at:at + share[p] * block]
+        at += share[p] * block
+        nb, nf = dep_blocks[p], share[p]
+        if nb and nf:
+            # depositing blocks spread evenly among the idle ones
+            t = nb + nf
+            pos_b = (torch.arange(nb, device=dev) * t) // nb
+            is_b = torch.zeros(t, dtype=torch.bool, device=dev)
+            is_b[pos_b] = True
+            src = torch.empty(t, dtype=torch.int64, device=dev)
+            src[is_b] = torch.arange(nb, device=dev)
+            src[~is_b] = torch.arange(nb, t, device=dev)
+            body = torch.cat((body, filler)).view(t, block)[src].reshape(-1)
+        else:
+            body = torch.cat((body, filler))
+        pieces.append(body)
+        starts.append(starts[-1] + (nb + nf))
+    pieces.append(idle[at:])            # fewer than `block` events: behind the last partition, padded by the engine
+    perm = torch.cat(pieces)
+    assert perm.numel() == n
+    starts[-1] = -(-n // block)         # the last partition takes the (idle) tail and its padding
+    return perm, starts
+
+
 def lds_bank_order(obin, window=4096, banks=32, per=2):
     """Second-level event order (applied on top of the node sort) that takes the LDS bank
     conflicts out of the deposits.
@@ -316,6 +382,7 @@ class HotPathEngine:
             cols = [column(col, sl) for col in c["sample"]]
             node = obin = perm = None
             static_w = wflux = None
+            part_starts, part_width = None, 0
             if self.osc_events:
                 # event-by-event oscillation: every event is its own "node"; the shard
                 # is stored sorted by coszen so that the lanes of a wavefront cross the
@@ -352,14 +419,24 @@ class HotPathEngine:
                     if sort_events == "bin":
                         perm = bin_window_order(obin, self.n_bins)
                     elif sort_events == "part":
-                        perm = bin_partition_order(obin, node, self.n_bins,
-                                                   width=672)
+                        # binning beyond the LDS accumulators: partitions = the kernel's LDS windows
+                        width = _lib.lib().pisa_hip_hist_window_bins(self.n_bins) if index16 else 0
+                        res = None
+                        if width > 0 and lds_order and block_order and not drop_unbinned:
+                            res = window_partition_order(obin, node, self.n_bins, width)
+                        if res is not None:
+                            perm, part_starts = res
+                            part_width = width
+                        else:
+                            perm = bin_partition_order(obin, node, self.n_bins, width=width if width > 0 else 672)
                     else:
                         perm = torch.argsort(node, stable=True)
                 blocked = (index16 and lds_order and block_order and perm is not None and sort_events == "node"
                            and self.n_bins * 96 <= 65536)
                 if blocked:
                     perm = deposit_block_order(obin, node, window=4096, banks=32)
+                elif part_starts is not None:
+                    pass                      # (bank order applied inside the partitions)
                 elif lds_order and perm is not None and (sort_events == "part" or (
                         sort_events != "bin" and self.n_bins * 96 <= 65536)):
                     perm = perm[lds_bank_order(obin[perm], window=4096, banks=32,
@@ -414,6 +491,11 @@ class HotPathEngine:
                             wq = torch.zeros((n_pad // 256, 4, 64, 2), dtype=torch.float64, device=self.dev)
                             self._keep += [nb16, wq]
                             d.d_node_bin16, d.d_weighted_flux_q = nb16.data_ptr(), wq.data_ptr()
+                            if part_starts is not None:
+                                ps = torch.tensor(part_starts, dtype=torch.int32, device=self.dev)
+                                assert int(ps[-1]) * 256 == n_pad
+                                self._keep.append(ps)
+                                d.d_part_start, d.n_part, d.part_width = ps.data_ptr(), len(part_starts) - 1, part_width
                             wflux = wq
                             self._fill_wflux(wq, cst, flux_d)
                         else:

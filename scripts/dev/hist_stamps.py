@@ -10,7 +10,8 @@ import torch
 from pisa_amd import _lib, synthetic
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
-wl = synthetic.Workload(n_events=n, grid=(200, 100), out_binning="dragon", seed=0)
+binning = sys.argv[2] if len(sys.argv) > 2 else "dragon"
+wl = synthetic.Workload(n_events=n, grid=(200, 100), out_binning=binning, seed=0)
 st = synthetic.DeviceState(wl, compact=True)
 import os
 if os.environ.get("REVERSE"):   # position or identity?  (timing only: the maps come out permuted)
@@ -37,6 +38,9 @@ for k, nm in enumerate(names):
 d = np.diff(t, axis=1)
 for k in range(5):
     print("%-18s -> %-18s median %6.2f max %6.2f" % (names[k], names[k + 1], np.median(d[:, k]), d[:, k].max()))
+order = np.argsort(-t[:, 3])
+print("slowest workgroups (index: loop done, flushed):", " ".join("%d:%.1f/%.1f" % (i, t[i, 3], t[i, 5]) for i in order[:24]))
+print("loop done by workgroup index:", " ".join("%.0f" % x for x in t[:, 3]))
 # per container (workgroups are numbered container by container)
 tot = sum(int(c.n_events) for c in st.cont)
 chunk = -(-tot // 512)

@@ -37,7 +37,7 @@ def test_struct_layout_matches_header(built):
     assert ctypes.sizeof(built.Prob3Params) == (9 + 18 + 18 + 18 + 9) * 8 + 8
     assert ctypes.sizeof(built.Earth) == 8 + 8 + 3 * 64 * 8
     assert ctypes.sizeof(built.Binning) == 8 + 3 * 8 * 3
-    assert ctypes.sizeof(built.Container) == 8 + 5 * 8 + 3 * 8 + 5 * 8 + 4 + 4 + 8 + 8 + 2 * 8
+    assert ctypes.sizeof(built.Container) == 8 + 5 * 8 + 3 * 8 + 5 * 8 + 4 + 4 + 8 + 8 + 2 * 8 + 8 + 4 + 4
 
 
 def test_status_strings_and_no_gpu_behaviour(built):
