@@ -299,7 +299,14 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
 
     STAMP(1);
     if (LDS_ACC) {
-        for (int k = threadIdx.x; k < n_acc * a.copies; k += nthreads) s_acc[k] = 0ull;
+        // (partitioned order: a chunk that reaches into a second partition uses a second window)
+        bool two_win = false;
+        if (QUAD && a.window > 0 && C.part_start) {
+            int p0 = 0;
+            while (p0 + 1 < C.n_part && (int64_t)C.part_start[p0 + 1] * 256 <= start) p0++;
+            two_win = p0 + 1 < C.n_part && (int64_t)C.part_start[p0 + 1] * 256 < end;
+        }
+        for (int k = threadIdx.x; k < n_acc * (two_win ? 2 : a.copies); k += nthreads) s_acc[k] = 0ull;
         if ((PACKED || QUAD) && a.window > 0 && !(QUAD && C.part_start)) {
             __shared__ int s_lo;
             if (threadIdx.x == 0) s_lo = 0x7fffffff;
@@ -380,7 +387,7 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
     // which the L2 atomic units take at full rate (scattered 96 B apart they do not).
     // Workgroups of a container finish together; each starts at a different offset so
     // that they do not all queue on the same limbs at the same moment.
-    auto flush_lds = [&]() {
+    auto flush_win = [&](const unsigned long long *win, int lo, int ncopies) {
         const int rot = (int)((lb * 7 * 64) % n_acc);
         for (int g0 = threadIdx.x; g0 < n_acc; g0 += nthreads) {
             int g = g0 + rot;
@@ -390,11 +397,13 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
             const int q = rem / NL;
             const int j = rem - q * NL;
             const int k = (j * 2 + q) * n_bins + bin;
-            unsigned long long v = s_acc[k];
-            for (int r = 1; r < a.copies; r++) v += s_acc[r * n_acc + k];  // integer: exact
-            if (v != 0ull && bin_lo + bin < (int)a.n_bins) atomicAdd(&g_out[(int64_t)bin_lo * 2 * NL + g], v);
+            unsigned long long v = win[k];
+            for (int r = 1; r < ncopies; r++) v += win[r * n_acc + k];  // integer: exact
+            if (v != 0ull && lo + bin < (int)a.n_bins) atomicAdd(&g_out[(int64_t)lo * 2 * NL + g], v);
         }
     };
+    // partitioned order: the other LDS window (see the QUAD sweep) and the first bin of what it holds
+    int other_lo = -1;
 
     if (QUAD) {
         const double2 *tab = C.pepmu_own ? C.pepmu_own
@@ -410,7 +419,11 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
         // deposit is an LDS deposit, nothing is scanned for the window's position, and only a chunk that
         // straddles a partition boundary flushes twice.  Partition boundaries are multiples of 256 events =
         // one wavefront's sweep.
-        int part = -1;
+        // A chunk that straddles a partition boundary keeps BOTH partitions' windows in LDS (2 x 63 KiB of the
+        // CU's 160): its wavefronts move from one to the other on their own, no barrier, no intermediate flush
+        // (in-kernel stamps: flushing, clearing and restarting in between left the straddling workgroups ~10 us
+        // behind the others); a third partition in one chunk recycles the older window behind a barrier.
+        int part = -1, phase = 0;
         if (LDS_ACC && a.window > 0 && C.part_start) {
             part = 0;
             while (part + 1 < C.n_part && (int64_t)C.part_start[part + 1] * 256 <= start) part++;
@@ -419,6 +432,18 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
         if (part >= 0) {
             const int64_t ps = (int64_t)C.part_start[part] * 256, pe = (int64_t)C.part_start[part + 1] * 256;
             const int64_t lo = ps > start ? ps : start, hi = pe < end ? pe : end;
+            if (phase >= 1) {
+                unsigned long long *win = s_acc + (phase & 1) * n_acc;
+                if (phase >= 2) {     // (workgroup-uniform: the chunk's geometry)
+                    __syncthreads();
+                    flush_win(win, other_lo, 1);
+                    __syncthreads();
+                    for (int k = threadIdx.x; k < n_acc; k += nthreads) win[k] = 0ull;
+                    __syncthreads();
+                }
+                other_lo = bin_lo;
+                my_acc = win;
+            }
             bin_lo = part * a.window;
             q_stop = (hi + 3) >> 2;
             if (lo > start) {     // a later partition of this chunk: its own first loads
@@ -478,15 +503,11 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
             qhave = have_n;
         }
         if (part < 0) break;
-        // next partition of this chunk, if any: flush this window, clear, move on
+        // next partition of this chunk, if any
         const int64_t pe = (int64_t)C.part_start[part + 1] * 256;
         if (pe >= end || part + 1 >= C.n_part) break;
-        __syncthreads();
-        flush_lds();
-        __syncthreads();
-        for (int k = threadIdx.x; k < n_acc * a.copies; k += nthreads) s_acc[k] = 0ull;
-        __syncthreads();
         part++;
+        phase++;
       }
     } else if (PACKED) {
         // packed columns: (node, bin) int2 and (aeff, w0) double2 per event; every load is 16 B
@@ -724,7 +745,8 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
     if (LDS_ACC) {
         __syncthreads();
         STAMP(4);
-        flush_lds();
+        flush_win(my_acc == s_acc || a.copies > 1 ? s_acc : s_acc + n_acc, bin_lo, a.copies);
+        if (other_lo >= 0) flush_win(my_acc == s_acc ? s_acc + n_acc : s_acc, other_lo, 1);
     }
     STAMP(5);
 }
@@ -1339,6 +1361,29 @@ static int run_hist(const ContDev *conts, int n_cont, int mode, const DevBinning
         size_t shmem = lds ? (size_t)lds_bytes * copies : 0;
         a.copies = lds ? copies : 1;
         a.window = window;
+        bool parts = false;
+        for (int c = 0; c < nc; c++) parts = parts || a.cont[c].part_start != nullptr;
+        if (parts) {
+            // partitioned order: two LDS windows per workgroup (a chunk may reach into a second partition);
+            // beyond the default 64 KiB of dynamic LDS, asked for once per device
+            const size_t want = (size_t)lds_bytes * 2;
+            static std::atomic<uint64_t> attr_set{0};
+            int dev = 0;
+            PISA_TRY_HIP(hipGetDevice(&dev));
+            const uint64_t bit = 1ull << (dev & 63);
+            bool ok = (int64_t)want <= device_lds_bytes() - 256;
+            if (ok && !(attr_set.load(std::memory_order_acquire) & bit)) {
+                ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&hist_accumulate_kernel<7, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)(device_lds_bytes() - 256)) == hipSuccess;
+                if (ok) attr_set.fetch_or(bit, std::memory_order_release);
+            }
+            if (ok) {
+                shmem = want;
+            } else {      // no room for two windows on this part: the general window path
+                for (int c = 0; c < nc; c++) { a.cont[c].part_start = nullptr; a.cont_chunk[c] = 0; }
+            }
+        }
         unsigned long long *out = reinterpret_cast<unsigned long long *>(d_limbs);
         if (g_prof_start) PISA_TRY_HIP(hipEventRecord(g_prof_start, s));
 #define LAUNCH(M, L) hipLaunchKernelGGL((hist_accumulate_kernel<M, L>), grid_dim, block, shmem, s, a, out, d_status)
