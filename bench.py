@@ -43,7 +43,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB
 FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 L3_BYTES = 256 * 2 ** 20
 ALL_LEGS = ("multi_point", "fit_c4_engine", "fit_c4", "osc_example_c1", "l3_exceeding", "exact_association", "coordinate_form", "fine_binning",
-            "update_flux", "node_flux", "pipeline_boundary", "icecube3y_boundary", "events_c2", "events_c5", "events_c5_full", "kde_c3")
+            "update_flux", "node_flux", "pipeline_boundary", "icecube3y_boundary", "events_c2", "events_c2_decay", "events_c5", "events_c5_full", "kde_c3")
 # the legs that also run with N > 1 (every rank takes part: configs C4 and C5, the multi-point sweep)
 DIST_LEGS = ("multi_point", "fit_c4_engine", "fit_c4", "events_c5")
 
@@ -754,7 +754,7 @@ def leg_icecube3y(torch, n_events, steps):
 
 
 def leg_events(synthetic, torch, n_events, steps, nsi, rank=0, world=1, share=None, sync=None, reduce_max=None,
-               on_device=False):
+               on_device=False, decay=False):
     """configs C2 / C5 (per-GPU share): prob3 EVENT BY EVENT (layers rebuilt per event in-kernel from the
     PREM table in LDS) + fused reweight + 10x10 histogram + LLH.  N > 1 (C5: 1e8 events on 8 GPUs): every
     rank holds `n_events` events of its own (seed = rank), the limbs are all-reduced over the ranks
@@ -776,8 +776,9 @@ def leg_events(synthetic, torch, n_events, steps, nsi, rank=0, world=1, share=No
         n.eps_emu, n.eps_etau, n.eps_mutau = ((0.07, np.deg2rad(340)), (0.06, np.deg2rad(35)),
                                               (0.003, np.deg2rad(175)))  # numba_osc_tests.py:129-136
         mat_pot = np.diag([1.0, 0, 0]).astype(complex) + n.eps_matrix
-    st.make_pseudo_data(wl.osc_params(mat_pot=mat_pot), seed=0)
-    plist = param_list(wl, 3 + steps, mat_pot=mat_pot)
+    dec = 1e-4 if decay else None     # decay_alpha3 in eV^2: the decay instantiation of the event kernel
+    st.make_pseudo_data(wl.osc_params(mat_pot=mat_pot, decay_alpha3=dec), seed=0)
+    plist = param_list(wl, 3 + steps, mat_pot=mat_pot, decay_alpha3=dec)
     # eval_host: the LLH arrives in pinned host memory (what a fit loop reads), as in the headline loop
     sync = sync or torch.cuda.synchronize
     reduce_max = reduce_max or (lambda x: x)
@@ -805,7 +806,7 @@ def leg_events(synthetic, torch, n_events, steps, nsi, rank=0, world=1, share=No
            "events_generated": "in HBM (torch generator)" if on_device else "on the host (numpy RandomState)",
            "workload": "%d events%s, prob3 event by event (PREM-12%s) + fused reweight + 10x10 hist + LLH"
                        % (wl.n_events * world, (" on %d GPUs (%d each, limbs all-reduced)" % (world, wl.n_events))
-                          if world > 1 else "", ", std NSI" if nsi else "")}
+                          if world > 1 else "", (", std NSI" if nsi else "") + (", neutrino decay" if decay else ""))}
     if world > 1:
         import torch.distributed as dist
 
@@ -817,7 +818,7 @@ def leg_events(synthetic, torch, n_events, steps, nsi, rank=0, world=1, share=No
     # executed fp64 flops per event of prob3_events_kernel from the committed SQ_INSTS_VALU_*_F64
     # counter passes (scripts/profile_round.sh); not measured in this run
     cal, src = latest_profile("events_flops.json")
-    key = "nsi" if nsi else "std"
+    key = "decay" if decay else ("nsi" if nsi else "std")
     if cal is not None and key in cal:
         fpe = cal[key]["flop_per_event"]
         ach = fpe * wl.n_events / t_osc / 1e12
@@ -1312,6 +1313,8 @@ def main(argv=None, hooks=None):
             elif name == "events_c5":
                 legs[name] = leg_events(synthetic, torch, 1.25e7, 6, nsi=True, rank=rank, world=world,
                                         share=st if dist_on else None, sync=barrier, reduce_max=max_over_ranks)
+            elif name == "events_c2_decay":
+                legs[name] = leg_events(synthetic, torch, 1e6, 20, nsi=False, decay=True)
             elif name == "events_c5_full":
                 # C5 at the size BASELINE.json states, on ONE device: 1e8 std-NSI events, generated in HBM
                 legs[name] = leg_events(synthetic, torch, 1e8, 3, nsi=True, on_device=True)

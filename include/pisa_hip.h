@@ -259,6 +259,10 @@ typedef struct {
 /* 0 if the fused kernels keep all n_bins accumulators of a container in LDS, else the number of
  * consecutive bins W their LDS window holds (a multiple of 32). */
 int pisa_hip_hist_window_bins(int64_t n_bins);
+/* Workgroups the fused kernels give each container of a launch on the current device (a hint for a caller
+ * that lays out the partitioned order: partitions that are whole numbers of a container's per-workgroup share
+ * keep every workgroup inside one partition; any other layout is handled, only slower). */
+int pisa_hip_hist_workgroups(const int64_t *h_n_events, int32_t n_containers, int32_t *h_workgroups);
 
 /* Fused  prob3.apply (prob3.py:621-622, with the grid->event lookup of
  * container.py:981-1012 / translation.py:427-438)  +  aeff.apply

@@ -37,6 +37,7 @@ namespace pisa {
 constexpr int NL = PISA_HIP_ACC_LIMBS;  // slabs ("limbs") per accumulator
 constexpr int FX_LSB = 116;             // value = sum limb_j * 2^(32j - 116)
 constexpr int MAX_CONT = 16;            // containers per launch (kernarg budget)
+constexpr int PART_MAX = 255;           // partitions of a container's resident order (pisa_hip_container::d_part_start)
 constexpr int HIST_THREADS = 1024;
 constexpr int64_t LDS_ACC_BYTES_MAX = 64 * 1024;
 
@@ -256,6 +257,7 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
     // replica used by this lane: neighbouring lanes (neighbouring, i.e. correlated,
     // events) add into different copies, which cuts same-address serialisation
     unsigned long long *my_acc = s_acc + (LDS_ACC ? (int)(threadIdx.x & (a.copies - 1)) * n_acc : 0);
+    int32_t *s_part = reinterpret_cast<int32_t *>(s_acc + 2 * (size_t)n_acc);   // partitioned order only (host: LDS size)
     unsigned long long *g_out = g_limbs + (int64_t)(a.cont_base + c) * a.n_bins * 2 * NL;
     int bin_lo = 0;
 
@@ -299,14 +301,11 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
 
     STAMP(1);
     if (LDS_ACC) {
-        // (partitioned order: a chunk that reaches into a second partition uses a second window)
-        bool two_win = false;
-        if (QUAD && a.window > 0 && C.part_start) {
-            int p0 = 0;
-            while (p0 + 1 < C.n_part && (int64_t)C.part_start[p0 + 1] * 256 <= start) p0++;
-            two_win = p0 + 1 < C.n_part && (int64_t)C.part_start[p0 + 1] * 256 < end;
-        }
-        for (int k = threadIdx.x; k < n_acc * (two_win ? 2 : a.copies); k += nthreads) s_acc[k] = 0ull;
+        // (partitioned order: two windows -- a chunk may reach into a second partition -- and the partition
+        // table in LDS: looking a partition up in global memory is a chain of dependent scalar loads, ~1 us each)
+        const bool parts = QUAD && a.window > 0 && C.part_start;
+        if (parts && (int)threadIdx.x <= C.n_part) s_part[threadIdx.x] = C.part_start[threadIdx.x];   // behind the two windows
+        for (int k = threadIdx.x; k < n_acc * (parts ? 2 : a.copies); k += nthreads) s_acc[k] = 0ull;
         if ((PACKED || QUAD) && a.window > 0 && !(QUAD && C.part_start)) {
             __shared__ int s_lo;
             if (threadIdx.x == 0) s_lo = 0x7fffffff;
@@ -426,11 +425,11 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
         int part = -1, phase = 0;
         if (LDS_ACC && a.window > 0 && C.part_start) {
             part = 0;
-            while (part + 1 < C.n_part && (int64_t)C.part_start[part + 1] * 256 <= start) part++;
+            while (part + 1 < C.n_part && (int64_t)s_part[part + 1] * 256 <= start) part++;
         }
       for (;;) {
         if (part >= 0) {
-            const int64_t ps = (int64_t)C.part_start[part] * 256, pe = (int64_t)C.part_start[part + 1] * 256;
+            const int64_t ps = (int64_t)s_part[part] * 256, pe = (int64_t)s_part[part + 1] * 256;
             const int64_t lo = ps > start ? ps : start, hi = pe < end ? pe : end;
             if (phase >= 1) {
                 unsigned long long *win = s_acc + (phase & 1) * n_acc;
@@ -504,7 +503,7 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
         }
         if (part < 0) break;
         // next partition of this chunk, if any
-        const int64_t pe = (int64_t)C.part_start[part + 1] * 256;
+        const int64_t pe = (int64_t)s_part[part + 1] * 256;
         if (pe >= end || part + 1 >= C.n_part) break;
         part++;
         phase++;
@@ -1366,7 +1365,7 @@ static int run_hist(const ContDev *conts, int n_cont, int mode, const DevBinning
         if (parts) {
             // partitioned order: two LDS windows per workgroup (a chunk may reach into a second partition);
             // beyond the default 64 KiB of dynamic LDS, asked for once per device
-            const size_t want = (size_t)lds_bytes * 2;
+            const size_t want = (size_t)lds_bytes * 2 + (PART_MAX + 1) * sizeof(int32_t);   // + the partition table
             static std::atomic<uint64_t> attr_set{0};
             int dev = 0;
             PISA_TRY_HIP(hipGetDevice(&dev));
@@ -1420,6 +1419,18 @@ static int run_hist(const ContDev *conts, int n_cont, int mode, const DevBinning
 }  // namespace pisa
 
 using namespace pisa;
+
+PISA_API int pisa_hip_hist_workgroups(const int64_t *h_n_events, int32_t n_containers, int32_t *h_workgroups) {
+    if (!h_n_events || !h_workgroups || n_containers < 1) return PISA_HIP_ERR_INVALID;
+    for (int base = 0; base < n_containers; base += MAX_CONT) {
+        const int nc = n_containers - base < MAX_CONT ? n_containers - base : MAX_CONT;
+        int64_t chunk = 0;
+        int32_t blk_start[MAX_CONT + 1];
+        plan_blocks(h_n_events + base, nc, HIST_THREADS, chunk, blk_start);
+        for (int c = 0; c < nc; c++) h_workgroups[base + c] = blk_start[c + 1] - blk_start[c];
+    }
+    return PISA_HIP_OK;
+}
 
 PISA_API int pisa_hip_hist_window_bins(int64_t n_bins) {
     if (n_bins < 1) return -1;
@@ -1511,7 +1522,7 @@ static int reweight_hist_impl(const pisa_hip_container *h_containers, int32_t n_
         d.wflux = reinterpret_cast<const double2 *>(h.d_weighted_flux);
         d.idx16 = h.d_node_bin16;
         d.wflux_q = reinterpret_cast<const double2 *>(h.d_weighted_flux_q);
-        d.part_start = (h.d_part_start && h.n_part >= 1 && h.part_width > 0) ? h.d_part_start : nullptr;
+        d.part_start = (h.d_part_start && h.n_part >= 1 && h.n_part <= PART_MAX && h.part_width > 0) ? h.d_part_start : nullptr;
         d.n_part = h.n_part;
         d.part_width = h.part_width;
         d.scale = h.scale;

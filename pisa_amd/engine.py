@@ -119,7 +119,39 @@ def bin_partition_order(obin, node, n_bins, width=672):
     return torch.argsort(key, stable=True)
 
 
-def window_partition_order(obin, node, n_bins, width, block=256):
+def _aligned_partition_blocks(dep_blocks, total_blocks, n_wg):
+    """blocks per partition such that every partition is a whole number of a workgroup's share (`chunk` =
+    ceil(total / n_wg) blocks; the last partition takes what is left): [blocks], or None if it cannot be done
+    (fewer workgroups than non-empty partitions, a partition's depositing blocks beyond its share)"""
+    n_part = len(dep_blocks)
+    if n_wg < 1 or total_blocks < 1:
+        return None
+    chunk = -(-total_blocks // n_wg)
+    wg_used = -(-total_blocks // chunk)                 # workgroups that really receive events
+    need = [-(-b // chunk) for b in dep_blocks]         # workgroups a partition needs at the very least
+    last = max((p for p in range(n_part) if dep_blocks[p] > 0), default=None)
+    if last is None or sum(need) > wg_used:
+        return None
+    g = list(need)
+    spare = wg_used - sum(g)
+    tot = max(1, sum(dep_blocks))
+    # the spare workgroups in proportion to the depositing blocks (largest remainder)
+    want = [wg_used * b / tot for b in dep_blocks]
+    while spare > 0:
+        p = max(range(n_part), key=lambda p: want[p] - g[p])
+        g[p] += 1
+        spare -= 1
+    sizes = [g[p] * chunk for p in range(n_part)]
+    # the partitions behind the last depositing one are empty; the last depositing one ends with the column
+    for p in range(last + 1, n_part):
+        sizes[p] = 0
+    sizes[last] = total_blocks - sum(sizes[:last])
+    if sizes[last] < dep_blocks[last] or any(sz < b for sz, b in zip(sizes, dep_blocks)):
+        return None
+    return sizes
+
+
+def window_partition_order(obin, node, n_bins, width, block=256, n_wg=None):
     """Resident order of the 16-bit index form for a binning beyond the LDS accumulators (`width` =
     `pisa_hip_hist_window_bins`): the events are cut into partitions, partition p holding every event that
     deposits into bins [p width, (p+1) width) -- sorted by calc-grid node and in the LDS-bank-aware order, as for
@@ -151,12 +183,25 @@ def window_partition_order(obin, node, n_bins, width, block=256):
         return None
     dep_blocks = [(k + t) // block for k, t in zip(n_dep, top)]
     idle_blocks = (n - sum(k + t for k, t in zip(n_dep, top))) // block
-    # idle blocks dealt to the partitions in proportion to their depositing blocks (largest remainder)
-    tot = max(1, sum(dep_blocks))
-    share = [idle_blocks * b // tot for b in dep_blocks]
-    rem = idle_blocks - sum(share)
-    for p in sorted(range(n_part), key=lambda p: -(idle_blocks * dep_blocks[p] % tot))[:rem]:
-        share[p] += 1
+    share = None
+    if n_wg:
+        # partitions of whole per-workgroup shares (`pisa_hip_hist_workgroups`): no workgroup's chunk reaches
+        # into a second partition
+        sizes = _aligned_partition_blocks(dep_blocks, -(-n // block), int(n_wg))   # (the padded column)
+        if sizes is not None:
+            share = [sz - b for sz, b in zip(sizes, dep_blocks)]
+            if n % block:        # the partial last block is made of the idle tail, not of a whole idle block
+                last = max(p for p in range(n_part) if sizes[p] > 0)
+                share[last] -= 1
+            if min(share) < 0 or sum(share) != idle_blocks:
+                share = None
+    if share is None:
+        # idle blocks dealt to the partitions in proportion to their depositing blocks (largest remainder)
+        tot = max(1, sum(dep_blocks))
+        share = [idle_blocks * b // tot for b in dep_blocks]
+        rem = idle_blocks - sum(share)
+        for p in sorted(range(n_part), key=lambda p: -(idle_blocks * dep_blocks[p] % tot))[:rem]:
+            share[p] += 1
     pieces, starts, at = [], [0], 0
     for p in range(n_part):
         body = torch.cat((deps[p], idle[at:at + top[p]]))
@@ -349,6 +394,13 @@ class HotPathEngine:
         self.index16 = index16
         self.n_local = 0
         shards = local_slices([len(c["true_energy"]) for c in containers], rank, world_size)
+        # workgroups the fused kernel will give each container (a layout hint for the partitioned order)
+        import ctypes as C
+
+        n_arr = (C.c_int64 * len(shards))(*[hi - lo for lo, hi in shards])
+        hist_wgs = (C.c_int32 * len(shards))()
+        if not (torch.cuda.is_available() and _lib.lib().pisa_hip_hist_workgroups(n_arr, len(shards), hist_wgs) == 0):
+            hist_wgs = [0] * len(shards)
 
         def column(x, sl):
             """this rank's slice of an event column -- host array or device tensor (a workload generated in
@@ -423,7 +475,7 @@ class HotPathEngine:
                         width = _lib.lib().pisa_hip_hist_window_bins(self.n_bins) if index16 else 0
                         res = None
                         if width > 0 and lds_order and block_order and not drop_unbinned:
-                            res = window_partition_order(obin, node, self.n_bins, width)
+                            res = window_partition_order(obin, node, self.n_bins, width, n_wg=hist_wgs[len(self.cont)])
                         if res is not None:
                             perm, part_starts = res
                             part_width = width

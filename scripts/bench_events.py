@@ -20,12 +20,14 @@ ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--nsi", action="store_true", help="standard-NSI matter potential (config C5)")
 ap.add_argument("--decay", action="store_true", help="neutrino decay on (decay_alpha3 = 1e-4 eV^2): the decay "
                                                      "instantiation of the event kernel")
+ap.add_argument("--on-device", action="store_true", help="generate the sample in HBM (C5 at its full 1e8 events)")
 args = ap.parse_args()
 
 from pisa_amd import kernels as K
 from pisa_amd import synthetic
 
-wl = synthetic.Workload(n_events=int(args.events), grid=(10, 10), out_binning="example2d", seed=0)
+wl = synthetic.Workload(n_events=int(args.events), grid=(10, 10), out_binning="example2d", seed=0,
+                        on_device=args.on_device)
 st = synthetic.DeviceState(wl, osc_mode="events", compact=True)
 mat_pot = None
 if args.nsi:

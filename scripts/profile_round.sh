@@ -28,8 +28,9 @@ pmc_pair () {  # name, extra bench args
 pmc_pair main ""
 pmc_pair l3 "--events 4e7"
 pmc_pair coord "--coordinate-form"
-for v in std nsi; do
-  F=""; [ $v = nsi ] && F="--nsi"
+pmc_pair fine "--binning fine3d"
+for v in std nsi decay; do
+  F=""; [ $v = nsi ] && F="--nsi"; [ $v = decay ] && F="--decay"
   rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/pmc_events_$v -o p -- python3 scripts/bench_events.py --events 1e6 --steps 3 --warmup 1 $F > $OUT/events_$v.json 2> $OUT/pmc_events_$v.log
   cp $OUT/pmc_events_$v/p_counter_collection.csv $OUT/pmc_events_$v.csv
 done
@@ -57,6 +58,7 @@ trace fine python3 bench.py $LEAN --no-kernel-timing --steps 200 --binning fine3
 trace update_flux python3 bench.py --no-cpu-baseline --no-drop-probe --no-batch-probe --no-kernel-timing --steps 50 --legs update_flux
 trace events_c2 python3 scripts/bench_events.py --events 1e6 --steps 20
 trace events_c5 python3 scripts/bench_events.py --events 1.25e7 --nsi --steps 6
+trace events_c5_full python3 scripts/bench_events.py --events 1e8 --nsi --steps 3 --on-device
 trace events_c2_decay python3 scripts/bench_events.py --events 1e6 --steps 20 --decay
 trace events_c5_decay python3 scripts/bench_events.py --events 1.25e7 --nsi --steps 6 --decay
 for K in 3 5 9; do trace multi_K$K python3 scripts/dev/multi_probe.py 1e7 $K; done
@@ -113,11 +115,12 @@ def traffic(tag, label, alg, fname):
 traffic("main", "hist_accumulate_kernel<7,true> (16-bit index layout, 20 B/event), 9999996 events", 20 * 9999996, "traffic.json")
 traffic("l3", "hist_accumulate_kernel<7,true>, 39999996 events (800 MB resident: beyond the 256 MiB Infinity Cache)", 20 * 39999996, "traffic_l3_exceeding.json")
 traffic("coord", "hist_accumulate_kernel<1,true> (coordinate form, SURVEY 8(d) 72 B/event), 9999996 events", 72 * 9999996, "traffic_coordinate_form.json")
+traffic("fine", "hist_accumulate_kernel<7,true>, 40x40x3 = 4 800 output bins (partitioned LDS-window order), 9999996 events", 20 * 9999996, "traffic_fine_binning.json")
 # executed fp64 lane operations of prob3_events_kernel.  One evaluation = one launch per sign, each over
 # the events of that sign: the counters are summed over all launches and divided by the summed grid
 # sizes (threads = events, padded to whole wavefronts), i.e. per event of the launch it belongs to.
 ev = {}
-for v in ("std", "nsi"):
+for v in ("std", "nsi", "decay"):
     tot, threads, launches = {}, {}, set()
     for r in csv.DictReader(open("%s/pmc_events_%s.csv" % (OUT, v))):
         if "prob3_events" not in r["Kernel_Name"]:

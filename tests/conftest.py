@@ -50,8 +50,11 @@ def run_dev_case(case, *args, timeout=900):
     (-DPISA_DEV_PROBES): the product library has no run-time switches"""
     import subprocess
 
-    if not os.path.exists(DEV_LIB):
-        subprocess.check_call(["make", "-s", "-j4", "-C", os.path.join(ROOT, "pisa_amd", "csrc"), "dev"])
+    src = os.path.join(ROOT, "pisa_amd", "csrc")
+    # (built by __graft_entry__.build(); rebuilt here only if missing or older than a source)
+    if not os.path.exists(DEV_LIB) or subprocess.call(["make", "-q", "-C", src, "dev"],
+                                                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) != 0:
+        subprocess.check_call(["make", "-s", "-j8", "-C", src, "dev"])
     env = dict(os.environ, PISA_HIP_LIB=DEV_LIB, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     res = subprocess.run([sys.executable, "-m", "tests.dev_cases", case] + [str(a) for a in args], env=env, cwd=ROOT,
                          capture_output=True, text=True, timeout=timeout)
