@@ -338,6 +338,35 @@ def check(status):
         raise PisaHipError(status, text)
 
 
+class Prob3ParamsBlock:
+    """ONE parameter block rewritten in place point after point (a fit loop's serial path: the library copies the
+    block during the call).  Matrices that are the very objects handed over last time are not converted again."""
+
+    def __init__(self):
+        self.buf = np.zeros(73, np.float64)
+        self.params = Prob3Params.from_buffer(self.buf)
+        self._last = [None] * 5
+        self._flag = None
+
+    def update(self, dm, mix, mat_pot, decay_flag, mat_decay, lri_pot):
+        buf, last = self.buf, self._last
+        buf[0:9] = dm.reshape(9)
+        buf[9:27] = mix.reshape(9).view(np.float64)
+        if mat_pot is not last[2]:
+            buf[27:45] = np.ascontiguousarray(mat_pot, np.complex128).reshape(9).view(np.float64)
+            last[2] = mat_pot if not getattr(mat_pot, "flags", None) or not mat_pot.flags.writeable else None
+        if mat_decay is not last[3]:
+            buf[45:63] = np.ascontiguousarray(mat_decay, np.complex128).reshape(9).view(np.float64)
+            last[3] = mat_decay if not getattr(mat_decay, "flags", None) or not mat_decay.flags.writeable else None
+        if lri_pot is not last[4]:
+            buf[63:72] = np.asarray(lri_pot, np.float64).reshape(9)
+            last[4] = lri_pot if not getattr(lri_pot, "flags", None) or not lri_pot.flags.writeable else None
+        if decay_flag != self._flag:
+            buf[72:73].view(np.int64)[0] = int(decay_flag)
+            self._flag = decay_flag
+        return self.params
+
+
 def make_prob3_params(dm, mix, mat_pot, decay_flag, mat_decay, lri_pot):
     """the parameter block, assembled in one numpy buffer (slice assignment into the ctypes fields
     converts element by element and costs 9 us per block; this is 3 us)"""

@@ -207,9 +207,13 @@ class Param:
 
     def validate_value(self, val):
         if self._range is not None and isinstance(val, Quantity):
-            lo, hi = self._range[0].m_as(self._units), self._range[1].m_as(self._units)
-            v = val.m_as(self._units)
-            if v < min(lo, hi) or v > max(lo, hi):
+            # the range's magnitudes in this parameter's units, converted once per range object
+            c = self.__dict__.get("_range_m")
+            if c is None or c[0] is not self._range or c[1] is not self._range[0] or c[2] is not self._range[1]:
+                lo, hi = self._range[0].m_as(self._units), self._range[1].m_as(self._units)
+                c = self._range_m = (self._range, self._range[0], self._range[1], min(lo, hi), max(lo, hi))
+            v = val.magnitude if val.units is self._units else val.m_as(self._units)
+            if v < c[3] or v > c[4]:
                 raise ValueError("Param %s has a value %s which is not in the range of %s"
                                  % (self.name, val, self._range))
 

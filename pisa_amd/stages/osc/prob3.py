@@ -98,6 +98,7 @@ class prob3(Stage):  # pylint: disable=invalid-name
     # ---------------------------------------------------------------- setup
     def setup_function(self):
         self.osc_params = OscParams()
+        self._std6_seen = None
         if self.nsi_type == "vacuum-like":
             self.nsi_params = VacuumLikeNSIParams()
         elif self.nsi_type == "standard":
@@ -166,12 +167,22 @@ class prob3(Stage):  # pylint: disable=invalid-name
             if prm.value.units == ureg.dimensionless:
                 raise ValueError("%s is dimensionless, but needs units rad or deg!" % prm.name)
         o = self.osc_params
-        o.theta12 = t12.m_in("rad")
-        o.theta13 = t13.m_in("rad")
-        o.theta23 = t23.m_in("rad")
-        o.dm21 = d21.m_in("eV**2")
-        o.dm31 = d31.m_in("eV**2")
-        o.deltacp = dcp.m_in("rad")
+        # only what moved since the last point (a fit moves one or two of the six; every setter is a numpy call)
+        seen = getattr(self, "_std6_seen", None)
+        if seen is None or seen[0] is not std6:
+            seen = self._std6_seen = [std6, None, None, None, None, None, None]
+        if seen[1] != t12._ver:
+            o.theta12, seen[1] = t12.m_in("rad"), t12._ver
+        if seen[2] != t13._ver:
+            o.theta13, seen[2] = t13.m_in("rad"), t13._ver
+        if seen[3] != t23._ver:
+            o.theta23, seen[3] = t23.m_in("rad"), t23._ver
+        if seen[4] != d21._ver:
+            o.dm21, seen[4] = d21.m_in("eV**2"), d21._ver
+        if seen[5] != d31._ver:
+            o.dm31, seen[5] = d31.m_in("eV**2"), d31._ver
+        if seen[6] != dcp._ver:
+            o.deltacp, seen[6] = dcp.m_in("rad"), dcp._ver
         if self.nsi_type == "vacuum-like":
             n = self.nsi_params
             n.eps_scale = p.eps_scale.value.m_as("dimensionless")
@@ -209,8 +220,11 @@ class prob3(Stage):  # pylint: disable=invalid-name
         if self.tomography_type is not None:
             self._apply_tomography()
         mix = o.mix_matrix_reparam_complex if self.reparam_mix_matrix else o.mix_matrix_complex
-        return _lib.make_prob3_params(o.dm_matrix, mix, self.gen_mat_pot_matrix_complex,
-                                      self.decay_flag, self.decay_matrix, self.lri_pot)
+        block = getattr(self, "_params_block", None)
+        if block is None:
+            block = self._params_block = _lib.Prob3ParamsBlock()
+        return block.update(o.dm_matrix, mix, self.gen_mat_pot_matrix_complex, self.decay_flag, self.decay_matrix,
+                            self.lri_pot)
 
     def _apply_tomography(self):
         """prob3.py:519-536.  `Layers.scaling` rewrites `rhos` from the scaled PREM column, then
