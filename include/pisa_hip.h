@@ -433,6 +433,20 @@ int pisa_hip_finalize_metric_split(int64_t *d_limbs, int32_t n_points, int32_t n
                                    int32_t *d_status, int32_t *d_metric_status, int32_t clear_limbs,
                                    void *stream);
 
+/* pisa_hip_finalize_metric_split with n_parts = 4 or 16 workgroups per point: workgroup k takes the bins
+ * b = k (mod n_parts) and leaves its sum in partial[n_parts * point + k]; the caller joins them along the
+ * kernel's own reduction tree, cut n_parts wide:
+ *      for (w = n_parts / 2; w >= 1; w /= 2) for (i = 0; i < w; i++) partial[i] += partial[i + w];   total = partial[0]
+ * (n_parts = 4: (p0 + p2) + (p1 + p3)) -- pisa_hip_finalize_metric_multi's value bit for bit.  Sixteen workgroups
+ * leave every thread at most one conversion of a limb sum: the tail of a 3 072-accumulator evaluation drops
+ * from 6.4 to ~3.5 us. */
+int pisa_hip_finalize_metric_parts(int64_t *d_limbs, int32_t n_points, int32_t n_containers,
+                                   int64_t n_bins, double *d_hist, double *d_sumw2, int32_t kind,
+                                   const double *d_actual, const double *d_scale,
+                                   int64_t scale_point_stride, const double *d_extra, double *partial,
+                                   int32_t n_parts, int32_t *d_status, int32_t *d_metric_status,
+                                   int32_t clear_limbs, void *stream);
+
 /* ------------------------------------------------ one template evaluation in ONE call
  * What `Pipeline.get_outputs()` followed by `Map.metric_total` amount to for the chain
  * osc.prob3 (calc grid) -> aeff.aeff -> utils.hist -> metric (pisa/core/pipeline.py:537-558 running
@@ -441,9 +455,9 @@ int pisa_hip_finalize_metric_split(int64_t *d_limbs, int32_t n_points, int32_t n
  * parameter points (the event columns, the binnings, the grid plan, the output buffers); per point
  *      pisa_hip_evaluator_eval(ev, params, kind, d_actual, ...)
  * enqueues  pisa_hip_prob3_grid_planned (gather tables only) -> pisa_hip_reweight_hist[_acc] ->
- * [all-reduce of the limbs] -> pisa_hip_finalize_metric_split (clear_limbs = 1)  -- the same launches,
- * the same bits as those four calls -- and, if asked to, waits for the value: the metric's four partial
- * sums arrive in device-mapped pinned host memory and are joined as pisa_hip_finalize_metric_split
+ * [all-reduce of the limbs] -> pisa_hip_finalize_metric_parts (16 workgroups, clear_limbs = 1)  -- the same
+ * launches, the same bits as those four calls -- and, if asked to, waits for the value: the metric's sixteen
+ * partial sums arrive in device-mapped pinned host memory and are joined as pisa_hip_finalize_metric_parts
  * documents.  A host binding crosses its FFI once per evaluation instead of three or four times.
  * kind = PISA_HIP_METRIC_CHI2 goes through the one-workgroup pisa_hip_finalize_metric.
  *
@@ -467,7 +481,7 @@ typedef struct {
     double *d_pepmu;                        /* [2][3][nodes][2] gather tables (written per point) */
     int64_t *d_limbs;                       /* [n_containers][n_bins][2][PISA_HIP_ACC_LIMBS] */
     double *d_hist, *d_sumw2;               /* [n_containers][n_bins] (written per point) */
-    double *partial;                        /* [4] device-mapped pinned host memory */
+    double *partial;                        /* [16] device-mapped pinned host memory */
     int32_t *d_status, *d_metric_status;
     pisa_hip_allreduce_fn allreduce;
     void *comm;

@@ -244,6 +244,7 @@ _SIGS = {
     "pisa_hip_multi_points_per_pass": (C.c_int, [C.c_int64]),
     "pisa_hip_finalize_metric_multi": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "pisa_hip_finalize_metric_split": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "pisa_hip_finalize_metric_parts": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "pisa_hip_profile_events": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pisa_hip_hist_window_bins": (C.c_int, [C.c_int64]),
     "pisa_hip_hist_workgroups": (C.c_int, [C.POINTER(C.c_int64), C.c_int32, C.POINTER(C.c_int32)]),

@@ -64,7 +64,8 @@ PISA_API int pisa_hip_evaluator_eval(pisa_hip_evaluator *ev, const pisa_hip_prob
     const pisa_hip_evaluator_desc &d = ev->d;
     const bool split = kind != PISA_HIP_METRIC_CHI2;
     volatile double *part = d.partial;
-    const int n_part = split ? 4 : 1;
+    constexpr int PARTS = 16;
+    const int n_part = split ? PARTS : 1;
     if (wait_us > 0)
         for (int k = 0; k < n_part; k++) part[k] = NAN;   // "not yet": a partial sum is never NaN unless an input was negative
     int rc = pisa_hip_prob3_grid_planned(h_params, d.plan, d.d_energy, d.n_e, d.e_major, nullptr, nullptr, d.d_pepmu,
@@ -83,9 +84,9 @@ PISA_API int pisa_hip_evaluator_eval(pisa_hip_evaluator *ev, const pisa_hip_prob
         }
     }
     if (split)
-        rc = pisa_hip_finalize_metric_split(d.d_limbs, 1, (int32_t)ev->cont.size(), ev->n_bins, d.d_hist, d.d_sumw2, kind,
-                                            d_actual, nullptr, 0, nullptr, d.partial, d.d_status, d.d_metric_status, 1,
-                                            stream);
+        rc = pisa_hip_finalize_metric_parts(d.d_limbs, 1, (int32_t)ev->cont.size(), ev->n_bins, d.d_hist, d.d_sumw2, kind,
+                                            d_actual, nullptr, 0, nullptr, d.partial, PARTS, d.d_status,
+                                            d.d_metric_status, 1, stream);
     else
         rc = pisa_hip_finalize_metric((int64_t *)d.d_limbs, (int32_t)ev->cont.size(), ev->n_bins, d.d_hist, d.d_sumw2, kind,
                                       d_actual, d.partial, d.d_status, d.d_metric_status, 1, stream);
@@ -94,7 +95,7 @@ PISA_API int pisa_hip_evaluator_eval(pisa_hip_evaluator *ev, const pisa_hip_prob
     // completion signal has travelled through the runtime: poll them.
     const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(wait_us);
     bool have = false;
-    double p[4] = {0, 0, 0, 0};
+    double p[PARTS] = {0};
     for (unsigned it = 0;; it++) {
         have = true;
         for (int k = 0; k < n_part; k++) {
@@ -109,6 +110,9 @@ PISA_API int pisa_hip_evaluator_eval(pisa_hip_evaluator *ev, const pisa_hip_prob
         PISA_TRY_HIP(hipStreamSynchronize(as_stream(stream)));
         for (int k = 0; k < n_part; k++) p[k] = part[k];
     }
-    *value = split ? (p[0] + p[2]) + (p[1] + p[3]) : p[0];
+    if (split)      // the kernel's reduction tree, its last four levels
+        for (int w = PARTS / 2; w >= 1; w >>= 1)
+            for (int i = 0; i < w; i++) p[i] += p[i + w];
+    *value = p[0];
     return PISA_HIP_OK;
 }

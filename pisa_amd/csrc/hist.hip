@@ -1090,7 +1090,7 @@ finalize_metric_kernel(long long *__restrict__ limbs, int n_cont, int n_bins,
     const double *expected = s_map, *sigma2 = s_map + n_tot;
     double acc = 0.0;
     if (threadIdx.x < 256) {
-        // (SPLIT > 1: b mod 4 = thread mod 4 -- the threads of the other residue classes have no bin here)
+        // (SPLIT > 1: b mod SPLIT = thread mod SPLIT -- the threads of the other residue classes have no bin here)
         for (int b = threadIdx.x; b < n_bins && (SPLIT == 1 || (int)(threadIdx.x % SPLIT) == part); b += 256) {
             const double k = (b == (int)threadIdx.x) ? k_first : actual[b];
             double lam = 0.0, s2 = 0.0;
@@ -1668,26 +1668,34 @@ static int finalize_metric_impl(int64_t *d_limbs, int32_t n_points, int32_t n_co
                                 const double *d_actual, const double *d_scale,
                                 int64_t scale_point_stride, const double *d_extra, double *total,
                                 int32_t *d_status, int32_t *d_metric_status,
-                                int32_t clear_limbs, void *stream, bool split) {
+                                int32_t clear_limbs, void *stream, int n_parts) {
     if (!d_limbs || !d_hist || !d_sumw2 || !d_actual || !total || n_containers < 1 || n_bins < 1 ||
         n_points < 1 || n_points > PISA_HIP_MAX_POINTS)
         return PISA_HIP_ERR_INVALID;
     if (kind < PISA_HIP_METRIC_LLH || kind > PISA_HIP_METRIC_MOD_CHI2) return PISA_HIP_ERR_INVALID;
+    if (n_parts != 1 && n_parts != 4 && n_parts != 16) return PISA_HIP_ERR_INVALID;
+    const bool split = n_parts > 1;
     if (split && kind == PISA_HIP_METRIC_CHI2) return PISA_HIP_ERR_INVALID;
     if ((int64_t)n_containers * n_bins > PISA_HIP_FINALIZE_METRIC_MAX) return PISA_HIP_ERR_INVALID;
     const int n_tot = (int)(n_containers * n_bins);
     // a thread per accumulator of the workgroup's share where 1 024 threads allow it
-    int threads = (((split ? (2 * n_tot + 3) / 4 : n_tot) + 63) / 64) * 64;
+    int threads = (((split ? (2 * n_tot + n_parts - 1) / n_parts : n_tot) + 63) / 64) * 64;
     if (threads < 256) threads = 256;  // the metric reduction tree is 256 wide
     if (threads > 1024) threads = 1024;
     const int64_t limb_stride = (int64_t)n_tot * 2 * NL;
     auto launch = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3((unsigned)(n_points * (split ? 4 : 1))), dim3(threads), (size_t)n_tot * 16,
+        hipLaunchKernelGGL(kern, dim3((unsigned)(n_points * n_parts)), dim3(threads), (size_t)n_tot * 16,
                            as_stream(stream), (long long *)d_limbs, (int)n_containers, (int)n_bins, d_hist, d_sumw2,
                            d_actual, total, d_status, d_metric_status, (int)clear_limbs, d_scale, d_extra,
                            limb_stride, (int64_t)scale_point_stride);
     };
-    if (split) {
+    if (n_parts == 16) {
+        switch (kind) {
+        case PISA_HIP_METRIC_LLH: launch(finalize_metric_kernel<PISA_HIP_METRIC_LLH, 16>); break;
+        case PISA_HIP_METRIC_POISSON_LLH: launch(finalize_metric_kernel<PISA_HIP_METRIC_POISSON_LLH, 16>); break;
+        default: launch(finalize_metric_kernel<PISA_HIP_METRIC_MOD_CHI2, 16>);
+        }
+    } else if (split) {
         switch (kind) {
         case PISA_HIP_METRIC_LLH: launch(finalize_metric_kernel<PISA_HIP_METRIC_LLH, 4>); break;
         case PISA_HIP_METRIC_POISSON_LLH: launch(finalize_metric_kernel<PISA_HIP_METRIC_POISSON_LLH, 4>); break;
@@ -1712,7 +1720,7 @@ PISA_API int pisa_hip_finalize_metric_multi(int64_t *d_limbs, int32_t n_points, 
                                             int32_t *d_status, int32_t *d_metric_status,
                                             int32_t clear_limbs, void *stream) {
     return finalize_metric_impl(d_limbs, n_points, n_containers, n_bins, d_hist, d_sumw2, kind, d_actual, d_scale,
-                                scale_point_stride, d_extra, total, d_status, d_metric_status, clear_limbs, stream, false);
+                                scale_point_stride, d_extra, total, d_status, d_metric_status, clear_limbs, stream, 1);
 }
 
 PISA_API int pisa_hip_finalize_metric_split(int64_t *d_limbs, int32_t n_points, int32_t n_containers,
@@ -1722,7 +1730,19 @@ PISA_API int pisa_hip_finalize_metric_split(int64_t *d_limbs, int32_t n_points, 
                                             int32_t *d_status, int32_t *d_metric_status,
                                             int32_t clear_limbs, void *stream) {
     return finalize_metric_impl(d_limbs, n_points, n_containers, n_bins, d_hist, d_sumw2, kind, d_actual, d_scale,
-                                scale_point_stride, d_extra, partial, d_status, d_metric_status, clear_limbs, stream, true);
+                                scale_point_stride, d_extra, partial, d_status, d_metric_status, clear_limbs, stream, 4);
+}
+
+PISA_API int pisa_hip_finalize_metric_parts(int64_t *d_limbs, int32_t n_points, int32_t n_containers,
+                                            int64_t n_bins, double *d_hist, double *d_sumw2, int32_t kind,
+                                            const double *d_actual, const double *d_scale,
+                                            int64_t scale_point_stride, const double *d_extra, double *partial,
+                                            int32_t n_parts, int32_t *d_status, int32_t *d_metric_status,
+                                            int32_t clear_limbs, void *stream) {
+    if (n_parts != 4 && n_parts != 16) return PISA_HIP_ERR_INVALID;
+    return finalize_metric_impl(d_limbs, n_points, n_containers, n_bins, d_hist, d_sumw2, kind, d_actual, d_scale,
+                                scale_point_stride, d_extra, partial, d_status, d_metric_status, clear_limbs, stream,
+                                n_parts);
 }
 
 PISA_API int pisa_hip_finalize_metric_scaled(int64_t *d_limbs, int32_t n_containers, int64_t n_bins,

@@ -577,8 +577,8 @@ class HotPathEngine:
         self.metric_out = torch.zeros(1, dtype=torch.float64, device=self.dev)
         self.metric_status = torch.zeros(1, dtype=torch.int32, device=self.dev)
         # [0]: the metric as the tail kernel leaves it; [0:4]: the four partial sums of its split form
-        # (`pisa_hip_finalize_metric_split`: total = (p0 + p2) + (p1 + p3), the one-workgroup value bit for bit)
-        self.metric_host = torch.zeros(4, dtype=torch.float64).pin_memory()
+        # (`pisa_hip_finalize_metric_parts`, 16 workgroups: joined along the kernel's own reduction tree, bit for bit)
+        self.metric_host = torch.zeros(16, dtype=torch.float64).pin_memory()
         self._metric_host_np = self.metric_host.numpy()
         self.split_tail = True     # four tail workgroups per point (an attribute, not an environment switch)
         self.spin_wait = 50000  # polls of the pinned result (~7 ms) before falling back to a stream sync
@@ -950,15 +950,31 @@ class HotPathEngine:
         pinned memory anyway; not for chi2 (its all-bins-equal rule, stats.py:160-161, needs every bin)"""
         return self.split_tail and self.spin_wait > 0 and kind != "chi2"
 
+    TAIL_PARTS = 16   # workgroups of the split tail (`pisa_hip_finalize_metric_parts`)
+
+    @staticmethod
+    def _join_parts(p):
+        """the metric kernel's reduction tree, its last levels: p[i] += p[i + w] for w = n/2 ... 1"""
+        p = [float(v) for v in p]
+        w = len(p) // 2
+        while w >= 1:
+            for i in range(w):
+                p[i] = p[i] + p[i + w]
+            w //= 2
+        return p[0]
+
     def _poll_split(self):
-        """(p0 + p2) + (p1 + p3) of the split tail's partial sums, as soon as all four have arrived"""
+        """the split tail's partial sums joined as the kernel's own tree joins them, as soon as all have arrived"""
         h = self._metric_host_np
+        n = self.TAIL_PARTS
+        hn = h[:n]
+        add = np.add.reduce
         for _ in range(self.spin_wait):
-            a, b, c, d = h[0], h[1], h[2], h[3]
-            if a == a and b == b and c == c and d == d:
-                return (float(a) + float(c)) + (float(b) + float(d))
+            v = add(hn)          # NaN while one of them is missing (one numpy call per poll)
+            if v == v:
+                return self._join_parts(hn)
         torch.cuda.current_stream().synchronize()
-        return (float(h[0]) + float(h[2])) + (float(h[1]) + float(h[3]))
+        return self._join_parts(hn)
 
     def tail_host(self, kind, scale=None, extra=None):
         """phase B: maps + metric against `self.data` of the accumulated limbs, value on the host.
@@ -983,11 +999,11 @@ class HotPathEngine:
             h = self._metric_host_np
             if self._split_ok(kind):
                 h[:] = np.nan
-                rc = a["lib"].pisa_hip_finalize_metric_split(
+                rc = a["lib"].pisa_hip_finalize_metric_parts(
                     a["limbs"], 1, a["n_cont"], self.n_bins, a["hist"], a["sumw2"], K.METRIC_KIND[kind], a["data"],
                     None if scale is None else C.c_void_p(scale.data_ptr()), 0,
                     None if extra is None else C.c_void_p(extra.data_ptr()),
-                    a["out"], a["status"], a["mstatus"], 1, K._stream())
+                    a["out"], self.TAIL_PARTS, a["status"], a["mstatus"], 1, K._stream())
                 self._limbs_zero = self._maps_valid = rc == 0
                 _lib.check(rc)
                 return self._poll_split()
@@ -1121,9 +1137,9 @@ class HotPathEngine:
         if rc == 0:
             self.allreduce()
             if split:
-                rc = lib.pisa_hip_finalize_metric_split(a["limbs"], 1, a["n_cont"], self.n_bins, a["hist"],
+                rc = lib.pisa_hip_finalize_metric_parts(a["limbs"], 1, a["n_cont"], self.n_bins, a["hist"],
                                                         a["sumw2"], K.METRIC_KIND[kind], a["data"], None, 0, None,
-                                                        a["out"], a["status"], a["mstatus"], 1, s)
+                                                        a["out"], self.TAIL_PARTS, a["status"], a["mstatus"], 1, s)
             else:
                 rc = lib.pisa_hip_finalize_metric(a["limbs"], a["n_cont"], self.n_bins, a["hist"],
                                                   a["sumw2"], K.METRIC_KIND[kind], a["data"], a["out"],

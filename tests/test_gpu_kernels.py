@@ -632,32 +632,45 @@ def test_split_tail_equals_one_workgroup_tail_bit_for_bit(K, L, n_cont, n_bins):
         for kind in ("llh", "poisson_llh", "mod_chi2"):
             for with_scale in (False, True):
                 res = []
-                for split in (False, True):
+                # one workgroup | four (`_split`) | four and sixteen through `pisa_hip_finalize_metric_parts`
+                for parts, entry in ((1, "multi"), (4, "split"), (4, "parts"), (16, "parts")):
                     limbs = fill_d.clone()
                     hist = torch.full((n_pts, n_cont, n_bins), -7.0, dtype=torch.float64, device=dev)
                     sumw2 = torch.full_like(hist, -7.0)
-                    tot = torch.full((n_pts * 4,), float("nan"), dtype=torch.float64, device=dev)
+                    tot = torch.full((n_pts * 16,), float("nan"), dtype=torch.float64, device=dev)
                     st = torch.zeros(1, dtype=torch.int32, device=dev)
                     mst = torch.zeros(1, dtype=torch.int32, device=dev)
-                    fn = lib.pisa_hip_finalize_metric_split if split else lib.pisa_hip_finalize_metric_multi
-                    rc = fn(limbs.data_ptr(), n_pts, n_cont, n_bins, hist.data_ptr(), sumw2.data_ptr(),
+                    head = (limbs.data_ptr(), n_pts, n_cont, n_bins, hist.data_ptr(), sumw2.data_ptr(),
                             K.METRIC_KIND[kind], data.data_ptr(), scale.data_ptr() if with_scale else None, 0,
-                            extra.data_ptr() if with_scale else None, tot.data_ptr(), st.data_ptr(), mst.data_ptr(), 1,
-                            None)
+                            extra.data_ptr() if with_scale else None, tot.data_ptr())
+                    rest = (st.data_ptr(), mst.data_ptr(), 1, None)
+                    if entry == "parts":
+                        rc = lib.pisa_hip_finalize_metric_parts(*head, parts, *rest)
+                    else:
+                        rc = (lib.pisa_hip_finalize_metric_split if entry == "split"
+                              else lib.pisa_hip_finalize_metric_multi)(*head, *rest)
                     assert rc == 0
                     torch.cuda.synchronize()
                     t = tot.cpu().numpy()
-                    if split:
-                        t = t.reshape(n_pts, 4)
-                        vals = [(float(p[0]) + float(p[2])) + (float(p[1]) + float(p[3])) for p in t]
+                    if parts > 1:
+                        vals = []
+                        for p in t[: n_pts * parts].reshape(n_pts, parts):
+                            p = [float(v) for v in p]
+                            w = parts // 2
+                            while w >= 1:            # the kernel's reduction tree, its last levels
+                                for i in range(w):
+                                    p[i] = p[i] + p[i + w]
+                                w //= 2
+                            vals.append(p[0])
                     else:
                         vals = [float(v) for v in t[:n_pts]]
                     assert int(limbs.abs().sum().item()) == 0
                     res.append((vals, hist.cpu().numpy(), sumw2.cpu().numpy(), int(st.item()), int(mst.item())))
-                (v0, h0, s0, st0, m0), (v1, h1, s1, st1, m1) = res
-                assert all(np.isfinite(v0)) and v0 == v1, (kind, with_scale, v0, v1)
-                assert np.array_equal(h0, h1) and np.array_equal(s0, s1) and (h0 != -7.0).all()
-                assert (st0, m0) == (st1, m1) == (0, 0)
+                v0, h0, s0, st0, m0 = res[0]
+                for v1, h1, s1, st1, m1 in res[1:]:
+                    assert all(np.isfinite(v0)) and v0 == v1, (kind, with_scale, v0, v1)
+                    assert np.array_equal(h0, h1) and np.array_equal(s0, s1) and (h0 != -7.0).all()
+                    assert (st0, m0) == (st1, m1) == (0, 0)
     # negative observed count: NaN + status in both forms
     bad = data.clone(); bad[n_bins // 2] = -1.0
     for split in (False, True):
