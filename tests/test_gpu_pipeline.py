@@ -719,3 +719,64 @@ def test_binned_pipeline_runs_its_weight_chains_in_one_launch():
     np.testing.assert_array_equal(maps2["numu_cc"].hist.ravel(), alone)
     assert np.abs(maps2["numu_cc"].hist - first["numu_cc"]).max() > 1e-3
     np.testing.assert_array_equal(maps["nue_cc"].hist, first["nue_cc"])      # the first evaluation's maps are intact
+
+
+def test_stage_protocol_outputs_are_lazy_rows_of_the_device_table():
+    """With the plan switched off every evaluation runs the Stage protocol in full; utils.hist then publishes
+    ROWS of the device map table (`BlockRow`) instead of copying maps: `get_outputs()` hands out device-backed
+    Maps (sum and metric on the device), reading a container gives the very numbers, in-place edits +
+    `mark_changed` behave as on any array, Maps somebody keeps survive the next evaluation, and rows nobody read
+    are void afterwards (a clear error, not stale numbers)."""
+    import sys
+
+    from tests.conftest import ROOT
+
+    sys.path.insert(0, ROOT)
+    import bench
+    from pisa_amd.core.container import BlockRow
+    from pisa_amd.core.pipeline import Pipeline
+    from pisa_amd.core.units import ureg
+
+    pipe = Pipeline(bench._pipeline_cfg(120000))
+    pipe.fast_path = False
+    maps = pipe.get_outputs()
+    assert all(m._lazy is not None for m in maps.maps)            # nothing has travelled yet
+    total = sum(maps)
+    data = total.fluctuate("poisson", random_state=0)
+    llh_dev = data.metric_total(expected_values=total, metric="llh")
+    host = {m.name: (m.hist.copy(), m.std_devs.copy()) for m in maps}         # fetches the block
+    ref_total = sum(h for h, _ in host.values())
+    np.testing.assert_array_equal(total.hist, ref_total)
+    from pisa_amd.core.map import Map
+
+    plain = Map("t", ref_total, total.binning)
+    # the tail kernel's value == the generic metric kernel's on the host total (same sums in the same order)
+    assert llh_dev == data.metric_total(expected_values=plain, metric="llh")
+    # the containers hold rows of the same table
+    binning = pipe.output_binning
+    c = pipe.data["numu_cc"]
+    c.representation = binning
+    assert type(c.current_data["weights"]) is BlockRow
+    np.testing.assert_array_equal(c["weights"].reshape(binning.shape), host["numu_cc"][0])
+    np.testing.assert_array_equal(c["errors"].reshape(binning.shape), host["numu_cc"][1])
+    w = c["weights"]
+    w *= 2.0
+    c.mark_changed("weights")
+    np.testing.assert_array_equal(c.device("weights").cpu().numpy().reshape(binning.shape), 2.0 * host["numu_cc"][0])
+    # next evaluation: the kept Maps keep their numbers, the containers get new rows
+    keep = maps["nue_cc"]
+    pipe.params.theta23.value = 48.0 * ureg.degree
+    row_before = pipe.data["nue_cc"].current_data["weights"]
+    maps2 = pipe.get_outputs()
+    np.testing.assert_array_equal(keep.hist, host["nue_cc"][0])
+    assert np.abs(maps2["numu_cc"].hist - host["numu_cc"][0]).max() > 0
+    c2 = pipe.data["nue_cc"]
+    c2.representation = binning
+    assert c2.current_data["weights"] is not row_before
+    # a row of the evaluation before last that nobody read: void
+    pipe.params.theta23.value = 49.0 * ureg.degree
+    stale = c2.current_data["weights"]
+    assert stale.pristine
+    pipe.get_outputs()
+    with pytest.raises(RuntimeError):
+        stale.get_host()
