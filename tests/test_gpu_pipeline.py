@@ -780,3 +780,53 @@ def test_stage_protocol_outputs_are_lazy_rows_of_the_device_table():
     pipe.get_outputs()
     with pytest.raises(RuntimeError):
         stale.get_host()
+
+
+def test_metric_many_without_errors_uses_zero_variance_for_mod_chi2():
+    """round-3 advisor finding: with `output_key = weights` the maps carry no errors and `Map.metric` gives
+    mod_chi2 a zero variance; the one-sweep tail would hand it the histogram's sumw2.  `FastPlan.metric_many`
+    therefore refuses mod_chi2 there (point by point, the serial values), and still takes llh in one sweep;
+    an unknown metric name goes point by point as well (and raises there, as the reference does)."""
+    import sys
+
+    from tests.conftest import ROOT
+
+    sys.path.insert(0, ROOT)
+    import bench
+    from pisa_amd.core.distribution_maker import DistributionMaker
+
+    cfg = bench._pipeline_cfg(120000)
+    cfg["pipeline"]["output_key"] = "weights"
+    dm = DistributionMaker([cfg])
+    for name in dm.params.free.names:
+        if name not in ("theta23", "deltam31"):
+            dm.params.fix(name)
+    data = dm.get_outputs(return_sum=True).fluctuate("poisson", random_state=1)
+    dm.get_outputs(return_sum=True)
+    plan = dm.pipelines[0]._plan
+    assert plan is not None and not plan.with_errors
+    rs = np.random.RandomState(4)
+    x0 = np.array(dm.params.free._rescaled_values)
+    pts = [np.clip(x0 + 0.05 * (rs.rand(len(x0)) - 0.5), 0, 1) for _ in range(3)]
+
+    def serial(points, metric):
+        out = []
+        for x in points:
+            dm._set_rescaled_free_params(x)
+            out.append(data.metric_total(expected_values=dm.get_outputs(return_sum=True), metric=metric)
+                       + dm.params.priors_penalty(metric=metric))
+        return out
+
+    eng = dm.pipelines[0]["hist"]._engine
+    eng.last_many = None
+    want = serial(pts, "mod_chi2")
+    assert dm.metric_many(pts, data, "mod_chi2") == want
+    assert eng.last_many is None                      # no sweep: the guard sent it point by point
+    # zero variance really is what the serial path uses: the sweep's value (sigma^2 = sumw2) would differ
+    hypo = dm.get_outputs(return_sum=True)
+    hypo = hypo.maps[0] if hasattr(hypo, "maps") else hypo
+    assert not np.any(hypo.variances)
+    assert dm.metric_many(pts, data, "llh") == serial(pts, "llh")
+    assert eng.last_many is not None                  # llh: one sweep
+    with pytest.raises(ValueError):
+        dm.metric_many(pts, data, "no_such_metric")
