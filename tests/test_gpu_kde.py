@@ -409,6 +409,16 @@ def test_kde_histogramdd_batch_equals_one_by_one():
             for a, b in zip(got, ref):
                 assert a.shape == b.shape and np.all(np.isfinite(a))
                 np.testing.assert_array_equal(a, b)
+    # (a 3-D binning WITHOUT pid stacking is refused by the one-by-one path and by the batch alike: the evaluation
+    # grid of kde_hist.get_hist is two-dimensional, pisa/utils/kde_hist.py:137-143 `megashape`)
+    bz = MultiDimBinning([OneDimBinning("energy", domain=[0.5, 3.5], num_bins=4, is_lin=True),
+                          OneDimBinning("coszen", domain=[-1, 1], num_bins=6, is_lin=True),
+                          OneDimBinning("z", domain=[0.0, 1.0], num_bins=3, is_lin=True)])
+    s3 = K.to_device(np.stack([rs.randn(5000) * 0.6 + 2.0, rs.rand(5000) * 2 - 1, rs.rand(5000)], axis=1))
+    for call in (lambda: kde_hist.kde_histogramdd(sample=s3, weights=None, binning=bz, stack_pid=False, **kw),
+                 lambda: kde_hist.kde_histogramdd_batch([dict(sample=s3, weights=None)] * 2, bz, stack_pid=False, **kw)):
+        with pytest.raises((ValueError, AssertionError, RuntimeError)):
+            call()
     with pytest.raises(ValueError):
         kde_hist.kde_histogramdd_batch([dict(sample=samples[0]["sample"], weights=samples[1]["weights"])], b3, **kw)
 
