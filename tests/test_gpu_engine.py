@@ -725,7 +725,7 @@ def test_one_call_evaluation_equals_the_separate_calls(kw):
         assert v != v and st.metric_status_host() != 0
 
 
-@pytest.mark.parametrize("n_events", [120_000, 2_400_000])
+@pytest.mark.parametrize("n_events", [120_000, 2_400_000, 9_999_996])
 def test_partitioned_window_order_same_bits(n_events):
     """The 20 B form with 4 800 output bins: the resident order cut into partitions = the kernel's LDS windows
     (`window_partition_order`, pisa_hip_container::d_part_start: every deposit an LDS deposit, chunks that

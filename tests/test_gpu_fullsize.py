@@ -430,3 +430,35 @@ def test_c5_at_its_full_size_on_one_gpu(oracle):
     h8, s28 = one.finalize()
     assert torch.equal(h8, h_full) and torch.equal(s28, s2_full)
     print("C5 full size: %d events, %.1f GB allocated on the device during the unsharded run" % (wl.n_events, resident / 1e9))
+
+
+def test_event_mode_with_decay_at_c5_share_size(oracle):
+    """The decay instantiation of the event kernel (layer matrix in polynomial form, round 4) at the size of one
+    rank's share of C5 (1.25e7 events, generated in HBM): (P_e->f, P_mu->f) of a random 2e5-event subset of the run's
+    resident tables against `oracle.propagate_array` (reference operation order: three projector products, LAPACK-like
+    eigenvalues by closed form + Newton) at the reference's tolerance; decay removes probability, so rows sum to
+    less than one -- by the same amount in kernel and oracle."""
+    from pisa_amd import synthetic
+
+    wl = synthetic.Workload(n_events=12_500_000, grid=(10, 10), out_binning="example2d", seed=9, on_device=True)
+    p = wl.osc_params(theta23_deg=47.5, dm31=2.6e-3, decay_alpha3=1e-4)
+    m = dict(wl.last_matrices)
+    assert m["decay_flag"] == 1
+    st = synthetic.DeviceState(wl, osc_mode="events", compact=True)
+    st.accumulate(p)
+    st.check_status()
+    lay = oracle.Layers(wl.layers.prem, wl.layers.detector_depth, wl.layers.prop_height)
+    lay.rhos = np.array(wl.layers.rhos)
+    rs = np.random.RandomState(4)
+    per = 200_000 // len(wl.events)
+    lost = 0.0
+    for ev, (e_res, cz_res, own) in zip(wl.events, st._event_tables):
+        idx = torch.from_numpy(np.sort(rs.choice(wl.n_per, per, replace=False))).to(own.device)
+        e_h, cz_h, got = e_res[idx].cpu().numpy(), cz_res[idx].cpu().numpy(), own[idx].cpu().numpy()
+        lay.calcLayers(cz_h)
+        want = oracle.propagate_array(m["dm"], m["mix"], m["mat_pot"], m["decay_flag"], m["mat_decay"], m["lri_pot"],
+                                      ev["nubar"], e_h, lay.density, lay.distance)
+        np.testing.assert_allclose(got[:, 0], want[:, 0, ev["flav"]], rtol=1e-10, atol=1e-14)
+        np.testing.assert_allclose(got[:, 1], want[:, 1, ev["flav"]], rtol=1e-10, atol=1e-14)
+        lost = max(lost, float((1.0 - want.sum(axis=2)).max()))
+    assert lost > 1e-3          # the decay term is not a no-op at these baselines
