@@ -418,7 +418,7 @@ class FastPlan:
                 return abandon()
             params_list.append(_lib.Prob3Params.from_buffer_copy(osc._matrices()))
             if self._many_scales is None or any(s is self.aeff for s in changed):
-                self._many_scales = [self.aeff.scale_for(name) for name in self.names]
+                self._many_scales = self.aeff.scales_for(self.names)
                 self._many_scales_key = (ParamSet.struct_clock,) + tuple(prm._ver for prm in self.aeff.params)
             scales.append(self._many_scales)
         osc.param_hash = None
@@ -487,8 +487,8 @@ class FastPlan:
                 _lib.check(self._lib.pisa_hip_prob3_grid_planned(
                     C.byref(params), a[1], a[2], a[3], a[4], a[5], a[6], a[7], K._stream()))
             if self.aeff in changed:
-                for name in self.names:
-                    eng.set_scale(name, self.aeff.scale_for(name))
+                for name, sc in zip(self.names, self.aeff.scales_for(self.names)):
+                    eng.set_scale(name, sc)
             post_changed = [s for s in self.post if any(s is c for c in changed)]
             if post_changed:
                 for s in post_changed:

@@ -16,23 +16,35 @@ class aeff(Stage):  # pylint: disable=invalid-name
         super().__init__(expected_params=expected_params,
                          expected_container_keys=expected_container_keys, **std_kwargs)
 
-    def scale_for(self, name):
-        p = self.params
-        scale = p.aeff_scale.m_in("dimensionless") * p.livetime.m_in("sec")
+    def scale_for(self, name, values=None):
+        """aeff.py:78-86; `values` = the five magnitudes read once (`_magnitudes`) when many containers are asked for"""
+        a, lt, tcc, tau, nc = values or self._magnitudes()
+        scale = a * lt
         if name in ("nutau_cc", "nutaubar_cc"):
-            scale *= p.nutau_cc_norm.m_in("dimensionless")
+            scale *= tcc
         if "nutau" in name:
-            scale *= p.nutau_norm.m_in("dimensionless")
+            scale *= tau
         if "nc" in name:
-            scale *= p.nu_nc_norm.m_in("dimensionless")
+            scale *= nc
         return scale
+
+    def _magnitudes(self):
+        p = self.params
+        return (p.aeff_scale.m_in("dimensionless"), p.livetime.m_in("sec"), p.nutau_cc_norm.m_in("dimensionless"),
+                p.nutau_norm.m_in("dimensionless"), p.nu_nc_norm.m_in("dimensionless"))
+
+    def scales_for(self, names):
+        """`scale_for` of several containers, the parameters looked up once"""
+        v = self._magnitudes()
+        return [self.scale_for(n, v) for n in names]
 
     def _scales(self):
         """`scale_for` of every container, recomputed when one of this stage's parameters moved"""
         key = tuple(p._ver for p in self.params) + (len(self.data.containers),)
         c = getattr(self, "_scale_cache", None)
         if c is None or c[0] != key or c[2] is not self.params:
-            c = self._scale_cache = (key, {cont.name: self.scale_for(cont.name) for cont in self.data}, self.params)
+            names = [cont.name for cont in self.data]
+            c = self._scale_cache = (key, dict(zip(names, self.scales_for(names))), self.params)
         return c[1]
 
     def apply_function(self):

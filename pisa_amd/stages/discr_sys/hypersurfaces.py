@@ -68,9 +68,52 @@ class hypersurfaces(Stage):  # pylint: disable=invalid-name
                 f"No match for map {container.name} found in the hypersurfaces"
         self.data.unlink_containers()
 
+    def _linear_block(self, conts):
+        """All surfaces linear in every parameter, nothing interpolated / fluctuated / propagated (the data-release
+        hyperplanes of the published 3-year analysis): intercepts and coefficients of all containers stacked once,
+        so that one evaluation is `len(params)` numpy operations on [n_surfaces, bins] instead of that many per
+        surface -- element by element the very additions of `Hypersurface.evaluate`, in its order."""
+        blk = getattr(self, "_lin_block", None)
+        names = tuple(c.name for c in conts)
+        if blk is not None and blk["names"] == names:
+            return blk
+        surfaces = [self.hypersurfaces[n] for n in names]
+        ok = (not self.interpolated and not self.fluctuate and not self.propagate_uncertainty
+              and all(list(sf.params.keys()) == self.hypersurface_param_names for sf in surfaces)
+              and all(p.func_name == "linear" for sf in surfaces for p in sf.params.values())
+              and len({sf.log for sf in surfaces}) == 1 and len({sf.using_legacy_data for sf in surfaces}) == 1
+              and all(sf.intercept.size == conts[0].size for sf in surfaces))
+        blk = self._lin_block = dict(names=names, ok=ok)
+        if ok:
+            blk["intercept"] = np.stack([np.asarray(sf.intercept, dtype=FTYPE).reshape(-1) for sf in surfaces])
+            blk["coef"] = [np.stack([sf.params[n].fit_coeffts[..., 0].reshape(-1) for sf in surfaces])
+                           for n in self.hypersurface_param_names]
+            blk["nominal"] = [[sf.params[n].nominal_value for sf in surfaces] for n in self.hypersurface_param_names]
+            blk["log"], blk["legacy"] = surfaces[0].log, surfaces[0].using_legacy_data
+        return blk
+
     def compute_function(self):
         self._link()
         param_values = {n: float(self.params[n].m) for n in self.hypersurface_param_names}
+        conts = list(self.data)
+        blk = self._linear_block(conts)
+        if blk["ok"]:
+            out = blk["intercept"].copy()
+            for n, coef, nominal in zip(self.hypersurface_param_names, blk["coef"], blk["nominal"]):
+                v = param_values[n]
+                if blk["legacy"]:
+                    out += coef * v                      # _lin(p, m) = m * p, out += ...
+                elif len(set(nominal)) == 1:
+                    out += coef * (v - nominal[0])
+                else:
+                    out += coef * (v - np.asarray(nominal, dtype=FTYPE))[:, None]
+            scales = np.exp(out) if blk["log"] else out
+            scales[~np.isfinite(scales)] = 1.0           # empty bins (:201-210)
+            for i, container in enumerate(conts):
+                container["hs_scales"] = scales[i]
+                container.mark_valid("hs_scales")
+            self.data.unlink_containers()
+            return
         # the same fluctuation on every call (:176-178)
         rs = np.random.RandomState(self.fluctuate_seed) if self.fluctuate else None
         inter = {n: self.params[n].value for n in self.inter_params}
