@@ -109,7 +109,14 @@ class Analysis:
         where x + eps == x; the sign of a step flips where the forward point would leave the bounds, and
         where neither direction has room the step shrinks to the wider side).  Returns (points, dx):
         points[0] = x0, points[1 + i] = x0 with coordinate i moved, dx[i] the step actually taken
-        (recomputed as the representable difference, as scipy does)."""
+        (recomputed as the representable difference, as scipy does).
+
+        Follows scipy's private `_numdiff` rules as of scipy 1.9 ... 1.15 (this image: 1.15.3);
+        `tests/test_host_logic.py::test_forward_stencil_is_scipys_two_point_scheme` compares it with the installed
+        scipy's own `approx_derivative` on random points, bounds and steps, and
+        `tests/test_gpu_pipeline.py` pins `fit_hypo(batched_gradient=True)` to the unbatched fit (x, fun, nfev, history)
+        for L-BFGS-B and SLSQP: a scipy release that changes the scheme fails those tests instead of silently
+        changing fit trajectories (`batched_gradient=False` is always available)."""
         # plain Python floats (IEEE doubles, the same operations as scipy's array code): for the handful
         # of free parameters of a fit the array version costs more than the arithmetic
         x0 = [float(v) for v in x0]
