@@ -350,9 +350,10 @@ class Prob3ParamsBlock:
         self._flag = None
 
     def update(self, dm, mix, mat_pot, decay_flag, mat_decay, lri_pot):
+        """`dm` / `mix`: the arrays, or their 9 / 18 entries as plain floats (OscParams.dm_floats / mix_floats)"""
         buf, last = self.buf, self._last
-        buf[0:9] = dm.reshape(9)
-        buf[9:27] = mix.reshape(9).view(np.float64)
+        buf[0:9] = dm if type(dm) is tuple else dm.reshape(9)
+        buf[9:27] = mix if type(mix) is tuple else mix.reshape(9).view(np.float64)
         if mat_pot is not last[2]:
             buf[27:45] = np.ascontiguousarray(mat_pot, np.complex128).reshape(9).view(np.float64)
             last[2] = mat_pot if not getattr(mat_pot, "flags", None) or not mat_pot.flags.writeable else None

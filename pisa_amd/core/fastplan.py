@@ -455,11 +455,16 @@ class FastPlan:
                     return _no("stage %s.%s moved" % (s.stage_name, s.service_name))
             self.clock = Param.clock
             if osc in changed:
-                p = osc.params
-                ye = (p.YeI.value.m_as("dimensionless"), p.YeO.value.m_as("dimensionless"),
-                      p.YeM.value.m_as("dimensionless"))
-                if ye != self.ye:
-                    return _no("Ye moved")          # new layers, new plan: ordinary path
+                yp = self.__dict__.get("_ye_params")
+                if yp is None or yp[0] != ParamSet.struct_clock:
+                    p = osc.params
+                    yp = self._ye_params = [ParamSet.struct_clock, (p.YeI, p.YeO, p.YeM), None]
+                vers = (yp[1][0]._ver, yp[1][1]._ver, yp[1][2]._ver)
+                if vers != yp[2]:                   # (a fit rarely moves them: looked at when one did)
+                    ye = tuple(q.value.m_as("dimensionless") for q in yp[1])
+                    if ye != self.ye:
+                        return _no("Ye moved")          # new layers, new plan: ordinary path
+                    yp[2] = vers
             if self.barr_stage is not None and any(self.barr_stage is c for c in changed):
                 if not self._replay_barr():
                     return _no("per-event flux refresh not available")

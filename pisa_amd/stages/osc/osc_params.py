@@ -67,6 +67,34 @@ class OscParams:
         return (s12, s13, s23, math.sqrt(1.0 - s12 ** 2), math.sqrt(1.0 - s13 ** 2),
                 math.sqrt(1.0 - s23 ** 2), self._trig_delta[1], self._trig_delta[2])
 
+    def mix_floats(self, reparam=False):
+        """the nine entries of `mix_matrix_complex` (or `mix_matrix_reparam_complex`) as 18 Python floats
+        (re, im interleaved, row major): the same arithmetic on the same operands, without building the array --
+        what a fit loop writes straight into the kernels' parameter block"""
+        s12, s13, s23, c12, c13, c23, sd, cd = self._trig()
+        if reparam:
+            return (c12 * c13, 0.0, s12 * c13 * cd, s12 * c13 * sd, s13, 0.0,
+                    -s12 * c23 * cd - c12 * s23 * s13, s12 * c23 * sd,
+                    c12 * c23 - s12 * s23 * s13 * cd, -s12 * s23 * s13 * sd, s23 * c13, 0.0,
+                    s12 * s23 * cd - c12 * c23 * s13, -s12 * s23 * sd,
+                    -c12 * s23 - s12 * c23 * s13 * cd, -s12 * c23 * s13 * sd, c23 * c13, 0.0)
+        return (c12 * c13, 0.0, s12 * c13, 0.0, s13 * cd, -s13 * sd,
+                -s12 * c23 - c12 * s23 * s13 * cd, -c12 * s23 * s13 * sd,
+                c12 * c23 - s12 * s23 * s13 * cd, -s12 * s23 * s13 * sd, s23 * c13, 0.0,
+                s12 * s23 - c12 * c23 * s13 * cd, -c12 * c23 * s13 * sd,
+                -c12 * s23 - s12 * c23 * s13 * cd, -s12 * c23 * s13 * sd, c23 * c13, 0.0)
+
+    def dm_floats(self):
+        """the nine entries of `dm_matrix` as Python floats (row major)"""
+        m0, m1, m2 = 0.0, float(self.dm21), float(self.dm31)
+        delta = 5.0e-9
+        if m1 == 0.0:
+            m0 -= delta
+        if m2 == 0.0:
+            m2 += delta
+        d01, d02, d12 = m0 - m1, m0 - m2, m1 - m2
+        return (0.0, d01, d02, -d01, 0.0, d12, -d02, -d12, 0.0)
+
     @property
     def mix_matrix_complex(self):
         """PDG parameterisation (osc_params.py:174-211)."""

@@ -163,26 +163,29 @@ class prob3(Stage):  # pylint: disable=invalid-name
             std6 = self._std6 = (ParamSet.struct_clock,
                                  tuple(p[n] for n in ("theta12", "theta13", "theta23", "deltacp", "deltam21", "deltam31")))
         t12, t13, t23, dcp, d21, d31 = std6[1]
-        for prm in (t12, t13, t23, dcp):
-            if prm.value.units == ureg.dimensionless:
-                raise ValueError("%s is dimensionless, but needs units rad or deg!" % prm.name)
         o = self.osc_params
         # only what moved since the last point (a fit moves one or two of the six; every setter is a numpy call)
         seen = getattr(self, "_std6_seen", None)
         if seen is None or seen[0] is not std6:
             seen = self._std6_seen = [std6, None, None, None, None, None, None]
+
+        def angle(prm):
+            if prm.value.units == ureg.dimensionless:
+                raise ValueError("%s is dimensionless, but needs units rad or deg!" % prm.name)
+            return prm.m_in("rad")
+
         if seen[1] != t12._ver:
-            o.theta12, seen[1] = t12.m_in("rad"), t12._ver
+            o.theta12, seen[1] = angle(t12), t12._ver
         if seen[2] != t13._ver:
-            o.theta13, seen[2] = t13.m_in("rad"), t13._ver
+            o.theta13, seen[2] = angle(t13), t13._ver
         if seen[3] != t23._ver:
-            o.theta23, seen[3] = t23.m_in("rad"), t23._ver
+            o.theta23, seen[3] = angle(t23), t23._ver
         if seen[4] != d21._ver:
             o.dm21, seen[4] = d21.m_in("eV**2"), d21._ver
         if seen[5] != d31._ver:
             o.dm31, seen[5] = d31.m_in("eV**2"), d31._ver
         if seen[6] != dcp._ver:
-            o.deltacp, seen[6] = dcp.m_in("rad"), dcp._ver
+            o.deltacp, seen[6] = angle(dcp), dcp._ver
         if self.nsi_type == "vacuum-like":
             n = self.nsi_params
             n.eps_scale = p.eps_scale.value.m_as("dimensionless")
@@ -219,12 +222,12 @@ class prob3(Stage):  # pylint: disable=invalid-name
             self.lri_pot = getattr(self.lri_params, "potential_matrix_" + self.lri_type.split("-")[0])
         if self.tomography_type is not None:
             self._apply_tomography()
-        mix = o.mix_matrix_reparam_complex if self.reparam_mix_matrix else o.mix_matrix_complex
         block = getattr(self, "_params_block", None)
         if block is None:
             block = self._params_block = _lib.Prob3ParamsBlock()
-        return block.update(o.dm_matrix, mix, self.gen_mat_pot_matrix_complex, self.decay_flag, self.decay_matrix,
-                            self.lri_pot)
+        # (the entries of dm_matrix / mix_matrix[_reparam]_complex as plain floats, straight into the block)
+        return block.update(o.dm_floats(), o.mix_floats(self.reparam_mix_matrix), self.gen_mat_pot_matrix_complex,
+                            self.decay_flag, self.decay_matrix, self.lri_pot)
 
     def _apply_tomography(self):
         """prob3.py:519-536.  `Layers.scaling` rewrites `rhos` from the scaled PREM column, then

@@ -135,3 +135,31 @@ def test_mixing_matrices_equal_the_numpy_scalar_formulation_bit_for_bit():
     for val in (0.3, np.float64(0.3)):
         o.sin12 = o.sin13 = o.sin23 = val
         assert np.array_equal(o.mix_matrix_complex, numpy_form(val, val, val, dcp, False))
+
+
+def test_float_tuple_forms_of_the_matrices_are_the_matrices():
+    """`OscParams.mix_floats / dm_floats` (what the fit loop writes straight into the kernels' parameter block) are,
+    entry by entry and bit by bit, `mix_matrix_complex` / `mix_matrix_reparam_complex` / `dm_matrix`, degeneracy
+    nudges included; `Prob3ParamsBlock.update` with them fills the block `make_prob3_params` builds."""
+    from pisa_amd import _lib
+    from pisa_amd.stages.osc.osc_params import OscParams
+
+    rs = np.random.RandomState(0)
+    blk = _lib.Prob3ParamsBlock()
+    std = np.diag([1.0, 0, 0]).astype(complex)
+    zc, zr = np.zeros((3, 3), complex), np.zeros((3, 3))
+    for m in (std, zc, zr):
+        m.setflags(write=False)
+    for _ in range(500):
+        o = OscParams()
+        o.theta12, o.theta13, o.theta23 = rs.rand(3) * 1.5
+        o.deltacp = rs.rand() * 2 * np.pi
+        o.dm21 = rs.choice([0.0, 7.5e-5 * rs.rand()])
+        o.dm31 = rs.choice([0.0, 2.5e-3 * (rs.rand() - 0.5)])
+        for reparam, want in ((False, o.mix_matrix_complex), (True, o.mix_matrix_reparam_complex)):
+            got = np.array(o.mix_floats(reparam)).view(np.complex128).reshape(3, 3)
+            assert got.tobytes() == want.tobytes()
+        assert np.array(o.dm_floats()).reshape(3, 3).tobytes() == o.dm_matrix.tobytes()
+        a = blk.update(o.dm_floats(), o.mix_floats(), std, -1, zc, zr)
+        b = _lib.make_prob3_params(o.dm_matrix, o.mix_matrix_complex, std, -1, zc, zr)
+        assert bytes(a) == bytes(b)
