@@ -237,6 +237,10 @@ class Quantity:
             raise DimensionalityError("only dimensionless quantities convert to float")
         return float(self._m * self._u.scale)
 
+    def __bool__(self):
+        # pint: the truth value of a quantity is that of its magnitude (arrays: numpy's rule)
+        return bool(self._m)
+
     def __len__(self):
         return len(self._m)
 

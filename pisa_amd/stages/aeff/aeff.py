@@ -57,3 +57,15 @@ class aeff(Stage):  # pylint: disable=invalid-name
                 w = container.device("weights")
                 K.apply_aeff(container.device("weighted_aeff"), scale, w)
                 container["weights"] = w
+
+def init_test(**param_kwargs):
+    """Instantiation example (what pisa_tests/test_services.py calls for every service; the reference's own values)"""
+    from pisa_amd.core.param import Param, ParamSet
+    from pisa_amd.core.units import ureg
+
+    return aeff(params=ParamSet([
+        Param(name="livetime", value=10 * ureg.s, **param_kwargs),
+        Param(name="aeff_scale", value=1.0, **param_kwargs),
+        Param(name="nutau_cc_norm", value=1.0, **param_kwargs),
+        Param(name="nutau_norm", value=1.0, **param_kwargs),
+        Param(name="nu_nc_norm", value=1.0, **param_kwargs)]))

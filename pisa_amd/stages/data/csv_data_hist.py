@@ -24,3 +24,7 @@ class csv_data_hist(Stage):  # pylint: disable=invalid-name
         container["reco_coszen"] = events["reco_coszen"].values.astype(FTYPE)
         container["pid"] = events["pid"].values.astype(FTYPE)
         self.data.add_container(container)
+
+def init_test(**param_kwargs):
+    """Instantiation example (what pisa_tests/test_services.py calls for every service; the reference's own values)"""
+    return csv_data_hist(events_file="events/IceCube_3y_oscillations/data.csv.bz2")

@@ -86,3 +86,10 @@ class csv_loader(Stage):  # pylint: disable=invalid-name
     def apply_function(self):
         for container in self.data:
             deferred.reset_weights(container)
+
+def init_test(**param_kwargs):
+    """Instantiation example (what pisa_tests/test_services.py calls for every service; the reference's own values)"""
+    data_dict = {"true_energy": "true_energy", "true_coszen": "true_coszen", "weighted_aeff": "weight",
+                 "reco_energy": "reco_energy", "reco_coszen": "reco_coszen", "pid": "pid"}
+    return csv_loader(events_file="events/IceCube_3y_oscillations/neutrino_mc.csv.bz2", data_dict=data_dict,
+                      output_names=["nue_cc", "numu_cc"])

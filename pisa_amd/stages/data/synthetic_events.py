@@ -44,3 +44,11 @@ class synthetic_events(Stage):  # pylint: disable=invalid-name
     def apply_function(self):
         for container in self.data:
             deferred.reset_weights(container)
+
+def init_test(**param_kwargs):
+    """Instantiation example (what pisa_tests/test_services.py calls for every service; the reference's own values)"""
+    from pisa_amd.core.param import Param, ParamSet
+
+    return synthetic_events(output_names=["numu_cc", "nuebar_nc"], params=ParamSet([
+        Param(name="n_events", value=1000, **param_kwargs),
+        Param(name="seed", value=3, **param_kwargs)]))

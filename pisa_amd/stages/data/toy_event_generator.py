@@ -57,3 +57,12 @@ class toy_event_generator(Stage):  # pylint: disable=invalid-name
     def apply_function(self):
         for container in self.data:
             deferred.reset_weights(container)
+
+def init_test(**param_kwargs):
+    """Instantiation example (what pisa_tests/test_services.py calls for every service; the reference's own values)"""
+    from pisa_amd.core.param import Param, ParamSet
+
+    return toy_event_generator(output_names=["numu", "nue_bar"], params=ParamSet([
+        Param(name="n_events", value=100, **param_kwargs),
+        Param(name="random", value=1, **param_kwargs),
+        Param(name="seed", value=666, **param_kwargs)]))

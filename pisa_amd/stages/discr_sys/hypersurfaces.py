@@ -170,3 +170,24 @@ class hypersurfaces(Stage):  # pylint: disable=invalid-name
             if all("bin_unc2" in c.keys for c in conts):
                 scaled("bin_unc2", 0.0)                    # clip(bin_unc2 * hs_scales, 0, inf) (:254-256)
         scaled("weights", 0.0)                             # clip(weights * hs_scales, 0, inf) (:259)
+
+def init_test(**param_kwargs):
+    """Instantiation example (what pisa_tests/test_services.py calls for every service; the reference's own values)"""
+    from pisa_amd.core.binning import OneDimBinning
+    from pisa_amd.core.param import Param, ParamSet
+    from pisa_amd.core.units import ureg
+
+    param_set = ParamSet([
+        Param(name="opt_eff_overall", value=1.0, **param_kwargs),
+        Param(name="opt_eff_lateral", value=25, **param_kwargs),
+        Param(name="opt_eff_headon", value=0.0, **param_kwargs),
+        Param(name="ice_scattering", value=0.0, **param_kwargs),
+        Param(name="ice_absorption", value=0.0, **param_kwargs)])
+    dd_en = OneDimBinning("reco_energy", is_log=True,
+                          bin_edges=[5.62341325, 7.49894209, 10.0, 13.33521432, 17.7827941, 23.71373706, 31.6227766,
+                                     42.16965034, 56.23413252] * ureg.GeV)
+    dd_cz = OneDimBinning("reco_coszen", num_bins=8, is_lin=True, domain=[-1, 1])
+    dd_pid = OneDimBinning("pid", bin_edges=[-0.5, 0.5, 1.5])
+    return hypersurfaces(params=param_set, fit_results_file="events/IceCube_3y_oscillations/hyperplanes_*.csv.bz2",
+                         error_method="sumw2", calc_mode=MultiDimBinning([dd_en, dd_cz, dd_pid], name="dragon_datarelease"),
+                         links={"nue_cc+nuebar_cc": ["test1_cc", "test2_nc"]})

@@ -71,3 +71,14 @@ class barr_simple(Stage):  # pylint: disable=invalid-name
         return (cd.get("nu_flux") is out_arr and out_arr.dev is out_t
                 and cd.get("nu_flux_nominal") is nu_arr and (nu_arr is None or (nu_arr.dev_valid and nu_arr.dev is nu_t))
                 and cd.get("nubar_flux_nominal") is nub_arr and (nub_arr is None or (nub_arr.dev_valid and nub_arr.dev is nub_t)))
+
+def init_test(**param_kwargs):
+    """Instantiation example (what pisa_tests/test_services.py calls for every service; the reference's own values)"""
+    from pisa_amd.core.param import Param, ParamSet
+
+    return barr_simple(params=ParamSet([
+        Param(name="nue_numu_ratio", value=1.0, **param_kwargs),
+        Param(name="nu_nubar_ratio", value=1.0, **param_kwargs),
+        Param(name="delta_index", value=0.0, **param_kwargs),
+        Param(name="Barr_uphor_ratio", value=0.0, **param_kwargs),
+        Param(name="Barr_nu_nubar_ratio", value=0.0, **param_kwargs)]))

@@ -312,3 +312,23 @@ class prob3(Stage):  # pylint: disable=invalid-name
                 K.apply_osc_weights(container.device("nu_flux"), container.device_view("prob_e"),
                                     container.device_view("prob_mu"), w)
                 container["weights"] = w
+
+def init_test(**param_kwargs):
+    """Instantiation example (what pisa_tests/test_services.py calls for every service; the reference's own values)"""
+    from pisa_amd.core.param import Param, ParamSet
+
+    param_set = ParamSet([
+        Param(name="detector_depth", value=10 * ureg.km, **param_kwargs),
+        Param(name="prop_height", value=18 * ureg.km, **param_kwargs),
+        Param(name="earth_model", value="osc/PREM_4layer.dat", **param_kwargs),
+        Param(name="YeI", value=0.5, **param_kwargs),
+        Param(name="YeO", value=0.5, **param_kwargs),
+        Param(name="YeM", value=0.5, **param_kwargs),
+        Param(name="theta12", value=33 * ureg.degree, **param_kwargs),
+        Param(name="theta13", value=8 * ureg.degree, **param_kwargs),
+        Param(name="theta23", value=50 * ureg.degree, **param_kwargs),
+        Param(name="deltam21", value=8e-5 * ureg.eV ** 2, **param_kwargs),
+        Param(name="deltam31", value=3e-3 * ureg.eV ** 2, **param_kwargs),
+        Param(name="deltacp", value=180 * ureg.degree, **param_kwargs),
+    ])
+    return prob3(include_nlo=True, params=param_set)

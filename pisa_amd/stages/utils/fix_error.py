@@ -24,3 +24,10 @@ class fix_error(Stage):  # pylint: disable=invalid-name
     def apply_function(self):
         for container in self.data:
             container["errors"] = container.device("frozen_errors").clone()
+
+def init_test(**param_kwargs):
+    """Instantiation example (what pisa_tests/test_services.py calls for every service; the reference's own values)"""
+    from pisa_amd.stages.utils.kde import service_test_binning
+
+    b = service_test_binning()
+    return fix_error(calc_mode=b, apply_mode=b)

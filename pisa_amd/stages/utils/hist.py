@@ -287,3 +287,7 @@ class hist(Stage):  # pylint: disable=invalid-name
             if self.error_method == "sumw2":
                 container["errors"] = torch.sqrt(sumw2)
                 container["bin_unc2"] = bin_unc2
+
+def init_test(**param_kwargs):
+    """Instantiation example (what pisa_tests/test_services.py calls for every service; the reference's own values)"""
+    return hist(calc_mode="events")

@@ -245,3 +245,18 @@ class kde(Stage):  # pylint: disable=invalid-name
                 if self.bootstrap:
                     self.stashed_errors[container.name] = kde_errors.copy()
         self.stash_valid = self.stash_hists
+
+
+def service_test_binning():
+    """TEST_BINNING of the reference's service tests (pisa_tests/test_services.py:71-75)"""
+    from pisa_amd.core.binning import MultiDimBinning, OneDimBinning
+    from pisa_amd.core.units import ureg
+
+    return MultiDimBinning([
+        OneDimBinning(name="reco_energy", is_log=True, num_bins=3, domain=[0.1, 1] * ureg.GeV),
+        OneDimBinning(name="reco_coszen", is_lin=True, num_bins=3, domain=[0.1, 1]),
+        OneDimBinning(name="pid", is_lin=True, num_bins=3, domain=[0.1, 1])])
+
+def init_test(**param_kwargs):
+    """Instantiation example (what pisa_tests/test_services.py calls for every service; the reference's own values)"""
+    return kde(calc_mode="events", apply_mode=service_test_binning())

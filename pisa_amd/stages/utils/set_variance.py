@@ -50,3 +50,10 @@ class set_variance(Stage):  # pylint: disable=invalid-name
     def apply_function(self):
         for container in self.data:
             container["errors"] = K.bin_sqrt(container.device("manual_variance"))
+
+def init_test(**param_kwargs):
+    """Instantiation example (what pisa_tests/test_services.py calls for every service; the reference's own values)"""
+    from pisa_amd.stages.utils.kde import service_test_binning
+
+    b = service_test_binning()
+    return set_variance(expected_total_mc=100, calc_mode=b, apply_mode=b)

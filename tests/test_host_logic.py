@@ -680,3 +680,11 @@ def test_priors_penalty_keeps_terms_and_follows_every_change():
     view = ParamSet([ps.p1, ps.p4, ps.p7])
     ps.p4.value = 33 * ureg.degree
     assert view.priors_penalty("llh") == plain(view, "llh") and ps.priors_penalty("llh") == plain(ps, "llh")
+
+
+def test_quantity_truth_value_is_its_magnitudes():
+    """`if param.value:` (toy_event_generator.py:80 on `random`) -- pint's rule: the magnitude decides"""
+    from pisa_amd.core.units import ureg
+
+    assert bool(1 * ureg.dimensionless) and bool(2.5 * ureg.GeV)
+    assert not bool(0 * ureg.dimensionless) and not bool(0.0 * ureg.m)
