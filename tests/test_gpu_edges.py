@@ -214,3 +214,58 @@ def test_node_flux_engine_empty_ragged_and_out_of_grid(oracle):
     one = synthetic.DeviceState(wl, compact=True, node_flux=True)
     one.accumulate(p)
     assert bool((parts[0] + parts[1] == one.ws.limbs).all())
+
+
+def test_container_reference_unit_test():
+    """pisa/core/container.py:1043-1138 `test_container`, both sets: the tuned 100 x 100 grid on which the weights
+    are identical per bin (events -> binned -> events is then exact), the unrolled bin centres of a binned
+    representation, `get_hist`, validity bookkeeping on a store in the binned representation, and translation modes
+    (irrelevant for a binning dimension, a ValueError for an unknown mode when a translation is really needed)."""
+    from pisa_amd import FTYPE
+    from pisa_amd.core.binning import MultiDimBinning, OneDimBinning
+    from pisa_amd.core.container import Container
+
+    n_evts = 10000
+    x = np.linspace(0, 100, n_evts, dtype=FTYPE)
+    y = np.linspace(0, 100, n_evts, dtype=FTYPE)
+    w = np.tile(np.arange(100, dtype=FTYPE) + 0.5, (100, 1)).T.ravel()
+    container = Container("test", "events")
+    container["x"], container["y"], container["w"] = x, y, w
+    binning = MultiDimBinning(name="xy binning", dimensions=[
+        OneDimBinning(name="x", num_bins=100, is_lin=True, domain=[0, 100]),
+        OneDimBinning(name="y", num_bins=100, is_lin=True, domain=[0, 100])])
+    container.representation = binning
+    bx = container["x"]
+    m = np.meshgrid(binning.midpoints[0].m, binning.midpoints[1].m)[1].ravel()
+    np.testing.assert_allclose(bx, m, rtol=1e-12)
+    container.representation = "events"
+    np.testing.assert_allclose(container["w"], w, rtol=1e-12)
+    container.representation = binning
+    diag = np.diag(np.arange(100) + 0.5)
+    np.testing.assert_allclose(container["w"], diag.ravel(), rtol=1e-12)
+    h = container.get_hist("w")
+    np.testing.assert_allclose(h[0], diag, rtol=1e-12)
+    assert h[1] == binning
+    container.representation = "events"
+    np.testing.assert_allclose(container["w"], w, rtol=1e-12)
+    # second set: representation and validity management
+    container = Container("nue", "events")
+    container["x"] = x
+    assert container.translation_modes["x"] == "average"
+    container["y"] = y
+    assert container.translation_modes["y"] == "average"
+    container["weights"] = w
+    container.representation = binning
+    for k in container.all_keys:
+        if "weight" in k:
+            container[k] = container[k] * 1.0      # a store in the binned representation invalidates 'events'
+            assert container.validity[k][hash(binning)]
+            assert not container.validity[k][hash("events")]
+    container.translation_modes["y"] = "median"    # ignored for a binning dimension
+    _ = container["y"]
+    _ = container["x"]
+    container["oneweight"] = container["weights"]
+    container.translation_modes["oneweight"] = "division"
+    container.representation = "events"
+    with pytest.raises(ValueError):
+        container["oneweight"]

@@ -688,3 +688,37 @@ def test_quantity_truth_value_is_its_magnitudes():
 
     assert bool(1 * ureg.dimensionless) and bool(2.5 * ureg.GeV)
     assert not bool(0 * ureg.dimensionless) and not bool(0.0 * ureg.m)
+
+
+def test_container_set_reference_unit_test():
+    """pisa/core/container.py:1141-1189 `test_container_set`: duplicate containers are refused, shared keys with and
+    without representation independence, auxiliary data count as keys in every representation"""
+    from pisa_amd import FTYPE
+    from pisa_amd.core.container import Container, ContainerSet
+
+    c1, c2 = Container("test1"), Container("test2")
+    data = ContainerSet("data", [c1, c2])
+    with pytest.raises(ValueError):
+        data.add_container(c1)
+    n = 10
+    c1["true_energy"] = np.linspace(1, 80, n, dtype=FTYPE)
+    c2["reco_coszen"] = np.linspace(-1, 1, 2 * n, dtype=FTYPE)
+    for rep_indep in (True, False):
+        assert len(data.get_shared_keys(rep_indep=rep_indep)) == 0
+    c1["reco_coszen"] = c2["reco_coszen"][:n]
+    for rep in (None, "events"):
+        data.representation = rep
+        for rep_indep in (True, False):
+            shared = data.get_shared_keys(rep_indep=rep_indep)
+            if rep_indep or rep is None:
+                assert tuple(shared) == ("reco_coszen",)
+            else:
+                for c in data.containers:
+                    assert len(c.keys) == 0
+                assert len(shared) == 0
+    key = "AmIEvil"
+    c1.set_aux_data(key=key, val=False)
+    c2.set_aux_data(key=key, val=True)
+    indep, dep = data.get_shared_keys(rep_indep=True), data.get_shared_keys(rep_indep=False)
+    assert key in indep and key in dep
+    assert len(indep) == 2 and len(dep) == 1
