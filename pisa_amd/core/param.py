@@ -39,6 +39,31 @@ def _as_quantity(v):
     return Quantity(v)
 
 
+def _same(a, b):
+    """recursive equality of Param state entries (utils/comparisons.py recursiveEquality: quantities by
+    value and dimension, arrays element by element, sequences and mappings entry by entry)"""
+    if a is b:
+        return True
+    if a is None or b is None:
+        return False
+    if isinstance(a, Quantity) or isinstance(b, Quantity):
+        if not (isinstance(a, Quantity) and isinstance(b, Quantity)) or a.units.dims != b.units.dims:
+            return False
+        return bool(np.all(np.asarray(a.m_as(b.units)) == np.asarray(b.magnitude)))
+    if isinstance(a, Prior) or isinstance(b, Prior):
+        return isinstance(a, Prior) and isinstance(b, Prior) and _same(a.state, b.state)
+    if isinstance(a, Mapping) and isinstance(b, Mapping):
+        return a.keys() == b.keys() and all(_same(a[k], b[k]) for k in a)
+    if isinstance(a, (list, tuple)) and isinstance(b, (list, tuple)):
+        return len(a) == len(b) and all(_same(x, y) for x, y in zip(a, b))
+    if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
+        return np.shape(a) == np.shape(b) and bool(np.all(np.asarray(a) == np.asarray(b)))
+    try:
+        return bool(a == b)
+    except (TypeError, ValueError):
+        return False
+
+
 class Prior:
     """uniform / gaussian / jeffreys priors (prior.py:189-262). `llh(x)` returns the
     log-prior (up to a constant); chi2 = -2 llh (prior.py:395-400)."""
@@ -83,6 +108,24 @@ class Prior:
         new.__dict__.update(self.__dict__)
         memo[id(self)] = new
         return new
+
+    _kind_attrs = {"uniform": ("llh_offset",), "gaussian": ("mean", "stddev"), "jeffreys": ("A", "B"),
+                   "spline": ("knots", "coeffs", "deg"), "linterp": ("param_vals", "llh_vals")}
+
+    @property
+    def state(self):
+        """`kind` and that kind's constructor arguments (prior.py:189-194): `Prior(**state)` is an equal prior"""
+        return OrderedDict([("kind", self.kind)] + [(a, getattr(self, a)) for a in self._kind_attrs[self.kind]])
+
+    serializable_state = state
+
+    def __eq__(self, other):
+        return isinstance(other, Prior) and _same(self.state, other.state)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = object.__hash__
 
     def _strip(self, x):
         x = _as_quantity(x)
@@ -340,6 +383,48 @@ class Param:
             return (m, v.units.scale, v.units.dims)
         return v
 
+    _state_attrs = ("name", "unique_id", "value", "prior", "range", "is_fixed", "is_discrete",
+                    "nominal_value", "tex", "help", "scales_as_log")
+
+    @property
+    def state(self):
+        """the attributes that define the Param, in a fixed order (param.py:402-414)"""
+        return OrderedDict((a, getattr(self, a)) for a in self._state_attrs)
+
+    @property
+    def serializable_state(self):
+        s = self.state
+        s["tex"] = self._tex            # the constructor's argument, not the derived default
+        return s
+
+    def to_json(self, filename, **kwargs):
+        """the state as a JSON file `Param.from_json` reads back (param.py:567-578)"""
+        from pisa_amd.utils import jsons
+
+        jsons.to_json(self.serializable_state, filename, **kwargs)
+
+    @classmethod
+    def from_json(cls, filename):
+        from pisa_amd.utils import jsons
+
+        return cls(**jsons.from_json(filename))
+
+    def __eq__(self, other):
+        """same state (param.py:223-226): name, value, nominal value, range, prior, flags"""
+        if not isinstance(other, Param):
+            return False
+        if other is self:
+            return True
+        return all(_same(getattr(self, a), getattr(other, a)) for a in self._state_attrs)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    def __lt__(self, other):
+        return self.name < other.name
+
+    __hash__ = object.__hash__      # identity: plans and caches key on the Param OBJECT
+
     def __repr__(self):
         return "Param(%s=%s, fixed=%s, range=%s, prior=%s)" % (self.name, self._value,
                                                                self.is_fixed, self._range, self.prior)
@@ -388,8 +473,73 @@ class ParamSet(Sequence):
         return self._params[i]
 
     def __contains__(self, item):
-        name = item.name if isinstance(item, Param) else item
-        return self._pos(name) is not None
+        """a name: a parameter of that name is present; a Param: an EQUAL one is (the reference's set has no
+        `__contains__`, membership falls to iteration and `Param.__eq__`, param.py:223)"""
+        if isinstance(item, Param):
+            i = self._pos(item.name)
+            return i is not None and self._params[i] == item
+        return self._pos(item) is not None
+
+    def issubset(self, other):
+        return all(p in other for p in self._params)
+
+    def issuperset(self, other):
+        return all(p in self for p in other)
+
+    def isdisjoint(self, other):
+        return not any(p in other for p in self._params)
+
+    def __le__(self, other):
+        return self.issubset(other)
+
+    def __lt__(self, other):
+        return len(other) > len(self) and self.issubset(other)
+
+    def __ge__(self, other):
+        return self.issuperset(other)
+
+    def __gt__(self, other):
+        return len(self) > len(other) and self.issuperset(other)
+
+    def __eq__(self, other):
+        if not isinstance(other, ParamSet):
+            return False
+        return len(self) == len(other) and all(a == b for a, b in zip(self._params, other._params))
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = object.__hash__
+
+    def __delitem__(self, i):
+        """`del ps[3]`, `del ps['name']` (param.py:1268-1270)"""
+        del self._params[self.index(i)]
+        self._reindex()
+
+    def __setitem__(self, i, val):
+        assert isinstance(val, Param)
+        self._params[self.index(i)] = val
+        self._reindex()
+
+    def insert(self, index, value):
+        assert isinstance(value, Param)
+        if value.name in self._index:
+            raise ValueError("parameter '%s' already present" % value.name)
+        self._params.insert(index, value)
+        self._reindex()
+
+    def remove(self, value):
+        del self[self.index(value)]
+
+    def pop(self, i=-1):
+        p = self._params.pop(self.index(i) if not isinstance(i, (int, np.integer)) else i)
+        self._reindex()
+        return p
+
+    def _reindex(self):
+        self._index.clear()
+        self._index.update((p.name, i) for i, p in enumerate(self._params))
+        self._bump()
 
     def _pos(self, name):
         return self._index.get(name)
@@ -411,17 +561,67 @@ class ParamSet(Sequence):
             object.__setattr__(self, attr, val)
             return
         i = self._pos(attr)
-        if i is not None:
-            self._params[i].value = val
-        else:
+        if i is None:
             object.__setattr__(self, attr, val)
+        elif isinstance(val, Param):            # `ps.theta23 = other_param` replaces the object (param.py:1312-1314)
+            assert val.name == attr
+            if self._params[i] is not val:
+                self._params[i] = val
+                self._bump()
+        else:
+            self._params[i].value = val
 
     names = property(lambda self: tuple(p.name for p in self._params))
-    values = property(lambda self: tuple(p.value for p in self._params))
-    nominal_values = property(lambda self: tuple(p.nominal_value for p in self._params))
+    def _each(attr):            # noqa: N805 -- one attribute of every param, read as a tuple, set from a sequence
+        def get(self):
+            return tuple(getattr(p, attr) for p in self._params)
+
+        def put(self, vals):
+            assert len(vals) == len(self._params)
+            for p, v in zip(self._params, vals):
+                setattr(p, attr, v)
+        return property(get, put)
+
+    values = _each("value")
+    nominal_values = _each("nominal_value")
+    priors = _each("prior")
+    ranges = _each("range")
+    del _each
     free = property(lambda self: ParamSet([p for p in self._params if not p.is_fixed]))
     fixed = property(lambda self: ParamSet([p for p in self._params if p.is_fixed]))
     are_fixed = property(lambda self: tuple(p.is_fixed for p in self._params))
+    continuous = property(lambda self: ParamSet([p for p in self._params if not p.is_discrete]))
+    discrete = property(lambda self: ParamSet([p for p in self._params if p.is_discrete]))
+    are_discrete = property(lambda self: tuple(p.is_discrete for p in self._params))
+    tex = property(lambda self: r",\,".join(p.tex for p in self._params))
+    name_val_dict = property(lambda self: OrderedDict((p.name, p.value) for p in self._params))
+    is_nominal = property(lambda self: all(_same(p.value, p.nominal_value) for p in self._params))
+    state = property(lambda self: tuple(p.state for p in self._params))
+
+    serializable_state = property(lambda self: [p.serializable_state for p in self._params])
+
+    def to_json(self, filename, **kwargs):
+        """a JSON file of the params' states, read back by `ParamSet.from_json` (param.py:1590-1601)"""
+        from pisa_amd.utils import jsons
+
+        jsons.to_json(self.serializable_state, filename, **kwargs)
+
+    @classmethod
+    def from_json(cls, filename):
+        from pisa_amd.utils import jsons
+
+        return cls([Param(**st) for st in jsons.from_json(filename)])
+
+    def set_values(self, new_params):
+        """values of the params of the same names in `new_params` (param.py:1116-1129)"""
+        for p in new_params:
+            self[p.name].value = p.value
+
+    def update_existing(self, obj):
+        self.update(obj, existing_must_match=False, extend=False)
+
+    def priors_penalties(self, metric):
+        return [p.prior_penalty(metric) for p in self._params]
     has_derived = False
 
     def index(self, name):
@@ -579,13 +779,16 @@ class ParamSelector:
             raise KeyError("none of the selections %s present" % (selections,))
         return self._current
 
-    def update(self, p, selector=None, existing_must_match=False, extend=False):
+    def update(self, p, selector=None, existing_must_match=False, extend=True):
         """Update params; params shared by name across stages become one object
-        (pipeline.py:342-346)."""
+        (pipeline.py:342-346; param.py:1708-1730: without a selector the regular and the current sets take
+        the params, with one that selector's set does and the current selection is applied again)."""
         new = [p] if isinstance(p, Param) else list(p)
         if selector is not None:
             self._selector_sets.setdefault(selector.strip().lower(), ParamSet()).update(
-                new, existing_must_match=existing_must_match, extend=True)
+                new, existing_must_match=existing_must_match, extend=extend)
+            if selector.strip().lower() in self._selections:
+                self.select_params([selector], error_on_missing=False)
             return
         for q in new:
             if q.name in self._regular.names:
@@ -598,6 +801,19 @@ class ParamSelector:
             elif extend:
                 self._regular.extend(q)
                 self._current.extend(q)
+
+    def __iter__(self):
+        return iter(self._current)
+
+    def __eq__(self, other):
+        """same selections, regular params and per-selector sets (param.py:1691-1700)"""
+        if not isinstance(other, ParamSelector):
+            return False
+        return (sorted(self._selections) == sorted(other._selections) and self._regular == other._regular
+                and self._selector_sets.keys() == other._selector_sets.keys()
+                and all(self._selector_sets[k] == other._selector_sets[k] for k in self._selector_sets))
+
+    __hash__ = object.__hash__
 
     def get(self, name, selector=None):
         if selector is None:

@@ -49,11 +49,12 @@ class Unit:
         dims = tuple(a + sign * b for a, b in zip(self.dims, other.dims))
         scale = self.scale * other.scale ** sign
         if self.dimensionless and self.name == "dimensionless":
-            name = other.name if sign > 0 else "1 / %s" % other.name
+            name = other.name if sign > 0 else "1 / %s" % ("(%s)" % other.name if " " in other.name else other.name)
         elif other.name == "dimensionless":
             name = self.name
         else:
-            name = "%s %s %s" % (self.name, "*" if sign > 0 else "/", other.name)
+            rhs = "(%s)" % other.name if (sign < 0 and " " in other.name) else other.name
+            name = "%s %s %s" % (self.name, "*" if sign > 0 else "/", rhs)
         return Unit(scale, dims, name)
 
     def __mul__(self, other):
@@ -74,7 +75,8 @@ class Unit:
         return Quantity(other, Unit() / self)
 
     def __pow__(self, p):
-        name = self.name if self.name == "dimensionless" else "%s ** %s" % (self.name, p)
+        name = self.name if self.name == "dimensionless" else \
+            "%s ** %s" % ("(%s)" % self.name if " " in self.name else self.name, p)
         return Unit(self.scale ** p, tuple(d * p for d in self.dims), name)
 
     def __eq__(self, other):
@@ -107,6 +109,14 @@ class Quantity:
             units = ureg.parse_units(units)
         if isinstance(magnitude, (list, tuple)):
             magnitude = np.array(magnitude, dtype=np.float64)
+        elif isinstance(magnitude, str):            # Quantity("0.1 dimensionless"), as pint parses it
+            q = ureg.parse_expression(magnitude)
+            if isinstance(q, Unit):
+                q = Quantity(1, q)
+            if isinstance(q, Quantity):
+                magnitude, units = (q.magnitude, q.units) if units is None else (q.m_as(units), units)
+            else:
+                magnitude = q
         self._m = magnitude
         self._u = units if units is not None else Unit()
 
@@ -149,6 +159,20 @@ class Quantity:
     def ito(self, units):
         q = self.to(units)
         self._m, self._u = q._m, q._u
+
+    def to_tuple(self):
+        """(magnitude, ((unit name, power), ...)): pint's `Quantity.to_tuple`, the form the reference's JSON
+        files hold (utils/jsons.py:300-302)"""
+        return self.magnitude, _name_powers(self.units.name)
+
+    @classmethod
+    def from_tuple(cls, tup):
+        m, parts = tup
+        u = ureg.dimensionless
+        for name, power in parts:
+            b = ureg.parse_units(name)
+            u = u * (b if power == 1 else b ** (int(power) if float(power).is_integer() else power))
+        return cls(m, u)
 
     def to_base_units(self):
         return Quantity(np.asarray(self._m) * self._u.scale if not np.isscalar(self._m)
@@ -264,6 +288,36 @@ class Quantity:
 Q_ = Quantity
 
 
+def _name_powers(name):
+    """'meter / second ** 2' -> (('meter', 1.0), ('second', -2.0)); a name that is not a product of powers
+    of registered units (a numeric factor in it) stays one entry, readable by `parse_units`"""
+    if name == "dimensionless":
+        return ()
+    acc = {}
+
+    def walk(node, sign):
+        if isinstance(node, ast.Name):
+            acc[node.id] = acc.get(node.id, 0.0) + sign
+        elif isinstance(node, ast.BinOp) and isinstance(node.op, (ast.Mult, ast.Div)):
+            walk(node.left, sign)
+            walk(node.right, sign if isinstance(node.op, ast.Mult) else -sign)
+        elif isinstance(node, ast.BinOp) and isinstance(node.op, ast.Pow) and isinstance(node.right, ast.Constant):
+            walk(node.left, sign * float(node.right.value))
+        elif isinstance(node, ast.BinOp) and isinstance(node.op, ast.Pow) and isinstance(node.right, ast.UnaryOp) \
+                and isinstance(node.right.op, ast.USub) and isinstance(node.right.operand, ast.Constant):
+            walk(node.left, -sign * float(node.right.operand.value))
+        elif isinstance(node, ast.Constant) and node.value == 1:
+            pass
+        else:
+            raise ValueError(name)
+
+    try:
+        walk(ast.parse(name.replace("^", "**"), mode="eval").body, 1.0)
+    except (ValueError, SyntaxError):
+        return ((name, 1.0),)
+    return tuple((n, p) for n, p in acc.items() if p != 0)
+
+
 def _dims(**kw):
     return tuple(kw.get(b, 0) for b in _BASE)
 
@@ -290,6 +344,9 @@ class UnitRegistry:
         add(["kilometer", "km", "kilometre", "kilometers"], 1e3, L)
         add(["centimeter", "cm", "centimetre"], 1e-2, L)
         add(["millimeter", "mm"], 1e-3, L)
+        add(["foot", "ft", "feet"], 0.3048, L)
+        add(["inch"], 0.0254, L)
+        add(["mile", "mi"], 1609.344, L)
         # time
         add(["second", "s", "sec", "seconds"], 1.0, T)
         add(["millisecond", "ms"], 1e-3, T)

@@ -1,0 +1,94 @@
+"""JSON files of host objects (utils/jsons.py:60-130 `from_json`/`to_json`, :262-330 the encoder, :380-500 the
+quantity-aware decoder).
+
+The file format is the reference's: a quantity is the two-element list pint's `Quantity.to_tuple()` gives,
+`[magnitude, [[unit name, power], ...]]`; arrays are nested lists; mappings keep their order.  Written for
+the states of `Param`, `ParamSet` and `Prior` (fit inputs and results); plain `.json` only (the reference's
+`.json.bz2`/`.json.xz` variants are a one-line `open` away and nobody on the hot path reads them).
+"""
+import bz2
+import json
+import lzma
+from collections import OrderedDict
+from collections.abc import Mapping
+
+import numpy as np
+
+from pisa_amd.core.units import Quantity, Unit
+
+__all__ = ["to_json", "from_json", "dumps", "loads"]
+
+
+def _plain(obj):
+    """the JSON-representable form of `obj`"""
+    if obj is None or isinstance(obj, (bool, str, int)):
+        return obj
+    if isinstance(obj, float):
+        return obj
+    if isinstance(obj, Quantity):
+        m, u = obj.to_tuple()
+        return [_plain(m), [[n, float(p)] for n, p in u]]
+    if isinstance(obj, Unit):
+        return str(obj)
+    if hasattr(obj, "serializable_state"):
+        return _plain(obj.serializable_state)
+    if isinstance(obj, Mapping):
+        return OrderedDict((str(k), _plain(v)) for k, v in obj.items())
+    if isinstance(obj, np.ndarray):
+        return _plain(obj.tolist())
+    if isinstance(obj, np.integer):
+        return int(obj)
+    if isinstance(obj, np.floating):
+        return float(obj)
+    if isinstance(obj, np.bool_):
+        return bool(obj)
+    if isinstance(obj, (list, tuple, set, frozenset)):
+        return [_plain(x) for x in obj]
+    raise TypeError("cannot write a %s to JSON" % type(obj).__name__)
+
+
+def _is_units_part(x):
+    return isinstance(x, list) and all(isinstance(e, list) and len(e) == 2 and isinstance(e[0], str)
+                                       and isinstance(e[1], (int, float)) and not isinstance(e[1], bool)
+                                       for e in x)
+
+
+def _revive(obj):
+    """lists of the form [magnitude, [[name, power], ...]] become quantities (jsons.py:445-475)"""
+    if isinstance(obj, Mapping):
+        return OrderedDict((k, _revive(v)) for k, v in obj.items())
+    if isinstance(obj, list):
+        if len(obj) == 2 and not isinstance(obj[0], (str, Mapping)) and obj[0] is not None \
+                and _is_units_part(obj[1]) and not _is_units_part(obj):
+            m = obj[0]
+            return Quantity.from_tuple((np.asarray(m, dtype=np.float64) if isinstance(m, list) else m, obj[1]))
+        return [_revive(x) for x in obj]
+    return obj
+
+
+def dumps(obj, **kwargs):
+    kwargs.setdefault("indent", 2)
+    return json.dumps(_plain(obj), allow_nan=True, **kwargs)
+
+
+def loads(text):
+    return _revive(json.loads(text, object_pairs_hook=OrderedDict))
+
+
+def _open(filename, mode):
+    name = str(filename)
+    if name.endswith(".bz2"):
+        return bz2.open(name, mode + "t")
+    if name.endswith(".xz"):
+        return lzma.open(name, mode + "t")
+    return open(name, mode)
+
+
+def to_json(content, filename, **kwargs):
+    with _open(filename, "w") as f:
+        f.write(dumps(content, **kwargs))
+
+
+def from_json(filename):
+    with _open(filename, "r") as f:
+        return loads(f.read())

@@ -1,0 +1,185 @@
+"""`Param`, `ParamSet`, `ParamSelector` behave as the reference's value types do (pisa/core/param.py:77-578,
+769-1601, 1604-1738): equality is equality of state, membership of a Param in a set is membership of an
+EQUAL Param, sets compare as sets, params can be inserted / removed / replaced, and the states go through
+the reference's JSON form (quantities as pint tuples) and come back equal.  CPU only."""
+from copy import deepcopy
+
+import numpy as np
+import pytest
+
+from pisa_amd.core.param import Param, ParamSelector, ParamSet, Prior
+from pisa_amd.core.units import Quantity, ureg
+from pisa_amd.utils import jsons
+
+
+def _params():
+    a = Param("a", 1.5 * ureg.GeV, prior=Prior("gaussian", mean=1.4 * ureg.GeV, stddev=0.2 * ureg.GeV),
+              range=[0.5, 3] * ureg.GeV, is_fixed=False)
+    b = Param("b", 20 * ureg.deg, prior=None, range=[0, 90] * ureg.deg, is_fixed=False)
+    c = Param("c", 0.3, prior=Prior("uniform"), range=[-1, 1], is_fixed=True)
+    d = Param("d", 7.0 * ureg.m / ureg.s, prior=None, range=None, is_fixed=True, is_discrete=True)
+    return a, b, c, d
+
+
+def test_param_equality_is_equality_of_state():
+    a, b, _, _ = _params()
+    twin = deepcopy(a)
+    assert twin == a and not twin != a and twin is not a
+    twin.value = 1.6 * ureg.GeV
+    assert twin != a
+    twin.value = 1500 * ureg.MeV                 # the same energy written in another unit
+    assert twin == a
+    twin.is_fixed = True
+    assert twin != a
+    assert a != b and a != "a" and sorted([b, a]) == [a, b]       # ordering is by name
+    other_prior = deepcopy(a)
+    other_prior.prior = Prior("gaussian", mean=1.4 * ureg.GeV, stddev=0.25 * ureg.GeV)
+    assert other_prior != a
+    assert {a: 1}[a] == 1                         # still usable as a key (by identity)
+
+
+def test_membership_and_set_relations():
+    a, b, c, d = _params()
+    small, big = ParamSet(a, b, c), ParamSet(a, b, c, d)
+    moved = deepcopy(a)
+    moved.value = 2.0 * ureg.GeV
+    assert a in small and deepcopy(a) in small and moved not in small
+    assert "a" in small and "zz" not in small     # names, as before
+    assert small.issubset(big) and small <= big and small < big and not big < small
+    assert big.issuperset(small) and big >= small and big > small
+    assert not small < ParamSet(a, b, c) and small <= ParamSet(a, b, c) and small == ParamSet(a, b, c)
+    assert small != big and small != ParamSet(a, c, b)             # order is part of the state
+    assert ParamSet(a, b).isdisjoint(ParamSet(c, d)) and not small.isdisjoint(big)
+    assert not ParamSet(moved) <= small
+
+
+def test_insert_remove_replace():
+    a, b, c, d = _params()
+    for where in range(4):
+        ps = ParamSet(a, b, c)
+        ps.insert(where, d)
+        assert len(ps) == 4 and ps[where] is d and ps.index("d") == where and ps.d is d
+        assert [ps.index(n) for n in ps.names] == [0, 1, 2, 3]
+        for how in ("del_name", "del_pos", "remove", "pop"):
+            q = ParamSet(list(ps))
+            if how == "del_name":
+                del q["d"]
+            elif how == "del_pos":
+                del q[where]
+            elif how == "remove":
+                q.remove(d)
+            else:
+                assert q.pop(where) is d
+            assert q == ParamSet(a, b, c) and "d" not in q.names and len(q.fixed) == 1
+            with pytest.raises(AttributeError):
+                q.d
+    ps = ParamSet(a, b, c)
+    with pytest.raises(ValueError):
+        ps.insert(0, deepcopy(a))
+    n = ParamSet.struct_clock
+    twin = deepcopy(b)
+    ps.b = twin                                    # a Param replaces the object ...
+    assert ps.b is twin and ps["b"] is twin and ParamSet.struct_clock > n
+    with pytest.raises(AssertionError):
+        ps.b = a                                   # ... of the same name only
+    ps.b = 30 * ureg.deg                           # a quantity or a number sets the value
+    assert ps.b is twin and twin.value == 30 * ureg.deg
+    ps.c = -1
+    assert ps.c.value == -1.0
+    with pytest.raises(ValueError):
+        ps.c = 30                                  # outside the range
+    with pytest.raises(ValueError):
+        ps.b = 3 * ureg.GeV                        # wrong dimension
+
+
+def test_views_and_sequence_setters():
+    a, b, c, d = _params()
+    ps = ParamSet(a, b, c, d)
+    assert ps.are_discrete == (False, False, False, True)
+    assert ps.discrete.names == ("d",) and ps.continuous.names == ("a", "b", "c")
+    assert list(ps.name_val_dict) == ["a", "b", "c", "d"] and ps.name_val_dict["b"] == 20 * ureg.deg
+    assert ps.is_nominal
+    ps.values = [2 * ureg.GeV, 10 * ureg.deg, 0.1, 6 * ureg.m / ureg.s]
+    assert ps.a.value == 2 * ureg.GeV and ps.c.value == 0.1 and not ps.is_nominal
+    ps.nominal_values = ps.values
+    assert ps.is_nominal
+    ps.ranges = [[1, 4] * ureg.GeV, [0, 45] * ureg.deg, [0, 1], None]
+    assert ps.ranges[1][1] == 45 * ureg.deg and ps.ranges[3] is None
+    ps.priors = [None, None, None, None]
+    assert ps.priors == (None,) * 4 and ps.priors_penalties("llh") == [0, 0, 0, 0]
+    other = ParamSet(deepcopy(a), deepcopy(c))
+    other.a = 3 * ureg.GeV
+    ps.set_values(other)
+    assert ps.a.value == 3 * ureg.GeV and ps.a is a
+    ps.update_existing(Param("never_seen", 1.0))
+    assert "never_seen" not in ps.names
+    assert len(ps.state) == 4 and list(ps.state[0])[:3] == ["name", "unique_id", "value"]
+
+
+def test_quantity_tuple_form():
+    for q, want in ((9.8 * ureg.m / ureg.s ** 2, (("meter", 1.0), ("second", -2.0))),
+                    (2.5e-3 * ureg.eV ** 2, (("electron_volt", 2.0),)),
+                    (0.5 * ureg.dimensionless, ()),
+                    (2 * ureg.km / (ureg.s * ureg.GeV), (("kilometer", 1.0), ("second", -1.0), ("GeV", -1.0)))):
+        m, parts = q.to_tuple()
+        assert m == q.magnitude and dict(parts) == dict(want)
+        assert Quantity.from_tuple((m, parts)) == q
+    assert Quantity("0.1 dimensionless") == 0.1 and Quantity("10.1 GeV") == 10100 * ureg.MeV
+    # a file written by the reference holds exactly this (utils/jsons.py:453-461)
+    got = jsons.loads('{"g": [9.8, [["meter", 1.0], ["second", -2.0]]], "arr": [[[0, 1, 2], [2, 3, 4]], '
+                      '[["meter", 1.0]]], "plain": [1.0, 2.0], "pairs": [["meter", 1.0], ["second", -2.0]]}')
+    assert got["g"] == 9.8 * ureg.m / ureg.s ** 2
+    assert got["arr"].magnitude.shape == (2, 3) and got["arr"].units == ureg.m
+    assert got["plain"] == [1.0, 2.0] and got["pairs"] == [["meter", 1.0], ["second", -2.0]]
+
+
+def test_json_round_trip(tmp_path):
+    xs = np.linspace(-10, 10, 21)
+    priors = [None, Prior("uniform", llh_offset=1.5),
+              Prior("gaussian", mean=10 * ureg.m, stddev=1 * ureg.m),
+              Prior("jeffreys", A=0.5 * ureg.m, B=50 * ureg.m),
+              Prior("linterp", param_vals=xs * ureg.m, llh_vals=xs ** 2),
+              Prior("spline", knots=ureg.Quantity(np.r_[[-10.0] * 3, xs[1:-1], [10.0] * 3], "m"),
+                    coeffs=np.r_[xs ** 2, 0, 0, 0, 0], deg=3)]
+    made = []
+    for i, pr in enumerate(priors):
+        p = Param("p%d" % i, 5 * ureg.m, prior=pr, range=[1, 9] * ureg.m, is_fixed=bool(i % 2),
+                  tex=r"\pi_%d" % i if i % 2 else None, help="parameter %d" % i, nominal_value=4 * ureg.m)
+        f = tmp_path / ("p%d.json" % i)
+        p.to_json(f)
+        back = Param.from_json(f)
+        assert back == p and back is not p
+        assert back.tex == p.tex and back.help == p.help and back.nominal_value == 4 * ureg.m
+        assert back.prior == p.prior
+        if pr is not None:
+            assert back.prior_penalty("llh") == p.prior_penalty("llh")
+        made.append(p)
+    plain = Param("unitless", 1, prior=None, range=(-1.1, 1.1), is_fixed=False)
+    speed = Param("speed", 2.1 * ureg.m / ureg.s, prior=None, range=(-1.1, 1.1) * ureg.cm / ureg.ns, is_fixed=True)
+    ps = ParamSet(made + [plain, speed])
+    ps.to_json(tmp_path / "set.json.bz2")
+    back = ParamSet.from_json(tmp_path / "set.json.bz2")
+    assert back == ps and back.names == ps.names and back.values_hash == ps.values_hash
+    assert back.speed.range[1] == 1.1 * ureg.cm / ureg.ns
+
+
+def test_selector_update_and_equality():
+    a, b, c, d = _params()
+    nh = Param("e", -11, prior=None, range=[-20, 20], is_fixed=True)
+    ih = Param("e", -22, prior=None, range=[-30, 20], is_fixed=True)
+    sel = ParamSelector(regular_params=[a, b], selector_param_sets={"nh": [nh], "ih": [ih]}, selections=["nh"])
+    view = sel.params
+    assert view.e.value == -11 and [p.name for p in sel] == list(view.names)
+    sel.update(c)                                  # a new regular param appears in the current view
+    assert view.c is c and sel.get("c") is c
+    sel.update(d, selector="ih")                   # a param of a selector that is not selected does not
+    assert "d" not in view.names and sel.get("d", selector="ih") is d
+    nh2 = Param("e", -12, prior=None, range=[-20, 20], is_fixed=True)
+    sel.update(nh2, selector="nh")                 # one of the selected selector does, at once
+    assert view.e is nh2
+    sel.select_params("ih")
+    assert view.e.value == -22 and view.d is d
+    twin = deepcopy(sel)
+    assert twin == sel and twin.params is not view
+    twin.params.a = 2.9 * ureg.GeV
+    assert twin != sel
