@@ -11,5 +11,6 @@ FTYPE = np.float64
 CTYPE = np.complex128
 ITYPE = np.int64
 TARGET = "hip"
+HASH_SIGFIGS = 12      # significant figures kept when values are normalised for hashing (pisa/__init__.py:277)
 
 __version__ = "0.1.0"

@@ -21,11 +21,12 @@ from copy import deepcopy
 
 import numpy as np
 
+from pisa_amd import HASH_SIGFIGS  # noqa: F401 (re-exported)
 from pisa_amd.core.units import Quantity, ureg
 
 __all__ = ["Prior", "Param", "ParamSet", "ParamSelector"]
 
-HASH_SIGFIGS = 12  # pisa/__init__.py:277
+
 FTYPE_PREC = np.finfo(np.float64).eps
 
 LLH_METRICS = ("llh", "poisson_llh", "conv_llh", "barlow_llh", "mcllh_mean", "mcllh_eff",

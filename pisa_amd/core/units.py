@@ -344,6 +344,8 @@ class UnitRegistry:
         add(["kilometer", "km", "kilometre", "kilometers"], 1e3, L)
         add(["centimeter", "cm", "centimetre"], 1e-2, L)
         add(["millimeter", "mm"], 1e-3, L)
+        add(["micrometer", "um", "micron"], 1e-6, L)
+        add(["nanometer", "nm"], 1e-9, L)
         add(["foot", "ft", "feet"], 0.3048, L)
         add(["inch"], 0.0254, L)
         add(["mile", "mi"], 1609.344, L)

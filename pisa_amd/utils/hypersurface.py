@@ -226,6 +226,10 @@ class Hypersurface:
         if not isinstance(state, Mapping):
             state = _read_json(state)
         params = [HypersurfaceParam.from_state(s) for s in state["params"].values()]
+        if binning is None and isinstance(state.get("binning"), Mapping):
+            from pisa_amd.core.binning import MultiDimBinning       # the file's own binning (:1262-1264)
+
+            binning = MultiDimBinning(**state["binning"])
         return cls(binning, params, np.asarray(state["intercept"], dtype=FTYPE), log=state.get("log", False),
                    fit_cov_mat=state.get("fit_cov_mat"), using_legacy_data=state.get("using_legacy_data", False))
 

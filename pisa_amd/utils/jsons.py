@@ -67,6 +67,8 @@ def _revive(obj):
 
 
 def dumps(obj, **kwargs):
+    kwargs.pop("warn", None)            # the reference's overwrite warning (jsons.py:193): nothing to warn of here
+    kwargs.pop("overwrite", None)
     kwargs.setdefault("indent", 2)
     return json.dumps(_plain(obj), allow_nan=True, **kwargs)
 

@@ -1,0 +1,276 @@
+"""`OneDimBinning`, `MultiDimBinning`, `VarBinning` as value types (pisa/core/binning.py:142-1480, 1484-3040,
+3043-3178): equality on normalised values, indexing by bin, resampling, unit conversion, compatibility,
+iteration, pickles and JSON states, eval-able reprs.  The numbers the hot path takes from a binning (edges,
+weighted centres, volumes) are pinned elsewhere (`test_host_logic.py`, the golden fixtures).  CPU only."""
+import pickle
+from collections import OrderedDict
+from copy import deepcopy
+
+import numpy as np
+import pytest
+from numpy import array  # noqa: F401 -- the reprs are evaluated with it in scope
+
+from pisa_amd.core.binning import MultiDimBinning, OneDimBinning, VarBinning
+from pisa_amd.core.units import DimensionalityError, ureg
+from pisa_amd.utils import jsons
+
+TIGHT = dict(rtol=1e-13, atol=0)
+
+
+def _dims():
+    e = OneDimBinning(name="true_energy", num_bins=40, is_log=True, domain=[1, 80] * ureg.GeV, tex=r"E_{\rm true}",
+                      bin_names=["e%d" % i for i in range(40)])
+    cz = OneDimBinning(name="true_coszen", num_bins=20, is_lin=True, domain=[-1, 0], tex=r"\cos\theta")
+    pid = OneDimBinning(name="pid", bin_edges=[0, 0.3, 0.8, 1.0], bin_names=["cascade", "mixed", "track"])
+    return e, cz, pid
+
+
+def test_constructor_refusals():
+    with pytest.raises(TypeError):
+        OneDimBinning(name=3, num_bins=2, domain=[0, 1])
+    with pytest.raises(ValueError):
+        OneDimBinning(name="x", bin_edges=[0, 1, 2], domain=[0, 2])
+    with pytest.raises(ValueError):
+        OneDimBinning(name="x", num_bins=2, domain=[0, 1], is_lin=True, is_log=True)
+    with pytest.raises(ValueError):
+        OneDimBinning(name="x", num_bins=2)
+    with pytest.raises(ValueError):
+        OneDimBinning(name="x", bin_edges=[0, 2, 1])
+    with pytest.raises(ValueError):
+        OneDimBinning(name="x", bin_edges=[0, 1, 2], bin_names=["only_one"])
+    with pytest.raises(ValueError):
+        OneDimBinning(name="x", bin_edges=[0, 1, 2], bin_names=["a", ""])
+    with pytest.raises(ValueError):
+        OneDimBinning(name="x", bin_edges=[0, 1, 2] * ureg.m, units="GeV")
+    b = OneDimBinning(name="x", bin_edges=[100, 200, 400] * ureg.cm, units="m")      # converted to the units given
+    assert b.units == ureg.m and np.array_equal(b.edge_magnitudes, [1, 2, 4]) and not b.is_log
+    assert not OneDimBinning.is_binning_ok([1]) and not OneDimBinning.is_binning_ok([1, 1])
+
+
+def test_equality_is_on_normalised_values():
+    metres = OneDimBinning(name="distance", num_bins=10, is_log=True, domain=[0.1, 10] * ureg.m)
+    microns = OneDimBinning(name="distance", num_bins=10, is_log=True, domain=[1e5, 1e7] * ureg.um)
+    raw_m, raw_u = metres.edge_magnitudes * 1.0, microns.edge_magnitudes * 1e-6
+    assert np.any(raw_m != raw_u)                     # the conversions do not agree to the last bit ...
+    assert metres == microns and hash(metres) == hash(microns) and metres.edges_hash == microns.edges_hash
+    metres.normalize_values = microns.normalize_values = False
+    assert metres != microns                          # ... which only the normalisation forgives
+    assert metres != OneDimBinning(name="length", num_bins=10, is_log=True, domain=[0.1, 10] * ureg.m)
+    lin = OneDimBinning(name="distance", bin_edges=metres.bin_edges, is_lin=True)
+    assert lin != OneDimBinning(name="distance", bin_edges=metres.bin_edges, is_log=True) and lin.is_irregular
+    e, _, pid = _dims()
+    assert e != OneDimBinning(name="true_energy", num_bins=40, is_log=True, domain=[1, 80] * ureg.GeV)  # bin names
+    assert e.basename_binning == OneDimBinning(name="energy", bin_edges=e.bin_edges, is_log=True, bin_names=e.bin_names)
+    assert e.basename_binning.tex is None and e.basename == "energy" and pid.basename == "pid"
+    assert e.to("MeV") == e and e.to("MeV").units == ureg.MeV and e.to("MeV").hash == e.hash
+    assert np.allclose(e.to("MeV").edge_magnitudes, e.edge_magnitudes * 1e3, **TIGHT)
+    with pytest.raises(DimensionalityError):
+        e.to("m")
+    mutable = deepcopy(e)
+    mutable.ito("TeV")
+    assert mutable.units == ureg.TeV and mutable == e
+
+
+def test_indexing_by_bin():
+    e, _, pid = _dims()
+    assert e[...] is e and e[:] == e and len(e[3]) == 1 and e[3].bin_names == ("e3",)
+    assert np.array_equal(e[3].edge_magnitudes, e.edge_magnitudes[3:5])
+    assert e[-1] == e[39] and e[-40] == e[0] and e["e7"] == e[7]
+    assert e[2:5].bin_names == ("e2", "e3", "e4") and e[[2, 3, 4]] == e[2:5] and e[["e2", "e3"]] == e[2:4]
+    assert e[:-1].num_bins == 39 and e[1:5].is_log
+    for bad in (slice(-1, -3), slice(5, 5), slice(0, 10, 2), [1, 3], [3, 2], 40, -41):
+        with pytest.raises(ValueError):
+            e[bad]
+    with pytest.raises(ValueError):
+        e["nonexistent"]
+    assert pid.index("mixed") == 1 and pid.index(2) == 2 and "track" in pid and 3 not in pid and "x" not in pid
+    with pytest.raises(TypeError):
+        pid.index(1.0)
+    assert [b.bin_names[0] for b in pid] == ["cascade", "mixed", "track"]
+    assert list(pid.iteredgetuples()) == [(0.0, 0.3), (0.3, 0.8), (0.8, 1.0)]
+    assert pid.inbounds_criteria == "(pid >= %.15e) & (pid <= %.15e)" % (0.0, 1.0)
+
+
+def test_resampling_keeps_totals_and_compatibility():
+    e, cz, _ = _dims()
+    over, down = e.oversample(2), e.downsample(2)
+    assert over.num_bins == 80 and down.num_bins == 20 and over.bin_names is None and e.oversample(1) is e
+    assert OneDimBinning.is_bin_spacing_log_uniform(over.bin_edges) and OneDimBinning.is_bin_spacing_log_uniform(down.bin_edges)
+    assert np.array_equal(over.edge_magnitudes[::2], e.edge_magnitudes)        # the original edges, bit for bit
+    assert np.array_equal(down.edge_magnitudes, e.edge_magnitudes[::2])
+    for b in (over, down):
+        assert np.isclose(b.bin_widths.m.sum(), e.bin_widths.m.sum(), **TIGHT)
+        assert np.isclose(b.weighted_bin_widths.m.sum(), e.weighted_bin_widths.m.sum(), **TIGHT)
+    assert down.is_compat(e) and e.is_compat(over) and down.is_compat(over)
+    assert not e.is_compat(down) and not over.is_compat(e) and not e.is_compat(cz)
+    with pytest.raises(AssertionError):
+        over.assert_compat(e)
+    for bad in (3, 0, 41, 2.5):
+        with pytest.raises(ValueError):
+            e.downsample(bad)
+    with pytest.raises(ValueError):
+        e.oversample(1.5)
+    assert cz.oversample(4).num_bins == 80 and OneDimBinning.is_bin_spacing_lin_uniform(cz.oversample(4).bin_edges)
+
+
+def test_multi_dim_bins_and_dimensions():
+    e, cz, pid = _dims()
+    mdb = MultiDimBinning([e, cz])
+    assert e * cz == mdb == e + cz and (mdb * pid).names == ["true_energy", "true_coszen", "pid"]
+    assert (pid * mdb).names == ["pid", "true_energy", "true_coszen"]
+    assert mdb["true_energy"] is e and mdb.true_coszen is cz and "true_energy" in mdb and "pid" not in mdb
+    with pytest.raises(ValueError):
+        mdb["nonexistent"]
+    with pytest.raises(ValueError):
+        MultiDimBinning([e, e])
+    assert mdb.num_bins == [40, 20] and mdb.shape == (40, 20) and mdb.tot_num_bins == 800 and len(mdb) == 2
+    assert mdb[:, :] == mdb and mdb[...] is mdb and mdb[0, 0].shape == (1, 1) and mdb[-1, -1] == mdb[39, 19]
+    assert mdb[2:6, 0].shape == (4, 1) and mdb[0:, 0:] == mdb and mdb[-2, 0] == mdb[38, 0]
+    assert MultiDimBinning([e])[0] == MultiDimBinning([e[0]])
+    with pytest.raises(ValueError):
+        mdb[0]
+    with pytest.raises(ValueError):
+        mdb[0, "x"]
+    for flat, one_bin in enumerate(mdb.iterbins()):
+        coord = mdb.index2coord(flat)
+        assert one_bin == mdb[coord] and coord == (flat // 20, flat % 20)
+        if flat == 45:
+            assert coord.true_energy == 2 and coord.true_coszen == 5
+    assert list(mdb.itercoords())[21] == (1, 1) and len(list(mdb.iteredgetuples())) == 800
+    assert next(iter(mdb.iteredgetuples())) == ((e.edge_magnitudes[0], e.edge_magnitudes[1]), (-1.0, -0.95))
+    assert mdb.indexer(true_coszen=3) == (slice(None), 3) and mdb.slice(true_energy=slice(0, 2)).shape == (2, 20)
+    assert mdb.broadcast(np.arange(20), "true_coszen", "true_energy").shape == (1, 20)
+    assert mdb.index("true_coszen") == 1 and mdb.index(cz) == 1 and mdb.index("reco_coszen", use_basenames=True) == 1
+    with pytest.raises(ValueError):
+        mdb.index(2)
+    assert (mdb * pid).remove("true_coszen").names == ["true_energy", "pid"]
+    assert (mdb * pid)[0:40, 0:20, 1].squeeze() == mdb
+    assert mdb.basenames == ["energy", "coszen"]
+    reco = MultiDimBinning([OneDimBinning(name="reco_energy", bin_edges=e.bin_edges, is_log=True, bin_names=e.bin_names),
+                            OneDimBinning(name="reco_coszen", bin_edges=cz.bin_edges)])
+    assert reco != mdb and reco.basename_binning == mdb.basename_binning
+    assert mdb.inbounds_criteria == "(%s & %s)" % (e.inbounds_criteria, cz.inbounds_criteria)
+
+
+def test_multi_dim_resampling_units_order():
+    e, cz, pid = _dims()
+    mdb = MultiDimBinning([e, cz])
+    assert mdb.oversample(10).shape == (400, 200) and mdb.oversample(10, 1).shape == (400, 20)
+    assert mdb.oversample(true_coszen=10, true_energy=2).shape == (80, 200) and mdb.oversample(1, 1) == mdb
+    assert mdb.downsample(4, 2).shape == (10, 10) and mdb.downsample(true_coszen=5).shape == (40, 4)
+    with pytest.raises(ValueError):
+        mdb.oversample(2, 2, 2)
+    with pytest.raises(ValueError):
+        mdb.oversample(2, true_coszen=2)
+    with pytest.raises(ValueError):
+        mdb.oversample(energy=2)
+    over, down = mdb.oversample(10, 3), mdb.downsample(4, 2)
+    for vols in ("bin_volumes", "weighted_bin_volumes"):
+        total = getattr(mdb, vols)(attach_units=False).sum()
+        assert np.isclose(getattr(over, vols)(attach_units=False).sum(), total, **TIGHT)
+        assert np.isclose(getattr(down, vols)(attach_units=False).sum(), total, **TIGHT)
+    assert mdb.bin_volumes(attach_units=True).units == ureg.GeV and mdb.bin_volumes(attach_units=True).m.shape == (40, 20)
+    assert mdb.weighted_bin_volumes(attach_units=True).units.dimensionless
+    for entity in ("bin_edges", "weighted_centers", "midpoints", "bin_widths", "weighted_bin_widths"):
+        grid = mdb.meshgrid(entity=entity)
+        assert len(grid) == 2 and grid[0].shape == grid[1].shape == ((41, 21) if entity == "bin_edges" else (40, 20))
+    assert mdb.meshgrid("midpoints", attach_units=True)[0].units == ureg.GeV
+    in_mev = mdb.to("MeV", "")
+    assert in_mev["true_energy"].units == ureg.MeV and in_mev == mdb and in_mev.hash == mdb.hash
+    assert mdb.to(true_energy="TeV")["true_coszen"] is cz and mdb.to("MeV", None) == mdb
+    assert mdb.to(ureg.joule, "").true_energy.units == ureg.joule
+    three = MultiDimBinning([e, cz, pid])
+    order = ["pid", "true_energy", "true_coszen"]
+    assert three.reorder_dimensions(order).names == order
+    assert three.reorder_dimensions([2, 0, 1]).names == order
+    assert three.reorder_dimensions([2, "true_energy", cz]).names == order
+    assert three.reorder_dimensions(order).reorder_dimensions(three).names == three.names
+    assert mdb.reorder_dimensions(order).names == ["true_energy", "true_coszen"]     # names it lacks are skipped
+    with pytest.raises(ValueError):
+        three.reorder_dimensions(order[:2])                                           # but none of its own may be
+    assert three.reorder_dimensions(["reco_coszen", "reco_pid", "energy"], use_basenames=True).names == \
+        ["true_coszen", "pid", "true_energy"]
+    coarse = MultiDimBinning([e.downsample(2), cz.downsample(2)])
+    assert coarse.is_compat(mdb) and not mdb.is_compat(coarse) and mdb.is_compat(deepcopy(mdb))
+    coarse.assert_compat(mdb)
+    with pytest.raises(AssertionError):
+        mdb.assert_compat(coarse)
+    assert not mdb.is_compat(MultiDimBinning([cz, e]))
+    mdb.assert_array_fits(np.zeros((40, 20)))
+    with pytest.raises(ValueError):
+        mdb.assert_array_fits(np.zeros((20, 40)))
+
+
+def test_masks_follow_the_bins():
+    e, cz, _ = _dims()
+    mask = np.ones((40, 20), dtype=bool)
+    mask[3, 4] = False
+    masked = MultiDimBinning([e, cz], mask=mask)
+    assert masked != MultiDimBinning([e, cz]) and masked == MultiDimBinning([e, cz], mask=mask.copy())
+    assert masked[2:5, 4:6].mask.tolist() == [[True, True], [False, True], [True, True]]
+    assert masked.reorder_dimensions(["true_coszen", "true_energy"]).mask[4, 3] == False  # noqa: E712
+    with pytest.raises(ValueError):
+        MultiDimBinning([e, cz], mask=np.ones((20, 40), dtype=bool))
+    assert eval(repr(masked)) == masked
+
+
+def test_text_pickle_and_json_forms(tmp_path):
+    e, cz, pid = _dims()
+    metres = OneDimBinning(name="distance", num_bins=10, is_log=True, domain=[0.1, 10] * ureg.m)
+    for b in (e, cz, pid, metres, e[4], e.oversample(3)):
+        assert eval(repr(b)) == b and pickle.loads(pickle.dumps(b, pickle.HIGHEST_PROTOCOL)) == b
+        assert np.array_equal(eval(repr(b)).edge_magnitudes, b.edge_magnitudes) and deepcopy(b) == b
+        f = tmp_path / "one.json"
+        b.to_json(f, warn=False)
+        assert OneDimBinning.from_json(f) == b and OneDimBinning.from_json(f).tex == b.tex
+        jsons.to_json(b, f)
+        assert OneDimBinning.from_json(f) == b
+        # a binning inside other containers
+        jsons.to_json(([OrderedDict(odb=b)],), f)
+        state = jsons.from_json(f)[0][0]["odb"]
+        assert OneDimBinning(**{k: v for k, v in state.items() if k != "is_lin"}) == b
+    assert "logarithmically-uniform" in str(e) and "equally-sized" in str(cz) and "irregularly-sized" in str(pid)
+    assert e.label.startswith(r"E_{\rm true}") and "GeV" in e.label and cz.label == r"\cos\theta"
+    assert OneDimBinning(name="reco_x", num_bins=1, domain=[0, 1]).label == r"{\rm reco\_x}"
+    for mdb in (MultiDimBinning([e, cz]), MultiDimBinning([e, cz, pid], name="analysis")[0, 0, 1], MultiDimBinning([pid])):
+        assert eval(repr(mdb)) == mdb and pickle.loads(pickle.dumps(mdb, pickle.HIGHEST_PROTOCOL)) == mdb
+        assert deepcopy(mdb) == mdb and mdb.index2coord(0) == (0,) * mdb.num_dims      # coord type made on demand
+        assert pickle.loads(pickle.dumps(mdb)) == mdb
+        f = tmp_path / "multi.json"
+        mdb.to_json(f, warn=False)
+        assert MultiDimBinning.from_json(f) == mdb
+        jsons.to_json(([OrderedDict(mdb=mdb)],), f)
+        assert MultiDimBinning(**jsons.from_json(f)[0][0]["mdb"]) == mdb
+    from_dicts = MultiDimBinning([dict(name="true_energy", is_log=True, domain=[1, 80] * ureg.GeV, num_bins=40,
+                                       bin_names=e.bin_names), dict(name="true_coszen", is_lin=True, domain=[-1, 0], num_bins=20)])
+    assert from_dicts == MultiDimBinning([e, cz])
+
+
+def test_maps_of_a_binning():
+    e, cz, _ = _dims()
+    mdb = MultiDimBinning([e, cz])
+    ones, full = mdb.ones(name="o"), mdb.full(2.5, name="f")
+    assert ones.hist.shape == (40, 20) and float(np.sum(ones.hist)) == 800 and ones.binning == mdb and ones.name == "o"
+    assert np.all(full.hist == 2.5) and np.all(mdb.zeros(name="z").hist == 0) and mdb.empty(name="e").hist.shape == (40, 20)
+
+
+def test_var_binning():
+    e, cz, pid = _dims()
+    fine, coarse = MultiDimBinning([e, cz]), MultiDimBinning([e.downsample(2), cz.downsample(2)])
+    by_bins = VarBinning([coarse, fine, fine], pid)
+    assert by_bins.nselections == 3 == len(by_bins) and by_bins.names == [fine.names] * 3
+    assert list(by_bins) == [coarse, fine, fine] and by_bins[0] is coarse and by_bins.selections is pid
+    cuts = by_bins.selection_strings
+    assert cuts[0] == "(pid >= %.15e) & (pid < %.15e)" % (0.0, 0.3) and cuts[2].count("<=") == 1
+    by_cuts = VarBinning([coarse, fine], ["pid < 0.3", "pid >= 0.3"])
+    assert by_cuts.selection_strings == ["pid < 0.3", "pid >= 0.3"] and by_cuts != by_bins
+    assert by_cuts == VarBinning([deepcopy(coarse), deepcopy(fine)], ["pid < 0.3", "pid >= 0.3"])
+    VarBinning([fine, coarse], ["true_coszen < -0.5", "true_coszen >= -0.5"])      # a cut on a binned variable is allowed
+    with pytest.raises(ValueError):
+        VarBinning([MultiDimBinning([e, pid])] * 3, pid)                             # a selection DIMENSION is not
+    with pytest.raises(ValueError):
+        VarBinning([fine, coarse], "pid < 0.3")
+    with pytest.raises(AssertionError):
+        VarBinning([fine], ["pid < 0.3"])
+    with pytest.raises(AssertionError):
+        VarBinning([fine, coarse], ["pid < 0.3"])

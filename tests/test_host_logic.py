@@ -383,7 +383,9 @@ def test_hypersurface_forms_state_roundtrip_and_uncertainty(tmp_path):
     np.testing.assert_allclose(u, np.sqrt(np.einsum("...i,...ij,...j", g2, cov[..., :2, :2], g2)), rtol=1e-12)
     # fit-file round trip through load_hypersurfaces
     path = tmp_path / "fits.json"
-    path.write_text(json.dumps({"nue_cc+nuebar_cc": hsf.serializable_state, "nu_nc+nubar_nc": lg.serializable_state}))
+    from pisa_amd.utils import jsons
+
+    path.write_text(jsons.dumps({"nue_cc+nuebar_cc": hsf.serializable_state, "nu_nc+nubar_nc": lg.serializable_state}))
     loaded = load_hypersurfaces(str(path), expected_binning=b)
     assert list(loaded) == ["nue_cc+nuebar_cc", "nu_nc+nubar_nc"] and loaded["nu_nc+nubar_nc"].log
     g2_, u2_ = loaded["nue_cc+nuebar_cc"].evaluate(vals, return_uncertainty=True)
@@ -473,8 +475,9 @@ def test_interpolated_hypersurfaces(tmp_path):
     spec = OrderedDict([("deltam31", {"values": [[v, [["electron_volt", 2.0]]] for v in dm_vals], "scales_log": True}),
                         ("theta23", {"values": [[v, [["degree", 1.0]]] for v in th_vals], "scales_log": False})])
     path = tmp_path / "interp.json"
-    path.write_text(json.dumps({"interpolation_param_spec": spec, "hs_fits": fits},
-                               default=lambda o: None if isinstance(o, float) and o != o else o).replace("NaN", "NaN"))
+    from pisa_amd.utils import jsons
+
+    path.write_text(jsons.dumps({"interpolation_param_spec": spec, "hs_fits": fits}))
     loaded = load_interpolated_hypersurfaces(str(path), expected_binning=b)
     assert list(loaded) == ["nue_cc+nuebar_cc", "nu_nc+nubar_nc"]
     hi = loaded["nue_cc+nuebar_cc"]
