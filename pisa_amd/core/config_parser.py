@@ -21,11 +21,12 @@ import configparser
 import math
 import re
 from collections import OrderedDict
+from collections.abc import Mapping
 
 import numpy as np
 
 from pisa_amd import FTYPE
-from pisa_amd.core.binning import MultiDimBinning, OneDimBinning
+from pisa_amd.core.binning import MultiDimBinning, OneDimBinning, VarBinning
 from pisa_amd.core.param import Param, ParamSelector, Prior
 from pisa_amd.core.units import Quantity, ureg
 from pisa_amd.utils.resources import find_resource
@@ -131,6 +132,43 @@ def _parse_multidimbinning(config, binning, order):
     return MultiDimBinning(dims, name=binning)
 
 
+_BINNING_NS = {"np": np, "numpy": np, "units": ureg, "inf": np.inf}
+
+
+def _parse_varbinning(config, binning, order, bin_split):
+    """`<name>.split` = a dict (the `OneDimBinning` whose bins select the events) or comma-separated cut
+    expressions; a dimension's entry is one dict for all selections or a list with one per selection; an
+    optional `<name>.mask` likewise (config_parser.py:584-644)"""
+    try:
+        parsed = eval(bin_split, dict(_BINNING_NS))  # pylint: disable=eval-used
+    except Exception:  # pylint: disable=broad-except
+        parsed = None
+    if isinstance(parsed, Mapping):
+        selections = OneDimBinning(**parsed)
+    else:
+        selections = split(bin_split)
+    n = len(selections)
+    dims = [[] for _ in range(n)]
+    for bin_name in order:
+        kwargs = eval(config.get("binning", binning + "." + bin_name), dict(_BINNING_NS))  # pylint: disable=eval-used
+        if isinstance(kwargs, list):
+            assert len(kwargs) == n
+        else:
+            kwargs = [kwargs] * n
+        for i, kw in enumerate(kwargs):
+            dims[i].append(OneDimBinning(name=bin_name, **kw))
+    mask = config["binning"].get(binning + ".mask", None)
+    if mask is not None:
+        mask = eval(mask, dict(_BINNING_NS))  # pylint: disable=eval-used
+        if not all(np.ndim(m) == len(order) for m in mask):     # ONE mask (as many levels as dimensions):
+            mask = [mask] * n                                     # for every selection
+        assert len(mask) == n
+    else:
+        mask = [None] * n
+    return VarBinning(binnings=[MultiDimBinning(dims[i], name="%s_%d" % (binning, i), mask=mask[i]) for i in range(n)],
+                      selections=selections)
+
+
 def _param_subfields(subfields):
     """param.<selector>.<name>.<attr> decomposition (config_parser.py:394-451)"""
     selector = pname = attr = None
@@ -219,9 +257,11 @@ def parse_pipeline_config(config):
         if name.endswith(".order"):
             order = split(config.get("binning", name))
             binning = name[: -len(".order")]
-            if config["binning"].get(binning + ".split", None) is not None:
-                continue  # VarBinning: not part of this build
-            binning_dict[binning] = _parse_multidimbinning(config, binning, order)
+            bin_split = config["binning"].get(binning + ".split", None)
+            if bin_split is not None:
+                binning_dict[binning] = _parse_varbinning(config, binning, order, bin_split)
+            else:
+                binning_dict[binning] = _parse_multidimbinning(config, binning, order)
 
     stage_dicts = OrderedDict()
     sec = "pipeline"

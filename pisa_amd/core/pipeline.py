@@ -13,9 +13,9 @@ from time import time
 
 import numpy as np
 
-from pisa_amd.core.binning import MultiDimBinning
+from pisa_amd.core.binning import MultiDimBinning, OneDimBinning, VarBinning
 from pisa_amd.core.config_parser import PISAConfigParser, parse_pipeline_config
-from pisa_amd.core.container import ContainerSet
+from pisa_amd.core.container import Container, ContainerSet
 from pisa_amd.core.param import ParamSet
 from pisa_amd.core.stage import Stage
 
@@ -70,6 +70,9 @@ class Pipeline:
         for s in stages:
             s.select_params(sorted(selections), error_on_missing=False)
         self.setup()
+        if isinstance(self.output_binning, VarBinning):     # pipeline.py:119-121
+            self.assert_varbinning_compat()
+            self.assert_exclusive_varbinning()
 
     # -- container protocol -----------------------------------------------------------
     def __len__(self):
@@ -109,6 +112,12 @@ class Pipeline:
 
     @output_binning.setter
     def output_binning(self, binning):
+        if isinstance(binning, VarBinning):     # checked against the events at hand; no new set-up (pipeline.py:767-771)
+            self.assert_varbinning_compat()
+            self.assert_exclusive_varbinning(output_binning=binning)
+            self._data["output_binning"] = binning
+            self._plan = None
+            return
         self._data["output_binning"] = binning
         self.setup()
 
@@ -176,6 +185,10 @@ class Pipeline:
     def run(self):
         t0 = time()
         self._containers_stale = False
+        modes = [s.apply_mode for s in self._stages]
+        if modes != self.__dict__.get("_apply_modes") and isinstance(self.output_binning, VarBinning):
+            self.assert_varbinning_compat()     # a stage's apply_mode was changed between runs (pipeline.py:539-543)
+        self._apply_modes = modes
         for s in self._stages:
             s.run()
         if self._profile:
@@ -202,8 +215,16 @@ class Pipeline:
         self.run()
         if output_binning is None:
             output_binning = self.output_binning
+        elif isinstance(output_binning, VarBinning):
+            self.assert_exclusive_varbinning(output_binning=output_binning)
         if output_key is None:
             output_key = self.output_key
+        if isinstance(output_binning, VarBinning):
+            self.assert_varbinning_compat()
+            outputs = self._get_outputs_varbinning(output_binning, output_key)
+            if self._profile:
+                self._get_outputs_times.append(time() - t0)
+            return outputs
         assert isinstance(output_binning, MultiDimBinning)
         self._data.representation = output_binning
         if isinstance(output_key, tuple):
@@ -217,6 +238,91 @@ class Pipeline:
             self._plan = FastPlan.build(self)
         if self._profile:
             self._get_outputs_times.append(time() - t0)
+        return outputs
+
+    # -- one MapSet per event selection (VarBinning) ----------------------------------
+    def assert_varbinning_compat(self):
+        """every stage that applies anything applies it to events: no histogramming service (pipeline.py:686-712)"""
+        bad = [s for s in self._stages if s.apply_mode is not None and s.apply_mode != "events"]
+        if bad:
+            raise ValueError("When a variable binning is used, all stages need to set apply_mode='events', but '%s'"
+                             " of '%s' do(es) not!" % (", ".join("%s.%s" % (s.stage_name, s.service_name) for s in bad),
+                                                       self.name))
+
+    def assert_exclusive_varbinning(self, output_binning=None):
+        """no event of any container passes two of the cut expressions (pipeline.py:714-763); the bins of a
+        `OneDimBinning` of selections are exclusive by construction"""
+        vb = self.output_binning if output_binning is None else output_binning
+        if not isinstance(vb, VarBinning) or not isinstance(vb.selections, list):
+            return
+        self._data.representation = "events"
+        for c in self._data:
+            passed = np.zeros(c.size, dtype=np.int64)
+            for sel in vb.selections:
+                passed += np.broadcast_to(np.asarray(c.get_keep_mask(sel), dtype=bool), passed.shape)
+            if np.any(passed > 1):
+                raise ValueError("Selections %s are not mutually exclusive for '%s' (at least) in pipeline '%s'!"
+                                 % (vb.selections, c.name, self.name))
+
+    def _selection_rows(self, container, selections, i):
+        """device indices of the events of `container` in selection `i`; kept while the container's event
+        columns are the same objects (the columns a cut reads do not move during a fit)"""
+        import torch
+
+        from pisa_amd import kernels as K
+
+        if isinstance(selections, OneDimBinning):
+            names = (selections.name,)
+            key = (selections.hash, i)
+        else:
+            names = tuple(k for k in container.keys if k in selections[i])
+            key = (selections[i], i)
+        stamp = tuple(container.version(n) for n in names) + (container.size,)
+        cache = container.__dict__.setdefault("_selection_rows", {})
+        hit = cache.get(key)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        if isinstance(selections, OneDimBinning):
+            var = container[selections.name]
+            e = selections.edge_magnitudes
+            keep = (var >= e[i]) & (var < e[i + 1])
+        else:
+            keep = np.broadcast_to(np.asarray(container.get_keep_mask(selections[i]), dtype=bool), (container.size,))
+        rows = torch.from_numpy(np.flatnonzero(keep)).to(K.device())
+        cache[key] = (stamp, rows)
+        return rows
+
+    def _get_outputs_varbinning(self, output_binning, output_key):
+        """list of MapSets, one per selection: the selected events of every container histogrammed in that
+        selection's binning, sum of weights and (with an error key) square root of the sum of their squares
+        (pipeline.py:389-451).  The selected rows are gathered on the device; the histograms are the
+        `array_to_binned` translation of a fresh container, as in the reference."""
+        import torch
+
+        self._data.representation = "events"
+        key, err = output_key if isinstance(output_key, tuple) else (output_key, None)
+        outputs = []
+        for i, binning in enumerate(output_binning.binnings):
+            containers = []
+            for c in self._data:
+                rows = self._selection_rows(c, output_binning.selections, i)
+                cc = Container(c.name)
+                for var in binning.names:
+                    cc[var] = c.device(var).index_select(0, rows)
+                w = c.device(key).index_select(0, rows)
+                cc[key] = w
+                cc.translation_modes[key] = "sum"
+                if err is not None:
+                    cc[err] = torch.square(w)
+                    cc.translation_modes[err] = "sum"
+                containers.append(cc)
+            dat = ContainerSet(self._data.name, containers=containers, representation=binning)
+            if err is not None:
+                for cc in dat:
+                    cc[err] = torch.sqrt(cc.device(err))
+                outputs.append(dat.get_mapset(key, error=err))
+            else:
+                outputs.append(dat.get_mapset(key))
         return outputs
 
     def report_profile(self, detailed=False):

@@ -830,3 +830,84 @@ def test_metric_many_without_errors_uses_zero_variance_for_mod_chi2():
     assert eng.last_many is not None                  # llh: one sweep
     with pytest.raises(ValueError):
         dm.metric_many(pts, data, "no_such_metric")
+
+
+def test_var_binning_pipeline_one_mapset_per_selection():
+    """A pipeline whose output binning is a `VarBinning` (pisa/core/pipeline.py:389-451, 686-763; the reference's
+    own checks at :920-958): one MapSet per selection, each the weighted histogram of that selection's events in that
+    selection's binning with errors sqrt(sum w^2) -- compared with numpy's histogram of the host copies --, a
+    binned apply_mode refused, overlapping cuts refused, an empty selection accepted."""
+    from pisa_amd.core.binning import MultiDimBinning, VarBinning
+    from pisa_amd.core.map import MapSet
+    from pisa_amd.core.pipeline import Pipeline
+    from pisa_amd.core.units import ureg
+
+    p = Pipeline("settings/pipeline/varbin_example_hip.cfg")
+    vb = p.output_binning
+    assert isinstance(vb, VarBinning) and vb.nselections == 2
+    out = p.get_outputs()
+    assert len(out) == 2 and all(isinstance(ms, MapSet) for ms in out)
+
+    def expected(container, binning, keep):
+        # the translation's histogram is fast_histogram's: the range is half open, an event ON the last edge (the
+        # synthetic reco_coszen is clipped to 1) is outside (translation.py:148-166), where numpy would count it
+        keep = keep.copy()
+        for d in binning:
+            keep &= container[d.name] < d.edge_magnitudes[-1]
+        sample = [container[d.name][keep] for d in binning]
+        edges = [d.edge_magnitudes for d in binning]
+        w = container["weights"][keep]
+        return np.histogramdd(sample, bins=edges, weights=w)[0], np.sqrt(np.histogramdd(sample, bins=edges, weights=w * w)[0])
+
+    p.data.representation = "events"
+    edges = vb.selections.edge_magnitudes
+    total = 0.0
+    for i, (ms, binning) in enumerate(zip(out, vb.binnings)):
+        assert [m.name for m in ms] == [c.name for c in p.data] and all(m.binning == binning for m in ms)
+        for m, c in zip(ms, p.data):
+            keep = (c["pid"] >= edges[i]) & (c["pid"] < edges[i + 1])
+            assert 0 < keep.sum() < c.size
+            h, e = expected(c, binning, keep)
+            np.testing.assert_allclose(m.nominal_values, h, rtol=1e-12, atol=1e-300)
+            np.testing.assert_allclose(m.std_devs, e, rtol=1e-12, atol=1e-300)
+            total += m.nominal_values.sum()
+    # the two selections partition the events inside the reco binning
+    whole = sum(c["weights"][(c["reco_energy"] >= 5) & (c["reco_energy"] < 100) & (c["reco_coszen"] < 1)].sum() for c in p.data)
+    np.testing.assert_allclose(total, whole, rtol=1e-10)
+
+    # new parameters move the maps (the selected rows are kept, the weights are gathered again)
+    before = out[1][3].nominal_values.copy()
+    p.params.theta23.value = 38.0 * ureg.deg
+    again = p.get_outputs()
+    assert np.abs(again[1][3].nominal_values - before).max() > 0
+    c, keep = p.data.containers[3], None
+    p.data.representation = "events"
+    keep = (c["pid"] >= edges[1]) & (c["pid"] < edges[2])
+    np.testing.assert_allclose(again[1][3].nominal_values, expected(c, vb.binnings[1], keep)[0], rtol=1e-12, atol=1e-300)
+
+    # selections by cut expressions, given from outside; a single output key: no errors
+    by_cuts = VarBinning(binnings=vb.binnings, selections=["(true_coszen > 0) & (pid > 0)", "true_coszen <= 0"])
+    maps = p.get_outputs(output_binning=by_cuts, output_key="weights")
+    c = p.data.containers[0]
+    p.data.representation = "events"
+    np.testing.assert_allclose(maps[0][0].nominal_values,
+                               expected(c, vb.binnings[0], (c["true_coszen"] > 0) & (c["pid"] > 0))[0], rtol=1e-12, atol=1e-300)
+    assert not np.any(maps[0][0].std_devs)
+
+    # a stage that applies to a binning cannot feed a variable binning
+    osc = p["prob3"]
+    assert isinstance(osc.calc_mode, MultiDimBinning)
+    osc.apply_mode = osc.calc_mode
+    with pytest.raises(ValueError, match="apply_mode='events'"):
+        p.get_outputs()
+    osc.apply_mode = "events"
+    p.get_outputs()
+    # overlapping selections are refused when they are set, empty ones are not
+    with pytest.raises(ValueError, match="not mutually exclusive"):
+        p.output_binning = VarBinning(binnings=vb.binnings, selections=["pid > 0"] * 2)
+    assert p.output_binning is vb
+    with pytest.raises(ValueError, match="not mutually exclusive"):
+        p.get_outputs(output_binning=VarBinning(binnings=vb.binnings, selections=["pid > 0"] * 2))
+    p.output_binning = VarBinning(binnings=vb.binnings, selections=["pid > 0", "pid > np.inf"])
+    out = p.get_outputs()
+    assert out[0][0].nominal_values.sum() > 0 and all(m.nominal_values.sum() == 0 for m in out[1])

@@ -274,3 +274,34 @@ def test_var_binning():
         VarBinning([fine], ["pid < 0.3"])
     with pytest.raises(AssertionError):
         VarBinning([fine, coarse], ["pid < 0.3"])
+
+
+def test_var_binning_from_cfg_text():
+    """`<name>.split` in a [binning] section makes a `VarBinning` (config_parser.py:584-644): the reference's own
+    settings/binning/example.cfg defines one split by a pid binning and one by cut expressions"""
+    from pisa_amd.core.config_parser import PISAConfigParser, _parse_varbinning, split
+    from pisa_amd.utils.resources import find_resource
+
+    cfg = PISAConfigParser()
+    cfg.read(find_resource("settings/pipeline/varbin_example_hip.cfg"))
+    by_pid = _parse_varbinning(cfg, "reco_var_binning", split(cfg.get("binning", "reco_var_binning.order")),
+                               cfg.get("binning", "reco_var_binning.split"))
+    assert isinstance(by_pid.selections, OneDimBinning) and by_pid.selections.name == "pid"
+    assert np.array_equal(by_pid.selections.edge_magnitudes, [-3.0, 0.0, 1000.0])
+    assert by_pid.names == [["reco_energy", "reco_coszen"]] * 2
+    assert [b.shape for b in by_pid] == [(10, 10), (10, 20)] and [b.name for b in by_pid] == \
+        ["reco_var_binning_0", "reco_var_binning_1"]
+    assert by_pid[0].reco_energy == by_pid[1].reco_energy and by_pid[0].reco_energy.is_log
+    by_cuts = _parse_varbinning(cfg, "reco_var_binning_2", split(cfg.get("binning", "reco_var_binning_2.order")),
+                                cfg.get("binning", "reco_var_binning_2.split"))
+    assert by_cuts.selections == ["(true_energy > 10) & (true_coszen > 0)", "(true_coszen <= 0)"]
+    assert [b.shape for b in by_cuts] == [(10, 10), (10, 20)]
+    # masks: one for all selections, or one per selection
+    cfg["binning"]["m.order"] = "x"
+    cfg["binning"]["m.split"] = "x < 1, x >= 1"
+    cfg["binning"]["m.x"] = "{'num_bins': 3, 'domain': [0, 3]}"
+    cfg["binning"]["m.mask"] = "[True, False, True]"
+    assert [b.mask.tolist() for b in _parse_varbinning(cfg, "m", ["x"], "x < 1, x >= 1")] == [[True, False, True]] * 2
+    cfg["binning"]["m.mask"] = "[[True, False, True], [False, True, True]]"
+    assert [b.mask.tolist() for b in _parse_varbinning(cfg, "m", ["x"], "x < 1, x >= 1")] == \
+        [[True, False, True], [False, True, True]]
