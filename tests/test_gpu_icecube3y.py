@@ -281,7 +281,9 @@ def test_hypersurface_fit_file_with_uncertainty_propagation(oracle, tmp_path, mo
         surfaces[key] = Hypersurface(ob, params, 1.0 + rs.randn(*ob.shape) * 0.01,
                                      fit_cov_mat=np.einsum("...ij,...kj->...ik", a, a))
         files[key] = surfaces[key].serializable_state
-    (tmp_path / "fits.json").write_text(json.dumps(files))
+    from pisa_amd.utils import jsons
+
+    (tmp_path / "fits.json").write_text(jsons.dumps(files))
     cfg[("discr_sys", "hypersurfaces")]["fit_results_file"] = str(tmp_path / "fits.json")
     cfg[("discr_sys", "hypersurfaces")]["propagate_uncertainty"] = True
     pipe = Pipeline(cfg)
@@ -441,7 +443,9 @@ def test_interpolated_hypersurfaces_in_the_3y_pipeline(oracle, tmp_path, monkeyp
                          "hs_fit": maps})
     spec = OrderedDict([("deltam31", {"values": [[v, [["electron_volt", 2.0]]] for v in dm_vals], "scales_log": False}),
                         ("theta23", {"values": [[v, [["degree", 1.0]]] for v in th_vals], "scales_log": False})])
-    (tmp_path / "interp.json").write_text(json.dumps({"interpolation_param_spec": spec, "hs_fits": fits}))
+    from pisa_amd.utils import jsons
+
+    (tmp_path / "interp.json").write_text(jsons.dumps({"interpolation_param_spec": spec, "hs_fits": fits}))
     cfg[("discr_sys", "hypersurfaces")]["fit_results_file"] = str(tmp_path / "interp.json")
     cfg[("discr_sys", "hypersurfaces")]["interpolated"] = True
     # the stage needs the interpolation parameters among its own: the objects of the oscillation stage
