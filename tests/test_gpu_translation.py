@@ -1,0 +1,101 @@
+"""`pisa_amd.core.translation`: the free-function interface of pisa/core/translation.py on the GPU.  Checked the
+way the reference checks its own (`test_histogram`, translation.py:779-818: against `np.histogramdd`), plus the
+fast_histogram rule on the last edge, logarithmic / irregular binnings, vector weights, lookups and resampling
+against plain numpy restatements written here."""
+import numpy as np
+import pytest
+
+from pisa_amd.core.binning import MultiDimBinning, OneDimBinning
+from pisa_amd.core.translation import find_index, histogram, lookup, resample
+from pisa_amd.core.units import ureg
+
+pytestmark = pytest.mark.gpu
+
+
+def test_histogram_matches_numpy_as_in_the_reference_test():
+    rand = np.random.RandomState(seed=0)
+    n = 10000
+    weights = rand.rand(n)
+    dims, sample = [], []
+    for k, num_bins in enumerate([2, 3, 4]):
+        dims.append(OneDimBinning(name="dim%d" % k, num_bins=num_bins, is_lin=True, domain=[0, num_bins]))
+        sample.append(rand.rand(n) * num_bins)
+        b = MultiDimBinning(dims)
+        edges = [d.edge_magnitudes for d in dims]
+        want = np.histogramdd(sample=sample, bins=edges, weights=weights)[0].ravel()
+        got = histogram(sample, weights, b, averaged=False)
+        assert got.dtype == np.float64 and got.shape == want.shape
+        np.testing.assert_allclose(got, want, rtol=1e-13)
+        counts = np.histogramdd(sample=sample, bins=edges)[0].ravel()
+        np.testing.assert_allclose(histogram(sample, weights, b, averaged=True), want / counts, rtol=1e-13)
+        assert np.array_equal(histogram(sample, None, b, averaged=False), counts)
+        # an (N, D) array is a sample too; `apply_weights` has no effect (as in the reference)
+        np.testing.assert_array_equal(histogram(np.stack(sample, axis=1), weights, b, averaged=False, apply_weights=False), got)
+
+
+def test_last_edge_rule_follows_the_regime():
+    x = np.array([0.0, 0.5, 1.0, 2.0, 2.0, -0.1, np.nan])
+    w = np.arange(1.0, 8.0)
+    lin = MultiDimBinning([OneDimBinning(name="x", num_bins=2, domain=[0, 2])])
+    assert histogram([x], w, lin, averaged=False).tolist() == [3.0, 3.0]              # 2.0 is outside: fast_histogram
+    irregular = MultiDimBinning([OneDimBinning(name="x", bin_edges=[0, 0.7, 2])])
+    assert histogram([x], w, irregular, averaged=False).tolist() == [3.0, 12.0]      # 2.0 is inside: numpy
+    logb = MultiDimBinning([OneDimBinning(name="x", num_bins=2, domain=[0.5, 2], is_log=True)])
+    want = np.histogramdd([x], bins=[logb.dims[0].edge_magnitudes], weights=w)[0]
+    assert histogram([x], w, logb, averaged=False).tolist() == want.tolist() == [2.0, 12.0]
+    # averaged: empty bins are 0, not NaN
+    assert histogram([np.array([0.1])], np.array([4.0]), lin, averaged=True).tolist() == [4.0, 0.0]
+
+
+def test_mixed_binning_vector_weights_and_device_tensors():
+    import torch
+
+    rs = np.random.RandomState(1)
+    n = 50000
+    e = OneDimBinning(name="reco_energy", num_bins=7, is_log=True, domain=[1, 100] * ureg.GeV)
+    cz = OneDimBinning(name="reco_coszen", num_bins=5, domain=[-1, 1])
+    pid = OneDimBinning(name="pid", bin_edges=[-3, 0, 0.2, 1000])
+    b = MultiDimBinning([e, cz, pid])
+    sample = [10 ** rs.uniform(-0.2, 2.2, n), np.clip(rs.normal(0, 0.7, n), -1, 1), rs.uniform(-4, 3, n)]
+    sample[0][:5] = [1.0, 100.0, e.edge_magnitudes[3], np.nan, 0.5]
+    w = rs.rand(n, 3)
+    edges = [d.edge_magnitudes for d in b]
+    got = histogram(sample, w, b, averaged=False)
+    assert got.shape == (b.size, 3)
+    for i in range(3):
+        np.testing.assert_allclose(got[:, i], np.histogramdd(sample, bins=edges, weights=w[:, i])[0].ravel(), rtol=1e-12)
+    dev = [torch.as_tensor(c, device="cuda") for c in sample]
+    on_dev = histogram(dev, torch.as_tensor(w[:, 0].copy(), device="cuda"), b, averaged=False)
+    assert isinstance(on_dev, torch.Tensor) and on_dev.is_cuda
+    np.testing.assert_array_equal(on_dev.cpu().numpy(), got[:, 0])
+    # lookup: the value of the bin an event falls in, 0 outside (last edge inside for this regime)
+    flat = rs.rand(b.size)
+    idx = [find_index(c, ed) for c, ed in zip(sample, edges)]
+    inside = np.all([(i >= 0) & (i < d.num_bins) for i, d in zip(idx, b)], axis=0)
+    want = np.where(inside, flat.reshape(b.shape)[tuple(np.clip(i, 0, d.num_bins - 1) for i, d in zip(idx, b))], 0.0)
+    np.testing.assert_array_equal(lookup(sample, flat, b), want)
+    np.testing.assert_array_equal(lookup(dev, torch.as_tensor(flat, device="cuda"), b).cpu().numpy(), want)
+    vec = rs.rand(b.size, 2)
+    got2 = lookup(sample, vec, b)
+    assert got2.shape == (n, 2) and np.array_equal(got2[:, 1], np.where(inside, vec[:, 1].reshape(b.shape)[tuple(np.clip(i, 0, d.num_bins - 1) for i, d in zip(idx, b))], 0.0))
+    # linear regular: half open
+    lin = MultiDimBinning([cz])
+    vals = np.arange(5.0) + 1
+    assert lookup([np.array([-1.0, 0.99, 1.0, 1.5, np.nan])], vals, lin).tolist() == [1.0, 5.0, 0.0, 0.0, 0.0]
+    with pytest.raises(ValueError):
+        histogram(sample, w, "not a binning", averaged=False)
+    with pytest.raises(ValueError):
+        histogram(sample[:2], w, b, averaged=False)
+
+
+def test_resample_between_binnings():
+    fine = MultiDimBinning([OneDimBinning(name="x", num_bins=8, domain=[0, 8]), OneDimBinning(name="y", num_bins=4, domain=[0, 4])])
+    coarse = MultiDimBinning([OneDimBinning(name="x", num_bins=4, domain=[0, 8]), OneDimBinning(name="y", num_bins=4, domain=[0, 4])])
+    values = np.arange(32.0)
+    centres = lambda b: [g.ravel() for g in b.meshgrid("weighted_centers")]  # noqa: E731
+    down = resample(values, centres(fine), fine, centres(coarse), coarse)
+    np.testing.assert_array_equal(down.reshape(4, 4), values.reshape(4, 2, 4).mean(axis=1))      # two old bins per new one
+    up = resample(down, centres(coarse), coarse, centres(fine), fine)
+    np.testing.assert_array_equal(up.reshape(8, 4), np.repeat(down.reshape(4, 4), 2, axis=0))     # nearest old bin
+    with pytest.raises(ValueError):
+        resample(values, centres(fine), fine, centres(coarse), MultiDimBinning([coarse.dims[0]]))

@@ -725,3 +725,28 @@ def test_container_set_reference_unit_test():
     indep, dep = data.get_shared_keys(rep_indep=True), data.get_shared_keys(rep_indep=False)
     assert key in indep and key in dep
     assert len(indep) == 2 and len(dep) == 1
+
+
+def test_find_index_is_numpys_bin_rule():
+    """`translation.find_index` (pisa/core/translation.py:504-553) by the reference's own recipe (:821-942): the bin
+    `np.histogramdd` counts a value in; -1 below the range or for NaN, `num_bins` above; infinite outer edges"""
+    from pisa_amd.core.translation import find_index
+
+    eps = np.finfo(float).eps
+    for basic in ([-1, -0.5, -0.1, 0, 0.1, 0.5, 1, 2, 3, 4], [], [0.1], [-0.1, 0.1]):
+        for lo, hi in ((None, None), (-np.inf, None), (None, np.inf), (-np.inf, np.inf)):
+            edges = ([] if lo is None else [lo]) + list(basic) + ([] if hi is None else [hi])
+            if len(edges) < 2:
+                continue
+            edges = np.array(edges, dtype=float)
+            n = len(edges) - 1
+            inside = [(a + b) / 2 if np.isfinite(a) and np.isfinite(b) else a + 10.5 if np.isfinite(a) else
+                      b - 10.5 if np.isfinite(b) else 10.5 for a, b in zip(edges[:-1], edges[1:])]
+            with np.errstate(invalid="ignore"):
+                vals = np.concatenate([[-np.inf, np.inf, np.nan], edges, inside, (1 - eps) * edges, (1 + eps) * edges])
+            want = []
+            for v in vals:
+                hit = np.nonzero(np.histogramdd([v], np.atleast_2d(edges))[0])[0]
+                want.append(-1 if (np.isnan(v) or v < edges[0]) else n if v > edges[-1] else int(hit[0]))
+            assert [find_index(v, edges) for v in vals] == want
+            assert find_index(vals, edges).tolist() == want
