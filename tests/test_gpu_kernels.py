@@ -449,6 +449,24 @@ def test_metric_golden_and_errors(K):
     # chi2 returns exactly 0 when all |delta| < 5 eps (stats.py:160-161)
     t = K.metric("chi2", K.to_device([1.0, 2.0]), K.to_device([1.0, 2.0]))
     assert float(t.item()) == 0.0
+    # the free functions of utils/stats.py: per-bin values in the shape of the inputs
+    from pisa_amd.core.map import Map
+    from pisa_amd.utils import stats
+
+    shape = (2, -1) if g["actual"].size % 2 == 0 else (1, -1)
+    a2, e2 = g["actual"].reshape(shape), g["expected"].reshape(shape)
+    for name in stats.ALL_METRICS:
+        got = getattr(stats, name)(a2, e2)
+        assert got.shape == a2.shape
+        np.testing.assert_allclose(got, g[name].reshape(shape), rtol=1e-12, equal_nan=True)
+    sigma = 0.3 * np.sqrt(e2)
+    want = (a2 - np.clip(e2, stats.SMALL_POS, None)) ** 2 / (sigma ** 2 + np.clip(e2, stats.SMALL_POS, None))
+    np.testing.assert_allclose(stats.mod_chi2(a2, e2, sigma=sigma), want, rtol=1e-12)
+    binning = [dict(name="x", num_bins=a2.shape[0], domain=[0, 1]), dict(name="y", num_bins=a2.shape[1], domain=[0, 1])]
+    exp_map = Map(name="e", hist=e2, binning=binning, error_hist=sigma)
+    np.testing.assert_allclose(stats.mod_chi2(Map(name="a", hist=a2, binning=binning), exp_map), want, rtol=1e-12)
+    with pytest.raises(ValueError):
+        stats.chi2(a2, e2.ravel())
 
 
 def test_barr_flux_golden(K):
