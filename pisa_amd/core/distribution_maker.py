@@ -1,7 +1,9 @@
 """`DistributionMaker`: a list of pipelines whose output maps are summed
 (counterpart of pisa/core/distribution_maker.py:53-520; `get_outputs`
 :251-294, free-parameter rescaling :462)."""
-from collections.abc import Sequence
+from collections.abc import Mapping, Sequence
+
+import numpy as np
 
 from pisa_amd.core.map import MapSet
 from pisa_amd.core.param import Param, ParamSet
@@ -11,14 +13,87 @@ __all__ = ["DistributionMaker"]
 
 
 class DistributionMaker:
-    def __init__(self, pipelines, label=None, profile=False):
+    def __init__(self, pipelines, label=None, set_livetime_from_data=True, profile=False):
         if isinstance(pipelines, (str, Pipeline)) or not isinstance(pipelines, Sequence):
             pipelines = [pipelines]
         self.label = label
         self._pipelines = [p if isinstance(p, Pipeline) else Pipeline(p, profile=profile)
                            for p in pipelines]
         self._profile = profile
+        self.metadata = {}
+        if set_livetime_from_data:
+            self._livetime_from_data()
+        # all pipelines of a maker belong to one detector (distribution_maker.py:178-187)
+        self.detector_name = "no_name"
+        for p in self._pipelines:
+            if p.detector_name != self.detector_name and self.detector_name != "no_name":
+                raise NameError("Different detector names in distribution_maker pipelines")
+            self.detector_name = p.detector_name
         self._unify_params()
+
+    def _livetime_from_data(self):
+        """a stage that carries `metadata['livetime']` (a data loader) fixes `params.livetime` of every pipeline that
+        has it, in seconds (distribution_maker.py:113-171)"""
+        from pisa_amd.core.units import ureg
+
+        found = None
+        for ip, p in enumerate(self._pipelines):
+            for js, s in enumerate(p.stages):
+                md = getattr(s, "metadata", None)
+                if not (isinstance(md, Mapping) and "livetime" in md):
+                    continue
+                if found is None:
+                    found = md["livetime"]
+                if md["livetime"] != found:
+                    raise ValueError("Pipeline index %d, stage index %d has data livetime = %s, in disagreement with"
+                                     " previously-found livetime = %s" % (ip, js, md["livetime"], found))
+        self.metadata["livetime"] = found
+        if found is None:
+            return
+        livetime = found * ureg.sec
+        for p in self._pipelines:
+            if "livetime" in p.params.names:
+                p.params.livetime.is_fixed = True
+                if p.params.livetime.value != livetime:
+                    p.params.livetime = livetime
+
+    @property
+    def profile(self):
+        return self._profile
+
+    @profile.setter
+    def profile(self, value):
+        for p in self._pipelines:
+            p.profile = value
+        self._profile = value
+
+    def report_profile(self, detailed=False, **kwargs):
+        for p in self._pipelines:
+            p.report_profile(detailed=detailed)
+
+    @property
+    def num_events_per_bin(self):
+        """unweighted events of all pipelines per output bin, flat (distribution_maker.py:385-408)"""
+        from pisa_amd.core.translation import histogram
+
+        binning = self._pipelines[0].output_binning
+        total = np.zeros(binning.size)
+        for p in self._pipelines:
+            assert p.output_binning == binning
+            data = p.data
+            keep = data.representation
+            try:
+                data.representation = "events"
+                for c in data:
+                    if all(n in c.keys for n in binning.names) and c.size:
+                        total += histogram([c[n] for n in binning.names], None, binning, averaged=False)
+            finally:
+                data.representation = keep
+        return total
+
+    @property
+    def empty_bin_indices(self):
+        return np.where(self.num_events_per_bin == 0)[0]
 
     pipelines = property(lambda self: self._pipelines)
 

@@ -107,3 +107,80 @@ def test_service_sets_up_and_runs(stage_dot_service):
             if "weights" in c.keys:
                 w = np.asarray(c["weights"])
                 assert w.size and np.all(np.isfinite(w)), (stage_dot_service, c.name)
+
+
+def test_detectors_shared_and_per_detector_parameters():
+    """`Detectors` (pisa/core/detectors.py:36-381; the flow of its own test, :384-433, on two copies of the event-mode
+    example): pipelines grouped by detector name, shared parameters ONE parameter of the fit, the others per
+    detector under `<name>_<detector>`, selections switched everywhere, rescaled values dealt in the order of
+    `params.free`."""
+    import numpy as np
+
+    from pisa_amd.core.detectors import Detectors
+    from pisa_amd.core.pipeline import Pipeline
+    from pisa_amd.core.units import ureg
+
+    pipes = [Pipeline("settings/pipeline/example_hip.cfg") for _ in range(3)]
+    pipes[0].detector_name = pipes[1].detector_name = "detector1"
+    pipes[2].detector_name = "detector2"
+    with pytest.raises(NameError):
+        Detectors([pipes[0], Pipeline("settings/pipeline/example_hip.cfg")])       # one pipeline without a detector
+    with pytest.raises(NameError):
+        Detectors(pipes, shared_params=["no_such_param"])
+    model = Detectors(pipes, shared_params=["theta23", "deltam31", "delta_index"])
+    assert model.det_names == ["detector1", "detector2"]
+    assert [len(d.pipelines) for d in model] == [2, 1] and [d.detector_name for d in model.distribution_makers] == model.det_names
+    names = list(model.params.names)
+    assert names[:3] == ["theta23", "deltam31", "delta_index"]                      # the shared ones first
+    assert "aeff_scale" in names and "aeff_scale_detector2" in names and "theta23_detector2" not in names
+    assert model.param_selections == ["nh"]
+
+    nominal = model.get_outputs(return_sum=True)
+    assert len(nominal) == 2 and nominal[0][0].hist.shape == nominal[1][0].hist.shape
+    np.testing.assert_allclose(nominal[0][0].hist, 2 * nominal[1][0].hist, rtol=1e-12)   # two pipelines against one
+
+    model.params.delta_index.value = 0.05                   # shared
+    model.params.aeff_scale.value = 2.0                     # detector1 only
+    model.params.aeff_scale_detector2.value = 0.5           # detector2 only
+    out = model.get_outputs(return_sum=True)
+    d1, d2 = model.distribution_makers
+    assert d1.params.delta_index.value == 0.05 and d2.params.delta_index.value == 0.05
+    assert d1.params.aeff_scale.value == 2.0 and d2.params.aeff_scale.value == 0.5
+    # aeff_scale multiplies every weight: detector1 = 2 pipelines x 2.0, detector2 = 1 pipeline x 0.5
+    np.testing.assert_allclose(out[0][0].hist, 8 * out[1][0].hist, rtol=1e-12)
+    assert np.abs(out[1][0].hist / 0.5 - nominal[1][0].hist).max() > 0              # and delta_index moved the maps
+    per_pipeline = model.get_outputs()
+    assert [len(x) for x in per_pipeline] == [2, 1]
+
+    # selections
+    t23 = dict(nh=model.params.theta23.value)
+    model.select_params("ih")
+    t23["ih"] = model.params.theta23.value
+    assert t23["ih"] != t23["nh"] and all(d.params.theta23.value == t23["ih"] for d in model)
+    model.select_params("nh")
+    assert model.params.theta23.value == t23["nh"] and model.param_selections == ["nh"]
+
+    # free parameters: values / rescaled values in the order of `params.free`
+    free = list(model.params.free.names)
+    assert free[:3] == ["theta23", "deltam31", "delta_index"] and "aeff_scale_detector2" in free
+    assert model.shared_param_ind_list == [[(list(d.params.free.names).index(n), model.shared_params.index(n))
+                                            for n in d.params.free.names if n in model.shared_params] for d in model]
+    r = np.linspace(0.2, 0.8, len(free))
+    model._set_rescaled_free_params(r)
+    for name, rv in zip(free, r):
+        np.testing.assert_allclose(model.params[name]._rescaled_value, rv, rtol=1e-12)
+    own = dict(zip(free, r))
+    for d in model:
+        for prm in d.params.free:
+            want = own.get("%s_%s" % (prm.name, d.detector_name), own[prm.name])
+            np.testing.assert_allclose(prm._rescaled_value, want, rtol=1e-12)
+    vals = [p.value for p in model.params.free]
+    vals[free.index("aeff_scale_detector2")] = 1.25 * ureg.dimensionless
+    model.set_free_params(vals)
+    assert model.distribution_makers[1].params.aeff_scale.value == 1.25 and model.distribution_makers[0].params.aeff_scale.value != 1.25
+    model.reset_free()
+    assert model.params.aeff_scale_detector2.value == model.params.aeff_scale_detector2.nominal_value
+    model.randomize_free_params(random_state=3)
+    assert model.params.theta23.value == d1.params.theta23.value == d2.params.theta23.value
+    counts = model.num_events_per_bin
+    assert len(counts) == 2 and counts[0].sum() == 2 * counts[1].sum() > 0 and len(model.empty_bin_indices) == 2
