@@ -75,11 +75,43 @@ class Analysis:
 
     @staticmethod
     def _sign(metric):
-        if metric in LLH_METRICS:
+        """-1 for likelihoods (maximised), +1 for chi-squares; a list (one metric per detector) must be of one
+        kind (analysis.py:926-935)"""
+        metrics = [metric] if isinstance(metric, str) else list(metric)
+        if metrics and all(m in LLH_METRICS for m in metrics):
             return -1
-        if metric in CHI2_METRICS:
+        if metrics and all(m in CHI2_METRICS for m in metrics):
             return +1
         raise ValueError("Defined metrics are not compatible")
+
+    @staticmethod
+    def _metrics(metric, n):
+        """one metric per detector: a name for all of them, or a list of `n` names (analysis.py:913-924)"""
+        if isinstance(metric, str):
+            return [metric] * n
+        metric = list(metric)
+        if len(metric) == 1:
+            return metric * n
+        assert len(metric) == n, "one metric per detector"
+        return metric
+
+    def _total_metric(self, data_dist, hypo, hypo_maker, metric):
+        """metric of the template(s) against the data plus the priors' penalty (analysis.py:2588-2630): summed over
+        the detectors of a `Detectors` (a metric each, the penalty by the first), over the selections of a
+        variable binning, or the one total"""
+        if type(hypo_maker).__name__ == "Detectors":
+            ms = self._metrics(metric, len(hypo_maker.distribution_makers))
+            val = 0.0
+            for d, h, m in zip(data_dist, hypo, ms):
+                val += d.metric_total(expected_values=h, metric=m)
+            return val + hypo_maker.params.priors_penalty(metric=ms[0])
+        m = metric if isinstance(metric, str) else metric[0]
+        if isinstance(hypo, list):
+            val = 0.0
+            for d, h in zip(data_dist, hypo):
+                val += d.metric_total(expected_values=h, metric=m)
+            return val + hypo_maker.params.priors_penalty(metric=m)
+        return data_dist.metric_total(expected_values=hypo, metric=m) + hypo_maker.params.priors_penalty(metric=m)
 
     def _minimizer_callable(self, scaled_param_vals, hypo_maker, data_dist, metric, counter,
                             fit_history, flip_x0=None, external_priors_penalty=None):
@@ -89,8 +121,7 @@ class Analysis:
             x = np.where(flip_x0, 1 - x, x)
         hypo_maker._set_rescaled_free_params(np.clip(x, 0.0, 1.0))  # pylint: disable=protected-access
         hypo = hypo_maker.get_outputs(return_sum=True)
-        metric_val = (data_dist.metric_total(expected_values=hypo, metric=metric)
-                      + hypo_maker.params.priors_penalty(metric=metric))
+        metric_val = self._total_metric(data_dist, hypo, hypo_maker, metric)
         counter += 1
         if fit_history is not None:
             fit_history.append([metric_val] + [p.value.m for p in hypo_maker.params.free])
@@ -211,8 +242,7 @@ class Analysis:
         free = hypo_maker.params.free
         if len(free) == 0:
             hypo = hypo_maker.get_outputs(return_sum=True)
-            val = (data_dist.metric_total(expected_values=hypo, metric=metric)
-                   + hypo_maker.params.priors_penalty(metric=metric))
+            val = self._total_metric(data_dist, hypo, hypo_maker, metric)
             return HypoFitResult(metric, val, hypo_maker.params, hypo, [], None, 1)
         x0 = np.array(free._rescaled_values, dtype=np.float64)
         bounds = [(0.0, 1.0)] * len(x0)
@@ -220,13 +250,17 @@ class Analysis:
         # a perfect match of data and template at the starting point (pseudo-data generated at the
         # nominal values): no fit (analysis.py:1746-1786; comparisons.ALLCLOSE_KW)
         hypo = hypo_maker.get_outputs(return_sum=True)
-        data_maps = list(data_dist) if hasattr(data_dist, "maps") else [data_dist]
-        if len(data_maps) == len(hypo) and all(
+
+        def maps_of(x):     # the maps of a MapSet, of a list of MapSets (detectors / selections), or the one map
+            if isinstance(x, list):
+                return [m for ms in x for m in maps_of(ms)]
+            return list(x) if hasattr(x, "maps") else [x]
+        data_maps, hypo_maps = maps_of(data_dist), maps_of(hypo)
+        if len(data_maps) == len(hypo_maps) and all(
                 d.hist.shape == h.hist.shape
                 and np.allclose(d.hist, h.hist, rtol=1e-12, atol=np.finfo(np.float64).eps, equal_nan=True)
-                for d, h in zip(data_maps, hypo)):
-            val = (data_dist.metric_total(expected_values=hypo, metric=metric)
-                   + hypo_maker.params.priors_penalty(metric=metric))
+                for d, h in zip(data_maps, hypo_maps)):
+            val = self._total_metric(data_dist, hypo, hypo_maker, metric)
             meta = OrderedDict(success=True, nit=0, nfev=0, message="Initial hypo matches data, no need for fit")
             return HypoFitResult(metric, val, hypo_maker.params, hypo, None, meta, 0)
         method = ms["method"].lower()

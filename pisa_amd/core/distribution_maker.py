@@ -196,7 +196,10 @@ class DistributionMaker:
         from pisa_amd.core.map import Map
 
         pts = [np.clip(np.asarray(x, dtype=np.float64), 0.0, 1.0) for x in rescaled_points]
-        data_map = data_dist if isinstance(data_dist, Map) else (data_dist.maps[0] if len(data_dist) == 1 else None)
+        if isinstance(data_dist, list):        # one MapSet per selection of a variable binning: point by point
+            data_map = None
+        else:
+            data_map = data_dist if isinstance(data_dist, Map) else (data_dist.maps[0] if len(data_dist) == 1 else None)
         plan = self._pipelines[0]._plan if len(self._pipelines) == 1 and self._pipelines[0].fast_path else None
         if plan is not None and data_map is not None and len(pts) > 1:
             pens = []
@@ -221,8 +224,11 @@ class DistributionMaker:
             if on_point is not None:
                 on_point(i)
             hypo = self.get_outputs(return_sum=True)
-            out.append(data_dist.metric_total(expected_values=hypo, metric=metric)
-                       + self.params.priors_penalty(metric=metric))
+            if isinstance(hypo, list):
+                val = sum(d.metric_total(expected_values=h, metric=metric) for d, h in zip(data_dist, hypo))
+            else:
+                val = data_dist.metric_total(expected_values=hypo, metric=metric)
+            out.append(val + self.params.priors_penalty(metric=metric))
         return out
 
     def randomize_free_params(self, random_state=None):
@@ -254,6 +260,14 @@ class DistributionMaker:
 
     def get_outputs(self, return_sum=False, sum_map_name="total", **kwargs):
         outputs = [p.get_outputs(**kwargs) for p in self._pipelines]
+        if return_sum and isinstance(outputs[0], list):
+            # pipelines with a VarBinning: one summed MapSet per selection (distribution_maker.py:283-291)
+            outs = []
+            for i in range(len(outputs[0])):
+                total = sum(ms[i].total(sum_map_name) for ms in outputs)
+                total.name = sum_map_name
+                outs.append(MapSet([total], name=self.label))
+            return outs
         if return_sum:
             # distribution_maker.py:274-281: sum([sum(x) for x in outputs]); `total()` is that sum
             # over one pipeline's maps -- for device-backed outputs without bringing them home
