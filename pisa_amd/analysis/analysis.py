@@ -362,3 +362,315 @@ class Analysis:
         for p in best.params.free:
             hypo_maker.params[p.name].value = p.value
         return best
+
+    # -- nested fit strategies (analysis.py:854-1560) -------------------------------------------------
+    # A strategy is {method, method_kwargs, local_fit_kwargs}; `local_fit_kwargs` is again such a dict (or a
+    # list of them) that the strategy runs as its inner fit(s).  `scipy` is the local fit; `iminuit` and
+    # `nlopt` need their packages.
+
+    @staticmethod
+    def _update_values(hypo_maker, params, update_nominal_values=False, update_range=False, update_is_fixed=False):
+        """values (optionally ranges, nominal values, fixed flags) of `params` onto the maker's OWN parameter
+        objects of the same names (manipulate_params.py:126-158; `_detector` form :161-190)"""
+        from pisa_amd.core.param import Param, ParamSet
+
+        if isinstance(params, Param):
+            params = [params]
+        if type(hypo_maker).__name__ == "Detectors":
+            for d in hypo_maker:
+                ps = ParamSet([deepcopy(p) for p in params])
+                for name in list(ps.names):
+                    tail = "_%s" % d.detector_name
+                    if name.endswith(tail):
+                        plain = name[: -len(tail)]
+                        if plain in ps.names:
+                            ps.remove(plain)
+                        ps[name].name = plain
+                        ps._reindex()  # pylint: disable=protected-access
+                Analysis._update_values(d, list(ps), update_nominal_values, update_range, update_is_fixed)
+            hypo_maker.init_params()
+            return
+        for p in params:
+            for pipeline in hypo_maker:
+                if p.name not in pipeline.params.names:
+                    continue
+                own = pipeline.params[p.name]
+                if update_range:
+                    own.range = p.range
+                own.value = p.value
+                if update_nominal_values:
+                    own.nominal_value = p.nominal_value
+                if update_is_fixed:
+                    own.is_fixed = p.is_fixed
+
+    def _better(self, new, old, metric):
+        sign = self._sign(metric)
+        return sign * new < sign * old
+
+    def _inner(self, data_dist, hypo_maker, metric, external_priors_penalty, spec, store_fit_history,
+               include_metric_maps):
+        return self.fit_recursively(data_dist, hypo_maker, metric, external_priors_penalty, spec["method"],
+                                    spec.get("method_kwargs"), spec.get("local_fit_kwargs"),
+                                    store_fit_history=store_fit_history, include_metric_maps=include_metric_maps)
+
+    def fit_recursively(self, data_dist, hypo_maker, metric, external_priors_penalty, method, method_kwargs=None,
+                        local_fit_kwargs=None, store_fit_history=False, include_metric_maps=False):
+        """Global search strategies around local fits, nested to any depth: `method` one of scipy, octants,
+        best_of, condition, grid_scan, constrained, ranges, staged (iminuit, nlopt: their packages).  Returns
+        the `HypoFitResult` of the best fit; the maker is left at its values."""
+        n = len(hypo_maker.distribution_makers) if type(hypo_maker).__name__ == "Detectors" else 1
+        metrics = [metric] if isinstance(metric, str) else list(metric)
+        if type(hypo_maker).__name__ == "Detectors":
+            if len(metrics) == 1:
+                metrics = metrics * n
+            elif len(metrics) != n:
+                raise IndexError("Number of defined metrics does not match with number of detectors.")
+        else:
+            assert len(metrics) == 1, "Only one metric allowed for DistributionMaker"
+        if method in ("fit_octants", "fit_ranges"):
+            method = method.split("_")[1]
+        fit = getattr(self, "_fit_%s" % method, None)
+        if fit is None:
+            raise ValueError("unknown fit method '%s'" % method)
+        return fit(data_dist, hypo_maker, metrics if n > 1 else metrics[0], external_priors_penalty,
+                   method_kwargs or {}, local_fit_kwargs, store_fit_history, include_metric_maps)
+
+    def _fit_scipy(self, data_dist, hypo_maker, metric, external_priors_penalty, method_kwargs, local_fit_kwargs,
+                   store_fit_history, include_metric_maps):
+        """a local scipy minimiser; `method_kwargs` are minimiser settings in the reference's form
+        ({"method": {"value": ...}, "options": {"value": {...}}}) or a settings file"""
+        if method_kwargs.get("global_method") is not None:
+            raise NotImplementedError("global scipy methods (%s) are not part of this build; nest a local fit in"
+                                      " `grid_scan` / `best_of` instead" % method_kwargs["global_method"])
+        settings = {k: v for k, v in method_kwargs.items() if k in ("method", "options")} or None
+        if external_priors_penalty is None:
+            res = self.fit_hypo(data_dist, hypo_maker, metric, minimizer_settings=settings, reset_free=False)
+        else:
+            res = self._fit_with_penalty(data_dist, hypo_maker, metric, settings, external_priors_penalty)
+        if not store_fit_history:
+            res.fit_history = None
+        return res
+
+    def _fit_iminuit(self, *args, **kwargs):
+        raise ImportError("the 'iminuit' strategy needs the iminuit package, which is not installed; use 'scipy'")
+
+    def _fit_nlopt(self, *args, **kwargs):
+        raise ImportError("the 'nlopt' strategy needs the nlopt package, which is not installed; use 'scipy'")
+
+    def _fit_with_penalty(self, data_dist, hypo_maker, metric, settings, external_priors_penalty):
+        """the local fit with a user penalty added to every evaluation (`_minimizer_callable`'s
+        `external_priors_penalty`, analysis.py:2640-2646): point by point"""
+        from scipy import optimize
+
+        ms = dict(method="L-BFGS-B", options=dict(ftol=2e-5, gtol=1e-5, eps=1e-4, maxiter=200))
+        if settings:
+            ms.update(load_minimizer_settings(settings))
+        x0 = np.array(hypo_maker.params.free._rescaled_values, dtype=np.float64)  # pylint: disable=protected-access
+        bounds = [(0.0, 1.0)] * len(x0)
+        counter, history = Counter(), []
+        method = ms["method"].lower()
+        res = optimize.minimize(
+            fun=self._minimizer_callable, x0=x0,
+            args=(hypo_maker, data_dist, metric, counter, history, None, external_priors_penalty),
+            bounds=bounds if method in ("l-bfgs-b", "slsqp", "tnc", "trust-constr") else None,
+            method=ms["method"], options=dict(ms.get("options", {})))
+        hypo_maker._set_rescaled_free_params(np.clip(res.x, 0.0, 1.0))  # pylint: disable=protected-access
+        hypo = hypo_maker.get_outputs(return_sum=True)
+        meta = OrderedDict(success=bool(res.success), nit=int(getattr(res, "nit", -1)), nfev=int(res.nfev),
+                           message=str(res.message))
+        return HypoFitResult(metric, self._sign(metric) * res.fun, hypo_maker.params, hypo, history, meta, counter.count)
+
+    def _fit_octants(self, data_dist, hypo_maker, metric, external_priors_penalty, method_kwargs, local_fit_kwargs,
+                     store_fit_history, include_metric_maps):
+        """both octants of a mixing angle, the better inner fit kept (analysis.py:974-1092)"""
+        angle = method_kwargs["angle"]
+        args = (data_dist, hypo_maker, metric, external_priors_penalty, local_fit_kwargs, store_fit_history,
+                include_metric_maps)
+        if angle not in hypo_maker.params.free.names:
+            return self._inner(*args)
+        reset_free = method_kwargs.get("reset_free", True)
+        start = None if reset_free else deepcopy(hypo_maker.params)
+        orig, case1, case2 = self.get_separate_octant_params(hypo_maker, angle, method_kwargs["inflection_point"],
+                                                             method_kwargs.get("tolerance"))
+        hypo_maker.update_params(case1)
+        best = self._inner(*args)
+        if reset_free:
+            hypo_maker.reset_free()
+        else:
+            for p in start:
+                if p.name != angle:
+                    hypo_maker.params[p.name].value = p.value
+        hypo_maker.update_params(case2)
+        other = self._inner(*args)
+        for res in (best, other):
+            res.params[angle].range = deepcopy(orig.range)
+        if self._better(other.metric_val, best.metric_val, metric):
+            best, other = other, best
+        best.alternate_fit = other
+        hypo_maker.update_params(orig)
+        self._update_values(hypo_maker, list(best.params.free), update_range=True)
+        return best
+
+    def _fit_best_of(self, data_dist, hypo_maker, metric, external_priors_penalty, method_kwargs, local_fit_kwargs,
+                     store_fit_history, include_metric_maps):
+        """several configured fits (`local_fit_kwargs` is a list), the best one returned (analysis.py:1094-1132)"""
+        results = []
+        for spec in local_fit_kwargs:
+            if method_kwargs.get("reset_free", True):
+                hypo_maker.reset_free()
+            results.append(self._inner(data_dist, hypo_maker, metric, external_priors_penalty, spec,
+                                       store_fit_history, include_metric_maps))
+        sign = self._sign(metric)
+        best = results[int(np.argmin([sign * r.metric_val for r in results]))]
+        self._update_values(hypo_maker, list(best.params.free))
+        return best
+
+    def _fit_condition(self, data_dist, hypo_maker, metric, external_priors_penalty, method_kwargs, local_fit_kwargs,
+                       store_fit_history, include_metric_maps):
+        """the first of two strategies if `condition_func(hypo_maker)` holds, else the second (analysis.py:1134-1170)"""
+        assert "condition_func" in method_kwargs and len(local_fit_kwargs) == 2
+        cond = method_kwargs["condition_func"]
+        if isinstance(cond, str):
+            cond = eval(cond)  # pylint: disable=eval-used
+        if not callable(cond):
+            raise ValueError("Condition function is neither a callable nor a string that can be evaluated to a callable.")
+        spec = local_fit_kwargs[0] if cond(hypo_maker) else local_fit_kwargs[1]
+        return self._inner(data_dist, hypo_maker, metric, external_priors_penalty, spec, store_fit_history,
+                           include_metric_maps)
+
+    def _fit_grid_scan(self, data_dist, hypo_maker, metric, external_priors_penalty, method_kwargs, local_fit_kwargs,
+                       store_fit_history, include_metric_maps):
+        """the inner fit started from (or, `fix_grid_params`, held at) every point of a grid of parameter values;
+        optionally a `refined_fit` from the best point with everything free again (analysis.py:1172-1290)"""
+        grid = method_kwargs["grid"]
+        names = list(grid)
+        reset_free = method_kwargs.get("reset_free", True)
+        fix = method_kwargs.get("fix_grid_params", False)
+        mesh = np.meshgrid(*[np.atleast_1d(grid[n].m) for n in names])
+        if reset_free:
+            hypo_maker.reset_free()
+        originally_free = list(hypo_maker.params.free.names)
+        results = []
+        for idx in np.ndindex(mesh[0].shape):
+            if reset_free:
+                hypo_maker.reset_free()
+            for n, m in zip(names, mesh):
+                moved = deepcopy(hypo_maker.params[n])
+                moved.value = m[idx] * grid[n].u
+                if fix:
+                    moved.is_fixed = True
+                self._update_values(hypo_maker, moved, update_is_fixed=True)
+            results.append(self._inner(data_dist, hypo_maker, metric, external_priors_penalty, local_fit_kwargs,
+                                       store_fit_history, include_metric_maps))
+        for n in originally_free:
+            self._set_fixed(hypo_maker, n, False)
+        sign = self._sign(metric)
+        best = results[int(np.argmin([sign * r.metric_val for r in results]))]
+        best.grid_metric_vals = np.array([r.metric_val for r in results]).reshape(mesh[0].shape)
+        self._update_values(hypo_maker, [p for p in best.params if p.name in originally_free])
+        refined = method_kwargs.get("refined_fit")
+        if refined is not None:
+            spec = dict(refined)
+            spec["method_kwargs"] = dict(spec.get("method_kwargs") or {}, reset_free=False) \
+                if spec["method"] != "scipy" else spec.get("method_kwargs")
+            best = self._inner(data_dist, hypo_maker, metric, external_priors_penalty, spec, store_fit_history,
+                               include_metric_maps)
+        return best
+
+    @staticmethod
+    def _set_fixed(hypo_maker, name, flag):
+        makers = hypo_maker if type(hypo_maker).__name__ == "Detectors" else [hypo_maker]
+        for maker in makers:
+            for pipeline in maker:
+                if name in pipeline.params.names:
+                    pipeline.params[name].is_fixed = flag
+        if type(hypo_maker).__name__ == "Detectors":
+            hypo_maker.init_params()
+
+    def _fit_constrained(self, data_dist, hypo_maker, metric, external_priors_penalty, method_kwargs, local_fit_kwargs,
+                         store_fit_history, include_metric_maps):
+        """the inner fit under `ineq_func(params) > 0`: its violation times a penalty is added to the metric and
+        the penalty doubled until the fit ends inside (analysis.py:1292-1394)"""
+        assert "ineq_func" in method_kwargs and "necessary_free_params" in method_kwargs
+        args = (store_fit_history, include_metric_maps)
+        if not set(method_kwargs["necessary_free_params"]).issubset(hypo_maker.params.free.names):
+            return self._inner(data_dist, hypo_maker, metric, external_priors_penalty, local_fit_kwargs, *args)
+        ineq = method_kwargs["ineq_func"]
+        if isinstance(ineq, str):
+            ineq = eval(ineq)  # pylint: disable=eval-used
+        if not callable(ineq):
+            raise ValueError("Inequality function is neither a callable nor a string that can be evaluated to a callable.")
+
+        def violation(params):
+            v = ineq(params)
+            return 0.0 if v > 0.0 else -v
+
+        penalty = method_kwargs.get("minimum_penalty", 1000.0)
+        tol = method_kwargs.get("constraint_tol", 1e-4)
+        sign = self._sign(metric)
+        if method_kwargs.get("reset_free", False):
+            hypo_maker.reset_free()
+        while True:
+            scale = penalty
+
+            def penalised(hypo_maker, metric, scale=scale):
+                extra = 0.0 if external_priors_penalty is None else external_priors_penalty(hypo_maker=hypo_maker, metric=metric)
+                return sign * scale * violation(hypo_maker.params) + extra
+
+            for name, value in method_kwargs.get("starting_values", {}).items():
+                self._update_values(hypo_maker, [_with_value(hypo_maker.params[name], value)])
+            res = self._inner(data_dist, hypo_maker, metric, penalised, local_fit_kwargs, *args)
+            penalty *= 2
+            if violation(res.params) <= tol:
+                return res
+
+    def _fit_ranges(self, data_dist, hypo_maker, metric, external_priors_penalty, method_kwargs, local_fit_kwargs,
+                    store_fit_history, include_metric_maps):
+        """the inner fit with one parameter confined to each of several ranges in turn, started at the same
+        relative position in each; the best kept (analysis.py:1396-1495)"""
+        name = method_kwargs["param_name"]
+        args = (data_dist, hypo_maker, metric, external_priors_penalty, local_fit_kwargs, store_fit_history,
+                include_metric_maps)
+        if name not in hypo_maker.params.free.names:
+            return self._inner(*args)
+        original = deepcopy(hypo_maker.params[name])
+        rescaled = original._rescaled_value  # pylint: disable=protected-access
+        results = []
+        for interval in method_kwargs["ranges"]:
+            moved = deepcopy(original)
+            moved.range = interval                      # (a range is not checked against the value it finds)
+            moved._rescaled_value = rescaled  # pylint: disable=protected-access
+            moved.nominal_value = moved.value
+            self._update_values(hypo_maker, moved, update_range=True, update_nominal_values=True)
+            results.append(self._inner(*args))
+        sign = self._sign(metric)
+        best = results[int(np.argmin([sign * r.metric_val for r in results]))]
+        best.params[name].range = original.range
+        best.params[name].nominal_value = original.nominal_value
+        self._update_values(hypo_maker, list(best.params.free), update_range=True, update_nominal_values=True)
+        return best
+
+    def _fit_staged(self, data_dist, hypo_maker, metric, external_priors_penalty, method_kwargs, local_fit_kwargs,
+                    store_fit_history, include_metric_maps):
+        """sub-fits one after the other, each starting where the one before ended: the nominal values are moved
+        to the last best fit so that an inner `reset_free` keeps the progress (analysis.py:1497-1559)"""
+        assert isinstance(local_fit_kwargs, list) and len(local_fit_kwargs) > 1
+        nominal = {p.name: p.nominal_value for p in hypo_maker.params.free}
+        best = None
+        for spec in local_fit_kwargs:
+            if best is not None:
+                self._update_values(hypo_maker, list(best.params.free), update_nominal_values=True)
+            best = self._inner(data_dist, hypo_maker, metric, external_priors_penalty, spec, store_fit_history,
+                               include_metric_maps)
+            for p in best.params.free:
+                p.nominal_value = p.value
+        for p in best.params.free:
+            p.nominal_value = nominal[p.name]
+        self._update_values(hypo_maker, list(best.params.free), update_nominal_values=True)
+        return best
+
+
+def _with_value(param, value):
+    p = deepcopy(param)
+    p.value = value
+    return p

@@ -252,3 +252,92 @@ def test_fits_over_detectors_and_over_a_variable_binning():
     maker.params.aeff_scale.value = 1.2
     again = ana.fit_hypo(pseudo, maker, "chi2", reset_free=False)
     assert again.minimizer_metadata["nit"] == 0 and again.num_distributions_generated == 0
+
+
+def test_nested_fit_strategies():
+    """`Analysis.fit_recursively` (pisa/analysis/analysis.py:854-1560): octants around a local scipy fit find an
+    injected second-octant theta23 and keep the mirrored fit as the alternate; ranges / grid_scan / best_of / staged /
+    condition run the same inner fit their way and end at the same point, constrained ends on its bound; the maker is
+    left at the best fit with its original ranges and nominal values."""
+    import numpy as np
+
+    from pisa_amd.analysis.analysis import Analysis
+    from pisa_amd.core.distribution_maker import DistributionMaker
+    from pisa_amd.core.units import ureg
+
+    maker = DistributionMaker(["settings/pipeline/example_hip.cfg"])
+    for p in maker.params:
+        p.is_fixed = p.name not in ("theta23", "aeff_scale")
+    nominal = {p.name: p.nominal_value for p in maker.params.free}
+    t23_range = [q for q in maker.params.theta23.range]
+    maker.params.theta23.value = 49.0 * ureg.deg
+    maker.params.aeff_scale.value = 1.08
+    truth = maker.get_outputs(return_sum=True)
+    data = type(truth)([truth[0]._new(truth[0].hist.copy(), None, name="total")])
+    maker.reset_free()
+    ana = Analysis()
+    local = dict(method="scipy", method_kwargs=dict(method=dict(value="L-BFGS-B"),
+                                                    options=dict(value=dict(ftol=1e-9, gtol=1e-8, eps=1e-6, maxiter=200))),
+                 local_fit_kwargs=None)
+
+    def at_truth(fit, tol=0.05):
+        np.testing.assert_allclose(maker.params.theta23.value.m_as("deg"), 49.0, atol=tol)
+        np.testing.assert_allclose(maker.params.aeff_scale.value.m, 1.08, atol=1e-3)
+        np.testing.assert_allclose(fit.params.theta23.value.m_as("deg"), 49.0, atol=tol)
+        assert fit.metric_val < 1e-3
+        assert maker.params.theta23.range[0] == t23_range[0] and maker.params.theta23.range[1] == t23_range[1]
+        assert all(maker.params[n].nominal_value == v for n, v in nominal.items())
+
+    # the local fit alone (on this sample it crosses the octant boundary by itself; histories only when asked for)
+    alone = ana.fit_recursively(data, maker, "chi2", None, **local)
+    at_truth(alone)
+    assert alone.fit_history is None
+    maker.reset_free()
+    octants = dict(method="octants", method_kwargs=dict(angle="theta23", inflection_point=45 * ureg.deg),
+                   local_fit_kwargs=local)
+    fit = ana.fit_recursively(data, maker, "chi2", None, store_fit_history=True, **octants)
+    at_truth(fit)
+    assert fit.alternate_fit.params.theta23.value.m_as("deg") <= 45.0 and fit.alternate_fit.metric_val > fit.metric_val   # held at the octant boundary
+    assert fit.fit_history and fit.params.theta23.range[1] == t23_range[1]
+    # the same through two ranges of the angle
+    maker.reset_free()
+    ranges = dict(method="fit_ranges", method_kwargs=dict(param_name="theta23", ranges=[[31, 45] * ureg.deg, [45, 59] * ureg.deg]),
+                  local_fit_kwargs=local)
+    at_truth(ana.fit_recursively(data, maker, "chi2", None, **ranges))
+    # a grid of starting points; then with the grid parameter held and a refined fit from the best point
+    maker.reset_free()
+    grid = dict(method="grid_scan", method_kwargs=dict(grid=dict(theta23=[40, 50] * ureg.deg)), local_fit_kwargs=local)
+    fit = ana.fit_recursively(data, maker, "chi2", None, **grid)
+    at_truth(fit)
+    assert fit.grid_metric_vals.shape == (2,) and fit.grid_metric_vals[1] < fit.grid_metric_vals[0]
+    maker.reset_free()
+    held = dict(method="grid_scan", method_kwargs=dict(grid=dict(theta23=[41, 48, 50.5] * ureg.deg), fix_grid_params=True,
+                                                       refined_fit=local), local_fit_kwargs=local)
+    at_truth(ana.fit_recursively(data, maker, "chi2", None, **held))
+    assert list(maker.params.free.names) == ["theta23", "aeff_scale"]
+    # best_of: the plain local fit against the octant search; staged: coarse, then fine from where it ended
+    maker.reset_free()
+    at_truth(ana.fit_recursively(data, maker, "chi2", None, "best_of", None, [local, octants]))
+    maker.reset_free()
+    coarse = dict(local, method_kwargs=dict(method=dict(value="L-BFGS-B"), options=dict(value=dict(ftol=1e-3, eps=1e-4, maxiter=5))))
+    at_truth(ana.fit_recursively(data, maker, "chi2", None, "staged", None, [dict(octants, local_fit_kwargs=coarse), local]))
+    # condition: a callable, or text that evaluates to one
+    maker.reset_free()
+    cond = dict(condition_func="lambda maker: 'theta23' in maker.params.free.names")
+    at_truth(ana.fit_recursively(data, maker, "chi2", None, "condition", cond, [octants, local]))
+    # constrained: theta23 held below 47 deg in rescaled space -> the fit ends on the bound, worse than the free fit
+    maker.reset_free()
+    r47 = (47.0 - t23_range[0].m_as("deg")) / (t23_range[1].m_as("deg") - t23_range[0].m_as("deg"))
+    bound = dict(method="constrained",
+                 method_kwargs=dict(ineq_func=lambda params: r47 - params.theta23._rescaled_value,
+                                    necessary_free_params=["theta23"], starting_values=dict(theta23=46.0 * ureg.deg)),
+                 local_fit_kwargs=local)
+    fit = ana.fit_recursively(data, maker, "chi2", None, **bound)
+    assert 46.5 < fit.params.theta23.value.m_as("deg") <= 47.0 + 0.02 and fit.metric_val > 1e-3
+    # refusals
+    with pytest.raises(ImportError):
+        ana.fit_recursively(data, maker, "chi2", None, "iminuit", {}, None)
+    with pytest.raises(ValueError):
+        ana.fit_recursively(data, maker, "chi2", None, "simulated_annealing", {}, None)
+    with pytest.raises(AssertionError):
+        ana.fit_recursively(data, maker, ["chi2", "chi2"], None, **local)
