@@ -47,6 +47,59 @@ class HypoFitResult:
         vals = ", ".join("%s=%s" % (p.name, p.value) for p in self.params.free)
         return "HypoFitResult(%s=%.8g; %s)" % (self.metric, self.metric_val, vals)
 
+    # -- dictionary access and files (analysis.py:229-232, 345-371) --------------------------------
+    _state_attrs = ("metric", "metric_val", "params", "hypo_asimov_dist", "num_distributions_generated",
+                    "minimizer_metadata", "fit_history")
+
+    def __getitem__(self, key):
+        if key in self._state_attrs:
+            return getattr(self, key)
+        raise ValueError("Unknown property %s" % key)
+
+    @property
+    def serializable_state(self):
+        """the result as plain containers: the parameters' states, the template's maps, the minimiser's report and
+        the history (first column the metric, then the free parameters in order)"""
+        hypo = self.hypo_asimov_dist
+        if isinstance(hypo, list):
+            hypo = [h.serializable_state for h in hypo]
+        elif hypo is not None:
+            hypo = hypo.serializable_state
+        return OrderedDict([("metric", self.metric), ("metric_val", float(self.metric_val)),
+                            ("params", self.params.serializable_state), ("hypo_asimov_dist", hypo),
+                            ("num_distributions_generated", self.num_distributions_generated),
+                            ("minimizer_metadata", None if self.minimizer_metadata is None
+                             else OrderedDict(self.minimizer_metadata)),
+                            ("fit_history", self.fit_history)])
+
+    state = serializable_state
+
+    def to_json(self, filename, **kwargs):
+        from pisa_amd.utils import jsons
+
+        jsons.to_json(self.serializable_state, filename, **kwargs)
+
+    @classmethod
+    def from_state(cls, state):
+        from pisa_amd.core.map import MapSet
+        from pisa_amd.core.param import Param, ParamSet
+
+        assert set(state) == set(cls._state_attrs), "ill-formed state dict"
+        hypo = state["hypo_asimov_dist"]
+        if isinstance(hypo, list):
+            hypo = [MapSet.from_json(h) for h in hypo]
+        elif hypo is not None:
+            hypo = MapSet.from_json(hypo)
+        params = ParamSet([Param(**p) for p in state["params"]])
+        return cls(state["metric"], state["metric_val"], params, hypo, state["fit_history"],
+                   state["minimizer_metadata"], state["num_distributions_generated"])
+
+    @classmethod
+    def from_json(cls, filename):
+        from pisa_amd.utils import jsons
+
+        return cls.from_state(jsons.from_json(filename))
+
 
 def load_minimizer_settings(settings):
     """`settings`: a dict {method, options}, or the reference's minimizer-settings format

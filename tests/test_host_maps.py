@@ -212,3 +212,28 @@ def test_json_states(tmp_path):
     ms.to_json(tmp_path / "ms.json.bz2")
     back = MapSet.from_json(tmp_path / "ms.json.bz2")
     assert back == ms and back.name == "pair" and back.tex == "P" and back["y"]._var is None
+
+
+def test_fit_result_state_round_trip(tmp_path):
+    """`HypoFitResult` as a dictionary and as a JSON file (pisa/analysis/analysis.py:229-232, 345-371)"""
+    from collections import OrderedDict
+
+    from pisa_amd.analysis.analysis import HypoFitResult
+    from pisa_amd.core.param import Param, ParamSet, Prior
+
+    params = ParamSet(Param("theta23", 42 * ureg.deg, prior=Prior("uniform"), range=[0, 90] * ureg.deg, is_fixed=False),
+                      Param("aeff_scale", 1.0, prior=Prior("gaussian", mean=1.0, stddev=0.1), range=[0, 3], is_fixed=True))
+    e, cz, _ = _binning()
+    total = Map(name="total", hist=np.arange(50.0).reshape(10, 5), binning=(e, cz), error_hist=np.ones((10, 5)))
+    meta = OrderedDict(success=True, nit=2, nfev=7, message="converged")
+    for template in (MapSet([total]), [MapSet([total]), MapSet([total * 2])]):
+        fit = HypoFitResult("chi2", 1.25, params, template, [[1.5, 40.0], [1.25, 42.0]], meta, 7)
+        assert fit["metric_val"] == 1.25 and fit["params"] == params and fit.params is not params      # a snapshot
+        with pytest.raises(ValueError):
+            fit["no_such_property"]
+        fit.to_json(tmp_path / "fit.json")
+        back = HypoFitResult.from_json(tmp_path / "fit.json")
+        assert back.metric == "chi2" and back.metric_val == 1.25 and back.params == fit.params
+        assert back.hypo_asimov_dist == fit.hypo_asimov_dist and back.fit_history == fit.fit_history
+        assert back.minimizer_metadata == meta and back.num_distributions_generated == 7
+        assert HypoFitResult.from_state(fit.state).params == fit.params
