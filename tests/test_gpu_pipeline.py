@@ -911,3 +911,56 @@ def test_var_binning_pipeline_one_mapset_per_selection():
     p.output_binning = VarBinning(binnings=vb.binnings, selections=["pid > 0", "pid > np.inf"])
     out = p.get_outputs()
     assert out[0][0].nominal_values.sum() > 0 and all(m.nominal_values.sum() == 0 for m in out[1])
+
+
+@pytest.mark.parametrize("cfg", ["example.cfg", "fast_example.cfg"])
+def test_reference_example_cfgs_unmodified(oracle, cfg):
+    """The reference's own `settings/pipeline/example.cfg` / `fast_example.cfg`, unmodified, on the reference's own toy
+    events file (read by this package's HDF5 reader, `utils/hdf.py`; the `data.simple_data_loader` service): two
+    selector dimensions (`nh`, `earth`), cuts, the legacy "oppo" flux columns, 12 x 100 events -- every output map
+    against the oracle's restatement of the reference chain on the same columns."""
+    from pisa_amd.core.pipeline import Pipeline
+    from pisa_amd.core.units import ureg
+
+    pipe = Pipeline("settings/pipeline/" + cfg)
+    assert pipe.service_names[0] == "simple_data_loader" and sorted(pipe.param_selections) == ["earth", "nh"]
+    maps = pipe.get_outputs()
+    pipe.data.representation = "events"
+    assert len(maps) == 12 and {c.size for c in pipe.data} == {100}
+    c = pipe.data["numubar_nc"]
+    assert c["nu_flux_nominal"].shape == (100, 2) and -1 <= c["true_coszen"].min() and c["true_energy"].max() <= 80
+    # the "oppo" columns of the file are the fluxes of the other sign (events_pi.py:74-85)
+    assert not np.array_equal(c["nu_flux_nominal"], c["nubar_flux_nominal"])
+    ref_h, ref_e = _oracle_event_pipeline(oracle, pipe)
+    for m in maps:
+        np.testing.assert_allclose(m.hist, ref_h[m.name], rtol=1e-11, atol=1e-300, err_msg=m.name)
+        np.testing.assert_allclose(m.std_devs, ref_e[m.name], rtol=1e-11, atol=1e-300, err_msg=m.name)
+    assert sum(m.hist.sum() for m in maps) > 0
+    # parameters of three stages move; the other Earth composition is selected and changes the maps
+    pipe.params.delta_index.value = 0.05 * ureg.dimensionless
+    pipe.params.theta23.value = 47.0 * ureg.degree
+    pipe.params.aeff_scale.value = 1.3 * ureg.dimensionless
+    maps2 = pipe.get_outputs()
+    ref_h2, ref_e2 = _oracle_event_pipeline(oracle, pipe, flux_params=(1.0, 1.0, 0.05, 0.0, 0.0), theta23_deg=47.0,
+                                            aeff_scale=1.3)
+    for m in maps2:
+        np.testing.assert_allclose(m.hist, ref_h2[m.name], rtol=1e-11, atol=1e-300, err_msg=m.name)
+        np.testing.assert_allclose(m.std_devs, ref_e2[m.name], rtol=1e-11, atol=1e-300)
+    before = sum(maps2).hist.copy()
+    pipe.select_params("lead")
+    assert pipe.params.YeI.value == 0.398
+    assert np.abs(sum(pipe.get_outputs()).hist - before).max() > 0
+
+
+def test_reference_varbin_example_cfg_unmodified():
+    """`settings/pipeline/varbin_example.cfg` as it is: a MapSet per pid selection of the toy events"""
+    from pisa_amd.core.pipeline import Pipeline
+
+    p = Pipeline("settings/pipeline/varbin_example.cfg")
+    out = p.get_outputs()
+    assert len(out) == 2 and [ms[0].hist.shape for ms in out] == [(10, 10), (10, 20)]
+    p.data.representation = "events"
+    kept = sum(float(c["weights"][(c["reco_energy"] >= 5) & (c["reco_energy"] < 100) & (c["reco_coszen"] < 1) & (c["pid"] < 1000)].sum())
+               for c in p.data)
+    np.testing.assert_allclose(sum(m.hist.sum() for ms in out for m in ms), kept, rtol=1e-10)
+    assert all(np.all(m.std_devs[m.hist > 0] > 0) for ms in out for m in ms)

@@ -750,3 +750,65 @@ def test_find_index_is_numpys_bin_rule():
                 want.append(-1 if (np.isnan(v) or v < edges[0]) else n if v > edges[-1] else int(hit[0]))
             assert [find_index(v, edges) for v in vals] == want
             assert find_index(vals, edges).tolist() == want
+
+
+def test_hdf5_reader_and_events_pi():
+    """`utils/hdf.py` on the reference's toy events file (an HDF5 file written by h5py with PISA's `to_hdf`: old-style
+    groups, chunked + byte-shuffled float64 arrays): structure, sizes, value ranges, selective reading; `EventsPi`:
+    flavour / interaction groups, renamed and stacked variables, the "oppo" flux fix, cuts, reproducible sub-samples."""
+    from pisa_amd.core.events_pi import EventsPi
+    from pisa_amd.utils.hdf import from_hdf
+
+    path = ("events/events__vlvnt__toy_1_to_80GeV_spidx1.0_cz-1_to_1_1e2evts_set0__unjoined__with_fluxes_"
+            "honda-2015-spl-solmin-aa.hdf5")
+    data = from_hdf(path)
+    assert list(data) == ["nue", "nue_bar", "numu", "numu_bar", "nutau", "nutau_bar"]
+    assert all(list(g) == ["cc", "nc"] for g in data.values())
+    cols = data["numu_bar"]["nc"]
+    assert sorted(cols) == ["neutrino_nue_flux", "neutrino_numu_flux", "neutrino_oppo_nue_flux", "neutrino_oppo_numu_flux",
+                            "pid", "reco_coszen", "reco_energy", "true_coszen", "true_energy", "weighted_aeff"]
+    for g in data.values():
+        for sub in g.values():
+            assert all(a.shape == (100,) and a.dtype == np.float64 and np.all(np.isfinite(a)) for a in sub.values())
+            assert 1.0 <= sub["true_energy"].min() and sub["true_energy"].max() <= 80.0
+            assert -1.0 <= sub["true_coszen"].min() and sub["true_coszen"].max() <= 1.0
+            assert set(np.unique(sub["pid"])) <= {-1.0, 1.0} and np.all(sub["weighted_aeff"] >= 0)
+            assert sub["neutrino_numu_flux"].mean() > sub["neutrino_nue_flux"].mean() > 0     # atmospheric: more numu than nue
+    assert len(set(float(g[s]["true_energy"].sum()) for g in data.values() for s in g)) == 12   # twelve different samples
+    few = from_hdf(path, choose=["pid", "true_energy"])
+    assert sorted(few["nue"]["cc"]) == ["pid", "true_energy"] and np.array_equal(few["nue"]["cc"]["pid"], data["nue"]["cc"]["pid"])
+    node = from_hdf(path, return_node="/nutau_bar/cc")
+    assert np.array_equal(node["reco_energy"], data["nutau_bar"]["cc"]["reco_energy"])
+    with pytest.raises(KeyError):
+        from_hdf(path, return_node="/nutau_bar/dis")
+
+    mapping = {"true_energy": "true_energy", "pid": "pid", "nu_flux_nominal": ["nominal_nue_flux", "nominal_numu_flux"],
+               "nubar_flux_nominal": ["nominal_nuebar_flux", "nominal_numubar_flux"]}
+    ev = EventsPi(name="Events")
+    ev.load_events_file(path, variable_mapping=mapping)
+    assert sorted(ev) == sorted("%s%s_%s" % (f, b, i) for f in ("nue", "numu", "nutau") for b in ("", "bar") for i in ("cc", "nc"))
+    nu, nubar = ev["numu_cc"], ev["numubar_cc"]
+    assert nu["nu_flux_nominal"].shape == (100, 2) and list(nu) == list(mapping)
+    assert np.array_equal(nu["nu_flux_nominal"][:, 0], data["numu"]["cc"]["neutrino_nue_flux"])
+    assert np.array_equal(nu["nubar_flux_nominal"][:, 1], data["numu"]["cc"]["neutrino_oppo_numu_flux"])
+    assert np.array_equal(nubar["nu_flux_nominal"][:, 0], data["numu_bar"]["cc"]["neutrino_oppo_nue_flux"])   # the other sign's
+    assert np.array_equal(nubar["nubar_flux_nominal"][:, 1], data["numu_bar"]["cc"]["neutrino_numu_flux"])
+    cut = ev.apply_cut("(true_energy <= 70) & (np.abs(pid) > 0)")
+    assert all(np.all(g["true_energy"] <= 70) for g in cut.values()) and 0 < len(cut["nue_nc"]["pid"]) < 100
+    assert cut.metadata["cuts"] == ["(true_energy <= 70) & (np.abs(pid) > 0)"] and ev.metadata["cuts"] == []
+    assert cut.apply_cut("(true_energy <= 70) & (np.abs(pid) > 0)") is cut
+    with pytest.raises(KeyError):
+        EventsPi().load_events_file(path, variable_mapping={"x": "no_such_variable"})
+    # three statistically independent quarters of the sample, the same for the same seed
+    parts = []
+    for k in range(3):
+        sub = EventsPi(fraction_events_to_keep=0.25, events_subsample_index=k)
+        sub.load_events_file(path, variable_mapping=mapping, seed=7)
+        parts.append(sub["nue_cc"]["true_energy"])
+        assert parts[-1].shape == (25,) and sub["nue_cc"]["nu_flux_nominal"].shape == (25, 2)
+    assert len(set(np.concatenate(parts))) == 75
+    again = EventsPi(fraction_events_to_keep=0.25, events_subsample_index=1)
+    again.load_events_file(path, variable_mapping=mapping, seed=7)
+    assert np.array_equal(again["nue_cc"]["true_energy"], parts[1])
+    with pytest.raises(AssertionError):
+        EventsPi(fraction_events_to_keep=0.25, events_subsample_index=4)
