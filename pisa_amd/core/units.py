@@ -177,7 +177,7 @@ class Quantity:
     def to_base_units(self):
         return Quantity(np.asarray(self._m) * self._u.scale if not np.isscalar(self._m)
                         else self._m * self._u.scale,
-                        Unit(1.0, self._u.dims, "base(%s)" % self._u.name))
+                        Unit(1.0, self._u.dims, _base_name(self._u.dims)))
 
     def _coerce(self, other):
         if isinstance(other, Quantity):
@@ -286,6 +286,16 @@ class Quantity:
 
 
 Q_ = Quantity
+
+
+_BASE_UNIT_NAMES = {"length": "meter", "time": "second", "mass": "gram", "energy": "electron_volt", "angle": "radian"}
+
+
+def _base_name(dims):
+    """'meter / second ** 2' for the dimensions of a unit with scale 1"""
+    parts = ["%s ** %g" % (_BASE_UNIT_NAMES.get(b, b), d) if d != 1 else _BASE_UNIT_NAMES.get(b, b)
+             for b, d in zip(_BASE, dims) if d != 0]
+    return " * ".join(parts) if parts else "dimensionless"
 
 
 def _name_powers(name):
