@@ -120,6 +120,16 @@ class DistributionMaker:
         for p in self._pipelines:
             p.update_params(merged, existing_must_match=True, extend=False)
 
+    def add_covariance(self, covmat):
+        """correlated priors between parameters of any of the pipelines (distribution_maker.py:327-348)"""
+        paramset = ParamSet(list(self.params))
+        paramset.add_covariance(covmat)
+        self.update_params(paramset)
+        done = [p._add_rotated(paramset, suppress_warning=True) for p in self._pipelines]
+        if not any(done):
+            raise ValueError("no pipeline holds one of the correlated parameters")
+        self.__dict__.pop("_params_view", None)
+
     @property
     def params(self):
         """merged view of the pipelines' parameters (distribution_maker.py:310-317); the Param objects

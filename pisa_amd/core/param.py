@@ -24,7 +24,7 @@ import numpy as np
 from pisa_amd import HASH_SIGFIGS  # noqa: F401 (re-exported)
 from pisa_amd.core.units import Quantity, ureg
 
-__all__ = ["Prior", "Param", "ParamSet", "ParamSelector"]
+__all__ = ["Prior", "Param", "DerivedParam", "LinearFunction", "ParamSet", "ParamSelector"]
 
 
 FTYPE_PREC = np.finfo(np.float64).eps
@@ -431,6 +431,145 @@ class Param:
                                                                self.is_fixed, self._range, self.prior)
 
 
+class LinearFunction:
+    """offset + sum_i coeff_i * value of the parameter named name_i: the functions `add_covariance` builds (the
+    reference composes them from `utils.callable.Var` / `Funct` objects, param.py:1070-1081)"""
+
+    def __init__(self, names, coeffs, offset=0.0):
+        self.names, self.coeffs, self.offset = tuple(names), tuple(float(c) for c in coeffs), float(offset)
+
+    def __call__(self, **params):
+        value = 0.0
+        for n, c in zip(self.names, self.coeffs):
+            value += c * float(params[n].value.m)
+        return value + self.offset
+
+    @property
+    def state(self):
+        return OrderedDict([("kind", "linear"), ("names", list(self.names)), ("coeffs", list(self.coeffs)),
+                            ("offset", self.offset)])
+
+
+class DerivedParam(Param):
+    """A parameter whose value is a function of other parameters (param.py:579-766): always fixed, no prior penalty
+    of its own (its arguments carry the priors), never validated.  `callable(**{name: Param})` gives the
+    (dimensionless) value.  Its change counter `_ver` is the sum of its arguments': every cache keyed on a
+    parameter's version follows the arguments."""
+
+    def __init__(self, name, value, unique_id=None, is_discrete=False, scales_as_log=False, nominal_value=None,
+                 tex=None, range=None, depends_names="", function_file="", help=""):  # noqa: A002
+        d = self.__dict__
+        d["_dependson"], d["_configured"], d["_callable"] = OrderedDict(), False, None
+        d["_depends_names"] = tuple(depends_names) if not isinstance(depends_names, str) else tuple(depends_names.split())
+        self.name = name
+        self.unique_id = unique_id if unique_id is not None else name
+        self._tex, self.help = tex, help
+        d["_is_fixed"] = True
+        self.is_discrete, self.scales_as_log = bool(is_discrete), bool(scales_as_log)
+        self._units = ureg.dimensionless
+        self.prior = None
+        self._range = None if range is None else list(range)
+        start = _as_quantity(value)
+        self._nominal_value = start if nominal_value is None else _as_quantity(nominal_value)
+        d["_start_value"] = start
+        if function_file:
+            raise NotImplementedError("DerivedParam functions from a file (`function_file`) are not part of this build;"
+                                      " set `callable` to a Python callable")
+
+    # the arguments and the function
+    @property
+    def callable(self):
+        if self._callable is None:
+            raise ValueError("No set callable for DerivedParam %s" % self.name)
+        return self._callable
+
+    @callable.setter
+    def callable(self, what):
+        self.__dict__["_callable"] = what
+        Param.clock += 1
+
+    @property
+    def depends_names(self):
+        return self._depends_names
+
+    @property
+    def dependson(self):
+        if not self._configured:
+            raise ValueError("Cannot access unconfigured Derived parameter!")
+        return self._dependson
+
+    @dependson.setter
+    def dependson(self, params):
+        working = [Param(**p) if isinstance(p, Mapping) else p for p in params]
+        if not all(isinstance(p, Param) for p in working):
+            raise TypeError("a DerivedParam depends on Params")
+        self.__dict__["_dependson"] = OrderedDict((p.name, p) for p in working)
+        self.__dict__["_depends_names"] = tuple(p.name for p in working)
+        self.__dict__["_configured"] = True
+        Param.clock += 1
+
+    # value, version
+    @property
+    def _value(self):
+        if not self._configured or self._callable is None:
+            return self._start_value
+        return Quantity(self._callable(**self._dependson), ureg.dimensionless)
+
+    @_value.setter
+    def _value(self, v):
+        raise AttributeError("the value of DerivedParam '%s' follows from %s" % (self.name, list(self._depends_names)))
+
+    @property
+    def _ver(self):
+        return sum(p._ver for p in self._dependson.values())
+
+    @_ver.setter
+    def _ver(self, v):
+        pass
+
+    value = property(lambda self: self._value)
+
+    @value.setter
+    def value(self, val):
+        raise AttributeError("the value of DerivedParam '%s' follows from %s" % (self.name, list(self._depends_names)))
+
+    is_fixed = property(lambda self: True)
+
+    @is_fixed.setter
+    def is_fixed(self, flag):
+        if not flag:
+            raise ValueError("DerivedParam '%s' cannot be freed: free the parameters it depends on" % self.name)
+
+    def validate_value(self, val):
+        return
+
+    def reset(self):
+        pass
+
+    def prior_penalty(self, metric):
+        return 0.0          # the arguments carry the priors: no double counting (param.py:729-733)
+
+    def __deepcopy__(self, memo):
+        new = object.__new__(DerivedParam)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = deepcopy(v, memo)
+        return new
+
+    @property
+    def state(self):
+        return OrderedDict([("callable", getattr(self._callable, "state", repr(self._callable))),
+                            ("depends", list(self._depends_names)), ("range", self._range)])
+
+    serializable_state = state
+
+    def __eq__(self, other):
+        return isinstance(other, DerivedParam) and self.name == other.name and _same(self.state, other.state) \
+            and _same(self.value, other.value)
+
+    __hash__ = object.__hash__
+
+
 class ParamSet(Sequence):
     """Ordered set of `Param`s with name access (param.py:776-1600).
 
@@ -623,7 +762,65 @@ class ParamSet(Sequence):
 
     def priors_penalties(self, metric):
         return [p.prior_penalty(metric) for p in self._params]
-    has_derived = False
+    has_derived = property(lambda self: any(isinstance(p, DerivedParam) for p in self._params))
+
+    def add_covariance(self, covmat):
+        """Correlated priors (param.py:949-1097): `covmat` = {name: {name: covariance}} over some of the set's
+        parameters.  With x the correlated parameters, mu their prior means (a uniform prior: the middle of the
+        range) and T the eigenvectors of the covariance, the fit runs in v = (x - mu) T: one new free parameter
+        `<name>_rotated` per x, Gaussian prior of width sqrt(eigenvalue) around 0, ranges from the corners of the
+        x ranges; every x becomes a `DerivedParam` x_i = sum_j v_j (T^-1)_ji + mu_i."""
+        names = list(covmat.keys())
+        dim = len(names)
+        if dim == 0:
+            return
+        cov = np.zeros((dim, dim))
+        for i, key in enumerate(names):
+            if key not in self.names:
+                raise KeyError("Key %s not in Params" % key)
+            if not isinstance(covmat[key], Mapping):
+                raise TypeError("Each entry in covmat should be another dict, found %s" % type(covmat[key]))
+            for j, sub in enumerate(covmat[key].keys()):
+                if sub not in self.names:
+                    raise KeyError("Key %s not in Params" % sub)
+                cov[i][j] = covmat[key][sub]
+        if np.linalg.det(cov) < 0:
+            raise ValueError("Covariance matrix *must* be positive definite!")
+        params = [self[n] for n in names]
+        means = []
+        for prm in params:
+            if prm.prior is not None and prm.prior.kind == "gaussian":
+                means.append(float(prm.prior.mean.m_as(prm.units)))
+            elif prm.prior is not None and prm.prior.kind == "uniform":
+                means.append(0.5 * float((prm.range[1] + prm.range[0]).m_as(prm.units)))
+            else:
+                raise NotImplementedError("prior mean of '%s' (%s)" % (prm.name, prm.prior))
+        evals, inv_t = np.linalg.eig(cov)
+        sigmas = np.sqrt(evals)
+        if any(abs(sg) < 1e-20 for sg in sigmas):
+            raise ValueError("Found zero-width param %s - your parameters might be linearly dependent!" % (sigmas,))
+        transformation = np.linalg.inv(inv_t)
+        ranges = [[float(r.m_as(prm.units)) for r in prm.range] for prm in params]
+        rotated = []
+        for i, prm in enumerate(params):
+            v_max = v_min = 0.0
+            for j in range(dim):
+                t = inv_t[j][i]
+                hi, lo = t * (ranges[j][1] - means[j]), t * (ranges[j][0] - means[j])
+                v_max += hi if t > 0 else lo
+                v_min += hi if t < 0 else lo
+            new = Param(name=prm.name + "_rotated", value=0.0 * ureg.dimensionless,
+                        prior=Prior(kind="gaussian", mean=0.0, stddev=float(sigmas[i])), range=(v_min, v_max),
+                        is_fixed=False, is_discrete=False, scales_as_log=prm.scales_as_log,
+                        nominal_value=0.0 * ureg.dimensionless, tex=prm.tex + "'")
+            rotated.append(new)
+            self.update(new)
+        for i, prm in enumerate(params):
+            derived = DerivedParam(name=prm.name, value=prm.value, range=prm.range)
+            derived.dependson = rotated
+            derived.callable = LinearFunction([r.name for r in rotated], [transformation[j][i] for j in range(dim)],
+                                              means[i])
+            self.replace(derived)
 
     def index(self, name):
         if isinstance(name, Param):

@@ -964,3 +964,39 @@ def test_reference_varbin_example_cfg_unmodified():
                for c in p.data)
     np.testing.assert_allclose(sum(m.hist.sum() for ms in out for m in ms), kept, rtol=1e-10)
     assert all(np.all(m.std_devs[m.hist > 0] > 0) for ms in out for m in ms)
+
+
+def test_pipeline_with_correlated_priors():
+    """`Pipeline.add_covariance` (pisa/core/pipeline.py:485-536): two parameters of `example.cfg` get correlated
+    priors; the pipeline then runs on the derived values, evaluation after evaluation (plan replays included), exactly
+    as a plain pipeline set to the same values does."""
+    from pisa_amd.core.param import DerivedParam
+    from pisa_amd.core.pipeline import Pipeline
+
+    pipe, plain = Pipeline("settings/pipeline/example.cfg"), Pipeline("settings/pipeline/example.cfg")
+    cov = {"aeff_scale": {"aeff_scale": 0.04, "nu_nc_norm": 0.01}, "nu_nc_norm": {"aeff_scale": 0.01, "nu_nc_norm": 0.04}}
+    assert pipe.add_covariance(cov)
+    with pytest.raises(ValueError):
+        pipe.add_covariance(cov)
+    aeff = pipe["aeff"]
+    assert isinstance(aeff.params.aeff_scale, DerivedParam) and isinstance(pipe.params.nu_nc_norm, DerivedParam)
+    assert "aeff_scale_rotated" in aeff.params.names and "nu_nc_norm_rotated" in pipe.params.free.names
+    assert "aeff_scale" not in pipe.params.free.names
+    evals, evecs = np.linalg.eig(np.array([[0.04, 0.01], [0.01, 0.04]]))
+    means = np.array([1.5, 1.0])            # aeff_scale: uniform prior on [0, 3]; nu_nc_norm: 1.0 +/- 0.2
+    rs = np.random.RandomState(2)
+    for k in range(6):
+        v = np.zeros(2) if k == 0 else rs.uniform(-0.15, 0.15, 2)
+        pipe.params.aeff_scale_rotated.value = v[0]
+        pipe.params.nu_nc_norm_rotated.value = v[1]
+        x = v @ np.linalg.inv(evecs) + means
+        np.testing.assert_allclose([pipe.params.aeff_scale.value.m, pipe.params.nu_nc_norm.value.m], x, atol=1e-12)
+        plain.params.aeff_scale.value = x[0]
+        plain.params.nu_nc_norm.value = x[1]
+        got, want = pipe.get_outputs(), plain.get_outputs()
+        for g, w in zip(got, want):
+            np.testing.assert_allclose(g.hist, w.hist, rtol=1e-12, atol=1e-300, err_msg="%s at step %d" % (g.name, k))
+        np.testing.assert_allclose(pipe.params.priors_penalty("llh") - plain.params.priors_penalty("llh")
+                                   + plain.params.nu_nc_norm.prior_penalty("llh"),
+                                   -0.5 * (x - means) @ np.linalg.inv(np.array([[0.04, 0.01], [0.01, 0.04]])) @ (x - means),
+                                   atol=1e-10)

@@ -183,3 +183,53 @@ def test_selector_update_and_equality():
     assert twin == sel and twin.params is not view
     twin.params.a = 2.9 * ureg.GeV
     assert twin != sel
+
+
+def test_correlated_priors_become_derived_params():
+    """`ParamSet.add_covariance` (pisa/core/param.py:949-1097; the checks of pisa_tests/test_covariance.py): the
+    rotation between the correlated and the uncorrelated basis, the widths of the new priors, and the sum of the
+    new priors' penalties equal to the correlated Gaussian's."""
+    from pisa_amd.core.param import DerivedParam
+
+    a = Param("a", 1.0, prior=Prior("gaussian", mean=1.0, stddev=0.3), range=[0, 2], is_fixed=False)
+    b = Param("b", 0.5, prior=Prior("uniform"), range=[-1, 3], is_fixed=False)
+    c = Param("c", 2.0 * ureg.GeV, prior=None, range=[1, 3] * ureg.GeV, is_fixed=False)
+    ps = ParamSet(a, b, c)
+    assert not ps.has_derived
+    cov = np.array([[1.0, 0.2], [0.2, 0.5]])
+    ps.add_covariance({"a": {"a": 1.0, "b": 0.2}, "b": {"a": 0.2, "b": 0.5}})
+    assert ps.names == ("a", "b", "c", "a_rotated", "b_rotated") and ps.has_derived
+    assert isinstance(ps.a, DerivedParam) and isinstance(ps.b, DerivedParam) and ps.free.names == ("c", "a_rotated", "b_rotated")
+    evals, evecs = np.linalg.eig(cov)
+    means = np.array([1.0, 1.0])                       # the Gaussian's mean, the middle of the uniform prior's range
+    np.testing.assert_allclose([ps.a_rotated.prior.stddev.m, ps.b_rotated.prior.stddev.m], np.sqrt(evals), rtol=1e-14)
+    assert ps.a.value == 1.0 and ps.b.value == 1.0     # v = 0 is x = mu
+    rs = np.random.RandomState(0)
+    for _ in range(20):
+        before = (ps.a._ver, ps.values_hash)
+        ps.randomize_free(random_state=rs)
+        v = np.array([ps.a_rotated.value.m, ps.b_rotated.value.m])
+        x = np.array([ps.a.value.m, ps.b.value.m])
+        np.testing.assert_allclose(x, v @ np.linalg.inv(evecs) + means, atol=1e-10)
+        np.testing.assert_allclose(v, (x - means) @ evecs, atol=1e-10)
+        assert (ps.a._ver, ps.values_hash) != before                # caches keyed on versions / hashes follow
+        direct = -0.5 * (x - means) @ np.linalg.inv(cov) @ (x - means)
+        np.testing.assert_allclose(ps.a_rotated.prior_penalty("llh") + ps.b_rotated.prior_penalty("llh"), direct, atol=1e-10)
+        assert ps.a.prior_penalty("llh") == 0.0 and ps.a.m_in("dimensionless") == x[0]
+    # the corners of the x ranges bound the new parameters
+    lo, hi = [q.m for q in ps.a_rotated.range]
+    corners = [(np.array([xa, xb]) - means) @ evecs for xa in (0, 2) for xb in (-1, 3)]
+    assert np.isclose(lo, min(k[0] for k in corners)) and np.isclose(hi, max(k[0] for k in corners))
+    # a derived parameter is fixed, is not set directly, and copies with its arguments
+    with pytest.raises(AttributeError):
+        ps.a.value = 1.2
+    with pytest.raises(ValueError):
+        ps.a.is_fixed = False
+    twin = deepcopy(ps)
+    twin.a_rotated.value = 0.25
+    assert twin.a.value != ps.a.value and twin.a.dependson["a_rotated"] is twin.a_rotated
+    for bad, err in (({"zz": {"zz": 1.0}}, KeyError), ({"a": [1.0]}, TypeError), ({"a": {"a": 1.0, "c": 0.1}, "c": {"a": 0.1, "c": 1.0}}, NotImplementedError)):
+        with pytest.raises(err):
+            ParamSet(deepcopy(a), deepcopy(b), deepcopy(c)).add_covariance(bad)
+    with pytest.raises(ValueError):
+        ParamSet(deepcopy(a), deepcopy(b)).add_covariance({"a": {"a": 1.0, "b": 1.0}, "b": {"a": 1.0, "b": 1.0}})
