@@ -1106,7 +1106,10 @@ def main(argv=None, hooks=None):
     import numpy as np
     import torch
 
-    cuda = hooks is None
+    # tests only: hooks = {"share_device": True} runs the REAL engine on N ranks that all use HIP device 0 and exchange over
+    # gloo (tests/test_gpu_distributed.py: the N > 1 control flow and the sharded kernels on hardware with one GPU)
+    share = bool(hooks and hooks.get("share_device"))
+    cuda = hooks is None or share
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -1115,14 +1118,15 @@ def main(argv=None, hooks=None):
                          % (args.gpus, world, args.gpus))
     if cuda:
         have = torch.cuda.device_count()
-        if have <= local_rank:
-            raise SystemExit("bench.py: rank %d wants HIP device %d, %d device(s) visible" % (rank, local_rank, have))
-        torch.cuda.set_device(local_rank)
+        device_index = 0 if share else local_rank
+        if have <= device_index:
+            raise SystemExit("bench.py: rank %d wants HIP device %d, %d device(s) visible" % (rank, device_index, have))
+        torch.cuda.set_device(device_index)
     dist_on = world > 1 or args.force_dist
     if dist_on:
         import torch.distributed as dist
 
-        if cuda:
+        if cuda and not share:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -1131,7 +1135,7 @@ def main(argv=None, hooks=None):
 
     make_state = synthetic.DeviceState if cuda else hooks["device_state"]
     dev_sync = torch.cuda.synchronize if cuda else (lambda: None)
-    if not cuda:
+    if not cuda or share:
         args.no_kernel_timing = args.no_batch_probe = args.no_drop_probe = args.no_cpu_baseline = True
 
     n_e, n_cz = (int(v) for v in args.grid.split("x"))
@@ -1151,7 +1155,7 @@ def main(argv=None, hooks=None):
             return x
         import torch.distributed as dist
 
-        t = torch.tensor([x], dtype=torch.float64, device="cuda" if cuda else "cpu")
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if (cuda and not share) else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -1230,7 +1234,8 @@ def main(argv=None, hooks=None):
     if dist_on:
         import torch.distributed as dist
 
-        mine = torch.tensor([int(np.float64(llh).view(np.int64))], dtype=torch.int64, device="cuda" if cuda else "cpu")
+        mine = torch.tensor([int(np.float64(llh).view(np.int64))], dtype=torch.int64,
+                            device="cuda" if (cuda and not share) else "cpu")
         every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
         dist.all_gather(every, mine)
         llh_bits = ["%016x" % (int(t.item()) & 0xFFFFFFFFFFFFFFFF) for t in every]
@@ -1274,7 +1279,7 @@ def main(argv=None, hooks=None):
                                            [x.strip() for x in args.legs.split(",") if x.strip()])
     if dist_on:
         want = [x for x in want if x in DIST_LEGS]
-    if not cuda:
+    if hooks is not None:
         want = [x for x in want if x in hooks.get("legs", ("multi_point",))]
     leg_steps = max(20, min(args.steps, 200))
     for name in want:

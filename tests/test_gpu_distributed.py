@@ -1,0 +1,48 @@
+"""The N > 1 path on hardware with ONE GPU: `python bench.py --gpus 2|4` as the driver would run it, its ranks all on
+HIP device 0 and exchanging over gloo (a test-only hook, `bench.py: share_device`).  Everything else is the product
+path: the self-launch, the sharded device state, the real kernels on every rank's contiguous shard of the events, the
+integer limb all-reduce between the fused kernel and the tail (through `torch.distributed`, the fall-back of the
+direct RCCL call), barriers and max-over-ranks timing, the weak-scaling leg, the bit-identity check of the line.
+What it cannot cover is RCCL itself over xGMI (one rank per GPU): `tests/test_gpu_engine.py` runs the RCCL
+communicator with one rank, `tests/test_distributed_cpu.py` the control flow on CPU ranks."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def share_device_hooks():
+    """what `PISA_BENCH_HOOKS=tests.test_gpu_distributed:share_device_hooks` hands to bench.main in every rank"""
+    return dict(share_device=True, legs=())
+
+
+def _bench(gpus, hooks=True):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--events", "2400000", "--steps", "6",
+           "--warmup", "2", "--min-timed-s", "0", "--legs", "none", "--no-cpu-baseline", "--no-drop-probe", "--no-batch-probe"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    if hooks:
+        env["PISA_BENCH_HOOKS"] = "tests.test_gpu_distributed:share_device_hooks"
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_and_four_ranks_on_one_device_reproduce_the_single_rank_bits():
+    one = _bench(1, hooks=False)
+    assert one["n_gpus"] == 1 and one["llh_bits_per_rank"] is None and one["config"]["events"] >= 2399990
+    for n in (2, 4):
+        line = _bench(n)
+        assert line["n_gpus"] == n and line["scaling"] == "strong" and line["steps"] == 6 and line["value"] > 0
+        assert line["llh_bits_identical"] is True and len(line["llh_bits_per_rank"]) == n and len(set(line["llh_bits_per_rank"])) == 1
+        # the same events, sharded differently, summed as integers: the very same LLH as one rank holds, bit for bit
+        assert line["last_llh"] == one["last_llh"], (n, line["last_llh"], one["last_llh"])
+        assert line["weak"]["samples_per_step"] == n and line["weak"]["value"] > 0
+        assert line["phase_ms"]["events_this_rank"] * n >= 2399990 and line["nccl_comm_count"] is None    # gloo here
