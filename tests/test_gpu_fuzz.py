@@ -1,0 +1,20 @@
+"""A short run of the randomised differential campaign (`scripts/dev/fuzz_engine.py`: random sample sizes, calc grids,
+output binnings of 1-3 dimensions up to ~6 000 bins, engine layouts and event orders, the four metrics, event-by-event
+oscillation with and without decay, several points in one sweep -- every trial against the CPU oracle).  Round 4 ran
+10 300 trials of it without a mismatch (EXPERIMENTS R4-15); these 60 keep it alive."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("seed", [101, 202])
+def test_randomised_workloads_against_the_oracle(seed):
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "dev", "fuzz_engine.py"), "30", str(seed)],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, (res.stdout[-3000:], res.stderr[-2000:])
+    assert "30 trials, 0 bad" in res.stdout
