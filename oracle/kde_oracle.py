@@ -40,9 +40,10 @@ def gaussian_kde_eval(x, weights, points, bw_method, adaptive, alpha):
     ones = np.ones(n)
     if adaptive:
         pilot = orc.kde_eval(x, w / norm, ones, x, inv_cov)
-        # a weightless source without weighted neighbours has pilot 0: it contributes nothing, is left out of the
-        # geometric mean and keeps the global bandwidth (the choice of pisa_amd/csrc/kde.hip, kde_logsum_kernel)
-        pos = pilot > 0
+        # a source of weight zero contributes nothing: it is left out of the geometric mean and keeps the global
+        # bandwidth (the choice of pisa_amd/csrc/kde.hip, kde_logsum_kernel; its pilot density would otherwise make
+        # the estimate depend on where a cut-off sets it to exactly 0)
+        pos = (w > 0) & (pilot > 0)
         glob = np.exp(np.mean(np.log(pilot[pos])))
         s = np.where(pos, (np.where(pos, pilot, 1.0) / glob) ** alpha, 1.0)
     else:

@@ -956,18 +956,20 @@ kde_lattice_points_kernel(int dim, double o0, double o1, double o2, double s0, d
     if (dim > 2) x[2 * m + i] = o2 + (double)i2 * s2_;
 }
 
-// sum of log(pilot) and the number of sources it runs over -> partial[block][2].  A source of weight zero with no
-// weighted neighbour within the cut-off has pilot density 0 (its own term is its weight): it contributes nothing to
-// any density, so it is left out of the geometric mean and keeps the global bandwidth -- otherwise one such event
-// would turn every local bandwidth, and with them the whole map, into NaN.
+// sum of log(pilot) and the number of sources it runs over -> partial[block][2].  A source of weight ZERO contributes
+// nothing to any density; it is left out of the geometric mean and keeps the global bandwidth.  (Its pilot density
+// is whatever its weighted neighbours leave there: exactly 0 beyond the cut-off -- log 0 would turn every local
+// bandwidth into NaN --, tiny but positive just inside it: counting such sources made the estimate depend on the
+// cut-off, found by scripts/dev/fuzz_kde.py in round 4.  A weighted source always has pilot > 0, its own term.)
 __global__ void __launch_bounds__(RED_THREADS)
-kde_logsum_kernel(const double *__restrict__ pilot, int64_t n, double *__restrict__ partial) {
+kde_logsum_kernel(const double *__restrict__ pilot, const double *__restrict__ wn, int64_t n,
+                  double *__restrict__ partial) {
     __shared__ double lds[RED_THREADS];
     double s = 0.0, c = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * RED_THREADS + threadIdx.x; i < n;
          i += (int64_t)RED_BLOCKS * RED_THREADS) {
         const double v = pilot[i];
-        if (v > 0.0) {
+        if (wn[i] > 0.0 && v > 0.0) {
             s += log(v);
             c += 1.0;
         }
@@ -995,7 +997,7 @@ kde_bandwidth_kernel(const double *__restrict__ pilot, const double *__restrict_
     for (int64_t i = (int64_t)blockIdx.x * RED_THREADS + threadIdx.x; i < n;
          i += (int64_t)RED_BLOCKS * RED_THREADS) {
         const double pv = pilot[i];
-        const double lam = pv > 0.0 ? pow(pv / glob, alpha) : 1.0;
+        const double lam = (wn[i] > 0.0 && pv > 0.0) ? pow(pv / glob, alpha) : 1.0;
         const double l2 = lam * lam;
         s2[i] = l2;
         coef[i] = wn[i] * (dim == 1 ? lam : (dim == 2 ? l2 : l2 * lam)) * inv_norm;
@@ -2182,7 +2184,7 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
         if (n_split > 1 && part != pilot)
             hipLaunchKernelGGL(kde_combine_kernel, dim3(nb), dim3(256), 0, s, part, n_split, n,
                                (const uint32_t *)nullptr, pilot);
-        hipLaunchKernelGGL(kde_logsum_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, pilot, n, partial);
+        hipLaunchKernelGGL(kde_logsum_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, pilot, k->wn, n, partial);
         double *partial_mm = partial + 2 * RED_BLOCKS;   // (its own region: the logsum partials are still being read)
         hipLaunchKernelGGL(kde_bandwidth_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, pilot, k->wn, n,
                            partial, alpha, dim, 1.0 / k->norm, k->coef, k->s2, partial_mm);

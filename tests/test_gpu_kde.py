@@ -494,6 +494,41 @@ def test_kde_weightless_isolated_sources_do_not_poison_the_bandwidths():
     np.testing.assert_array_equal(lat, got)   # tol = 0: the lattice is written out
 
 
+def test_kde_weightless_sources_near_the_cutoff_do_not_move_the_estimate():
+    """found by scripts/dev/fuzz_kde.py (round 4): weightless events in the sparse tail of a skewed sample sit 8 ... 38
+    bandwidths from their nearest weighted neighbour -- inside the exact sum (pilot tiny but positive), beyond the
+    cut-off (pilot exactly 0).  While such events counted in the geometric mean of the pilot densities the local
+    bandwidths of ALL events, and the map, depended on the cut-off (per cent level).  Events of weight zero are left
+    out of the mean now: the estimate is the same with and without cut-off, equal to the oracle, and equal to the
+    estimate of the sample without them up to the sample size in the bandwidth rule."""
+    from oracle import kde_oracle
+
+    from pisa_amd import kernels as K
+
+    rs = np.random.RandomState(4)
+    n = 6000
+    x = rs.gamma(2.0, 0.8, (1, n))
+    w = rs.rand(n) * 2 + 0.05
+    w[rs.rand(n) < 0.3] = 0.0
+    tail = np.argsort(x[0])[-12:]
+    x[0, tail] = x[0].max() * np.linspace(1.05, 1.6, 12)       # a sparse far tail ...
+    w[tail] = 0.0                                               # ... of weightless events
+    q = np.linspace(0.0, 8.0, 400)[None, :]
+    res = []
+    for tol in (1e-14, 1e-12, 0.0):
+        est = K.KdeEstimator(K.to_device(x), K.to_device(w), bw_method="silverman", adaptive=True, alpha=0.35, tol=tol)
+        res.append(est(K.to_device(q)).cpu().numpy())
+    want = kde_oracle.gaussian_kde_eval(x, w, q, "silverman", True, 0.35)
+    for got, tol in zip(res, (1e-14, 1e-12, 0.0)):
+        np.testing.assert_allclose(got, want, rtol=1e-10, atol=max(tol, 1e-16) * 100 * want.max())
+    # the local bandwidth factors of the weighted events do not know about the weightless ones
+    keep = w > 0
+    s2_all = K.KdeEstimator(K.to_device(x), K.to_device(w), adaptive=True, alpha=0.35).arrays()[2].cpu().numpy()
+    assert np.count_nonzero(s2_all == 1.0) >= np.count_nonzero(~keep)           # they keep the global bandwidth
+    lam = np.sqrt(s2_all[s2_all != 1.0])
+    assert abs(np.mean(np.log(lam))) < 1e-9                                       # geometric mean of the others' factors: 1
+
+
 def test_kde_batch_reports_a_failing_job_and_stays_usable():
     """a job the estimator refuses (all weights zero: no finite moments) comes back as an error of the batch call;
     the other jobs of the batch have run, and the library's pool takes the next batch"""
