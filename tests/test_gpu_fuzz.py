@@ -41,3 +41,13 @@ def test_randomised_prob3_against_the_oracle():
                          capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0, (res.stdout[-3000:], res.stderr[-2000:])
     assert "80 trials, 0 bad" in res.stdout
+
+
+def test_randomised_small_kernels_against_the_oracle():
+    """`scripts/dev/fuzz_misc.py`: histogram / lookup (edges, NaN, +-inf, weights of both signs down to 1e-100), the four
+    metrics (zeros, several maps, variances), the Honda flux table, the Barr systematics.  Round 4: 2 800 trials, no mismatch
+    (what the first runs reported were the documented limits: |w| >= 2^76 refused, deposits below 2^-116 vanish)."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "dev", "fuzz_misc.py"), "60", "505"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, (res.stdout[-3000:], res.stderr[-2000:])
+    assert "60 trials, 0 bad" in res.stdout
