@@ -440,7 +440,10 @@ class FastPlan:
             return _no("engine replaced")
         if self._writes() != self.container_clock:
             return _no("a container was written")   # e.g. somebody edited a flux column in place
-        if Param.clock != self.clock or self._dirty:
+        if Param.clock != self.clock or self._dirty or ParamSet.struct_clock != self.struct_clock:
+            # (the structural counter by itself: `select_params` exchanges parameter OBJECTS without setting a value --
+            # found by scripts/dev/fuzz_pipeline.py, round 4: a switch of the mass ordering alone was replayed with the
+            # old ordering's tables)
             changed = self._changed()
             if changed is None:
                 return _no("parameter objects exchanged")

@@ -40,7 +40,11 @@ class aeff(Stage):  # pylint: disable=invalid-name
 
     def _scales(self):
         """`scale_for` of every container, recomputed when one of this stage's parameters moved"""
-        key = tuple(p._ver for p in self.params) + (len(self.data.containers),)
+        from pisa_amd.core.param import ParamSet
+
+        # (the structural counter: after `select_params` another parameter OBJECT may stand behind a name, its change
+        # counter by chance the same)
+        key = tuple(p._ver for p in self.params) + (len(self.data.containers), ParamSet.struct_clock)
         c = getattr(self, "_scale_cache", None)
         if c is None or c[0] != key or c[2] is not self.params:
             names = [cont.name for cont in self.data]

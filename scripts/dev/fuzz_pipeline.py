@@ -1,0 +1,169 @@
+"""Stateful randomised run of a whole pipeline against the oracle (development tool, GPU box): ONE pipeline object built
+from cfg text (`example_hip.cfg`: synthetic events -> flux.barr_simple -> osc.prob3 on the calc grid -> aeff.aeff ->
+utils.hist), then a long random walk -- at every step a random subset of ALL its physics parameters moves (none, one,
+many: the six oscillation parameters, the five Barr parameters, livetime and the four aeff norms), sometimes the mass
+ordering selection is switched, sometimes the evaluation plan is switched off or on, sometimes a container column is read
+on the host between evaluations (which materialises deferred weights), sometimes the same point is evaluated twice -- and
+after every step all twelve maps with their errors are compared with the oracle's chain on the pipeline's own columns
+(rtol 1e-10).  What this hunts: a stale memo, a replay that missed a change, an invalidation that came too late.
+usage: fuzz_pipeline.py [steps] [seed] [events]"""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from oracle import oracle as orc  # noqa: E402
+from pisa_amd.core.config_parser import parse_pipeline_config  # noqa: E402
+from pisa_amd.core.pipeline import Pipeline  # noqa: E402
+from pisa_amd.core.units import ureg  # noqa: E402
+from pisa_amd.utils.resources import find_resource  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+n_events = float(sys.argv[3]) if len(sys.argv) > 3 else 2.4e4
+rs = np.random.RandomState(seed)
+
+cfg = parse_pipeline_config("settings/pipeline/example_hip.cfg")
+sel = cfg[("data", "synthetic_events")]["params"]
+sel.params.n_events.value = n_events
+sel.params.seed.value = float(seed)
+pipe = Pipeline(cfg)
+PREM = np.loadtxt(find_resource("osc/PREM_12layer.dat"))
+
+RANGES = dict(theta12=(25, 40, "deg"), theta13=(5, 12, "deg"), theta23=(31, 59, "deg"), deltacp=(0, 360, "deg"),
+              deltam21=(6e-5, 9e-5, "eV**2"), nue_numu_ratio=(0.8, 1.2, ""), nu_nubar_ratio=(0.8, 1.2, ""),
+              delta_index=(-0.3, 0.3, ""), Barr_uphor_ratio=(-2, 2, ""), Barr_nu_nubar_ratio=(-2, 2, ""),
+              aeff_scale=(0.3, 2.5, ""), nutau_cc_norm=(0.3, 1.9, ""), nutau_norm=(0.2, 3.0, ""), nu_nc_norm=(0.6, 1.4, ""),
+              livetime=(1.0, 4.0, "common_year"))
+
+
+def val(name):
+    p = pipe.params[name]
+    return p.value
+
+
+def oracle_maps():
+    """the reference chain with the pipeline's CURRENT parameter values on its own event columns"""
+    g = lambda n, u: float(val(n).m_as(u))  # noqa: E731
+    cm = pipe["prob3"].calc_mode
+    e_n = cm["true_energy"].weighted_centers.m_as("GeV")
+    cz_n = cm["true_coszen"].weighted_centers.magnitude
+    lay = orc.Layers(PREM, g("detector_depth", "km"), g("prop_height", "km"))
+    lay.setElecFrac(g("YeI", ""), g("YeO", ""), g("YeM", ""))
+    lay.calcLayers(cz_n)
+    mix = orc.mix_matrix(g("theta12", "rad"), g("theta13", "rad"), g("theta23", "rad"), g("deltacp", "rad"))
+    dm = orc.dm_matrix(g("deltam21", "eV**2"), g("deltam31", "eV**2"))
+    zero = np.zeros((3, 3))
+    grid = {}
+    for s in (1, -1):
+        grid[s] = orc.propagate_array(dm, mix, np.diag([1.0, 0, 0]).astype(complex), -1, zero.astype(complex), zero, s,
+                                      np.repeat(e_n, len(cz_n)), np.tile(lay.density, (len(e_n), 1)),
+                                      np.tile(lay.distance, (len(e_n), 1)))
+    lo, hi = cm["true_energy"].domain.m_as("GeV")
+    mins, maxs, nb = [np.log(lo), -1.0], [np.log(hi), 1.0], [len(e_n), len(cz_n)]
+    ob = pipe.output_binning
+    omin, omax = [], []
+    for d in ob:
+        lo_d, hi_d = (float(v) for v in d.domain.magnitude)
+        omin.append(np.log(lo_d) if d.is_log else lo_d)
+        omax.append(np.log(hi_d) if d.is_log else hi_d)
+    flux_params = tuple(g(n, "") for n in ("nue_numu_ratio", "nu_nubar_ratio", "delta_index", "Barr_uphor_ratio", "Barr_nu_nubar_ratio"))
+    a, lt = g("aeff_scale", ""), g("livetime", "sec")
+    out = {}
+    keep = pipe.data.representation
+    pipe.data.representation = "events"
+    for c in pipe.data.containers:
+        name = c.name
+        scale = a * lt
+        if name in ("nutau_cc", "nutaubar_cc"):
+            scale *= g("nutau_cc_norm", "")
+        if "nutau" in name:
+            scale *= g("nutau_norm", "")
+        if "nc" in name:
+            scale *= g("nu_nc_norm", "")
+        e, cz = c["true_energy"], c["true_coszen"]
+        nubar, flav = c["nubar"], c["flav"]
+        flux = orc.barr_simple(e, cz, c["nu_flux_nominal"], c["nubar_flux_nominal"], nubar, *flux_params)
+        P = grid[nubar].reshape(-1, 3, 3)
+        pe = orc.lookup_regular([np.log(e), cz], np.ascontiguousarray(P[:, 0, flav]), mins, maxs, nb)
+        pmu = orc.lookup_regular([np.log(e), cz], np.ascontiguousarray(P[:, 1, flav]), mins, maxs, nb)
+        w = orc.reweight(c["initial_weights"], flux, pe, pmu, c["weighted_aeff"], scale)
+        sample = [np.log(c[d.name]) if d.is_log else c[d.name] for d in ob]
+        out[name] = (orc.histogram_regular(sample, w, omin, omax, list(ob.shape)).reshape(ob.shape),
+                     np.sqrt(orc.histogram_regular(sample, w * w, omin, omax, list(ob.shape))).reshape(ob.shape))
+    pipe.data.representation = keep
+    return out
+
+
+bad = 0
+t0 = time.time()
+log = []
+for step in range(steps):
+    action = []
+    r = rs.rand()
+    if r < 0.08:
+        new = "ih" if "nh" in pipe.param_selections else "nh"
+        pipe.select_params(new)
+        action.append("select " + new)
+    names = list(RANGES)
+    k = int(rs.choice([0, 1, 1, 2, 3, len(names)]))
+    for n in rs.choice(names, size=k, replace=False):
+        lo, hi, u = RANGES[n]
+        unit = ureg.parse_units(u) if u else ureg.dimensionless
+        rng = pipe.params[n].range
+        if rng is not None:                 # inside the parameter's own range
+            lo, hi = max(lo, rng[0].m_as(unit)), min(hi, rng[1].m_as(unit))
+        pipe.params[n].value = rs.uniform(lo, hi) * unit
+        action.append(n)
+    if rs.rand() < 0.5:          # dm31 in the range of the selected ordering
+        rng = pipe.params.deltam31.range
+        lo, hi = rng[0].m_as("eV**2"), rng[1].m_as("eV**2")
+        pipe.params.deltam31.value = rs.uniform(lo + 0.1 * (hi - lo), hi - 0.1 * (hi - lo)) * ureg.eV ** 2
+        action.append("deltam31")
+    if rs.rand() < 0.1:
+        pipe.fast_path = not pipe.fast_path
+        action.append("fast_path=%s" % pipe.fast_path)
+    if rs.rand() < 0.1:
+        c = pipe.data.containers[rs.randint(12)]
+        keep = pipe.data.representation
+        pipe.data.representation = "events"
+        _ = c[["weights", "true_energy", "nu_flux"][rs.randint(3)]] if "nu_flux" in c.keys else c["weights"]
+        pipe.data.representation = keep
+        action.append("host read")
+    repeat = 2 if rs.rand() < 0.15 else 1
+    log.append(", ".join(action) or "nothing")
+    try:
+        for _ in range(repeat):
+            maps = pipe.get_outputs()
+            total = sum(maps)                   # (device-backed sums, as a fit takes them)
+            _ = total.hist
+        want = oracle_maps()
+        worst = 0.0
+        for m in maps:
+            h, e = want[m.name]
+            scale = max(np.abs(h).max(), 1e-300)
+            if not (np.allclose(m.hist, h, rtol=1e-10, atol=1e-13 * scale) and np.allclose(m.std_devs, e, rtol=1e-10, atol=1e-13 * max(e.max(), 1e-300))):
+                worst = max(worst, float(np.max(np.abs(m.hist - h)) / scale))
+        if worst:
+            bad += 1
+            print("MISMATCH step %d (%s): worst %.2e | previous steps: %s" % (step, log[-1], worst, " / ".join(log[-4:-1])), flush=True)
+            # diagnosis: which maps, which path, does a second evaluation / the Stage protocol agree with the oracle?
+            wrong = [m.name for m in maps if not np.allclose(m.hist, want[m.name][0], rtol=1e-10, atol=1e-13 * max(np.abs(want[m.name][0]).max(), 1e-300))]
+            print("   wrong maps:", wrong, "| fast_path", pipe.fast_path, "| plan", pipe._plan is not None, "| selections", pipe.param_selections)
+            print("   theta23 %s deltam31 %s (stage prob3 sees %s %s)" % (val("theta23"), val("deltam31"), pipe["prob3"].params.theta23.value,
+                                                                           pipe["prob3"].params.deltam31.value))
+            again = pipe.get_outputs()
+            ok2 = all(np.allclose(m.hist, want[m.name][0], rtol=1e-10, atol=1e-13 * max(np.abs(want[m.name][0]).max(), 1e-300)) for m in again)
+            keep_fp, pipe.fast_path, pipe._plan = pipe.fast_path, False, None
+            slow = pipe.get_outputs()
+            ok3 = all(np.allclose(m.hist, want[m.name][0], rtol=1e-10, atol=1e-13 * max(np.abs(want[m.name][0]).max(), 1e-300)) for m in slow)
+            pipe.fast_path = keep_fp
+            print("   evaluated again: %s; Stage protocol without plan: %s" % ("agrees" if ok2 else "still wrong", "agrees" if ok3 else "still wrong"), flush=True)
+    except Exception as e:  # pylint: disable=broad-except
+        bad += 1
+        print("ERROR step %d (%s): %s %s" % (step, log[-1], type(e).__name__, str(e)[:300]), flush=True)
+    if step % 50 == 49:
+        print("... %d steps, %d bad, %.0f s" % (step + 1, bad, time.time() - t0), flush=True)
+print("fuzz_pipeline: %d steps, %d bad" % (steps, bad))
+sys.exit(1 if bad else 0)

@@ -51,3 +51,13 @@ def test_randomised_small_kernels_against_the_oracle():
                          capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0, (res.stdout[-3000:], res.stderr[-2000:])
     assert "60 trials, 0 bad" in res.stdout
+
+
+def test_random_walk_of_a_pipeline_against_the_oracle():
+    """`scripts/dev/fuzz_pipeline.py`: ONE pipeline through a random walk over all its physics parameters, selection
+    switches, plan on / off, host reads between evaluations -- every step against the oracle's chain.  Round 4: 5 500
+    steps; one defect found (a selection switch alone was not seen by the plan: EXPERIMENTS R4-19), none since."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "dev", "fuzz_pipeline.py"), "120", "606"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, (res.stdout[-3000:], res.stderr[-2000:])
+    assert "120 steps, 0 bad" in res.stdout

@@ -13,7 +13,7 @@ NAMES = ["nue_cc", "numu_cc", "nutau_cc", "nue_nc", "numu_nc", "nutau_nc",
          "nuebar_cc", "numubar_cc", "nutaubar_cc", "nuebar_nc", "numubar_nc", "nutaubar_nc"]
 
 
-def _oracle_grid(oracle, binning, theta23_deg=42.0, dm31=2.457e-3):
+def _oracle_grid(oracle, binning, theta23_deg=42.0, dm31=2.457e-3, theta13_deg=8.5):
     """P[nubar][iE, jcz, 3, 3] on the calc grid with osc_example.cfg's nominal parameters"""
     e = binning["true_energy"].weighted_centers.m_as("GeV")
     cz = binning["true_coszen"].weighted_centers.magnitude
@@ -21,7 +21,7 @@ def _oracle_grid(oracle, binning, theta23_deg=42.0, dm31=2.457e-3):
     lay = oracle.Layers(prem, 2.0, 20.0)
     lay.setElecFrac(0.4656, 0.4656, 0.4957)
     lay.calcLayers(cz)
-    mix = oracle.mix_matrix(np.deg2rad(33.48), np.deg2rad(8.5), np.deg2rad(theta23_deg), 0.0)
+    mix = oracle.mix_matrix(np.deg2rad(33.48), np.deg2rad(theta13_deg), np.deg2rad(theta23_deg), 0.0)
     dm = oracle.dm_matrix(7.5e-5, dm31)
     mat_pot = np.diag([1.0, 0, 0]).astype(complex)
     zero = np.zeros((3, 3))
@@ -71,9 +71,9 @@ def test_osc_example_cfg_unmodified(oracle):
 
 
 def _oracle_event_pipeline(oracle, pipe, flux_params=(1.0, 1.0, 0.0, 0.0, 0.0), theta23_deg=42.3,
-                           aeff_scale=1.0, dm31=2.457e-3):
+                           aeff_scale=1.0, dm31=2.457e-3, theta13_deg=8.5):
     """reference chain on the pipeline's own input columns"""
-    grid = _oracle_grid(oracle, pipe["prob3"].calc_mode, theta23_deg=theta23_deg, dm31=dm31)
+    grid = _oracle_grid(oracle, pipe["prob3"].calc_mode, theta23_deg=theta23_deg, dm31=dm31, theta13_deg=theta13_deg)
     cm = pipe["prob3"].calc_mode
     lo, hi = cm["true_energy"].domain.m_as("GeV")
     mins, maxs, nb = [np.log(lo), -1.0], [np.log(hi), 1.0], [cm["true_energy"].num_bins, cm["true_coszen"].num_bins]
@@ -1000,3 +1000,39 @@ def test_pipeline_with_correlated_priors():
                                    + plain.params.nu_nc_norm.prior_penalty("llh"),
                                    -0.5 * (x - means) @ np.linalg.inv(np.array([[0.04, 0.01], [0.01, 0.04]])) @ (x - means),
                                    atol=1e-10)
+
+
+def test_selection_switch_alone_is_seen_by_the_plan(oracle):
+    """found by scripts/dev/fuzz_pipeline.py (round 4): `select_params` exchanges parameter OBJECTS without setting a
+    value; the evaluation plan looked at the structural counter only after the value counter had moved, so a switch of the
+    mass ordering ALONE was replayed with the other ordering's oscillation tables.  Every evaluation after a switch --
+    with nothing else touched -- must be the new selection's."""
+    from pisa_amd.core.pipeline import Pipeline
+    from pisa_amd.core.units import ureg
+
+    pipe = Pipeline("settings/pipeline/example_hip.cfg")
+    pipe.get_outputs()
+    pipe.get_outputs()
+    assert pipe._plan is not None                                  # replaying
+    nh = sum(pipe.get_outputs()).hist.copy()
+    ref_nh, _ = _oracle_event_pipeline(oracle, pipe)
+    pipe.select_params("ih")                                       # ... and nothing else
+    t23, dm31 = pipe.params.theta23.value.m_as("deg"), pipe.params.deltam31.value.m_as("eV**2")
+    t13 = pipe.params.theta13.value.m_as("deg")
+    assert dm31 < 0 and t13 != 8.5                                   # the other ordering's own values
+    ih_maps = pipe.get_outputs()
+    ref_ih, _ = _oracle_event_pipeline(oracle, pipe, theta23_deg=t23, dm31=dm31, theta13_deg=t13)
+    for m in ih_maps:
+        np.testing.assert_allclose(m.hist, ref_ih[m.name], rtol=1e-11, atol=1e-300, err_msg=m.name)
+    assert np.abs(sum(ih_maps).hist - nh).max() > 1e-6 * nh.max()
+    pipe.get_outputs()
+    pipe.select_params("nh")
+    for m in pipe.get_outputs():
+        np.testing.assert_allclose(m.hist, ref_nh[m.name], rtol=1e-11, atol=1e-300, err_msg=m.name)
+    # the same with values set on the deselected objects in between
+    pipe.select_params("ih")
+    pipe.params.theta23.value = 51.0 * ureg.deg
+    pipe.get_outputs()
+    pipe.select_params("nh")
+    for m in pipe.get_outputs():
+        np.testing.assert_allclose(m.hist, ref_nh[m.name], rtol=1e-11, atol=1e-300, err_msg=m.name)
