@@ -61,3 +61,15 @@ def test_random_walk_of_a_pipeline_against_the_oracle():
                          capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0, (res.stdout[-3000:], res.stderr[-2000:])
     assert "120 steps, 0 bad" in res.stdout
+
+
+@pytest.mark.parametrize("which,steps", [("3y", 150), ("osc", 100)])
+def test_random_walk_plan_against_stage_protocol(which, steps):
+    """`scripts/dev/fuzz_twins.py`: a DistributionMaker walking through the evaluation plan against a twin on the Stage
+    protocol and, every 25 steps, against a freshly built maker -- the published 3-year analysis chain (synthetic MC
+    stand-in) and the binned `osc_example.cfg`; parameters of every stage, fixed and free, selections, reset_free.
+    Round 4: 6 300 steps, no disagreement."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "dev", "fuzz_twins.py"), which, str(steps), "707"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, (res.stdout[-3000:], res.stderr[-2000:])
+    assert "%d steps, 0 bad" % steps in res.stdout
