@@ -321,11 +321,13 @@ def kde_histogramdd_batch(samples, binning, bw_method="scott", adaptive=True, al
     samples]` with all the estimators (one per sample and pid channel) built and evaluated on the library's own
     threads and streams (`K.KdeLatticeBatch`) and one copy of the densities to the host.  `weights` may be a
     callable returning the tensor: it is called when the sample's turn comes, while the estimators of the earlier
-    samples already run.  Device tensors only; without bootstrap.  The maps are those of the one-by-one path bit
+    samples already run.  Samples: device tensors (host arrays are uploaded); without bootstrap.  The maps are those of the one-by-one path bit
     for bit."""
-    samples = list(samples)
+    samples = [dict(smp) for smp in samples]
     plans, g, n_jobs = [], None, 0
     for smp in samples:
+        if not torch.is_tensor(smp["sample"]):      # a host array, as `kde_histogramdd` takes it too
+            smp["sample"] = K.to_device(np.ascontiguousarray(np.asarray(smp["sample"], dtype=np.float64)))
         sample = smp["sample"]
         if stack_pid:
             pid_bin, d2d, chans = smp.get("channels") or pid_channels(sample, binning)

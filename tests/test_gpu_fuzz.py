@@ -73,3 +73,13 @@ def test_random_walk_plan_against_stage_protocol(which, steps):
                          capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0, (res.stdout[-3000:], res.stderr[-2000:])
     assert "%d steps, 0 bad" % steps in res.stdout
+
+
+def test_randomised_kde_maps_against_the_kde_oracle():
+    """`scripts/dev/fuzz_kde_maps.py`: the KDE map chain (oversampling, coszen reflection at either / both / no end, bin
+    volumes, pid stacking, dimension order, the library's batch path) against `oracle/kde_oracle.py`.  Round 4: 2 250 trials,
+    no mismatch; the batch entry point learned to take host arrays on the way."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "dev", "fuzz_kde_maps.py"), "40", "808"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, (res.stdout[-3000:], res.stderr[-2000:])
+    assert "40 trials, 0 bad" in res.stdout
