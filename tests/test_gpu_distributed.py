@@ -46,3 +46,13 @@ def test_two_and_four_ranks_on_one_device_reproduce_the_single_rank_bits():
         assert line["last_llh"] == one["last_llh"], (n, line["last_llh"], one["last_llh"])
         assert line["weak"]["samples_per_step"] == n and line["weak"]["value"] > 0
         assert line["phase_ms"]["events_this_rank"] * n >= 2399990 and line["nccl_comm_count"] is None    # gloo here
+
+
+def test_random_shardings_on_one_device_reproduce_the_single_rank_bits():
+    """`scripts/dev/fuzz_ranks.py`: 2-6 ranks on HIP device 0 over gloo, random samples (down to fewer events than ranks),
+    grids, binnings, layouts, metrics; single points through the one-call evaluator or the three calls, several points
+    in one sweep -- every value and every map bit for bit the single-rank engine's.  Round 4: 200 trials, no difference."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "dev", "fuzz_ranks.py"), "6", "909"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, (res.stdout[-3000:], res.stderr[-2000:])
+    assert "6 trials, 0 bad" in res.stdout
