@@ -83,3 +83,13 @@ def test_randomised_kde_maps_against_the_kde_oracle():
                          capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0, (res.stdout[-3000:], res.stderr[-2000:])
     assert "40 trials, 0 bad" in res.stdout
+
+
+def test_randomised_translation_module_against_numpy():
+    """`scripts/dev/fuzz_translation.py`: `core.translation.histogram / lookup` (scalar and vector weights, host arrays and
+    device tensors, values on edges / outside / NaN / inf) against numpy restatements of the reference's two regimes, the
+    switch between them the reference's own (`binning.is_irregular or not binning.is_lin`).  Round 4: 4 500 trials."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "dev", "fuzz_translation.py"), "200", "111"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, (res.stdout[-3000:], res.stderr[-2000:])
+    assert "200 trials, 0 bad" in res.stdout
