@@ -6,7 +6,7 @@ ordering selection is switched, sometimes the evaluation plan is switched off or
 on the host between evaluations (which materialises deferred weights), sometimes the same point is evaluated twice -- and
 after every step all twelve maps with their errors are compared with the oracle's chain on the pipeline's own columns
 (rtol 1e-10).  What this hunts: a stale memo, a replay that missed a change, an invalidation that came too late.
-usage: fuzz_pipeline.py [steps] [seed] [events]"""
+usage: fuzz_pipeline.py [steps] [seed] [events] [randbin]"""
 import sys
 import time
 
@@ -25,6 +25,30 @@ n_events = float(sys.argv[3]) if len(sys.argv) > 3 else 2.4e4
 rs = np.random.RandomState(seed)
 
 cfg = parse_pipeline_config("settings/pipeline/example_hip.cfg")
+if len(sys.argv) > 4 and sys.argv[4] == "randbin":
+    # a random output binning: reco_energy log-regular or irregular, reco_coszen linear or irregular, pid with 1-3 irregular bins,
+    # in a random order, sometimes without pid (utils/hist.py:86-126: irregular dimensions are digitised, log ones binned in ln)
+    from pisa_amd.core.binning import MultiDimBinning, OneDimBinning
+
+    def edges(lo, hi, n, log):
+        cuts = np.sort(rs.uniform(np.log(lo) if log else lo, np.log(hi) if log else hi, n - 1))
+        e = np.concatenate([[np.log(lo) if log else lo], cuts, [np.log(hi) if log else hi]])
+        return np.exp(e) if log else e
+
+    n_e, n_cz = int(rs.randint(1, 14)), int(rs.randint(1, 14))
+    lo_e, hi_e = rs.uniform(3, 8), rs.uniform(60, 150)
+    d_e = OneDimBinning("reco_energy", num_bins=n_e, domain=[lo_e, hi_e] * ureg.GeV, is_log=True) if rs.rand() < 0.5 else \
+        OneDimBinning("reco_energy", bin_edges=edges(lo_e, hi_e, n_e, True) * ureg.GeV, is_log=bool(rs.rand() < 0.5))
+    cz_hi = [1.0, rs.uniform(0.0, 0.9)][rs.randint(2)]
+    d_cz = OneDimBinning("reco_coszen", num_bins=n_cz, domain=[-1, cz_hi], is_lin=True) if rs.rand() < 0.5 else \
+        OneDimBinning("reco_coszen", bin_edges=edges(-1.0, cz_hi, n_cz, False))
+    d_pid = OneDimBinning("pid", bin_edges=[[-3.0, 1000.0], [-1000.0, 0.0, 1000.0], [-3.0, 0.0, 0.5, 1000.0]][rs.randint(3)])
+    dims_out = [d_e, d_cz] + ([d_pid] if rs.rand() < 0.7 else [])
+    order = rs.permutation(len(dims_out))
+    ob_rand = MultiDimBinning([dims_out[i] for i in order], name="fuzz_binning")
+    cfg["pipeline"]["output_binning"] = ob_rand
+    cfg[("utils", "hist")]["apply_mode"] = ob_rand
+    print("output binning:", [(d.name, d.num_bins, "log" if d.is_log else "lin", "irregular" if d.is_irregular else "regular") for d in ob_rand])
 sel = cfg[("data", "synthetic_events")]["params"]
 sel.params.n_events.value = n_events
 sel.params.seed.value = float(seed)
@@ -66,8 +90,21 @@ def oracle_maps():
     omin, omax = [], []
     for d in ob:
         lo_d, hi_d = (float(v) for v in d.domain.magnitude)
-        omin.append(np.log(lo_d) if d.is_log else lo_d)
-        omax.append(np.log(hi_d) if d.is_log else hi_d)
+        if d.is_irregular:                          # digitised: bins [0, n) of the bin number (utils/hist.py:92-113)
+            omin.append(0.0)
+            omax.append(float(d.num_bins))
+        else:
+            omin.append(np.log(lo_d) if d.is_log else lo_d)
+            omax.append(np.log(hi_d) if d.is_log else hi_d)
+
+    def column(c, d):
+        x = c[d.name]
+        if d.is_irregular:
+            e = d.edge_magnitudes
+            idx = (np.searchsorted(e, x, side="right") - 1).astype(float)
+            idx[x == e[-1]] -= 1
+            return idx
+        return np.log(x) if d.is_log else x
     flux_params = tuple(g(n, "") for n in ("nue_numu_ratio", "nu_nubar_ratio", "delta_index", "Barr_uphor_ratio", "Barr_nu_nubar_ratio"))
     a, lt = g("aeff_scale", ""), g("livetime", "sec")
     out = {}
@@ -89,7 +126,7 @@ def oracle_maps():
         pe = orc.lookup_regular([np.log(e), cz], np.ascontiguousarray(P[:, 0, flav]), mins, maxs, nb)
         pmu = orc.lookup_regular([np.log(e), cz], np.ascontiguousarray(P[:, 1, flav]), mins, maxs, nb)
         w = orc.reweight(c["initial_weights"], flux, pe, pmu, c["weighted_aeff"], scale)
-        sample = [np.log(c[d.name]) if d.is_log else c[d.name] for d in ob]
+        sample = [column(c, d) for d in ob]
         out[name] = (orc.histogram_regular(sample, w, omin, omax, list(ob.shape)).reshape(ob.shape),
                      np.sqrt(orc.histogram_regular(sample, w * w, omin, omax, list(ob.shape))).reshape(ob.shape))
     pipe.data.representation = keep

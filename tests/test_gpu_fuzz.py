@@ -61,6 +61,11 @@ def test_random_walk_of_a_pipeline_against_the_oracle():
                          capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0, (res.stdout[-3000:], res.stderr[-2000:])
     assert "120 steps, 0 bad" in res.stdout
+    # the same walk into a random output binning (irregular / logarithmic dimensions, any order, with or without pid)
+    for seed in ("616", "626"):
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "dev", "fuzz_pipeline.py"), "30", seed, "2.4e4", "randbin"],
+                             capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert res.returncode == 0 and "30 steps, 0 bad" in res.stdout, (res.stdout[-3000:], res.stderr[-2000:])
 
 
 @pytest.mark.parametrize("which,steps", [("3y", 150), ("osc", 100)])
