@@ -102,10 +102,7 @@ for trial in range(trials):
             if not close(got, want, 1e-10, 1e-14):
                 problems.append("propagate_array nubar=%d (%.2e)" % (nubar, np.nanmax(np.abs(got - want))))
             ev = K.prob3_events(params, lay.earth_struct(), nubar, K.to_device(energy), K.to_device(cz)).cpu().numpy()
-            # decay on a degenerate vacuum spectrum (dm21 = 0: the two light states 5e-9 eV^2 apart, osc_params.py:283-289):
-            # the event kernel's Lagrange form of the layer matrix loses log10(dm31 / 5e-9) ~ 6 digits there
-            ev_atol = 1e-9 if (decay and dm21 == 0.0) else 1e-13
-            if not close(ev, want, 1e-9, ev_atol):
+            if not close(ev, want, 1e-9, 1e-13):
                 problems.append("events nubar=%d (%.2e)" % (nubar, np.nanmax(np.abs(ev - want))))
         # grids
         e_nodes = np.sort(10 ** rs.uniform(-0.5, 3.5, n_e))

@@ -35,8 +35,8 @@ def test_randomised_prob3_against_the_oracle():
     """`scripts/dev/fuzz_prob3.py` (Earth model, detector geometry, all six oscillation parameters incl. angles of 0 / 90
     degrees and dm21 = 0, standard / NLO / random NSI / vacuum potentials, decay, long-range potentials, 0.1 GeV - 10 TeV,
     the whole sky): layers bit for bit, `propagate_array`, both grid forms with their gather tables and the event kernel
-    against the oracle.  Round 4: 2 200 trials; the one finding is the event kernel with decay on a degenerate vacuum
-    spectrum (3e-10 absolute instead of 1e-10 relative; EXPERIMENTS R4-17)."""
+    against the oracle.  Round 4: 6 300 trials; the one finding, the event kernel with decay on a degenerate vacuum
+    spectrum (3e-10 absolute: EXPERIMENTS R4-17), is gone with the Newton form of the layer polynomial (R4-25)."""
     res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "dev", "fuzz_prob3.py"), "80", "404"],
                          capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0, (res.stdout[-3000:], res.stderr[-2000:])
