@@ -687,11 +687,7 @@ __device__ __forceinline__ void layer_amplitude_decay_poly(const Prob3Side &S, d
     cplx M[3];
     eigvals3_general<true>(X, M);
     const double lf = (baseline * fast_rcp(energy)) * 2.534;
-    // exp(-i X lf) as the Newton interpolation polynomial of exp(-i m lf) in the eigenvalues (a, b, c), the CLOSEST pair
-    // first:  f[a] + f[a,b] (X - a) + f[a,b,c] (X - a)(X - b).  The Lagrange form (terms e_k / prod(m_k - m_j)) divides by the
-    // gap of a nearly degenerate pair and loses log10(scale / gap) digits in the sum of its two large terms (found by
-    // scripts/dev/fuzz_prob3.py: dm21 = 0 leaves the light states 5e-9 eV^2 apart, 3e-10 on the probabilities); here the
-    // first divided difference of a close pair is  e_a (-i lf) phi(z),  phi(z) = (exp z - 1) / z  by its series.
+    // exp(-i X lf) = c0 + c1 X + c2 X^2: the interpolation polynomial of exp(-i m lf) in the eigenvalues of X.
     cplx e[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -701,30 +697,43 @@ __device__ __forceinline__ void layer_amplitude_decay_poly(const Prob3Side &S, d
         sincos(-M[k].re * lf, &sn, &cs);
         e[k] = cmake(l * cs, l * sn);
     }
-    const double g01 = cabs2(csub(M[0], M[1])), g02 = cabs2(csub(M[0], M[2])), g12 = cabs2(csub(M[1], M[2]));
-    // (a, b) = the closest pair, c the third
-    const bool p01 = g01 <= g02 && g01 <= g12, p02 = !p01 && g02 <= g12;
-    const cplx ma = p01 ? M[0] : (p02 ? M[0] : M[1]), mb = p01 ? M[1] : M[2], mc = p01 ? M[2] : (p02 ? M[1] : M[0]);
-    const cplx ea = p01 ? e[0] : (p02 ? e[0] : e[1]), eb = p01 ? e[1] : e[2], ec = p01 ? e[2] : (p02 ? e[1] : e[0]);
-    const cplx dab = csub(mb, ma);
-    const cplx z = cmul(cmake(0.0, -lf), dab);            // e_b = e_a exp(z)
-    cplx f01;
-    if (cabs2(z) < 0.0625) {                                // |z| < 1/4: twelve terms of phi give 1e-17
-        cplx phi = cmake(1.0, 0.0);
-        cplx term = cmake(1.0, 0.0);
+    const cplx d01 = csub(M[0], M[1]), d02 = csub(M[0], M[2]), d12 = csub(M[1], M[2]);
+    const double g01 = cabs2(d01), g02 = cabs2(d02), g12 = cabs2(d12);
+    cplx c0, c1, c2;
+    // LAGRANGE form (terms e_k / prod(m_k - m_j)): the cheapest, and fine while the eigenvalues are separated.  It divides by the
+    // gap of a nearly degenerate pair and loses log10(scale / gap) digits in the sum of its two large terms (found by
+    // scripts/dev/fuzz_prob3.py: dm21 = 0 leaves the light states 5e-9 eV^2 apart, 3e-10 on the probabilities).  A wavefront in
+    // which some lane has a pair closer than 1e-3 of its largest gap takes the NEWTON form instead, the closest pair (a, b) first:
+    //     f[a] + f[a,b] (X - a) + f[a,b,c] (X - a)(X - b),   f[a,b] = e_a (-i lf) phi(z),  phi(z) = (exp z - 1) / z  by its series
+    // for |z| = |lf (b - a)| < 1/16, the plain quotient otherwise.
+    const double gmin = fmin(g01, fmin(g02, g12)), gmax = fmax(g01, fmax(g02, g12));
+    if (!__any(gmin < 1e-6 * gmax)) {
+        const cplx t0 = cmul(e[0], crecip(cmul(d01, d02)));
+        const cplx t1 = cmul(e[1], crecip(cscale(-1.0, cmul(d12, d01))));
+        const cplx t2 = cmul(e[2], crecip(cmul(d02, d12)));
+        c2 = cadd(cadd(t0, t1), t2);
+        c1 = cscale(-1.0, cadd(cadd(cmul(t0, cadd(M[1], M[2])), cmul(t1, cadd(M[2], M[0]))), cmul(t2, cadd(M[0], M[1]))));
+        c0 = cadd(cadd(cmul(t0, cmul(M[1], M[2])), cmul(t1, cmul(M[2], M[0]))), cmul(t2, cmul(M[0], M[1])));
+    } else {
+        const bool p01 = g01 <= g02 && g01 <= g12, p02 = !p01 && g02 <= g12;
+        const cplx ma = p01 ? M[0] : (p02 ? M[0] : M[1]), mb = p01 ? M[1] : M[2], mc = p01 ? M[2] : (p02 ? M[1] : M[0]);
+        const cplx ea = p01 ? e[0] : (p02 ? e[0] : e[1]), eb = p01 ? e[1] : e[2], ec = p01 ? e[2] : (p02 ? e[1] : e[0]);
+        const cplx dab = csub(mb, ma);
+        const cplx z = cmul(cmake(0.0, -lf), dab);            // e_b = e_a exp(z)
+        const bool small = cabs2(z) < 1.0 / 256.0;            // nine terms of phi give 1e-17 there
+        cplx phi = cmake(1.0, 0.0), term = cmake(1.0, 0.0);
 #pragma unroll
-        for (int n = 2; n <= 13; n++) {
+        for (int n = 2; n <= 10; n++) {
             term = cscale(1.0 / (double)n, cmul(term, z));
             phi = cadd(phi, term);
         }
-        f01 = cmul(cmul(ea, cmake(0.0, -lf)), phi);
-    } else {
-        f01 = cmul(csub(eb, ea), crecip(dab));
+        const cplx quot = cmul(csub(eb, ea), crecip(dab));   // (of an exactly degenerate pair: not taken)
+        const cplx f01 = small ? cmul(cmul(ea, cmake(0.0, -lf)), phi) : quot;
+        const cplx f12 = cmul(csub(ec, eb), crecip(csub(mc, mb)));
+        c2 = cmul(csub(f12, f01), crecip(csub(mc, ma)));
+        c1 = csub(f01, cmul(c2, cadd(ma, mb)));
+        c0 = cadd(csub(ea, cmul(f01, ma)), cmul(c2, cmul(ma, mb)));
     }
-    const cplx f12 = cmul(csub(ec, eb), crecip(csub(mc, mb)));
-    const cplx c2 = cmul(csub(f12, f01), crecip(csub(mc, ma)));
-    const cplx c1 = csub(f01, cmul(c2, cadd(ma, mb)));
-    const cplx c0 = cadd(csub(ea, cmul(f01, ma)), cmul(c2, cmul(ma, mb)));
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
