@@ -168,6 +168,15 @@ for step in range(steps):
         _ = c[["weights", "true_energy", "nu_flux"][rs.randint(3)]] if "nu_flux" in c.keys else c["weights"]
         pipe.data.representation = keep
         action.append("host read")
+    if rs.rand() < 0.06:
+        # somebody edits an input column between evaluations (a third-party stage, a notebook): the maps must follow
+        c = pipe.data.containers[rs.randint(12)]
+        keep = pipe.data.representation
+        pipe.data.representation = "events"
+        col = ["weighted_aeff", "initial_weights"][rs.randint(2)]
+        c[col] = c[col] * rs.uniform(0.8, 1.2)
+        pipe.data.representation = keep
+        action.append("host write %s of %s" % (col, c.name))
     repeat = 2 if rs.rand() < 0.15 else 1
     log.append(", ".join(action) or "nothing")
     try:
