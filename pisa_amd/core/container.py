@@ -570,6 +570,17 @@ class Container:
         self.representation = dest_representation
         return torch.where(counts > 1, torch.nan_to_num(flat / counts), looked_up)
 
+    def _kernel_form(self, binning):
+        """(argument block, device sample columns) with which the kernels histogram into / look up from `binning`, by the
+        reference's rule (container.py:948-973, 985-1011): NO irregular dimension -- every logarithmic dimension in ln x, the
+        others as they are, fast_histogram's arithmetic on half-open ranges; ANY irregular dimension -- ALL dimensions by
+        comparison with their edges in the original coordinates, last edge included (numpy's `histogramdd`)"""
+        if binning.is_irregular:
+            from pisa_amd.core import translation as T
+
+            return T._kernel_form([self._column(d.name, False) for d in binning], binning, by_edges=True)
+        return regularized(binning, self._column)
+
     def array_to_binned(self, key, src_representation, dest_representation, averaged=True):
         """events -> map (container.py:933-979) on the GPU"""
         from pisa_amd import kernels as K
@@ -577,12 +588,7 @@ class Container:
         assert src_representation in self.array_representations
         self.representation = src_representation
         weights = self.device(key)
-        needs_host = any(d.is_irregular for d in dest_representation)
-        if needs_host:
-            b, cols = regularized(dest_representation, self._host_column)
-            cols = [K.to_device(c) for c in cols]
-        else:
-            b, cols = regularized(dest_representation, self._column)
+        b, cols = self._kernel_form(dest_representation)
         if weights.dim() == 2:
             import torch
 
@@ -598,12 +604,7 @@ class Container:
         self.representation = src_representation
         flat = self.device(key)
         self.representation = dest_representation
-        needs_host = any(d.is_irregular for d in src_representation)
-        if needs_host:
-            b, cols = regularized(src_representation, self._host_column)
-            cols = [K.to_device(c) for c in cols]
-        else:
-            b, cols = regularized(src_representation, self._column)
+        b, cols = self._kernel_form(src_representation)
         return K.lookup_regular(cols, flat, b)
 
     def get_keep_mask(self, keep_criteria):

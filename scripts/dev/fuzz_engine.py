@@ -89,6 +89,12 @@ for trial in range(trials):
             one_by_one = [float(st.eval(q, kind).item()) for q in pts]
             many_ok = all(a == b or (np.isnan(a) and np.isnan(b)) for a, b in zip(got, one_by_one)) and \
                 (one_by_one[-1] == llh or np.isnan(llh))
+        if extra and not events_mode:
+            # the same points with the oscillation kernels of point k + 1 overlapping the fused kernel of point k (two streams)
+            pts = [q for q, _ in extra] + [p]
+            one_by_one = [float(st.eval(q, kind).item()) for q in pts]
+            got = [float(v) for v in st.eval_batch(pts, kind).cpu().numpy()]
+            many_ok = many_ok and all(a == b or (np.isnan(a) and np.isnan(b)) for a, b in zip(got, one_by_one))
         if not (ok and llh_ok and same and many_ok):
             bad += 1
             print("MISMATCH", tag, kind, "events-mode" if events_mode else "", "decay" if decay else "", "maps", ok, "metric", llh,

@@ -108,3 +108,13 @@ def test_random_fits_batched_gradient_equals_point_by_point():
                          capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0, (res.stdout[-3000:], res.stderr[-2000:])
     assert "12 trials, 0 bad" in res.stdout
+
+
+def test_randomised_container_translations_against_the_reference_rule():
+    """`scripts/dev/fuzz_container.py`: `Container`'s events -> map and map -> events against numpy restatements of
+    container.py:933-1012 -- no irregular dimension: ln x for log dimensions and half-open arithmetic; any irregular
+    dimension: every dimension by its edges in original coordinates, last edge included."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "dev", "fuzz_container.py"), "80", "131"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, (res.stdout[-3000:], res.stderr[-2000:])
+    assert "80 trials, 0 bad" in res.stdout

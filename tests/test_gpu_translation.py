@@ -99,3 +99,24 @@ def test_resample_between_binnings():
     np.testing.assert_array_equal(up.reshape(8, 4), np.repeat(down.reshape(4, 4), 2, axis=0))     # nearest old bin
     with pytest.raises(ValueError):
         resample(values, centres(fine), fine, centres(coarse), MultiDimBinning([coarse.dims[0]]))
+
+
+def test_container_with_one_irregular_dimension_includes_every_last_edge():
+    """container.py:948-973: ONE irregular dimension sends ALL dimensions through numpy's rule (an event on the last edge
+    of the regular dimension counts); without it the regular rule leaves that event out."""
+    from pisa_amd.core.container import Container
+
+    x = np.array([0.5, 2.0, 2.0, 1.0])
+    y = np.array([0.1, 0.1, 3.0, 3.0])
+    for irregular, want in ((True, [[1.0, 0.0], [2.0, 12.0]]), (False, [[1.0, 0.0], [0.0, 0.0]])):
+        c = Container("c")
+        c["x"], c["y"], c["w"] = x, y, np.array([1.0, 2.0, 4.0, 8.0])
+        ydim = OneDimBinning(name="y", bin_edges=[0, 1, 3]) if irregular else OneDimBinning(name="y", num_bins=2, domain=[0, 3])
+        b = MultiDimBinning([OneDimBinning(name="x", num_bins=2, domain=[0, 2]), ydim])
+        assert b.is_irregular == irregular
+        c.representation = b
+        assert c["w"].reshape(2, 2).tolist() == want, (irregular, c["w"])
+        c["m"] = np.array([1.0, 2.0, 3.0, 4.0])
+        c.translation_modes["m"] = "average"
+        c.representation = "events"
+        assert c["m"].tolist() == ([1.0, 3.0, 4.0, 4.0] if irregular else [1.0, 0.0, 0.0, 0.0])
