@@ -650,6 +650,41 @@ int pisa_hip_bin_scale(const double *d_x, const double *d_scale, double scalar, 
 /* d_out[i] = sqrt(d_x[i])  (set_variance.py:84-86: errors = sqrt(manual_variance)) */
 int pisa_hip_bin_sqrt(const double *d_x, int64_t n, double *d_out, void *stream);
 
+/* ------------------------------------------------- services around the path */
+
+#define PISA_HIP_MAX_POLY_TERMS 8
+
+/* Replaces `lookup_indices_vectorized_{1,2,3}d` (pisa/core/bin_indexing.py:46-101): flat bin number (C order) of every
+ * event among the bin EDGES of 1-3 dimensions, each dimension by the rule of `find_index`
+ * (pisa/core/translation.py:504-553: half-open bins, the last edge inside; NaN counts as below); any dimension below
+ * -> -1, else any dimension above -> n_bins.  h_d_sample[d]: device column [n]; h_d_edges[d]: device array of
+ * h_n_edges[d] ascending edges. */
+int pisa_hip_lookup_indices(const double *const *h_d_sample, const double *const *h_d_edges,
+                            const int32_t *h_n_edges, int32_t ndim, int64_t n, int64_t *d_index, void *stream);
+
+/* Replaces the gufunc `apply_probs_vectorized` (pisa/stages/osc/two_nu_osc.py:122-127; `calc_probs` :101-110) for one
+ * container: d_weights[i] *= flux[i][1]*(1 - P) (flav 1), flux[i][1]*P (flav 2), flux[i][0] (flav 0), with
+ * P = theta * sin^2(1.267 deltam31 L(coszen) / E) -- `theta` enters as the reference passes it (the angle itself).
+ * d_nu_flux [n][2]. */
+int pisa_hip_two_nu_osc(const double *d_nu_flux, double theta, double deltam31, const double *d_energy,
+                        const double *d_coszen, int32_t flav, int64_t n, double *d_weights, void *stream);
+
+/* d_out[i] = norm * d_nominal[i] * (d_energy[i] / pivot)^index  (d_nominal may be NULL = 1): the nominal flux and
+ * `apply_sys_loop` of pisa/stages/flux/astrophysical.py:69-72, 121-149. */
+int pisa_hip_power_law(const double *d_energy, double pivot, double index, double norm, const double *d_nominal,
+                       int64_t n, double *d_out, void *stream);
+
+/* d_out[i] = x + (target - x) * fraction, then np.clip(lo, hi) if has_clip; target = d_target[i] or, where d_target
+ * is NULL, target_value (pisa/stages/reco/resolutions.py:74-96).  d_out may alias d_x. */
+int pisa_hip_shift_toward(const double *d_x, const double *d_target, double target_value, double fraction,
+                          int32_t has_clip, double lo, double hi, int64_t n, double *d_out, void *stream);
+
+/* Replaces `apply_genie_sys` (pisa/stages/xsec/genie_sys.py:103-113) and `apply_dis_sys` (xsec/dis_sys.py:196-206):
+ * d_weights[i] *= max(0, prod_k (1 + (lin_k[i] + quad_k[i] p_k) p_k)), k < n_terms <= PISA_HIP_MAX_POLY_TERMS;
+ * h_d_quad, or single entries of it, may be NULL (= 0). */
+int pisa_hip_poly_scale(const double *const *h_d_linear, const double *const *h_d_quad, const double *h_params,
+                        int32_t n_terms, int64_t n, double *d_weights, void *stream);
+
 /* -------------------------------------------------------------------- flux */
 
 /* 2-D (azimuth-averaged) Honda flux table prepared for `pisa_hip_flux_2d`

@@ -18,6 +18,9 @@ Outputs (all numpy .npz, inputs + expected outputs only -- no reference text):
   stats_ref.npz           reference stats.llh/poisson_llh/chi2/mod_chi2
   barr_ref.npz            reference barr_simple.apply_sys_kernel
   hist_ref.npz            np.histogramdd recipe of translation.test_histogram
+  side_stages_ref.npz     the services around the path: reference two_nu_osc.apply_probs_vectorized,
+                          astrophysical.apply_sys_loop, genie_sys.apply_genie_sys,
+                          bin_indexing.lookup_indices_vectorized_{1,2,3}d (+ the arrays of its unit test)
 """
 import glob
 import os
@@ -357,10 +360,81 @@ def gen_flux():
     save("flux_bartol_ref.npz", **out)
 
 
+def gen_side():
+    """the small services around the hot path, each by the reference's own function on seeded inputs"""
+    p = os.path.join(ref_shim.REF_ROOT, "pisa", "stages")
+    ref_shim.install()
+    ref_shim._pkg("pisa.stages.xsec", os.path.join(p, "xsec"))
+    rs = np.random.RandomState(31)
+    n = 400
+    out = {}
+    # --- osc.two_nu_osc
+    two = ref_shim.ref_module("pisa.stages.osc.two_nu_osc")
+    e = 10 ** (rs.rand(n) * 3 - 0.5)
+    cz = rs.rand(n) * 2 - 1
+    cz[:4] = [-1.0, 1.0, 0.0, -0.5]
+    flux = rs.rand(n, 2) * 5
+    w0 = rs.rand(n) + 0.5
+    out.update(two_e=e, two_cz=cz, two_flux=flux, two_w0=w0)
+    cases = [(np.deg2rad(45.0), 2.5e-3), (0.6, -2.4e-3), (1.0, 0.0)]
+    out["two_params"] = np.array(cases)
+    for ic, (t23, dm31) in enumerate(cases):
+        for code, tag in ((0, "nue"), (1, "numu"), (3, "nutau")):
+            w = w0.copy()
+            for i in range(n):
+                two.apply_probs_vectorized(flux[i], t23, dm31, e[i], cz[i], code, w[i:i + 1])
+            out["two_%d_%s" % (ic, tag)] = w
+    # --- flux.astrophysical
+    astro = ref_shim.ref_module("pisa.stages.flux.astrophysical")
+    ea = 10 ** (rs.rand(n) * 5 + 2)
+    nominal = 0.787e-18 * np.power(ea / astro.PIVOT, -2.5)            # astrophysical.py:69-72
+    out.update(astro_e=ea, astro_nominal=nominal)
+    acases = [(0.0, 1.0), (0.3, 1.7), (-0.45, 0.2)]
+    out["astro_params"] = np.array(acases)
+    for ic, (delta, norm) in enumerate(acases):
+        o = np.zeros(n)
+        astro.apply_sys_loop(ea, np.zeros(n), delta, norm, nominal, o)
+        out["astro_%d" % ic] = o
+    # --- xsec.genie_sys
+    genie = ref_shim.ref_module("pisa.stages.xsec.genie_sys")
+    lin = [rs.randn(n) * 0.3 for _ in range(3)]
+    quad = [rs.randn(n) * 0.2 for _ in range(3)]
+    out.update(genie_lin=np.array(lin), genie_quad=np.array(quad), genie_w0=w0)
+    gcases = [(0.0, 0.0, 0.0), (1.0, -0.5, 0.3), (-2.0, 2.0, 1.5), (-4.0, 3.0, -3.0)]
+    out["genie_params"] = np.array(gcases)
+    for ic, ps in enumerate(gcases):
+        for k in (1, 2, 3):
+            w = w0.copy()
+            genie.apply_genie_sys(list(ps[:k]), lin[:k], quad[:k], out=w)
+            out["genie_%d_%d" % (ic, k)] = w
+    # --- core.bin_indexing
+    bi = ref_shim.ref_module("pisa.core.bin_indexing")
+    edges = [np.array([0.0, 1.0, 2.5, 2.75, 7.0]), np.logspace(0, 2, 7), np.linspace(-1, 1, 4)]
+    cols = [rs.uniform(-1, 8, n), 10 ** rs.uniform(-0.3, 2.3, n), rs.uniform(-1.3, 1.3, n)]
+    for c, ed in zip(cols, edges):
+        c[:len(ed)] = ed
+    cols[0][10], cols[1][11], cols[2][12] = np.nan, np.nan, np.nan
+    out.update(idx_edges0=edges[0], idx_edges1=edges[1], idx_edges2=edges[2], idx_cols=np.array(cols))
+    funcs = {1: bi.lookup_indices_vectorized_1d, 2: bi.lookup_indices_vectorized_2d, 3: bi.lookup_indices_vectorized_3d}
+    for nd in (1, 2, 3):
+        res = np.zeros(n, dtype=np.int64)
+        for i in range(n):
+            funcs[nd](*([c[i:i + 1] for c in cols[:nd]] + edges[:nd] + [res[i:i + 1]]))
+        out["idx_%dd" % nd] = res
+    # the arrays of test_lookup_indices (bin_indexing.py:164-226): binnings 7 x 4 x 2 over [0,7] x [0,4] x [0,2]
+    out["idx_test_x"] = np.array([-5, 0.5, 1.5, 7.0, 6.5, 8.0, 6.5])
+    out["idx_test_y"] = np.array([-5, 0.5, 1.5, 1.5, 3.0, 1.5, 2.5])
+    out["idx_test_z"] = np.array([-5, 0.5, 1.5, 1.5, 0.5, 6.0, 0.5])
+    out["idx_test_1d"] = np.array([-1, 0, 1, 6, 6, 7, 6])
+    out["idx_test_2d"] = np.array([-1, 0, 5, 25, 27, 28, 26])
+    out["idx_test_3d"] = np.array([-1, 0, 11, 51, 54, 56, 52])
+    save("side_stages_ref.npz", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["pickles", "layers", "params", "lookup", "stats", "barr", "hist", "grid", "flux"]
+    which = sys.argv[1:] or ["pickles", "layers", "params", "lookup", "stats", "barr", "hist", "grid", "flux", "side"]
     fns = dict(pickles=gen_ref_pickles, layers=gen_layers, params=gen_params, lookup=gen_lookup,
-               stats=gen_stats, barr=gen_barr, hist=gen_hist, grid=gen_grid, flux=gen_flux)
+               stats=gen_stats, barr=gen_barr, hist=gen_hist, grid=gen_grid, flux=gen_flux, side=gen_side)
     for w in which:
         fns[w]()

@@ -1,0 +1,69 @@
+"""CPU restatement of the small services around the hot path.  TEST INFRASTRUCTURE ONLY: imported by tests/ and
+scripts/dev as the checker, never by pisa_amd/.  Pinned against the reference's own functions executed in the build
+container (`oracle/gen_golden.py side` -> tests/golden/side_stages_ref.npz; tests/test_oracle_stages.py)."""
+import numpy as np
+
+
+def find_index(val, edges):
+    """pisa/core/translation.py:504-553: half-open bins, the last edge inside; -1 below / NaN, n_bins above"""
+    edges = np.asarray(edges, dtype=np.float64)
+    v = np.asarray(val, dtype=np.float64)
+    nb = len(edges) - 1
+    with np.errstate(invalid="ignore"):
+        idx = np.searchsorted(edges, v, side="right") - 1
+        idx = np.where(v == edges[-1], nb - 1, idx)
+        idx = np.where(v > edges[-1], nb, idx)
+        idx = np.where(v >= edges[0], idx, -1)
+    return idx.astype(np.int64)
+
+
+def lookup_indices(sample, edges):
+    """pisa/core/bin_indexing.py:46-101: C-order flat index; any dimension below -> -1, else any above -> n_bins"""
+    per_dim = [find_index(x, e) for x, e in zip(sample, edges)]
+    nbins = [len(e) - 1 for e in edges]
+    under = np.zeros(len(per_dim[0]), dtype=bool)
+    over = np.zeros(len(per_dim[0]), dtype=bool)
+    flat = np.zeros(len(per_dim[0]), dtype=np.int64)
+    for k, nb in zip(per_dim, nbins):
+        under |= k == -1
+        over |= k == nb
+        flat = flat * nb + np.clip(k, 0, nb - 1)
+    return np.where(under, -1, np.where(over, int(np.prod(nbins)), flat))
+
+
+def two_nu_prob(t23, dm31, true_energy, true_coszen):
+    """pisa/stages/osc/two_nu_osc.py:101-110"""
+    L1 = 19.0
+    R = 6378.2 + L1
+    phi = np.arcsin((1 - L1 / R) * np.sin(np.arccos(true_coszen)))
+    psi = np.arccos(true_coszen) - phi
+    propdist = np.sqrt((R - L1) ** 2 + R ** 2 - (2 * (R - L1) * R * np.cos(psi)))
+    return t23 * np.sin(1.267 * dm31 * propdist / true_energy) ** 2
+
+
+def two_nu_weights(nu_flux, t23, dm31, true_energy, true_coszen, flav, weights):
+    """pisa/stages/osc/two_nu_osc.py:122-127; flav 0 e, 1 mu, 2 tau (the reference's codes 0, 1, 3)"""
+    if flav == 0:
+        return weights * nu_flux[:, 0]
+    p = two_nu_prob(t23, dm31, true_energy, true_coszen)
+    return weights * (nu_flux[:, 1] * ((1.0 - p) if flav == 1 else p))
+
+
+def power_law(true_energy, pivot, index, norm=1.0, nominal=None):
+    """pisa/stages/flux/astrophysical.py:69-72 (nominal=None) and :121-149"""
+    scale = np.power(true_energy / pivot, index)
+    return norm * scale if nominal is None else norm * nominal * scale
+
+
+def shift_toward(x, target, fraction, clip=None):
+    """pisa/stages/reco/resolutions.py:76-92"""
+    out = x + (target - x) * fraction
+    return out if clip is None else np.clip(out, clip[0], clip[1])
+
+
+def poly_scale(params, linear, quad, weights):
+    """pisa/stages/xsec/genie_sys.py:103-113"""
+    factor = 1
+    for p, lin, q in zip(params, linear, quad):
+        factor = factor * (1.0 + (lin + q * p) * p)
+    return weights * np.maximum(0, factor)

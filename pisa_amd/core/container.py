@@ -587,10 +587,13 @@ class Container:
 
         assert src_representation in self.array_representations
         self.representation = src_representation
+        import torch
+
         weights = self.device(key)
+        if weights.dtype != torch.float64:        # an integer column (`bin_indices`): the kernels read doubles
+            weights = weights.to(torch.float64)
         b, cols = self._kernel_form(dest_representation)
         if weights.dim() == 2:
-            import torch
 
             outs = [K.histogram_regular(cols, weights[:, i].contiguous(), b, averaged=averaged)
                     for i in range(weights.shape[1])]
@@ -601,8 +604,12 @@ class Container:
         """map -> events nearest-bin lookup (container.py:981-1012) on the GPU"""
         from pisa_amd import kernels as K
 
+        import torch
+
         self.representation = src_representation
         flat = self.device(key)
+        if flat.dtype != torch.float64:
+            flat = flat.to(torch.float64)
         self.representation = dest_representation
         b, cols = self._kernel_form(src_representation)
         return K.lookup_regular(cols, flat, b)

@@ -132,7 +132,7 @@ class Quantity:
             units = ureg.parse_units(units)
         if isinstance(units, Quantity):
             units = units.units
-        if units.dims != self._u.dims:
+        if units.dims != self._u.dims and units.dims[:-1] != self._u.dims[:-1]:
             raise DimensionalityError("Cannot convert from '%s' to '%s'" % (self._u, units))
         factor = self._u.scale / units.scale
         if factor == 1.0:
@@ -149,7 +149,9 @@ class Quantity:
         mine = self._u
         if units is mine:
             return self._m
-        if units.dims != mine.dims:
+        if units.dims != mine.dims and units.dims[:-1] != mine.dims[:-1]:
+            # pint's radian is dimensionless: `theta.m_as('dimensionless')` is the angle in radians (the last base
+            # dimension here is the angle, kept apart only so that names survive)
             raise DimensionalityError("Cannot convert from '%s' to '%s'" % (mine, units))
         factor = mine.scale / units.scale
         if factor == 1.0:

@@ -591,6 +591,64 @@ def bin_scale(x, scale=None, scalar=1.0, floor=None, out=None):
     return out
 
 
+def lookup_indices(sample, edges):
+    """flat bin number (int64) of every event by the bin edges: -1 below, n_bins above (`pisa_hip_lookup_indices`)"""
+    lib = _lib.lib()
+    n = sample[0].numel()
+    ndim = len(sample)
+    edges = [e.contiguous() for e in edges]
+    n_edges = (C.c_int32 * ndim)(*[e.numel() for e in edges])
+    out = torch.empty(n, dtype=torch.int64, device=sample[0].device)
+    _lib.check(lib.pisa_hip_lookup_indices(_sample_array(sample), _sample_array(edges), n_edges, ndim, n, _ptr(out),
+                                           _stream()))
+    return out
+
+
+def two_nu_osc(nu_flux, theta, deltam31, energy, coszen, flav, weights):
+    """weights *= flux x two-flavour probability, in place (`pisa_hip_two_nu_osc`)"""
+    lib = _lib.lib()
+    assert nu_flux.is_contiguous() and nu_flux.shape == (energy.numel(), 2) and weights.is_contiguous()
+    _lib.check(lib.pisa_hip_two_nu_osc(_ptr(nu_flux), float(theta), float(deltam31), _ptr(energy), _ptr(coszen), int(flav),
+                                       energy.numel(), _ptr(weights), _stream()))
+    return weights
+
+
+def power_law(energy, pivot, index, norm=1.0, nominal=None, out=None):
+    """norm * nominal * (E / pivot)^index (`pisa_hip_power_law`)"""
+    lib = _lib.lib()
+    if out is None:
+        out = torch.empty_like(energy)
+    _lib.check(lib.pisa_hip_power_law(_ptr(energy), float(pivot), float(index), float(norm), _ptr(nominal), energy.numel(),
+                                      _ptr(out), _stream()))
+    return out
+
+
+def shift_toward(x, target, fraction, clip=None, out=None):
+    """x + (target - x) * fraction [clipped]; `target` a device column or a number (`pisa_hip_shift_toward`)"""
+    lib = _lib.lib()
+    if out is None:
+        out = torch.empty_like(x)
+    col = target if isinstance(target, torch.Tensor) else None
+    _lib.check(lib.pisa_hip_shift_toward(_ptr(x), _ptr(col), 0.0 if col is not None else float(target), float(fraction),
+                                         0 if clip is None else 1, 0.0 if clip is None else float(clip[0]),
+                                         0.0 if clip is None else float(clip[1]), x.numel(), _ptr(out), _stream()))
+    return out
+
+
+def poly_scale(linear, quad, params, weights):
+    """weights *= max(0, prod_k (1 + (lin_k + quad_k p_k) p_k)), in place (`pisa_hip_poly_scale`)"""
+    lib = _lib.lib()
+    k = len(linear)
+    assert k == len(params) and (quad is None or len(quad) == k) and weights.is_contiguous()
+    lin = (C.c_void_p * max(k, 1))(*[t.data_ptr() for t in linear])
+    qd = None if quad is None else (C.c_void_p * max(k, 1))(*[None if t is None else t.data_ptr() for t in quad])
+    p = (C.c_double * max(k, 1))(*[float(v) for v in params])
+    for t in list(linear) + [t for t in (quad or []) if t is not None]:
+        assert t.is_cuda and t.is_contiguous() and t.numel() == weights.numel()
+    _lib.check(lib.pisa_hip_poly_scale(lin, qd, p, k, weights.numel(), _ptr(weights), _stream()))
+    return weights
+
+
 def bin_sqrt(x, out=None):
     lib = _lib.lib()
     if out is None:

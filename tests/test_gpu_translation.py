@@ -111,6 +111,7 @@ def test_container_with_one_irregular_dimension_includes_every_last_edge():
     for irregular, want in ((True, [[1.0, 0.0], [2.0, 12.0]]), (False, [[1.0, 0.0], [0.0, 0.0]])):
         c = Container("c")
         c["x"], c["y"], c["w"] = x, y, np.array([1.0, 2.0, 4.0, 8.0])
+        c.translation_modes["w"] = "sum"
         ydim = OneDimBinning(name="y", bin_edges=[0, 1, 3]) if irregular else OneDimBinning(name="y", num_bins=2, domain=[0, 3])
         b = MultiDimBinning([OneDimBinning(name="x", num_bins=2, domain=[0, 2]), ydim])
         assert b.is_irregular == irregular

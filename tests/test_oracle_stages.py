@@ -1,0 +1,74 @@
+"""The restatement of the services around the path (`oracle/stages_oracle.py`) against the reference's own functions
+executed in the build container (`oracle/gen_golden.py side` -> tests/golden/side_stages_ref.npz), the host-side
+pieces of those services, and the arrays of the reference's `test_lookup_indices` (bin_indexing.py:164-226)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import stages_oracle as so
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "side_stages_ref.npz"))
+
+
+def test_two_nu_osc_restatement():
+    for ic, (t23, dm31) in enumerate(G["two_params"]):
+        for flav, tag in ((0, "nue"), (1, "numu"), (2, "nutau")):
+            got = so.two_nu_weights(G["two_flux"], t23, dm31, G["two_e"], G["two_cz"], flav, G["two_w0"])
+            np.testing.assert_allclose(got, G["two_%d_%s" % (ic, tag)], rtol=1e-13, atol=1e-15)
+
+
+def test_power_law_and_genie_restatements():
+    for ic, (delta, norm) in enumerate(G["astro_params"]):
+        got = so.power_law(G["astro_e"], 100.0e3, delta, norm, G["astro_nominal"])
+        np.testing.assert_allclose(got, G["astro_%d" % ic], rtol=1e-15, atol=0)
+    np.testing.assert_allclose(so.power_law(G["astro_e"], 100.0e3, -2.5, 0.787e-18), G["astro_nominal"], rtol=1e-15)
+    for ic, ps in enumerate(G["genie_params"]):
+        for k in (1, 2, 3):
+            got = so.poly_scale(ps[:k], G["genie_lin"][:k], G["genie_quad"][:k], G["genie_w0"])
+            assert np.array_equal(got, G["genie_%d_%d" % (ic, k)])
+    assert (G["genie_3_3"] == 0).any() and (G["genie_3_3"] > 0).any()       # the clamp at 0 is exercised
+
+
+def test_lookup_indices_restatement():
+    edges = [G["idx_edges0"], G["idx_edges1"], G["idx_edges2"]]
+    for nd in (1, 2, 3):
+        got = so.lookup_indices(list(G["idx_cols"][:nd]), edges[:nd])
+        assert np.array_equal(got, G["idx_%dd" % nd])
+    e = [np.linspace(0, 7, 8), np.linspace(0, 4, 5), np.linspace(0, 2, 3)]
+    cols = [G["idx_test_x"], G["idx_test_y"], G["idx_test_z"]]
+    for nd in (1, 2, 3):
+        assert np.array_equal(so.lookup_indices(cols[:nd], e[:nd]), G["idx_test_%dd" % nd])
+
+
+def test_kfold_folds_are_scikit_learns():
+    from sklearn.model_selection import KFold
+
+    from pisa_amd.stages.utils.kfold import _fold
+
+    for n in (10, 11, 13):
+        for k in (2, 3, 5):
+            for sel in range(k + 2):
+                for shuffle, seed in ((False, None), (True, 3)):
+                    for i, (_, test) in enumerate(KFold(n_splits=k, shuffle=shuffle, random_state=seed).split(np.empty(n))):
+                        if i == sel:
+                            break
+                    assert np.array_equal(test, _fold(n, k, sel, shuffle, seed)), (n, k, sel, shuffle)
+    with pytest.raises(ValueError):
+        _fold(3, 5, 0, False, None)
+
+
+def test_bootstrap_insertion_and_angle_as_dimensionless():
+    from collections import OrderedDict
+
+    from pisa_amd.core.units import DimensionalityError, ureg
+    from pisa_amd.stages.utils.bootstrap import insert_bootstrap_after_data_loader
+
+    cfg = OrderedDict([(("data", "simple_data_loader"), {"a": 1}), (("flux", "barr_simple"), {}), (("utils", "hist"), {})])
+    out = insert_bootstrap_after_data_loader(cfg, seed=4)
+    assert list(out) == [("data", "simple_data_loader"), ("utils", "bootstrap"), ("flux", "barr_simple"), ("utils", "hist")]
+    assert out[("utils", "bootstrap")] == {"apply_mode": "events", "calc_mode": "events", "seed": 4} and list(cfg) != list(out)
+    # pint's radian is dimensionless: two_nu_osc.py:68 reads theta23 this way
+    assert (45 * ureg.degree).m_as("dimensionless") == np.deg2rad(45.0)
+    with pytest.raises(DimensionalityError):
+        (1 * ureg.m).m_as("dimensionless")
