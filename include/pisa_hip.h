@@ -679,11 +679,29 @@ int pisa_hip_power_law(const double *d_energy, double pivot, double index, doubl
 int pisa_hip_shift_toward(const double *d_x, const double *d_target, double target_value, double fraction,
                           int32_t has_clip, double lo, double hi, int64_t n, double *d_out, void *stream);
 
-/* Replaces `apply_genie_sys` (pisa/stages/xsec/genie_sys.py:103-113) and `apply_dis_sys` (xsec/dis_sys.py:196-206):
- * d_weights[i] *= max(0, prod_k (1 + (lin_k[i] + quad_k[i] p_k) p_k)), k < n_terms <= PISA_HIP_MAX_POLY_TERMS;
- * h_d_quad, or single entries of it, may be NULL (= 0). */
+/* Replaces `apply_genie_sys` (pisa/stages/xsec/genie_sys.py:103-113), `apply_dis_sys` (xsec/dis_sys.py:196-206) and
+ * the weight update of background/atm_muons.py:95-101:
+ * d_weights[i] *= max(0, scale * prod_k (1 + (lin_k[i] + quad_k[i] p_k) p_k)), k < n_terms <= PISA_HIP_MAX_POLY_TERMS;
+ * h_d_quad, or single entries of it, may be NULL (= 0); scale = 1 where the reference has none. */
 int pisa_hip_poly_scale(const double *const *h_d_linear, const double *const *h_d_quad, const double *h_params,
-                        int32_t n_terms, int64_t n, double *d_weights, void *stream);
+                        int32_t n_terms, double scale, int64_t n, double *d_weights, void *stream);
+
+/* numpy.interp(d_x, x_knots, y_knots) -- what scipy's `interp1d(kind='linear')` evaluates for 1-D float data
+ * (background/atm_muons.py:82-87 with the spline of :159-164) -- for ascending knots in device memory.  A finite
+ * d_x[i] outside [x_knots[0], x_knots[last]] sets *d_status (int32, may be NULL) and gives NaN: interp1d's
+ * bounds_error, which the caller raises. */
+int pisa_hip_interp_linear(const double *d_x_knots, const double *d_y_knots, int32_t n_knots, const double *d_x,
+                           int64_t n, double *d_out, int32_t *d_status, void *stream);
+
+/* Replaces `decoherence.calc_probs` (pisa/stages/osc/decoherence.py:449-466 over `calc_decoherence_probs` :66-106):
+ * d_probability[n][3][3], rows (1, 0, 0), (0, 1 - D, D), (0, D, 1 - D) with the numu disappearance D(E, L) of
+ * `_calc_numu_disappearance_prob_3flav` (:229-269; h_coef[k] = |U[2][j]|^2 |U[2][k]|^2, h_gamma[k] in GeV, h_delta[k]
+ * in eV^2 for the pairs (1,0), (2,0), (2,1)) or, two_flavor != 0, of `_calc_numu_disappearance_prob_2flav`
+ * (:112-139; h_coef[0] = 0.5 sin^2(2 theta23), h_gamma[0] = gamma32 in eV, h_delta[0] = dm32).  d_energy in GeV,
+ * d_baseline in km. */
+int pisa_hip_decoherence_probs(const double *h_coef, const double *h_gamma, const double *h_delta, int32_t two_flavor,
+                               const double *d_energy, const double *d_baseline, int64_t n, double *d_probability,
+                               void *stream);
 
 /* -------------------------------------------------------------------- flux */
 

@@ -26,6 +26,7 @@ import glob
 import os
 import pickle
 import sys
+import types
 import warnings
 
 import numpy as np
@@ -421,6 +422,41 @@ def gen_side():
         for i in range(n):
             funcs[nd](*([c[i:i + 1] for c in cols[:nd]] + edges[:nd] + [res[i:i + 1]]))
         out["idx_%dd" % nd] = res
+    # --- osc.decoherence, 3-flavour form.  pint is absent: the quantities are handed over as an INERT stand-in whose
+    # m_as() returns the magnitude as it is, every value already in the unit the reference asks for (rad, GeV, eV**2,
+    # km) -- no conversion is emulated; the 2-flavour form (which converts km -> m and GeV -> eV) is not pinned here
+    dec = ref_shim.ref_module("pisa.stages.osc.decoherence")
+
+    class Q:
+        def __init__(self, m):
+            self.m = m
+
+        shape = property(lambda self: np.shape(self.m))
+
+        def m_as(self, _unit):
+            return self.m
+
+        def __sub__(self, other):
+            return Q(self.m - other.m)
+
+    dec.ureg = types.SimpleNamespace(Quantity=Q)
+    ed = 10 ** (rs.rand(n) * 3)
+    ld = rs.uniform(10.0, 12800.0, n)
+    out.update(dec_e=ed, dec_l=ld)
+    dcases = [(np.deg2rad(33.0), np.deg2rad(8.0), np.deg2rad(50.0), 8e-5, 3e-3, 1e-11, 5e-10, 2.5e-13),
+              (np.deg2rad(33.6), np.deg2rad(8.5), np.deg2rad(42.0), 7.5e-5, 2.457e-3, 0.0, 0.0, 0.0),
+              (np.deg2rad(30.0), np.deg2rad(9.0), np.deg2rad(47.0), 7.0e-5, -2.4e-3, 1e-23, 1e-22, 3e-23)]
+    out["dec_params"] = np.array(dcases)
+    for ic, (t12, t13, t23, dm21, dm31, g21, g31, g32) in enumerate(dcases):
+        # DecoherenceParams' constructor routes the angles through pint (OscParams' property keeps sin(theta) and hands
+        # back arcsin of it): the functions get a plain namespace with that value
+        thetas = {k: Q(float(np.arcsin(np.sin(v)))) for k, v in (("theta12", t12), ("theta13", t13), ("theta23", t23))}
+        view = types.SimpleNamespace(dm21=Q(dm21), dm31=Q(dm31), dm32=Q(dm31 - dm21), gamma21=Q(g21), gamma31=Q(g31),
+                                     gamma32=Q(g32), **thetas)
+        for flav in ("nue", "numu"):
+            pe, pm, pt = np.zeros(n), np.zeros(n), np.zeros(n)
+            dec.calc_decoherence_probs(view, flav, Q(ed), Q(ld), pe, pm, pt, two_flavor=False)
+            out["dec_%d_%s" % (ic, flav)] = np.stack([pe, pm, pt], axis=1)
     # the arrays of test_lookup_indices (bin_indexing.py:164-226): binnings 7 x 4 x 2 over [0,7] x [0,4] x [0,2]
     out["idx_test_x"] = np.array([-5, 0.5, 1.5, 7.0, 6.5, 8.0, 6.5])
     out["idx_test_y"] = np.array([-5, 0.5, 1.5, 1.5, 3.0, 1.5, 2.5])

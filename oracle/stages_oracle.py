@@ -67,3 +67,46 @@ def poly_scale(params, linear, quad, weights):
     for p, lin, q in zip(params, linear, quad):
         factor = factor * (1.0 + (lin + q * p) * p)
     return weights * np.maximum(0, factor)
+
+
+def decoherence_disappearance(coef, gamma, delta, energy, baseline):
+    """pisa/stages/osc/decoherence.py:229-269: pairs (1,0), (2,0), (2,1); gamma in GeV, delta in eV^2, E GeV, L km"""
+    prob_dec = np.zeros(np.shape(energy))
+    for c, g, d in zip(coef, gamma, delta):
+        prob_dec += c * (1.0 - np.exp(-g * baseline * 5.07e+18) * np.cos(d * 1.0e-18 / (2.0 * energy) * baseline * 5.07e+18))
+    return 2.0 * prob_dec
+
+
+def decoherence_disappearance_2flav(theta23, gamma32_ev, dm32, energy, baseline):
+    """pisa/stages/osc/decoherence.py:112-139 (parity unpinned: the reference converts units through pint, absent here)"""
+    norm_term = 0.5 * (np.sin(2.0 * theta23) ** 2)
+    decoh_term = np.exp(-gamma32_ev * (baseline * 1000.0 / 1.97e-7))
+    osc_term = np.cos((2.0 * 1.27 * dm32 * baseline) / energy)
+    return norm_term * (1.0 - (decoh_term * osc_term))
+
+
+def decoherence_table(disappearance):
+    """pisa/stages/osc/decoherence.py:90-106, 449-466: P[n, 3, 3]"""
+    n = len(disappearance)
+    p = np.zeros((n, 3, 3))
+    p[:, 0, 0] = 1.0
+    p[:, 1, 1] = 1.0 - disappearance
+    p[:, 1, 2] = 1.0 - p[:, 1, 0] - p[:, 1, 1]
+    p[:, 2, 1] = p[:, 1, 2]
+    p[:, 2, 2] = p[:, 1, 1]
+    return p
+
+
+def tau_row_sq(theta12, theta13, theta23):
+    """|U[2][k]|^2 of pisa/stages/osc/decoherence.py:176-227 (its delta_cp phases are 0.0)"""
+    c12, c13, c23 = np.cos(theta12), np.cos(theta13), np.cos(theta23)
+    s12, s13, s23 = np.sin(theta12), np.sin(theta13), np.sin(theta23)
+    eid = 0.0
+    row = [(s12 * s23) - (c12 * c23 * s13 * eid), (0.0 - c12 * s23) - (s12 * c23 * s13 * eid), c23 * c13]
+    return [abs(v) ** 2 for v in row]
+
+
+def atm_muon_weights(weights, cr_rw_array, delta_gamma_mu, atm_muon_scale):
+    """pisa/stages/background/atm_muons.py:95-101"""
+    weight_mod = 1 + (delta_gamma_mu * cr_rw_array)
+    return weights * np.clip(weight_mod * atm_muon_scale, a_min=0, a_max=np.inf)

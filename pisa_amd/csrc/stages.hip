@@ -5,9 +5,12 @@
 //   two_nu_osc       weights *= flux x two-flavour vacuum probability     (pisa/stages/osc/two_nu_osc.py:66-127)
 //   power_law        out = norm * nominal * (E / pivot)^index             (pisa/stages/flux/astrophysical.py:69-149)
 //   shift_toward     out = clip(x + (target - x) * fraction)              (pisa/stages/reco/resolutions.py:74-96)
-//   poly_scale       weights *= max(0, prod_k (1 + (lin_k + quad_k p_k) p_k))
+//   poly_scale       weights *= max(0, scale * prod_k (1 + (lin_k + quad_k p_k) p_k))
 //                                                                          (pisa/stages/xsec/genie_sys.py:103-113,
-//                                                                           pisa/stages/xsec/dis_sys.py:196-206)
+//                                                                           pisa/stages/xsec/dis_sys.py:196-206,
+//                                                                           pisa/stages/background/atm_muons.py:95-101)
+//   interp_linear    numpy.interp between knots                            (atm_muons.py:82-87, 159-164)
+//   decoherence      P[n][3][3] of the vacuum decoherence model            (pisa/stages/osc/decoherence.py:66-269)
 #include <math.h>
 
 #include "common.hpp"
@@ -101,6 +104,7 @@ struct PolySet {
     const double *lin[POLY_MAX];
     const double *quad[POLY_MAX];
     double p[POLY_MAX];
+    double scale;
     int32_t k;
 };
 
@@ -113,9 +117,75 @@ poly_scale_kernel(const PolySet s, int64_t n, double *__restrict__ weights) {
         const double q = s.quad[k] ? s.quad[k][i] * s.p[k] : 0.0;
         factor *= 1. + (s.lin[k][i] + q) * s.p[k];
     }
+    factor *= s.scale;      // atm_muons.py:100-101: clip(weight_mod * atm_muon_scale, 0, inf); 1.0 elsewhere (exact)
     // np.maximum(0, factor) hands a NaN on; Python's max(0, NaN) of dis_sys.py:206 gives 0 -- only genie's form is
     // reachable with finite columns, and both agree there
     weights[i] *= factor < 0 ? 0.0 : factor;
+}
+
+// numpy's `interp` (what scipy's interp1d(kind='linear') calls for 1-D float data): linear between the knots, the
+// knot value AT a knot; outside [x_0, x_last] the status flag is raised (interp1d's bounds_error) and NaN written
+__global__ void __launch_bounds__(256)
+interp_linear_kernel(const double *__restrict__ xk, const double *__restrict__ yk, int nk,
+                     const double *__restrict__ x, int64_t n, double *__restrict__ out, int32_t *__restrict__ status) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double v = x[i];
+    if (!(v >= xk[0] && v <= xk[nk - 1])) {
+        if (status && v == v) atomicOr(status, 1);      // NaN passes through, as in numpy
+        out[i] = nan("");
+        return;
+    }
+    int lo = 0, hi = nk - 1;                            // xk[lo] <= v <= xk[hi]
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (v >= xk[mid]) lo = mid; else hi = mid;
+    }
+    if (v == xk[hi]) lo = hi;                           // numpy's search lands on the knot itself
+    if (lo == nk - 1 || v == xk[lo]) {
+        out[i] = yk[lo];
+        return;
+    }
+    const double slope = (yk[lo + 1] - yk[lo]) / (xk[lo + 1] - xk[lo]);
+    double r = slope * (v - xk[lo]) + yk[lo];
+    if (r != r) {
+        r = slope * (v - xk[lo + 1]) + yk[lo + 1];
+        if (r != r && yk[lo] == yk[lo + 1]) r = yk[lo];
+    }
+    out[i] = r;
+}
+
+// decoherence.py:66-106, 229-269, 449-466: P[i][3][3] of the vacuum decoherence model.  nue stays nue; the numu
+// row is (0, 1 - D, D), the nutau row its mirror, D the numu disappearance in the 3-flavour or 2-flavour form
+struct DecohArgs {
+    double coef[3], gamma[3], delta[3];
+    int32_t two_flavor;
+};
+
+__global__ void __launch_bounds__(256)
+decoherence_kernel(const DecohArgs a, const double *__restrict__ energy, const double *__restrict__ baseline,
+                   int64_t n, double *__restrict__ prob) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double E = energy[i], L = baseline[i];
+    double dis;
+    if (a.two_flavor) {
+        // :135-139  gamma in eV, L in m / 1.97e-7; cos(2 * 1.27 dm32 L / E)
+        const double decoh = exp(-a.gamma[0] * (L * 1000.0 / 1.97e-7));
+        const double osc = cos((2. * 1.27 * a.delta[0] * L) / E);
+        dis = a.coef[0] * (1. - (decoh * osc));
+    } else {
+        double acc = 0.0;
+        for (int k = 0; k < 3; k++)        // pairs (1,0), (2,0), (2,1) in the order of :262-265
+            acc += a.coef[k] * (1.0 - exp(-a.gamma[k] * L * 5.07e+18) *
+                                          cos(a.delta[k] * 1.0e-18 / (2.0 * E) * L * 5.07e+18));
+        dis = 2.0 * acc;
+    }
+    const double surv = 1. - dis;
+    double *p = prob + 9 * i;
+    p[0] = 1.; p[1] = 0.; p[2] = 1. - 1. - 0.;
+    p[3] = 0.; p[4] = surv; p[5] = 1. - 0. - surv;
+    p[6] = 0.; p[7] = p[5]; p[8] = surv;
 }
 
 }  // namespace pisa
@@ -182,11 +252,13 @@ PISA_API int pisa_hip_shift_toward(const double *d_x, const double *d_target, do
 }
 
 PISA_API int pisa_hip_poly_scale(const double *const *h_d_linear, const double *const *h_d_quad,
-                                 const double *h_params, int32_t n_terms, int64_t n, double *d_weights, void *stream) {
+                                 const double *h_params, int32_t n_terms, double scale, int64_t n, double *d_weights,
+                                 void *stream) {
     if (n_terms < 0 || n_terms > POLY_MAX || n < 0 || (n_terms && (!h_d_linear || !h_params)))
         return PISA_HIP_ERR_INVALID;
     PolySet s;
     s.k = n_terms;
+    s.scale = scale;
     for (int k = 0; k < POLY_MAX; k++) {
         s.lin[k] = nullptr; s.quad[k] = nullptr; s.p[k] = 0;
     }
@@ -200,5 +272,33 @@ PISA_API int pisa_hip_poly_scale(const double *const *h_d_linear, const double *
     if (!d_weights) return PISA_HIP_ERR_INVALID;
     hipLaunchKernelGGL(poly_scale_kernel, grid_for(n), dim3(256), 0, as_stream(stream), s, n, d_weights);
     PISA_CHECK_LAUNCH("poly_scale_kernel");
+    return PISA_HIP_OK;
+}
+
+PISA_API int pisa_hip_interp_linear(const double *d_x_knots, const double *d_y_knots, int32_t n_knots, const double *d_x,
+                                    int64_t n, double *d_out, int32_t *d_status, void *stream) {
+    if (n_knots < 2 || n < 0 || !d_x_knots || !d_y_knots) return PISA_HIP_ERR_INVALID;
+    if (n == 0) return PISA_HIP_OK;
+    if (!d_x || !d_out) return PISA_HIP_ERR_INVALID;
+    hipLaunchKernelGGL(interp_linear_kernel, grid_for(n), dim3(256), 0, as_stream(stream), d_x_knots, d_y_knots,
+                       (int)n_knots, d_x, n, d_out, d_status);
+    PISA_CHECK_LAUNCH("interp_linear_kernel");
+    return PISA_HIP_OK;
+}
+
+PISA_API int pisa_hip_decoherence_probs(const double *h_coef, const double *h_gamma, const double *h_delta,
+                                        int32_t two_flavor, const double *d_energy, const double *d_baseline, int64_t n,
+                                        double *d_probability, void *stream) {
+    if (!h_coef || !h_gamma || !h_delta || n < 0) return PISA_HIP_ERR_INVALID;
+    if (n == 0) return PISA_HIP_OK;
+    if (!d_energy || !d_baseline || !d_probability) return PISA_HIP_ERR_INVALID;
+    DecohArgs a;
+    for (int k = 0; k < 3; k++) {
+        a.coef[k] = h_coef[k]; a.gamma[k] = h_gamma[k]; a.delta[k] = h_delta[k];
+    }
+    a.two_flavor = two_flavor ? 1 : 0;
+    hipLaunchKernelGGL(decoherence_kernel, grid_for(n), dim3(256), 0, as_stream(stream), a, d_energy, d_baseline, n,
+                       d_probability);
+    PISA_CHECK_LAUNCH("decoherence_kernel");
     return PISA_HIP_OK;
 }

@@ -635,8 +635,8 @@ def shift_toward(x, target, fraction, clip=None, out=None):
     return out
 
 
-def poly_scale(linear, quad, params, weights):
-    """weights *= max(0, prod_k (1 + (lin_k + quad_k p_k) p_k)), in place (`pisa_hip_poly_scale`)"""
+def poly_scale(linear, quad, params, weights, scale=1.0):
+    """weights *= max(0, scale * prod_k (1 + (lin_k + quad_k p_k) p_k)), in place (`pisa_hip_poly_scale`)"""
     lib = _lib.lib()
     k = len(linear)
     assert k == len(params) and (quad is None or len(quad) == k) and weights.is_contiguous()
@@ -645,8 +645,35 @@ def poly_scale(linear, quad, params, weights):
     p = (C.c_double * max(k, 1))(*[float(v) for v in params])
     for t in list(linear) + [t for t in (quad or []) if t is not None]:
         assert t.is_cuda and t.is_contiguous() and t.numel() == weights.numel()
-    _lib.check(lib.pisa_hip_poly_scale(lin, qd, p, k, weights.numel(), _ptr(weights), _stream()))
+    _lib.check(lib.pisa_hip_poly_scale(lin, qd, p, k, float(scale), weights.numel(), _ptr(weights), _stream()))
     return weights
+
+
+def interp_linear(x_knots, y_knots, x, out=None):
+    """numpy.interp(x, x_knots, y_knots) on the device; a value outside the knots raises, as scipy's interp1d does
+    (`pisa_hip_interp_linear`)"""
+    lib = _lib.lib()
+    if out is None:
+        out = torch.empty_like(x)
+    status = torch.zeros(1, dtype=torch.int32, device=x.device)
+    _lib.check(lib.pisa_hip_interp_linear(_ptr(x_knots), _ptr(y_knots), x_knots.numel(), _ptr(x), x.numel(), _ptr(out),
+                                          _ptr(status), _stream()))
+    if int(status.item()):
+        raise ValueError("A value in x_new is outside the interpolation range.")
+    return out
+
+
+def decoherence_probs(coef, gamma, delta, two_flavor, energy, baseline, out=None):
+    """P[n, 3, 3] of the vacuum decoherence model (`pisa_hip_decoherence_probs`)"""
+    lib = _lib.lib()
+    n = energy.numel()
+    assert baseline.numel() == n
+    if out is None:
+        out = torch.empty((n, 3, 3), dtype=F8, device=energy.device)
+    arr = [(C.c_double * 3)(*[float(v) for v in a]) for a in (coef, gamma, delta)]
+    _lib.check(lib.pisa_hip_decoherence_probs(arr[0], arr[1], arr[2], 1 if two_flavor else 0, _ptr(energy), _ptr(baseline), n,
+                                              _ptr(out), _stream()))
+    return out
 
 
 def bin_sqrt(x, out=None):

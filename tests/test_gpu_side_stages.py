@@ -321,3 +321,93 @@ def test_bootstrap_in_the_example_pipeline_as_in_the_reference_unit_test():
         std_ratio = np.std(nominal, axis=0) / baseline.std_devs
     assert abs(np.nanmean(nom_ratio) - 1.0) < 0.01
     assert abs(np.nanmean(std_ratio) - 1.0) < 0.02
+
+
+def test_decoherence_kernel_and_stage():
+    from oracle import stages_oracle as so
+    from pisa_amd import kernels as K
+    from pisa_amd.core.param import Param, ParamSet
+    from pisa_amd.core.units import ureg
+    from pisa_amd.stages.osc import decoherence as D
+
+    for ic, (t12, t13, t23, dm21, dm31, g21, g31, g32) in enumerate(G["dec_params"]):
+        u2 = so.tau_row_sq(*(np.arcsin(np.sin(t)) for t in (t12, t13, t23)))
+        coef = [u2[1] * u2[0], u2[2] * u2[0], u2[2] * u2[1]]
+        table = K.decoherence_probs(coef, [g21, g31, g32], [dm21, dm31, dm31 - dm21], False, _dev(G["dec_e"]),
+                                    _dev(G["dec_l"])).cpu().numpy()
+        assert np.array_equal(table[:, 0, :], G["dec_%d_nue" % ic])
+        np.testing.assert_allclose(table[:, 1, :], G["dec_%d_numu" % ic], rtol=1e-10, atol=1e-14)
+        assert np.array_equal(table[:, 2, 1], table[:, 1, 2]) and np.array_equal(table[:, 2, 2], table[:, 1, 1])
+    # the 2-flavour form against the restatement
+    e, length = G["dec_e"], G["dec_l"]
+    got = K.decoherence_probs([0.48, 0, 0], [2.5e-4 * 1e-12, 0, 0], [2.9e-3, 0, 0], True, _dev(e), _dev(length)).cpu().numpy()
+    want = so.decoherence_table(so.decoherence_disappearance_2flav(0.5 * np.arcsin(np.sqrt(0.96)), 2.5e-16, 2.9e-3, e, length))
+    np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-13)
+    # the stage: example values of the reference; sys_flux stands where prob3 reads nu_flux
+    data = _containers(extra=())
+    for c in data:
+        c["sys_flux"] = np.array(c["nu_flux"])
+    before = _columns(data, ["weights", "sys_flux", "true_energy", "true_coszen"])
+    st = D.init_test(prior=None, range=None, is_fixed=False)
+    st.data, st.calc_mode, st.apply_mode = data, "events", "events"
+    st.setup()
+    st.run()
+    p = st.params
+    u2 = so.tau_row_sq(*(np.arcsin(np.sin(p[n].value.m_as("rad"))) for n in ("theta12", "theta13", "theta23")))
+    coef = [u2[1] * u2[0], u2[2] * u2[0], u2[2] * u2[1]]
+    r_det = 6371.0 - 0.5
+    for c in data:
+        b = before[c.name]
+        cz = b["true_coszen"]
+        length = -r_det * cz + np.sqrt(r_det ** 2.0 * cz ** 2 - (r_det ** 2.0 - (r_det + 0.5 + 20.0) ** 2.0))
+        np.testing.assert_allclose(c["distances"], length, rtol=1e-15)
+        table = so.decoherence_table(so.decoherence_disappearance(coef, [1e-11, 5e-10, 2.5e-13], [8e-5, 3e-3, 3e-3 - 8e-5],
+                                                                  b["true_energy"], length))
+        np.testing.assert_allclose(c["probability"], table, rtol=1e-10, atol=1e-14)
+        flav = c["flav"]
+        want = b["weights"] * (b["sys_flux"][:, 0] * table[:, 0, flav] + b["sys_flux"][:, 1] * table[:, 1, flav])
+        np.testing.assert_allclose(c["weights"], want, rtol=1e-10, atol=1e-14)
+    # host-array form of the reference's free function
+    pe, pm, pt = np.zeros(50), np.zeros(50), np.zeros(50)
+    D.calc_decoherence_probs(st.decoh_params, "numu_cc", G["dec_e"][:50], G["dec_l"][:50] * ureg.km, pe, pm, pt)
+    np.testing.assert_allclose(np.stack([pe, pm, pt], axis=1), G["dec_0_numu"][:50], rtol=1e-10, atol=1e-14)
+    with pytest.raises(ValueError):
+        D.calc_decoherence_probs(st.decoh_params, "nutau", G["dec_e"][:5], G["dec_l"][:5], pe[:5], pm[:5], pt[:5])
+    with pytest.raises(ValueError):
+        D.decoherence(params=ParamSet([Param(name=q.name, value="osc/PREM_4layer.dat" if q.name == "earth_model" else q.value,
+                                             prior=None, range=None, is_fixed=True) for q in p]))
+
+
+def test_atm_muons_stage_and_linear_interpolation():
+    from oracle import stages_oracle as so
+    from pisa_amd import kernels as K
+    from pisa_amd.core.container import Container, ContainerSet
+    from pisa_amd.stages.background import atm_muons as A
+
+    st = A.init_test(prior=None, range=None, is_fixed=False)
+    xk, yk = st._make_prim_unc_spline()
+    rs = np.random.RandomState(4)
+    x = np.concatenate([rs.rand(5000), xk, [np.nan]])
+    got = K.interp_linear(_dev(xk), _dev(yk), _dev(x)).cpu().numpy()
+    assert np.array_equal(got, np.interp(x, xk, yk), equal_nan=True)
+    with pytest.raises(ValueError):
+        K.interp_linear(_dev(xk), _dev(yk), _dev(np.array([0.5, 1.0001])))
+    c = Container("muons")
+    c["true_coszen"] = rs.rand(3000)
+    c["weights"] = rs.rand(3000) + 0.5
+    w0, cz = np.array(c["weights"]), np.array(c["true_coszen"])
+    st.data, st.apply_mode, st.calc_mode = ContainerSet("data", [c], representation="events"), "events", "events"
+    st.setup()
+    rw = np.interp(cz, xk, yk)
+    cr = rw - rw.sum() / rw.size
+    assert np.array_equal(c["rw_array"], rw) and np.array_equal(c["cr_rw_array"], cr)
+    for scale, dg in ((1.0, 1.0), (0.8, -3.0), (1.3, 40.0)):
+        st.params.atm_muon_scale.value, st.params.delta_gamma_mu.value = scale, dg
+        c["weights"] = w0.copy()
+        st.run()
+        want = so.atm_muon_weights(w0, cr, dg, scale)
+        assert np.array_equal(c["weights"], want)
+    assert (want == 0).any()
+    st.params.delta_gamma_mu_spline_kind.value = "cubic"
+    with pytest.raises(NotImplementedError):
+        st.setup()
