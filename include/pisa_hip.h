@@ -623,6 +623,12 @@ int pisa_hip_kde_configure(int32_t use_expansion);
 #define PISA_HIP_METRIC_POISSON_LLH 1  /* stats.py:255-326 */
 #define PISA_HIP_METRIC_CHI2 2         /* stats.py:98-167  */
 #define PISA_HIP_METRIC_MOD_CHI2 3     /* stats.py:651-695 */
+/* pisa_hip_metric only (maps in HBM; the fused tails of the evaluation take the four above) */
+#define PISA_HIP_METRIC_CORRECT_CHI2 4          /* stats.py:697-730 */
+#define PISA_HIP_METRIC_SIGNED_SQRT_MOD_CHI2 5  /* stats.py:762-786 */
+#define PISA_HIP_METRIC_MCLLH_MEAN 6            /* stats.py:328-382, likelihood_functions.py:22-63 (a = 0) */
+#define PISA_HIP_METRIC_MCLLH_EFF 7             /* stats.py:384-438 (a = 1) */
+#define PISA_HIP_METRIC_CONV_LLH 8              /* stats.py:440-596 */
 
 /* Map.metric / metric_total (pisa/core/map.py:1572-1604): per-bin metric of
  * (actual, expected[, sigma2]) and its nansum.  If n_maps > 1 the expectation

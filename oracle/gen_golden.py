@@ -18,6 +18,7 @@ Outputs (all numpy .npz, inputs + expected outputs only -- no reference text):
   stats_ref.npz           reference stats.llh/poisson_llh/chi2/mod_chi2
   barr_ref.npz            reference barr_simple.apply_sys_kernel
   hist_ref.npz            np.histogramdd recipe of translation.test_histogram
+  stats_wide_ref.npz      reference stats.mcllh_mean / mcllh_eff / correct_chi2 / signed_sqrt_mod_chi2 / conv_llh
   side_stages_ref.npz     the services around the path: reference two_nu_osc.apply_probs_vectorized,
                           astrophysical.apply_sys_loop, genie_sys.apply_genie_sys,
                           bin_indexing.lookup_indices_vectorized_{1,2,3}d (+ the arrays of its unit test)
@@ -282,6 +283,47 @@ def gen_stats():
     save("stats_ref.npz", **out)
 
 
+def gen_stats_wide():
+    """the metrics beyond llh / poisson_llh / chi2 / mod_chi2, by the reference's own functions.  `uncertainties` is
+    absent: expected values travel as an ndarray subclass carrying its standard deviations, which the stand-in for
+    `unumpy` splits off again (nominal_values / std_devs) -- no arithmetic of that package is emulated."""
+    import importlib.util
+
+    st = ref_shim.ref_module("pisa.utils.stats")
+    spec = importlib.util.spec_from_file_location(
+        "pisa.utils.likelihood_functions", os.path.join(ref_shim.REF_ROOT, "pisa", "utils", "likelihood_functions.py"))
+    lf = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lf)
+    st.likelihood_functions = lf
+
+    class WithStd(np.ndarray):
+        pass
+
+    def with_std(values, sigma):
+        a = np.array(values, dtype=np.float64).view(WithStd)
+        a.s = np.array(sigma, dtype=np.float64)
+        return a
+
+    st.unp = types.SimpleNamespace(nominal_values=lambda x: np.array(x, dtype=np.float64),
+                                   std_devs=lambda x: np.array(getattr(x, "s", np.zeros(np.shape(x)))))
+    rs = np.random.RandomState(7)
+    n = 160
+    expected = rs.rand(n) * 60
+    expected[:6] = [0.0, 1e-12, 1e-10, 5.0, 0.3, 1500.0]
+    sigma = np.sqrt(expected) * rs.rand(n) * 0.7
+    sigma[6:12] = 0.0                                   # the Poisson limit of the mixture
+    sigma[12:16] = [1e-6, 1e-3, 30.0, 100.0]
+    actual = rs.poisson(np.maximum(expected, 0.5)).astype(np.float64)
+    actual[16:20] = 0.0
+    actual[5] = 1450.0
+    out = dict(actual=actual, expected=expected, sigma=sigma)
+    for name in ("mcllh_mean", "mcllh_eff", "correct_chi2", "signed_sqrt_mod_chi2", "conv_llh", "mod_chi2"):
+        v = getattr(st, name)(actual.copy(), with_std(expected, sigma))
+        v = np.ma.filled(np.ma.masked_invalid(np.ma.asarray(v, dtype=float)), np.nan)
+        out[name] = np.asarray(v, dtype=np.float64)
+    save("stats_wide_ref.npz", **out)
+
+
 def gen_barr():
     bs = ref_shim.ref_module("pisa.stages.flux.barr_simple")
     rs = np.random.RandomState(11)
@@ -469,8 +511,8 @@ def gen_side():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["pickles", "layers", "params", "lookup", "stats", "barr", "hist", "grid", "flux", "side"]
+    which = sys.argv[1:] or ["pickles", "layers", "params", "lookup", "stats", "barr", "hist", "grid", "flux", "side", "stats_wide"]
     fns = dict(pickles=gen_ref_pickles, layers=gen_layers, params=gen_params, lookup=gen_lookup,
-               stats=gen_stats, barr=gen_barr, hist=gen_hist, grid=gen_grid, flux=gen_flux, side=gen_side)
+               stats=gen_stats, barr=gen_barr, hist=gen_hist, grid=gen_grid, flux=gen_flux, side=gen_side, stats_wide=gen_stats_wide)
     for w in which:
         fns[w]()

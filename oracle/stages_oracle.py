@@ -110,3 +110,68 @@ def atm_muon_weights(weights, cr_rw_array, delta_gamma_mu, atm_muon_scale):
     """pisa/stages/background/atm_muons.py:95-101"""
     weight_mod = 1 + (delta_gamma_mu * cr_rw_array)
     return weights * np.clip(weight_mod * atm_muon_scale, a_min=0, a_max=np.inf)
+
+
+# ---- the metrics beyond llh / poisson_llh / chi2 / mod_chi2 (pisa/utils/stats.py), per bin -------------------------
+SMALL_POS = 1e-10
+
+
+def _poisson_gamma(data, sum_w, sum_w2, a, b=0):
+    """pisa/utils/likelihood_functions.py:22-63"""
+    from scipy import special
+
+    llh = np.ones(data.shape) * -np.inf
+    bad = np.logical_or(sum_w <= 0, sum_w2 < 0)
+    llh[np.logical_and(data == 0, bad)] = 0
+    good = ~bad
+    pois = np.logical_and(sum_w2 == 0, good)
+    llh[pois] = data[pois] * np.log(sum_w[pois]) - sum_w[pois] - special.loggamma(data[pois] + 1)
+    reg = np.logical_and(good, ~pois)
+    alpha = sum_w[reg] ** 2.0 / sum_w2[reg] + a
+    beta = sum_w[reg] / sum_w2[reg] + b
+    k = data[reg]
+    llh[reg] = (alpha * np.log(beta) + special.loggamma(k + alpha).real - special.loggamma(k + 1.0).real
+                - (k + alpha) * np.log1p(beta) - special.loggamma(alpha).real)
+    return llh
+
+
+def _conv_poisson(k, l, s, nsigma=3, steps=50):
+    """pisa/utils/stats.py:479-527"""
+    from scipy.special import gammaln
+
+    l, k, s = max(SMALL_POS, l), max(SMALL_POS, k), max(SMALL_POS, s)
+    st = 2 * (steps + 1)
+    conv_x = np.linspace(-nsigma * s, +nsigma * s, st)[:-1] + nsigma * s / (st - 1.0)
+    conv_y = -np.log(s) - 0.5 * np.log(2 * np.pi) - conv_x ** 2 / (2 * s ** 2)
+    f_x = conv_x + l
+    idx = np.argmax(f_x > 0)
+    f_y = np.nan_to_num(k * np.log(f_x[idx:]) - f_x[idx:] - gammaln(k + 1))
+    return np.exp(conv_y[idx:] + f_y).sum() / np.sum(np.exp(conv_y))
+
+
+def _norm_conv_poisson(k, l, s):
+    """pisa/utils/stats.py:529-556"""
+    from scipy.special import gammaln
+
+    with np.errstate(all="ignore"):
+        n1 = np.exp(l * np.log(l) - l - gammaln(l + 1))
+    return _conv_poisson(k, l, s) * n1 / _conv_poisson(l, l, s)
+
+
+def metric_wide(kind, actual, expected, sigma):
+    """per-bin values of stats.correct_chi2 (:697-730), signed_sqrt_mod_chi2 (:762-786), mcllh_mean (:328-382),
+    mcllh_eff (:384-438), conv_llh (:558-596)"""
+    actual, expected, sigma = (np.array(x, dtype=np.float64).ravel() for x in (actual, expected, sigma))
+    if kind == "conv_llh":
+        out = []
+        for k, l, s in zip(actual, expected, sigma):
+            with np.errstate(all="ignore"):
+                out.append(np.log(max(SMALL_POS, _norm_conv_poisson(k, l, s))) - np.log(max(SMALL_POS, _norm_conv_poisson(k, k, s))))
+        return np.array(out)
+    expected = np.clip(expected, SMALL_POS, np.inf)
+    if kind == "correct_chi2":
+        tv = sigma ** 2 + expected
+        return (actual - expected) ** 2 / tv + np.log(tv)
+    if kind == "signed_sqrt_mod_chi2":
+        return (actual - expected) / np.sqrt(sigma ** 2 + expected)
+    return _poisson_gamma(actual, expected, sigma ** 2, a=1 if kind == "mcllh_eff" else 0)

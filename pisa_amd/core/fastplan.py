@@ -135,7 +135,7 @@ class DeviceMapBlock:
         """metric of the TOTAL template against `data_hist` on the device, or None if this block
         cannot provide it (partial sum, already fetched, no longer the engine's evaluation).
         `extra` = (hist, variances or None) host arrays added to the template after the containers."""
-        if mask != self.full or not self._live or self._host is not None:
+        if mask != self.full or not self._live or self._host is not None or kind not in K.METRIC_KIND:
             return None
         if kind == "mod_chi2" and not (self.with_errors if with_errors is None else with_errors):
             return None

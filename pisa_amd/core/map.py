@@ -20,7 +20,9 @@ from pisa_amd.core.binning import MultiDimBinning, OneDimBinning, _round_sig
 
 __all__ = ["Map", "MapSet", "ALL_METRICS", "rebin"]
 
-ALL_METRICS = ("llh", "poisson_llh", "chi2", "mod_chi2")
+# stats.py:43-51 without barlow_llh, generalized_poisson_llh and weighted_chi2 (not built)
+ALL_METRICS = ("llh", "poisson_llh", "conv_llh", "mcllh_mean", "mcllh_eff", "chi2", "mod_chi2", "correct_chi2",
+               "signed_sqrt_mod_chi2")
 FLUCTUATE_METHODS = ("poisson", "scaled_poisson", "gauss", "gauss+poisson")
 _ALLCLOSE = dict(rtol=1e-12, atol=np.finfo(FTYPE).eps, equal_nan=True)
 
@@ -557,7 +559,10 @@ class Map:
             raise ValueError("Shape mismatch: actual %s, expected %s" % (self._hist.shape, exp_hist.shape))
         a = K.to_device(self._hist.ravel())
         e = K.to_device(exp_hist.ravel())
-        s2 = K.to_device(exp_var.ravel()) if (exp_var is not None and metric == "mod_chi2") else None
+        s2 = None
+        if metric in K.VARIANCE_METRICS and (exp_var is not None or metric != "mod_chi2"):
+            # (a map without errors has sigma = 0, as `unp.std_devs` of plain numbers)
+            s2 = K.to_device(np.zeros(exp_hist.size, dtype=FTYPE) if exp_var is None else exp_var.ravel())
         total, per_bin = K.metric(metric, a, e, s2, per_bin=True)
         if binned:
             return per_bin.cpu().numpy().reshape(self._hist.shape)
@@ -577,6 +582,21 @@ class Map:
 
     def mod_chi2(self, expected_values, binned=False):
         return self.metric(expected_values, "mod_chi2", binned)
+
+    def correct_chi2(self, expected_values, binned=False):
+        return self.metric(expected_values, "correct_chi2", binned)
+
+    def signed_sqrt_mod_chi2(self, expected_values, binned=False):
+        return self.metric(expected_values, "signed_sqrt_mod_chi2", binned)
+
+    def mcllh_mean(self, expected_values, binned=False):
+        return self.metric(expected_values, "mcllh_mean", binned)
+
+    def mcllh_eff(self, expected_values, binned=False):
+        return self.metric(expected_values, "mcllh_eff", binned)
+
+    def conv_llh(self, expected_values, binned=False):
+        return self.metric(expected_values, "conv_llh", binned)
 
     def __repr__(self):
         if self._lazy is not None:

@@ -9,6 +9,78 @@
 
 namespace pisa {
 
+// The metrics beyond the four of the fused tail (hist.hip), per bin, from the raw expectation and its variance:
+//   correct_chi2          (k - l)^2 / (s2 + l) + ln(s2 + l)                        stats.py:697-730
+//   signed_sqrt_mod_chi2  (k - l) / sqrt(s2 + l)                                   stats.py:762-786
+//   mcllh_mean / _eff     Poisson-gamma mixture with a = 0 / 1, b = 0              stats.py:328-438,
+//                                                                                   likelihood_functions.py:22-63
+//   conv_llh              Poisson smeared with a normal of width sigma, 101 steps   stats.py:440-596
+__device__ __forceinline__ double log_poisson_(double k, double l) { return k * log(l) - l - lgamma(k + 1); }
+
+__device__ double conv_poisson_(double k, double l, double s) {
+    l = l > SMALL_POS ? l : SMALL_POS;      // Python's max(SMALL_POS, x): NaN -> SMALL_POS
+    k = k > SMALL_POS ? k : SMALL_POS;
+    s = s > SMALL_POS ? s : SMALL_POS;
+    const int st = 2 * (50 + 1);
+    const double start = -3 * s, stop = 3 * s;
+    const double step = (stop - start) / (st - 1);
+    const double shift = 3 * s / (st - 1.);
+    const double log_s = log(s), half_log_2pi = 0.5 * log(2 * 3.141592653589793);
+    double conv = 0.0, norm = 0.0;
+    bool open_ = false;
+    for (int j = 0; j < st - 1; j++) {
+        const double x = (j * step + start) + shift;
+        const double cy = -log_s - half_log_2pi - x * x / (2 * (s * s));
+        norm += exp(cy);
+        const double fx = x + l;
+        open_ = open_ || fx > 0;            // idx = argmax(f_x > 0); f_x ascends
+        if (open_) {
+            double fy = log_poisson_(k, fx);
+            if (fy != fy) fy = 0.0;         // np.nan_to_num
+            conv += exp(cy + fy);
+        }
+    }
+    return conv / norm;
+}
+
+__device__ double norm_conv_poisson_(double k, double l, double s) {
+    const double cp = conv_poisson_(k, l, s);
+    const double n1 = exp(log_poisson_(l, l));
+    const double n2 = conv_poisson_(l, l, s);
+    return cp * n1 / n2;
+}
+
+__device__ double metric_bin_wide(int kind, double k, double lam, double s2) {
+    if (kind == PISA_HIP_METRIC_CONV_LLH) {
+        const double s = sqrt(s2);
+        const double a = norm_conv_poisson_(k, lam, s), b = norm_conv_poisson_(k, k, s);
+        return log(a > SMALL_POS ? a : SMALL_POS) - log(b > SMALL_POS ? b : SMALL_POS);
+    }
+    if (lam < SMALL_POS) lam = SMALL_POS;
+    if (kind == PISA_HIP_METRIC_CORRECT_CHI2) {
+        const double tv = s2 + lam, d = k - lam;
+        return (d * d) / tv + log(tv);
+    }
+    if (kind == PISA_HIP_METRIC_SIGNED_SQRT_MOD_CHI2) return (k - lam) / sqrt(s2 + lam);
+    // poisson_gamma(data=k, sum_w=lam, sum_w2=s2, a, b=0)
+    const double a = kind == PISA_HIP_METRIC_MCLLH_EFF ? 1.0 : 0.0;
+    if (lam <= 0 || s2 < 0) return k == 0 ? 0.0 : -HUGE_VAL;
+    if (s2 == 0) return k * log(lam) - lam - lgamma(k + 1);
+    const double alpha = (lam * lam) / s2 + a;
+    const double beta = lam / s2 + 0.0;
+    return alpha * log(beta) + lgamma(k + alpha) - lgamma(k + 1.0) - (k + alpha) * log1p(beta) - lgamma(alpha);
+}
+
+__device__ __forceinline__ double metric_any(int kind, double k, double lam, double s2) {
+    return kind <= PISA_HIP_METRIC_MOD_CHI2 ? metric_bin(kind, k, lam, s2) : metric_bin_wide(kind, k, lam, s2);
+}
+
+// which kinds refuse negative counts / expectations (stats.py:231-240 and the like); the chi2 family beyond
+// Pearson's and conv_llh only clip
+__device__ __forceinline__ bool kind_checks_sign(int kind) {
+    return kind <= PISA_HIP_METRIC_MOD_CHI2 || kind == PISA_HIP_METRIC_MCLLH_MEAN || kind == PISA_HIP_METRIC_MCLLH_EFF;
+}
+
 __global__ void __launch_bounds__(256)
 metric_kernel(int kind, const double *__restrict__ actual, const double *__restrict__ expected,
               const double *__restrict__ sigma2, int n_maps, int64_t n_bins,
@@ -32,12 +104,12 @@ metric_kernel(int kind, const double *__restrict__ actual, const double *__restr
         if (!finite) {
             v = __longlong_as_double(0x7ff8000000000000LL);
         } else {
-            if (k < 0.0 || lam < 0.0) atomicOr(&s_flag[0], 1);
+            if ((k < 0.0 || lam < 0.0) && kind_checks_sign(kind)) atomicOr(&s_flag[0], 1);
             if (kind == PISA_HIP_METRIC_CHI2) {
                 double lc = lam < SMALL_POS ? SMALL_POS : lam;
                 if (!(fabs(k - lc) < 5 * FTYPE_PREC)) atomicOr(&s_flag[1], 1);
             }
-            v = metric_bin(kind, k, lam, s2);
+            v = metric_any(kind, k, lam, s2);
         }
         if (per_bin) per_bin[b] = v;
         if (v == v) acc += v;  // np.nansum
@@ -85,12 +157,12 @@ metric_partial_kernel(int kind, const double *__restrict__ actual, const double 
         if (!finite) {
             v = __longlong_as_double(0x7ff8000000000000LL);
         } else {
-            if (k < 0.0 || lam < 0.0) atomicOr(&flags[0], 1);
+            if ((k < 0.0 || lam < 0.0) && kind_checks_sign(kind)) atomicOr(&flags[0], 1);
             if (kind == PISA_HIP_METRIC_CHI2) {
                 double lc = lam < SMALL_POS ? SMALL_POS : lam;
                 if (!(fabs(k - lc) < 5 * FTYPE_PREC)) atomicOr(&flags[1], 1);
             }
-            v = metric_bin(kind, k, lam, s2);
+            v = metric_any(kind, k, lam, s2);
         }
         if (per_bin) per_bin[b] = v;
         if (v == v) acc = v;  // np.nansum
@@ -364,7 +436,7 @@ using namespace pisa;
 PISA_API int pisa_hip_metric(int32_t kind, const double *d_actual, const double *d_expected,
                              const double *d_sigma2, int32_t n_maps, int64_t n_bins,
                              double *d_per_bin, double *d_total, int32_t *d_status, void *stream) {
-    if (kind < 0 || kind > 3 || n_maps < 1 || n_bins < 0 || !d_total) return PISA_HIP_ERR_INVALID;
+    if (kind < 0 || kind > PISA_HIP_METRIC_CONV_LLH || n_maps < 1 || n_bins < 0 || !d_total) return PISA_HIP_ERR_INVALID;
     if (n_bins > 0 && (!d_actual || !d_expected)) return PISA_HIP_ERR_INVALID;
     if (n_bins > METRIC_ONE_WG_MAX) {
         const int64_t n_part = (n_bins + 255) / 256;

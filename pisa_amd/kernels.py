@@ -465,7 +465,10 @@ class KdeEstimator:
 
 
 # --------------------------------------------------------------- metric
-METRIC_KIND = {"llh": 0, "poisson_llh": 1, "chi2": 2, "mod_chi2": 3}
+METRIC_KIND = {"llh": 0, "poisson_llh": 1, "chi2": 2, "mod_chi2": 3}          # the fused tails of an evaluation
+# `metric()` on maps takes these too (PISA_HIP_METRIC_* of include/pisa_hip.h)
+MAP_METRIC_KIND = dict(METRIC_KIND, correct_chi2=4, signed_sqrt_mod_chi2=5, mcllh_mean=6, mcllh_eff=7, conv_llh=8)
+VARIANCE_METRICS = ("mod_chi2", "correct_chi2", "signed_sqrt_mod_chi2", "mcllh_mean", "mcllh_eff", "conv_llh")
 
 
 class KdeLatticeBatch:
@@ -570,7 +573,7 @@ def metric(kind, actual, expected, sigma2=None, per_bin=False, total_out=None, s
     if own_status:
         status = torch.zeros(1, dtype=torch.int32, device=dev)
     _lib.check(lib.pisa_hip_metric(
-        METRIC_KIND[kind], _ptr(actual), _ptr(expected), _ptr(sigma2), n_maps, n_bins, _ptr(pb),
+        MAP_METRIC_KIND[kind], _ptr(actual), _ptr(expected), _ptr(sigma2), n_maps, n_bins, _ptr(pb),
         total_out.data_ptr() if not total_out.is_cuda and total_out.is_pinned() else _ptr(total_out),
         _ptr(status), _stream()))
     if own_status:

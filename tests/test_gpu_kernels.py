@@ -455,7 +455,7 @@ def test_metric_golden_and_errors(K):
 
     shape = (2, -1) if g["actual"].size % 2 == 0 else (1, -1)
     a2, e2 = g["actual"].reshape(shape), g["expected"].reshape(shape)
-    for name in stats.ALL_METRICS:
+    for name in ("llh", "poisson_llh", "chi2", "mod_chi2"):      # (the others: test_wide_metrics_... below)
         got = getattr(stats, name)(a2, e2)
         assert got.shape == a2.shape
         np.testing.assert_allclose(got, g[name].reshape(shape), rtol=1e-12, equal_nan=True)
@@ -731,3 +731,75 @@ def test_apply_osc_weights_reads_strided_columns_in_place(K):
     K.apply_osc_weights(flux, t2[:, 1], t9[:, 3], a)
     K.apply_osc_weights(flux, t2[:, 1].contiguous(), t9[:, 3].contiguous(), b)
     assert torch.equal(a, b)
+
+
+def test_wide_metrics_reference_vectors_and_restatement():
+    """`pisa_hip_metric` kinds 4-8 (correct_chi2, signed_sqrt_mod_chi2, mcllh_mean, mcllh_eff, conv_llh) against the
+    reference's own values (tests/golden/stats_wide_ref.npz), against the restatement on larger seeded maps, through
+    `Map.metric` / `utils.stats`, and their sign rules (stats.py:359-368: the mcllh pair refuses negative inputs, the
+    chi2 family and conv_llh only clip)"""
+    import os
+
+    from oracle import stages_oracle as so
+    from pisa_amd import kernels as K
+    from pisa_amd.core.binning import MultiDimBinning, OneDimBinning
+    from pisa_amd.core.map import Map
+    from pisa_amd.utils import stats
+
+    W = np.load(os.path.join(os.path.dirname(__file__), "golden", "stats_wide_ref.npz"))
+    kinds = ("mcllh_mean", "mcllh_eff", "correct_chi2", "signed_sqrt_mod_chi2", "conv_llh")
+
+    def dev(a):
+        return K.to_device(np.ascontiguousarray(a, dtype=np.float64))
+
+    def scale_of(kind, k, lam, s):
+        """size of the terms a value is the difference of (gamma functions of ~lam^2 / sigma^2 cancel in the mixture)"""
+        if kind.startswith("mcllh"):
+            with np.errstate(all="ignore"):
+                alpha = np.where(s > 0, np.maximum(lam, 1e-10) ** 2 / np.maximum(s, 1e-300) ** 2, 0.0)
+            return 1.0 + (k + alpha) * (1.0 + np.abs(np.log(np.maximum(k + alpha, 1e-300))))
+        return 1.0
+
+    for kind in kinds:
+        total, per_bin = K.metric(kind, dev(W["actual"]), dev(W["expected"]), dev(W["sigma"] ** 2), per_bin=True)
+        got = per_bin.cpu().numpy()
+        tol = 1e-12 * scale_of(kind, W["actual"], W["expected"], W["sigma"])
+        assert np.all(np.abs(got - W[kind]) <= tol + 1e-12 * np.abs(W[kind])), (kind, np.abs(got - W[kind]).max())
+        np.testing.assert_allclose(float(total.item()), np.nansum(got), rtol=1e-13)
+    rs = np.random.RandomState(3)
+    n = 6000                                                      # the two-stage reduction (> 4096 bins)
+    lam = rs.rand(n) * 40 + 0.01
+    s = np.sqrt(lam) * rs.rand(n)
+    s[:50] = 0.0
+    k = rs.poisson(lam).astype(np.float64)
+    for kind in kinds:
+        total, per_bin = K.metric(kind, dev(k), dev(lam), dev(s ** 2), per_bin=True)
+        want = so.metric_wide(kind, k, lam, s)
+        got = per_bin.cpu().numpy()
+        tol = 1e-12 * scale_of(kind, k, lam, s)
+        assert np.all(np.abs(got - want) <= tol + 1e-11 * np.abs(want)), (kind, np.abs(got - want).max())
+        assert abs(float(total.item()) - np.nansum(got)) <= 1e-13 * np.abs(got).sum()     # the reduction itself
+    # Map / stats front ends
+    b = MultiDimBinning([OneDimBinning(name="x", num_bins=16, domain=[0, 1]), OneDimBinning(name="y", num_bins=10, domain=[0, 1])])
+    data = Map("data", k[:160].reshape(16, 10), b)
+    templ = Map("t", lam[:160].reshape(16, 10), b, error_hist=s[:160].reshape(16, 10))
+    for kind in kinds:
+        want = so.metric_wide(kind, k[:160], lam[:160], s[:160])
+        binned = getattr(data, kind)(templ, binned=True)
+        assert binned.shape == (16, 10)
+        np.testing.assert_allclose(binned.ravel(), want, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(data.metric_total(templ, kind), np.nansum(want), rtol=1e-10)
+        np.testing.assert_allclose(getattr(stats, kind)(k[:160], lam[:160], sigma=s[:160]), want, rtol=1e-9, atol=1e-9)
+        # plain numbers carry no errors: sigma = 0
+        np.testing.assert_allclose(getattr(stats, kind)(k[:160], lam[:160]), so.metric_wide(kind, k[:160], lam[:160], np.zeros(160)),
+                                   rtol=1e-9, atol=1e-9)
+    neg = k[:160].copy()
+    neg[3] = -1.0
+    for kind in ("mcllh_mean", "mcllh_eff"):
+        with pytest.raises(ValueError):
+            getattr(stats, kind)(neg, lam[:160], sigma=s[:160])
+    for kind in ("correct_chi2", "signed_sqrt_mod_chi2"):
+        np.testing.assert_allclose(getattr(stats, kind)(neg, lam[:160], sigma=s[:160]), so.metric_wide(kind, neg, lam[:160], s[:160]),
+                                   rtol=1e-12)
+    with pytest.raises(ValueError):
+        data.metric(templ, "barlow_llh")

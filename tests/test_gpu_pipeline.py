@@ -1036,3 +1036,32 @@ def test_selection_switch_alone_is_seen_by_the_plan(oracle):
     pipe.select_params("nh")
     for m in pipe.get_outputs():
         np.testing.assert_allclose(m.hist, ref_nh[m.name], rtol=1e-11, atol=1e-300, err_msg=m.name)
+
+
+@pytest.mark.parametrize("metric", ["mcllh_eff", "correct_chi2", "conv_llh"])
+def test_fit_with_a_metric_beyond_the_fused_tail(metric):
+    """a metric the one-kernel tail does not carry (stats.py:384-438, 697-730, 558-596): the minimiser callable goes
+    through the maps and `pisa_hip_metric`; the value at the fit's end is the restatement's on those maps, the fit
+    improves on its start, and the parameters move towards the injected truth"""
+    from oracle import stages_oracle as so
+    from pisa_amd.analysis.analysis import Analysis
+    from pisa_amd.core.distribution_maker import DistributionMaker
+    from pisa_amd.core.units import ureg
+
+    dm = DistributionMaker("settings/pipeline/example_hip.cfg")
+    for name in dm.params.free.names:
+        if name not in ("theta23", "deltam31"):
+            dm.params.fix(name)
+    dm.params.theta23.value = 46.5 * ureg.degree
+    dm.params.deltam31.value = 2.6e-3 * ureg.eV ** 2
+    data = dm.get_outputs(return_sum=True)
+    dm.params.reset_free()
+    start = data[0].metric_total(dm.get_outputs(return_sum=True)[0], metric)
+    res = Analysis().fit_hypo(data, dm, metric)
+    templ = dm.get_outputs(return_sum=True)[0]
+    want = np.nansum(so.metric_wide(metric, data[0].hist, templ.hist, templ.std_devs))
+    prior = dm.params.priors_penalty(metric=metric)
+    np.testing.assert_allclose(res.metric_val, want + prior, rtol=1e-9, atol=1e-9)
+    better = res.metric_val > start if metric.endswith("llh") or metric.startswith("mcllh") else res.metric_val < start
+    assert better, (start, res.metric_val)
+    assert abs(res.params.theta23.value.m_as("deg") - 46.5) < abs(42.3 - 46.5)

@@ -97,3 +97,16 @@ def test_linear_interpolant_of_atm_muons_is_numpy_interp():
     assert np.array_equal(interp1d(xk, yk, kind="linear")(x), np.interp(x, xk, yk))
     with pytest.raises(ValueError):
         interp1d(xk, yk, kind="linear")(1.5)
+
+
+def test_wide_metric_restatements():
+    """oracle/stages_oracle.metric_wide against the reference's stats functions (oracle/gen_golden.py stats_wide)"""
+    W = np.load(os.path.join(os.path.dirname(__file__), "golden", "stats_wide_ref.npz"))
+    for kind in ("mcllh_mean", "mcllh_eff", "correct_chi2", "signed_sqrt_mod_chi2", "conv_llh"):
+        got = so.metric_wide(kind, W["actual"], W["expected"], W["sigma"])
+        np.testing.assert_allclose(got, W[kind], rtol=1e-13, atol=1e-13, equal_nan=True, err_msg=kind)
+    # the Poisson limit of the mixture where sigma = 0
+    from scipy.special import gammaln
+
+    k, lam = W["actual"][6:12], W["expected"][6:12]
+    np.testing.assert_allclose(W["mcllh_eff"][6:12], k * np.log(lam) - lam - gammaln(k + 1), rtol=1e-14)
