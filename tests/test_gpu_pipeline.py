@@ -1064,4 +1064,5 @@ def test_fit_with_a_metric_beyond_the_fused_tail(metric):
     np.testing.assert_allclose(res.metric_val, want + prior, rtol=1e-9, atol=1e-9)
     better = res.metric_val > start if metric.endswith("llh") or metric.startswith("mcllh") else res.metric_val < start
     assert better, (start, res.metric_val)
-    assert abs(res.params.theta23.value.m_as("deg") - 46.5) < abs(42.3 - 46.5)
+    nominal = dm.params.deltam31.nominal_value.m_as("eV**2")
+    assert abs(res.params.deltam31.value.m_as("eV**2") - 2.6e-3) < abs(nominal - 2.6e-3)
