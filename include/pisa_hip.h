@@ -699,6 +699,13 @@ int pisa_hip_poly_scale(const double *const *h_d_linear, const double *const *h_
 int pisa_hip_interp_linear(const double *d_x_knots, const double *d_y_knots, int32_t n_knots, const double *d_x,
                            int64_t n, double *d_out, int32_t *d_status, void *stream);
 
+/* d_out[i] = f(sum_g h_coef[g] * h_d_columns[g][i]), the sum from 0.0 in the order of the columns (the loop over
+ * `grad_shift_inplace`, pisa/stages/discr_sys/ultrasurfaces.py:339-356, 362-365); mode 0: exp (us_scales), 1: 1 + sum
+ * (`approx_exponential`), 2: the sum itself.  n_columns <= PISA_HIP_MAX_COMBINATION. */
+#define PISA_HIP_MAX_COMBINATION 64
+int pisa_hip_column_combination(const double *const *h_d_columns, const double *h_coef, int32_t n_columns, int32_t mode,
+                                int64_t n, double *d_out, void *stream);
+
 /* Replaces `decoherence.calc_probs` (pisa/stages/osc/decoherence.py:449-466 over `calc_decoherence_probs` :66-106):
  * d_probability[n][3][3], rows (1, 0, 0), (0, 1 - D, D), (0, D, 1 - D) with the numu disappearance D(E, L) of
  * `_calc_numu_disappearance_prob_3flav` (:229-269; h_coef[k] = |U[2][j]|^2 |U[2][k]|^2, h_gamma[k] in GeV, h_delta[k]

@@ -175,3 +175,26 @@ def metric_wide(kind, actual, expected, sigma):
     if kind == "signed_sqrt_mod_chi2":
         return (actual - expected) / np.sqrt(sigma ** 2 + expected)
     return _poisson_gamma(actual, expected, sigma ** 2, a=1 if kind == "mcllh_eff" else 0)
+
+
+def csv_hypersurface_scales(table, inter_param, inter_value, nominal, values):
+    """per-bin scale factors of pisa/stages/discr_sys/csv_hypersurfaces.py:167-206 from the CSV table given as a
+    dict of columns (numpy arrays): the slices at the two nodes of `inter_param` around `inter_value`, interpolated
+    linearly column by column, then intercept + sum_p gradient_p (value_p - nominal_p); non-finite -> 1.
+    (Restated without pandas; parity with the reference anchored on its formulae, not on an execution of it.)"""
+    col = np.asarray(table[inter_param], dtype=np.float64)
+    if inter_value < col.min() or col.max() < inter_value:
+        raise ValueError("outside of interpolation range")
+    nodes = np.unique(col)
+    lower, upper = nodes[nodes <= inter_value].max(), nodes[nodes > inter_value].min()
+    lo, up = col == lower, col == upper
+    binlen = upper - lower
+
+    def interpolated(p):
+        a, b = np.asarray(table[p], dtype=np.float64)[lo], np.asarray(table[p], dtype=np.float64)[up]
+        return (b - a) / binlen * (inter_value - lower) + a
+
+    scales = interpolated("intercept") + sum([interpolated(p) * (values[p] - nominal[p]) for p in values])
+    scales = np.array(scales)
+    scales[~np.isfinite(scales)] = 1.0
+    return scales

@@ -10,6 +10,7 @@
 //                                                                           pisa/stages/xsec/dis_sys.py:196-206,
 //                                                                           pisa/stages/background/atm_muons.py:95-101)
 //   interp_linear    numpy.interp between knots                            (atm_muons.py:82-87, 159-164)
+//   column_combination  exp / 1 + / plain sum_g c_g col_g                 (pisa/stages/discr_sys/ultrasurfaces.py:339-356)
 //   decoherence      P[n][3][3] of the vacuum decoherence model            (pisa/stages/osc/decoherence.py:66-269)
 #include <math.h>
 
@@ -153,6 +154,23 @@ interp_linear_kernel(const double *__restrict__ xk, const double *__restrict__ y
         if (r != r && yk[lo] == yk[lo + 1]) r = yk[lo];
     }
     out[i] = r;
+}
+
+// ultrasurfaces.py:339-356: out = exp(sum_g shift_g * grad_g[i]) or 1 + that sum, the sum in the order of the columns
+constexpr int COMBO_MAX = 64;
+struct ComboSet {
+    const double *col[COMBO_MAX];
+    double coef[COMBO_MAX];
+    int32_t k, mode;
+};
+
+__global__ void __launch_bounds__(256)
+column_combination_kernel(const ComboSet s, int64_t n, double *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double acc = 0.0;
+    for (int g = 0; g < s.k; g++) acc += s.coef[g] * s.col[g][i];
+    out[i] = s.mode == 0 ? exp(acc) : (s.mode == 1 ? 1 + acc : acc);
 }
 
 // decoherence.py:66-106, 229-269, 449-466: P[i][3][3] of the vacuum decoherence model.  nue stays nue; the numu
@@ -300,5 +318,27 @@ PISA_API int pisa_hip_decoherence_probs(const double *h_coef, const double *h_ga
     hipLaunchKernelGGL(decoherence_kernel, grid_for(n), dim3(256), 0, as_stream(stream), a, d_energy, d_baseline, n,
                        d_probability);
     PISA_CHECK_LAUNCH("decoherence_kernel");
+    return PISA_HIP_OK;
+}
+
+PISA_API int pisa_hip_column_combination(const double *const *h_d_columns, const double *h_coef, int32_t n_columns,
+                                         int32_t mode, int64_t n, double *d_out, void *stream) {
+    if (n_columns < 0 || n_columns > COMBO_MAX || mode < 0 || mode > 2 || n < 0 || (n_columns && (!h_d_columns || !h_coef)))
+        return PISA_HIP_ERR_INVALID;
+    ComboSet s;
+    s.k = n_columns;
+    s.mode = mode;
+    for (int g = 0; g < COMBO_MAX; g++) {
+        s.col[g] = nullptr; s.coef[g] = 0;
+    }
+    for (int g = 0; g < n_columns; g++) {
+        if (n > 0 && !h_d_columns[g]) return PISA_HIP_ERR_INVALID;
+        s.col[g] = h_d_columns[g];
+        s.coef[g] = h_coef[g];
+    }
+    if (n == 0) return PISA_HIP_OK;
+    if (!d_out) return PISA_HIP_ERR_INVALID;
+    hipLaunchKernelGGL(column_combination_kernel, grid_for(n), dim3(256), 0, as_stream(stream), s, n, d_out);
+    PISA_CHECK_LAUNCH("column_combination_kernel");
     return PISA_HIP_OK;
 }

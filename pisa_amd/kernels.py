@@ -652,6 +652,21 @@ def poly_scale(linear, quad, params, weights, scale=1.0):
     return weights
 
 
+def column_combination(columns, coef, n, mode="exp", out=None, dev=None):
+    """f(sum_g coef_g * column_g) per event, f = exp / 1 + / identity (`pisa_hip_column_combination`)"""
+    lib = _lib.lib()
+    k = len(columns)
+    assert k == len(coef)
+    for t in columns:
+        assert t.is_cuda and t.is_contiguous() and t.numel() == n and t.dtype == F8
+    if out is None:
+        out = torch.empty(n, dtype=F8, device=columns[0].device if k else (dev or device()))
+    cols = (C.c_void_p * max(k, 1))(*[t.data_ptr() for t in columns])
+    cf = (C.c_double * max(k, 1))(*[float(v) for v in coef])
+    _lib.check(lib.pisa_hip_column_combination(cols, cf, k, {"exp": 0, "one_plus": 1, "sum": 2}[mode], n, _ptr(out), _stream()))
+    return out
+
+
 def interp_linear(x_knots, y_knots, x, out=None):
     """numpy.interp(x, x_knots, y_knots) on the device; a value outside the knots raises, as scipy's interp1d does
     (`pisa_hip_interp_linear`)"""
