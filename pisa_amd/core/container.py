@@ -351,7 +351,7 @@ class Container:
         if self._lazy:
             self._lazy.pop(key, None)
         v = self.validity[key]
-        if len(v) > 1:
+        if len(v) > 1 or self._rep_hash not in v:      # (a single entry that IS the current one: nothing to do)
             for rep in v:
                 v[rep] = False
         v[self._rep_hash] = True

@@ -570,3 +570,90 @@ def test_ultrasurfaces_stage_and_column_combination():
                 os.remove(sub)
     finally:
         os.remove(path)
+
+
+def test_snowstorm_hist_stage():
+    """gradients from the split histograms (Gaussian and uniform simulated distributions), the per-bin scale, its
+    clipping, and the tolerance rule for re-making the gradients (snowstorm_hist.py:173-228).  The stage stands behind
+    utils.hist, which wrote the BINNED weights: read per event they are the looked-up bin contents (the Container's
+    rule, container.py:636-645, 742-767), as in the reference."""
+    from pisa_amd.core.binning import MultiDimBinning, OneDimBinning
+    from pisa_amd.core.container import Container, ContainerSet
+    from pisa_amd.core.param import Param, ParamSet
+    from pisa_amd.core.units import ureg
+    from pisa_amd.stages.cont_sys.snowstorm_hist import snowstorm_hist
+
+    b = MultiDimBinning([OneDimBinning(name="reco_energy", num_bins=6, domain=[1, 100], is_log=True),
+                         OneDimBinning(name="pid", bin_edges=[0.0, 0.3, 0.8, 1.0])], name="out")
+    edges = [np.logspace(0, 2, 7), np.array([0.0, 0.3, 0.8, 1.0])]
+    rs = np.random.RandomState(12)
+    cs = []
+    for name, n in (("numu_cc", 20000), ("nue_nc", 7000)):
+        c = Container(name)
+        c["reco_energy"] = 10 ** (rs.rand(n) * 2.2 - 0.1)
+        c["pid"] = rs.rand(n) * 1.05
+        c["hole_ice"] = rs.uniform(-1.0, 2.0, n)
+        c["dom_eff"] = 1.0 + 0.1 * rs.randn(n) + 0.05 * (np.array(c["pid"]) - 0.5)      # more high values at high pid
+        c["weights"] = rs.rand(n) + 0.5
+        cs.append(c)
+    data = ContainerSet("data", cs, representation="events")
+    data["output_binning"] = b
+    kw = dict(prior=None, range=None, is_fixed=False)
+    st = snowstorm_hist(systematics=["dom_eff", "hole_ice"], simulation_dists=["gauss", "uniform"],
+                        simulation_dists_params=[(1.0, 0.1), (-1.0, 2.0)], additional_params=["deltam31"], tolerances=[1e-4],
+                        data=data, calc_mode="events",
+                        params=ParamSet([Param(name="dom_eff", value=1.1, **kw), Param(name="hole_ice", value=0.2, **kw),
+                                         Param(name="deltam31", value=3e-3 * ureg.eV ** 2, **kw)]))
+    st.setup()
+    assert st.central_values == [1.0, 0.5]
+    ev = {c.name: {k: np.array(c[k]) for k in ("reco_energy", "pid", "dom_eff", "hole_ice", "weights")} for c in cs}
+    hist0, index = {}, {}
+    for c in cs:                                # what utils.hist leaves in the binned representation
+        e = ev[c.name]
+        hist0[c.name] = np.histogramdd([e["reco_energy"], e["pid"]], bins=edges, weights=e["weights"])[0].ravel()
+        i0, i1 = np.digitize(e["reco_energy"], edges[0]) - 1, np.digitize(e["pid"], edges[1]) - 1
+        index[c.name] = np.where((i0 >= 0) & (i0 < 6) & (i1 >= 0) & (i1 < 3), i0 * 3 + i1, -1)
+
+    def binned_weights_written():
+        for c in cs:
+            c.representation = b
+            c["weights"] = hist0[c.name].copy()
+
+    def want_scale(name, d_eff, h_ice, mirrored=False):
+        e, idx = ev[name], index[name]
+        per_event = np.where(idx >= 0, hist0[name][np.clip(idx, 0, 17)], 0.0)
+        scale, grads = np.ones(18), {}
+        for col, central, factor, value in (("dom_eff", 1.0, 1 / 0.1 * np.sqrt(np.pi / 2), d_eff), ("hole_ice", 0.5, 1 / 1.5, h_ice)):
+            x = 2.0 - e[col] if (mirrored and col == "dom_eff") else e[col]
+            hs = [np.bincount(idx[(idx >= 0) & sel], weights=per_event[(idx >= 0) & sel], minlength=18) for sel in (x > central, x < central)]
+            with np.errstate(all="ignore"):
+                grads[col] = np.nan_to_num(2 * (hs[0] - hs[1]) * factor / (hs[0] + hs[1]))
+            scale *= 1 + (value - central) * grads[col]
+        return np.clip(scale, 0, np.inf), grads
+
+    binned_weights_written()
+    st.run()
+    for c in cs:
+        want, grads = want_scale(c.name, 1.1, 0.2)
+        np.testing.assert_allclose(st.grads[c.name]["dom_eff"], grads["dom_eff"], rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(c["syst_scale"], want, rtol=1e-11, atol=1e-13)
+        assert np.array_equal(c["weights"], hist0[c.name] * np.array(c["syst_scale"]))
+    g = st.grads["numu_cc"]["dom_eff"].reshape(6, 3)
+    assert g[:, 2].mean() > g[:, 0].mean() + 0.1                               # the injected trend shows
+    # a large offset drives bins to the clip; gradients are kept while deltam31 stays within its tolerance
+    kept = {c.name: {k: v.copy() for k, v in st.grads[c.name].items()} for c in cs}
+    for c in cs:
+        c.representation = "events"
+        c["dom_eff"] = 2.0 - ev[c.name]["dom_eff"]                             # mirrored: new gradients would flip sign
+    binned_weights_written()
+    st.params.dom_eff.value, st.params.deltam31.value = -3.0, 3.00005e-3 * ureg.eV ** 2
+    st.run()
+    for c in cs:
+        assert all(np.array_equal(st.grads[c.name][k], kept[c.name][k]) for k in kept[c.name])
+        assert (np.array(c["syst_scale"]) == 0).any()
+    st.params.deltam31.value = 3.2e-3 * ureg.eV ** 2
+    binned_weights_written()
+    st.run()
+    for c in cs:
+        assert np.array_equal(st.grads[c.name]["dom_eff"], -kept[c.name]["dom_eff"])
+        np.testing.assert_allclose(c["syst_scale"], want_scale(c.name, -3.0, 0.2, mirrored=True)[0], rtol=1e-11, atol=1e-13)
