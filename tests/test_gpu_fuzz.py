@@ -118,3 +118,12 @@ def test_randomised_container_translations_against_the_reference_rule():
                          capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0, (res.stdout[-3000:], res.stderr[-2000:])
     assert "80 trials, 0 bad" in res.stdout
+
+
+def test_randomised_side_kernels_against_the_restatement():
+    """`scripts/dev/fuzz_side.py`: the kernels of the services around the path and the wide metrics on random sizes
+    (0, 1, around the workgroup size, up to 3e5), binnings, parameters and degenerate inputs."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "dev", "fuzz_side.py"), "60", "141"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, (res.stdout[-3000:], res.stderr[-2000:])
+    assert "60 trials, 0 bad" in res.stdout
