@@ -499,6 +499,20 @@ def gen_side():
             pe, pm, pt = np.zeros(n), np.zeros(n), np.zeros(n)
             dec.calc_decoherence_probs(view, flav, Q(ed), Q(ld), pe, pm, pt, two_flavor=False)
             out["dec_%d_%s" % (ic, flav)] = np.stack([pe, pm, pt], axis=1)
+    # --- reco.simple_param: the three smearing functions drawing from ONE RandomState(0), container after container
+    ref_shim._pkg("pisa.stages.reco", os.path.join(p, "reco"))
+    sp = ref_shim.ref_module("pisa.stages.reco.simple_param")
+    er = 10 ** (rs.rand(300) * 2.5)
+    czr = rs.rand(300) * 2 - 1
+    out.update(reco_e=er, reco_cz=czr)
+    state = np.random.RandomState(0)
+    e_params = {"nu*_cc": [10.0, 0.3, -0.2], "*_nc": [10.0, 0.5, 0.1], "muons": [5.0, 0.6, 0.0]}
+    cz_params = {"nu*_cc": [10.0, 0.4, -0.5], "*_nc": [10.0, 0.6, -0.3], "muons": [5.0, 0.1, 0.0]}
+    pid_params = {"numu*_cc": [0.9, 0.3, 12.0], "nue*": [0.3, 0.1, 30.0], "nutau*": [0.3, 0.1, 30.0], "muons": [1.0, 1.0, 0.0]}
+    for key in ("numu_cc", "nutau_cc", "nue_nc", "muons", "numubar_cc"):
+        out["reco_%s_energy" % key] = sp.simple_reco_energy_parameterization(key, er, e_params, state)
+        out["reco_%s_coszen" % key] = sp.simple_reco_coszen_parameterization(key, er, czr, cz_params, state)
+        out["reco_%s_pid" % key] = sp.simple_pid_parameterization(key, er, pid_params, 1.0, 0.0, state)
     # the arrays of test_lookup_indices (bin_indexing.py:164-226): binnings 7 x 4 x 2 over [0,7] x [0,4] x [0,2]
     out["idx_test_x"] = np.array([-5, 0.5, 1.5, 7.0, 6.5, 8.0, 6.5])
     out["idx_test_y"] = np.array([-5, 0.5, 1.5, 1.5, 3.0, 1.5, 2.5])

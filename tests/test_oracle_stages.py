@@ -110,3 +110,42 @@ def test_wide_metric_restatements():
 
     k, lam = W["actual"][6:12], W["expected"][6:12]
     np.testing.assert_allclose(W["mcllh_eff"][6:12], k * np.log(lam) - lam - gammaln(k + 1), rtol=1e-14)
+
+
+def test_simple_param_stage_reproduces_the_reference_draws():
+    """reco.simple_param is event preparation on the host (numpy's RandomState(0) stream, the reference's order of
+    draws): the whole stage against the reference's three functions executed in the build container, container
+    after container from one generator; then the `perfect_reco` switch"""
+    from pisa_amd.core.container import Container, ContainerSet
+    from pisa_amd.core.param import Param, ParamSet
+    from pisa_amd.stages.reco.simple_param import dict_lookup_wildcard, simple_param
+
+    names = ("numu_cc", "nutau_cc", "nue_nc", "muons", "numubar_cc")
+
+    def make(perfect):
+        cs = []
+        for name in names:
+            c = Container(name)
+            c["true_energy"], c["true_coszen"] = G["reco_e"].copy(), G["reco_cz"].copy()
+            cs.append(c)
+        values = [("perfect_reco", perfect),
+                  ("reco_energy_params", "{'nu*_cc': [10., 0.3, -0.2], '*_nc': [10., 0.5, 0.1], 'muons': [5., 0.6, 0.]}"),
+                  ("reco_coszen_params", "{'nu*_cc': [10., 0.4, -0.5], '*_nc': [10., 0.6, -0.3], 'muons': [5., 0.1, 0.]}"),
+                  ("pid_track_params", "{'numu*_cc': [0.9, 0.3, 12.], 'nue*': [0.3, 0.1, 30.], 'nutau*': [0.3, 0.1, 30.], 'muons': [1., 1., 0.]}"),
+                  ("track_pid", 1.0), ("cascade_pid", 0.0)]
+        st = simple_param(data=ContainerSet("data", cs, representation="events"), calc_mode="events",
+                          params=ParamSet([Param(name=n, value=v, prior=None, range=None, is_fixed=True) for n, v in values]))
+        st.setup()
+        return cs
+
+    for c in make(False):
+        for key in ("energy", "coszen"):
+            assert np.array_equal(c["reco_" + key], G["reco_%s_%s" % (c.name, key)]), (c.name, key)
+        assert np.array_equal(c["pid"], G["reco_%s_pid" % c.name])
+        assert (np.array(c["reco_energy"]) >= 0).all()          # (coszen is reflected ONCE: a large error may still leave it outside)
+    assert set(np.unique(G["reco_numu_cc_pid"])) == {0.0, 1.0} and G["reco_muons_pid"].mean() > 0.45
+    for c in make(True):
+        assert np.array_equal(c["reco_energy"], G["reco_e"]) and np.array_equal(c["reco_coszen"], G["reco_cz"])
+        assert np.array_equal(c["pid"], np.full(300, 1.0 if c.name in ("numu_cc", "numubar_cc", "muons") else 0.0))
+    with pytest.raises(AssertionError):
+        dict_lookup_wildcard({"nu*": 1, "numu*": 2}, "numu_cc")
