@@ -657,3 +657,49 @@ def test_snowstorm_hist_stage():
     for c in cs:
         assert np.array_equal(st.grads[c.name]["dom_eff"], -kept[c.name]["dom_eff"])
         np.testing.assert_allclose(c["syst_scale"], want_scale(c.name, -3.0, 0.2, mirrored=True)[0], rtol=1e-11, atol=1e-13)
+
+
+def test_aeff_param_stage():
+    """aeff.param with the reference's example parameterisation files (lambda strings, np.poly1d, an interpolation
+    table): the product in the reference's order of multiplications (param.py:170-180), names without a
+    parameterisation only scaled, the static factors re-made when a coordinate column changes"""
+    from pisa_amd.core.container import Container, ContainerSet
+    from pisa_amd.core.units import ureg
+    from pisa_amd.stages.aeff import param as P
+
+    st = P.init_test(prior=None, range=None, is_fixed=False)
+    rs = np.random.RandomState(6)
+    cs = []
+    for name in ("nue_cc + numu_cc", "nutau_cc", "nuall_nc", "unlisted"):
+        c = Container(name)
+        c["true_energy"] = 10 ** (rs.rand(2000) * 2.2 - 0.1)
+        c["true_coszen"] = rs.rand(2000) * 2 - 1
+        c["weights"] = rs.rand(2000) + 0.5
+        cs.append(c)
+    st.data, st.apply_mode = ContainerSet("data", cs, representation="events"), "events"
+    before = _columns(st.data, ["true_energy", "true_coszen", "weights"])
+    st.params.aeff_scale.value = 0.9
+    st.params.livetime.value = 2.5 * ureg.common_year
+    st.setup()
+    st.run()
+
+    def want(name, b):
+        scale = 0.9 * (2.5 * ureg.common_year).m_as("sec") * np.ones(2000)
+        if name in st.energy_param:
+            scale *= st.energy_param[name](b["true_energy"])
+        if name in st.coszen_param:
+            scale *= st.coszen_param[name](b["true_coszen"])
+        return b["weights"] * scale
+
+    for c in cs:
+        assert np.array_equal(c["weights"], want(c.name, before[c.name])), c.name
+    assert (np.array(cs[1]["weights"]) == 0).any()                   # the table: 0 outside its energies
+    cs[0]["true_energy"] = before[cs[0].name]["true_energy"] * 1.5   # new coordinates: the factors follow
+    cs[0]["weights"] = before[cs[0].name]["weights"].copy()
+    st.run()
+    moved = dict(before[cs[0].name], true_energy=before[cs[0].name]["true_energy"] * 1.5)
+    assert np.array_equal(cs[0]["weights"], want(cs[0].name, moved))
+    with pytest.raises(ValueError):
+        P.load_aeff_param({"x": {"energy": [1, 2]}})
+    with pytest.raises(TypeError):
+        P.load_aeff_param(3)
