@@ -812,3 +812,26 @@ def test_hdf5_reader_and_events_pi():
     assert np.array_equal(again["nue_cc"]["true_energy"], parts[1])
     with pytest.raises(AssertionError):
         EventsPi(fraction_events_to_keep=0.25, events_subsample_index=4)
+
+
+def test_sqlite_loader_reads_the_reference_test_database(tmp_path):
+    """data.sqlite_loader on the ten-event database the reference's init_test writes (sqlite_loader.py:152-177): rows
+    selected by PDG code and interaction type, truth and reconstruction joined by event number, weighted_aeff"""
+    from pisa_amd.core.container import ContainerSet
+    from pisa_amd.stages.data.sqlite_loader import sqlite_loader, write_test_database
+
+    path = str(tmp_path / "events.db")
+    truth, reco = write_test_database(path)
+    st = sqlite_loader(database=path, output_names=["numu_cc", "numubar_cc"], data=ContainerSet("data"), calc_mode="events",
+                       apply_mode="events")
+    assert st.get_pid_and_interaction_type("nutaubar_nc") == (-16, 2, -1, 2)
+    assert st.get_pid_and_interaction_type("nue_cc") == (12, 1, 1, 0)
+    st.setup()
+    st.run()
+    c, empty = st.data.containers
+    t, r = np.array(truth), np.array(reco)
+    assert c.size == 10 and empty.size == 0 and c["nubar"] == 1 and c["flav"] == 1
+    assert np.array_equal(c["true_energy"], t[:, 0]) and np.array_equal(c["true_coszen"], np.cos(t[:, 1]))
+    assert np.array_equal(c["reco_energy"], r[:, 0]) and np.array_equal(c["reco_coszen"], np.cos(r[:, 1]))
+    assert np.array_equal(c["pid"], r[:, 2]) and np.array_equal(c["weights"], np.ones(10))
+    assert np.array_equal(c["weighted_aeff"], 1e-4 * t[:, 2] / 1 / t[:, 3] / 10)
