@@ -493,8 +493,11 @@ class Analysis:
         """a local scipy minimiser; `method_kwargs` are minimiser settings in the reference's form
         ({"method": {"value": ...}, "options": {"value": {...}}}) or a settings file"""
         if method_kwargs.get("global_method") is not None:
-            raise NotImplementedError("global scipy methods (%s) are not part of this build; nest a local fit in"
-                                      " `grid_scan` / `best_of` instead" % method_kwargs["global_method"])
+            res = self._fit_scipy_global(data_dist, hypo_maker, metric, external_priors_penalty, method_kwargs,
+                                         local_fit_kwargs)
+            if not store_fit_history:
+                res.fit_history = None
+            return res
         settings = {k: v for k, v in method_kwargs.items() if k in ("method", "options")} or None
         if external_priors_penalty is None:
             res = self.fit_hypo(data_dist, hypo_maker, metric, minimizer_settings=settings, reset_free=False)
@@ -503,6 +506,78 @@ class Analysis:
         if not store_fit_history:
             res.fit_history = None
         return res
+
+    GLOBAL_SCIPY_METHODS = ("differential_evolution", "basinhopping", "dual_annealing", "shgo")
+
+    def _fit_scipy_global(self, data_dist, hypo_maker, metric, external_priors_penalty, method_kwargs, local_fit_kwargs):
+        """scipy's global optimisers over the [0, 1]-rescaled free parameters (analysis.py:1594-1680, 1811-1893):
+        `method_kwargs = {"global_method": name, "options": {...}}`, the options handed to scipy as they are;
+        basinhopping (with the reference's bounded random displacement, manipulate_params.py:18-41), dual_annealing
+        and shgo polish with the local minimiser of `local_fit_kwargs` (settings in the reference's form) if given.
+        Every evaluation is the minimiser callable of the local fits.  Constraints are not built."""
+        from scipy import optimize
+        from sklearn.utils import check_random_state
+
+        name = method_kwargs["global_method"]
+        if name not in self.GLOBAL_SCIPY_METHODS:
+            raise ValueError("Unsupported global fit method %s" % name)
+        opt = dict(method_kwargs.get("options") or {})
+        if opt.pop("constraints", None):
+            raise NotImplementedError("constraints with global scipy methods are not part of this build")
+        uses_local = name in ("basinhopping", "dual_annealing", "shgo")
+        local = None
+        if uses_local and local_fit_kwargs is not None:
+            ms = load_minimizer_settings({k: v for k, v in local_fit_kwargs.items() if k in ("method", "options")})
+            if dict(ms.get("options", {})).get("constraints"):
+                raise NotImplementedError("constraints with global scipy methods are not part of this build")
+            local = dict(method=ms["method"], options=dict(ms.get("options", {})))
+        free = hypo_maker.params.free
+        if len(free) == 0:
+            hypo = hypo_maker.get_outputs(return_sum=True)
+            return HypoFitResult(metric, self._total_metric(data_dist, hypo, hypo_maker, metric), hypo_maker.params, hypo,
+                                 [], None, 1)
+        x0 = np.array(free._rescaled_values, dtype=np.float64)
+        bounds = [(0.0, 1.0)] * len(x0)
+        counter, history = Counter(), []
+        sign = self._sign(metric)
+
+        def fun(x, *unused):
+            return self._minimizer_callable(np.clip(x, 0.0, 1.0), hypo_maker, data_dist, metric, counter, history, None,
+                                            external_priors_penalty)
+
+        self._nit = 0
+
+        def count(*unused_args, **unused_kwargs):
+            self._nit += 1
+
+        if name == "differential_evolution":
+            res = optimize.differential_evolution(func=fun, bounds=bounds, callback=count, **opt)
+        elif name == "basinhopping":
+            rng = check_random_state(opt.get("seed"))
+            stepsize = opt.get("stepsize", 0.5)
+            lo, hi = np.array(bounds).T
+
+            def take_step(x):
+                x += rng.uniform(-stepsize, stepsize, np.shape(x))
+                return np.clip(x, lo, hi)
+
+            minimizer_kwargs = dict(local, bounds=bounds) if local is not None else {"bounds": bounds}
+            res = optimize.basinhopping(func=fun, x0=x0, take_step=take_step, callback=count,
+                                        minimizer_kwargs=minimizer_kwargs, **opt)
+        elif name == "dual_annealing":
+            res = optimize.dual_annealing(func=fun, bounds=bounds, x0=x0, callback=count,
+                                          minimizer_kwargs=dict(local, bounds=bounds) if local is not None else {}, **opt)
+        else:
+            res = optimize.shgo(func=fun, bounds=bounds, callback=count,
+                                minimizer_kwargs=dict(local, bounds=bounds) if local is not None else {}, **opt)
+        success = bool(getattr(res, "success", True))
+        if name == "basinhopping":          # its OptimizeResult reports through the last local result
+            success = bool(getattr(getattr(res, "lowest_optimization_result", res), "success", True))
+        hypo_maker._set_rescaled_free_params(np.clip(res.x, 0.0, 1.0))  # pylint: disable=protected-access
+        hypo = hypo_maker.get_outputs(return_sum=True)
+        meta = OrderedDict(success=success, nit=int(getattr(res, "nit", self._nit)), nfev=int(getattr(res, "nfev", counter.count)),
+                           message=str(getattr(res, "message", "")), global_method=name)
+        return HypoFitResult(metric, sign * float(res.fun), hypo_maker.params, hypo, history, meta, counter.count)
 
     def _fit_iminuit(self, *args, **kwargs):
         raise ImportError("the 'iminuit' strategy needs the iminuit package, which is not installed; use 'scipy'")

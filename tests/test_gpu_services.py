@@ -341,3 +341,52 @@ def test_nested_fit_strategies():
         ana.fit_recursively(data, maker, "chi2", None, "simulated_annealing", {}, None)
     with pytest.raises(AssertionError):
         ana.fit_recursively(data, maker, ["chi2", "chi2"], None, **local)
+
+
+@pytest.mark.parametrize("name", ["differential_evolution", "basinhopping", "dual_annealing", "shgo"])
+def test_global_scipy_methods(name):
+    """`fit_recursively("scipy", {"global_method": ...})` (analysis.py:1594-1680, 1811-1893): the four global optimisers
+    over the rescaled free parameters, small budgets; each reports a point it evaluated (the best of its population for
+    differential evolution, no worse than the start for those that start there) and what it spent; with a fixed seed the
+    run repeats itself"""
+    from pisa_amd.analysis.analysis import Analysis
+    from pisa_amd.core.distribution_maker import DistributionMaker
+    from pisa_amd.core.units import ureg
+
+    dm = DistributionMaker("settings/pipeline/example_hip.cfg")
+    for n in dm.params.free.names:
+        if n not in ("theta23", "deltam31"):
+            dm.params.fix(n)
+    dm.params.theta23.value = 47.0 * ureg.degree
+    dm.params.deltam31.value = 2.55e-3 * ureg.eV ** 2
+    data = dm.get_outputs(return_sum=True)
+    dm.params.reset_free()
+    start = data[0].metric_total(dm.get_outputs(return_sum=True)[0], "mod_chi2")
+    local = {"method": {"value": "L-BFGS-B"}, "options": {"value": {"ftol": 1e-6, "gtol": 1e-5, "eps": 1e-4, "maxiter": 30}}}
+    options = {"differential_evolution": dict(seed=3, maxiter=4, popsize=6, tol=0.1, polish=False),
+               "basinhopping": dict(seed=3, niter=2, stepsize=0.2),
+               "dual_annealing": dict(seed=3, maxiter=15, no_local_search=True),
+               "shgo": dict(n=16, iters=1, sampling_method="sobol")}[name]
+
+    def run():
+        dm.params.reset_free()
+        return Analysis().fit_recursively(data, dm, "mod_chi2", None, "scipy", {"global_method": name, "options": dict(options)},
+                                          local if name in ("basinhopping", "shgo") else None, store_fit_history=True)
+
+    res = run()
+    assert res.minimizer_metadata["global_method"] == name and res.num_distributions_generated >= 10
+    assert len(res.fit_history) == res.num_distributions_generated
+    values = np.array([h[0] for h in res.fit_history])
+    assert np.min(np.abs(values - res.metric_val)) <= 1e-12 * max(1.0, abs(res.metric_val))     # a point that was evaluated
+    if name == "differential_evolution":            # (starts from its own population, not from the nominal point)
+        assert res.metric_val == values.min()
+    else:
+        assert res.metric_val <= start * (1 + 1e-12)
+    # the parameters were left at the optimum: the template there gives the reported value
+    np.testing.assert_allclose(data[0].metric_total(dm.get_outputs(return_sum=True)[0], "mod_chi2")
+                               + dm.params.priors_penalty(metric="mod_chi2"), res.metric_val, rtol=1e-10)
+    if name != "shgo":
+        again = run()
+        assert again.metric_val == res.metric_val and again.num_distributions_generated == res.num_distributions_generated
+    with pytest.raises(ValueError):
+        Analysis().fit_recursively(data, dm, "mod_chi2", None, "scipy", {"global_method": "simulated_magic", "options": {}}, None)
