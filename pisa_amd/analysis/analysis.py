@@ -120,6 +120,27 @@ def load_minimizer_settings(settings):
     return out
 
 
+def scipy_constraints_to_callables(constr_dicts, hypo_maker):
+    """constraints given as functions (or strings that evaluate to functions) of the ParamSet become functions of the
+    rescaled free-parameter vector, in place (configure_scipy_minimization.py:274-302)"""
+    from collections.abc import Mapping, Sequence
+    from functools import partial
+
+    def constr_func(x, constr_func_params):
+        hypo_maker._set_rescaled_free_params(x)  # pylint: disable=protected-access
+        return constr_func_params(hypo_maker.params)
+
+    assert isinstance(constr_dicts, Sequence)
+    for cd in constr_dicts:
+        assert isinstance(cd, Mapping) and "fun" in cd
+        constr = cd["fun"]
+        fn = constr if callable(constr) else eval(constr)  # pylint: disable=eval-used
+        if not callable(fn):
+            raise TypeError("Evaluated object not a callable, but %s." % type(fn))
+        cd["fun"] = partial(constr_func, constr_func_params=fn)
+    return constr_dicts
+
+
 class Analysis:
     def __init__(self):
         self._nit = 0
@@ -318,7 +339,11 @@ class Analysis:
             return HypoFitResult(metric, val, hypo_maker.params, hypo, None, meta, 0)
         method = ms["method"].lower()
         options = dict(ms.get("options", {}))
-        if (batched_gradient and method in ("l-bfgs-b", "slsqp") and hasattr(hypo_maker, "metric_many")
+        # "constraints" among the options (analysis.py:1687-1696): SLSQP, COBYLA, trust-constr
+        constrs = options.pop("constraints", None) or []
+        if constrs:
+            constrs = scipy_constraints_to_callables([dict(c) for c in constrs], hypo_maker)
+        if (not constrs and batched_gradient and method in ("l-bfgs-b", "slsqp") and hasattr(hypo_maker, "metric_many")
                 and "jac" not in ms and "finite_diff_rel_step" not in options):
             # the step the method would use itself: `eps` (L-BFGS-B default 1e-8, SLSQP default sqrt(eps))
             eps = options.get("eps", 1e-8 if method == "l-bfgs-b" else np.sqrt(np.finfo(np.float64).eps))
@@ -347,8 +372,8 @@ class Analysis:
         else:
             res = optimize.minimize(
                 fun=self._minimizer_callable, x0=x0, args=(hypo_maker, data_dist, metric, counter, history),
-                bounds=bounds if method in ("l-bfgs-b", "slsqp", "tnc", "trust-constr") else None,
-                method=ms["method"], options=options)
+                bounds=bounds if method in ("l-bfgs-b", "slsqp", "tnc", "trust-constr", "cobyla", "cobyqa") else None,
+                constraints=constrs or (), method=ms["method"], options=options)
         hypo_maker._set_rescaled_free_params(np.clip(res.x, 0.0, 1.0))  # pylint: disable=protected-access
         hypo = hypo_maker.get_outputs(return_sum=True)
         val = self._sign(metric) * res.fun
