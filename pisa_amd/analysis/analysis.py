@@ -43,6 +43,40 @@ class HypoFitResult:
         self.minimizer_metadata = minimizer_result
         self.num_distributions_generated = num_distributions_generated
 
+    detailed_metric_info = None
+
+    @staticmethod
+    def get_detailed_metric_info(data_dist, hypo_maker, hypo_asimov_dist, params, metric, other_metrics=None,
+                                 detector_name=None, include_maps_binned=False):
+        """per metric (the fit's and `other_metrics`): its value map by map, the priors' penalties parameter by
+        parameter and, if asked for, the per-bin values as maps (analysis.py:373-459; generalized_poisson_llh and
+        weighted_chi2 are not built)"""
+        from pisa_amd.core.map import Map, MapSet
+
+        others = [] if other_metrics is None else ([other_metrics] if isinstance(other_metrics, str) else list(other_metrics))
+        first = metric[0] if isinstance(metric, (list, tuple)) else metric
+        info = OrderedDict()
+        if detector_name is not None:
+            info["detector_name"] = detector_name
+        for m in sorted(set([first] + others)):
+            d = OrderedDict()
+            d["maps"] = data_dist.metric_per_map(expected_values=hypo_asimov_dist, metric=m)
+            if include_maps_binned:
+                hists = data_dist.metric_per_map(expected_values=hypo_asimov_dist, metric="binned_" + m)
+                d["maps_binned"] = MapSet([Map(name=a.name, hist=np.reshape(hists[k], a.shape), binning=a.binning)
+                                           for a, k in zip(hypo_asimov_dist, hists)])
+            d["priors"] = params.priors_penalties(metric=first)
+            info[m] = d
+        return info
+
+    def add_detailed_metric_info(self, data_dist, hypo_maker=None, other_metrics=None, include_maps_binned=False):
+        """fills `detailed_metric_info` from the data and this result's template and parameters"""
+        self.detailed_metric_info = self.get_detailed_metric_info(
+            data_dist, hypo_maker, self.hypo_asimov_dist, self.params, self.metric, other_metrics=other_metrics,
+            detector_name=getattr(hypo_maker, "detector_name", None) if hypo_maker is not None else None,
+            include_maps_binned=include_maps_binned)
+        return self.detailed_metric_info
+
     def __repr__(self):
         vals = ", ".join("%s=%s" % (p.name, p.value) for p in self.params.free)
         return "HypoFitResult(%s=%.8g; %s)" % (self.metric, self.metric_val, vals)

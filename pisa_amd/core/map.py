@@ -877,7 +877,8 @@ class MapSet:
                 exp = expected_values[m.name] if self.collate_by_name else expected_values[i]
             else:
                 exp = expected_values
-            out[m.name] = m.metric(exp, metric)
+            # 'binned_<metric>': the per-bin values instead of their sum (map.py:3121-3130)
+            out[m.name] = m.metric(exp, metric[7:], binned=True) if metric.startswith("binned_") else m.metric(exp, metric)
         return out
 
     def metric_total(self, expected_values, metric, metric_kwargs=None):

@@ -432,3 +432,32 @@ def test_constrained_local_fits_as_in_the_reference_unit_test():
     assert bf.params.aeff_scale.m_as("dimensionless") >= min_aeff_scale - 1e-4
     with pytest.raises(TypeError):
         fit("slsqp", [{"type": "ineq", "fun": "3.0"}])
+
+
+def test_detailed_metric_info_of_a_fit_result():
+    """analysis.py:373-459: the metric map by map, the priors' penalties, the per-bin values as maps; other metrics
+    alongside the fit's"""
+    from oracle import stages_oracle as so
+    from pisa_amd.analysis.analysis import Analysis
+    from pisa_amd.core.distribution_maker import DistributionMaker
+    from pisa_amd.core.units import ureg
+
+    dm = DistributionMaker("settings/pipeline/example_hip.cfg")
+    for n in dm.params.free.names:
+        if n not in ("theta23", "delta_index"):
+            dm.params.fix(n)
+    dm.params.theta23.value = 45.5 * ureg.degree
+    data = dm.get_outputs(return_sum=True)
+    dm.params.reset_free()
+    res = Analysis().fit_hypo(data, dm, "mod_chi2")
+    info = res.add_detailed_metric_info(data, dm, other_metrics=["correct_chi2", "llh"], include_maps_binned=True)
+    assert list(info) == ["detector_name", "correct_chi2", "llh", "mod_chi2"] or list(info) == ["correct_chi2", "llh", "mod_chi2"]
+    templ = res.hypo_asimov_dist[0]
+    for m in ("mod_chi2", "correct_chi2", "llh"):
+        d = info[m]
+        assert list(d["maps"]) == ["total"] and d["maps_binned"][0].hist.shape == templ.hist.shape
+        np.testing.assert_allclose(np.nansum(d["maps_binned"][0].hist), d["maps"]["total"], rtol=1e-12)
+        assert d["priors"] == res.params.priors_penalties(metric="mod_chi2") and len(d["priors"]) == len(res.params)
+    np.testing.assert_allclose(info["correct_chi2"]["maps_binned"][0].hist.ravel(),
+                               so.metric_wide("correct_chi2", data[0].hist, templ.hist, templ.std_devs), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(info["mod_chi2"]["maps"]["total"] + sum(info["mod_chi2"]["priors"]), res.metric_val, rtol=1e-10)
