@@ -706,6 +706,22 @@ int pisa_hip_interp_linear(const double *d_x_knots, const double *d_y_knots, int
 int pisa_hip_column_combination(const double *const *h_d_columns, const double *h_coef, int32_t n_columns, int32_t mode,
                                 int64_t n, double *d_out, void *stream);
 
+/* The element-wise helpers of pisa/utils/vectorizer.py:44-209 (its gufuncs `scale_gufunc` ... `replace_where_counts_gt_gufunc`):
+ *   SCALE out = a*scalar;  MUL out = a*b;  IMUL out *= a;  IMUL_AND_SCALE out *= a*scalar;
+ *   ITRUEDIV out /= a (0 where a == 0);  ASSIGN out = a;  POW out = a**scalar;  SQRT out = sqrt(a);
+ *   REPLACE_WHERE_COUNTS_GT out = a where b > scalar.   d_out may alias d_a. */
+#define PISA_HIP_VEC_SCALE 0
+#define PISA_HIP_VEC_MUL 1
+#define PISA_HIP_VEC_IMUL 2
+#define PISA_HIP_VEC_IMUL_AND_SCALE 3
+#define PISA_HIP_VEC_ITRUEDIV 4
+#define PISA_HIP_VEC_ASSIGN 5
+#define PISA_HIP_VEC_POW 6
+#define PISA_HIP_VEC_SQRT 7
+#define PISA_HIP_VEC_REPLACE_WHERE_COUNTS_GT 8
+int pisa_hip_vector_op(int32_t op, const double *d_a, const double *d_b, double scalar, int64_t n, double *d_out,
+                       void *stream);
+
 /* Replaces `decoherence.calc_probs` (pisa/stages/osc/decoherence.py:449-466 over `calc_decoherence_probs` :66-106):
  * d_probability[n][3][3], rows (1, 0, 0), (0, 1 - D, D), (0, D, 1 - D) with the numu disappearance D(E, L) of
  * `_calc_numu_disappearance_prob_3flav` (:229-269; h_coef[k] = |U[2][j]|^2 |U[2][k]|^2, h_gamma[k] in GeV, h_delta[k]

@@ -286,6 +286,7 @@ _SIGS = {
     "pisa_hip_shift_toward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_double, C.c_double, C.c_int64, C.c_void_p, C.c_void_p]),
     "pisa_hip_poly_scale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_int64, C.c_void_p, C.c_void_p]),
     "pisa_hip_column_combination": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
+    "pisa_hip_vector_op": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_int64, C.c_void_p, C.c_void_p]),
     "pisa_hip_interp_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pisa_hip_decoherence_probs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "pisa_hip_flux_2d": (C.c_int, [C.POINTER(FluxTable), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -11,6 +11,8 @@
 //                                                                           pisa/stages/background/atm_muons.py:95-101)
 //   interp_linear    numpy.interp between knots                            (atm_muons.py:82-87, 159-164)
 //   column_combination  exp / 1 + / plain sum_g c_g col_g                 (pisa/stages/discr_sys/ultrasurfaces.py:339-356)
+//   vector_op        scale / mul / imul / imul_and_scale / itruediv / assign / pow / sqrt / replace_where_counts_gt
+//                                                                          (pisa/utils/vectorizer.py:44-209)
 //   decoherence      P[n][3][3] of the vacuum decoherence model            (pisa/stages/osc/decoherence.py:66-269)
 #include <math.h>
 
@@ -154,6 +156,25 @@ interp_linear_kernel(const double *__restrict__ xk, const double *__restrict__ y
         if (r != r && yk[lo] == yk[lo + 1]) r = yk[lo];
     }
     out[i] = r;
+}
+
+// pisa/utils/vectorizer.py:44-209: the element-wise helpers stages are written with
+__global__ void __launch_bounds__(256)
+vector_op_kernel(int op, const double *__restrict__ a, const double *__restrict__ b, double s, int64_t n,
+                 double *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    switch (op) {
+    case PISA_HIP_VEC_SCALE: out[i] = a[i] * s; break;
+    case PISA_HIP_VEC_MUL: out[i] = a[i] * b[i]; break;
+    case PISA_HIP_VEC_IMUL: out[i] *= a[i]; break;
+    case PISA_HIP_VEC_IMUL_AND_SCALE: out[i] *= a[i] * s; break;
+    case PISA_HIP_VEC_ITRUEDIV: out[i] = a[i] == 0.0 ? 0.0 : out[i] / a[i]; break;
+    case PISA_HIP_VEC_ASSIGN: out[i] = a[i]; break;
+    case PISA_HIP_VEC_POW: out[i] = pow(a[i], s); break;
+    case PISA_HIP_VEC_SQRT: out[i] = sqrt(a[i]); break;
+    default: if (b[i] > s) out[i] = a[i];      // replace_where_counts_gt
+    }
 }
 
 // ultrasurfaces.py:339-356: out = exp(sum_g shift_g * grad_g[i]) or 1 + that sum, the sum in the order of the columns
@@ -340,5 +361,16 @@ PISA_API int pisa_hip_column_combination(const double *const *h_d_columns, const
     if (!d_out) return PISA_HIP_ERR_INVALID;
     hipLaunchKernelGGL(column_combination_kernel, grid_for(n), dim3(256), 0, as_stream(stream), s, n, d_out);
     PISA_CHECK_LAUNCH("column_combination_kernel");
+    return PISA_HIP_OK;
+}
+
+PISA_API int pisa_hip_vector_op(int32_t op, const double *d_a, const double *d_b, double scalar, int64_t n,
+                                double *d_out, void *stream) {
+    if (op < PISA_HIP_VEC_SCALE || op > PISA_HIP_VEC_REPLACE_WHERE_COUNTS_GT || n < 0) return PISA_HIP_ERR_INVALID;
+    if (n == 0) return PISA_HIP_OK;
+    const bool needs_b = op == PISA_HIP_VEC_MUL || op == PISA_HIP_VEC_REPLACE_WHERE_COUNTS_GT;
+    if (!d_a || !d_out || (needs_b && !d_b)) return PISA_HIP_ERR_INVALID;
+    hipLaunchKernelGGL(vector_op_kernel, grid_for(n), dim3(256), 0, as_stream(stream), (int)op, d_a, d_b, scalar, n, d_out);
+    PISA_CHECK_LAUNCH("vector_op_kernel");
     return PISA_HIP_OK;
 }

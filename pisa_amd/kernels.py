@@ -667,6 +667,19 @@ def column_combination(columns, coef, n, mode="exp", out=None, dev=None):
     return out
 
 
+VECTOR_OPS = {"scale": 0, "mul": 1, "imul": 2, "imul_and_scale": 3, "itruediv": 4, "assign": 5, "pow": 6, "sqrt": 7,
+              "replace_where_counts_gt": 8}
+
+
+def vector_op(op, a, out, b=None, scalar=0.0):
+    """the element-wise helpers of pisa/utils/vectorizer.py on device tensors, `out` written in place
+    (`pisa_hip_vector_op`)"""
+    lib = _lib.lib()
+    assert out.is_contiguous() and a.numel() == out.numel() and (b is None or b.numel() == out.numel())
+    _lib.check(lib.pisa_hip_vector_op(VECTOR_OPS[op], _ptr(a), _ptr(b), float(scalar), out.numel(), _ptr(out), _stream()))
+    return out
+
+
 def interp_linear(x_knots, y_knots, x, out=None):
     """numpy.interp(x, x_knots, y_knots) on the device; a value outside the knots raises, as scipy's interp1d does
     (`pisa_hip_interp_linear`)"""

@@ -803,3 +803,36 @@ def test_wide_metrics_reference_vectors_and_restatement():
                                    rtol=1e-12)
     with pytest.raises(ValueError):
         data.metric(templ, "barlow_llh")
+
+
+def test_vectorizer_helpers():
+    """pisa/utils/vectorizer.py's functions on device tensors (in place) and on numpy arrays, against numpy; the
+    reference's own unit test (`test_imul_and_scale`, vectorizer.py:111-117)"""
+    from pisa_amd import kernels as K
+    from pisa_amd.utils import vectorizer as V
+
+    rs = np.random.RandomState(2)
+    n = 10007
+    a, b, o = rs.rand(n) + 0.1, rs.randn(n), rs.randn(n)
+    b[:10] = 0.0
+    cases = [("scale", (a, 2.5), a * 2.5), ("mul", (a, b), a * b), ("imul", (a,), o * a), ("imul_and_scale", (a, -3.0), o * (a * -3.0)),
+             ("itruediv", (b,), np.where(b == 0, 0.0, o / np.where(b == 0, 1.0, b))), ("assign", (a,), a), ("pow", (a, 1.7), a ** 1.7),
+             ("sqrt", (a,), np.sqrt(a)), ("replace_where_counts_gt", (a, b, 0.3), np.where(b > 0.3, a, o))]
+    for name, args, want in cases:
+        host_out = o.copy()
+        getattr(V, name)(*args, out=host_out)
+        dev_out = K.to_device(o.copy())
+        dev_args = [K.to_device(x) if isinstance(x, np.ndarray) else x for x in args]
+        assert getattr(V, name)(*dev_args, out=dev_out) is dev_out
+        for got in (host_out, dev_out.cpu().numpy()):
+            if name == "pow":
+                np.testing.assert_allclose(got, want, rtol=1e-14)
+            else:
+                assert np.array_equal(got, want), name
+    lin = np.linspace(0, 1, 1000)
+    out = np.ones_like(lin)
+    V.imul_and_scale(vals=lin, scale=10.0, out=out)
+    assert np.allclose(out, np.linspace(0, 10, 1000))
+    two_d = np.ones((20, 3))
+    V.imul(np.arange(60.0).reshape(20, 3), out=two_d)
+    assert np.array_equal(two_d, np.arange(60.0).reshape(20, 3))
