@@ -132,6 +132,37 @@ class Prior:
         x = _as_quantity(x)
         return x.m_as(self.units) if self.units is not None else x.magnitude
 
+    @property
+    def valid_range(self):
+        """(low, high) quantities between which the prior is defined (prior.py:209-210, 232-233, 257-258, 280-281, 313-314)"""
+        u = self.units if self.units is not None else ureg.dimensionless
+        if self.kind in ("uniform", "gaussian"):
+            lo, hi = -np.inf, np.inf
+        elif self.kind == "jeffreys":
+            lo, hi = self.A.magnitude, self.B.magnitude
+        elif self.kind == "spline":
+            lo, hi = np.min(self.knots.magnitude), np.max(self.knots.magnitude)
+        else:
+            lo, hi = np.min(self.param_vals.magnitude), np.max(self.param_vals.magnitude)
+        return Quantity(lo, u), Quantity(hi, u)
+
+    @property
+    def max_at(self):
+        """where the prior is largest: NaN for a uniform prior, the mean / A, the tabulated maxima, or scipy's
+        `fminbound` of chi2 between the outer knots of a spline (prior.py:207, 230, 255, 277, 306-310)"""
+        if self.kind == "uniform":
+            return np.nan
+        if self.kind == "gaussian":
+            return self.mean
+        if self.kind == "jeffreys":
+            return self.A
+        if self.kind == "linterp":
+            return Quantity(np.asarray(self.param_vals.magnitude)[self.llh_vals == np.max(self.llh_vals)], self.units)
+        from scipy.optimize import fminbound
+
+        k = self.knots.magnitude
+        return Quantity(fminbound(func=lambda v: self.chi2(Quantity(v, self.units)), x1=np.min(k), x2=np.max(k)), self.units)
+
     def llh(self, x):
         if self.kind == "uniform":
             return 0.0 * _as_quantity(x).magnitude + self.llh_offset
