@@ -95,6 +95,27 @@ class DistributionMaker:
     def empty_bin_indices(self):
         return np.where(self.num_events_per_bin == 0)[0]
 
+    def tabulate(self, tablefmt="plain"):
+        """one row per pipeline (distribution_maker.py:203-218)"""
+        from tabulate import tabulate
+
+        headers = ["pipeline number", "name", "detector name", "output_binning", "output_key", "profile"]
+        table = [[i, p.name, p.detector_name, getattr(p.output_binning, "name", None), p.output_key, p.profile]
+                 for i, p in enumerate(self._pipelines)]
+        return tabulate(table, headers, tablefmt=tablefmt, colalign=["right"] + ["center"] * (len(headers) - 1))
+
+    def __repr__(self):
+        return self.tabulate(tablefmt="presto")
+
+    def _repr_html_(self):
+        return self.tabulate(tablefmt="html")
+
+    @property
+    def hash(self):
+        from pisa_amd.utils.hash import hash_obj
+
+        return hash_obj([p.hash for p in self._pipelines])
+
     pipelines = property(lambda self: self._pipelines)
 
     def __iter__(self):

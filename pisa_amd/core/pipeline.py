@@ -89,6 +89,47 @@ class Pipeline:
             raise KeyError(idx)
         return self._stages[idx]
 
+    def index(self, stage_id):
+        """number of the stage with that `stage_name` (or that number), pipeline.py:199-220"""
+        assert isinstance(stage_id, (int, str))
+        for stage_num, stage in enumerate(self._stages):
+            if stage_id in [stage_num, stage.stage_name]:
+                return stage_num
+        raise ValueError('No stage "%s" found in the pipeline.' % stage_id)
+
+    def __getattr__(self, attr):
+        # only reached when normal lookup failed: a stage by its stage name (pipeline.py:240-247)
+        if not attr.startswith("_"):
+            for stage in self.__dict__.get("_stages", ()):
+                if stage.stage_name == attr:
+                    return stage
+        raise AttributeError('"%s" is neither a stage in this pipeline nor an attribute/property of the `Pipeline` object.'
+                             % attr)
+
+    def tabulate(self, tablefmt="plain"):
+        """one row per stage: number, class, modes, which functions it has, fixed / free parameters (pipeline.py:138-146)"""
+        from tabulate import tabulate
+
+        headers = ["stage number", "name", "calc_mode", "apply_mode", "has setup", "has compute", "has apply",
+                   "# fixed params", "# free params"]
+        table = [[i, s.__class__.__name__, s.calc_mode, s.apply_mode, s.has_setup, s.has_compute, s.has_apply,
+                  len(s.params.fixed), len(s.params.free)] for i, s in enumerate(self._stages)]
+        return tabulate(table, headers, tablefmt=tablefmt, colalign=["right"] + ["center"] * (len(headers) - 1))
+
+    def __repr__(self):
+        return self.tabulate(tablefmt="presto")
+
+    def _repr_html_(self):
+        return self.tabulate(tablefmt="html")
+
+    @property
+    def hash(self):
+        """of the stages' classes, modes and parameter states (pipeline.py:676-680 hashes source code and stage states)"""
+        from pisa_amd.utils.hash import hash_obj
+
+        return hash_obj([(type(s).__module__, type(s).__name__, str(s.calc_mode), str(s.apply_mode), s.params.values_hash,
+                          tuple(s.params.names), tuple(p.is_fixed for p in s.params)) for s in self._stages])
+
     stages = property(lambda self: list(self._stages))
     stage_names = property(lambda self: [s.stage_name for s in self._stages])
     service_names = property(lambda self: [s.service_name for s in self._stages])

@@ -1135,3 +1135,29 @@ def test_pipeline_cfg_with_the_services_around_the_path(oracle, tmp_path):
         np.testing.assert_array_equal(c["reco_energy"], so.shift_toward(np.array(t["reco_energy"]), np.array(t["true_energy"]), 0.25))
         np.testing.assert_array_equal(c["reco_coszen"], so.shift_toward(np.array(t["reco_coszen"]), np.array(t["true_coszen"]), 0.5, (-1, 1)))
         np.testing.assert_array_equal(c["pid"], so.shift_toward(np.array(t["pid"]), 1.0 if c.name in ("numu_cc", "numubar_cc") else 0.0, 0.1))
+
+
+def test_pipeline_and_maker_tables_lookup_and_hash():
+    """pipeline.py:138-146, 199-247, 676-680; distribution_maker.py:211-217: the table of stages, stages by stage
+    name / number / attribute, a hash that follows the parameter values"""
+    from pisa_amd.core.distribution_maker import DistributionMaker
+    from pisa_amd.core.units import ureg
+
+    dm = DistributionMaker("settings/pipeline/example_hip.cfg")
+    pipe = dm.pipelines[0]
+    table = pipe.tabulate()
+    lines = table.splitlines()
+    assert len(lines) >= 1 + len(pipe.stages) and "stage number" in lines[0] and "# free params" in lines[0]
+    assert all(s.__class__.__name__ in table for s in pipe.stages) and repr(pipe).count("\n") >= len(pipe.stages)
+    assert pipe.index("osc") == 2 and pipe.index(4) == 4 and pipe.osc is pipe["osc"] is pipe.stages[2]
+    with pytest.raises(ValueError):
+        pipe.index("reco")
+    with pytest.raises(AttributeError):
+        pipe.no_such_stage  # pylint: disable=pointless-statement
+    assert "<table>" in pipe._repr_html_() and "neutrinos" in dm.tabulate() and "<table>" in dm._repr_html_()
+    h0, m0 = pipe.hash, dm.hash
+    assert h0 == pipe.hash
+    dm.params.theta23.value = 44.0 * ureg.degree
+    assert pipe.hash != h0 and dm.hash != m0
+    dm.params.reset_free()
+    assert pipe.hash == h0 and dm.hash == m0
