@@ -1,6 +1,15 @@
 """CPU restatement of the small services around the hot path.  TEST INFRASTRUCTURE ONLY: imported by tests/ and
-scripts/dev as the checker, never by pisa_amd/.  Pinned against the reference's own functions executed in the build
-container (`oracle/gen_golden.py side` -> tests/golden/side_stages_ref.npz; tests/test_oracle_stages.py)."""
+scripts/dev as the checker, never by pisa_amd/.
+
+PINNED against the reference's own functions executed in the build container (`oracle/gen_golden.py side` /
+`stats_wide` -> tests/golden/side_stages_ref.npz, stats_wide_ref.npz; tests/test_oracle_stages.py): find_index /
+lookup_indices, two_nu_prob / two_nu_weights, power_law, poly_scale (genie form), decoherence_disappearance /
+decoherence_table / tau_row_sq (3-flavour form), metric_wide (five metrics).  `numpy.interp` stands for scipy's
+`interp1d(kind='linear')` (checked equal in the same test file).
+PARITY UNPINNED (restated from the reference's text, nothing of it executed): decoherence_disappearance_2flav (its
+unit conversions run through pint, absent here), csv_hypersurface_scales (pandas table arithmetic of the stage itself),
+shift_toward and atm_muon_weights (one-line numpy expressions of resolutions.py / atm_muons.py); the expectations of
+the ultrasurfaces and snowstorm_hist tests are written out in those tests the same way."""
 import numpy as np
 
 
