@@ -17,6 +17,16 @@ the textbook form (this build, scipy's covariance convention + Abramson-type lam
 mean)^-alpha entering as lambda^-d * exp(-r^2 / (2 lambda^2))) gives 9.8 %, and the only lever that brings the
 number below 5 % is a stronger adaptation (alpha >= 0.26; the package's own default alpha = 0.3 gives 3.5 %).
 No family is singled out => nothing to adopt; the KDE core stays PARITY UNPINNED.
+
+Round 5 (verdict "Next #1a", time-boxed): the combinations the first table lacked -- float32 storage of sample and
+pilot, pilot on the sample mirrored at the coszen edges, separate exponents for the kernel width (a_w) and for its
+normalisation (a_n), and the bandwidth factor scaled.  Result: storage precision and a mirrored pilot do not move the
+number (9.8 / 9.5 %); the criterion IS met by several mutually exclusive forms -- a consistent effective alpha of 0.4
+(a_w = a_n = 0.4: 0.4 %), an inconsistent normalisation (a_w = 0.1, a_n = 0.2: 1.2 %, not a density), and a bandwidth
+factor 0.84 x Silverman's (1.8 %; 0.84 happens to be the ONE-dimensional Silverman rule (3n/4)^(-1/5) over the
+two-dimensional one at n = 1000).  The criterion is a weak discriminator: three unrelated changes pass it, nothing in
+the reference says which (if any) the package makes.  Closed: parity stays UNPINNED, criterion failing for the
+textbook form, no further time goes here.
 """
 import numpy as np
 
@@ -39,10 +49,14 @@ def _kde_eval(x, coef, s2, pts, inv_cov):
 
 
 def estimator(x, weights, pts, bw="silverman", alpha=0.1, bias="unbiased", diag=False, self_term=True,
-              lam_norm="d", lam_exp=2.0, glob="geometric", alpha_times_d=False, two_pass=False):
+              lam_norm="d", lam_exp=2.0, glob="geometric", alpha_times_d=False, two_pass=False,
+              f32=False, mirror_pilot=(), a_w=None, a_n=None, hfac=1.0):
     d, n = x.shape
+    if f32:
+        x, pts = x.astype(np.float32).astype(np.float64), pts.astype(np.float32).astype(np.float64)
     wn = weights / weights.sum()
     factor = (n * (d + 2) / 4.0) ** (-1.0 / (d + 4)) if bw == "silverman" else n ** (-1.0 / (d + 4))
+    factor *= hfac
     xc = x - (x * wn).sum(1, keepdims=True)
     cov = (xc * wn) @ xc.T
     if bias == "unbiased":
@@ -54,6 +68,18 @@ def estimator(x, weights, pts, bw="silverman", alpha=0.1, bias="unbiased", diag=
     norm = np.sqrt(np.linalg.det(2 * np.pi * covh))
     a = alpha * d if alpha_times_d else alpha
     s = np.ones(n)
+    if f32 or mirror_pilot or a_w is not None:
+        # round-5 forms: pilot over the sample plus its mirror images about coszen = edge (dimension 0), pilot kept
+        # in float32, separate exponents of (pilot / g) for the kernel width and for its normalisation
+        xa = np.concatenate([x] + [np.vstack([2 * e - x[:1], x[1:]]) for e in mirror_pilot], axis=1)
+        wa = np.concatenate([wn] * (1 + len(mirror_pilot)))
+        pilot = _kde_eval(xa, wa / norm, np.ones(xa.shape[1]), x, inv)
+        if f32:
+            pilot = pilot.astype(np.float32).astype(np.float64)
+        r = pilot / np.exp(np.mean(np.log(pilot)))
+        a_w = a if a_w is None else a_w
+        a_n = a_w if a_n is None else a_n
+        return _kde_eval(x, wn * (r ** a_n) ** d / norm, (r ** a_w) ** 2, pts, inv)
     for _ in range(2 if two_pass else 1):
         pilot = _kde_eval(x, wn * s ** d / norm, s ** 2, x, inv)
         if not self_term:
@@ -105,6 +131,16 @@ VARIANTS = [
     ("alpha = 0.3 (default of the `kde` package and of kde_hist.get_hist)", dict(alpha=0.3)),
     ("alpha = 0.5 (Abramson)", dict(alpha=0.5)),
     ("fixed bandwidth (alpha = 0)", dict(alpha=0.0)),
+    # round 5
+    ("float32 storage of sample, evaluation points and pilot", dict(f32=True)),
+    ("pilot over the sample mirrored at coszen = -1", dict(mirror_pilot=(-1.0,))),
+    ("pilot over the sample mirrored at coszen = -1 and +1", dict(mirror_pilot=(-1.0, 1.0))),
+    ("width exponent 0.2, normalisation exponent 0.1", dict(a_w=0.2, a_n=0.1)),
+    ("width exponent 0.4 (alpha * d with lambda^2 in h^2), normalisation exponent 0.4", dict(a_w=0.4, a_n=0.4)),
+    ("width exponent 0.1, normalisation exponent 0.2 (not a density)", dict(a_w=0.1, a_n=0.2)),
+    ("bandwidth factor x 0.84 (the 1-D Silverman rule used in 2-D at n = 1000)", dict(hfac=0.84)),
+    ("bandwidth factor x 0.7", dict(hfac=0.7)),
+    ("bandwidth factor x 1.2", dict(hfac=1.2)),
 ]
 
 
