@@ -725,24 +725,50 @@ kde_lattice_load_kernel(const KdeLattice L, int R, const double *__restrict__ bo
         __hip_atomic_store(&load[blockIdx.x], lds[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __threadfence();
         last = atomicAdd(done, 1ull) == (unsigned long long)(n_patches - 1);
-        if (last) {
-            __threadfence();
-            *done = 0ull;   // back to zero for the next launch
-            unsigned long long total = 0;
-            for (int p = 0; p < n_patches; p++) total += __hip_atomic_load(&load[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long spare = (unsigned long long)(n_waves - n_patches);
-            int32_t w = 0;
-            for (int p = 0; p < n_patches; p++) {
-                wstart[p] = w;
-                const unsigned long long lp = __hip_atomic_load(&load[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                unsigned long long extra = total ? spare * lp / total : 0;
-                const unsigned long long per = (unsigned long long)min_shares;   // shares per wavefront at least
-                if (per * (extra + 1) > lp) extra = lp >= per ? lp / per - 1 : 0;
-                w += 1 + (int32_t)extra;
-            }
-            wstart[n_patches] = w;
-        }
     }
+    __syncthreads();
+    if (!last) return;
+    // the plan: the loads fetched by the whole workgroup (one thread walking n_patches dependent agent-scope loads
+    // twice cost 45 us at 65 sub-patches), the walk itself on LDS / registers
+    __shared__ unsigned long long tot_lds;
+    __threadfence();
+    if (threadIdx.x == 0) { *done = 0ull; tot_lds = 0ull; }   // back to zero for the next launch
+    __syncthreads();
+    unsigned long long mine = 0;
+    for (int p = threadIdx.x; p < n_patches; p += 256) mine += __hip_atomic_load(&load[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    atomicAdd(&tot_lds, mine);   // (integer sum: order-independent)
+    __syncthreads();
+    const unsigned long long total = tot_lds;
+    const unsigned long long spare = (unsigned long long)(n_waves - n_patches);
+    const unsigned long long per = (unsigned long long)min_shares;   // shares per wavefront at least
+    // waves of sub-patch p, then an exclusive prefix sum over the sub-patches in chunks of 256
+    __shared__ int32_t scan[256];
+    __shared__ int32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n_patches; base += 256) {
+        const int p = base + (int)threadIdx.x;
+        int32_t nw = 0;
+        if (p < n_patches) {
+            const unsigned long long lp = __hip_atomic_load(&load[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long extra = total ? spare * lp / total : 0;
+            if (per * (extra + 1) > lp) extra = lp >= per ? lp / per - 1 : 0;
+            nw = 1 + (int32_t)extra;
+        }
+        scan[threadIdx.x] = nw;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const int32_t v = (int)threadIdx.x >= off ? scan[threadIdx.x - off] : 0;
+            __syncthreads();
+            scan[threadIdx.x] += v;
+            __syncthreads();
+        }
+        if (p < n_patches) wstart[p] = carry + scan[threadIdx.x] - nw;
+        __syncthreads();
+        if (threadIdx.x == 255) carry += scan[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) wstart[n_patches] = carry;
 }
 
 // Workgroup = one wavefront = one SUB-PATCH of the lattice (sw strips x lpw lines = LG lanes) x every n-th share of the

@@ -12,7 +12,9 @@ The sample columns never change between evaluations: they -- and, with
 `stack_pid`, the per-channel event indices -- are kept in HBM from the first
 evaluation on; per evaluation only the weights move.  The estimator itself is
 native code (`csrc/kde.hip`: cell-list Gaussian cut-off at kernel value `tol`,
-extra kwarg of this build, default 1e-14, 0 = all pairs).
+extra kwarg of this build, 0 = all pairs).  The stage's default `tol` comes from
+the parity budget of its MAPS: every bin within 1e-10 relative of the all-pairs
+evaluation, the sparsest bins included (`KDE_STAGE_TOL`).
 """
 import os
 
@@ -24,7 +26,14 @@ from pisa_amd.core.binning import MultiDimBinning, OneDimBinning
 from pisa_amd.core.stage import Stage
 from pisa_amd.utils import kde_hist
 
-__all__ = ["kde"]
+__all__ = ["kde", "KDE_STAGE_TOL"]
+
+# Cut-off of the stage's estimators.  Measured against the all-pairs evaluation (tol = 0) on the C3 workload (1e7 events, 24
+# estimators, 2 400 bins spanning 8 decades of content; scripts/dev/kde_tol_budget.py, EXPERIMENTS R5-3), largest relative
+# difference of any bin: 1.3e-13 at tol = 1e-14 (rounding), 4.9e-13 at 1e-13, 6.2e-12 at 1e-12, 6.3e-11 at 1e-11,
+# 4.5e-10 at 1e-10.  1e-12 keeps a factor 16 to the 1e-10 budget; 1e-11 would keep 1.6.  (The estimator objects
+# themselves -- `kernels.KdeEstimator`, `kde_hist.gaussian_kde` -- keep 1e-14.)
+KDE_STAGE_TOL = 1e-12
 
 
 class kde(Stage):  # pylint: disable=invalid-name
@@ -47,7 +56,7 @@ class kde(Stage):  # pylint: disable=invalid-name
         self.bootstrap = bootstrap
         self.bootstrap_niter = int(bootstrap_niter)
         self.bootstrap_seed = int(bootstrap_seed) if bootstrap_seed is not None else None
-        self.tol = None if tol is None else float(tol)
+        self.tol = KDE_STAGE_TOL if tol is None else float(tol)
         if self.bootstrap and self.oversample > 1:
             # errors inside a bin are highly correlated (kde_hist.py:67-70)
             raise ValueError("Bootstrapping cannot be combined with oversampling.")

@@ -190,3 +190,36 @@ def test_kde_stage_many_evaluations_same_bits_and_no_memory_growth():
     assert not np.array_equal(ref[42.0][0], ref[47.5][0])
     assert torch.cuda.memory_allocated() <= alloc_after_warmup + (8 << 20)
     assert torch.cuda.mem_get_info()[0] >= free_after_warmup - (64 << 20)
+
+
+def test_stage_cutoff_meets_the_parity_budget_of_its_maps():
+    """The stage's default cut-off (`KDE_STAGE_TOL`, round 5) is chosen from the parity budget of the MAPS: every bin of
+    every map -- the sparsest included -- within 1e-10 relative of the all-pairs evaluation (tol = 0).  C3-shaped pipeline
+    (12 containers x 2 pid channels, 10 x 10 x 2 bins, oversample 10) at 3e5 events; 1e7 events: scripts/dev/kde_tol_budget.py."""
+    import torch
+
+    from pisa_amd.core.config_parser import parse_pipeline_config
+    from pisa_amd.core.pipeline import Pipeline
+    from pisa_amd.stages.utils.kde import KDE_STAGE_TOL
+
+    def maps(tol):
+        cfg = parse_pipeline_config("settings/pipeline/example_hip.cfg")
+        out = OrderedDict()
+        for k, v in cfg.items():
+            if k == ("utils", "hist"):
+                out[("utils", "kde")] = OrderedDict(calc_mode="events", apply_mode=v["apply_mode"], **({} if tol is None else {"tol": tol}))
+            else:
+                out[k] = v
+        out["pipeline"]["output_key"] = "weights"
+        out[("data", "synthetic_events")]["params"].params.n_events.value = 3e5
+        pipe = Pipeline(out)
+        assert pipe["kde"].tol == (KDE_STAGE_TOL if tol is None else tol)
+        m = pipe.get_outputs()
+        torch.cuda.synchronize()
+        return np.stack([np.asarray(x.hist, dtype=np.float64) for x in m])
+
+    exact, default = maps(0.0), maps(None)
+    assert exact.min() > 0 and exact.min() / exact.max() < 1e-4      # bins over many decades of content
+    rel = np.abs(default - exact) / exact
+    assert rel.max() <= 1e-10, rel.max()
+    assert 0 < KDE_STAGE_TOL <= 1e-12
