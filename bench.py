@@ -42,10 +42,10 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 L3_BYTES = 256 * 2 ** 20
-ALL_LEGS = ("multi_point", "fit_c4_engine", "fit_c4", "osc_example_c1", "l3_exceeding", "exact_association", "coordinate_form", "fine_binning",
+ALL_LEGS = ("multi_point", "point_parallel", "fit_c4_engine", "fit_c4", "osc_example_c1", "l3_exceeding", "exact_association", "coordinate_form", "fine_binning",
             "update_flux", "node_flux", "pipeline_boundary", "icecube3y_boundary", "events_c2", "events_c2_decay", "events_c5", "events_c5_full", "kde_c3")
 # the legs that also run with N > 1 (every rank takes part: configs C4 and C5, the multi-point sweep)
-DIST_LEGS = ("multi_point", "fit_c4_engine", "fit_c4", "events_c5")
+DIST_LEGS = ("multi_point", "point_parallel", "fit_c4_engine", "fit_c4", "events_c5")
 
 
 def parse(argv=None):
@@ -866,6 +866,51 @@ def leg_multi_point(torch, st, wl, sync, reduce_max):
     return out
 
 
+def leg_point_parallel(make_state, st, wl, rank, world, state_kw, sync, reduce_max):
+    """Hybrid point x event parallelism (`engine.PointGroups`): the W ranks as G groups x R shards, the K points of an
+    `eval_many` call dealt to the groups, every point computed inside one group (the sample replicated on a group's one
+    rank, or sharded over its R ranks with the limb all-reduce inside the group), one all-gather of K doubles.  Measured
+    for G = W (sample replicated on every GPU) and, from four ranks on, G = W / 2 (two shards per group): 9 points per
+    group and call, evaluations per second of the whole job; the values are compared, bit for bit, with the event-sharded
+    engine's `eval_many` of the same points."""
+    from pisa_amd.engine import PointGroups
+
+    out = {}
+    nominal = wl.osc_params()
+    for n_groups in ([world, world // 2] if world >= 4 else [world]):
+        pg = PointGroups(rank, world, n_groups)
+        stp = make_state(wl, points=pg, **state_kw)
+        stp.make_pseudo_data(nominal, seed=0)
+        k = 9 * n_groups
+        plist = param_list(wl, 3 * k)
+        batches = [plist[i:i + k] for i in range(0, len(plist), k)]
+        for b in batches:
+            vals = stp.eval_many(b, "llh")
+        sync()
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            for b in batches:
+                vals = stp.eval_many(b, "llh")
+                n += k
+            sync()
+            dt = reduce_max(time.perf_counter() - t0)
+            if dt > 0.15:
+                break
+        want = st.eval_many(batches[-1], "llh")      # the event-sharded engine (one group of W shards), same points
+        out[pg.topology] = {"groups": n_groups, "shards_per_group": pg.n_shards, "points_per_call": k,
+                            "evals_per_s": n / dt, "us_per_point": 1e6 * dt / n,
+                            "same_bits_as_event_sharded": bool(vals == want)}
+        stp.check_status()
+        if hasattr(stp, "close"):
+            stp.close()
+        del stp
+    out["what"] = ("K = 9 G points per eval_many call dealt to G groups of R ranks (world rank = group R + shard); a group "
+                   "holds the whole sample (R = 1: replicated) or shards it (int64 limb all-reduce inside the group); one "
+                   "all-gather of K doubles; per point the single-GPU bits")
+    return out
+
+
 def leg_fit_engine(torch, st, wl, sync, reduce_max):
     """The C4 fit loop on the engine itself (no Pipeline / Param layer in between): scipy L-BFGS-B
     (eps 1e-4, ftol 2e-5, gtol 1e-5: the reference's l-bfgs-b settings) over (theta23, deltam31) rescaled
@@ -1288,6 +1333,11 @@ def main(argv=None, hooks=None):
             if name == "multi_point":
                 legs[name] = leg_multi_point(torch, st, wl, barrier, max_over_ranks) \
                     if (compact and index16 and not args.coordinate_form) else None
+            elif name == "point_parallel":
+                legs[name] = leg_point_parallel(make_state, st, wl, rank, world,
+                                                dict(indexed=not args.coordinate_form, sort_events=order, compact=compact,
+                                                     index16=index16), barrier, max_over_ranks) \
+                    if (dist_on and world > 1 and compact and index16 and not args.coordinate_form) else None
             elif name == "fit_c4_engine":
                 legs[name] = leg_fit_engine(torch, st, wl, barrier, max_over_ranks)
             elif name == "fit_c4":
@@ -1404,6 +1454,9 @@ def main(argv=None, hooks=None):
             "batched_evals_per_s3": (legs.get("multi_point") or {}).get("K3", {}).get("evals_per_s"),
             "batched_evals_per_s5": (legs.get("multi_point") or {}).get("K5", {}).get("evals_per_s"),
             "batched_evals_per_s9": (legs.get("multi_point") or {}).get("K9", {}).get("evals_per_s"),
+            # hybrid point x event parallelism (engine.PointGroups): the stencil's points dealt to groups of ranks
+            "topology": "%dx1" % world if (legs.get("point_parallel") or {}).get("%dx1" % world) else "1x%d" % world,
+            "point_parallel_evals_per_s": ((legs.get("point_parallel") or {}).get("%dx1" % world) or {}).get("evals_per_s"),
             "unbinned_events_dropped": dropped,
             "phase_ms": {"prob3_grid": t_prob3, "fused_reweight_hist": 1e3 * fused_avg_s, "finalize_metric": t_tail,
                          "allreduce": t_allreduce, "events_this_rank": st.n_local},

@@ -254,13 +254,19 @@ def test_kde_stage_map_exchange_on_gloo_ranks(tmp_path, world):
 #      several ranks, the JSON line) and HotPathEngine.eval_many's (one all-reduce of K limb sets, chunking)
 #      on CPU ranks over gloo: the HIP launches are replaced by host stand-ins, everything else is the
 #      product's / the bench's code
-def _make_bench_state(wl, rank=0, world_size=1, **_kw):
+def _make_bench_state(wl, rank=0, world_size=1, points=None, **_kw):
     from pisa_amd.engine import HotPathEngine, allreduce_limbs, float_to_limbs, limbs_to_float, local_slices
+
+    group = None
+    if points is not None:   # hybrid point x event topology: the engine sees its coordinates inside its group
+        kw = points.engine_kwargs()
+        rank, world_size, group = kw["rank"], kw["world_size"], kw["group"]
 
     class CpuState(HotPathEngine):
         def __init__(self):  # pylint: disable=super-init-not-called
             self.dev = torch.device("cpu")
-            self.rank, self.world_size, self.group, self._rccl = rank, world_size, None, None
+            self.rank, self.world_size, self.group, self._rccl = rank, world_size, group, None
+            self.points = points
             self.wl = wl
             self.names = [ev["name"] for ev in wl.events]
             self.cont = list(wl.events)
@@ -353,7 +359,7 @@ def _bench_worker(rank, world, port, out_path):
     got = {}
     bench.main(["--gpus", str(world), "--events", "360", "--steps", "3", "--warmup", "1", "--min-timed-s", "0",
                 "--grid", "12x8", "--legs", "all"],
-               hooks=dict(device_state=_make_bench_state, legs=("multi_point", "fit_c4_engine"), result=got.update))
+               hooks=dict(device_state=_make_bench_state, legs=("multi_point", "point_parallel", "fit_c4_engine"), result=got.update))
     if rank == 0:
         with open(out_path, "w") as fh:
             json.dump(got, fh)
@@ -372,7 +378,10 @@ def test_bench_multi_gpu_control_flow_on_gloo_ranks(tmp_path):
     line = json.load(open(out))
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["steps"] == 3 and line["warmup"] == 1
     assert line["unit"] == "evals/s" and line["value"] > 0 and line["weak_value"] > 0
-    assert set(line["legs"]) == {"multi_point", "fit_c4_engine"}
+    assert set(line["legs"]) == {"multi_point", "point_parallel", "fit_c4_engine"}
+    pp = line["legs"]["point_parallel"]["2x1"]         # two groups of one rank: the sample replicated, 18 points dealt 9 + 9
+    assert pp["same_bits_as_event_sharded"] and pp["points_per_call"] == 18 and pp["evals_per_s"] > 0
+    assert line["topology"] == "2x1" and line["point_parallel_evals_per_s"] == pp["evals_per_s"]
     fit = line["legs"]["fit_c4_engine"]
     assert fit["same_history"] and fit["point_by_point"]["llh_evaluations"] == fit["stencil_in_one_sweep"]["llh_evaluations"]
     mpt = line["legs"]["multi_point"]
@@ -395,6 +404,66 @@ def test_bench_multi_gpu_control_flow_on_gloo_ranks(tmp_path):
     pts = bench.param_list(wl, _lib.MAX_POINTS + 2)
     assert single.eval_many(pts, "llh") == [single.eval_host(p, "llh") for p in pts]
     assert single.sweeps == 2
+
+
+def _point_groups_worker(rank, world, port, n_groups, out_dir):
+    import sys
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from pisa_amd import synthetic
+    from pisa_amd.engine import PointGroups
+
+    pg = PointGroups(rank, world, n_groups)
+    assert pg.topology == "%dx%d" % (n_groups, world // n_groups)
+    wl = synthetic.Workload(n_events=360, grid=(12, 8), out_binning="dragon", seed=0)
+    st = _make_bench_state(wl, points=pg)
+    assert (st.rank, st.world_size) == (rank % (world // n_groups), world // n_groups)
+    st.make_pseudo_data(wl.osc_params(), seed=0)     # (inside the group: sharded + reduced over its ranks only)
+    out = {}
+    for k in (1, 2, 5, 7):
+        pts = bench.param_list(wl, k)
+        sweeps = st.sweeps
+        out["K%d" % k] = st.eval_many(pts, "llh")
+        lo, hi = pg.block(k)
+        assert st.sweeps - sweeps == (1 if hi - lo > 1 else 0)     # this group's block in ONE sweep of its events
+    np.save(os.path.join(out_dir, "r%d.npy" % rank), np.array([out["K%d" % k] for k in (1, 2, 5, 7)], dtype=object),
+            allow_pickle=True)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_groups", [1, 2, 4])
+def test_point_groups_deal_points_and_keep_the_single_rank_bits(tmp_path, n_groups):
+    """Hybrid point x event parallelism (`engine.PointGroups`): four gloo ranks as 1 x 4 (event sharding alone), 2 x 2 and
+    4 x 1 (the sample replicated, points dealt); `eval_many` of 1, 2, 5 and 7 points returns on EVERY rank the list one
+    rank computes on the whole sample, bit for bit (a point is evaluated entirely inside one group; integer limbs)."""
+    import sys
+
+    mp.spawn(_point_groups_worker, args=(4, _free_port(), n_groups, str(tmp_path)), nprocs=4, join=True)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from pisa_amd import synthetic
+
+    wl = synthetic.Workload(n_events=360, grid=(12, 8), out_binning="dragon", seed=0)
+    single = _make_bench_state(wl)
+    single.make_pseudo_data(wl.osc_params(), seed=0)
+    want = [[single.eval_host(p, "llh") for p in bench.param_list(wl, k)] for k in (1, 2, 5, 7)]
+    for rank in range(4):
+        got = np.load(str(tmp_path / ("r%d.npy" % rank)), allow_pickle=True)
+        for g, w_ in zip(got, want):
+            assert list(g) == w_
+    from pisa_amd.engine import PointGroups
+
+    with pytest.raises(ValueError):
+        PointGroups(0, 4, 3)
+    pg = PointGroups(3, 4, 2, make_group=lambda ranks: tuple(ranks))
+    assert (pg.group_id, pg.shard, pg.shard_group) == (1, 1, (2, 3))
+    assert [pg.block(7, g) for g in range(2)] == [(0, 3), (3, 7)]
 
 
 def bench_hooks():

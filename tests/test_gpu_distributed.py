@@ -21,12 +21,16 @@ def share_device_hooks():
     return dict(share_device=True, legs=())
 
 
-def _bench(gpus, hooks=True):
+def share_device_hooks_points():
+    return dict(share_device=True, legs=("point_parallel",))
+
+
+def _bench(gpus, hooks=True, legs="none"):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--events", "2400000", "--steps", "6",
-           "--warmup", "2", "--min-timed-s", "0", "--legs", "none", "--no-cpu-baseline", "--no-drop-probe", "--no-batch-probe"]
+           "--warmup", "2", "--min-timed-s", "0", "--legs", legs, "--no-cpu-baseline", "--no-drop-probe", "--no-batch-probe"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     if hooks:
-        env["PISA_BENCH_HOOKS"] = "tests.test_gpu_distributed:share_device_hooks"
+        env["PISA_BENCH_HOOKS"] = "tests.test_gpu_distributed:share_device_hooks" + ("_points" if legs != "none" else "")
     env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-4000:]
@@ -46,6 +50,19 @@ def test_two_and_four_ranks_on_one_device_reproduce_the_single_rank_bits():
         assert line["last_llh"] == one["last_llh"], (n, line["last_llh"], one["last_llh"])
         assert line["weak"]["samples_per_step"] == n and line["weak"]["value"] > 0
         assert line["phase_ms"]["events_this_rank"] * n >= 2399990 and line["nccl_comm_count"] is None    # gloo here
+
+
+def test_point_groups_on_one_device_reproduce_the_single_rank_bits():
+    """Hybrid point x event parallelism (`engine.PointGroups`, round 5) with the real kernels: four ranks on HIP device 0 as
+    4 x 1 (the sample replicated per rank, 36 points dealt 9 each) and 2 x 2 (two shards per group, the limb all-reduce
+    inside the group): the values every rank holds after the all-gather are, bit for bit, those of the event-sharded
+    engine on the same points -- which are the single-rank bits (the test above)."""
+    line = _bench(4, legs="point_parallel")
+    pp = line["legs"]["point_parallel"]
+    assert set(pp) >= {"4x1", "2x2"}
+    for topo, k in (("4x1", 36), ("2x2", 18)):
+        assert pp[topo]["same_bits_as_event_sharded"] is True and pp[topo]["points_per_call"] == k and pp[topo]["evals_per_s"] > 0
+    assert line["topology"] == "4x1" and line["point_parallel_evals_per_s"] == pp["4x1"]["evals_per_s"]
 
 
 def test_random_shardings_on_one_device_reproduce_the_single_rank_bits():
