@@ -200,25 +200,30 @@ def sockets_of_team(n_threads):
     return sorted(set(pk))
 
 
-def llh_gate(data, lam, device_llh, oracle_llh):
-    """which gate the device LLH meets against the oracle's: the north star's pure 1e-10 relative one, or only
-    the rounding floor of the reference's formula  llh = sum_b k ln(lam) - lam - (k ln k - k)  (stats.py:169-253),
-    a difference of terms orders of magnitude larger than the total: 8 eps sum_b (|k ln lam| + lam + |k ln k| + k)"""
+def llh_gate(data, lam, device_llh, oracle_llh, device_hist=None):
+    """Which gate the device LLH of the line's last point meets against the oracle's.  `pure_1e-10_relative_met` is the
+    headline pass / fail field: the north star's 1e-10 on the two fp64 numbers.  Where it is not met -- the reference's
+    formula  llh = sum_b k ln(lam) - lam - (k ln k - k)  (stats.py:169-253) cancels terms orders of magnitude larger than the
+    total, so two correct fp64 evaluations differ by ulps of the TERMS -- the extended-precision referee
+    (`oracle/referee.py`, round 5; round 4: a floor of 8 eps sum|terms|) says whether the MAPS agree to 1e-10 (the formula in
+    np.longdouble on the device's and the oracle's summed map) and each fp64 value is a correctly rounded evaluation (within
+    2 eps sum|terms| of the extended value on its own map)."""
     import numpy as np
 
-    k = np.asarray(data, dtype=np.float64).ravel()
-    lam = np.asarray(lam, dtype=np.float64).ravel()
-    with np.errstate(divide="ignore", invalid="ignore"):
-        klk = np.where(k > 0, np.abs(k * np.log(np.where(k > 0, k, 1.0))), 0.0)
-        terms = np.abs(k * np.log(lam)) + lam + klk + k
-    floor = 8 * np.finfo(np.float64).eps * float(terms.sum())
     diff = abs(device_llh - oracle_llh)
     pure = diff <= 1e-10 * abs(oracle_llh)
-    return {"abs_diff": diff, "pure_1e-10_relative_met": bool(pure), "term_floor": floor,
-            "applied": "1e-10 relative" if pure else ("term floor (8 eps sum |terms|)" if diff <= floor else "NONE MET")}
+    out = {"abs_diff": diff, "pure_1e-10_relative_met": bool(pure), "applied": "1e-10 relative" if pure else "NONE MET"}
+    if device_hist is not None:
+        from oracle.referee import llh_referee
+
+        lam_dev = np.asarray(device_hist, dtype=np.float64).reshape(-1, np.asarray(lam).size).sum(axis=0)
+        ref = llh_referee(data, lam_dev, lam, device_llh, oracle_llh)
+        out["referee"] = ref
+        out["applied"] = ref["applied"]
+    return out
 
 
-def cpu_baseline_subprocess(args, n_e, n_cz, data, matrices, device_llh):
+def cpu_baseline_subprocess(args, n_e, n_cz, data, matrices, device_llh, device_hist=None):
     """`cpu_baseline` in a process of its own: its OpenMP team is pinned one thread per core
     (OMP_PLACES=cores, OMP_PROC_BIND=close), which must not reach this process -- the runtime would pin
     the main thread as well and every helper thread the HIP runtime starts afterwards inherits that mask
@@ -231,6 +236,7 @@ def cpu_baseline_subprocess(args, n_e, n_cz, data, matrices, device_llh):
     with tempfile.TemporaryDirectory(prefix="pisa_cpu_baseline_") as tmp:
         path = os.path.join(tmp, "in.npz")
         np.savez(path, data=data, device_llh=device_llh, events=int(args.events), grid=[n_e, n_cz],
+                 device_hist=np.zeros(0) if device_hist is None else np.asarray(device_hist, dtype=np.float64),
                  cores=list(physical_cores()),     # counted here: the worker's main thread is pinned
                  **{"m_" + k: np.asarray(v) for k, v in matrices.items()})
         env = dict(os.environ, OMP_PLACES="cores", OMP_PROC_BIND="close")
@@ -249,10 +255,11 @@ def cpu_baseline_worker(path, binning):
                             seed=0)
     m = {k[2:]: z[k] for k in z.files if k.startswith("m_")}
     m["decay_flag"] = int(m["decay_flag"])
-    print(json.dumps(cpu_baseline(wl, z["data"], m, float(z["device_llh"]), tuple(int(v) for v in z["cores"]))))
+    dev_hist = z["device_hist"] if "device_hist" in z.files and z["device_hist"].size else None
+    print(json.dumps(cpu_baseline(wl, z["data"], m, float(z["device_llh"]), tuple(int(v) for v in z["cores"]), dev_hist)))
 
 
-def cpu_baseline(wl, data, matrices, device_llh, cores_logical=None):
+def cpu_baseline(wl, data, matrices, device_llh, cores_logical=None, device_hist=None):
     """The oracle (C restatement of the reference algorithms) timed on this box's host cores on the
     WHOLE workload -- full calc grid and all events, nothing scaled from a sample:
       * all physical cores (the reference's TARGET='parallel'): prob3 grid under OpenMP + every
@@ -1241,6 +1248,8 @@ def main(argv=None, hooks=None):
     mats_last = dict(wl.last_matrices)     # of plist[-1], the point whose LLH the line reports
     dt, llh = timed_loop(st, plist)
     headline_blocks = timed_loop.blocks
+    # the device's maps of the last timed point (12 x n_bins doubles): what the LLH referee compares with the oracle's
+    dev_hist_last = st.maps()[0] if (cuda and not args.no_cpu_baseline and world == 1) else None
     lib = _lib.lib() if cuda else None
     d_out = len(wl.ob["nbins"])
     bpe = bytes_per_event(st, args.coordinate_form, compact, d_out)
@@ -1450,6 +1459,9 @@ def main(argv=None, hooks=None):
             "last_llh": llh,
             "llh_bits_per_rank": llh_bits,
             "llh_bits_identical": None if llh_bits is None else len(set(llh_bits)) == 1,
+            # test-only stand-ins (PISA_BENCH_HOOKS / hooks=): a line produced with them says so
+            "hooks_used": hooks is not None,
+            "share_device": share,
             "pipelined_evals_per_s": pipelined,
             "batched_evals_per_s3": (legs.get("multi_point") or {}).get("K3", {}).get("evals_per_s"),
             "batched_evals_per_s5": (legs.get("multi_point") or {}).get("K5", {}).get("evals_per_s"),
@@ -1481,7 +1493,7 @@ def main(argv=None, hooks=None):
             "legs": legs,
         }
         if not args.no_cpu_baseline and world == 1:
-            cb = cpu_baseline_subprocess(args, n_e, n_cz, st.data.cpu().numpy(), mats_last, llh)
+            cb = cpu_baseline_subprocess(args, n_e, n_cz, st.data.cpu().numpy(), mats_last, llh, dev_hist_last)
             out["cpu_baseline"] = cb
             # the bench's last headline point against the oracle on identical inputs (north star: <= 1e-10)
             out["oracle_llh"], out["llh_rel_diff"] = cb["oracle_llh"], cb["llh_rel_diff"]

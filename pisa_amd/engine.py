@@ -406,6 +406,30 @@ class PointGroups:
         return out
 
 
+_POINT_GROUPS = {"n": 0, "obj": None}
+
+
+def configure_point_groups(n_groups):
+    """Topology of the engines that stages build for themselves (`stages/utils/hist.py`): 0 / 1 = event sharding over the
+    whole torch.distributed world (the default, north star), G > 1 = G groups of world / G ranks with the points of
+    `eval_many` -- the stencil of `Analysis.fit_hypo(batched_gradient=True)` -- dealt to the groups.  Call on every rank,
+    after `init_process_group`, before the first evaluation."""
+    _POINT_GROUPS["n"], _POINT_GROUPS["obj"] = int(n_groups), None
+
+
+def configured_points():
+    """the PointGroups of this rank under `configure_point_groups`, or None"""
+    if _POINT_GROUPS["n"] <= 1:
+        return None
+    if _POINT_GROUPS["obj"] is None:
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized()):
+            return None
+        _POINT_GROUPS["obj"] = PointGroups(dist.get_rank(), dist.get_world_size(), _POINT_GROUPS["n"])
+    return _POINT_GROUPS["obj"]
+
+
 class HotPathEngine:
     """See module docstring.  `containers` is a list of dicts with keys
     name, flav, nubar, true_energy, true_coszen, nu_flux[n,2], weighted_aeff,

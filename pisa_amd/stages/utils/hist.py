@@ -179,9 +179,11 @@ class hist(Stage):  # pylint: disable=invalid-name
                 evs.append(ev)
             # compact columns: initial_weights*weighted_aeff folded into the flux pair once
             # (refreshed by update_flux below whenever a flux systematic moved)
+            from pisa_amd.engine import configured_points
+
             self._engine = HotPathEngine(evs, grid, self._reg_binning, None, 0, rank=rank,
                                          world_size=world, external_tables=True, compact=True,
-                                         node_flux=node_flux)
+                                         node_flux=node_flux, points=configured_points())
             self._engine_versions = [{k: c.version(k) for k in static_keys + (flux_key,)}
                                      for c in conts]
             self._node_flux_src = (flux_key, cm) if node_flux else None

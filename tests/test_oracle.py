@@ -358,3 +358,32 @@ def test_kde_criterion_diagnosis_table():
             assert ok, name         # round 5: three mutually exclusive forms pass -> the criterion singles out none
         else:
             assert not ok, name
+
+
+def test_llh_referee_separates_map_error_from_log_rounding():
+    """oracle/referee.py (round 5): the reference's llh formula (stats.py:169-253) in extended precision.  Two fp64
+    evaluations on maps that agree to 1e-13 differ by more than 1e-10 of the total (terms of 1e6 cancel to -60) and are
+    accepted by the referee -- maps within 1e-10 in extended precision, each fp64 value within 2 eps sum|terms| of its own
+    extended value --; a map that is off by 1e-8 relative, or an LLH that is off by more than rounding, is not."""
+    from oracle.referee import EPS, llh_extended, llh_referee
+
+    rs = np.random.RandomState(0)
+    lam = rs.rand(128) * 1e6 + 1e5
+    k = rs.poisson(lam).astype(np.float64)
+    k[:3] = 0.0                                     # empty data bins: the term is -lam (masked k ln k)
+    lam2 = lam * (1 + 1e-13 * rs.randn(128))
+
+    def f(x):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return float(np.nansum(k * np.log(x) - x - (k * np.log(k) - k)))
+
+    ext, terms, rms = llh_extended(k, lam)
+    assert abs(f(lam) - ext) <= 2 * EPS * terms and rms <= terms and abs(ext) < 1e-5 * terms
+    ok = llh_referee(k, lam2, lam, f(lam2), f(lam))
+    assert ok["met"] and ok["maps"]["met"] and ok["device_evaluation"]["met"] and ok["oracle_evaluation"]["met"]
+    bad_map = llh_referee(k, lam * (1 + 1e-8), lam, f(lam * (1 + 1e-8)), f(lam))
+    assert not bad_map["maps"]["met"] and not bad_map["met"] and bad_map["applied"] == "NONE MET"
+    bad_eval = llh_referee(k, lam2, lam, f(lam2) + 1e-5, f(lam))
+    assert bad_eval["maps"]["met"] and not bad_eval["device_evaluation"]["met"] and not bad_eval["met"]
+    exact = llh_referee(k, lam, lam, f(lam), f(lam))
+    assert exact["pure_1e-10_relative_met"] and exact["applied"].startswith("1e-10 relative")
