@@ -37,16 +37,17 @@ def _log_ext(x):
 
 
 def llh_extended(data, lam):
-    """the reference's llh formula in extended precision (terms with k = 0 are -lam: the masked k ln k of stats.py:245)
-    -> (value as float, sum of |terms| as float, sqrt(sum terms^2) as float)"""
+    """the reference's llh formula in extended precision -> (value as float, sum of |terms| as float, sqrt(sum terms^2) as
+    float).  A bin with k = 0 contributes NOTHING: 0 * log(0) is NaN in stats.py:249 and map.py:1604 sums with np.nansum
+    (the whole bin, its -lam included, drops out)."""
     ld = np.longdouble
     k = np.asarray(data, dtype=np.float64).ravel()
     lam = np.maximum(np.asarray(lam, dtype=np.float64).ravel(), 1e-10)     # SMALL_POS, stats.py:40
     pos = k > 0
     ln_lam, ln_k = _log_ext(lam), _log_ext(np.where(pos, k, 1.0))
     kl = k.astype(ld)
-    t1 = kl * ln_lam
-    t2 = lam.astype(ld)
+    t1 = np.where(pos, kl * ln_lam, ld(0.0))
+    t2 = np.where(pos, lam.astype(ld), ld(0.0))
     t3 = np.where(pos, kl * ln_k, ld(0.0))
     total = (t1 - t2 - (t3 - kl)).sum()
     mags = np.abs(t1) + t2 + np.abs(t3) + kl

@@ -370,7 +370,7 @@ def test_llh_referee_separates_map_error_from_log_rounding():
     rs = np.random.RandomState(0)
     lam = rs.rand(128) * 1e6 + 1e5
     k = rs.poisson(lam).astype(np.float64)
-    k[:3] = 0.0                                     # empty data bins: the term is -lam (masked k ln k)
+    k[:3] = 0.0                                     # empty data bins drop out (0 log 0 = NaN, np.nansum: map.py:1604)
     lam2 = lam * (1 + 1e-13 * rs.randn(128))
 
     def f(x):
