@@ -439,8 +439,23 @@ class HotPathEngine:
     def __init__(self, containers, grid, out_binning, earth, max_layers, rank=0, world_size=1,
                  group=None, indexed=True, planned=True, packed=True, sort_events=True,
                  external_tables=False, osc_mode="grid", drop_unbinned=False, compact=False, index16=True,
-                 lds_order=True, node_flux=False, block_order=True, points=None):
+                 lds_order=True, node_flux=False, block_order=True, points=None, time_setup=False):
         self.dev = K.device()
+        # `time_setup`: device-synchronised wall time of the phases of this constructor (host columns -> first evaluation
+        # ready) in `self.setup_ms`: upload / digitise / order / pack / plan (bench.py reports it; off: no synchronisation)
+        import time as _time
+
+        # ("upload" = what the launch stream still waits for the copies: they run beside the previous container's phases)
+        self.setup_ms = {"upload": 0.0, "digitise": 0.0, "order": 0.0, "pack": 0.0, "plan": 0.0} if time_setup else None
+        _t = [_time.perf_counter()]
+
+        def _phase(name):
+            if self.setup_ms is not None:
+                torch.cuda.synchronize()
+                now = _time.perf_counter()
+                self.setup_ms[name] += 1e3 * (now - _t[0])
+                _t[0] = now
+
         # hybrid point x event parallelism: `points` (a PointGroups) carries this rank's coordinates; the engine itself
         # only sees its group (rank = shard, world_size = shards per group) and deals the points of `eval_many`
         self.points = points
@@ -504,16 +519,56 @@ class HotPathEngine:
                 return x[sl].to(self.dev, torch.float64).clone()
             return K.to_device(np.asarray(x, dtype=np.float64)[sl])
 
-        for c, (lo, hi) in zip(containers, shards):
+        def upload(c, sl):
+            """this rank's slice of a container's columns in HBM (the calc-grid coordinates as (ln E, coszen): the log is
+            numpy's, on the host, so that the digitisation sees the reference's values)"""
+            e_col = column(c["true_energy"], sl)
+            lnE = torch.log(e_col) if torch.is_tensor(c["true_energy"]) else \
+                K.to_device(np.log(np.asarray(c["true_energy"], dtype=np.float64)[sl]))
+            cz = column(c["true_coszen"], sl)
+            flux_d = None if self.node_flux else column(c["nu_flux"], sl)
+            aeff_d = column(c["weighted_aeff"], sl)
+            w0_d = column(c["initial_weights"], sl)
+            cols = [column(col, sl) for col in c["sample"]]
+            return e_col, lnE, cz, flux_d, aeff_d, w0_d, cols
+
+        # The columns of container i + 1 cross PCIe (a second thread, a stream of its own) while container i is digitised
+        # and ordered on the launch stream: at 1e7 events 22 ms of copies beside 30 ms of ordering and packing instead of
+        # in front of them (round 5, bench.py `setup_ms`).
+        prefetch = torch.cuda.is_available() and len(containers) > 1
+        if prefetch:
+            from concurrent.futures import ThreadPoolExecutor
+
+            pool = ThreadPoolExecutor(max_workers=1)
+            side = torch.cuda.Stream(device=self.dev)
+
+            def upload_async(c, sl):
+                torch.cuda.set_device(self.dev)
+                with torch.cuda.stream(side):
+                    out = upload(c, sl)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                return out, ev
+
+            side.wait_stream(torch.cuda.current_stream())     # (columns generated in HBM: their producer has run)
+            pending = pool.submit(upload_async, containers[0], slice(*shards[0])) if containers else None
+        for ci, (c, (lo, hi)) in enumerate(zip(containers, shards)):
             sl = slice(lo, hi)
             self._slices.append((lo, hi))
             d = _lib.Container()
             d.n_events = hi - lo
             self.n_local += hi - lo
-            e_col = column(c["true_energy"], sl)
-            lnE = torch.log(e_col) if torch.is_tensor(c["true_energy"]) else \
-                K.to_device(np.log(np.asarray(c["true_energy"], dtype=np.float64)[sl]))
-            cz = column(c["true_coszen"], sl)
+            if prefetch:
+                (e_col, lnE, cz, flux_d, aeff_d, w0_d, cols), ev = pending.result()
+                pending = pool.submit(upload_async, containers[ci + 1], slice(*shards[ci + 1])) \
+                    if ci + 1 < len(containers) else None
+                main = torch.cuda.current_stream()
+                main.wait_event(ev)
+                for t in [e_col, lnE, cz, flux_d, aeff_d, w0_d] + cols:
+                    if t is not None:
+                        t.record_stream(main)      # allocated on the side stream, used (and freed) on this one
+            else:
+                e_col, lnE, cz, flux_d, aeff_d, w0_d, cols = upload(c, sl)
             gx, gy = (lnE, cz) if grid.energy_first else (cz, lnE)
             if self.node_flux:
                 fn = c["nu_flux_nodes"]
@@ -522,11 +577,7 @@ class HotPathEngine:
                 self._node_flux_t.append(fn)
                 d.d_pepmu = self._own_tables[len(self.cont)].data_ptr()
                 flux_d = torch.ones((hi - lo, 2), dtype=torch.float64, device=self.dev)
-            else:
-                flux_d = column(c["nu_flux"], sl)
-            aeff_d = column(c["weighted_aeff"], sl)
-            w0_d = column(c["initial_weights"], sl)
-            cols = [column(col, sl) for col in c["sample"]]
+            _phase("upload")
             node = obin = perm = None
             static_w = wflux = None
             part_starts, part_width = None, 0
@@ -557,6 +608,7 @@ class HotPathEngine:
                 # coordinates never change between evaluations: digitise once
                 node = K.event_indices([gx, gy], grid.binning)
                 obin = K.event_indices(cols, out_binning)
+                _phase("digitise")
                 if sort_events and hi - lo > 1:
                     # Event order inside a container is arbitrary and the exact
                     # accumulation makes the result independent of it, so the
@@ -588,6 +640,7 @@ class HotPathEngine:
                         sort_events != "bin" and self.n_bins * 96 <= 65536)):
                     perm = perm[lds_bank_order(obin[perm], window=4096, banks=32,
                                                per=4 if index16 else 2)]
+                _phase("order")
                 if drop_unbinned:
                     # an event outside the output binning (or outside the calc grid: P = 0)
                     # adds nothing to any map, whatever the parameters: the coordinates are
@@ -651,6 +704,7 @@ class HotPathEngine:
                             self._keep.append(wf)
                             d.d_weighted_flux = wf.data_ptr()
                             wflux = wf
+            _phase("pack")
             d.flav, d.nubar, d.scale = int(c["flav"]), int(c["nubar"]), float(c["scale"])
             self._static_w.append(static_w)
             self._wflux.append(wflux)
@@ -666,9 +720,14 @@ class HotPathEngine:
             self.prob_nubar = torch.empty((grid.size, 3, 3), dtype=torch.float64, device=self.dev)
             self.pepmu = torch.empty((2, 3, grid.size, 2), dtype=torch.float64, device=self.dev)
             self.plan = K.GridPlan(self.dens_d, self.dist_d) if planned else None
+        if prefetch:
+            pool.shutdown(wait=True)
         self._event_arr = (_lib.EventSet * len(self._event_sets))(*self._event_sets) \
             if self._event_sets else None
         self.ws = K.HistWorkspace(len(self.cont), self.n_bins, self.dev)
+        _phase("plan")
+        if self.setup_ms is not None:
+            self.setup_ms["total"] = sum(self.setup_ms.values())
         self.metric_out = torch.zeros(1, dtype=torch.float64, device=self.dev)
         self.metric_status = torch.zeros(1, dtype=torch.int32, device=self.dev)
         # [0]: the metric as the tail kernel leaves it; [0:4]: the four partial sums of its split form

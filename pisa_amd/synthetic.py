@@ -179,13 +179,13 @@ class DeviceState(HotPathEngine):
 
     def __init__(self, wl, rank=0, world_size=1, group=None, indexed=True, planned=True,
                  packed=True, sort_events=True, osc_mode="grid", drop_unbinned=False, compact=False,
-                 lds_order=True, index16=True, node_flux=False, block_order=True, points=None):
+                 lds_order=True, index16=True, node_flux=False, block_order=True, points=None, time_setup=False):
         super().__init__(wl.events, wl.grid, wl.out_binning, wl.layers.earth_struct(),
                          wl.layers.max_layers, rank=rank, world_size=world_size, group=group,
                          indexed=indexed, planned=planned, packed=packed, sort_events=sort_events,
                          osc_mode=osc_mode, drop_unbinned=drop_unbinned, compact=compact,
                          lds_order=lds_order, index16=index16, node_flux=node_flux, block_order=block_order,
-                         points=points)
+                         points=points, time_setup=time_setup)
         self.wl = wl
 
     def make_pseudo_data(self, params, seed=0):
