@@ -1511,6 +1511,11 @@ def main(argv=None, hooks=None):
                 "traffic_source": traffic_src,
                 "timing": "HIP events recorded on the launch stream around the kernel, inside the library",
                 "by_kernel_trace": trace_roofline(args, bpe * st.n_local) if not dist_on else None,
+                # the same kernel on 4 x the events (800 MB of columns: beyond the 256 MiB Infinity Cache, every byte from HBM):
+                # the HBM-true fraction beside `frac` (whose 200 MB of columns stay inside the Infinity Cache between launches)
+                "frac_beyond_l3": ((legs.get("l3_exceeding") or {}).get("roofline") or {}).get("frac"),
+                "beyond_l3": {k: ((legs.get("l3_exceeding") or {}).get("roofline") or {}).get(k) for k in ("achieved", "avg_launch_ms")}
+                if legs.get("l3_exceeding") else None,
             },
             "legs": legs,
         }
