@@ -350,7 +350,10 @@ def check(status):
 
 class Prob3ParamsBlock:
     """ONE parameter block rewritten in place point after point (a fit loop's serial path: the library copies the
-    block during the call).  Matrices that are the very objects handed over last time are not converted again."""
+    block during the call).  A matrix that is the very READ-ONLY ndarray handed over last time is not converted again
+    (anything that could have been edited in place -- a writeable array, a list, a wrapper object -- is converted at
+    every call).  `update` returns a VIEW of the one shared buffer: a caller that keeps several points needs
+    `Prob3Params.from_buffer_copy(block.update(...))` (as `FastPlan.metric_many` does)."""
 
     def __init__(self):
         self.buf = np.zeros(73, np.float64)
@@ -365,13 +368,13 @@ class Prob3ParamsBlock:
         buf[9:27] = mix if type(mix) is tuple else mix.reshape(9).view(np.float64)
         if mat_pot is not last[2]:
             buf[27:45] = np.ascontiguousarray(mat_pot, np.complex128).reshape(9).view(np.float64)
-            last[2] = mat_pot if not getattr(mat_pot, "flags", None) or not mat_pot.flags.writeable else None
+            last[2] = mat_pot if isinstance(mat_pot, np.ndarray) and not mat_pot.flags.writeable else None
         if mat_decay is not last[3]:
             buf[45:63] = np.ascontiguousarray(mat_decay, np.complex128).reshape(9).view(np.float64)
-            last[3] = mat_decay if not getattr(mat_decay, "flags", None) or not mat_decay.flags.writeable else None
+            last[3] = mat_decay if isinstance(mat_decay, np.ndarray) and not mat_decay.flags.writeable else None
         if lri_pot is not last[4]:
             buf[63:72] = np.asarray(lri_pot, np.float64).reshape(9)
-            last[4] = lri_pot if not getattr(lri_pot, "flags", None) or not lri_pot.flags.writeable else None
+            last[4] = lri_pot if isinstance(lri_pot, np.ndarray) and not lri_pot.flags.writeable else None
         if decay_flag != self._flag:
             buf[72:73].view(np.int64)[0] = int(decay_flag)
             self._flag = decay_flag
