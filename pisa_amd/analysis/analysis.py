@@ -154,6 +154,23 @@ def load_minimizer_settings(settings):
     return out
 
 
+BOUNDED_METHODS = ("l-bfgs-b", "slsqp", "tnc", "trust-constr", "cobyla", "cobyqa")
+
+
+def local_minimizer_arguments(ms, n_free, hypo_maker):
+    """bounds, constraints and options of the local scipy fit from minimiser settings `ms` -- ONE place for `fit_hypo` and
+    for the fit with an external penalty (they had drifted apart: bounds for cobyla / cobyqa, `constraints` left among
+    the options).  -> (method in lower case, options without "constraints", bounds or None, constraints or ())"""
+    method = ms["method"].lower()
+    options = dict(ms.get("options", {}))
+    # "constraints" among the options (analysis.py:1687-1696): SLSQP, COBYLA, trust-constr
+    constrs = options.pop("constraints", None) or []
+    if constrs:
+        constrs = scipy_constraints_to_callables([dict(c) for c in constrs], hypo_maker)
+    bounds = [(0.0, 1.0)] * n_free
+    return method, options, (bounds if method in BOUNDED_METHODS else None), (constrs or ())
+
+
 def scipy_constraints_to_callables(constr_dicts, hypo_maker):
     """constraints given as functions (or strings that evaluate to functions) of the ParamSet become functions of the
     rescaled free-parameter vector, in place (configure_scipy_minimization.py:274-302)"""
@@ -371,12 +388,7 @@ class Analysis:
             val = self._total_metric(data_dist, hypo, hypo_maker, metric)
             meta = OrderedDict(success=True, nit=0, nfev=0, message="Initial hypo matches data, no need for fit")
             return HypoFitResult(metric, val, hypo_maker.params, hypo, None, meta, 0)
-        method = ms["method"].lower()
-        options = dict(ms.get("options", {}))
-        # "constraints" among the options (analysis.py:1687-1696): SLSQP, COBYLA, trust-constr
-        constrs = options.pop("constraints", None) or []
-        if constrs:
-            constrs = scipy_constraints_to_callables([dict(c) for c in constrs], hypo_maker)
+        method, options, method_bounds, constrs = local_minimizer_arguments(ms, len(x0), hypo_maker)
         if (not constrs and batched_gradient and method in ("l-bfgs-b", "slsqp") and hasattr(hypo_maker, "metric_many")
                 and "jac" not in ms and "finite_diff_rel_step" not in options):
             # the step the method would use itself: `eps` (L-BFGS-B default 1e-8, SLSQP default sqrt(eps))
@@ -406,8 +418,7 @@ class Analysis:
         else:
             res = optimize.minimize(
                 fun=self._minimizer_callable, x0=x0, args=(hypo_maker, data_dist, metric, counter, history),
-                bounds=bounds if method in ("l-bfgs-b", "slsqp", "tnc", "trust-constr", "cobyla", "cobyqa") else None,
-                constraints=constrs or (), method=ms["method"], options=options)
+                bounds=method_bounds, constraints=constrs, method=ms["method"], options=options)
         hypo_maker._set_rescaled_free_params(np.clip(res.x, 0.0, 1.0))  # pylint: disable=protected-access
         hypo = hypo_maker.get_outputs(return_sum=True)
         val = self._sign(metric) * res.fun
@@ -653,14 +664,12 @@ class Analysis:
         if settings:
             ms.update(load_minimizer_settings(settings))
         x0 = np.array(hypo_maker.params.free._rescaled_values, dtype=np.float64)  # pylint: disable=protected-access
-        bounds = [(0.0, 1.0)] * len(x0)
         counter, history = Counter(), []
-        method = ms["method"].lower()
+        _, options, method_bounds, constrs = local_minimizer_arguments(ms, len(x0), hypo_maker)
         res = optimize.minimize(
             fun=self._minimizer_callable, x0=x0,
             args=(hypo_maker, data_dist, metric, counter, history, None, external_priors_penalty),
-            bounds=bounds if method in ("l-bfgs-b", "slsqp", "tnc", "trust-constr") else None,
-            method=ms["method"], options=dict(ms.get("options", {})))
+            bounds=method_bounds, constraints=constrs, method=ms["method"], options=options)
         hypo_maker._set_rescaled_free_params(np.clip(res.x, 0.0, 1.0))  # pylint: disable=protected-access
         hypo = hypo_maker.get_outputs(return_sum=True)
         meta = OrderedDict(success=bool(res.success), nit=int(getattr(res, "nit", -1)), nfev=int(res.nfev),

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <chrono>
+#include <thread>
 #include <vector>
 
 #include "common.hpp"
@@ -103,7 +104,11 @@ PISA_API int pisa_hip_evaluator_eval(pisa_hip_evaluator *ev, const pisa_hip_prob
             if (p[k] != p[k]) have = false;
         }
         if (have) break;
+#if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
+#else
+        std::this_thread::yield();
+#endif
         if ((it & 255u) == 255u && std::chrono::steady_clock::now() > t_end) break;
     }
     if (!have) {   // slow evaluation or a genuine NaN (negative input: the status word says so)

@@ -304,7 +304,8 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
         // (partitioned order: two windows -- a chunk may reach into a second partition -- and the partition
         // table in LDS: looking a partition up in global memory is a chain of dependent scalar loads, ~1 us each)
         const bool parts = QUAD && a.window > 0 && C.part_start;
-        if (parts && (int)threadIdx.x <= C.n_part) s_part[threadIdx.x] = C.part_start[threadIdx.x];   // behind the two windows
+        if (parts)   // behind the two windows (a strided fill: the table has up to PART_MAX + 1 entries whatever the block size)
+            for (int k = threadIdx.x; k <= C.n_part; k += nthreads) s_part[k] = C.part_start[k];
         for (int k = threadIdx.x; k < n_acc * (parts ? 2 : a.copies); k += nthreads) s_acc[k] = 0ull;
         if ((PACKED || QUAD) && a.window > 0 && !(QUAD && C.part_start)) {
             __shared__ int s_lo;
@@ -424,6 +425,13 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
         // behind the others); a third partition in one chunk recycles the older window behind a barrier.
         int part = -1, phase = 0;
         if (LDS_ACC && a.window > 0 && C.part_start) {
+            // the caller's table is taken on trust by the sweep below (an entry that decreases, or a last entry short of
+            // the container, would end the loop early and DROP events without a trace): checked here, status bit 2
+            if (threadIdx.x == 0 && lb == 0 && status) {
+                bool ok = s_part[0] == 0 && (int64_t)s_part[C.n_part] * 256 >= C.n;
+                for (int k = 0; k < C.n_part; k++) ok = ok && s_part[k] <= s_part[k + 1];
+                if (!ok) atomicOr(status, 2);
+            }
             part = 0;
             while (part + 1 < C.n_part && (int64_t)s_part[part + 1] * 256 <= start) part++;
         }

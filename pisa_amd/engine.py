@@ -912,6 +912,7 @@ class HotPathEngine:
         ev = self._evaluator
         if ev is not None:
             _lib.check(_lib.lib().pisa_hip_evaluator_set_scale(ev["handle"], i, float(scale)))
+            ev["key"] = ev["key"][:-1] + (hash(bytes(self._cont_arr)),)     # the snapshot moved with the array
 
     # -- one evaluation per C-ABI call (`pisa_hip_evaluator_*`) --------------
     def _evaluator_for(self):
@@ -932,9 +933,13 @@ class HotPathEngine:
                 return None
             fn = C.cast(self._rccl.lib.ncclAllReduce, C.c_void_p)
             comm = self._rccl.comm
-        key = (self.pepmu.data_ptr(), self.ws.limbs.data_ptr(), self.ws.hist.data_ptr(), self.plan.handle.value
-               if hasattr(self.plan.handle, "value") else self.plan.handle, self.energy_d.data_ptr(),
-               None if comm is None else comm.value, self.world_size)
+        # every buffer the evaluator was made from, and the container array it SNAPSHOTS (pisa_hip_evaluator_create copies
+        # it; `set_scale` keeps the copy and this signature in step): a change of the array that bypasses `set_scale`
+        # makes a new evaluator instead of running on stale pointers
+        key = (self.pepmu.data_ptr(), self.ws.limbs.data_ptr(), self.ws.hist.data_ptr(), self.ws.sumw2.data_ptr(),
+               self.ws.status.data_ptr(), self.metric_status.data_ptr(), self.metric_host.data_ptr(),
+               self.plan.handle.value if hasattr(self.plan.handle, "value") else self.plan.handle, self.energy_d.data_ptr(),
+               None if comm is None else comm.value, self.world_size, hash(bytes(self._cont_arr)))
         ev = self._evaluator
         if ev is not None and ev["key"] == key:
             return ev
@@ -1510,8 +1515,12 @@ class HotPathEngine:
         return st
 
     def check_status(self):
-        if int(self.ws.status.item()) != 0:
+        st = int(self.ws.status.item())
+        if st != 0:
             self.ws.status.zero_()
+            if st & 2:
+                raise ValueError("partition table of the resident order (pisa_hip_container::d_part_start) does not start at 0, "
+                                 "decreases or stops short of the container: events would have been dropped")
             raise OverflowError("event weight not finite or outside the accumulator range")
         st = int(self.metric_status.item())
         if st != 0:
