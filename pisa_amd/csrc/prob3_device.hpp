@@ -761,7 +761,10 @@ constexpr int PROB3_NF = 60;  // fields per record, decay form: M[3] (re,im) + Q
 constexpr int PROB3_NF_REDUCED = 18;  // without decay (see eigen_terms)
 
 // field(f) = value callback; f in [0, PROB3_NF)
-template <bool DECAY, bool FAST = false, class StoreFn>
+// LRI = false (event mode, chosen on the host when lri_pot is all zeros -- every configuration without a long-range
+// potential): the XL terms are not formed.  2E XL = 0 added nothing (x + 0 = x, and a fused ka XV + 0 rounds once like
+// the product): same bits; nine multiply-adds and eighteen scalar registers less per layer matrix.
+template <bool DECAY, bool FAST = false, bool LRI = true, class StoreFn>
 __device__ __forceinline__ void eigen_terms(const Prob3Side &S, const double (&dm)[3][3],
                                             const int32_t (&vac_order)[3], double energy, double rho,
                                             const StoreFn &store) {
@@ -776,12 +779,12 @@ __device__ __forceinline__ void eigen_terms(const Prob3Side &S, const double (&d
         // complex products per (E, rho).  Without decay X is Hermitian:
         //     X = [[x0, u, v], [conj u, x1, w], [conj v, conj w, x2]],
         // nine real numbers, and everything below works on them.
-        const double x0 = S.X0.m[0][0].re + (ka * S.XV.m[0][0].re + two_e * S.XL.m[0][0].re);
-        const double x1 = S.X0.m[1][1].re + (ka * S.XV.m[1][1].re + two_e * S.XL.m[1][1].re);
-        const double x2 = S.X0.m[2][2].re + (ka * S.XV.m[2][2].re + two_e * S.XL.m[2][2].re);
-        const cplx u = cadd(S.X0.m[0][1], cadd(cscale(ka, S.XV.m[0][1]), cscale(two_e, S.XL.m[0][1])));
-        const cplx v = cadd(S.X0.m[0][2], cadd(cscale(ka, S.XV.m[0][2]), cscale(two_e, S.XL.m[0][2])));
-        const cplx w = cadd(S.X0.m[1][2], cadd(cscale(ka, S.XV.m[1][2]), cscale(two_e, S.XL.m[1][2])));
+        const double x0 = S.X0.m[0][0].re + (LRI ? ka * S.XV.m[0][0].re + two_e * S.XL.m[0][0].re : ka * S.XV.m[0][0].re);
+        const double x1 = S.X0.m[1][1].re + (LRI ? ka * S.XV.m[1][1].re + two_e * S.XL.m[1][1].re : ka * S.XV.m[1][1].re);
+        const double x2 = S.X0.m[2][2].re + (LRI ? ka * S.XV.m[2][2].re + two_e * S.XL.m[2][2].re : ka * S.XV.m[2][2].re);
+        const cplx u = cadd(S.X0.m[0][1], LRI ? cadd(cscale(ka, S.XV.m[0][1]), cscale(two_e, S.XL.m[0][1])) : cscale(ka, S.XV.m[0][1]));
+        const cplx v = cadd(S.X0.m[0][2], LRI ? cadd(cscale(ka, S.XV.m[0][2]), cscale(two_e, S.XL.m[0][2])) : cscale(ka, S.XV.m[0][2]));
+        const cplx w = cadd(S.X0.m[1][2], LRI ? cadd(cscale(ka, S.XV.m[1][2]), cscale(two_e, S.XL.m[1][2])) : cscale(ka, S.XV.m[1][2]));
         const double uu = u.re * u.re + u.im * u.im, vv = v.re * v.re + v.im * v.im,
                      ww = w.re * w.re + w.im * w.im;
         const cplx vw = cmake(v.re * w.re + v.im * w.im, v.im * w.re - v.re * w.im);   // v conj(w)

@@ -60,11 +60,11 @@ struct EvArgs {
 // up to twelve (each 18 instructions).  Lengths, densities, the cache rule (the out-going segment
 // takes the in-going one's matrix iff their lengths agree to 1e-5, numba_osc_kernels.py:236-249) and
 // the order of the products are those of propagate_path_nested_lds: results are bit-identical.
-template <class E>
+template <bool LRI, class E>
 __device__ __forceinline__ void propagate_path_direct_lds(const Prob3Side &S, const double (&dm)[3][3],
                                                           const int32_t (&vac_order)[3], double energy,
                                                           const E &e, const PathGeom &g, bool ok,
-                                                          TLds T, double (&P)[9], int32_t *status) {
+                                                          TLds T, const double *s_uud, double (&P)[9], int32_t *status) {
     bool have = false;
     const double inv_energy = fast_rcp(energy);
     // Every layer matrix A' is in SU(3) (eigen_terms), so the running product T is as well: its third
@@ -75,7 +75,7 @@ __device__ __forceinline__ void propagate_path_direct_lds(const Prob3Side &S, co
     auto amplitude = [&](double rho, double dist, mat3 &A) {   // rows 0 and 1
         double rec[PROB3_NF_REDUCED];
         auto store = [&](int f, double v) { rec[f] = v; };
-        eigen_terms<false, true>(S, dm, vac_order, energy, rho, store);
+        eigen_terms<false, true, LRI>(S, dm, vac_order, energy, rho, store);
         auto load = [&](int f) { return rec[f]; };
         amplitude_from_terms<false>(load, dist * inv_energy, A);
     };
@@ -174,8 +174,20 @@ __device__ __forceinline__ void propagate_path_direct_lds(const Prob3Side &S, co
 #pragma unroll
         for (int j = 0; j < 3; j++) Tm.m[i][j] = have ? T.get(i, j) : cmake(0.0, 0.0);
     third_row(Tm.m[0], Tm.m[1], Tm.m[2]);
-    mat_mul(Tm, S.Ud, t2);
-    mat_mul(S.U, t2, Tf);
+    // U and U^dagger of the closing flavour-basis transform come back from LDS (staged by the kernel before the walk):
+    // as by-value kernel arguments they sat in 72 scalar registers across the whole layer loop, pushed the loop's own
+    // constants (X0, XV: 36 more) beyond the scalar register file, and every use inside the loop then began with a
+    // v_readlane from a spill lane -- 78 of the loop's 1 287 vector instructions (round 5, ISA count)
+    mat3 Um, Udm;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            Um.m[i][j] = cmake(s_uud[2 * (3 * i + j)], s_uud[2 * (3 * i + j) + 1]);
+            Udm.m[i][j] = cmake(s_uud[18 + 2 * (3 * i + j)], s_uud[18 + 2 * (3 * i + j) + 1]);
+        }
+    mat_mul(Tm, Udm, t2);
+    mat_mul(Um, t2, Tf);
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
@@ -183,7 +195,7 @@ __device__ __forceinline__ void propagate_path_direct_lds(const Prob3Side &S, co
             P[3 * i + j] = Tf.m[j][i].re * Tf.m[j][i].re + Tf.m[j][i].im * Tf.m[j][i].im;
 }
 
-template <bool DECAY, int SIDE, bool STAGED, int WAVES = 2>
+template <bool DECAY, int SIDE, bool STAGED, int WAVES = 2, bool LRI = true>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 prob3_events_kernel(const Prob3Consts c, const EarthDev earth, const EvArgs ev, int max_seg,
                     int32_t *__restrict__ status) {
@@ -211,6 +223,18 @@ prob3_events_kernel(const Prob3Consts c, const EarthDev earth, const EvArgs ev, 
         s_radii[k] = earth.radii[k];
         s_rhos[k] = earth.rhos[k];
         s_lim[k] = earth.coszen_limit[k];
+    }
+    __shared__ double s_uud[36];   // U, U^dagger of this side (re, im interleaved, row major): see propagate_path_direct_lds
+    if (WAVES > 2 && !DECAY && !STAGED && threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                s_uud[2 * (3 * i + j)] = c.side[SIDE].U.m[i][j].re;
+                s_uud[2 * (3 * i + j) + 1] = c.side[SIDE].U.m[i][j].im;
+                s_uud[18 + 2 * (3 * i + j)] = c.side[SIDE].Ud.m[i][j].re;
+                s_uud[18 + 2 * (3 * i + j) + 1] = c.side[SIDE].Ud.m[i][j].im;
+            }
     }
     __syncthreads();
     struct LdsEarth {
@@ -279,7 +303,7 @@ prob3_events_kernel(const Prob3Consts c, const EarthDev earth, const EvArgs ev, 
         };
         if (WAVES > 2 && !DECAY) {
             TLds T{s_len + lane, bd};
-            propagate_path_direct_lds(c.side[side], c.dm, vac_order, energy[i], e, g, ok, T, P, status);
+            propagate_path_direct_lds<LRI>(c.side[side], c.dm, vac_order, energy[i], e, g, ok, T, s_uud, P, status);
         } else if (WAVES > 2 || DECAY) {
             // decay: the reference-order layer matrices (layer_amplitude: complex eigenvalues, three full
             // projectors) need every register there is; the running product waits in LDS meanwhile
@@ -322,6 +346,12 @@ static int launch_events(const Prob3Consts &c, const EarthDev &e, const EvCont *
     if (force_staged) staged = true;   // development / test switch: the general form
     // direct form: 3 wavefronts per SIMD with the running product in LDS (see the kernel); 2: product in registers
     static const int waves_cfg = PISA_DEV_INT("EVENTS_WAVES", 3);
+    // a long-range potential at all?  (XL = U^dagger . lri . U of either side: all zeros without one)
+    bool has_lri = false;
+    for (int sd = 0; sd < 2; sd++)
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++)
+                if (c.side[sd].XL.m[i][j].re != 0.0 || c.side[sd].XL.m[i][j].im != 0.0) has_lri = true;
     size_t lds = 3 * PISA_HIP_MAX_SHELLS * sizeof(double) +
                  (staged ? (size_t)max_seg * threads * 10
                          : (c.decay ? (size_t)18 * threads * 8 : (waves_cfg > 2 ? (size_t)12 * threads * 8 : 0))) + 16;
@@ -346,7 +376,9 @@ static int launch_events(const Prob3Consts &c, const EarthDev &e, const EvCont *
                 else hipLaunchKernelGGL((prob3_events_kernel<true, 1, false, DECAY_WAVES>), grid, block, lds, s, c, e, a, max_seg, d_status);
             }
             else if (staged) LAUNCH_SIDE(false, true);
-            else if (waves_cfg == 3) { if (side == 0) hipLaunchKernelGGL((prob3_events_kernel<false, 0, false, 3>), grid, block, lds, s, c, e, a, max_seg, d_status); else hipLaunchKernelGGL((prob3_events_kernel<false, 1, false, 3>), grid, block, lds, s, c, e, a, max_seg, d_status); }
+            else if (waves_cfg == 4 && !has_lri) { if (side == 0) hipLaunchKernelGGL((prob3_events_kernel<false, 0, false, 4, false>), grid, block, lds, s, c, e, a, max_seg, d_status); else hipLaunchKernelGGL((prob3_events_kernel<false, 1, false, 4, false>), grid, block, lds, s, c, e, a, max_seg, d_status); }
+            else if (waves_cfg >= 3 && !has_lri) { if (side == 0) hipLaunchKernelGGL((prob3_events_kernel<false, 0, false, 3, false>), grid, block, lds, s, c, e, a, max_seg, d_status); else hipLaunchKernelGGL((prob3_events_kernel<false, 1, false, 3, false>), grid, block, lds, s, c, e, a, max_seg, d_status); }
+            else if (waves_cfg >= 3) { if (side == 0) hipLaunchKernelGGL((prob3_events_kernel<false, 0, false, 3>), grid, block, lds, s, c, e, a, max_seg, d_status); else hipLaunchKernelGGL((prob3_events_kernel<false, 1, false, 3>), grid, block, lds, s, c, e, a, max_seg, d_status); }
             else LAUNCH_SIDE(false, false);
 #undef LAUNCH_SIDE
 #undef LAUNCH_EV
