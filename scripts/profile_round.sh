@@ -193,3 +193,8 @@ print({k: round(v["timed_loop_mean_us"], 2) for k, v in phase.items() if k != "n
 PY
 rm -rf $OUT/pmc_c3 $OUT/pmc_c3_full.csv $OUT/stats $OUT/pmc_*_FETCH_SIZE $OUT/pmc_*_WRITE_SIZE $OUT/pmc_events_std $OUT/pmc_events_nsi $OUT/pmc_kde $OUT/kde_stats
 ls $OUT
+# keep the merged output small (gpurun copies back at most 64 MiB): logs of the profiler runs are not evidence
+find $OUT -name "*.log" -size +256k -delete
+rm -rf $GRAFT_REPO_ROOT/gpurun_out/kl $GRAFT_REPO_ROOT/gpurun_out/kde_pmc/pmc_*.csv
+du -sk $GRAFT_REPO_ROOT/gpurun_out/* | sort -n | tail -4
+du -sk $OUT/* | sort -n | tail -6

@@ -30,6 +30,10 @@ def test_header_symbols_all_exported(built):
         assert hasattr(handle, name), "symbol %s missing from libpisa_hip.so" % name
     # the binding covers the whole header
     assert declared == set(built.EXPORTED_SYMBOLS)
+    # and DESIGN.md quotes the count that is true today (it had drifted: "74 entry points" against 84)
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    quoted = re.search(r"`include/pisa_hip.h`, (\d+) entry points", design)
+    assert quoted and int(quoted.group(1)) == len(declared), (quoted and quoted.group(1), len(declared))
 
 
 def test_struct_layout_matches_header(built):
