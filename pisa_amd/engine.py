@@ -1416,7 +1416,9 @@ class HotPathEngine:
             return pg.gather(mine, n, self.dev)
         plan = plan or self.plan
         energy = energy if energy is not None else getattr(self, "energy_d", None)
-        if n == 1 or not self.multi_capable(plan):
+        # (a single point goes point by point where the engine has oscillation tables of its own; with the caller's plan
+        # -- a stage-built engine whose group was dealt one point of a stencil -- it takes the sweep path with K = 1)
+        if (n == 1 and self.plan is not None) or not self.multi_capable(plan):
             assert self.plan is not None, "point-by-point evaluation needs the engine's own oscillation tables"
             out = []
             for i, p in enumerate(params_list):
