@@ -263,6 +263,18 @@ int pisa_hip_hist_window_bins(int64_t n_bins);
  * that lays out the partitioned order: partitions that are whole numbers of a container's per-workgroup share
  * keep every workgroup inside one partition; any other layout is handled, only slower). */
 int pisa_hip_hist_workgroups(const int64_t *h_n_events, int32_t n_containers, int32_t *h_workgroups);
+/* The resident order of one container's events for the 16-bit index form (d_node_bin16 / d_weighted_flux_q): the
+ * permutation that gathers the events that can deposit (d_node >= 0 and d_bin >= 0: the digitised calc-grid node and output
+ * bin of every event, DEVICE int32[n]) into whole blocks of 256 -- sorted by node, dealt over the 32 LDS bank pairs inside
+ * windows of 4 096, the blocks spread evenly among the blocks of events that deposit nothing.  No counterpart in the
+ * reference (its events stay in file order; `container.py:981-1012` looks them up one by one): the sums are exact, so the
+ * order is this build's to choose, and it is part of the set-up a caller pays once per event sample.
+ * d_perm: DEVICE int64[n], out: position i of the resident order holds input event d_perm[i].  n_nodes: size of the calc
+ * grid (d_node < n_nodes).  Asynchronous on `stream`; d_work: DEVICE scratch of pisa_hip_deposit_block_order_workspace(n)
+ * bytes. */
+int64_t pisa_hip_deposit_block_order_workspace(int64_t n);
+int pisa_hip_deposit_block_order(const int32_t *d_node, const int32_t *d_bin, int64_t n, int64_t n_nodes,
+                                 int64_t *d_perm, void *d_work, int64_t work_bytes, void *stream);
 
 /* Fused  prob3.apply (prob3.py:621-622, with the grid->event lookup of
  * container.py:981-1012 / translation.py:427-438)  +  aeff.apply

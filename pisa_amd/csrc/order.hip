@@ -1,0 +1,171 @@
+// order.hip -- the resident ORDER of a container's events for the 16-bit index form of the fused kernel
+// (engine.deposit_block_order; the accumulation is exact, so the order is free to choose -- DESIGN section 3).
+//
+// What the order is (the torch formulation in pisa_amd/engine.py is the specification and stays the test's reference):
+//   1. events that can deposit (inside the output binning AND the calc grid) first, sorted by calc-grid node (gather
+//      locality), ties in input order; the others ("idle") behind them, sorted by node as well;
+//   2. inside whole windows of 4 096 depositing events: dealt round-robin over the 32 LDS bank pairs (bin mod 32) --
+//      sorted by (rank inside the (window, residue) queue, residue) -- and laid out so that 32 consecutive emissions land
+//      in the same slot of 32 consecutive quads (lds_bank_order with per = 4);
+//   3. the depositing blocks of 256 events (what one wavefront takes per sweep) spread evenly among the idle blocks.
+//
+// Round 5: the torch formulation costs ~40 launches, four sorts and two host synchronisations per container (2 ms per
+// 8.3e5 events: 24 ms of a 44 ms set-up at 1e7 events).  Here: one key per event, ONE stable radix sort on 17-18 bits,
+// one workgroup per window for step 2 (ballot ranks + a 32-entry table: no second and third sort), step 3 in closed form
+// inside the final write.  No host synchronisation: the number of depositing events stays on the device.
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.hpp"
+
+namespace pisa {
+
+constexpr int ORD_WINDOW = 4096, ORD_BANKS = 32, ORD_PER = 4, ORD_BLOCK = 256;
+
+// key: depositing events by node, idle events behind them by node (node = -1 first)
+__global__ void __launch_bounds__(256)
+order_key_kernel(const int32_t *__restrict__ node, const int32_t *__restrict__ bin, int64_t n, uint32_t n_nodes,
+                 uint32_t *__restrict__ key, uint32_t *__restrict__ val, unsigned long long *__restrict__ n_dep) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool dep = false;
+    if (i < n) {
+        const int32_t nd = node[i], b = bin[i];
+        dep = nd >= 0 && b >= 0;
+        key[i] = dep ? (uint32_t)nd : n_nodes + 1u + (uint32_t)(nd + 1);
+        val[i] = (uint32_t)i;
+    }
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(dep);
+    __shared__ unsigned int cnt[4];
+    if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = (unsigned int)__builtin_popcountll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int c = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+        if (c) atomicAdd(n_dep, (unsigned long long)c);    // (an integer count: order-independent)
+    }
+}
+
+// step 2: one workgroup per window of 4 096 sorted events
+__global__ void __launch_bounds__(1024)
+order_bank_kernel(const uint32_t *__restrict__ sorted, const int32_t *__restrict__ bin, int64_t n,
+                  const unsigned long long *__restrict__ n_dep_p, uint32_t *__restrict__ out) {
+    __shared__ unsigned short s_cnt[64 * ORD_BANKS];   // [chunk of 64 positions][residue]: count, then exclusive offset
+    __shared__ unsigned short s_tot[ORD_BANKS];
+    const int64_t base = (int64_t)blockIdx.x * ORD_WINDOW;
+    const int64_t n_dep = (int64_t)*n_dep_p;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (base + ORD_WINDOW > n_dep) {   // not a whole window of depositing events: kept as sorted
+        for (int p = threadIdx.x; p < ORD_WINDOW && base + p < n; p += 1024) out[base + p] = sorted[base + p];
+        return;
+    }
+    uint32_t v[4];
+    int res[4], rk[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int chunk = wave * 4 + c;
+        v[c] = sorted[base + chunk * 64 + lane];
+        res[c] = (int)((uint32_t)bin[v[c]] % ORD_BANKS);
+        rk[c] = 0;
+        for (int r = 0; r < ORD_BANKS; r++) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(res[c] == r);
+            if (res[c] == r) rk[c] = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+            if (lane == r) s_cnt[chunk * ORD_BANKS + r] = (unsigned short)__builtin_popcountll(m);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < ORD_BANKS) {     // exclusive prefix over the chunks, per residue
+        unsigned int run = 0;
+        for (int chunk = 0; chunk < 64; chunk++) {
+            const unsigned int c = s_cnt[chunk * ORD_BANKS + threadIdx.x];
+            s_cnt[chunk * ORD_BANKS + threadIdx.x] = (unsigned short)run;
+            run += c;
+        }
+        s_tot[threadIdx.x] = (unsigned short)run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int chunk = wave * 4 + c;
+        const int k = (int)s_cnt[chunk * ORD_BANKS + res[c]] + rk[c];     // rank inside the (window, residue) queue
+        // emission position: every residue's queue contributes its first min(len, k) events, the shorter residues of
+        // rank k come before this one
+        int s = 0;
+        for (int r = 0; r < ORD_BANKS; r++) {
+            const int len = (int)s_tot[r];
+            s += len < k ? len : k;
+            s += (r < res[c] && len > k) ? 1 : 0;
+        }
+        const int blk = s / (32 * ORD_PER), t = s % (32 * ORD_PER);
+        const int slot = ORD_PER * (blk * 32 + (t % 32)) + t / 32;
+        out[base + slot] = v[c];
+    }
+}
+
+// step 3 + the int64 permutation torch gathers with
+__global__ void __launch_bounds__(256)
+order_interleave_kernel(const uint32_t *__restrict__ seq, int64_t n, const unsigned long long *__restrict__ n_dep_p,
+                        int64_t *__restrict__ perm) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t t_full = n / ORD_BLOCK;
+    const int64_t n_dep = (int64_t)*n_dep_p;
+    int64_t nbb = (n_dep + ORD_BLOCK - 1) / ORD_BLOCK;
+    if (nbb > t_full) nbb = t_full;
+    const int64_t j = i / ORD_BLOCK, l = i % ORD_BLOCK;
+    int64_t src = j;
+    if (j < t_full && nbb > 0 && nbb < t_full) {
+        // depositing block q sits at output block floor(q t_full / nbb); the idle blocks fill the rest in order
+        const int64_t q = (j * nbb + t_full - 1) / t_full;          // depositing positions in front of block j
+        const bool is_b = q < nbb && (q * t_full) / nbb == j;
+        src = is_b ? q : nbb + (j - q);
+    }
+    perm[i] = (int64_t)seq[src * ORD_BLOCK + l];
+}
+
+static int order_key_bits(uint32_t n_nodes) {
+    int bits = 1;
+    while (bits < 32 && (1ull << bits) <= 2ull * n_nodes + 2ull) bits++;
+    return bits;
+}
+
+}  // namespace pisa
+
+using namespace pisa;
+
+PISA_API int64_t pisa_hip_deposit_block_order_workspace(int64_t n) {
+    if (n < 0 || n > 0x7FFFFFF0LL) return -1;
+    size_t temp = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, temp, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                                    (uint32_t *)nullptr, (size_t)n, 0u, 32u);
+    return (int64_t)(5 * (size_t)(n + ORD_WINDOW) * 4 + temp + 1024);
+}
+
+PISA_API int pisa_hip_deposit_block_order(const int32_t *d_node, const int32_t *d_bin, int64_t n, int64_t n_nodes,
+                                          int64_t *d_perm, void *d_work, int64_t work_bytes, void *stream) {
+    if (n < 0 || n > 0x7FFFFFF0LL || n_nodes < 1 || n_nodes > 0x3FFFFFFFLL) return PISA_HIP_ERR_INVALID;
+    if (n == 0) return PISA_HIP_OK;
+    if (!d_node || !d_bin || !d_perm || !d_work) return PISA_HIP_ERR_INVALID;
+    const int64_t need = pisa_hip_deposit_block_order_workspace(n);
+    if (need < 0 || work_bytes < need) return PISA_HIP_ERR_NOMEM;
+    hipStream_t s = as_stream(stream);
+    char *w = (char *)d_work;
+    unsigned long long *n_dep = (unsigned long long *)w;
+    const size_t stride = (size_t)(n + ORD_WINDOW) * 4;
+    uint32_t *key_a = (uint32_t *)(w + 256), *key_b = (uint32_t *)(w + 256 + stride);
+    uint32_t *val_a = (uint32_t *)(w + 256 + 2 * stride), *val_b = (uint32_t *)(w + 256 + 3 * stride);
+    uint32_t *seq = (uint32_t *)(w + 256 + 4 * stride);
+    char *temp = w + 256 + 5 * stride;
+    size_t temp_bytes = (size_t)work_bytes - (256 + 5 * stride);
+    PISA_TRY_HIP(hipMemsetAsync(n_dep, 0, 8, s));
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(order_key_kernel, dim3(nb), dim3(256), 0, s, d_node, d_bin, n, (uint32_t)n_nodes, key_a, val_a, n_dep);
+    PISA_TRY_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, key_a, key_b, val_a, val_b, (size_t)n, 0u,
+                                           (unsigned)order_key_bits((uint32_t)n_nodes), s));
+    hipLaunchKernelGGL(order_bank_kernel, dim3((unsigned)((n + ORD_WINDOW - 1) / ORD_WINDOW)), dim3(1024), 0, s, val_b,
+                       d_bin, n, n_dep, seq);
+    hipLaunchKernelGGL(order_interleave_kernel, dim3(nb), dim3(256), 0, s, seq, n, n_dep, d_perm);
+    PISA_CHECK_LAUNCH("deposit block order kernels");
+    return PISA_HIP_OK;
+}

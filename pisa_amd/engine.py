@@ -307,6 +307,30 @@ def deposit_block_order(obin, node, block=256, window=4096, banks=32):
     return torch.cat((body, seq[t_full * block:]))
 
 
+def deposit_block_order_native(obin, node, n_nodes):
+    """`deposit_block_order` in one native call (`pisa_hip_deposit_block_order`, csrc/order.hip): one key per event, one
+    stable radix sort, one workgroup per 4 096-event window for the bank order, the block interleave in closed form -- the
+    SAME permutation as the torch formulation above (tests/test_gpu_engine.py compares them element by element), without
+    its ~40 launches, four sorts and two host synchronisations per container."""
+    import ctypes as C
+
+    lib = _lib.lib()
+    n = int(obin.numel())
+    perm = torch.empty(n, dtype=torch.int64, device=obin.device)
+    if n == 0:
+        return perm
+    need = int(lib.pisa_hip_deposit_block_order_workspace(n))
+    if need < 0:
+        raise ValueError("too many events for one container's order: %d" % n)
+    work = torch.empty(need, dtype=torch.uint8, device=obin.device)
+    node32 = node if node.dtype == torch.int32 else node.to(torch.int32)
+    obin32 = obin if obin.dtype == torch.int32 else obin.to(torch.int32)
+    _lib.check(lib.pisa_hip_deposit_block_order(C.c_void_p(node32.contiguous().data_ptr()), C.c_void_p(obin32.contiguous().data_ptr()),
+                                                n, int(n_nodes), C.c_void_p(perm.data_ptr()), C.c_void_p(work.data_ptr()),
+                                                need, K._stream()))
+    return perm
+
+
 def local_slices(sizes, rank, world_size):
     """[(lo, hi)] of this rank's shard of every container (`sizes` = events per container): the
     partition `HotPathEngine` uses -- contiguous, equal to within one event, disjoint, complete"""
@@ -539,19 +563,24 @@ class HotPathEngine:
         if prefetch:
             from concurrent.futures import ThreadPoolExecutor
 
-            pool = ThreadPoolExecutor(max_workers=1)
-            side = torch.cuda.Stream(device=self.dev)
+            # three containers ahead: the host side of an upload (slicing, numpy's log of the energies: 3-5 ms per container,
+            # it releases the GIL) runs on three cores at once, the copies themselves queue on the link
+            AHEAD = 3
+            pool = ThreadPoolExecutor(max_workers=AHEAD)
+            sides = [torch.cuda.Stream(device=self.dev) for _ in range(AHEAD)]
 
-            def upload_async(c, sl):
+            def upload_async(k):
                 torch.cuda.set_device(self.dev)
+                side = sides[k % AHEAD]
                 with torch.cuda.stream(side):
-                    out = upload(c, sl)
+                    out = upload(containers[k], slice(*shards[k]))
                     ev = torch.cuda.Event()
                     ev.record(side)
                 return out, ev
 
-            side.wait_stream(torch.cuda.current_stream())     # (columns generated in HBM: their producer has run)
-            pending = pool.submit(upload_async, containers[0], slice(*shards[0])) if containers else None
+            for side in sides:
+                side.wait_stream(torch.cuda.current_stream())     # (columns generated in HBM: their producer has run)
+            pending = [pool.submit(upload_async, k) for k in range(min(AHEAD, len(containers)))]
         for ci, (c, (lo, hi)) in enumerate(zip(containers, shards)):
             sl = slice(lo, hi)
             self._slices.append((lo, hi))
@@ -559,9 +588,9 @@ class HotPathEngine:
             d.n_events = hi - lo
             self.n_local += hi - lo
             if prefetch:
-                (e_col, lnE, cz, flux_d, aeff_d, w0_d, cols), ev = pending.result()
-                pending = pool.submit(upload_async, containers[ci + 1], slice(*shards[ci + 1])) \
-                    if ci + 1 < len(containers) else None
+                (e_col, lnE, cz, flux_d, aeff_d, w0_d, cols), ev = pending.pop(0).result()
+                if ci + AHEAD < len(containers):
+                    pending.append(pool.submit(upload_async, ci + AHEAD))
                 main = torch.cuda.current_stream()
                 main.wait_event(ev)
                 for t in [e_col, lnE, cz, flux_d, aeff_d, w0_d] + cols:
@@ -633,7 +662,7 @@ class HotPathEngine:
                 blocked = (index16 and lds_order and block_order and perm is not None and sort_events == "node"
                            and self.n_bins * 96 <= 65536)
                 if blocked:
-                    perm = deposit_block_order(obin, node, window=4096, banks=32)
+                    perm = deposit_block_order_native(obin, node, grid.size)
                 elif part_starts is not None:
                     pass                      # (bank order applied inside the partitions)
                 elif lds_order and perm is not None and (sort_events == "part" or (

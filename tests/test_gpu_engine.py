@@ -757,3 +757,32 @@ def test_partitioned_window_order_same_bits(n_events):
             assert llh == ref[1], kw
         else:
             assert abs(llh - ref[1]) <= 1e-9 * abs(ref[1])   # reference operation order: <= 3 ulp per weight
+
+
+@pytest.mark.parametrize("n,n_nodes,n_bins,frac_out", [
+    (833333, 20000, 128, 0.55), (20000, 2400, 128, 0.3), (4096 * 3, 600, 200, 0.0), (4096 * 3 + 17, 600, 200, 1.0),
+    (1000, 60, 7, 0.5), (255, 10, 3, 0.2), (256, 10, 3, 0.0), (257, 1, 1, 0.0), (9000, 5, 31, 0.9), (70001, 19999, 4800, 0.4)])
+def test_native_resident_order_is_the_torch_formulation(n, n_nodes, n_bins, frac_out):
+    """`pisa_hip_deposit_block_order` (csrc/order.hip, round 5: one key, one radix sort, one workgroup per window, the block
+    interleave in closed form) returns, element by element, the permutation of `engine.deposit_block_order` (the torch
+    formulation: ~40 launches, four sorts, two host synchronisations per container) -- sizes around the 256-event block and the
+    4 096-event window, no / only idle events, one node, more bins than bank pairs, events outside the grid (node -1)."""
+    import torch
+
+    from pisa_amd import engine
+    from pisa_amd import kernels as K
+
+    rs = np.random.RandomState(n % 9973)
+    node = rs.randint(0, n_nodes, size=n).astype(np.int32)
+    obin = rs.randint(0, n_bins, size=n).astype(np.int32)
+    out = rs.rand(n) < frac_out
+    obin[out & (rs.rand(n) < 0.7)] = -1
+    node[out & (rs.rand(n) < 0.4)] = -1
+    if frac_out == 1.0:
+        obin[:] = -1
+    d_node, d_bin = torch.from_numpy(node).to(K.device()), torch.from_numpy(obin).to(K.device())
+    want = engine.deposit_block_order(d_bin, d_node, window=4096, banks=32).cpu().numpy()
+    got = engine.deposit_block_order_native(d_bin, d_node, n_nodes).cpu().numpy()
+    assert np.array_equal(np.sort(got), np.arange(n))
+    assert np.array_equal(got, want)
+    assert np.array_equal(got, engine.deposit_block_order_native(d_bin, d_node, n_nodes).cpu().numpy())
