@@ -2124,7 +2124,17 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
         // host tables uploaded asynchronously below: they live until the synchronisation at the end
         std::vector<int32_t> dense, tcells;
         std::vector<double> hankel;
-        const int P = tol >= 1e-12 ? 18 : 20;
+        // Order of the Hermite / local series: the smallest of 14, 16, 18, 20 whose truncation bound (see above: 2.3 K^2
+        // (cell / 2)^P / sqrt(P!) of a cell's weight, all of it at a corner of the cell) is within 4 x tol.  The cells are
+        // r_cut / 8 wide, so the bound depends on tol through the cell size as well: 20 at 1e-14 (1.8e-15), 16 at 1e-12
+        // (2.8e-12; round 4 took 18 there: 3.5e-14, 28 x finer than the cut-off it sits beside), 14 at 1e-10.  The pilot's
+        // error reaches a density only through lambda = (pilot / g)^-alpha, i.e. scaled by alpha (<= 1).
+        int P = 20;
+        for (int cand : {14, 16, 18}) {
+            double bound = 2.3 * 1.09 * 1.09, fact = 1.0;
+            for (int i = 1; i <= cand; i++) { bound *= 0.5 * g.cell; fact *= (double)i; }
+            if (bound / sqrt(fact) <= 4.0 * tol) { P = cand; break; }
+        }
         // local expansions need the intermediate V of every cell of the grid: bounded
         const bool local_ok = g_kde_expansion >= 2 && ceil(sqrt(g.rcut2) * g.inv_cell) <= (double)H2L_MAX_REACH &&
                               (double)k->n_cells * (P * P) * 8.0 < 2.0e9;
@@ -2237,7 +2247,7 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
                     hipLaunchKernelGGL(kde_hermite_pilot_kernel<PP>, grid, dim3(KDE_THREADS), 0, s, g, d_blocks, \
                                        k->ys, n, k->coef, k->cell_start, slot, herm, n_split, part, k->pair_count); \
                 } } while (0)
-            if (P == 18) KDE_FGT(18); else KDE_FGT(20);
+            if (P == 14) KDE_FGT(14); else if (P == 16) KDE_FGT(16); else if (P == 18) KDE_FGT(18); else KDE_FGT(20);
 #undef KDE_FGT
             KDE_TRY(check_hip(hipGetLastError(), "kde expansion kernels"));
             k->n_dense = nd;
