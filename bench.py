@@ -67,6 +67,8 @@ def parse(argv=None):
                          "separate, the reference's operation order)")
     ap.add_argument("--wide-index", action="store_true",
                     help="compact form with 32-bit node and bin indices (24 B/event)")
+    ap.add_argument("--point-hybrid", action="store_true",
+                    help="leg point_parallel: also measure G = N / 2 groups of two shards (sub-groups, per-group RCCL communicators)")
     ap.add_argument("--legs", default="all",
                     help="comma list of extra measurements at N = 1 (%s), 'all' or 'none'" % ", ".join(ALL_LEGS))
     ap.add_argument("--no-batch-probe", action="store_true", help="(accepted for old command lines: the probe is off by default)")
@@ -875,7 +877,7 @@ def leg_multi_point(torch, st, wl, sync, reduce_max):
     return out
 
 
-def leg_point_parallel(make_state, st, wl, rank, world, state_kw, sync, reduce_max):
+def leg_point_parallel(make_state, st, wl, rank, world, state_kw, sync, reduce_max, hybrid=False):
     """Hybrid point x event parallelism (`engine.PointGroups`): the W ranks as G groups x R shards, the K points of an
     `eval_many` call dealt to the groups, every point computed inside one group (the sample replicated on a group's one
     rank, or sharded over its R ranks with the limb all-reduce inside the group), one all-gather of K doubles.  Measured
@@ -886,7 +888,9 @@ def leg_point_parallel(make_state, st, wl, rank, world, state_kw, sync, reduce_m
 
     out = {}
     nominal = wl.osc_params()
-    for n_groups in ([world, world // 2] if world >= 4 else [world]):
+    # (the hybrid topology creates sub-groups and per-group RCCL communicators: measured on request -- `--point-hybrid` --
+    # and in the tests; the default multi-GPU line keeps to G = W, which needs nothing beyond the world's all-gather)
+    for n_groups in ([world, world // 2] if (world >= 4 and hybrid) else [world]):
         pg = PointGroups(rank, world, n_groups)
         stp = make_state(wl, points=pg, **state_kw)
         stp.make_pseudo_data(nominal, seed=0)
@@ -1360,7 +1364,8 @@ def main(argv=None, hooks=None):
             elif name == "point_parallel":
                 legs[name] = leg_point_parallel(make_state, st, wl, rank, world,
                                                 dict(indexed=not args.coordinate_form, sort_events=order, compact=compact,
-                                                     index16=index16), barrier, max_over_ranks) \
+                                                     index16=index16), barrier, max_over_ranks,
+                                                hybrid=bool(args.point_hybrid or hooks is not None)) \
                     if (dist_on and world > 1 and compact and index16 and not args.coordinate_form) else None
             elif name == "fit_c4_engine":
                 legs[name] = leg_fit_engine(torch, st, wl, barrier, max_over_ranks)
