@@ -365,6 +365,18 @@ def test_rccl_limb_allreduce_single_rank(tmp_path, monkeypatch):
         print("eval: plain %.1f us, 1-rank RCCL direct %.1f us, through torch.distributed %.1f us"
               % (t_plain, t_direct, t_torch))
         st.check_status()
+        # the all-gather of the point groups on an RCCL group (device tensors; one rank here: the only RCCL a one-GPU
+        # box has), and a dealt `eval_many` end to end: one group of one rank evaluates every point itself
+        from pisa_amd.engine import PointGroups
+
+        pg = PointGroups(0, 1, 1)
+        assert pg.gather([1.5, -2.25, 3.0], 3, st.dev) == [1.5, -2.25, 3.0]
+        st.world_size = 1
+        st.points = pg
+        many = st.eval_many(points, "llh")
+        assert many == ref
+        assert pg.block(len(points)) == (0, 3) and pg.gather(many, 3, st.dev) == ref      # the values through RCCL, bit for bit
+        st.points = None
     finally:
         dist.destroy_process_group()
 
