@@ -702,27 +702,39 @@ __device__ inline void lattice_patch_box(const KdeLattice &L, int R, int p, doub
 // wstart[p] .. wstart[p + 1] = the wavefronts of patch p: every patch gets one, the remaining n_waves - n_patches go
 // by load (integer arithmetic: the same plan for the same data).  The plan is made by the workgroup that finishes
 // last (`done`: a counter the estimator keeps at zero between launches).
+// lists[p][0 .. load[p]) = the shares within reach of patch p, in share order (ordered compaction: ballot + prefix per 256
+// candidates): the wavefronts of a patch take CONTIGUOUS, equal parts of this list (+- one share), where a strided walk
+// over all shares with a box test per candidate gave a wavefront 13 +- 4 shares (round 5: the slowest wavefront of a launch
+// had 1.66 x the mean work).
 __global__ void __launch_bounds__(256)
 kde_lattice_load_kernel(const KdeLattice L, int R, const double *__restrict__ box, int64_t n_shares,
-                        unsigned int *__restrict__ load, int n_patches, int n_waves, int min_shares, int32_t *__restrict__ wstart,
-                        unsigned long long *__restrict__ done) {
-    __shared__ unsigned int lds[256];
+                        unsigned int *__restrict__ load, int32_t *__restrict__ lists, int n_patches, int n_waves,
+                        int min_shares, int32_t *__restrict__ wstart, unsigned long long *__restrict__ done) {
+    __shared__ unsigned int wcnt[4];
     __shared__ int last;
     double pa_lo, pa_hi, pb_lo, pb_hi;
     lattice_patch_box(L, R, (int)blockIdx.x, pa_lo, pa_hi, pb_lo, pb_hi);
-    unsigned int cnt = 0;
-    for (int64_t sub = threadIdx.x; sub < n_shares; sub += 256) {
-        const double *__restrict__ bx = box + 4 * sub;
-        cnt += !(bx[0] > pa_hi || bx[1] < pa_lo || bx[2] > pb_hi || bx[3] < pb_lo);
-    }
-    lds[threadIdx.x] = cnt;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st) lds[threadIdx.x] += lds[threadIdx.x + st];
+    int32_t *__restrict__ mine_list = lists + (int64_t)blockIdx.x * n_shares;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned int base = 0;
+    for (int64_t sub0 = 0; sub0 < n_shares; sub0 += 256) {
+        const int64_t sub = sub0 + threadIdx.x;
+        bool ok = false;
+        if (sub < n_shares) {
+            const double *__restrict__ bx = box + 4 * sub;
+            ok = !(bx[0] > pa_hi || bx[1] < pa_lo || bx[2] > pb_hi || bx[3] < pb_lo);
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
+        if (lane == 0) wcnt[wave] = (unsigned int)__builtin_popcountll(m);
+        __syncthreads();
+        unsigned int before = 0;
+        for (int q = 0; q < wave; q++) before += wcnt[q];
+        if (ok) mine_list[base + before + (unsigned int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (int32_t)sub;
+        base += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        __hip_atomic_store(&load[blockIdx.x], lds[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&load[blockIdx.x], base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __threadfence();
         last = atomicAdd(done, 1ull) == (unsigned long long)(n_patches - 1);
     }
@@ -772,7 +784,8 @@ kde_lattice_load_kernel(const KdeLattice L, int R, const double *__restrict__ bo
 }
 
 // Workgroup = one wavefront = one SUB-PATCH of the lattice (sw strips x lpw lines = LG lanes) x every n-th share of the
-// sources, n = the sub-patch's number of wavefronts (wstart).  The wavefront's G = 64 / LG lane GROUPS all own the same
+// sources: the load kernel lists the shares within reach of every sub-patch, the sub-patch's wavefronts (wstart) take
+// contiguous, equal parts of its list.  The wavefront's G = 64 / LG lane GROUPS all own the same
 // sub-patch, each with accumulators of its own, and work through G different shares side by side (round i: group g takes
 // entry i G + g of the wavefront's list of shares within reach).  partial[wavefront][m][lane]; the combine kernel adds the
 // wavefronts AND the groups of a sub-patch in fixed order.
@@ -793,7 +806,8 @@ constexpr int LAT_PIECE = 32;   // records per piece, all groups together
 template <int R, int LG>
 __global__ void __launch_bounds__(64, 3)   // <= 168 VGPRs: at four wavefronts per SIMD (128) the record loop spills
 kde_lattice_kernel(const KdeLattice L, double rcut2, const double *__restrict__ rec, int64_t n_src,
-                   const double *__restrict__ box, const int32_t *__restrict__ wstart,
+                   const int32_t *__restrict__ lists, const unsigned int *__restrict__ load,
+                   const int32_t *__restrict__ wstart,
                    int n_patches, double *__restrict__ partial,
                    unsigned long long *__restrict__ pair_count, unsigned long long *__restrict__ stamps) {
     constexpr int C = R / 2;   // the strip's middle point
@@ -806,7 +820,7 @@ kde_lattice_kernel(const KdeLattice L, double rcut2, const double *__restrict__ 
     static_assert(C <= LAT_QMAX, "Q table");
     static_assert(G * LG == 64 && HP * G == LAT_PIECE && UNITS * LG == GD2 && N_PIECE * HP == LAT_SHARE, "piece layout");
     __shared__ __attribute__((aligned(16))) double ring[2][G * GS];
-    __shared__ int32_t lst[128];
+    __shared__ int32_t lst[64];
     const int w = (int)blockIdx.x;
     const int lane = (int)threadIdx.x;
     if (w >= wstart[n_patches]) return;
@@ -830,8 +844,6 @@ kde_lattice_kernel(const KdeLattice L, double rcut2, const double *__restrict__ 
     const double yb = L.yb0 + j * L.db;
     const double ya_c = L.ya0 + j * L.sa + (double)(t * R + C) * L.da;
     const double ext_lo = C * L.da, ext_hi = (R - 1 - C) * L.da;
-    double pa_lo, pa_hi, pb_lo, pb_hi;   // the sub-patch's bounding box (wave-uniform)
-    lattice_patch_box(L, R, p, pa_lo, pa_hi, pb_lo, pb_hi);
     double acc[R];
 #pragma unroll
     for (int k = 0; k < R; k++) acc[k] = 0.0;
@@ -863,26 +875,16 @@ kde_lattice_kernel(const KdeLattice L, double rcut2, const double *__restrict__ 
         }
     };
 
-    // The sorted sources are cut into shares of LAT_SHARE sources (compact in y_a and y_b); this wavefront takes every
-    // n_split-th share: every wavefront sees a sample of all regions, so the work is balanced without a dynamic queue.
-    int64_t sub = split;
-    while (sub < n_shares) {
-        // the next (64 ... 127) shares of this wavefront within reach of the sub-patch: 64 candidates per scan, one per lane
-        // (one candidate at a time, by scalar loads, cost a wavefront with a narrow sub-patch ~200 dependent L2 latencies)
-        int nl = 0;
+    // The sorted sources are cut into shares of LAT_SHARE sources (compact in y_a and y_b); the load kernel has listed the
+    // shares within reach of this sub-patch, in share order; the sub-patch's wavefronts take contiguous, equal parts of
+    // that list (+- one share), 64 entries at a time.
+    const int32_t *__restrict__ my_list = lists + (int64_t)p * n_shares;
+    const int64_t n_in = (int64_t)load[p];
+    const int64_t e_end = ((int64_t)(split + 1) * n_in) / n_split;
+    for (int64_t e0 = ((int64_t)split * n_in) / n_split; e0 < e_end; e0 += 64) {
+        const int nl = (int)(e_end - e0 < 64 ? e_end - e0 : 64);
         __syncthreads();
-        for (; sub < n_shares && nl < 64; sub += (int64_t)64 * n_split) {
-            const int64_t cand = sub + (int64_t)lane * n_split;
-            bool ok = cand < n_shares;
-            if (ok) {
-                const d2 *__restrict__ bx = reinterpret_cast<const d2 *>(box + 4 * cand);
-                const d2 ba = bx[0], bb = bx[1];
-                ok = !(ba.x > pa_hi || ba.y < pa_lo || bb.x > pb_hi || bb.y < pb_lo);
-            }
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
-            if (ok) lst[nl + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (int32_t)cand;
-            nl += __builtin_popcountll(m);
-        }
+        if (lane < nl) lst[lane] = my_list[e0 + lane];
         __syncthreads();
         // The list is ONE stream of nl x 64 records, cut evenly among the groups: group g works records
         // [g nl LG, (g + 1) nl LG) of it, piece by piece (a piece never crosses a share: HP divides 64 and nl LG).
@@ -2385,7 +2387,7 @@ static int lattice_strip(const pisa_hip_kde *k, const double *step, const int64_
 // number of strips it reaches there, so the sub-patch should be as compact as the kernel discs: the expected number
 // of sub-patches a unit-bandwidth source touches (sources spread evenly over the lattice and its margin) picks sw for
 // a given LG; LG = 8 (eight shares side by side: scripts/dev/kde_pass_model.py) unless the lattice then has more
-// than 4 096 sub-patches (every sub-patch has a wavefront and R x 64 partial sums of its own).
+// than 4 096 sub-patches (every sub-patch has a wavefront, partial sums and a share list of its own).
 static int64_t lattice_patches(int R, int sw, int lpw, const int64_t *count) {
     const int64_t strips_a = (count[0] + R - 1) / R;
     return ((strips_a + sw - 1) / sw) * ((count[1] + lpw - 1) / lpw);
@@ -2414,7 +2416,10 @@ static void lattice_shape(const pisa_hip_kde *k, int R, const double *step, cons
         }
         sw_out = best;
         lg_out = lg;
-        if (lattice_patches(R, best, lg / best, count) <= 4096 || forced_lg > 0) return;
+        // (every sub-patch also has a list of the shares within reach of it, n_shares entries at most: 256 MB in all)
+        const int64_t n_shares = k->n / LAT_SHARE + 1;
+        const int64_t cap = std::min<int64_t>(4096, std::max<int64_t>(1, ((int64_t)64 << 20) / n_shares));
+        if (lattice_patches(R, best, lg / best, count) <= cap || forced_lg > 0 || lg == 64) return;
     }
 }
 
@@ -2448,6 +2453,7 @@ PISA_API int64_t pisa_hip_kde_lattice_workspace_bytes(const pisa_hip_kde *k, con
         const size_t waves = (size_t)lattice_waves(R, sw, lg / sw, h_count, k->n);
         const size_t patches = (size_t)lattice_patches(R, sw, lg / sw, h_count);
         return (int64_t)(((size_t)k->n + LAT_SHARE) * LAT_REC * 8 + waves * R * lg * 8 + ((size_t)k->n / LAT_SHARE + 1) * 32 +
+                         patches * ((size_t)k->n / LAT_SHARE + 1) * 4 +   /* lists of the shares within reach of each sub-patch */
                          (patches + 1) * 8 + 4096);
     }
     const int64_t general = pisa_hip_kde_eval_workspace_bytes(k, m);
@@ -2503,6 +2509,7 @@ PISA_API int pisa_hip_kde_evaluate_lattice(pisa_hip_kde *k, const double *h_orig
     double *part = ar.take<double>((size_t)n_waves * R * lg);
     double *box = ar.take<double>((size_t)n_shares * 4);
     unsigned int *load = ar.take<unsigned int>((size_t)n_patches);
+    int32_t *lists = ar.take<int32_t>((size_t)n_patches * (size_t)n_shares);
     int32_t *wstart = ar.take<int32_t>((size_t)n_patches + 1);
     if (!ar.ok) return PISA_HIP_ERR_NOMEM;
     hipLaunchKernelGGL(kde_lattice_prep_kernel, dim3((unsigned)((k->n + 63) / 64)), dim3(64), 0, s, k->ys,
@@ -2510,7 +2517,7 @@ PISA_API int pisa_hip_kde_evaluate_lattice(pisa_hip_kde *k, const double *h_orig
     // (a wavefront's list is cut evenly among its lane groups whatever its length: the floor only bounds the fixed cost per
     // wavefront -- scan of the share boxes, 16 KB of partial sums -- against its work)
     static const int min_shares = PISA_DEV_INT("KDE_LATTICE_MIN_SHARES", 8);
-    hipLaunchKernelGGL(kde_lattice_load_kernel, dim3((unsigned)n_patches), dim3(256), 0, s, L, R, box, n_shares, load,
+    hipLaunchKernelGGL(kde_lattice_load_kernel, dim3((unsigned)n_patches), dim3(256), 0, s, L, R, box, n_shares, load, lists,
                        n_patches, n_waves, min_shares, wstart, k->pair_count + 4);
     unsigned long long *stamps = nullptr;
 #ifdef PISA_DEV_PROBES
@@ -2520,7 +2527,7 @@ PISA_API int pisa_hip_kde_evaluate_lattice(pisa_hip_kde *k, const double *h_orig
         PISA_TRY_HIP(hipMemsetAsync(stamps, 0, (size_t)n_waves * 32, s));
     }
 #endif
-#define KDE_LAT(RR, LL) hipLaunchKernelGGL((kde_lattice_kernel<RR, LL>), dim3((unsigned)n_waves), dim3(64), 0, s, L, g.rcut2, rec, k->n, box, wstart, n_patches, part, k->pair_count, stamps)
+#define KDE_LAT(RR, LL) hipLaunchKernelGGL((kde_lattice_kernel<RR, LL>), dim3((unsigned)n_waves), dim3(64), 0, s, L, g.rcut2, rec, k->n, lists, load, wstart, n_patches, part, k->pair_count, stamps)
 #define KDE_LAT_R(RR) do { if (lg == 8) KDE_LAT(RR, 8); else if (lg == 16) KDE_LAT(RR, 16); else if (lg == 32) KDE_LAT(RR, 32); else KDE_LAT(RR, 64); } while (0)
     if (R == 32) KDE_LAT_R(32); else if (R == 16) KDE_LAT_R(16); else KDE_LAT_R(8);
 #undef KDE_LAT_R
