@@ -706,18 +706,21 @@ __device__ inline void lattice_patch_box(const KdeLattice &L, int R, int p, doub
 // candidates): the wavefronts of a patch take CONTIGUOUS, equal parts of this list (+- one share), where a strided walk
 // over all shares with a box test per candidate gave a wavefront 13 +- 4 shares (round 5: the slowest wavefront of a launch
 // had 1.66 x the mean work).
-__global__ void __launch_bounds__(256)
+constexpr int LOAD_THREADS = 1024;   // (256: 36 dependent rounds of 32-byte loads per sub-patch at C3's size, 21 us; 1 024: 9 rounds)
+__global__ void __launch_bounds__(LOAD_THREADS)
 kde_lattice_load_kernel(const KdeLattice L, int R, const double *__restrict__ box, int64_t n_shares,
                         unsigned int *__restrict__ load, int32_t *__restrict__ lists, int n_patches, int n_waves,
                         int min_shares, int32_t *__restrict__ wstart, unsigned long long *__restrict__ done) {
-    __shared__ unsigned int wcnt[4];
+    constexpr int NW = LOAD_THREADS / 64;
+    __shared__ unsigned int wcnt[2][NW];
     __shared__ int last;
     double pa_lo, pa_hi, pb_lo, pb_hi;
     lattice_patch_box(L, R, (int)blockIdx.x, pa_lo, pa_hi, pb_lo, pb_hi);
     int32_t *__restrict__ mine_list = lists + (int64_t)blockIdx.x * n_shares;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned int base = 0;
-    for (int64_t sub0 = 0; sub0 < n_shares; sub0 += 256) {
+    int flip = 0;
+    for (int64_t sub0 = 0; sub0 < n_shares; sub0 += LOAD_THREADS, flip ^= 1) {
         const int64_t sub = sub0 + threadIdx.x;
         bool ok = false;
         if (sub < n_shares) {
@@ -725,13 +728,16 @@ kde_lattice_load_kernel(const KdeLattice L, int R, const double *__restrict__ bo
             ok = !(bx[0] > pa_hi || bx[1] < pa_lo || bx[2] > pb_hi || bx[3] < pb_lo);
         }
         const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
-        if (lane == 0) wcnt[wave] = (unsigned int)__builtin_popcountll(m);
-        __syncthreads();
-        unsigned int before = 0;
-        for (int q = 0; q < wave; q++) before += wcnt[q];
+        if (lane == 0) wcnt[flip][wave] = (unsigned int)__builtin_popcountll(m);
+        __syncthreads();      // (two count buffers in turn: one barrier per round)
+        unsigned int before = 0, total = 0;
+        for (int q = 0; q < NW; q++) {
+            const unsigned int c = wcnt[flip][q];
+            before += q < wave ? c : 0u;
+            total += c;
+        }
         if (ok) mine_list[base + before + (unsigned int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (int32_t)sub;
-        base += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-        __syncthreads();
+        base += total;
     }
     if (threadIdx.x == 0) {
         __hip_atomic_store(&load[blockIdx.x], base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -747,7 +753,7 @@ kde_lattice_load_kernel(const KdeLattice L, int R, const double *__restrict__ bo
     if (threadIdx.x == 0) { *done = 0ull; tot_lds = 0ull; }   // back to zero for the next launch
     __syncthreads();
     unsigned long long mine = 0;
-    for (int p = threadIdx.x; p < n_patches; p += 256) mine += __hip_atomic_load(&load[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int p = threadIdx.x; p < n_patches; p += LOAD_THREADS) mine += __hip_atomic_load(&load[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     atomicAdd(&tot_lds, mine);   // (integer sum: order-independent)
     __syncthreads();
     const unsigned long long total = tot_lds;
@@ -758,24 +764,25 @@ kde_lattice_load_kernel(const KdeLattice L, int R, const double *__restrict__ bo
     __shared__ int32_t carry;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
+    const bool act = threadIdx.x < 256;     // (the prefix runs on the first 256 threads; the others only meet the barriers)
     for (int base = 0; base < n_patches; base += 256) {
         const int p = base + (int)threadIdx.x;
         int32_t nw = 0;
-        if (p < n_patches) {
+        if (act && p < n_patches) {
             const unsigned long long lp = __hip_atomic_load(&load[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             unsigned long long extra = total ? spare * lp / total : 0;
             if (per * (extra + 1) > lp) extra = lp >= per ? lp / per - 1 : 0;
             nw = 1 + (int32_t)extra;
         }
-        scan[threadIdx.x] = nw;
+        if (act) scan[threadIdx.x] = nw;
         __syncthreads();
         for (int off = 1; off < 256; off <<= 1) {
-            const int32_t v = (int)threadIdx.x >= off ? scan[threadIdx.x - off] : 0;
+            const int32_t v = (act && (int)threadIdx.x >= off) ? scan[threadIdx.x - off] : 0;
             __syncthreads();
-            scan[threadIdx.x] += v;
+            if (act) scan[threadIdx.x] += v;
             __syncthreads();
         }
-        if (p < n_patches) wstart[p] = carry + scan[threadIdx.x] - nw;
+        if (act && p < n_patches) wstart[p] = carry + scan[threadIdx.x] - nw;
         __syncthreads();
         if (threadIdx.x == 255) carry += scan[255];
         __syncthreads();
@@ -786,9 +793,9 @@ kde_lattice_load_kernel(const KdeLattice L, int R, const double *__restrict__ bo
 // Workgroup = one wavefront = one SUB-PATCH of the lattice (sw strips x lpw lines = LG lanes) x every n-th share of the
 // sources: the load kernel lists the shares within reach of every sub-patch, the sub-patch's wavefronts (wstart) take
 // contiguous, equal parts of its list.  The wavefront's G = 64 / LG lane GROUPS all own the same
-// sub-patch, each with accumulators of its own, and work through G different shares side by side (round i: group g takes
-// entry i G + g of the wavefront's list of shares within reach).  partial[wavefront][m][lane]; the combine kernel adds the
-// wavefronts AND the groups of a sub-patch in fixed order.
+// sub-patch, each with accumulators of its own, and work through the wavefront's part of the list side by side (its records
+// as ONE stream cut evenly among the groups); the groups' sums are added in the wavefront, partial[wavefront][m][sub-lane];
+// the combine kernel adds the wavefronts of a sub-patch in fixed order.
 //
 // Why groups (round 5; scripts/dev/kde_pass_model.py counts what a shape executes on real estimators): a source reaches a
 // disc of the lattice (17 ... 76 lines at the stage's settings); with one 64-line patch per wavefront a pass of the
@@ -2517,7 +2524,7 @@ PISA_API int pisa_hip_kde_evaluate_lattice(pisa_hip_kde *k, const double *h_orig
     // (a wavefront's list is cut evenly among its lane groups whatever its length: the floor only bounds the fixed cost per
     // wavefront -- scan of the share boxes, 16 KB of partial sums -- against its work)
     static const int min_shares = PISA_DEV_INT("KDE_LATTICE_MIN_SHARES", 8);
-    hipLaunchKernelGGL(kde_lattice_load_kernel, dim3((unsigned)n_patches), dim3(256), 0, s, L, R, box, n_shares, load, lists,
+    hipLaunchKernelGGL(kde_lattice_load_kernel, dim3((unsigned)n_patches), dim3(LOAD_THREADS), 0, s, L, R, box, n_shares, load, lists,
                        n_patches, n_waves, min_shares, wstart, k->pair_count + 4);
     unsigned long long *stamps = nullptr;
 #ifdef PISA_DEV_PROBES
