@@ -1475,7 +1475,7 @@ template <int P, int PASS>
 __global__ void __launch_bounds__(H2L_THREADS)
 kde_h2l4_kernel(KdeGeom g, const int32_t *__restrict__ hslot, const int32_t *__restrict__ slot,
                 const double *__restrict__ herm, const double *__restrict__ hankel, int reach,
-                double *__restrict__ V, uint8_t *__restrict__ vflag, double *__restrict__ local) {
+                double *__restrict__ V, uint8_t *__restrict__ vflag, double *__restrict__ local, int n_heads) {
     constexpr int NH = 2 * P - 1, PT = (P + 3) / 4, PR = PT * 4, PP = P * P;
     constexpr int SR = PR + 1;                                  // row stride of the staged matrix: with 20 the four-row tiles of pass 0 fall on one bank
     constexpr int NHP = NH + 8;                                 // padded Hankel row (tiles beyond P read past NH)
@@ -1512,7 +1512,16 @@ kde_h2l4_kernel(KdeGeom g, const int32_t *__restrict__ hslot, const int32_t *__r
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = 0.0;
     bool any = false;
-    // source matrix at position v of the convolution direction, or nullptr (workgroup-uniform)
+    // The source positions of a workgroup's targets are a dependent sequence (fetch -> barrier -> stage -> barrier -> P
+    // rounds of multiply-adds, ~2.5 us each, 20 of them), and that sequence, not the arithmetic, is what a pass takes (VALU busy
+    // 0.35 with every workgroup resident; one target per workgroup, four times the workgroups: the same time).  Round 5: the
+    // positions are cut into gridDim.z contiguous parts, part z writes its own V / local (buffers [part][cell]); the
+    // consumer adds the parts in part order as it fetches (pass 1: here; the local expansions: kde_local_pilot_kernel).
+    const int n_part = (int)gridDim.z, part = (int)blockIdx.z;
+    const int64_t n_cells_all = (int64_t)nx * ny;
+    // source matrix at position v of the convolution direction, or nullptr (workgroup-uniform); pass 1: the parts of V of
+    // that cell that hold anything (bit z of `have`)
+    unsigned int have = 0;
     auto source = [&](int v) -> const double * {
         if (v < 0 || v >= nu) return nullptr;
         if (PASS == 0) {
@@ -1520,28 +1529,40 @@ kde_h2l4_kernel(KdeGeom g, const int32_t *__restrict__ hslot, const int32_t *__r
             return sl < 0 ? nullptr : herm + (int64_t)sl * PP;
         }
         const int64_t cb = (int64_t)w * nx + v;                 // V of (cx_B = v, cy = w)
-        return vflag[cb] ? V + cb * PP : nullptr;
+        have = 0;
+        for (int z = 0; z < n_part; z++) have |= vflag[z * n_cells_all + cb] ? (1u << z) : 0u;
+        return have ? V + cb * PP : nullptr;
     };
-    auto fetch = [&](const double *src, double (&buf)[PER]) {
+    auto fetch = [&](const double *src, unsigned int parts, double (&buf)[PER]) {
 #pragma unroll
         for (int u = 0; u < PER; u++) {
             const int e = t + u * H2L_THREADS;
-            buf[u] = (src && e < PP) ? src[e] : 0.0;
+            double val = 0.0;
+            if (src && e < PP) {
+                if (PASS == 0) val = src[e];
+                else
+                    for (int z = 0; z < n_part; z++)              // the parts of pass 0, added in part order
+                        if (parts & (1u << z)) val += src[z * n_cells_all * PP + e];
+            }
+            buf[u] = val;
         }
     };
     // sources from the highest position down: for every target the offsets o = target - source ascend
-    const int v_hi = u0 + H2L4_T - 1 + reach < nu - 1 ? u0 + H2L4_T - 1 + reach : nu - 1;
-    const int v_lo = u0 - reach > 0 ? u0 - reach : 0;
+    const int v_hi_all = u0 + H2L4_T - 1 + reach < nu - 1 ? u0 + H2L4_T - 1 + reach : nu - 1;
+    const int v_lo_all = u0 - reach > 0 ? u0 - reach : 0;
+    const int n_pos = v_hi_all - v_lo_all + 1;
+    const int v_hi = v_hi_all - (part * n_pos) / n_part;
+    const int v_lo = v_hi_all - ((part + 1) * n_pos) / n_part + 1;
     int v = v_hi;
-    const double *src = source(v);
+    const double *src = v >= v_lo ? source(v) : nullptr;
     while (!src && v > v_lo) src = source(--v);
     double mine[PER], ahead[PER];
-    fetch(src, mine);
+    fetch(src, have, mine);
     while (src) {
         int vn = v - 1;
         const double *nxt = vn >= v_lo ? source(vn) : nullptr;
         while (!nxt && vn > v_lo) nxt = source(--vn);
-        fetch(nxt, ahead);
+        fetch(nxt, have, ahead);
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < PER; u++) {
@@ -1596,7 +1617,7 @@ kde_h2l4_kernel(KdeGeom g, const int32_t *__restrict__ hslot, const int32_t *__r
     }
     if (PASS == 0) {
         if (act && my_u < nu) {
-            const int64_t c = (int64_t)my_u * nx + w;
+            const int64_t c = part * n_cells_all + (int64_t)my_u * nx + w;
             if (tile == 0) vflag[c] = any ? 1 : 0;
             if (any) {
 #pragma unroll
@@ -1617,7 +1638,7 @@ kde_h2l4_kernel(KdeGeom g, const int32_t *__restrict__ hslot, const int32_t *__r
                 if (r0 < P && r1 < P) {
                     // D_k D_l = (-1)^(k+l) / (k! l!)
                     const double sgn = ((r0 + r1) & 1) ? -1.0 : 1.0;
-                    local[(int64_t)my_head * PP + r0 * P + r1] = sgn * acc[di][dj] * INV_FACT[r0] * INV_FACT[r1];
+                    local[((int64_t)part * n_heads + my_head) * PP + r0 * P + r1] = sgn * acc[di][dj] * INV_FACT[r0] * INV_FACT[r1];
                 }
             }
     }
@@ -1630,7 +1651,7 @@ __global__ void __launch_bounds__(KDE_THREADS)
 kde_local_pilot_kernel(KdeGeom g, const KdeBlock *__restrict__ blocks, const double *__restrict__ sy,
                        int64_t n_src, const double *__restrict__ coef,
                        const int32_t *__restrict__ cell_start, const int32_t *__restrict__ slot,
-                       const double *__restrict__ local, double *__restrict__ out,
+                       const double *__restrict__ local, int n_heads, int n_part, double *__restrict__ out,
                        unsigned long long *__restrict__ pair_count) {
     constexpr int W = 4;
     __shared__ double t_src[SRC_TILE * W];
@@ -1646,7 +1667,11 @@ kde_local_pilot_kernel(KdeGeom g, const KdeBlock *__restrict__ blocks, const dou
     }
     unsigned long long work = (unsigned long long)(P * P / 23 + 1) * b.q_count;
     __shared__ double sL[P * P];   // the cell's local expansion: fetched once by the workgroup, read back as broadcasts
-    for (int i = threadIdx.x; i < P * P; i += KDE_THREADS) sL[i] = local[(int64_t)b.head * (P * P) + i];
+    for (int i = threadIdx.x; i < P * P; i += KDE_THREADS) {
+        double v = local[(int64_t)b.head * (P * P) + i];
+        for (int z = 1; z < n_part; z++) v += local[((int64_t)z * n_heads + b.head) * (P * P) + i];   // the parts of the translation passes, in part order
+        sL[i] = v;
+    }
     __syncthreads();
     {
         const double *L = sL;
@@ -2171,14 +2196,18 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
             // Hermite / local coefficients live in a grow-only scratch of the library (up to
             // 3.2 KB per cell: sized by what this call needs, not by the workspace's worst case)
             const size_t pp = (size_t)(P * P);
-            const size_t need = (nd * pp + (local_exp ? (n_heads + (size_t)k->n_cells) * pp + (2 * reach + 1) * (2 * P - 1) : 0))
-                                * sizeof(double) + (local_exp ? (size_t)k->n_cells : 0) + 8192;
+            // translation passes in H2L_SPLIT parts of the source positions (see kde_h2l4_kernel): V, its flags and the local
+            // expansions once per part
+            static const int h2l_split_cfg = PISA_DEV_INT("KDE_H2L_SPLIT", 2);
+            const int h2l_split = h2l_split_cfg >= 1 && h2l_split_cfg <= 8 ? h2l_split_cfg : 2;
+            const size_t need = (nd * pp + (local_exp ? h2l_split * (n_heads + (size_t)k->n_cells) * pp + (2 * reach + 1) * (2 * P - 1) : 0))
+                                * sizeof(double) + (local_exp ? (size_t)h2l_split * k->n_cells : 0) + 8192;
             double *herm = nullptr;
             KDE_TRY(kde_scratch(need > g_kde_scratch_bytes ? need + need / 2 : need, s, &herm));
             double *local = herm + nd * pp;
-            double *d_hankel = local + (local_exp ? n_heads * pp : 0);
+            double *d_hankel = local + (local_exp ? h2l_split * n_heads * pp : 0);
             double *d_V = d_hankel + (2 * reach + 1) * (2 * P - 1);
-            uint8_t *d_vflag = (uint8_t *)(d_V + (local_exp ? (size_t)k->n_cells * pp : 0));
+            uint8_t *d_vflag = (uint8_t *)(d_V + (local_exp ? (size_t)h2l_split * k->n_cells * pp : 0));
             int32_t *d_dense = ar.take<int32_t>(dense.size());
             int32_t *slot = ar.take<int32_t>(k->n_cells);
             int32_t *d_tcells = ar.take<int32_t>(n_heads);
@@ -2236,10 +2265,10 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
                                    k->cell_start, k->ys, n, k->coef, herm); \
                 if (local_exp) { \
                     if (h2l_form == 1) { \
-                        hipLaunchKernelGGL((kde_h2l4_kernel<PP, 0>), dim3((unsigned)g.nc[0], (unsigned)((g.nc[1] + H2L4_T - 1) / H2L4_T)), \
-                                           dim3(H2L_THREADS), 0, s, g, hslot, slot, herm, d_hankel, reach, d_V, d_vflag, local); \
-                        hipLaunchKernelGGL((kde_h2l4_kernel<PP, 1>), dim3((unsigned)((g.nc[0] + H2L4_T - 1) / H2L4_T), (unsigned)g.nc[1]), \
-                                           dim3(H2L_THREADS), 0, s, g, hslot, slot, herm, d_hankel, reach, d_V, d_vflag, local); \
+                        hipLaunchKernelGGL((kde_h2l4_kernel<PP, 0>), dim3((unsigned)g.nc[0], (unsigned)((g.nc[1] + H2L4_T - 1) / H2L4_T), (unsigned)h2l_split), \
+                                           dim3(H2L_THREADS), 0, s, g, hslot, slot, herm, d_hankel, reach, d_V, d_vflag, local, n_heads); \
+                        hipLaunchKernelGGL((kde_h2l4_kernel<PP, 1>), dim3((unsigned)((g.nc[0] + H2L4_T - 1) / H2L4_T), (unsigned)g.nc[1], (unsigned)h2l_split), \
+                                           dim3(H2L_THREADS), 0, s, g, hslot, slot, herm, d_hankel, reach, d_V, d_vflag, local, n_heads); \
                     } else { \
                         hipLaunchKernelGGL((kde_h2l_kernel<PP, 0>), dim3((unsigned)k->n_cells), dim3(H2L_THREADS), 0, s, g, d_tcells, \
                                            slot, herm, d_hankel, reach, d_V, d_vflag, local); \
@@ -2248,10 +2277,10 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
                     } \
                     if (nd < n_heads) \
                         hipLaunchKernelGGL((kde_local_pilot_kernel<PP, true>), dim3((unsigned)n_blocks), dim3(KDE_THREADS), 0, s, g, \
-                                           d_blocks, k->ys, n, k->coef, k->cell_start, slot, local, pilot, k->pair_count); \
+                                           d_blocks, k->ys, n, k->coef, k->cell_start, slot, local, n_heads, h2l_form == 1 ? h2l_split : 1, pilot, k->pair_count); \
                     else \
                         hipLaunchKernelGGL((kde_local_pilot_kernel<PP, false>), dim3((unsigned)n_blocks), dim3(KDE_THREADS), 0, s, g, \
-                                           d_blocks, k->ys, n, k->coef, k->cell_start, slot, local, pilot, k->pair_count); \
+                                           d_blocks, k->ys, n, k->coef, k->cell_start, slot, local, n_heads, h2l_form == 1 ? h2l_split : 1, pilot, k->pair_count); \
                 } else { \
                     hipLaunchKernelGGL(kde_hermite_pilot_kernel<PP>, grid, dim3(KDE_THREADS), 0, s, g, d_blocks, \
                                        k->ys, n, k->coef, k->cell_start, slot, herm, n_split, part, k->pair_count); \
