@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/r5_coord; rm -rf $OUT; mkdir -p $OUT
+OUT=gpurun_out/coord_traffic; rm -rf $OUT; mkdir -p $OUT
 LEAN="--no-cpu-baseline --no-drop-probe --no-batch-probe --legs none"
 python3 bench.py $LEAN --coordinate-form --steps 100 2>/dev/null | python3 -c "
 import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('coord evals/s', round(d['value']), 'roofline', {k: d['roofline'][k] for k in ('achieved','frac','avg_launch_ms')})"
@@ -9,7 +9,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python3 - <<'PY'
 import csv
-OUT="gpurun_out/r5_coord"
+OUT="gpurun_out/coord_traffic"
 def per_launch(path, kernel, name):
     v = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if kernel in r["Kernel_Name"] and r["Counter_Name"] == name]
     return sum(v) / len(v), len(v)
