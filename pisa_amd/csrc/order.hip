@@ -124,6 +124,11 @@ order_interleave_kernel(const uint32_t *__restrict__ seq, int64_t n, const unsig
     perm[i] = (int64_t)seq[src * ORD_BLOCK + l];
 }
 
+// bytes of one of the five index arrays, a multiple of 256: the sort's temporary storage behind them holds 64-bit look-back
+// states and must not start at an odd multiple of four bytes (an odd event count did that: the sort of 3.3e6 events then hung
+// under a counter-collecting profiler)
+static size_t order_stride(int64_t n) { return (((size_t)(n + ORD_WINDOW) * 4 + 255) / 256) * 256; }
+
 static int order_key_bits(uint32_t n_nodes) {
     int bits = 1;
     while (bits < 32 && (1ull << bits) <= 2ull * n_nodes + 2ull) bits++;
@@ -139,7 +144,7 @@ PISA_API int64_t pisa_hip_deposit_block_order_workspace(int64_t n) {
     size_t temp = 0;
     (void)rocprim::radix_sort_pairs(nullptr, temp, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
                                     (uint32_t *)nullptr, (size_t)n, 0u, 32u);
-    return (int64_t)(5 * (size_t)(n + ORD_WINDOW) * 4 + temp + 1024);
+    return (int64_t)(5 * order_stride(n) + temp + 1024);
 }
 
 PISA_API int pisa_hip_deposit_block_order(const int32_t *d_node, const int32_t *d_bin, int64_t n, int64_t n_nodes,
@@ -152,7 +157,7 @@ PISA_API int pisa_hip_deposit_block_order(const int32_t *d_node, const int32_t *
     hipStream_t s = as_stream(stream);
     char *w = (char *)d_work;
     unsigned long long *n_dep = (unsigned long long *)w;
-    const size_t stride = (size_t)(n + ORD_WINDOW) * 4;
+    const size_t stride = order_stride(n);
     uint32_t *key_a = (uint32_t *)(w + 256), *key_b = (uint32_t *)(w + 256 + stride);
     uint32_t *val_a = (uint32_t *)(w + 256 + 2 * stride), *val_b = (uint32_t *)(w + 256 + 3 * stride);
     uint32_t *seq = (uint32_t *)(w + 256 + 4 * stride);

@@ -559,13 +559,18 @@ class HotPathEngine:
         # The columns of container i + 1 cross PCIe (a second thread, a stream of its own) while container i is digitised
         # and ordered on the launch stream: at 1e7 events 22 ms of copies beside 30 ms of ordering and packing instead of
         # in front of them (round 5, bench.py `setup_ms`).
-        prefetch = torch.cuda.is_available() and len(containers) > 1
+        # (PISA_HIP_UPLOAD_THREADS=0: everything on the calling thread and the launch stream -- for counter-collecting
+        # profilers, which serialise dispatches and have been seen to stall when several host threads submit work)
+        import os as _os
+
+        n_up = int(_os.environ.get("PISA_HIP_UPLOAD_THREADS", "3"))
+        prefetch = torch.cuda.is_available() and len(containers) > 1 and n_up > 0
         if prefetch:
             from concurrent.futures import ThreadPoolExecutor
 
             # three containers ahead: the host side of an upload (slicing, numpy's log of the energies: 3-5 ms per container,
             # it releases the GIL) runs on three cores at once, the copies themselves queue on the link
-            AHEAD = 3
+            AHEAD = max(1, min(n_up, 4))
             pool = ThreadPoolExecutor(max_workers=AHEAD)
             sides = [torch.cuda.Stream(device=self.dev) for _ in range(AHEAD)]
 
@@ -662,7 +667,9 @@ class HotPathEngine:
                 blocked = (index16 and lds_order and block_order and perm is not None and sort_events == "node"
                            and self.n_bins * 96 <= 65536)
                 if blocked:
-                    perm = deposit_block_order_native(obin, node, grid.size)
+                    # (PISA_HIP_TORCH_ORDER=1: the torch formulation, the specification the native call is tested against)
+                    perm = deposit_block_order(obin, node, window=4096, banks=32) \
+                        if _os.environ.get("PISA_HIP_TORCH_ORDER") == "1" else deposit_block_order_native(obin, node, grid.size)
                 elif part_starts is not None:
                     pass                      # (bank order applied inside the partitions)
                 elif lds_order and perm is not None and (sort_events == "part" or (

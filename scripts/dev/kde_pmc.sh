@@ -5,7 +5,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/kde_pmc; mkdir -p $OUT
 pass () {  # tag, counters...
   tag=$1; shift
   rm -rf /tmp/kp_$tag
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/kp_$tag -o p -- python3 $GRAFT_REPO_ROOT/scripts/dev/kde_facts.py 1e7 ${NC:-3} > /tmp/kp_$tag.log 2>&1
+  timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/kp_$tag -o p -- python3 $GRAFT_REPO_ROOT/scripts/dev/kde_facts.py 1e7 ${NC:-3} > /tmp/kp_$tag.log 2>&1
   cp /tmp/kp_$tag/p_counter_collection.csv $OUT/pmc_$tag.csv
 }
 pass a SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY

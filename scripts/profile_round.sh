@@ -1,6 +1,6 @@
 # Full measurement set of the default bench for profiles/<tag> (run on the GPU box):
 #   bench.json                  plain bench.py run (the judged line, with all legs)
-#   kernel_stats.csv            rocprofv3 --kernel-trace --stats of the headline loop (bench.py --legs none)
+#   kernel_stats.csv            timeout 600 rocprofv3 --kernel-trace --stats of the headline loop (bench.py --legs none)
 #   kernels_by_phase.json       per-kernel mean over the timed loop from the same trace
 #   pmc_FETCH_SIZE.csv / pmc_WRITE_SIZE.csv   separate --pmc passes (bench.py --steps 3 --no-kernel-timing)
 #   traffic.json                HBM bytes per launch of the dominant kernel derived from them
@@ -17,11 +17,11 @@ cd $GRAFT_REPO_ROOT
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.stderr
 tail -c 400 $OUT/bench.json
 LEAN="--no-cpu-baseline --no-drop-probe --no-batch-probe --legs none"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py $LEAN > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py $LEAN > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
 cp $OUT/stats/bench_kernel_stats.csv $OUT/kernel_stats.csv
 pmc_pair () {  # name, extra bench args
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$1_$c -o p -- python3 bench.py --steps 3 --warmup 1 --no-kernel-timing $LEAN $2 > /dev/null 2> $OUT/pmc_$1_$c.log
+    timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$1_$c -o p -- python3 bench.py --steps 3 --warmup 1 --no-kernel-timing $LEAN $2 > /dev/null 2> $OUT/pmc_$1_$c.log
     cp $OUT/pmc_$1_$c/p_counter_collection.csv $OUT/pmc_$1_$c.csv
   done
 }
@@ -31,14 +31,14 @@ pmc_pair coord "--coordinate-form"
 pmc_pair fine "--binning fine3d"
 for v in std nsi decay; do
   F=""; [ $v = nsi ] && F="--nsi"; [ $v = decay ] && F="--decay"
-  rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/pmc_events_$v -o p -- python3 scripts/bench_events.py --events 1e6 --steps 3 --warmup 1 $F > $OUT/events_$v.json 2> $OUT/pmc_events_$v.log
+  timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/pmc_events_$v -o p -- python3 scripts/bench_events.py --events 1e6 --steps 3 --warmup 1 $F > $OUT/events_$v.json 2> $OUT/pmc_events_$v.log
   cp $OUT/pmc_events_$v/p_counter_collection.csv $OUT/pmc_events_$v.csv
 done
-rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/pmc_kde -o p -- python3 scripts/bench_kde.py 2e5 > $OUT/kde_pmc_run.json 2> $OUT/pmc_kde.log
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/pmc_kde -o p -- python3 scripts/bench_kde.py 2e5 > $OUT/kde_pmc_run.json 2> $OUT/pmc_kde.log
 cp $OUT/pmc_kde/p_counter_collection.csv $OUT/pmc_kde.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kde_stats -o kde -- python3 scripts/dev/c3_probe.py 1e7 > $OUT/c3_probe.log 2> $OUT/kde_stats.log
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kde_stats -o kde -- python3 scripts/dev/c3_probe.py 1e7 > $OUT/c3_probe.log 2> $OUT/kde_stats.log
 cp $OUT/kde_stats/kde_kernel_stats.csv $OUT/kde_kernel_stats.csv
-rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 --kernel-trace --output-format csv -d $OUT/pmc_c3 -o p -- python3 scripts/dev/c3_probe.py 1e7 > $OUT/c3_pmc_run.log 2> $OUT/pmc_c3.log
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 --kernel-trace --output-format csv -d $OUT/pmc_c3 -o p -- python3 scripts/dev/c3_probe.py 1e7 > $OUT/c3_pmc_run.log 2> $OUT/pmc_c3.log
 cp $OUT/pmc_c3/p_counter_collection.csv $OUT/pmc_c3_full.csv
 # SQ counters of the KDE kernels (VALU occupancy, wavefront lifetimes, LDS conflicts): kde_sq_counters.json
 bash scripts/dev/kde_pmc.sh > $OUT/kde_pmc.log 2>&1; cp gpurun_out/kde_pmc/kde_sq_counters.json $OUT/kde_sq_counters.json
@@ -47,7 +47,7 @@ bash scripts/dev/kde_pmc.sh > $OUT/kde_pmc.log 2>&1; cp gpurun_out/kde_pmc/kde_s
 # with its SQ counters, the multi-point kernels, the one-pass flux refresh
 trace () {  # name, command...
   name=$1; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tr_$name -o t -- "$@" > $OUT/run_$name.json 2> $OUT/tr_$name.log
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tr_$name -o t -- "$@" > $OUT/run_$name.json 2> $OUT/tr_$name.log
   cp $OUT/tr_$name/t_kernel_stats.csv $OUT/kernel_stats_$name.csv
   rm -rf $OUT/tr_$name
 }
@@ -62,7 +62,7 @@ trace events_c5_full python3 scripts/bench_events.py --events 1e8 --nsi --steps 
 trace events_c2_decay python3 scripts/bench_events.py --events 1e6 --steps 20 --decay
 trace events_c5_decay python3 scripts/bench_events.py --events 1.25e7 --nsi --steps 6 --decay
 for K in 3 5 9; do trace multi_K$K python3 scripts/dev/multi_probe.py 1e7 $K; done
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_events_sq -o p -- python3 scripts/bench_events.py --events 1.25e7 --nsi --steps 3 --warmup 1 > /dev/null 2> $OUT/pmc_events_sq.log
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_events_sq -o p -- python3 scripts/bench_events.py --events 1.25e7 --nsi --steps 3 --warmup 1 > /dev/null 2> $OUT/pmc_events_sq.log
 cp $OUT/pmc_events_sq/p_counter_collection.csv $OUT/pmc_events_sq.csv
 rm -rf $OUT/pmc_events_sq
 python3 - <<PY
@@ -80,7 +80,7 @@ if sq:
     sq["valu_issue_fraction_of_wave_cycles"] = sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"]
     sq["waiting_fraction_of_wave_cycles"] = sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"]
     sq["valu_instructions_per_wave"] = sq["SQ_INSTS_VALU"] / sq["SQ_WAVES"]
-    sq["method"] = ("rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY "
+    sq["method"] = ("timeout 600 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY "
                     "over scripts/bench_events.py --events 1.25e7 --nsi; mean per launch of prob3_events_kernel")
 json.dump(sq, open(OUT + "/events_sq_counters.json", "w"), indent=1)
 print("events SQ", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in sq.items() if k != "method"})
@@ -101,7 +101,7 @@ def per_launch(path, kernel, name):
     v = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
          if kernel in r["Kernel_Name"] and r["Counter_Name"] == name]
     return (sum(v) / len(v), len(v)) if v else (float("nan"), 0)
-METHOD = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (bench.py --steps 3 --no-kernel-timing); "
+METHOD = ("timeout 600 rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (bench.py --steps 3 --no-kernel-timing); "
           "FETCH_SIZE is in KiB and on gfx950 reports half of the bytes of 16-B/lane coalesced streams "
           "(MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE exact")
 def traffic(tag, label, alg, fname):
@@ -133,7 +133,7 @@ for v in ("std", "nsi", "decay"):
             + per["SQ_INSTS_VALU_TRANS_F64"])
     ev[v] = {"instructions_per_event_lane": per, "launches": len(launches), "flop_per_event": flop,
              "valu_instructions_per_event_lane": per["SQ_INSTS_VALU"]}
-ev["method"] = ("rocprofv3 --pmc SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 SQ_INSTS_VALU over scripts/bench_events.py --events 1e6; "
+ev["method"] = ("timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 SQ_INSTS_VALU over scripts/bench_events.py --events 1e6; "
                 "wave-level instruction counts x 64 lanes summed over the launches, divided by the summed grid sizes "
                 "(each launch covers the events of one sign); inactive lanes of partially filled or divergent waves "
                 "are counted: an upper bound of the useful lane operations; FMA = 2 flop")
@@ -165,7 +165,7 @@ tot = sum(d["flop"] for d in per_kernel.values())
 json.dump({"events": 9999996, "evaluations_in_run": n_eval, "fp64_flop_per_evaluation": tot / n_eval,
            "per_kernel_flop_per_evaluation": {k_: v["flop"] / n_eval for k_, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["flop"])},
            "launches_per_evaluation": {k_: len(v["dispatches"]) / n_eval for k_, v in per_kernel.items()},
-           "method": "rocprofv3 --pmc SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 over scripts/dev/c3_probe.py 1e7 (4 evaluations of the "
+           "method": "timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 over scripts/dev/c3_probe.py 1e7 (4 evaluations of the "
                      "1e7-event pipeline with utils.kde); wave-level counts x 64 lanes, FMA = 2 flop, summed over every kernel "
                      "whose name contains kde_"}, open(OUT + "/kde_flops.json", "w"), indent=1)
 print("kde flop per evaluation %.3e" % (tot / n_eval))

@@ -773,7 +773,10 @@ def test_partitioned_window_order_same_bits(n_events):
 
 @pytest.mark.parametrize("n,n_nodes,n_bins,frac_out", [
     (833333, 20000, 128, 0.55), (20000, 2400, 128, 0.3), (4096 * 3, 600, 200, 0.0), (4096 * 3 + 17, 600, 200, 1.0),
-    (1000, 60, 7, 0.5), (255, 10, 3, 0.2), (256, 10, 3, 0.0), (257, 1, 1, 0.0), (9000, 5, 31, 0.9), (70001, 19999, 4800, 0.4)])
+    (1000, 60, 7, 0.5), (255, 10, 3, 0.2), (256, 10, 3, 0.0), (257, 1, 1, 0.0), (9000, 5, 31, 0.9), (70001, 19999, 4800, 0.4),
+    # an ODD count beyond the size at which the library's radix sort switches to its one-sweep form: the sort's temporary
+    # storage started at an odd multiple of 4 bytes and the launch hung (found under the counter passes of round 5)
+    (3333333, 20000, 128, 0.55)])
 def test_native_resident_order_is_the_torch_formulation(n, n_nodes, n_bins, frac_out):
     """`pisa_hip_deposit_block_order` (csrc/order.hip, round 5: one key, one radix sort, one workgroup per window, the block
     interleave in closed form) returns, element by element, the permutation of `engine.deposit_block_order` (the torch
