@@ -368,7 +368,7 @@ def cpu_baseline(wl, data, matrices, device_llh, cores_logical=None, device_hist
         "oracle_llh": oracle_llh,
         "device_llh": device_llh,
         "llh_rel_diff": abs(device_llh - oracle_llh) / abs(oracle_llh) if oracle_llh else None,
-        "llh_gate": llh_gate(data, lam, device_llh, oracle_llh),
+        "llh_gate": llh_gate(data, lam, device_llh, oracle_llh, device_hist),
     }
 
 
