@@ -2104,7 +2104,9 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
     {
         unsigned bits = 1;
         while (bits < 32 && ((int64_t)1 << bits) < k->n_cells) bits++;
-        KDE_TRY_HIP(rocprim::radix_sort_pairs<FlatSortConfig>(temp, tb, flat_a, flat_b, idx_a, idx_b, (size_t)n, 0u, bits, s));
+        static const int twice = PISA_DEV_INT("KDE_TWICE", 0);   // development: marginal cost of a phase = wall time with it run twice
+        for (int rep = 0; rep < ((twice & 4) ? 2 : 1); rep++)
+            KDE_TRY_HIP(rocprim::radix_sort_pairs<FlatSortConfig>(temp, tb, flat_a, flat_b, idx_a, idx_b, (size_t)n, 0u, bits, s));
     }
     KDE_D(kde_gather_sources_kernel, dim3(nb), dim3(256), 0, s, y, d_w, 1.0 / sw, 1.0 / k->norm, idx_b, n, k->ys, k->wn,
           k->coef, adaptive ? (double *)nullptr : k->s2);
@@ -2285,7 +2287,10 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
                     hipLaunchKernelGGL(kde_hermite_pilot_kernel<PP>, grid, dim3(KDE_THREADS), 0, s, g, d_blocks, \
                                        k->ys, n, k->coef, k->cell_start, slot, herm, n_split, part, k->pair_count); \
                 } } while (0)
-            if (P == 14) KDE_FGT(14); else if (P == 16) KDE_FGT(16); else if (P == 18) KDE_FGT(18); else KDE_FGT(20);
+            static const int twice = PISA_DEV_INT("KDE_TWICE", 0);
+            for (int rep = 0; rep < ((twice & 2) ? 2 : 1); rep++) {
+                if (P == 14) KDE_FGT(14); else if (P == 16) KDE_FGT(16); else if (P == 18) KDE_FGT(18); else KDE_FGT(20);
+            }
 #undef KDE_FGT
             KDE_TRY(check_hip(hipGetLastError(), "kde expansion kernels"));
             k->n_dense = nd;
@@ -2565,7 +2570,10 @@ PISA_API int pisa_hip_kde_evaluate_lattice(pisa_hip_kde *k, const double *h_orig
 #endif
 #define KDE_LAT(RR, LL) hipLaunchKernelGGL((kde_lattice_kernel<RR, LL>), dim3((unsigned)n_waves), dim3(64), 0, s, L, g.rcut2, rec, k->n, lists, load, wstart, n_patches, part, k->pair_count, stamps)
 #define KDE_LAT_R(RR) do { if (lg == 8) KDE_LAT(RR, 8); else if (lg == 16) KDE_LAT(RR, 16); else if (lg == 32) KDE_LAT(RR, 32); else KDE_LAT(RR, 64); } while (0)
-    if (R == 32) KDE_LAT_R(32); else if (R == 16) KDE_LAT_R(16); else KDE_LAT_R(8);
+    static const int twice = PISA_DEV_INT("KDE_TWICE", 0);
+    for (int rep = 0; rep < ((twice & 1) ? 2 : 1); rep++) {
+        if (R == 32) KDE_LAT_R(32); else if (R == 16) KDE_LAT_R(16); else KDE_LAT_R(8);
+    }
 #undef KDE_LAT_R
 #undef KDE_LAT
     hipLaunchKernelGGL(kde_lattice_combine_kernel, dim3((unsigned)(n_patches * R)), dim3(256), 0, s, part, L, R, wstart, d_out);

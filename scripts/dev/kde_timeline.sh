@@ -38,4 +38,22 @@ for s, e in sorted(heavy):
     else: ce = max(ce, e)
 hb += ce - cs
 print("union of heavy kernels %.2f ms" % (hb / 1e6))
+# the evaluation in slices of 250 us: heavy kernels running (mean concurrency), any kernel running (fraction)
+SL = 250000
+first_kde = min(s for s, e, n in sel if "kde_" in n)
+first_heavy = min(s for s, e in heavy)
+last_heavy = max(e for s, e in heavy)
+print("evaluation starts %.2f ms before its first kde kernel; first heavy kernel at %.2f ms, last heavy kernel ends at %.2f ms, window ends %.2f ms"
+      % ((first_kde - t0) / 1e6, (first_heavy - t0) / 1e6, (last_heavy - t0) / 1e6, (t1 - t0) / 1e6))
+def cover(iv, a, b):
+    return sum(max(0, min(e, b) - max(s, a)) for s, e in iv) / (b - a)
+allk = [(s, e) for s, e, _ in sel]
+lat = [(s, e) for s, e, n in sel if "kde_lattice_kernel" in n]
+fgt = [(s, e) for s, e, n in sel if any(x in n for x in ("kde_h2l", "kde_hermite_coef", "kde_local_pilot"))]
+print("slice   all  heavy  lattice  fgt   (mean number of kernels running)")
+a = t0
+while a < t1:
+    b = min(a + SL, t1)
+    print("%5.2f  %5.2f %5.2f %5.2f %5.2f" % ((a - t0) / 1e6, cover(allk, a, b), cover(heavy, a, b), cover(lat, a, b), cover(fgt, a, b)))
+    a = b
 PY
