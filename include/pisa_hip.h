@@ -618,6 +618,10 @@ int pisa_hip_kde_lattice_submit(pisa_hip_kde_job *jobs, int32_t n_jobs, int32_t 
                                 int32_t adaptive, double alpha, double tol, const double *h_origin,
                                 const double *h_step, const int64_t *h_count, int32_t n_threads, void *stream);
 int pisa_hip_kde_lattice_wait(void);
+/* returns when THESE jobs (a range of an array handed to _submit) are done -- their `status` and outputs may be read --,
+ * whatever else is still queued: the stage copies and folds the densities of one container's estimators while the later
+ * containers' are still being built (a job that was never submitted counts as done). */
+int pisa_hip_kde_lattice_wait_jobs(const pisa_hip_kde_job *jobs, int32_t n_jobs);
 /* The pool threads keep their stream, workspaces and estimator scratch between calls (grow-only, a few hundred MB per
  * thread at C3 sizes).  This call waits for the queued jobs, has every pool thread free what it holds and returns when
  * all have; the next submission allocates again. */

@@ -274,6 +274,7 @@ _SIGS = {
     "pisa_hip_kde_lattice_submit": (C.c_int, [C.POINTER(KdeJob), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "pisa_hip_kde_lattice_wait": (C.c_int, []),
+    "pisa_hip_kde_lattice_wait_jobs": (C.c_int, [C.c_void_p, C.c_int32]),
     "pisa_hip_kde_pool_release": (C.c_int, []),
     "pisa_hip_kde_arrays": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "pisa_hip_kde_destroy": (C.c_int, [C.c_void_p]),

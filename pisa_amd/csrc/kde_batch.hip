@@ -19,6 +19,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <unordered_set>
 #include <vector>
 
 #include "common.hpp"
@@ -82,7 +83,8 @@ class KdePool {
         for (auto &t : threads_) t.join();
     }
     // queues the tasks (in the given order) for up to n_threads pool threads and returns
-    void submit(std::vector<Task> &&tasks, int n_threads) {
+    // (`tags`: what wait_for() is asked about -- the job a task works on)
+    void submit(std::vector<Task> &&tasks, const std::vector<const void *> &tags, int n_threads) {
         std::lock_guard<std::mutex> lk(m_);
         // a new thread starts from the release epoch of its creation (read here, under the lock): a release()
         // that arrives before the thread has run a single instruction is still seen and answered by it
@@ -92,8 +94,20 @@ class KdePool {
         }
         limit_ = std::max(limit_, n_threads);
         pending_ += (int)tasks.size();
-        for (auto &t : tasks) queue_.push_back(std::move(t));
+        for (size_t i = 0; i < tasks.size(); i++) {
+            open_.insert(tags[i]);
+            queue_.emplace_back(std::move(tasks[i]), tags[i]);
+        }
         cv_job_.notify_all();
+    }
+    // returns when none of the n tagged tasks is queued or running any more
+    void wait_for(const void *const *tags, int n) {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_done_.wait(lk, [&] {
+            for (int i = 0; i < n; i++)
+                if (open_.count(tags[i])) return false;
+            return true;
+        });
     }
     // returns when everything submitted so far is done
     void wait() {
@@ -128,18 +142,22 @@ class KdePool {
                 if (++released_ == (int)threads_.size()) cv_done_.notify_all();
                 continue;
             }
-            Task task = std::move(queue_.front());
+            Task task = std::move(queue_.front().first);
+            const void *tag = queue_.front().second;
             queue_.pop_front();
             lk.unlock();
             task(st);
             lk.lock();
-            if (--pending_ == 0) cv_done_.notify_all();
+            open_.erase(tag);
+            --pending_;
+            cv_done_.notify_all();   // (wait() looks at the count, wait_for() at the tags)
         }
     }
     std::mutex m_;
     std::condition_variable cv_job_, cv_done_;
     std::vector<std::thread> threads_;
-    std::deque<Task> queue_;
+    std::deque<std::pair<Task, const void *>> queue_;
+    std::unordered_set<const void *> open_;
     int pending_ = 0, limit_ = 0, n_started_ = 0, release_epoch_ = 0, released_ = 0;
     bool stop_ = false;
 };
@@ -243,16 +261,26 @@ PISA_API int pisa_hip_kde_lattice_submit(pisa_hip_kde_job *jobs, int32_t n_jobs,
     for (int i = 0; i < n_jobs; i++) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return jobs[a].n > jobs[b].n; });   // longest first
     std::vector<KdePool::Task> tasks;
+    std::vector<const void *> tags;
     for (int i : order) {
         pisa_hip_kde_job *job = jobs + i;
+        tags.push_back(job);
         tasks.push_back([job, P, ready](KdeWorkerState &st) { job->status = run_job(*job, P, (hipEvent_t)ready.get(), st); });
     }
-    pool().submit(std::move(tasks), n_threads > 0 ? n_threads : 8);
+    pool().submit(std::move(tasks), tags, n_threads > 0 ? n_threads : 8);
     return PISA_HIP_OK;
 }
 
 PISA_API int pisa_hip_kde_lattice_wait(void) {
     pool().wait();
+    return PISA_HIP_OK;
+}
+
+PISA_API int pisa_hip_kde_lattice_wait_jobs(const pisa_hip_kde_job *jobs, int32_t n_jobs) {
+    if (n_jobs < 0 || (n_jobs > 0 && !jobs)) return PISA_HIP_ERR_INVALID;
+    std::vector<const void *> tags((size_t)n_jobs);
+    for (int i = 0; i < n_jobs; i++) tags[i] = jobs + i;
+    pool().wait_for(tags.data(), n_jobs);
     return PISA_HIP_OK;
 }
 

@@ -531,6 +531,19 @@ class KdeLatticeBatch:
                                                              self._args[2], self._args[3], self._o, self._st, self._cnt,
                                                              self._threads, _stream()))
 
+    def wait_jobs(self, first, count):
+        """returns when jobs first .. first + count - 1 are done (`pisa_hip_kde_lattice_wait_jobs`), whatever else is
+        still running: (their densities [count, m] -- a view of the batch's output --, [sum of the weights used per job])"""
+        import ctypes as C
+
+        assert 0 <= first and first + count <= self.n
+        _lib.check(self._lib.pisa_hip_kde_lattice_wait_jobs(
+            C.c_void_p(C.addressof(self._arr) + first * C.sizeof(_lib.KdeJob)), count))
+        a = self._arr
+        for i in range(first, first + count):
+            _lib.check(a[i].status)
+        return self.out[first:first + count], [a[i].sum_w for i in range(first, first + count)]
+
     def wait(self):
         _lib.check(self._lib.pisa_hip_kde_lattice_wait())
         self._waited = True

@@ -357,27 +357,29 @@ def kde_histogramdd_batch(samples, binning, bw_method="scott", adaptive=True, al
                                 stats=stats, channels=smp.get("channels")) for smp in samples]
     batch = K.KdeLatticeBatch(n_jobs, lat[0], lat[1], lat[2], samples[0]["sample"].device, bw_method=bw_method,
                               adaptive=adaptive, alpha=alpha, tol=K.KDE_DEFAULT_TOL if tol is None else tol, n_threads=n_threads)
-    owner, sizes = [], []
+    sizes, first_of = [], []
     try:
         for si, (smp, (pid_bin, chans)) in enumerate(zip(samples, plans)):
             w = weights_of(smp)
+            first_of.append(batch.n)
             batch.submit([(x, w, idx if w is not None else None) for x, idx in chans])
-            owner += [(si, pid_bin)] * len(chans)
             sizes += [int(x.shape[1]) for x, _ in chans]
+        # sample by sample, as its estimators finish: densities to the host (one copy per sample), folded and summed into
+        # bins while the later samples' estimators still run -- the element operations of `_finish_hist`, job by job
+        per_sample = [[] for _ in samples]
+        for si, (pid_bin, chans) in enumerate(plans):
+            dens, sums = batch.wait_jobs(first_of[si], len(chans))
+            dens = dens.cpu().numpy()
+            hists = _finish_hist_many(g, dens.reshape((len(chans),) + tuple(g["megashape"])), oversample)
+            hists = hists * np.asarray(sums, dtype=np.float64).reshape((-1,) + (1,) * (hists.ndim - 1))
+            per_sample[si] = list(hists)
     finally:
-        dens, sums, pairs = batch.wait() if batch.n else (None, [], (0, 0))
-    dens = dens.cpu().numpy()
+        pairs = batch.wait()[2] if batch.n else (0, 0)
     if stats is not None:
         stats["pairs_pilot"] = stats.get("pairs_pilot", 0) + pairs[0]
         stats["pairs_eval"] = stats.get("pairs_eval", 0) + pairs[1]
         stats["all_pairs"] = stats.get("all_pairs", 0) + sum(n * (n * bool(adaptive) + g["n_points"]) for n in sizes)
-    per_sample = [[] for _ in samples]
-    pid_of = [None] * len(samples)
-    hists = _finish_hist_many(g, dens.reshape((n_jobs,) + tuple(g["megashape"])), oversample)
-    hists = hists * np.asarray(sums, dtype=np.float64).reshape((-1,) + (1,) * (hists.ndim - 1))
-    for k, (si, pid_bin) in enumerate(owner):
-        per_sample[si].append(hists[k])
-        pid_of[si] = pid_bin
+    pid_of = [pid_bin for pid_bin, _ in plans]
     out = []
     for si, stack in enumerate(per_sample):
         if not stack_pid:

@@ -548,6 +548,37 @@ def test_kde_batch_reports_a_failing_job_and_stays_usable():
     assert sums[1] == 25000.0 and np.isclose(sums[0], float(w_good.sum()), rtol=1e-13)
 
 
+def test_kde_batch_waits_for_a_range_of_jobs():
+    """`pisa_hip_kde_lattice_wait_jobs`: a caller that wants the first jobs' maps does not wait for the rest of the queue:
+    the range it names is done when the call returns (status and densities final: equal to the estimator built alone), the
+    large job behind it may still run; a failing job inside the range is reported by the range's wait; the batch's own
+    `wait` still closes it"""
+    from pisa_amd import _lib
+    from pisa_amd import kernels as K
+
+    rs = np.random.RandomState(37)
+    small = [K.to_device(rs.randn(2, 20000)) for _ in range(3)]
+    big = K.to_device(rs.randn(2, 600000))
+    origin, step, count = [-2.0, -2.0], [0.1, 0.1], (41, 41)
+    b = K.KdeLatticeBatch(5, origin, step, count, big.device, n_threads=3)
+    b.submit([(big, None, None)])
+    b.submit([(x, None, None) for x in small])
+    dens, sums = b.wait_jobs(1, 3)
+    got = dens.cpu().numpy()
+    for i, x in enumerate(small):
+        ref = K.KdeEstimator(x, None, alpha=0.3).evaluate_lattice(origin, step, count)
+        np.testing.assert_array_equal(got[i], ref.cpu().numpy())
+    assert sums == [20000.0] * 3
+    b.submit([(small[0], K.to_device(np.zeros(20000)), None)])     # refused by the estimator: no finite moments
+    with pytest.raises(_lib.PisaHipError):
+        b.wait_jobs(4, 1)
+    dens0, _ = b.wait_jobs(0, 1)
+    np.testing.assert_array_equal(dens0.cpu().numpy()[0],
+                                  K.KdeEstimator(big, None, alpha=0.3).evaluate_lattice(origin, step, count).cpu().numpy())
+    with pytest.raises(_lib.PisaHipError):
+        b.wait()
+
+
 def test_kde_pool_release_returns_the_workspaces():
     """`pisa_hip_kde_pool_release`: the pool threads' grow-only workspaces go back to the device, and the pool works again"""
     import torch
