@@ -987,7 +987,7 @@ kde_lattice_kernel(const KdeLattice L, double rcut2, const double *__restrict__ 
         strips *= R;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) strips += __shfl_down(strips, off);
-        if (lane == 0 && strips) atomicAdd(pair_count, strips);
+        if (lane == 0 && strips) atomicAdd(pair_count, strips);   // (one per wavefront, spread over the launch: 2 % of it, measured without)
     }
 }
 
@@ -1197,6 +1197,84 @@ kde_hermite_coef_kernel(KdeGeom g, const int32_t *__restrict__ dense_cells,
         for (int s = 1; s < NG; s++) v += red[s * (PR * PR) + n * PR + m];
         herm[(int64_t)blockIdx.x * (P * P) + e] = v;
     }
+}
+
+// 1 / n!, n < 24 (the factorial scaling of the local expansion: two multiplications instead of two loops and a division per element)
+__device__ constexpr double INV_FACT[24] = {1.0, 1.0, 0.5, 0.16666666666666666, 0.041666666666666664, 0.008333333333333333, 0.001388888888888889, 0.0001984126984126984, 2.48015873015873e-05, 2.7557319223985893e-06, 2.755731922398589e-07, 2.505210838544172e-08, 2.08767569878681e-09, 1.6059043836821613e-10, 1.1470745597729725e-11, 7.647163731819816e-13, 4.779477332387385e-14, 2.8114572543455206e-15, 1.5619206968586225e-16, 8.22063524662433e-18, 4.110317623312165e-19, 1.9572941063391263e-20, 8.896791392450574e-22, 3.8681701706306835e-23};
+typedef double __attribute__((ext_vector_type(4))) mfma_d4;
+// The same coefficients on the matrix cores (round 5; series orders up to 16): A = X^T Y with X[j][n] = d1_j^n / n!,
+// Y[j][m] = q_j d2_j^m / m! over the sources j of the cell -- a 16 x J by J x 16 product, four sources per
+// `v_mfma_f64_16x16x4_f64`.  One wavefront per cell, no LDS, no barrier: lane (i = lane & 15, k = lane >> 4) forms the
+// i-th power of source 4 s + k of the round for both coordinates (its exponent never changes: square-and-multiply with
+// lane-constant selects, six multiplications) as its element of the A and of the B operand.  The vector form above stages
+// the powers of 64 sources in LDS between two barriers and adds four partial sums through LDS: 37 us per estimator for
+// 0.2 GFLOP.  The products are summed in the matrix cores' order and the powers are not formed by the running product
+// d^n / n!: the coefficients differ from the vector form's by rounding (a few 1e-16 relative), run to run the same.
+__device__ __forceinline__ double lane_power(double d, int e) {   // d^e, 0 <= e < 16
+    double p = (e & 1) ? d : 1.0;
+    const double d2 = d * d;
+    p = (e & 2) ? p * d2 : p;
+    const double d4 = d2 * d2;
+    p = (e & 4) ? p * d4 : p;
+    const double d8 = d4 * d4;
+    return (e & 8) ? p * d8 : p;
+}
+constexpr int FGT_WAVES = 4;   // wavefronts per workgroup of the matrix-core kernels, each with a cell (or targets) of its own:
+                               // a launch of 5 600 one-wavefront workgroups took as long to hand out as to compute
+__global__ void __launch_bounds__(64 * FGT_WAVES)
+kde_hermite_coef_mfma_kernel(KdeGeom g, const int32_t *__restrict__ dense_cells, int n_dense,
+                             const int32_t *__restrict__ cell_start,
+                             const double *__restrict__ sy, int64_t n_src, const double *__restrict__ coef, int P,
+                             double *__restrict__ herm) {
+    // (the FGT_WAVES wavefronts of a workgroup take every FGT_WAVES-th round of 16 sources of ONE cell; their sums are
+    //  added in wavefront order through LDS: the chain of memory latencies of a cell's rounds is what the launch takes)
+    __shared__ double red[FGT_WAVES][256];
+    const int lane = (int)threadIdx.x & 63, li = lane & 15, lk = lane >> 4, wave = (int)threadIdx.x >> 6;
+    const int slot_i = (int)blockIdx.x;
+    const int c = dense_cells[slot_i];
+    const int cx = c % g.nc[0], cy = c / g.nc[0];
+    const double c1 = g.ylo[0] + (cx + 0.5) * g.cell, c2 = g.ylo[1] + (cy + 0.5) * g.cell;
+    const int begin = cell_start[c], end = cell_start[c + 1];
+    const double scale = INV_FACT[li];
+    mfma_d4 acc = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+    // the sources of the NEXT round are requested before this round's powers are formed (a cell in the middle of the
+    // cloud holds thousands of sources: its wavefront is the launch's critical path, one memory latency per round)
+    double s1[4], s2[4], sq[4], n1[4], n2[4], nq[4];
+    auto fetch = [&](int base, double (&a1)[4], double (&a2)[4], double (&aq)[4]) {
+#pragma unroll
+        for (int sx = 0; sx < 4; sx++) {
+            const int j = base + 4 * sx + lk;
+            const int64_t jj = j < end ? j : begin;               // (unconditional loads; a source beyond the cell gets weight zero below)
+            a1[sx] = sy[jj];
+            a2[sx] = sy[n_src + jj];
+            aq[sx] = coef[jj];
+        }
+    };
+    constexpr int STEP = 16 * FGT_WAVES;
+    fetch(begin + 16 * wave, s1, s2, sq);
+    for (int base = begin + 16 * wave; base < end; base += STEP) {
+        fetch(base + STEP < end ? base + STEP : begin, n1, n2, nq);
+#pragma unroll
+        for (int sx = 0; sx < 4; sx++) {
+            const bool ok = base + 4 * sx + lk < end;
+            const double d1 = (s1[sx] - c1) * RSQRT2, d2 = (s2[sx] - c2) * RSQRT2;
+            const double q = ok ? sq[sx] : 0.0;
+            const double a = lane_power(d1, li) * scale;
+            const double b = lane_power(d2, li) * scale * q;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int sx = 0; sx < 4; sx++) { s1[sx] = n1[sx]; s2[sx] = n2[sx]; sq[sx] = nq[sx]; }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) red[wave][r * 64 + lane] = acc[r];
+    __syncthreads();
+    static_assert(FGT_WAVES == 4, "one accumulator register per wavefront in the final sum");
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < FGT_WAVES; q++) v += red[q][wave * 64 + lane];
+    const int row = lk + 4 * wave;
+    if (row < P && li < P) herm[(int64_t)slot_i * (P * P) + row * P + li] = v;
 }
 
 // pilot densities at the (cell-sorted) sources: dense cells through their Hermite series, sparse
@@ -1468,8 +1546,6 @@ kde_h2l_kernel(KdeGeom g, const int32_t *__restrict__ tcells, const int32_t *__r
 // order of the kernel above (offsets ascending = sources descending, inner index ascending): same bits.
 //   pass 0   grid (nx, ceil(ny / 4)):  V[cy_C][cx] for cy_C = 4 q .. 4 q + 3
 //   pass 1   grid (ceil(nx / 4), ny):  L[head of (cx_C, cy)] for cx_C = 4 q .. 4 q + 3 (cells with sources only)
-// 1 / n!, n < 24 (the factorial scaling of the local expansion: two multiplications instead of two loops and a division per element)
-__device__ constexpr double INV_FACT[24] = {1.0, 1.0, 0.5, 0.16666666666666666, 0.041666666666666664, 0.008333333333333333, 0.001388888888888889, 0.0001984126984126984, 2.48015873015873e-05, 2.7557319223985893e-06, 2.755731922398589e-07, 2.505210838544172e-08, 2.08767569878681e-09, 1.6059043836821613e-10, 1.1470745597729725e-11, 7.647163731819816e-13, 4.779477332387385e-14, 2.8114572543455206e-15, 1.5619206968586225e-16, 8.22063524662433e-18, 4.110317623312165e-19, 1.9572941063391263e-20, 8.896791392450574e-22, 3.8681701706306835e-23};
 constexpr int H2L4_T = 4;
 template <int P, int PASS>
 __global__ void __launch_bounds__(H2L_THREADS)
@@ -1644,6 +1720,172 @@ kde_h2l4_kernel(KdeGeom g, const int32_t *__restrict__ hslot, const int32_t *__r
     }
 }
 
+// The two passes on the matrix cores (round 5; series orders up to 16, i.e. the stage's cut-off).  A pass is a sum of
+// products of 16 x 16 matrices -- W = sum_v A_v H(o_v) with the symmetric Hankel matrix H(o)[b][l] = h_{b+l}(o) --, which is
+// what `v_mfma_f64_16x16x4_f64` computes: 1 024 multiply-adds per instruction from ONE double per lane and operand,
+//     A operand  lane -> [row = lane & 15][k = lane >> 4],   B operand  lane -> [k = lane >> 4][col = lane & 15],
+//     C / D      lane, register r -> [row = (lane >> 4) + 4 r][col = lane & 15]
+// (four instructions per matrix product: k = 4 s + (lane >> 4)).  The vector form above spends five LDS reads per sixteen
+// multiply-adds and two barriers per source position: VALU busy 0.35-0.4, ~50 us per pass and estimator.  Here a workgroup
+// is ONE wavefront with H2LM_T consecutive targets of the convolution direction: a source matrix comes straight from
+// global memory into the operand registers (pass 0: A_v as the A operand, pass 1: V_v as the B operand; zero beyond a
+// series order of 14), the Hankel entry of a lane -- h_{(lane & 15) + (lane >> 4) + 4 s}(o), the same for both passes --
+// from a table in LDS, no barrier in the loop, absent sources and out-of-reach offsets skipped wavefront-uniformly.
+// Sources descend as above (offsets ascend per target); inside a product the matrix cores' own order: the results differ
+// from the vector form's by rounding (1e-16 relative), and are the same from run to run.
+constexpr int H2LM_T = 2;
+template <int PASS>
+__global__ void __launch_bounds__(64 * FGT_WAVES)
+kde_h2l_mfma_kernel(KdeGeom g, const int32_t *__restrict__ hslot, const int32_t *__restrict__ slot,
+                    const double *__restrict__ herm, const double *__restrict__ hankel, int reach, int P,
+                    double *__restrict__ V, uint8_t *__restrict__ vflag, double *__restrict__ local) {
+    constexpr int NHP = 32;                                      // padded Hankel row: indices up to 15 + 15
+    __shared__ double sH[(2 * H2L_MAX_REACH + 1) * NHP];
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const int NH = 2 * P - 1, PP = P * P;
+    for (int i = (int)threadIdx.x; i < (2 * reach + 1) * NHP; i += 64 * FGT_WAVES) {
+        const int row = i / NHP, col = i % NHP;
+        sH[i] = col < NH ? hankel[row * NH + col] : 0.0;
+    }
+    __syncthreads();
+    const int nx = g.nc[0], ny = g.nc[1];
+    // the FGT_WAVES wavefronts of a workgroup share the source positions of ONE group of targets (every FGT_WAVES-th
+    // position each, their sums added in wavefront order through LDS at the end): a wavefront's time is a chain of memory
+    // latencies, one per position it multiplies, and that chain is what the launch takes
+    __shared__ double red[FGT_WAVES][H2LM_T][256];
+    __shared__ int any_w[FGT_WAVES][H2LM_T];
+    const int u0 = (PASS == 0 ? (int)blockIdx.y : (int)blockIdx.x) * H2LM_T;
+    const int w = PASS == 0 ? (int)blockIdx.x : (int)blockIdx.y;
+    const int nu = PASS == 0 ? ny : nx;
+    bool tgt[H2LM_T], any[H2LM_T];
+    int head[H2LM_T];
+    bool some = false;
+#pragma unroll
+    for (int t = 0; t < H2LM_T; t++) {
+        tgt[t] = u0 + t < nu;
+        head[t] = -1;
+        any[t] = false;
+        if (PASS == 1 && tgt[t]) {
+            head[t] = hslot[(int64_t)w * nx + u0 + t];
+            tgt[t] = head[t] >= 0;
+        }
+        some = some || tgt[t];
+    }
+    if (!some) return;                                           // (pass 1: no cell with sources among the targets)
+    mfma_d4 acc[H2LM_T];
+#pragma unroll
+    for (int t = 0; t < H2LM_T; t++) acc[t] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+    const int li = lane & 15, lk = lane >> 4;
+    const int v_hi = u0 + H2LM_T - 1 + reach < nu - 1 ? u0 + H2LM_T - 1 + reach : nu - 1;
+    const int v_lo = u0 - reach > 0 ? u0 - reach : 0;
+    // this lane's element of k-step s of a source matrix: pass 0 [li][4 s + lk] (A operand), pass 1 [4 s + lk][li] (B operand)
+    int off[4];
+    bool inside[4];
+#pragma unroll
+    for (int sx = 0; sx < 4; sx++) {
+        const int kk = 4 * sx + lk;
+        inside[sx] = li < P && kk < P;
+        off[sx] = inside[sx] ? (PASS == 0 ? li * P + kk : kk * P + li) : 0;
+    }
+    // Which of the <= 2 reach + H2LM_T source positions hold a matrix: looked up by the lanes at once (lane j: position
+    // v_lo + j) -- one position per loop iteration, each a dependent global load in front of the matrix's own loads, was
+    // what a wavefront's time consisted of (two memory latencies per position against 0.2 us of matrix instructions).
+    const int n_pos = v_hi - v_lo + 1;                           // <= 2 * H2L_MAX_REACH + H2LM_T < 64
+    int my_slot = -1;
+    if (lane < n_pos) {
+        if (PASS == 0) my_slot = slot[(int64_t)(v_lo + lane) * nx + w];                  // source cell (cx = w, cy_B = v)
+        else my_slot = vflag[(int64_t)w * nx + v_lo + lane] ? 0 : -1;                    // V of (cx_B = v, cy = w)
+    }
+    unsigned long long present = __builtin_amdgcn_ballot_w64(my_slot >= 0);
+    {   // this wavefront's share: ranks wave, wave + FGT_WAVES, ... of the positions that hold a matrix, from the highest down
+        unsigned long long all = present, keep = 0;
+        for (int rank = 0; all; rank++) {
+            const int j = 63 - __builtin_clzll(all);
+            all &= ~(1ull << j);
+            if (rank % FGT_WAVES == wave) keep |= 1ull << j;
+        }
+        present = keep;
+    }
+    auto next_pos = [&]() -> int {                               // highest position first: offsets ascend per target
+        if (!present) return -1;
+        const int j = 63 - __builtin_clzll(present);
+        present &= ~(1ull << j);
+        return j;
+    };
+    // (unconditional loads -- element 0 for a lane outside the matrix, the first matrix of the array behind the last
+    //  source --, so that the compiler can count them and wait for the current matrix only, not for those requested ahead)
+    auto fetch = [&](int j, double (&m)[4]) {
+        const double *from = PASS == 0 ? herm : V;
+        if (j >= 0)
+            from += PASS == 0 ? (int64_t)__builtin_amdgcn_readlane(my_slot, j) * PP : ((int64_t)w * nx + v_lo + j) * PP;
+#pragma unroll
+        for (int sx = 0; sx < 4; sx++) m[sx] = from[off[sx]];
+    };
+    auto multiply = [&](int j, const double (&m)[4]) {
+        const int v = v_lo + j;
+#pragma unroll
+        for (int t = 0; t < H2LM_T; t++) {
+            const int o = u0 + t - v;
+            if (!tgt[t] || o < -reach || o > reach) continue;    // wavefront-uniform
+            any[t] = true;
+            const double *hk = sH + (o + reach) * NHP + li + lk;
+#pragma unroll
+            for (int sx = 0; sx < 4; sx++) {
+                const double h = hk[4 * sx], x = inside[sx] ? m[sx] : 0.0;
+                acc[t] = PASS == 0 ? __builtin_amdgcn_mfma_f64_16x16x4f64(x, h, acc[t], 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_f64_16x16x4f64(h, x, acc[t], 0, 0, 0);
+            }
+        }
+    };
+    // two matrices requested ahead of the one being multiplied, in three register sets taken in turn (a copy from set to
+    // set would wait for the matrix just requested)
+    int ja = next_pos(), jb = next_pos(), jc = -1;
+    double ma[4], mb[4], mc[4];
+    fetch(ja, ma);
+    fetch(jb, mb);
+    for (;;) {
+        if (ja < 0) break;
+        jc = next_pos(); fetch(jc, mc); multiply(ja, ma);
+        if (jb < 0) break;
+        ja = next_pos(); fetch(ja, ma); multiply(jb, mb);
+        if (jc < 0) break;
+        jb = next_pos(); fetch(jb, mb); multiply(jc, mc);
+    }
+    // the wavefronts' sums, added in wavefront order; wavefront r of the workgroup finishes register r (rows lk + 4 r)
+#pragma unroll
+    for (int t = 0; t < H2LM_T; t++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[wave][t][r * 64 + lane] = acc[t][r];
+        if (lane == 0) any_w[wave][t] = any[t] ? 1 : 0;
+    }
+    __syncthreads();
+    static_assert(FGT_WAVES == 4, "one accumulator register per wavefront in the final sum");
+#pragma unroll
+    for (int t = 0; t < H2LM_T; t++) {
+        bool got = false;
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < FGT_WAVES; q++) {
+            got = got || any_w[q][t];
+            v += red[q][t][wave * 64 + lane];
+        }
+        const int row = lk + 4 * wave;
+        if (PASS == 0) {
+            if (u0 + t >= nu) continue;
+            const int64_t c = (int64_t)(u0 + t) * nx + w;
+            if (threadIdx.x == 0) vflag[c] = got ? 1 : 0;
+            if (got && row < P && li < P) V[c * PP + row * P + li] = v;
+        } else {
+            if (!tgt[t]) continue;
+            if (row < P && li < P) {
+                // D_k D_l = (-1)^(k+l) / (k! l!)
+                const double sgn = ((row + li) & 1) ? -1.0 : 1.0;
+                local[(int64_t)head[t] * PP + row * P + li] = sgn * v * INV_FACT[row] * INV_FACT[li];
+            }
+        }
+    }
+}
+
 // pilot densities at the (cell-sorted) sources: the local expansion of the target's cell for all
 // dense cells in range + direct sums over the sparse ones.
 template <int P, bool SPARSE>
@@ -1750,6 +1992,54 @@ kde_local_pilot_kernel(KdeGeom g, const KdeBlock *__restrict__ blocks, const dou
         if (jq < b.q_count) out[b.q_begin + jq] = acc[u];
     }
     if (pair_count && threadIdx.x == 0 && work) atomicAdd(pair_count, work);
+}
+
+// The local expansions at the sources when EVERY non-empty cell has a series (the default: nothing is summed directly):
+// one wavefront per 64 targets of a block (<= 512 sources of one cell), the cell's P x P coefficients as
+// LDS broadcasts.  The kernel above gives a block 256 threads with two targets each: a cell of the C3 estimators holds
+// ~200 sources, so most lanes had one target or none and still ran both Horner schemes (42 us per estimator for 0.2 GFLOP).
+// Same nested Horner scheme per target, same bits.
+template <int P>
+__global__ void __launch_bounds__(64 * FGT_WAVES)
+kde_local_pilot_wave_kernel(KdeGeom g, const KdeBlock *__restrict__ blocks, const double *__restrict__ sy, int64_t n_src,
+                            const double *__restrict__ local, double *__restrict__ out,
+                            unsigned long long *__restrict__ stamps) {
+    const unsigned long long t_start = stamps ? wall_clock64() : 0ull;
+    // grid (blocks, Q_CHUNK / (64 FGT_WAVES)): a wavefront takes ONE round of 64 targets of its block (a block of 512
+    // targets worked through by one wavefront was the launch's critical path), the cell's coefficients fetched once by the
+    // workgroup (one element per thread: ONE memory round trip) and read back from LDS as broadcasts
+    __shared__ double sL[P * P];
+    const int bi = (int)blockIdx.x;
+    const int round = (int)blockIdx.y * FGT_WAVES + ((int)threadIdx.x >> 6);
+    const KdeBlock b = blocks[bi];
+    const int q_count = b.q_count, q_begin = b.q_begin;
+    if ((int)blockIdx.y * FGT_WAVES * 64 >= q_count) return;     // (workgroup-uniform)
+    for (int i = (int)threadIdx.x; i < P * P; i += 64 * FGT_WAVES) sL[i] = local[(int64_t)b.head * (P * P) + i];
+    const double c1 = g.ylo[0] + (b.c0[0] + 0.5) * g.cell, c2 = g.ylo[1] + (b.c0[1] + 0.5) * g.cell;
+    const int jq = round * 64 + ((int)threadIdx.x & 63);
+    const int64_t j = q_begin + (jq < q_count ? jq : 0);
+    const double x = (sy[j] - c1) * RSQRT2, y = (sy[n_src + j] - c2) * RSQRT2;
+    __syncthreads();
+    if (round * 64 >= q_count) return;
+    const unsigned long long t_mid = stamps ? wall_clock64() : 0ull;
+    const double *L = sL;
+    double sum = 0.0;
+#pragma unroll 4
+    for (int k = P - 1; k >= 0; k--) {
+        const double *row = L + k * P;
+        double inner = 0.0;
+#pragma unroll
+        for (int l = P - 1; l >= 0; l--) inner = __builtin_fma(inner, y, row[l]);
+        sum = __builtin_fma(sum, x, inner);
+    }
+    if (jq < q_count) out[q_begin + jq] = sum;
+    // (the work count of this form -- (P^2 / 23 + 1) per target -- is added on the host: one atomic per block on ONE
+    //  address took 17 ns each, one after the other across the eight dies: 22 of the launch's 27 us, stamps of round 5)
+    if (stamps && (threadIdx.x & 63) == 0) {   // development: when this wavefront started, had its inputs, ended
+        unsigned long long *st = stamps + 4 * (((int64_t)bi * gridDim.y + blockIdx.y) * FGT_WAVES + (threadIdx.x >> 6));
+        st[0] = t_start; st[1] = t_mid; st[2] = wall_clock64();
+        st[3] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned long long)__builtin_amdgcn_s_getreg(63492);   // XCC_ID, HW_ID
+    }
 }
 
 // ------------------------------------------------------------------ host side
@@ -2150,6 +2440,7 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
         }
         const int n_blocks = (int)blocks.size();
         const int n_split = pick_split(n_blocks);
+        unsigned long long pilot_host_pairs = 0;   // work counted here instead of by the kernel (kde_local_pilot_wave_kernel)
         KdeBlock *d_blocks = ar.take<KdeBlock>(blocks.size());
         double *pilot = ar.take<double>(n);
         double *part = n_split > 1 ? ar.take<double>((size_t)n_split * n) : pilot;
@@ -2200,8 +2491,23 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
             const size_t pp = (size_t)(P * P);
             // translation passes in H2L_SPLIT parts of the source positions (see kde_h2l4_kernel): V, its flags and the local
             // expansions once per part
+            // translation passes: 2 = on the matrix cores where the series order allows (<= 16), 1 = four targets per
+            // workgroup on the vector units, 0 = one target per workgroup
+            unsigned long long *pstamps = nullptr;
+#ifdef PISA_DEV_PROBES
+            const size_t n_pstamps = (size_t)n_blocks * (Q_CHUNK / 64);
+            static const char *pstamp_path = PISA_DEV_STR("KDE_PILOT_STAMPS");   // development: per-wavefront (start, inputs, end, targets of the block)
+            if (pstamp_path) {
+                KDE_TRY_HIP(hipMalloc((void **)&pstamps, n_pstamps * 32));
+                KDE_TRY_HIP(hipMemsetAsync(pstamps, 0, n_pstamps * 32, s));
+            }
+#endif
+            static const int coef_form = PISA_DEV_INT("KDE_COEF_FORM", 1);     // 1 = the coefficients on the matrix cores (with the translations)
+            static const int pilot_form = PISA_DEV_INT("KDE_PILOT_FORM", 1);   // 1 = the local expansions a wavefront per block (where they are all there is)
+            static const int h2l_form_cfg = PISA_DEV_INT("KDE_H2L_FORM", 2);
+            const int h2l_form = h2l_form_cfg == 2 && P > 16 ? 1 : h2l_form_cfg;
             static const int h2l_split_cfg = PISA_DEV_INT("KDE_H2L_SPLIT", 2);
-            const int h2l_split = h2l_split_cfg >= 1 && h2l_split_cfg <= 8 ? h2l_split_cfg : 2;
+            const int h2l_split = h2l_form == 2 ? 1 : (h2l_split_cfg >= 1 && h2l_split_cfg <= 8 ? h2l_split_cfg : 2);
             const size_t need = (nd * pp + (local_exp ? h2l_split * (n_heads + (size_t)k->n_cells) * pp + (2 * reach + 1) * (2 * P - 1) : 0))
                                 * sizeof(double) + (local_exp ? (size_t)h2l_split * k->n_cells : 0) + 8192;
             double *herm = nullptr;
@@ -2260,13 +2566,20 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
                 }
             }
             dim3 grid((unsigned)n_blocks, (unsigned)n_split);
-            // translation passes: 1 = four targets per workgroup (default), 0 = one target per workgroup
-            static const int h2l_form = PISA_DEV_INT("KDE_H2L_FORM", 1);
 #define KDE_FGT(PP) do { \
-                hipLaunchKernelGGL(kde_hermite_coef_kernel<PP>, dim3((unsigned)nd), dim3(HC_THREADS), 0, s, g, d_dense, \
-                                   k->cell_start, k->ys, n, k->coef, herm); \
+                if (h2l_form == 2 && coef_form == 1) \
+                    hipLaunchKernelGGL(kde_hermite_coef_mfma_kernel, dim3((unsigned)nd), dim3(64 * FGT_WAVES), 0, s, g, d_dense, nd, \
+                                       k->cell_start, k->ys, n, k->coef, PP, herm); \
+                else \
+                    hipLaunchKernelGGL(kde_hermite_coef_kernel<PP>, dim3((unsigned)nd), dim3(HC_THREADS), 0, s, g, d_dense, \
+                                       k->cell_start, k->ys, n, k->coef, herm); \
                 if (local_exp) { \
-                    if (h2l_form == 1) { \
+                    if (h2l_form == 2) { \
+                        hipLaunchKernelGGL(kde_h2l_mfma_kernel<0>, dim3((unsigned)g.nc[0], (unsigned)((g.nc[1] + H2LM_T - 1) / H2LM_T)), \
+                                           dim3(64 * FGT_WAVES), 0, s, g, hslot, slot, herm, d_hankel, reach, PP, d_V, d_vflag, local); \
+                        hipLaunchKernelGGL(kde_h2l_mfma_kernel<1>, dim3((unsigned)((g.nc[0] + H2LM_T - 1) / H2LM_T), (unsigned)g.nc[1]), \
+                                           dim3(64 * FGT_WAVES), 0, s, g, hslot, slot, herm, d_hankel, reach, PP, d_V, d_vflag, local); \
+                    } else if (h2l_form == 1) { \
                         hipLaunchKernelGGL((kde_h2l4_kernel<PP, 0>), dim3((unsigned)g.nc[0], (unsigned)((g.nc[1] + H2L4_T - 1) / H2L4_T), (unsigned)h2l_split), \
                                            dim3(H2L_THREADS), 0, s, g, hslot, slot, herm, d_hankel, reach, d_V, d_vflag, local, n_heads); \
                         hipLaunchKernelGGL((kde_h2l4_kernel<PP, 1>), dim3((unsigned)((g.nc[0] + H2L4_T - 1) / H2L4_T), (unsigned)g.nc[1], (unsigned)h2l_split), \
@@ -2277,12 +2590,16 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
                         hipLaunchKernelGGL((kde_h2l_kernel<PP, 1>), dim3((unsigned)n_heads), dim3(H2L_THREADS), 0, s, g, d_tcells, \
                                            slot, herm, d_hankel, reach, d_V, d_vflag, local); \
                     } \
-                    if (nd < n_heads) \
+                    if (nd == n_heads && h2l_split == 1 && pilot_form == 1) { \
+                        hipLaunchKernelGGL(kde_local_pilot_wave_kernel<PP>, dim3((unsigned)n_blocks, (unsigned)(Q_CHUNK / (64 * FGT_WAVES))), dim3(64 * FGT_WAVES), 0, s, g, \
+                                           d_blocks, k->ys, n, local, pilot, pstamps); \
+                        pilot_host_pairs = (unsigned long long)(PP * PP / 23 + 1) * (unsigned long long)n; \
+                    } else if (nd < n_heads) \
                         hipLaunchKernelGGL((kde_local_pilot_kernel<PP, true>), dim3((unsigned)n_blocks), dim3(KDE_THREADS), 0, s, g, \
-                                           d_blocks, k->ys, n, k->coef, k->cell_start, slot, local, n_heads, h2l_form == 1 ? h2l_split : 1, pilot, k->pair_count); \
+                                           d_blocks, k->ys, n, k->coef, k->cell_start, slot, local, n_heads, h2l_form >= 1 ? h2l_split : 1, pilot, k->pair_count); \
                     else \
                         hipLaunchKernelGGL((kde_local_pilot_kernel<PP, false>), dim3((unsigned)n_blocks), dim3(KDE_THREADS), 0, s, g, \
-                                           d_blocks, k->ys, n, k->coef, k->cell_start, slot, local, n_heads, h2l_form == 1 ? h2l_split : 1, pilot, k->pair_count); \
+                                           d_blocks, k->ys, n, k->coef, k->cell_start, slot, local, n_heads, h2l_form >= 1 ? h2l_split : 1, pilot, k->pair_count); \
                 } else { \
                     hipLaunchKernelGGL(kde_hermite_pilot_kernel<PP>, grid, dim3(KDE_THREADS), 0, s, g, d_blocks, \
                                        k->ys, n, k->coef, k->cell_start, slot, herm, n_split, part, k->pair_count); \
@@ -2293,6 +2610,18 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
             }
 #undef KDE_FGT
             KDE_TRY(check_hip(hipGetLastError(), "kde expansion kernels"));
+#ifdef PISA_DEV_PROBES
+            if (pstamps) {
+                std::vector<unsigned long long> h(n_pstamps * 4);
+                KDE_TRY_HIP(hipStreamSynchronize(s));
+                KDE_TRY_HIP(hipMemcpy(h.data(), pstamps, h.size() * 8, hipMemcpyDeviceToHost));
+                (void)hipFree(pstamps);
+                if (FILE *f = fopen(pstamp_path, "wb")) {
+                    fwrite(h.data(), 8, h.size(), f);
+                    fclose(f);
+                }
+            }
+#endif
             k->n_dense = nd;
             if (local_exp) part = pilot;   // complete (no split)
         } else {
@@ -2315,6 +2644,7 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
         KDE_TRY_HIP(hipMemsetAsync(k->pair_count, 0, 64, s));
         // one synchronisation for the uploads of this block, the two read-backs and the reset
         KDE_TRY_HIP(hipStreamSynchronize(s));
+        k->pairs_pilot += pilot_host_pairs;
     }
     if (!adaptive) KDE_TRY_HIP(hipStreamSynchronize(s));
     k->cell_s2min_valid = 0;   // per-cell widest kernel: only the point evaluation needs it
@@ -2568,7 +2898,9 @@ PISA_API int pisa_hip_kde_evaluate_lattice(pisa_hip_kde *k, const double *h_orig
         PISA_TRY_HIP(hipMemsetAsync(stamps, 0, (size_t)n_waves * 32, s));
     }
 #endif
-#define KDE_LAT(RR, LL) hipLaunchKernelGGL((kde_lattice_kernel<RR, LL>), dim3((unsigned)n_waves), dim3(64), 0, s, L, g.rcut2, rec, k->n, lists, load, wstart, n_patches, part, k->pair_count, stamps)
+    static const int no_count = PISA_DEV_INT("KDE_LATTICE_NO_COUNT", 0);   // development: the launch without its per-wavefront atomic
+    unsigned long long *lat_count = no_count ? nullptr : k->pair_count;
+#define KDE_LAT(RR, LL) hipLaunchKernelGGL((kde_lattice_kernel<RR, LL>), dim3((unsigned)n_waves), dim3(64), 0, s, L, g.rcut2, rec, k->n, lists, load, wstart, n_patches, part, lat_count, stamps)
 #define KDE_LAT_R(RR) do { if (lg == 8) KDE_LAT(RR, 8); else if (lg == 16) KDE_LAT(RR, 16); else if (lg == 32) KDE_LAT(RR, 32); else KDE_LAT(RR, 64); } while (0)
     static const int twice = PISA_DEV_INT("KDE_TWICE", 0);
     for (int rep = 0; rep < ((twice & 1) ? 2 : 1); rep++) {

@@ -47,7 +47,7 @@ for rep in range(3):
     for name, x, w, g in jobs:
         axes = g["bin_points"]
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        est = K.KdeEstimator(x, w, bw_method=stage.bw_method, adaptive=stage.adaptive, alpha=stage.alpha)
+        est = K.KdeEstimator(x, w, bw_method=stage.bw_method, adaptive=stage.adaptive, alpha=stage.alpha, tol=stage.tol)
         torch.cuda.synchronize(); t1 = time.perf_counter()
         d = est.evaluate_lattice([a[0] for a in axes], [(a[-1] - a[0]) / (len(a) - 1) for a in axes], [len(a) for a in axes])
         torch.cuda.synchronize(); t2 = time.perf_counter()
@@ -62,4 +62,10 @@ for rep in range(3):
                                   pairs_eval=est.pairs_eval, eval_per_src=round(est.pairs_eval / est.n, 1),
                                   count=[len(a) for a in axes], da=round(U[0, 0] * step[0], 4), sa=round(U[0, 1] * step[1], 4), db=round(U[1, 1] * step[1], 4),
                                   s2=[round(float(s2.min()), 3), round(float(s2.max()), 3)], checksum=float(d.sum()))), flush=True)
+            yy = ys.cpu().numpy()
+            cid = (np.floor((yy[0] - yy[0].min()) / est.cell).astype(np.int64) * 100000
+                   + np.floor((yy[1] - yy[1].min()) / est.cell).astype(np.int64))
+            pop = np.sort(np.unique(cid, return_counts=True)[1])[::-1]
+            print("   sources per non-empty cell: max %d, top five %s, median %d; cells with > 512: %d, holding %.0f %% of the sources"
+                  % (pop[0], pop[:5].tolist(), int(np.median(pop)), int((pop > 512).sum()), 100.0 * pop[pop > 512].sum() / pop.sum()), flush=True)
 print(json.dumps(dict(estimators=len(jobs), create_ms=round(tot[0] * 1e3, 2), lattice_ms=round(tot[1] * 1e3, 2))))
