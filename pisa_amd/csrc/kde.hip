@@ -366,11 +366,13 @@ __device__ inline int64_t flat_cell(uint64_t key, const KdeGeom &g) {
 // whitened coordinates + flat cell index of every source (put inside the cell grid like kde_whiten_key_kernel's clamp)
 template <int D>
 __global__ void __launch_bounds__(256)
-kde_whiten_flat_kernel(const double *__restrict__ x, int64_t n, KdeGeom g, double *__restrict__ y,
-                       uint32_t *__restrict__ flat, uint32_t *__restrict__ idx) {
+kde_whiten_flat_kernel(const double *__restrict__ x, const double *__restrict__ w, int64_t n, KdeGeom g,
+                       double *__restrict__ rec, uint32_t *__restrict__ flat, uint32_t *__restrict__ idx) {
+    // rec[i] = (y_0, y_1, y_2, weight): ONE 32-byte record per source, so that the gather into cell order touches one
+    // sector per source instead of one per array (three random 8-byte reads each pulled their own: 27 us at 5.8e5 sources)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    double xc[3] = {0, 0, 0}, yy[3] = {0, 0, 0};
+    double xc[3] = {0, 0, 0}, yy[3] = {0, 0, 0}, out[4] = {0, 0, 0, w ? w[i] : 1.0};
 #pragma unroll
     for (int d = 0; d < D; d++) xc[d] = x[(int64_t)d * n + i] - g.mean[d];
 #pragma unroll
@@ -381,8 +383,12 @@ kde_whiten_flat_kernel(const double *__restrict__ x, int64_t n, KdeGeom g, doubl
         const double lo = g.ylo[d], hi = g.ylo[d] + (g.nc[d] - 0.5) * g.cell;
         const double v = fmin(fmax(a, lo), hi);   // rounding may put a point a hair outside the transformed bounding box
         yy[d] = (a == a) ? v : a;
-        y[(int64_t)d * n + i] = a;
+        out[d] = a;
     }
+    typedef double __attribute__((ext_vector_type(2))) d2;
+    d2 *dst = reinterpret_cast<d2 *>(rec + 4 * i);
+    dst[0] = (d2){out[0], out[1]};
+    dst[1] = (d2){out[2], out[3]};
     flat[i] = (uint32_t)flat_cell(tile_key(yy, g, 1), g);
     idx[i] = (uint32_t)i;
 }
@@ -398,19 +404,23 @@ kde_cell_start_flat_kernel(const uint32_t *__restrict__ flat, int64_t n, int64_t
     for (int64_t c = prev + 1; c <= cur; c++) cell_start[c] = (int32_t)k;
 }
 
-// sorted copies of the sources: ys[d][k] = y[d][perm[k]], wn[k] = w[perm[k]] / sum w, and the fixed-bandwidth
+// sorted copies of the sources (from the records of kde_whiten_flat_kernel): ys[d][k] = y[d][perm[k]], wn[k] = w[perm[k]] / sum w, and the fixed-bandwidth
 // coefficients coef[k] = wn[k] / norm (s2[k] = 1 if given)
 template <int D>
 __global__ void __launch_bounds__(256)
-kde_gather_sources_kernel(const double *__restrict__ y, const double *__restrict__ w, double scale, double inv_norm,
+kde_gather_sources_kernel(const double *__restrict__ rec, double scale, double inv_norm,
                           const uint32_t *__restrict__ perm, int64_t n, double *__restrict__ ys,
                           double *__restrict__ wn, double *__restrict__ coef, double *__restrict__ s2) {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= n) return;
     const uint32_t i = perm[k];
+    typedef double __attribute__((ext_vector_type(2))) d2;
+    const d2 *src = reinterpret_cast<const d2 *>(rec + 4 * (int64_t)i);
+    const d2 r01 = src[0], r23 = src[1];
+    const double r[4] = {r01.x, r01.y, r23.x, r23.y};
 #pragma unroll
-    for (int d = 0; d < D; d++) ys[(int64_t)d * n + k] = y[(int64_t)d * n + i];
-    const double v = (w ? w[i] : 1.0) * scale;
+    for (int d = 0; d < D; d++) ys[(int64_t)d * n + k] = r[d];
+    const double v = r[3] * scale;
     wn[k] = v;
     coef[k] = v * inv_norm;
     if (s2) s2[k] = 1.0;
@@ -2199,7 +2209,7 @@ PISA_API int64_t pisa_hip_kde_workspace_bytes(int32_t dim, int64_t n_src) {
     if (dim < 1 || dim > 3 || n_src < 1 || n_src > 0x7FFFFFF0LL) return -1;
     const size_t n = (size_t)n_src;
     size_t total = resident_bytes(dim, n_src, cells_cap(n_src)) + (size_t)RED_BLOCKS * 16 * 8;
-    total += dim * n * 8 + 2 * n * 8 + 2 * n * 4;        // y, keys x2, idx x2
+    total += 4 * n * 8 + n * 8 + 2 * n * 4;              // (y, weight) records, flat keys x2, idx x2
     total += n + n * 4 + n * 8;                          // flags, starts, head keys
     total += n * 8 + split_bytes(n_src);                 // pilot, split partials
     total += sort_temp_bytes(n_src) + (n / Q_CHUNK + (size_t)cells_cap(n_src)) * sizeof(KdeBlock);
@@ -2380,8 +2390,8 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
     k->scalars = ar.take<double>(8);
     k->pair_count = ar.take<unsigned long long>(8);
     // ---- transient arrays
-    double *y = ar.take<double>((size_t)dim * n);
-    uint64_t *keys_a = ar.take<uint64_t>(n), *keys_b = ar.take<uint64_t>(n);
+    double *rec = ar.take<double>((size_t)4 * n);      // (y, weight) per source, 32 bytes
+    uint64_t *keys_a = ar.take<uint64_t>(n);
     uint32_t *idx_a = ar.take<uint32_t>(n), *idx_b = ar.take<uint32_t>(n);
     const size_t temp_bytes = sort_temp_bytes(n);
     char *temp = ar.take<char>(temp_bytes);
@@ -2389,7 +2399,7 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
     KDE_TRY_HIP(hipMemsetAsync(k->pair_count, 0, 64, s));
     // ---- whiten, sort by cell, cell table
     uint32_t *flat_a = (uint32_t *)keys_a, *flat_b = flat_a + n;   // (the key arrays of the general form hold two 32-bit ones)
-    KDE_D(kde_whiten_flat_kernel, dim3(nb), dim3(256), 0, s, d_x, n, g, y, flat_a, idx_a);
+    KDE_D(kde_whiten_flat_kernel, dim3(nb), dim3(256), 0, s, d_x, d_w, n, g, rec, flat_a, idx_a);
     size_t tb = temp_bytes;
     {
         unsigned bits = 1;
@@ -2398,12 +2408,11 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
         for (int rep = 0; rep < ((twice & 4) ? 2 : 1); rep++)
             KDE_TRY_HIP(rocprim::radix_sort_pairs<FlatSortConfig>(temp, tb, flat_a, flat_b, idx_a, idx_b, (size_t)n, 0u, bits, s));
     }
-    KDE_D(kde_gather_sources_kernel, dim3(nb), dim3(256), 0, s, y, d_w, 1.0 / sw, 1.0 / k->norm, idx_b, n, k->ys, k->wn,
+    KDE_D(kde_gather_sources_kernel, dim3(nb), dim3(256), 0, s, rec, 1.0 / sw, 1.0 / k->norm, idx_b, n, k->ys, k->wn,
           k->coef, adaptive ? (double *)nullptr : k->s2);
     hipLaunchKernelGGL(kde_cell_start_flat_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, s, flat_b, n,
                        k->n_cells, k->cell_start);
     KDE_TRY(check_hip(hipGetLastError(), "kde setup kernels"));
-    (void)keys_b;
     if (!adaptive) {
         k->s2_range[0] = k->s2_range[1] = 1.0;
         KDE_TRY_HIP(hipMemcpyAsync(k->scalars + 1, k->s2_range, 2 * sizeof(double), hipMemcpyHostToDevice, s));

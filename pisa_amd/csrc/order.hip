@@ -25,26 +25,27 @@ namespace pisa {
 
 constexpr int ORD_WINDOW = 4096, ORD_BANKS = 32, ORD_PER = 4, ORD_BLOCK = 256;
 
-// key: depositing events by node, idle events behind them by node (node = -1 first)
+// key: depositing events by node, idle events behind them by node (node = -1 first).  A fixed number of workgroups walks
+// the events (grid stride): the count of depositing events is ONE atomic per workgroup on one address, and such atomics go
+// one after the other at ~17 ns each across the eight dies (3 255 of them per 8.3e5-event container cost more than the keys).
+constexpr int ORD_KEY_BLOCKS = 512;
 __global__ void __launch_bounds__(256)
 order_key_kernel(const int32_t *__restrict__ node, const int32_t *__restrict__ bin, int64_t n, uint32_t n_nodes,
                  uint32_t *__restrict__ key, uint32_t *__restrict__ val, unsigned long long *__restrict__ n_dep) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    bool dep = false;
-    if (i < n) {
+    unsigned int mine = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int32_t nd = node[i], b = bin[i];
-        dep = nd >= 0 && b >= 0;
+        const bool dep = nd >= 0 && b >= 0;
         key[i] = dep ? (uint32_t)nd : n_nodes + 1u + (uint32_t)(nd + 1);
         val[i] = (uint32_t)i;
+        mine += dep ? 1u : 0u;
     }
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(dep);
-    __shared__ unsigned int cnt[4];
-    if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = (unsigned int)__builtin_popcountll(m);
+    __shared__ unsigned int cnt;
+    if (threadIdx.x == 0) cnt = 0u;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned int c = cnt[0] + cnt[1] + cnt[2] + cnt[3];
-        if (c) atomicAdd(n_dep, (unsigned long long)c);    // (an integer count: order-independent)
-    }
+    if (mine) atomicAdd(&cnt, mine);                           // (integer counts: order-independent)
+    __syncthreads();
+    if (threadIdx.x == 0 && cnt) atomicAdd(n_dep, (unsigned long long)cnt);
 }
 
 // step 2: one workgroup per window of 4 096 sorted events
@@ -165,7 +166,7 @@ PISA_API int pisa_hip_deposit_block_order(const int32_t *d_node, const int32_t *
     size_t temp_bytes = (size_t)work_bytes - (256 + 5 * stride);
     PISA_TRY_HIP(hipMemsetAsync(n_dep, 0, 8, s));
     const unsigned nb = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(order_key_kernel, dim3(nb), dim3(256), 0, s, d_node, d_bin, n, (uint32_t)n_nodes, key_a, val_a, n_dep);
+    hipLaunchKernelGGL(order_key_kernel, dim3(nb < (unsigned)ORD_KEY_BLOCKS ? nb : (unsigned)ORD_KEY_BLOCKS), dim3(256), 0, s, d_node, d_bin, n, (uint32_t)n_nodes, key_a, val_a, n_dep);
     PISA_TRY_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, key_a, key_b, val_a, val_b, (size_t)n, 0u,
                                            (unsigned)order_key_bits((uint32_t)n_nodes), s));
     hipLaunchKernelGGL(order_bank_kernel, dim3((unsigned)((n + ORD_WINDOW - 1) / ORD_WINDOW)), dim3(1024), 0, s, val_b,
