@@ -1136,12 +1136,12 @@ def leg_kde(torch, n_events, steps):
     cal, src = latest_profile("kde_flops.json")
     if cal is not None and cal.get("events") == out["events"]:
         flop = cal["fp64_flop_per_evaluation"]
-        out["roofline"] = {"bound": "fp64 valu", "achieved": flop / dt / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
+        out["roofline"] = {"bound": "fp64 valu (the matrix cores' fp64 peak is the same 78.6 TFLOP/s)", "achieved": flop / dt / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
                            "unit": "TFLOP/s", "frac": flop / dt / 1e12 / FP64_VALU_PEAK_TFLOPS,
                            "fp64_flop_per_evaluation": flop,
                            "flop_source": "%s/kde_flops.json (executed fp64 FMA x2 + ADD + MUL + TRANS lane operations "
-                                          "of all kde_* kernels of one evaluation, committed rocprofv3 pass, not this "
-                                          "run)" % src,
+                                          "and the matrix cores' fp64 operations of all kde_* kernels of one evaluation, "
+                                          "committed rocprofv3 pass, not this run)" % src,
                            "note": "whole evaluation wall time (24 estimators on 8 threads / streams of the library: "
                                    "sorts, pilot through local expansions, lattice evaluation, host glue)"}
     return out

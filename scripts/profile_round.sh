@@ -38,7 +38,7 @@ timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS
 cp $OUT/pmc_kde/p_counter_collection.csv $OUT/pmc_kde.csv
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kde_stats -o kde -- python3 scripts/dev/c3_probe.py 1e7 > $OUT/c3_probe.log 2> $OUT/kde_stats.log
 cp $OUT/kde_stats/kde_kernel_stats.csv $OUT/kde_kernel_stats.csv
-timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 --kernel-trace --output-format csv -d $OUT/pmc_c3 -o p -- python3 scripts/dev/c3_probe.py 1e7 > $OUT/c3_pmc_run.log 2> $OUT/pmc_c3.log
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 --kernel-trace --output-format csv -d $OUT/pmc_c3 -o p -- python3 scripts/dev/c3_probe.py 1e7 > $OUT/c3_pmc_run.log 2> $OUT/pmc_c3.log
 cp $OUT/pmc_c3/p_counter_collection.csv $OUT/pmc_c3_full.csv
 # SQ counters of the KDE kernels (VALU occupancy, wavefront lifetimes, LDS conflicts): kde_sq_counters.json
 bash scripts/dev/kde_pmc.sh > $OUT/kde_pmc.log 2>&1; cp gpurun_out/kde_pmc/kde_sq_counters.json $OUT/kde_sq_counters.json
@@ -154,27 +154,30 @@ for r in rows:
         continue
     short = name.split("(")[0].replace("void ", "").replace("pisa::", "")
     wgt = {"SQ_INSTS_VALU_FMA_F64": 2.0, "SQ_INSTS_VALU_ADD_F64": 1.0, "SQ_INSTS_VALU_MUL_F64": 1.0,
-           "SQ_INSTS_VALU_TRANS_F64": 1.0}.get(r["Counter_Name"])
+           "SQ_INSTS_VALU_TRANS_F64": 1.0, "SQ_INSTS_VALU_MFMA_MOPS_F64": 512.0 / 64.0}.get(r["Counter_Name"])
     if wgt is None:
         continue
-    d = per_kernel.setdefault(short, {"flop": 0.0, "dispatches": set()})
+    d = per_kernel.setdefault(short, {"flop": 0.0, "dispatches": set(), "matrix_flop": 0.0})
     d["flop"] += 64.0 * wgt * float(r["Counter_Value"])
+    if "MFMA" in r["Counter_Name"]:
+        d["matrix_flop"] += 512.0 * float(r["Counter_Value"])
     d["dispatches"].add(r["Dispatch_Id"])
 n_eval = 4
 tot = sum(d["flop"] for d in per_kernel.values())
 json.dump({"events": 9999996, "evaluations_in_run": n_eval, "fp64_flop_per_evaluation": tot / n_eval,
            "per_kernel_flop_per_evaluation": {k_: v["flop"] / n_eval for k_, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["flop"])},
            "launches_per_evaluation": {k_: len(v["dispatches"]) / n_eval for k_, v in per_kernel.items()},
-           "method": "timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 over scripts/dev/c3_probe.py 1e7 (4 evaluations of the "
-                     "1e7-event pipeline with utils.kde); wave-level counts x 64 lanes, FMA = 2 flop, summed over every kernel "
-                     "whose name contains kde_"}, open(OUT + "/kde_flops.json", "w"), indent=1)
+           "matrix_core_flop_per_evaluation": sum(v["matrix_flop"] for v in per_kernel.values()) / n_eval,
+           "method": "timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 over scripts/dev/c3_probe.py 1e7 "
+                     "(4 evaluations of the 1e7-event pipeline with utils.kde); wave-level counts x 64 lanes, FMA = 2 flop, the matrix cores' "
+                     "count x 512 flop (one v_mfma_f64_16x16x4_f64 = 2 048 flop = 4 counts), summed over every kernel whose name contains kde_"}, open(OUT + "/kde_flops.json", "w"), indent=1)
 print("kde flop per evaluation %.3e" % (tot / n_eval))
 # the raw rows of the KDE kernels only
 with open(OUT + "/pmc_c3.csv", "w", newline="") as f:
     wr = csv.writer(f)
     wr.writerow(list(rows[0].keys()))
     for r in rows:
-        if "kde_lattice_kernel" in r["Kernel_Name"] or "kde_local_pilot" in r["Kernel_Name"] or "kde_h2l" in r["Kernel_Name"]:
+        if any(x in r["Kernel_Name"] for x in ("kde_lattice_kernel", "kde_local_pilot", "kde_h2l", "kde_hermite_coef")):
             wr.writerow(list(r.values()))
 json.dump({"kde_pairs_kernel_totals": k, "run": open(OUT + "/kde_pmc_run.json").read()[-1500:]}, open(OUT + "/kde_counter_check.json", "w"), indent=1)
 for r in list(csv.reader(open(OUT + "/kernel_stats.csv")))[:8]:
