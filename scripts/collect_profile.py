@@ -7,7 +7,7 @@ import shutil
 import sys
 
 KEEP = ("hist_accumulate_kernel", "hist_accumulate_multi_kernel", "prob3_events_kernel", "kde_pairs_kernel",
-        "kde_lattice_kernel", "barr_fold_multi_kernel")
+        "kde_lattice_kernel", "kde_h2l", "kde_hermite_coef", "kde_local_pilot", "barr_fold_multi_kernel")
 
 
 def main(tag):
