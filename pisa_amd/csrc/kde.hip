@@ -367,7 +367,7 @@ __device__ inline int64_t flat_cell(uint64_t key, const KdeGeom &g) {
 template <int D>
 __global__ void __launch_bounds__(256)
 kde_whiten_flat_kernel(const double *__restrict__ x, const double *__restrict__ w, int64_t n, KdeGeom g,
-                       double *__restrict__ rec, uint32_t *__restrict__ flat, uint32_t *__restrict__ idx) {
+                       double *__restrict__ rec, uint32_t *__restrict__ flat, uint32_t *__restrict__ idx, int pack) {
     // rec[i] = (y_0, y_1, y_2, weight): ONE 32-byte record per source, so that the gather into cell order touches one
     // sector per source instead of one per array (three random 8-byte reads each pulled their own: 27 us at 5.8e5 sources)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -389,18 +389,20 @@ kde_whiten_flat_kernel(const double *__restrict__ x, const double *__restrict__ 
     d2 *dst = reinterpret_cast<d2 *>(rec + 4 * i);
     dst[0] = (d2){out[0], out[1]};
     dst[1] = (d2){out[2], out[3]};
-    flat[i] = (uint32_t)flat_cell(tile_key(yy, g, 1), g);
-    idx[i] = (uint32_t)i;
+    // pack > 0: (cell << pack) | index in ONE 32-bit word (the index fits below the cell's bits): the sort then moves keys only
+    const uint32_t cell_i = (uint32_t)flat_cell(tile_key(yy, g, 1), g);
+    flat[i] = pack ? (cell_i << pack) | (uint32_t)i : cell_i;
+    if (!pack) idx[i] = (uint32_t)i;
 }
 
 // cell_start[c] = first sorted source of cell c, from the sorted flat cell indices
 __global__ void __launch_bounds__(256)
 kde_cell_start_flat_kernel(const uint32_t *__restrict__ flat, int64_t n, int64_t n_cells,
-                           int32_t *__restrict__ cell_start) {
+                           int32_t *__restrict__ cell_start, int pack) {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (k > n) return;
-    const int64_t prev = k == 0 ? -1 : (int64_t)flat[k - 1];
-    const int64_t cur = k == n ? n_cells : (int64_t)flat[k];
+    const int64_t prev = k == 0 ? -1 : (int64_t)(flat[k - 1] >> pack);
+    const int64_t cur = k == n ? n_cells : (int64_t)(flat[k] >> pack);
     for (int64_t c = prev + 1; c <= cur; c++) cell_start[c] = (int32_t)k;
 }
 
@@ -409,11 +411,11 @@ kde_cell_start_flat_kernel(const uint32_t *__restrict__ flat, int64_t n, int64_t
 template <int D>
 __global__ void __launch_bounds__(256)
 kde_gather_sources_kernel(const double *__restrict__ rec, double scale, double inv_norm,
-                          const uint32_t *__restrict__ perm, int64_t n, double *__restrict__ ys,
+                          const uint32_t *__restrict__ perm, uint32_t perm_mask, int64_t n, double *__restrict__ ys,
                           double *__restrict__ wn, double *__restrict__ coef, double *__restrict__ s2) {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= n) return;
-    const uint32_t i = perm[k];
+    const uint32_t i = perm[k] & perm_mask;            // (packed keys: the index is the low part of the sorted word)
     typedef double __attribute__((ext_vector_type(2))) d2;
     const d2 *src = reinterpret_cast<const d2 *>(rec + 4 * (int64_t)i);
     const d2 r01 = src[0], r23 = src[1];
@@ -2078,6 +2080,9 @@ static size_t sort_temp_bytes(int64_t n) {
     (void)rocprim::radix_sort_pairs<FlatSortConfig>(nullptr, b3, (uint32_t *)nullptr, (uint32_t *)nullptr,
                                                     (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, 0u, 32u);
     bytes = std::max(bytes, b3);
+    size_t b4 = 0;
+    (void)rocprim::radix_sort_keys<FlatSortConfig>(nullptr, b4, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, 0u, 32u);
+    bytes = std::max(bytes, b4);
     size_t b2 = 0;
     (void)hipcub::DeviceSelect::Flagged(nullptr, b2, hipcub::CountingInputIterator<int32_t>(0),
                                   (uint8_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int)n, 0);
@@ -2399,19 +2404,28 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
     KDE_TRY_HIP(hipMemsetAsync(k->pair_count, 0, 64, s));
     // ---- whiten, sort by cell, cell table
     uint32_t *flat_a = (uint32_t *)keys_a, *flat_b = flat_a + n;   // (the key arrays of the general form hold two 32-bit ones)
-    KDE_D(kde_whiten_flat_kernel, dim3(nb), dim3(256), 0, s, d_x, d_w, n, g, rec, flat_a, idx_a);
+    unsigned bits = 1;
+    while (bits < 32 && ((int64_t)1 << bits) < k->n_cells) bits++;
+    // cell and source index in one 32-bit word where both fit ((cell << pack) | index): the sort moves keys only -- half the
+    // bytes per pass --, sorted on the cell's bits; the order is the stable order of the pair sort (the indices ascend)
+    static const int pack_ok = PISA_DEV_INT("KDE_SORT_PACK", 1);
+    const int pack = (pack_ok && bits < 32 && n <= ((int64_t)1 << (32 - bits))) ? (int)(32 - bits) : 0;
+    KDE_D(kde_whiten_flat_kernel, dim3(nb), dim3(256), 0, s, d_x, d_w, n, g, rec, flat_a, idx_a, pack);
     size_t tb = temp_bytes;
     {
-        unsigned bits = 1;
-        while (bits < 32 && ((int64_t)1 << bits) < k->n_cells) bits++;
         static const int twice = PISA_DEV_INT("KDE_TWICE", 0);   // development: marginal cost of a phase = wall time with it run twice
-        for (int rep = 0; rep < ((twice & 4) ? 2 : 1); rep++)
-            KDE_TRY_HIP(rocprim::radix_sort_pairs<FlatSortConfig>(temp, tb, flat_a, flat_b, idx_a, idx_b, (size_t)n, 0u, bits, s));
+        for (int rep = 0; rep < ((twice & 4) ? 2 : 1); rep++) {
+            if (pack)
+                KDE_TRY_HIP(rocprim::radix_sort_keys<FlatSortConfig>(temp, tb, flat_a, flat_b, (size_t)n, (unsigned)pack, 32u, s));
+            else
+                KDE_TRY_HIP(rocprim::radix_sort_pairs<FlatSortConfig>(temp, tb, flat_a, flat_b, idx_a, idx_b, (size_t)n, 0u, bits, s));
+        }
     }
-    KDE_D(kde_gather_sources_kernel, dim3(nb), dim3(256), 0, s, rec, 1.0 / sw, 1.0 / k->norm, idx_b, n, k->ys, k->wn,
+    KDE_D(kde_gather_sources_kernel, dim3(nb), dim3(256), 0, s, rec, 1.0 / sw, 1.0 / k->norm, pack ? flat_b : idx_b,
+          pack ? (uint32_t)(((uint64_t)1 << pack) - 1) : 0xFFFFFFFFu, n, k->ys, k->wn,
           k->coef, adaptive ? (double *)nullptr : k->s2);
     hipLaunchKernelGGL(kde_cell_start_flat_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, s, flat_b, n,
-                       k->n_cells, k->cell_start);
+                       k->n_cells, k->cell_start, pack);
     KDE_TRY(check_hip(hipGetLastError(), "kde setup kernels"));
     if (!adaptive) {
         k->s2_range[0] = k->s2_range[1] = 1.0;
