@@ -72,6 +72,8 @@ def test_kde_estimator_cutoff_vs_oracle_large(oracle):
     (2, 20000, 3000, False, "scott", 0.3, 1e-14),
     (2, 5000, 1000, True, "silverman", 0.5, 0.0),       # no cut-off: one cell, all pairs
     (2, 300, 200, True, "silverman", 0.1, 1e-12),       # tiny: cells nearly empty
+    (2, 60000, 3000, True, "scott", 0.3, 1e-12),        # series order 16: the pilot on the matrix cores (one MFMA tile)
+    (2, 60000, 3000, True, "silverman", 0.2, 1e-10),    # series order 14: the same kernels, padded to the tile
 ])
 def test_kde_estimator_vs_oracle(oracle, dim, n, m, adaptive, bw, alpha, tol):
     est, got, want = _estimator_vs_oracle(oracle, dim, n, m, adaptive, bw, alpha, tol, 5 + dim)
