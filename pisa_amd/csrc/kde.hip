@@ -1216,21 +1216,10 @@ __device__ constexpr double INV_FACT[24] = {1.0, 1.0, 0.5, 0.16666666666666666, 
 typedef double __attribute__((ext_vector_type(4))) mfma_d4;
 // The same coefficients on the matrix cores (round 5; series orders up to 16): A = X^T Y with X[j][n] = d1_j^n / n!,
 // Y[j][m] = q_j d2_j^m / m! over the sources j of the cell -- a 16 x J by J x 16 product, four sources per
-// `v_mfma_f64_16x16x4_f64`.  One wavefront per cell, no LDS, no barrier: lane (i = lane & 15, k = lane >> 4) forms the
-// i-th power of source 4 s + k of the round for both coordinates (its exponent never changes: square-and-multiply with
-// lane-constant selects, six multiplications) as its element of the A and of the B operand.  The vector form above stages
-// the powers of 64 sources in LDS between two barriers and adds four partial sums through LDS: 37 us per estimator for
-// 0.2 GFLOP.  The products are summed in the matrix cores' order and the powers are not formed by the running product
-// d^n / n!: the coefficients differ from the vector form's by rounding (a few 1e-16 relative), run to run the same.
-__device__ __forceinline__ double lane_power(double d, int e) {   // d^e, 0 <= e < 16
-    double p = (e & 1) ? d : 1.0;
-    const double d2 = d * d;
-    p = (e & 2) ? p * d2 : p;
-    const double d4 = d2 * d2;
-    p = (e & 4) ? p * d4 : p;
-    const double d8 = d4 * d4;
-    return (e & 8) ? p * d8 : p;
-}
+// `v_mfma_f64_16x16x4_f64`: lane (i = lane & 15, k = lane >> 4) supplies X[4 s + k][i] as the A and Y[4 s + k][i] as the B
+// operand.  The vector form above stages the powers of 64 sources in LDS between two workgroup barriers, multiplies 4 x 4
+// register tiles and adds four partial sums through LDS: 37 us per estimator for 0.2 GFLOP.  The products are summed in
+// the matrix cores' order: the coefficients differ from the vector form's by rounding (1e-16 relative), run to run the same.
 constexpr int FGT_WAVES = 4;   // wavefronts per workgroup of the matrix-core kernels, each with a cell (or targets) of its own:
                                // a launch of 5 600 one-wavefront workgroups took as long to hand out as to compute
 __global__ void __launch_bounds__(64 * FGT_WAVES)
@@ -1238,45 +1227,56 @@ kde_hermite_coef_mfma_kernel(KdeGeom g, const int32_t *__restrict__ dense_cells,
                              const int32_t *__restrict__ cell_start,
                              const double *__restrict__ sy, int64_t n_src, const double *__restrict__ coef, int P,
                              double *__restrict__ herm) {
-    // (the FGT_WAVES wavefronts of a workgroup take every FGT_WAVES-th round of 16 sources of ONE cell; their sums are
-    //  added in wavefront order through LDS: the chain of memory latencies of a cell's rounds is what the launch takes)
+    // A workgroup = one cell, its FGT_WAVES wavefronts take every FGT_WAVES-th batch of 32 sources and add their sums in
+    // wavefront order through LDS.  A batch: lanes 0-31 form the 16 scaled powers of the first coordinate of "their" source
+    // by the running product v <- v d / (n + 1) (the vector kernel's values), lanes 32-63 those of the second coordinate
+    // times the weight; the powers go through the wavefront's own LDS tile [power][source] (row stride 36 doubles: the
+    // operand reads below fall on all banks) and come back in the operand layout -- lane (i, k) reads power i of source
+    // 4 s + k.  (Each lane forming ITS power of ITS source by square-and-multiply, no LDS, cost 8 vector instructions per
+    // source against 2 here: 28 us per estimator, 58 us beside the lattice kernels of the other streams.)
+    constexpr int BATCH = 32, ROW = 36;
+    __shared__ double tile[FGT_WAVES][2][16 * ROW];
     __shared__ double red[FGT_WAVES][256];
     const int lane = (int)threadIdx.x & 63, li = lane & 15, lk = lane >> 4, wave = (int)threadIdx.x >> 6;
     const int slot_i = (int)blockIdx.x;
     const int c = dense_cells[slot_i];
     const int cx = c % g.nc[0], cy = c / g.nc[0];
-    const double c1 = g.ylo[0] + (cx + 0.5) * g.cell, c2 = g.ylo[1] + (cy + 0.5) * g.cell;
+    const int half = lane >> 5, js = lane & 31;                  // which coordinate, which source of the batch
+    const double centre = half ? g.ylo[1] + (cy + 0.5) * g.cell : g.ylo[0] + (cx + 0.5) * g.cell;
     const int begin = cell_start[c], end = cell_start[c + 1];
-    const double scale = INV_FACT[li];
+    const double *__restrict__ coord = sy + (half ? n_src : 0);
+    double *mine = &tile[wave][half][0];
+    const double *tx = &tile[wave][0][0], *ty = &tile[wave][1][0];
     mfma_d4 acc = (mfma_d4){0.0, 0.0, 0.0, 0.0};
-    // the sources of the NEXT round are requested before this round's powers are formed (a cell in the middle of the
-    // cloud holds thousands of sources: its wavefront is the launch's critical path, one memory latency per round)
-    double s1[4], s2[4], sq[4], n1[4], n2[4], nq[4];
-    auto fetch = [&](int base, double (&a1)[4], double (&a2)[4], double (&aq)[4]) {
-#pragma unroll
-        for (int sx = 0; sx < 4; sx++) {
-            const int j = base + 4 * sx + lk;
-            const int64_t jj = j < end ? j : begin;               // (unconditional loads; a source beyond the cell gets weight zero below)
-            a1[sx] = sy[jj];
-            a2[sx] = sy[n_src + jj];
-            aq[sx] = coef[jj];
-        }
+    constexpr int STEP = BATCH * FGT_WAVES;
+    // (the next batch's sources are requested before this batch's powers are formed)
+    auto fetch = [&](int base, double &d, double &q) {
+        const int j = base + js;
+        const int64_t jj = j < end ? j : begin;                  // (unconditional loads; a source beyond the cell gets weight zero)
+        d = coord[jj];
+        q = coef[jj];
     };
-    constexpr int STEP = 16 * FGT_WAVES;
-    fetch(begin + 16 * wave, s1, s2, sq);
-    for (int base = begin + 16 * wave; base < end; base += STEP) {
-        fetch(base + STEP < end ? base + STEP : begin, n1, n2, nq);
+    double d_cur, q_cur, d_nxt, q_nxt;
+    fetch(begin + BATCH * wave, d_cur, q_cur);
+    for (int base = begin + BATCH * wave; base < end; base += STEP) {
+        fetch(base + STEP < end ? base + STEP : begin, d_nxt, q_nxt);
+        const double d = (d_cur - centre) * RSQRT2;
+        double v = half ? (base + js < end ? q_cur : 0.0) : 1.0;   // the weight rides on the second factor
 #pragma unroll
-        for (int sx = 0; sx < 4; sx++) {
-            const bool ok = base + 4 * sx + lk < end;
-            const double d1 = (s1[sx] - c1) * RSQRT2, d2 = (s2[sx] - c2) * RSQRT2;
-            const double q = ok ? sq[sx] : 0.0;
-            const double a = lane_power(d1, li) * scale;
-            const double b = lane_power(d2, li) * scale * q;
+        for (int n = 0; n < 16; n++) {
+            mine[n * ROW + js] = v;
+            v = v * d * (1.0 / (double)(n + 1));                 // (the reciprocal is a compile-time constant)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int sx = 0; sx < BATCH / 4; sx++) {
+            const double a = tx[li * ROW + 4 * sx + lk], b = ty[li * ROW + 4 * sx + lk];
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
         }
-#pragma unroll
-        for (int sx = 0; sx < 4; sx++) { s1[sx] = n1[sx]; s2[sx] = n2[sx]; sq[sx] = nq[sx]; }
+        __builtin_amdgcn_wave_barrier();                         // (the tile is rewritten by the next batch)
+        d_cur = d_nxt;
+        q_cur = q_nxt;
     }
 #pragma unroll
     for (int r = 0; r < 4; r++) red[wave][r * 64 + lane] = acc[r];
