@@ -724,32 +724,57 @@ kde_lattice_load_kernel(const KdeLattice L, int R, const double *__restrict__ bo
                         unsigned int *__restrict__ load, int32_t *__restrict__ lists, int n_patches, int n_waves,
                         int min_shares, int32_t *__restrict__ wstart, unsigned long long *__restrict__ done) {
     constexpr int NW = LOAD_THREADS / 64;
-    __shared__ unsigned int wcnt[2][NW];
+    constexpr int MAXR = 32;                       // rounds of LOAD_THREADS candidates per pass through the two phases below
+    __shared__ unsigned short wcnt[MAXR][NW];
     __shared__ int last;
     double pa_lo, pa_hi, pb_lo, pb_hi;
     lattice_patch_box(L, R, (int)blockIdx.x, pa_lo, pa_hi, pb_lo, pb_hi);
     int32_t *__restrict__ mine_list = lists + (int64_t)blockIdx.x * n_shares;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned int base = 0;
-    int flip = 0;
-    for (int64_t sub0 = 0; sub0 < n_shares; sub0 += LOAD_THREADS, flip ^= 1) {
-        const int64_t sub = sub0 + threadIdx.x;
-        bool ok = false;
-        if (sub < n_shares) {
-            const double *__restrict__ bx = box + 4 * sub;
-            ok = !(bx[0] > pa_hi || bx[1] < pa_lo || bx[2] > pb_hi || bx[3] < pb_lo);
+    // Two phases per pass of MAXR rounds: (1) every round's box tests, all loads independent of each other, the wavefronts'
+    // counts of every round to LDS; ONE barrier; (2) per round, from the counts, where a wavefront's entries go.  (A barrier
+    // and a dependent 32-byte load per round made the 9 rounds of a C3 estimator 9 memory latencies: 18 us per launch.)
+    for (int64_t pass0 = 0; pass0 < n_shares; pass0 += (int64_t)MAXR * LOAD_THREADS) {
+        const int n_rounds = (int)(((n_shares - pass0) + LOAD_THREADS - 1) / LOAD_THREADS < MAXR
+                                       ? ((n_shares - pass0) + LOAD_THREADS - 1) / LOAD_THREADS : MAXR);
+        unsigned int okmask = 0;
+        if (pass0) __syncthreads();                // (the counts of the previous pass have been read)
+        for (int r0 = 0; r0 < n_rounds; r0 += 4) {     // four rounds' boxes requested together (unconditional loads), then tested
+            double b[4][4];
+            bool in[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int64_t sub = pass0 + (int64_t)(r0 + u) * LOAD_THREADS + threadIdx.x;
+                in[u] = r0 + u < n_rounds && sub < n_shares;
+                const double *__restrict__ bx = box + 4 * (in[u] ? sub : 0);
+#pragma unroll
+                for (int e = 0; e < 4; e++) b[u][e] = bx[e];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool ok = in[u] && !(b[u][0] > pa_hi || b[u][1] < pa_lo || b[u][2] > pb_hi || b[u][3] < pb_lo);
+                okmask |= ok ? (1u << (r0 + u)) : 0u;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
+                if (lane == 0 && r0 + u < n_rounds) wcnt[r0 + u][wave] = (unsigned short)__builtin_popcountll(m);
+            }
         }
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
-        if (lane == 0) wcnt[flip][wave] = (unsigned int)__builtin_popcountll(m);
-        __syncthreads();      // (two count buffers in turn: one barrier per round)
-        unsigned int before = 0, total = 0;
-        for (int q = 0; q < NW; q++) {
-            const unsigned int c = wcnt[flip][q];
-            before += q < wave ? c : 0u;
-            total += c;
+        __syncthreads();
+        for (int r = 0; r < n_rounds; r++) {
+            const bool ok = (okmask >> r) & 1u;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
+            unsigned int before = 0, total = 0;
+#pragma unroll
+            for (int q = 0; q < NW; q++) {
+                const unsigned int c = wcnt[r][q];
+                before += q < wave ? c : 0u;
+                total += c;
+            }
+            if (ok)
+                mine_list[base + before + (unsigned int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] =
+                    (int32_t)(pass0 + (int64_t)r * LOAD_THREADS + threadIdx.x);
+            base += total;
         }
-        if (ok) mine_list[base + before + (unsigned int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (int32_t)sub;
-        base += total;
     }
     if (threadIdx.x == 0) {
         __hip_atomic_store(&load[blockIdx.x], base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
