@@ -1297,7 +1297,7 @@ kde_hermite_coef_mfma_kernel(KdeGeom g, const int32_t *__restrict__ dense_cells,
 #pragma unroll
         for (int sx = 0; sx < BATCH / 4; sx++) {
             const double a = tx[li * ROW + 4 * sx + lk], b = ty[li * ROW + 4 * sx + lk];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, acc, 0, 0, 0);   // Y^T X = A^T: stored TRANSPOSED, see below
         }
         __builtin_amdgcn_wave_barrier();                         // (the tile is rewritten by the next batch)
         d_cur = d_nxt;
@@ -1310,6 +1310,9 @@ kde_hermite_coef_mfma_kernel(KdeGeom g, const int32_t *__restrict__ dense_cells,
     double v = 0.0;
 #pragma unroll
     for (int q = 0; q < FGT_WAVES; q++) v += red[q][wave * 64 + lane];
+    // herm[slot][m][n] = A[n][m]: the first translation pass (kde_h2l_mfma_kernel<0>, the only reader of this form) takes
+    // A[alpha][beta] as its A operand, lane (alpha, k) <- element [alpha][4 s + k]; from the transposed array that is a
+    // row of 16 consecutive doubles per k instead of 16 rows of 32 bytes (the loads of that pass: 30 -> 21 us)
     const int row = lk + 4 * wave;
     if (row < P && li < P) herm[(int64_t)slot_i * (P * P) + row * P + li] = v;
 }
@@ -1815,14 +1818,15 @@ kde_h2l_mfma_kernel(KdeGeom g, const int32_t *__restrict__ hslot, const int32_t 
     const int li = lane & 15, lk = lane >> 4;
     const int v_hi = u0 + H2LM_T - 1 + reach < nu - 1 ? u0 + H2LM_T - 1 + reach : nu - 1;
     const int v_lo = u0 - reach > 0 ? u0 - reach : 0;
-    // this lane's element of k-step s of a source matrix: pass 0 [li][4 s + lk] (A operand), pass 1 [4 s + lk][li] (B operand)
+    // this lane's element of k-step s of a source matrix: pass 0 A[li][4 s + lk] (A operand; the array holds A transposed),
+    // pass 1 V[4 s + lk][li] (B operand): the same offset
     int off[4];
     bool inside[4];
 #pragma unroll
     for (int sx = 0; sx < 4; sx++) {
         const int kk = 4 * sx + lk;
         inside[sx] = li < P && kk < P;
-        off[sx] = inside[sx] ? (PASS == 0 ? li * P + kk : kk * P + li) : 0;
+        off[sx] = inside[sx] ? kk * P + li : 0;                  // (pass 0 reads the coefficients TRANSPOSED: kde_hermite_coef_mfma_kernel)
     }
     // Which of the <= 2 reach + H2LM_T source positions hold a matrix: looked up by the lanes at once (lane j: position
     // v_lo + j) -- one position per loop iteration, each a dependent global load in front of the matrix's own loads, was
@@ -2550,7 +2554,6 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
                 KDE_TRY_HIP(hipMemsetAsync(pstamps, 0, n_pstamps * 32, s));
             }
 #endif
-            static const int coef_form = PISA_DEV_INT("KDE_COEF_FORM", 1);     // 1 = the coefficients on the matrix cores (with the translations)
             static const int pilot_form = PISA_DEV_INT("KDE_PILOT_FORM", 1);   // 1 = the local expansions a wavefront per block (where they are all there is)
             static const int h2l_form_cfg = PISA_DEV_INT("KDE_H2L_FORM", 2);
             const int h2l_form = h2l_form_cfg == 2 && P > 16 ? 1 : h2l_form_cfg;
@@ -2615,7 +2618,7 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
             }
             dim3 grid((unsigned)n_blocks, (unsigned)n_split);
 #define KDE_FGT(PP) do { \
-                if (h2l_form == 2 && coef_form == 1) \
+                if (local_exp && h2l_form == 2) /* (the matrix-core translation reads the coefficients transposed: the two go together) */ \
                     hipLaunchKernelGGL(kde_hermite_coef_mfma_kernel, dim3((unsigned)nd), dim3(64 * FGT_WAVES), 0, s, g, d_dense, nd, \
                                        k->cell_start, k->ys, n, k->coef, PP, herm); \
                 else \
