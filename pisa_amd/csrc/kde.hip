@@ -1245,8 +1245,8 @@ typedef double __attribute__((ext_vector_type(4))) mfma_d4;
 // operand.  The vector form above stages the powers of 64 sources in LDS between two workgroup barriers, multiplies 4 x 4
 // register tiles and adds four partial sums through LDS: 37 us per estimator for 0.2 GFLOP.  The products are summed in
 // the matrix cores' order: the coefficients differ from the vector form's by rounding (1e-16 relative), run to run the same.
-constexpr int FGT_WAVES = 4;   // wavefronts per workgroup of the matrix-core kernels, each with a cell (or targets) of its own:
-                               // a launch of 5 600 one-wavefront workgroups took as long to hand out as to compute
+constexpr int FGT_WAVES = 4;   // wavefronts per workgroup of the matrix-core kernels: they share the sources of ONE cell / the source
+                               // positions of ONE target pair and add their sums in wavefront order through LDS
 __global__ void __launch_bounds__(64 * FGT_WAVES)
 kde_hermite_coef_mfma_kernel(KdeGeom g, const int32_t *__restrict__ dense_cells, int n_dense,
                              const int32_t *__restrict__ cell_start,
@@ -1767,9 +1767,9 @@ kde_h2l4_kernel(KdeGeom g, const int32_t *__restrict__ hslot, const int32_t *__r
 //     C / D      lane, register r -> [row = (lane >> 4) + 4 r][col = lane & 15]
 // (four instructions per matrix product: k = 4 s + (lane >> 4)).  The vector form above spends five LDS reads per sixteen
 // multiply-adds and two barriers per source position: VALU busy 0.35-0.4, ~50 us per pass and estimator.  Here a workgroup
-// is ONE wavefront with H2LM_T consecutive targets of the convolution direction: a source matrix comes straight from
-// global memory into the operand registers (pass 0: A_v as the A operand, pass 1: V_v as the B operand; zero beyond a
-// series order of 14), the Hankel entry of a lane -- h_{(lane & 15) + (lane >> 4) + 4 s}(o), the same for both passes --
+// has H2LM_T consecutive targets of the convolution direction, its wavefronts every FGT_WAVES-th source position: a source
+// matrix comes straight from global memory into the operand registers (pass 0: A_v as the A operand -- read from the
+// TRANSPOSED array kde_hermite_coef_mfma_kernel writes --, pass 1: V_v as the B operand; zero beyond a series order of 14), the Hankel entry of a lane -- h_{(lane & 15) + (lane >> 4) + 4 s}(o), the same for both passes --
 // from a table in LDS, no barrier in the loop, absent sources and out-of-reach offsets skipped wavefront-uniformly.
 // Sources descend as above (offsets ascend per target); inside a product the matrix cores' own order: the results differ
 // from the vector form's by rounding (1e-16 relative), and are the same from run to run.
