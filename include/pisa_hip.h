@@ -275,6 +275,28 @@ int pisa_hip_hist_workgroups(const int64_t *h_n_events, int32_t n_containers, in
 int64_t pisa_hip_deposit_block_order_workspace(int64_t n);
 int pisa_hip_deposit_block_order(const int32_t *d_node, const int32_t *d_bin, int64_t n, int64_t n_nodes,
                                  int64_t *d_perm, void *d_work, int64_t work_bytes, void *stream);
+/* The resident copies of one container's event columns in the order `d_perm` (the permutation above), in ONE launch: the
+ * permuted columns themselves and the interleaved / folded forms the fused kernel reads -- what pisa_amd/engine.py built
+ * with ~25 tensor operations per container (6 ms of a 24 ms set-up at 1e7 events, bound by their dispatch on the host).
+ * out[k] = in[d_perm[k]] for every column; d_node_bin[k] = (node, bin); d_aeff_w0[k] = (aeff, w0); d_static_w[k] =
+ * w0 * aeff; d_node_bin16[k] = node | bin << 16 with 0xFFFF for a negative index, 0xFFFFFFFF for n <= k < n_pad (n_pad = n
+ * rounded up to whole blocks of 256 events).  All pointers DEVICE; columns double[n], d_nu_flux double[n][2], d_node /
+ * d_bin int32[n], d_perm int64[n]; d_sample: up to three output-binning coordinate columns (n_sample of them).  No
+ * counterpart in the reference (its containers keep file order, `container.py:933-1012`).  Asynchronous on `stream`. */
+typedef struct {
+    int64_t n, n_pad;
+    const int64_t *d_perm;
+    const double *d_grid_x, *d_grid_y, *d_nu_flux, *d_weighted_aeff, *d_initial_weights;
+    const double *d_sample[3];
+    const int32_t *d_node, *d_bin;
+    double *o_grid_x, *o_grid_y, *o_nu_flux, *o_weighted_aeff, *o_initial_weights;
+    double *o_sample[3];
+    int32_t *o_node, *o_bin, *o_node_bin;
+    double *o_aeff_w0, *o_static_w;
+    int32_t *o_node_bin16;
+    int32_t n_sample, reserved;
+} pisa_hip_pack_set;
+int pisa_hip_pack_resident_columns(const pisa_hip_pack_set *set, void *stream);
 
 /* Fused  prob3.apply (prob3.py:621-622, with the grid->event lookup of
  * container.py:981-1012 / translation.py:427-438)  +  aeff.apply

@@ -135,6 +135,36 @@ class BarrFoldSet(C.Structure):
     ]
 
 
+class PackSet(C.Structure):
+    _fields_ = [
+        ("n", C.c_int64),
+        ("n_pad", C.c_int64),
+        ("d_perm", C.c_void_p),
+        ("d_grid_x", C.c_void_p),
+        ("d_grid_y", C.c_void_p),
+        ("d_nu_flux", C.c_void_p),
+        ("d_weighted_aeff", C.c_void_p),
+        ("d_initial_weights", C.c_void_p),
+        ("d_sample", C.c_void_p * 3),
+        ("d_node", C.c_void_p),
+        ("d_bin", C.c_void_p),
+        ("o_grid_x", C.c_void_p),
+        ("o_grid_y", C.c_void_p),
+        ("o_nu_flux", C.c_void_p),
+        ("o_weighted_aeff", C.c_void_p),
+        ("o_initial_weights", C.c_void_p),
+        ("o_sample", C.c_void_p * 3),
+        ("o_node", C.c_void_p),
+        ("o_bin", C.c_void_p),
+        ("o_node_bin", C.c_void_p),
+        ("o_aeff_w0", C.c_void_p),
+        ("o_static_w", C.c_void_p),
+        ("o_node_bin16", C.c_void_p),
+        ("n_sample", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
 class KdeJob(C.Structure):
     _fields_ = [
         ("d_x", C.c_void_p),
@@ -250,6 +280,7 @@ _SIGS = {
     "pisa_hip_hist_workgroups": (C.c_int, [C.POINTER(C.c_int64), C.c_int32, C.POINTER(C.c_int32)]),
     "pisa_hip_deposit_block_order_workspace": (C.c_int64, [C.c_int64]),
     "pisa_hip_deposit_block_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "pisa_hip_pack_resident_columns": (C.c_int, [C.POINTER(PackSet), C.c_void_p]),
     "pisa_hip_weight_chain_multi": (C.c_int, [C.POINTER(ChainSet), C.c_int32, C.c_void_p]),
     "pisa_hip_evaluator_create": (C.c_int, [C.POINTER(EvaluatorDesc), C.POINTER(C.c_void_p)]),
     "pisa_hip_evaluator_destroy": (C.c_int, [C.c_void_p]),

@@ -125,6 +125,36 @@ order_interleave_kernel(const uint32_t *__restrict__ seq, int64_t n, const unsig
     perm[i] = (int64_t)seq[src * ORD_BLOCK + l];
 }
 
+// the resident copies of a container's columns in the order `perm` and their interleaved / folded forms, one thread per event
+__global__ void __launch_bounds__(256)
+pack_columns_kernel(const pisa_hip_pack_set a) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= a.n_pad) return;
+    if (k >= a.n) {
+        a.o_node_bin16[k] = (int32_t)0xFFFFFFFFu;
+        return;
+    }
+    const int64_t i = a.d_perm[k];
+    const double aeff = a.d_weighted_aeff[i], w0 = a.d_initial_weights[i];
+    const int32_t nd = a.d_node[i], b = a.d_bin[i];
+    a.o_grid_x[k] = a.d_grid_x[i];
+    a.o_grid_y[k] = a.d_grid_y[i];
+    a.o_nu_flux[2 * k] = a.d_nu_flux[2 * i];
+    a.o_nu_flux[2 * k + 1] = a.d_nu_flux[2 * i + 1];
+    a.o_weighted_aeff[k] = aeff;
+    a.o_initial_weights[k] = w0;
+    for (int c = 0; c < a.n_sample; c++) a.o_sample[c][k] = a.d_sample[c][i];
+    a.o_node[k] = nd;
+    a.o_bin[k] = b;
+    a.o_node_bin[2 * k] = nd;
+    a.o_node_bin[2 * k + 1] = b;
+    a.o_aeff_w0[2 * k] = aeff;
+    a.o_aeff_w0[2 * k + 1] = w0;
+    a.o_static_w[k] = w0 * aeff;
+    const uint32_t lo = nd < 0 ? 0xFFFFu : (uint32_t)nd, hi = b < 0 ? 0xFFFFu : (uint32_t)b;
+    a.o_node_bin16[k] = (int32_t)(lo | (hi << 16));
+}
+
 // bytes of one of the five index arrays, a multiple of 256: the sort's temporary storage behind them holds 64-bit look-back
 // states and must not start at an odd multiple of four bytes (an odd event count did that: the sort of 3.3e6 events then hung
 // under a counter-collecting profiler)
@@ -173,5 +203,24 @@ PISA_API int pisa_hip_deposit_block_order(const int32_t *d_node, const int32_t *
                        d_bin, n, n_dep, seq);
     hipLaunchKernelGGL(order_interleave_kernel, dim3(nb), dim3(256), 0, s, seq, n, n_dep, d_perm);
     PISA_CHECK_LAUNCH("deposit block order kernels");
+    return PISA_HIP_OK;
+}
+
+PISA_API int pisa_hip_pack_resident_columns(const pisa_hip_pack_set *set, void *stream) {
+    if (!set || set->n < 0 || set->n_pad < set->n || set->n_pad % 256 != 0 || set->n_pad > 0x7FFFFFF0LL || set->n_sample < 0 || set->n_sample > 3)
+        return PISA_HIP_ERR_INVALID;
+    if (set->n_pad == 0) return PISA_HIP_OK;
+    const pisa_hip_pack_set &a = *set;
+    if (!a.o_node_bin16) return PISA_HIP_ERR_INVALID;
+    if (a.n > 0) {
+        if (!a.d_perm || !a.d_grid_x || !a.d_grid_y || !a.d_nu_flux || !a.d_weighted_aeff || !a.d_initial_weights || !a.d_node || !a.d_bin ||
+            !a.o_grid_x || !a.o_grid_y || !a.o_nu_flux || !a.o_weighted_aeff || !a.o_initial_weights || !a.o_node || !a.o_bin ||
+            !a.o_node_bin || !a.o_aeff_w0 || !a.o_static_w)
+            return PISA_HIP_ERR_INVALID;
+        for (int c = 0; c < a.n_sample; c++)
+            if (!a.d_sample[c] || !a.o_sample[c]) return PISA_HIP_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(pack_columns_kernel, dim3((unsigned)(a.n_pad / 256)), dim3(256), 0, as_stream(stream), a);
+    PISA_CHECK_LAUNCH("pack_columns_kernel");
     return PISA_HIP_OK;
 }

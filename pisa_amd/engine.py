@@ -331,6 +331,37 @@ def deposit_block_order_native(obin, node, n_nodes):
     return perm
 
 
+def pack_resident_columns(perm, gx, gy, flux, aeff, w0, cols, node, obin):
+    """The resident copies of one container's columns in the order `perm` and the interleaved / folded forms of the
+    16-bit index layout, in ONE native launch (`pisa_hip_pack_resident_columns`, csrc/order.hip) -- element for element what
+    the tensor operations of `HotPathEngine.__init__` produce (tests/test_gpu_engine.py compares them bit for bit).
+    Returns (gx, gy, flux, aeff, w0, cols, node, obin, node_bin [n, 2], aeff_w0 [n, 2], static_w [n], node_bin16 [n_pad])."""
+    import ctypes as C
+
+    n = int(perm.numel())
+    n_pad = -(-n // 256) * 256
+    dev = perm.device
+    f8 = lambda *shape: torch.empty(shape, dtype=torch.float64, device=dev)      # noqa: E731
+    i4 = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)        # noqa: E731
+    o_gx, o_gy, o_flux, o_aeff, o_w0 = f8(n), f8(n), f8(n, 2), f8(n), f8(n)
+    o_cols = [f8(n) for _ in cols]
+    o_node, o_obin, o_nb, o_aw, o_cst, o_nb16 = i4(n), i4(n), i4(n, 2), f8(n, 2), f8(n), i4(n_pad)
+    ins = [perm, gx, gy, flux, aeff, w0, node, obin] + list(cols)
+    ins = [t.contiguous() for t in ins]
+    ps = _lib.PackSet()
+    ps.n, ps.n_pad, ps.n_sample = n, n_pad, len(cols)
+    ps.d_perm, ps.d_grid_x, ps.d_grid_y, ps.d_nu_flux = (ins[k].data_ptr() for k in range(4))
+    ps.d_weighted_aeff, ps.d_initial_weights, ps.d_node, ps.d_bin = (ins[k].data_ptr() for k in range(4, 8))
+    ps.o_grid_x, ps.o_grid_y, ps.o_nu_flux = o_gx.data_ptr(), o_gy.data_ptr(), o_flux.data_ptr()
+    ps.o_weighted_aeff, ps.o_initial_weights = o_aeff.data_ptr(), o_w0.data_ptr()
+    for k in range(len(cols)):
+        ps.d_sample[k], ps.o_sample[k] = ins[8 + k].data_ptr(), o_cols[k].data_ptr()
+    ps.o_node, ps.o_bin, ps.o_node_bin = o_node.data_ptr(), o_obin.data_ptr(), o_nb.data_ptr()
+    ps.o_aeff_w0, ps.o_static_w, ps.o_node_bin16 = o_aw.data_ptr(), o_cst.data_ptr(), o_nb16.data_ptr()
+    _lib.check(_lib.lib().pisa_hip_pack_resident_columns(C.byref(ps), K._stream()))
+    return o_gx, o_gy, o_flux, o_aeff, o_w0, o_cols, o_node, o_obin, o_nb, o_aw, o_cst, o_nb16
+
+
 def local_slices(sizes, rank, world_size):
     """[(lo, hi)] of this rank's shard of every container (`sizes` = events per container): the
     partition `HotPathEngine` uses -- contiguous, equal to within one event, disjoint, complete"""
@@ -613,6 +644,7 @@ class HotPathEngine:
                 flux_d = torch.ones((hi - lo, 2), dtype=torch.float64, device=self.dev)
             _phase("upload")
             node = obin = perm = None
+            packed_forms = None          # (nb, aw, cst, nb16) from the native pack call, where it applies
             static_w = wflux = None
             part_starts, part_width = None, 0
             if self.osc_events:
@@ -683,7 +715,20 @@ class HotPathEngine:
                     # static, so such events need not be resident at all
                     keep = (obin >= 0) & (node >= 0)
                     perm = torch.nonzero(keep).reshape(-1) if perm is None else perm[keep[perm]]
-                if perm is not None:
+                # the columns in resident order: one native launch for the 16-bit index layout (round 5: the ~25 tensor
+                # operations per container below were 6 ms of a 24 ms set-up at 1e7 events, bound by their dispatch on the
+                # host; PISA_HIP_TORCH_ORDER=1 keeps them: they are the specification the call is tested against)
+                native_pack = (perm is not None and packed and compact and index16 and len(cols) <= 3
+                               and perm.dtype == torch.int64 and node.dtype == torch.int32 and obin.dtype == torch.int32
+                               and flux_d.dim() == 2 and flux_d.shape[1] == 2
+                               and all(t.dtype == torch.float64 for t in [gx, gy, flux_d, aeff_d, w0_d] + cols)
+                               and _os.environ.get("PISA_HIP_TORCH_ORDER") != "1")
+                if native_pack:
+                    (gx, gy, flux_d, aeff_d, w0_d, cols, node, obin, *packed_forms) = pack_resident_columns(
+                        perm, gx, gy, flux_d, aeff_d, w0_d, cols, node, obin)
+                    self.n_local += int(perm.numel()) - d.n_events
+                    d.n_events = int(perm.numel())
+                elif perm is not None:
                     gx, gy, flux_d, aeff_d, w0_d = (t[perm].contiguous() for t in
                                                    (gx, gy, flux_d, aeff_d, w0_d))
                     cols = [t[perm].contiguous() for t in cols]
@@ -712,14 +757,17 @@ class HotPathEngine:
                 d.d_node, d.d_bin = node.data_ptr(), obin.data_ptr()
                 if packed:
                     # interleaved columns: every load of the fused kernel is 16 bytes
-                    nb = torch.stack([node, obin], dim=1).contiguous()
-                    aw = torch.stack([aeff_d, w0_d], dim=1).contiguous()
+                    if packed_forms is not None:
+                        nb, aw = packed_forms[0], packed_forms[1]
+                    else:
+                        nb = torch.stack([node, obin], dim=1).contiguous()
+                        aw = torch.stack([aeff_d, w0_d], dim=1).contiguous()
                     self._keep += [nb, aw]
                     d.d_node_bin, d.d_aeff_w0 = nb.data_ptr(), aw.data_ptr()
                     if compact:
                         # the factors of the weight that no oscillation parameter touches,
                         # multiplied once: (w0*aeff) * (f_e, f_mu)
-                        cst = (w0_d * aeff_d).contiguous()
+                        cst = packed_forms[2] if packed_forms is not None else (w0_d * aeff_d).contiguous()
                         self._keep.append(cst)
                         static_w = cst
                         if index16:
@@ -729,10 +777,13 @@ class HotPathEngine:
                             # padded to whole blocks of 64 quads with events outside the binning
                             n_ev = int(node.numel())
                             n_pad = -(-n_ev // 256) * 256
-                            v = torch.full((n_pad,), 0xFFFFFFFF, dtype=torch.int64, device=self.dev)
-                            v[:n_ev] = (torch.where(node < 0, 0xFFFF, node.long())
-                                        | (torch.where(obin < 0, 0xFFFF, obin.long()) << 16))
-                            nb16 = torch.where(v >= 2 ** 31, v - 2 ** 32, v).to(torch.int32).contiguous()
+                            if packed_forms is not None:
+                                nb16 = packed_forms[3]
+                            else:
+                                v = torch.full((n_pad,), 0xFFFFFFFF, dtype=torch.int64, device=self.dev)
+                                v[:n_ev] = (torch.where(node < 0, 0xFFFF, node.long())
+                                            | (torch.where(obin < 0, 0xFFFF, obin.long()) << 16))
+                                nb16 = torch.where(v >= 2 ** 31, v - 2 ** 32, v).to(torch.int32).contiguous()
                             wq = torch.zeros((n_pad // 256, 4, 64, 2), dtype=torch.float64, device=self.dev)
                             self._keep += [nb16, wq]
                             d.d_node_bin16, d.d_weighted_flux_q = nb16.data_ptr(), wq.data_ptr()

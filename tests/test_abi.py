@@ -110,7 +110,7 @@ def test_every_struct_of_the_header_has_the_layout_of_its_binding(built, tmp_pat
              ("pisa_hip_flux_table", built.FluxTable), ("pisa_hip_fold_set", built.FoldSet),
              ("pisa_hip_barr_set", built.BarrSet), ("pisa_hip_barr_fold_set", built.BarrFoldSet),
              ("pisa_hip_kde_job", built.KdeJob), ("pisa_hip_evaluator_desc", built.EvaluatorDesc),
-             ("pisa_hip_chain_set", built.ChainSet)]
+             ("pisa_hip_chain_set", built.ChainSet), ("pisa_hip_pack_set", built.PackSet)]
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "pisa_hip.h"', 'int main(void) {', 'printf("{");']
     for k, (cname, cls) in enumerate(pairs):
         lines.append('printf("%s\\"%s\\": {\\"sizeof\\": %%zu", sizeof(%s));' % (", " if k else "", cname, cname))

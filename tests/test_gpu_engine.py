@@ -801,3 +801,40 @@ def test_native_resident_order_is_the_torch_formulation(n, n_nodes, n_bins, frac
     assert np.array_equal(np.sort(got), np.arange(n))
     assert np.array_equal(got, want)
     assert np.array_equal(got, engine.deposit_block_order_native(d_bin, d_node, n_nodes).cpu().numpy())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,n_cols", [(1, 0), (255, 1), (256, 2), (100003, 3), (833333, 3)])
+def test_native_pack_is_the_tensor_formulation(n, n_cols):
+    """`pisa_hip_pack_resident_columns` (one launch per container at set-up) against the tensor operations of
+    `HotPathEngine.__init__` it replaces: every permuted column, the interleaved pairs, the folded static weight and the
+    16-bit index column with its padding, bit for bit -- a random permutation (also shorter than the sample: dropped events),
+    negative indices in both columns"""
+    import torch
+
+    from pisa_amd import engine as E
+
+    g = torch.Generator(device="cpu").manual_seed(n + n_cols)
+    dev = torch.device("cuda")
+    m = n + 17
+    perm = torch.randperm(m, generator=g)[:n].to(dev)
+    f = lambda *shape: torch.rand(shape, generator=g, dtype=torch.float64).to(dev)        # noqa: E731
+    gx, gy, flux, aeff, w0 = f(m), f(m), f(m, 2), f(m), f(m)
+    cols = [f(m) for _ in range(n_cols)]
+    node = torch.randint(-1, 20000, (m,), generator=g, dtype=torch.int32).to(dev)
+    obin = torch.randint(-1, 128, (m,), generator=g, dtype=torch.int32).to(dev)
+    got = E.pack_resident_columns(perm, gx, gy, flux, aeff, w0, cols, node, obin)
+    want_cols = [t[perm].contiguous() for t in (gx, gy, flux, aeff, w0)]
+    for a, b in zip(got[:5], want_cols):
+        assert torch.equal(a, b)
+    for a, b in zip(got[5], cols):
+        assert torch.equal(a, b[perm])
+    nd, ob = node[perm], obin[perm]
+    assert torch.equal(got[6], nd) and torch.equal(got[7], ob)
+    assert torch.equal(got[8], torch.stack([nd, ob], dim=1))
+    assert torch.equal(got[9], torch.stack([aeff[perm], w0[perm]], dim=1))
+    assert torch.equal(got[10], w0[perm] * aeff[perm])
+    n_pad = -(-n // 256) * 256
+    v = torch.full((n_pad,), 0xFFFFFFFF, dtype=torch.int64, device=dev)
+    v[:n] = torch.where(nd < 0, 0xFFFF, nd.long()) | (torch.where(ob < 0, 0xFFFF, ob.long()) << 16)
+    assert torch.equal(got[11], torch.where(v >= 2 ** 31, v - 2 ** 32, v).to(torch.int32))
