@@ -21,7 +21,10 @@ histogram limbs all-reduced over RCCL -- strong scaling; `value` is the evaluati
 one sample.  The weak-scaling rate (every rank holds 1e7 events of its own, N samples per step)
 is measured in the same run and reported as `weak_value`.
 
-Prints ONE JSON line on rank 0.  Besides the headline it carries, at N = 1, the `legs`:
+Rank 0 prints, as its LAST stdout line, ONE compact JSON object below 4 KB: the contract's fields, `roofline`,
+`cpu_baseline`, the LLH gate and one number per leg (`compact_line`).  The full result goes to `bench_detail.json`
+beside this script (`--detail-out`) and, marked `bench_detail `, to stderr.  Besides the headline the full result
+carries, at N = 1, the `legs`:
 bounded extra measurements of the same hot path (larger-than-L3 sample, the reference-order and
 the coordinate-form kernels, a 4 800-bin output binning, flux systematics moving every evaluation
 with the flux per event and on the oscillation grid, the evaluation through the Pipeline/cfg
@@ -86,6 +89,9 @@ def parse(argv=None):
                     help="test aid: take the N > 1 code path (RCCL process group, limb all-reduce, barriers, "
                          "max over ranks) with the ranks that are there, e.g. one rank under "
                          "torch.distributed.run on a single-GPU box")
+    ap.add_argument("--detail-out", default=None,
+                    help="where the full result (every leg, thread scan, LLH referee) is written; default bench_detail.json "
+                         "beside this script ('-': nowhere).  The LAST stdout line is the compact contract line either way")
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--min-timed-s", type=float, default=0.2,
                     help="repeat the block of --steps timed steps until this much timed work has been seen "
@@ -93,6 +99,112 @@ def parse(argv=None):
     ap.add_argument("--event-order", default="auto", choices=["auto", "node", "bin", "part"],
                     help="resident event order: sorted by calc-grid node, or by (output bin, node)")
     return ap.parse_args(argv)
+
+
+COMPACT_LIMIT = 4096   # bytes: the LAST stdout line (what the driver parses) stays below this
+
+
+def _r(x, digits=6):
+    """floats to `digits` significant digits (the compact line only; the detail file keeps every bit)"""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x)) if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _r(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, digits) for v in x]
+    return x
+
+
+def compact_line(out, detail_path=None):
+    """The contract's fields + `roofline` + `cpu_baseline` + one number per leg: what rank 0 prints as its
+    LAST stdout line.  Everything else of `out` (the legs in full, the thread scan of the CPU baseline, the
+    LLH referee's report) lives in the detail file."""
+    legs = out.get("legs") or {}
+
+    def leg(name, *path):
+        v = legs.get(name)
+        for k in path:
+            v = v.get(k) if isinstance(v, dict) else None
+        return v
+
+    cfg = out["config"]
+    rf = out["roofline"]
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                "scaling", "vs_baseline", "dtype")}
+    line["data"] = "synthetic"
+    line["config"] = {"workload": "%d events/12 containers, prob3 %dx%d PREM-12 grid (nu+nubar), fused lookup+reweight+%s hist+sumw2, "
+                                  "Poisson LLH read back every eval, %d B/event"
+                                  % (cfg["events"], cfg["calc_grid"][0], cfg["calc_grid"][1],
+                                     "x".join(str(b) for b in cfg["out_bins"]), rf["bytes_per_event"]),
+                      "events": cfg["events"], "calc_grid": cfg["calc_grid"], "out_bins": cfg["out_bins"],
+                      "parallelism": "events sharded over %d GPU(s), int64 limb all-reduce (RCCL)" % out["n_gpus"]}
+    bt = rf.get("by_kernel_trace") or {}
+    line["roofline"] = {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "bytes_per_event",
+                                               "events_per_launch", "avg_launch_ms", "fits_l3", "traffic", "frac_beyond_l3")}
+    line["roofline"]["by_kernel_trace"] = {"frac": bt.get("frac"), "avg_launch_us": bt.get("avg_launch_us")} if bt else None
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "cpu_model", "oracle_llh", "device_llh",
+                                                       "llh_rel_diff")}
+        line["cpu_baseline"]["sample"] = "all %d events + full grid, nothing scaled" % cfg["events"]
+        line["cpu_baseline"]["single_thread"] = (cb.get("single_thread") or {}).get("value")
+    gate = out.get("llh_gate")
+    if gate:
+        line["llh_gate"] = {"pure_1e-10_relative_met": gate.get("pure_1e-10_relative_met"), "applied": gate.get("applied"),
+                            "referee_met": (gate.get("referee") or {}).get("met")}
+    for k in ("strong_value", "weak_value", "allreduce_ms", "nccl_comm_count", "last_llh", "llh_bits_identical", "setup_ms",
+              "topology", "point_parallel_evals_per_s", "batched_evals_per_s3", "batched_evals_per_s9", "timed_blocks",
+              "hooks_used"):
+        if out.get(k) is not None:
+            line[k] = out[k]
+    if out.get("llh_bits_per_rank"):
+        line["llh_bits"] = out["llh_bits_per_rank"][0]
+    line["setup_first_ms"] = ((out.get("setup") or {}).get("first_in_process") or {}).get("wall_ms")
+    line["phase_ms"] = {k: v for k, v in (out.get("phase_ms") or {}).items() if k != "events_this_rank" and v is not None}
+    summary = {
+        "kde_c3_ms": leg("kde_c3", "ms_per_step"), "kde_c3_frac": leg("kde_c3", "roofline", "frac"),
+        "kde_c3_launches": leg("kde_c3", "launches_per_evaluation"),
+        "events_c2_ms": leg("events_c2", "ms_per_step"), "events_c2_frac": leg("events_c2", "roofline", "frac"),
+        "events_c2_decay_ms": leg("events_c2_decay", "ms_per_step"),
+        "events_c5_ms": leg("events_c5", "ms_per_step"),
+        "events_c5_full_ms": leg("events_c5_full", "ms_per_step"), "events_c5_full_frac": leg("events_c5_full", "roofline", "frac"),
+        "coordinate_form_frac": leg("coordinate_form", "roofline", "frac"),
+        "exact_association_frac": leg("exact_association", "roofline", "frac"),
+        "fine_binning_frac": leg("fine_binning", "roofline", "frac"), "fine_binning_ms": leg("fine_binning", "ms_per_step"),
+        "pipeline_boundary_evals_per_s": leg("pipeline_boundary", "evals_per_s"),
+        "pipeline_boundary_over_engine": leg("pipeline_boundary", "boundary_over_engine"),
+        "icecube3y_evals_per_s": leg("icecube3y_boundary", "evals_per_s"),
+        "osc_example_c1_ms": leg("osc_example_c1", "ms_per_step"),
+        "fit_c4_evals_per_s": leg("fit_c4", "stencil_in_one_sweep", "evals_per_s"),
+        "fit_c4_same_history": leg("fit_c4", "same_history"),
+        "update_flux_ms": leg("update_flux", "ms_per_step"),
+        "c4_llh_gate": out.get("c4_llh_gate"),
+    }
+    line["legs_summary"] = {k: v for k, v in summary.items() if v is not None}
+    line["legs_run"] = sorted(k for k, v in legs.items() if v is not None)
+    errs = sorted(k for k, v in legs.items() if isinstance(v, dict) and "error" in v)
+    if errs:
+        line["legs_failed"] = errs
+    if detail_path:
+        line["detail"] = os.path.relpath(detail_path, ROOT) if detail_path.startswith(ROOT) else detail_path
+    line = _r(line)
+    line["value"], line["ms_per_step"] = out["value"], out["ms_per_step"]          # every bit of the headline and the LLHs
+    for k in ("last_llh",):
+        if k in line:
+            line[k] = out[k]
+    if cb:
+        for k in ("oracle_llh", "device_llh"):
+            line["cpu_baseline"][k] = cb.get(k)
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= COMPACT_LIMIT:     # never let the line outgrow the driver again: shed the optional parts
+        for k in ("legs_summary", "phase_ms", "legs_run", "llh_gate"):
+            line.pop(k, None)
+            text = json.dumps(line, separators=(",", ":"))
+            if len(text) < COMPACT_LIMIT:
+                break
+    return text
 
 
 HOOKS_ENV = "PISA_BENCH_HOOKS"   # tests only: "module:function" returning the `hooks` dict of main()
@@ -1532,7 +1644,19 @@ def main(argv=None, hooks=None):
             # the bench's last headline point against the oracle on identical inputs (north star: <= 1e-10)
             out["oracle_llh"], out["llh_rel_diff"] = cb["oracle_llh"], cb["llh_rel_diff"]
             out["llh_gate"] = cb["llh_gate"]
-        print(json.dumps(out))
+        detail_path = None
+        if args.detail_out != "-":
+            detail_path = os.path.abspath(args.detail_out or os.path.join(ROOT, "bench_detail.json"))
+            try:
+                with open(detail_path, "w") as fh:
+                    json.dump(out, fh)
+                    fh.write("\n")
+            except OSError as exc:
+                print("bench.py: detail file not written (%s)" % exc, file=sys.stderr)
+                detail_path = None
+        # the full result also on stderr (one line, marked), the compact contract line LAST on stdout
+        print("bench_detail " + json.dumps(out), file=sys.stderr, flush=True)
+        print(compact_line(out, detail_path), flush=True)
         if hooks is not None and "result" in hooks:
             hooks["result"](out)
     if dist_on:

@@ -28,6 +28,32 @@ def oracle():
     return orc
 
 
+BENCH_LINE_LIMIT = 4096
+
+
+def bench_result(stdout, detail_path):
+    """bench.py's contract as the driver reads it: the LAST stdout line is ONE compact strict-JSON object below 4 KB
+    (round 5's 20 KB line was not parsed); the full result is in the detail file.  Returns (compact, detail)."""
+    import json
+
+    lines = [ln for ln in stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), stdout[-2000:]
+    assert len(lines[0].encode()) < BENCH_LINE_LIMIT, len(lines[0])
+
+    def no_constants(name):   # NaN / Infinity are not JSON
+        raise ValueError("non-JSON constant %s in the bench line" % name)
+
+    compact = json.loads(lines[0], parse_constant=no_constants)
+    need = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline"}
+    assert need <= set(compact), need - set(compact)
+    assert {"workload", "events", "calc_grid", "out_bins", "parallelism"} <= set(compact["config"])
+    with open(detail_path) as fh:
+        detail = json.load(fh)
+    assert detail["value"] == compact["value"] and detail["ms_per_step"] == compact["ms_per_step"]
+    return compact, detail
+
+
 def has_gpu():
     try:
         import torch

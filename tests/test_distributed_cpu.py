@@ -11,6 +11,8 @@ import socket
 
 import numpy as np
 import pytest
+
+from tests.conftest import bench_result
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -483,15 +485,16 @@ def test_bench_gpus_2_launches_its_own_ranks(tmp_path):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--events", "360", "--steps", "3",
-           "--warmup", "1", "--min-timed-s", "0", "--grid", "12x8", "--legs", "multi_point"]
+           "--warmup", "1", "--min-timed-s", "0", "--grid", "12x8", "--legs", "multi_point",
+           "--detail-out", str(tmp_path / "detail.json")]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["PISA_BENCH_HOOKS"] = "tests.test_distributed_cpu:bench_hooks"
     env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
-    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, res.stdout
-    line = json.loads(lines[0])
+    compact, line = bench_result(res.stdout, str(tmp_path / "detail.json"))
+    assert compact["legs_run"] == ["multi_point"] and compact["llh_bits_identical"] is True and compact["hooks_used"] is True
+    assert compact["llh_bits"] == line["llh_bits_per_rank"][0] and compact["batched_evals_per_s9"] > 0
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0 and line["scaling"] == "strong"
     assert line["llh_bits_identical"] is True and len(line["llh_bits_per_rank"]) == 2
     assert set(line["legs"]) == {"multi_point"}

@@ -12,6 +12,8 @@ import sys
 
 import pytest
 
+from tests.conftest import bench_result
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -26,17 +28,21 @@ def share_device_hooks_points():
 
 
 def _bench(gpus, hooks=True, legs="none"):
+    import tempfile
+
+    detail = os.path.join(tempfile.mkdtemp(prefix="pisa_bench_"), "detail.json")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--events", "2400000", "--steps", "6",
-           "--warmup", "2", "--min-timed-s", "0", "--legs", legs, "--no-cpu-baseline", "--no-drop-probe", "--no-batch-probe"]
+           "--warmup", "2", "--min-timed-s", "0", "--legs", legs, "--no-cpu-baseline", "--no-drop-probe", "--no-batch-probe",
+           "--detail-out", detail]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     if hooks:
         env["PISA_BENCH_HOOKS"] = "tests.test_gpu_distributed:share_device_hooks" + ("_points" if legs != "none" else "")
     env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-4000:]
-    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, res.stdout[-2000:]
-    return json.loads(lines[0])
+    compact, line = bench_result(res.stdout, detail)
+    assert compact["n_gpus"] == gpus and compact.get("llh_bits_identical") == line["llh_bits_identical"]
+    return line
 
 
 def test_two_and_four_ranks_on_one_device_reproduce_the_single_rank_bits():
