@@ -705,7 +705,7 @@ def leg_node_flux(synthetic, torch, args, n_e, n_cz, steps):
     return out
 
 
-def _pipeline_cfg(n_events, kde=False):
+def _pipeline_cfg(n_events, kde=False, kde_tol=None):
     from collections import OrderedDict
 
     from pisa_amd.core.config_parser import parse_pipeline_config
@@ -717,7 +717,8 @@ def _pipeline_cfg(n_events, kde=False):
     out = OrderedDict()
     for k, v in cfg.items():
         if k == ("utils", "hist"):
-            out[("utils", "kde")] = OrderedDict(calc_mode="events", apply_mode=v["apply_mode"])
+            out[("utils", "kde")] = OrderedDict(calc_mode="events", apply_mode=v["apply_mode"],
+                                                **({} if kde_tol is None else {"tol": kde_tol}))
         else:
             out[k] = v
     out["pipeline"]["output_key"] = "weights"
