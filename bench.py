@@ -166,6 +166,7 @@ def compact_line(out, detail_path=None):
     summary = {
         "kde_c3_ms": leg("kde_c3", "ms_per_step"), "kde_c3_frac": leg("kde_c3", "roofline", "frac"),
         "kde_c3_launches": leg("kde_c3", "launches_per_evaluation"),
+        "kde_c3_default_tol_ms": leg("kde_c3", "default_tol", "ms_per_step"),
         "events_c2_ms": leg("events_c2", "ms_per_step"), "events_c2_frac": leg("events_c2", "roofline", "frac"),
         "events_c2_decay_ms": leg("events_c2_decay", "ms_per_step"),
         "events_c5_ms": leg("events_c5", "ms_per_step"),
@@ -175,7 +176,7 @@ def compact_line(out, detail_path=None):
         "fine_binning_frac": leg("fine_binning", "roofline", "frac"), "fine_binning_ms": leg("fine_binning", "ms_per_step"),
         "pipeline_boundary_evals_per_s": leg("pipeline_boundary", "evals_per_s"),
         "pipeline_boundary_over_engine": leg("pipeline_boundary", "boundary_over_engine"),
-        "icecube3y_evals_per_s": leg("icecube3y_boundary", "evals_per_s"),
+        "icecube3y_evals_per_s": leg("icecube3y_boundary", "all_free", "evals_per_s"),
         "osc_example_c1_ms": leg("osc_example_c1", "ms_per_step"),
         "fit_c4_evals_per_s": leg("fit_c4", "stencil_in_one_sweep", "evals_per_s"),
         "fit_c4_same_history": leg("fit_c4", "same_history"),
@@ -1223,23 +1224,36 @@ def leg_kde(torch, n_events, steps):
     from pisa_amd.core.pipeline import Pipeline
     from pisa_amd.core.units import ureg
 
-    pipe = Pipeline(_pipeline_cfg(n_events, kde=True))
-    for i in range(3):   # (the library's worker threads size their workspaces on their first jobs)
-        pipe.params.theta23.value = (37.0 + i) * ureg.degree
-        pipe.get_outputs()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        pipe.params.theta23.value = (40.0 + 0.5 * i) * ureg.degree
-        maps = pipe.get_outputs()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    from pisa_amd.stages.utils.kde import KDE_FAST_TOL, KDE_STAGE_TOL
+
+    def run(tol, steps):
+        pipe = Pipeline(_pipeline_cfg(n_events, kde=True, kde_tol=tol))
+        for i in range(3):   # (the library's worker threads size their workspaces on their first jobs)
+            pipe.params.theta23.value = (37.0 + i) * ureg.degree
+            pipe.get_outputs()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            pipe.params.theta23.value = (40.0 + 0.5 * i) * ureg.degree
+            maps = pipe.get_outputs()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps, pipe, maps
+
+    # the stage's default cut-off (1e-14: all pairs at rounding level) beside the explicit fast one the leg reports
+    dt_default, pipe, maps = run(None, max(4, steps // 2))
+    total_default = float(sum(m.hist.sum() for m in maps))
+    del pipe, maps
+    dt, pipe, maps = run(KDE_FAST_TOL, steps)
     st = pipe["kde"].stats
     work = st["pairs_pilot"] + st["pairs_eval"]
     out = {"events": int(n_events) // 12 * 12, "evals_per_s": 1.0 / dt, "ms_per_step": dt * 1e3,
            "kernel_evaluations_per_step": work, "all_pairs_would_be": st["all_pairs"],
            "total_of_maps": float(sum(m.hist.sum() for m in maps)),
-           "workload": "settings/pipeline/example_hip.cfg with utils.kde in place of utils.hist: 12 containers x 2 "
+           "tol": KDE_FAST_TOL,
+           "default_tol": {"tol": KDE_STAGE_TOL, "ms_per_step": dt_default * 1e3, "total_of_maps": total_default},
+           "workload": "settings/pipeline/example_hip.cfg with utils.kde (tol = 1e-12 set in the cfg: every bin of these maps "
+                       "within 6.2e-12 of the all-pairs evaluation, scripts/dev/kde_tol_budget.py; the stage's default 1e-14 "
+                       "timed beside it) in place of utils.hist: 12 containers x 2 "
                        "pid channels = 24 adaptive 2-D KDEs per evaluation, 150 x 100 evaluation points each; "
                        "theta23 changed every step; KDE core parity unpinned (un-vendored `kde` package)"}
     # executed fp64 flops of ALL kde_* kernels of one evaluation from the committed SQ_INSTS_VALU_*_F64

@@ -633,3 +633,19 @@ def test_fixed_bandwidth_estimator_equals_scipy(dim, n, bw):
     got_w = est_w(K.to_device(q)).cpu().numpy()
     want_w = stats.gaussian_kde(x, bw_method=est_w.factor, weights=w)(q)
     np.testing.assert_allclose(got_w, want_w, rtol=1e-10, atol=1e-12 * want_w.max())
+
+
+def test_kde_pinned_by_the_reference_package():
+    """With the fixture of `python -m oracle.pin_kde` present (written wherever the un-vendored `kde` package is
+    installed): the DEVICE estimator against the package's densities at 1e-10 relative on the reference test's exact
+    set-up and three small adaptive cases (skips otherwise -- KDE core parity unpinned)."""
+    from pisa_amd import kernels as K
+    from tests.test_oracle import _kde_pin_fixture
+
+    z = _kde_pin_fixture()
+    for name in sorted({k.split("__")[0] for k in z.files}):
+        bw, adaptive, alpha = z[name + "__settings"]
+        est = K.KdeEstimator(K.to_device(z[name + "__x"]), K.to_device(z[name + "__w"]), bw_method="silverman" if bw else "scott",
+                             adaptive=bool(adaptive), alpha=float(alpha), tol=0.0)
+        got = est(K.to_device(z[name + "__points"])).cpu().numpy()
+        np.testing.assert_allclose(got, z[name + "__density"], rtol=1e-10, atol=0, err_msg=name)

@@ -78,7 +78,10 @@ def _linearisation_ratio(c, **kde):
                    "this textbook form (the invariant holds here from alpha ~ 0.26 on, next test).  oracle/kde_variants.py "
                    "(tests/test_oracle.py::test_kde_criterion_diagnosis_table) evaluates the criterion for 19 variants of "
                    "the estimator on the reference's exact set-up: all weights are equal there, and no structural variant "
-                   "meets the 5 % at alpha = 0.1 -- nothing singles out a form to adopt")
+                   "meets the 5 % at alpha = 0.1 -- nothing singles out a form to adopt.  Pin recipe for whoever has the "
+                   "package: `python -m oracle.pin_kde` writes tests/golden/kde_ref.npz (this very set-up among its cases), "
+                   "which tests/test_oracle.py / tests/test_gpu_kde.py::test_kde_pinned_by_the_reference_package then compare "
+                   "at 1e-10")
 def test_linearisation_changes_the_total_by_less_than_5_percent_reference_criterion():
     """pisa_tests/test_kde_stage.py:136-153, verbatim criterion, the stage's defaults"""
     a, b = _linearisation_ratio(_configs())

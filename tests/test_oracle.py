@@ -387,3 +387,56 @@ def test_llh_referee_separates_map_error_from_log_rounding():
     assert bad_eval["maps"]["met"] and not bad_eval["device_evaluation"]["met"] and not bad_eval["met"]
     exact = llh_referee(k, lam, lam, f(lam), f(lam))
     assert exact["pure_1e-10_relative_met"] and exact["applied"].startswith("1e-10 relative")
+
+
+def _kde_pin_fixture():
+    import os
+
+    from tests.conftest import GOLDEN
+
+    path = os.path.join(GOLDEN, "kde_ref.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/kde_ref.npz absent: the un-vendored `kde` package is not available in this image; "
+                    "`python -m oracle.pin_kde` writes the fixture wherever the package is installed (INTEGRATION.md)")
+    return np.load(path, allow_pickle=False)
+
+
+def test_kde_pin_recipe_runs(tmp_path):
+    """oracle/pin_kde.py (round 6): the one-command pin of the KDE core.  Here -- no `kde` package -- it must say so and
+    write nothing; its --self-check mode runs every case (the reference test's exact set-up with and without
+    linearisation, three small adaptive 2-D cases) through the oracle and writes the file layout the pinned tests read."""
+    from oracle import kde_oracle, pin_kde
+
+    out = str(tmp_path / "self.npz")
+    assert pin_kde.main(["--self-check", "--out", out]) == 0
+    z = np.load(out, allow_pickle=False)
+    names = sorted({k.split("__")[0] for k in z.files})
+    assert names == sorted(pin_kde.cases()) and len(names) == 5
+    c = pin_kde.cases()["ref_test_linearized"]
+    assert c["x"].shape == (2, 1000) and c["points"].shape == (2, 20 * 15) and np.all(c["w"] == 12345.0)
+    # the case IS the reference test's set-up: same sample as oracle/kde_variants.py restates (toy_event_generator.py:75-76)
+    from oracle import kde_variants as kv
+
+    e, cz, w = kv.sample()
+    assert np.array_equal(c["x"][0], cz) and np.array_equal(c["x"][1], np.log(e)) and np.array_equal(c["w"], w)
+    for name in names:
+        want = kde_oracle.gaussian_kde_eval(z[name + "__x"], z[name + "__w"], z[name + "__points"],
+                                            "silverman" if z[name + "__settings"][0] else "scott", True, float(z[name + "__settings"][2]))
+        assert np.array_equal(z[name + "__density"], want)
+    try:
+        import kde.cudakde  # noqa: F401
+    except ImportError:
+        assert pin_kde.main([]) == 2       # nothing written, says why
+
+
+def test_kde_pinned_by_the_reference_package():
+    """With the fixture of `python -m oracle.pin_kde` present: the ORACLE's estimator against the `kde` package's
+    densities at 1e-10 relative on every case (skips otherwise -- KDE core parity unpinned)."""
+    from oracle import kde_oracle
+
+    z = _kde_pin_fixture()
+    for name in sorted({k.split("__")[0] for k in z.files}):
+        bw, adaptive, alpha = z[name + "__settings"]
+        got = kde_oracle.gaussian_kde_eval(z[name + "__x"], z[name + "__w"], z[name + "__points"],
+                                           "silverman" if bw else "scott", bool(adaptive), float(alpha))
+        np.testing.assert_allclose(got, z[name + "__density"], rtol=1e-10, atol=0, err_msg=name)
