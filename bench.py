@@ -92,6 +92,9 @@ def parse(argv=None):
     ap.add_argument("--detail-out", default=None,
                     help="where the full result (every leg, thread scan, LLH referee) is written; default bench_detail.json "
                          "beside this script ('-': nowhere).  The LAST stdout line is the compact contract line either way")
+    ap.add_argument("--c4-gate-points", type=int, default=50,
+                    help="config C4's seeded (theta23, dm31) points put through the LLH gate against the oracle after the timed "
+                         "regions (with the CPU baseline; 0: none)")
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--min-timed-s", type=float, default=0.2,
                     help="repeat the block of --steps timed steps until this much timed work has been seen "
@@ -181,7 +184,9 @@ def compact_line(out, detail_path=None):
         "fit_c4_evals_per_s": leg("fit_c4", "stencil_in_one_sweep", "evals_per_s"),
         "fit_c4_same_history": leg("fit_c4", "same_history"),
         "update_flux_ms": leg("update_flux", "ms_per_step"),
-        "c4_llh_gate": out.get("c4_llh_gate"),
+        "c4_llh_gate": None if not out.get("c4_llh_gate") else {k: out["c4_llh_gate"].get(k) for k in
+                                                                 ("points", "pure_1e-10_met", "all_met", "max_fp64_rel_diff",
+                                                                  "max_maps_rel_diff_extended", "max_device_over_eps_rms")},
     }
     line["legs_summary"] = {k: v for k, v in summary.items() if v is not None}
     line["legs_run"] = sorted(k for k, v in legs.items() if v is not None)
@@ -273,6 +278,16 @@ def param_list(wl, n, **kw):
     return out
 
 
+def param_points(wl, n, **kw):
+    """the points of `param_list`, one at a time, each with the matrices it was made from: (params, matrices)"""
+    import numpy as np
+
+    rs = np.random.RandomState(2024)
+    for _ in range(n):
+        p = wl.osc_params(theta23_deg=31.0 + 28.0 * rs.rand(), dm31=1e-3 + 6e-3 * rs.rand(), **kw)
+        yield p, dict(wl.last_matrices)
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as fh:
@@ -338,7 +353,7 @@ def llh_gate(data, lam, device_llh, oracle_llh, device_hist=None):
     return out
 
 
-def cpu_baseline_subprocess(args, n_e, n_cz, data, matrices, device_llh, device_hist=None):
+def cpu_baseline_subprocess(args, n_e, n_cz, data, matrices, device_llh, device_hist=None, c4=None):
     """`cpu_baseline` in a process of its own: its OpenMP team is pinned one thread per core
     (OMP_PLACES=cores, OMP_PROC_BIND=close), which must not reach this process -- the runtime would pin
     the main thread as well and every helper thread the HIP runtime starts afterwards inherits that mask
@@ -353,7 +368,10 @@ def cpu_baseline_subprocess(args, n_e, n_cz, data, matrices, device_llh, device_
         np.savez(path, data=data, device_llh=device_llh, events=int(args.events), grid=[n_e, n_cz],
                  device_hist=np.zeros(0) if device_hist is None else np.asarray(device_hist, dtype=np.float64),
                  cores=list(physical_cores()),     # counted here: the worker's main thread is pinned
-                 **{"m_" + k: np.asarray(v) for k, v in matrices.items()})
+                 **{"m_" + k: np.asarray(v) for k, v in matrices.items()},
+                 **({} if not c4 else dict(c4_llh=np.asarray(c4["llh"]), c4_lam=np.asarray(c4["lam"]),
+                                           **{"c4m_" + k: np.stack([np.asarray(m[k]) for m in c4["matrices"]])
+                                              for k in c4["matrices"][0]})))
         env = dict(os.environ, OMP_PLACES="cores", OMP_PROC_BIND="close")
         res = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", path,
                               "--binning", args.binning], env=env, stdout=subprocess.PIPE, check=True)
@@ -371,10 +389,19 @@ def cpu_baseline_worker(path, binning):
     m = {k[2:]: z[k] for k in z.files if k.startswith("m_")}
     m["decay_flag"] = int(m["decay_flag"])
     dev_hist = z["device_hist"] if "device_hist" in z.files and z["device_hist"].size else None
-    print(json.dumps(cpu_baseline(wl, z["data"], m, float(z["device_llh"]), tuple(int(v) for v in z["cores"]), dev_hist)))
+    c4 = None
+    if "c4_llh" in z.files:
+        keys = [k[4:] for k in z.files if k.startswith("c4m_")]
+        mats = []
+        for i in range(len(z["c4_llh"])):
+            mi = {k: z["c4m_" + k][i] for k in keys}
+            mi["decay_flag"] = int(mi["decay_flag"])
+            mats.append(mi)
+        c4 = {"llh": z["c4_llh"], "lam": z["c4_lam"], "matrices": mats}
+    print(json.dumps(cpu_baseline(wl, z["data"], m, float(z["device_llh"]), tuple(int(v) for v in z["cores"]), dev_hist, c4)))
 
 
-def cpu_baseline(wl, data, matrices, device_llh, cores_logical=None, device_hist=None):
+def cpu_baseline(wl, data, matrices, device_llh, cores_logical=None, device_hist=None, c4=None):
     """The oracle (C restatement of the reference algorithms) timed on this box's host cores on the
     WHOLE workload -- full calc grid and all events, nothing scaled from a sample:
       * all physical cores (the reference's TARGET='parallel'): prob3 grid under OpenMP + every
@@ -456,7 +483,28 @@ def cpu_baseline(wl, data, matrices, device_llh, cores_logical=None, device_hist
         oracle_eval(wl, matrices)
         t1.append(time.perf_counter() - t0)
     t_one = float(np.median(t1))
+    # config C4's 50 parameter points through the LLH gate (round 6): device LLH + summed device map of every point (made
+    # by the caller, outside every timed region) against the all-core oracle on the same matrices
+    c4_gate = None
+    if c4:
+        from oracle.referee import llh_referee
+
+        rows = []
+        for mi, llh_dev, lam_dev in zip(c4["matrices"], c4["llh"], c4["lam"]):
+            r = oracle_eval_allcore(wl, events, threads=cores_used, matrices=mi, ln_energy=ln_e)
+            lam_o = np.asarray(r["hist"]).reshape(len(wl.events), -1).sum(axis=0)
+            rows.append(llh_referee(data, lam_dev, lam_o, float(llh_dev), float(orc.metric("llh", data, lam_o)[1])))
+        rel = [r["fp64_abs_diff"] / abs(r["oracle_evaluation"]["llh_fp64"]) for r in rows]
+        c4_gate = {"points": len(rows), "pure_1e-10_met": int(sum(r["pure_1e-10_relative_met"] for r in rows)),
+                   "referee_met": int(sum(r["met"] for r in rows)),
+                   "all_met": bool(all(r["pure_1e-10_relative_met"] or r["met"] for r in rows)),
+                   "max_fp64_rel_diff": float(max(rel)),
+                   "max_maps_rel_diff_extended": float(max(r["maps"]["rel_diff"] for r in rows)),
+                   "max_device_over_eps_rms": float(max(r["device_evaluation"]["over_eps_rms"] for r in rows)),
+                   "max_oracle_over_eps_rms": float(max(r["oracle_evaluation"]["over_eps_rms"] for r in rows)),
+                   "gate_in_eps_rms": 8.0}
     return {
+        "c4_llh_gate": c4_gate,
         "value": 1.0 / t_all,
         "unit": "evals/s",
         "cores": cores_used,
@@ -1654,8 +1702,16 @@ def main(argv=None, hooks=None):
             "legs": legs,
         }
         if not args.no_cpu_baseline and world == 1:
-            cb = cpu_baseline_subprocess(args, n_e, n_cz, st.data.cpu().numpy(), mats_last, llh, dev_hist_last)
+            c4 = None
+            if cuda and args.c4_gate_points > 0:
+                c4 = {"llh": [], "lam": [], "matrices": []}
+                for p, mats in param_points(wl, args.c4_gate_points):
+                    c4["matrices"].append(mats)
+                    c4["llh"].append(st.eval_host(p, "llh"))
+                    c4["lam"].append(np.asarray(st.maps()[0]).sum(axis=0))
+            cb = cpu_baseline_subprocess(args, n_e, n_cz, st.data.cpu().numpy(), mats_last, llh, dev_hist_last, c4)
             out["cpu_baseline"] = cb
+            out["c4_llh_gate"] = cb.pop("c4_llh_gate", None)
             # the bench's last headline point against the oracle on identical inputs (north star: <= 1e-10)
             out["oracle_llh"], out["llh_rel_diff"] = cb["oracle_llh"], cb["llh_rel_diff"]
             out["llh_gate"] = cb["llh_gate"]

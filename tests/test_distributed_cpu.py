@@ -427,13 +427,13 @@ def _point_groups_worker(rank, world, port, n_groups, out_dir):
     assert (st.rank, st.world_size) == (rank % (world // n_groups), world // n_groups)
     st.make_pseudo_data(wl.osc_params(), seed=0)     # (inside the group: sharded + reduced over its ranks only)
     out = {}
-    for k in (1, 2, 5, 7):
+    for k in (1, 2, 3, 5, 7):
         pts = bench.param_list(wl, k)
         sweeps = st.sweeps
         out["K%d" % k] = st.eval_many(pts, "llh")
         lo, hi = pg.block(k)
         assert st.sweeps - sweeps == (1 if hi - lo > 1 else 0)     # this group's block in ONE sweep of its events
-    np.save(os.path.join(out_dir, "r%d.npy" % rank), np.array([out["K%d" % k] for k in (1, 2, 5, 7)], dtype=object),
+    np.save(os.path.join(out_dir, "r%d.npy" % rank), np.array([out["K%d" % k] for k in (1, 2, 3, 5, 7)], dtype=object),
             allow_pickle=True)
     dist.destroy_process_group()
 
@@ -441,8 +441,9 @@ def _point_groups_worker(rank, world, port, n_groups, out_dir):
 @pytest.mark.parametrize("n_groups", [1, 2, 4])
 def test_point_groups_deal_points_and_keep_the_single_rank_bits(tmp_path, n_groups):
     """Hybrid point x event parallelism (`engine.PointGroups`): four gloo ranks as 1 x 4 (event sharding alone), 2 x 2 and
-    4 x 1 (the sample replicated, points dealt); `eval_many` of 1, 2, 5 and 7 points returns on EVERY rank the list one
-    rank computes on the whole sample, bit for bit (a point is evaluated entirely inside one group; integer limbs)."""
+    4 x 1 (the sample replicated, points dealt); `eval_many` of 1, 2, 3, 5 and 7 points -- fewer points than groups
+    included: 3 points on 4 groups leave one group idle and the blocks ragged (0, 1, 1, 1) -- returns on EVERY rank the
+    list one rank computes on the whole sample, bit for bit (a point is evaluated entirely inside one group; integer limbs)."""
     import sys
 
     mp.spawn(_point_groups_worker, args=(4, _free_port(), n_groups, str(tmp_path)), nprocs=4, join=True)
@@ -454,7 +455,10 @@ def test_point_groups_deal_points_and_keep_the_single_rank_bits(tmp_path, n_grou
     wl = synthetic.Workload(n_events=360, grid=(12, 8), out_binning="dragon", seed=0)
     single = _make_bench_state(wl)
     single.make_pseudo_data(wl.osc_params(), seed=0)
-    want = [[single.eval_host(p, "llh") for p in bench.param_list(wl, k)] for k in (1, 2, 5, 7)]
+    want = [[single.eval_host(p, "llh") for p in bench.param_list(wl, k)] for k in (1, 2, 3, 5, 7)]
+    from pisa_amd.engine import PointGroups as _PG
+
+    assert [_PG(0, 4, 4, make_group=lambda r: tuple(r)).block(3, g) for g in range(4)] == [(0, 0), (0, 1), (1, 2), (2, 3)]
     for rank in range(4):
         got = np.load(str(tmp_path / ("r%d.npy" % rank)), allow_pickle=True)
         for g, w_ in zip(got, want):
