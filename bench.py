@@ -197,6 +197,8 @@ def compact_line(out, detail_path=None):
         line["detail"] = os.path.relpath(detail_path, ROOT) if detail_path.startswith(ROOT) else detail_path
     line = _r(line)
     line["value"], line["ms_per_step"] = out["value"], out["ms_per_step"]          # every bit of the headline and the LLHs
+    for k in ("achieved", "frac", "avg_launch_ms"):                                 # (frac == achieved / peak to the last bit)
+        line["roofline"][k] = rf.get(k)
     for k in ("last_llh",):
         if k in line:
             line[k] = out[k]

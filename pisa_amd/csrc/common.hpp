@@ -53,6 +53,22 @@ inline const char *dev_env_str(const char *name) { return getenv(name); }
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Cross-kernel hand-over of the oscillation tables (development builds only, evaluator.hip: the round-6 experiment
+// "accumulate kernel resident and polling while the chain kernel runs", EXPERIMENTS R6-3).  The evaluator sets
+// `g_chain_signal` before the one-point chain launch -- one lane of each of its workgroups then adds 1 to counter
+// (linear workgroup index mod HANDOVER_SLOTS) behind an agent-scope release, the launch code leaves its workgroup count in
+// `n_wg` -- and `g_hist_wait` before the accumulate launch, whose workgroups poll all counters for epoch x (workgroups of
+// that slot) between their first column loads and their first table gathers.
+constexpr int HANDOVER_SLOTS = 64;
+struct HandOver {
+    unsigned long long *flags;   // HANDOVER_SLOTS counters, never reset
+    unsigned long long epoch;    // chain launches that have signalled so far (this one included)
+    int n_wg;                    // workgroups of one chain launch
+};
+#ifdef PISA_DEV_PROBES
+extern thread_local HandOver g_chain_signal, g_hist_wait;
+#endif
+
 // Regular (linear, equal-width) binning as the kernels see it
 // (fast_histogram rule / translation.py:417-456): bin = (int)((x - min) * norm)
 struct DevBinning {

@@ -17,9 +17,23 @@ struct pisa_hip_evaluator {
     pisa_hip_binning calc_grid, out_binning;
     pisa_hip_evaluator_desc d;
     int64_t n_bins, limb_count;
+#ifdef PISA_DEV_PROBES
+    // round-6 experiment (EXPERIMENTS R6-3): the accumulate kernel on a second stream, resident and polling while the chain
+    // kernel runs (PISA_HIP_EVAL_OVERLAP=1)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_before = nullptr, ev_after = nullptr;
+    pisa::HandOver hand = {nullptr, 0, 0};
+    bool overlap_ok = false;
+#endif
 };
 
 using namespace pisa;
+
+#ifdef PISA_DEV_PROBES
+namespace pisa {
+thread_local HandOver g_chain_signal = {nullptr, 0, 0}, g_hist_wait = {nullptr, 0, 0};
+}
+#endif
 
 PISA_API int pisa_hip_evaluator_create(const pisa_hip_evaluator_desc *desc, pisa_hip_evaluator **out) {
     if (!desc || !out || !desc->h_containers || desc->n_containers < 1 || desc->n_containers > 1024 ||
@@ -43,11 +57,39 @@ PISA_API int pisa_hip_evaluator_create(const pisa_hip_evaluator_desc *desc, pisa
     ev->d.h_out_binning = &ev->out_binning;
     ev->n_bins = n_bins;
     ev->limb_count = (int64_t)desc->n_containers * n_bins * 2 * PISA_HIP_ACC_LIMBS;
+#ifdef PISA_DEV_PROBES
+    if (PISA_DEV_INT("EVAL_OVERLAP", 0) && !desc->allreduce && desc->n_containers <= 16) {
+        // only where the accumulate launch leaves every CU room for the chain kernel's workgroups: one workgroup per CU
+        std::vector<int64_t> nev(desc->n_containers);
+        std::vector<int32_t> wgs(desc->n_containers);
+        for (int c = 0; c < desc->n_containers; c++) nev[c] = desc->h_containers[c].n_events;
+        int total = 0, cus = 0, dev = 0;
+        if (pisa_hip_hist_workgroups(nev.data(), desc->n_containers, wgs.data()) == PISA_HIP_OK &&
+            hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) {
+            for (int w : wgs) total += w;
+            if (total <= cus && hipStreamCreateWithFlags(&ev->side, hipStreamNonBlocking) == hipSuccess &&
+                hipEventCreateWithFlags(&ev->ev_before, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&ev->ev_after, hipEventDisableTiming) == hipSuccess &&
+                hipMalloc((void **)&ev->hand.flags, HANDOVER_SLOTS * sizeof(unsigned long long)) == hipSuccess &&
+                hipMemset(ev->hand.flags, 0, HANDOVER_SLOTS * sizeof(unsigned long long)) == hipSuccess)
+                ev->overlap_ok = true;
+        }
+    }
+#endif
     *out = ev;
     return PISA_HIP_OK;
 }
 
 PISA_API int pisa_hip_evaluator_destroy(pisa_hip_evaluator *ev) {
+#ifdef PISA_DEV_PROBES
+    if (ev && ev->side) {
+        (void)hipStreamSynchronize(ev->side);
+        (void)hipStreamDestroy(ev->side);
+        if (ev->ev_before) (void)hipEventDestroy(ev->ev_before);
+        if (ev->ev_after) (void)hipEventDestroy(ev->ev_after);
+        if (ev->hand.flags) (void)hipFree(ev->hand.flags);
+    }
+#endif
     delete ev;
     return PISA_HIP_OK;
 }
@@ -69,13 +111,70 @@ PISA_API int pisa_hip_evaluator_eval(pisa_hip_evaluator *ev, const pisa_hip_prob
     const int n_part = split ? PARTS : 1;
     if (wait_us > 0)
         for (int k = 0; k < n_part; k++) part[k] = NAN;   // "not yet": a partial sum is never NaN unless an input was negative
-    int rc = pisa_hip_prob3_grid_planned(h_params, d.plan, d.d_energy, d.n_e, d.e_major, nullptr, nullptr, d.d_pepmu,
+    int rc;
+#ifdef PISA_DEV_PROBES
+    if (ev->overlap_ok) {
+        // the accumulate launch goes to the side stream behind everything queued on `stream` so far, the oscillation
+        // launches to `stream`; the tail joins them again
+        hipStream_t s = as_stream(stream);
+        PISA_TRY_HIP(hipEventRecord(ev->ev_before, s));
+        PISA_TRY_HIP(hipStreamWaitEvent(ev->side, ev->ev_before, 0));
+        const int order = PISA_DEV_INT("EVAL_OVERLAP", 0);    // 1: oscillation launches first, 2: accumulate launch first
+        g_chain_signal = ev->hand;
+        g_chain_signal.epoch = ev->hand.epoch;
+        auto osc = [&]() {
+            int r = pisa_hip_prob3_grid_planned(h_params, d.plan, d.d_energy, d.n_e, d.e_major, nullptr, nullptr, d.d_pepmu, stream);
+            return r;
+        };
+        auto acc = [&]() {
+            return (limbs_zero ? pisa_hip_reweight_hist_acc : pisa_hip_reweight_hist)(
+                ev->cont.data(), (int32_t)ev->cont.size(), &ev->calc_grid, nullptr, nullptr, d.d_pepmu, &ev->out_binning,
+                d.d_limbs, d.d_status, (void *)ev->side);
+        };
+        if (order == 2 && ev->hand.n_wg > 0) {
+            // (the workgroup count of the chain launch is known from the previous evaluation)
+            g_hist_wait = {ev->hand.flags, ev->hand.epoch + 1, ev->hand.n_wg};
+            rc = acc();
+            g_hist_wait = {nullptr, 0, 0};
+            if (rc) { g_chain_signal = {nullptr, 0, 0}; return rc; }
+            rc = osc();
+            const bool signalled = g_chain_signal.epoch == ev->hand.epoch + 1;
+            ev->hand.epoch = g_chain_signal.epoch;
+            ev->hand.n_wg = g_chain_signal.n_wg;
+            g_chain_signal = {nullptr, 0, 0};
+            if (rc) return rc;
+            if (!signalled) { set_last_hip_error(hipErrorUnknown, "overlap: the chain launch did not signal"); return PISA_HIP_ERR_HIP; }
+        } else {
+            rc = osc();
+            const bool signalled = g_chain_signal.epoch == ev->hand.epoch + 1;
+            ev->hand.epoch = g_chain_signal.epoch;
+            ev->hand.n_wg = g_chain_signal.n_wg;
+            g_chain_signal = {nullptr, 0, 0};
+            if (rc) return rc;
+            if (signalled) g_hist_wait = {ev->hand.flags, ev->hand.epoch, ev->hand.n_wg};
+            else PISA_TRY_HIP(hipStreamWaitEvent(ev->side, ev->ev_before, 0));   // (not the packed one-point form: no hand-over)
+            if (!signalled) {
+                // no signal: order the accumulate launch behind the oscillation launches the ordinary way
+                PISA_TRY_HIP(hipEventRecord(ev->ev_before, s));
+                PISA_TRY_HIP(hipStreamWaitEvent(ev->side, ev->ev_before, 0));
+            }
+            rc = acc();
+            g_hist_wait = {nullptr, 0, 0};
+            if (rc) return rc;
+        }
+        PISA_TRY_HIP(hipEventRecord(ev->ev_after, ev->side));
+        PISA_TRY_HIP(hipStreamWaitEvent(s, ev->ev_after, 0));
+    } else
+#endif
+    {
+    rc = pisa_hip_prob3_grid_planned(h_params, d.plan, d.d_energy, d.n_e, d.e_major, nullptr, nullptr, d.d_pepmu,
                                          stream);
     if (rc) return rc;
     rc = (limbs_zero ? pisa_hip_reweight_hist_acc : pisa_hip_reweight_hist)(
         ev->cont.data(), (int32_t)ev->cont.size(), &ev->calc_grid, nullptr, nullptr, d.d_pepmu, &ev->out_binning,
         d.d_limbs, d.d_status, stream);
     if (rc) return rc;
+    }
     if (d.allreduce) {
         const int nrc = d.allreduce(d.d_limbs, d.d_limbs, (size_t)ev->limb_count, 4 /* ncclInt64 */, 0 /* ncclSum */,
                                     d.comm, stream);

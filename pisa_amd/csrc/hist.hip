@@ -208,6 +208,11 @@ struct HistArgs {
     int32_t opts;         // 1: the caller has no use for the second quantity (plain histogram without counts).
                           // Builds with -DPISA_DEV_PROBES only (PISA_HIP_HIST_DBG): 2 no deposits, 4 no flush
     int32_t window;       // > 0: LDS holds this many bins starting at the chunk's lowest bin
+    // development builds (common.hpp, HandOver): the tables this launch gathers from are being written by a kernel that
+    // runs BESIDE it; poll these counters before the first gather
+    const unsigned long long *wait_flags;
+    unsigned long long wait_epoch;
+    int32_t wait_wgs;
 };
 
 // MODE 0: generic histogram (weights or counts; quantities (w, 1))
@@ -340,6 +345,27 @@ hist_accumulate_kernel(const HistArgs a, unsigned long long *__restrict__ g_limb
         __syncthreads();
     }
     bool bad = false;
+#ifdef PISA_DEV_PROBES
+    if (a.wait_flags) {
+        // consumer side of the hand-over (guide, "valid forms"): relaxed agent-scope polls by the first wavefront (one counter
+        // per lane), ONE agent acquire, its wait, workgroup barrier, then plain loads of the tables
+        if (threadIdx.x < HANDOVER_SLOTS) {
+            const int k = (int)threadIdx.x;
+            const unsigned long long need = a.wait_epoch * (unsigned long long)(a.wait_wgs / HANDOVER_SLOTS + (k < a.wait_wgs % HANDOVER_SLOTS ? 1 : 0));
+            const unsigned long long t0 = wall_clock64();
+            while (__hip_atomic_load(a.wait_flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                if (wall_clock64() - t0 > 100000000ull) {   // ~1 s of the 100 MHz counter: the producer is not coming
+                    if (status) atomicOr(status, 8);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+    }
+#endif
     STAMP(2);
 
     auto accumulate = [&](int bin, double w, double w2) {
@@ -1344,6 +1370,16 @@ static int run_hist(const ContDev *conts, int n_cont, int mode, const DevBinning
         a.prob[1] = prob_nubar;
         a.pepmu = reinterpret_cast<const double2 *>(pepmu);
         a.opts = (PISA_DEV_INT("HIST_DBG", 0) & ~1) | (second_quantity ? 0 : 1);
+        a.wait_flags = nullptr;
+        a.wait_epoch = 0;
+        a.wait_wgs = 0;
+#ifdef PISA_DEV_PROBES
+        if (g_hist_wait.flags) {
+            a.wait_flags = g_hist_wait.flags;
+            a.wait_epoch = g_hist_wait.epoch;
+            a.wait_wgs = g_hist_wait.n_wg;
+        }
+#endif
         int64_t nev[MAX_CONT];
         for (int c = 0; c < nc; c++) {
             a.cont[c] = conts[base + c];

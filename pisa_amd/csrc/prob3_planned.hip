@@ -172,6 +172,12 @@ __device__ unsigned long long g_chain_stamps[8 * 4096];
 #else
 #define CSTAMP(k) do {} while (0)
 #endif
+template <int G, int AMP>
+__device__ __forceinline__ void chain_tail(const Prob3Consts &c, const Prob3Side &S, mat3 &L, mat3 &R, mat3 &T, bool have_l, bool have_r,
+                                           const double *s_part, int part_0, int lane, int Gr, int n_steps, int cnt, int mid,
+                                           int e_major, int ie, int n_e, int n_cz, int jcz, int side, int n_points, int pt,
+                                           double *__restrict__ out, double2 *__restrict__ pepmu);
+
 template <int G, int AMP, class CS = ConstsByValue>
 __global__ void __launch_bounds__(G ? 64 * G : 256)
 prob3_chain_kernel(const CS cs, int n_e, const int32_t *__restrict__ row_start,
@@ -180,7 +186,8 @@ prob3_chain_kernel(const CS cs, int n_e, const int32_t *__restrict__ row_start,
                     double *__restrict__ prob_nu, double *__restrict__ prob_nubar,
                     double2 *__restrict__ pepmu, const double *__restrict__ energy,
                     const int32_t *__restrict__ pair_u, const double *__restrict__ pair_dist,
-                    int n_unique, const int32_t *__restrict__ blk, int n_points, int n_tiles) {
+                    int n_unique, const int32_t *__restrict__ blk, int n_points, int n_tiles,
+                    unsigned long long *__restrict__ signal) {
     auto MM = [](const mat3 &A_, const mat3 &B_, mat3 &C_) { mat_mul_fma(A_, B_, C_); };
     CSTAMP(0);
     // Several points, packed launch (n_tiles > 0): a 1-D grid in which the (point, sign, energy tile)
@@ -306,7 +313,36 @@ prob3_chain_kernel(const CS cs, int n_e, const int32_t *__restrict__ row_start,
     if (g == 0 && live && cnt > 0) load_pair(k0 + mid, T);
     __syncthreads();
     CSTAMP(3);
+#ifdef PISA_DEV_PROBES
+    if (signal) {
+        // hand-over to a consumer kernel that is already resident (common.hpp, HandOver; guide: "valid forms", producer):
+        // every wave waits for its own stores, workgroup barrier, ONE lane releases at agent scope and adds to its counter
+        const unsigned lin = ((unsigned)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        if (g == 0 && live) chain_tail<G, AMP>(c, S, L, R, T, have_l, have_r, s_part, part_0, lane, Gr, n_steps, cnt, mid, e_major, ie, n_e, n_cz, jcz,
+                                               side, n_points, pt, out, pepmu);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(signal + (lin & (HANDOVER_SLOTS - 1)), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+#endif
     if (g != 0 || !live) return;
+    chain_tail<G, AMP>(c, S, L, R, T, have_l, have_r, s_part, part_0, lane, Gr, n_steps, cnt, mid, e_major, ie, n_e, n_cz, jcz, side, n_points, pt,
+                       out, pepmu);
+}
+
+// the leader's part of the chain kernel: joins the partial products of its partner waves, closes the chain with the
+// mixing matrices and stores the node's probabilities
+template <int G, int AMP>
+__device__ __forceinline__ void chain_tail(const Prob3Consts &c, const Prob3Side &S, mat3 &L, mat3 &R, mat3 &T, bool have_l, bool have_r,
+                                           const double *s_part, int part_0, int lane, int Gr, int n_steps, int cnt, int mid,
+                                           int e_major, int ie, int n_e, int n_cz, int jcz, int side, int n_points, int pt,
+                                           double *__restrict__ out, double2 *__restrict__ pepmu) {
+    auto MM = [](const mat3 &A_, const mat3 &B_, mat3 &C_) { mat_mul_fma(A_, B_, C_); };
     // wave 0: T_right = R_0 . R_1 .. (later groups further right), T_left = .. L_1 . L_0
     for (int h = 1; h < Gr; h++) {
         const int h0 = 1 + (int)(((int64_t)n_steps * h) / Gr);
@@ -634,8 +670,9 @@ static int launch_planned(const CS &cs, bool decay, int n_points, pisa_hip_grid_
 #define CHAIN(G, A) hipLaunchKernelGGL((prob3_chain_kernel<G, A, CS>), cgrid, cblock, 0, s, cs, (int)n_e, plan->d_row_start, \
                        plan->d_row_cnt, plan->d_row_pairs, plan->n_cz, plan->n_pairs, plan->d_terms,              \
                        (int)e_major, d_prob_nu, d_prob_nubar, (double2 *)d_pepmu, d_energy, plan->d_chain_u,      \
-                       plan->d_chain_dist, plan->n_unique, plan->d_blk, n_points, lin_tiles)
+                       plan->d_chain_dist, plan->n_unique, plan->d_blk, n_points, lin_tiles, sig)
     int lin_tiles = 0;
+    unsigned long long *sig = nullptr;
     if (plan->chain_packed && plan->n_blk > 0) {
         cblock = dim3(256);
         cgrid = dim3((unsigned)plan->n_blk, 2u * n_points, tiles);
@@ -643,6 +680,13 @@ static int launch_planned(const CS &cs, bool decay, int n_points, pisa_hip_grid_
             lin_tiles = (int)tiles;
             cgrid = dim3((unsigned)plan->n_blk * 2u * n_points * tiles, 1, 1);
         }
+#ifdef PISA_DEV_PROBES
+        if (n_points == 1 && g_chain_signal.flags) {   // (evaluator.hip: the accumulate kernel of this evaluation polls these counters)
+            sig = g_chain_signal.flags;
+            g_chain_signal.n_wg = (int)(cgrid.x * cgrid.y * cgrid.z);
+            g_chain_signal.epoch++;
+        }
+#endif
         if (decay) CHAIN(0, 2); else CHAIN(0, 1);
     } else if (decay) { if (groups == 1) CHAIN(1, 2); else if (groups == 4) CHAIN(4, 2); else CHAIN(2, 2); }
     else { if (groups == 1) CHAIN(1, 1); else if (groups == 4) CHAIN(4, 1); else CHAIN(2, 1); }
@@ -692,7 +736,7 @@ PISA_API int pisa_hip_prob3_grid_planned(const pisa_hip_prob3_params *h_params,
 #define CHAIN(G) hipLaunchKernelGGL((prob3_chain_kernel<G, 0, ConstsByValue>), cgrid, cblock, 0, s, cv, (int)n_e, plan->d_row_start, \
                        plan->d_row_cnt, plan->d_row_pairs, plan->n_cz, plan->n_pairs, plan->d_amp,          \
                        (int)e_major, d_prob_nu, d_prob_nubar, (double2 *)d_pepmu, d_energy, plan->d_pair_u,  \
-                       plan->d_pair_dist, plan->n_unique, plan->d_blk, 1, 0)
+                       plan->d_pair_dist, plan->n_unique, plan->d_blk, 1, 0, (unsigned long long *)nullptr)
     if (groups == 1) CHAIN(1); else if (groups == 4) CHAIN(4); else CHAIN(2);
 #undef CHAIN
     PISA_CHECK_LAUNCH("prob3_chain_kernel");
