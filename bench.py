@@ -198,7 +198,8 @@ def compact_line(out, detail_path=None):
     line = _r(line)
     line["value"], line["ms_per_step"] = out["value"], out["ms_per_step"]          # every bit of the headline and the LLHs
     for k in ("achieved", "frac", "avg_launch_ms"):                                 # (frac == achieved / peak to the last bit)
-        line["roofline"][k] = rf.get(k)
+        v = rf.get(k)
+        line["roofline"][k] = v if (isinstance(v, (int, float)) and v == v and abs(v) != float("inf")) else None
     for k in ("last_llh",):
         if k in line:
             line[k] = out[k]

@@ -19,7 +19,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
-#include <unordered_set>
+#include <unordered_map>
 #include <vector>
 
 #include "common.hpp"
@@ -95,7 +95,7 @@ class KdePool {
         limit_ = std::max(limit_, n_threads);
         pending_ += (int)tasks.size();
         for (size_t i = 0; i < tasks.size(); i++) {
-            open_.insert(tags[i]);
+            ++open_[tags[i]];      // (counted: the same job struct may be queued again while its first run is still open)
             queue_.emplace_back(std::move(tasks[i]), tags[i]);
         }
         cv_job_.notify_all();
@@ -148,7 +148,8 @@ class KdePool {
             lk.unlock();
             task(st);
             lk.lock();
-            open_.erase(tag);
+            auto it = open_.find(tag);
+            if (it != open_.end() && --it->second <= 0) open_.erase(it);
             --pending_;
             cv_done_.notify_all();   // (wait() looks at the count, wait_for() at the tags)
         }
@@ -157,7 +158,7 @@ class KdePool {
     std::condition_variable cv_job_, cv_done_;
     std::vector<std::thread> threads_;
     std::deque<std::pair<Task, const void *>> queue_;
-    std::unordered_set<const void *> open_;
+    std::unordered_map<const void *, int> open_;   // job -> its runs queued or running
     int pending_ = 0, limit_ = 0, n_started_ = 0, release_epoch_ = 0, released_ = 0;
     bool stop_ = false;
 };

@@ -617,197 +617,203 @@ class HotPathEngine:
             for side in sides:
                 side.wait_stream(torch.cuda.current_stream())     # (columns generated in HBM: their producer has run)
             pending = [pool.submit(upload_async, k) for k in range(min(AHEAD, len(containers)))]
-        for ci, (c, (lo, hi)) in enumerate(zip(containers, shards)):
-            sl = slice(lo, hi)
-            self._slices.append((lo, hi))
-            d = _lib.Container()
-            d.n_events = hi - lo
-            self.n_local += hi - lo
-            if prefetch:
-                (e_col, lnE, cz, flux_d, aeff_d, w0_d, cols), ev = pending.pop(0).result()
-                if ci + AHEAD < len(containers):
-                    pending.append(pool.submit(upload_async, ci + AHEAD))
-                main = torch.cuda.current_stream()
-                main.wait_event(ev)
-                for t in [e_col, lnE, cz, flux_d, aeff_d, w0_d] + cols:
-                    if t is not None:
-                        t.record_stream(main)      # allocated on the side stream, used (and freed) on this one
-            else:
-                e_col, lnE, cz, flux_d, aeff_d, w0_d, cols = upload(c, sl)
-            gx, gy = (lnE, cz) if grid.energy_first else (cz, lnE)
-            if self.node_flux:
-                fn = c["nu_flux_nodes"]
-                fn = (fn.to(self.dev, torch.float64) if torch.is_tensor(fn)
-                      else K.to_device(np.asarray(fn, dtype=np.float64))).reshape(grid.size, 2).contiguous().clone()
-                self._node_flux_t.append(fn)
-                d.d_pepmu = self._own_tables[len(self.cont)].data_ptr()
-                flux_d = torch.ones((hi - lo, 2), dtype=torch.float64, device=self.dev)
-            _phase("upload")
-            node = obin = perm = None
-            packed_forms = None          # (nb, aw, cst, nb16) from the native pack call, where it applies
-            static_w = wflux = None
-            part_starts, part_width = None, 0
-            if self.osc_events:
-                # event-by-event oscillation: every event is its own "node"; the shard
-                # is stored sorted by coszen so that the lanes of a wavefront cross the
-                # same number of Earth layers (3.4x faster than random order: no
-                # divergence in the layer loop)
-                e_true = e_col
-                obin = K.event_indices(cols, out_binning)
-                if sort_events and hi - lo > 1:
-                    perm = torch.argsort(cz, stable=True)
-                    gx, gy, flux_d, aeff_d, w0_d, e_true, cz = (
-                        t[perm].contiguous() for t in (gx, gy, flux_d, aeff_d, w0_d, e_true, cz))
-                    cols = [t[perm].contiguous() for t in cols]
-                    obin = obin[perm].contiguous()
-                node = torch.arange(hi - lo, dtype=torch.int32, device=self.dev)
-                own = torch.zeros((hi - lo, 2), dtype=torch.float64, device=self.dev)
-                es = _lib.EventSet()
-                es.n_events, es.d_energy, es.d_coszen = hi - lo, e_true.data_ptr(), cz.data_ptr()
-                es.d_probability, es.d_pepmu = None, own.data_ptr()
-                es.nubar, es.flav = int(c["nubar"]), int(c["flav"])
-                self._event_sets.append(es)
-                self._event_tables.append((e_true, cz, own))   # resident (coszen-sorted) order
-                self._keep += [e_true, cz, own]
-                d.d_pepmu = own.data_ptr()
-            elif indexed:
-                # coordinates never change between evaluations: digitise once
-                node = K.event_indices([gx, gy], grid.binning)
-                obin = K.event_indices(cols, out_binning)
-                _phase("digitise")
-                if sort_events and hi - lo > 1:
-                    # Event order inside a container is arbitrary and the exact
-                    # accumulation makes the result independent of it, so the
-                    # shard is stored sorted by calc-grid node: the (P_e, P_mu)
-                    # gathers of a wavefront then hit a handful of cache lines
-                    # instead of 64 different ones.
-                    if sort_events == "bin":
-                        perm = bin_window_order(obin, self.n_bins)
-                    elif sort_events == "part":
-                        # binning beyond the LDS accumulators: partitions = the kernel's LDS windows
-                        width = _lib.lib().pisa_hip_hist_window_bins(self.n_bins) if index16 else 0
-                        res = None
-                        if width > 0 and lds_order and block_order and not drop_unbinned:
-                            res = window_partition_order(obin, node, self.n_bins, width, n_wg=hist_wgs[len(self.cont)])
-                        if res is not None:
-                            perm, part_starts = res
-                            part_width = width
-                        else:
-                            perm = bin_partition_order(obin, node, self.n_bins, width=width if width > 0 else 672)
-                    else:
-                        perm = torch.argsort(node, stable=True)
-                blocked = (index16 and lds_order and block_order and perm is not None and sort_events == "node"
-                           and self.n_bins * 96 <= 65536)
-                if blocked:
-                    # (PISA_HIP_TORCH_ORDER=1: the torch formulation, the specification the native call is tested against)
-                    perm = deposit_block_order(obin, node, window=4096, banks=32) \
-                        if _os.environ.get("PISA_HIP_TORCH_ORDER") == "1" else deposit_block_order_native(obin, node, grid.size)
-                elif part_starts is not None:
-                    pass                      # (bank order applied inside the partitions)
-                elif lds_order and perm is not None and (sort_events == "part" or (
-                        sort_events != "bin" and self.n_bins * 96 <= 65536)):
-                    perm = perm[lds_bank_order(obin[perm], window=4096, banks=32,
-                                               per=4 if index16 else 2)]
-                _phase("order")
-                if drop_unbinned:
-                    # an event outside the output binning (or outside the calc grid: P = 0)
-                    # adds nothing to any map, whatever the parameters: the coordinates are
-                    # static, so such events need not be resident at all
-                    keep = (obin >= 0) & (node >= 0)
-                    perm = torch.nonzero(keep).reshape(-1) if perm is None else perm[keep[perm]]
-                # the columns in resident order: one native launch for the 16-bit index layout (round 5: the ~25 tensor
-                # operations per container below were 6 ms of a 24 ms set-up at 1e7 events, bound by their dispatch on the
-                # host; PISA_HIP_TORCH_ORDER=1 keeps them: they are the specification the call is tested against)
-                native_pack = (perm is not None and packed and compact and index16 and len(cols) <= 3
-                               and perm.dtype == torch.int64 and node.dtype == torch.int32 and obin.dtype == torch.int32
-                               and flux_d.dim() == 2 and flux_d.shape[1] == 2
-                               and all(t.dtype == torch.float64 for t in [gx, gy, flux_d, aeff_d, w0_d] + cols)
-                               and _os.environ.get("PISA_HIP_TORCH_ORDER") != "1")
-                if native_pack:
-                    (gx, gy, flux_d, aeff_d, w0_d, cols, node, obin, *packed_forms) = pack_resident_columns(
-                        perm, gx, gy, flux_d, aeff_d, w0_d, cols, node, obin)
-                    self.n_local += int(perm.numel()) - d.n_events
-                    d.n_events = int(perm.numel())
-                elif perm is not None:
-                    gx, gy, flux_d, aeff_d, w0_d = (t[perm].contiguous() for t in
-                                                   (gx, gy, flux_d, aeff_d, w0_d))
-                    cols = [t[perm].contiguous() for t in cols]
-                    node, obin = node[perm].contiguous(), obin[perm].contiguous()
-                    self.n_local += int(perm.numel()) - d.n_events
-                    d.n_events = int(perm.numel())
-            if not indexed and not self.osc_events and sort_events and hi - lo > 1 and not self.node_flux:
-                # coordinate form (both digitisations in the kernel, 72 B/event): the resident ORDER is still
-                # free, so the events are stored sorted by the calc-grid node they will fall on -- digitised here once, for
-                # the order only, the indices are not kept -- and the kernel's 16-byte table gathers of a wavefront stay
-                # inside a few cache lines (random order: 11 % more HBM traffic than the columns, round-4 PMC pass)
-                perm = torch.argsort(K.event_indices([gx, gy], grid.binning), stable=True)
-                gx, gy, flux_d, aeff_d, w0_d = (t[perm].contiguous() for t in (gx, gy, flux_d, aeff_d, w0_d))
-                cols = [t[perm].contiguous() for t in cols]
-                _phase("order")
-            self._keep += [gx, gy, flux_d, aeff_d, w0_d] + cols
-            self._perm.append(perm)
-            self._flux.append(flux_d)
-            d.d_grid_x, d.d_grid_y = gx.data_ptr(), gy.data_ptr()
-            d.d_nu_flux = flux_d.data_ptr()
-            d.d_weighted_aeff, d.d_initial_weights = aeff_d.data_ptr(), w0_d.data_ptr()
-            for k, col in enumerate(cols):
-                d.d_sample[k] = col.data_ptr()
-            if indexed:
-                self._keep += [node, obin]
-                d.d_node, d.d_bin = node.data_ptr(), obin.data_ptr()
-                if packed:
-                    # interleaved columns: every load of the fused kernel is 16 bytes
-                    if packed_forms is not None:
-                        nb, aw = packed_forms[0], packed_forms[1]
-                    else:
-                        nb = torch.stack([node, obin], dim=1).contiguous()
-                        aw = torch.stack([aeff_d, w0_d], dim=1).contiguous()
-                    self._keep += [nb, aw]
-                    d.d_node_bin, d.d_aeff_w0 = nb.data_ptr(), aw.data_ptr()
-                    if compact:
-                        # the factors of the weight that no oscillation parameter touches,
-                        # multiplied once: (w0*aeff) * (f_e, f_mu)
-                        cst = packed_forms[2] if packed_forms is not None else (w0_d * aeff_d).contiguous()
-                        self._keep.append(cst)
-                        static_w = cst
-                        if index16:
-                            # 20 B/event: both indices in 16 bits, and the flux pairs of a quad of
-                            # events stored lane-contiguously ([quad / 64][4][quad % 64]) so that
-                            # every load of the kernel is 16 contiguous bytes per lane; columns
-                            # padded to whole blocks of 64 quads with events outside the binning
-                            n_ev = int(node.numel())
-                            n_pad = -(-n_ev // 256) * 256
-                            if packed_forms is not None:
-                                nb16 = packed_forms[3]
+        # (an exception while a container is loaded must not leave the upload threads and their side streams behind)
+        try:
+            for ci, (c, (lo, hi)) in enumerate(zip(containers, shards)):
+                sl = slice(lo, hi)
+                self._slices.append((lo, hi))
+                d = _lib.Container()
+                d.n_events = hi - lo
+                self.n_local += hi - lo
+                if prefetch:
+                    (e_col, lnE, cz, flux_d, aeff_d, w0_d, cols), ev = pending.pop(0).result()
+                    if ci + AHEAD < len(containers):
+                        pending.append(pool.submit(upload_async, ci + AHEAD))
+                    main = torch.cuda.current_stream()
+                    main.wait_event(ev)
+                    for t in [e_col, lnE, cz, flux_d, aeff_d, w0_d] + cols:
+                        if t is not None:
+                            t.record_stream(main)      # allocated on the side stream, used (and freed) on this one
+                else:
+                    e_col, lnE, cz, flux_d, aeff_d, w0_d, cols = upload(c, sl)
+                gx, gy = (lnE, cz) if grid.energy_first else (cz, lnE)
+                if self.node_flux:
+                    fn = c["nu_flux_nodes"]
+                    fn = (fn.to(self.dev, torch.float64) if torch.is_tensor(fn)
+                          else K.to_device(np.asarray(fn, dtype=np.float64))).reshape(grid.size, 2).contiguous().clone()
+                    self._node_flux_t.append(fn)
+                    d.d_pepmu = self._own_tables[len(self.cont)].data_ptr()
+                    flux_d = torch.ones((hi - lo, 2), dtype=torch.float64, device=self.dev)
+                _phase("upload")
+                node = obin = perm = None
+                packed_forms = None          # (nb, aw, cst, nb16) from the native pack call, where it applies
+                static_w = wflux = None
+                part_starts, part_width = None, 0
+                if self.osc_events:
+                    # event-by-event oscillation: every event is its own "node"; the shard
+                    # is stored sorted by coszen so that the lanes of a wavefront cross the
+                    # same number of Earth layers (3.4x faster than random order: no
+                    # divergence in the layer loop)
+                    e_true = e_col
+                    obin = K.event_indices(cols, out_binning)
+                    if sort_events and hi - lo > 1:
+                        perm = torch.argsort(cz, stable=True)
+                        gx, gy, flux_d, aeff_d, w0_d, e_true, cz = (
+                            t[perm].contiguous() for t in (gx, gy, flux_d, aeff_d, w0_d, e_true, cz))
+                        cols = [t[perm].contiguous() for t in cols]
+                        obin = obin[perm].contiguous()
+                    node = torch.arange(hi - lo, dtype=torch.int32, device=self.dev)
+                    own = torch.zeros((hi - lo, 2), dtype=torch.float64, device=self.dev)
+                    es = _lib.EventSet()
+                    es.n_events, es.d_energy, es.d_coszen = hi - lo, e_true.data_ptr(), cz.data_ptr()
+                    es.d_probability, es.d_pepmu = None, own.data_ptr()
+                    es.nubar, es.flav = int(c["nubar"]), int(c["flav"])
+                    self._event_sets.append(es)
+                    self._event_tables.append((e_true, cz, own))   # resident (coszen-sorted) order
+                    self._keep += [e_true, cz, own]
+                    d.d_pepmu = own.data_ptr()
+                elif indexed:
+                    # coordinates never change between evaluations: digitise once
+                    node = K.event_indices([gx, gy], grid.binning)
+                    obin = K.event_indices(cols, out_binning)
+                    _phase("digitise")
+                    if sort_events and hi - lo > 1:
+                        # Event order inside a container is arbitrary and the exact
+                        # accumulation makes the result independent of it, so the
+                        # shard is stored sorted by calc-grid node: the (P_e, P_mu)
+                        # gathers of a wavefront then hit a handful of cache lines
+                        # instead of 64 different ones.
+                        if sort_events == "bin":
+                            perm = bin_window_order(obin, self.n_bins)
+                        elif sort_events == "part":
+                            # binning beyond the LDS accumulators: partitions = the kernel's LDS windows
+                            width = _lib.lib().pisa_hip_hist_window_bins(self.n_bins) if index16 else 0
+                            res = None
+                            if width > 0 and lds_order and block_order and not drop_unbinned:
+                                res = window_partition_order(obin, node, self.n_bins, width, n_wg=hist_wgs[len(self.cont)])
+                            if res is not None:
+                                perm, part_starts = res
+                                part_width = width
                             else:
-                                v = torch.full((n_pad,), 0xFFFFFFFF, dtype=torch.int64, device=self.dev)
-                                v[:n_ev] = (torch.where(node < 0, 0xFFFF, node.long())
-                                            | (torch.where(obin < 0, 0xFFFF, obin.long()) << 16))
-                                nb16 = torch.where(v >= 2 ** 31, v - 2 ** 32, v).to(torch.int32).contiguous()
-                            wq = torch.zeros((n_pad // 256, 4, 64, 2), dtype=torch.float64, device=self.dev)
-                            self._keep += [nb16, wq]
-                            d.d_node_bin16, d.d_weighted_flux_q = nb16.data_ptr(), wq.data_ptr()
-                            if part_starts is not None:
-                                ps = torch.tensor(part_starts, dtype=torch.int32, device=self.dev)
-                                assert int(ps[-1]) * 256 == n_pad
-                                self._keep.append(ps)
-                                d.d_part_start, d.n_part, d.part_width = ps.data_ptr(), len(part_starts) - 1, part_width
-                            wflux = wq
-                            self._fill_wflux(wq, cst, flux_d)
+                                perm = bin_partition_order(obin, node, self.n_bins, width=width if width > 0 else 672)
                         else:
-                            # 24 B/event with node_bin
-                            wf = (cst[:, None] * flux_d).contiguous()
-                            self._keep.append(wf)
-                            d.d_weighted_flux = wf.data_ptr()
-                            wflux = wf
-            _phase("pack")
-            d.flav, d.nubar, d.scale = int(c["flav"]), int(c["nubar"]), float(c["scale"])
-            self._static_w.append(static_w)
-            self._wflux.append(wflux)
-            self.cont.append(d)
-        self._cont_arr = (_lib.Container * len(self.cont))(*self.cont)
-        # Earth layers for the coszen nodes (prob3.setup_function, prob3.py:398-409)
-        self.earth = earth
+                            perm = torch.argsort(node, stable=True)
+                    blocked = (index16 and lds_order and block_order and perm is not None and sort_events == "node"
+                               and self.n_bins * 96 <= 65536)
+                    if blocked:
+                        # (PISA_HIP_TORCH_ORDER=1: the torch formulation, the specification the native call is tested against)
+                        perm = deposit_block_order(obin, node, window=4096, banks=32) \
+                            if _os.environ.get("PISA_HIP_TORCH_ORDER") == "1" else deposit_block_order_native(obin, node, grid.size)
+                    elif part_starts is not None:
+                        pass                      # (bank order applied inside the partitions)
+                    elif lds_order and perm is not None and (sort_events == "part" or (
+                            sort_events != "bin" and self.n_bins * 96 <= 65536)):
+                        perm = perm[lds_bank_order(obin[perm], window=4096, banks=32,
+                                                   per=4 if index16 else 2)]
+                    _phase("order")
+                    if drop_unbinned:
+                        # an event outside the output binning (or outside the calc grid: P = 0)
+                        # adds nothing to any map, whatever the parameters: the coordinates are
+                        # static, so such events need not be resident at all
+                        keep = (obin >= 0) & (node >= 0)
+                        perm = torch.nonzero(keep).reshape(-1) if perm is None else perm[keep[perm]]
+                    # the columns in resident order: one native launch for the 16-bit index layout (round 5: the ~25 tensor
+                    # operations per container below were 6 ms of a 24 ms set-up at 1e7 events, bound by their dispatch on the
+                    # host; PISA_HIP_TORCH_ORDER=1 keeps them: they are the specification the call is tested against)
+                    native_pack = (perm is not None and packed and compact and index16 and len(cols) <= 3
+                                   and perm.dtype == torch.int64 and node.dtype == torch.int32 and obin.dtype == torch.int32
+                                   and flux_d.dim() == 2 and flux_d.shape[1] == 2
+                                   and all(t.dtype == torch.float64 for t in [gx, gy, flux_d, aeff_d, w0_d] + cols)
+                                   and _os.environ.get("PISA_HIP_TORCH_ORDER") != "1")
+                    if native_pack:
+                        (gx, gy, flux_d, aeff_d, w0_d, cols, node, obin, *packed_forms) = pack_resident_columns(
+                            perm, gx, gy, flux_d, aeff_d, w0_d, cols, node, obin)
+                        self.n_local += int(perm.numel()) - d.n_events
+                        d.n_events = int(perm.numel())
+                    elif perm is not None:
+                        gx, gy, flux_d, aeff_d, w0_d = (t[perm].contiguous() for t in
+                                                       (gx, gy, flux_d, aeff_d, w0_d))
+                        cols = [t[perm].contiguous() for t in cols]
+                        node, obin = node[perm].contiguous(), obin[perm].contiguous()
+                        self.n_local += int(perm.numel()) - d.n_events
+                        d.n_events = int(perm.numel())
+                if not indexed and not self.osc_events and sort_events and hi - lo > 1 and not self.node_flux:
+                    # coordinate form (both digitisations in the kernel, 72 B/event): the resident ORDER is still
+                    # free, so the events are stored sorted by the calc-grid node they will fall on -- digitised here once, for
+                    # the order only, the indices are not kept -- and the kernel's 16-byte table gathers of a wavefront stay
+                    # inside a few cache lines (random order: 11 % more HBM traffic than the columns, round-4 PMC pass)
+                    perm = torch.argsort(K.event_indices([gx, gy], grid.binning), stable=True)
+                    gx, gy, flux_d, aeff_d, w0_d = (t[perm].contiguous() for t in (gx, gy, flux_d, aeff_d, w0_d))
+                    cols = [t[perm].contiguous() for t in cols]
+                    _phase("order")
+                self._keep += [gx, gy, flux_d, aeff_d, w0_d] + cols
+                self._perm.append(perm)
+                self._flux.append(flux_d)
+                d.d_grid_x, d.d_grid_y = gx.data_ptr(), gy.data_ptr()
+                d.d_nu_flux = flux_d.data_ptr()
+                d.d_weighted_aeff, d.d_initial_weights = aeff_d.data_ptr(), w0_d.data_ptr()
+                for k, col in enumerate(cols):
+                    d.d_sample[k] = col.data_ptr()
+                if indexed:
+                    self._keep += [node, obin]
+                    d.d_node, d.d_bin = node.data_ptr(), obin.data_ptr()
+                    if packed:
+                        # interleaved columns: every load of the fused kernel is 16 bytes
+                        if packed_forms is not None:
+                            nb, aw = packed_forms[0], packed_forms[1]
+                        else:
+                            nb = torch.stack([node, obin], dim=1).contiguous()
+                            aw = torch.stack([aeff_d, w0_d], dim=1).contiguous()
+                        self._keep += [nb, aw]
+                        d.d_node_bin, d.d_aeff_w0 = nb.data_ptr(), aw.data_ptr()
+                        if compact:
+                            # the factors of the weight that no oscillation parameter touches,
+                            # multiplied once: (w0*aeff) * (f_e, f_mu)
+                            cst = packed_forms[2] if packed_forms is not None else (w0_d * aeff_d).contiguous()
+                            self._keep.append(cst)
+                            static_w = cst
+                            if index16:
+                                # 20 B/event: both indices in 16 bits, and the flux pairs of a quad of
+                                # events stored lane-contiguously ([quad / 64][4][quad % 64]) so that
+                                # every load of the kernel is 16 contiguous bytes per lane; columns
+                                # padded to whole blocks of 64 quads with events outside the binning
+                                n_ev = int(node.numel())
+                                n_pad = -(-n_ev // 256) * 256
+                                if packed_forms is not None:
+                                    nb16 = packed_forms[3]
+                                else:
+                                    v = torch.full((n_pad,), 0xFFFFFFFF, dtype=torch.int64, device=self.dev)
+                                    v[:n_ev] = (torch.where(node < 0, 0xFFFF, node.long())
+                                                | (torch.where(obin < 0, 0xFFFF, obin.long()) << 16))
+                                    nb16 = torch.where(v >= 2 ** 31, v - 2 ** 32, v).to(torch.int32).contiguous()
+                                wq = torch.zeros((n_pad // 256, 4, 64, 2), dtype=torch.float64, device=self.dev)
+                                self._keep += [nb16, wq]
+                                d.d_node_bin16, d.d_weighted_flux_q = nb16.data_ptr(), wq.data_ptr()
+                                if part_starts is not None:
+                                    ps = torch.tensor(part_starts, dtype=torch.int32, device=self.dev)
+                                    assert int(ps[-1]) * 256 == n_pad
+                                    self._keep.append(ps)
+                                    d.d_part_start, d.n_part, d.part_width = ps.data_ptr(), len(part_starts) - 1, part_width
+                                wflux = wq
+                                self._fill_wflux(wq, cst, flux_d)
+                            else:
+                                # 24 B/event with node_bin
+                                wf = (cst[:, None] * flux_d).contiguous()
+                                self._keep.append(wf)
+                                d.d_weighted_flux = wf.data_ptr()
+                                wflux = wf
+                _phase("pack")
+                d.flav, d.nubar, d.scale = int(c["flav"]), int(c["nubar"]), float(c["scale"])
+                self._static_w.append(static_w)
+                self._wflux.append(wflux)
+                self.cont.append(d)
+            self._cont_arr = (_lib.Container * len(self.cont))(*self.cont)
+            self._cont_gen = 0      # bumped by every writer of `_cont_arr` (set_scale, containers_changed): part of the evaluator's key
+            # Earth layers for the coszen nodes (prob3.setup_function, prob3.py:398-409)
+            self.earth = earth
+        finally:
+            if prefetch:
+                pool.shutdown(wait=True, cancel_futures=True)
         self.prob_nu = self.prob_nubar = self.pepmu = self.plan = None
         if not external_tables:
             self.energy_d = K.to_device(grid.energy)
@@ -816,8 +822,6 @@ class HotPathEngine:
             self.prob_nubar = torch.empty((grid.size, 3, 3), dtype=torch.float64, device=self.dev)
             self.pepmu = torch.empty((2, 3, grid.size, 2), dtype=torch.float64, device=self.dev)
             self.plan = K.GridPlan(self.dens_d, self.dist_d) if planned else None
-        if prefetch:
-            pool.shutdown(wait=True)
         self._event_arr = (_lib.EventSet * len(self._event_sets))(*self._event_sets) \
             if self._event_sets else None
         self.ws = K.HistWorkspace(len(self.cont), self.n_bins, self.dev)
@@ -998,8 +1002,14 @@ class HotPathEngine:
         self._cont_arr[i].scale = float(scale)
         ev = self._evaluator
         if ev is not None:
+            # the evaluator's snapshot moves with the array: same generation on both sides, no new evaluator
             _lib.check(_lib.lib().pisa_hip_evaluator_set_scale(ev["handle"], i, float(scale)))
-            ev["key"] = ev["key"][:-1] + (hash(bytes(self._cont_arr)),)     # the snapshot moved with the array
+
+    def containers_changed(self):
+        """to be called by whoever writes a field of `_cont_arr` other than through `set_scale` (a pointer swapped for
+        another column, an event count): the next evaluation makes a new evaluator from the array as it then is.  (Round 5
+        hashed the array's bytes on every evaluation instead -- a copy and a hash of 2.4 KB on a 67 us step.)"""
+        self._cont_gen += 1
 
     # -- one evaluation per C-ABI call (`pisa_hip_evaluator_*`) --------------
     def _evaluator_for(self):
@@ -1020,13 +1030,13 @@ class HotPathEngine:
                 return None
             fn = C.cast(self._rccl.lib.ncclAllReduce, C.c_void_p)
             comm = self._rccl.comm
-        # every buffer the evaluator was made from, and the container array it SNAPSHOTS (pisa_hip_evaluator_create copies
-        # it; `set_scale` keeps the copy and this signature in step): a change of the array that bypasses `set_scale`
-        # makes a new evaluator instead of running on stale pointers
+        # every buffer the evaluator was made from, and the generation of the container array it SNAPSHOTS
+        # (pisa_hip_evaluator_create copies it; `set_scale` updates array and copy together, any other writer calls
+        # `containers_changed`): a changed array makes a new evaluator instead of running on stale pointers
         key = (self.pepmu.data_ptr(), self.ws.limbs.data_ptr(), self.ws.hist.data_ptr(), self.ws.sumw2.data_ptr(),
                self.ws.status.data_ptr(), self.metric_status.data_ptr(), self.metric_host.data_ptr(),
                self.plan.handle.value if hasattr(self.plan.handle, "value") else self.plan.handle, self.energy_d.data_ptr(),
-               None if comm is None else comm.value, self.world_size, hash(bytes(self._cont_arr)))
+               None if comm is None else comm.value, self.world_size, self._cont_gen)
         ev = self._evaluator
         if ev is not None and ev["key"] == key:
             return ev

@@ -16,6 +16,10 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; rm -rf $OUT; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.stderr
 tail -c 400 $OUT/bench.json
+cp bench_detail.json $OUT/bench_detail.json
+# every profiled run below: set-up uploads on the calling thread (counter-collecting profilers serialise dispatches and have
+# been seen to stall with several submitting host threads) -- set in this script's environment, never as a hop after `--`
+export PISA_HIP_UPLOAD_THREADS=0
 LEAN="--no-cpu-baseline --no-drop-probe --no-batch-probe --legs none"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py $LEAN > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
 cp $OUT/stats/bench_kernel_stats.csv $OUT/kernel_stats.csv
