@@ -1022,6 +1022,17 @@ class HotPathEngine:
 
         if self.node_flux or not self.spin_wait:
             return None
+        # fast path (this sits between the LLH read-back and the first launch of the next point): the very tensor OBJECTS
+        # the evaluator was made from are still the engine's (the evaluator keeps references, so an identity cannot be
+        # recycled) and nobody has written the container array -- a dozen `data_ptr()` calls (~0.3 us each) otherwise
+        ev = self._evaluator
+        if ev is not None:
+            o = ev["objects"]
+            ws = self.ws
+            if (o[0] is self.pepmu and o[1] is ws.limbs and o[2] is ws.hist and o[3] is ws.sumw2 and o[4] is ws.status
+                    and o[5] is self.metric_status and o[6] is self.metric_host and o[7] is self.plan and o[8] is self.energy_d
+                    and o[9] is self._rccl and ev["gen"] == self._cont_gen and ev["world"] == self.world_size):
+                return ev
         fn = comm = None
         if self.world_size > 1:
             if self._rccl is None:
@@ -1057,7 +1068,9 @@ class HotPathEngine:
         h = C.c_void_p()
         _lib.check(_lib.lib().pisa_hip_evaluator_create(C.byref(d), C.byref(h)))
         value = C.c_double()
-        ev = self._evaluator = dict(key=key, handle=h, value=value, value_ref=C.byref(value),
+        ev = self._evaluator = dict(key=key, handle=h, value=value, value_ref=C.byref(value), gen=self._cont_gen, world=self.world_size,
+                                    objects=(self.pepmu, self.ws.limbs, self.ws.hist, self.ws.sumw2, self.ws.status, self.metric_status,
+                                             self.metric_host, self.plan, self.energy_d, self._rccl),
                                     call=_lib.lib().pisa_hip_evaluator_eval, keep=(fn, comm))
         return ev
 

@@ -8,11 +8,12 @@ from pisa_amd.core.pipeline import Pipeline
 from pisa_amd.core.units import ureg
 
 n = float(sys.argv[1]) if len(sys.argv) > 1 else 1e7
+tol = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-12     # (the bench leg's explicit cut-off; "0" / "1e-14": others)
 cfg = parse_pipeline_config("settings/pipeline/example_hip.cfg")
 out = OrderedDict()
 for k, v in cfg.items():
     if k == ("utils", "hist"):
-        out[("utils", "kde")] = OrderedDict(calc_mode="events", apply_mode=v["apply_mode"])
+        out[("utils", "kde")] = OrderedDict(calc_mode="events", apply_mode=v["apply_mode"], tol=tol)
     else:
         out[k] = v
 out["pipeline"]["output_key"] = "weights"
@@ -29,5 +30,8 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 4):
     st = pipe["kde"].stats
     times.append(dt)
     print(json.dumps(dict(it=it, s=dt, total=float(sum(m.hist.sum() for m in maps)), **st)), flush=True)
-print(json.dumps(dict(median_ms=round(1e3 * float(np.median(times[1:])), 2), min_ms=round(1e3 * min(times[1:]), 2), n=len(times) - 1)))
+import hashlib
+digest = hashlib.sha256(b"".join(np.ascontiguousarray(np.asarray(m.hist, dtype=np.float64)).tobytes() for m in maps)).hexdigest()[:16]
+print(json.dumps(dict(median_ms=round(1e3 * float(np.median(times[1:])), 2), min_ms=round(1e3 * min(times[1:]), 2), n=len(times) - 1, tol=tol,
+                      maps_sha_last=digest)))
 pipe.report_profile()
