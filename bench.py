@@ -95,6 +95,9 @@ def parse(argv=None):
     ap.add_argument("--c4-gate-points", type=int, default=50,
                     help="config C4's seeded (theta23, dm31) points put through the LLH gate against the oracle after the timed "
                          "regions (with the CPU baseline; 0: none)")
+    ap.add_argument("--no-warm-up", action="store_true",
+                    help="do not call pisa_amd.warm_up() beside the generation of the sample: `setup.first_in_process` then includes "
+                         "the runtime's first-use costs (code objects, staging buffers)")
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--min-timed-s", type=float, default=0.2,
                     help="repeat the block of --steps timed steps until this much timed work has been seen "
@@ -1421,12 +1424,22 @@ def main(argv=None, hooks=None):
         return total / blocks, llh
 
     # ---- headline: ONE sample of --events events, sharded over the ranks (strong scaling)
+    # (the runtime's first-use costs -- code objects, staging buffers -- are paid on a background thread while the host
+    #  generates the sample, as a user's program would call pisa_amd.warm_up() beside reading its event files)
+    warm_ms = None
+    if cuda and not args.no_warm_up:
+        import pisa_amd
+
+        pisa_amd.warm_up(background=True)
     wl = synthetic.Workload(n_events=int(args.events), grid=(n_e, n_cz), out_binning=args.binning, seed=0)
+    if cuda and not args.no_warm_up:
+        warm_ms = pisa_amd.warm_up_wait()
     t_setup0 = time.perf_counter()
     st = make_state(wl, rank=rank, world_size=world, indexed=not args.coordinate_form,
                     sort_events=order, compact=compact, index16=index16, **({"time_setup": True} if cuda else {}))
     dev_sync()
-    setup_first = {"wall_ms": 1e3 * (time.perf_counter() - t_setup0), "phases_ms": getattr(st, "setup_ms", None)}
+    setup_first = {"wall_ms": 1e3 * (time.perf_counter() - t_setup0), "phases_ms": getattr(st, "setup_ms", None),
+                   "after_warm_up": warm_ms is not None, "warm_up_ms": warm_ms}
     if args.force_dist and world == 1:
         st.world_size = 2   # one rank, but through the collective
     nominal = wl.osc_params()

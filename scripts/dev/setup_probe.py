@@ -5,7 +5,12 @@ import torch
 from pisa_amd import synthetic
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
 binning = sys.argv[2] if len(sys.argv) > 2 else "dragon"
+if os.environ.get("SETUP_PROBE_WARM_UP"):      # round 6: the runtime's first-use costs paid beside the generation of the sample
+    import pisa_amd
+    pisa_amd.warm_up(background=True)
 wl = synthetic.Workload(n_events=n, grid=(200, 100), out_binning=binning, seed=0)
+if os.environ.get("SETUP_PROBE_WARM_UP"):
+    print(json.dumps(dict(warm_up_ms=round(pisa_amd.warm_up_wait(), 1))), flush=True)
 for rep in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     st = synthetic.DeviceState(wl, compact=True, time_setup=True)
