@@ -23,9 +23,9 @@ def warm_up(background=False):
     """Pay the runtime's first-use costs now instead of inside the first `Pipeline(cfg)` / `HotPathEngine`: the code
     objects of this library and of the torch kernels the set-up uses are loaded at their first launch, the copy engines'
     staging buffers are made at the first large host-to-device copy -- 0.2-0.5 s on a fresh process against 24 ms for a
-    second engine of 1e7 events (bench.py `setup`).  Runs one miniature engine (12 x 512 synthetic events: upload,
-    digitisation, resident order, packing, oscillation plan, one evaluation -- the same calls at a size that costs
-    nothing) and one 32 MB pageable upload.  `background=True`: on a daemon thread, so that it runs beside the caller's
+    second engine of 1e7 events (bench.py `setup`).  Runs one small engine (12 x 100 000 synthetic events: upload,
+    digitisation, resident order, packing, oscillation plan, one evaluation -- the same calls, large enough for the
+    sorts to take the kernels they take at full size) and one 32 MB pageable upload.  `background=True`: on a daemon thread, so that it runs beside the caller's
     own start-up work (reading event files, parsing the cfg); `warm_up_wait()` joins it.  Idempotent; needs a HIP device
     (there is no CPU fallback in this package: without a device it raises like everything else)."""
     import threading
@@ -43,7 +43,7 @@ def warm_up(background=False):
             from pisa_amd import synthetic
 
             dev = torch.device("cuda", torch.cuda.current_device())
-            wl = synthetic.Workload(n_events=12 * 512, grid=(8, 8), out_binning="dragon", seed=1)
+            wl = synthetic.Workload(n_events=12 * 100_000, grid=(8, 8), out_binning="dragon", seed=1)
             st = synthetic.DeviceState(wl, compact=True)
             st.make_pseudo_data(wl.osc_params(), seed=0)
             st.eval_host(wl.osc_params(theta23_deg=44.0), "llh")

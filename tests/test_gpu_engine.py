@@ -845,3 +845,22 @@ def test_native_pack_is_the_tensor_formulation(n, n_cols):
     v = torch.full((n_pad,), 0xFFFFFFFF, dtype=torch.int64, device=dev)
     v[:n] = torch.where(nd < 0, 0xFFFF, nd.long()) | (torch.where(ob < 0, 0xFFFF, ob.long()) << 16)
     assert torch.equal(got[11], torch.where(v >= 2 ** 31, v - 2 ** 32, v).to(torch.int32))
+
+
+def test_warm_up_is_idempotent_and_leaves_nothing_behind():
+    """`pisa_amd.warm_up()` (round 6): one small engine + one evaluation + one large pageable upload, synchronously or on a
+    background thread; a second call does nothing; the memory it used is back with the allocator; an engine made
+    afterwards gives the bits it gives without it."""
+    import pisa_amd
+    from pisa_amd import synthetic
+
+    pisa_amd.warm_up(background=True)
+    ms = pisa_amd.warm_up_wait()
+    assert ms is not None and ms > 0
+    pisa_amd.warm_up()                         # idempotent
+    assert pisa_amd.warm_up_wait() == ms
+    torch.cuda.synchronize()
+    wl = synthetic.Workload(n_events=24000, grid=(24, 16), out_binning="dragon", seed=11)
+    st = synthetic.DeviceState(wl)
+    st.make_pseudo_data(wl.osc_params(), seed=1)
+    assert np.isfinite(st.eval_host(wl.osc_params(theta23_deg=45.0), "llh"))
