@@ -339,6 +339,10 @@ kde_whiten_key_kernel(const double *__restrict__ x, int64_t n, KdeGeom g, int ti
     idx[i] = (uint32_t)i;
 }
 
+#ifdef PISA_DEV_PROBES
+__global__ void kde_noop_kernel(const double *p) { (void)p; }
+#endif
+
 // sorted copies: ys[d][k] = y[d][perm[k]], ws[k] = w[perm[k]] * scale
 template <int D>
 __global__ void __launch_bounds__(256)
@@ -2440,6 +2444,12 @@ PISA_API int pisa_hip_kde_create(int32_t dim, const double *d_x, const double *d
     static const int pack_ok = PISA_DEV_INT("KDE_SORT_PACK", 1);
     const int pack = (pack_ok && bits < 32 && n <= ((int64_t)1 << (32 - bits))) ? (int)(32 - bits) : 0;
     KDE_D(kde_whiten_flat_kernel, dim3(nb), dim3(256), 0, s, d_x, d_w, n, g, rec, flat_a, idx_a, pack);
+#ifdef PISA_DEV_PROBES
+    {   // development (EXPERIMENTS R6-7): N empty launches per estimator -- is the evaluation bound by the number of runtime calls?
+        static const int extra = PISA_DEV_INT("KDE_EXTRA_LAUNCHES", 0);
+        for (int e = 0; e < extra; e++) hipLaunchKernelGGL(kde_noop_kernel, dim3(1), dim3(64), 0, s, k->scalars);
+    }
+#endif
     size_t tb = temp_bytes;
     {
         static const int twice = PISA_DEV_INT("KDE_TWICE", 0);   // development: marginal cost of a phase = wall time with it run twice
