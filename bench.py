@@ -1433,7 +1433,10 @@ def main(argv=None, hooks=None):
         pisa_amd.warm_up(background=True)
     wl = synthetic.Workload(n_events=int(args.events), grid=(n_e, n_cz), out_binning=args.binning, seed=0)
     if cuda and not args.no_warm_up:
-        warm_ms = pisa_amd.warm_up_wait()
+        try:
+            warm_ms = pisa_amd.warm_up_wait()
+        except Exception as exc:     # the warm-up is a convenience: whatever stopped it stops the real set-up below, with its own message
+            print("bench.py: pisa_amd.warm_up() failed (%s: %s)" % (type(exc).__name__, exc), file=sys.stderr)
     t_setup0 = time.perf_counter()
     st = make_state(wl, rank=rank, world_size=world, indexed=not args.coordinate_form,
                     sort_events=order, compact=compact, index16=index16, **({"time_setup": True} if cuda else {}))
