@@ -187,6 +187,9 @@ def compact_line(out, detail_path=None):
         "fit_c4_evals_per_s": leg("fit_c4", "stencil_in_one_sweep", "evals_per_s"),
         "fit_c4_same_history": leg("fit_c4", "same_history"),
         "update_flux_ms": leg("update_flux", "ms_per_step"),
+        # informational: the same evaluations with the events outside the output binning (which deposit nothing) not resident
+        "unbinned_dropped_evals_per_s": (out.get("unbinned_events_dropped") or {}).get("evals_per_s"),
+        "unbinned_dropped_events_resident": (out.get("unbinned_events_dropped") or {}).get("events_resident"),
         "c4_llh_gate": None if not out.get("c4_llh_gate") else {k: out["c4_llh_gate"].get(k) for k in
                                                                  ("points", "pure_1e-10_met", "all_met", "max_fp64_rel_diff",
                                                                   "max_maps_rel_diff_extended", "max_device_over_eps_rms")},
