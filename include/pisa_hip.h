@@ -275,6 +275,25 @@ int pisa_hip_hist_workgroups(const int64_t *h_n_events, int32_t n_containers, in
 int64_t pisa_hip_deposit_block_order_workspace(int64_t n);
 int pisa_hip_deposit_block_order(const int32_t *d_node, const int32_t *d_bin, int64_t n, int64_t n_nodes,
                                  int64_t *d_perm, void *d_work, int64_t work_bytes, void *stream);
+/* The resident order for a binning BEYOND the LDS accumulators (pisa_hip_hist_window_bins(n_bins) = W > 0): partition p holds
+ * the events that deposit into bins [p W, (p + 1) W) -- sorted by node, whole 4 096-event windows of a partition of >= 8 192
+ * events in the bank order --, topped up with idle events to whole blocks of 256 and interleaved with further idle blocks
+ * (pisa_hip_container::d_part_start is the table the fused kernel then walks).  Two calls around the caller's block accounting:
+ *   _sort      one key per event, one stable radix sort; h_counts[0 .. n_part) = depositing events of every partition,
+ *              h_counts[n_part] = idle events (HOST, out; the call synchronises `stream`);
+ *   _assemble  h_n_dep = those counts, h_dep_blocks[p] = ceil(h_n_dep[p] / 256), h_idle_blocks[p] = idle blocks partition p
+ *              is interleaved with (depositing block q of its nb goes to block floor(q (nb + nf) / nb) of the partition):
+ *              d_perm DEVICE int64[n], out, position i of the resident order holds input event d_perm[i]; whatever idle
+ *              events the blocks do not use follow the last partition.  Synchronises `stream`.
+ * Both take the SAME d_work (DEVICE, pisa_hip_partition_order_workspace(n) bytes: the sorted sequence lives in it between the
+ * calls).  n_part <= 255, (n_part + 1) (n_nodes + 1) < 2^32.  No counterpart in the reference (its events stay in file
+ * order): the sums are exact, so the order is this build's to choose. */
+int64_t pisa_hip_partition_order_workspace(int64_t n);
+int pisa_hip_partition_order_sort(const int32_t *d_node, const int32_t *d_bin, int64_t n, int64_t n_nodes, int32_t width,
+                                  int32_t n_part, int64_t *h_counts, void *d_work, int64_t work_bytes, void *stream);
+int pisa_hip_partition_order_assemble(const int32_t *d_bin, int64_t n, int32_t n_part, const int64_t *h_n_dep,
+                                      const int64_t *h_dep_blocks, const int64_t *h_idle_blocks, int64_t *d_perm,
+                                      void *d_work, int64_t work_bytes, void *stream);
 /* The resident copies of one container's event columns in the order `d_perm` (the permutation above), in ONE launch: the
  * permuted columns themselves and the interleaved / folded forms the fused kernel reads -- what pisa_amd/engine.py built
  * with ~25 tensor operations per container (6 ms of a 24 ms set-up at 1e7 events, bound by their dispatch on the host).

@@ -280,6 +280,11 @@ _SIGS = {
     "pisa_hip_hist_workgroups": (C.c_int, [C.POINTER(C.c_int64), C.c_int32, C.POINTER(C.c_int32)]),
     "pisa_hip_deposit_block_order_workspace": (C.c_int64, [C.c_int64]),
     "pisa_hip_deposit_block_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "pisa_hip_partition_order_workspace": (C.c_int64, [C.c_int64]),
+    "pisa_hip_partition_order_sort": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                                C.POINTER(C.c_int64), C.c_void_p, C.c_int64, C.c_void_p]),
+    "pisa_hip_partition_order_assemble": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                                    C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "pisa_hip_pack_resident_columns": (C.c_int, [C.POINTER(PackSet), C.c_void_p]),
     "pisa_hip_weight_chain_multi": (C.c_int, [C.POINTER(ChainSet), C.c_int32, C.c_void_p]),
     "pisa_hip_evaluator_create": (C.c_int, [C.POINTER(EvaluatorDesc), C.POINTER(C.c_void_p)]),

@@ -151,33 +151,13 @@ def _aligned_partition_blocks(dep_blocks, total_blocks, n_wg):
     return sizes
 
 
-def window_partition_order(obin, node, n_bins, width, block=256, n_wg=None):
-    """Resident order of the 16-bit index form for a binning beyond the LDS accumulators (`width` =
-    `pisa_hip_hist_window_bins`): the events are cut into partitions, partition p holding every event that
-    deposits into bins [p width, (p+1) width) -- sorted by calc-grid node and in the LDS-bank-aware order, as for
-    small binnings -- topped up with events that deposit nothing to a whole number of `block`-event blocks
-    (what one wavefront takes per sweep) and interleaved with further idle blocks so that every stretch of the
-    resident order carries the same share of depositing events.  The fused kernel then works a chunk through
-    partition by partition with its LDS window on that partition's bins (pisa_hip_container::d_part_start).
-    Returns (permutation, part_start in blocks [n_part + 1]), or None when the container has too few idle
-    events to top the partitions up (the caller keeps the general order)."""
-    n = int(obin.numel())
-    dev = obin.device
-    n_part = max(1, -(-int(n_bins) // int(width)))
-    dep = (obin >= 0) & (node >= 0)
-    idle = torch.nonzero(~dep).reshape(-1)
-    idle = idle[torch.argsort(node[idle], stable=True)]
-    part_of = torch.where(dep, obin.long() // int(width), torch.full_like(obin, -1, dtype=torch.int64))
-    deps = []
-    for p in range(n_part):
-        ip = torch.nonzero(part_of == p).reshape(-1)
-        ip = ip[torch.argsort(node[ip], stable=True)]
-        if ip.numel() >= 8192:
-            ip = ip[lds_bank_order(obin[ip], window=4096, banks=32, per=4)]
-        deps.append(ip)
-    n_dep = [int(d.numel()) for d in deps]
+def _partition_accounting(n, n_dep, n_idle, block, n_wg):
+    """the host side of the partitioned order: from the number of depositing events of every partition and of idle events,
+    (top, dep_blocks, share) -- idle events that complete a partition's last depositing block, its depositing blocks, the
+    idle blocks it is interleaved with -- or None when the container has too few idle events to top the partitions up"""
+    n_part = len(n_dep)
     top = [(-k) % block for k in n_dep]                      # idle events that complete the last depositing block
-    spare = int(idle.numel()) - sum(top)
+    spare = int(n_idle) - sum(top)
     n_blocks = n // block                                    # (the tail beyond whole blocks stays idle, see below)
     if spare < 0 or n_blocks == 0:
         return None
@@ -202,6 +182,39 @@ def window_partition_order(obin, node, n_bins, width, block=256, n_wg=None):
         rem = idle_blocks - sum(share)
         for p in sorted(range(n_part), key=lambda p: -(idle_blocks * dep_blocks[p] % tot))[:rem]:
             share[p] += 1
+    return top, dep_blocks, share
+
+
+def window_partition_order(obin, node, n_bins, width, block=256, n_wg=None):
+    """Resident order of the 16-bit index form for a binning beyond the LDS accumulators (`width` =
+    `pisa_hip_hist_window_bins`): the events are cut into partitions, partition p holding every event that
+    deposits into bins [p width, (p+1) width) -- sorted by calc-grid node and in the LDS-bank-aware order, as for
+    small binnings -- topped up with events that deposit nothing to a whole number of `block`-event blocks
+    (what one wavefront takes per sweep) and interleaved with further idle blocks so that every stretch of the
+    resident order carries the same share of depositing events.  The fused kernel then works a chunk through
+    partition by partition with its LDS window on that partition's bins (pisa_hip_container::d_part_start).
+    Returns (permutation, part_start in blocks [n_part + 1]), or None when the container has too few idle
+    events to top the partitions up (the caller keeps the general order).  This torch formulation (~25 launches
+    per container) is the specification; the engine calls `window_partition_order_native`."""
+    n = int(obin.numel())
+    dev = obin.device
+    n_part = max(1, -(-int(n_bins) // int(width)))
+    dep = (obin >= 0) & (node >= 0)
+    idle = torch.nonzero(~dep).reshape(-1)
+    idle = idle[torch.argsort(node[idle], stable=True)]
+    part_of = torch.where(dep, obin.long() // int(width), torch.full_like(obin, -1, dtype=torch.int64))
+    deps = []
+    for p in range(n_part):
+        ip = torch.nonzero(part_of == p).reshape(-1)
+        ip = ip[torch.argsort(node[ip], stable=True)]
+        if ip.numel() >= 8192:
+            ip = ip[lds_bank_order(obin[ip], window=4096, banks=32, per=4)]
+        deps.append(ip)
+    n_dep = [int(d.numel()) for d in deps]
+    acc = _partition_accounting(n, n_dep, int(idle.numel()), block, n_wg)
+    if acc is None:
+        return None
+    top, dep_blocks, share = acc
     pieces, starts, at = [], [0], 0
     for p in range(n_part):
         body = torch.cat((deps[p], idle[at:at + top[p]]))
@@ -227,6 +240,45 @@ def window_partition_order(obin, node, n_bins, width, block=256, n_wg=None):
     perm = torch.cat(pieces)
     assert perm.numel() == n
     starts[-1] = -(-n // block)         # the last partition takes the (idle) tail and its padding
+    return perm, starts
+
+
+def window_partition_order_native(obin, node, n_bins, width, n_nodes, n_wg=None):
+    """`window_partition_order` through `pisa_hip_partition_order_sort` / `_assemble` (csrc/order.hip, round 6): one key per
+    event and ONE stable radix sort instead of a nonzero + argsort per partition, the bank order of the large partitions by
+    the window kernel, every output position's source in closed form; the block accounting in between is
+    `_partition_accounting`, on the host, as in the torch formulation.  The SAME (permutation, part_start)
+    (tests/test_gpu_engine.py compares them element by element), or None under the same condition."""
+    import ctypes as C
+
+    lib = _lib.lib()
+    n = int(obin.numel())
+    n_part = max(1, -(-int(n_bins) // int(width)))
+    if n == 0 or n_part > 255 or (n_part + 1) * (int(n_nodes) + 1) > 0xFFFFFFFF:
+        return window_partition_order(obin, node, n_bins, width, n_wg=n_wg)
+    need = int(lib.pisa_hip_partition_order_workspace(n))
+    if need < 0:
+        raise ValueError("too many events for one container's order: %d" % n)
+    work = torch.empty(need, dtype=torch.uint8, device=obin.device)
+    node32 = (node if node.dtype == torch.int32 else node.to(torch.int32)).contiguous()
+    obin32 = (obin if obin.dtype == torch.int32 else obin.to(torch.int32)).contiguous()
+    counts = (C.c_int64 * (n_part + 1))()
+    _lib.check(lib.pisa_hip_partition_order_sort(C.c_void_p(node32.data_ptr()), C.c_void_p(obin32.data_ptr()), n, int(n_nodes),
+                                                 int(width), n_part, counts, C.c_void_p(work.data_ptr()), need, K._stream()))
+    n_dep = [int(counts[p]) for p in range(n_part)]
+    acc = _partition_accounting(n, n_dep, int(counts[n_part]), 256, n_wg)
+    if acc is None:
+        return None
+    _, dep_blocks, share = acc
+    perm = torch.empty(n, dtype=torch.int64, device=obin.device)
+    arr = C.c_int64 * n_part
+    _lib.check(lib.pisa_hip_partition_order_assemble(C.c_void_p(obin32.data_ptr()), n, n_part, arr(*n_dep), arr(*dep_blocks),
+                                                     arr(*share), C.c_void_p(perm.data_ptr()), C.c_void_p(work.data_ptr()), need,
+                                                     K._stream()))
+    starts = [0]
+    for nb, nf in zip(dep_blocks, share):
+        starts.append(starts[-1] + nb + nf)
+    starts[-1] = -(-n // 256)           # the last partition takes the (idle) tail and its padding
     return perm, starts
 
 
@@ -690,7 +742,8 @@ class HotPathEngine:
                             width = _lib.lib().pisa_hip_hist_window_bins(self.n_bins) if index16 else 0
                             res = None
                             if width > 0 and lds_order and block_order and not drop_unbinned:
-                                res = window_partition_order(obin, node, self.n_bins, width, n_wg=hist_wgs[len(self.cont)])
+                                res = window_partition_order_native(obin, node, self.n_bins, width, grid.size,
+                                                                    n_wg=hist_wgs[len(self.cont)])
                             if res is not None:
                                 perm, part_starts = res
                                 part_width = width

@@ -864,3 +864,39 @@ def test_warm_up_is_idempotent_and_leaves_nothing_behind():
     st = synthetic.DeviceState(wl)
     st.make_pseudo_data(wl.osc_params(), seed=1)
     assert np.isfinite(st.eval_host(wl.osc_params(theta23_deg=45.0), "llh"))
+
+
+@pytest.mark.parametrize("n,n_nodes,n_bins,width,frac_out,n_wg", [
+    (100003, 20000, 4800, 672, 0.6, 21), (100003, 20000, 4800, 672, 0.6, None), (833333, 20000, 4800, 672, 0.68, 21),
+    (40000, 300, 1500, 672, 0.5, 5), (9000, 50, 700, 672, 0.3, 3), (300, 10, 1400, 672, 0.5, 2), (255, 10, 1400, 672, 0.5, None),
+    (50000, 1000, 4800, 672, 0.02, 8), (50000, 1000, 4800, 672, 1.0, 8), (70001, 65000, 6000, 672, 0.5, 16)])
+def test_native_partitioned_order_is_the_torch_formulation(n, n_nodes, n_bins, width, frac_out, n_wg):
+    """`pisa_hip_partition_order_sort` / `_assemble` (csrc/order.hip, round 6) against `engine.window_partition_order`, the
+    torch formulation (a nonzero + stable argsort per partition, the bank order, concatenations, an index shuffle): the same
+    permutation element by element and the same partition table -- partitions above and below the 8 192 events from which
+    the bank order applies, empty partitions, sizes around the 256-event block, events outside the grid, aligned and
+    proportional sharing of the idle blocks, too few idle events (None from both), no depositing event at all."""
+    from pisa_amd import engine
+    from pisa_amd import kernels as K
+
+    rs = np.random.RandomState(n % 9973 + n_bins)
+    node = rs.randint(0, n_nodes, size=n).astype(np.int32)
+    # (bins crowd into the lower partitions: sizes differ, the upper ones may stay empty)
+    obin = np.minimum((rs.rand(n) ** 2 * n_bins).astype(np.int32), n_bins - 1)
+    out = rs.rand(n) < frac_out
+    obin[out & (rs.rand(n) < 0.7)] = -1
+    node[out & (rs.rand(n) < 0.4)] = -1
+    if frac_out == 1.0:
+        obin[:] = -1
+    d_node, d_bin = torch.from_numpy(node).to(K.device()), torch.from_numpy(obin).to(K.device())
+    want = engine.window_partition_order(d_bin, d_node, n_bins, width, n_wg=n_wg)
+    got = engine.window_partition_order_native(d_bin, d_node, n_bins, width, n_nodes, n_wg=n_wg)
+    if want is None:
+        assert got is None
+        return
+    assert got is not None and got[1] == want[1]
+    g, w_ = got[0].cpu().numpy(), want[0].cpu().numpy()
+    assert np.array_equal(np.sort(g), np.arange(n))
+    assert np.array_equal(g, w_)
+    again = engine.window_partition_order_native(d_bin, d_node, n_bins, width, n_nodes, n_wg=n_wg)
+    assert np.array_equal(again[0].cpu().numpy(), g)
