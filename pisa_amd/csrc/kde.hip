@@ -633,11 +633,15 @@ __device__ inline void exp_pair(double t, double h, double &up, double &dn) {
     dn = __builtin_ldexp(ce - so, -ki) * h;
 }
 
-// Source record (192 B, read with scalar loads): [0] y_a  [1] y_b  [2] coef  [3] -s2 / 2  [4] -s2 da
-// [5] h = exp(-s2 da^2 / 2)  [8 + k - 2] Q_k = exp(-s2 da^2 k (k - 1) / 2), k = 2 .. 16.
+// Source record as the lattice kernel uses it in LDS (192 B): [0] y_a  [1] y_b  [2] coef  [3] -s2 / 2  [4] -s2 da
+// [5] h = exp(-s2 da^2 / 2)  [8 + k - 2] Q_k = exp(-s2 da^2 k (k - 1) / 2) = h^(k (k - 1)), k = 2 .. 16.
 // With the strip's middle value g_c and the ratios r_up = g_{c+1} / g_c, r_dn = g_{c-1} / g_c the
 // values along the line are  g_{c +- k} = g_c r^k Q_k : one multiplication (p <- p r) and one
 // multiply-add (acc += p Q_k, Q_k a scalar operand) per point.
+// In GLOBAL memory a record is its first eight numbers only (LAT_GREC, 64 B; round 6): the Q table is rebuilt in LDS when a
+// piece is staged, Q_k = Q_{k-1} h^(2 (k - 1)) -- two multiplications per entry by one lane per record.  A record is fetched
+// ~11 times per launch (once per sub-patch and lane group within its reach): 0.9 GB per estimator at 192 B, a quarter of it now.
+constexpr int LAT_GREC = 8;
 constexpr int LAT_REC = 24;
 constexpr int LAT_Q0 = 8;
 constexpr int LAT_QMAX = 16;
@@ -647,14 +651,14 @@ kde_lattice_prep_kernel(const double *__restrict__ ys, const double *__restrict_
                         const double *__restrict__ s2, int64_t n, double da, double rcut2, double *__restrict__ rec,
                         double *__restrict__ box) {
     // one source per thread; the 64 records of a wavefront go through LDS so that they leave as 16-byte
-    // stores of consecutive lanes (12 KB contiguous per wavefront)
+    // stores of consecutive lanes (4 KB contiguous per wavefront)
     typedef double __attribute__((ext_vector_type(2))) d2;
-    __shared__ __attribute__((aligned(16))) double stage[64 * LAT_REC];
+    __shared__ __attribute__((aligned(16))) double stage[64 * LAT_GREC];
     const int lane = threadIdx.x;
     const int64_t k0 = (int64_t)blockIdx.x * 64, k = k0 + lane;
     if (k < n) {
         const double v = s2[k];
-        double *r = stage + lane * LAT_REC;
+        double *r = stage + lane * LAT_GREC;
         r[0] = ys[k];
         r[1] = ys[n + k];
         r[2] = coef[k];
@@ -663,9 +667,6 @@ kde_lattice_prep_kernel(const double *__restrict__ ys, const double *__restrict_
         r[5] = exp_nonpos(-0.5 * v * da * da);
         r[6] = 0.0;
         r[7] = 0.0;
-#pragma unroll
-        for (int kk = 2; kk <= LAT_QMAX; kk++) r[LAT_Q0 + kk - 2] = exp_nonpos(-v * da * da * (double)(kk * (kk - 1) / 2));
-        r[LAT_Q0 + LAT_QMAX - 1] = 0.0;
     }
     // the share's (y_a, y_b) box: outside it no lattice point is within the cut-off of any of the 64 sources
     // (sources are sorted by cell row, then cell column: a share is compact)
@@ -692,9 +693,9 @@ kde_lattice_prep_kernel(const double *__restrict__ ys, const double *__restrict_
     }
     __syncthreads();
     const int64_t n_here = n - k0 < 64 ? n - k0 : 64;
-    const int n_d2 = (int)n_here * (LAT_REC / 2);
+    const int n_d2 = (int)n_here * (LAT_GREC / 2);
     const d2 *src = reinterpret_cast<const d2 *>(stage);
-    d2 *dst = reinterpret_cast<d2 *>(rec + k0 * LAT_REC);
+    d2 *dst = reinterpret_cast<d2 *>(rec + k0 * LAT_GREC);
     for (int i = lane; i < n_d2; i += 64) dst[i] = src[i];
 }
 
@@ -862,11 +863,11 @@ kde_lattice_kernel(const KdeLattice L, double rcut2, const double *__restrict__ 
     constexpr int G = 64 / LG;                  // lane groups = shares side by side
     constexpr int HP = LAT_PIECE / G;           // records of one group per piece
     constexpr int GS = HP * LAT_REC + 2;        // doubles of one group in a ring slot (+ 2: the groups on different banks)
-    constexpr int GD2 = HP * LAT_REC / 2;       // 16-byte units of one group per piece
-    constexpr int UNITS = GD2 / LG;             // ... per lane
+    constexpr int GD2 = HP * LAT_GREC / 2;      // 16-byte units of one group per piece in global memory (eight numbers per record)
+    constexpr int UNITS = GD2 / LG;             // ... per lane (two, whatever LG)
     constexpr int N_PIECE = LAT_SHARE / HP;     // pieces per share
     static_assert(C <= LAT_QMAX, "Q table");
-    static_assert(G * LG == 64 && HP * G == LAT_PIECE && UNITS * LG == GD2 && N_PIECE * HP == LAT_SHARE, "piece layout");
+    static_assert(G * LG == 64 && HP * G == LAT_PIECE && UNITS * LG == GD2 && N_PIECE * HP == LAT_SHARE && HP <= LG, "piece layout");
     __shared__ __attribute__((aligned(16))) double ring[2][G * GS];
     __shared__ int32_t lst[64];
     const int w = (int)blockIdx.x;
@@ -942,7 +943,7 @@ kde_lattice_kernel(const KdeLattice L, double rcut2, const double *__restrict__ 
             const int pos0 = grp * nl * LG;
             auto piece_src = [&](int c) -> const d2 * {
                 const int pos = pos0 + c * HP;
-                return reinterpret_cast<const d2 *>(rec + ((int64_t)lst[pos >> 6] * LAT_SHARE + (pos & 63)) * LAT_REC) + sl;
+                return reinterpret_cast<const d2 *>(rec + ((int64_t)lst[pos >> 6] * LAT_SHARE + (pos & 63)) * LAT_GREC) + sl;
             };
             // (the record array is padded by a whole share: the loads of a last, partial share stay inside it)
             d2 a[UNITS], b[UNITS];
@@ -959,11 +960,29 @@ kde_lattice_kernel(const KdeLattice L, double rcut2, const double *__restrict__ 
                 }
                 double *slot = ring[c & 1] + grp * GS;   // this group's part of the slot
                 {
-                    d2 *dst = reinterpret_cast<d2 *>(slot) + sl;
+                    // unit uid of the piece = numbers 2 (uid % 4), 2 (uid % 4) + 1 of its record uid / 4, at the record's place in LDS
+                    d2 *dst = reinterpret_cast<d2 *>(slot);
 #pragma unroll
-                    for (int u = 0; u < UNITS; u++) dst[u * LG] = a[u];
+                    for (int u = 0; u < UNITS; u++) {
+                        const int uid = sl + u * LG;
+                        dst[(uid >> 2) * (LAT_REC / 2) + (uid & 3)] = a[u];
+                    }
                 }
                 __syncthreads();   // one wavefront: orders the stores above against the reads below
+                if (sl < HP) {
+                    // the record's Q table, rebuilt here from h: Q_2 = h^2, Q_k = Q_{k-1} h^(2 (k - 1)) (lane sl of the group: record sl)
+                    double *q = slot + sl * LAT_REC;
+                    const double hh = q[5] * q[5];
+                    double t = hh, qk = hh;
+                    q[LAT_Q0] = qk;
+#pragma unroll
+                    for (int kk = 3; kk <= C; kk++) {
+                        t *= hh;
+                        qk *= t;
+                        q[LAT_Q0 + kk - 2] = qk;
+                    }
+                }
+                __syncthreads();
                 const int nr = (int)(n_src - k0 < HP ? n_src - k0 : HP);   // records of this piece that exist
                 // (y_a, y_b, -s2 / 2) of the record, read one iteration ahead
                 double ay = slot[0], by = slot[1], shh = slot[3];
@@ -2884,7 +2903,7 @@ PISA_API int64_t pisa_hip_kde_lattice_workspace_bytes(const pisa_hip_kde *k, con
         lattice_shape(k, R, h_step, h_count, sw, lg);
         const size_t waves = (size_t)lattice_waves(R, sw, lg / sw, h_count, k->n);
         const size_t patches = (size_t)lattice_patches(R, sw, lg / sw, h_count);
-        return (int64_t)(((size_t)k->n + LAT_SHARE) * LAT_REC * 8 + waves * R * lg * 8 + ((size_t)k->n / LAT_SHARE + 1) * 32 +
+        return (int64_t)(((size_t)k->n + LAT_SHARE) * LAT_GREC * 8 + waves * R * lg * 8 + ((size_t)k->n / LAT_SHARE + 1) * 32 +
                          patches * ((size_t)k->n / LAT_SHARE + 1) * 4 +   /* lists of the shares within reach of each sub-patch */
                          (patches + 1) * 8 + 4096);
     }
@@ -2937,7 +2956,7 @@ PISA_API int pisa_hip_kde_evaluate_lattice(pisa_hip_kde *k, const double *h_orig
     const int n_patches = (int)lattice_patches(R, L.sw, L.lpw, h_count);
     const int n_waves = (int)lattice_waves(R, L.sw, L.lpw, h_count, k->n);
     const int64_t n_shares = (k->n + LAT_SHARE - 1) / LAT_SHARE;
-    double *rec = ar.take<double>(((size_t)k->n + LAT_SHARE) * LAT_REC);   // padded by a whole share of records
+    double *rec = ar.take<double>(((size_t)k->n + LAT_SHARE) * LAT_GREC);   // padded by a whole share of records
     double *part = ar.take<double>((size_t)n_waves * R * lg);
     double *box = ar.take<double>((size_t)n_shares * 4);
     unsigned int *load = ar.take<unsigned int>((size_t)n_patches);
