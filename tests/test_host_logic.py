@@ -835,3 +835,36 @@ def test_sqlite_loader_reads_the_reference_test_database(tmp_path):
     assert np.array_equal(c["reco_energy"], r[:, 0]) and np.array_equal(c["reco_coszen"], np.cos(r[:, 1]))
     assert np.array_equal(c["pid"], r[:, 2]) and np.array_equal(c["weights"], np.ones(10))
     assert np.array_equal(c["weighted_aeff"], 1e-4 * t[:, 2] / 1 / t[:, 3] / 10)
+
+
+def test_partition_accounting_adds_up():
+    """`engine._partition_accounting` (round 6: the host side shared by the torch and the native form of the partitioned
+    resident order): for random partition populations the depositing blocks are the events topped up to whole blocks of 256,
+    the idle blocks dealt to the partitions add up to what the container has, nothing is used twice, and a container
+    without enough idle events to top its partitions up is refused (None)."""
+    from pisa_amd.engine import _partition_accounting
+
+    rs = np.random.RandomState(6)
+    seen_none = seen_aligned = 0
+    for _ in range(300):
+        n_part = int(rs.randint(2, 9))
+        n_dep = [int(v) for v in rs.randint(0, 40000, size=n_part) * (rs.rand(n_part) < 0.8)]
+        n_idle = int(rs.randint(0, 90000))
+        n = sum(n_dep) + n_idle
+        n_wg = int(rs.randint(1, 40)) if rs.rand() < 0.7 else None
+        acc = _partition_accounting(n, n_dep, n_idle, 256, n_wg)
+        top_need = sum((-k) % 256 for k in n_dep)
+        if n_idle < top_need or n // 256 == 0:
+            assert acc is None
+            seen_none += 1
+            continue
+        top, dep_blocks, share = acc
+        assert all(0 <= t < 256 and (k + t) % 256 == 0 and b == (k + t) // 256 for k, t, b in zip(n_dep, top, dep_blocks))
+        assert all(s >= 0 for s in share)
+        used_idle = sum(top) + 256 * sum(share)
+        assert used_idle <= n_idle
+        if sum(n_dep) > 0:      # (a container in which nothing deposits keeps its idle events in the tail: any order serves)
+            assert n_idle - used_idle < 512                # what is left is the tail behind the last partition
+            assert sum(dep_blocks) + sum(share) in (n // 256, n // 256 - 1)
+        seen_aligned += n_wg is not None
+    assert seen_none > 0 and seen_aligned > 50
